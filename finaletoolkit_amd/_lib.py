@@ -1,0 +1,176 @@
+"""
+ctypes binding of ``libftk_hip.so`` (C ABI: ``include/ftk.h``).
+
+The shared object is built in-tree by ``finaletoolkit_amd/csrc/Makefile``
+(``__graft_entry__.build()`` drives it).  There is no fallback: if the library
+is missing, or no MI355X is usable, the callers raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libftk_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+FTK_OK = 0
+FTK_ERR_INVALID = -1
+FTK_ERR_NO_DEVICE = -2
+FTK_ERR_HIP = -3
+FTK_ERR_OOM = -4
+FTK_ERR_IO = -5
+FTK_ERR_FORMAT = -6
+FTK_ERR_NO_CONTIG = -7
+FTK_ERR_UNSORTED = -8
+
+OPEN_LO = -(2 ** 31)
+OPEN_HI = 2 ** 31 - 1
+LEN_OPEN = -1
+POLICY = {"midpoint": 0, "any": 1}
+FETCH_TABIX = 0
+FETCH_BAM_READ1 = 1
+MAX_TELOMERES = 8
+
+# every symbol include/ftk.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "ftk_version", "ftk_device_count", "ftk_ctx_create", "ftk_ctx_destroy", "ftk_last_error",
+    "ftk_ctx_set_stream", "ftk_ctx_sync", "ftk_timer_start", "ftk_timer_stop",
+    "ftk_frags_from_host", "ftk_frags_from_device", "ftk_frags_set_read1", "ftk_frags_info", "ftk_frags_release",
+    "ftk_fragfile_decode", "ftk_bam_decode", "ftk_fragtable_error", "ftk_fragtable_is_bed6",
+    "ftk_fragtable_n_contigs", "ftk_fragtable_contig_name", "ftk_fragtable_contig_length",
+    "ftk_fragtable_contig_rows", "ftk_fragtable_columns", "ftk_fragtable_free",
+    "ftk_window_counts", "ftk_delfi_counts", "ftk_fraglen_hist", "ftk_frag_lengths", "ftk_frag_select",
+    "ftk_wps", "ftk_wps_intervals",
+]
+
+
+class FtkError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"ftk error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class Filter(C.Structure):
+    _fields_ = [("mapq_min", C.c_int32), ("min_len", C.c_int32), ("max_len", C.c_int32),
+                ("policy", C.c_int32), ("fetch_mode", C.c_int32)]
+
+
+class Gaps(C.Structure):
+    _fields_ = [("has_gaps", C.c_int32), ("cen_start", C.c_int32), ("cen_stop", C.c_int32),
+                ("n_telo", C.c_int32), ("telo_start", C.c_int32 * MAX_TELOMERES),
+                ("telo_stop", C.c_int32 * MAX_TELOMERES)]
+
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile libftk_hip.so for gfx950 with hipcc (in-tree)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "ftk.h")]
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.exists(s))
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
+            "finaletoolkit_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.ftk_version.restype = C.c_char_p
+    lib.ftk_last_error.restype = C.c_char_p
+    lib.ftk_last_error.argtypes = [vp]
+    lib.ftk_fragtable_error.restype = C.c_char_p
+    lib.ftk_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.ftk_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.ftk_ctx_destroy.argtypes = [vp]
+    lib.ftk_ctx_destroy.restype = None
+    lib.ftk_ctx_set_stream.argtypes = [vp, vp]
+    lib.ftk_ctx_sync.argtypes = [vp]
+    lib.ftk_timer_start.argtypes = [vp]
+    lib.ftk_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.ftk_frags_from_host.argtypes = [vp, C.c_int, vp, vp, vp, vp, i64]
+    lib.ftk_frags_from_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, i64]
+    lib.ftk_frags_set_read1.argtypes = [vp, C.c_int, vp, vp, i64]
+    lib.ftk_frags_info.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]
+    lib.ftk_frags_release.argtypes = [vp, C.c_int]
+    lib.ftk_fragfile_decode.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.ftk_bam_decode.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.ftk_fragtable_is_bed6.argtypes = [vp]
+    lib.ftk_fragtable_n_contigs.argtypes = [vp]
+    lib.ftk_fragtable_contig_name.argtypes = [vp, C.c_int]
+    lib.ftk_fragtable_contig_name.restype = C.c_char_p
+    lib.ftk_fragtable_contig_length.argtypes = [vp, C.c_int]
+    lib.ftk_fragtable_contig_length.restype = i64
+    lib.ftk_fragtable_contig_rows.argtypes = [vp, C.c_int]
+    lib.ftk_fragtable_contig_rows.restype = i64
+    lib.ftk_fragtable_columns.argtypes = [vp, C.c_int] + [C.POINTER(vp)] * 6
+    lib.ftk_fragtable_free.argtypes = [vp]
+    lib.ftk_fragtable_free.restype = None
+    lib.ftk_window_counts.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), vp]
+    lib.ftk_delfi_counts.argtypes = [vp, C.c_int, vp, vp, i64, i32, vp, vp, i64, C.POINTER(Gaps), vp, vp, vp]
+    lib.ftk_fraglen_hist.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), i32, i32, vp, vp]
+    lib.ftk_frag_lengths.argtypes = [vp, C.c_int, i32, i32, C.POINTER(Filter), vp, i64, C.POINTER(i64)]
+    lib.ftk_frag_select.argtypes = [vp, C.c_int, i32, i32, C.POINTER(Filter), vp, vp, vp, vp, i64, C.POINTER(i64)]
+    lib.ftk_wps.argtypes = [vp, C.c_int, i64, i64, i64, i32, i32, i32, i32, vp]
+    lib.ftk_wps_intervals.argtypes = [vp, C.c_int, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    """Pointer for a numpy array, an int address (device pointer) or None."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if hasattr(a, "data_ptr"):  # torch tensor (device or host); caller keeps it alive
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(f"cannot pass {type(a)} through the C ABI")
+
+
+def make_filter(quality_threshold=30, min_length=None, max_length=None, intersect_policy="midpoint",
+                fetch_mode=FETCH_TABIX) -> Filter:
+    if intersect_policy not in POLICY:
+        from .exceptions import InvalidInputError
+        raise InvalidInputError(f"{intersect_policy} is not a valid policy")
+    mn = LEN_OPEN if min_length is None else max(int(min_length), 0)
+    if max_length is None:
+        mx = LEN_OPEN
+    elif int(max_length) < 0:  # nothing can pass: an empty length interval
+        mn, mx = 1, 0
+    else:
+        mx = int(max_length)
+    return Filter(int(quality_threshold), mn, mx, POLICY[intersect_policy], fetch_mode)
+
+
+def make_gaps(gaps) -> Gaps:
+    """gaps: None or (cen_start, cen_stop, [(t0, t1), ...])  (genome/gaps.py:202-215)."""
+    g = Gaps()
+    if gaps is None:
+        return g
+    tel = list(gaps[2])
+    if len(tel) > MAX_TELOMERES:
+        raise ValueError(f"at most {MAX_TELOMERES} telomere intervals per contig are supported")
+    g.has_gaps = 1
+    g.cen_start, g.cen_stop = int(gaps[0]), int(gaps[1])
+    g.n_telo = len(tel)
+    for i, (a, b) in enumerate(tel):
+        g.telo_start[i] = int(a)
+        g.telo_stop[i] = int(b)
+    return g

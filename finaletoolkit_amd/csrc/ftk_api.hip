@@ -1,0 +1,716 @@
+// C-ABI implementation (include/ftk.h): contexts, HBM residency of fragments,
+// and the host side of every feature call.  No CPU compute fallback exists.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "ftk_kernels.h"
+
+using namespace ftk;
+
+namespace {
+
+thread_local std::string g_err;  // for ctx-less failures
+
+int fail(ftk_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_err = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (void)hipGetLastError();                                                            \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? FTK_ERR_OOM : FTK_ERR_HIP, "%s: %s",   \
+                        #call, hipGetErrorString(e_));                                          \
+        }                                                                                       \
+    } while (0)
+
+bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// Bump allocator over the ctx scratch; the total is reserved up front so the
+// base never moves within one API call.
+struct Arena {
+    char* base;
+    size_t off = 0, cap;
+    Arena(ftk_ctx* c) : base((char*)c->scratch), cap(c->scratch_bytes) {}
+    template <class T>
+    T* take(size_t n) {
+        size_t bytes = align_up(n * sizeof(T));
+        T* p = reinterpret_cast<T*>(base + off);
+        off += bytes;
+        return p;
+    }
+};
+
+int reserve_scratch(ftk_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->scratch_bytes) return FTK_OK;
+    // earlier work on the stream may still read the old scratch
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) HIPCHK(ctx, hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    size_t want = align_up(bytes + bytes / 4, 1 << 20);
+    HIPCHK(ctx, hipMalloc(&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+    return FTK_OK;
+}
+
+int get_contig(ftk_ctx* ctx, int contig_id, ContigData** out) {
+    auto it = ctx->contigs.find(contig_id);
+    if (it == ctx->contigs.end()) return fail(ctx, FTK_ERR_NO_CONTIG, "contig id %d is not loaded", contig_id);
+    *out = &it->second;
+    return FTK_OK;
+}
+
+void free_contig(ContigData& c) {
+    if (c.base) (void)hipFree(c.base);
+    if (c.r1) (void)hipFree(c.r1);
+    if (c.bin_idx) (void)hipFree(c.bin_idx);
+    c = ContigData{};
+}
+
+int check_filter(ftk_ctx* ctx, const ftk_filter* f, const ContigData& c) {
+    if (!f) return fail(ctx, FTK_ERR_INVALID, "filter is NULL");
+    if (f->policy != FTK_POLICY_MIDPOINT && f->policy != FTK_POLICY_ANY)
+        return fail(ctx, FTK_ERR_INVALID, "unknown intersect policy %d", f->policy);
+    if (f->fetch_mode != FTK_FETCH_TABIX && f->fetch_mode != FTK_FETCH_BAM_READ1)
+        return fail(ctx, FTK_ERR_INVALID, "unknown fetch mode %d", f->fetch_mode);
+    if (f->fetch_mode == FTK_FETCH_BAM_READ1 && !c.v.r1_start)
+        return fail(ctx, FTK_ERR_INVALID, "FTK_FETCH_BAM_READ1 needs ftk_frags_set_read1 first");
+    return FTK_OK;
+}
+
+// longest fragment that can pass the filter
+int eff_lmax(const ftk_filter* f, const ContigData& c) {
+    int l = c.max_len;
+    if (f && f->max_len >= 0) l = std::min(l, f->max_len);
+    return std::max(l, 0);
+}
+
+// Stage an input array on the device if the caller gave a host pointer.
+template <class T>
+int stage_in(ftk_ctx* ctx, const T* src, size_t n, T* dev_buf, const T** out) {
+    if (is_device_ptr(src)) {
+        *out = src;
+        return FTK_OK;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(dev_buf, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    *out = dev_buf;
+    return FTK_OK;
+}
+
+int upload_common(ftk_ctx* ctx, int contig_id, const int32_t* start, const int32_t* end, const uint8_t* mapq,
+                  const uint8_t* strand, int64_t n, hipMemcpyKind kind) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    if (n < 0 || n > (int64_t)INT32_MAX - 1024) return fail(ctx, FTK_ERR_INVALID, "fragment count %lld out of range", (long long)n);
+    if (n > 0 && (!start || !end || !mapq)) return fail(ctx, FTK_ERR_INVALID, "NULL fragment column");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    auto it = ctx->contigs.find(contig_id);
+    if (it != ctx->contigs.end()) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        free_contig(it->second);
+        ctx->contigs.erase(it);
+    }
+    ContigData c;
+    c.n = n;
+    // columns padded to a multiple of 4 fragments (+4) so 16-byte loads never
+    // leave the allocation
+    size_t n_pad = ((size_t)n + 3) / 4 * 4 + 4;
+    size_t b_i32 = align_up(n_pad * 4), b_u8 = align_up(n_pad);
+    size_t total = 2 * b_i32 + 2 * b_u8;
+    HIPCHK(ctx, hipMalloc(&c.base, total));
+    char* base = (char*)c.base;
+    int32_t* d_start = (int32_t*)base;
+    int32_t* d_end = (int32_t*)(base + b_i32);
+    uint8_t* d_mapq = (uint8_t*)(base + 2 * b_i32);
+    uint8_t* d_strand = (uint8_t*)(base + 2 * b_i32 + b_u8);
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMemsetAsync(c.base, 0, total, s);
+    if (e == hipSuccess && n > 0) {
+        e = hipMemcpyAsync(d_start, start, n * 4, kind, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_end, end, n * 4, kind, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_mapq, mapq, n, kind, s);
+        if (e == hipSuccess && strand) e = hipMemcpyAsync(d_strand, strand, n, kind, s);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        free_contig(c);
+        return fail(ctx, FTK_ERR_HIP, "fragment upload failed: %s", hipGetErrorString(e));
+    }
+    // validate + summarise on the device
+    FragStats init{0, INT32_MIN, INT32_MAX, INT32_MIN, INT32_MAX};
+    FragStats* d_st = nullptr;
+    FragStats h_st = init;
+    e = hipMalloc((void**)&d_st, sizeof(FragStats));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_st, &init, sizeof(init), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && n > 0) launch_stats(s, d_start, d_end, (int)n, d_st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_st, d_st, sizeof(h_st), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (d_st) (void)hipFree(d_st);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        free_contig(c);
+        return fail(ctx, FTK_ERR_HIP, "fragment validation failed: %s", hipGetErrorString(e));
+    }
+    if (n > 0) {
+        if (h_st.unsorted) {
+            free_contig(c);
+            return fail(ctx, FTK_ERR_UNSORTED, "fragments of contig %d are not sorted by start", contig_id);
+        }
+        if (h_st.min_len < 0 || h_st.min_start < 0 || h_st.max_end >= (1 << 30)) {
+            free_contig(c);
+            return fail(ctx, FTK_ERR_INVALID,
+                        "contig %d: coordinates must satisfy 0 <= start <= end < 2^30 (min len %d, min start %d, max end %d)",
+                        contig_id, h_st.min_len, h_st.min_start, h_st.max_end);
+        }
+        c.max_len = h_st.max_len;
+        c.max_end = h_st.max_end;
+    }
+    // coarse position index
+    int32_t max_start = 0;
+    if (n > 0) {
+        // sorted: the last start is the largest
+        e = hipMemcpy(&max_start, d_start + (n - 1), 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            free_contig(c);
+            return fail(ctx, FTK_ERR_HIP, "index build failed: %s", hipGetErrorString(e));
+        }
+    }
+    int n_bins = (max_start >> kBinShift) + 1;
+    e = hipMalloc((void**)&c.bin_idx, (size_t)(n_bins + 1) * 4);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        free_contig(c);
+        return fail(ctx, FTK_ERR_OOM, "index allocation failed");
+    }
+    launch_bin_index(s, d_start, (int)n, n_bins, c.bin_idx);
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        free_contig(c);
+        return fail(ctx, FTK_ERR_HIP, "index build failed: %s", hipGetErrorString(e));
+    }
+    c.v.start = d_start;
+    c.v.end = d_end;
+    c.v.mapq = d_mapq;
+    c.v.strand = d_strand;
+    c.v.r1_start = nullptr;
+    c.v.r1_end = nullptr;
+    c.v.bin_idx = c.bin_idx;
+    c.v.n = (int32_t)n;
+    c.v.n_bins = n_bins;
+    c.v.max_len = c.max_len;
+    ctx->contigs[contig_id] = c;
+    return FTK_OK;
+}
+
+// Shared body of the window features: stage windows, plan candidate ranges.
+struct WindowCall {
+    const int32_t* d_ws = nullptr;
+    const int32_t* d_we = nullptr;
+    WindowPlan plan{};
+};
+
+size_t window_scratch_bytes(int64_t n_win) {
+    return 2 * align_up(n_win * 4) + 3 * align_up(n_win * 4) + align_up((n_win + 1) * 4);
+}
+
+int window_prepare(ftk_ctx* ctx, ContigData* c, Arena& a, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                   int lmax, int small_max, WindowCall* wc) {
+    int32_t* b_ws = a.take<int32_t>(n_win);
+    int32_t* b_we = a.take<int32_t>(n_win);
+    wc->plan.cand_lo = a.take<int32_t>(n_win);
+    wc->plan.cand_hi = a.take<int32_t>(n_win);
+    wc->plan.nchunks = a.take<uint32_t>(n_win);
+    wc->plan.chunk_off = a.take<uint32_t>(n_win + 1);
+    int rc = stage_in(ctx, w_start, n_win, b_ws, &wc->d_ws);
+    if (rc) return rc;
+    rc = stage_in(ctx, w_end, n_win, b_we, &wc->d_we);
+    if (rc) return rc;
+    launch_plan(ctx->stream, c->v, wc->d_ws, wc->d_we, (int)n_win, lmax, small_max, wc->plan);
+    return FTK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ftk_version(void) { return "ftk-hip 0.1.0 (gfx950)"; }
+
+int ftk_device_count(int* n_out) {
+    if (!n_out) return fail(nullptr, FTK_ERR_INVALID, "n_out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *n_out = n;
+    return FTK_OK;
+}
+
+int ftk_ctx_create(int device_id, ftk_ctx** out) {
+    if (!out) return fail(nullptr, FTK_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, FTK_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    }
+    if (device_id < 0 || device_id >= n)
+        return fail(nullptr, FTK_ERR_NO_DEVICE, "device %d out of range (have %d); no CPU fallback", device_id, n);
+    ftk_ctx* ctx = new (std::nothrow) ftk_ctx();
+    if (!ctx) return fail(nullptr, FTK_ERR_OOM, "out of host memory");
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_start)) != hipSuccess || (e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) {
+        (void)hipGetLastError();
+        int rc = fail(nullptr, FTK_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return rc;
+    }
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return FTK_OK;
+}
+
+void ftk_ctx_destroy(ftk_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->contigs) free_contig(kv.second);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* ftk_last_error(ftk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int ftk_ctx_set_stream(ftk_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return FTK_OK;
+}
+
+int ftk_ctx_sync(ftk_ctx* ctx) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
+int ftk_timer_start(ftk_ctx* ctx) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    HIPCHK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    return FTK_OK;
+}
+
+int ftk_timer_stop(ftk_ctx* ctx, float* ms_out) {
+    if (!ctx || !ms_out) return fail(ctx, FTK_ERR_INVALID, "NULL argument");
+    HIPCHK(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_stop));
+    HIPCHK(ctx, hipEventElapsedTime(ms_out, ctx->ev_start, ctx->ev_stop));
+    return FTK_OK;
+}
+
+int ftk_frags_from_host(ftk_ctx* ctx, int contig_id, const int32_t* start, const int32_t* end, const uint8_t* mapq,
+                        const uint8_t* strand, int64_t n) {
+    return upload_common(ctx, contig_id, start, end, mapq, strand, n, hipMemcpyHostToDevice);
+}
+
+int ftk_frags_from_device(ftk_ctx* ctx, int contig_id, const int32_t* d_start, const int32_t* d_end,
+                          const uint8_t* d_mapq, const uint8_t* d_strand, int64_t n) {
+    return upload_common(ctx, contig_id, d_start, d_end, d_mapq, d_strand, n, hipMemcpyDeviceToDevice);
+}
+
+int ftk_frags_set_read1(ftk_ctx* ctx, int contig_id, const int32_t* r1_start, const int32_t* r1_end, int64_t n) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    ContigData* c;
+    int rc = get_contig(ctx, contig_id, &c);
+    if (rc) return rc;
+    if (n != c->n) return fail(ctx, FTK_ERR_INVALID, "read1 columns have %lld rows, contig has %lld", (long long)n, (long long)c->n);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    size_t n_pad = ((size_t)n + 3) / 4 * 4 + 4;
+    size_t b = align_up(n_pad * 4);
+    if (c->r1) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(c->r1));
+        c->r1 = nullptr;
+    }
+    HIPCHK(ctx, hipMalloc((void**)&c->r1, 2 * b));
+    HIPCHK(ctx, hipMemsetAsync(c->r1, 0, 2 * b, ctx->stream));
+    hipMemcpyKind k = is_device_ptr(r1_start) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (n > 0) {
+        HIPCHK(ctx, hipMemcpyAsync(c->r1, r1_start, n * 4, k, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync((char*)c->r1 + b, r1_end, n * 4, k, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    c->v.r1_start = c->r1;
+    c->v.r1_end = (int32_t*)((char*)c->r1 + b);
+    return FTK_OK;
+}
+
+int ftk_frags_info(ftk_ctx* ctx, int contig_id, int64_t* n_out, int32_t* max_len_out, int32_t* max_end_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    ContigData* c;
+    int rc = get_contig(ctx, contig_id, &c);
+    if (rc) return rc;
+    if (n_out) *n_out = c->n;
+    if (max_len_out) *max_len_out = c->max_len;
+    if (max_end_out) *max_end_out = c->max_end;
+    return FTK_OK;
+}
+
+int ftk_frags_release(ftk_ctx* ctx, int contig_id) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    auto it = ctx->contigs.find(contig_id);
+    if (it == ctx->contigs.end()) return fail(ctx, FTK_ERR_NO_CONTIG, "contig id %d is not loaded", contig_id);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    free_contig(it->second);
+    ctx->contigs.erase(it);
+    return FTK_OK;
+}
+
+int ftk_window_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                      const ftk_filter* f, int64_t* count_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    ContigData* c;
+    int rc = get_contig(ctx, contig_id, &c);
+    if (rc) return rc;
+    if ((rc = check_filter(ctx, f, *c))) return rc;
+    if (n_win < 0 || n_win > (1 << 30)) return fail(ctx, FTK_ERR_INVALID, "n_win out of range");
+    if (n_win == 0) return FTK_OK;
+    if (!w_start || !w_end || !count_out) return fail(ctx, FTK_ERR_INVALID, "NULL window/output pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool out_dev = is_device_ptr(count_out);
+    size_t need = window_scratch_bytes(n_win) + (out_dev ? 0 : align_up(n_win * 8));
+    if ((rc = reserve_scratch(ctx, need))) return rc;
+    Arena a(ctx);
+    WindowCall wc;
+    if ((rc = window_prepare(ctx, c, a, w_start, w_end, n_win, eff_lmax(f, *c), kSmallMax, &wc))) return rc;
+    int64_t* d_out = out_dev ? count_out : a.take<int64_t>(n_win);
+    launch_window_counts(ctx->stream, ctx->n_cu * 8, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, *f, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    if (!out_dev) {
+        HIPCHK(ctx, hipMemcpyAsync(count_out, d_out, n_win * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FTK_OK;
+}
+
+int ftk_delfi_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                     int32_t mapq_min, const int32_t* bl_start, const int32_t* bl_end, int64_t n_bl,
+                     const ftk_gaps* gaps, int64_t* short_out, int64_t* long_out, int64_t* nfrag_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    ContigData* c;
+    int rc = get_contig(ctx, contig_id, &c);
+    if (rc) return rc;
+    if (n_win < 0 || n_win > (1 << 30)) return fail(ctx, FTK_ERR_INVALID, "n_win out of range");
+    if (n_win == 0) return FTK_OK;
+    if (!w_start || !w_end || !short_out || !long_out) return fail(ctx, FTK_ERR_INVALID, "NULL window/output pointer");
+    if (n_bl < 0 || (n_bl > 0 && (!bl_start || !bl_end))) return fail(ctx, FTK_ERR_INVALID, "bad blacklist arguments");
+    ftk_gaps g{};
+    if (gaps) g = *gaps;
+    if (g.has_gaps && (g.n_telo < 0 || g.n_telo > FTK_MAX_TELOMERES))
+        return fail(ctx, FTK_ERR_INVALID, "at most %d telomere intervals per contig are supported", FTK_MAX_TELOMERES);
+    if (is_device_ptr(w_start) || is_device_ptr(w_end) || is_device_ptr(bl_start))
+        return fail(ctx, FTK_ERR_INVALID, "ftk_delfi_counts takes host window and blacklist arrays");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+
+    // Blacklist regions fully inside each window (frag/_delfi.py:110-126):
+    // region start >= w_start (bisect on the sorted starts) and stop <= w_end.
+    // Per window keep (r0, running max of r1); a fragment is blacklisted iff
+    // max{r1 : r0 <= fs} > fe, which equals "some region has r0 <= fs and
+    // fe < r1" (frag/_delfi.py:455-462) also for overlapping regions.
+    std::vector<int32_t> off(n_win + 1, 0), r0, pm;
+    if (n_bl > 0) {
+        for (int64_t i = 1; i < n_bl; ++i)
+            if (bl_start[i] < bl_start[i - 1]) return fail(ctx, FTK_ERR_INVALID, "blacklist must be sorted by start");
+        for (int64_t w = 0; w < n_win; ++w) {
+            const int32_t* lo = std::lower_bound(bl_start, bl_start + n_bl, w_start[w]);
+            int32_t run = INT32_MIN;
+            for (int64_t j = lo - bl_start; j < n_bl && bl_start[j] < w_end[w]; ++j) {
+                if (bl_end[j] <= w_end[w]) {
+                    run = std::max(run, bl_end[j]);
+                    r0.push_back(bl_start[j]);
+                    pm.push_back(run);
+                }
+            }
+            if (r0.size() > (size_t)INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "blacklist expansion too large");
+            off[w + 1] = (int32_t)r0.size();
+        }
+    }
+    const size_t n_r = r0.size();
+    const bool use_bl = n_r > 0;
+    const bool s_dev = is_device_ptr(short_out), l_dev = is_device_ptr(long_out), n_dev = is_device_ptr(nfrag_out);
+    size_t need = window_scratch_bytes(n_win) + 2 * align_up(n_win * 8) +
+                  (use_bl ? align_up((n_win + 1) * 4) + 2 * align_up(n_r * 4) : 0);
+    if ((rc = reserve_scratch(ctx, need))) return rc;
+    Arena a(ctx);
+    WindowCall wc;
+    ftk_filter f{mapq_min, 100, 220, FTK_POLICY_MIDPOINT, c->v.r1_start ? FTK_FETCH_BAM_READ1 : FTK_FETCH_TABIX};
+    if ((rc = window_prepare(ctx, c, a, w_start, w_end, n_win, eff_lmax(&f, *c), kSmallMax, &wc))) return rc;
+    int64_t* d_short = s_dev ? short_out : a.take<int64_t>(n_win);
+    int64_t* d_long = l_dev ? long_out : a.take<int64_t>(n_win);
+    int32_t *d_off = nullptr, *d_r0 = nullptr, *d_pm = nullptr;
+    if (use_bl) {
+        d_off = a.take<int32_t>(n_win + 1);
+        d_r0 = a.take<int32_t>(n_r);
+        d_pm = a.take<int32_t>(n_r);
+        HIPCHK(ctx, hipMemcpyAsync(d_off, off.data(), (n_win + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(d_r0, r0.data(), n_r * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(d_pm, pm.data(), n_r * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    launch_delfi_counts(ctx->stream, ctx->n_cu * 8, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, mapq_min,
+                        c->v.r1_start != nullptr, g, d_off, d_r0, d_pm, d_short, d_long);
+    HIPCHK(ctx, hipGetLastError());
+    if (!s_dev) HIPCHK(ctx, hipMemcpyAsync(short_out, d_short, n_win * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (!l_dev) HIPCHK(ctx, hipMemcpyAsync(long_out, d_long, n_win * 8, hipMemcpyDeviceToHost, ctx->stream));
+    // the pageable staging vectors above must outlive the copies
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (nfrag_out) {
+        if (n_dev || s_dev || l_dev)
+            return fail(ctx, FTK_ERR_INVALID, "nfrag_out is only filled for host outputs (nfrag = short + long)");
+        for (int64_t w = 0; w < n_win; ++w) nfrag_out[w] = short_out[w] + long_out[w];
+    }
+    return FTK_OK;
+}
+
+int ftk_fraglen_hist(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                     const ftk_filter* f, int32_t len_lo, int32_t n_bins, uint32_t* hist_out, int64_t* overflow_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    ContigData* c;
+    int rc = get_contig(ctx, contig_id, &c);
+    if (rc) return rc;
+    if ((rc = check_filter(ctx, f, *c))) return rc;
+    if (n_win < 0 || n_win > (1 << 30)) return fail(ctx, FTK_ERR_INVALID, "n_win out of range");
+    if (n_bins <= 0 || n_bins > kHistMaxBins)
+        return fail(ctx, FTK_ERR_INVALID, "n_bins must be in [1, %d]; split the length range", kHistMaxBins);
+    if (n_win == 0) return FTK_OK;
+    if (!w_start || !w_end || !hist_out || !overflow_out) return fail(ctx, FTK_ERR_INVALID, "NULL window/output pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool h_dev = is_device_ptr(hist_out), o_dev = is_device_ptr(overflow_out);
+    const size_t hist_elems = (size_t)n_win * (size_t)n_bins;
+    size_t need = window_scratch_bytes(n_win) + (h_dev ? 0 : align_up(hist_elems * 4)) + (o_dev ? 0 : align_up(n_win * 8));
+    if ((rc = reserve_scratch(ctx, need))) return rc;
+    Arena a(ctx);
+    WindowCall wc;
+    const int small_max = n_bins <= kHistSmallMaxBins ? kSmallMax : -1;
+    if ((rc = window_prepare(ctx, c, a, w_start, w_end, n_win, eff_lmax(f, *c), small_max, &wc))) return rc;
+    uint32_t* d_hist = h_dev ? hist_out : a.take<uint32_t>(hist_elems);
+    int64_t* d_over = o_dev ? overflow_out : a.take<int64_t>(n_win);
+    HIPCHK(ctx, hipMemsetAsync(d_hist, 0, hist_elems * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_over, 0, n_win * 8, ctx->stream));
+    launch_fraglen_hist(ctx->stream, ctx->n_cu * 8, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, *f, len_lo, n_bins,
+                        d_hist, d_over);
+    HIPCHK(ctx, hipGetLastError());
+    if (!h_dev) HIPCHK(ctx, hipMemcpyAsync(hist_out, d_hist, hist_elems * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (!o_dev) HIPCHK(ctx, hipMemcpyAsync(overflow_out, d_over, n_win * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (!h_dev || !o_dev) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
+static int select_common(ftk_ctx* ctx, int contig_id, int32_t w_start, int32_t w_end, const ftk_filter* f,
+                         int32_t* len_out, int32_t* start_out, int32_t* end_out, uint8_t* mapq_out,
+                         uint8_t* strand_out, int64_t cap, int64_t* n_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    ContigData* c;
+    int rc = get_contig(ctx, contig_id, &c);
+    if (rc) return rc;
+    if ((rc = check_filter(ctx, f, *c))) return rc;
+    if (!n_out || cap < 0) return fail(ctx, FTK_ERR_INVALID, "bad output arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // candidate range of the single window (planned on the device, read back)
+    if ((rc = reserve_scratch(ctx, window_scratch_bytes(1)))) return rc;
+    int32_t lohi[2];
+    {
+        Arena a(ctx);
+        WindowCall wc;
+        if ((rc = window_prepare(ctx, c, a, &w_start, &w_end, 1, eff_lmax(f, *c), kSmallMax, &wc))) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(&lohi[0], wc.plan.cand_lo, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(&lohi[1], wc.plan.cand_hi, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const int lo = lohi[0], hi = lohi[1];
+    const int64_t n_cand = hi - lo;
+    if (n_cand <= 0) {
+        *n_out = 0;
+        return FTK_OK;
+    }
+    const int nb = (int)((n_cand + 255) / 256);
+    const int64_t ncap = std::min<int64_t>(cap, n_cand);
+    size_t need = 2 * align_up((size_t)(nb + 1) * 4) + 3 * align_up(ncap * 4) + 2 * align_up(ncap);
+    if ((rc = reserve_scratch(ctx, need))) return rc;
+    Arena a(ctx);
+    uint32_t* d_cnt = a.take<uint32_t>(nb + 1);
+    uint32_t* d_off = a.take<uint32_t>(nb + 1);
+    int32_t* d_len = len_out ? a.take<int32_t>(ncap) : nullptr;
+    int32_t* d_s = start_out ? a.take<int32_t>(ncap) : nullptr;
+    int32_t* d_e = end_out ? a.take<int32_t>(ncap) : nullptr;
+    uint8_t* d_q = mapq_out ? a.take<uint8_t>(ncap) : nullptr;
+    uint8_t* d_st = strand_out ? a.take<uint8_t>(ncap) : nullptr;
+    launch_select_count(ctx->stream, c->v, lo, hi, w_start, w_end, *f, d_cnt);
+    launch_scan_u32(ctx->stream, d_cnt, nb, d_off);
+    launch_select_write(ctx->stream, c->v, lo, hi, w_start, w_end, *f, d_off, ncap, d_len, d_s, d_e, d_q, d_st);
+    HIPCHK(ctx, hipGetLastError());
+    uint32_t total = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&total, d_off + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = total;
+    const int64_t n_copy = std::min<int64_t>(total, ncap);
+    if (n_copy > 0) {
+        if (len_out) HIPCHK(ctx, hipMemcpyAsync(len_out, d_len, n_copy * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (start_out) HIPCHK(ctx, hipMemcpyAsync(start_out, d_s, n_copy * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (end_out) HIPCHK(ctx, hipMemcpyAsync(end_out, d_e, n_copy * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (mapq_out) HIPCHK(ctx, hipMemcpyAsync(mapq_out, d_q, n_copy, hipMemcpyDeviceToHost, ctx->stream));
+        if (strand_out) HIPCHK(ctx, hipMemcpyAsync(strand_out, d_st, n_copy, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FTK_OK;
+}
+
+int ftk_frag_lengths(ftk_ctx* ctx, int contig_id, int32_t w_start, int32_t w_end, const ftk_filter* f,
+                     int32_t* len_out, int64_t cap, int64_t* n_out) {
+    return select_common(ctx, contig_id, w_start, w_end, f, len_out, nullptr, nullptr, nullptr, nullptr, cap, n_out);
+}
+
+int ftk_frag_select(ftk_ctx* ctx, int contig_id, int32_t w_start, int32_t w_end, const ftk_filter* f,
+                    int32_t* start_out, int32_t* end_out, uint8_t* mapq_out, uint8_t* strand_out, int64_t cap,
+                    int64_t* n_out) {
+    return select_common(ctx, contig_id, w_start, w_end, f, nullptr, start_out, end_out, mapq_out, strand_out, cap,
+                         n_out);
+}
+
+static int wps_params(ftk_ctx* ctx, const ContigData& c, int64_t chrom_size, int32_t window_size, int32_t min_len,
+                      int32_t max_len, int32_t mapq_min, WpsParams* p) {
+    if (window_size <= 0 || window_size > (1 << 20)) return fail(ctx, FTK_ERR_INVALID, "window_size out of range");
+    if (max_len < 0 || max_len > (1 << 28)) return fail(ctx, FTK_ERR_INVALID, "max_len out of range");
+    if (chrom_size < 0) return fail(ctx, FTK_ERR_INVALID, "chrom_size must be >= 0");
+    p->chrom_size = chrom_size;
+    p->odd = window_size & 1;
+    if (p->odd) {
+        p->hl = p->hr = (window_size - 1) / 2;
+    } else {
+        p->hl = window_size / 2;
+        p->hr = window_size / 2 - 1;
+    }
+    p->min_len = min_len < 0 ? 0 : min_len;
+    p->max_len = max_len;
+    p->mapq_min = mapq_min;
+    p->lmax = std::max(0, std::min(max_len, c.max_len));
+    return FTK_OK;
+}
+
+int ftk_wps(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t chrom_size, int32_t window_size,
+            int32_t min_len, int32_t max_len, int32_t mapq_min, int64_t* wps_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    ContigData* c;
+    int rc = get_contig(ctx, contig_id, &c);
+    if (rc) return rc;
+    WpsParams p{};
+    if ((rc = wps_params(ctx, *c, chrom_size, window_size, min_len, max_len, mapq_min, &p))) return rc;
+    if (stop <= start) return FTK_OK;  // degenerate interval: empty result (frag/_wps.py:145-152)
+    if (start < -(1LL << 30) || stop > (1LL << 31)) return fail(ctx, FTK_ERR_INVALID, "interval out of range");
+    if (!wps_out) return fail(ctx, FTK_ERR_INVALID, "wps_out is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t n_pos = stop - start;
+    const bool out_dev = is_device_ptr(wps_out);
+    if (!out_dev && (rc = reserve_scratch(ctx, align_up(n_pos * 8)))) return rc;
+    int64_t* d_out = out_dev ? wps_out : (int64_t*)ctx->scratch;
+    p.start = start;
+    p.stop = stop;
+    const int64_t n_tiles = (n_pos + kWpsTile - 1) / kWpsTile;
+    launch_wps(ctx->stream, c->v, p, n_tiles, nullptr, nullptr, nullptr, nullptr, nullptr, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    if (!out_dev) {
+        HIPCHK(ctx, hipMemcpyAsync(wps_out, d_out, n_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FTK_OK;
+}
+
+int ftk_wps_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start, const int64_t* iv_stop, int64_t n_iv,
+                      const int64_t* out_offset, int64_t chrom_size, int32_t window_size, int32_t min_len,
+                      int32_t max_len, int32_t mapq_min, int64_t* wps_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    ContigData* c;
+    int rc = get_contig(ctx, contig_id, &c);
+    if (rc) return rc;
+    WpsParams p{};
+    if ((rc = wps_params(ctx, *c, chrom_size, window_size, min_len, max_len, mapq_min, &p))) return rc;
+    if (n_iv < 0 || n_iv > INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "n_iv out of range");
+    if (n_iv == 0) return FTK_OK;
+    if (!iv_start || !iv_stop || !out_offset || !wps_out) return fail(ctx, FTK_ERR_INVALID, "NULL argument");
+    if (is_device_ptr(iv_start) || is_device_ptr(iv_stop) || is_device_ptr(out_offset))
+        return fail(ctx, FTK_ERR_INVALID, "interval arrays must be host arrays");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<int32_t> tile_iv, tile_k;
+    int64_t total_out = 0;
+    for (int64_t i = 0; i < n_iv; ++i) {
+        int64_t len = iv_stop[i] - iv_start[i];
+        if (len <= 0) continue;
+        if (iv_start[i] < -(1LL << 30) || iv_stop[i] > (1LL << 31)) return fail(ctx, FTK_ERR_INVALID, "interval out of range");
+        if (out_offset[i] < 0) return fail(ctx, FTK_ERR_INVALID, "negative output offset");
+        total_out = std::max(total_out, out_offset[i] + len);
+        int64_t nt = (len + kWpsTile - 1) / kWpsTile;
+        for (int64_t k = 0; k < nt; ++k) {
+            tile_iv.push_back((int32_t)i);
+            tile_k.push_back((int32_t)k);
+        }
+    }
+    const size_t n_tiles = tile_iv.size();
+    if (n_tiles == 0) return FTK_OK;
+    if (n_tiles > (size_t)INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "too many WPS tiles in one call");
+    const bool out_dev = is_device_ptr(wps_out);
+    size_t need = 3 * align_up(n_iv * 8) + 2 * align_up(n_tiles * 4) + (out_dev ? 0 : align_up(total_out * 8));
+    if ((rc = reserve_scratch(ctx, need))) return rc;
+    Arena a(ctx);
+    int64_t* d_s = a.take<int64_t>(n_iv);
+    int64_t* d_e = a.take<int64_t>(n_iv);
+    int64_t* d_o = a.take<int64_t>(n_iv);
+    int32_t* d_ti = a.take<int32_t>(n_tiles);
+    int32_t* d_tk = a.take<int32_t>(n_tiles);
+    int64_t* d_out = out_dev ? wps_out : a.take<int64_t>(total_out);
+    HIPCHK(ctx, hipMemcpyAsync(d_s, iv_start, n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_e, iv_stop, n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_o, out_offset, n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_ti, tile_iv.data(), n_tiles * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_tk, tile_k.data(), n_tiles * 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_wps(ctx->stream, c->v, p, (int64_t)n_tiles, d_s, d_e, d_o, d_ti, d_tk, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    if (!out_dev) HIPCHK(ctx, hipMemcpyAsync(wps_out, d_out, total_out * 8, hipMemcpyDeviceToHost, ctx->stream));
+    // tile descriptor vectors are pageable staging: wait before they go away
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
+}  // extern "C"

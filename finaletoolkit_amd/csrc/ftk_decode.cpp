@@ -1,0 +1,441 @@
+// Host-side decoders: BGZF/gzip fragment text (frag.gz, BED6 bed.gz) and BAM
+// -> per-contig SoA columns.  Pure host code (zlib + std::thread): usable and
+// tested without a GPU.  Follows io/alignment.py:270-302 (_fetch_tabix) and
+// io/alignment.py:60-71,242-268 (_fetch_sam) of the reference; mapq is kept as
+// a column (the cut is applied by the kernels).
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ftk.h"
+
+namespace {
+
+thread_local std::string g_decode_err;
+
+int dfail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_decode_err = buf;
+    return code;
+}
+
+struct Columns {
+    std::vector<int32_t> start, end, r1s, r1e;
+    std::vector<uint8_t> mapq, strand;
+    void append(const Columns& o) {
+        start.insert(start.end(), o.start.begin(), o.start.end());
+        end.insert(end.end(), o.end.begin(), o.end.end());
+        mapq.insert(mapq.end(), o.mapq.begin(), o.mapq.end());
+        strand.insert(strand.end(), o.strand.begin(), o.strand.end());
+        r1s.insert(r1s.end(), o.r1s.begin(), o.r1s.end());
+        r1e.insert(r1e.end(), o.r1e.begin(), o.r1e.end());
+    }
+};
+
+struct Contig {
+    std::string name;
+    int64_t length = -1;
+    Columns c;
+};
+
+}  // namespace
+
+struct ftk_fragtable {
+    std::vector<Contig> contigs;
+    bool bed6 = false;
+    bool bam = false;
+};
+
+namespace {
+
+bool read_file(const char* path, std::vector<uint8_t>* out) {
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return false;
+    fseek(fp, 0, SEEK_END);
+    long sz = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    if (sz < 0) { fclose(fp); return false; }
+    out->resize((size_t)sz);
+    size_t got = sz ? fread(out->data(), 1, (size_t)sz, fp) : 0;
+    fclose(fp);
+    return got == (size_t)sz;
+}
+
+struct Block {
+    size_t in_off, in_len;   // raw deflate payload
+    size_t out_off, out_len;
+};
+
+// Parse one gzip member header; returns payload offset or 0 on error.
+// *bsize = BGZF total block size when the BC subfield is present, else 0.
+size_t gzip_header(const uint8_t* p, size_t n, size_t off, size_t* bsize) {
+    *bsize = 0;
+    if (off + 18 > n) return 0;
+    if (p[off] != 31 || p[off + 1] != 139 || p[off + 2] != 8) return 0;
+    int flg = p[off + 3];
+    size_t q = off + 10;
+    if (flg & 4) {
+        if (q + 2 > n) return 0;
+        size_t xlen = p[q] | (p[q + 1] << 8);
+        q += 2;
+        if (q + xlen > n) return 0;
+        size_t x = q, xe = q + xlen;
+        while (x + 4 <= xe) {
+            size_t slen = p[x + 2] | (p[x + 3] << 8);
+            if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2 && x + 6 <= xe) *bsize = (size_t)(p[x + 4] | (p[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        q = xe;
+    }
+    if (flg & 8) { while (q < n && p[q]) ++q; ++q; }
+    if (flg & 16) { while (q < n && p[q]) ++q; ++q; }
+    if (flg & 2) q += 2;
+    return q <= n ? q : 0;
+}
+
+// Inflate a BGZF (block-parallel) or plain gzip (serial) file image.
+int inflate_all(const std::vector<uint8_t>& in, int n_threads, std::vector<uint8_t>* out) {
+    const uint8_t* p = in.data();
+    const size_t n = in.size();
+    if (n == 0) { out->clear(); return FTK_OK; }
+    size_t bsize = 0;
+    size_t pay = gzip_header(p, n, 0, &bsize);
+    if (!pay) return dfail(FTK_ERR_FORMAT, "not a gzip/BGZF file");
+    if (bsize) {
+        std::vector<Block> blocks;
+        size_t off = 0, total = 0;
+        while (off < n) {
+            size_t bs = 0;
+            size_t q = gzip_header(p, n, off, &bs);
+            if (!q || !bs || off + bs > n || q + 8 > off + bs) return dfail(FTK_ERR_FORMAT, "corrupt BGZF block at %zu", off);
+            const uint8_t* tr = p + off + bs - 8;
+            size_t isize = (size_t)tr[4] | ((size_t)tr[5] << 8) | ((size_t)tr[6] << 16) | ((size_t)tr[7] << 24);
+            blocks.push_back({q, off + bs - 8 - q, total, isize});
+            total += isize;
+            off += bs;
+        }
+        out->resize(total);
+        std::atomic<size_t> next{0};
+        std::atomic<int> bad{0};
+        auto work = [&]() {
+            z_stream zs;
+            for (;;) {
+                size_t i = next.fetch_add(1);
+                if (i >= blocks.size() || bad.load()) break;
+                const Block& b = blocks[i];
+                if (b.out_len == 0) continue;
+                memset(&zs, 0, sizeof(zs));
+                if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; break; }
+                zs.next_in = const_cast<Bytef*>(p + b.in_off);
+                zs.avail_in = (uInt)b.in_len;
+                zs.next_out = out->data() + b.out_off;
+                zs.avail_out = (uInt)b.out_len;
+                int rc = inflate(&zs, Z_FINISH);
+                inflateEnd(&zs);
+                if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; break; }
+            }
+        };
+        int nt = std::max(1, std::min<int>(n_threads, (int)blocks.size()));
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+        if (bad.load()) return dfail(FTK_ERR_FORMAT, "BGZF inflate failed");
+        return FTK_OK;
+    }
+    // plain (possibly multi-member) gzip
+    out->clear();
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) return dfail(FTK_ERR_FORMAT, "zlib init failed");
+    zs.next_in = const_cast<Bytef*>(p);
+    zs.avail_in = (uInt)std::min<size_t>(n, 0xFFFFFFFFu);
+    std::vector<uint8_t> buf(1 << 20);
+    for (;;) {
+        zs.next_out = buf.data();
+        zs.avail_out = (uInt)buf.size();
+        int rc = inflate(&zs, Z_NO_FLUSH);
+        if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); return dfail(FTK_ERR_FORMAT, "gzip inflate failed (%d)", rc); }
+        out->insert(out->end(), buf.data(), buf.data() + (buf.size() - zs.avail_out));
+        if (rc == Z_STREAM_END) {
+            if (zs.avail_in == 0) break;
+            if (inflateReset(&zs) != Z_OK) { inflateEnd(&zs); return dfail(FTK_ERR_FORMAT, "gzip member reset failed"); }
+        } else if (zs.avail_in == 0 && zs.avail_out != 0) {
+            break;  // truncated stream: keep what we have
+        }
+    }
+    inflateEnd(&zs);
+    return FTK_OK;
+}
+
+// Python int(): optional surrounding blanks, optional sign, decimal digits.
+bool parse_int(const char* b, const char* e, long long* v) {
+    while (b < e && (*b == ' ' || *b == '\r')) ++b;
+    while (e > b && (e[-1] == ' ' || e[-1] == '\r')) --e;
+    if (b == e) return false;
+    bool neg = false;
+    if (*b == '+' || *b == '-') { neg = (*b == '-'); ++b; }
+    if (b == e) return false;
+    long long x = 0;
+    for (; b < e; ++b) {
+        if (*b < '0' || *b > '9') return false;
+        x = x * 10 + (*b - '0');
+        if (x > (1LL << 40)) return false;
+    }
+    *v = neg ? -x : x;
+    return true;
+}
+
+struct Run {
+    std::string name;
+    Columns c;
+};
+
+void parse_segment(const char* b, const char* e, bool bed6, const char* only, std::vector<Run>* runs) {
+    const int mq_col = bed6 ? 4 : 3, st_col = bed6 ? 5 : 4;
+    const size_t only_len = only ? strlen(only) : 0;
+    Run* cur = nullptr;
+    while (b < e) {
+        const char* nl = (const char*)memchr(b, '\n', (size_t)(e - b));
+        const char* le = nl ? nl : e;
+        const char* line = b;
+        b = nl ? nl + 1 : e;
+        if (le > line && le[-1] == '\r') --le;
+        if (le == line || *line == '#') continue;
+        const char* fb[7];
+        const char* fe[7];
+        int nf = 0;
+        const char* q = line;
+        while (nf < 7) {
+            const char* tab = (const char*)memchr(q, '\t', (size_t)(le - q));
+            fb[nf] = q;
+            fe[nf] = tab ? tab : le;
+            ++nf;
+            if (!tab) break;
+            q = tab + 1;
+        }
+        if (nf <= st_col) continue;  // IndexError in the reference -> row skipped
+        size_t cl = (size_t)(fe[0] - fb[0]);
+        if (only && (cl != only_len || memcmp(fb[0], only, cl) != 0)) continue;
+        long long s, t, m;
+        if (!parse_int(fb[1], fe[1], &s) || !parse_int(fb[2], fe[2], &t) || !parse_int(fb[mq_col], fe[mq_col], &m)) continue;
+        if (s < 0 || t < 0 || s > INT32_MAX || t > INT32_MAX || m < 0) continue;
+        if (!cur || cur->name.size() != cl || memcmp(cur->name.data(), fb[0], cl) != 0) {
+            runs->push_back(Run{std::string(fb[0], cl), {}});
+            cur = &runs->back();
+        }
+        cur->c.start.push_back((int32_t)s);
+        cur->c.end.push_back((int32_t)t);
+        cur->c.mapq.push_back((uint8_t)std::min<long long>(m, 255));
+        cur->c.strand.push_back(memchr(fb[st_col], '+', (size_t)(fe[st_col] - fb[st_col])) ? 1 : 0);
+    }
+}
+
+Contig* find_or_add(ftk_fragtable* t, const std::string& name) {
+    for (auto& c : t->contigs)
+        if (c.name == name) return &c;
+    t->contigs.push_back(Contig{name, -1, {}});
+    return &t->contigs.back();
+}
+
+inline int32_t rd_i32(const uint8_t* p) { return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
+inline uint32_t rd_u32(const uint8_t* p) { return (uint32_t)rd_i32(p); }
+inline uint16_t rd_u16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+}  // namespace
+
+extern "C" {
+
+const char* ftk_fragtable_error(void) { return g_decode_err.c_str(); }
+
+int ftk_fragfile_decode(const char* path, const char* contig, int n_threads, ftk_fragtable** out) {
+    if (!path || !out) return dfail(FTK_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (n_threads < 1) n_threads = 1;
+    std::vector<uint8_t> raw, text;
+    if (!read_file(path, &raw)) return dfail(FTK_ERR_IO, "cannot read %s", path);
+    int rc = inflate_all(raw, n_threads, &text);
+    if (rc) return rc;
+    raw.clear();
+    raw.shrink_to_fit();
+    std::unique_ptr<ftk_fragtable> t(new ftk_fragtable());
+    const char* b = (const char*)text.data();
+    const char* e = b + text.size();
+    // layout detection on the first data row (io/alignment.py:143-156)
+    {
+        const char* q = b;
+        while (q < e) {
+            const char* nl = (const char*)memchr(q, '\n', (size_t)(e - q));
+            const char* le = nl ? nl : e;
+            if (le > q && *q != '#') {
+                int tabs = 0;
+                for (const char* x = q; x < le; ++x) tabs += (*x == '\t');
+                t->bed6 = (tabs + 1) > 5;
+                break;
+            }
+            if (!nl) break;
+            q = nl + 1;
+        }
+    }
+    // split at line boundaries, parse segments in parallel, merge in order
+    int nseg = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, text.size() / (1 << 16) + 1));
+    std::vector<const char*> cut(nseg + 1);
+    cut[0] = b;
+    cut[nseg] = e;
+    for (int i = 1; i < nseg; ++i) {
+        const char* q = b + text.size() * (size_t)i / (size_t)nseg;
+        if (q < cut[i - 1]) q = cut[i - 1];
+        const char* nl = (const char*)memchr(q, '\n', (size_t)(e - q));
+        cut[i] = nl ? nl + 1 : e;
+    }
+    std::vector<std::vector<Run>> seg_runs(nseg);
+    std::vector<std::thread> th;
+    for (int i = 1; i < nseg; ++i)
+        th.emplace_back(parse_segment, cut[i], cut[i + 1], t->bed6, contig, &seg_runs[i]);
+    parse_segment(cut[0], cut[1], t->bed6, contig, &seg_runs[0]);
+    for (auto& x : th) x.join();
+    for (auto& runs : seg_runs)
+        for (auto& r : runs) find_or_add(t.get(), r.name)->c.append(r.c);
+    *out = t.release();
+    return FTK_OK;
+}
+
+int ftk_bam_decode(const char* path, const char* contig, int n_threads, ftk_fragtable** out) {
+    if (!path || !out) return dfail(FTK_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (n_threads < 1) n_threads = 1;
+    std::vector<uint8_t> raw, bam;
+    if (!read_file(path, &raw)) return dfail(FTK_ERR_IO, "cannot read %s", path);
+    int rc = inflate_all(raw, n_threads, &bam);
+    if (rc) return rc;
+    raw.clear();
+    raw.shrink_to_fit();
+    const uint8_t* p = bam.data();
+    const size_t n = bam.size();
+    if (n < 12 || memcmp(p, "BAM\1", 4) != 0) return dfail(FTK_ERR_FORMAT, "%s is not a BAM file", path);
+    size_t off = 4;
+    uint32_t l_text = rd_u32(p + off);
+    off += 4 + (size_t)l_text;
+    if (off + 4 > n) return dfail(FTK_ERR_FORMAT, "truncated BAM header");
+    uint32_t n_ref = rd_u32(p + off);
+    off += 4;
+    std::unique_ptr<ftk_fragtable> t(new ftk_fragtable());
+    t->bam = true;
+    std::vector<int> ref_to_contig(n_ref, -1);
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        if (off + 4 > n) return dfail(FTK_ERR_FORMAT, "truncated BAM reference list");
+        uint32_t l_name = rd_u32(p + off);
+        off += 4;
+        if (off + l_name + 4 > n || l_name == 0) return dfail(FTK_ERR_FORMAT, "truncated BAM reference list");
+        std::string name((const char*)p + off, l_name - 1);
+        off += l_name;
+        int32_t l_ref = rd_i32(p + off);
+        off += 4;
+        if (!contig || name == contig) {
+            ref_to_contig[r] = (int)t->contigs.size();
+            t->contigs.push_back(Contig{name, l_ref, {}});
+        }
+    }
+    // records (io/alignment.py:242-268)
+    while (off + 4 <= n) {
+        uint32_t bs = rd_u32(p + off);
+        off += 4;
+        if (bs < 32 || off + bs > n) return dfail(FTK_ERR_FORMAT, "truncated BAM record");
+        const uint8_t* r = p + off;
+        off += bs;
+        int32_t ref_id = rd_i32(r);
+        if (ref_id < 0 || (uint32_t)ref_id >= n_ref || ref_to_contig[ref_id] < 0) continue;
+        int32_t pos = rd_i32(r + 4);
+        uint8_t l_read_name = r[8];
+        uint8_t mapq = r[9];
+        uint16_t n_cigar = rd_u16(r + 12);
+        uint16_t flag = rd_u16(r + 14);
+        int32_t tlen = rd_i32(r + 28);
+        // _read_is_low_quality (io/alignment.py:60-71), mapq cut left to the kernels
+        if ((flag & 0x4) || (flag & 0x100) || !(flag & 0x1) || (flag & 0x8) || (flag & 0x400) || (flag & 0x200) ||
+            (flag & 0x800) || !(flag & 0x2))
+            continue;
+        if (flag & 0x80) continue;  // read1_only: skip read2
+        if (tlen == 0) continue;
+        if (32 + (size_t)l_read_name + 4 * (size_t)n_cigar > bs) return dfail(FTK_ERR_FORMAT, "corrupt BAM record");
+        const uint8_t* cg = r + 32 + l_read_name;
+        int64_t ref_len = 0;
+        for (uint16_t k = 0; k < n_cigar; ++k) {
+            uint32_t v = rd_u32(cg + 4 * k);
+            uint32_t op = v & 15;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += v >> 4;
+        }
+        if (n_cigar == 0) continue;  // reference_end is None in pysam: cannot form the fragment
+        int64_t ref_end = (int64_t)pos + ref_len;
+        int64_t fs, fe;
+        if (tlen > 0) { fs = pos; fe = (int64_t)pos + tlen; } else { fs = ref_end + tlen; fe = ref_end; }
+        if (fs < 0 || fe < 0 || fs > INT32_MAX || fe > INT32_MAX) continue;
+        Columns& c = t->contigs[ref_to_contig[ref_id]].c;
+        c.start.push_back((int32_t)fs);
+        c.end.push_back((int32_t)fe);
+        c.mapq.push_back(mapq);
+        c.strand.push_back((flag & 0x10) ? 0 : 1);
+        c.r1s.push_back(pos);
+        c.r1e.push_back((int32_t)ref_end);
+    }
+    // the kernels need start-sorted fragments; read1 order is by read position
+    for (auto& ct : t->contigs) {
+        Columns& c = ct.c;
+        size_t m = c.start.size();
+        if (std::is_sorted(c.start.begin(), c.start.end())) continue;
+        std::vector<uint32_t> perm(m);
+        std::iota(perm.begin(), perm.end(), 0u);
+        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return c.start[a] < c.start[b]; });
+        Columns s;
+        s.start.resize(m); s.end.resize(m); s.mapq.resize(m); s.strand.resize(m); s.r1s.resize(m); s.r1e.resize(m);
+        for (size_t i = 0; i < m; ++i) {
+            uint32_t j = perm[i];
+            s.start[i] = c.start[j]; s.end[i] = c.end[j]; s.mapq[i] = c.mapq[j];
+            s.strand[i] = c.strand[j]; s.r1s[i] = c.r1s[j]; s.r1e[i] = c.r1e[j];
+        }
+        c = std::move(s);
+    }
+    *out = t.release();
+    return FTK_OK;
+}
+
+int ftk_fragtable_is_bed6(const ftk_fragtable* t) { return t && t->bed6 ? 1 : 0; }
+int ftk_fragtable_n_contigs(const ftk_fragtable* t) { return t ? (int)t->contigs.size() : 0; }
+const char* ftk_fragtable_contig_name(const ftk_fragtable* t, int i) {
+    return (t && i >= 0 && i < (int)t->contigs.size()) ? t->contigs[i].name.c_str() : nullptr;
+}
+int64_t ftk_fragtable_contig_length(const ftk_fragtable* t, int i) {
+    return (t && i >= 0 && i < (int)t->contigs.size()) ? t->contigs[i].length : -1;
+}
+int64_t ftk_fragtable_contig_rows(const ftk_fragtable* t, int i) {
+    return (t && i >= 0 && i < (int)t->contigs.size()) ? (int64_t)t->contigs[i].c.start.size() : -1;
+}
+int ftk_fragtable_columns(const ftk_fragtable* t, int i, const int32_t** start, const int32_t** end,
+                          const uint8_t** mapq, const uint8_t** strand, const int32_t** r1_start,
+                          const int32_t** r1_end) {
+    if (!t || i < 0 || i >= (int)t->contigs.size()) return dfail(FTK_ERR_NO_CONTIG, "contig index %d out of range", i);
+    const Columns& c = t->contigs[i].c;
+    if (start) *start = c.start.data();
+    if (end) *end = c.end.data();
+    if (mapq) *mapq = c.mapq.data();
+    if (strand) *strand = c.strand.data();
+    if (r1_start) *r1_start = c.r1s.empty() ? nullptr : c.r1s.data();
+    if (r1_end) *r1_end = c.r1e.empty() ? nullptr : c.r1e.data();
+    return FTK_OK;
+}
+void ftk_fragtable_free(ftk_fragtable* t) { delete t; }
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// Internal declarations shared by the HIP translation units of libftk_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ftk.h"
+
+namespace ftk {
+
+// Coarse position index: bin_idx[k] = first fragment whose start >= k << kBinShift.
+constexpr int kBinShift = 9;
+// Work-item size (fragments) of the chunked large-window path.
+constexpr int kChunk = 4096;
+// Candidate ranges up to this many fragments are handled one-wave-per-window.
+constexpr int kSmallMax = 1024;
+// Positions per WPS tile.
+constexpr int kWpsTile = 4096;
+
+// One contig's fragments, resident in HBM (start-sorted SoA, 10 B / fragment).
+struct ContigView {
+    const int32_t* start;
+    const int32_t* end;
+    const uint8_t* mapq;
+    const uint8_t* strand;
+    const int32_t* r1_start;  // BAM only (else nullptr)
+    const int32_t* r1_end;
+    const int32_t* bin_idx;   // n_bins + 1 entries
+    int32_t n;                // fragments
+    int32_t n_bins;
+    int32_t max_len;          // longest fragment in the contig
+};
+
+struct ContigData {
+    ContigView v{};
+    void* base = nullptr;     // one allocation holding all columns
+    int32_t* r1 = nullptr;    // optional allocation for read1 columns
+    int32_t* bin_idx = nullptr;
+    int64_t n = 0;
+    int32_t max_len = 0;
+    int32_t max_end = 0;
+};
+
+}  // namespace ftk
+
+struct ftk_ctx {
+    int device = -1;
+    int n_cu = 256;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::map<int, ftk::ContigData> contigs;
+    std::string err;
+    // grow-only device scratch, reused by every call (stream-ordered)
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+};

@@ -1,0 +1,60 @@
+// Launchers of the HIP kernels in ftk_kernels.hip (internal).
+#pragma once
+
+#include "ftk_internal.h"
+
+namespace ftk {
+
+// per-wave LDS histograms are used up to this many bins (4 waves x bins x 4 B)
+constexpr int kHistSmallMaxBins = 2048;
+// block-wide LDS histogram limit (128 KiB of the CU's 160 KiB)
+constexpr int kHistMaxBins = 32768;
+
+struct FragStats {
+    int unsorted;
+    int max_len;
+    int min_len;
+    int max_end;
+    int min_start;
+};
+
+// Device scratch describing where each window's candidate fragments are.
+struct WindowPlan {
+    int32_t* cand_lo;     // [n_win]
+    int32_t* cand_hi;     // [n_win]
+    uint32_t* nchunks;    // [n_win] 0 = wave-per-window path
+    uint32_t* chunk_off;  // [n_win + 1]
+};
+
+struct WpsParams {
+    long long start, stop;  // single-interval form
+    long long chrom_size;
+    int hl, hr, odd;
+    int min_len, max_len, mapq_min;
+    int lmax;  // min(max_len, longest fragment of the contig)
+};
+
+void launch_stats(hipStream_t s, const int32_t* start, const int32_t* end, int n, FragStats* st);
+void launch_bin_index(hipStream_t s, const int32_t* start, int n, int n_bins, int32_t* idx);
+void launch_plan(hipStream_t s, const ContigView& cv, const int32_t* ws, const int32_t* we, int n_win, int lmax,
+                 int small_max, const WindowPlan& pl);
+void launch_window_counts(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
+                          int n_win, const WindowPlan& pl, const ftk_filter& f, int64_t* out);
+void launch_delfi_counts(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
+                         int n_win, const WindowPlan& pl, int mapq_min, int bam, const ftk_gaps& g,
+                         const int32_t* bl_off, const int32_t* bl_r0, const int32_t* bl_pm, int64_t* short_out,
+                         int64_t* long_out);
+void launch_fraglen_hist(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
+                         int n_win, const WindowPlan& pl, const ftk_filter& f, int len_lo, int n_bins,
+                         uint32_t* hist_out, int64_t* overflow_out);
+void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t n_tiles, const int64_t* iv_start,
+                const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv, const int32_t* tile_k,
+                int64_t* out);
+void launch_select_count(hipStream_t s, const ContigView& cv, int lo, int hi, int ws, int we, const ftk_filter& f,
+                         uint32_t* block_cnt);
+void launch_scan_u32(hipStream_t s, const uint32_t* in, int n, uint32_t* off);
+void launch_select_write(hipStream_t s, const ContigView& cv, int lo, int hi, int ws, int we, const ftk_filter& f,
+                         const uint32_t* block_off, int64_t cap, int32_t* len_out, int32_t* start_out,
+                         int32_t* end_out, uint8_t* mapq_out, uint8_t* strand_out);
+
+}  // namespace ftk

@@ -1,0 +1,690 @@
+// HIP kernels (gfx950 / CDNA4, wave64) of the fragment-feature engine.
+//
+// All kernels are integer compare/count/scan work bound by HBM bandwidth: no
+// MFMA.  Design notes live in DESIGN.md; the short version:
+//   * fragments of a contig are a start-sorted SoA in HBM plus a coarse
+//     position index (first fragment per 512-bp bin), so the candidate
+//     fragments of a window / WPS tile are one contiguous index range;
+//   * window features (coverage, DELFI, length histogram) are computed
+//     window-centrically: small candidate ranges one wave per window, large
+//     ones cut into 4096-fragment chunks that a fixed grid walks in order;
+//   * WPS builds a per-tile difference array in LDS with ds_add, scans it in
+//     LDS/registers and streams int64 scores out with 16-byte stores.
+#include "ftk_kernels.h"
+
+namespace ftk {
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int wave_reduce_add(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ long long wave_reduce_add64(long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// First fragment index whose start >= p (coarse bin index + local bisection).
+__device__ __forceinline__ int lower_bound_start(const ContigView& cv, long long p) {
+    if (p <= 0) return 0;
+    long long k = p >> kBinShift;
+    if (k >= cv.n_bins) return cv.n;
+    int lo = cv.bin_idx[k], hi = cv.bin_idx[k + 1];
+    while (lo < hi) {
+        int m = (lo + hi) >> 1;
+        if (cv.start[m] < p) lo = m + 1; else hi = m;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------
+// load-time kernels
+// ---------------------------------------------------------------------------
+__global__ void stats_kernel(const int32_t* start, const int32_t* end, int n, FragStats* st) {
+    int unsorted = 0, max_len = INT32_MIN, min_len = INT32_MAX, max_end = INT32_MIN, min_start = INT32_MAX;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int s = start[i], e = end[i];
+        if (i > 0 && start[i - 1] > s) unsorted = 1;
+        int len = e - s;
+        max_len = max(max_len, len);
+        min_len = min(min_len, len);
+        max_end = max(max_end, e);
+        min_start = min(min_start, s);
+    }
+    if (unsorted) atomicOr(&st->unsorted, 1);
+    atomicMax(&st->max_len, max_len);
+    atomicMin(&st->min_len, min_len);
+    atomicMax(&st->max_end, max_end);
+    atomicMin(&st->min_start, min_start);
+}
+
+__global__ void bin_index_kernel(const int32_t* start, int n, int n_bins, int32_t* idx) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > n_bins) return;
+    if (k == n_bins) { idx[k] = n; return; }
+    long long p = (long long)k << kBinShift;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int m = (lo + hi) >> 1;
+        if (start[m] < p) lo = m + 1; else hi = m;
+    }
+    idx[k] = lo;
+}
+
+// ---------------------------------------------------------------------------
+// window planning: candidate range per window, chunk counts, chunk offsets
+// ---------------------------------------------------------------------------
+// A fragment can only pass a window [ws, we) (either policy, and the tabix
+// overlap query itself) if fs < we and fe > ws - 1, hence
+// ws - lmax <= fs < we with lmax = longest admissible fragment.
+__global__ void bounds_kernel(ContigView cv, const int32_t* ws, const int32_t* we, int n_win, int lmax,
+                              int small_max, int32_t* cand_lo, int32_t* cand_hi, uint32_t* nchunks) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_win) return;
+    int s = ws[w], e = we[w];
+    int lo = (s == INT32_MIN) ? 0 : lower_bound_start(cv, (long long)s - lmax);
+    int hi = (e == INT32_MAX) ? cv.n : lower_bound_start(cv, (long long)e);
+    if (hi < lo || e < s) hi = lo;
+    cand_lo[w] = lo;
+    cand_hi[w] = hi;
+    int cnt = hi - lo;
+    nchunks[w] = (cnt <= small_max) ? 0u : (uint32_t)((cnt + kChunk - 1) / kChunk);
+}
+
+// Exclusive scan of nchunks[0..n) into off[0..n]; one 1024-thread block.
+__global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* nchunks, int n, uint32_t* off) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + tid;
+        uint32_t v = (i < n) ? nchunks[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wave_tot[wv] = x;
+        __syncthreads();
+        uint32_t pre = carry_s;
+        for (int j = 0; j < wv; ++j) pre += wave_tot[j];
+        if (i < n) off[i] = pre + x - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = pre + x;
+        __syncthreads();
+    }
+    if (tid == 0) off[n] = carry_s;
+}
+
+// ---------------------------------------------------------------------------
+// predicates
+// ---------------------------------------------------------------------------
+// utils/_frag_generator.py:117-130 + io/alignment.py:291 (mapq) + the index
+// query that produced the stream (io/alignment.py:270-279 tabix overlap, or
+// :245 read1 overlap for BAM).  Returns 1 when the fragment counts.
+struct WinPred {
+    int mapq_min, min_len, max_len, policy, bam;
+    __device__ __forceinline__ int operator()(const ContigView& cv, int i, int fs, int fe, int q, int ws, int we,
+                                              int /*w*/) const {
+        int len = fe - fs;
+        bool ok = (q >= mapq_min) && (len >= min_len) && (len <= max_len);
+        if (bam) {
+            int rs = cv.r1_start[i], re = cv.r1_end[i];
+            ok = ok && (rs < we) && (re > ws);
+        } else {
+            ok = ok && (fs < we) && (fe > ws);
+        }
+        if (policy == FTK_POLICY_MIDPOINT) {
+            int mid = (int)(((long long)fs + (long long)fe) >> 1);
+            ok = ok && (mid >= ws) && (mid < we);
+        } else {
+            ok = ok && (fe > ws) && (fs < we);
+        }
+        return ok ? 1 : 0;
+    }
+};
+
+// frag/_delfi.py:443-472.  Returns 0 (skip), 1 (short) or 2 (long).
+struct DelfiPred {
+    int mapq_min, bam;
+    ftk_gaps g;
+    const int32_t* bl_off;  // n_win + 1 offsets into bl_r0 / bl_pm
+    const int32_t* bl_r0;   // region starts (sorted) of the regions fully inside each window
+    const int32_t* bl_pm;   // running maximum of the region stops inside each window
+    __device__ __forceinline__ int operator()(const ContigView& cv, int i, int fs, int fe, int q, int ws, int we,
+                                              int w) const {
+        if (q < mapq_min) return 0;
+        if (bam) {
+            int rs = cv.r1_start[i], re = cv.r1_end[i];
+            if (!((rs < we) && (re > ws))) return 0;
+        } else if (!((fs < we) && (fe > ws))) {
+            return 0;
+        }
+        int len = fe - fs;
+        if (len < 100 || len > 220) return 0;
+        int mid = (int)(((long long)fs + (long long)fe) >> 1);
+        if (mid < ws || mid >= we) return 0;
+        if (g.has_gaps) {  // genome/gaps.py:217-237
+            bool in_cen = (fe > g.cen_start) && (fs < g.cen_stop);
+            bool in_tel = g.n_telo > 0;
+            for (int t = 0; t < g.n_telo; ++t) in_tel = in_tel && (fe > g.telo_start[t]) && (fs < g.telo_stop[t]);
+            if (in_cen || in_tel) return 0;
+        }
+        if (bl_off) {  // frag/_delfi.py:455-462
+            int o0 = bl_off[w], o1 = bl_off[w + 1];
+            int lo = o0, hi = o1;  // upper bound: first region with r0 > fs
+            while (lo < hi) {
+                int m = (lo + hi) >> 1;
+                if (bl_r0[m] <= fs) lo = m + 1; else hi = m;
+            }
+            if (lo > o0 && bl_pm[lo - 1] > fe) return 0;
+        }
+        return (len >= 151) ? 2 : 1;
+    }
+};
+
+// ---------------------------------------------------------------------------
+// window counters (coverage / DELFI): small path = one wave per window
+// ---------------------------------------------------------------------------
+template <class Pred>
+__global__ __launch_bounds__(256) void count_small_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
+                                                          int n_win, const int32_t* cand_lo, const int32_t* cand_hi,
+                                                          const uint32_t* nchunks, Pred pred, int64_t* out1,
+                                                          int64_t* out2) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (w >= n_win) return;
+    if (nchunks[w] != 0) return;  // handled by the chunked path (which also owns the output)
+    const int lo = cand_lo[w], hi = cand_hi[w];
+    const int ws = ws_[w], we = we_[w];
+    int a1 = 0, a2 = 0;
+    for (int i = (lo & ~3) + 4 * lane; i < hi; i += 256) {
+        const int4 s = *reinterpret_cast<const int4*>(cv.start + i);
+        const int4 e = *reinterpret_cast<const int4*>(cv.end + i);
+        const uchar4 q = *reinterpret_cast<const uchar4*>(cv.mapq + i);
+        const int ss[4] = {s.x, s.y, s.z, s.w}, ee[4] = {e.x, e.y, e.z, e.w}, qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int idx = i + j;
+            if (idx >= lo && idx < hi) {
+                int r = pred(cv, idx, ss[j], ee[j], qq[j], ws, we, w);
+                a1 += (r == 1);
+                a2 += (r == 2);
+            }
+        }
+    }
+    a1 = wave_reduce_add(a1);
+    a2 = wave_reduce_add(a2);
+    if (lane == 0) {
+        out1[w] = a1;
+        if (out2) out2[w] = a2;
+    }
+}
+
+// large path: a fixed grid walks the chunk list in order; one atomic per
+// (block, window) pair.
+template <class Pred>
+__global__ __launch_bounds__(256) void count_large_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
+                                                          int n_win, const int32_t* cand_lo, const int32_t* cand_hi,
+                                                          const uint32_t* chunk_off, Pred pred, int64_t* out1,
+                                                          int64_t* out2) {
+    __shared__ int red[2][4];
+    const uint32_t total = chunk_off[n_win];
+    const uint32_t c0 = (uint32_t)(((unsigned long long)total * blockIdx.x) / gridDim.x);
+    const uint32_t c1 = (uint32_t)(((unsigned long long)total * (blockIdx.x + 1)) / gridDim.x);
+    if (c0 >= c1) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int w;
+    {
+        int lo = 0, hi = n_win;  // largest w with chunk_off[w] <= c0
+        while (hi - lo > 1) {
+            int m = (lo + hi) >> 1;
+            if (chunk_off[m] <= c0) lo = m; else hi = m;
+        }
+        w = lo;
+    }
+    int a1 = 0, a2 = 0;
+    uint32_t c = c0;
+    while (c < c1) {
+        uint32_t w_first = chunk_off[w], w_next = chunk_off[w + 1];
+        if (c >= w_next) { ++w; continue; }
+        const int ws = ws_[w], we = we_[w];
+        const int wlo = cand_lo[w], whi = cand_hi[w];
+        const uint32_t c_end = min(c1, w_next);
+        for (; c < c_end; ++c) {
+            const int lo = wlo + (int)(c - w_first) * kChunk;
+            const int hi = min(lo + kChunk, whi);
+            for (int i = (lo & ~3) + 4 * tid; i < hi; i += 1024) {
+                const int4 s = *reinterpret_cast<const int4*>(cv.start + i);
+                const int4 e = *reinterpret_cast<const int4*>(cv.end + i);
+                const uchar4 q = *reinterpret_cast<const uchar4*>(cv.mapq + i);
+                const int ss[4] = {s.x, s.y, s.z, s.w}, ee[4] = {e.x, e.y, e.z, e.w}, qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int idx = i + j;
+                    if (idx >= lo && idx < hi) {
+                        int r = pred(cv, idx, ss[j], ee[j], qq[j], ws, we, w);
+                        a1 += (r == 1);
+                        a2 += (r == 2);
+                    }
+                }
+            }
+        }
+        // flush this window's partial sums
+        a1 = wave_reduce_add(a1);
+        a2 = wave_reduce_add(a2);
+        if (lane == 0) { red[0][wv] = a1; red[1][wv] = a2; }
+        __syncthreads();
+        if (tid == 0) {
+            int t1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+            int t2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            if (t1) atomicAdd(reinterpret_cast<unsigned long long*>(out1 + w), (unsigned long long)t1);
+            if (out2 && t2) atomicAdd(reinterpret_cast<unsigned long long*>(out2 + w), (unsigned long long)t2);
+        }
+        __syncthreads();
+        a1 = 0; a2 = 0;
+    }
+}
+
+// zero the outputs of the windows the chunked path owns
+__global__ void zero_large_kernel(const uint32_t* nchunks, int n_win, int64_t* out1, int64_t* out2) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_win) return;
+    if (nchunks[w] != 0) {
+        out1[w] = 0;
+        if (out2) out2[w] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fragment-length histogram per window (frag/_frag_length.py:147-153)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hist_small_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
+                                                         int n_win, const int32_t* cand_lo, const int32_t* cand_hi,
+                                                         const uint32_t* nchunks, WinPred pred, int len_lo, int n_bins,
+                                                         uint32_t* hist_out, int64_t* overflow_out) {
+    extern __shared__ uint32_t lds_hist[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + wv;
+    if (w >= n_win) return;
+    if (nchunks[w] != 0) return;
+    const int lo = cand_lo[w], hi = cand_hi[w];
+    if (lo >= hi) { if (lane == 0) overflow_out[w] = 0; return; }
+    uint32_t* h = lds_hist + (size_t)wv * n_bins;
+    for (int b = lane; b < n_bins; b += 64) h[b] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int ws = ws_[w], we = we_[w];
+    int over = 0;
+    for (int i = (lo & ~3) + 4 * lane; i < hi; i += 256) {
+        const int4 s = *reinterpret_cast<const int4*>(cv.start + i);
+        const int4 e = *reinterpret_cast<const int4*>(cv.end + i);
+        const uchar4 q = *reinterpret_cast<const uchar4*>(cv.mapq + i);
+        const int ss[4] = {s.x, s.y, s.z, s.w}, ee[4] = {e.x, e.y, e.z, e.w}, qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int idx = i + j;
+            if (idx >= lo && idx < hi && pred(cv, idx, ss[j], ee[j], qq[j], ws, we, w)) {
+                int b = (ee[j] - ss[j]) - len_lo;
+                if (b >= 0 && b < n_bins) atomicAdd(&h[b], 1u); else ++over;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t* dst = hist_out + (size_t)w * n_bins;
+    for (int b = lane; b < n_bins; b += 64) {
+        uint32_t v = h[b];
+        if (v) dst[b] = v;
+    }
+    over = wave_reduce_add(over);
+    if (lane == 0) overflow_out[w] = over;
+}
+
+__global__ __launch_bounds__(256) void hist_large_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
+                                                         int n_win, const int32_t* cand_lo, const int32_t* cand_hi,
+                                                         const uint32_t* chunk_off, WinPred pred, int len_lo,
+                                                         int n_bins, uint32_t* hist_out, int64_t* overflow_out) {
+    extern __shared__ uint32_t lds_hist[];
+    __shared__ int red[4];
+    const uint32_t total = chunk_off[n_win];
+    const uint32_t c0 = (uint32_t)(((unsigned long long)total * blockIdx.x) / gridDim.x);
+    const uint32_t c1 = (uint32_t)(((unsigned long long)total * (blockIdx.x + 1)) / gridDim.x);
+    if (c0 >= c1) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int b = tid; b < n_bins; b += 256) lds_hist[b] = 0;
+    __syncthreads();
+    int w;
+    {
+        int lo = 0, hi = n_win;
+        while (hi - lo > 1) {
+            int m = (lo + hi) >> 1;
+            if (chunk_off[m] <= c0) lo = m; else hi = m;
+        }
+        w = lo;
+    }
+    int over = 0;
+    uint32_t c = c0;
+    while (c < c1) {
+        uint32_t w_first = chunk_off[w], w_next = chunk_off[w + 1];
+        if (c >= w_next) { ++w; continue; }
+        const int ws = ws_[w], we = we_[w];
+        const int wlo = cand_lo[w], whi = cand_hi[w];
+        const uint32_t c_end = min(c1, w_next);
+        for (; c < c_end; ++c) {
+            const int lo = wlo + (int)(c - w_first) * kChunk;
+            const int hi = min(lo + kChunk, whi);
+            for (int i = (lo & ~3) + 4 * tid; i < hi; i += 1024) {
+                const int4 s = *reinterpret_cast<const int4*>(cv.start + i);
+                const int4 e = *reinterpret_cast<const int4*>(cv.end + i);
+                const uchar4 q = *reinterpret_cast<const uchar4*>(cv.mapq + i);
+                const int ss[4] = {s.x, s.y, s.z, s.w}, ee[4] = {e.x, e.y, e.z, e.w}, qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int idx = i + j;
+                    if (idx >= lo && idx < hi && pred(cv, idx, ss[j], ee[j], qq[j], ws, we, w)) {
+                        int b = (ee[j] - ss[j]) - len_lo;
+                        if (b >= 0 && b < n_bins) atomicAdd(&lds_hist[b], 1u); else ++over;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t* dst = hist_out + (size_t)w * n_bins;
+        for (int b = tid; b < n_bins; b += 256) {
+            uint32_t v = lds_hist[b];
+            if (v) { atomicAdd(&dst[b], v); lds_hist[b] = 0; }
+        }
+        over = wave_reduce_add(over);
+        if (lane == 0) red[wv] = over;
+        __syncthreads();
+        if (tid == 0) {
+            int t = red[0] + red[1] + red[2] + red[3];
+            if (t) atomicAdd(reinterpret_cast<unsigned long long*>(overflow_out + w), (unsigned long long)t);
+        }
+        over = 0;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// WPS (frag/_wps.py:25-53,156-188): LDS difference array + LDS scan per tile
+// ---------------------------------------------------------------------------
+// Window of "virtual" position v is [v - hl, v + hr].  Even W: hl = W/2,
+// hr = W/2 - 1 and every base is its own virtual position.  Odd W = 2k+1:
+// numpy.rint rounds c -/+ W/2 half-to-even, which gives base c the symmetric
+// window (hl = hr = k) of v = c when (c - k) is even and of v = c - 1 when it
+// is odd.  A fragment [fs, fe) contributes -1 on [fs-hr, fs+hl] and
+// [fe-hr, fe+hl] (start / stop inside the window; one interval when they
+// touch or overlap) and +1 on [fs+hl+1, fe-hr-1] (spanning).
+__global__ __launch_bounds__(256) void wps_kernel(ContigView cv, WpsParams p, const int64_t* iv_start_,
+                                                  const int64_t* iv_stop_, const int64_t* out_off_,
+                                                  const int32_t* tile_iv, const int32_t* tile_k,
+                                                  int64_t* __restrict__ out) {
+    constexpr int T = kWpsTile;
+    __shared__ int d[T];
+    __shared__ int pre_s;       // sum of events left of the tile
+    __shared__ int rng[2];      // candidate fragment range
+    __shared__ int wtot[4][4];  // [pass][wave] totals
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    long long iv_start, iv_stop, out_off, k;
+    if (tile_iv) {
+        int iv = tile_iv[blockIdx.x];
+        iv_start = iv_start_[iv]; iv_stop = iv_stop_[iv]; out_off = out_off_[iv];
+        k = tile_k[blockIdx.x];
+    } else {
+        iv_start = p.start; iv_stop = p.stop; out_off = 0; k = blockIdx.x;
+    }
+    const long long t0 = iv_start + k * T;                   // first base of the tile
+    const long long t1 = min(t0 + (long long)T, iv_stop);    // one past the last base
+    const int len_t = (int)(t1 - t0);
+    // fetch window of the interval (frag/_wps.py:156-157)
+    long long fmin = iv_start - p.max_len; if (fmin < 0) fmin = 0;
+    long long fmax = iv_stop + p.max_len; if (fmax > p.chrom_size) fmax = p.chrom_size;
+
+    const int hl = p.hl, hr = p.hr;
+    if (tid < 2) {
+        // candidates: fs - hr <= t1 - 1 and fe + hl >= t0 - 1  (=> fs >= t0 - 1 - hl - lmax)
+        long long q = (tid == 0) ? (t0 - 1 - hl - (long long)p.lmax) : (t1 + hr);
+        rng[tid] = lower_bound_start(cv, q);
+    }
+    if (tid == 2) pre_s = 0;
+    {
+        int4 z = make_int4(0, 0, 0, 0);
+        int4* d4 = reinterpret_cast<int4*>(d);
+#pragma unroll
+        for (int j = 0; j < T / 4 / 256; ++j) d4[j * 256 + tid] = z;
+    }
+    __syncthreads();
+    const int lo = rng[0], hi = rng[1];
+    for (int i = lo + tid; i < hi; i += 256) {
+        const int fs = cv.start[i], fe = cv.end[i], q = cv.mapq[i];
+        const int len = fe - fs;
+        const long long mid = ((long long)fs + (long long)fe) >> 1;
+        if (q < p.mapq_min || len < p.min_len || len > p.max_len || mid < fmin || mid >= fmax) continue;
+        if (cv.r1_start) {  // BAM: the fetch returns read1 alignments overlapping [fmin, fmax)
+            if (!((long long)cv.r1_start[i] < fmax && (long long)cv.r1_end[i] > fmin)) continue;
+        } else if (!((long long)fs < fmax && (long long)fe > fmin)) {
+            continue;
+        }
+        // event positions relative to t0
+        const long long a = (long long)fs - hr - t0;
+        const long long b = (long long)fs + hl + 1 - t0;
+        const long long c = (long long)fe - hr - t0;
+        const long long e = (long long)fe + hl + 1 - t0;
+        if (e <= -1 || a >= len_t) continue;  // no effect on [t0 - 1, t1)
+        if (c >= b) {
+            if (a < 0) atomicAdd(&pre_s, -1); else if (a < T) atomicAdd(&d[a], -1);
+            if (b < 0) atomicAdd(&pre_s, 2); else if (b < T) atomicAdd(&d[b], 2);
+            if (c < 0) atomicAdd(&pre_s, -2); else if (c < T) atomicAdd(&d[c], -2);
+            if (e < 0) atomicAdd(&pre_s, 1); else if (e < T) atomicAdd(&d[e], 1);
+        } else {
+            if (a < 0) atomicAdd(&pre_s, -1); else if (a < T) atomicAdd(&d[a], -1);
+            if (e < 0) atomicAdd(&pre_s, 1); else if (e < T) atomicAdd(&d[e], 1);
+        }
+    }
+    __syncthreads();
+
+    // scan: pass j covers d[1024 j .. 1024 j + 1023]; wave wv 256 of them, 4 per lane
+    constexpr int NP = T / 1024;
+    int4 v[NP];
+    int incl[NP];
+    const int4* d4 = reinterpret_cast<const int4*>(d);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        v[j] = d4[j * 256 + tid];
+        int x = v[j].x + v[j].y + v[j].z + v[j].w;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            int y = __shfl_up(x, s, 64);
+            if (lane >= s) x += y;
+        }
+        incl[j] = x;
+        if (lane == 63) wtot[j][wv] = x;
+    }
+    __syncthreads();
+    int base = pre_s;
+    int64_t* dst = out + out_off + k * T;
+    const int odd = p.odd, kk = p.hl;  // for odd W, hl == k
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        // carry of everything before (pass j, wave wv)
+        int carry = base;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+            int t = wtot[j][w2];
+            if (w2 < wv) carry += t;
+            base += t;
+        }
+        const int sum4 = v[j].x + v[j].y + v[j].z + v[j].w;
+        const int ex = carry + incl[j] - sum4;  // G(position before this lane's first)
+        const int g0 = ex + v[j].x, g1 = g0 + v[j].y, g2 = g1 + v[j].z, g3 = g2 + v[j].w;
+        const int i0 = j * 1024 + tid * 4;
+        long long o0 = g0, o1 = g1, o2 = g2, o3 = g3;
+        if (odd) {
+            // base c uses virtual position c - ((c - k) & 1)
+            const long long c0 = t0 + i0;
+            if ((c0 - kk) & 1) { o0 = ex; o2 = g1; } else { o1 = g0; o3 = g2; }
+        }
+        if (i0 + 3 < len_t) {
+            longlong2* q2 = reinterpret_cast<longlong2*>(dst + i0);
+            if ((reinterpret_cast<uintptr_t>(q2) & 15) == 0) {
+                q2[0] = make_longlong2(o0, o1);
+                q2[1] = make_longlong2(o2, o3);
+            } else {
+                dst[i0] = o0; dst[i0 + 1] = o1; dst[i0 + 2] = o2; dst[i0 + 3] = o3;
+            }
+        } else {
+            if (i0 < len_t) dst[i0] = o0;
+            if (i0 + 1 < len_t) dst[i0 + 1] = o1;
+            if (i0 + 2 < len_t) dst[i0 + 2] = o2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// ordered selection of one window's fragments (frag_length / frag_array)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_count_kernel(ContigView cv, int lo, int hi, int ws, int we,
+                                                           WinPred pred, uint32_t* block_cnt) {
+    __shared__ int red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = lo + blockIdx.x * 256 + tid;
+    int f = 0;
+    if (i < hi) f = pred(cv, i, cv.start[i], cv.end[i], cv.mapq[i], ws, we, 0);
+    int c = wave_reduce_add(f);
+    if (lane == 0) red[wv] = c;
+    __syncthreads();
+    if (tid == 0) block_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void select_write_kernel(ContigView cv, int lo, int hi, int ws, int we,
+                                                           WinPred pred, const uint32_t* block_off, int64_t cap,
+                                                           int32_t* len_out, int32_t* start_out, int32_t* end_out,
+                                                           uint8_t* mapq_out, uint8_t* strand_out) {
+    __shared__ int wtot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = lo + blockIdx.x * 256 + tid;
+    int f = 0, fs = 0, fe = 0, q = 0;
+    if (i < hi) {
+        fs = cv.start[i]; fe = cv.end[i]; q = cv.mapq[i];
+        f = pred(cv, i, fs, fe, q, ws, we, 0);
+    }
+    unsigned long long m = __ballot(f);
+    int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[wv] = __popcll(m);
+    __syncthreads();
+    int64_t off = block_off[blockIdx.x];
+    for (int j = 0; j < wv; ++j) off += wtot[j];
+    off += rank;
+    if (f && off < cap) {
+        if (len_out) len_out[off] = fe - fs;
+        if (start_out) start_out[off] = fs;
+        if (end_out) end_out[off] = fe;
+        if (mapq_out) mapq_out[off] = (uint8_t)q;
+        if (strand_out) strand_out[off] = cv.strand[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------
+void launch_stats(hipStream_t s, const int32_t* start, const int32_t* end, int n, FragStats* st) {
+    int blocks = min(2048, max(1, (n + 255) / 256));
+    hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, s, start, end, n, st);
+}
+
+void launch_bin_index(hipStream_t s, const int32_t* start, int n, int n_bins, int32_t* idx) {
+    int threads = n_bins + 1;
+    hipLaunchKernelGGL(bin_index_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, start, n, n_bins, idx);
+}
+
+void launch_plan(hipStream_t s, const ContigView& cv, const int32_t* ws, const int32_t* we, int n_win, int lmax,
+                 int small_max, const WindowPlan& pl) {
+    hipLaunchKernelGGL(bounds_kernel, dim3((n_win + 255) / 256), dim3(256), 0, s, cv, ws, we, n_win, lmax, small_max,
+                       pl.cand_lo, pl.cand_hi, pl.nchunks);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, pl.nchunks, n_win, pl.chunk_off);
+}
+
+template <class Pred>
+static void launch_count_t(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
+                           int n_win, const WindowPlan& pl, const Pred& pred, int64_t* out1, int64_t* out2) {
+    hipLaunchKernelGGL(zero_large_kernel, dim3((n_win + 255) / 256), dim3(256), 0, s, pl.nchunks, n_win, out1, out2);
+    hipLaunchKernelGGL(count_small_kernel<Pred>, dim3((n_win + 3) / 4), dim3(256), 0, s, cv, ws, we, n_win,
+                       pl.cand_lo, pl.cand_hi, pl.nchunks, pred, out1, out2);
+    hipLaunchKernelGGL(count_large_kernel<Pred>, dim3(grid_large), dim3(256), 0, s, cv, ws, we, n_win, pl.cand_lo,
+                       pl.cand_hi, pl.chunk_off, pred, out1, out2);
+}
+
+void launch_window_counts(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
+                          int n_win, const WindowPlan& pl, const ftk_filter& f, int64_t* out) {
+    WinPred pred{f.mapq_min, f.min_len < 0 ? INT32_MIN : f.min_len, f.max_len < 0 ? INT32_MAX : f.max_len, f.policy,
+                 f.fetch_mode == FTK_FETCH_BAM_READ1};
+    launch_count_t(s, grid_large, cv, ws, we, n_win, pl, pred, out, nullptr);
+}
+
+void launch_delfi_counts(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
+                         int n_win, const WindowPlan& pl, int mapq_min, int bam, const ftk_gaps& g,
+                         const int32_t* bl_off, const int32_t* bl_r0, const int32_t* bl_pm, int64_t* short_out,
+                         int64_t* long_out) {
+    DelfiPred pred{mapq_min, bam, g, bl_off, bl_r0, bl_pm};
+    launch_count_t(s, grid_large, cv, ws, we, n_win, pl, pred, short_out, long_out);
+}
+
+void launch_fraglen_hist(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
+                         int n_win, const WindowPlan& pl, const ftk_filter& f, int len_lo, int n_bins,
+                         uint32_t* hist_out, int64_t* overflow_out) {
+    WinPred pred{f.mapq_min, f.min_len < 0 ? INT32_MIN : f.min_len, f.max_len < 0 ? INT32_MAX : f.max_len, f.policy,
+                 f.fetch_mode == FTK_FETCH_BAM_READ1};
+    // hist_out and overflow_out were zeroed by the caller (hipMemsetAsync on s)
+    if (n_bins <= kHistSmallMaxBins) {
+        hipLaunchKernelGGL(hist_small_kernel, dim3((n_win + 3) / 4), dim3(256), (size_t)4 * n_bins * sizeof(uint32_t),
+                           s, cv, ws, we, n_win, pl.cand_lo, pl.cand_hi, pl.nchunks, pred, len_lo, n_bins, hist_out,
+                           overflow_out);
+    }
+    hipLaunchKernelGGL(hist_large_kernel, dim3(grid_large), dim3(256), (size_t)n_bins * sizeof(uint32_t), s, cv, ws,
+                       we, n_win, pl.cand_lo, pl.cand_hi, pl.chunk_off, pred, len_lo, n_bins, hist_out, overflow_out);
+}
+
+void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t n_tiles, const int64_t* iv_start,
+                const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv, const int32_t* tile_k,
+                int64_t* out) {
+    if (n_tiles <= 0) return;
+    hipLaunchKernelGGL(wps_kernel, dim3((unsigned)n_tiles), dim3(256), 0, s, cv, p, iv_start, iv_stop, out_off,
+                       tile_iv, tile_k, out);
+}
+
+void launch_select_count(hipStream_t s, const ContigView& cv, int lo, int hi, int ws, int we, const ftk_filter& f,
+                         uint32_t* block_cnt) {
+    WinPred pred{f.mapq_min, f.min_len < 0 ? INT32_MIN : f.min_len, f.max_len < 0 ? INT32_MAX : f.max_len, f.policy,
+                 f.fetch_mode == FTK_FETCH_BAM_READ1};
+    int nb = (hi - lo + 255) / 256;
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(select_count_kernel, dim3(nb), dim3(256), 0, s, cv, lo, hi, ws, we, pred, block_cnt);
+}
+
+void launch_scan_u32(hipStream_t s, const uint32_t* in, int n, uint32_t* off) {
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, in, n, off);
+}
+
+void launch_select_write(hipStream_t s, const ContigView& cv, int lo, int hi, int ws, int we, const ftk_filter& f,
+                         const uint32_t* block_off, int64_t cap, int32_t* len_out, int32_t* start_out,
+                         int32_t* end_out, uint8_t* mapq_out, uint8_t* strand_out) {
+    WinPred pred{f.mapq_min, f.min_len < 0 ? INT32_MIN : f.min_len, f.max_len < 0 ? INT32_MAX : f.max_len, f.policy,
+                 f.fetch_mode == FTK_FETCH_BAM_READ1};
+    int nb = (hi - lo + 255) / 256;
+    if (nb <= 0) return;
+    hipLaunchKernelGGL(select_write_kernel, dim3(nb), dim3(256), 0, s, cv, lo, hi, ws, we, pred, block_off, cap,
+                       len_out, start_out, end_out, mapq_out, strand_out);
+}
+
+}  // namespace ftk

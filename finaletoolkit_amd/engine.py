@@ -1,0 +1,230 @@
+"""
+``Engine``: one MI355X context holding fragments resident in HBM and running
+the per-window kernels through the C ABI (``include/ftk.h``).
+
+This is the host-side object the ``finaletoolkit_amd.frag`` functions drive.
+It replaces the reference's "open the file per window, stream Python tuples"
+feeder (``utils/_frag_generator.py:112-130``) by "decode once, keep the SoA in
+HBM, answer every window in one launch".
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _win(values, open_value):
+    if isinstance(values, np.ndarray) and values.dtype == np.int32:
+        return np.ascontiguousarray(values)
+    return np.ascontiguousarray([open_value if v is None else int(v) for v in values], dtype=np.int32)
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        self.lib = L.load()
+        ctx = C.c_void_p()
+        rc = self.lib.ftk_ctx_create(int(device), C.byref(ctx))
+        if rc != L.FTK_OK:
+            raise L.FtkError(rc, self.lib.ftk_last_error(None).decode())
+        self.ctx = ctx
+        self.device = int(device)
+        self._ids: dict[str, int] = {}
+        self._bam: dict[str, bool] = {}
+
+    # -- plumbing -------------------------------------------------------------
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.ftk_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != L.FTK_OK:
+            raise L.FtkError(rc, self.lib.ftk_last_error(self.ctx).decode())
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self._check(self.lib.ftk_ctx_set_stream(self.ctx, C.c_void_p(hip_stream or 0)))
+
+    def sync(self):
+        self._check(self.lib.ftk_ctx_sync(self.ctx))
+
+    def timer_start(self):
+        self._check(self.lib.ftk_timer_start(self.ctx))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._check(self.lib.ftk_timer_stop(self.ctx, C.byref(ms)))
+        return float(ms.value)
+
+    # -- fragments ------------------------------------------------------------
+    def contig_id(self, name: str) -> int:
+        if name not in self._ids:
+            raise KeyError(name)
+        return self._ids[name]
+
+    def has_contig(self, name: str) -> bool:
+        return name in self._ids
+
+    @property
+    def contigs(self):
+        return list(self._ids)
+
+    def is_bam(self, name: str) -> bool:
+        return self._bam.get(name, False)
+
+    def load_contig(self, name: str, start, end, mapq, strand=None, r1_start=None, r1_end=None):
+        """Upload one contig's start-sorted fragments (host numpy arrays)."""
+        start = np.ascontiguousarray(start, dtype=np.int32)
+        end = np.ascontiguousarray(end, dtype=np.int32)
+        mapq = np.ascontiguousarray(mapq, dtype=np.uint8)
+        strand = None if strand is None else np.ascontiguousarray(strand, dtype=np.uint8)
+        n = len(start)
+        if not (len(end) == n and len(mapq) == n and (strand is None or len(strand) == n)):
+            raise ValueError("fragment columns differ in length")
+        cid = self._ids.setdefault(name, len(self._ids))
+        self._check(self.lib.ftk_frags_from_host(self.ctx, cid, L.ptr(start), L.ptr(end), L.ptr(mapq),
+                                                 L.ptr(strand), n))
+        self._bam[name] = False
+        if r1_start is not None:
+            r1s = np.ascontiguousarray(r1_start, dtype=np.int32)
+            r1e = np.ascontiguousarray(r1_end, dtype=np.int32)
+            self._check(self.lib.ftk_frags_set_read1(self.ctx, cid, L.ptr(r1s), L.ptr(r1e), n))
+            self._bam[name] = True
+        return cid
+
+    def load_contig_device(self, name: str, d_start, d_end, d_mapq, d_strand, n: int):
+        """Adopt columns already in HBM (torch tensors or raw device addresses)."""
+        cid = self._ids.setdefault(name, len(self._ids))
+        self._check(self.lib.ftk_frags_from_device(self.ctx, cid, L.ptr(d_start), L.ptr(d_end), L.ptr(d_mapq),
+                                                   L.ptr(d_strand), int(n)))
+        self._bam[name] = False
+        return cid
+
+    def info(self, name: str):
+        n, ml, me = C.c_int64(), C.c_int32(), C.c_int32()
+        self._check(self.lib.ftk_frags_info(self.ctx, self.contig_id(name), C.byref(n), C.byref(ml), C.byref(me)))
+        return int(n.value), int(ml.value), int(me.value)
+
+    def release(self, name: str):
+        self._check(self.lib.ftk_frags_release(self.ctx, self._ids.pop(name)))
+        self._bam.pop(name, None)
+
+    def _filter(self, name, quality_threshold, min_length, max_length, intersect_policy):
+        return L.make_filter(quality_threshold, min_length, max_length, intersect_policy,
+                             L.FETCH_BAM_READ1 if self.is_bam(name) else L.FETCH_TABIX)
+
+    # -- features -------------------------------------------------------------
+    def window_counts(self, name: str, starts: Sequence, stops: Sequence, quality_threshold=30, min_length=None,
+                      max_length=None, intersect_policy="midpoint", out=None):
+        """a5: fragments per window (frag/_coverage.py:117-130)."""
+        ws, we = _win(starts, L.OPEN_LO), _win(stops, L.OPEN_HI)
+        f = self._filter(name, quality_threshold, min_length, max_length, intersect_policy)
+        res = np.zeros(len(ws), np.int64) if out is None else out
+        self._check(self.lib.ftk_window_counts(self.ctx, self.contig_id(name), L.ptr(ws), L.ptr(we), len(ws),
+                                               C.byref(f), L.ptr(res)))
+        return res
+
+    def delfi_counts(self, name: str, starts, stops, quality_threshold=30, bl_start=None, bl_end=None, gaps=None):
+        """a10: DELFI short/long/num_frags per window (frag/_delfi.py:443-472)."""
+        ws, we = _win(starts, L.OPEN_LO), _win(stops, L.OPEN_HI)
+        n_bl = 0 if bl_start is None else len(bl_start)
+        bs = None if n_bl == 0 else np.ascontiguousarray(bl_start, dtype=np.int32)
+        be = None if n_bl == 0 else np.ascontiguousarray(bl_end, dtype=np.int32)
+        g = L.make_gaps(gaps)
+        sh = np.zeros(len(ws), np.int64)
+        lg = np.zeros(len(ws), np.int64)
+        nf = np.zeros(len(ws), np.int64)
+        self._check(self.lib.ftk_delfi_counts(self.ctx, self.contig_id(name), L.ptr(ws), L.ptr(we), len(ws),
+                                              int(quality_threshold), L.ptr(bs), L.ptr(be), n_bl, C.byref(g),
+                                              L.ptr(sh), L.ptr(lg), L.ptr(nf)))
+        return sh, lg, nf
+
+    def fraglen_hist(self, name: str, starts, stops, len_lo: int, n_bins: int, quality_threshold=30,
+                     min_length=None, max_length=None, intersect_policy="midpoint"):
+        """a9: per-window length histogram (frag/_frag_length.py:147-153)."""
+        ws, we = _win(starts, L.OPEN_LO), _win(stops, L.OPEN_HI)
+        f = self._filter(name, quality_threshold, min_length, max_length, intersect_policy)
+        hist = np.zeros((len(ws), int(n_bins)), np.uint32)
+        over = np.zeros(len(ws), np.int64)
+        self._check(self.lib.ftk_fraglen_hist(self.ctx, self.contig_id(name), L.ptr(ws), L.ptr(we), len(ws),
+                                              C.byref(f), int(len_lo), int(n_bins), L.ptr(hist), L.ptr(over)))
+        return hist, over
+
+    def frag_lengths(self, name: str, start, stop, quality_threshold=30, min_length=None, max_length=None,
+                     intersect_policy="midpoint"):
+        """Lengths of one window's passing fragments in file order."""
+        ws = L.OPEN_LO if start is None else int(start)
+        we = L.OPEN_HI if stop is None else int(stop)
+        f = self._filter(name, quality_threshold, min_length, max_length, intersect_policy)
+        n = C.c_int64()
+        cid = self.contig_id(name)
+        cap = 1 << 16
+        while True:
+            out = np.zeros(cap, np.int32)
+            self._check(self.lib.ftk_frag_lengths(self.ctx, cid, ws, we, C.byref(f), L.ptr(out), cap, C.byref(n)))
+            if n.value <= cap:
+                return out[: n.value].copy()
+            cap = int(n.value)
+
+    def frag_select(self, name: str, start, stop, quality_threshold=30, min_length=None, max_length=None,
+                    intersect_policy="midpoint"):
+        """(start, end, mapq, strand) of one window's passing fragments in file order."""
+        ws = L.OPEN_LO if start is None else int(start)
+        we = L.OPEN_HI if stop is None else int(stop)
+        f = self._filter(name, quality_threshold, min_length, max_length, intersect_policy)
+        n = C.c_int64()
+        cid = self.contig_id(name)
+        cap = 1 << 16
+        while True:
+            s = np.zeros(cap, np.int32)
+            e = np.zeros(cap, np.int32)
+            q = np.zeros(cap, np.uint8)
+            st = np.zeros(cap, np.uint8)
+            self._check(self.lib.ftk_frag_select(self.ctx, cid, ws, we, C.byref(f), L.ptr(s), L.ptr(e), L.ptr(q),
+                                                 L.ptr(st), cap, C.byref(n)))
+            if n.value <= cap:
+                k = n.value
+                return s[:k].copy(), e[:k].copy(), q[:k].copy(), st[:k].copy()
+            cap = int(n.value)
+
+    def wps(self, name: str, start: int, stop: int, chrom_size: int, window_size=120, min_length=120,
+            max_length=180, quality_threshold=30, out=None):
+        """a7: WPS per base of [start, stop) (frag/_wps.py:156-188)."""
+        n_pos = max(int(stop) - int(start), 0)
+        res = np.zeros(n_pos, np.int64) if out is None else out
+        self._check(self.lib.ftk_wps(self.ctx, self.contig_id(name), int(start), int(stop), int(chrom_size),
+                                     int(window_size), int(min_length), int(max_length), int(quality_threshold),
+                                     L.ptr(res)))
+        return res
+
+    def wps_intervals(self, name: str, starts, stops, chrom_size: int, window_size=120, min_length=120,
+                      max_length=180, quality_threshold=30):
+        """a8: WPS of many intervals of one contig in one launch; returns
+        (scores, offsets) with interval i at scores[offsets[i]:offsets[i+1]]."""
+        s = np.ascontiguousarray(starts, dtype=np.int64)
+        e = np.ascontiguousarray(stops, dtype=np.int64)
+        lens = np.maximum(e - s, 0)
+        offs = np.zeros(len(s) + 1, np.int64)
+        np.cumsum(lens, out=offs[1:])
+        out = np.zeros(int(offs[-1]), np.int64)
+        if len(s) and offs[-1] > 0:
+            self._check(self.lib.ftk_wps_intervals(self.ctx, self.contig_id(name), L.ptr(s), L.ptr(e), len(s),
+                                                   L.ptr(np.ascontiguousarray(offs[:-1])), int(chrom_size),
+                                                   int(window_size), int(min_length), int(max_length),
+                                                   int(quality_threshold), L.ptr(out)))
+        return out, offs

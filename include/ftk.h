@@ -1,0 +1,202 @@
+/*
+ * ftk.h -- C ABI of the MI355X fragment-feature engine (libftk_hip.so).
+ *
+ * This is the drop-in boundary for FinaleToolkit's per-window hot path.  The
+ * reference (epifluidlab/FinaleToolkit 1.1.0) is pure Python and has no FFI of
+ * its own; every entry point below names the reference loop it replaces
+ * (paths relative to the reference checkout, `src/finaletoolkit/...`).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.
+ *  - Every call returns an int: FTK_OK (0) or a negative FTK_ERR_* code.
+ *    ftk_last_error(ctx) returns a message owned by the library, valid until
+ *    the next call on that ctx (ctx may be NULL for context-less calls).
+ *  - One ftk_ctx per GPU.  A ctx is single-threaded (caller serialises);
+ *    different ctxs may be driven from different threads.
+ *  - Coordinates are 0-based half-open int32 (same as the reference's
+ *    Fragment record, io/alignment.py:25-54).  Fragments of one contig are
+ *    held as a start-sorted SoA (start i32, end i32, mapq u8, strand u8) in
+ *    HBM: 10 bytes per fragment.
+ *  - "in" pointers for windows/intervals and "out" pointers for results may be
+ *    host OR device pointers; the library detects which and copies only when
+ *    it has to.  Results are complete when the call returns for host
+ *    pointers; for device pointers they are ordered on the ctx stream
+ *    (ftk_ctx_sync / ftk_timer_stop to wait).
+ *  - There is NO CPU fallback inside this library: without a usable gfx950
+ *    device ftk_ctx_create fails with FTK_ERR_NO_DEVICE.
+ */
+#ifndef FTK_H
+#define FTK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FTK_OK 0
+#define FTK_ERR_INVALID (-1)   /* bad argument / out-of-domain input       */
+#define FTK_ERR_NO_DEVICE (-2) /* no usable HIP device                      */
+#define FTK_ERR_HIP (-3)       /* a HIP runtime call failed                 */
+#define FTK_ERR_OOM (-4)       /* host or device allocation failed          */
+#define FTK_ERR_IO (-5)        /* file could not be opened / read           */
+#define FTK_ERR_FORMAT (-6)    /* file is not BGZF/gzip fragment text or BAM */
+#define FTK_ERR_NO_CONTIG (-7) /* contig id / name not loaded               */
+#define FTK_ERR_UNSORTED (-8)  /* fragments not sorted by start             */
+
+/* Open window bounds (the reference's `start=None` / `stop=None`,
+ * utils/_frag_generator.py:35-50). */
+#define FTK_OPEN_LO INT32_MIN
+#define FTK_OPEN_HI INT32_MAX
+/* Open length bound (`min_length=None` / `max_length=None`,
+ * utils/_comparison.py:13-24). */
+#define FTK_LEN_OPEN (-1)
+
+#define FTK_POLICY_MIDPOINT 0 /* utils/_frag_generator.py:35-42 */
+#define FTK_POLICY_ANY 1      /* utils/_frag_generator.py:44-50 */
+
+#define FTK_FETCH_TABIX 0     /* io/alignment.py:270-302: rows overlapping the window */
+#define FTK_FETCH_BAM_READ1 1 /* io/alignment.py:242-268: read1 alignments overlapping the window */
+
+#define FTK_MAX_TELOMERES 8
+
+typedef struct ftk_ctx ftk_ctx;
+typedef struct ftk_fragtable ftk_fragtable;
+
+/* The shared per-fragment predicate of utils/_frag_generator.py:117-130 plus
+ * the mapq cut of io/alignment.py:291 / :60-71. */
+typedef struct ftk_filter {
+    int32_t mapq_min;   /* keep mapq >= mapq_min                               */
+    int32_t min_len;    /* keep len >= min_len; FTK_LEN_OPEN = no bound        */
+    int32_t max_len;    /* keep len <= max_len; FTK_LEN_OPEN = no bound        */
+    int32_t policy;     /* FTK_POLICY_*                                        */
+    int32_t fetch_mode; /* FTK_FETCH_*                                         */
+} ftk_filter;
+
+/* Per-contig centromere/telomere constants of genome/gaps.py:202-267
+ * (ContigGaps).  has_gaps == 0 means `contig_gaps is None`
+ * (frag/_delfi.py:416-428,464). */
+typedef struct ftk_gaps {
+    int32_t has_gaps;
+    int32_t cen_start, cen_stop;
+    int32_t n_telo;
+    int32_t telo_start[FTK_MAX_TELOMERES];
+    int32_t telo_stop[FTK_MAX_TELOMERES];
+} ftk_gaps;
+
+/* ---- library / device ---------------------------------------------------- */
+const char* ftk_version(void);
+int ftk_device_count(int* n_out);
+int ftk_ctx_create(int device_id, ftk_ctx** out);
+void ftk_ctx_destroy(ftk_ctx* ctx);
+const char* ftk_last_error(ftk_ctx* ctx);
+/* Launch on a caller-provided hipStream_t (e.g. torch's current stream);
+ * NULL restores the ctx's own stream. */
+int ftk_ctx_set_stream(ftk_ctx* ctx, void* hip_stream);
+int ftk_ctx_sync(ftk_ctx* ctx);
+/* HIP-event stopwatch on the ctx stream (used by bench.py for per-kernel
+ * durations).  ftk_timer_stop waits for the stop event. */
+int ftk_timer_start(ftk_ctx* ctx);
+int ftk_timer_stop(ftk_ctx* ctx, float* ms_out);
+
+/* ---- fragments: SoA residency in HBM -------------------------------------
+ * Replaces the per-window `AlignmentWrapper.fetch` re-open + Fragment tuple
+ * stream (io/alignment.py:217-302, utils/_frag_generator.py:112-116): one
+ * contig is decoded once and stays resident. */
+int ftk_frags_from_host(ftk_ctx* ctx, int contig_id, const int32_t* start, const int32_t* end,
+                        const uint8_t* mapq, const uint8_t* strand, int64_t n);
+/* Same, sources already in device memory (copied device-to-device into the
+ * library's padded SoA). */
+int ftk_frags_from_device(ftk_ctx* ctx, int contig_id, const int32_t* d_start, const int32_t* d_end,
+                          const uint8_t* d_mapq, const uint8_t* d_strand, int64_t n);
+/* BAM only: read1 alignment span per fragment, needed for FTK_FETCH_BAM_READ1
+ * (io/alignment.py:245: pysam fetch returns read1 alignments overlapping the
+ * window).  Arrays are parallel to the fragment arrays. */
+int ftk_frags_set_read1(ftk_ctx* ctx, int contig_id, const int32_t* r1_start, const int32_t* r1_end, int64_t n);
+int ftk_frags_info(ftk_ctx* ctx, int contig_id, int64_t* n_out, int32_t* max_len_out, int32_t* max_end_out);
+int ftk_frags_release(ftk_ctx* ctx, int contig_id);
+
+/* ---- fragment-file decoder (host only; no ctx / GPU needed) ---------------
+ * io/alignment.py:270-302 (_fetch_tabix): BGZF/gzip text rows -> fragments.
+ * Column layout: FinaleDB `chrom start stop mapq strand`; BED6 when the first
+ * data row has > 5 columns (io/alignment.py:143-156) -> mapq = col 4, strand =
+ * col 5.  Rows that do not parse are skipped (io/alignment.py:301-302).  No
+ * mapq filtering here: mapq is a column, the cut is applied by the kernels.
+ * io/alignment.py:242-268 (_fetch_sam): BAM records -> fragments (flag filter,
+ * read1 only, TLEN reconstruction); rows sorted by fragment start. */
+int ftk_fragfile_decode(const char* path, const char* contig /* NULL = all */, int n_threads, ftk_fragtable** out);
+int ftk_bam_decode(const char* path, const char* contig /* NULL = all */, int n_threads, ftk_fragtable** out);
+const char* ftk_fragtable_error(void); /* message for a failed decode call (thread-local) */
+int ftk_fragtable_is_bed6(const ftk_fragtable* t);
+int ftk_fragtable_n_contigs(const ftk_fragtable* t);
+const char* ftk_fragtable_contig_name(const ftk_fragtable* t, int i);
+int64_t ftk_fragtable_contig_length(const ftk_fragtable* t, int i); /* BAM @SQ LN, -1 for text */
+int64_t ftk_fragtable_contig_rows(const ftk_fragtable* t, int i);
+int ftk_fragtable_columns(const ftk_fragtable* t, int i, const int32_t** start, const int32_t** end,
+                          const uint8_t** mapq, const uint8_t** strand,
+                          const int32_t** r1_start /* NULL for text */, const int32_t** r1_end);
+void ftk_fragtable_free(ftk_fragtable* t);
+
+/* ---- a5: coverage --------------------------------------------------------
+ * frag/_coverage.py:117-130 (`for _ in frags: coverage += 1`) over
+ * utils/_frag_generator.py:117-130, for n_win windows of one contig at once.
+ * Windows may overlap and come in any order.  count_out[i] = number of
+ * fragments passing `f` for window i. */
+int ftk_window_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                      const ftk_filter* f, int64_t* count_out);
+
+/* ---- a10/a11: DELFI short/long counts ------------------------------------
+ * frag/_delfi.py:443-472 per window: mapq >= mapq_min, 100 <= len <= 220,
+ * midpoint in [w_start, w_end), not inside a blacklist region that lies fully
+ * inside the window (frag/_delfi.py:110-126,455-462), not
+ * ContigGaps.in_tcmere (genome/gaps.py:217-237; note the all() over
+ * telomeres); len >= 151 -> long, else short; nfrag = short + long.
+ * bl_start/bl_end: the contig's blacklist, sorted by (start, stop)
+ * (frag/_delfi.py:85-107); may be NULL when n_bl == 0.  The window-level
+ * NOARM gate (frag/_delfi.py:423-428) is the caller's. */
+int ftk_delfi_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                     int32_t mapq_min, const int32_t* bl_start, const int32_t* bl_end, int64_t n_bl,
+                     const ftk_gaps* gaps, int64_t* short_out, int64_t* long_out, int64_t* nfrag_out);
+
+/* ---- a9: fragment-length histogram per window -----------------------------
+ * frag/_frag_length.py:147-153 (_distribution_from_gen) for n_win windows:
+ * hist_out[i * n_bins + (len - len_lo)] counts fragments of window i passing
+ * `f`; lengths outside [len_lo, len_lo + n_bins) are tallied in
+ * overflow_out[i].  The statistics of frag/_frag_length.py:175-238 are host
+ * arithmetic on these histograms. */
+int ftk_fraglen_hist(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                     const ftk_filter* f, int32_t len_lo, int32_t n_bins, uint32_t* hist_out, int64_t* overflow_out);
+
+/* frag/_frag_length.py:290-305 (frag_length): lengths of the fragments of ONE
+ * window passing `f`, in file order.  Writes at most cap values to len_out
+ * and always the true count to n_out. */
+int ftk_frag_lengths(ftk_ctx* ctx, int contig_id, int32_t w_start, int32_t w_end, const ftk_filter* f,
+                     int32_t* len_out, int64_t cap, int64_t* n_out);
+
+/* utils/utils.py:186-255 (frag_array) / utils/_frag_generator.py:58-141: the
+ * passing fragments of ONE window in file order (any column pointer may be
+ * NULL). */
+int ftk_frag_select(ftk_ctx* ctx, int contig_id, int32_t w_start, int32_t w_end, const ftk_filter* f,
+                    int32_t* start_out, int32_t* end_out, uint8_t* mapq_out, uint8_t* strand_out, int64_t cap,
+                    int64_t* n_out);
+
+/* ---- a7/a8: Windowed Protection Score --------------------------------------
+ * frag/_wps.py:25-53,156-188 for every base c in [start, stop):
+ *   ws = rint(c - W/2), we = rint(c + W/2 - 1)   (numpy rint: half to even)
+ *   WPS(c) = #{fs < ws and fe > we} - #{ws <= fs <= we or ws <= fe <= we}
+ * over the fragments with mapq >= mapq_min, min_len <= len <= max_len whose
+ * midpoint lies in [max(start - max_len, 0), min(stop + max_len, chrom_size))
+ * (frag/_wps.py:156-169).  wps_out has stop - start entries. */
+int ftk_wps(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t chrom_size, int32_t window_size,
+            int32_t min_len, int32_t max_len, int32_t mapq_min, int64_t* wps_out);
+/* frag/_multi_wps.py:196-198: the same for n_iv intervals of one contig in
+ * one launch; interval i writes iv_stop[i] - iv_start[i] values at
+ * wps_out + out_offset[i].  iv_* / out_offset are host arrays. */
+int ftk_wps_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start, const int64_t* iv_stop, int64_t n_iv,
+                      const int64_t* out_offset, int64_t chrom_size, int32_t window_size, int32_t min_len,
+                      int32_t max_len, int32_t mapq_min, int64_t* wps_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FTK_H */

@@ -1,0 +1,116 @@
+"""
+TEST INFRASTRUCTURE ONLY -- never imported by the product path.
+
+Stand-in modules that let the *reference* package (``/root/reference/src``)
+be imported in the build container, where its compiled third-party
+dependencies (pysam, numba, pyBigWig, py2bit, loess) are absent.  Used only by
+``oracle/gen_golden.py`` to emit golden vectors and by
+``oracle/check_against_reference.py`` to validate the restatement.  Nothing
+here travels to the GPU box as a dependency of any test: the reference source
+is not in this repository and ``/root/reference`` does not exist there.
+
+The tabix stand-in implements the documented htslib region semantics the
+reference relies on (``src/finaletoolkit/io/alignment.py:270-302``):
+
+* rows are returned in file order as tuples of *strings* (``asTuple``),
+* a region query ``(reference, start, end)`` returns rows of that contig with
+  ``row.start < end and row.end > start`` (bounds ``None`` = open),
+* ``reference=None`` iterates the whole file and ignores ``start``/``end``
+  (pysam builds no region string without a reference),
+* lines starting with the meta character ``#`` are skipped.
+"""
+from __future__ import annotations
+
+import gzip
+import sys
+import types
+
+REFERENCE_SRC = "/root/reference/src"
+
+
+class _TabixFile:
+    def __init__(self, filename, *args, **kwargs):
+        self.filename = str(filename)
+        self._rows = []
+        with gzip.open(self.filename, "rt") as fh:
+            for line in fh:
+                if not line.strip() or line.startswith("#"):
+                    continue
+                self._rows.append(tuple(line.rstrip("\n").split("\t")))
+        seen = []
+        for row in self._rows:
+            if row[0] not in seen:
+                seen.append(row[0])
+        self.contigs = seen
+
+    def fetch(self, reference=None, start=None, end=None, region=None,
+              parser=None, multiple_iterators=False):
+        for row in self._rows:
+            if reference is not None:
+                if row[0] != reference:
+                    continue
+                try:
+                    r_start = int(row[1])
+                    r_end = int(row[2])
+                except (ValueError, IndexError):
+                    # htslib would have failed to index such a row; hand it on
+                    # so the caller's own skip logic is exercised.
+                    yield row
+                    continue
+                if end is not None and not (r_start < end):
+                    continue
+                if start is not None and not (r_end > start):
+                    continue
+            yield row
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+class _Dummy:
+    def __init__(self, *a, **k):
+        raise RuntimeError("not available in the oracle stub")
+
+
+def install():
+    """Insert the stand-in modules and put the reference on ``sys.path``."""
+    if "pysam" not in sys.modules:
+        pysam = types.ModuleType("pysam")
+        pysam.TabixFile = _TabixFile
+        pysam.AlignmentFile = type("AlignmentFile", (_Dummy,), {})
+        pysam.AlignedSegment = type("AlignedSegment", (_Dummy,), {})
+        pysam.FastaFile = type("FastaFile", (_Dummy,), {})
+        pysam.asTuple = lambda *a, **k: None
+        pysam.faidx = lambda *a, **k: None
+        pysam.tabix_index = lambda *a, **k: None
+        sys.modules["pysam"] = pysam
+
+    if "numba" not in sys.modules:
+        numba = types.ModuleType("numba")
+
+        def jit(*jargs, **jkwargs):
+            if len(jargs) == 1 and callable(jargs[0]) and not jkwargs:
+                return jargs[0]
+            return lambda fn: fn
+
+        numba.jit = jit
+        numba.njit = jit
+        sys.modules["numba"] = numba
+
+    for name in ("pyBigWig", "py2bit", "loess"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    if "loess.loess_1d" not in sys.modules:
+        sub = types.ModuleType("loess.loess_1d")
+        sub.loess_1d = None
+        sys.modules["loess.loess_1d"] = sub
+        sys.modules["loess"].loess_1d = sub
+
+    if REFERENCE_SRC not in sys.path:
+        sys.path.insert(0, REFERENCE_SRC)

@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+DATA = os.path.join(ROOT, "tests", "data")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """One Engine (ftk_ctx) on device 0 for the GPU tests; fails loudly without the HIP library/GPU."""
+    from finaletoolkit_amd.engine import Engine
+    eng = Engine(0)
+    yield eng
+    eng.close()

@@ -1,0 +1,180 @@
+"""
+GPU parity: every kernel, through the C ABI, against the C oracle on the same
+seeded synthetic fragments.  Integer results must be bit-exact.
+"""
+import numpy as np
+import pytest
+
+from finaletoolkit_amd import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CONTIG_LEN = 3_000_000
+
+
+@pytest.fixture(scope="module")
+def data(engine):
+    s, e, q, st = synth.synth_contig(CONTIG_LEN, depth=30.0, seed=7)
+    # sprinkle short (< 120) and very short fragments so every WPS branch is hit
+    engine.load_contig("synA", s, e, q, st)
+    return dict(s=s, e=e, q=q, st=st, fr=O.Frags(s, e, q, st))
+
+
+def _window_sets(rng):
+    sets = {}
+    sets["tile100k"] = synth.tiling_windows(CONTIG_LEN, 100_000)
+    sets["tile400"] = tuple(a[:5000] for a in synth.tiling_windows(CONTIG_LEN, 400))
+    ws = rng.integers(0, CONTIG_LEN - 10, 700).astype(np.int32)
+    we = (ws + rng.integers(1, 250_000, 700)).astype(np.int32)
+    sets["random_overlapping"] = (ws, we)
+    # degenerate / malformed / open-ended windows
+    ws = np.array([0, 500, 1000, 2_999_000, 100, O.OPEN_LO, 5000, O.OPEN_LO], np.int32)
+    we = np.array([CONTIG_LEN, 500, 900, 4_000_000, 101, 70_000, O.OPEN_HI, O.OPEN_HI], np.int32)
+    sets["edge"] = (ws, we)
+    sets["one_big"] = (np.array([0], np.int32), np.array([CONTIG_LEN], np.int32))
+    return sets
+
+
+@pytest.mark.parametrize("policy", ["midpoint", "any"])
+@pytest.mark.parametrize("flt", [dict(mapq_min=30), dict(mapq_min=0, min_len=120, max_len=180),
+                                 dict(mapq_min=60, min_len=None, max_len=150), dict(mapq_min=10, min_len=300)])
+def test_window_counts(engine, data, policy, flt):
+    rng = np.random.default_rng(11)
+    for name, (ws, we) in _window_sets(rng).items():
+        want = O.c_window_counts(data["fr"], ws, we, policy=policy, **flt)
+        got = engine.window_counts("synA", ws, we, quality_threshold=flt["mapq_min"],
+                                   min_length=flt.get("min_len"), max_length=flt.get("max_len"),
+                                   intersect_policy=policy)
+        assert np.array_equal(got, want), (name, policy, flt)
+
+
+def test_window_counts_total_property(engine, data):
+    # tiling windows + midpoint: every passing fragment is counted exactly once
+    ws, we = synth.tiling_windows(CONTIG_LEN, 100_000)
+    got = engine.window_counts("synA", ws, we, quality_threshold=30)
+    assert got.sum() == int((data["q"] >= 30).sum())
+
+
+@pytest.mark.parametrize("n_bins,len_lo", [(1001, 0), (64, 150), (3000, 0)])
+def test_fraglen_hist(engine, data, n_bins, len_lo):
+    rng = np.random.default_rng(12)
+    for name, (ws, we) in _window_sets(rng).items():
+        if name == "tile400":
+            ws, we = ws[:800], we[:800]
+        want_h, want_o = O.c_fraglen_hist(data["fr"], ws, we, len_lo, n_bins, mapq_min=30)
+        got_h, got_o = engine.fraglen_hist("synA", ws, we, len_lo, n_bins, quality_threshold=30)
+        assert np.array_equal(got_h, want_h), name
+        assert np.array_equal(got_o, want_o), name
+
+
+def test_delfi_counts(engine, data):
+    rng = np.random.default_rng(13)
+    ws, we = synth.tiling_windows(CONTIG_LEN, 100_000)
+    we = (we - 1).astype(np.int32)  # the reference's inclusive-end bins used as exclusive stops
+    bl_s = np.sort(rng.integers(0, CONTIG_LEN - 6000, 400)).astype(np.int32)
+    bl_e = (bl_s + rng.integers(200, 5000, 400)).astype(np.int32)
+    order = np.lexsort((bl_e, bl_s))
+    bl_s, bl_e = bl_s[order], bl_e[order]
+    gaps = (1_200_000, 1_500_000, [(0, 10_000), (CONTIG_LEN - 10_000, CONTIG_LEN)])
+    for g in (None, gaps, (1_200_000, 1_500_000, []), (1_200_000, 1_500_000, [(0, 2_000_000)])):
+        for bl in ((None, None), (bl_s, bl_e)):
+            want = O.c_delfi_counts(data["fr"], ws, we, 30, bl[0], bl[1], g)
+            got = engine.delfi_counts("synA", ws, we, 30, bl[0], bl[1], g)
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b)
+    # small windows (wave-per-window path) with blacklist
+    ws2, we2 = synth.tiling_windows(300_000, 2_000)
+    want = O.c_delfi_counts(data["fr"], ws2, we2, 20, bl_s, bl_e, gaps)
+    got = engine.delfi_counts("synA", ws2, we2, 20, bl_s, bl_e, gaps)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("W,mn,mx", [(120, 120, 180), (120, 30, 400), (40, 30, 90), (121, 100, 200),
+                                     (75, 20, 500), (160, 120, 150), (2, 0, 1000), (1, 0, 1000)])
+def test_wps_intervals_vs_oracle(engine, data, W, mn, mx):
+    rng = np.random.default_rng(W)
+    ivs = [(0, 3000), (CONTIG_LEN - 2500, CONTIG_LEN), (1_000_000, 1_005_000), (4095, 4097), (8191, 12289)]
+    ivs += [(int(a), int(a) + int(l)) for a, l in zip(rng.integers(0, CONTIG_LEN - 6000, 6),
+                                                       rng.integers(1, 6000, 6))]
+    starts = [a for a, _ in ivs]
+    stops = [b for _, b in ivs]
+    got, offs = engine.wps_intervals("synA", starts, stops, CONTIG_LEN, W, mn, mx, 30)
+    for i, (a, b) in enumerate(ivs):
+        want = O.c_wps(data["fr"], a, b, CONTIG_LEN, W, mn, mx, 30)
+        assert np.array_equal(got[offs[i]:offs[i + 1]], want), (W, mn, mx, a, b)
+        single = engine.wps("synA", a, b, CONTIG_LEN, W, mn, mx, 30)
+        assert np.array_equal(single, want), ("single", W, mn, mx, a, b)
+
+
+def test_wps_chrom_size_clip_and_degenerate(engine, data):
+    # fetch window clipped by a chrom_size smaller than the data extent
+    want = O.c_wps(data["fr"], 990_000, 1_000_000, 1_000_050, 120, 120, 180, 0)
+    got = engine.wps("synA", 990_000, 1_000_000, 1_000_050, 120, 120, 180, 0)
+    assert np.array_equal(got, want)
+    assert len(engine.wps("synA", 500, 500, CONTIG_LEN)) == 0
+    assert len(engine.wps("synA", 600, 500, CONTIG_LEN)) == 0
+
+
+def test_wps_whole_contig_sum_property(engine, data):
+    # One call over the whole contig == tiled 5 kb calls (W <= max_len: the
+    # per-interval fetch cut cannot drop an influencing fragment).
+    whole = engine.wps("synA", 0, 200_000, CONTIG_LEN, 120, 120, 180, 30)
+    starts = list(range(0, 200_000, 5000))
+    tiled, offs = engine.wps_intervals("synA", starts, [s + 5000 for s in starts], CONTIG_LEN, 120, 120, 180, 30)
+    assert np.array_equal(whole, tiled)
+
+
+@pytest.mark.parametrize("policy", ["midpoint", "any"])
+def test_frag_select_and_lengths(engine, data, policy):
+    for (a, b) in [(100_000, 160_000), (None, 5000), (2_990_000, None), (7, 8), (None, None)]:
+        ws, we, wq, wst = O.c_frag_select(data["fr"], a, b, mapq_min=20, min_len=100, max_len=400, policy=policy)
+        gs, ge, gq, gst = engine.frag_select("synA", a, b, 20, 100, 400, policy)
+        assert np.array_equal(gs, ws) and np.array_equal(ge, we)
+        assert np.array_equal(gq, wq) and np.array_equal(gst, wst)
+        gl = engine.frag_lengths("synA", a, b, 20, 100, 400, policy)
+        assert np.array_equal(gl, we - ws)
+
+
+def test_bam_read1_fetch_mode(engine, data):
+    # synthesise read1 spans: forward -> read1 at the fragment start, reverse -> at its end
+    s, e, st = data["s"], data["e"], data["st"]
+    rl = np.minimum(e - s, 100)
+    r1s = np.where(st == 1, s, e - rl).astype(np.int32)
+    r1e = (r1s + rl).astype(np.int32)
+    engine.load_contig("synBAM", s, e, data["q"], st, r1s, r1e)
+    fr = O.Frags(s, e, data["q"], st, r1s, r1e)
+    rng = np.random.default_rng(5)
+    for name, (ws, we) in _window_sets(rng).items():
+        for policy in ("midpoint", "any"):
+            want = O.c_window_counts(fr, ws, we, mapq_min=30, policy=policy)
+            got = engine.window_counts("synBAM", ws, we, 30, None, None, policy)
+            assert np.array_equal(got, want), (name, policy)
+    want = O.c_wps(fr, 50_000, 58_000, CONTIG_LEN, 120, 120, 180, 30)
+    assert np.array_equal(engine.wps("synBAM", 50_000, 58_000, CONTIG_LEN, 120, 120, 180, 30), want)
+    ws, we = synth.tiling_windows(CONTIG_LEN, 100_000)
+    want = O.c_delfi_counts(fr, ws, we, 30, None, None, None)
+    got = engine.delfi_counts("synBAM", ws, we, 30)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    engine.release("synBAM")
+
+
+def test_empty_and_errors(engine):
+    from finaletoolkit_amd._lib import FtkError
+    z32 = np.zeros(0, np.int32)
+    z8 = np.zeros(0, np.uint8)
+    engine.load_contig("empty", z32, z32, z8, z8)
+    assert engine.window_counts("empty", [0, None], [100, None]).tolist() == [0, 0]
+    assert engine.wps("empty", 0, 300, 1000).tolist() == [0] * 300
+    h, o = engine.fraglen_hist("empty", [0], [10], 0, 10)
+    assert h.sum() == 0 and o.sum() == 0
+    with pytest.raises(FtkError) as ei:
+        engine.load_contig("bad", np.array([5, 3], np.int32), np.array([9, 9], np.int32),
+                           np.array([1, 1], np.uint8), np.array([1, 1], np.uint8))
+    assert ei.value.code == -8
+    with pytest.raises(FtkError):
+        engine.load_contig("bad2", np.array([5], np.int32), np.array([3], np.int32), np.array([1], np.uint8))
+    with pytest.raises(KeyError):
+        engine.window_counts("nope", [0], [1])
