@@ -1,0 +1,272 @@
+"""
+TEST INFRASTRUCTURE -- runs ONLY in the build container (needs /root/reference).
+
+Imports the reference package through oracle/refstub.py and records its
+outputs on (i) the reference's own 17-fragment fixture and (ii) a seeded
+synthetic two-contig fragment file, as small fixtures under tests/golden/:
+
+    tests/golden/synth.frag.gz(.tbi)   input rows (BGZF, written by this script)
+    tests/golden/synth_windows.bed     interval file used for coverage / stats
+    tests/golden/synth_sites.bed       site file used for multi_wps
+    tests/golden/golden.json           scalar / list outputs
+    tests/golden/golden.npz            array outputs (WPS vectors, ...)
+
+Usage:  python oracle/gen_golden.py
+"""
+from __future__ import annotations
+
+import gzip
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import refstub  # noqa: E402
+
+refstub.install()
+
+import finaletoolkit.frag as F  # noqa: E402  (the reference)
+import finaletoolkit.frag._delfi as RD  # noqa: E402
+from finaletoolkit.frag._frag_length import _find_median  # noqa: E402
+from finaletoolkit.genome.gaps import ContigGaps  # noqa: E402
+from finaletoolkit.io.alignment import AlignmentWrapper  # noqa: E402
+from finaletoolkit.utils import frag_array, frag_generator  # noqa: E402
+
+from finaletoolkit_amd import bgzf, synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(ROOT, "tests", "data")
+FIX = os.path.join(DATA, "12.3444.b37.frag.gz")
+FIX_BED6 = os.path.join(DATA, "12.3444.b37.frag.bed.gz")
+INTERVALS = os.path.join(DATA, "intervals.bed")
+
+CONTIGS = {"chrA": 400_000, "chrB": 150_000}
+
+
+def make_synth():
+    rows = []
+    cols = {}
+    for i, (name, size) in enumerate(CONTIGS.items()):
+        s, e, q, st = synth.synth_contig(size, depth=7.5, seed=4242 + i)
+        rng = np.random.default_rng(99 + i)
+        # make ~8 % of the fragments short (20..119 bp) so len < window_size paths are hit
+        pick = rng.random(len(s)) < 0.08
+        e = np.where(pick, s + rng.integers(20, 120, len(s)), e).astype(np.int32)
+        order = np.lexsort((e, s))
+        s, e, q, st = s[order], e[order], q[order], st[order]
+        rows.append((name, s, e, q, st))
+        cols[name] = (s, e, q, st)
+    path = os.path.join(GOLD, "synth.frag.gz")
+    bgzf.write_frag_gz(path, rows)
+    return path, cols
+
+
+def tup(x):
+    return [None if v is None else (v.item() if hasattr(v, "item") else v) for v in x]
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    warnings.simplefilter("ignore")
+    J = {}
+    A = {}
+
+    # ------------------------------------------------------------------ fixture
+    fx = {}
+    fx["frag_generator_all"] = [list(t) for t in frag_generator(FIX, "12", quality_threshold=0, min_length=0,
+                                                                max_length=9999)]
+    fx["frag_generator_bed6"] = [list(t) for t in frag_generator(FIX_BED6, "12", quality_threshold=0, min_length=0,
+                                                                 max_length=9999)]
+    fx["frag_generator_detail"] = [list(t) for t in frag_generator(FIX, contig="12", start=34443119, stop=34443538)]
+    fa = frag_array(FIX, "12", min_length=120, max_length=180)
+    fx["frag_array_120_180"] = [[int(r["start"]), int(r["stop"]), bool(r["strand"])] for r in fa]
+    cov = []
+    for (a, b, q, pol, mn, mx) in [(0, None, 0, "midpoint", None, None), (34443000, 34447000, 0, "midpoint", None, None),
+                                   (34443400, 34443600, 0, "midpoint", None, None),
+                                   (34443400, 34443600, 0, "any", None, None),
+                                   (34443400, 34443600, 30, "any", 150, 170),
+                                   (34445000, 34446000, 30, "midpoint", None, 160)]:
+        r = F.single_coverage(FIX, "12", a, b, quality_threshold=q, intersect_policy=pol, min_length=mn, max_length=mx)
+        cov.append(dict(start=a, stop=b, q=q, policy=pol, min_length=mn, max_length=mx, coverage=int(r.coverage)))
+    fx["single_coverage"] = cov
+    fx["coverage_raw"] = [list(r) for r in F.coverage(FIX, INTERVALS, None, normalize=False)]
+    fx["coverage_norm"] = [list(r) for r in F.coverage(FIX, INTERVALS, None, normalize=True)]
+    out_bed = os.path.join(GOLD, "_tmp_cov.bed")
+    F.coverage(FIX, INTERVALS, out_bed, normalize=True, scale_factor=1e6)
+    fx["coverage_norm_bed_text"] = open(out_bed).read()
+    out_bg = os.path.join(GOLD, "_tmp_cov.bedgraph")
+    F.coverage(FIX, INTERVALS, out_bg, normalize=False)
+    fx["coverage_bedgraph_text"] = open(out_bg).read()
+    os.remove(out_bed)
+    os.remove(out_bg)
+    fx["wps_145_155"] = F.wps(FIX, "12", 34444145, 34444155, 133851895, quality_threshold=0)["wps"].tolist()
+    w = F.wps(FIX, "12", 34443000, 34447000, 133851895, quality_threshold=0)
+    A["fixture_wps_34443000_34447000"] = w["wps"].astype(np.int64)
+    fx["frag_length"] = F.frag_length(FIX, contig="12", start=34443119, stop=34443538).tolist()
+    b, c = F.frag_length_bins(FIX, contig="12", start=34443119, stop=34443538)
+    fx["frag_length_bins"] = dict(bins=np.asarray(b).tolist(), counts=list(map(int, c)))
+    b, c = F.frag_length_bins(FIX, contig="12", bin_size=5, quality_threshold=0)
+    fx["frag_length_bins_bs5_q0"] = dict(bins=np.asarray(b).tolist(), counts=list(map(int, c)))
+    tsv = os.path.join(GOLD, "_tmp_bins.tsv")
+    F.frag_length_bins(FIX, contig="12", output_file=tsv, summary_stats=True, short_fraction=150)
+    fx["frag_length_bins_tsv_text"] = open(tsv).read()
+    os.remove(tsv)
+    fx["frag_length_intervals"] = [tup(r) for r in F.frag_length_intervals(FIX, INTERVALS)]
+    iv_out = os.path.join(GOLD, "_tmp_iv.bed")
+    F.frag_length_intervals(FIX, INTERVALS, output_file=iv_out, quality_threshold=0, short_reads=160)
+    fx["frag_length_intervals_bed_text"] = open(iv_out).read()
+    os.remove(iv_out)
+    fx["median_quirk"] = _find_median({121: 1, 137: 1, 147: 1, 152: 1, 161: 1, 170: 1, 205: 1})
+    J["fixture"] = fx
+
+    # ---------------------------------------------------------------- synthetic
+    path, cols = make_synth()
+    sy = {"contigs": CONTIGS}
+    rng = np.random.default_rng(2024)
+    # interval file: tiling + overlapping + unsorted windows on both contigs
+    wins = []
+    for name, size in CONTIGS.items():
+        for a in range(0, size, 25_000):
+            wins.append((name, a, min(a + 25_000, size), f"t{a}"))
+        for a, l in zip(rng.integers(0, size - 2000, 12), rng.integers(50, 60_000, 12)):
+            wins.append((name, int(a), int(min(a + l, size)), "."))
+    with open(os.path.join(GOLD, "synth_windows.bed"), "w") as fh:
+        fh.write("# synthetic windows\ntrack name=x\n")
+        for c, a, b, n in wins:
+            fh.write(f"{c}\t{a}\t{b}" + ("" if n == "." else f"\t{n}") + "\n")
+    wbed = os.path.join(GOLD, "synth_windows.bed")
+    covs = {}
+    for key, kw in {
+        "default": {},
+        "any_q0": dict(intersect_policy="any", quality_threshold=0),
+        "len_120_180": dict(min_length=120, max_length=180),
+        "q60_max150_any": dict(quality_threshold=60, max_length=150, intersect_policy="any"),
+        "min300": dict(min_length=300, quality_threshold=10),
+    }.items():
+        covs[key] = [list(r) for r in F.coverage(path, wbed, None, **kw)]
+    covs["normalized"] = [list(r) for r in F.coverage(path, wbed, None, normalize=True, scale_factor=1e6)]
+    sy["coverage"] = covs
+    sy["single_coverage_whole_chrA"] = int(F.single_coverage(path, "chrA", 0, None).coverage)
+    sy["single_coverage_whole_file"] = int(F.single_coverage(path, None, 0, None).coverage)
+    sy["frag_length_intervals"] = [tup(r) for r in F.frag_length_intervals(path, wbed)]
+    sy["frag_length_intervals_120_400_any"] = [tup(r) for r in F.frag_length_intervals(
+        path, wbed, min_length=120, max_length=400, intersect_policy="any", quality_threshold=0, short_reads=167)]
+    b, c = F.frag_length_bins(path, contig="chrA")
+    sy["frag_length_bins_chrA"] = dict(bins=np.asarray(b).tolist(), counts=list(map(int, c)))
+    b, c = F.frag_length_bins(path, contig="chrB", start=20_000, stop=90_000, bin_size=7, min_length=50, max_length=450)
+    sy["frag_length_bins_chrB_bs7"] = dict(bins=np.asarray(b).tolist(), counts=list(map(int, c)))
+    b, c = F.frag_length_bins(path)  # genome-wide
+    sy["frag_length_bins_genome"] = dict(bins=np.asarray(b).tolist(), counts=list(map(int, c)))
+    A["synth_frag_length_chrB_any"] = F.frag_length(path, contig="chrB", start=10_000, stop=30_000,
+                                                    intersect_policy="any", quality_threshold=0)
+    A["synth_frag_length_chrA_all"] = F.frag_length(path, contig="chrA")
+    fsel = list(frag_generator(path, "chrA", 20, 100_000, 130_000, 100, 400, "any"))
+    sy["frag_generator_chrA_any"] = [list(t) for t in fsel]
+
+    # WPS: intervals x parameter sets (incl. odd W, len < W, W > max_len, contig edges)
+    wps_cases = []
+    k = 0
+    for (W, mn, mx, q) in [(120, 120, 180, 30), (120, 30, 400, 0), (40, 30, 90, 30), (121, 100, 200, 30),
+                           (75, 20, 500, 10), (160, 120, 150, 30), (7, 0, 1000, 0)]:
+        for (c, a, b) in [("chrA", 0, 1500), ("chrA", 398_700, 400_000), ("chrA", 200_000, 202_500),
+                          ("chrB", 4000, 4300), ("chrB", 149_000, 150_000)]:
+            r = F.wps(path, c, a, b, CONTIGS[c], window_size=W, min_length=mn, max_length=mx, quality_threshold=q)
+            A[f"wps_{k}"] = r["wps"].astype(np.int64)
+            wps_cases.append(dict(key=f"wps_{k}", contig=c, start=a, stop=b, window_size=W, min_length=mn,
+                                  max_length=mx, quality_threshold=q))
+            k += 1
+    sy["wps_cases"] = wps_cases
+
+    # multi_wps -> bedGraph.gz (no pyBigWig needed for this writer)
+    sites = [("chrB", 100, 300), ("chrA", 50_000, 50_400), ("chrA", 52_000, 52_100), ("chrA", 399_900, 400_000),
+             ("chrB", 70_000, 70_010), ("chrZ", 5, 10)]
+    with open(os.path.join(GOLD, "synth_sites.bed"), "w") as fh:
+        for c, a, b in sites:
+            fh.write(f"{c}\t{a}\t{b}\n")
+    with open(os.path.join(GOLD, "synth.chrom.sizes"), "w") as fh:
+        for c, n in CONTIGS.items():
+            fh.write(f"{c}\t{n}\n")
+    mw_out = os.path.join(GOLD, "_tmp_mwps.bed.gz")
+    F.multi_wps(path, os.path.join(GOLD, "synth_sites.bed"), os.path.join(GOLD, "synth.chrom.sizes"), mw_out,
+                interval_size=3000)
+    rows = [l.split("\t") for l in gzip.open(mw_out, "rt").read().splitlines()]
+    os.remove(mw_out)
+    sy["multi_wps_contigs"] = [r[0] for r in rows[::500]]
+    A["multi_wps_pos"] = np.array([int(r[1]) for r in rows], np.int64)
+    A["multi_wps_val"] = np.array([int(r[3]) for r in rows], np.int64)
+    sy["multi_wps_rows"] = len(rows)
+    sy["multi_wps_contig_runs"] = []
+    prev = None
+    for r in rows:
+        if r[0] != prev:
+            sy["multi_wps_contig_runs"].append([r[0], 0])
+            prev = r[0]
+        sy["multi_wps_contig_runs"][-1][1] += 1
+
+    # DELFI per-window counts with blacklist + gaps (worker globals set by hand)
+    bl = {}
+    bl_rows = []
+    for i, (name, size) in enumerate(CONTIGS.items()):
+        r2 = np.random.default_rng(555 + i)
+        s0 = np.sort(r2.integers(0, size - 5000, 60))
+        e0 = s0 + r2.integers(150, 5000, 60)
+        regs = sorted(zip(s0.tolist(), e0.tolist()))
+        bl[name] = (np.array([r[0] for r in regs], np.int64), np.array([r[1] for r in regs], np.int64))
+        bl_rows += [(name, a, b) for a, b in regs]
+    with open(os.path.join(GOLD, "synth_blacklist.bed"), "w") as fh:
+        for c, a, b in bl_rows:
+            fh.write(f"{c}\t{a}\t{b}\n")
+    gaps = {"chrA": ContigGaps("chrA", (180_000, 230_000), [(0, 10_000), (390_000, 400_000)]),
+            "chrB": ContigGaps("chrB", (60_000, 80_000), [(0, 140_000)], has_short_arm=True)}
+    sy["gaps"] = {k2: dict(centromere=list(v.centromere), telomeres=[list(t) for t in v.telomeres],
+                           has_short_arm=v.has_short_arm) for k2, v in gaps.items()}
+
+    class _Ref:
+        chroms = dict(CONTIGS)
+
+        def sequence(self, contig, start, stop):
+            return "ACGT" * ((stop - start) // 4) + "G" * ((stop - start) % 4)
+
+    delfi_rows = []
+    for use_gaps in (True, False):
+        for use_bl in (True, False):
+            RD._WORKER_ALIGNMENT = AlignmentWrapper(path, quality_threshold=30)
+            RD._WORKER_REF = _Ref()
+            RD._WORKER_BLACKLIST = bl if use_bl else {}
+            RD._WORKER_CONTIG_GAPS = gaps if use_gaps else None
+            for name, size in CONTIGS.items():
+                for a in range(0, size, 10_000):
+                    b2 = a + 9_999
+                    r = RD._delfi_single_window(name, a, b2)
+                    delfi_rows.append(dict(gaps=use_gaps, blacklist=use_bl, contig=r[0], start=int(r[1]),
+                                           stop=int(r[2]), arm=r[3],
+                                           short=None if r[4] != r[4] else int(r[4]),
+                                           long=None if r[5] != r[5] else int(r[5]),
+                                           gc=None if r[6] != r[6] else float(r[6]), num_frags=int(r[7])))
+    sy["delfi_windows"] = delfi_rows
+    J["synth"] = sy
+
+    # delfi_merge_bins on the reference's CSV fixture, with and without the corrected columns
+    import pandas as pd
+    d100 = pd.read_csv(os.path.join(DATA, "delfi", "test_delfi_100kb.csv"), dtype={"contig": str, "start": int,
+                                                                                  "stop": int})
+    m = F.delfi_merge_bins(d100)
+    m.to_csv(os.path.join(GOLD, "delfi_merge_gc.csv"), index=False)
+    m2 = F.delfi_merge_bins(d100.drop(columns=[c for c in d100.columns if c.endswith("_corrected")]), gc_corrected=False)
+    m2.to_csv(os.path.join(GOLD, "delfi_merge_nogc.csv"), index=False)
+
+    with open(os.path.join(GOLD, "golden.json"), "w") as fh:
+        json.dump(J, fh, indent=0, sort_keys=True)
+    np.savez_compressed(os.path.join(GOLD, "golden.npz"), **A)
+    print("golden vectors written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()
