@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""
+bench.py -- genomic windows/sec (coverage + fragment-length histogram + DELFI +
+WPS) at 30x WGS on 1/2/4/8 MI355X.
+
+One "step" = one pass of the whole hot path over every 100 kb window of the
+rank's contigs: per-window coverage counts, per-window length histograms
+(1001 bins), DELFI short/long counts (blacklist + gap constants) and WPS for
+every base, followed by the all-gather of the DELFI bin vector (N > 1).
+Fragments are synthetic (seeded, BASELINE.md section 4 distribution), generated
+on the device and resident in HBM before the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W [--depth 30] [--contigs 1,2,...]
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from finaletoolkit_amd import synth  # noqa: E402
+
+WINDOW = 100_000
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HIST_BINS = 1001
+WPS_W, WPS_MIN, WPS_MAX, MAPQ = 120, 120, 180, 30
+
+
+def lpt_assign(sizes: dict, n_ranks: int):
+    """Longest-processing-time greedy: contigs -> ranks."""
+    loads = [0] * n_ranks
+    owner = {}
+    for name in sorted(sizes, key=lambda k: -sizes[k]):
+        r = loads.index(min(loads))
+        owner[name] = r
+        loads[r] += sizes[name]
+    return owner
+
+
+def gen_contig_device(torch, dev, contig_len, n, seed):
+    """Seeded device-side generator of the BASELINE.md mixture; start-sorted SoA tensors."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    start = torch.randint(0, max(contig_len - 1000, 1), (n,), generator=g, device=dev, dtype=torch.int64)
+    u = torch.rand(n, generator=g, device=dev)
+    z = torch.randn(n, generator=g, device=dev)
+    v = torch.rand(n, generator=g, device=dev)
+    length = torch.where(u < 0.85, 167.0 + 12.0 * z, torch.where(u < 0.97, 334.0 + 25.0 * z, 30.0 + 570.0 * v))
+    length = torch.clamp(torch.round(length), 30, 1000).to(torch.int64)
+    del u, z, v
+    key, _ = torch.sort(start * 2048 + length)  # sort by (start, end)
+    del start, length
+    s = (key >> 11).to(torch.int32)
+    e = (s + (key & 2047).to(torch.int32)).contiguous()
+    del key
+    m = torch.rand(n, generator=g, device=dev)
+    mapq = torch.where(m < 0.85, torch.full((n,), 60, device=dev, dtype=torch.int64),
+                       torch.randint(0, 60, (n,), generator=g, device=dev)).to(torch.uint8)
+    strand = (torch.rand(n, generator=g, device=dev) < 0.5).to(torch.uint8)
+    return s, e, mapq, strand
+
+
+def synth_gaps(contig_len):
+    """Synthetic centromere / telomere constants (hg19-like proportions)."""
+    c0 = int(contig_len * 0.40) // WINDOW * WINDOW
+    return (c0, c0 + 3_000_000, [(0, 10_000), (contig_len - 10_000, contig_len)])
+
+
+def synth_blacklist(contig_len, seed, n_regions):
+    rng = np.random.default_rng(seed)
+    s = np.sort(rng.integers(0, contig_len - 6000, n_regions)).astype(np.int32)
+    e = (s + rng.integers(200, 5000, n_regions)).astype(np.int32)
+    order = np.lexsort((e, s))
+    return s[order], e[order]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--depth", type=float, default=30.0)
+    ap.add_argument("--contigs", type=str, default="", help="comma list (default: b37 1-22,X,Y)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from finaletoolkit_amd.engine import Engine
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    sizes = dict(synth.B37_SIZES)
+    if args.contigs:
+        sizes = {k: sizes[k] for k in args.contigs.split(",")}
+    names = list(sizes)
+    owner = lpt_assign(sizes, world)
+    mine = [c for c in names if owner[c] == rank]
+
+    eng = Engine(local)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # ---- resident inputs (untimed) -------------------------------------------
+    t_load = time.time()
+    per = {}
+    for c in mine:
+        ci = names.index(c)
+        n = synth.n_fragments(sizes[c], args.depth)
+        s, e, q, st = gen_contig_device(torch, dev, sizes[c], n, synth.SEED_BASE + ci)
+        torch.cuda.synchronize()
+        eng.load_contig_device(c, s, e, q, st, n)
+        ws, we = synth.tiling_windows(sizes[c], WINDOW)
+        bl_s, bl_e = synth_blacklist(sizes[c], 77 + ci, max(8, int(2000 * sizes[c] / 3.1e9)))
+        nw = len(ws)
+        per[c] = dict(
+            n=n, ws=ws, we=we, nw=nw, bl=(bl_s, bl_e), gaps=synth_gaps(sizes[c]),
+            d_ws=torch.from_numpy(ws).to(dev), d_we=torch.from_numpy(we).to(dev),
+            cov=torch.zeros(nw, dtype=torch.int64, device=dev),
+            hist=torch.zeros((nw, HIST_BINS), dtype=torch.int32, device=dev),
+            over=torch.zeros(nw, dtype=torch.int64, device=dev),
+            wps=torch.empty(sizes[c], dtype=torch.int64, device=dev),
+            keep=(s, e, q, st) if c == mine[-1] else None,
+        )
+        del s, e, q, st
+    torch.cuda.synchronize()
+    t_load = time.time() - t_load
+
+    import ctypes as C
+    from finaletoolkit_amd import _lib as L
+    lib = eng.lib
+    flt = L.make_filter(MAPQ, None, None, "midpoint")
+    bins_all = sum(int(np.ceil(sizes[c] / WINDOW)) for c in names)
+    max_bins_rank = max(sum(int(np.ceil(sizes[c] / WINDOW)) for c in names if owner[c] == r) for r in range(world))
+    gather_in = torch.zeros((max_bins_rank, 2), dtype=torch.int64, device=dev)
+    gather_out = [torch.zeros_like(gather_in) for _ in range(world)] if world > 1 else None
+    wps_ev = {}
+
+    def step(record_events=False):
+        row = 0
+        ev = 0
+        for c in mine:
+            p = per[c]
+            cid = eng.contig_id(c)
+            eng._check(lib.ftk_window_counts(eng.ctx, cid, L.ptr(p["d_ws"]), L.ptr(p["d_we"]), p["nw"], C.byref(flt),
+                                             L.ptr(p["cov"])))
+            eng._check(lib.ftk_fraglen_hist(eng.ctx, cid, L.ptr(p["d_ws"]), L.ptr(p["d_we"]), p["nw"], C.byref(flt),
+                                            0, HIST_BINS, L.ptr(p["hist"]), L.ptr(p["over"])))
+            sh, lg, _ = eng.delfi_counts(c, p["ws"], p["we"], MAPQ, p["bl"][0], p["bl"][1], p["gaps"])
+            p["short"], p["long"] = sh, lg
+            if record_events:
+                eng.event_record(ev)
+            eng.wps(c, 0, sizes[c], sizes[c], WPS_W, WPS_MIN, WPS_MAX, MAPQ, out=p["wps"])
+            if record_events:
+                eng.event_record(ev + 1)
+                wps_ev[c] = (ev, ev + 1)
+                ev += 2
+            row += p["nw"]
+        if world > 1:
+            r0 = 0
+            for c in mine:
+                p = per[c]
+                gather_in[r0:r0 + p["nw"], 0] = torch.from_numpy(p["short"]).to(dev)
+                gather_in[r0:r0 + p["nw"], 1] = torch.from_numpy(p["long"]).to(dev)
+                r0 += p["nw"]
+            dist.all_gather(gather_out, gather_in)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(record_events=(i == args.steps - 1))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt * 1e3 / args.steps
+    value = bins_all * args.steps / dt
+
+    # ---- roofline of the dominant kernel (WPS), from the last timed step -------
+    wps_bytes = 0
+    wps_ms = 0.0
+    for c, (a, b) in wps_ev.items():
+        wps_ms += eng.event_elapsed_ms(a, b)
+        wps_bytes += 10 * per[c]["n"] + 8 * sizes[c]
+    achieved = wps_bytes / (wps_ms * 1e-3) / 1e9 if wps_ms > 0 else 0.0
+    roofline = dict(bound="hbm", kernel="wps_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    algorithmic_bytes_per_launch=int(wps_bytes / max(len(wps_ev), 1)),
+                    launches=len(wps_ev), avg_launch_ms=round(wps_ms / max(len(wps_ev), 1), 4))
+
+    # ---- size-independent checks on the full workload ---------------------------
+    checks = {}
+    tot_cov = sum(int(per[c]["cov"].sum().item()) for c in mine)
+    tot_hist = sum(int(per[c]["hist"].sum().item()) + int(per[c]["over"].sum().item()) for c in mine)
+    checks["cov_sum_eq_hist_sum"] = tot_cov == tot_hist
+
+    out = None
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(torch, eng, per, mine, sizes, args.cpu_seconds, checks)
+        out = {
+            "metric": "genomic windows/sec (coverage+WPS+DELFI) at 30x WGS",
+            "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "int32/int64", "data": "synthetic",
+            "config": {"workload": f"whole-genome b37 1-22,X,Y synthetic {args.depth:g}x fragments "
+                                   f"({sum(synth.n_fragments(sizes[c], args.depth) for c in names)} fragments), "
+                                   f"{bins_all} x 100 kb windows: coverage + length histogram (1001 bins) + DELFI "
+                                   f"short/long (blacklist+gaps) + WPS W=120 every base",
+                       "contigs": len(names), "windows": bins_all, "depth": args.depth,
+                       "sharding": f"contigs LPT over {world} GPU(s); all-gather of DELFI bin vector" if world > 1
+                       else "single GPU"},
+            "roofline": roofline, "cpu_baseline": cpu, "checks": checks, "load_s": round(t_load, 2),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(torch, eng, per, mine, sizes, budget_s, checks):
+    """C oracle (kind "port", 1 core) on a bounded sample of the same workload,
+    checked against the GPU results for the same windows."""
+    from oracle import oracle as O
+    c = mine[-1]
+    p = per[c]
+    s, e, q, st = [t.cpu().numpy() for t in p["keep"]]
+    fr = O.Frags(s, e, q, st)
+    n_s = min(p["nw"], 64)
+    ws, we = p["ws"][:n_s], p["we"][:n_s]
+    t0 = time.perf_counter()
+    cov = O.c_window_counts(fr, ws, we, mapq_min=MAPQ)
+    hist, over = O.c_fraglen_hist(fr, ws, we, 0, HIST_BINS, mapq_min=MAPQ)
+    sh, lg, nf = O.c_delfi_counts(fr, ws, we, MAPQ, p["bl"][0], p["bl"][1], p["gaps"])
+    t_count = time.perf_counter() - t0
+    # WPS in 5 kb tiles like multi_wps; stop when the budget is used, extrapolate per window
+    done = 0
+    t1 = time.perf_counter()
+    ok_wps = True
+    wps_gpu = None
+    while done < n_s and (time.perf_counter() - t1) < budget_s:
+        a, b = int(ws[done]), int(we[done])
+        ref = np.concatenate([O.c_wps(fr, x, min(x + 5000, b), sizes[c], WPS_W, WPS_MIN, WPS_MAX, MAPQ)
+                              for x in range(a, b, 5000)])
+        wps_gpu = p["wps"][a:b].cpu().numpy()
+        ok_wps = ok_wps and bool(np.array_equal(ref, wps_gpu))
+        done += 1
+    t_wps = time.perf_counter() - t1
+    per_window = t_count / n_s + t_wps / max(done, 1)
+    checks["sample_cov"] = bool(np.array_equal(cov, p["cov"][:n_s].cpu().numpy()))
+    checks["sample_hist"] = bool(np.array_equal(hist.astype(np.int64), p["hist"][:n_s].cpu().numpy().astype(np.int64)))
+    checks["sample_delfi"] = bool(np.array_equal(sh, p["short"][:n_s]) and np.array_equal(lg, p["long"][:n_s]))
+    checks["sample_wps"] = ok_wps
+    return {"value": round(1.0 / per_window, 3), "unit": "windows/s", "cores": 1, "kind": "port",
+            "sample": f"C oracle (oracle/ftk_oracle.c, gcc -O2): coverage+hist+DELFI on {n_s} and WPS (5 kb tiles) on "
+                      f"{done} x 100 kb windows of contig {c}; extrapolated per window"}
+
+
+if __name__ == "__main__":
+    main()

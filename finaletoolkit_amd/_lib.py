@@ -38,7 +38,8 @@ MAX_TELOMERES = 8
 # every symbol include/ftk.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "ftk_version", "ftk_device_count", "ftk_ctx_create", "ftk_ctx_destroy", "ftk_last_error",
-    "ftk_ctx_set_stream", "ftk_ctx_sync", "ftk_timer_start", "ftk_timer_stop",
+    "ftk_ctx_set_stream", "ftk_ctx_sync", "ftk_timer_start", "ftk_timer_stop", "ftk_event_record",
+    "ftk_event_elapsed_ms",
     "ftk_frags_from_host", "ftk_frags_from_device", "ftk_frags_set_read1", "ftk_frags_info", "ftk_frags_release",
     "ftk_fragfile_decode", "ftk_bam_decode", "ftk_fragtable_error", "ftk_fragtable_is_bed6",
     "ftk_fragtable_n_contigs", "ftk_fragtable_contig_name", "ftk_fragtable_contig_length",
@@ -102,6 +103,8 @@ def load() -> C.CDLL:
     lib.ftk_ctx_sync.argtypes = [vp]
     lib.ftk_timer_start.argtypes = [vp]
     lib.ftk_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.ftk_event_record.argtypes = [vp, C.c_int]
+    lib.ftk_event_elapsed_ms.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.ftk_frags_from_host.argtypes = [vp, C.c_int, vp, vp, vp, vp, i64]
     lib.ftk_frags_from_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, i64]
     lib.ftk_frags_set_read1.argtypes = [vp, C.c_int, vp, vp, i64]

@@ -308,6 +308,8 @@ void ftk_ctx_destroy(ftk_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    for (hipEvent_t e : ctx->ev_slots)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -338,6 +340,25 @@ int ftk_timer_stop(ftk_ctx* ctx, float* ms_out) {
     HIPCHK(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     HIPCHK(ctx, hipEventSynchronize(ctx->ev_stop));
     HIPCHK(ctx, hipEventElapsedTime(ms_out, ctx->ev_start, ctx->ev_stop));
+    return FTK_OK;
+}
+
+int ftk_event_record(ftk_ctx* ctx, int slot) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    if (slot < 0 || slot >= FTK_MAX_EVENTS) return fail(ctx, FTK_ERR_INVALID, "event slot %d out of range", slot);
+    if (ctx->ev_slots.empty()) ctx->ev_slots.assign(FTK_MAX_EVENTS, nullptr);
+    if (!ctx->ev_slots[slot]) HIPCHK(ctx, hipEventCreate(&ctx->ev_slots[slot]));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_slots[slot], ctx->stream));
+    return FTK_OK;
+}
+
+int ftk_event_elapsed_ms(ftk_ctx* ctx, int slot_a, int slot_b, float* ms_out) {
+    if (!ctx || !ms_out) return fail(ctx, FTK_ERR_INVALID, "NULL argument");
+    if (slot_a < 0 || slot_b < 0 || slot_a >= FTK_MAX_EVENTS || slot_b >= FTK_MAX_EVENTS || ctx->ev_slots.empty() ||
+        !ctx->ev_slots[slot_a] || !ctx->ev_slots[slot_b])
+        return fail(ctx, FTK_ERR_INVALID, "event slot not recorded");
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_slots[slot_b]));
+    HIPCHK(ctx, hipEventElapsedTime(ms_out, ctx->ev_slots[slot_a], ctx->ev_slots[slot_b]));
     return FTK_OK;
 }
 

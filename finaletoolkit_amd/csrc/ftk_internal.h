@@ -53,6 +53,7 @@ struct ftk_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::vector<hipEvent_t> ev_slots;  // lazily created, FTK_MAX_EVENTS entries
     std::map<int, ftk::ContigData> contigs;
     std::string err;
     // grow-only device scratch, reused by every call (stream-ordered)

@@ -71,6 +71,14 @@ class Engine:
         self._check(self.lib.ftk_timer_stop(self.ctx, C.byref(ms)))
         return float(ms.value)
 
+    def event_record(self, slot: int):
+        self._check(self.lib.ftk_event_record(self.ctx, int(slot)))
+
+    def event_elapsed_ms(self, slot_a: int, slot_b: int) -> float:
+        ms = C.c_float()
+        self._check(self.lib.ftk_event_elapsed_ms(self.ctx, int(slot_a), int(slot_b), C.byref(ms)))
+        return float(ms.value)
+
     # -- fragments ------------------------------------------------------------
     def contig_id(self, name: str) -> int:
         if name not in self._ids:

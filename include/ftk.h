@@ -98,6 +98,12 @@ int ftk_ctx_sync(ftk_ctx* ctx);
  * durations).  ftk_timer_stop waits for the stop event. */
 int ftk_timer_start(ftk_ctx* ctx);
 int ftk_timer_stop(ftk_ctx* ctx, float* ms_out);
+/* Event slots for timing individual launches without draining the stream:
+ * record any number of slots inside a timed region, read the differences
+ * afterwards (ftk_event_elapsed_ms waits for slot_b). */
+#define FTK_MAX_EVENTS 4096
+int ftk_event_record(ftk_ctx* ctx, int slot);
+int ftk_event_elapsed_ms(ftk_ctx* ctx, int slot_a, int slot_b, float* ms_out);
 
 /* ---- fragments: SoA residency in HBM -------------------------------------
  * Replaces the per-window `AlignmentWrapper.fetch` re-open + Fragment tuple
