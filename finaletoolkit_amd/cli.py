@@ -1,0 +1,118 @@
+"""
+Command line for the hot-path commands, flag-compatible with the reference's
+``finaletoolkit`` CLI (``cli/commands/__init__.py:92-127,130-232,280-324,415-479`` and ``cli/_args.py``):
+``coverage``, ``frag-length-bins``, ``frag-length-intervals``, ``wps``, ``delfi``.
+
+    python -m finaletoolkit_amd.cli coverage INPUT INTERVALS -o out.bed
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+
+
+def _shared(p, min_default, max_default=None, threads=True, policy=True, output_default="-"):
+    """Options shared by the commands (cli/_args.py:46-160 of the reference)."""
+    p.add_argument("-r", "--reference", dest="reference_file", default=None, metavar="FASTA_OR_2BIT")
+    p.add_argument("-o", "--output", dest="output_file", default=output_default, metavar="FILE")
+    p.add_argument("--min-length", dest="min_length", type=int, default=min_default, metavar="BP")
+    p.add_argument("--max-length", dest="max_length", type=int, default=max_default, metavar="BP")
+    if policy:
+        p.add_argument("-p", "--intersect-policy", dest="intersect_policy", choices=["midpoint", "any"],
+                       default="midpoint")
+    p.add_argument("-q", "--min-mapq", dest="quality_threshold", type=int, default=30, metavar="N")
+    if threads:
+        p.add_argument("-t", "--threads", dest="workers", type=int, default=1, metavar="N")
+    p.add_argument("-v", "--verbose", action="count", default=0)
+
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(prog="finaletoolkit-amd", description="MI355X fragment-feature engine")
+    sub = ap.add_subparsers(dest="command", required=True)
+
+    p = sub.add_parser("coverage", help="fragment coverage over BED intervals")
+    p.add_argument("input_file", metavar="INPUT")
+    p.add_argument("interval_file", metavar="REGIONS")
+    p.add_argument("-n", "--normalize", action="store_true")
+    p.add_argument("--scale-factor", dest="scale_factor", type=float, default=1.0, metavar="X")
+    _shared(p, min_default=0)
+
+    p = sub.add_parser("frag-length-bins", help="binned fragment-length distribution")
+    p.add_argument("input_file", metavar="INPUT")
+    p.add_argument("-c", "--contig", default=None)
+    p.add_argument("-S", "--start", type=int, default=None)
+    p.add_argument("-E", "--stop", type=int, default=None)
+    p.add_argument("--bin-size", dest="bin_size", type=int, default=1)
+    p.add_argument("--summary-stats", dest="summary_stats", action="store_true")
+    p.add_argument("--short-threshold", dest="short_fraction", type=int, default=None)
+    p.add_argument("--histogram", dest="histogram_path", default=None)
+    _shared(p, min_default=0, threads=False)
+
+    p = sub.add_parser("frag-length-intervals", help="fragment-length statistics per BED interval")
+    p.add_argument("input_file", metavar="INPUT")
+    p.add_argument("interval_file", metavar="REGIONS")
+    p.add_argument("--short-threshold", dest="short_reads", type=int, default=150)
+    _shared(p, min_default=0)
+
+    p = sub.add_parser("wps", help="windowed protection score over BED sites")
+    p.add_argument("input_file", metavar="INPUT")
+    p.add_argument("site_bed", metavar="REGIONS")
+    p.add_argument("--chrom-sizes", dest="chrom_sizes", default=None)
+    p.add_argument("-i", "--interval-size", dest="interval_size", type=int, default=5000)
+    p.add_argument("-W", "--window-size", dest="window_size", type=int, default=120)
+    _shared(p, min_default=120, max_default=180, policy=False)
+
+    p = sub.add_parser("delfi", help="DELFI short/long fragment features")
+    p.add_argument("input_file", metavar="INPUT")
+    p.add_argument("chrom_sizes", metavar="CHROM_SIZES")
+    p.add_argument("reference_file", metavar="REFERENCE")
+    p.add_argument("bins_file", metavar="BINS")
+    p.add_argument("-b", "--blacklist", dest="blacklist_file", default=None)
+    p.add_argument("-g", "--gap-file", dest="gap_file", default=None)
+    p.add_argument("-o", "--output", dest="output_file", default="-")
+    p.add_argument("--no-gc-correct", dest="no_gc_correct", action="store_true")
+    p.add_argument("--remove-nocov", dest="remove_nocov", action="store_true", default=True)
+    p.add_argument("--no-remove-nocov", dest="remove_nocov", action="store_false")
+    p.add_argument("--merge-bins", dest="merge_bins", action="store_true", default=True)
+    p.add_argument("--no-merge-bins", dest="merge_bins", action="store_false")
+    p.add_argument("--merge-size", dest="window_size", type=int, default=5000000)
+    p.add_argument("-q", "--min-mapq", dest="quality_threshold", type=int, default=30)
+    p.add_argument("-t", "--threads", dest="workers", type=int, default=1)
+    p.add_argument("-v", "--verbose", action="count", default=0)
+    return ap
+
+
+def main(argv=None) -> int:
+    a = build_parser().parse_args(argv)
+    from . import frag
+    if a.command == "coverage":
+        frag.coverage(a.input_file, a.interval_file, a.output_file, scale_factor=a.scale_factor,
+                      min_length=a.min_length, max_length=a.max_length, normalize=a.normalize,
+                      intersect_policy=a.intersect_policy, quality_threshold=a.quality_threshold, workers=a.workers,
+                      verbose=a.verbose, reference_file=a.reference_file)
+    elif a.command == "frag-length-bins":
+        frag.frag_length_bins(a.input_file, contig=a.contig, start=a.start, stop=a.stop, min_length=a.min_length,
+                              max_length=a.max_length, bin_size=a.bin_size, output_file=a.output_file,
+                              intersect_policy=a.intersect_policy, quality_threshold=a.quality_threshold,
+                              summary_stats=a.summary_stats, short_fraction=a.short_fraction,
+                              histogram_path=a.histogram_path, verbose=a.verbose, reference_file=a.reference_file)
+    elif a.command == "frag-length-intervals":
+        frag.frag_length_intervals(a.input_file, a.interval_file, output_file=a.output_file, min_length=a.min_length,
+                                   max_length=a.max_length, quality_threshold=a.quality_threshold,
+                                   intersect_policy=a.intersect_policy, short_reads=a.short_reads, workers=a.workers,
+                                   verbose=a.verbose, reference_file=a.reference_file)
+    elif a.command == "wps":
+        frag.multi_wps(a.input_file, a.site_bed, chrom_sizes=a.chrom_sizes, output_file=a.output_file,
+                       window_size=a.window_size, interval_size=a.interval_size, min_length=a.min_length,
+                       max_length=a.max_length, quality_threshold=a.quality_threshold, workers=a.workers,
+                       verbose=a.verbose, reference_file=a.reference_file)
+    elif a.command == "delfi":
+        frag.delfi(a.input_file, a.chrom_sizes, a.bins_file, a.reference_file, blacklist_file=a.blacklist_file,
+                   gap_file=a.gap_file, output_file=a.output_file, no_gc_correct=a.no_gc_correct,
+                   remove_nocov=a.remove_nocov, merge_bins=a.merge_bins, window_size=a.window_size,
+                   quality_threshold=a.quality_threshold, workers=a.workers, verbose=a.verbose)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,14 @@
+"""
+``finaletoolkit.frag`` surface of the hot path, MI355X-backed (names, arguments
+and results as in the reference's ``frag/__init__.py:7-34``).
+"""
+from ._coverage import CoverageResult, coverage, single_coverage
+from ._delfi import delfi
+from ._delfi_gc_correct import delfi_gc_correct
+from ._delfi_merge_bins import delfi_merge_bins
+from ._frag_length import FragLengthStats, frag_length, frag_length_bins, frag_length_intervals
+from ._multi_wps import multi_wps
+from ._wps import wps
+
+__all__ = ["frag_length", "frag_length_bins", "frag_length_intervals", "FragLengthStats", "coverage",
+           "single_coverage", "CoverageResult", "wps", "multi_wps", "delfi", "delfi_gc_correct", "delfi_merge_bins"]

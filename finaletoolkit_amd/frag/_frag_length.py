@@ -1,0 +1,260 @@
+"""
+Fragment-length features with the reference's surface
+(``src/finaletoolkit/frag/_frag_length.py``): ``frag_length`` (raw lengths),
+``frag_length_bins`` (binned distribution + statistics) and
+``frag_length_intervals`` (per-interval statistics).
+
+The ``length -> count`` dictionaries of ``_distribution_from_gen`` (``:147-153``)
+come from the ``ftk_fraglen_hist`` kernel; the statistics (``:156-238``) are host
+arithmetic on those histograms with the reference's exact formulas, including
+the odd-count median search for ``total // 2``.
+"""
+from __future__ import annotations
+
+import gzip
+import time
+import warnings
+from pathlib import Path
+from sys import stderr, stdout
+from typing import NamedTuple, Union
+
+import numpy as np
+
+from ..source import get_engine, open_source
+from ..utils import _check_policy, _check_region, _region_contigs, get_intervals
+
+__all__ = ["frag_length", "frag_length_bins", "frag_length_intervals", "FragLengthStats"]
+
+_MAX_BINS = 32768               # kHistMaxBins of the kernel
+_HIST_BYTES_PER_CALL = 1 << 29  # window batches are cut to keep one histogram block <= 512 MiB
+
+
+class FragLengthStats(NamedTuple):
+    """Per-interval length statistics (frag/_frag_length.py:32-75); all ``-1`` when empty."""
+
+    contig: str
+    start: int
+    stop: int
+    name: str
+    mean: float
+    median: float
+    stdev: float
+    minimum: int
+    maximum: int
+    count: int
+    frac_short_reads: float
+
+
+def _find_median(values: np.ndarray, freq: np.ndarray) -> float:
+    """frag/_frag_length.py:156-172 on sorted ``values`` with counts ``freq``."""
+    cdf = np.cumsum(freq)
+    total_count = cdf[-1]
+    if total_count % 2 == 1:
+        return float(values[np.searchsorted(cdf, total_count // 2)])
+    idx = np.searchsorted(cdf, [total_count // 2, total_count // 2 + 1])
+    return float(np.mean(values[idx]))
+
+
+def _stats_from_dist(values: np.ndarray, freq: np.ndarray, short_cut):
+    """(mean, median, stdev, min, max, total, n_short) from sorted lengths/counts
+    (frag/_frag_length.py:202-224, :432-456)."""
+    vals = [int(v) for v in values]
+    cnts = [int(c) for c in freq]
+    total_count = sum(cnts)
+    mean = sum(v * c for v, c in zip(vals, cnts)) / total_count
+    median = _find_median(values, freq)
+    variance = sum(c * ((v - mean) ** 2) for v, c in zip(vals, cnts)) / total_count
+    n_short = None if short_cut is None else sum(c for v, c in zip(vals, cnts) if v <= short_cut)
+    return mean, median, variance ** 0.5, vals[0], vals[-1], total_count, n_short
+
+
+def _length_range(eng, key, min_length, max_length):
+    _, data_max, _ = eng.info(key)
+    lo = 0 if min_length is None else max(int(min_length), 0)
+    hi = data_max if max_length is None else min(int(max_length), data_max)
+    return lo, hi
+
+
+def _window_hists(eng, key, ws, we, lo, hi, quality_threshold, min_length, max_length, intersect_policy):
+    """Dense histograms [n_win, hi - lo + 1] (uint32->int64), length range split when it exceeds the kernel limit."""
+    n_win = len(ws)
+    if hi < lo or n_win == 0:
+        return np.zeros((n_win, 0), np.int64)
+    n_total = hi - lo + 1
+    out = np.zeros((n_win, n_total), np.int64)
+    for b0 in range(0, n_total, _MAX_BINS):
+        nb = min(_MAX_BINS, n_total - b0)
+        step = max(1, _HIST_BYTES_PER_CALL // (4 * nb))
+        for w0 in range(0, n_win, step):
+            h, _ = eng.fraglen_hist(key, ws[w0:w0 + step], we[w0:w0 + step], lo + b0, nb, quality_threshold,
+                                    min_length, max_length, intersect_policy)
+            out[w0:w0 + step, b0:b0 + nb] = h
+    return out
+
+
+def frag_length(input_file: Union[str, Path], contig: str | None = None, start: int | None = None,
+                stop: int | None = None, intersect_policy: str = "midpoint", output_file: str | None = None,
+                quality_threshold: int = 30, verbose: bool = False,
+                reference_file: str | Path | None = None) -> np.ndarray:
+    """``int32`` array of fragment lengths in file order (frag/_frag_length.py:246-330)."""
+    if verbose:
+        t0 = time.time()
+        stderr.write("Finding frag lengths.\n")
+    _check_policy(intersect_policy)
+    _check_region(contig, start, stop)
+    src = open_source(input_file)
+    eng = get_engine()
+    names, whole = _region_contigs(src, contig)
+    parts = [eng.frag_lengths(src.require(c), None if whole else start, None if whole else stop, quality_threshold,
+                              0, 1000000000, intersect_policy) for c in names]
+    lengths = np.concatenate(parts).astype(np.int32) if parts else np.zeros(0, np.int32)
+
+    if isinstance(output_file, str):
+        if output_file.endswith(".bin"):
+            with open(output_file, "wb") as out:
+                lengths.tofile(out)
+        elif output_file == "-":
+            for line in lengths:
+                stdout.write(f"{line}\n")
+        else:
+            raise ValueError("output_file can only have suffixes .wig or .wig.gz.")
+    elif output_file is not None:
+        raise TypeError(f'output_file is unsupported type "{type(input_file)}". output_file should be a string '
+                        "specifying the path of the file to write output scores to.")
+    if verbose:
+        stderr.write(f"frag_length took {time.time() - t0} s to complete\n")
+    return lengths
+
+
+def frag_length_bins(input_file, contig: str | None = None, start: int | None = None, stop: int | None = None,
+                     min_length: int | None = 0, max_length: int | None = None, bin_size: int = 1,
+                     output_file: str | None = None, intersect_policy: str = "midpoint", quality_threshold: int = 30,
+                     summary_stats: bool = False, short_fraction: int | None = None,
+                     histogram_path: str | None = None, verbose: Union[bool, int] = False,
+                     reference_file: str | Path | None = None):
+    """Binned length distribution of a region / contig / the whole file
+    (frag/_frag_length.py:333-508).  Returns ``(bins, counts)``."""
+    if verbose:
+        t0 = time.time()
+        stderr.write("Generating fragment dictionary. \n")
+    _check_policy(intersect_policy)
+    _check_region(contig, start, stop)
+    src = open_source(input_file)
+    eng = get_engine()
+    names, whole = _region_contigs(src, contig)
+    dist: dict[int, int] = {}
+    for c in names:
+        key = src.require(c)
+        lo, hi = _length_range(eng, key, min_length, max_length)
+        h = _window_hists(eng, key, [None if whole else start], [None if whole else stop], lo, hi, quality_threshold,
+                          min_length, max_length, intersect_policy)
+        if h.shape[1]:
+            for b in np.nonzero(h[0])[0]:
+                dist[lo + int(b)] = dist.get(lo + int(b), 0) + int(h[0, b])
+    total_count = sum(dist.values())
+    if total_count == 0:
+        warnings.warn("No fragments found in the specified region. Returning empty result.", RuntimeWarning,
+                      stacklevel=2)
+        return np.array([]), np.array([])
+
+    values = np.array(sorted(dist), dtype=np.int64)
+    freq = np.array([dist[int(v)] for v in values], dtype=np.int64)
+    mean, median, stdev, vmin, vmax, _, n_short = _stats_from_dist(values, freq, short_fraction)
+    stats = [("mean", mean), ("median", median), ("stdev", stdev), ("min", vmin), ("max", vmax),
+             ("total count", total_count)]
+    if short_fraction is not None:
+        stats.append((f"short fraction (s{short_fraction})", n_short / total_count))
+
+    bin_start, bin_stop = vmin, vmax
+    n_bins = (bin_stop - bin_start) // bin_size
+    bins = np.arange(bin_start, bin_stop + bin_size, bin_size)
+    counts_arr = np.zeros(n_bins + 1, dtype=np.int64)
+    np.add.at(counts_arr, (values - bin_start) // bin_size, freq)
+    counts = counts_arr.tolist()
+
+    if output_file is not None:
+        out_is_file = False
+        try:
+            if output_file == "-":
+                out = stdout
+            elif output_file.endswith(".gz"):
+                out_is_file = True
+                out = gzip.open(output_file, "wt")
+            else:
+                out_is_file = True
+                out = open(output_file, "w")
+            out.write("min\tmax\tcount\n")
+            for bin_val, count in zip(bins, counts):
+                out.write(f"{bin_val}\t{bin_val + bin_size - 1}\t{count}\n")
+            if summary_stats:
+                for name, value in stats:
+                    out.write(f"#{name}: {value}\n")
+        finally:
+            if out_is_file:
+                out.close()
+    if histogram_path is not None:
+        raise NotImplementedError("histogram plotting (matplotlib) is outside the MI355X hot path")
+    if verbose:
+        stderr.write(f"frag_length_bins took {time.time() - t0} s to complete.\n")
+    return bins, counts
+
+
+def frag_length_intervals(input_file, interval_file: str, output_file: str | None = None,
+                          min_length: int | None = 0, max_length: int | None = None, quality_threshold: int = 30,
+                          intersect_policy: str = "midpoint", short_reads: int = 150, workers: int = 1,
+                          verbose: Union[bool, int] = False,
+                          reference_file: str | Path | None = None) -> list[FragLengthStats]:
+    """Per-interval length statistics over a BED file (frag/_frag_length.py:511-640)."""
+    if verbose:
+        t0 = time.time()
+        stderr.write("Reading intervals.\n")
+    _check_policy(intersect_policy)
+    src = open_source(input_file, workers)
+    eng = get_engine()
+    intervals = get_intervals(interval_file)
+    results: list = [None] * len(intervals)
+    by_contig: dict[str, list[int]] = {}
+    for i, (c, _, _, _) in enumerate(intervals):
+        by_contig.setdefault(c, []).append(i)
+    for c, idx in by_contig.items():
+        key = src.require(c)
+        lo, hi = _length_range(eng, key, min_length, max_length)
+        ws = np.array([intervals[i][1] for i in idx], np.int64).astype(np.int32)
+        we = np.array([intervals[i][2] for i in idx], np.int64).astype(np.int32)
+        n_total = max(hi - lo + 1, 1)
+        step = max(1, _HIST_BYTES_PER_CALL // (8 * n_total))
+        for w0 in range(0, len(idx), step):
+            h = _window_hists(eng, key, ws[w0:w0 + step], we[w0:w0 + step], lo, hi, quality_threshold, min_length,
+                              max_length, intersect_policy)
+            for j in range(h.shape[0]):
+                contig, start, stop, name = intervals[idx[w0 + j]]
+                nz = np.nonzero(h[j])[0] if h.shape[1] else np.zeros(0, np.int64)
+                if len(nz) == 0:
+                    results[idx[w0 + j]] = FragLengthStats(contig, start, stop, name, -1, -1, -1, -1, -1, -1, -1)
+                    continue
+                mean, median, stdev, vmin, vmax, total, n_short = _stats_from_dist(nz + lo, h[j][nz], short_reads)
+                results[idx[w0 + j]] = FragLengthStats(contig, start, stop, name, mean, median, stdev, vmin, vmax,
+                                                       total, n_short / total)
+
+    output_is_file = False
+    if output_file is not None:
+        try:
+            if output_file.endswith(".bed") or output_file.endswith(".bedgraph"):
+                output_is_file = True
+                output = open(output_file, "w")
+            elif output_file.endswith(".bed.gz"):
+                output = gzip.open(output_file, "wt")
+                output_is_file = True
+            elif output_file == "-":
+                output = stdout
+            else:
+                raise ValueError("The output file should have .bed or .bed.gz as as suffix.")
+            output.write(f"contig\tstart\tstop\tname\tmean\tmedian\tstdev\tmin\tmax\tcount\ts{short_reads}\n")
+            output.write("\n".join("\t".join(str(element) for element in item) for item in results))
+            output.write("\n")
+        finally:
+            if output_is_file:
+                output.close()
+    if verbose:
+        stderr.write(f"Calculating fragment length statistics for intervals took {time.time() - t0} s\n")
+    return results

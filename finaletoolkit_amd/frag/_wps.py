@@ -1,0 +1,101 @@
+"""
+Windowed Protection Score over one interval -- ``wps`` with the reference's
+signature, result dtype, WIG writer, deprecation handling and degenerate-
+interval behaviour (``src/finaletoolkit/frag/_wps.py:56-229``).  The per-base
+loop (``:180-188``) is the ``ftk_wps`` kernel.
+"""
+from __future__ import annotations
+
+import gzip
+import time
+import warnings
+from pathlib import Path
+from sys import stderr, stdout
+from typing import Union
+
+import numpy as np
+
+from ..source import get_engine, open_source
+
+__all__ = ["wps"]
+
+_WPS_DTYPE = [("contig", "U16"), ("start", "i8"), ("wps", "i8")]
+
+
+def _resolve_aliases(min_length, max_length, fraction_low, fraction_high):
+    """frag/_wps.py:112-140 (supplying both spellings is an error)."""
+    if fraction_low is not None and min_length is None:
+        min_length = fraction_low
+        warnings.warn("fraction_low is deprecated. Use min_length instead.", category=DeprecationWarning, stacklevel=3)
+    elif fraction_low is not None and min_length is not None:
+        warnings.warn("fraction_low is deprecated. Use min_length instead.", category=DeprecationWarning, stacklevel=3)
+        raise ValueError("fraction_low and min_length cannot both be specified")
+    if fraction_high is not None and max_length is None:
+        max_length = fraction_high
+        warnings.warn("fraction_high is deprecated. Use max_length instead.", category=DeprecationWarning,
+                      stacklevel=3)
+    elif fraction_high is not None and max_length is not None:
+        warnings.warn("fraction_high is deprecated. Use max_length instead.", category=DeprecationWarning,
+                      stacklevel=3)
+        raise ValueError("fraction_high and max_length cannot both be specified")
+    return min_length, max_length
+
+
+def _scores_array(chrom, start, values):
+    scores = np.zeros(len(values), dtype=_WPS_DTYPE)
+    scores["contig"] = chrom
+    scores["start"] = np.arange(start, start + len(values), dtype=np.int64)
+    scores["wps"] = values
+    return scores
+
+
+def wps(input_file: Union[str, Path], chrom: str, start: int, stop: int, chrom_size: int,
+        output_file: str | None = None, window_size: int = 120, min_length: int = 120, max_length: int = 180,
+        quality_threshold: int = 30, verbose: bool | int = 0, fraction_low: int | None = None,
+        fraction_high: int | None = None, reference_file: str | Path | None = None) -> np.ndarray:
+    """Raw WPS for every base of ``chrom:[start, stop)``; structured array with
+    fields ``('contig', 'start', 'wps')``."""
+    if verbose:
+        t0 = time.time()
+        stderr.write(f"[finaletoolkit-wps] Region: {chrom}:{start}-{stop}\n")
+    min_length, max_length = _resolve_aliases(min_length, max_length, fraction_low, fraction_high)
+    start = int(start)
+    stop = int(stop)
+    if stop <= start:
+        warnings.warn(f"[wps] {chrom}:{start}-{stop} is a degenerate interval (stop <= start); skipping.",
+                      UserWarning, stacklevel=2)
+        return np.zeros(0, dtype=_WPS_DTYPE)
+    src = open_source(input_file)
+    eng = get_engine()
+    values = eng.wps(src.require(chrom), start, stop, int(chrom_size), int(window_size),
+                     0 if min_length is None else int(min_length), int(max_length), int(quality_threshold))
+    scores = _scores_array(chrom, start, values)
+
+    if isinstance(output_file, str):
+        _write_wig(output_file, chrom, start, stop, scores)
+    elif output_file is not None:
+        raise TypeError(f'output_file is unsupported type "{type(input_file)}". output_file should be a string '
+                        "specifying the path of the file to output scores to.")
+    if verbose:
+        stderr.write(f"wps took {time.time() - t0} s to complete\n")
+    return scores
+
+
+def _write_wig(output_file, chrom, start, stop, scores) -> None:
+    """fixedStep WIG (frag/_wps.py:208-229)."""
+    header = f"fixedStep\tchrom={chrom}\tstart={start}\tstep={1}\tspan={stop - start}\n"
+    body = "".join(f"{score}\n" for score in scores["wps"])
+    if output_file.endswith(".wig.gz"):
+        with gzip.open(output_file, "wt") as out:
+            out.write(header)
+            out.write(body)
+    elif output_file.endswith(".wig"):
+        with open(output_file, "wt") as out:
+            out.write(header)
+            out.write(body)
+    elif output_file == "-":
+        stdout.write(header)
+        stdout.write(body)
+        stdout.flush()
+    else:
+        raise ValueError("output_file can only have suffixes .wig or .wig.gz.")

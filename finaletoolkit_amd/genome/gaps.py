@@ -1,0 +1,135 @@
+"""
+UCSC gap-track lookups used by DELFI: which bins overlap an assembly gap, which
+chromosome arm a bin is on, and the per-contig centromere / telomere constants
+the DELFI kernel tests every fragment against.
+
+Same classes and semantics as the reference's ``genome/gaps.py:40-267``
+(``GenomeGaps``, ``ContigGaps.in_tcmere`` with its deliberate ``all()`` over
+telomeres, ``get_arm``); the bundled tracks are the UCSC hg19 / hg38 ``gap``
+tables reduced to BED4 (``genome/data/*.gaps.bed.gz``).
+"""
+from __future__ import annotations
+
+import gzip
+import os
+from typing import Iterable, Optional, Union
+
+import numpy as np
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+_GAP_DTYPE = [("contig", "<U32"), ("start", "<i8"), ("stop", "<i8"), ("type", "<U32")]
+
+__all__ = ["GenomeGaps", "ContigGaps"]
+
+
+def _read_bed4(path) -> np.ndarray:
+    opener = gzip.open if str(path).endswith(".gz") else open
+    rows = []
+    with opener(path, "rt") as fh:
+        for line in fh:
+            if not line.strip() or line.startswith("#"):
+                continue
+            p = line.split()
+            rows.append((p[0], int(p[1]), int(p[2]), p[3]))
+    return np.array(rows, dtype=_GAP_DTYPE)
+
+
+class GenomeGaps:
+    """Telomere / centromere / short-arm intervals of a reference genome."""
+
+    def __init__(self, gaps_bed: Union[os.PathLike, str, None] = None) -> None:
+        if gaps_bed is None:
+            return
+        if isinstance(gaps_bed, str) and gaps_bed in ("hg19", "b37", "human_g1k_v37", "hg38", "GRCh38") \
+                and not os.path.exists(gaps_bed):
+            named = {"hg19": GenomeGaps.ucsc_hg19, "b37": GenomeGaps.b37, "human_g1k_v37": GenomeGaps.b37,
+                     "hg38": GenomeGaps.hg38, "GRCh38": GenomeGaps.hg38}[gaps_bed]()
+            self._set_gaps(named.gaps)
+            return
+        self._set_gaps(_read_bed4(gaps_bed))
+
+    def _set_gaps(self, gaps: np.ndarray) -> None:
+        self.centromeres = gaps[gaps["type"] == "centromere"]
+        self.telomeres = gaps[gaps["type"] == "telomere"]
+        self.short_arms = gaps[gaps["type"] == "short_arm"]
+        self.gaps = gaps
+
+    @classmethod
+    def _from_track(cls, name: str, strip_chr: bool = False) -> "GenomeGaps":
+        g = cls()
+        gaps = _read_bed4(os.path.join(_DATA, f"{name}.gaps.bed.gz"))
+        if strip_chr:
+            gaps["contig"] = np.char.replace(gaps["contig"], "chr", "")
+        g._set_gaps(gaps)
+        return g
+
+    @classmethod
+    def ucsc_hg19(cls) -> "GenomeGaps":
+        return cls._from_track("hg19")
+
+    @classmethod
+    def b37(cls) -> "GenomeGaps":
+        return cls._from_track("hg19", strip_chr=True)
+
+    @classmethod
+    def hg38(cls) -> "GenomeGaps":
+        return cls._from_track("hg38")
+
+    def get_contig_gaps(self, contig: str) -> Optional["ContigGaps"]:
+        """genome/gaps.py:157-169: ``None`` when the contig has no centromere row."""
+        cen = self.centromeres[self.centromeres["contig"] == contig]
+        if cen.shape[0] == 0:
+            return None
+        tel = self.telomeres[self.telomeres["contig"] == contig]
+        short_arm = self.short_arms[self.short_arms["contig"] == contig]
+        return ContigGaps(contig, (int(cen[0]["start"]), int(cen[0]["stop"])),
+                          [(int(t["start"]), int(t["stop"])) for t in tel], short_arm.shape[0] > 0)
+
+    def to_bed(self, output_file) -> None:
+        gaps = np.sort(self.gaps)
+        lines = "".join(f"{g['contig']}\t{g['start']}\t{g['stop']}\t{g['type']}\n" for g in gaps)
+        if str(output_file).endswith(".gz"):
+            with gzip.open(output_file, "wt") as out:
+                out.write(lines)
+        elif str(output_file) == "-":
+            import sys
+            sys.stdout.write(lines)
+        else:
+            with open(output_file, "w") as out:
+                out.write(lines)
+
+
+class ContigGaps:
+    """Centromere / telomere intervals of one contig (genome/gaps.py:202-267)."""
+
+    def __init__(self, contig: str, centromere: tuple[int, int], telomeres: Iterable[tuple[int, int]],
+                 has_short_arm: bool = False) -> None:
+        self.contig = contig
+        self.centromere = centromere
+        self.telomeres = list(telomeres)
+        self.has_short_arm = has_short_arm
+
+    def in_tcmere(self, start: int, stop: int) -> bool:
+        """Overlaps the centromere, or overlaps EVERY telomere (the reference's
+        ``all()``, kept because its DELFI outputs were produced with it)."""
+        in_centromere = stop > self.centromere[0] and start < self.centromere[1]
+        if not self.telomeres:
+            in_telomeres = False
+        else:
+            in_telomeres = all(stop > t[0] and start < t[1] for t in self.telomeres)
+        return in_centromere or in_telomeres
+
+    def get_arm(self, start: int, stop: int) -> str:
+        if stop < start:
+            raise ValueError("start must be less than stop")
+        if stop < self.centromere[0]:
+            if not self.has_short_arm:
+                return f"{self.contig.replace('chr', '')}p"
+            return "NOARM"
+        if start > self.centromere[1]:
+            return f"{self.contig.replace('chr', '')}q"
+        return "NOARM"
+
+    def as_kernel_constants(self):
+        """(cen_start, cen_stop, [(t0, t1), ...]) for ``ftk_gaps``."""
+        return (self.centromere[0], self.centromere[1], list(self.telomeres))

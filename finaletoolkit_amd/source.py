@@ -1,0 +1,194 @@
+"""
+Fragment sources: open a BAM / tabix-indexed fragment file once, decode it with
+the C++ decoders (``csrc/ftk_decode.cpp``) and keep every contig's SoA resident
+in HBM on the process-wide :class:`Engine`.
+
+This is the counterpart of the reference's ``AlignmentWrapper``
+(``src/finaletoolkit/io/alignment.py:74-302``): same accepted inputs by
+extension, same index-presence checks and exception types, same BED6 warning --
+but instead of handing out a per-window Python iterator it hands out contigs
+that are already on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import warnings
+from collections import OrderedDict
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+from .engine import Engine
+from .exceptions import MissingIndexError, UnsupportedFormatError
+
+_ENGINE: Optional[Engine] = None
+_SOURCES: "OrderedDict[tuple, FragSource]" = OrderedDict()
+_MAX_SOURCES = 4
+_NEXT_ID = 0
+
+
+def get_engine() -> Engine:
+    """Process-wide engine on ``FTK_DEVICE`` (else ``LOCAL_RANK``, else 0)."""
+    global _ENGINE
+    if _ENGINE is None:
+        dev = int(os.environ.get("FTK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _ENGINE = Engine(dev)
+    return _ENGINE
+
+
+def decode_threads(workers: int | None = None) -> int:
+    if workers and workers > 0:
+        return int(workers)
+    return max(1, min(16, os.cpu_count() or 1))
+
+
+class FragSource:
+    """One decoded input file; contig ``c`` lives on the engine as ``key(c)``."""
+
+    def __init__(self, path: str, is_bam: bool, bed6: bool, contigs, lengths, uid: int):
+        self.path = path
+        self.is_bam = is_bam
+        self.bed6 = bed6
+        self.contigs = list(contigs)              # file order
+        self.lengths = dict(lengths)              # name -> length (BAM) / None
+        self.uid = uid
+        self.loaded = set()
+
+    def key(self, contig: str) -> str:
+        return f"{self.uid}:{contig}"
+
+    @property
+    def chroms(self):
+        return {c: self.lengths.get(c) for c in self.contigs}
+
+    def require(self, contig: str) -> str:
+        """Engine key of ``contig``; ValueError if the file has no such contig
+        (pysam raises ValueError for an unknown region, which the reference
+        lets propagate)."""
+        if contig not in self.loaded:
+            raise ValueError(f"could not create iterator for region '{contig}': contig not present in {self.path}")
+        return self.key(contig)
+
+    def release(self):
+        eng = get_engine()
+        for c in list(self.loaded):
+            if eng.has_contig(self.key(c)):
+                eng.release(self.key(c))
+        self.loaded.clear()
+
+
+def _check_path(input_file) -> tuple[str, bool]:
+    """Mirror AlignmentWrapper.__init__/_open_file (io/alignment.py:103-203)."""
+    if not isinstance(input_file, (str, Path)):
+        raise UnsupportedFormatError(
+            "finaletoolkit_amd reads BAM and tabix-indexed fragment files by path; "
+            f"open pysam handles are not supported (got {type(input_file).__name__})")
+    path = str(input_file)
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"Alignment file not found: {input_file}")
+    lower = path.lower()
+    if lower.endswith((".bam", ".cram", ".sam")):
+        if lower.endswith(".bam"):
+            if not (os.path.exists(path + ".bai") or os.path.exists(path[:-4] + ".bai")):
+                raise MissingIndexError(f"BAM file {path} missing index (.bai)")
+            return path, True
+        if lower.endswith(".cram"):
+            if not (os.path.exists(path + ".crai") or os.path.exists(path[:-5] + ".crai")):
+                raise MissingIndexError(f"CRAM file {path} missing index (.crai)")
+        raise UnsupportedFormatError(
+            f"{path}: CRAM/SAM decoding needs htslib codecs and is not implemented in finaletoolkit_amd; "
+            "convert to BAM or a fragment file")
+    if lower.endswith((".gz", ".bgz")):
+        if not os.path.exists(path + ".tbi"):
+            raise MissingIndexError(f"Compressed file {path} missing tabix index (.tbi)")
+        return path, False
+    raise UnsupportedFormatError(f"Unsupported file format: {path}")
+
+
+def _columns(lib, table, i, rows):
+    ps = [C.c_void_p() for _ in range(6)]
+    rc = lib.ftk_fragtable_columns(table, i, *[C.byref(p) for p in ps])
+    if rc != L.FTK_OK:
+        raise L.FtkError(rc, lib.ftk_fragtable_error().decode())
+
+    def arr(p, ctype):
+        if not p.value or rows == 0:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(ctype)), (rows,))
+
+    return (arr(ps[0], C.c_int32), arr(ps[1], C.c_int32), arr(ps[2], C.c_uint8), arr(ps[3], C.c_uint8),
+            arr(ps[4], C.c_int32), arr(ps[5], C.c_int32))
+
+
+def open_source(input_file, workers: int | None = None, warn_bed6: bool = True) -> FragSource:
+    """Decode ``input_file`` (cached by path/mtime/size) and upload its contigs."""
+    global _NEXT_ID
+    path, is_bam = _check_path(input_file)
+    st = os.stat(path)
+    ckey = (os.path.abspath(path), st.st_mtime_ns, st.st_size)
+    src = _SOURCES.get(ckey)
+    if src is not None:
+        _SOURCES.move_to_end(ckey)
+        if src.bed6 and warn_bed6:
+            _warn_bed6()
+        return src
+    eng = get_engine()  # fails loudly without the HIP library / a GPU
+    lib = L.load()
+    table = C.c_void_p()
+    fn = lib.ftk_bam_decode if is_bam else lib.ftk_fragfile_decode
+    rc = fn(path.encode(), None, decode_threads(workers), C.byref(table))
+    if rc != L.FTK_OK:
+        msg = lib.ftk_fragtable_error().decode()
+        if rc == L.FTK_ERR_IO:
+            raise FileNotFoundError(msg)
+        raise UnsupportedFormatError(msg)
+    try:
+        n = lib.ftk_fragtable_n_contigs(table)
+        names = [lib.ftk_fragtable_contig_name(table, i).decode() for i in range(n)]
+        lengths = {names[i]: (lib.ftk_fragtable_contig_length(table, i) if is_bam else None) for i in range(n)}
+        src = FragSource(path, is_bam, bool(lib.ftk_fragtable_is_bed6(table)), names, lengths, _NEXT_ID)
+        _NEXT_ID += 1
+        z32, z8 = np.zeros(0, np.int32), np.zeros(0, np.uint8)
+        for i, name in enumerate(names):
+            rows = lib.ftk_fragtable_contig_rows(table, i)
+            if rows == 0:
+                if not is_bam:
+                    continue
+                eng.load_contig(src.key(name), z32, z32, z8, z8, z32, z32)
+            else:
+                s, e, q, stn, r1s, r1e = _columns(lib, table, i, rows)
+                eng.load_contig(src.key(name), s, e, q, stn, r1s if is_bam else None, r1e if is_bam else None)
+            src.loaded.add(name)
+    finally:
+        lib.ftk_fragtable_free(table)
+    _SOURCES[ckey] = src
+    while len(_SOURCES) > _MAX_SOURCES:
+        _, old = _SOURCES.popitem(last=False)
+        old.release()
+    if src.bed6 and warn_bed6:
+        _warn_bed6()
+    return src
+
+
+def _warn_bed6():
+    # io/alignment.py:148-154
+    warnings.warn(
+        "input_file does not follow Fragmentation file format accepted by FinaleToolkit. "
+        "Attempting to read as a BED6 file.", UserWarning)
+
+
+def close_all():
+    """Drop every cached source and the engine (tests / long-running hosts)."""
+    global _ENGINE
+    for src in list(_SOURCES.values()):
+        try:
+            src.release()
+        except Exception:
+            pass
+    _SOURCES.clear()
+    if _ENGINE is not None:
+        _ENGINE.close()
+        _ENGINE = None

@@ -1,0 +1,134 @@
+"""
+Host-side helpers of the hot path with the reference's names and semantics
+(``src/finaletoolkit/utils/utils.py`` and ``utils/_frag_generator.py``):
+chrom.sizes / BED readers, ``overlaps``, and the fragment stream
+(``frag_generator`` / ``frag_array``), which here is a device-side ordered
+selection (``ftk_frag_select``) instead of a per-row Python predicate.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Generator, Tuple
+
+import numpy as np
+
+from .exceptions import InvalidInputError
+from .source import get_engine, open_source
+
+__all__ = ["chrom_sizes_to_list", "chrom_sizes_to_dict", "get_intervals", "overlaps", "frag_generator",
+           "frag_array"]
+
+FragTuple = Tuple[str, int, int, int, bool]
+
+
+def chrom_sizes_to_list(chrom_sizes_file) -> list[tuple[str, int]]:
+    """utils/utils.py:53-73."""
+    out = []
+    with open(chrom_sizes_file, "r") as fh:
+        for line in fh:
+            if line != "\n":
+                chrom, size = line.strip().split("\t")
+                out.append((chrom, int(size)))
+    return out
+
+
+def chrom_sizes_to_dict(chrom_sizes_file) -> dict[str, int]:
+    """utils/utils.py:76-94."""
+    return dict(chrom_sizes_to_list(chrom_sizes_file))
+
+
+def get_intervals(interval_file) -> list[tuple[str, int, int, str]]:
+    """BED reader (utils/utils.py:310-343): skips ``#``/``track``/``browser``/blank
+    lines and rows with < 3 columns; missing name -> ``'.'``."""
+    intervals = []
+    with open(interval_file, "r") as bed:
+        for line in bed:
+            if line.startswith(("#", "track", "browser")) or not line.strip():
+                continue
+            parts = line.strip().split("\t")
+            if len(parts) < 3:
+                continue
+            intervals.append((parts[0], int(parts[1]), int(parts[2]), parts[3] if len(parts) > 3 else "."))
+    return intervals
+
+
+def overlaps(contigs_1, starts_1, stops_1, contigs_2, starts_2, stops_2):
+    """Does each interval of set 1 overlap any interval of set 2 on the same
+    contig?  (utils/utils.py:346-382; grouped by contig instead of an
+    n1 x n2 broadcast.)"""
+    contigs_1 = np.asarray(contigs_1)
+    starts_1 = np.asarray(starts_1)
+    stops_1 = np.asarray(stops_1)
+    contigs_2 = np.asarray(contigs_2)
+    starts_2 = np.asarray(starts_2)
+    stops_2 = np.asarray(stops_2)
+    out = np.zeros(contigs_1.shape[0], dtype=bool)
+    for c in np.unique(contigs_1):
+        m1 = contigs_1 == c
+        m2 = contigs_2 == c
+        if not m2.any():
+            continue
+        s1 = starts_1[m1][:, None]
+        e1 = stops_1[m1][:, None]
+        out[m1] = np.any((s1 < stops_2[m2][None]) & (e1 > starts_2[m2][None]), axis=1)
+    return out
+
+
+def _check_policy(intersect_policy: str):
+    if intersect_policy not in ("midpoint", "any"):
+        raise InvalidInputError(f"{intersect_policy} is not a valid policy")
+
+
+def _check_region(contig, start, stop):
+    # utils/_frag_generator.py:105-110
+    if contig is None and not (start is None and stop is None):
+        if not (start == 0 and stop is None):
+            raise InvalidInputError("contig should be specified if start or stop given.")
+
+
+def _region_contigs(src, contig):
+    """Contigs a fetch(contig, ...) touches, in file order, with their bounds
+    semantics: ``contig=None`` iterates the whole file and pysam ignores
+    start/stop (io/alignment.py:245,273-279)."""
+    if contig is None:
+        return [c for c in src.contigs if c in src.loaded], True
+    return [contig], False
+
+
+def frag_generator(input_file, contig, quality_threshold: int = 30, start=None, stop=None, min_length=None,
+                   max_length=None, intersect_policy: str = "midpoint", verbose=False,
+                   reference_file=None) -> Generator[FragTuple, None, None]:
+    """Stream ``(contig, start, stop, mapq, is_forward)`` of the fragments
+    passing the shared predicate (utils/_frag_generator.py:58-141)."""
+    _check_policy(intersect_policy)
+    _check_region(contig, start, stop)
+    src = open_source(input_file)
+    eng = get_engine()
+    names, whole = _region_contigs(src, contig)
+    for c in names:
+        key = src.require(c)
+        s, e, q, st = eng.frag_select(key, None if whole else start, None if whole else stop, quality_threshold,
+                                      min_length, max_length, intersect_policy)
+        for i in range(len(s)):
+            yield (c, int(s[i]), int(e[i]), int(q[i]), bool(st[i]))
+
+
+def frag_array(input_file, contig: str, quality_threshold: int = 30, start=None, stop=None, min_length=None,
+               max_length=None, intersect_policy: str = "midpoint", verbose: bool = False, reference_file=None):
+    """Structured ``[('start','i8'),('stop','i8'),('strand','?')]`` array of the
+    passing fragments (utils/utils.py:186-255)."""
+    _check_policy(intersect_policy)
+    _check_region(contig, start, stop)
+    src = open_source(input_file)
+    eng = get_engine()
+    names, whole = _region_contigs(src, contig)
+    parts = []
+    for c in names:
+        s, e, _, st = eng.frag_select(src.require(c), None if whole else start, None if whole else stop,
+                                      quality_threshold, min_length, max_length, intersect_policy)
+        a = np.zeros(len(s), dtype=[("start", "i8"), ("stop", "i8"), ("strand", "?")])
+        a["start"], a["stop"], a["strand"] = s, e, st.astype(bool)
+        parts.append(a)
+    if not parts:
+        return np.zeros(0, dtype=[("start", "i8"), ("stop", "i8"), ("strand", "?")])
+    return np.concatenate(parts)
