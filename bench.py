@@ -28,22 +28,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from finaletoolkit_amd import synth  # noqa: E402
+from finaletoolkit_amd.sharding import lpt_assign  # noqa: E402
 
 WINDOW = 100_000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 HIST_BINS = 1001
 WPS_W, WPS_MIN, WPS_MAX, MAPQ = 120, 120, 180, 30
-
-
-def lpt_assign(sizes: dict, n_ranks: int):
-    """Longest-processing-time greedy: contigs -> ranks."""
-    loads = [0] * n_ranks
-    owner = {}
-    for name in sorted(sizes, key=lambda k: -sizes[k]):
-        r = loads.index(min(loads))
-        owner[name] = r
-        loads[r] += sizes[name]
-    return owner
 
 
 def gen_contig_device(torch, dev, contig_len, n, seed):

@@ -1,0 +1,80 @@
+"""
+Multi-GPU sharding of the hot path: one process per GPU, contigs assigned to
+ranks by longest-processing-time greedy (every window / bin / base depends only
+on the fragments of its own contig, so no data-path collective is needed), and
+one all-gather of the fixed-size per-bin vectors so every rank ends up with the
+whole-genome DELFI / coverage vector in contig order.  ``torch.distributed``
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests) is the
+transport; payloads are a few hundred KB, i.e. latency-bound.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import numpy as np
+
+
+def lpt_assign(weights: Dict[str, float], n_ranks: int) -> Dict[str, int]:
+    """Longest-processing-time greedy: heaviest contig first onto the least loaded rank."""
+    loads = [0.0] * n_ranks
+    owner = {}
+    for name in sorted(weights, key=lambda k: (-weights[k], k)):
+        r = loads.index(min(loads))
+        owner[name] = r
+        loads[r] += weights[name]
+    return owner
+
+
+def shard_contigs(names: Sequence[str], weights: Dict[str, float], rank: int, world: int) -> List[str]:
+    owner = lpt_assign({n: weights[n] for n in names}, world)
+    return [n for n in names if owner[n] == rank]
+
+
+def gather_bin_vectors(local: Dict[str, np.ndarray], names: Sequence[str], n_bins: Dict[str, int],
+                       weights: Dict[str, float], group=None, device=None) -> Dict[str, np.ndarray]:
+    """All-gather per-contig integer vectors (shape [n_bins[c], k]) so every rank
+    holds all contigs.  ``local`` has this rank's contigs; ``n_bins`` the row
+    count of EVERY contig (known from the bin file on all ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return dict(local)
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    owner = lpt_assign({n: weights[n] for n in names}, world)
+    k = next((v.shape[1] for v in local.values()), None)
+    ks = [None] * world
+    dist.all_gather_object(ks, k, group=group)
+    k = next(x for x in ks if x is not None)
+    rows = [sum(n_bins[n] for n in names if owner[n] == r) for r in range(world)]
+    pad = max(rows)
+    send = torch.zeros((pad, k), dtype=torch.int64)
+    off = 0
+    for n in names:
+        if owner[n] == rank:
+            send[off:off + n_bins[n]] = torch.from_numpy(np.ascontiguousarray(local[n], dtype=np.int64))
+            off += n_bins[n]
+    if device is not None:
+        send = send.to(device)
+    recv = [torch.zeros_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    out = {}
+    offs = [0] * world
+    for n in names:
+        r = owner[n]
+        out[n] = recv[r][offs[r]:offs[r] + n_bins[n]].cpu().numpy()
+        offs[r] += n_bins[n]
+    return out
+
+
+def allreduce_sum(value: int, group=None, device=None) -> int:
+    """Sum of one int64 over ranks (the genome-wide total of ``coverage(normalize=True)``)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
