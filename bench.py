@@ -108,7 +108,10 @@ def main():
     mine = [c for c in names if owner[c] == rank]
 
     eng = Engine(local)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    # one explicit stream for torch ops, RCCL and the ftk launches (a NULL handle would mean "ctx's own stream")
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    eng.set_stream(stream.cuda_stream)
 
     # ---- resident inputs (untimed) -------------------------------------------
     t_load = time.time()

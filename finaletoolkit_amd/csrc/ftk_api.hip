@@ -237,7 +237,7 @@ size_t window_scratch_bytes(int64_t n_win) {
 }
 
 int window_prepare(ftk_ctx* ctx, ContigData* c, Arena& a, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
-                   int lmax, int small_max, WindowCall* wc) {
+                   int lmax, int small_max, WindowCall* wc, int64_t* zero1 = nullptr, int64_t* zero2 = nullptr) {
     int32_t* b_ws = a.take<int32_t>(n_win);
     int32_t* b_we = a.take<int32_t>(n_win);
     wc->plan.cand_lo = a.take<int32_t>(n_win);
@@ -248,7 +248,7 @@ int window_prepare(ftk_ctx* ctx, ContigData* c, Arena& a, const int32_t* w_start
     if (rc) return rc;
     rc = stage_in(ctx, w_end, n_win, b_we, &wc->d_we);
     if (rc) return rc;
-    launch_plan(ctx->stream, c->v, wc->d_ws, wc->d_we, (int)n_win, lmax, small_max, wc->plan);
+    launch_plan(ctx->stream, c->v, wc->d_ws, wc->d_we, (int)n_win, lmax, small_max, wc->plan, zero1, zero2);
     return FTK_OK;
 }
 
@@ -437,8 +437,8 @@ int ftk_window_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const
     if ((rc = reserve_scratch(ctx, need))) return rc;
     Arena a(ctx);
     WindowCall wc;
-    if ((rc = window_prepare(ctx, c, a, w_start, w_end, n_win, eff_lmax(f, *c), kSmallMax, &wc))) return rc;
     int64_t* d_out = out_dev ? count_out : a.take<int64_t>(n_win);
+    if ((rc = window_prepare(ctx, c, a, w_start, w_end, n_win, eff_lmax(f, *c), kSmallMax, &wc, d_out))) return rc;
     launch_window_counts(ctx->stream, ctx->n_cu * 8, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, *f, d_out);
     HIPCHK(ctx, hipGetLastError());
     if (!out_dev) {
@@ -499,9 +499,10 @@ int ftk_delfi_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const 
     Arena a(ctx);
     WindowCall wc;
     ftk_filter f{mapq_min, 100, 220, FTK_POLICY_MIDPOINT, c->v.r1_start ? FTK_FETCH_BAM_READ1 : FTK_FETCH_TABIX};
-    if ((rc = window_prepare(ctx, c, a, w_start, w_end, n_win, eff_lmax(&f, *c), kSmallMax, &wc))) return rc;
     int64_t* d_short = s_dev ? short_out : a.take<int64_t>(n_win);
     int64_t* d_long = l_dev ? long_out : a.take<int64_t>(n_win);
+    if ((rc = window_prepare(ctx, c, a, w_start, w_end, n_win, eff_lmax(&f, *c), kSmallMax, &wc, d_short, d_long)))
+        return rc;
     int32_t *d_off = nullptr, *d_r0 = nullptr, *d_pm = nullptr;
     if (use_bl) {
         d_off = a.take<int32_t>(n_win + 1);

@@ -37,7 +37,7 @@ struct WpsParams {
 void launch_stats(hipStream_t s, const int32_t* start, const int32_t* end, int n, FragStats* st);
 void launch_bin_index(hipStream_t s, const int32_t* start, int n, int n_bins, int32_t* idx);
 void launch_plan(hipStream_t s, const ContigView& cv, const int32_t* ws, const int32_t* we, int n_win, int lmax,
-                 int small_max, const WindowPlan& pl);
+                 int small_max, const WindowPlan& pl, int64_t* zero1, int64_t* zero2);
 void launch_window_counts(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
                           int n_win, const WindowPlan& pl, const ftk_filter& f, int64_t* out);
 void launch_delfi_counts(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,

@@ -81,19 +81,39 @@ __global__ void bin_index_kernel(const int32_t* start, int n, int n_bins, int32_
 // ---------------------------------------------------------------------------
 // A fragment can only pass a window [ws, we) (either policy, and the tabix
 // overlap query itself) if fs < we and fe > ws - 1, hence
-// ws - lmax <= fs < we with lmax = longest admissible fragment.
+// ws - lmax <= fs < we with lmax = longest admissible fragment.  The range is
+// taken straight from the 512-bp index (conservative by < 1 bin on each side;
+// the predicate decides), so planning costs two index reads per window and no
+// dependent bisection.
+__device__ __forceinline__ void window_candidates(const ContigView& cv, int s, int e, int lmax, int small_max, int& lo,
+                                                  int& hi, uint32_t& nchunks) {
+    const long long ql = (long long)s - lmax;
+    if (s == INT32_MIN || ql <= 0) lo = 0;
+    else { const long long k = ql >> kBinShift; lo = k >= cv.n_bins ? cv.n : cv.bin_idx[k]; }
+    if (e == INT32_MAX) hi = cv.n;
+    else if (e <= 0) hi = 0;
+    else { const long long k = (long long)e >> kBinShift; hi = k >= cv.n_bins ? cv.n : cv.bin_idx[k + 1]; }
+    lo &= ~3;  // chunks then start on 16-byte boundaries of the columns
+    if (hi < lo || e < s) hi = lo;
+    const int cnt = hi - lo;
+    nchunks = (cnt <= small_max) ? 0u : (uint32_t)((cnt + kChunk - 1) / kChunk);
+}
+
 __global__ void bounds_kernel(ContigView cv, const int32_t* ws, const int32_t* we, int n_win, int lmax,
-                              int small_max, int32_t* cand_lo, int32_t* cand_hi, uint32_t* nchunks) {
+                              int small_max, int32_t* cand_lo, int32_t* cand_hi, uint32_t* nchunks, int64_t* zero1,
+                              int64_t* zero2) {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_win) return;
-    int s = ws[w], e = we[w];
-    int lo = (s == INT32_MIN) ? 0 : lower_bound_start(cv, (long long)s - lmax);
-    int hi = (e == INT32_MAX) ? cv.n : lower_bound_start(cv, (long long)e);
-    if (hi < lo || e < s) hi = lo;
+    int lo, hi;
+    uint32_t nc;
+    window_candidates(cv, ws[w], we[w], lmax, small_max, lo, hi, nc);
     cand_lo[w] = lo;
     cand_hi[w] = hi;
-    int cnt = hi - lo;
-    nchunks[w] = (cnt <= small_max) ? 0u : (uint32_t)((cnt + kChunk - 1) / kChunk);
+    nchunks[w] = nc;
+    if (nc) {  // the chunked path accumulates with atomics: start from zero
+        if (zero1) zero1[w] = 0;
+        if (zero2) zero2[w] = 0;
+    }
 }
 
 // Exclusive scan of nchunks[0..n) into off[0..n]; one 1024-thread block.
@@ -122,6 +142,48 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* nchunks, int
         __syncthreads();
     }
     if (tid == 0) off[n] = carry_s;
+}
+
+// Candidate ranges + chunk offsets in ONE single-block launch (n_win up to a
+// few thousand per contig is the common case: saves two dependent launches).
+__global__ __launch_bounds__(1024) void plan_kernel(ContigView cv, const int32_t* ws, const int32_t* we, int n_win,
+                                                    int lmax, int small_max, int32_t* cand_lo, int32_t* cand_hi,
+                                                    uint32_t* nchunks, uint32_t* off, int64_t* zero1, int64_t* zero2) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n_win; base += 1024) {
+        const int w = base + tid;
+        uint32_t v = 0;
+        if (w < n_win) {
+            int lo, hi;
+            window_candidates(cv, ws[w], we[w], lmax, small_max, lo, hi, v);
+            cand_lo[w] = lo;
+            cand_hi[w] = hi;
+            nchunks[w] = v;
+            if (v) {
+                if (zero1) zero1[w] = 0;
+                if (zero2) zero2[w] = 0;
+            }
+        }
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wave_tot[wv] = x;
+        __syncthreads();
+        uint32_t pre = carry_s;
+        for (int j = 0; j < wv; ++j) pre += wave_tot[j];
+        if (w < n_win) off[w] = pre + x - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = pre + x;
+        __syncthreads();
+    }
+    if (tid == 0) off[n_win] = carry_s;
 }
 
 // ---------------------------------------------------------------------------
@@ -262,18 +324,34 @@ __global__ __launch_bounds__(256) void count_large_kernel(ContigView cv, const i
         for (; c < c_end; ++c) {
             const int lo = wlo + (int)(c - w_first) * kChunk;
             const int hi = min(lo + kChunk, whi);
-            for (int i = (lo & ~3) + 4 * tid; i < hi; i += 1024) {
-                const int4 s = *reinterpret_cast<const int4*>(cv.start + i);
-                const int4 e = *reinterpret_cast<const int4*>(cv.end + i);
-                const uchar4 q = *reinterpret_cast<const uchar4*>(cv.mapq + i);
-                const int ss[4] = {s.x, s.y, s.z, s.w}, ee[4] = {e.x, e.y, e.z, e.w}, qq[4] = {q.x, q.y, q.z, q.w};
+            // a whole chunk (4 x 1024 fragments) is requested before any of it is used
+            const int i0 = (lo & ~3) + 4 * tid;
+            int4 s4[4], e4[4];
+            uchar4 q4[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int idx = i + j;
-                    if (idx >= lo && idx < hi) {
-                        int r = pred(cv, idx, ss[j], ee[j], qq[j], ws, we, w);
-                        a1 += (r == 1);
-                        a2 += (r == 2);
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 1024;
+                if (i < hi) {
+                    s4[u] = *reinterpret_cast<const int4*>(cv.start + i);
+                    e4[u] = *reinterpret_cast<const int4*>(cv.end + i);
+                    q4[u] = *reinterpret_cast<const uchar4*>(cv.mapq + i);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 1024;
+                if (i < hi) {
+                    const int ss[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w};
+                    const int ee[4] = {e4[u].x, e4[u].y, e4[u].z, e4[u].w};
+                    const int qq[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int idx = i + j;
+                        if (idx >= lo && idx < hi) {
+                            const int r = pred(cv, idx, ss[j], ee[j], qq[j], ws, we, w);
+                            a1 += (r == 1);
+                            a2 += (r == 2);
+                        }
                     }
                 }
             }
@@ -291,16 +369,6 @@ __global__ __launch_bounds__(256) void count_large_kernel(ContigView cv, const i
         }
         __syncthreads();
         a1 = 0; a2 = 0;
-    }
-}
-
-// zero the outputs of the windows the chunked path owns
-__global__ void zero_large_kernel(const uint32_t* nchunks, int n_win, int64_t* out1, int64_t* out2) {
-    int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_win) return;
-    if (nchunks[w] != 0) {
-        out1[w] = 0;
-        if (out2) out2[w] = 0;
     }
 }
 
@@ -382,17 +450,32 @@ __global__ __launch_bounds__(256) void hist_large_kernel(ContigView cv, const in
         for (; c < c_end; ++c) {
             const int lo = wlo + (int)(c - w_first) * kChunk;
             const int hi = min(lo + kChunk, whi);
-            for (int i = (lo & ~3) + 4 * tid; i < hi; i += 1024) {
-                const int4 s = *reinterpret_cast<const int4*>(cv.start + i);
-                const int4 e = *reinterpret_cast<const int4*>(cv.end + i);
-                const uchar4 q = *reinterpret_cast<const uchar4*>(cv.mapq + i);
-                const int ss[4] = {s.x, s.y, s.z, s.w}, ee[4] = {e.x, e.y, e.z, e.w}, qq[4] = {q.x, q.y, q.z, q.w};
+            const int i0 = (lo & ~3) + 4 * tid;
+            int4 s4[4], e4[4];
+            uchar4 q4[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int idx = i + j;
-                    if (idx >= lo && idx < hi && pred(cv, idx, ss[j], ee[j], qq[j], ws, we, w)) {
-                        int b = (ee[j] - ss[j]) - len_lo;
-                        if (b >= 0 && b < n_bins) atomicAdd(&lds_hist[b], 1u); else ++over;
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 1024;
+                if (i < hi) {
+                    s4[u] = *reinterpret_cast<const int4*>(cv.start + i);
+                    e4[u] = *reinterpret_cast<const int4*>(cv.end + i);
+                    q4[u] = *reinterpret_cast<const uchar4*>(cv.mapq + i);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 1024;
+                if (i < hi) {
+                    const int ss[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w};
+                    const int ee[4] = {e4[u].x, e4[u].y, e4[u].z, e4[u].w};
+                    const int qq[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int idx = i + j;
+                        if (idx >= lo && idx < hi && pred(cv, idx, ss[j], ee[j], qq[j], ws, we, w)) {
+                            const int b = (ee[j] - ss[j]) - len_lo;
+                            if (b >= 0 && b < n_bins) atomicAdd(&lds_hist[b], 1u); else ++over;
+                        }
                     }
                 }
             }
@@ -416,7 +499,7 @@ __global__ __launch_bounds__(256) void hist_large_kernel(ContigView cv, const in
 }
 
 // ---------------------------------------------------------------------------
-// WPS (frag/_wps.py:25-53,156-188): LDS difference array + LDS scan per tile
+// WPS (frag/_wps.py:25-53,156-188): LDS difference array + scan per tile
 // ---------------------------------------------------------------------------
 // Window of "virtual" position v is [v - hl, v + hr].  Even W: hl = W/2,
 // hr = W/2 - 1 and every base is its own virtual position.  Odd W = 2k+1:
@@ -425,129 +508,214 @@ __global__ __launch_bounds__(256) void hist_large_kernel(ContigView cv, const in
 // is odd.  A fragment [fs, fe) contributes -1 on [fs-hr, fs+hl] and
 // [fe-hr, fe+hl] (start / stop inside the window; one interval when they
 // touch or overlap) and +1 on [fs+hl+1, fe-hr-1] (spanning).
-__global__ __launch_bounds__(256) void wps_kernel(ContigView cv, WpsParams p, const int64_t* iv_start_,
-                                                  const int64_t* iv_stop_, const int64_t* out_off_,
-                                                  const int32_t* tile_iv, const int32_t* tile_k,
-                                                  int64_t* __restrict__ out) {
-    constexpr int T = kWpsTile;
-    __shared__ int d[T];
-    __shared__ int pre_s;       // sum of events left of the tile
-    __shared__ int rng[2];      // candidate fragment range
-    __shared__ int wtot[4][4];  // [pass][wave] totals
+// Kernel shape: blocks walk a few consecutive 4096-base tiles; the next tile's
+// fragments are prefetched into registers while the current tile's scores
+// stream out; the wave scan runs on DPP (no LDS traffic); every lane owns two
+// adjacent bases of each 128-base half so each store instruction writes 1 KB
+// contiguously (measured +18 % over 32-byte-strided stores).
+// inclusive scan across the 64 lanes of a wave (row_shr 1/2/4/8 inside rows of
+// 16, then row_bcast:15 / row_bcast:31 across rows)
+__device__ __forceinline__ int wave_incl_scan_dpp(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+
+struct WpsTile {
+    long long t0;        // first base
+    long long fmin, fmax;  // fetch window of the owning interval (frag/_wps.py:156-157)
+    long long out_base;  // index of t0's score in the output
+    int len_t;           // bases in the tile (<= kWpsTile)
+};
+
+constexpr int kWpsPrefetch = 4;  // fragments per thread held in registers for the next tile
+
+__global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParams p, const int64_t* iv_start_,
+                                                         const int64_t* iv_stop_, const int64_t* out_off_,
+                                                         const int32_t* tile_iv, const int32_t* tile_k,
+                                                         long long n_tiles, int tiles_per_block,
+                                                         int64_t* __restrict__ out) {
+    constexpr int T = kWpsTile, NP = T / 1024, PF = kWpsPrefetch;
+    __shared__ __attribute__((aligned(16))) int d[T];
+    __shared__ int pre_s[2];
+    __shared__ int rng_s[2];
+    __shared__ int wtot[NP][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-
-    long long iv_start, iv_stop, out_off, k;
-    if (tile_iv) {
-        int iv = tile_iv[blockIdx.x];
-        iv_start = iv_start_[iv]; iv_stop = iv_stop_[iv]; out_off = out_off_[iv];
-        k = tile_k[blockIdx.x];
-    } else {
-        iv_start = p.start; iv_stop = p.stop; out_off = 0; k = blockIdx.x;
-    }
-    const long long t0 = iv_start + k * T;                   // first base of the tile
-    const long long t1 = min(t0 + (long long)T, iv_stop);    // one past the last base
-    const int len_t = (int)(t1 - t0);
-    // fetch window of the interval (frag/_wps.py:156-157)
-    long long fmin = iv_start - p.max_len; if (fmin < 0) fmin = 0;
-    long long fmax = iv_stop + p.max_len; if (fmax > p.chrom_size) fmax = p.chrom_size;
-
     const int hl = p.hl, hr = p.hr;
-    if (tid < 2) {
-        // candidates: fs - hr <= t1 - 1 and fe + hl >= t0 - 1  (=> fs >= t0 - 1 - hl - lmax)
-        long long q = (tid == 0) ? (t0 - 1 - hl - (long long)p.lmax) : (t1 + hr);
-        rng[tid] = lower_bound_start(cv, q);
-    }
-    if (tid == 2) pre_s = 0;
+
+    const long long tfirst = (long long)blockIdx.x * tiles_per_block;
+    const long long tlast = min(tfirst + (long long)tiles_per_block, n_tiles);
+    if (tfirst >= tlast) return;
+
+    auto tile_info = [&](long long t) {
+        WpsTile ti;
+        long long iv_start, iv_stop, out_off, k;
+        if (tile_iv) {
+            const int iv = tile_iv[t];
+            iv_start = iv_start_[iv]; iv_stop = iv_stop_[iv]; out_off = out_off_[iv]; k = tile_k[t];
+        } else {
+            iv_start = p.start; iv_stop = p.stop; out_off = 0; k = t;
+        }
+        ti.t0 = iv_start + k * T;
+        ti.len_t = (int)(min(ti.t0 + (long long)T, iv_stop) - ti.t0);
+        ti.fmin = max(iv_start - (long long)p.max_len, 0LL);
+        ti.fmax = min(iv_stop + (long long)p.max_len, p.chrom_size);
+        ti.out_base = out_off + k * T;
+        return ti;
+    };
+    // Candidate fragments: fs - hr <= t1 - 1 and fe + hl >= t0 - 1, i.e.
+    // t0 - 1 - hl - lmax <= fs < t1 + hr.  Bounds come straight from the 512-bp
+    // index (conservative): surplus candidates add nothing, their events clip.
+    auto cand_bound = [&](const WpsTile& ti, int which) -> int {
+        const long long q = which == 0 ? ti.t0 - 1 - hl - (long long)p.lmax : ti.t0 + ti.len_t + hr;
+        if (q <= 0) return 0;
+        const long long kb = q >> kBinShift;
+        return kb >= cv.n_bins ? cv.n : cv.bin_idx[kb + which];
+    };
+    // one fragment -> its +-1/+-2 events in the tile's difference array
+    auto apply = [&](const WpsTile& ti, int par, int i, int fs, int fe, int q) {
+        const int len = fe - fs;
+        const long long mid = ((long long)fs + (long long)fe) >> 1;
+        if (q < p.mapq_min || len < p.min_len || len > p.max_len || mid < ti.fmin || mid >= ti.fmax) return;
+        if (cv.r1_start) {  // BAM: the fetch returns read1 alignments overlapping [fmin, fmax)
+            if (!((long long)cv.r1_start[i] < ti.fmax && (long long)cv.r1_end[i] > ti.fmin)) return;
+        } else if (!((long long)fs < ti.fmax && (long long)fe > ti.fmin)) {
+            return;
+        }
+        const long long a = (long long)fs - hr - ti.t0;
+        const long long b = (long long)fs + hl + 1 - ti.t0;
+        const long long c = (long long)fe - hr - ti.t0;
+        const long long e = (long long)fe + hl + 1 - ti.t0;
+        if (e <= -1 || a >= ti.len_t) return;  // no effect on [t0 - 1, t1)
+        if (a < 0) atomicAdd(&pre_s[par], -1); else if (a < T) atomicAdd(&d[a], -1);
+        if (c >= b) {  // start / stop ranges disjoint: spanning range in between
+            if (b < 0) atomicAdd(&pre_s[par], 2); else if (b < T) atomicAdd(&d[b], 2);
+            if (c < 0) atomicAdd(&pre_s[par], -2); else if (c < T) atomicAdd(&d[c], -2);
+        }
+        if (e < 0) atomicAdd(&pre_s[par], 1); else if (e < T) atomicAdd(&d[e], 1);
+    };
+
+    WpsTile cur = tile_info(tfirst);
+    if (tid < 2) rng_s[tid] = cand_bound(cur, tid);
+    if (tid == 2) { pre_s[0] = 0; pre_s[1] = 0; }
     {
-        int4 z = make_int4(0, 0, 0, 0);
+        const int4 z = make_int4(0, 0, 0, 0);
         int4* d4 = reinterpret_cast<int4*>(d);
 #pragma unroll
         for (int j = 0; j < T / 4 / 256; ++j) d4[j * 256 + tid] = z;
     }
     __syncthreads();
-    const int lo = rng[0], hi = rng[1];
-    for (int i = lo + tid; i < hi; i += 256) {
-        const int fs = cv.start[i], fe = cv.end[i], q = cv.mapq[i];
-        const int len = fe - fs;
-        const long long mid = ((long long)fs + (long long)fe) >> 1;
-        if (q < p.mapq_min || len < p.min_len || len > p.max_len || mid < fmin || mid >= fmax) continue;
-        if (cv.r1_start) {  // BAM: the fetch returns read1 alignments overlapping [fmin, fmax)
-            if (!((long long)cv.r1_start[i] < fmax && (long long)cv.r1_end[i] > fmin)) continue;
-        } else if (!((long long)fs < fmax && (long long)fe > fmin)) {
-            continue;
-        }
-        // event positions relative to t0
-        const long long a = (long long)fs - hr - t0;
-        const long long b = (long long)fs + hl + 1 - t0;
-        const long long c = (long long)fe - hr - t0;
-        const long long e = (long long)fe + hl + 1 - t0;
-        if (e <= -1 || a >= len_t) continue;  // no effect on [t0 - 1, t1)
-        if (c >= b) {
-            if (a < 0) atomicAdd(&pre_s, -1); else if (a < T) atomicAdd(&d[a], -1);
-            if (b < 0) atomicAdd(&pre_s, 2); else if (b < T) atomicAdd(&d[b], 2);
-            if (c < 0) atomicAdd(&pre_s, -2); else if (c < T) atomicAdd(&d[c], -2);
-            if (e < 0) atomicAdd(&pre_s, 1); else if (e < T) atomicAdd(&d[e], 1);
-        } else {
-            if (a < 0) atomicAdd(&pre_s, -1); else if (a < T) atomicAdd(&d[a], -1);
-            if (e < 0) atomicAdd(&pre_s, 1); else if (e < T) atomicAdd(&d[e], 1);
-        }
+    int lo = rng_s[0], hi = rng_s[1];
+    int pfs[PF], pfe[PF], pfq[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        const int i = lo + tid + 256 * k;
+        const bool ok = i < hi;
+        pfs[k] = ok ? cv.start[i] : 0;
+        pfe[k] = ok ? cv.end[i] : 0;
+        pfq[k] = ok ? (int)cv.mapq[i] : -1;
     }
-    __syncthreads();
 
-    // scan: pass j covers d[1024 j .. 1024 j + 1023]; wave wv 256 of them, 4 per lane
-    constexpr int NP = T / 1024;
-    int4 v[NP];
-    int incl[NP];
-    const int4* d4 = reinterpret_cast<const int4*>(d);
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        v[j] = d4[j * 256 + tid];
-        int x = v[j].x + v[j].y + v[j].z + v[j].w;
-#pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            int y = __shfl_up(x, s, 64);
-            if (lane >= s) x += y;
+    const int odd = p.odd, kk = p.hl;  // odd W: hl == k
+    for (long long t = tfirst; t < tlast; ++t) {
+        const int par = (int)((t - tfirst) & 1);
+        const bool has_next = t + 1 < tlast;
+        WpsTile nxt = cur;
+        int nb = 0;
+        if (has_next) {
+            nxt = tile_info(t + 1);
+            if (tid < 2) nb = cand_bound(nxt, tid);
         }
-        incl[j] = x;
-        if (lane == 63) wtot[j][wv] = x;
-    }
-    __syncthreads();
-    int base = pre_s;
-    int64_t* dst = out + out_off + k * T;
-    const int odd = p.odd, kk = p.hl;  // for odd W, hl == k
+        // ---- events -----------------------------------------------------------------
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        // carry of everything before (pass j, wave wv)
-        int carry = base;
+        for (int k = 0; k < PF; ++k) {
+            const int i = lo + tid + 256 * k;
+            if (i < hi) apply(cur, par, i, pfs[k], pfe[k], pfq[k]);
+        }
+        for (int i = lo + PF * 256 + tid; i < hi; i += 256) apply(cur, par, i, cv.start[i], cv.end[i], cv.mapq[i]);
+        __syncthreads();
+        // ---- read the difference array (and clear it for the next tile), scan ---------
+        int2 va[NP], vb[NP];
+        int exa[NP], exb[NP];
+        {
+            int2* d2 = reinterpret_cast<int2*>(d);
+            const int2 z = make_int2(0, 0);
 #pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) {
-            int t = wtot[j][w2];
-            if (w2 < wv) carry += t;
-            base += t;
-        }
-        const int sum4 = v[j].x + v[j].y + v[j].z + v[j].w;
-        const int ex = carry + incl[j] - sum4;  // G(position before this lane's first)
-        const int g0 = ex + v[j].x, g1 = g0 + v[j].y, g2 = g1 + v[j].z, g3 = g2 + v[j].w;
-        const int i0 = j * 1024 + tid * 4;
-        long long o0 = g0, o1 = g1, o2 = g2, o3 = g3;
-        if (odd) {
-            // base c uses virtual position c - ((c - k) & 1)
-            const long long c0 = t0 + i0;
-            if ((c0 - kk) & 1) { o0 = ex; o2 = g1; } else { o1 = g0; o3 = g2; }
-        }
-        if (i0 + 3 < len_t) {
-            longlong2* q2 = reinterpret_cast<longlong2*>(dst + i0);
-            if ((reinterpret_cast<uintptr_t>(q2) & 15) == 0) {
-                q2[0] = make_longlong2(o0, o1);
-                q2[1] = make_longlong2(o2, o3);
-            } else {
-                dst[i0] = o0; dst[i0 + 1] = o1; dst[i0 + 2] = o2; dst[i0 + 3] = o3;
+            for (int j = 0; j < NP; ++j) {
+                const int ia = j * 512 + wv * 128 + lane;  // int2 index of bases sb + 2l, sb + 2l + 1
+                va[j] = d2[ia];
+                vb[j] = d2[ia + 64];
+                d2[ia] = z;
+                d2[ia + 64] = z;
+                const int sa = va[j].x + va[j].y, sb2 = vb[j].x + vb[j].y;
+                const int ia_incl = wave_incl_scan_dpp(sa);
+                const int ib_incl = wave_incl_scan_dpp(sb2);
+                const int tot_a = __builtin_amdgcn_readlane(ia_incl, 63);
+                const int tot_b = __builtin_amdgcn_readlane(ib_incl, 63);
+                exa[j] = ia_incl - sa;
+                exb[j] = tot_a + ib_incl - sb2;
+                if (lane == 0) wtot[j][wv] = tot_a + tot_b;
             }
-        } else {
-            if (i0 < len_t) dst[i0] = o0;
-            if (i0 + 1 < len_t) dst[i0 + 1] = o1;
-            if (i0 + 2 < len_t) dst[i0 + 2] = o2;
         }
+        if (tid < 2) rng_s[tid] = nb;
+        if (tid == 2) pre_s[par ^ 1] = 0;
+        __syncthreads();
+        // ---- prefetch the next tile's fragments (in flight behind the stores below) ---
+        int base = pre_s[par];
+        int lo2 = lo, hi2 = lo;
+        int nfs[PF], nfe[PF], nfq[PF];
+        if (has_next) { lo2 = rng_s[0]; hi2 = rng_s[1]; }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int i = lo2 + tid + 256 * k;
+            const bool ok = i < hi2;
+            nfs[k] = ok ? cv.start[i] : 0;
+            nfe[k] = ok ? cv.end[i] : 0;
+            nfq[k] = ok ? (int)cv.mapq[i] : -1;
+        }
+        // ---- scores -------------------------------------------------------------------
+        int64_t* dst = out + cur.out_base;
+        const bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            int carry = base;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) {
+                const int tt = wtot[j][w2];
+                if (w2 < wv) carry += tt;
+                base += tt;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int2 v = h ? vb[j] : va[j];
+                const int ex = carry + (h ? exb[j] : exa[j]);  // G(base before this lane's pair)
+                const int g0 = ex + v.x, g1 = g0 + v.y;
+                const int i0 = j * 1024 + wv * 256 + h * 128 + 2 * lane;
+                long long o0 = g0, o1 = g1;
+                if (odd) {  // base c uses virtual position c - ((c - k) & 1)
+                    if ((cur.t0 + i0 - kk) & 1) o0 = ex; else o1 = g0;
+                }
+                if (i0 + 1 < cur.len_t) {
+                    if (vec_ok) {
+                        *reinterpret_cast<longlong2*>(dst + i0) = make_longlong2(o0, o1);
+                    } else {
+                        dst[i0] = o0;
+                        dst[i0 + 1] = o1;
+                    }
+                } else if (i0 < cur.len_t) {
+                    dst[i0] = o0;
+                }
+            }
+        }
+        cur = nxt;
+        lo = lo2;
+        hi = hi2;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) { pfs[k] = nfs[k]; pfe[k] = nfe[k]; pfq[k] = nfq[k]; }
     }
 }
 
@@ -609,16 +777,20 @@ void launch_bin_index(hipStream_t s, const int32_t* start, int n, int n_bins, in
 }
 
 void launch_plan(hipStream_t s, const ContigView& cv, const int32_t* ws, const int32_t* we, int n_win, int lmax,
-                 int small_max, const WindowPlan& pl) {
+                 int small_max, const WindowPlan& pl, int64_t* zero1, int64_t* zero2) {
+    if (n_win <= 16384) {
+        hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, s, cv, ws, we, n_win, lmax, small_max, pl.cand_lo,
+                           pl.cand_hi, pl.nchunks, pl.chunk_off, zero1, zero2);
+        return;
+    }
     hipLaunchKernelGGL(bounds_kernel, dim3((n_win + 255) / 256), dim3(256), 0, s, cv, ws, we, n_win, lmax, small_max,
-                       pl.cand_lo, pl.cand_hi, pl.nchunks);
+                       pl.cand_lo, pl.cand_hi, pl.nchunks, zero1, zero2);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, pl.nchunks, n_win, pl.chunk_off);
 }
 
 template <class Pred>
 static void launch_count_t(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
                            int n_win, const WindowPlan& pl, const Pred& pred, int64_t* out1, int64_t* out2) {
-    hipLaunchKernelGGL(zero_large_kernel, dim3((n_win + 255) / 256), dim3(256), 0, s, pl.nchunks, n_win, out1, out2);
     hipLaunchKernelGGL(count_small_kernel<Pred>, dim3((n_win + 3) / 4), dim3(256), 0, s, cv, ws, we, n_win,
                        pl.cand_lo, pl.cand_hi, pl.nchunks, pred, out1, out2);
     hipLaunchKernelGGL(count_large_kernel<Pred>, dim3(grid_large), dim3(256), 0, s, cv, ws, we, n_win, pl.cand_lo,
@@ -659,8 +831,12 @@ void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t
                 const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv, const int32_t* tile_k,
                 int64_t* out) {
     if (n_tiles <= 0) return;
-    hipLaunchKernelGGL(wps_kernel, dim3((unsigned)n_tiles), dim3(256), 0, s, cv, p, iv_start, iv_stop, out_off,
-                       tile_iv, tile_k, out);
+    // two consecutive tiles per block: the second tile's fragment loads hide behind the first
+    // tile's stores and their halos share cache lines (measured best of 1/2/4/8/16/32)
+    const long long tpb = 2;
+    const long long grid = (n_tiles + tpb - 1) / tpb;
+    hipLaunchKernelGGL(wps_stream_kernel, dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop, out_off,
+                       tile_iv, tile_k, (long long)n_tiles, (int)tpb, out);
 }
 
 void launch_select_count(hipStream_t s, const ContigView& cv, int lo, int hi, int ws, int we, const ftk_filter& f,

@@ -20,6 +20,8 @@ from . import _lib as L
 def _win(values, open_value):
     if isinstance(values, np.ndarray) and values.dtype == np.int32:
         return np.ascontiguousarray(values)
+    if hasattr(values, "data_ptr"):  # int32 torch tensor (host or device), passed through by address
+        return values
     return np.ascontiguousarray([open_value if v is None else int(v) for v in values], dtype=np.int32)
 
 

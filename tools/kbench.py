@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Kernel micro-bench on one synthetic contig (GPU box): times ftk_wps / window features with
+HIP events, interleaved repetitions.  usage: tools/kbench.py [contig_len] [reps]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from finaletoolkit_amd import synth  # noqa: E402
+from finaletoolkit_amd.engine import Engine  # noqa: E402
+
+size = int(sys.argv[1]) if len(sys.argv) > 1 else synth.B37_SIZES["2"]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+dev = torch.device("cuda", 0)
+eng = Engine(0)
+_stream = torch.cuda.Stream()  # one explicit stream for torch ops and ftk launches (handle 0 = "own stream")
+torch.cuda.set_stream(_stream)
+eng.set_stream(_stream.cuda_stream)
+n = synth.n_fragments(size, 30.0)
+s, e, q, st = bench.gen_contig_device(torch, dev, size, n, 1)
+torch.cuda.synchronize()
+eng.load_contig_device("c", s, e, q, st, n)
+ws, we = synth.tiling_windows(size, 100_000)
+d_ws, d_we = torch.from_numpy(ws).to(dev), torch.from_numpy(we).to(dev)
+out = torch.empty(size, dtype=torch.int64, device=dev)
+cov = torch.zeros(len(ws), dtype=torch.int64, device=dev)
+hist = torch.zeros((len(ws), 1001), dtype=torch.int32, device=dev)
+over = torch.zeros(len(ws), dtype=torch.int64, device=dev)
+
+
+flush_buf = torch.empty(160_000_000, dtype=torch.int32, device=dev)  # 640 MB > Infinity Cache
+
+
+def timeit(fn, name, nbytes, cold=False):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        if cold:
+            flush_buf.fill_(1)  # evict the contig from the 256 MiB Infinity Cache
+        eng.event_record(0)
+        fn()
+        eng.event_record(1)
+        ts.append(eng.event_elapsed_ms(0, 1))
+    ts = np.array(ts)
+    print(f"{name:28s} median {np.median(ts)*1e3:9.1f} us  min {ts.min()*1e3:9.1f} us   "
+          f"{nbytes/np.median(ts)/1e6:8.1f} GB/s (median)  {nbytes/ts.min()/1e6:8.1f} GB/s (best)", flush=True)
+
+
+which = os.environ.get("KBENCH", "wps,cov,hist").split(",")
+if "cal" in which:
+    src = torch.ones(size, dtype=torch.int64, device=dev)
+    timeit(lambda: out.fill_(7), "torch fill int64", 8 * size)
+    timeit(lambda: out.copy_(src), "torch copy int64 (r+w)", 16 * size)
+    del src
+if "wps" in which:
+    timeit(lambda: eng.wps("c", 0, size, size, 120, 120, 180, 30, out=out), "wps W=120 120-180", 10 * n + 8 * size)
+if "rd" in which:
+    big = torch.ones(60_000_000, dtype=torch.int32, device=dev)  # 240 MB
+    timeit(lambda: big.sum(), "torch sum 240MB warm", 240e6)
+    timeit(lambda: big.sum(), "torch sum 240MB COLD", 240e6, cold=True)
+    timeit(lambda: flush_buf.sum(), "torch sum 640MB (always cold)", 640e6)
+    del big
+if "cov" in which:
+    timeit(lambda: eng.window_counts("c", d_ws, d_we, 30, out=cov), "window_counts 100kb", 10 * n)
+    timeit(lambda: eng.window_counts("c", d_ws, d_we, 30, out=cov), "window_counts 100kb COLD", 10 * n, cold=True)
+if "hist" in which:
+    import ctypes as C
+    from finaletoolkit_amd import _lib as L
+    flt = L.make_filter(30, None, None, "midpoint")
+    timeit(lambda: eng._check(eng.lib.ftk_fraglen_hist(eng.ctx, eng.contig_id("c"), L.ptr(d_ws), L.ptr(d_we), len(ws),
+                                                       C.byref(flt), 0, 1001, L.ptr(hist), L.ptr(over))),
+           "fraglen_hist 100kb x1001", 10 * n)
+    timeit(lambda: eng._check(eng.lib.ftk_fraglen_hist(eng.ctx, eng.contig_id("c"), L.ptr(d_ws), L.ptr(d_we), len(ws),
+                                                       C.byref(flt), 0, 1001, L.ptr(hist), L.ptr(over))),
+           "fraglen_hist COLD", 10 * n, cold=True)
+print("wps checksum", int(out[:5_000_000].sum().item()), "cov", int(cov.sum().item()))
