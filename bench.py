@@ -111,7 +111,8 @@ def main():
     # one explicit stream for torch ops, RCCL and the ftk launches (a NULL handle would mean "ctx's own stream")
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    eng.set_stream(stream.cuda_stream)
+    if not os.environ.get("FTK_BENCH_OWN_STREAM"):
+        eng.set_stream(stream.cuda_stream)
 
     # ---- resident inputs (untimed) -------------------------------------------
     t_load = time.time()
@@ -131,6 +132,8 @@ def main():
             cov=torch.zeros(nw, dtype=torch.int64, device=dev),
             hist=torch.zeros((nw, HIST_BINS), dtype=torch.int32, device=dev),
             over=torch.zeros(nw, dtype=torch.int64, device=dev),
+            short=torch.zeros(nw, dtype=torch.int64, device=dev),
+            long=torch.zeros(nw, dtype=torch.int64, device=dev),
             wps=torch.empty(sizes[c], dtype=torch.int64, device=dev),
             keep=(s, e, q, st) if c == mine[-1] else None,
         )
@@ -142,6 +145,8 @@ def main():
     from finaletoolkit_amd import _lib as L
     lib = eng.lib
     flt = L.make_filter(MAPQ, None, None, "midpoint")
+    for c in mine:
+        per[c]["gaps_c"] = L.make_gaps(per[c]["gaps"])
     bins_all = sum(int(np.ceil(sizes[c] / WINDOW)) for c in names)
     max_bins_rank = max(sum(int(np.ceil(sizes[c] / WINDOW)) for c in names if owner[c] == r) for r in range(world))
     gather_in = torch.zeros((max_bins_rank, 2), dtype=torch.int64, device=dev)
@@ -158,8 +163,11 @@ def main():
                                              L.ptr(p["cov"])))
             eng._check(lib.ftk_fraglen_hist(eng.ctx, cid, L.ptr(p["d_ws"]), L.ptr(p["d_we"]), p["nw"], C.byref(flt),
                                             0, HIST_BINS, L.ptr(p["hist"]), L.ptr(p["over"])))
-            sh, lg, _ = eng.delfi_counts(c, p["ws"], p["we"], MAPQ, p["bl"][0], p["bl"][1], p["gaps"])
-            p["short"], p["long"] = sh, lg
+            # host windows/blacklist are hashed and their device form (windows + per-window
+            # blacklist CSR) is cached inside the ctx; outputs stay on the device: no sync
+            eng._check(lib.ftk_delfi_counts(eng.ctx, cid, L.ptr(p["ws"]), L.ptr(p["we"]), p["nw"], MAPQ,
+                                            L.ptr(p["bl"][0]), L.ptr(p["bl"][1]), len(p["bl"][0]),
+                                            C.byref(p["gaps_c"]), L.ptr(p["short"]), L.ptr(p["long"]), None))
             if record_events:
                 eng.event_record(ev)
             eng.wps(c, 0, sizes[c], sizes[c], WPS_W, WPS_MIN, WPS_MAX, MAPQ, out=p["wps"])
@@ -172,8 +180,8 @@ def main():
             r0 = 0
             for c in mine:
                 p = per[c]
-                gather_in[r0:r0 + p["nw"], 0] = torch.from_numpy(p["short"]).to(dev)
-                gather_in[r0:r0 + p["nw"], 1] = torch.from_numpy(p["long"]).to(dev)
+                gather_in[r0:r0 + p["nw"], 0] = p["short"]
+                gather_in[r0:r0 + p["nw"], 1] = p["long"]
                 r0 += p["nw"]
             dist.all_gather(gather_out, gather_in)
 
@@ -272,7 +280,8 @@ def cpu_baseline(torch, eng, per, mine, sizes, budget_s, checks):
     per_window = t_count / n_s + t_wps / max(done, 1)
     checks["sample_cov"] = bool(np.array_equal(cov, p["cov"][:n_s].cpu().numpy()))
     checks["sample_hist"] = bool(np.array_equal(hist.astype(np.int64), p["hist"][:n_s].cpu().numpy().astype(np.int64)))
-    checks["sample_delfi"] = bool(np.array_equal(sh, p["short"][:n_s]) and np.array_equal(lg, p["long"][:n_s]))
+    checks["sample_delfi"] = bool(np.array_equal(sh, p["short"][:n_s].cpu().numpy())
+                                  and np.array_equal(lg, p["long"][:n_s].cpu().numpy()))
     checks["sample_wps"] = ok_wps
     return {"value": round(1.0 / per_window, 3), "unit": "windows/s", "cores": 1, "kind": "port",
             "sample": f"C oracle (oracle/ftk_oracle.c, gcc -O2): coverage+hist+DELFI on {n_s} and WPS (5 kb tiles) on "

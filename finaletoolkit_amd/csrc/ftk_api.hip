@@ -305,6 +305,7 @@ void ftk_ctx_destroy(ftk_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->contigs) free_contig(kv.second);
+    for (auto& m : ctx->delfi_cache) (void)hipFree(m.base);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -418,6 +419,11 @@ int ftk_frags_release(ftk_ctx* ctx, int contig_id) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     free_contig(it->second);
     ctx->contigs.erase(it);
+    for (size_t i = ctx->delfi_cache.size(); i-- > 0;)
+        if (ctx->delfi_cache[i].contig_id == contig_id) {
+            (void)hipFree(ctx->delfi_cache[i].base);
+            ctx->delfi_cache.erase(ctx->delfi_cache.begin() + i);
+        }
     return FTK_OK;
 }
 
@@ -467,63 +473,97 @@ int ftk_delfi_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const 
         return fail(ctx, FTK_ERR_INVALID, "ftk_delfi_counts takes host window and blacklist arrays");
     HIPCHK(ctx, hipSetDevice(ctx->device));
 
-    // Blacklist regions fully inside each window (frag/_delfi.py:110-126):
-    // region start >= w_start (bisect on the sorted starts) and stop <= w_end.
-    // Per window keep (r0, running max of r1); a fragment is blacklisted iff
-    // max{r1 : r0 <= fs} > fe, which equals "some region has r0 <= fs and
-    // fe < r1" (frag/_delfi.py:455-462) also for overlapping regions.
-    std::vector<int32_t> off(n_win + 1, 0), r0, pm;
-    if (n_bl > 0) {
-        for (int64_t i = 1; i < n_bl; ++i)
-            if (bl_start[i] < bl_start[i - 1]) return fail(ctx, FTK_ERR_INVALID, "blacklist must be sorted by start");
-        for (int64_t w = 0; w < n_win; ++w) {
-            const int32_t* lo = std::lower_bound(bl_start, bl_start + n_bl, w_start[w]);
-            int32_t run = INT32_MIN;
-            for (int64_t j = lo - bl_start; j < n_bl && bl_start[j] < w_end[w]; ++j) {
-                if (bl_end[j] <= w_end[w]) {
-                    run = std::max(run, bl_end[j]);
-                    r0.push_back(bl_start[j]);
-                    pm.push_back(run);
+    // ---- device-resident windows + blacklist CSR, cached by content -----------------
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&key](const void* p, size_t n) {
+        const unsigned char* b = (const unsigned char*)p;
+        for (size_t i = 0; i < n; ++i) key = (key ^ b[i]) * 1099511628211ull;
+    };
+    mix(&contig_id, sizeof(contig_id));
+    mix(&n_win, sizeof(n_win));
+    mix(&n_bl, sizeof(n_bl));
+    mix(w_start, n_win * 4);
+    mix(w_end, n_win * 4);
+    if (n_bl) { mix(bl_start, n_bl * 4); mix(bl_end, n_bl * 4); }
+    DelfiMeta* meta = nullptr;
+    for (auto& m : ctx->delfi_cache)
+        if (m.key == key && m.contig_id == contig_id && m.n_win == n_win) meta = &m;
+    if (!meta) {
+        // Blacklist regions fully inside each window (frag/_delfi.py:110-126):
+        // region start >= w_start (bisect on the sorted starts) and stop <= w_end.
+        // Per window keep (r0, running max of r1); a fragment is blacklisted iff
+        // max{r1 : r0 <= fs} > fe, which equals "some region has r0 <= fs and
+        // fe < r1" (frag/_delfi.py:455-462) also for overlapping regions.
+        std::vector<int32_t> off(n_win + 1, 0), r0, pm;
+        if (n_bl > 0) {
+            for (int64_t i = 1; i < n_bl; ++i)
+                if (bl_start[i] < bl_start[i - 1]) return fail(ctx, FTK_ERR_INVALID, "blacklist must be sorted by start");
+            for (int64_t w = 0; w < n_win; ++w) {
+                const int32_t* lo = std::lower_bound(bl_start, bl_start + n_bl, w_start[w]);
+                int32_t run = INT32_MIN;
+                for (int64_t j = lo - bl_start; j < n_bl && bl_start[j] < w_end[w]; ++j) {
+                    if (bl_end[j] <= w_end[w]) {
+                        run = std::max(run, bl_end[j]);
+                        r0.push_back(bl_start[j]);
+                        pm.push_back(run);
+                    }
                 }
+                if (r0.size() > (size_t)INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "blacklist expansion too large");
+                off[w + 1] = (int32_t)r0.size();
             }
-            if (r0.size() > (size_t)INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "blacklist expansion too large");
-            off[w + 1] = (int32_t)r0.size();
         }
+        if (ctx->delfi_cache.size() >= 64) {  // drop the oldest entry
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->delfi_cache.front().base);
+            ctx->delfi_cache.erase(ctx->delfi_cache.begin());
+        }
+        DelfiMeta m;
+        m.key = key;
+        m.contig_id = contig_id;
+        m.n_win = n_win;
+        m.n_r = r0.size();
+        const size_t b_w = align_up(n_win * 4), b_o = align_up((n_win + 1) * 4), b_r = align_up(std::max<size_t>(m.n_r, 1) * 4);
+        HIPCHK(ctx, hipMalloc(&m.base, 2 * b_w + b_o + 2 * b_r));
+        char* q = (char*)m.base;
+        m.d_ws = (int32_t*)q;
+        m.d_we = (int32_t*)(q + b_w);
+        m.d_off = (int32_t*)(q + 2 * b_w);
+        m.d_r0 = (int32_t*)(q + 2 * b_w + b_o);
+        m.d_pm = (int32_t*)(q + 2 * b_w + b_o + b_r);
+        hipError_t e = hipMemcpy(m.d_ws, w_start, n_win * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(m.d_we, w_end, n_win * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(m.d_off, off.data(), (n_win + 1) * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && m.n_r) e = hipMemcpy(m.d_r0, r0.data(), m.n_r * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && m.n_r) e = hipMemcpy(m.d_pm, pm.data(), m.n_r * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(m.base);
+            return fail(ctx, FTK_ERR_HIP, "DELFI metadata upload failed: %s", hipGetErrorString(e));
+        }
+        ctx->delfi_cache.push_back(m);
+        meta = &ctx->delfi_cache.back();
     }
-    const size_t n_r = r0.size();
-    const bool use_bl = n_r > 0;
+    const bool use_bl = meta->n_r > 0;
     const bool s_dev = is_device_ptr(short_out), l_dev = is_device_ptr(long_out), n_dev = is_device_ptr(nfrag_out);
-    size_t need = window_scratch_bytes(n_win) + 2 * align_up(n_win * 8) +
-                  (use_bl ? align_up((n_win + 1) * 4) + 2 * align_up(n_r * 4) : 0);
+    size_t need = window_scratch_bytes(n_win) + 3 * align_up(n_win * 8);
     if ((rc = reserve_scratch(ctx, need))) return rc;
     Arena a(ctx);
     WindowCall wc;
     ftk_filter f{mapq_min, 100, 220, FTK_POLICY_MIDPOINT, c->v.r1_start ? FTK_FETCH_BAM_READ1 : FTK_FETCH_TABIX};
     int64_t* d_short = s_dev ? short_out : a.take<int64_t>(n_win);
     int64_t* d_long = l_dev ? long_out : a.take<int64_t>(n_win);
-    if ((rc = window_prepare(ctx, c, a, w_start, w_end, n_win, eff_lmax(&f, *c), kSmallMax, &wc, d_short, d_long)))
+    int64_t* d_nfrag = nfrag_out ? (n_dev ? nfrag_out : a.take<int64_t>(n_win)) : nullptr;
+    if ((rc = window_prepare(ctx, c, a, meta->d_ws, meta->d_we, n_win, eff_lmax(&f, *c), kSmallMax, &wc, d_short, d_long)))
         return rc;
-    int32_t *d_off = nullptr, *d_r0 = nullptr, *d_pm = nullptr;
-    if (use_bl) {
-        d_off = a.take<int32_t>(n_win + 1);
-        d_r0 = a.take<int32_t>(n_r);
-        d_pm = a.take<int32_t>(n_r);
-        HIPCHK(ctx, hipMemcpyAsync(d_off, off.data(), (n_win + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(d_r0, r0.data(), n_r * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(d_pm, pm.data(), n_r * 4, hipMemcpyHostToDevice, ctx->stream));
-    }
     launch_delfi_counts(ctx->stream, ctx->n_cu * 8, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, mapq_min,
-                        c->v.r1_start != nullptr, g, d_off, d_r0, d_pm, d_short, d_long);
+                        c->v.r1_start != nullptr, g, use_bl ? meta->d_off : nullptr, meta->d_r0, meta->d_pm, d_short,
+                        d_long);
+    if (d_nfrag) launch_add_i64(ctx->stream, d_short, d_long, d_nfrag, (int)n_win);
     HIPCHK(ctx, hipGetLastError());
     if (!s_dev) HIPCHK(ctx, hipMemcpyAsync(short_out, d_short, n_win * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (!l_dev) HIPCHK(ctx, hipMemcpyAsync(long_out, d_long, n_win * 8, hipMemcpyDeviceToHost, ctx->stream));
-    // the pageable staging vectors above must outlive the copies
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (nfrag_out) {
-        if (n_dev || s_dev || l_dev)
-            return fail(ctx, FTK_ERR_INVALID, "nfrag_out is only filled for host outputs (nfrag = short + long)");
-        for (int64_t w = 0; w < n_win; ++w) nfrag_out[w] = short_out[w] + long_out[w];
-    }
+    if (nfrag_out && !n_dev) HIPCHK(ctx, hipMemcpyAsync(nfrag_out, d_nfrag, n_win * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (!s_dev || !l_dev || (nfrag_out && !n_dev)) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return FTK_OK;
 }
 

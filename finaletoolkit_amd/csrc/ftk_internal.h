@@ -45,6 +45,19 @@ struct ContigData {
     int32_t max_end = 0;
 };
 
+// Device-resident DELFI metadata of one (contig, bins, blacklist) combination:
+// the windows and the per-window blacklist CSR.  Built once, reused while the
+// caller keeps passing the same arrays (the reference parses its blacklist
+// once per worker too, frag/_delfi.py:65-107).
+struct DelfiMeta {
+    uint64_t key = 0;
+    int contig_id = -1;
+    int64_t n_win = 0;
+    size_t n_r = 0;
+    void* base = nullptr;  // one allocation
+    int32_t *d_ws = nullptr, *d_we = nullptr, *d_off = nullptr, *d_r0 = nullptr, *d_pm = nullptr;
+};
+
 }  // namespace ftk
 
 struct ftk_ctx {
@@ -56,6 +69,7 @@ struct ftk_ctx {
     std::vector<hipEvent_t> ev_slots;  // lazily created, FTK_MAX_EVENTS entries
     std::map<int, ftk::ContigData> contigs;
     std::string err;
+    std::vector<ftk::DelfiMeta> delfi_cache;
     // grow-only device scratch, reused by every call (stream-ordered)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;

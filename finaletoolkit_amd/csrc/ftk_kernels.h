@@ -47,6 +47,7 @@ void launch_delfi_counts(hipStream_t s, int grid_large, const ContigView& cv, co
 void launch_fraglen_hist(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
                          int n_win, const WindowPlan& pl, const ftk_filter& f, int len_lo, int n_bins,
                          uint32_t* hist_out, int64_t* overflow_out);
+void launch_add_i64(hipStream_t s, const int64_t* a, const int64_t* b, int64_t* out, int n);
 void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t n_tiles, const int64_t* iv_start,
                 const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv, const int32_t* tile_k,
                 int64_t* out);

@@ -763,9 +763,18 @@ __global__ __launch_bounds__(256) void select_write_kernel(ContigView cv, int lo
     }
 }
 
+__global__ void add_i64_kernel(const int64_t* a, const int64_t* b, int64_t* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
 // ---------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------
+void launch_add_i64(hipStream_t s, const int64_t* a, const int64_t* b, int64_t* out, int n) {
+    hipLaunchKernelGGL(add_i64_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);
+}
+
 void launch_stats(hipStream_t s, const int32_t* start, const int32_t* end, int n, FragStats* st) {
     int blocks = min(2048, max(1, (n + 255) / 256));
     hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(256), 0, s, start, end, n, st);

@@ -159,7 +159,10 @@ int ftk_window_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const
  * telomeres); len >= 151 -> long, else short; nfrag = short + long.
  * bl_start/bl_end: the contig's blacklist, sorted by (start, stop)
  * (frag/_delfi.py:85-107); may be NULL when n_bl == 0.  The window-level
- * NOARM gate (frag/_delfi.py:423-428) is the caller's. */
+ * NOARM gate (frag/_delfi.py:423-428) is the caller's.  Windows and blacklist
+ * are HOST arrays; their device form (windows + per-window blacklist CSR) is
+ * cached in the ctx by content, so repeated calls with the same bins upload
+ * nothing.  Outputs may be host or device pointers; nfrag_out may be NULL. */
 int ftk_delfi_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
                      int32_t mapq_min, const int32_t* bl_start, const int32_t* bl_end, int64_t n_bl,
                      const ftk_gaps* gaps, int64_t* short_out, int64_t* long_out, int64_t* nfrag_out);

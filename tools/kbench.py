@@ -41,8 +41,10 @@ def timeit(fn, name, nbytes, cold=False):
     torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
-        if cold:
-            flush_buf.fill_(1)  # evict the contig from the 256 MiB Infinity Cache
+        if cold == "read":
+            flush_buf.sum()      # evict with clean lines
+        elif cold:
+            flush_buf.fill_(1)  # evict the contig from the 256 MiB Infinity Cache (dirty lines)
         eng.event_record(0)
         fn()
         eng.event_record(1)
@@ -69,6 +71,7 @@ if "rd" in which:
 if "cov" in which:
     timeit(lambda: eng.window_counts("c", d_ws, d_we, 30, out=cov), "window_counts 100kb", 10 * n)
     timeit(lambda: eng.window_counts("c", d_ws, d_we, 30, out=cov), "window_counts 100kb COLD", 10 * n, cold=True)
+    timeit(lambda: eng.window_counts("c", d_ws, d_we, 30, out=cov), "window_counts COLD(read-flush)", 10 * n, cold="read")
 if "hist" in which:
     import ctypes as C
     from finaletoolkit_amd import _lib as L
