@@ -213,8 +213,12 @@ def main():
         wps_ms += eng.event_elapsed_ms(a, b)
         wps_bytes += 10 * per[c]["n"] + 8 * sizes[c]
     achieved = wps_bytes / (wps_ms * 1e-3) / 1e9 if wps_ms > 0 else 0.0
-    roofline = dict(bound="hbm", kernel="wps_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+    traffic = None  # HBM bytes per launch from the committed PMC passes (same workload only)
+    tpath = os.path.join(ROOT, "profiles", "wps_traffic.json")
+    if world == 1 and not args.contigs and args.depth == 30.0 and os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+    roofline = dict(bound="hbm", kernel="wps_stream_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     algorithmic_bytes_per_launch=int(wps_bytes / max(len(wps_ev), 1)),
                     launches=len(wps_ev), avg_launch_ms=round(wps_ms / max(len(wps_ev), 1), 4))
 
