@@ -1,6 +1,279 @@
-"""bigWig output for multi_wps (fixedStep sections).  Placeholder until the
-writer lands: the kernels and the bedGraph.gz path do not depend on it."""
+"""
+bigWig output for ``multi_wps`` without pyBigWig: the equivalent of
+``bigwig.addHeader(header)`` + ``bigwig.addEntries(chrom, start, values=f64,
+span=1, step=1)`` per interval (reference ``frag/_multi_wps.py:300-325``), i.e.
+zlib-compressed **fixedStep** sections of float32 values, a chromosome B+ tree
+and an R-tree index (bigWig v4, little endian).  One zoom level of per-section
+summaries is written so browsers and ``stats`` readers that insist on a zoom
+level have one.  ``read_bigwig`` is the matching minimal reader (tests, and a
+way to inspect results without pyBigWig).
+"""
+from __future__ import annotations
+
+import struct
+import sys
+import zlib
+
+import numpy as np
+
+_BW_MAGIC = 0x888FFC26
+_CHROM_TREE_MAGIC = 0x78CA8C91
+_RTREE_MAGIC = 0x2468ACE0
+_ITEMS_PER_SECTION = 16384  # <= 65535 (u16 item count)
+_BLOCK = 256                # children per index node
 
 
-def write_fixed_step_bigwig(output_file, header, interval_scores):
-    raise NotImplementedError("bigWig (.bw) output is not implemented yet; use a .bed.gz / .bedGraph.gz output path")
+def _chrom_tree(header) -> bytes:
+    """B+ tree over ``(name -> id, size)``; ids follow header order."""
+    key = max([len(c.encode()) for c, _ in header] + [1])
+    items = sorted(((c.encode().ljust(key, b"\0"), i, int(n)) for i, (c, n) in enumerate(header)), key=lambda t: t[0])
+    out = struct.pack("<IIIIQQ", _CHROM_TREE_MAGIC, _BLOCK, key, 8, len(items), 0)
+    base = 0  # node offsets are absolute file offsets; patched by the caller through `reloc`
+    # levels bottom-up: leaves hold (key, id, size); inner nodes (key, child offset)
+    leaves = [items[i:i + _BLOCK] for i in range(0, len(items), _BLOCK)] or [[]]
+    levels = [leaves]
+    while len(levels[-1]) > 1:
+        prev = levels[-1]
+        levels.append([prev[i:i + _BLOCK] for i in range(0, len(prev), _BLOCK)])
+    levels.reverse()  # root first
+    # sizes
+    sizes = []
+    for li, lv in enumerate(levels):
+        leaf = li == len(levels) - 1
+        sizes.append([4 + len(node) * (key + 8) for node in lv])
+    offs = []
+    pos = len(out)
+    for lv_sizes in sizes:
+        offs.append([])
+        for sz in lv_sizes:
+            offs[-1].append(pos)
+            pos += sz
+    body = bytearray()
+    reloc = []  # positions (in `out + body`) of child offsets that need the tree's file offset added
+
+    def first_key(node, li):
+        while li < len(levels) - 1:
+            node = node[0]
+            li += 1
+        return node[0][0] if node else b"\0" * key
+
+    for li, lv in enumerate(levels):
+        leaf = li == len(levels) - 1
+        child = 0
+        for node in lv:
+            body += struct.pack("<BBH", 1 if leaf else 0, 0, len(node))
+            for it in node:
+                if leaf:
+                    body += it[0] + struct.pack("<II", it[1], it[2])
+                else:
+                    body += first_key(it, li + 1)
+                    reloc.append(len(out) + len(body))
+                    body += struct.pack("<Q", offs[li + 1][child])
+                    child += 1
+    return out + bytes(body), reloc
+
+
+def _rtree(leaf_items, index_offset) -> bytes:
+    """R-tree over section records ``(chrom, start, chrom, end, offset, size)``."""
+    n = len(leaf_items)
+    if n:
+        bounds = (leaf_items[0][0], leaf_items[0][1], leaf_items[-1][2], leaf_items[-1][3],
+                  leaf_items[-1][4] + leaf_items[-1][5])
+    else:
+        bounds = (0, 0, 0, 0, index_offset)
+    head = struct.pack("<IIQIIIIQII", _RTREE_MAGIC, _BLOCK, n, bounds[0], bounds[1], bounds[2], bounds[3], bounds[4],
+                       1, 0)
+    levels = [[leaf_items[i:i + _BLOCK] for i in range(0, n, _BLOCK)] or [[]]]
+
+    def bbox(node, leaf):
+        if leaf:
+            return (node[0][0], node[0][1], node[-1][2], max(x[3] for x in node if x[2] == node[-1][2]))
+        boxes = [bbox(ch, lf) for ch, lf in node]
+        return (boxes[0][0], boxes[0][1], boxes[-1][2], max(b[3] for b in boxes if b[2] == boxes[-1][2]))
+
+    # upper levels hold (child node, child_is_leaf)
+    cur = [(nd, True) for nd in levels[0]]
+    tree = [cur]
+    while len(cur) > 1:
+        cur = [(cur[i:i + _BLOCK], False) for i in range(0, len(cur), _BLOCK)]
+        tree.append(cur)
+    tree.reverse()  # root level first
+    # layout
+    pos = index_offset + len(head)
+    offs = []
+    for lv in tree:
+        offs.append([])
+        for node, leaf in lv:
+            offs[-1].append(pos)
+            pos += 4 + len(node) * (32 if leaf else 24)
+    body = bytearray()
+    for li, lv in enumerate(tree):
+        child = 0
+        for node, leaf in lv:
+            body += struct.pack("<BBH", 1 if leaf else 0, 0, len(node))
+            if leaf:
+                for it in node:
+                    body += struct.pack("<IIIIQQ", *it)
+            else:
+                for ch, ch_leaf in node:
+                    bb = bbox(ch, ch_leaf)
+                    body += struct.pack("<IIIIQ", bb[0], bb[1], bb[2], bb[3], offs[li + 1][child])
+                    child += 1
+    return head + bytes(body)
+
+
+def write_fixed_step_bigwig(output_file, header, interval_scores) -> None:
+    """``header``: list of ``(contig, length)``; ``interval_scores``: iterable of
+    ``(contig, start, values)`` in header order.  An out-of-order or overlapping
+    interval is skipped with a note on stderr (pyBigWig raises RuntimeError there
+    and the reference skips the interval, frag/_multi_wps.py:319-325)."""
+    chrom_id = {c: i for i, (c, _) in enumerate(header)}
+    tree, reloc = _chrom_tree(header)
+    n_zoom = 1
+    chrom_tree_off = 64 + 24 * n_zoom
+    total_summary_off = chrom_tree_off + len(tree)
+    data_off = total_summary_off + 40
+    tree = bytearray(tree)
+    for r in reloc:
+        (v,) = struct.unpack_from("<Q", tree, r)
+        struct.pack_into("<Q", tree, r, v + chrom_tree_off)
+
+    sections = bytearray()
+    leaf_items = []
+    zoom_recs = []
+    last = (-1, -1)
+    n_valid, vmin, vmax, vsum, vsq, max_raw = 0, np.inf, -np.inf, 0.0, 0.0, 0
+    pos = data_off + 8
+    for contig, start, values in interval_scores:
+        values = np.asarray(values)
+        if len(values) == 0:
+            continue
+        cid = chrom_id.get(contig)
+        if cid is None or (cid, int(start)) < last:
+            sys.stderr.write(f"{contig}:{start}-{start + len(values)}\n invalid or out of order interval "
+                             "encountered. Skipping to next.\n")
+            continue
+        v32 = values.astype(np.float64).astype("<f4")
+        for o in range(0, len(v32), _ITEMS_PER_SECTION):
+            chunk = v32[o:o + _ITEMS_PER_SECTION]
+            s0 = int(start) + o
+            raw = struct.pack("<IIIIIBBH", cid, s0, s0 + len(chunk), 1, 1, 3, 0, len(chunk)) + chunk.tobytes()
+            comp = zlib.compress(raw, 6)
+            sections += comp
+            leaf_items.append((cid, s0, cid, s0 + len(chunk), pos, len(comp)))
+            pos += len(comp)
+            max_raw = max(max_raw, len(raw))
+            c64 = chunk.astype(np.float64)
+            zoom_recs.append((cid, s0, s0 + len(chunk), len(chunk), float(c64.min()), float(c64.max()),
+                              float(c64.sum()), float((c64 * c64).sum())))
+            n_valid += len(chunk)
+            vmin, vmax = min(vmin, zoom_recs[-1][4]), max(vmax, zoom_recs[-1][5])
+            vsum += zoom_recs[-1][6]
+            vsq += zoom_recs[-1][7]
+        last = (cid, int(start) + len(values))
+    if n_valid == 0:
+        vmin = vmax = 0.0
+    index_off = pos
+    index = _rtree(leaf_items, index_off)
+    # zoom level: one summary record per data section, in blocks of 512 records
+    zoom_data_off = index_off + len(index)
+    zdata = bytearray(struct.pack("<I", len(zoom_recs)))
+    zleaf = []
+    zpos = zoom_data_off + 4
+    for o in range(0, len(zoom_recs), 512):
+        blk = zoom_recs[o:o + 512]
+        raw = b"".join(struct.pack("<IIIIffff", *r) for r in blk)
+        comp = zlib.compress(raw, 6)
+        zdata += comp
+        zleaf.append((blk[0][0], blk[0][1], blk[-1][0], blk[-1][2], zpos, len(comp)))
+        zpos += len(comp)
+        max_raw = max(max_raw, len(raw))
+    zoom_index_off = zpos
+    zindex = _rtree(zleaf, zoom_index_off)
+
+    with open(output_file, "wb") as fh:
+        fh.write(struct.pack("<IHHQQQHHQQIQ", _BW_MAGIC, 4, n_zoom, chrom_tree_off, data_off, index_off, 0, 0, 0,
+                             total_summary_off, max(max_raw, 1), 0))
+        fh.write(struct.pack("<IIQQ", _ITEMS_PER_SECTION, 0, zoom_data_off, zoom_index_off))
+        fh.write(bytes(tree))
+        fh.write(struct.pack("<Qdddd", n_valid, vmin, vmax, vsum, vsq))
+        fh.write(struct.pack("<Q", len(leaf_items)))
+        fh.write(bytes(sections))
+        fh.write(index)
+        fh.write(bytes(zdata))
+        fh.write(zindex)
+        fh.write(struct.pack("<I", _BW_MAGIC))
+
+
+# ---------------------------------------------------------------------------
+# minimal reader
+# ---------------------------------------------------------------------------
+def read_bigwig(path):
+    """Return ``(chroms, intervals)``: ``chroms`` = {name: (id, size)};
+    ``intervals`` = list of ``(chrom_name, start, end, value)`` runs decoded from
+    every data section (bedGraph, varStep and fixedStep), in file order."""
+    b = open(path, "rb").read()
+    magic, ver, nzoom, ct_off, data_off, idx_off, _, _, _, ts_off, ubuf, _ = struct.unpack_from("<IHHQQQHHQQIQ", b, 0)
+    if magic != _BW_MAGIC:
+        raise ValueError(f"{path} is not a little-endian bigWig file")
+    tmagic, bsize, key, val, count, _ = struct.unpack_from("<IIIIQQ", b, ct_off)
+    if tmagic != _CHROM_TREE_MAGIC:
+        raise ValueError("bad chromosome tree")
+    chroms = {}
+
+    def walk_ct(off):
+        leaf, _, n = struct.unpack_from("<BBH", b, off)
+        off += 4
+        for _ in range(n):
+            k = b[off:off + key].rstrip(b"\0").decode()
+            if leaf:
+                cid, size = struct.unpack_from("<II", b, off + key)
+                chroms[k] = (cid, size)
+            else:
+                (child,) = struct.unpack_from("<Q", b, off + key)
+                walk_ct(child)
+            off += key + 8
+
+    walk_ct(ct_off + 32)
+    names = {cid: name for name, (cid, _) in chroms.items()}
+    rmagic = struct.unpack_from("<I", b, idx_off)[0]
+    if rmagic != _RTREE_MAGIC:
+        raise ValueError("bad R-tree index")
+    blocks = []
+
+    def walk_rt(off):
+        leaf, _, n = struct.unpack_from("<BBH", b, off)
+        off += 4
+        for _ in range(n):
+            if leaf:
+                _, _, _, _, doff, dsize = struct.unpack_from("<IIIIQQ", b, off)
+                blocks.append((doff, dsize))
+                off += 32
+            else:
+                (child,) = struct.unpack_from("<Q", b, off + 16)
+                walk_rt(child)
+                off += 24
+
+    walk_rt(idx_off + 48)
+    out = []
+    for doff, dsize in blocks:
+        raw = b[doff:doff + dsize]
+        if ubuf:
+            raw = zlib.decompress(raw)
+        cid, s0, e0, step, span, typ, _, n = struct.unpack_from("<IIIIIBBH", raw, 0)
+        p = 24
+        for i in range(n):
+            if typ == 1:
+                s, e, v = struct.unpack_from("<IIf", raw, p)
+                p += 12
+            elif typ == 2:
+                s, v = struct.unpack_from("<If", raw, p)
+                e = s + span
+                p += 8
+            else:
+                (v,) = struct.unpack_from("<f", raw, p)
+                s = s0 + i * step
+                e = s + span
+                p += 4
+            out.append((names[cid], s, e, v))
+    return chroms, out

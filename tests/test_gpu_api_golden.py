@@ -208,6 +208,36 @@ class TestWPS:  # reference tests/test_wps.py
         assert all(int(r[2]) == int(r[1]) + 1 for r in rows[::97])
 
 
+    def test_multi_wps_bigwig_all_chroms_present(self, tmp_path):
+        """reference tests/test_wps.py:90-135: BED sorted alphabetically ("10" before "2") while the
+        header order is ("2", "10") must not drop a chromosome; one 160 bp fragment per contig gives
+        WPS +1 on [1_000_061, 1_000_100] and -1 on the two 120 bp end ranges."""
+        from finaletoolkit_amd import bgzf
+        from finaletoolkit_amd.bigwig import read_bigwig
+        frag = str(tmp_path / "two.frag.gz")
+        one = (np.array([1_000_000], np.int32), np.array([1_000_160], np.int32), np.array([60], np.uint8),
+               np.array([1], np.uint8))
+        bgzf.write_frag_gz(frag, [("2",) + one, ("10",) + one])
+        cs = tmp_path / "cs.sizes"
+        cs.write_text("2\t100000000\n10\t100000000\n")
+        bed = tmp_path / "sites.bed"
+        bed.write_text("10\t999500\t1000500\n2\t999500\t1000500\n")
+        out = str(tmp_path / "out.bw")
+        assert frag.endswith(".gz")
+        frag_ret = __import__("finaletoolkit_amd").frag.multi_wps(frag, str(bed), str(cs), out, interval_size=1000,
+                                                                  min_length=120, max_length=180,
+                                                                  quality_threshold=0)
+        assert frag_ret == out
+        chroms, iv = read_bigwig(out)
+        assert chroms == {"2": (0, 100000000), "10": (1, 100000000)}
+        for c in ("2", "10"):
+            vals = {s: v for (cc, s, e, v) in iv if cc == c}
+            assert len(vals) == 1000 and min(vals) == 999_500
+            assert max(vals.values()) == 1.0 and min(vals.values()) == -1.0
+            assert [s for s, v in vals.items() if v == 1.0] == list(range(1_000_061, 1_000_101))
+        assert [c for c, *_ in iv][0] == "2"  # header order
+
+
 class TestFragLength:  # reference tests/test_frag_length.py
     def test_frag_lengths(self, G, A):
         lengths = frag.frag_length(FIX, contig="12", start=34443119, stop=34443538)
