@@ -159,15 +159,13 @@ def main():
         for c in mine:
             p = per[c]
             cid = eng.contig_id(c)
-            eng._check(lib.ftk_window_counts(eng.ctx, cid, L.ptr(p["d_ws"]), L.ptr(p["d_we"]), p["nw"], C.byref(flt),
-                                             L.ptr(p["cov"])))
-            eng._check(lib.ftk_fraglen_hist(eng.ctx, cid, L.ptr(p["d_ws"]), L.ptr(p["d_we"]), p["nw"], C.byref(flt),
-                                            0, HIST_BINS, L.ptr(p["hist"]), L.ptr(p["over"])))
-            # host windows/blacklist are hashed and their device form (windows + per-window
-            # blacklist CSR) is cached inside the ctx; outputs stay on the device: no sync
-            eng._check(lib.ftk_delfi_counts(eng.ctx, cid, L.ptr(p["ws"]), L.ptr(p["we"]), p["nw"], MAPQ,
-                                            L.ptr(p["bl"][0]), L.ptr(p["bl"][1]), len(p["bl"][0]),
-                                            C.byref(p["gaps_c"]), L.ptr(p["short"]), L.ptr(p["long"]), None))
+            # coverage + length histogram + DELFI short/long in ONE pass over the contig's fragments.
+            # Windows/blacklist are host arrays: hashed, their device form (windows + per-window
+            # blacklist CSR) is cached in the ctx; every output stays on the device (no sync).
+            eng._check(lib.ftk_window_features(
+                eng.ctx, cid, L.ptr(p["ws"]), L.ptr(p["we"]), p["nw"], C.byref(flt), L.ptr(p["cov"]), 0, HIST_BINS,
+                L.ptr(p["hist"]), L.ptr(p["over"]), MAPQ, L.ptr(p["bl"][0]), L.ptr(p["bl"][1]), len(p["bl"][0]),
+                C.byref(p["gaps_c"]), L.ptr(p["short"]), L.ptr(p["long"])))
             if record_events:
                 eng.event_record(ev)
             eng.wps(c, 0, sizes[c], sizes[c], WPS_W, WPS_MIN, WPS_MAX, MAPQ, out=p["wps"])

@@ -44,7 +44,8 @@ EXPORTS = [
     "ftk_fragfile_decode", "ftk_bam_decode", "ftk_fragtable_error", "ftk_fragtable_is_bed6",
     "ftk_fragtable_n_contigs", "ftk_fragtable_contig_name", "ftk_fragtable_contig_length",
     "ftk_fragtable_contig_rows", "ftk_fragtable_columns", "ftk_fragtable_free",
-    "ftk_window_counts", "ftk_delfi_counts", "ftk_fraglen_hist", "ftk_frag_lengths", "ftk_frag_select",
+    "ftk_window_counts", "ftk_delfi_counts", "ftk_fraglen_hist", "ftk_window_features", "ftk_frag_lengths",
+    "ftk_frag_select",
     "ftk_wps", "ftk_wps_intervals",
 ]
 
@@ -126,6 +127,8 @@ def load() -> C.CDLL:
     lib.ftk_window_counts.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), vp]
     lib.ftk_delfi_counts.argtypes = [vp, C.c_int, vp, vp, i64, i32, vp, vp, i64, C.POINTER(Gaps), vp, vp, vp]
     lib.ftk_fraglen_hist.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), i32, i32, vp, vp]
+    lib.ftk_window_features.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), vp, i32, i32, vp, vp, i32, vp, vp,
+                                        i64, C.POINTER(Gaps), vp, vp]
     lib.ftk_frag_lengths.argtypes = [vp, C.c_int, i32, i32, C.POINTER(Filter), vp, i64, C.POINTER(i64)]
     lib.ftk_frag_select.argtypes = [vp, C.c_int, i32, i32, C.POINTER(Filter), vp, vp, vp, vp, i64, C.POINTER(i64)]
     lib.ftk_wps.argtypes = [vp, C.c_int, i64, i64, i64, i32, i32, i32, i32, vp]

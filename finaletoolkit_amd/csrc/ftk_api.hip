@@ -237,7 +237,7 @@ size_t window_scratch_bytes(int64_t n_win) {
 }
 
 int window_prepare(ftk_ctx* ctx, ContigData* c, Arena& a, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
-                   int lmax, int small_max, WindowCall* wc, int64_t* zero1 = nullptr, int64_t* zero2 = nullptr) {
+                   int lmax, int small_max, WindowCall* wc, int64_t* const zero[4] = nullptr) {
     int32_t* b_ws = a.take<int32_t>(n_win);
     int32_t* b_we = a.take<int32_t>(n_win);
     wc->plan.cand_lo = a.take<int32_t>(n_win);
@@ -248,7 +248,7 @@ int window_prepare(ftk_ctx* ctx, ContigData* c, Arena& a, const int32_t* w_start
     if (rc) return rc;
     rc = stage_in(ctx, w_end, n_win, b_we, &wc->d_we);
     if (rc) return rc;
-    launch_plan(ctx->stream, c->v, wc->d_ws, wc->d_we, (int)n_win, lmax, small_max, wc->plan, zero1, zero2);
+    launch_plan(ctx->stream, c->v, wc->d_ws, wc->d_we, (int)n_win, lmax, small_max, wc->plan, zero);
     return FTK_OK;
 }
 
@@ -427,53 +427,12 @@ int ftk_frags_release(ftk_ctx* ctx, int contig_id) {
     return FTK_OK;
 }
 
-int ftk_window_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
-                      const ftk_filter* f, int64_t* count_out) {
-    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
-    ContigData* c;
-    int rc = get_contig(ctx, contig_id, &c);
-    if (rc) return rc;
-    if ((rc = check_filter(ctx, f, *c))) return rc;
-    if (n_win < 0 || n_win > (1 << 30)) return fail(ctx, FTK_ERR_INVALID, "n_win out of range");
-    if (n_win == 0) return FTK_OK;
-    if (!w_start || !w_end || !count_out) return fail(ctx, FTK_ERR_INVALID, "NULL window/output pointer");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    const bool out_dev = is_device_ptr(count_out);
-    size_t need = window_scratch_bytes(n_win) + (out_dev ? 0 : align_up(n_win * 8));
-    if ((rc = reserve_scratch(ctx, need))) return rc;
-    Arena a(ctx);
-    WindowCall wc;
-    int64_t* d_out = out_dev ? count_out : a.take<int64_t>(n_win);
-    if ((rc = window_prepare(ctx, c, a, w_start, w_end, n_win, eff_lmax(f, *c), kSmallMax, &wc, d_out))) return rc;
-    launch_window_counts(ctx->stream, ctx->n_cu * 8, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, *f, d_out);
-    HIPCHK(ctx, hipGetLastError());
-    if (!out_dev) {
-        HIPCHK(ctx, hipMemcpyAsync(count_out, d_out, n_win * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    return FTK_OK;
-}
+// ---- window features: one implementation behind four entry points ----------------
+namespace {
 
-int ftk_delfi_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
-                     int32_t mapq_min, const int32_t* bl_start, const int32_t* bl_end, int64_t n_bl,
-                     const ftk_gaps* gaps, int64_t* short_out, int64_t* long_out, int64_t* nfrag_out) {
-    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
-    ContigData* c;
-    int rc = get_contig(ctx, contig_id, &c);
-    if (rc) return rc;
-    if (n_win < 0 || n_win > (1 << 30)) return fail(ctx, FTK_ERR_INVALID, "n_win out of range");
-    if (n_win == 0) return FTK_OK;
-    if (!w_start || !w_end || !short_out || !long_out) return fail(ctx, FTK_ERR_INVALID, "NULL window/output pointer");
-    if (n_bl < 0 || (n_bl > 0 && (!bl_start || !bl_end))) return fail(ctx, FTK_ERR_INVALID, "bad blacklist arguments");
-    ftk_gaps g{};
-    if (gaps) g = *gaps;
-    if (g.has_gaps && (g.n_telo < 0 || g.n_telo > FTK_MAX_TELOMERES))
-        return fail(ctx, FTK_ERR_INVALID, "at most %d telomere intervals per contig are supported", FTK_MAX_TELOMERES);
-    if (is_device_ptr(w_start) || is_device_ptr(w_end) || is_device_ptr(bl_start))
-        return fail(ctx, FTK_ERR_INVALID, "ftk_delfi_counts takes host window and blacklist arrays");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-
-    // ---- device-resident windows + blacklist CSR, cached by content -----------------
+// Device-resident windows + per-window blacklist CSR, cached by content.
+int get_delfi_meta(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                   const int32_t* bl_start, const int32_t* bl_end, int64_t n_bl, DelfiMeta** out) {
     uint64_t key = 1469598103934665603ull;
     auto mix = [&key](const void* p, size_t n) {
         const unsigned char* b = (const unsigned char*)p;
@@ -485,120 +444,224 @@ int ftk_delfi_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const 
     mix(w_start, n_win * 4);
     mix(w_end, n_win * 4);
     if (n_bl) { mix(bl_start, n_bl * 4); mix(bl_end, n_bl * 4); }
-    DelfiMeta* meta = nullptr;
     for (auto& m : ctx->delfi_cache)
-        if (m.key == key && m.contig_id == contig_id && m.n_win == n_win) meta = &m;
-    if (!meta) {
-        // Blacklist regions fully inside each window (frag/_delfi.py:110-126):
-        // region start >= w_start (bisect on the sorted starts) and stop <= w_end.
-        // Per window keep (r0, running max of r1); a fragment is blacklisted iff
-        // max{r1 : r0 <= fs} > fe, which equals "some region has r0 <= fs and
-        // fe < r1" (frag/_delfi.py:455-462) also for overlapping regions.
-        std::vector<int32_t> off(n_win + 1, 0), r0, pm;
-        if (n_bl > 0) {
-            for (int64_t i = 1; i < n_bl; ++i)
-                if (bl_start[i] < bl_start[i - 1]) return fail(ctx, FTK_ERR_INVALID, "blacklist must be sorted by start");
-            for (int64_t w = 0; w < n_win; ++w) {
-                const int32_t* lo = std::lower_bound(bl_start, bl_start + n_bl, w_start[w]);
-                int32_t run = INT32_MIN;
-                for (int64_t j = lo - bl_start; j < n_bl && bl_start[j] < w_end[w]; ++j) {
-                    if (bl_end[j] <= w_end[w]) {
-                        run = std::max(run, bl_end[j]);
-                        r0.push_back(bl_start[j]);
-                        pm.push_back(run);
-                    }
+        if (m.key == key && m.contig_id == contig_id && m.n_win == n_win) { *out = &m; return FTK_OK; }
+    // Blacklist regions fully inside each window (frag/_delfi.py:110-126):
+    // region start >= w_start (bisect on the sorted starts) and stop <= w_end.
+    // Per window keep (r0, running max of r1); a fragment is blacklisted iff
+    // max{r1 : r0 <= fs} > fe, which equals "some region has r0 <= fs and
+    // fe < r1" (frag/_delfi.py:455-462) also for overlapping regions.
+    std::vector<int32_t> off(n_win + 1, 0), r0, pm;
+    if (n_bl > 0) {
+        for (int64_t i = 1; i < n_bl; ++i)
+            if (bl_start[i] < bl_start[i - 1]) return fail(ctx, FTK_ERR_INVALID, "blacklist must be sorted by start");
+        for (int64_t w = 0; w < n_win; ++w) {
+            const int32_t* lo = std::lower_bound(bl_start, bl_start + n_bl, w_start[w]);
+            int32_t run = INT32_MIN;
+            for (int64_t j = lo - bl_start; j < n_bl && bl_start[j] < w_end[w]; ++j) {
+                if (bl_end[j] <= w_end[w]) {
+                    run = std::max(run, bl_end[j]);
+                    r0.push_back(bl_start[j]);
+                    pm.push_back(run);
                 }
-                if (r0.size() > (size_t)INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "blacklist expansion too large");
-                off[w + 1] = (int32_t)r0.size();
             }
+            if (r0.size() > (size_t)INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "blacklist expansion too large");
+            off[w + 1] = (int32_t)r0.size();
         }
-        if (ctx->delfi_cache.size() >= 64) {  // drop the oldest entry
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            (void)hipFree(ctx->delfi_cache.front().base);
-            ctx->delfi_cache.erase(ctx->delfi_cache.begin());
-        }
-        DelfiMeta m;
-        m.key = key;
-        m.contig_id = contig_id;
-        m.n_win = n_win;
-        m.n_r = r0.size();
-        const size_t b_w = align_up(n_win * 4), b_o = align_up((n_win + 1) * 4), b_r = align_up(std::max<size_t>(m.n_r, 1) * 4);
-        HIPCHK(ctx, hipMalloc(&m.base, 2 * b_w + b_o + 2 * b_r));
-        char* q = (char*)m.base;
-        m.d_ws = (int32_t*)q;
-        m.d_we = (int32_t*)(q + b_w);
-        m.d_off = (int32_t*)(q + 2 * b_w);
-        m.d_r0 = (int32_t*)(q + 2 * b_w + b_o);
-        m.d_pm = (int32_t*)(q + 2 * b_w + b_o + b_r);
-        hipError_t e = hipMemcpy(m.d_ws, w_start, n_win * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(m.d_we, w_end, n_win * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(m.d_off, off.data(), (n_win + 1) * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess && m.n_r) e = hipMemcpy(m.d_r0, r0.data(), m.n_r * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess && m.n_r) e = hipMemcpy(m.d_pm, pm.data(), m.n_r * 4, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            (void)hipFree(m.base);
-            return fail(ctx, FTK_ERR_HIP, "DELFI metadata upload failed: %s", hipGetErrorString(e));
-        }
-        ctx->delfi_cache.push_back(m);
-        meta = &ctx->delfi_cache.back();
     }
-    const bool use_bl = meta->n_r > 0;
-    const bool s_dev = is_device_ptr(short_out), l_dev = is_device_ptr(long_out), n_dev = is_device_ptr(nfrag_out);
-    size_t need = window_scratch_bytes(n_win) + 3 * align_up(n_win * 8);
-    if ((rc = reserve_scratch(ctx, need))) return rc;
-    Arena a(ctx);
-    WindowCall wc;
-    ftk_filter f{mapq_min, 100, 220, FTK_POLICY_MIDPOINT, c->v.r1_start ? FTK_FETCH_BAM_READ1 : FTK_FETCH_TABIX};
-    int64_t* d_short = s_dev ? short_out : a.take<int64_t>(n_win);
-    int64_t* d_long = l_dev ? long_out : a.take<int64_t>(n_win);
-    int64_t* d_nfrag = nfrag_out ? (n_dev ? nfrag_out : a.take<int64_t>(n_win)) : nullptr;
-    if ((rc = window_prepare(ctx, c, a, meta->d_ws, meta->d_we, n_win, eff_lmax(&f, *c), kSmallMax, &wc, d_short, d_long)))
-        return rc;
-    launch_delfi_counts(ctx->stream, ctx->n_cu * 8, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, mapq_min,
-                        c->v.r1_start != nullptr, g, use_bl ? meta->d_off : nullptr, meta->d_r0, meta->d_pm, d_short,
-                        d_long);
-    if (d_nfrag) launch_add_i64(ctx->stream, d_short, d_long, d_nfrag, (int)n_win);
-    HIPCHK(ctx, hipGetLastError());
-    if (!s_dev) HIPCHK(ctx, hipMemcpyAsync(short_out, d_short, n_win * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (!l_dev) HIPCHK(ctx, hipMemcpyAsync(long_out, d_long, n_win * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (nfrag_out && !n_dev) HIPCHK(ctx, hipMemcpyAsync(nfrag_out, d_nfrag, n_win * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (!s_dev || !l_dev || (nfrag_out && !n_dev)) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->delfi_cache.size() >= 64) {  // drop the oldest entry
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->delfi_cache.front().base);
+        ctx->delfi_cache.erase(ctx->delfi_cache.begin());
+    }
+    DelfiMeta m;
+    m.key = key;
+    m.contig_id = contig_id;
+    m.n_win = n_win;
+    m.n_r = r0.size();
+    const size_t b_w = align_up(n_win * 4), b_o = align_up((n_win + 1) * 4), b_r = align_up(std::max<size_t>(m.n_r, 1) * 4);
+    HIPCHK(ctx, hipMalloc(&m.base, 2 * b_w + b_o + 2 * b_r));
+    char* q = (char*)m.base;
+    m.d_ws = (int32_t*)q;
+    m.d_we = (int32_t*)(q + b_w);
+    m.d_off = (int32_t*)(q + 2 * b_w);
+    m.d_r0 = (int32_t*)(q + 2 * b_w + b_o);
+    m.d_pm = (int32_t*)(q + 2 * b_w + b_o + b_r);
+    hipError_t e = hipMemcpy(m.d_ws, w_start, n_win * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m.d_we, w_end, n_win * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m.d_off, off.data(), (n_win + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && m.n_r) e = hipMemcpy(m.d_r0, r0.data(), m.n_r * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && m.n_r) e = hipMemcpy(m.d_pm, pm.data(), m.n_r * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(m.base);
+        return fail(ctx, FTK_ERR_HIP, "DELFI metadata upload failed: %s", hipGetErrorString(e));
+    }
+    ctx->delfi_cache.push_back(m);
+    *out = &ctx->delfi_cache.back();
     return FTK_OK;
 }
 
-int ftk_fraglen_hist(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
-                     const ftk_filter* f, int32_t len_lo, int32_t n_bins, uint32_t* hist_out, int64_t* overflow_out) {
+struct FeatCall {
+    const ftk_filter* f = nullptr;  // coverage / histogram predicate
+    int64_t* count_out = nullptr;
+    uint32_t* hist_out = nullptr;
+    int64_t* overflow_out = nullptr;
+    int32_t len_lo = 0, n_bins = 0;
+    bool delfi = false;
+    int32_t mapq_min = 0;
+    const int32_t* bl_start = nullptr;
+    const int32_t* bl_end = nullptr;
+    int64_t n_bl = 0;
+    const ftk_gaps* gaps = nullptr;
+    int64_t *short_out = nullptr, *long_out = nullptr, *nfrag_out = nullptr;
+};
+
+int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                    const FeatCall& fc) {
     if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
     ContigData* c;
     int rc = get_contig(ctx, contig_id, &c);
     if (rc) return rc;
-    if ((rc = check_filter(ctx, f, *c))) return rc;
+    const bool ch = fc.count_out || fc.hist_out;
+    if (ch && (rc = check_filter(ctx, fc.f, *c))) return rc;
     if (n_win < 0 || n_win > (1 << 30)) return fail(ctx, FTK_ERR_INVALID, "n_win out of range");
-    if (n_bins <= 0 || n_bins > kHistMaxBins)
+    if (fc.hist_out && (fc.n_bins <= 0 || fc.n_bins > kHistMaxBins))
         return fail(ctx, FTK_ERR_INVALID, "n_bins must be in [1, %d]; split the length range", kHistMaxBins);
     if (n_win == 0) return FTK_OK;
-    if (!w_start || !w_end || !hist_out || !overflow_out) return fail(ctx, FTK_ERR_INVALID, "NULL window/output pointer");
+    if (!w_start || !w_end) return fail(ctx, FTK_ERR_INVALID, "NULL window pointer");
+    if (fc.hist_out && !fc.overflow_out) return fail(ctx, FTK_ERR_INVALID, "overflow_out is NULL");
+    if (!ch && !fc.delfi) return fail(ctx, FTK_ERR_INVALID, "no feature requested");
+    ftk_gaps g{};
+    DelfiMeta* meta = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const bool h_dev = is_device_ptr(hist_out), o_dev = is_device_ptr(overflow_out);
-    const size_t hist_elems = (size_t)n_win * (size_t)n_bins;
-    size_t need = window_scratch_bytes(n_win) + (h_dev ? 0 : align_up(hist_elems * 4)) + (o_dev ? 0 : align_up(n_win * 8));
+    if (fc.delfi) {
+        if (!fc.short_out || !fc.long_out) return fail(ctx, FTK_ERR_INVALID, "NULL DELFI output pointer");
+        if (fc.n_bl < 0 || (fc.n_bl > 0 && (!fc.bl_start || !fc.bl_end)))
+            return fail(ctx, FTK_ERR_INVALID, "bad blacklist arguments");
+        if (fc.gaps) g = *fc.gaps;
+        if (g.has_gaps && (g.n_telo < 0 || g.n_telo > FTK_MAX_TELOMERES))
+            return fail(ctx, FTK_ERR_INVALID, "at most %d telomere intervals per contig are supported", FTK_MAX_TELOMERES);
+        if (is_device_ptr(w_start) || is_device_ptr(w_end) || is_device_ptr(fc.bl_start))
+            return fail(ctx, FTK_ERR_INVALID, "DELFI takes host window and blacklist arrays");
+        if ((rc = get_delfi_meta(ctx, contig_id, w_start, w_end, n_win, fc.bl_start, fc.bl_end, fc.n_bl, &meta)))
+            return rc;
+    }
+    const bool c_dev = is_device_ptr(fc.count_out), h_dev = is_device_ptr(fc.hist_out),
+               o_dev = is_device_ptr(fc.overflow_out), s_dev = is_device_ptr(fc.short_out),
+               l_dev = is_device_ptr(fc.long_out), n_dev = is_device_ptr(fc.nfrag_out);
+    const size_t hist_elems = fc.hist_out ? (size_t)n_win * (size_t)fc.n_bins : 0;
+    size_t need = window_scratch_bytes(n_win) + 5 * align_up(n_win * 8) + (h_dev ? 0 : align_up(hist_elems * 4));
     if ((rc = reserve_scratch(ctx, need))) return rc;
     Arena a(ctx);
+    FeatureRequest r;
+    r.filter = fc.f;
+    r.cov_out = fc.count_out ? (c_dev ? fc.count_out : a.take<int64_t>(n_win)) : nullptr;
+    r.hist_out = fc.hist_out ? (h_dev ? fc.hist_out : a.take<uint32_t>(hist_elems)) : nullptr;
+    r.over_out = fc.hist_out ? (o_dev ? fc.overflow_out : a.take<int64_t>(n_win)) : nullptr;
+    r.len_lo = fc.len_lo;
+    r.n_bins = fc.n_bins;
+    int64_t* d_nfrag = nullptr;
+    if (fc.delfi) {
+        r.short_out = s_dev ? fc.short_out : a.take<int64_t>(n_win);
+        r.long_out = l_dev ? fc.long_out : a.take<int64_t>(n_win);
+        d_nfrag = fc.nfrag_out ? (n_dev ? fc.nfrag_out : a.take<int64_t>(n_win)) : nullptr;
+        r.delfi_mapq_min = fc.mapq_min;
+        r.gaps = g;
+        if (meta->n_r) { r.bl_off = meta->d_off; r.bl_r0 = meta->d_r0; r.bl_pm = meta->d_pm; }
+    }
+    // longest fragment any requested feature can accept
+    int lmax = 0;
+    if (ch) lmax = std::max(lmax, eff_lmax(fc.f, *c));
+    if (fc.delfi) lmax = std::max(lmax, std::max(0, std::min(220, c->max_len)));
+    const bool small_path = !(fc.hist_out && fc.n_bins > kHistSmallMaxBins);
     WindowCall wc;
-    const int small_max = n_bins <= kHistSmallMaxBins ? kSmallMax : -1;
-    if ((rc = window_prepare(ctx, c, a, w_start, w_end, n_win, eff_lmax(f, *c), small_max, &wc))) return rc;
-    uint32_t* d_hist = h_dev ? hist_out : a.take<uint32_t>(hist_elems);
-    int64_t* d_over = o_dev ? overflow_out : a.take<int64_t>(n_win);
-    HIPCHK(ctx, hipMemsetAsync(d_hist, 0, hist_elems * 4, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(d_over, 0, n_win * 8, ctx->stream));
-    launch_fraglen_hist(ctx->stream, ctx->n_cu * 8, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, *f, len_lo, n_bins,
-                        d_hist, d_over);
+    int64_t* zero[4] = {r.cov_out, r.short_out, r.long_out, nullptr};
+    if ((rc = window_prepare(ctx, c, a, meta ? meta->d_ws : w_start, meta ? meta->d_we : w_end, n_win, lmax,
+                             small_path ? kSmallMax : -1, &wc, zero)))
+        return rc;
+    if (r.hist_out) {
+        HIPCHK(ctx, hipMemsetAsync(r.hist_out, 0, hist_elems * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(r.over_out, 0, n_win * 8, ctx->stream));
+    }
+    launch_window_features(ctx->stream, ctx->n_cu * 8, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, r, small_path);
+    if (d_nfrag) launch_add_i64(ctx->stream, r.short_out, r.long_out, d_nfrag, (int)n_win);
     HIPCHK(ctx, hipGetLastError());
-    if (!h_dev) HIPCHK(ctx, hipMemcpyAsync(hist_out, d_hist, hist_elems * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (!o_dev) HIPCHK(ctx, hipMemcpyAsync(overflow_out, d_over, n_win * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (!h_dev || !o_dev) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    bool host_out = false;
+    auto back = [&](void* dst, const void* src, size_t bytes, bool dev) -> hipError_t {
+        if (!dst || dev) return hipSuccess;
+        host_out = true;
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    };
+    HIPCHK(ctx, back(fc.count_out, r.cov_out, n_win * 8, c_dev));
+    HIPCHK(ctx, back(fc.hist_out, r.hist_out, hist_elems * 4, h_dev));
+    HIPCHK(ctx, back(fc.hist_out ? fc.overflow_out : nullptr, r.over_out, n_win * 8, o_dev));
+    HIPCHK(ctx, back(fc.short_out, r.short_out, n_win * 8, s_dev));
+    HIPCHK(ctx, back(fc.long_out, r.long_out, n_win * 8, l_dev));
+    HIPCHK(ctx, back(fc.nfrag_out, d_nfrag, n_win * 8, n_dev));
+    if (host_out) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return FTK_OK;
+}
+
+}  // namespace
+
+int ftk_window_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                      const ftk_filter* f, int64_t* count_out) {
+    if (ctx && n_win > 0 && !count_out) return fail(ctx, FTK_ERR_INVALID, "count_out is NULL");
+    FeatCall fc;
+    fc.f = f;
+    fc.count_out = count_out;
+    return features_common(ctx, contig_id, w_start, w_end, n_win, fc);
+}
+
+int ftk_delfi_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                     int32_t mapq_min, const int32_t* bl_start, const int32_t* bl_end, int64_t n_bl,
+                     const ftk_gaps* gaps, int64_t* short_out, int64_t* long_out, int64_t* nfrag_out) {
+    FeatCall fc;
+    fc.delfi = true;
+    fc.mapq_min = mapq_min;
+    fc.bl_start = bl_start;
+    fc.bl_end = bl_end;
+    fc.n_bl = n_bl;
+    fc.gaps = gaps;
+    fc.short_out = short_out;
+    fc.long_out = long_out;
+    fc.nfrag_out = nfrag_out;
+    return features_common(ctx, contig_id, w_start, w_end, n_win, fc);
+}
+
+int ftk_fraglen_hist(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                     const ftk_filter* f, int32_t len_lo, int32_t n_bins, uint32_t* hist_out, int64_t* overflow_out) {
+    if (ctx && n_win > 0 && !hist_out) return fail(ctx, FTK_ERR_INVALID, "hist_out is NULL");
+    FeatCall fc;
+    fc.f = f;
+    fc.hist_out = hist_out;
+    fc.overflow_out = overflow_out;
+    fc.len_lo = len_lo;
+    fc.n_bins = n_bins;
+    return features_common(ctx, contig_id, w_start, w_end, n_win, fc);
+}
+
+int ftk_window_features(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                        const ftk_filter* f, int64_t* count_out, int32_t len_lo, int32_t n_bins, uint32_t* hist_out,
+                        int64_t* overflow_out, int32_t delfi_mapq_min, const int32_t* bl_start, const int32_t* bl_end,
+                        int64_t n_bl, const ftk_gaps* gaps, int64_t* short_out, int64_t* long_out) {
+    FeatCall fc;
+    fc.f = f;
+    fc.count_out = count_out;
+    fc.hist_out = hist_out;
+    fc.overflow_out = overflow_out;
+    fc.len_lo = len_lo;
+    fc.n_bins = n_bins;
+    fc.delfi = short_out != nullptr || long_out != nullptr;
+    fc.mapq_min = delfi_mapq_min;
+    fc.bl_start = bl_start;
+    fc.bl_end = bl_end;
+    fc.n_bl = n_bl;
+    fc.gaps = gaps;
+    fc.short_out = short_out;
+    fc.long_out = long_out;
+    return features_common(ctx, contig_id, w_start, w_end, n_win, fc);
 }
 
 static int select_common(ftk_ctx* ctx, int contig_id, int32_t w_start, int32_t w_end, const ftk_filter* f,

@@ -37,16 +37,25 @@ struct WpsParams {
 void launch_stats(hipStream_t s, const int32_t* start, const int32_t* end, int n, FragStats* st);
 void launch_bin_index(hipStream_t s, const int32_t* start, int n, int n_bins, int32_t* idx);
 void launch_plan(hipStream_t s, const ContigView& cv, const int32_t* ws, const int32_t* we, int n_win, int lmax,
-                 int small_max, const WindowPlan& pl, int64_t* zero1, int64_t* zero2);
-void launch_window_counts(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
-                          int n_win, const WindowPlan& pl, const ftk_filter& f, int64_t* out);
-void launch_delfi_counts(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
-                         int n_win, const WindowPlan& pl, int mapq_min, int bam, const ftk_gaps& g,
-                         const int32_t* bl_off, const int32_t* bl_r0, const int32_t* bl_pm, int64_t* short_out,
-                         int64_t* long_out);
-void launch_fraglen_hist(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
-                         int n_win, const WindowPlan& pl, const ftk_filter& f, int len_lo, int n_bins,
-                         uint32_t* hist_out, int64_t* overflow_out);
+                 int small_max, const WindowPlan& pl, int64_t* const zero[4]);
+
+// What one window-feature pass should produce (NULL output = feature off).
+struct FeatureRequest {
+    const ftk_filter* filter = nullptr;  // coverage + histogram predicate
+    int64_t* cov_out = nullptr;
+    uint32_t* hist_out = nullptr;        // [n_win][n_bins], zero-filled by the caller
+    int64_t* over_out = nullptr;         // zero-filled by the caller
+    int len_lo = 0, n_bins = 0;
+    int64_t* short_out = nullptr;        // DELFI
+    int64_t* long_out = nullptr;
+    int delfi_mapq_min = 0;
+    ftk_gaps gaps{};
+    const int32_t* bl_off = nullptr;
+    const int32_t* bl_r0 = nullptr;
+    const int32_t* bl_pm = nullptr;
+};
+void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
+                            int n_win, const WindowPlan& pl, const FeatureRequest& r, bool small_path);
 void launch_add_i64(hipStream_t s, const int64_t* a, const int64_t* b, int64_t* out, int n);
 void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t n_tiles, const int64_t* iv_start,
                 const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv, const int32_t* tile_k,

@@ -99,9 +99,12 @@ __device__ __forceinline__ void window_candidates(const ContigView& cv, int s, i
     nchunks = (cnt <= small_max) ? 0u : (uint32_t)((cnt + kChunk - 1) / kChunk);
 }
 
+struct ZeroList {  // outputs the chunked path accumulates into with atomics
+    int64_t* p[4];
+};
+
 __global__ void bounds_kernel(ContigView cv, const int32_t* ws, const int32_t* we, int n_win, int lmax,
-                              int small_max, int32_t* cand_lo, int32_t* cand_hi, uint32_t* nchunks, int64_t* zero1,
-                              int64_t* zero2) {
+                              int small_max, int32_t* cand_lo, int32_t* cand_hi, uint32_t* nchunks, ZeroList z) {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_win) return;
     int lo, hi;
@@ -111,8 +114,9 @@ __global__ void bounds_kernel(ContigView cv, const int32_t* ws, const int32_t* w
     cand_hi[w] = hi;
     nchunks[w] = nc;
     if (nc) {  // the chunked path accumulates with atomics: start from zero
-        if (zero1) zero1[w] = 0;
-        if (zero2) zero2[w] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (z.p[k]) z.p[k][w] = 0;
     }
 }
 
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* nchunks, int
 // few thousand per contig is the common case: saves two dependent launches).
 __global__ __launch_bounds__(1024) void plan_kernel(ContigView cv, const int32_t* ws, const int32_t* we, int n_win,
                                                     int lmax, int small_max, int32_t* cand_lo, int32_t* cand_hi,
-                                                    uint32_t* nchunks, uint32_t* off, int64_t* zero1, int64_t* zero2) {
+                                                    uint32_t* nchunks, uint32_t* off, ZeroList z) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -164,8 +168,9 @@ __global__ __launch_bounds__(1024) void plan_kernel(ContigView cv, const int32_t
             cand_hi[w] = hi;
             nchunks[w] = v;
             if (v) {
-                if (zero1) zero1[w] = 0;
-                if (zero2) zero2[w] = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (z.p[k]) z.p[k][w] = 0;
             }
         }
         uint32_t x = v;
@@ -194,57 +199,61 @@ __global__ __launch_bounds__(1024) void plan_kernel(ContigView cv, const int32_t
 // :245 read1 overlap for BAM).  Returns 1 when the fragment counts.
 struct WinPred {
     int mapq_min, min_len, max_len, policy, bam;
-    __device__ __forceinline__ int operator()(const ContigView& cv, int i, int fs, int fe, int q, int ws, int we,
-                                              int /*w*/) const {
-        int len = fe - fs;
+    template <bool BAM>
+    __device__ __forceinline__ int test(const ContigView& cv, int i, int fs, int fe, int q, int ws, int we) const {
+        const int len = fe - fs;
         bool ok = (q >= mapq_min) && (len >= min_len) && (len <= max_len);
-        if (bam) {
-            int rs = cv.r1_start[i], re = cv.r1_end[i];
+        if (BAM) {
+            const int rs = cv.r1_start[i], re = cv.r1_end[i];
             ok = ok && (rs < we) && (re > ws);
         } else {
             ok = ok && (fs < we) && (fe > ws);
         }
         if (policy == FTK_POLICY_MIDPOINT) {
-            int mid = (int)(((long long)fs + (long long)fe) >> 1);
+            const int mid = (int)(((long long)fs + (long long)fe) >> 1);
             ok = ok && (mid >= ws) && (mid < we);
         } else {
             ok = ok && (fe > ws) && (fs < we);
         }
         return ok ? 1 : 0;
     }
+    __device__ __forceinline__ int operator()(const ContigView& cv, int i, int fs, int fe, int q, int ws, int we,
+                                              int /*w*/) const {
+        return bam ? test<true>(cv, i, fs, fe, q, ws, we) : test<false>(cv, i, fs, fe, q, ws, we);
+    }
 };
 
-// frag/_delfi.py:443-472.  Returns 0 (skip), 1 (short) or 2 (long).
+// frag/_delfi.py:443-472.  Returns 0 (skip), 1 (short) or 2 (long).  [o0, o1) is
+// the window's slice of the blacklist CSR (hoisted per window by the caller).
 struct DelfiPred {
-    int mapq_min, bam;
+    int mapq_min;
     ftk_gaps g;
-    const int32_t* bl_off;  // n_win + 1 offsets into bl_r0 / bl_pm
+    const int32_t* bl_off;  // n_win + 1 offsets into bl_r0 / bl_pm (NULL: no blacklist)
     const int32_t* bl_r0;   // region starts (sorted) of the regions fully inside each window
     const int32_t* bl_pm;   // running maximum of the region stops inside each window
-    __device__ __forceinline__ int operator()(const ContigView& cv, int i, int fs, int fe, int q, int ws, int we,
-                                              int w) const {
-        if (q < mapq_min) return 0;
-        if (bam) {
-            int rs = cv.r1_start[i], re = cv.r1_end[i];
-            if (!((rs < we) && (re > ws))) return 0;
-        } else if (!((fs < we) && (fe > ws))) {
-            return 0;
+    template <bool BAM>
+    __device__ __forceinline__ int test(const ContigView& cv, int i, int fs, int fe, int q, int ws, int we, int o0,
+                                        int o1) const {
+        const int len = fe - fs;
+        const int mid = (int)(((long long)fs + (long long)fe) >> 1);
+        bool ok = (q >= mapq_min) && (len >= 100) && (len <= 220) && (mid >= ws) && (mid < we);
+        if (BAM) {
+            const int rs = cv.r1_start[i], re = cv.r1_end[i];
+            ok = ok && (rs < we) && (re > ws);
+        } else {
+            ok = ok && (fs < we) && (fe > ws);
         }
-        int len = fe - fs;
-        if (len < 100 || len > 220) return 0;
-        int mid = (int)(((long long)fs + (long long)fe) >> 1);
-        if (mid < ws || mid >= we) return 0;
+        if (!ok) return 0;
         if (g.has_gaps) {  // genome/gaps.py:217-237
-            bool in_cen = (fe > g.cen_start) && (fs < g.cen_stop);
+            const bool in_cen = (fe > g.cen_start) && (fs < g.cen_stop);
             bool in_tel = g.n_telo > 0;
             for (int t = 0; t < g.n_telo; ++t) in_tel = in_tel && (fe > g.telo_start[t]) && (fs < g.telo_stop[t]);
             if (in_cen || in_tel) return 0;
         }
-        if (bl_off) {  // frag/_delfi.py:455-462
-            int o0 = bl_off[w], o1 = bl_off[w + 1];
+        if (o1 > o0) {  // frag/_delfi.py:455-462: blacklisted iff max{r1 : r0 <= fs} > fe
             int lo = o0, hi = o1;  // upper bound: first region with r0 > fs
             while (lo < hi) {
-                int m = (lo + hi) >> 1;
+                const int m = (lo + hi) >> 1;
                 if (bl_r0[m] <= fs) lo = m + 1; else hi = m;
             }
             if (lo > o0 && bl_pm[lo - 1] > fe) return 0;
@@ -253,204 +262,142 @@ struct DelfiPred {
     }
 };
 
-// ---------------------------------------------------------------------------
-// window counters (coverage / DELFI): small path = one wave per window
-// ---------------------------------------------------------------------------
-template <class Pred>
-__global__ __launch_bounds__(256) void count_small_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
-                                                          int n_win, const int32_t* cand_lo, const int32_t* cand_hi,
-                                                          const uint32_t* nchunks, Pred pred, int64_t* out1,
-                                                          int64_t* out2) {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (w >= n_win) return;
-    if (nchunks[w] != 0) return;  // handled by the chunked path (which also owns the output)
-    const int lo = cand_lo[w], hi = cand_hi[w];
-    const int ws = ws_[w], we = we_[w];
-    int a1 = 0, a2 = 0;
-    for (int i = (lo & ~3) + 4 * lane; i < hi; i += 256) {
-        const int4 s = *reinterpret_cast<const int4*>(cv.start + i);
-        const int4 e = *reinterpret_cast<const int4*>(cv.end + i);
-        const uchar4 q = *reinterpret_cast<const uchar4*>(cv.mapq + i);
-        const int ss[4] = {s.x, s.y, s.z, s.w}, ee[4] = {e.x, e.y, e.z, e.w}, qq[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int idx = i + j;
-            if (idx >= lo && idx < hi) {
-                int r = pred(cv, idx, ss[j], ee[j], qq[j], ws, we, w);
-                a1 += (r == 1);
-                a2 += (r == 2);
-            }
-        }
-    }
-    a1 = wave_reduce_add(a1);
-    a2 = wave_reduce_add(a2);
-    if (lane == 0) {
-        out1[w] = a1;
-        if (out2) out2[w] = a2;
-    }
-}
+// What one window-feature launch computes (any combination, ONE pass over the fragments):
+//   coverage count + length histogram under `wp`  (frag/_coverage.py:117-130, _frag_length.py:147-153)
+//   DELFI short / long under `dp`                   (frag/_delfi.py:443-472)
+struct FeatParams {
+    WinPred wp;
+    DelfiPred dp;
+    int do_cov, do_hist;
+    int len_lo, n_bins;
+    int64_t* cov_out;
+    uint32_t* hist_out;
+    int64_t* over_out;
+    int64_t* short_out;
+    int64_t* long_out;
+};
 
-// large path: a fixed grid walks the chunk list in order; one atomic per
-// (block, window) pair.
-template <class Pred>
-__global__ __launch_bounds__(256) void count_large_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
-                                                          int n_win, const int32_t* cand_lo, const int32_t* cand_hi,
-                                                          const uint32_t* chunk_off, Pred pred, int64_t* out1,
-                                                          int64_t* out2) {
-    __shared__ int red[2][4];
-    const uint32_t total = chunk_off[n_win];
-    const uint32_t c0 = (uint32_t)(((unsigned long long)total * blockIdx.x) / gridDim.x);
-    const uint32_t c1 = (uint32_t)(((unsigned long long)total * (blockIdx.x + 1)) / gridDim.x);
-    if (c0 >= c1) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int w;
-    {
-        int lo = 0, hi = n_win;  // largest w with chunk_off[w] <= c0
-        while (hi - lo > 1) {
-            int m = (lo + hi) >> 1;
-            if (chunk_off[m] <= c0) lo = m; else hi = m;
+struct FeatAcc {
+    int cov = 0, over = 0, sh = 0, lg = 0;
+};
+
+template <bool CH, bool DF, bool BAM>
+__device__ __forceinline__ void feat_element(const ContigView& cv, const FeatParams& P, int idx, int fs, int fe, int q,
+                                             int ws, int we, int o0, int o1, uint32_t* h, FeatAcc& a) {
+    if (CH) {
+        if (P.wp.test<BAM>(cv, idx, fs, fe, q, ws, we)) {
+            ++a.cov;
+            if (P.do_hist) {
+                const int b = (fe - fs) - P.len_lo;
+                if (b >= 0 && b < P.n_bins) atomicAdd(&h[b], 1u); else ++a.over;
+            }
         }
-        w = lo;
     }
-    int a1 = 0, a2 = 0;
-    uint32_t c = c0;
-    while (c < c1) {
-        uint32_t w_first = chunk_off[w], w_next = chunk_off[w + 1];
-        if (c >= w_next) { ++w; continue; }
-        const int ws = ws_[w], we = we_[w];
-        const int wlo = cand_lo[w], whi = cand_hi[w];
-        const uint32_t c_end = min(c1, w_next);
-        for (; c < c_end; ++c) {
-            const int lo = wlo + (int)(c - w_first) * kChunk;
-            const int hi = min(lo + kChunk, whi);
-            // a whole chunk (4 x 1024 fragments) is requested before any of it is used
-            const int i0 = (lo & ~3) + 4 * tid;
-            int4 s4[4], e4[4];
-            uchar4 q4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 1024;
-                if (i < hi) {
-                    s4[u] = *reinterpret_cast<const int4*>(cv.start + i);
-                    e4[u] = *reinterpret_cast<const int4*>(cv.end + i);
-                    q4[u] = *reinterpret_cast<const uchar4*>(cv.mapq + i);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 1024;
-                if (i < hi) {
-                    const int ss[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w};
-                    const int ee[4] = {e4[u].x, e4[u].y, e4[u].z, e4[u].w};
-                    const int qq[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int idx = i + j;
-                        if (idx >= lo && idx < hi) {
-                            const int r = pred(cv, idx, ss[j], ee[j], qq[j], ws, we, w);
-                            a1 += (r == 1);
-                            a2 += (r == 2);
-                        }
-                    }
-                }
-            }
-        }
-        // flush this window's partial sums
-        a1 = wave_reduce_add(a1);
-        a2 = wave_reduce_add(a2);
-        if (lane == 0) { red[0][wv] = a1; red[1][wv] = a2; }
-        __syncthreads();
-        if (tid == 0) {
-            int t1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-            int t2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-            if (t1) atomicAdd(reinterpret_cast<unsigned long long*>(out1 + w), (unsigned long long)t1);
-            if (out2 && t2) atomicAdd(reinterpret_cast<unsigned long long*>(out2 + w), (unsigned long long)t2);
-        }
-        __syncthreads();
-        a1 = 0; a2 = 0;
+    if (DF) {
+        const int r = P.dp.test<BAM>(cv, idx, fs, fe, q, ws, we, o0, o1);
+        a.sh += (r == 1);
+        a.lg += (r == 2);
     }
 }
 
 // ---------------------------------------------------------------------------
-// fragment-length histogram per window (frag/_frag_length.py:147-153)
+// window features, small path: one wave per window (candidate range <= kSmallMax)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void hist_small_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
+template <bool CH, bool DF, bool BAM>
+__global__ __launch_bounds__(256) void feat_small_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
                                                          int n_win, const int32_t* cand_lo, const int32_t* cand_hi,
-                                                         const uint32_t* nchunks, WinPred pred, int len_lo, int n_bins,
-                                                         uint32_t* hist_out, int64_t* overflow_out) {
+                                                         const uint32_t* nchunks, FeatParams P) {
     extern __shared__ uint32_t lds_hist[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + wv;
     if (w >= n_win) return;
-    if (nchunks[w] != 0) return;
+    if (nchunks[w] != 0) return;  // the chunked path owns this window
     const int lo = cand_lo[w], hi = cand_hi[w];
-    if (lo >= hi) { if (lane == 0) overflow_out[w] = 0; return; }
-    uint32_t* h = lds_hist + (size_t)wv * n_bins;
-    for (int b = lane; b < n_bins; b += 64) h[b] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     const int ws = ws_[w], we = we_[w];
-    int over = 0;
-    for (int i = (lo & ~3) + 4 * lane; i < hi; i += 256) {
+    const bool hist = CH && P.do_hist;
+    uint32_t* h = lds_hist + (size_t)wv * P.n_bins;
+    if (hist && lo < hi) {
+        for (int b = lane; b < P.n_bins; b += 64) h[b] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    int o0 = 0, o1 = 0;
+    if (DF && P.dp.bl_off) { o0 = P.dp.bl_off[w]; o1 = P.dp.bl_off[w + 1]; }
+    FeatAcc a;
+    for (int i = lo + 4 * lane; i < hi; i += 256) {  // lo is a multiple of 4 (planner)
         const int4 s = *reinterpret_cast<const int4*>(cv.start + i);
         const int4 e = *reinterpret_cast<const int4*>(cv.end + i);
         const uchar4 q = *reinterpret_cast<const uchar4*>(cv.mapq + i);
         const int ss[4] = {s.x, s.y, s.z, s.w}, ee[4] = {e.x, e.y, e.z, e.w}, qq[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int idx = i + j;
-            if (idx >= lo && idx < hi && pred(cv, idx, ss[j], ee[j], qq[j], ws, we, w)) {
-                int b = (ee[j] - ss[j]) - len_lo;
-                if (b >= 0 && b < n_bins) atomicAdd(&h[b], 1u); else ++over;
-            }
+        for (int j = 0; j < 4; ++j)
+            if (i + j < hi) feat_element<CH, DF, BAM>(cv, P, i + j, ss[j], ee[j], qq[j], ws, we, o0, o1, h, a);
+    }
+    if (hist && lo < hi) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t* dst = P.hist_out + (size_t)w * P.n_bins;
+        for (int b = lane; b < P.n_bins; b += 64) {
+            const uint32_t v = h[b];
+            if (v) dst[b] = v;  // hist_out was zero-filled by the caller
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    uint32_t* dst = hist_out + (size_t)w * n_bins;
-    for (int b = lane; b < n_bins; b += 64) {
-        uint32_t v = h[b];
-        if (v) dst[b] = v;
+    a.cov = wave_reduce_add(a.cov);
+    a.over = wave_reduce_add(a.over);
+    a.sh = wave_reduce_add(a.sh);
+    a.lg = wave_reduce_add(a.lg);
+    if (lane == 0) {
+        if (CH && P.do_cov) P.cov_out[w] = a.cov;
+        if (hist) P.over_out[w] = a.over;
+        if (DF) { P.short_out[w] = a.sh; P.long_out[w] = a.lg; }
     }
-    over = wave_reduce_add(over);
-    if (lane == 0) overflow_out[w] = over;
 }
 
-__global__ __launch_bounds__(256) void hist_large_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
+// ---------------------------------------------------------------------------
+// window features, large path: a fixed grid walks the list of 4096-fragment
+// chunks in order; a block keeps accumulating while the window stays the same
+// and issues one atomic per counter per (block, window).
+// ---------------------------------------------------------------------------
+template <bool CH, bool DF, bool BAM>
+__global__ __launch_bounds__(256) void feat_large_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
                                                          int n_win, const int32_t* cand_lo, const int32_t* cand_hi,
-                                                         const uint32_t* chunk_off, WinPred pred, int len_lo,
-                                                         int n_bins, uint32_t* hist_out, int64_t* overflow_out) {
+                                                         const uint32_t* chunk_off, FeatParams P) {
     extern __shared__ uint32_t lds_hist[];
-    __shared__ int red[4];
+    __shared__ int red[4][4];
     const uint32_t total = chunk_off[n_win];
     const uint32_t c0 = (uint32_t)(((unsigned long long)total * blockIdx.x) / gridDim.x);
     const uint32_t c1 = (uint32_t)(((unsigned long long)total * (blockIdx.x + 1)) / gridDim.x);
     if (c0 >= c1) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int b = tid; b < n_bins; b += 256) lds_hist[b] = 0;
-    __syncthreads();
+    const bool hist = CH && P.do_hist;
+    if (hist) {
+        for (int b = tid; b < P.n_bins; b += 256) lds_hist[b] = 0;
+        __syncthreads();
+    }
     int w;
     {
-        int lo = 0, hi = n_win;
+        int lo = 0, hi = n_win;  // largest w with chunk_off[w] <= c0
         while (hi - lo > 1) {
-            int m = (lo + hi) >> 1;
+            const int m = (lo + hi) >> 1;
             if (chunk_off[m] <= c0) lo = m; else hi = m;
         }
         w = lo;
     }
-    int over = 0;
+    FeatAcc a;
     uint32_t c = c0;
     while (c < c1) {
-        uint32_t w_first = chunk_off[w], w_next = chunk_off[w + 1];
+        const uint32_t w_first = chunk_off[w], w_next = chunk_off[w + 1];
         if (c >= w_next) { ++w; continue; }
         const int ws = ws_[w], we = we_[w];
         const int wlo = cand_lo[w], whi = cand_hi[w];
+        int o0 = 0, o1 = 0;
+        if (DF && P.dp.bl_off) { o0 = P.dp.bl_off[w]; o1 = P.dp.bl_off[w + 1]; }
         const uint32_t c_end = min(c1, w_next);
         for (; c < c_end; ++c) {
-            const int lo = wlo + (int)(c - w_first) * kChunk;
+            const int lo = wlo + (int)(c - w_first) * kChunk;  // multiple of 4 (planner)
             const int hi = min(lo + kChunk, whi);
-            const int i0 = (lo & ~3) + 4 * tid;
+            // a whole chunk (4 x 1024 fragments) is requested before any of it is used
+            const int i0 = lo + 4 * tid;
             int4 s4[4], e4[4];
             uchar4 q4[4];
 #pragma unroll
@@ -470,31 +417,36 @@ __global__ __launch_bounds__(256) void hist_large_kernel(ContigView cv, const in
                     const int ee[4] = {e4[u].x, e4[u].y, e4[u].z, e4[u].w};
                     const int qq[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int idx = i + j;
-                        if (idx >= lo && idx < hi && pred(cv, idx, ss[j], ee[j], qq[j], ws, we, w)) {
-                            const int b = (ee[j] - ss[j]) - len_lo;
-                            if (b >= 0 && b < n_bins) atomicAdd(&lds_hist[b], 1u); else ++over;
-                        }
-                    }
+                    for (int j = 0; j < 4; ++j)
+                        if (i + j < hi)
+                            feat_element<CH, DF, BAM>(cv, P, i + j, ss[j], ee[j], qq[j], ws, we, o0, o1, lds_hist, a);
                 }
             }
         }
-        __syncthreads();
-        uint32_t* dst = hist_out + (size_t)w * n_bins;
-        for (int b = tid; b < n_bins; b += 256) {
-            uint32_t v = lds_hist[b];
-            if (v) { atomicAdd(&dst[b], v); lds_hist[b] = 0; }
+        // ---- flush this window's partial results -------------------------------------
+        if (hist) {
+            __syncthreads();
+            uint32_t* dst = P.hist_out + (size_t)w * P.n_bins;
+            for (int b = tid; b < P.n_bins; b += 256) {
+                const uint32_t v = lds_hist[b];
+                if (v) { atomicAdd(&dst[b], v); lds_hist[b] = 0; }
+            }
         }
-        over = wave_reduce_add(over);
-        if (lane == 0) red[wv] = over;
+        a.cov = wave_reduce_add(a.cov);
+        a.over = wave_reduce_add(a.over);
+        a.sh = wave_reduce_add(a.sh);
+        a.lg = wave_reduce_add(a.lg);
+        if (lane == 0) { red[0][wv] = a.cov; red[1][wv] = a.over; red[2][wv] = a.sh; red[3][wv] = a.lg; }
         __syncthreads();
-        if (tid == 0) {
-            int t = red[0] + red[1] + red[2] + red[3];
-            if (t) atomicAdd(reinterpret_cast<unsigned long long*>(overflow_out + w), (unsigned long long)t);
+        if (tid < 4) {
+            const int t = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+            int64_t* dst = tid == 0 ? (CH && P.do_cov ? P.cov_out : nullptr)
+                         : tid == 1 ? (hist ? P.over_out : nullptr)
+                         : tid == 2 ? (DF ? P.short_out : nullptr) : (DF ? P.long_out : nullptr);
+            if (dst && t) atomicAdd(reinterpret_cast<unsigned long long*>(dst + w), (unsigned long long)t);
         }
-        over = 0;
         __syncthreads();
+        a = FeatAcc{};
     }
 }
 
@@ -786,54 +738,63 @@ void launch_bin_index(hipStream_t s, const int32_t* start, int n, int n_bins, in
 }
 
 void launch_plan(hipStream_t s, const ContigView& cv, const int32_t* ws, const int32_t* we, int n_win, int lmax,
-                 int small_max, const WindowPlan& pl, int64_t* zero1, int64_t* zero2) {
+                 int small_max, const WindowPlan& pl, int64_t* const zero[4]) {
+    ZeroList z;
+    for (int k = 0; k < 4; ++k) z.p[k] = zero ? zero[k] : nullptr;
     if (n_win <= 16384) {
         hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, s, cv, ws, we, n_win, lmax, small_max, pl.cand_lo,
-                           pl.cand_hi, pl.nchunks, pl.chunk_off, zero1, zero2);
+                           pl.cand_hi, pl.nchunks, pl.chunk_off, z);
         return;
     }
     hipLaunchKernelGGL(bounds_kernel, dim3((n_win + 255) / 256), dim3(256), 0, s, cv, ws, we, n_win, lmax, small_max,
-                       pl.cand_lo, pl.cand_hi, pl.nchunks, zero1, zero2);
+                       pl.cand_lo, pl.cand_hi, pl.nchunks, z);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, pl.nchunks, n_win, pl.chunk_off);
 }
 
-template <class Pred>
-static void launch_count_t(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
-                           int n_win, const WindowPlan& pl, const Pred& pred, int64_t* out1, int64_t* out2) {
-    hipLaunchKernelGGL(count_small_kernel<Pred>, dim3((n_win + 3) / 4), dim3(256), 0, s, cv, ws, we, n_win,
-                       pl.cand_lo, pl.cand_hi, pl.nchunks, pred, out1, out2);
-    hipLaunchKernelGGL(count_large_kernel<Pred>, dim3(grid_large), dim3(256), 0, s, cv, ws, we, n_win, pl.cand_lo,
-                       pl.cand_hi, pl.chunk_off, pred, out1, out2);
+static WinPred make_win_pred(const ftk_filter& f) {
+    return WinPred{f.mapq_min, f.min_len < 0 ? INT32_MIN : f.min_len, f.max_len < 0 ? INT32_MAX : f.max_len, f.policy,
+                   f.fetch_mode == FTK_FETCH_BAM_READ1};
 }
 
-void launch_window_counts(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
-                          int n_win, const WindowPlan& pl, const ftk_filter& f, int64_t* out) {
-    WinPred pred{f.mapq_min, f.min_len < 0 ? INT32_MIN : f.min_len, f.max_len < 0 ? INT32_MAX : f.max_len, f.policy,
-                 f.fetch_mode == FTK_FETCH_BAM_READ1};
-    launch_count_t(s, grid_large, cv, ws, we, n_win, pl, pred, out, nullptr);
+template <bool CH, bool DF, bool BAM>
+static void launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
+                          int n_win, const WindowPlan& pl, const FeatParams& P, bool small_path) {
+    const size_t lds1 = (CH && P.do_hist) ? (size_t)P.n_bins * sizeof(uint32_t) : 0;
+    if (small_path)
+        hipLaunchKernelGGL((feat_small_kernel<CH, DF, BAM>), dim3((n_win + 3) / 4), dim3(256), 4 * lds1, s, cv, ws, we,
+                           n_win, pl.cand_lo, pl.cand_hi, pl.nchunks, P);
+    hipLaunchKernelGGL((feat_large_kernel<CH, DF, BAM>), dim3(grid_large), dim3(256), lds1, s, cv, ws, we, n_win,
+                       pl.cand_lo, pl.cand_hi, pl.chunk_off, P);
 }
 
-void launch_delfi_counts(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
-                         int n_win, const WindowPlan& pl, int mapq_min, int bam, const ftk_gaps& g,
-                         const int32_t* bl_off, const int32_t* bl_r0, const int32_t* bl_pm, int64_t* short_out,
-                         int64_t* long_out) {
-    DelfiPred pred{mapq_min, bam, g, bl_off, bl_r0, bl_pm};
-    launch_count_t(s, grid_large, cv, ws, we, n_win, pl, pred, short_out, long_out);
-}
-
-void launch_fraglen_hist(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
-                         int n_win, const WindowPlan& pl, const ftk_filter& f, int len_lo, int n_bins,
-                         uint32_t* hist_out, int64_t* overflow_out) {
-    WinPred pred{f.mapq_min, f.min_len < 0 ? INT32_MIN : f.min_len, f.max_len < 0 ? INT32_MAX : f.max_len, f.policy,
-                 f.fetch_mode == FTK_FETCH_BAM_READ1};
-    // hist_out and overflow_out were zeroed by the caller (hipMemsetAsync on s)
-    if (n_bins <= kHistSmallMaxBins) {
-        hipLaunchKernelGGL(hist_small_kernel, dim3((n_win + 3) / 4), dim3(256), (size_t)4 * n_bins * sizeof(uint32_t),
-                           s, cv, ws, we, n_win, pl.cand_lo, pl.cand_hi, pl.nchunks, pred, len_lo, n_bins, hist_out,
-                           overflow_out);
-    }
-    hipLaunchKernelGGL(hist_large_kernel, dim3(grid_large), dim3(256), (size_t)n_bins * sizeof(uint32_t), s, cv, ws,
-                       we, n_win, pl.cand_lo, pl.cand_hi, pl.chunk_off, pred, len_lo, n_bins, hist_out, overflow_out);
+// One pass computing any combination of {coverage, length histogram} (filter `f`) and DELFI
+// short/long.  hist_out / over_out must be zero-filled by the caller when histograms are on.
+void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
+                            int n_win, const WindowPlan& pl, const FeatureRequest& r, bool small_path) {
+    FeatParams P{};
+    const bool ch = r.cov_out || r.hist_out;
+    const bool df = r.short_out != nullptr;
+    if (r.filter) P.wp = make_win_pred(*r.filter);
+    P.do_cov = r.cov_out != nullptr;
+    P.do_hist = r.hist_out != nullptr;
+    P.len_lo = r.len_lo;
+    P.n_bins = r.n_bins;
+    P.cov_out = r.cov_out;
+    P.hist_out = r.hist_out;
+    P.over_out = r.over_out;
+    P.short_out = r.short_out;
+    P.long_out = r.long_out;
+    P.dp = DelfiPred{r.delfi_mapq_min, r.gaps, r.bl_off, r.bl_r0, r.bl_pm};
+    const bool bam = cv.r1_start != nullptr && (!r.filter || r.filter->fetch_mode == FTK_FETCH_BAM_READ1);
+#define FTK_FEAT(CH, DF)                                                                              \
+    do {                                                                                              \
+        if (bam) launch_feat_t<CH, DF, true>(s, grid_large, cv, ws, we, n_win, pl, P, small_path);    \
+        else launch_feat_t<CH, DF, false>(s, grid_large, cv, ws, we, n_win, pl, P, small_path);       \
+    } while (0)
+    if (ch && df) FTK_FEAT(true, true);
+    else if (ch) FTK_FEAT(true, false);
+    else if (df) FTK_FEAT(false, true);
+#undef FTK_FEAT
 }
 
 void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t n_tiles, const int64_t* iv_start,
@@ -850,8 +811,7 @@ void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t
 
 void launch_select_count(hipStream_t s, const ContigView& cv, int lo, int hi, int ws, int we, const ftk_filter& f,
                          uint32_t* block_cnt) {
-    WinPred pred{f.mapq_min, f.min_len < 0 ? INT32_MIN : f.min_len, f.max_len < 0 ? INT32_MAX : f.max_len, f.policy,
-                 f.fetch_mode == FTK_FETCH_BAM_READ1};
+    WinPred pred = make_win_pred(f);
     int nb = (hi - lo + 255) / 256;
     if (nb <= 0) return;
     hipLaunchKernelGGL(select_count_kernel, dim3(nb), dim3(256), 0, s, cv, lo, hi, ws, we, pred, block_cnt);
@@ -864,8 +824,7 @@ void launch_scan_u32(hipStream_t s, const uint32_t* in, int n, uint32_t* off) {
 void launch_select_write(hipStream_t s, const ContigView& cv, int lo, int hi, int ws, int we, const ftk_filter& f,
                          const uint32_t* block_off, int64_t cap, int32_t* len_out, int32_t* start_out,
                          int32_t* end_out, uint8_t* mapq_out, uint8_t* strand_out) {
-    WinPred pred{f.mapq_min, f.min_len < 0 ? INT32_MIN : f.min_len, f.max_len < 0 ? INT32_MAX : f.max_len, f.policy,
-                 f.fetch_mode == FTK_FETCH_BAM_READ1};
+    WinPred pred = make_win_pred(f);
     int nb = (hi - lo + 255) / 256;
     if (nb <= 0) return;
     hipLaunchKernelGGL(select_write_kernel, dim3(nb), dim3(256), 0, s, cv, lo, hi, ws, we, pred, block_off, cap,

@@ -175,6 +175,42 @@ class Engine:
                                               C.byref(f), int(len_lo), int(n_bins), L.ptr(hist), L.ptr(over)))
         return hist, over
 
+    def window_features(self, name: str, starts, stops, quality_threshold=30, min_length=None, max_length=None,
+                        intersect_policy="midpoint", coverage=True, hist=None, delfi=None):
+        """Coverage / length histogram / DELFI counts of the same windows in ONE pass
+        (``ftk_window_features``).  ``hist=(len_lo, n_bins)``; ``delfi=dict(quality_threshold=,
+        bl_start=, bl_end=, gaps=)``.  Returns a dict of the requested arrays."""
+        ws, we = _win(starts, L.OPEN_LO), _win(stops, L.OPEN_HI)
+        n = len(ws)
+        f = self._filter(name, quality_threshold, min_length, max_length, intersect_policy)
+        out = {}
+        cov = np.zeros(n, np.int64) if coverage else None
+        h = o = None
+        len_lo = n_bins = 0
+        if hist is not None:
+            len_lo, n_bins = int(hist[0]), int(hist[1])
+            h, o = np.zeros((n, n_bins), np.uint32), np.zeros(n, np.int64)
+        sh = lg = bs = be = None
+        n_bl, q, g = 0, 0, L.make_gaps(None)
+        if delfi is not None:
+            sh, lg = np.zeros(n, np.int64), np.zeros(n, np.int64)
+            q = int(delfi.get("quality_threshold", 30))
+            if delfi.get("bl_start") is not None and len(delfi["bl_start"]):
+                bs = np.ascontiguousarray(delfi["bl_start"], dtype=np.int32)
+                be = np.ascontiguousarray(delfi["bl_end"], dtype=np.int32)
+                n_bl = len(bs)
+            g = L.make_gaps(delfi.get("gaps"))
+        self._check(self.lib.ftk_window_features(self.ctx, self.contig_id(name), L.ptr(ws), L.ptr(we), n, C.byref(f),
+                                                 L.ptr(cov), len_lo, n_bins, L.ptr(h), L.ptr(o), q, L.ptr(bs),
+                                                 L.ptr(be), n_bl, C.byref(g), L.ptr(sh), L.ptr(lg)))
+        if coverage:
+            out["coverage"] = cov
+        if hist is not None:
+            out["hist"], out["overflow"] = h, o
+        if delfi is not None:
+            out["short"], out["long"] = sh, lg
+        return out
+
     def frag_lengths(self, name: str, start, stop, quality_threshold=30, min_length=None, max_length=None,
                      intersect_policy="midpoint"):
         """Lengths of one window's passing fragments in file order."""

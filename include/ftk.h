@@ -176,6 +176,16 @@ int ftk_delfi_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const 
 int ftk_fraglen_hist(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
                      const ftk_filter* f, int32_t len_lo, int32_t n_bins, uint32_t* hist_out, int64_t* overflow_out);
 
+/* ---- fused pass: any combination of the three window features in ONE sweep over
+ * the contig's fragments (one plan, one launch pair instead of three): coverage
+ * (count_out) and length histogram (hist_out/overflow_out) under `f`, DELFI
+ * short/long under the rules of ftk_delfi_counts.  A NULL output switches its
+ * feature off; windows and blacklist must be host arrays when DELFI is on. */
+int ftk_window_features(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                        const ftk_filter* f, int64_t* count_out, int32_t len_lo, int32_t n_bins, uint32_t* hist_out,
+                        int64_t* overflow_out, int32_t delfi_mapq_min, const int32_t* bl_start, const int32_t* bl_end,
+                        int64_t n_bl, const ftk_gaps* gaps, int64_t* short_out, int64_t* long_out);
+
 /* frag/_frag_length.py:290-305 (frag_length): lengths of the fragments of ONE
  * window passing `f`, in file order.  Writes at most cap values to len_out
  * and always the true count to n_out. */

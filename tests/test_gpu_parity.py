@@ -178,3 +178,32 @@ def test_empty_and_errors(engine):
         engine.load_contig("bad2", np.array([5], np.int32), np.array([3], np.int32), np.array([1], np.uint8))
     with pytest.raises(KeyError):
         engine.window_counts("nope", [0], [1])
+
+
+def test_fused_window_features_equal_separate_calls(engine, data):
+    rng = np.random.default_rng(21)
+    bl_s = np.sort(rng.integers(0, CONTIG_LEN - 6000, 300)).astype(np.int32)
+    bl_e = (bl_s + rng.integers(200, 5000, 300)).astype(np.int32)
+    o = np.lexsort((bl_e, bl_s))
+    bl_s, bl_e = bl_s[o], bl_e[o]
+    gaps = (1_200_000, 1_500_000, [(0, 10_000), (CONTIG_LEN - 10_000, CONTIG_LEN)])
+    for name, (ws, we) in _window_sets(rng).items():
+        if name == "edge":
+            continue  # open-ended windows are a coverage notion; DELFI bins are closed
+        if name == "tile400":
+            ws, we = ws[:600], we[:600]
+        for n_bins in (301, 2500):  # per-wave LDS histograms / block histograms only
+            r = engine.window_features("synA", ws, we, quality_threshold=20, min_length=50, max_length=400,
+                                       hist=(50, n_bins), delfi=dict(quality_threshold=30, bl_start=bl_s, bl_end=bl_e,
+                                                                     gaps=gaps))
+            assert np.array_equal(r["coverage"], O.c_window_counts(data["fr"], ws, we, mapq_min=20, min_len=50,
+                                                                   max_len=400)), name
+            wh, wo = O.c_fraglen_hist(data["fr"], ws, we, 50, n_bins, mapq_min=20, min_len=50, max_len=400)
+            assert np.array_equal(r["hist"], wh) and np.array_equal(r["overflow"], wo), name
+            sh, lg, _ = O.c_delfi_counts(data["fr"], ws, we, 30, bl_s, bl_e, gaps)
+            assert np.array_equal(r["short"], sh) and np.array_equal(r["long"], lg), name
+    # feature subsets
+    ws, we = synth.tiling_windows(CONTIG_LEN, 100_000)
+    r = engine.window_features("synA", ws, we, coverage=False, delfi=dict(quality_threshold=30))
+    sh, lg, _ = O.c_delfi_counts(data["fr"], ws, we, 30)
+    assert set(r) == {"short", "long"} and np.array_equal(r["short"], sh) and np.array_equal(r["long"], lg)
