@@ -43,7 +43,8 @@ EXPORTS = [
     "ftk_frags_from_host", "ftk_frags_from_device", "ftk_frags_set_read1", "ftk_frags_info", "ftk_frags_release",
     "ftk_fragfile_decode", "ftk_bam_decode", "ftk_fragtable_error", "ftk_fragtable_is_bed6",
     "ftk_fragtable_n_contigs", "ftk_fragtable_contig_name", "ftk_fragtable_contig_length",
-    "ftk_fragtable_contig_rows", "ftk_fragtable_columns", "ftk_fragtable_free",
+    "ftk_fragtable_contig_rows", "ftk_fragtable_columns", "ftk_fragtable_is_pinned", "ftk_fragtable_free",
+    "ftk_frags_from_table",
     "ftk_window_counts", "ftk_delfi_counts", "ftk_fraglen_hist", "ftk_window_features", "ftk_frag_lengths",
     "ftk_frag_select",
     "ftk_wps", "ftk_wps_intervals",
@@ -122,6 +123,8 @@ def load() -> C.CDLL:
     lib.ftk_fragtable_contig_rows.argtypes = [vp, C.c_int]
     lib.ftk_fragtable_contig_rows.restype = i64
     lib.ftk_fragtable_columns.argtypes = [vp, C.c_int] + [C.POINTER(vp)] * 6
+    lib.ftk_fragtable_is_pinned.argtypes = [vp, C.c_int]
+    lib.ftk_frags_from_table.argtypes = [vp, C.c_int, vp, C.c_int]
     lib.ftk_fragtable_free.argtypes = [vp]
     lib.ftk_fragtable_free.restype = None
     lib.ftk_window_counts.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), vp]

@@ -373,6 +373,19 @@ int ftk_frags_from_device(ftk_ctx* ctx, int contig_id, const int32_t* d_start, c
     return upload_common(ctx, contig_id, d_start, d_end, d_mapq, d_strand, n, hipMemcpyDeviceToDevice);
 }
 
+int ftk_frags_from_table(ftk_ctx* ctx, int contig_id, const ftk_fragtable* t, int i) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    const int32_t *s0 = nullptr, *e0 = nullptr, *r1s = nullptr, *r1e = nullptr;
+    const uint8_t *q0 = nullptr, *st0 = nullptr;
+    if (ftk_fragtable_columns(t, i, &s0, &e0, &q0, &st0, &r1s, &r1e) != FTK_OK)
+        return fail(ctx, FTK_ERR_NO_CONTIG, "table has no contig %d", i);
+    const int64_t n = ftk_fragtable_contig_rows(t, i);
+    int rc = upload_common(ctx, contig_id, s0, e0, q0, st0, n, hipMemcpyHostToDevice);
+    if (rc) return rc;
+    if (r1s && r1e) rc = ftk_frags_set_read1(ctx, contig_id, r1s, r1e, n);
+    return rc;
+}
+
 int ftk_frags_set_read1(ftk_ctx* ctx, int contig_id, const int32_t* r1_start, const int32_t* r1_end, int64_t n) {
     if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
     ContigData* c;

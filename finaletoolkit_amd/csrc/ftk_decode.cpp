@@ -16,6 +16,8 @@
 #include <thread>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include "ftk.h"
 
 namespace {
@@ -45,11 +47,64 @@ struct Columns {
     }
 };
 
+// Final, immutable form of one contig's columns: ONE block, page-locked when a
+// HIP device is present (so the upload is a straight DMA), plain memory otherwise.
+struct Packed {
+    void* base = nullptr;
+    bool pinned = false;
+    size_t rows = 0;
+    int32_t *start = nullptr, *end = nullptr, *r1s = nullptr, *r1e = nullptr;
+    uint8_t *mapq = nullptr, *strand = nullptr;
+};
+
 struct Contig {
     std::string name;
     int64_t length = -1;
-    Columns c;
+    Columns c;   // parse-time storage, emptied by pack()
+    Packed p;
 };
+
+bool have_hip_device() {
+    static const bool yes = [] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return n > 0;
+    }();
+    return yes;
+}
+
+void pack(Contig& ct) {
+    Columns& c = ct.c;
+    const size_t m = c.start.size();
+    const bool bam = !c.r1s.empty();
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t b32 = up(m * 4 + 16), b8 = up(m + 16);
+    const size_t total = (bam ? 4 : 2) * b32 + 2 * b8;
+    Packed& p = ct.p;
+    p.rows = m;
+    if (have_hip_device() && hipHostMalloc(&p.base, total, hipHostMallocDefault) == hipSuccess) {
+        p.pinned = true;
+    } else {
+        (void)hipGetLastError();
+        p.base = malloc(total);
+        p.pinned = false;
+    }
+    if (!p.base) return;
+    char* q = (char*)p.base;
+    p.start = (int32_t*)q; q += b32;
+    p.end = (int32_t*)q; q += b32;
+    if (bam) { p.r1s = (int32_t*)q; q += b32; p.r1e = (int32_t*)q; q += b32; }
+    p.mapq = (uint8_t*)q; q += b8;
+    p.strand = (uint8_t*)q;
+    if (m) {
+        memcpy(p.start, c.start.data(), m * 4);
+        memcpy(p.end, c.end.data(), m * 4);
+        memcpy(p.mapq, c.mapq.data(), m);
+        memcpy(p.strand, c.strand.data(), m);
+        if (bam) { memcpy(p.r1s, c.r1s.data(), m * 4); memcpy(p.r1e, c.r1e.data(), m * 4); }
+    }
+    c = Columns{};
+}
 
 }  // namespace
 
@@ -57,6 +112,12 @@ struct ftk_fragtable {
     std::vector<Contig> contigs;
     bool bed6 = false;
     bool bam = false;
+    ~ftk_fragtable() {
+        for (auto& ct : contigs) {
+            if (!ct.p.base) continue;
+            if (ct.p.pinned) (void)hipHostFree(ct.p.base); else free(ct.p.base);
+        }
+    }
 };
 
 namespace {
@@ -309,6 +370,10 @@ int ftk_fragfile_decode(const char* path, const char* contig, int n_threads, ftk
     for (auto& x : th) x.join();
     for (auto& runs : seg_runs)
         for (auto& r : runs) find_or_add(t.get(), r.name)->c.append(r.c);
+    for (auto& ct : t->contigs) {
+        pack(ct);
+        if (!ct.p.base) return dfail(FTK_ERR_OOM, "out of host memory");
+    }
     *out = t.release();
     return FTK_OK;
 }
@@ -408,6 +473,10 @@ int ftk_bam_decode(const char* path, const char* contig, int n_threads, ftk_frag
         }
         c = std::move(s);
     }
+    for (auto& ct : t->contigs) {
+        pack(ct);
+        if (!ct.p.base) return dfail(FTK_ERR_OOM, "out of host memory");
+    }
     *out = t.release();
     return FTK_OK;
 }
@@ -421,20 +490,23 @@ int64_t ftk_fragtable_contig_length(const ftk_fragtable* t, int i) {
     return (t && i >= 0 && i < (int)t->contigs.size()) ? t->contigs[i].length : -1;
 }
 int64_t ftk_fragtable_contig_rows(const ftk_fragtable* t, int i) {
-    return (t && i >= 0 && i < (int)t->contigs.size()) ? (int64_t)t->contigs[i].c.start.size() : -1;
+    return (t && i >= 0 && i < (int)t->contigs.size()) ? (int64_t)t->contigs[i].p.rows : -1;
 }
 int ftk_fragtable_columns(const ftk_fragtable* t, int i, const int32_t** start, const int32_t** end,
                           const uint8_t** mapq, const uint8_t** strand, const int32_t** r1_start,
                           const int32_t** r1_end) {
     if (!t || i < 0 || i >= (int)t->contigs.size()) return dfail(FTK_ERR_NO_CONTIG, "contig index %d out of range", i);
-    const Columns& c = t->contigs[i].c;
-    if (start) *start = c.start.data();
-    if (end) *end = c.end.data();
-    if (mapq) *mapq = c.mapq.data();
-    if (strand) *strand = c.strand.data();
-    if (r1_start) *r1_start = c.r1s.empty() ? nullptr : c.r1s.data();
-    if (r1_end) *r1_end = c.r1e.empty() ? nullptr : c.r1e.data();
+    const Packed& c = t->contigs[i].p;
+    if (start) *start = c.start;
+    if (end) *end = c.end;
+    if (mapq) *mapq = c.mapq;
+    if (strand) *strand = c.strand;
+    if (r1_start) *r1_start = c.r1s;
+    if (r1_end) *r1_end = c.r1e;
     return FTK_OK;
+}
+int ftk_fragtable_is_pinned(const ftk_fragtable* t, int i) {
+    return (t && i >= 0 && i < (int)t->contigs.size() && t->contigs[i].p.pinned) ? 1 : 0;
 }
 void ftk_fragtable_free(ftk_fragtable* t) { delete t; }
 

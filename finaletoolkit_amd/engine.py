@@ -117,6 +117,14 @@ class Engine:
             self._bam[name] = True
         return cid
 
+    def load_contig_from_table(self, name: str, table, index: int, is_bam: bool):
+        """Upload contig ``index`` of a decoded ``ftk_fragtable`` (page-locked columns -> HBM)."""
+        cid = self._ids.setdefault(name, len(self._ids))
+        self._check(self.lib.ftk_frags_from_table(self.ctx, cid, table, int(index)))
+        # an empty BAM contig carries no read1 columns: plain fetch mode is equivalent
+        self._bam[name] = bool(is_bam) and self.lib.ftk_fragtable_contig_rows(table, int(index)) > 0
+        return cid
+
     def load_contig_device(self, name: str, d_start, d_end, d_mapq, d_strand, n: int):
         """Adopt columns already in HBM (torch tensors or raw device addresses)."""
         cid = self._ids.setdefault(name, len(self._ids))

@@ -151,16 +151,11 @@ def open_source(input_file, workers: int | None = None, warn_bed6: bool = True) 
         lengths = {names[i]: (lib.ftk_fragtable_contig_length(table, i) if is_bam else None) for i in range(n)}
         src = FragSource(path, is_bam, bool(lib.ftk_fragtable_is_bed6(table)), names, lengths, _NEXT_ID)
         _NEXT_ID += 1
-        z32, z8 = np.zeros(0, np.int32), np.zeros(0, np.uint8)
         for i, name in enumerate(names):
             rows = lib.ftk_fragtable_contig_rows(table, i)
-            if rows == 0:
-                if not is_bam:
-                    continue
-                eng.load_contig(src.key(name), z32, z32, z8, z8, z32, z32)
-            else:
-                s, e, q, stn, r1s, r1e = _columns(lib, table, i, rows)
-                eng.load_contig(src.key(name), s, e, q, stn, r1s if is_bam else None, r1e if is_bam else None)
+            if rows == 0 and not is_bam:
+                continue
+            eng.load_contig_from_table(src.key(name), table, i, is_bam)
             src.loaded.add(name)
     finally:
         lib.ftk_fragtable_free(table)

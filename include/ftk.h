@@ -141,7 +141,12 @@ int64_t ftk_fragtable_contig_rows(const ftk_fragtable* t, int i);
 int ftk_fragtable_columns(const ftk_fragtable* t, int i, const int32_t** start, const int32_t** end,
                           const uint8_t** mapq, const uint8_t** strand,
                           const int32_t** r1_start /* NULL for text */, const int32_t** r1_end);
+/* 1 when contig i's columns sit in page-locked host memory (a HIP device was present at decode time). */
+int ftk_fragtable_is_pinned(const ftk_fragtable* t, int i);
 void ftk_fragtable_free(ftk_fragtable* t);
+/* Upload contig i of a decoded table (including the BAM read1 columns) as contig_id: the
+ * decode -> pinned SoA -> hipMemcpyAsync leg of the pipeline, without a detour through the caller. */
+int ftk_frags_from_table(ftk_ctx* ctx, int contig_id, const ftk_fragtable* t, int i);
 
 /* ---- a5: coverage --------------------------------------------------------
  * frag/_coverage.py:117-130 (`for _ in frags: coverage += 1`) over

@@ -207,3 +207,17 @@ def test_fused_window_features_equal_separate_calls(engine, data):
     r = engine.window_features("synA", ws, we, coverage=False, delfi=dict(quality_threshold=30))
     sh, lg, _ = O.c_delfi_counts(data["fr"], ws, we, 30)
     assert set(r) == {"short", "long"} and np.array_equal(r["short"], sh) and np.array_equal(r["long"], lg)
+
+
+def test_many_windows_multiblock_planner(engine, data):
+    # > 16384 windows: bounds_kernel + scan_kernel path instead of the fused single-block planner
+    rng = np.random.default_rng(33)
+    n = 40_000
+    ws = rng.integers(0, CONTIG_LEN - 10, n).astype(np.int32)
+    we = (ws + rng.integers(1, 3000, n)).astype(np.int32)
+    we[::1000] = ws[::1000] + 200_000  # a few large windows among the small ones
+    want = O.c_window_counts(data["fr"], ws, we, mapq_min=30)
+    assert np.array_equal(engine.window_counts("synA", ws, we, 30), want)
+    h, o = engine.fraglen_hist("synA", ws[:20_000], we[:20_000], 100, 200, 30)
+    wh, wo = O.c_fraglen_hist(data["fr"], ws[:20_000], we[:20_000], 100, 200, mapq_min=30)
+    assert np.array_equal(h, wh) and np.array_equal(o, wo)
