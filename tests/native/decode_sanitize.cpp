@@ -1,0 +1,71 @@
+// Sanitizer harness for the host decoders (csrc/ftk_decode.cpp), CPU build only:
+//   g++ -fsanitize=address,undefined ... ; run on the committed fixtures and on
+// malformed inputs.  GPU sanitizers are not available on the pool; the decoder is
+// the only component that parses untrusted bytes.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ftk.h"
+
+static int decode(const char* path, bool bam, int threads, long* rows_out) {
+    ftk_fragtable* t = nullptr;
+    int rc = bam ? ftk_bam_decode(path, nullptr, threads, &t) : ftk_fragfile_decode(path, nullptr, threads, &t);
+    if (rc != FTK_OK) return rc;
+    long rows = 0;
+    for (int i = 0; i < ftk_fragtable_n_contigs(t); ++i) {
+        const int32_t *s, *e, *r1s, *r1e;
+        const uint8_t *q, *st;
+        ftk_fragtable_columns(t, i, &s, &e, &q, &st, &r1s, &r1e);
+        long n = (long)ftk_fragtable_contig_rows(t, i);
+        long acc = 0;
+        for (long k = 0; k < n; ++k) acc += s[k] + e[k] + q[k] + st[k] + (r1s ? r1s[k] + r1e[k] : 0);
+        rows += n;
+        if (acc == 42) printf(" ");
+    }
+    ftk_fragtable_free(t);
+    *rows_out = rows;
+    return FTK_OK;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    std::string data = argv[1];
+    long rows = 0;
+    struct { const char* f; bool bam; long want; } cases[] = {
+        {"/12.3444.b37.frag.gz", false, 17}, {"/12.3444.b37.frag.bed.gz", false, 17}, {"/12.3444.b37.bam", true, 17}};
+    for (auto& c : cases)
+        for (int th : {1, 3}) {
+            if (decode((data + c.f).c_str(), c.bam, th, &rows) != FTK_OK || rows != c.want) {
+                fprintf(stderr, "FAIL %s rows=%ld (%s)\n", c.f, rows, ftk_fragtable_error());
+                return 1;
+            }
+        }
+    // truncated / corrupted copies must fail cleanly or decode a prefix, never crash
+    for (auto& c : cases) {
+        FILE* fp = fopen((data + c.f).c_str(), "rb");
+        std::vector<unsigned char> buf(1 << 16);
+        size_t n = fread(buf.data(), 1, buf.size(), fp);
+        fclose(fp);
+        for (size_t cut : {n / 2, n - 5, (size_t)20, (size_t)0}) {
+            std::string tmp = std::string(argv[2]) + "/cut.bin";
+            FILE* out = fopen(tmp.c_str(), "wb");
+            fwrite(buf.data(), 1, cut, out);
+            fclose(out);
+            decode(tmp.c_str(), c.bam, 2, &rows);
+        }
+        for (size_t pos = 0; pos < n; pos += 7) {
+            std::vector<unsigned char> b2(buf.begin(), buf.begin() + n);
+            b2[pos] ^= 0x5a;
+            std::string tmp = std::string(argv[2]) + "/flip.bin";
+            FILE* out = fopen(tmp.c_str(), "wb");
+            fwrite(b2.data(), 1, n, out);
+            fclose(out);
+            decode(tmp.c_str(), c.bam, 2, &rows);
+        }
+    }
+    printf("decode_sanitize ok\n");
+    return 0;
+}
