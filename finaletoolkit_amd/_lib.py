@@ -47,7 +47,7 @@ EXPORTS = [
     "ftk_frags_from_table",
     "ftk_window_counts", "ftk_delfi_counts", "ftk_fraglen_hist", "ftk_window_features", "ftk_frag_lengths",
     "ftk_frag_select",
-    "ftk_wps", "ftk_wps_intervals",
+    "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals",
 ]
 
 
@@ -136,6 +136,8 @@ def load() -> C.CDLL:
     lib.ftk_frag_select.argtypes = [vp, C.c_int, i32, i32, C.POINTER(Filter), vp, vp, vp, vp, i64, C.POINTER(i64)]
     lib.ftk_wps.argtypes = [vp, C.c_int, i64, i64, i64, i32, i32, i32, i32, vp]
     lib.ftk_wps_intervals.argtypes = [vp, C.c_int, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]
+    lib.ftk_cleavage.argtypes = [vp, C.c_int, i64, i64, i32, i32, i32, vp]
+    lib.ftk_cleavage_intervals.argtypes = [vp, C.c_int, vp, vp, i64, vp, i32, i32, i32, vp]
     _lib = lib
     return lib
 

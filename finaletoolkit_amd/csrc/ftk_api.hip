@@ -851,4 +851,67 @@ int ftk_wps_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start, cons
     return FTK_OK;
 }
 
+int ftk_cleavage_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start, const int64_t* iv_stop, int64_t n_iv,
+                           const int64_t* out_offset, int32_t min_len, int32_t max_len, int32_t mapq_min,
+                           double* prop_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    ContigData* c;
+    int rc = get_contig(ctx, contig_id, &c);
+    if (rc) return rc;
+    if (n_iv < 0 || n_iv > INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "n_iv out of range");
+    if (n_iv == 0) return FTK_OK;
+    if (!iv_start || !iv_stop || !out_offset || !prop_out) return fail(ctx, FTK_ERR_INVALID, "NULL argument");
+    if (is_device_ptr(iv_start) || is_device_ptr(iv_stop) || is_device_ptr(out_offset))
+        return fail(ctx, FTK_ERR_INVALID, "interval arrays must be host arrays");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CleaveParams p{};
+    p.min_len = min_len < 0 ? INT32_MIN : min_len;
+    p.max_len = max_len < 0 ? INT32_MAX : max_len;
+    p.mapq_min = mapq_min;
+    p.lmax = std::max(0, max_len < 0 ? c->max_len : std::min(max_len, c->max_len));
+    std::vector<int32_t> tile_iv, tile_k;
+    int64_t total_out = 0;
+    for (int64_t i = 0; i < n_iv; ++i) {
+        const int64_t len = iv_stop[i] - iv_start[i];
+        if (len <= 0) continue;
+        if (iv_start[i] < 0 || iv_stop[i] > (1LL << 31)) return fail(ctx, FTK_ERR_INVALID, "interval out of range");
+        if (out_offset[i] < 0) return fail(ctx, FTK_ERR_INVALID, "negative output offset");
+        total_out = std::max(total_out, out_offset[i] + len);
+        for (int64_t k = 0; k < (len + kWpsTile - 1) / kWpsTile; ++k) {
+            tile_iv.push_back((int32_t)i);
+            tile_k.push_back((int32_t)k);
+        }
+    }
+    const size_t n_tiles = tile_iv.size();
+    if (n_tiles == 0) return FTK_OK;
+    if (n_tiles > (size_t)INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "too many tiles in one call");
+    const bool out_dev = is_device_ptr(prop_out);
+    size_t need = 3 * align_up(n_iv * 8) + 2 * align_up(n_tiles * 4) + (out_dev ? 0 : align_up(total_out * 8));
+    if ((rc = reserve_scratch(ctx, need))) return rc;
+    Arena a(ctx);
+    int64_t* d_s = a.take<int64_t>(n_iv);
+    int64_t* d_e = a.take<int64_t>(n_iv);
+    int64_t* d_o = a.take<int64_t>(n_iv);
+    int32_t* d_ti = a.take<int32_t>(n_tiles);
+    int32_t* d_tk = a.take<int32_t>(n_tiles);
+    double* d_out = out_dev ? prop_out : a.take<double>(total_out);
+    HIPCHK(ctx, hipMemcpyAsync(d_s, iv_start, n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_e, iv_stop, n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_o, out_offset, n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_ti, tile_iv.data(), n_tiles * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_tk, tile_k.data(), n_tiles * 4, hipMemcpyHostToDevice, ctx->stream));
+    launch_cleavage(ctx->stream, c->v, p, (int64_t)n_tiles, d_s, d_e, d_o, d_ti, d_tk, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    if (!out_dev) HIPCHK(ctx, hipMemcpyAsync(prop_out, d_out, total_out * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the tile descriptor vectors are pageable staging
+    return FTK_OK;
+}
+
+int ftk_cleavage(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int32_t min_len, int32_t max_len,
+                 int32_t mapq_min, double* prop_out) {
+    if (ctx && stop <= start) return FTK_OK;
+    const int64_t off = 0;
+    return ftk_cleavage_intervals(ctx, contig_id, &start, &stop, 1, &off, min_len, max_len, mapq_min, prop_out);
+}
+
 }  // extern "C"

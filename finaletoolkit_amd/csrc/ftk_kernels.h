@@ -34,6 +34,12 @@ struct WpsParams {
     int lmax;  // min(max_len, longest fragment of the contig)
 };
 
+struct CleaveParams {
+    long long start, stop;  // single-interval form
+    int min_len, max_len, mapq_min;
+    int lmax;  // longest admissible fragment
+};
+
 void launch_stats(hipStream_t s, const int32_t* start, const int32_t* end, int n, FragStats* st);
 void launch_bin_index(hipStream_t s, const int32_t* start, int n, int n_bins, int32_t* idx);
 void launch_plan(hipStream_t s, const ContigView& cv, const int32_t* ws, const int32_t* we, int n_win, int lmax,
@@ -60,6 +66,9 @@ void launch_add_i64(hipStream_t s, const int64_t* a, const int64_t* b, int64_t* 
 void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t n_tiles, const int64_t* iv_start,
                 const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv, const int32_t* tile_k,
                 int64_t* out);
+void launch_cleavage(hipStream_t s, const ContigView& cv, const CleaveParams& p, int64_t n_tiles,
+                     const int64_t* iv_start, const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv,
+                     const int32_t* tile_k, double* out);
 void launch_select_count(hipStream_t s, const ContigView& cv, int lo, int hi, int ws, int we, const ftk_filter& f,
                          uint32_t* block_cnt);
 void launch_scan_u32(hipStream_t s, const uint32_t* in, int n, uint32_t* off);

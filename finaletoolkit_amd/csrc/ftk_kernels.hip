@@ -672,6 +672,116 @@ __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParam
 }
 
 // ---------------------------------------------------------------------------
+// Cleavage profile (frag/_cleavage_profile.py:33-90,204-216): per base, the
+// number of fragment ends (start of + fragments, stop of - fragments) over the
+// fragment depth, as a percentage.  Same tile skeleton as WPS: LDS difference
+// array for the depth + LDS counters for the ends, DPP scan, 1 KB-contiguous
+// float64 stores.  Fragments are selected like frag_array(start, stop, "any").
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cleavage_kernel(ContigView cv, CleaveParams p, const int64_t* iv_start_,
+                                                       const int64_t* iv_stop_, const int64_t* out_off_,
+                                                       const int32_t* tile_iv, const int32_t* tile_k,
+                                                       double* __restrict__ out) {
+    constexpr int T = kWpsTile, NP = T / 1024;
+    __shared__ __attribute__((aligned(16))) int dd[T];
+    __shared__ __attribute__((aligned(16))) int en[T];
+    __shared__ int pre_s;
+    __shared__ int rng_s[2];
+    __shared__ int wtot[NP][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    long long iv_start, iv_stop, out_off, k;
+    if (tile_iv) {
+        const int iv = tile_iv[blockIdx.x];
+        iv_start = iv_start_[iv]; iv_stop = iv_stop_[iv]; out_off = out_off_[iv]; k = tile_k[blockIdx.x];
+    } else {
+        iv_start = p.start; iv_stop = p.stop; out_off = 0; k = blockIdx.x;
+    }
+    const long long t0 = iv_start + k * T;
+    const int len_t = (int)(min(t0 + (long long)T, iv_stop) - t0);
+    if (tid < 2) {
+        // candidates: fs < t1 and fe >= t0 (a - fragment ending exactly at t0 still puts an end there)
+        const long long q = tid == 0 ? t0 - (long long)p.lmax : t0 + len_t;
+        int r;
+        if (q <= 0) r = 0;
+        else { const long long kb = q >> kBinShift; r = kb >= cv.n_bins ? cv.n : cv.bin_idx[kb + tid]; }
+        rng_s[tid] = r;
+    }
+    if (tid == 2) pre_s = 0;
+    {
+        const int4 z = make_int4(0, 0, 0, 0);
+        int4* a4 = reinterpret_cast<int4*>(dd);
+        int4* b4 = reinterpret_cast<int4*>(en);
+#pragma unroll
+        for (int j = 0; j < T / 4 / 256; ++j) { a4[j * 256 + tid] = z; b4[j * 256 + tid] = z; }
+    }
+    __syncthreads();
+    const int lo = rng_s[0], hi = rng_s[1];
+    for (int i = lo + tid; i < hi; i += 256) {
+        const int fs = cv.start[i], fe = cv.end[i], q = cv.mapq[i];
+        const int len = fe - fs;
+        if (q < p.mapq_min || len < p.min_len || len > p.max_len) continue;
+        if (!((long long)fe > iv_start && (long long)fs < iv_stop)) continue;  // "any" policy (= tabix overlap)
+        if (cv.r1_start && !((long long)cv.r1_start[i] < iv_stop && (long long)cv.r1_end[i] > iv_start)) continue;
+        const long long a = (long long)fs - t0, b = (long long)fe - t0;
+        if (b > 0 && a < len_t) {  // covers [max(a,0), min(b,len_t))
+            if (a <= 0) atomicAdd(&pre_s, 1); else atomicAdd(&dd[a], 1);
+            if (b < len_t) atomicAdd(&dd[b], -1);
+        }
+        const long long e = cv.strand[i] ? a : b;
+        if (e >= 0 && e < len_t) atomicAdd(&en[e], 1);
+    }
+    __syncthreads();
+    int2 va[NP], vb[NP];
+    int exa[NP], exb[NP];
+    const int2* d2 = reinterpret_cast<const int2*>(dd);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int ia = j * 512 + wv * 128 + lane;
+        va[j] = d2[ia];
+        vb[j] = d2[ia + 64];
+        const int sa = va[j].x + va[j].y, sb2 = vb[j].x + vb[j].y;
+        const int ia_incl = wave_incl_scan_dpp(sa);
+        const int ib_incl = wave_incl_scan_dpp(sb2);
+        const int tot_a = __builtin_amdgcn_readlane(ia_incl, 63);
+        const int tot_b = __builtin_amdgcn_readlane(ib_incl, 63);
+        exa[j] = ia_incl - sa;
+        exb[j] = tot_a + ib_incl - sb2;
+        if (lane == 0) wtot[j][wv] = tot_a + tot_b;
+    }
+    __syncthreads();
+    int base = pre_s;
+    double* dst = out + out_off + k * T;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    const int2* e2 = reinterpret_cast<const int2*>(en);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        int carry = base;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+            const int tt = wtot[j][w2];
+            if (w2 < wv) carry += tt;
+            base += tt;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int2 v = h ? vb[j] : va[j];
+            const int2 ends = e2[j * 512 + wv * 128 + h * 64 + lane];
+            const int g0 = carry + (h ? exb[j] : exa[j]) + v.x, g1 = g0 + v.y;
+            const int i0 = j * 1024 + wv * 256 + h * 128 + 2 * lane;
+            // numpy: ends / depth * 100 in float64, 0 where depth == 0 (frag/_cleavage_profile.py:208-210)
+            const double o0 = g0 ? (double)ends.x / (double)g0 * 100.0 : 0.0;
+            const double o1 = g1 ? (double)ends.y / (double)g1 * 100.0 : 0.0;
+            if (i0 + 1 < len_t) {
+                if (vec_ok) *reinterpret_cast<double2*>(dst + i0) = make_double2(o0, o1);
+                else { dst[i0] = o0; dst[i0 + 1] = o1; }
+            } else if (i0 < len_t) {
+                dst[i0] = o0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // ordered selection of one window's fragments (frag_length / frag_array)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void select_count_kernel(ContigView cv, int lo, int hi, int ws, int we,
@@ -807,6 +917,14 @@ void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t
     const long long grid = (n_tiles + tpb - 1) / tpb;
     hipLaunchKernelGGL(wps_stream_kernel, dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop, out_off,
                        tile_iv, tile_k, (long long)n_tiles, (int)tpb, out);
+}
+
+void launch_cleavage(hipStream_t s, const ContigView& cv, const CleaveParams& p, int64_t n_tiles,
+                     const int64_t* iv_start, const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv,
+                     const int32_t* tile_k, double* out) {
+    if (n_tiles <= 0) return;
+    hipLaunchKernelGGL(cleavage_kernel, dim3((unsigned)n_tiles), dim3(256), 0, s, cv, p, iv_start, iv_stop, out_off,
+                       tile_iv, tile_k, out);
 }
 
 void launch_select_count(hipStream_t s, const ContigView& cv, int lo, int hi, int ws, int we, const ftk_filter& f,

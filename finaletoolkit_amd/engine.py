@@ -282,3 +282,22 @@ class Engine:
                                                    int(window_size), int(min_length), int(max_length),
                                                    int(quality_threshold), L.ptr(out)))
         return out, offs
+
+    def cleavage_intervals(self, name: str, starts, stops, min_length=None, max_length=None, quality_threshold=30):
+        """Cleavage proportion (percent) per base of many intervals of one contig in one launch
+        (frag/_cleavage_profile.py:33-90,204-216); returns (proportions f64, offsets)."""
+        s = np.ascontiguousarray(starts, dtype=np.int64)
+        e = np.ascontiguousarray(stops, dtype=np.int64)
+        offs = np.zeros(len(s) + 1, np.int64)
+        np.cumsum(np.maximum(e - s, 0), out=offs[1:])
+        out = np.zeros(int(offs[-1]), np.float64)
+        if len(s) and offs[-1] > 0:
+            self._check(self.lib.ftk_cleavage_intervals(
+                self.ctx, self.contig_id(name), L.ptr(s), L.ptr(e), len(s), L.ptr(np.ascontiguousarray(offs[:-1])),
+                L.LEN_OPEN if min_length is None else max(int(min_length), 0),
+                L.LEN_OPEN if max_length is None else int(max_length), int(quality_threshold), L.ptr(out)))
+        return out, offs
+
+    def cleavage(self, name: str, start: int, stop: int, min_length=None, max_length=None, quality_threshold=30):
+        return self.cleavage_intervals(name, [start], [stop], min_length, max_length, quality_threshold)[0]
+

@@ -220,6 +220,21 @@ int ftk_wps_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start, cons
                       const int64_t* out_offset, int64_t chrom_size, int32_t window_size, int32_t min_len,
                       int32_t max_len, int32_t mapq_min, int64_t* wps_out);
 
+/* ---- next row: cleavage profile ----------------------------------
+ * frag/_cleavage_profile.py:33-90,204-216 for every base of [start, stop) (already
+ * expanded by left/right and clipped by the caller, :201-202): fragments selected
+ * like frag_array(start, stop, intersect_policy="any") with mapq >= mapq_min and
+ * min_len <= len <= max_len (FTK_LEN_OPEN = no bound); depth = fragments covering the
+ * base, ends = + fragments starting there plus - fragments whose stop is there;
+ * prop_out = ends / depth * 100 (float64, 0 where depth == 0).
+ * ftk_cleavage_intervals: n_iv intervals of one contig in one launch (host interval
+ * arrays), interval i written at prop_out + out_offset[i]. */
+int ftk_cleavage(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int32_t min_len, int32_t max_len,
+                 int32_t mapq_min, double* prop_out);
+int ftk_cleavage_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start, const int64_t* iv_stop, int64_t n_iv,
+                           const int64_t* out_offset, int32_t min_len, int32_t max_len, int32_t mapq_min,
+                           double* prop_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -266,3 +266,32 @@ int orc_wps(const orc_frags* f, int64_t start, int64_t stop, int64_t chrom_size,
     free(fs); free(fe);
     return 0;
 }
+
+/* frag/_cleavage_profile.py:33-90 (_coverage_and_ends) over the fragments
+ * frag_array(start=adj_start, stop=adj_stop, intersect_policy="any") returns
+ * (:204-213): per base depth and fragment-end counts.  min_len / max_len -1 = None. */
+void orc_cleavage(const orc_frags* f, int64_t adj_start, int64_t adj_stop, int32_t min_len, int32_t max_len,
+                  int32_t mapq_min, int64_t* depth_out, int64_t* ends_out) {
+    int64_t n = adj_stop - adj_start;
+    if (n <= 0) return;
+    int64_t* diff = (int64_t*)calloc((size_t)n + 1, sizeof(int64_t));
+    memset(ends_out, 0, (size_t)n * sizeof(int64_t));
+    orc_filter flt = {mapq_min, min_len, max_len, 1, f->r1s ? 1 : 0};
+    int64_t lo, hi;
+    fetch_range(f, (int32_t)adj_start, (int32_t)adj_stop, &lo, &hi);
+    for (int64_t i = lo; i < hi; ++i) {
+        if (!(fetched(f, i, (int32_t)adj_start, (int32_t)adj_stop, flt.fetch_mode) &&
+              passes(f, i, (int32_t)adj_start, (int32_t)adj_stop, &flt)))
+            continue;
+        int64_t raw_start_idx = (int64_t)f->start[i] - adj_start, raw_stop_idx = (int64_t)f->end[i] - adj_start;
+        int64_t a = raw_start_idx < 0 ? 0 : (raw_start_idx > n ? n : raw_start_idx);   /* np.clip(.., 0, n) */
+        int64_t b = raw_stop_idx < 0 ? 0 : (raw_stop_idx > n ? n : raw_stop_idx);
+        diff[a] += 1;                                                                   /* :72-73 */
+        diff[b] -= 1;
+        int64_t e = f->strand[i] ? raw_start_idx : raw_stop_idx;                        /* :80-86 */
+        if (e >= 0 && e < n) ends_out[e] += 1;
+    }
+    int64_t run = 0;
+    for (int64_t k = 0; k < n; ++k) { run += diff[k]; depth_out[k] = run; }             /* cumsum(diff[:-1]) */
+    free(diff);
+}

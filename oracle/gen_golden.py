@@ -184,6 +184,32 @@ def main():
             k += 1
     sy["wps_cases"] = wps_cases
 
+    # cleavage profile (next row): single intervals with left/right padding and length filters
+    cl_cases = []
+    for k2, (c, a, b, left, right, mn, mx, q) in enumerate([
+            ("chrA", 1000, 6000, 0, 0, None, None, 30), ("chrA", 0, 300, 5, 5, None, None, 0),
+            ("chrA", 399_000, 400_000, 0, 500, 100, 220, 30), ("chrB", 50_000, 59_000, 10, 20, None, 167, 10),
+            ("chrB", 149_900, 150_000, 0, 0, 300, None, 0)]):
+        r = F.cleavage_profile(path, CONTIGS[c], c, a, b, left=left, right=right, min_length=mn, max_length=mx,
+                               quality_threshold=q)
+        A[f"cleavage_{k2}"] = r["proportion"].astype(np.float64)
+        A[f"cleavage_pos_{k2}"] = r["pos"].astype(np.int64)
+        cl_cases.append(dict(key=f"cleavage_{k2}", contig=c, start=a, stop=b, left=left, right=right, min_length=mn,
+                             max_length=mx, quality_threshold=q))
+    sy["cleavage_cases"] = cl_cases
+    with open(os.path.join(GOLD, "synth_cleavage_intervals.bed"), "w") as fh:
+        fh.write("chrA\t100\t400\nchrA\t350\t900\nchrA\t5000\t9500\nchrQ\t1\t5\nchrB\t149000\t150000\n")
+    cl_out = os.path.join(GOLD, "_tmp_cleave.bed.gz")
+    F.multi_cleavage_profile(path, os.path.join(GOLD, "synth_cleavage_intervals.bed"),
+                             os.path.join(GOLD, "synth.chrom.sizes"), left=10, right=30, output_file=cl_out)
+    sy["multi_cleavage_text_sha"] = __import__("hashlib").sha256(gzip.open(cl_out, "rb").read()).hexdigest()
+    rows_c = [l.split("\t") for l in gzip.open(cl_out, "rt").read().splitlines()]
+    os.remove(cl_out)
+    sy["multi_cleavage_rows"] = len(rows_c)
+    sy["multi_cleavage_head"] = rows_c[:3]
+    A["multi_cleavage_pos"] = np.array([int(r[1]) for r in rows_c], np.int64)
+    A["multi_cleavage_val"] = np.array([float(r[3]) for r in rows_c], np.float64)
+
     # multi_wps -> bedGraph.gz (no pyBigWig needed for this writer)
     sites = [("chrB", 100, 300), ("chrA", 50_000, 50_400), ("chrA", 52_000, 52_100), ("chrA", 399_900, 400_000),
              ("chrB", 70_000, 70_010), ("chrZ", 5, 10)]

@@ -165,6 +165,20 @@ def c_wps(fr: Frags, start, stop, chrom_size, window_size=120, min_len=120, max_
     return out
 
 
+def c_cleavage(fr: Frags, adj_start, adj_stop, min_len=None, max_len=None, mapq_min=30):
+    """(depth, ends, proportion) per base; proportion as frag/_cleavage_profile.py:208-210."""
+    n = max(int(adj_stop) - int(adj_start), 0)
+    depth = np.zeros(n, np.int64)
+    ends = np.zeros(n, np.int64)
+    _lib().orc_cleavage(C.byref(fr.c), C.c_int64(adj_start), C.c_int64(adj_stop),
+                        C.c_int32(-1 if min_len is None else min_len), C.c_int32(-1 if max_len is None else max_len),
+                        C.c_int32(mapq_min), _p(depth), _p(ends))
+    prop = np.zeros(n, np.float64)
+    nz = depth != 0
+    prop[nz] = ends[nz] / depth[nz] * 100
+    return depth, ends, prop
+
+
 # ---------------------------------------------------------------------------
 # Pure-Python, reference-shaped restatement (small cases / timed baseline)
 # ---------------------------------------------------------------------------

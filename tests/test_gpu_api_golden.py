@@ -377,3 +377,48 @@ class TestDelfi:
                             remove_nocov=False, merge_bins=True, output_file=str(tmp_path / "d.tsv"))
         assert merged.shape[0] == len([1 for a in ("Ap", "Aq")]) * 0 + merged.shape[0] and merged.shape[0] >= 5
         assert open(tmp_path / "d.tsv").readline().startswith("#contig\tstart\tstop\tarm\tshort\tlong\tgc")
+
+
+class TestCleavage:  # next row: reference tests/test_cleavage_profile.py
+    def test_single_intervals_golden(self, G, A):
+        for c in G["synth"]["cleavage_cases"]:
+            r = frag.cleavage_profile(SYN, G["synth"]["contigs"][c["contig"]], c["contig"], c["start"], c["stop"],
+                                      left=c["left"], right=c["right"], min_length=c["min_length"],
+                                      max_length=c["max_length"], quality_threshold=c["quality_threshold"])
+            assert r.dtype == np.dtype([("contig", "U16"), ("pos", "i8"), ("proportion", "f8")])
+            assert np.array_equal(r["pos"], A["cleavage_pos_" + c["key"].split("_")[1]])
+            assert np.array_equal(r["proportion"], A[c["key"]]), c  # float64 bit-exact
+
+    def test_multi_bedgraph_golden(self, G, A, tmp_path):
+        import hashlib
+        out = str(tmp_path / "c.bed.gz")
+        with pytest.warns(UserWarning):  # chrQ is not in chrom.sizes
+            frag.multi_cleavage_profile(SYN, os.path.join(GOLDEN, "synth_cleavage_intervals.bed"),
+                                        os.path.join(GOLDEN, "synth.chrom.sizes"), left=10, right=30, output_file=out)
+        raw = gzip.open(out, "rb").read()
+        rows = [l.split("\t") for l in raw.decode().splitlines()]
+        assert len(rows) == G["synth"]["multi_cleavage_rows"] and rows[:3] == G["synth"]["multi_cleavage_head"]
+        assert np.array_equal(np.array([int(r[1]) for r in rows]), A["multi_cleavage_pos"])
+        assert np.array_equal(np.array([float(r[3]) for r in rows]), A["multi_cleavage_val"])
+        assert hashlib.sha256(raw).hexdigest() == G["synth"]["multi_cleavage_text_sha"]  # text identical
+
+    def test_vs_brute_force(self, engine):
+        """The reference's own equivalence test (tests/test_cleavage_profile.py:52-86): difference-array
+        result == broadcasting every fragment against every position."""
+        rng = np.random.default_rng(5)
+        n, size = 3000, 20_000
+        s = np.sort(rng.integers(0, size - 400, n)).astype(np.int32)
+        e = (s + rng.integers(1, 400, n)).astype(np.int32)
+        st = (rng.random(n) < 0.5).astype(np.uint8)
+        engine.load_contig("cleave_bf", s, e, np.full(n, 60, np.uint8), st)
+        a, b = 4000, 16_500
+        got = engine.cleavage("cleave_bf", a, b)
+        pos = np.arange(a, b)[None, :]
+        sel = (e > a) & (s < b)
+        S, E, ST = s[sel, None].astype(np.int64), e[sel, None].astype(np.int64), st[sel, None].astype(bool)
+        depth = ((S <= pos) & (pos < E)).sum(axis=0)
+        ends = ((ST & (S == pos)) | (~ST & (E == pos))).sum(axis=0)
+        want = np.zeros(b - a)
+        want[depth != 0] = ends[depth != 0] / depth[depth != 0] * 100
+        assert np.array_equal(got, want)
+        engine.release("cleave_bf")

@@ -197,3 +197,13 @@ def test_synth_delfi_windows(G, syn):
                     got = O.py_delfi_single_window(syn[contig]["rows"], r["start"], r["stop"], 30, b,
                                                    gaps[contig] if use_gaps else None)
                     assert got == (r["short"], r["long"], r["num_frags"])
+
+
+def test_synth_cleavage(G, A, syn):
+    for c in G["synth"]["cleavage_cases"]:
+        size = G["synth"]["contigs"][c["contig"]]
+        a, b = max(c["start"] - c["left"], 0), min(c["stop"] + c["right"], size)
+        depth, ends, prop = O.c_cleavage(syn[c["contig"]]["fr"], a, b, c["min_length"], c["max_length"],
+                                         c["quality_threshold"])
+        assert np.array_equal(A["cleavage_pos_" + c["key"].split("_")[1]], np.arange(a, b))
+        assert np.array_equal(prop, A[c["key"]]), c  # float64, bit for bit
