@@ -1,7 +1,7 @@
 """
 Command line for the hot-path commands, flag-compatible with the reference's
 ``finaletoolkit`` CLI (``cli/commands/__init__.py:92-127,130-232,280-324,415-479`` and ``cli/_args.py``):
-``coverage``, ``frag-length-bins``, ``frag-length-intervals``, ``wps``, ``delfi``.
+``coverage``, ``frag-length-bins``, ``frag-length-intervals``, ``wps``, ``delfi`` (+ ``cleavage-profile``).
 
     python -m finaletoolkit_amd.cli coverage INPUT INTERVALS -o out.bed
 """
@@ -62,6 +62,15 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("-W", "--window-size", dest="window_size", type=int, default=120)
     _shared(p, min_default=120, max_default=180, policy=False)
 
+    p = sub.add_parser("cleavage-profile", help="cleavage proportion over BED intervals")
+    p.add_argument("input_file", metavar="INPUT")
+    p.add_argument("interval_file", metavar="REGIONS")
+    p.add_argument("chrom_sizes", metavar="CHROM_SIZES")
+    p.add_argument("--pad-left", dest="left", type=int, default=0)
+    p.add_argument("--pad-right", dest="right", type=int, default=0)
+    _shared(p, min_default=0, policy=False)
+    p.set_defaults(quality_threshold=20)
+
     p = sub.add_parser("delfi", help="DELFI short/long fragment features")
     p.add_argument("input_file", metavar="INPUT")
     p.add_argument("chrom_sizes", metavar="CHROM_SIZES")
@@ -106,6 +115,11 @@ def main(argv=None) -> int:
                        window_size=a.window_size, interval_size=a.interval_size, min_length=a.min_length,
                        max_length=a.max_length, quality_threshold=a.quality_threshold, workers=a.workers,
                        verbose=a.verbose, reference_file=a.reference_file)
+    elif a.command == "cleavage-profile":
+        frag.multi_cleavage_profile(a.input_file, a.interval_file, a.chrom_sizes, left=a.left, right=a.right,
+                                    min_length=a.min_length, max_length=a.max_length,
+                                    quality_threshold=a.quality_threshold, output_file=a.output_file,
+                                    workers=a.workers, verbose=a.verbose, reference_file=a.reference_file)
     elif a.command == "delfi":
         frag.delfi(a.input_file, a.chrom_sizes, a.bins_file, a.reference_file, blacklist_file=a.blacklist_file,
                    gap_file=a.gap_file, output_file=a.output_file, no_gc_correct=a.no_gc_correct,
