@@ -96,9 +96,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # FTK_BENCH_FORCE_DIST=1 drives the collective code path with a 1-rank RCCL group (1-GPU boxes)
+    use_dist = world > 1 or bool(os.environ.get("FTK_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     sizes = dict(synth.B37_SIZES)
     if args.contigs:
@@ -150,8 +153,10 @@ def main():
     bins_all = sum(int(np.ceil(sizes[c] / WINDOW)) for c in names)
     max_bins_rank = max(sum(int(np.ceil(sizes[c] / WINDOW)) for c in names if owner[c] == r) for r in range(world))
     gather_in = torch.zeros((max_bins_rank, 2), dtype=torch.int64, device=dev)
-    gather_out = [torch.zeros_like(gather_in) for _ in range(world)] if world > 1 else None
+    gather_out = [torch.zeros_like(gather_in) for _ in range(world)] if use_dist else None
     wps_ev = {}
+    per_rank_order = {r: [c for c in names if owner[c] == r] for r in range(world)}
+    per_rank_rows = {r: [int(np.ceil(sizes[c] / WINDOW)) for c in per_rank_order[r]] for r in range(world)}
 
     def step(record_events=False):
         row = 0
@@ -174,7 +179,7 @@ def main():
                 wps_ev[c] = (ev, ev + 1)
                 ev += 2
             row += p["nw"]
-        if world > 1:
+        if use_dist:
             r0 = 0
             for c in mine:
                 p = per[c]
@@ -185,7 +190,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -197,7 +202,7 @@ def main():
         step(record_events=(i == args.steps - 1))
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -226,6 +231,11 @@ def main():
     tot_hist = sum(int(per[c]["hist"].sum().item()) + int(per[c]["over"].sum().item()) for c in mine)
     checks["cov_sum_eq_hist_sum"] = tot_cov == tot_hist
 
+    if use_dist:  # every rank must hold every contig's (short, long) rows, in LPT rank order
+        got = torch.cat([gather_out[owner[c]][sum(per_rank_rows[owner[c]][:per_rank_order[owner[c]].index(c)]):][:int(np.ceil(sizes[c] / WINDOW))]
+                         for c in mine]) if mine else None
+        mine_rows = torch.cat([torch.stack([per[c]["short"], per[c]["long"]], dim=1) for c in mine]) if mine else None
+        checks["allgather_roundtrip"] = bool(mine is None or torch.equal(got, mine_rows))
     out = None
     if rank == 0:
         cpu = None
@@ -246,7 +256,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "checks": checks, "load_s": round(t_load, 2),
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -259,7 +269,7 @@ def cpu_baseline(torch, eng, per, mine, sizes, budget_s, checks):
     p = per[c]
     s, e, q, st = [t.cpu().numpy() for t in p["keep"]]
     fr = O.Frags(s, e, q, st)
-    n_s = min(p["nw"], 64)
+    n_s = min(p["nw"], 600)
     ws, we = p["ws"][:n_s], p["we"][:n_s]
     t0 = time.perf_counter()
     cov = O.c_window_counts(fr, ws, we, mapq_min=MAPQ)
@@ -285,9 +295,30 @@ def cpu_baseline(torch, eng, per, mine, sizes, budget_s, checks):
     checks["sample_delfi"] = bool(np.array_equal(sh, p["short"][:n_s].cpu().numpy())
                                   and np.array_equal(lg, p["long"][:n_s].cpu().numpy()))
     checks["sample_wps"] = ok_wps
+    # reference-shaped single-thread baseline: the pure-Python restatement that
+    # follows the reference loop for loop, on a few windows / WPS tiles
+    rows = list(zip(s[:40_000].tolist(), e[:40_000].tolist(), q[:40_000].tolist(), st[:40_000].tolist()))
+    t2 = time.perf_counter()
+    n_py = 3
+    for w in range(n_py):
+        a, b = int(ws[w]), int(we[w])
+        O.py_single_coverage(rows, a, b, None, None, "midpoint", MAPQ)
+        O.py_distribution(rows, a, b, None, None, "midpoint", MAPQ)
+        O.py_delfi_single_window(rows, a, b, MAPQ, list(zip(p["bl"][0].tolist(), p["bl"][1].tolist())), p["gaps"])
+    t_py_count = (time.perf_counter() - t2) / n_py
+    t3 = time.perf_counter()
+    n_tiles_py = 2
+    for k in range(n_tiles_py):
+        O.py_wps(rows, 5000 * k + 100_000, 5000 * k + 105_000, sizes[c], WPS_W, WPS_MIN, WPS_MAX, MAPQ)
+    t_py_wps = (time.perf_counter() - t3) / n_tiles_py * (WINDOW / 5000)
     return {"value": round(1.0 / per_window, 3), "unit": "windows/s", "cores": 1, "kind": "port",
             "sample": f"C oracle (oracle/ftk_oracle.c, gcc -O2): coverage+hist+DELFI on {n_s} and WPS (5 kb tiles) on "
-                      f"{done} x 100 kb windows of contig {c}; extrapolated per window"}
+                      f"{done} x 100 kb windows of contig {c}; extrapolated per window",
+            "reference_shaped_python": {
+                "value": round(1.0 / (t_py_count + t_py_wps), 4), "unit": "windows/s", "cores": 1,
+                "sample": f"oracle/oracle.py py_* (per-window fetch + per-fragment Python predicate, numpy "
+                          f"_single_nt_wps): {n_py} windows of counters, {n_tiles_py} x 5 kb WPS tiles, over the first "
+                          f"40 000 fragments of contig {c}; extrapolated per 100 kb window"}}
 
 
 if __name__ == "__main__":
