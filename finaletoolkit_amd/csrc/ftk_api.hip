@@ -593,7 +593,7 @@ int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const i
     if ((rc = window_prepare(ctx, c, a, meta ? meta->d_ws : w_start, meta ? meta->d_we : w_end, n_win, lmax,
                              small_path ? kSmallMax : -1, &wc, zero)))
         return rc;
-    if (r.hist_out) {
+    if (r.hist_out && !small_path) {  // with the wave-per-window pass on, it writes / clears every row itself
         HIPCHK(ctx, hipMemsetAsync(r.hist_out, 0, hist_elems * 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(r.over_out, 0, n_win * 8, ctx->stream));
     }

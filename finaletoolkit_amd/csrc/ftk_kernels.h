@@ -49,8 +49,8 @@ void launch_plan(hipStream_t s, const ContigView& cv, const int32_t* ws, const i
 struct FeatureRequest {
     const ftk_filter* filter = nullptr;  // coverage + histogram predicate
     int64_t* cov_out = nullptr;
-    uint32_t* hist_out = nullptr;        // [n_win][n_bins], zero-filled by the caller
-    int64_t* over_out = nullptr;         // zero-filled by the caller
+    uint32_t* hist_out = nullptr;        // [n_win][n_bins]; zero-filled by the caller only when small_path is off
+    int64_t* over_out = nullptr;         // (same)
     int len_lo = 0, n_bins = 0;
     int64_t* short_out = nullptr;        // DELFI
     int64_t* long_out = nullptr;

@@ -99,6 +99,8 @@ __device__ __forceinline__ void window_candidates(const ContigView& cv, int s, i
     nchunks = (cnt <= small_max) ? 0u : (uint32_t)((cnt + kChunk - 1) / kChunk);
 }
 
+constexpr int kPlanSingleBlockMax = 16384;  // windows one plan_kernel block handles (16 per thread)
+
 struct ZeroList {  // outputs the chunked path accumulates into with atomics
     int64_t* p[4];
 };
@@ -157,22 +159,33 @@ __global__ __launch_bounds__(1024) void plan_kernel(ContigView cv, const int32_t
     __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n_win; base += 1024) {
-        const int w = base + tid;
-        uint32_t v = 0;
+    // phase 1: every window's candidate range (up to 16 independent index lookups per thread in flight)
+    constexpr int R = kPlanSingleBlockMax / 1024;
+    uint32_t vv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int w = r * 1024 + tid;
+        vv[r] = 0;
         if (w < n_win) {
             int lo, hi;
-            window_candidates(cv, ws[w], we[w], lmax, small_max, lo, hi, v);
+            window_candidates(cv, ws[w], we[w], lmax, small_max, lo, hi, vv[r]);
             cand_lo[w] = lo;
             cand_hi[w] = hi;
-            nchunks[w] = v;
-            if (v) {
+            nchunks[w] = vv[r];
+            if (vv[r]) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (z.p[k]) z.p[k][w] = 0;
             }
         }
+    }
+    __syncthreads();
+    // phase 2: exclusive scan of the chunk counts
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (r * 1024 >= n_win) break;
+        const int w = r * 1024 + tid;
+        const uint32_t v = vv[r];
         uint32_t x = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -311,10 +324,19 @@ __global__ __launch_bounds__(256) void feat_small_kernel(ContigView cv, const in
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + wv;
     if (w >= n_win) return;
-    if (nchunks[w] != 0) return;  // the chunked path owns this window
+    const bool hist = CH && P.do_hist;
+    if (nchunks[w] != 0) {
+        // the chunked path owns this window and adds into its histogram row with atomics: clear it here
+        // (this kernel precedes feat_large_kernel on the stream), so no separate memset is needed
+        if (hist) {
+            uint32_t* dst = P.hist_out + (size_t)w * P.n_bins;
+            for (int b = lane; b < P.n_bins; b += 64) dst[b] = 0;
+            if (lane == 0) P.over_out[w] = 0;
+        }
+        return;
+    }
     const int lo = cand_lo[w], hi = cand_hi[w];
     const int ws = ws_[w], we = we_[w];
-    const bool hist = CH && P.do_hist;
     uint32_t* h = lds_hist + (size_t)wv * P.n_bins;
     if (hist && lo < hi) {
         for (int b = lane; b < P.n_bins; b += 64) h[b] = 0;
@@ -337,10 +359,10 @@ __global__ __launch_bounds__(256) void feat_small_kernel(ContigView cv, const in
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint32_t* dst = P.hist_out + (size_t)w * P.n_bins;
-        for (int b = lane; b < P.n_bins; b += 64) {
-            const uint32_t v = h[b];
-            if (v) dst[b] = v;  // hist_out was zero-filled by the caller
-        }
+        for (int b = lane; b < P.n_bins; b += 64) dst[b] = h[b];  // full row: no pre-fill needed
+    } else if (hist) {
+        uint32_t* dst = P.hist_out + (size_t)w * P.n_bins;
+        for (int b = lane; b < P.n_bins; b += 64) dst[b] = 0;
     }
     a.cov = wave_reduce_add(a.cov);
     a.over = wave_reduce_add(a.over);
@@ -851,7 +873,7 @@ void launch_plan(hipStream_t s, const ContigView& cv, const int32_t* ws, const i
                  int small_max, const WindowPlan& pl, int64_t* const zero[4]) {
     ZeroList z;
     for (int k = 0; k < 4; ++k) z.p[k] = zero ? zero[k] : nullptr;
-    if (n_win <= 16384) {
+    if (n_win <= kPlanSingleBlockMax) {
         hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, s, cv, ws, we, n_win, lmax, small_max, pl.cand_lo,
                            pl.cand_hi, pl.nchunks, pl.chunk_off, z);
         return;
@@ -878,7 +900,8 @@ static void launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, c
 }
 
 // One pass computing any combination of {coverage, length histogram} (filter `f`) and DELFI
-// short/long.  hist_out / over_out must be zero-filled by the caller when histograms are on.
+// short/long.  With small_path the wave-per-window kernel writes or clears every histogram row;
+// without it hist_out / over_out must be zero-filled by the caller.
 void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
                             int n_win, const WindowPlan& pl, const FeatureRequest& r, bool small_path) {
     FeatParams P{};
