@@ -161,24 +161,27 @@ def main():
     def step(record_events=False):
         row = 0
         ev = 0
-        for c in mine:
-            p = per[c]
-            cid = eng.contig_id(c)
-            # coverage + length histogram + DELFI short/long in ONE pass over the contig's fragments.
-            # Windows/blacklist are host arrays: hashed, their device form (windows + per-window
-            # blacklist CSR) is cached in the ctx; every output stays on the device (no sync).
-            eng._check(lib.ftk_window_features(
-                eng.ctx, cid, L.ptr(p["ws"]), L.ptr(p["we"]), p["nw"], C.byref(flt), L.ptr(p["cov"]), 0, HIST_BINS,
-                L.ptr(p["hist"]), L.ptr(p["over"]), MAPQ, L.ptr(p["bl"][0]), L.ptr(p["bl"][1]), len(p["bl"][0]),
-                C.byref(p["gaps_c"]), L.ptr(p["short"]), L.ptr(p["long"])))
-            if record_events:
-                eng.event_record(ev)
-            eng.wps(c, 0, sizes[c], sizes[c], WPS_W, WPS_MIN, WPS_MAX, MAPQ, out=p["wps"])
-            if record_events:
-                eng.event_record(ev + 1)
-                wps_ev[c] = (ev, ev + 1)
-                ev += 2
-            row += p["nw"]
+        split = bool(os.environ.get("FTK_BENCH_SPLIT_ORDER"))  # experiment: all feature passes, then all WPS
+        for phase in ((0, 1) if split else (2,)):
+            for c in mine:
+                p = per[c]
+                cid = eng.contig_id(c)
+                if phase in (0, 2):
+                    # coverage + length histogram + DELFI short/long in ONE pass over the contig's fragments.
+                    # Windows/blacklist are host arrays: hashed, their device form (windows + per-window
+                    # blacklist CSR) is cached in the ctx; every output stays on the device (no sync).
+                    eng._check(lib.ftk_window_features(
+                        eng.ctx, cid, L.ptr(p["ws"]), L.ptr(p["we"]), p["nw"], C.byref(flt), L.ptr(p["cov"]), 0,
+                        HIST_BINS, L.ptr(p["hist"]), L.ptr(p["over"]), MAPQ, L.ptr(p["bl"][0]), L.ptr(p["bl"][1]),
+                        len(p["bl"][0]), C.byref(p["gaps_c"]), L.ptr(p["short"]), L.ptr(p["long"])))
+                if phase in (1, 2):
+                    if record_events:
+                        eng.event_record(ev)
+                    eng.wps(c, 0, sizes[c], sizes[c], WPS_W, WPS_MIN, WPS_MAX, MAPQ, out=p["wps"])
+                    if record_events:
+                        eng.event_record(ev + 1)
+                        wps_ev[c] = (ev, ev + 1)
+                        ev += 2
         if use_dist:
             r0 = 0
             for c in mine:

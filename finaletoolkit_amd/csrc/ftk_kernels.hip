@@ -12,6 +12,8 @@
 //     LDS/registers and streams int64 scores out with 16-byte stores.
 #include "ftk_kernels.h"
 
+#include <algorithm>
+
 namespace ftk {
 
 // ---------------------------------------------------------------------------
@@ -223,7 +225,7 @@ struct WinPred {
             ok = ok && (fs < we) && (fe > ws);
         }
         if (policy == FTK_POLICY_MIDPOINT) {
-            const int mid = (int)(((long long)fs + (long long)fe) >> 1);
+            const int mid = (int)(((unsigned)fs + (unsigned)fe) >> 1);  // coordinates < 2^30
             ok = ok && (mid >= ws) && (mid < we);
         } else {
             ok = ok && (fe > ws) && (fs < we);
@@ -238,9 +240,13 @@ struct WinPred {
 
 // frag/_delfi.py:443-472.  Returns 0 (skip), 1 (short) or 2 (long).  [o0, o1) is
 // the window's slice of the blacklist CSR (hoisted per window by the caller).
+// ContigGaps.in_tcmere (genome/gaps.py:217-237) is pre-reduced on the host to two
+// intervals: the centromere [cen0, cen1) and the telomere condition
+// all_i(stop > t0_i and start < t1_i) == stop > max_i t0_i and start < min_i t1_i
+// (tel0 = INT32_MAX when there are no telomeres / no gap annotation at all).
 struct DelfiPred {
     int mapq_min;
-    ftk_gaps g;
+    int cen0, cen1, tel0, tel1;
     const int32_t* bl_off;  // n_win + 1 offsets into bl_r0 / bl_pm (NULL: no blacklist)
     const int32_t* bl_r0;   // region starts (sorted) of the regions fully inside each window
     const int32_t* bl_pm;   // running maximum of the region stops inside each window
@@ -248,7 +254,7 @@ struct DelfiPred {
     __device__ __forceinline__ int test(const ContigView& cv, int i, int fs, int fe, int q, int ws, int we, int o0,
                                         int o1) const {
         const int len = fe - fs;
-        const int mid = (int)(((long long)fs + (long long)fe) >> 1);
+        const int mid = (int)(((unsigned)fs + (unsigned)fe) >> 1);  // coordinates < 2^30
         bool ok = (q >= mapq_min) && (len >= 100) && (len <= 220) && (mid >= ws) && (mid < we);
         if (BAM) {
             const int rs = cv.r1_start[i], re = cv.r1_end[i];
@@ -256,13 +262,8 @@ struct DelfiPred {
         } else {
             ok = ok && (fs < we) && (fe > ws);
         }
+        ok = ok && !((fe > cen0) && (fs < cen1)) && !((fe > tel0) && (fs < tel1));
         if (!ok) return 0;
-        if (g.has_gaps) {  // genome/gaps.py:217-237
-            const bool in_cen = (fe > g.cen_start) && (fs < g.cen_stop);
-            bool in_tel = g.n_telo > 0;
-            for (int t = 0; t < g.n_telo; ++t) in_tel = in_tel && (fe > g.telo_start[t]) && (fs < g.telo_stop[t]);
-            if (in_cen || in_tel) return 0;
-        }
         if (o1 > o0) {  // frag/_delfi.py:455-462: blacklisted iff max{r1 : r0 <= fs} > fe
             int lo = o0, hi = o1;  // upper bound: first region with r0 > fs
             while (lo < hi) {
@@ -917,7 +918,23 @@ void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv,
     P.over_out = r.over_out;
     P.short_out = r.short_out;
     P.long_out = r.long_out;
-    P.dp = DelfiPred{r.delfi_mapq_min, r.gaps, r.bl_off, r.bl_r0, r.bl_pm};
+    {
+        const ftk_gaps& g = r.gaps;
+        int cen0 = INT32_MAX, cen1 = INT32_MIN, tel0 = INT32_MAX, tel1 = INT32_MIN;
+        if (g.has_gaps) {
+            cen0 = g.cen_start;
+            cen1 = g.cen_stop;
+            if (g.n_telo > 0) {
+                tel0 = INT32_MIN;
+                tel1 = INT32_MAX;
+                for (int t = 0; t < g.n_telo; ++t) {
+                    tel0 = std::max(tel0, g.telo_start[t]);
+                    tel1 = std::min(tel1, g.telo_stop[t]);
+                }
+            }
+        }
+        P.dp = DelfiPred{r.delfi_mapq_min, cen0, cen1, tel0, tel1, r.bl_off, r.bl_r0, r.bl_pm};
+    }
     const bool bam = cv.r1_start != nullptr && (!r.filter || r.filter->fetch_mode == FTK_FETCH_BAM_READ1);
 #define FTK_FEAT(CH, DF)                                                                              \
     do {                                                                                              \

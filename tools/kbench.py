@@ -82,4 +82,23 @@ if "hist" in which:
     timeit(lambda: eng._check(eng.lib.ftk_fraglen_hist(eng.ctx, eng.contig_id("c"), L.ptr(d_ws), L.ptr(d_we), len(ws),
                                                        C.byref(flt), 0, 1001, L.ptr(hist), L.ptr(over))),
            "fraglen_hist COLD", 10 * n, cold=True)
+if "feat" in which:
+    import ctypes as C
+    from finaletoolkit_amd import _lib as L
+    flt = L.make_filter(30, None, None, "midpoint")
+    sh = torch.zeros(len(ws), dtype=torch.int64, device=dev)
+    lg = torch.zeros(len(ws), dtype=torch.int64, device=dev)
+    bl_s, bl_e = bench.synth_blacklist(size, 5, 160)
+    g = L.make_gaps(bench.synth_gaps(size))
+
+    def fused(cov_on=True, hist_on=True, delfi_on=True):
+        eng._check(eng.lib.ftk_window_features(
+            eng.ctx, eng.contig_id("c"), L.ptr(ws), L.ptr(we), len(ws), C.byref(flt), L.ptr(cov) if cov_on else None,
+            0, 1001, L.ptr(hist) if hist_on else None, L.ptr(over) if hist_on else None, 30, L.ptr(bl_s), L.ptr(bl_e),
+            len(bl_s), C.byref(g), L.ptr(sh) if delfi_on else None, L.ptr(lg) if delfi_on else None))
+    for name, kw in [("cov", dict(hist_on=False, delfi_on=False)), ("cov+hist", dict(delfi_on=False)),
+                     ("delfi", dict(cov_on=False, hist_on=False)), ("cov+hist+delfi", {})]:
+        timeit(lambda: fused(**kw), "fused " + name, 10 * n)
+        timeit(lambda: fused(**kw), "fused " + name + " COLD(read)", 10 * n, cold="read")
+        timeit(lambda: fused(**kw), "fused " + name + " COLD(dirty)", 10 * n, cold=True)
 print("wps checksum", int(out[:5_000_000].sum().item()), "cov", int(cov.sum().item()))
