@@ -238,7 +238,7 @@ def main():
         got = torch.cat([gather_out[owner[c]][sum(per_rank_rows[owner[c]][:per_rank_order[owner[c]].index(c)]):][:int(np.ceil(sizes[c] / WINDOW))]
                          for c in mine]) if mine else None
         mine_rows = torch.cat([torch.stack([per[c]["short"], per[c]["long"]], dim=1) for c in mine]) if mine else None
-        checks["allgather_roundtrip"] = bool(mine is None or torch.equal(got, mine_rows))
+        checks["allgather_roundtrip"] = bool(not mine or torch.equal(got, mine_rows))
     out = None
     if rank == 0:
         cpu = None

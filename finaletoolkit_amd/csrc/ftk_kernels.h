@@ -32,6 +32,7 @@ struct WpsParams {
     int hl, hr, odd;
     int min_len, max_len, mapq_min;
     int lmax;  // min(max_len, longest fragment of the contig)
+    int nt_store;  // non-temporal score stores (default on)
 };
 
 struct CleaveParams {

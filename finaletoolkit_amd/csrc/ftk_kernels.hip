@@ -676,7 +676,10 @@ __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParam
                 }
                 if (i0 + 1 < cur.len_t) {
                     if (vec_ok) {
-                        *reinterpret_cast<longlong2*>(dst + i0) = make_longlong2(o0, o1);
+                        typedef long long ll2 __attribute__((ext_vector_type(2)));
+                        ll2 v2 = {o0, o1};
+                        if (p.nt_store) __builtin_nontemporal_store(v2, reinterpret_cast<ll2*>(dst + i0));
+                        else *reinterpret_cast<ll2*>(dst + i0) = v2;
                     } else {
                         dst[i0] = o0;
                         dst[i0 + 1] = o1;
@@ -795,7 +798,11 @@ __global__ __launch_bounds__(256) void cleavage_kernel(ContigView cv, CleavePara
             const double o0 = g0 ? (double)ends.x / (double)g0 * 100.0 : 0.0;
             const double o1 = g1 ? (double)ends.y / (double)g1 * 100.0 : 0.0;
             if (i0 + 1 < len_t) {
-                if (vec_ok) *reinterpret_cast<double2*>(dst + i0) = make_double2(o0, o1);
+                if (vec_ok) {
+                    typedef double d2 __attribute__((ext_vector_type(2)));
+                    d2 v2 = {o0, o1};
+                    __builtin_nontemporal_store(v2, reinterpret_cast<d2*>(dst + i0));
+                }
                 else { dst[i0] = o0; dst[i0 + 1] = o1; }
             } else if (i0 < len_t) {
                 dst[i0] = o0;
