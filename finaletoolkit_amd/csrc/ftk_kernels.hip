@@ -12,6 +12,8 @@
 //     LDS/registers and streams int64 scores out with 16-byte stores.
 #include "ftk_kernels.h"
 
+#include <cstdlib>
+
 #include <algorithm>
 
 namespace ftk {
@@ -958,9 +960,10 @@ void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t
                 const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv, const int32_t* tile_k,
                 int64_t* out) {
     if (n_tiles <= 0) return;
-    // two consecutive tiles per block: the second tile's fragment loads hide behind the first
-    // tile's stores and their halos share cache lines (measured best of 1/2/4/8/16/32)
-    const long long tpb = 2;
+    // tiles per block: with non-temporal score stores one tile per block is fastest (6.4 TB/s vs 6.2 at
+    // 2, 5.9-6.2 at 3-8 on chr2); with ordinary stores 2 was.  FTK_WPS_TPB overrides for experiments.
+    static const long long tpb_env = getenv("FTK_WPS_TPB") ? atoll(getenv("FTK_WPS_TPB")) : 0;
+    const long long tpb = tpb_env > 0 ? tpb_env : 1;
     const long long grid = (n_tiles + tpb - 1) / tpb;
     hipLaunchKernelGGL(wps_stream_kernel, dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop, out_off,
                        tile_iv, tile_k, (long long)n_tiles, (int)tpb, out);
