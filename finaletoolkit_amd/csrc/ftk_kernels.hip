@@ -511,6 +511,7 @@ struct WpsTile {
 
 constexpr int kWpsPrefetch = 4;  // fragments per thread held in registers for the next tile
 
+template <bool MULTI>  // MULTI: a block walks several tiles and prefetches the next one's fragments
 __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParams p, const int64_t* iv_start_,
                                                          const int64_t* iv_stop_, const int64_t* out_off_,
                                                          const int32_t* tile_iv, const int32_t* tile_k,
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParam
     const int odd = p.odd, kk = p.hl;  // odd W: hl == k
     for (long long t = tfirst; t < tlast; ++t) {
         const int par = (int)((t - tfirst) & 1);
-        const bool has_next = t + 1 < tlast;
+        const bool has_next = MULTI && (t + 1 < tlast);
         WpsTile nxt = cur;
         int nb = 0;
         if (has_next) {
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParam
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             const int i = lo2 + tid + 256 * k;
-            const bool ok = i < hi2;
+            const bool ok = MULTI && i < hi2;
             nfs[k] = ok ? cv.start[i] : 0;
             nfe[k] = ok ? cv.end[i] : 0;
             nfq[k] = ok ? (int)cv.mapq[i] : -1;
@@ -965,8 +966,12 @@ void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t
     static const long long tpb_env = getenv("FTK_WPS_TPB") ? atoll(getenv("FTK_WPS_TPB")) : 0;
     const long long tpb = tpb_env > 0 ? tpb_env : 1;
     const long long grid = (n_tiles + tpb - 1) / tpb;
-    hipLaunchKernelGGL(wps_stream_kernel, dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop, out_off,
-                       tile_iv, tile_k, (long long)n_tiles, (int)tpb, out);
+    if (tpb == 1)
+        hipLaunchKernelGGL(wps_stream_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop,
+                           out_off, tile_iv, tile_k, (long long)n_tiles, (int)tpb, out);
+    else
+        hipLaunchKernelGGL(wps_stream_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop,
+                           out_off, tile_iv, tile_k, (long long)n_tiles, (int)tpb, out);
 }
 
 void launch_cleavage(hipStream_t s, const ContigView& cv, const CleaveParams& p, int64_t n_tiles,
