@@ -598,7 +598,10 @@ int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const i
         HIPCHK(ctx, hipMemsetAsync(r.hist_out, 0, hist_elems * 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(r.over_out, 0, n_win * 8, ctx->stream));
     }
-    launch_window_features(ctx->stream, ctx->n_cu * 8, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, r, small_path);
+    // blocks per CU of the chunk walker: 8 are resident, 32 give shorter per-block chunk ranges and a
+    // smoother tail (measured best of 2..256 on the whole-genome bench); FTK_FEAT_BPC for experiments
+    static const int bpc = getenv("FTK_FEAT_BPC") ? atoi(getenv("FTK_FEAT_BPC")) : 32;
+    launch_window_features(ctx->stream, ctx->n_cu * bpc, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, r, small_path);
     if (d_nfrag) launch_add_i64(ctx->stream, r.short_out, r.long_out, d_nfrag, (int)n_win);
     HIPCHK(ctx, hipGetLastError());
     bool host_out = false;
