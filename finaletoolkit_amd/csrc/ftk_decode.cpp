@@ -7,8 +7,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -33,6 +35,28 @@ int dfail(int code, const char* fmt, ...) {
     g_decode_err = buf;
     return code;
 }
+
+// Byte buffer that is NOT zero-filled on allocation (a 9 GB text image would otherwise
+// be memset by one thread before the inflaters overwrite it).
+struct Bytes {
+    std::unique_ptr<uint8_t[]> p;
+    size_t n = 0;
+    void alloc(size_t m) { p.reset(new uint8_t[m ? m : 1]); n = m; }
+    uint8_t* data() { return p.get(); }
+    const uint8_t* data() const { return p.get(); }
+    size_t size() const { return n; }
+};
+
+struct Stopwatch {  // FTK_DECODE_TIMING=1 prints stage times to stderr
+    bool on = getenv("FTK_DECODE_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ftk decode] %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
 
 struct Columns {
     std::vector<int32_t> start, end, r1s, r1e;
@@ -71,6 +95,23 @@ bool have_hip_device() {
         return n > 0;
     }();
     return yes;
+}
+
+// Lay a contig's final columns out inside an existing block (no copy).
+size_t packed_bytes(size_t m, bool bam) {
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    return (bam ? 4 : 2) * up(m * 4 + 16) + 2 * up(m + 16);
+}
+
+void place(Packed& p, char* q, size_t m, bool bam) {
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t b32 = up(m * 4 + 16), b8 = up(m + 16);
+    p.rows = m;
+    p.start = (int32_t*)q; q += b32;
+    p.end = (int32_t*)q; q += b32;
+    if (bam) { p.r1s = (int32_t*)q; q += b32; p.r1e = (int32_t*)q; q += b32; }
+    p.mapq = (uint8_t*)q; q += b8;
+    p.strand = (uint8_t*)q;
 }
 
 void pack(Contig& ct) {
@@ -112,7 +153,10 @@ struct ftk_fragtable {
     std::vector<Contig> contigs;
     bool bed6 = false;
     bool bam = false;
+    void* block = nullptr;  // one allocation holding every contig's columns (text decoder)
+    bool block_pinned = false;
     ~ftk_fragtable() {
+        if (block) { if (block_pinned) (void)hipHostFree(block); else free(block); }
         for (auto& ct : contigs) {
             if (!ct.p.base) continue;
             if (ct.p.pinned) (void)hipHostFree(ct.p.base); else free(ct.p.base);
@@ -122,14 +166,14 @@ struct ftk_fragtable {
 
 namespace {
 
-bool read_file(const char* path, std::vector<uint8_t>* out) {
+bool read_file(const char* path, Bytes* out) {
     FILE* fp = fopen(path, "rb");
     if (!fp) return false;
     fseek(fp, 0, SEEK_END);
     long sz = ftell(fp);
     fseek(fp, 0, SEEK_SET);
     if (sz < 0) { fclose(fp); return false; }
-    out->resize((size_t)sz);
+    out->alloc((size_t)sz);
     size_t got = sz ? fread(out->data(), 1, (size_t)sz, fp) : 0;
     fclose(fp);
     return got == (size_t)sz;
@@ -168,10 +212,10 @@ size_t gzip_header(const uint8_t* p, size_t n, size_t off, size_t* bsize) {
 }
 
 // Inflate a BGZF (block-parallel) or plain gzip (serial) file image.
-int inflate_all(const std::vector<uint8_t>& in, int n_threads, std::vector<uint8_t>* out) {
+int inflate_all(const Bytes& in, int n_threads, Bytes* out) {
     const uint8_t* p = in.data();
     const size_t n = in.size();
-    if (n == 0) { out->clear(); return FTK_OK; }
+    if (n == 0) { out->alloc(0); return FTK_OK; }
     size_t bsize = 0;
     size_t pay = gzip_header(p, n, 0, &bsize);
     if (!pay) return dfail(FTK_ERR_FORMAT, "not a gzip/BGZF file");
@@ -188,7 +232,7 @@ int inflate_all(const std::vector<uint8_t>& in, int n_threads, std::vector<uint8
             total += isize;
             off += bs;
         }
-        out->resize(total);
+        out->alloc(total);
         std::atomic<size_t> next{0};
         std::atomic<int> bad{0};
         auto work = [&]() {
@@ -218,7 +262,7 @@ int inflate_all(const std::vector<uint8_t>& in, int n_threads, std::vector<uint8
         return FTK_OK;
     }
     // plain (possibly multi-member) gzip
-    out->clear();
+    std::vector<uint8_t> acc;
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, 15 + 16) != Z_OK) return dfail(FTK_ERR_FORMAT, "zlib init failed");
@@ -230,7 +274,7 @@ int inflate_all(const std::vector<uint8_t>& in, int n_threads, std::vector<uint8
         zs.avail_out = (uInt)buf.size();
         int rc = inflate(&zs, Z_NO_FLUSH);
         if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); return dfail(FTK_ERR_FORMAT, "gzip inflate failed (%d)", rc); }
-        out->insert(out->end(), buf.data(), buf.data() + (buf.size() - zs.avail_out));
+        acc.insert(acc.end(), buf.data(), buf.data() + (buf.size() - zs.avail_out));
         if (rc == Z_STREAM_END) {
             if (zs.avail_in == 0) break;
             if (inflateReset(&zs) != Z_OK) { inflateEnd(&zs); return dfail(FTK_ERR_FORMAT, "gzip member reset failed"); }
@@ -239,6 +283,8 @@ int inflate_all(const std::vector<uint8_t>& in, int n_threads, std::vector<uint8
         }
     }
     inflateEnd(&zs);
+    out->alloc(acc.size());
+    if (!acc.empty()) memcpy(out->data(), acc.data(), acc.size());
     return FTK_OK;
 }
 
@@ -326,12 +372,14 @@ int ftk_fragfile_decode(const char* path, const char* contig, int n_threads, ftk
     if (!path || !out) return dfail(FTK_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (n_threads < 1) n_threads = 1;
-    std::vector<uint8_t> raw, text;
+    Stopwatch sw;
+    Bytes raw, text;
     if (!read_file(path, &raw)) return dfail(FTK_ERR_IO, "cannot read %s", path);
+    sw.lap("read file");
     int rc = inflate_all(raw, n_threads, &text);
     if (rc) return rc;
-    raw.clear();
-    raw.shrink_to_fit();
+    raw.alloc(0);
+    sw.lap("inflate");
     std::unique_ptr<ftk_fragtable> t(new ftk_fragtable());
     const char* b = (const char*)text.data();
     const char* e = b + text.size();
@@ -368,12 +416,54 @@ int ftk_fragfile_decode(const char* path, const char* contig, int n_threads, ftk
         th.emplace_back(parse_segment, cut[i], cut[i + 1], t->bed6, contig, &seg_runs[i]);
     parse_segment(cut[0], cut[1], t->bed6, contig, &seg_runs[0]);
     for (auto& x : th) x.join();
-    for (auto& runs : seg_runs)
-        for (auto& r : runs) find_or_add(t.get(), r.name)->c.append(r.c);
-    for (auto& ct : t->contigs) {
-        pack(ct);
-        if (!ct.p.base) return dfail(FTK_ERR_OOM, "out of host memory");
+    sw.lap("parse");
+    // Assemble: row offsets of every run (serial, tiny), ONE block for the whole table (page-locked
+    // when a HIP device is present), then every segment copies its runs to their final place in parallel.
+    struct Dest { int contig; size_t off; };
+    std::vector<std::vector<Dest>> dest(nseg);
+    std::vector<size_t> rows_of;
+    for (int sg = 0; sg < nseg; ++sg)
+        for (auto& r : seg_runs[sg]) {
+            Contig* ct = find_or_add(t.get(), r.name);
+            const int ci = (int)(ct - t->contigs.data());
+            if ((size_t)ci >= rows_of.size()) rows_of.resize(ci + 1, 0);
+            dest[sg].push_back({ci, rows_of[ci]});
+            rows_of[ci] += r.c.start.size();
+        }
+    size_t total = 0;
+    std::vector<size_t> base_of(t->contigs.size());
+    for (size_t ci = 0; ci < t->contigs.size(); ++ci) { base_of[ci] = total; total += packed_bytes(rows_of[ci], false); }
+    if (total == 0) total = 256;
+    if (have_hip_device() && hipHostMalloc(&t->block, total, hipHostMallocDefault) == hipSuccess) {
+        t->block_pinned = true;
+    } else {
+        (void)hipGetLastError();
+        t->block = malloc(total);
     }
+    if (!t->block) return dfail(FTK_ERR_OOM, "out of host memory (%zu bytes)", total);
+    for (size_t ci = 0; ci < t->contigs.size(); ++ci) {
+        place(t->contigs[ci].p, (char*)t->block + base_of[ci], rows_of[ci], false);
+        t->contigs[ci].p.pinned = t->block_pinned;
+    }
+    sw.lap("allocate (pinned)");
+    auto assemble = [&](int sg) {
+        for (size_t k = 0; k < seg_runs[sg].size(); ++k) {
+            const Columns& c = seg_runs[sg][k].c;
+            const Packed& p = t->contigs[dest[sg][k].contig].p;
+            const size_t o = dest[sg][k].off, m = c.start.size();
+            if (!m) continue;
+            memcpy(p.start + o, c.start.data(), m * 4);
+            memcpy(p.end + o, c.end.data(), m * 4);
+            memcpy(p.mapq + o, c.mapq.data(), m);
+            memcpy(p.strand + o, c.strand.data(), m);
+        }
+        std::vector<Run>().swap(seg_runs[sg]);
+    };
+    th.clear();
+    for (int i = 1; i < nseg; ++i) th.emplace_back(assemble, i);
+    assemble(0);
+    for (auto& x : th) x.join();
+    sw.lap("assemble");
     *out = t.release();
     return FTK_OK;
 }
@@ -382,12 +472,11 @@ int ftk_bam_decode(const char* path, const char* contig, int n_threads, ftk_frag
     if (!path || !out) return dfail(FTK_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (n_threads < 1) n_threads = 1;
-    std::vector<uint8_t> raw, bam;
+    Bytes raw, bam;
     if (!read_file(path, &raw)) return dfail(FTK_ERR_IO, "cannot read %s", path);
     int rc = inflate_all(raw, n_threads, &bam);
     if (rc) return rc;
-    raw.clear();
-    raw.shrink_to_fit();
+    raw.alloc(0);
     const uint8_t* p = bam.data();
     const size_t n = bam.size();
     if (n < 12 || memcmp(p, "BAM\1", 4) != 0) return dfail(FTK_ERR_FORMAT, "%s is not a BAM file", path);
