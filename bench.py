@@ -135,8 +135,6 @@ def main():
             cov=torch.zeros(nw, dtype=torch.int64, device=dev),
             hist=torch.zeros((nw, HIST_BINS), dtype=torch.int32, device=dev),
             over=torch.zeros(nw, dtype=torch.int64, device=dev),
-            short=torch.zeros(nw, dtype=torch.int64, device=dev),
-            long=torch.zeros(nw, dtype=torch.int64, device=dev),
             wps=torch.empty(sizes[c], dtype=torch.int64, device=dev),
             keep=(s, e, q, st) if c == mine[-1] else None,
         )
@@ -152,8 +150,15 @@ def main():
         per[c]["gaps_c"] = L.make_gaps(per[c]["gaps"])
     bins_all = sum(int(np.ceil(sizes[c] / WINDOW)) for c in names)
     max_bins_rank = max(sum(int(np.ceil(sizes[c] / WINDOW)) for c in names if owner[c] == r) for r in range(world))
-    gather_in = torch.zeros((max_bins_rank, 2), dtype=torch.int64, device=dev)
+    # The DELFI (short, long) vectors are written by the kernels straight into the all-gather send
+    # buffer: row 0 = short, row 1 = long, this rank's contigs back to back (no packing kernels).
+    gather_in = torch.zeros((2, max_bins_rank), dtype=torch.int64, device=dev)
     gather_out = [torch.zeros_like(gather_in) for _ in range(world)] if use_dist else None
+    r0 = 0
+    for c in mine:
+        per[c]["short"] = gather_in[0, r0:r0 + per[c]["nw"]]
+        per[c]["long"] = gather_in[1, r0:r0 + per[c]["nw"]]
+        r0 += per[c]["nw"]
     wps_ev = {}
     per_rank_order = {r: [c for c in names if owner[c] == r] for r in range(world)}
     per_rank_rows = {r: [int(np.ceil(sizes[c] / WINDOW)) for c in per_rank_order[r]] for r in range(world)}
@@ -183,12 +188,6 @@ def main():
                         wps_ev[c] = (ev, ev + 1)
                         ev += 2
         if use_dist:
-            r0 = 0
-            for c in mine:
-                p = per[c]
-                gather_in[r0:r0 + p["nw"], 0] = p["short"]
-                gather_in[r0:r0 + p["nw"], 1] = p["long"]
-                r0 += p["nw"]
             dist.all_gather(gather_out, gather_in)
 
     def barrier():
@@ -235,10 +234,17 @@ def main():
     checks["cov_sum_eq_hist_sum"] = tot_cov == tot_hist
 
     if use_dist:  # every rank must hold every contig's (short, long) rows, in LPT rank order
-        got = torch.cat([gather_out[owner[c]][sum(per_rank_rows[owner[c]][:per_rank_order[owner[c]].index(c)]):][:int(np.ceil(sizes[c] / WINDOW))]
-                         for c in mine]) if mine else None
-        mine_rows = torch.cat([torch.stack([per[c]["short"], per[c]["long"]], dim=1) for c in mine]) if mine else None
-        checks["allgather_roundtrip"] = bool(not mine or torch.equal(got, mine_rows))
+        ok = True
+        for c in mine:
+            o = sum(per_rank_rows[rank][:per_rank_order[rank].index(c)])
+            ok = ok and torch.equal(gather_out[rank][0, o:o + per[c]["nw"]], per[c]["short"]) \
+                and torch.equal(gather_out[rank][1, o:o + per[c]["nw"]], per[c]["long"])
+        checks["allgather_roundtrip"] = bool(ok)
+        # every rank now holds the whole-genome vector: total DELFI fragments must match on all ranks
+        tot = torch.stack([g.sum() for g in gather_out]).sum().reshape(1)
+        tots = [torch.zeros_like(tot) for _ in range(world)]
+        dist.all_gather(tots, tot)
+        checks["allgather_same_on_all_ranks"] = bool(all(int(t.item()) == int(tot.item()) for t in tots))
     out = None
     if rank == 0:
         cpu = None
