@@ -8,8 +8,9 @@
 //   * window features (coverage, DELFI, length histogram) are computed
 //     window-centrically: small candidate ranges one wave per window, large
 //     ones cut into 4096-fragment chunks that a fixed grid walks in order;
-//   * WPS builds a per-tile difference array in LDS with ds_add, scans it in
-//     LDS/registers and streams int64 scores out with 16-byte stores.
+//   * WPS (and the cleavage profile) build a per-tile difference array in LDS
+//     with ds_add, scan it on DPP and stream the scores out with non-temporal
+//     16-byte stores, 1 KB contiguous per store instruction.
 #include "ftk_kernels.h"
 
 #include <cstdlib>
@@ -25,25 +26,6 @@ __device__ __forceinline__ int wave_reduce_add(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
-}
-
-__device__ __forceinline__ long long wave_reduce_add64(long long v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// First fragment index whose start >= p (coarse bin index + local bisection).
-__device__ __forceinline__ int lower_bound_start(const ContigView& cv, long long p) {
-    if (p <= 0) return 0;
-    long long k = p >> kBinShift;
-    if (k >= cv.n_bins) return cv.n;
-    int lo = cv.bin_idx[k], hi = cv.bin_idx[k + 1];
-    while (lo < hi) {
-        int m = (lo + hi) >> 1;
-        if (cv.start[m] < p) lo = m + 1; else hi = m;
-    }
-    return lo;
 }
 
 // ---------------------------------------------------------------------------
