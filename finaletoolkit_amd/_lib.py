@@ -48,6 +48,7 @@ EXPORTS = [
     "ftk_window_counts", "ftk_delfi_counts", "ftk_fraglen_hist", "ftk_window_features", "ftk_frag_lengths",
     "ftk_frag_select",
     "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals",
+    "ftk_ref_upload", "ftk_ref_release", "ftk_ref_gc_counts",
 ]
 
 
@@ -138,6 +139,9 @@ def load() -> C.CDLL:
     lib.ftk_wps_intervals.argtypes = [vp, C.c_int, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]
     lib.ftk_cleavage.argtypes = [vp, C.c_int, i64, i64, i32, i32, i32, vp]
     lib.ftk_cleavage_intervals.argtypes = [vp, C.c_int, vp, vp, i64, vp, i32, i32, i32, vp]
+    lib.ftk_ref_upload.argtypes = [vp, C.c_int, vp, i64, C.c_int]
+    lib.ftk_ref_release.argtypes = [vp, C.c_int]
+    lib.ftk_ref_gc_counts.argtypes = [vp, C.c_int, vp, vp, i64, vp]
     _lib = lib
     return lib
 

@@ -307,6 +307,7 @@ void ftk_ctx_destroy(ftk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->contigs) free_contig(kv.second);
     for (auto& m : ctx->delfi_cache) (void)hipFree(m.base);
+    for (auto& kv : ctx->refs) (void)hipFree(kv.second.d);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -920,6 +921,77 @@ int ftk_cleavage(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int32
     if (ctx && stop <= start) return FTK_OK;
     const int64_t off = 0;
     return ftk_cleavage_intervals(ctx, contig_id, &start, &stop, 1, &off, min_len, max_len, mapq_min, prop_out);
+}
+
+int ftk_ref_upload(ftk_ctx* ctx, int ref_id, const uint8_t* image, int64_t n_bytes, int kind) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    if (n_bytes < 0 || (n_bytes > 0 && !image) || (kind != FTK_REF_FASTA_TEXT && kind != FTK_REF_2BIT))
+        return fail(ctx, FTK_ERR_INVALID, "bad reference image arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    auto it = ctx->refs.find(ref_id);
+    if (it != ctx->refs.end()) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(it->second.d);
+        ctx->refs.erase(it);
+    }
+    ftk_ctx::RefImage r;
+    r.bytes = n_bytes;
+    r.kind = kind;
+    HIPCHK(ctx, hipMalloc(&r.d, (size_t)n_bytes + 32));  // padded: 16-byte loads never leave the block
+    hipError_t e = hipMemset((char*)r.d + n_bytes, 0, 32);
+    if (e == hipSuccess && n_bytes)
+        e = hipMemcpy(r.d, image, n_bytes, is_device_ptr(image) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(r.d);
+        return fail(ctx, FTK_ERR_HIP, "reference upload failed: %s", hipGetErrorString(e));
+    }
+    ctx->refs[ref_id] = r;
+    return FTK_OK;
+}
+
+int ftk_ref_release(ftk_ctx* ctx, int ref_id) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    auto it = ctx->refs.find(ref_id);
+    if (it == ctx->refs.end()) return fail(ctx, FTK_ERR_NO_CONTIG, "reference image %d is not loaded", ref_id);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(it->second.d);
+    ctx->refs.erase(it);
+    return FTK_OK;
+}
+
+int ftk_ref_gc_counts(ftk_ctx* ctx, int ref_id, const int64_t* range_lo, const int64_t* range_hi, int64_t n,
+                      int64_t* gc_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    auto it = ctx->refs.find(ref_id);
+    if (it == ctx->refs.end()) return fail(ctx, FTK_ERR_NO_CONTIG, "reference image %d is not loaded", ref_id);
+    if (n < 0 || n > INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "n out of range");
+    if (n == 0) return FTK_OK;
+    if (!range_lo || !range_hi || !gc_out) return fail(ctx, FTK_ERR_INVALID, "NULL argument");
+    const ftk_ctx::RefImage& r = it->second;
+    const int64_t limit = r.kind == FTK_REF_2BIT ? r.bytes * 4 : r.bytes;
+    if (!is_device_ptr(range_lo))
+        for (int64_t i = 0; i < n; ++i)
+            if (range_lo[i] < 0 || range_hi[i] > limit)
+                return fail(ctx, FTK_ERR_INVALID, "range %lld outside the reference image", (long long)i);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool out_dev = is_device_ptr(gc_out);
+    int rc = reserve_scratch(ctx, 3 * align_up(n * 8));
+    if (rc) return rc;
+    Arena a(ctx);
+    int64_t* b_lo = a.take<int64_t>(n);
+    int64_t* b_hi = a.take<int64_t>(n);
+    int64_t* d_out = out_dev ? gc_out : a.take<int64_t>(n);
+    const int64_t *d_lo, *d_hi;
+    if ((rc = stage_in(ctx, range_lo, n, b_lo, &d_lo))) return rc;
+    if ((rc = stage_in(ctx, range_hi, n, b_hi, &d_hi))) return rc;
+    launch_gc_count(ctx->stream, (const uint8_t*)r.d, r.bytes, r.kind, d_lo, d_hi, (int)n, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    if (!out_dev) {
+        HIPCHK(ctx, hipMemcpyAsync(gc_out, d_out, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FTK_OK;
 }
 
 }  // extern "C"

@@ -70,6 +70,8 @@ struct ftk_ctx {
     std::map<int, ftk::ContigData> contigs;
     std::string err;
     std::vector<ftk::DelfiMeta> delfi_cache;
+    struct RefImage { void* d = nullptr; int64_t bytes = 0; int kind = 0; };
+    std::map<int, RefImage> refs;  // reference-sequence images for the DELFI GC count
     // grow-only device scratch, reused by every call (stream-ordered)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;

@@ -70,6 +70,8 @@ void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t
 void launch_cleavage(hipStream_t s, const ContigView& cv, const CleaveParams& p, int64_t n_tiles,
                      const int64_t* iv_start, const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv,
                      const int32_t* tile_k, double* out);
+void launch_gc_count(hipStream_t s, const uint8_t* img, int64_t img_bytes, int kind, const int64_t* lo,
+                     const int64_t* hi, int n, int64_t* out);
 void launch_select_count(hipStream_t s, const ContigView& cv, int lo, int hi, int ws, int we, const ftk_filter& f,
                          uint32_t* block_cnt);
 void launch_scan_u32(hipStream_t s, const uint32_t* in, int n, uint32_t* off);

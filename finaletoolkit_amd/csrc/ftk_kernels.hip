@@ -797,6 +797,72 @@ __global__ __launch_bounds__(256) void cleavage_kernel(ContigView cv, CleavePara
 }
 
 // ---------------------------------------------------------------------------
+// DELFI per-bin GC count (frag/_delfi.py:476-490: ref_bases.count("G") + count("C") on the
+// upper-cased window sequence) over a reference image resident in HBM: either the raw FASTA
+// text of a contig (1 byte per base, line breaks included: ranges are byte offsets) or the
+// packed DNA of a .2bit record (T=0 C=1 A=2 G=3, first base in the high bits: ranges are base
+// positions, G/C = codes with the low bit set).  One wave per range, 16-byte loads.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int gc_in_text_word(uint32_t w) {
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t b = ((w >> (8 * k)) & 0xffu) | 0x20u;  // fold case
+        c += (b == 'g') | (b == 'c');
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(256) void gc_count_kernel(const uint8_t* __restrict__ img, int64_t img_bytes, int kind,
+                                                       const int64_t* lo_, const int64_t* hi_, int n,
+                                                       int64_t* __restrict__ out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    int64_t lo = lo_[r], hi = hi_[r];
+    long long acc = 0;
+    if (hi > lo) {
+        // byte range [b0, b1) of the image; for 2-bit, partial first/last bytes are masked
+        const int64_t b0 = kind ? lo >> 2 : lo, b1 = kind ? (hi + 3) >> 2 : hi;
+        const int64_t a0 = (b0 + 15) & ~15LL, a1 = b1 & ~15LL;  // 16-byte aligned interior
+        auto byte_gc = [&](int64_t b) -> int {
+            const uint32_t v = img[b];
+            if (!kind) { const uint32_t x = v | 0x20u; return (x == 'g') | (x == 'c'); }
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t pos = b * 4 + k;
+                if (pos >= lo && pos < hi) c += (v >> (6 - 2 * k)) & 1u;
+            }
+            return c;
+        };
+        if (a0 >= a1) {
+            for (int64_t b = b0 + lane; b < b1; b += 64) acc += byte_gc(b);
+        } else {
+            for (int64_t b = b0 + lane; b < a0; b += 64) acc += byte_gc(b);
+            for (int64_t b = a1 + lane; b < b1; b += 64) acc += byte_gc(b);
+            // interior bytes are whole: every base of a 2-bit byte is inside [lo, hi) unless it is the very
+            // first or last byte of the range, which can only sit in the interior if it is complete
+            const int64_t first_full = kind ? ((lo + 3) >> 2) : b0, last_full = kind ? (hi >> 2) : b1;
+            for (int64_t b = a0 + 16 * lane; b < a1; b += 16 * 64) {
+                const uint4 v = *reinterpret_cast<const uint4*>(img + b);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                if (!kind) {
+                    acc += gc_in_text_word(w[0]) + gc_in_text_word(w[1]) + gc_in_text_word(w[2]) + gc_in_text_word(w[3]);
+                } else if (b >= first_full && b + 16 <= last_full) {
+                    acc += __popc(w[0] & 0x55555555u) + __popc(w[1] & 0x55555555u) + __popc(w[2] & 0x55555555u) +
+                           __popc(w[3] & 0x55555555u);
+                } else {
+                    for (int k = 0; k < 16; ++k) acc += byte_gc(b + k);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) out[r] = acc;
+}
+
+// ---------------------------------------------------------------------------
 // ordered selection of one window's fragments (frag_length / frag_array)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void select_count_kernel(ContigView cv, int lo, int hi, int ws, int we,
@@ -962,6 +1028,12 @@ void launch_cleavage(hipStream_t s, const ContigView& cv, const CleaveParams& p,
     if (n_tiles <= 0) return;
     hipLaunchKernelGGL(cleavage_kernel, dim3((unsigned)n_tiles), dim3(256), 0, s, cv, p, iv_start, iv_stop, out_off,
                        tile_iv, tile_k, out);
+}
+
+void launch_gc_count(hipStream_t s, const uint8_t* img, int64_t img_bytes, int kind, const int64_t* lo,
+                     const int64_t* hi, int n, int64_t* out) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(gc_count_kernel, dim3((n + 3) / 4), dim3(256), 0, s, img, img_bytes, kind, lo, hi, n, out);
 }
 
 void launch_select_count(hipStream_t s, const ContigView& cv, int lo, int hi, int ws, int we, const ftk_filter& f,

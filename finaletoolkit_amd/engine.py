@@ -301,3 +301,27 @@ class Engine:
     def cleavage(self, name: str, start: int, stop: int, min_length=None, max_length=None, quality_threshold=30):
         return self.cleavage_intervals(name, [start], [stop], min_length, max_length, quality_threshold)[0]
 
+    # -- reference images (DELFI GC on the device) ----------------------------------
+    def ref_upload(self, key, image: np.ndarray, kind: int) -> int:
+        """Upload a contig's reference image (uint8); returns the ref id, cached by ``key`` (2 images kept)."""
+        refs = self.__dict__.setdefault("_refs", {})
+        if key in refs:
+            return refs[key]
+        while len(refs) >= 2:  # images are up to ~250 MB each
+            old_key = next(iter(refs))
+            self._check(self.lib.ftk_ref_release(self.ctx, refs.pop(old_key)))
+        rid = self.__dict__.setdefault("_next_ref", 0)
+        self._next_ref = rid + 1
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        self._check(self.lib.ftk_ref_upload(self.ctx, rid, L.ptr(image), len(image), int(kind)))
+        refs[key] = rid
+        return rid
+
+    def ref_gc_counts(self, rid: int, lo, hi):
+        lo = np.ascontiguousarray(lo, dtype=np.int64)
+        hi = np.ascontiguousarray(hi, dtype=np.int64)
+        out = np.zeros(len(lo), np.int64)
+        if len(lo):
+            self._check(self.lib.ftk_ref_gc_counts(self.ctx, rid, L.ptr(lo), L.ptr(hi), len(lo), L.ptr(out)))
+        return out
+

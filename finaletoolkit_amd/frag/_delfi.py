@@ -103,14 +103,16 @@ def _contig_windows(src, eng, ref, contig, starts, stops, contig_gaps, blacklist
             src.require(contig), starts[idx].astype(np.int32), stops[idx].astype(np.int32), quality_threshold,
             None if bl is None else bl[0], None if bl is None else bl[1],
             None if contig_gaps is None else contig_gaps.as_kernel_constants())
+        # GC count of every live bin in one device launch (frag/_delfi.py:476-490)
+        ok = np.array([_valid_interval(ref.chroms, contig, int(starts[i]), int(stops[i])) for i in idx], dtype=bool)
+        num_gc = np.zeros(len(idx), np.int64)
+        if ok.any():
+            num_gc[ok] = ref.gc_counts(eng, contig, starts[idx][ok], stops[idx][ok])
         for k, i in enumerate(idx):
             ws, we = int(starts[i]), int(stops[i])
-            if _valid_interval(ref.chroms, contig, ws, we):
-                num_gc = ref.gc_count(contig, ws, we)
-            else:
+            if not ok[k]:
                 warnings.warn(f"Invalid interval {contig}:{ws}-{we} for reference. Skipping GC calculation.")
-                num_gc = 0
-            gc = num_gc / (we - ws) if nf[k] > 0 else np.nan
+            gc = int(num_gc[k]) / (we - ws) if nf[k] > 0 else np.nan
             rows[i] = (contig, ws, we, arms[i], int(sh[k]), int(lg[k]), gc, int(nf[k]))
     for i in np.nonzero(~live)[0]:
         rows[i] = (contig, int(starts[i]), int(stops[i]), "NOARM", np.nan, np.nan, np.nan, 0)

@@ -131,6 +131,36 @@ class ReferenceGenome:
             return 0
         return self._gc_2bit(contig, start, stop) if self.is_2bit else self._gc_fasta(contig, start, stop)
 
+    def gc_counts(self, engine, contig: str, starts, stops) -> np.ndarray:
+        """G + C per interval ``[starts[i], stops[i])`` of one contig, counted on the device from a
+        reference image uploaded once per contig (``ftk_ref_upload`` / ``ftk_ref_gc_counts``).
+        Same numbers as ``gc_count`` (which stays as the host-side definition used by the tests)."""
+        starts = np.asarray(starts, dtype=np.int64)
+        stops = np.asarray(stops, dtype=np.int64)
+        key = (self.path, contig)
+        if self.is_2bit:
+            size, n_starts, n_sizes, dna_off = self._records[contig]
+            self._fh.seek(dna_off)
+            rid = engine.ref_upload(key, np.frombuffer(self._fh.read((size + 3) // 4), dtype=np.uint8), 1)
+            counts = engine.ref_gc_counts(rid, starts, stops)
+            # bases inside N blocks count as neither (they are stored as some code): subtract their share
+            for s0, n in zip(n_starts, n_sizes):
+                a = np.maximum(starts, s0)
+                b = np.minimum(stops, s0 + n)
+                hit = np.nonzero(a < b)[0]
+                if len(hit):
+                    counts[hit] -= engine.ref_gc_counts(rid, a[hit], b[hit])
+            return counts
+        length, offset, linebases, linewidth = self._fai[contig]
+        if linebases == 0:
+            return np.zeros(len(starts), np.int64)
+        n_text = (length // linebases) * linewidth + length % linebases
+        self._fh.seek(offset)
+        rid = engine.ref_upload(key, np.frombuffer(self._fh.read(n_text), dtype=np.uint8), 0)
+        lo = (starts // linebases) * linewidth + starts % linebases
+        hi = (stops // linebases) * linewidth + stops % linebases
+        return engine.ref_gc_counts(rid, lo, hi)
+
     def close(self):
         if self._fh:
             self._fh.close()

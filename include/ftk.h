@@ -235,6 +235,22 @@ int ftk_cleavage_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start,
                            const int64_t* out_offset, int32_t min_len, int32_t max_len, int32_t mapq_min,
                            double* prop_out);
 
+/* ---- next row: DELFI per-bin GC count on the device ------------------
+ * frag/_delfi.py:476-490 counts G + C of the upper-cased window sequence
+ * (io/reference.py:120-189) once per bin on the host.  Here a contig's reference image
+ * is uploaded once and every bin is counted in one launch:
+ *   FTK_REF_FASTA_TEXT  the contig's raw FASTA text (bases and line breaks, no header line);
+ *                       ranges are BYTE offsets into the image (faidx arithmetic is the caller's);
+ *   FTK_REF_2BIT        the packed DNA of a .2bit record (T=0 C=1 A=2 G=3, first base in the high
+ *                       bits); ranges are BASE positions; N / mask blocks are the caller's to subtract.
+ * gc_out[i] = number of G/C (either case) in [range_lo[i], range_hi[i]). */
+#define FTK_REF_FASTA_TEXT 0
+#define FTK_REF_2BIT 1
+int ftk_ref_upload(ftk_ctx* ctx, int ref_id, const uint8_t* image, int64_t n_bytes, int kind);
+int ftk_ref_release(ftk_ctx* ctx, int ref_id);
+int ftk_ref_gc_counts(ftk_ctx* ctx, int ref_id, const int64_t* range_lo, const int64_t* range_hi, int64_t n,
+                      int64_t* gc_out);
+
 #ifdef __cplusplus
 }
 #endif

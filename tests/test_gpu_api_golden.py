@@ -307,6 +307,9 @@ class TestDelfi:
                 n = stop - start
                 return 2 * (n // 4) + n % 4  # "ACGT" * k + "G" * rest
 
+            def gc_counts(self, eng, contig, starts, stops):
+                return np.array([self.gc_count(contig, int(a), int(b)) for a, b in zip(starts, stops)], np.int64)
+
             def __enter__(self):
                 return self
 
@@ -422,3 +425,27 @@ class TestCleavage:  # next row: reference tests/test_cleavage_prof
         want[depth != 0] = ends[depth != 0] / depth[depth != 0] * 100
         assert np.array_equal(got, want)
         engine.release("cleave_bf")
+
+
+class TestDeviceGC:  # next row: DELFI per-bin GC counted on the device
+    def test_2bit_and_fasta_match_host_definition(self, engine, tmp_path):
+        from finaletoolkit_amd.reference import ReferenceGenome
+        from tests.test_host_logic import _write_2bit
+        rng = np.random.default_rng(8)
+        n = 300_007
+        seq = "".join(rng.choice(list("ACGT"), n))
+        seq = seq[:1000] + "N" * 5003 + seq[6003:200_000] + "N" * 77 + seq[200_077:]
+        tb = str(tmp_path / "g.2bit")
+        _write_2bit(tb, "chrG", seq, [(1000, 5003), (200_000, 77)])
+        fa = tmp_path / "g.fa"
+        low = seq[:150_000] + seq[150_000:].lower()
+        fa.write_text(">chrG\n" + "\n".join(low[i:i + 70] for i in range(0, n, 70)) + "\n>z\nACGT\n")
+        starts = np.concatenate([np.arange(0, n - 10_000, 9_973), rng.integers(0, n - 50, 60), [0, n - 1, 999, 6002]])
+        stops = np.concatenate([np.arange(0, n - 10_000, 9_973) + 10_000, starts[-64:-4] + rng.integers(1, 50, 60),
+                                [n, n, 1001, 6004]])
+        want = np.array([sum(ch in "GC" for ch in seq[a:b]) for a, b in zip(starts, stops)])
+        for path in (tb, str(fa)):
+            with ReferenceGenome(path) as ref:
+                got = ref.gc_counts(engine, "chrG", starts, stops)
+                assert np.array_equal(got, want), path
+                assert [ref.gc_count("chrG", int(a), int(b)) for a, b in zip(starts[:40], stops[:40])] == want[:40].tolist()
