@@ -264,10 +264,18 @@ def main():
                        else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu, "checks": checks, "load_s": round(t_load, 2),
         }
-        print(json.dumps(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio: flush that first so the JSON line is the last line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(torch, eng, per, mine, sizes, budget_s, checks):

@@ -88,6 +88,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and os.path.exists("/opt/rocm/bin/hipcc"):
+        try:  # fresh checkout: compile in-tree once (about a minute); never a substitute implementation
+            build()
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
