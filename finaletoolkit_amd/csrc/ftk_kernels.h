@@ -33,6 +33,7 @@ struct WpsParams {
     int min_len, max_len, mapq_min;
     int lmax;  // min(max_len, longest fragment of the contig)
     int nt_store;  // non-temporal score stores (default on)
+    int xcd_remap; // XCD-contiguous block -> tile map (experiment, default off: measured slower)
 };
 
 struct CleaveParams {

@@ -472,6 +472,14 @@ __global__ __launch_bounds__(256) void feat_large_kernel(ContigView cv, const in
 // stream out; the wave scan runs on DPP (no LDS traffic); every lane owns two
 // adjacent bases of each 128-base half so each store instruction writes 1 KB
 // contiguously (measured +18 % over 32-byte-strided stores).
+// Bijective remap of a block id so that the blocks an XCD receives (id % 8 == const) cover one
+// contiguous range of work items (cdna_hip_programming.md T1; placement only affects speed).
+__device__ __forceinline__ long long xcd_contiguous(unsigned orig, unsigned nwg) {
+    const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return (long long)base + orig / 8;
+}
+
 // inclusive scan across the 64 lanes of a wave (row_shr 1/2/4/8 inside rows of
 // 16, then row_bcast:15 / row_bcast:31 across rows)
 __device__ __forceinline__ int wave_incl_scan_dpp(int x) {
@@ -507,7 +515,10 @@ __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParam
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int hl = p.hl, hr = p.hr;
 
-    const long long tfirst = (long long)blockIdx.x * tiles_per_block;
+    // Optional XCD-contiguous block -> tile map (blocks are dealt round-robin to the 8 XCDs; this gives
+    // each XCD one contiguous run of tiles so halos share an L2).  Off by default: measured slower.
+    const long long bid = p.xcd_remap ? xcd_contiguous(blockIdx.x, gridDim.x) : (long long)blockIdx.x;
+    const long long tfirst = bid * tiles_per_block;
     const long long tlast = min(tfirst + (long long)tiles_per_block, n_tiles);
     if (tfirst >= tlast) return;
 
