@@ -35,6 +35,7 @@ class Engine:
         self.ctx = ctx
         self.device = int(device)
         self._ids: dict[str, int] = {}
+        self._next_id = 0
         self._bam: dict[str, bool] = {}
 
     # -- plumbing -------------------------------------------------------------
@@ -82,6 +83,13 @@ class Engine:
         return float(ms.value)
 
     # -- fragments ------------------------------------------------------------
+    def _new_id(self, name: str) -> int:
+        """Contig id of ``name``; fresh ids are never reused (released ids must not alias live contigs)."""
+        if name not in self._ids:
+            self._ids[name] = self._next_id
+            self._next_id += 1
+        return self._ids[name]
+
     def contig_id(self, name: str) -> int:
         if name not in self._ids:
             raise KeyError(name)
@@ -106,7 +114,7 @@ class Engine:
         n = len(start)
         if not (len(end) == n and len(mapq) == n and (strand is None or len(strand) == n)):
             raise ValueError("fragment columns differ in length")
-        cid = self._ids.setdefault(name, len(self._ids))
+        cid = self._new_id(name)
         self._check(self.lib.ftk_frags_from_host(self.ctx, cid, L.ptr(start), L.ptr(end), L.ptr(mapq),
                                                  L.ptr(strand), n))
         self._bam[name] = False
@@ -119,7 +127,7 @@ class Engine:
 
     def load_contig_from_table(self, name: str, table, index: int, is_bam: bool):
         """Upload contig ``index`` of a decoded ``ftk_fragtable`` (page-locked columns -> HBM)."""
-        cid = self._ids.setdefault(name, len(self._ids))
+        cid = self._new_id(name)
         self._check(self.lib.ftk_frags_from_table(self.ctx, cid, table, int(index)))
         # an empty BAM contig carries no read1 columns: plain fetch mode is equivalent
         self._bam[name] = bool(is_bam) and self.lib.ftk_fragtable_contig_rows(table, int(index)) > 0
@@ -127,7 +135,7 @@ class Engine:
 
     def load_contig_device(self, name: str, d_start, d_end, d_mapq, d_strand, n: int):
         """Adopt columns already in HBM (torch tensors or raw device addresses)."""
-        cid = self._ids.setdefault(name, len(self._ids))
+        cid = self._new_id(name)
         self._check(self.lib.ftk_frags_from_device(self.ctx, cid, L.ptr(d_start), L.ptr(d_end), L.ptr(d_mapq),
                                                    L.ptr(d_strand), int(n)))
         self._bam[name] = False

@@ -52,3 +52,57 @@ def read_bed(path):
                 continue
             out.append((p[0], int(p[1]), int(p[2]), p[3] if len(p) > 3 else "."))
     return out
+
+
+def write_synthetic_bam(path, contigs, frags, junk=True, read_len=100):
+    """Write a coordinate-sorted BAM (+ empty .bai stub) holding one read pair per fragment.
+
+    contigs: [(name, length)]; frags: {name: (start[], end[], mapq[], forward[])}.  Forward fragments put
+    read1 at the fragment start (flag 99 / mate 147), reverse ones at its end (flag 83 / mate 163).  With
+    ``junk`` a few records the reference must drop are mixed in (unmapped, secondary, duplicate, qc-fail,
+    supplementary, improper pair, mate unmapped, unpaired, TLEN 0).  Returns the expected per-contig rows
+    ``(start, end, mapq, forward, r1_start, r1_end)`` in the decoder's order (stable sort by fragment start
+    of the read1 records in file order)."""
+    import struct
+    from finaletoolkit_amd import bgzf
+
+    def rec(ref_id, pos, mapq, flag, tlen, name, rl, mate_pos):
+        nm = name.encode() + b"\0"
+        cigar = struct.pack("<I", (rl << 4) | 0) if rl > 0 else b""
+        body = struct.pack("<iiBBHHHiiii", ref_id, pos, len(nm), mapq, 4680, 1 if rl > 0 else 0, flag, rl, ref_id,
+                           mate_pos, tlen) + nm + cigar + b"\x11" * ((rl + 1) // 2) + b"\xff" * rl
+        return struct.pack("<i", len(body)) + body
+
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{c}\tLN:{n}\n" for c, n in contigs)
+    out = [b"BAM\1", struct.pack("<i", len(text)), text.encode(), struct.pack("<i", len(contigs))]
+    for c, n in contigs:
+        out.append(struct.pack("<i", len(c) + 1) + c.encode() + b"\0" + struct.pack("<i", n))
+    expected = {}
+    for ref_id, (c, _) in enumerate(contigs):
+        s, e, q, fw = frags.get(c, ([], [], [], []))
+        records = []  # (pos, order, bytes, read1 fragment or None)
+        k = 0
+        for i in range(len(s)):
+            fs, fe, mq, f = int(s[i]), int(e[i]), int(q[i]), bool(fw[i])
+            ln = fe - fs
+            rl = min(read_len, ln)
+            if f:
+                records.append((fs, k, rec(ref_id, fs, mq, 99, ln, f"f{i}", rl, fe - rl), (fs, fe, mq, 1, fs, fs + rl)))
+                records.append((fe - rl, k + 1, rec(ref_id, fe - rl, mq, 147, -ln, f"f{i}", rl, fs), None))
+            else:
+                records.append((fe - rl, k, rec(ref_id, fe - rl, mq, 83, -ln, f"f{i}", rl, fs), (fs, fe, mq, 0, fe - rl, fe)))
+                records.append((fs, k + 1, rec(ref_id, fs, mq, 163, ln, f"f{i}", rl, fe - rl), None))
+            k += 2
+            if junk and i % 7 == 0:
+                for flag, tl in ((99 | 0x400, ln), (99 | 0x100, ln), (99 | 0x200, ln), (99 | 0x800, ln), (97, ln),
+                                 (99 | 0x8, ln), (0x40, ln), (99, 0), (0x4 | 0x41, 0)):
+                    records.append((fs, k, rec(ref_id, fs, mq, flag, tl, f"j{i}", rl, fs), None))
+                    k += 1
+        records.sort(key=lambda r: (r[0], r[1]))
+        out += [r[2] for r in records]
+        rows = [r[3] for r in records if r[3] is not None]
+        order = sorted(range(len(rows)), key=lambda j: rows[j][0])  # stable, like the decoder
+        expected[c] = [rows[j] for j in order]
+    bgzf.write_bgzf(path, b"".join(out), level=1)
+    open(str(path) + ".bai", "ab").close()
+    return expected

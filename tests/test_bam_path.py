@@ -1,0 +1,67 @@
+"""BAM input: CPU test of the decoder's flag / TLEN / read1 rules on a synthetic BAM, and a
+GPU test of the whole file path in BAM_READ1 fetch mode against the oracle."""
+import numpy as np
+import pytest
+
+from finaletoolkit_amd import synth
+from tests.helpers import write_synthetic_bam
+from tests.test_abi import _decode
+
+CONTIGS = [("chr1", 400_000), ("chrEmpty", 1000), ("chr2", 250_000)]
+
+
+def _make(tmp_path, depth=6.0):
+    frags = {}
+    for i, (c, n) in enumerate(CONTIGS):
+        if c == "chrEmpty":
+            continue
+        s, e, q, st = synth.synth_contig(n, depth=depth, seed=900 + i)
+        frags[c] = (s, e, q, st)
+    path = str(tmp_path / "syn.bam")
+    return path, write_synthetic_bam(path, CONTIGS, frags)
+
+
+def test_bam_decoder_rules(tmp_path):
+    path, expected = _make(tmp_path, depth=3.0)
+    got = _decode(path, bam=True, threads=3)
+    assert got["chrEmpty"][0] == 0 and got["chrEmpty"][2] == 1000
+    for c in ("chr1", "chr2"):
+        rows, cols, length = got[c]
+        want = np.array(expected[c], dtype=np.int64)
+        assert rows == len(want) and length == dict(CONTIGS)[c]
+        for k in range(6):
+            assert np.array_equal(np.asarray(cols[k], dtype=np.int64), want[:, k]), (c, k)
+    only = _decode(path, bam=True, contig="chr2")
+    assert [k for k in only if not k.startswith("__")] == ["chr2"]
+
+
+@pytest.mark.gpu
+def test_bam_file_path_read1_semantics(tmp_path):
+    from finaletoolkit_amd import frag
+    from oracle import oracle as O
+    path, expected = _make(tmp_path)
+    for c, size in (("chr1", 400_000), ("chr2", 250_000)):
+        w = np.array(expected[c], dtype=np.int64)
+        fr = O.Frags(w[:, 0], w[:, 1], w[:, 2], w[:, 3], w[:, 4], w[:, 5])
+        ws, we = synth.tiling_windows(size, 5_000)
+        for policy in ("midpoint", "any"):
+            want = O.c_window_counts(fr, ws, we, mapq_min=30, policy=policy)
+            got = [frag.single_coverage(path, c, int(a), int(b), intersect_policy=policy).coverage
+                   for a, b in zip(ws[:40], we[:40])]
+            assert got == want[:40].tolist(), (c, policy)
+        # whole-contig fetch (no window): every read1 record of the contig
+        assert frag.single_coverage(path, c, 0, None, quality_threshold=0).coverage == len(w)
+        r = frag.wps(path, c, 100_000, 104_000, size)
+        assert np.array_equal(r["wps"], O.c_wps(fr, 100_000, 104_000, size, 120, 120, 180, 30))
+    # the htslib quirk the reference documents (tests/test_delfi.py:135-139): a fragment whose midpoint is
+    # in the window but whose read1 lies outside is NOT counted for BAM input
+    w = np.array(expected["chr1"], dtype=np.int64)
+    mid = (w[:, 0] + w[:, 1]) // 2
+    rev = np.nonzero((w[:, 3] == 0) & (w[:, 2] >= 30) & (w[:, 1] - w[:, 0] > 210))[0]
+    i = int(rev[len(rev) // 2])
+    a, b = int(mid[i]) - 5, int(mid[i]) + 1  # midpoint inside, read1 (at the fragment end) outside
+    assert w[i, 4] >= b
+    tab_like = int(((mid >= a) & (mid < b) & (w[:, 2] >= 30)).sum())
+    got = frag.single_coverage(path, "chr1", a, b).coverage
+    assert got < tab_like
+    assert frag.single_coverage(path, "chrEmpty", 0, None).coverage == 0

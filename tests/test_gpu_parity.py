@@ -221,3 +221,17 @@ def test_many_windows_multiblock_planner(engine, data):
     h, o = engine.fraglen_hist("synA", ws[:20_000], we[:20_000], 100, 200, 30)
     wh, wo = O.c_fraglen_hist(data["fr"], ws[:20_000], we[:20_000], 100, 200, mapq_min=30)
     assert np.array_equal(h, wh) and np.array_equal(o, wo)
+
+
+def test_contig_ids_are_not_reused_after_release(engine):
+    # regression: releasing a contig must not let a later upload alias a live contig's id
+    one = lambda v: (np.array([v], np.int32), np.array([v + 100], np.int32), np.array([60], np.uint8),
+                     np.array([1], np.uint8))
+    for k, v in (("idA", 1000), ("idB", 2000), ("idC", 3000)):
+        engine.load_contig(k, *one(v))
+    engine.release("idA")
+    engine.load_contig("idD", *one(4000))
+    for k, v in (("idB", 2000), ("idC", 3000), ("idD", 4000)):
+        assert engine.frag_select(k, None, None, 0)[0].tolist() == [v]
+    for k in ("idB", "idC", "idD"):
+        engine.release(k)
