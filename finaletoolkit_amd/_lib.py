@@ -47,7 +47,7 @@ EXPORTS = [
     "ftk_frags_from_table",
     "ftk_window_counts", "ftk_delfi_counts", "ftk_fraglen_hist", "ftk_window_features", "ftk_frag_lengths",
     "ftk_frag_select",
-    "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals",
+    "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals", "ftk_wps_adjust",
     "ftk_ref_upload", "ftk_ref_release", "ftk_ref_gc_counts",
 ]
 
@@ -144,6 +144,7 @@ def load() -> C.CDLL:
     lib.ftk_wps_intervals.argtypes = [vp, C.c_int, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]
     lib.ftk_cleavage.argtypes = [vp, C.c_int, i64, i64, i32, i32, i32, vp]
     lib.ftk_cleavage_intervals.argtypes = [vp, C.c_int, vp, vp, i64, vp, i32, i32, i32, vp]
+    lib.ftk_wps_adjust.argtypes = [vp, vp, vp, i64, i32, C.c_int, vp, i32, vp, vp, vp]
     lib.ftk_ref_upload.argtypes = [vp, C.c_int, vp, i64, C.c_int]
     lib.ftk_ref_release.argtypes = [vp, C.c_int]
     lib.ftk_ref_gc_counts.argtypes = [vp, C.c_int, vp, vp, i64, vp]

@@ -206,74 +206,147 @@ def write_fixed_step_bigwig(output_file, header, interval_scores) -> None:
 
 
 # ---------------------------------------------------------------------------
-# minimal reader
+# reader
 # ---------------------------------------------------------------------------
+_BEDGRAPH_DT = np.dtype([("s", "<u4"), ("e", "<u4"), ("v", "<f4")])
+_VARSTEP_DT = np.dtype([("s", "<u4"), ("v", "<f4")])
+
+
+class BigWigFile:
+    """Read side of pyBigWig as the reference uses it (frag/_adjust_wps.py:79-101): ``chroms()`` and
+    ``intervals(contig, start, stop)``; data sections (bedGraph, varStep, fixedStep) are decoded with
+    numpy, the most recently used ones are kept."""
+
+    def __init__(self, path):
+        self.path = str(path)
+        b = self._b = open(path, "rb").read()
+        if len(b) < 64:
+            raise ValueError(f"{path} is not a bigWig file")
+        magic, ver, nzoom, ct_off, data_off, idx_off, _, _, _, ts_off, ubuf, _ = struct.unpack_from("<IHHQQQHHQQIQ", b, 0)
+        if magic != _BW_MAGIC:
+            raise ValueError(f"{path} is not a little-endian bigWig file")
+        self._compressed = bool(ubuf)
+        tmagic, bsize, key, val, count, _ = struct.unpack_from("<IIIIQQ", b, ct_off)
+        if tmagic != _CHROM_TREE_MAGIC:
+            raise ValueError("bad chromosome tree")
+        self._chroms = {}
+
+        def walk_ct(off):
+            leaf, _, n = struct.unpack_from("<BBH", b, off)
+            off += 4
+            for _ in range(n):
+                k = b[off:off + key].rstrip(b"\0").decode()
+                if leaf:
+                    cid, size = struct.unpack_from("<II", b, off + key)
+                    self._chroms[k] = (cid, size)
+                else:
+                    (child,) = struct.unpack_from("<Q", b, off + key)
+                    walk_ct(child)
+                off += key + 8
+
+        if count:
+            walk_ct(ct_off + 32)
+        self._names = {cid: name for name, (cid, _) in self._chroms.items()}
+        if struct.unpack_from("<I", b, idx_off)[0] != _RTREE_MAGIC:
+            raise ValueError("bad R-tree index")
+        leaves = []
+
+        def walk_rt(off):
+            leaf, _, n = struct.unpack_from("<BBH", b, off)
+            off += 4
+            for _ in range(n):
+                if leaf:
+                    leaves.append(struct.unpack_from("<IIIIQQ", b, off))
+                    off += 32
+                else:
+                    (child,) = struct.unpack_from("<Q", b, off + 16)
+                    walk_rt(child)
+                    off += 24
+
+        (n_blocks,) = struct.unpack_from("<Q", b, idx_off + 8)
+        if n_blocks:
+            walk_rt(idx_off + 48)
+        self._leaves = np.array(leaves, dtype=np.int64).reshape(-1, 6)
+        self._cache = {}
+
+    def close(self):
+        self._cache.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def chroms(self):
+        return {k: size for k, (_, size) in self._chroms.items()}
+
+    def _section(self, k):
+        sec = self._cache.get(k)
+        if sec is None:
+            doff, dsize = int(self._leaves[k, 4]), int(self._leaves[k, 5])
+            raw = self._b[doff:doff + dsize]
+            if self._compressed:
+                raw = zlib.decompress(raw)
+            cid, s0, e0, step, span, typ, _, n = struct.unpack_from("<IIIIIBBH", raw, 0)
+            if typ == 1:
+                rec = np.frombuffer(raw, _BEDGRAPH_DT, n, 24)
+                st, en, v = rec["s"].astype(np.int64), rec["e"].astype(np.int64), rec["v"]
+            elif typ == 2:
+                rec = np.frombuffer(raw, _VARSTEP_DT, n, 24)
+                st, v = rec["s"].astype(np.int64), rec["v"]
+                en = st + span
+            else:
+                v = np.frombuffer(raw, "<f4", n, 24)
+                st = s0 + np.arange(n, dtype=np.int64) * step
+                en = st + span
+            sec = (cid, st, en, v.astype(np.float64))
+            if len(self._cache) >= 64:
+                self._cache.pop(next(iter(self._cache)))
+            self._cache[k] = sec
+        return sec
+
+    def sections(self):
+        """All data sections in index order: ``(contig, starts, ends, values)``."""
+        for k in range(len(self._leaves)):
+            cid, st, en, v = self._section(k)
+            yield self._names[cid], st, en, v
+
+    def intervals(self, contig, start=0, stop=0):
+        """Entries overlapping ``[start, stop)`` as ``(starts, ends, values)`` arrays, or ``None`` when
+        there are none; RuntimeError for an unknown contig or bounds outside it (as pyBigWig)."""
+        if contig not in self._chroms:
+            raise RuntimeError("Invalid interval bounds!")
+        cid, size = self._chroms[contig]
+        if start == 0 and stop == 0:
+            stop = size
+        if start < 0 or stop > size or start >= stop:
+            raise RuntimeError("Invalid interval bounds!")
+        lv = self._leaves
+        if len(lv) == 0:
+            return None
+        after_start = (lv[:, 2] > cid) | ((lv[:, 2] == cid) & (lv[:, 3] > start))
+        before_stop = (lv[:, 0] < cid) | ((lv[:, 0] == cid) & (lv[:, 1] < stop))
+        parts = []
+        for k in np.flatnonzero(after_start & before_stop):
+            scid, st, en, v = self._section(int(k))
+            if scid != cid:
+                continue
+            keep = (en > start) & (st < stop)
+            if keep.any():
+                parts.append((st[keep], en[keep], v[keep]))
+        if not parts:
+            return None
+        return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
+
+
 def read_bigwig(path):
     """Return ``(chroms, intervals)``: ``chroms`` = {name: (id, size)};
-    ``intervals`` = list of ``(chrom_name, start, end, value)`` runs decoded from
-    every data section (bedGraph, varStep and fixedStep), in file order."""
-    b = open(path, "rb").read()
-    magic, ver, nzoom, ct_off, data_off, idx_off, _, _, _, ts_off, ubuf, _ = struct.unpack_from("<IHHQQQHHQQIQ", b, 0)
-    if magic != _BW_MAGIC:
-        raise ValueError(f"{path} is not a little-endian bigWig file")
-    tmagic, bsize, key, val, count, _ = struct.unpack_from("<IIIIQQ", b, ct_off)
-    if tmagic != _CHROM_TREE_MAGIC:
-        raise ValueError("bad chromosome tree")
-    chroms = {}
-
-    def walk_ct(off):
-        leaf, _, n = struct.unpack_from("<BBH", b, off)
-        off += 4
-        for _ in range(n):
-            k = b[off:off + key].rstrip(b"\0").decode()
-            if leaf:
-                cid, size = struct.unpack_from("<II", b, off + key)
-                chroms[k] = (cid, size)
-            else:
-                (child,) = struct.unpack_from("<Q", b, off + key)
-                walk_ct(child)
-            off += key + 8
-
-    walk_ct(ct_off + 32)
-    names = {cid: name for name, (cid, _) in chroms.items()}
-    rmagic = struct.unpack_from("<I", b, idx_off)[0]
-    if rmagic != _RTREE_MAGIC:
-        raise ValueError("bad R-tree index")
-    blocks = []
-
-    def walk_rt(off):
-        leaf, _, n = struct.unpack_from("<BBH", b, off)
-        off += 4
-        for _ in range(n):
-            if leaf:
-                _, _, _, _, doff, dsize = struct.unpack_from("<IIIIQQ", b, off)
-                blocks.append((doff, dsize))
-                off += 32
-            else:
-                (child,) = struct.unpack_from("<Q", b, off + 16)
-                walk_rt(child)
-                off += 24
-
-    walk_rt(idx_off + 48)
+    ``intervals`` = list of ``(chrom_name, start, end, value)`` decoded from
+    every data section, in file order."""
+    bw = BigWigFile(path)
     out = []
-    for doff, dsize in blocks:
-        raw = b[doff:doff + dsize]
-        if ubuf:
-            raw = zlib.decompress(raw)
-        cid, s0, e0, step, span, typ, _, n = struct.unpack_from("<IIIIIBBH", raw, 0)
-        p = 24
-        for i in range(n):
-            if typ == 1:
-                s, e, v = struct.unpack_from("<IIf", raw, p)
-                p += 12
-            elif typ == 2:
-                s, v = struct.unpack_from("<If", raw, p)
-                e = s + span
-                p += 8
-            else:
-                (v,) = struct.unpack_from("<f", raw, p)
-                s = s0 + i * step
-                e = s + span
-                p += 4
-            out.append((names[cid], s, e, v))
-    return chroms, out
+    for name, st, en, v in bw.sections():
+        f32 = v.astype(np.float32)
+        out.extend((name, int(a), int(b), float(c)) for a, b, c in zip(st, en, f32))
+    return dict(bw._chroms), out

@@ -62,6 +62,23 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("-W", "--window-size", dest="window_size", type=int, default=120)
     _shared(p, min_default=120, max_default=180, policy=False)
 
+    p = sub.add_parser("adjust-wps", help="median/mean + Savitzky-Golay adjustment of a raw WPS bigWig")
+    p.add_argument("input_file", metavar="INPUT")
+    p.add_argument("interval_file", metavar="REGIONS")
+    p.add_argument("chrom_sizes", metavar="CHROM_SIZES")
+    p.add_argument("-o", "--output", dest="output_file", required=True, metavar="FILE")
+    p.add_argument("-i", "--interval-size", dest="interval_size", type=int, default=5000)
+    p.add_argument("-m", "--median-window-size", dest="median_window_size", type=int, default=1000)
+    p.add_argument("--savgol-window-size", dest="savgol_window_size", type=int, default=21)
+    p.add_argument("--savgol-poly-deg", dest="savgol_poly_deg", type=int, default=2)
+    p.add_argument("--savgol", dest="savgol", action="store_true", default=True)
+    p.add_argument("--no-savgol", dest="savgol", action="store_false")
+    p.add_argument("--mean", dest="mean", action="store_true")
+    p.add_argument("--subtract-edges", dest="subtract_edges", action="store_true")
+    p.add_argument("--edge-size", dest="edge_size", type=int, default=500)
+    p.add_argument("-t", "--threads", dest="workers", type=int, default=1, metavar="N")
+    p.add_argument("-v", "--verbose", action="count", default=0)
+
     p = sub.add_parser("cleavage-profile", help="cleavage proportion over BED intervals")
     p.add_argument("input_file", metavar="INPUT")
     p.add_argument("interval_file", metavar="REGIONS")
@@ -115,6 +132,12 @@ def main(argv=None) -> int:
                        window_size=a.window_size, interval_size=a.interval_size, min_length=a.min_length,
                        max_length=a.max_length, quality_threshold=a.quality_threshold, workers=a.workers,
                        verbose=a.verbose, reference_file=a.reference_file)
+    elif a.command == "adjust-wps":
+        frag.adjust_wps(a.input_file, a.interval_file, a.output_file, a.chrom_sizes, interval_size=a.interval_size,
+                        median_window_size=a.median_window_size, savgol_window_size=a.savgol_window_size,
+                        savgol_poly_deg=a.savgol_poly_deg, savgol=a.savgol, mean=a.mean,
+                        subtract_edges=a.subtract_edges, edge_size=a.edge_size, workers=a.workers,
+                        verbose=a.verbose)
     elif a.command == "cleavage-profile":
         frag.multi_cleavage_profile(a.input_file, a.interval_file, a.chrom_sizes, left=a.left, right=a.right,
                                     min_length=a.min_length, max_length=a.max_length,

@@ -1,0 +1,172 @@
+// WPS post-processing kernels: running median / mean subtraction and the
+// Savitzky-Golay pass (reference: frag/_adjust_wps.py:25-50, 119-140).
+//
+// Running median of a W-wide window, one tile of outputs per block:
+//   1. the tile's n_out + W - 1 inputs are turned into order-preserving 64-bit
+//      keys and bitonic-sorted in LDS together with their positions;
+//   2. every input is replaced by its rank in the tile (a permutation, so ties
+//      need no special care);
+//   3. each output walks its window once per rank bit (radix descent) to find
+//      the rank of the (W/2-1)-th smallest element, then once more for the next
+//      larger one; the two values come from the sorted key array.
+// LDS reads in step 3 are rank[o + j] with o = lane: conflict-free.
+#include "ftk_kernels.h"
+
+namespace ftk {
+
+namespace {
+
+constexpr int kAdjThreads = 256;
+
+__device__ __forceinline__ unsigned long long f64_key(double v) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double key_f64(unsigned long long k) {
+    unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// median_window W (even), n_sort = power of two >= n_out + W - 1
+__global__ __launch_bounds__(kAdjThreads) void adjust_median_kernel(const double* __restrict__ scores,
+                                                                     const AdjustTile* __restrict__ tiles,
+                                                                     const double* __restrict__ edge_sub, int W,
+                                                                     int n_sort, int rank_bits,
+                                                                     double* __restrict__ out) {
+    extern __shared__ unsigned long long lds_keys[];                  // [n_sort]
+    unsigned short* pos = (unsigned short*)(lds_keys + n_sort);       // [n_sort] position of sorted slot
+    unsigned short* rank = pos + n_sort;                              // [n_sort] rank of each input position
+    const AdjustTile t = tiles[blockIdx.x];
+    const double sub = edge_sub ? edge_sub[t.interval] : 0.0;
+    const double* in = scores + t.in_base;
+    const int n_in = t.n_out + W - 1;
+    for (int i = threadIdx.x; i < n_sort; i += kAdjThreads) {
+        lds_keys[i] = i < n_in ? f64_key(in[i] - sub) : ~0ULL;
+        pos[i] = (unsigned short)i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n_sort; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n_sort / 2; i += kAdjThreads) {
+                const int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const int b = a | j;
+                const bool up = (a & k) == 0;
+                const unsigned long long ka = lds_keys[a], kb = lds_keys[b];
+                if ((ka > kb) == up) {
+                    lds_keys[a] = kb;
+                    lds_keys[b] = ka;
+                    const unsigned short pa = pos[a];
+                    pos[a] = pos[b];
+                    pos[b] = pa;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n_sort; i += kAdjThreads) rank[pos[i]] = (unsigned short)i;
+    __syncthreads();
+    const int kth = W / 2 - 1;
+    for (int o = threadIdx.x; o < t.n_out; o += kAdjThreads) {
+        const unsigned short* w = rank + o;
+        int r = 0;
+        for (int bit = rank_bits - 1; bit >= 0; --bit) {
+            const int cand = r | (1 << bit);
+            int below = 0;
+#pragma unroll 8
+            for (int j = 0; j < W; ++j) below += (int)w[j] < cand;
+            if (below <= kth) r = cand;
+        }
+        int r2 = n_sort;
+#pragma unroll 8
+        for (int j = 0; j < W; ++j) {
+            const int v = w[j];
+            r2 = (v > r && v < r2) ? v : r2;
+        }
+        const double med = (key_f64(lds_keys[r]) + key_f64(lds_keys[r2])) * 0.5;
+        out[t.out_base + o] = (in[o + W / 2] - sub) - med;
+    }
+}
+
+__global__ __launch_bounds__(kAdjThreads) void adjust_mean_kernel(const double* __restrict__ scores,
+                                                                   const AdjustTile* __restrict__ tiles,
+                                                                   const double* __restrict__ edge_sub, int W,
+                                                                   double* __restrict__ out) {
+    extern __shared__ unsigned long long lds_keys[];
+    double* x = (double*)lds_keys;
+    const AdjustTile t = tiles[blockIdx.x];
+    const double sub = edge_sub ? edge_sub[t.interval] : 0.0;
+    const double* in = scores + t.in_base;
+    const int n_in = t.n_out + W - 1;
+    for (int i = threadIdx.x; i < n_in; i += kAdjThreads) x[i] = in[i] - sub;
+    __syncthreads();
+    for (int o = threadIdx.x; o < t.n_out; o += kAdjThreads) {
+        double s = 0.0;
+        for (int j = 0; j < W; ++j) s += x[o + j];
+        out[t.out_base + o] = x[o + W / 2] - s / (double)W;
+    }
+}
+
+// One thread per output.  Interior points follow scipy.ndimage's symmetric
+// correlate1d order (centre tap first, then outermost pair inwards) with no
+// fused multiply-add, so they reproduce savgol_filter bit for bit; the first
+// and last `half` points apply the polynomial edge fit as a half x window matrix.
+__global__ __launch_bounds__(kAdjThreads) void savgol_kernel(const double* __restrict__ adj,
+                                                              const AdjustTile* __restrict__ tiles,
+                                                              const double* __restrict__ coef,
+                                                              const double* __restrict__ edge, int sw,
+                                                              double* __restrict__ out) {
+    const AdjustTile t = tiles[blockIdx.x];
+    const int half = sw / 2;
+    const double* x = adj + (t.out_base - t.o0);  // interval's first adjusted value
+    for (int i = threadIdx.x; i < t.n_out; i += kAdjThreads) {
+        const int o = t.o0 + i;
+        double acc;
+        if (o < half) {
+            const double* e = edge + (size_t)o * sw;
+            acc = 0.0;
+            for (int j = 0; j < sw; ++j) acc = __dadd_rn(acc, __dmul_rn(e[j], x[j]));
+        } else if (o >= t.m - half) {
+            const double* e = edge + (size_t)(half + o - (t.m - half)) * sw;
+            const double* xr = x + (t.m - sw);
+            acc = 0.0;
+            for (int j = 0; j < sw; ++j) acc = __dadd_rn(acc, __dmul_rn(e[j], xr[j]));
+        } else {
+            acc = __dmul_rn(x[o], coef[half]);
+            for (int jj = -half; jj < 0; ++jj)
+                acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(x[o + jj], x[o - jj]), coef[half + jj]));
+        }
+        out[t.out_base + i] = acc;
+    }
+}
+
+}  // namespace
+
+int adjust_sort_size(int W, int* tile_out) {
+    int n = 1;
+    while (n < 2 * W) n <<= 1;
+    n = n < 256 ? 256 : n;
+    if (tile_out) *tile_out = n - W + 1;
+    return n;
+}
+
+void launch_adjust_filter(hipStream_t s, const double* scores, const AdjustTile* tiles, int n_tiles,
+                          const double* edge_sub, int W, int use_mean, double* out) {
+    int tile;
+    const int n_sort = adjust_sort_size(W, &tile);
+    if (use_mean) {
+        const size_t lds = (size_t)(tile + W - 1) * 8;
+        adjust_mean_kernel<<<n_tiles, kAdjThreads, lds, s>>>(scores, tiles, edge_sub, W, out);
+    } else {
+        int bits = 0;
+        while ((1 << bits) < n_sort) ++bits;
+        const size_t lds = (size_t)n_sort * (8 + 2 + 2);
+        adjust_median_kernel<<<n_tiles, kAdjThreads, lds, s>>>(scores, tiles, edge_sub, W, n_sort, bits, out);
+    }
+}
+
+void launch_savgol(hipStream_t s, const double* adj, const AdjustTile* tiles, int n_tiles, const double* coef,
+                   const double* edge, int sw, double* out) {
+    savgol_kernel<<<n_tiles, kAdjThreads, 0, s>>>(adj, tiles, coef, edge, sw, out);
+}
+
+}  // namespace ftk

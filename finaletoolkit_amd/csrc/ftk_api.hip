@@ -927,6 +927,88 @@ int ftk_cleavage(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int32
     return ftk_cleavage_intervals(ctx, contig_id, &start, &stop, 1, &off, min_len, max_len, mapq_min, prop_out);
 }
 
+int ftk_wps_adjust(ftk_ctx* ctx, const double* scores, const int64_t* offsets, int64_t n_iv, int32_t median_window,
+                   int use_mean, const double* edge_sub, int32_t savgol_window, const double* savgol_coef,
+                   const double* savgol_edge, double* out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    if (n_iv < 0 || n_iv > INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "n_iv out of range");
+    if (n_iv == 0) return FTK_OK;
+    if (!scores || !offsets || !out) return fail(ctx, FTK_ERR_INVALID, "NULL argument");
+    if (is_device_ptr(offsets) || is_device_ptr(edge_sub) || is_device_ptr(savgol_coef) ||
+        is_device_ptr(savgol_edge))
+        return fail(ctx, FTK_ERR_INVALID, "offsets / edge_sub / savgol arrays must be host arrays");
+    const int W = median_window;
+    if (W < 2 || (W & 1) || W > kAdjustMaxWindow)
+        return fail(ctx, FTK_ERR_INVALID, "median_window must be even and in [2, %d]", kAdjustMaxWindow);
+    const int sw = savgol_window;
+    if (sw < 0 || (sw > 0 && (!(sw & 1) || !savgol_coef || !savgol_edge)))
+        return fail(ctx, FTK_ERR_INVALID, "savgol_window must be odd and come with coef/edge arrays");
+    int tile;
+    adjust_sort_size(W, &tile);
+    std::vector<AdjustTile> tiles;
+    for (int64_t i = 0; i < n_iv; ++i) {
+        const int64_t len = offsets[i + 1] - offsets[i];
+        if (offsets[i] < 0 || len < W)
+            return fail(ctx, FTK_ERR_INVALID, "run %lld is shorter than median_window (%lld < %d)", (long long)i,
+                        (long long)len, W);
+        const int64_t m = len - W;
+        if (m > INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "run %lld too long", (long long)i);
+        if (sw > 0 && m < sw)
+            return fail(ctx, FTK_ERR_INVALID, "run %lld: savgol_window (%d) exceeds the filtered length (%lld)",
+                        (long long)i, sw, (long long)m);
+        const int64_t out_i = offsets[i] - i * (int64_t)W;
+        for (int64_t o0 = 0; o0 < m; o0 += tile) {
+            AdjustTile t;
+            t.in_base = offsets[i] + o0;
+            t.out_base = out_i + o0;
+            t.n_out = (int32_t)std::min<int64_t>(tile, m - o0);
+            t.o0 = (int32_t)o0;
+            t.m = (int32_t)m;
+            t.interval = (int32_t)i;
+            tiles.push_back(t);
+        }
+    }
+    const int64_t total_in = offsets[n_iv], total_out = total_in - n_iv * (int64_t)W;
+    if (tiles.empty()) return FTK_OK;
+    if (tiles.size() > (size_t)INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "too many tiles in one call");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool in_dev = is_device_ptr(scores), out_dev = is_device_ptr(out);
+    const int half = sw / 2;
+    size_t need = align_up(tiles.size() * sizeof(AdjustTile)) + align_up(n_iv * 8) + align_up((size_t)sw * 8) +
+                  align_up((size_t)2 * half * sw * 8) + (in_dev ? 0 : align_up(total_in * 8)) +
+                  (out_dev ? 0 : align_up(total_out * 8)) + (sw ? align_up(total_out * 8) : 0);
+    int rc = reserve_scratch(ctx, need);
+    if (rc) return rc;
+    Arena a(ctx);
+    AdjustTile* d_tiles = a.take<AdjustTile>(tiles.size());
+    double* d_sub = edge_sub ? a.take<double>(n_iv) : nullptr;
+    double* d_coef = sw ? a.take<double>(sw) : nullptr;
+    double* d_edge = sw ? a.take<double>((size_t)2 * half * sw) : nullptr;
+    const double* d_in = scores;
+    if (!in_dev) {
+        double* b = a.take<double>(total_in);
+        HIPCHK(ctx, hipMemcpyAsync(b, scores, total_in * 8, hipMemcpyHostToDevice, ctx->stream));
+        d_in = b;
+    }
+    double* d_out = out_dev ? out : a.take<double>(total_out);
+    double* d_adj = sw ? a.take<double>(total_out) : d_out;
+    HIPCHK(ctx, hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(AdjustTile), hipMemcpyHostToDevice,
+                               ctx->stream));
+    if (d_sub) HIPCHK(ctx, hipMemcpyAsync(d_sub, edge_sub, n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (sw) {
+        HIPCHK(ctx, hipMemcpyAsync(d_coef, savgol_coef, (size_t)sw * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (half)
+            HIPCHK(ctx, hipMemcpyAsync(d_edge, savgol_edge, (size_t)2 * half * sw * 8, hipMemcpyHostToDevice,
+                                       ctx->stream));
+    }
+    launch_adjust_filter(ctx->stream, d_in, d_tiles, (int)tiles.size(), d_sub, W, use_mean, d_adj);
+    if (sw) launch_savgol(ctx->stream, d_adj, d_tiles, (int)tiles.size(), d_coef, d_edge, sw, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    if (!out_dev) HIPCHK(ctx, hipMemcpyAsync(out, d_out, total_out * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // tiles / coefficient arrays are pageable staging
+    return FTK_OK;
+}
+
 int ftk_ref_upload(ftk_ctx* ctx, int ref_id, const uint8_t* image, int64_t n_bytes, int kind) {
     if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
     if (n_bytes < 0 || (n_bytes > 0 && !image) || (kind != FTK_REF_FASTA_TEXT && kind != FTK_REF_2BIT))

@@ -71,6 +71,22 @@ void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t
 void launch_cleavage(hipStream_t s, const ContigView& cv, const CleaveParams& p, int64_t n_tiles,
                      const int64_t* iv_start, const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv,
                      const int32_t* tile_k, double* out);
+// One block's share of an adjust_wps run: n_out outputs starting at output o0 of
+// a run with m outputs; inputs start at scores[in_base], results at out[out_base].
+struct AdjustTile {
+    int64_t in_base;
+    int64_t out_base;
+    int32_t n_out;
+    int32_t o0;
+    int32_t m;
+    int32_t interval;
+};
+constexpr int kAdjustMaxWindow = 2048;
+int adjust_sort_size(int W, int* tile_out);
+void launch_adjust_filter(hipStream_t s, const double* scores, const AdjustTile* tiles, int n_tiles,
+                          const double* edge_sub, int W, int use_mean, double* out);
+void launch_savgol(hipStream_t s, const double* adj, const AdjustTile* tiles, int n_tiles, const double* coef,
+                   const double* edge, int sw, double* out);
 void launch_gc_count(hipStream_t s, const uint8_t* img, int64_t img_bytes, int kind, const int64_t* lo,
                      const int64_t* hi, int n, int64_t* out);
 void launch_select_count(hipStream_t s, const ContigView& cv, int lo, int hi, int ws, int we, const ftk_filter& f,

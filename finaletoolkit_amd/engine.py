@@ -25,6 +25,32 @@ def _win(values, open_value):
     return np.ascontiguousarray([open_value if v is None else int(v) for v in values], dtype=np.int32)
 
 
+_SAVGOL = {}
+
+
+def savgol_operators(window: int, deg: int):
+    """Savitzky-Golay taps and the edge-fit matrices of ``scipy.signal.savgol_filter(mode="interp")``:
+    ``coef`` [window] (interior correlation taps) and ``edge`` [2*half, window] whose first ``half`` rows
+    map the first ``window`` samples to the first ``half`` outputs and whose last ``half`` rows map the last
+    ``window`` samples to the last ``half`` outputs (polyfit + polyval is linear in the samples)."""
+    key = (int(window), int(deg))
+    if key not in _SAVGOL:
+        from scipy.signal import savgol_coeffs
+        if window % 2 == 0:
+            raise ValueError("savgol_window_size must be odd")
+        coef = np.ascontiguousarray(savgol_coeffs(window, deg), dtype=np.float64)
+        half = window // 2
+        x = np.arange(window)
+        eye = np.eye(window)
+        edge = np.zeros((2 * half, window))
+        for j in range(window):
+            p = np.polyfit(x, eye[j], deg)
+            edge[:half, j] = np.polyval(p, np.arange(0, half))
+            edge[half:, j] = np.polyval(p, np.arange(window - half, window))
+        _SAVGOL[key] = (coef, np.ascontiguousarray(edge))
+    return _SAVGOL[key]
+
+
 class Engine:
     def __init__(self, device: int = 0):
         self.lib = L.load()
@@ -308,6 +334,46 @@ class Engine:
 
     def cleavage(self, name: str, start: int, stop: int, min_length=None, max_length=None, quality_threshold=30):
         return self.cleavage_intervals(name, [start], [stop], min_length, max_length, quality_threshold)[0]
+
+    # -- WPS post-processing --------------------------------------------------------
+    def wps_adjust(self, scores, offsets, median_window_size=1000, mean=False, edge_sub=None, savgol_window_size=21,
+                   savgol_poly_deg=2, savgol=True, out=None):
+        """Running median/mean subtraction + Savitzky-Golay pass over score runs laid end to end
+        (frag/_adjust_wps.py:25-50,119-140).  ``scores`` is a host float64 array or a device pointer
+        (int) to one; run ``i`` is ``scores[offsets[i]:offsets[i+1]]`` and yields ``len_i - W`` values at
+        ``offsets[i] - i*W`` of the result.  Raises ValueError where the reference does (window longer
+        than a run, odd median window, Savitzky-Golay window longer than the filtered run)."""
+        W = int(median_window_size)
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        n_iv = len(offs) - 1
+        lens = np.diff(offs)
+        if W % 2 or W < 2:
+            # data[W//2:-(W//2)] and the n-W running values only line up for even W (numpy broadcast error)
+            raise ValueError(f"median_window_size ({W}) must be even: operands could not be broadcast together")
+        if n_iv and W > int(lens.min()):
+            raise ValueError(f"median_window_size ({W}) cannot be greater than the length of interval "
+                             f"({int(lens.min())}).")
+        sw = int(savgol_window_size) if savgol else 0
+        coef = edge = None
+        if sw:
+            if n_iv and sw > int(lens.min()) - W:
+                raise ValueError("If mode is 'interp', window_length must be less than or equal to the size of x.")
+            coef, edge = savgol_operators(sw, int(savgol_poly_deg))
+        total_out = int(offs[-1]) - n_iv * W if n_iv else 0
+        if isinstance(scores, (int, np.integer)):
+            sp = C.c_void_p(int(scores))
+        else:
+            scores = np.ascontiguousarray(scores, dtype=np.float64)
+            sp = L.ptr(scores)
+        res = np.empty(total_out, np.float64) if out is None else out
+        op = C.c_void_p(int(res)) if isinstance(res, (int, np.integer)) else L.ptr(res)
+        sub = None if edge_sub is None else np.ascontiguousarray(edge_sub, dtype=np.float64)
+        if n_iv and total_out >= 0:
+            self._check(self.lib.ftk_wps_adjust(self.ctx, sp, L.ptr(offs), n_iv, W, int(bool(mean)),
+                                                None if sub is None else L.ptr(sub), sw,
+                                                None if coef is None else L.ptr(coef),
+                                                None if edge is None else L.ptr(edge), op))
+        return res
 
     # -- reference images (DELFI GC on the device) ----------------------------------
     def ref_upload(self, key, image: np.ndarray, kind: int) -> int:

@@ -2,6 +2,7 @@
 ``finaletoolkit.frag`` surface of the hot path, MI355X-backed (names, arguments
 and results as in the reference's ``frag/__init__.py:7-34``).
 """
+from ._adjust_wps import adjust_wps
 from ._cleavage_profile import cleavage_profile, multi_cleavage_profile
 from ._coverage import CoverageResult, coverage, single_coverage
 from ._delfi import delfi
@@ -13,4 +14,4 @@ from ._wps import wps
 
 __all__ = ["frag_length", "frag_length_bins", "frag_length_intervals", "FragLengthStats", "coverage",
            "single_coverage", "CoverageResult", "wps", "multi_wps", "delfi", "delfi_gc_correct", "delfi_merge_bins",
-           "cleavage_profile", "multi_cleavage_profile"]
+           "cleavage_profile", "multi_cleavage_profile", "adjust_wps"]

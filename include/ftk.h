@@ -235,6 +235,24 @@ int ftk_cleavage_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start,
                            const int64_t* out_offset, int32_t min_len, int32_t max_len, int32_t mapq_min,
                            double* prop_out);
 
+/* ---- next row: WPS post-processing (adjust_wps) ---------------------
+ * frag/_adjust_wps.py:25-50,119-140 for n_iv score runs laid end to end in `scores`
+ * (run i = scores[offsets[i] .. offsets[i+1]), offsets is a host array of n_iv + 1):
+ *   x      = scores - edge_sub[i]                      (edge_sub NULL = no subtraction; host array)
+ *   adj[o] = x[o + W/2] - stat(x[o .. o+W))            o in [0, len_i - W), stat = median, or mean
+ *                                                      when use_mean; W = median_window, even, 2..2048
+ *   out    = adj, or savgol_filter(adj, savgol_window, mode="interp") when savgol_window > 0:
+ *            interior o: sum_j coef[j] * adj[o - h + j]            (h = savgol_window / 2, window odd)
+ *            first h   : sum_j edge[o][j]     * adj[j]             (polynomial edge fit as a matrix)
+ *            last h    : sum_j edge[h + k][j] * adj[m - window + j], o = m - h + k
+ *            coef [savgol_window] and edge [2*h][savgol_window] are host arrays prepared by the caller.
+ * Run i writes len_i - W values at out + offsets[i] - i*W.  Every run needs len_i >= W and, with the
+ * Savitzky-Golay pass, len_i - W >= savgol_window (the reference raises ValueError in both cases).
+ * The median is exact (selection, no arithmetic besides the final (a+b)/2). */
+int ftk_wps_adjust(ftk_ctx* ctx, const double* scores, const int64_t* offsets, int64_t n_iv, int32_t median_window,
+                   int use_mean, const double* edge_sub, int32_t savgol_window, const double* savgol_coef,
+                   const double* savgol_edge, double* out);
+
 /* ---- next row: DELFI per-bin GC count on the device ------------------
  * frag/_delfi.py:476-490 counts G + C of the upper-cased window sequence
  * (io/reference.py:120-189) once per bin on the host.  Here a contig's reference image

@@ -321,3 +321,33 @@ def py_wps(rows, start, stop, chrom_size, window_size=120, min_length=120, max_l
         stop_in = (fe >= w0[i]) * (fe <= w1[i])
         out[i] = spanning - np.sum(np.logical_or(start_in, stop_in))
     return out
+
+
+# ---------------------------------------------------------------------------
+# adjust_wps (frag/_adjust_wps.py:25-50,119-140), one run of consecutive scores
+# ---------------------------------------------------------------------------
+def py_adjust_run(scores, window_size=1000, use_mean=False, edge_size=None, savgol_window=21, savgol_deg=2,
+                  savgol=True):
+    """``edge_size`` not None = subtract_edges.  The running statistic is stated with an explicit sort
+    of every window (middle pair averaged) instead of np.median; the Savitzky-Golay pass is scipy's,
+    as in the reference."""
+    x = np.asarray(scores, np.float64)
+    if edge_size is not None:
+        x = x - np.mean([np.mean(x[:edge_size]), np.mean(x[-edge_size:])])
+    if window_size > len(x):
+        raise ValueError("median_window_size cannot be greater than the length of interval")
+    n = len(x) - window_size
+    h = window_size // 2
+    running = np.empty(max(n, 0), np.float64)
+    for i in range(n):
+        w = x[i:i + window_size]
+        if use_mean:
+            running[i] = np.mean(w)
+        else:
+            s = np.sort(w)
+            running[i] = (s[h - 1] + s[h]) / 2.0 if window_size % 2 == 0 else s[h]
+    adj = x[h:len(x) - h] - running
+    if savgol:
+        from scipy.signal import savgol_filter
+        adj = savgol_filter(adj, savgol_window, savgol_deg)
+    return adj
