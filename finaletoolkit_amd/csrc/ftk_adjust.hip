@@ -4,12 +4,13 @@
 // Running median of a W-wide window, one tile of outputs per block:
 //   1. the tile's n_out + W - 1 inputs are turned into order-preserving 64-bit
 //      keys and bitonic-sorted in LDS together with their positions;
-//   2. every input is replaced by its rank in the tile (a permutation, so ties
-//      need no special care);
-//   3. each output walks its window once per rank bit (radix descent) to find
-//      the rank of the (W/2-1)-th smallest element, then once more for the next
-//      larger one; the two values come from the sorted key array.
-// LDS reads in step 3 are rank[o + j] with o = lane: conflict-free.
+//   2. each output walks the sorted slots in ascending order and counts the
+//      slots whose position falls inside its window [o, o + W); the slot at
+//      which the count reaches W/2 is the lower middle element, the next member
+//      the upper one (ties need no special care: slots are distinct).
+// All lanes of a wave read the same slots in step 2 (LDS broadcast reads), and a
+// wave stops as soon as all of its outputs are resolved: about n_in / 2 slots
+// per output instead of W reads per bit of a radix descent.
 #include "ftk_kernels.h"
 
 namespace ftk {
@@ -31,18 +32,16 @@ __device__ __forceinline__ double key_f64(unsigned long long k) {
 __global__ __launch_bounds__(kAdjThreads) void adjust_median_kernel(const double* __restrict__ scores,
                                                                      const AdjustTile* __restrict__ tiles,
                                                                      const double* __restrict__ edge_sub, int W,
-                                                                     int n_sort, int rank_bits,
-                                                                     double* __restrict__ out) {
-    extern __shared__ unsigned long long lds_keys[];                  // [n_sort]
-    unsigned short* pos = (unsigned short*)(lds_keys + n_sort);       // [n_sort] position of sorted slot
-    unsigned short* rank = pos + n_sort;                              // [n_sort] rank of each input position
+                                                                     int n_sort, double* __restrict__ out) {
+    extern __shared__ unsigned long long lds_keys[];       // [n_sort] sorted keys
+    unsigned int* pos = (unsigned int*)(lds_keys + n_sort);  // [n_sort] input position of each sorted slot
     const AdjustTile t = tiles[blockIdx.x];
     const double sub = edge_sub ? edge_sub[t.interval] : 0.0;
     const double* in = scores + t.in_base;
     const int n_in = t.n_out + W - 1;
     for (int i = threadIdx.x; i < n_sort; i += kAdjThreads) {
         lds_keys[i] = i < n_in ? f64_key(in[i] - sub) : ~0ULL;
-        pos[i] = (unsigned short)i;
+        pos[i] = (unsigned int)i;
     }
     __syncthreads();
     for (int k = 2; k <= n_sort; k <<= 1) {
@@ -55,7 +54,7 @@ __global__ __launch_bounds__(kAdjThreads) void adjust_median_kernel(const double
                 if ((ka > kb) == up) {
                     lds_keys[a] = kb;
                     lds_keys[b] = ka;
-                    const unsigned short pa = pos[a];
+                    const unsigned int pa = pos[a];
                     pos[a] = pos[b];
                     pos[b] = pa;
                 }
@@ -63,26 +62,38 @@ __global__ __launch_bounds__(kAdjThreads) void adjust_median_kernel(const double
             __syncthreads();
         }
     }
-    for (int i = threadIdx.x; i < n_sort; i += kAdjThreads) rank[pos[i]] = (unsigned short)i;
-    __syncthreads();
-    const int kth = W / 2 - 1;
-    for (int o = threadIdx.x; o < t.n_out; o += kAdjThreads) {
-        const unsigned short* w = rank + o;
-        int r = 0;
-        for (int bit = rank_bits - 1; bit >= 0; --bit) {
-            const int cand = r | (1 << bit);
-            int below = 0;
-#pragma unroll 8
-            for (int j = 0; j < W; ++j) below += (int)w[j] < cand;
-            if (below <= kth) r = cand;
+    // Selection: walk the sorted slots in order, counting those whose position lies in this
+    // output's window; the slot where the count reaches W/2 holds the lower middle value, the
+    // next member the upper one.  Every lane reads the same slots (LDS broadcast, 4 per read).
+    const unsigned int uW = (unsigned int)W;
+    const int target = W / 2;
+    const uint4* pos4 = (const uint4*)pos;
+    const int n_blk = n_sort / 4;
+    for (int o0 = 0; o0 < t.n_out; o0 += kAdjThreads) {
+        const int o = o0 + (int)threadIdx.x;
+        const bool live = o < t.n_out;
+        const unsigned int uo = (unsigned int)o;
+        int cnt = 0, blk = -1, cnt_at = 0;
+        for (int b = 0; b < n_blk; ++b) {
+            const uint4 p = pos4[b];
+            const int before = cnt;
+            cnt += (p.x - uo < uW) + (p.y - uo < uW) + (p.z - uo < uW) + (p.w - uo < uW);
+            if (blk < 0 && cnt >= target) {
+                blk = b;
+                cnt_at = before;
+            }
+            if (__all(blk >= 0 || !live)) break;
         }
-        int r2 = n_sort;
-#pragma unroll 8
-        for (int j = 0; j < W; ++j) {
-            const int v = w[j];
-            r2 = (v > r && v < r2) ? v : r2;
+        if (!live) continue;
+        int s = blk * 4, c = cnt_at, s1 = -1;
+        for (;; ++s) {
+            if (pos[s] - uo < uW) {
+                ++c;
+                if (c == target) s1 = s;
+                else if (c > target) break;
+            }
         }
-        const double med = (key_f64(lds_keys[r]) + key_f64(lds_keys[r2])) * 0.5;
+        const double med = (key_f64(lds_keys[s1]) + key_f64(lds_keys[s])) * 0.5;
         out[t.out_base + o] = (in[o + W / 2] - sub) - med;
     }
 }
@@ -157,10 +168,8 @@ void launch_adjust_filter(hipStream_t s, const double* scores, const AdjustTile*
         const size_t lds = (size_t)(tile + W - 1) * 8;
         adjust_mean_kernel<<<n_tiles, kAdjThreads, lds, s>>>(scores, tiles, edge_sub, W, out);
     } else {
-        int bits = 0;
-        while ((1 << bits) < n_sort) ++bits;
-        const size_t lds = (size_t)n_sort * (8 + 2 + 2);
-        adjust_median_kernel<<<n_tiles, kAdjThreads, lds, s>>>(scores, tiles, edge_sub, W, n_sort, bits, out);
+        const size_t lds = (size_t)n_sort * (8 + 4);
+        adjust_median_kernel<<<n_tiles, kAdjThreads, lds, s>>>(scores, tiles, edge_sub, W, n_sort, out);
     }
 }
 
