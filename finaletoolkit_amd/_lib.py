@@ -48,7 +48,7 @@ EXPORTS = [
     "ftk_window_counts", "ftk_delfi_counts", "ftk_fraglen_hist", "ftk_window_features", "ftk_frag_lengths",
     "ftk_frag_select",
     "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals", "ftk_wps_adjust",
-    "ftk_ref_upload", "ftk_ref_release", "ftk_ref_gc_counts",
+    "ftk_ref_upload", "ftk_ref_release", "ftk_ref_gc_counts", "ftk_ref_set_layout", "ftk_motif_counts",
 ]
 
 
@@ -68,6 +68,12 @@ class Gaps(C.Structure):
     _fields_ = [("has_gaps", C.c_int32), ("cen_start", C.c_int32), ("cen_stop", C.c_int32),
                 ("n_telo", C.c_int32), ("telo_start", C.c_int32 * MAX_TELOMERES),
                 ("telo_stop", C.c_int32 * MAX_TELOMERES)]
+
+
+class Motif(C.Structure):
+    _fields_ = [("k", C.c_int32), ("fwd_offset", C.c_int32), ("rev_offset", C.c_int32),
+                ("both_strands", C.c_int32), ("negative_strand", C.c_int32), ("guard", C.c_int32),
+                ("rev_oob_is_error", C.c_int32)]
 
 
 _lib = None
@@ -148,6 +154,8 @@ def load() -> C.CDLL:
     lib.ftk_ref_upload.argtypes = [vp, C.c_int, vp, i64, C.c_int]
     lib.ftk_ref_release.argtypes = [vp, C.c_int]
     lib.ftk_ref_gc_counts.argtypes = [vp, C.c_int, vp, vp, i64, vp]
+    lib.ftk_ref_set_layout.argtypes = [vp, C.c_int, i64, i32, i32, vp, vp, i64]
+    lib.ftk_motif_counts.argtypes = [vp, C.c_int, C.c_int, vp, vp, i64, C.POINTER(Motif), i32, i32, vp, vp, vp]
     _lib = lib
     return lib
 

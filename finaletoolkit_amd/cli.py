@@ -1,7 +1,9 @@
 """
 Command line for the hot-path commands, flag-compatible with the reference's
 ``finaletoolkit`` CLI (``cli/commands/__init__.py:92-127,130-232,280-324,415-479`` and ``cli/_args.py``):
-``coverage``, ``frag-length-bins``, ``frag-length-intervals``, ``wps``, ``delfi`` (+ ``cleavage-profile``).
+``coverage``, ``frag-length-bins``, ``frag-length-intervals``, ``wps``, ``delfi`` (+ ``cleavage-profile``,
+``adjust-wps``, ``end-motifs``, ``interval-end-motifs``, ``breakpoint-motifs``, ``interval-breakpoint-motifs``,
+``mds``, ``regional-mds``).
 
     python -m finaletoolkit_amd.cli coverage INPUT INTERVALS -o out.bed
 """
@@ -88,6 +90,35 @@ def build_parser() -> argparse.ArgumentParser:
     _shared(p, min_default=0, policy=False)
     p.set_defaults(quality_threshold=20)
 
+    for name, kdef, with_bed in (("end-motifs", 4, False), ("interval-end-motifs", 4, True),
+                                 ("breakpoint-motifs", 6, False), ("interval-breakpoint-motifs", 6, True)):
+        p = sub.add_parser(name, help=f"k-mer {name.replace('interval-', '')} frequencies"
+                                      + (" per BED interval" if with_bed else ""))
+        p.add_argument("input_file", metavar="INPUT")
+        p.add_argument("refseq_file", metavar="REFERENCE")
+        if with_bed:
+            p.add_argument("intervals", metavar="REGIONS")
+        p.add_argument("-k", "--kmer-length", dest="k", type=int, default=kdef, metavar="K")
+        p.add_argument("--min-length", dest="min_length", type=int, default=50, metavar="BP")
+        p.add_argument("--max-length", dest="max_length", type=int, default=None, metavar="BP")
+        p.add_argument("--strand", choices=["both", "forward", "reverse"], default="both")
+        p.add_argument("-o", "--output", dest="output_file", default="-", metavar="FILE")
+        p.add_argument("-q", "--min-mapq", dest="quality_threshold", type=int, default=20, metavar="N")
+        p.add_argument("-t", "--threads", dest="workers", type=int, default=1, metavar="N")
+        p.add_argument("-v", "--verbose", action="count", default=0)
+
+    p = sub.add_parser("mds", help="motif diversity score of a k-mer frequency table")
+    p.add_argument("file_path", metavar="INPUT", nargs="?", default="-")
+    p.add_argument("-s", "--sep", default="\t")
+    p.add_argument("--header", type=int, default=0)
+
+    p = sub.add_parser("regional-mds", help="regional motif diversity score per interval")
+    p.add_argument("file_path", metavar="INPUT", nargs="?", default="-")
+    p.add_argument("file_out", metavar="OUTPUT")
+    p.add_argument("-s", "--sep", default="\t")
+    p.add_argument("--header", type=int, default=0)
+    p.add_argument("--miller-madow", dest="miller_madow", action="store_true")
+
     p = sub.add_parser("delfi", help="DELFI short/long fragment features")
     p.add_argument("input_file", metavar="INPUT")
     p.add_argument("chrom_sizes", metavar="CHROM_SIZES")
@@ -143,6 +174,19 @@ def main(argv=None) -> int:
                                     min_length=a.min_length, max_length=a.max_length,
                                     quality_threshold=a.quality_threshold, output_file=a.output_file,
                                     workers=a.workers, verbose=a.verbose, reference_file=a.reference_file)
+    elif a.command in ("end-motifs", "interval-end-motifs", "breakpoint-motifs", "interval-breakpoint-motifs"):
+        # --strand -> both_strands / negative_strand (cli/_dispatch.py:_translate_strand of the reference)
+        fn = getattr(frag, a.command.replace("-", "_"))
+        args = [a.input_file, a.refseq_file] + ([a.intervals] if a.command.startswith("interval") else [])
+        fn(*args, k=a.k, min_length=a.min_length, max_length=a.max_length, both_strands=a.strand == "both",
+           negative_strand=a.strand == "reverse", output_file=a.output_file,
+           quality_threshold=a.quality_threshold, workers=a.workers, verbose=a.verbose)
+    elif a.command == "mds":
+        from .frag._end_motifs import _cli_mds
+        _cli_mds(a.file_path, a.sep, a.header)
+    elif a.command == "regional-mds":
+        from .frag._end_motifs import _cli_regional_mds
+        _cli_regional_mds(a.file_path, a.file_out, a.sep, a.header, a.miller_madow)
     elif a.command == "delfi":
         frag.delfi(a.input_file, a.chrom_sizes, a.bins_file, a.reference_file, blacklist_file=a.blacklist_file,
                    gap_file=a.gap_file, output_file=a.output_file, no_gc_correct=a.no_gc_correct,

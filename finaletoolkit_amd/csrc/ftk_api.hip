@@ -307,7 +307,10 @@ void ftk_ctx_destroy(ftk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->contigs) free_contig(kv.second);
     for (auto& m : ctx->delfi_cache) (void)hipFree(m.base);
-    for (auto& kv : ctx->refs) (void)hipFree(kv.second.d);
+    for (auto& kv : ctx->refs) {
+        (void)hipFree(kv.second.d);
+        if (kv.second.d_nblk) (void)hipFree(kv.second.d_nblk);
+    }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -530,6 +533,7 @@ struct FeatCall {
     int64_t n_bl = 0;
     const ftk_gaps* gaps = nullptr;
     int64_t *short_out = nullptr, *long_out = nullptr, *nfrag_out = nullptr;
+    const MotifParams* motif = nullptr;  // hist_out = k-mer histogram, overflow_out = error counts
 };
 
 int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
@@ -576,6 +580,7 @@ int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const i
     r.over_out = fc.hist_out ? (o_dev ? fc.overflow_out : a.take<int64_t>(n_win)) : nullptr;
     r.len_lo = fc.len_lo;
     r.n_bins = fc.n_bins;
+    r.motif = fc.motif;
     int64_t* d_nfrag = nullptr;
     if (fc.delfi) {
         r.short_out = s_dev ? fc.short_out : a.take<int64_t>(n_win);
@@ -1018,6 +1023,7 @@ int ftk_ref_upload(ftk_ctx* ctx, int ref_id, const uint8_t* image, int64_t n_byt
     if (it != ctx->refs.end()) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(it->second.d);
+        if (it->second.d_nblk) (void)hipFree(it->second.d_nblk);
         ctx->refs.erase(it);
     }
     ftk_ctx::RefImage r;
@@ -1042,8 +1048,85 @@ int ftk_ref_release(ftk_ctx* ctx, int ref_id) {
     if (it == ctx->refs.end()) return fail(ctx, FTK_ERR_NO_CONTIG, "reference image %d is not loaded", ref_id);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(it->second.d);
+    if (it->second.d_nblk) (void)hipFree(it->second.d_nblk);
     ctx->refs.erase(it);
     return FTK_OK;
+}
+
+int ftk_ref_set_layout(ftk_ctx* ctx, int ref_id, int64_t chrom_len, int32_t line_bases, int32_t line_width,
+                       const int32_t* nblock_start, const int32_t* nblock_end, int64_t n_nblocks) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    auto it = ctx->refs.find(ref_id);
+    if (it == ctx->refs.end()) return fail(ctx, FTK_ERR_NO_CONTIG, "reference image %d is not loaded", ref_id);
+    ftk_ctx::RefImage& r = it->second;
+    if (chrom_len < 0 || chrom_len > INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "chrom_len out of range");
+    if (n_nblocks < 0 || n_nblocks > (1 << 28) || (n_nblocks > 0 && (!nblock_start || !nblock_end)))
+        return fail(ctx, FTK_ERR_INVALID, "bad N-block arguments");
+    if (r.kind == FTK_REF_FASTA_TEXT) {
+        if (chrom_len > 0 && (line_bases <= 0 || line_width < line_bases))
+            return fail(ctx, FTK_ERR_INVALID, "FASTA images need line_bases > 0 and line_width >= line_bases");
+        if (chrom_len > 0 && (chrom_len / line_bases) * line_width + chrom_len % line_bases > r.bytes)
+            return fail(ctx, FTK_ERR_INVALID, "chrom_len does not fit the uploaded FASTA text");
+    } else if ((chrom_len + 3) / 4 > r.bytes) {
+        return fail(ctx, FTK_ERR_INVALID, "chrom_len does not fit the uploaded 2bit image");
+    }
+    for (int64_t i = 0; i < n_nblocks; ++i)
+        if (nblock_start[i] < 0 || nblock_end[i] < nblock_start[i] || (i && nblock_start[i] < nblock_end[i - 1]))
+            return fail(ctx, FTK_ERR_INVALID, "N blocks must be sorted and disjoint");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (r.d_nblk) (void)hipFree(r.d_nblk);
+    r.d_nblk = nullptr;
+    r.n_nblk = 0;
+    if (n_nblocks) {
+        HIPCHK(ctx, hipMalloc((void**)&r.d_nblk, (size_t)n_nblocks * 8));
+        HIPCHK(ctx, hipMemcpy(r.d_nblk, nblock_start, (size_t)n_nblocks * 4, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(r.d_nblk + n_nblocks, nblock_end, (size_t)n_nblocks * 4, hipMemcpyHostToDevice));
+        r.n_nblk = (int32_t)n_nblocks;
+    }
+    r.chrom_len = chrom_len;
+    r.line_bases = line_bases;
+    r.line_width = line_width;
+    return FTK_OK;
+}
+
+int ftk_motif_counts(ftk_ctx* ctx, int contig_id, int ref_id, const int32_t* w_start, const int32_t* w_end,
+                     int64_t n_win, const ftk_motif* motif, int32_t mapq_min, int32_t fetch_mode,
+                     uint32_t* counts_out, int64_t* nfrag_out, int64_t* err_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    auto it = ctx->refs.find(ref_id);
+    if (it == ctx->refs.end()) return fail(ctx, FTK_ERR_NO_CONTIG, "reference image %d is not loaded", ref_id);
+    const ftk_ctx::RefImage& ri = it->second;
+    if (ri.chrom_len < 0) return fail(ctx, FTK_ERR_INVALID, "reference image %d has no layout (ftk_ref_set_layout)", ref_id);
+    if (!motif) return fail(ctx, FTK_ERR_INVALID, "motif is NULL");
+    if (motif->k < 1 || motif->k > 7) return fail(ctx, FTK_ERR_INVALID, "k must be in [1, 7]");
+    if (n_win > 0 && (!counts_out || !err_out)) return fail(ctx, FTK_ERR_INVALID, "NULL output pointer");
+    MotifParams mp{};
+    mp.img = (const uint8_t*)ri.d;
+    mp.nblk_start = ri.d_nblk;
+    mp.nblk_end = ri.d_nblk ? ri.d_nblk + ri.n_nblk : nullptr;
+    mp.n_nblk = ri.n_nblk;
+    mp.kind = ri.kind;
+    mp.chrom_len = (int)ri.chrom_len;
+    mp.line_bases = ri.line_bases > 0 ? ri.line_bases : 1;
+    mp.line_width = ri.line_width > 0 ? ri.line_width : 1;
+    mp.k = motif->k;
+    mp.f_off = motif->fwd_offset;
+    mp.r_off = motif->rev_offset;
+    mp.both = motif->both_strands != 0;
+    mp.neg = motif->negative_strand != 0;
+    mp.guard = motif->guard;
+    mp.rev_err = motif->rev_oob_is_error != 0;
+    ftk_filter f{mapq_min, FTK_LEN_OPEN, FTK_LEN_OPEN, FTK_POLICY_ANY, fetch_mode};
+    FeatCall fc;
+    fc.f = &f;
+    fc.count_out = nfrag_out;
+    fc.hist_out = counts_out;
+    fc.overflow_out = err_out;
+    fc.len_lo = 0;
+    fc.n_bins = 1 << (2 * motif->k);
+    fc.motif = &mp;
+    return features_common(ctx, contig_id, w_start, w_end, n_win, fc);
 }
 
 int ftk_ref_gc_counts(ftk_ctx* ctx, int ref_id, const int64_t* range_lo, const int64_t* range_hi, int64_t n,

@@ -70,7 +70,16 @@ struct ftk_ctx {
     std::map<int, ftk::ContigData> contigs;
     std::string err;
     std::vector<ftk::DelfiMeta> delfi_cache;
-    struct RefImage { void* d = nullptr; int64_t bytes = 0; int kind = 0; };
+    struct RefImage {
+        void* d = nullptr;
+        int64_t bytes = 0;
+        int kind = 0;
+        // ftk_ref_set_layout (needed by the motif pass)
+        int64_t chrom_len = -1;
+        int32_t line_bases = 0, line_width = 0;
+        int32_t* d_nblk = nullptr;  // [2][n_nblk]: starts then ends
+        int32_t n_nblk = 0;
+    };
     std::map<int, RefImage> refs;  // reference-sequence images for the DELFI GC count
     // grow-only device scratch, reused by every call (stream-ordered)
     void* scratch = nullptr;

@@ -47,6 +47,19 @@ void launch_bin_index(hipStream_t s, const int32_t* start, int n, int n_bins, in
 void launch_plan(hipStream_t s, const ContigView& cv, const int32_t* ws, const int32_t* we, int n_win, int lmax,
                  int small_max, const WindowPlan& pl, int64_t* const zero[4]);
 
+// Where the motif pass reads its k-mers (device pointers) and which ends count.
+struct MotifParams {
+    const uint8_t* img;        // reference image of the contig (ftk_ref_upload)
+    const int32_t* nblk_start; // 2bit: N blocks, sorted
+    const int32_t* nblk_end;
+    int n_nblk;
+    int kind;                  // FTK_REF_*
+    int chrom_len;
+    int line_bases, line_width;  // FASTA text geometry
+    int k, f_off, r_off;
+    int both, neg, guard, rev_err;
+};
+
 // What one window-feature pass should produce (NULL output = feature off).
 struct FeatureRequest {
     const ftk_filter* filter = nullptr;  // coverage + histogram predicate
@@ -61,6 +74,8 @@ struct FeatureRequest {
     const int32_t* bl_off = nullptr;
     const int32_t* bl_r0 = nullptr;
     const int32_t* bl_pm = nullptr;
+    // motif histogram instead of the length histogram (hist_out = [n_win][4^k], over_out = errors)
+    const MotifParams* motif = nullptr;
 };
 void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
                             int n_win, const WindowPlan& pl, const FeatureRequest& r, bool small_path);

@@ -260,12 +260,51 @@ struct DelfiPred {
     }
 };
 
+// k-mer starting at base `lo` of the reference image as a base-4 number in ACGT order
+// (gen_kmers order, utils/utils.py:388-410), or -1 when it holds anything but A/C/G/T
+// (upper- or lower-case: io/reference.py:171 upper-cases).  revcomp: the reverse complement's code.
+__device__ __forceinline__ int kmer_code(const MotifParams& M, int lo, bool revcomp) {
+    int code = 0;
+    if (M.kind == FTK_REF_2BIT) {
+        // N blocks (sorted, disjoint): first block ending after lo
+        int a = 0, b = M.n_nblk;
+        while (a < b) {
+            const int m = (a + b) >> 1;
+            if (M.nblk_end[m] <= lo) a = m + 1; else b = m;
+        }
+        if (a < M.n_nblk && M.nblk_start[a] < lo + M.k) return -1;
+        for (int j = 0; j < M.k; ++j) {
+            const int p = lo + j;
+            const int v = (M.img[p >> 2] >> (6 - 2 * (p & 3))) & 3;   // T=0 C=1 A=2 G=3
+            const int base = (0x87 >> (2 * v)) & 3;                   // -> A=0 C=1 G=2 T=3 ({3,1,0,2} packed)
+            code = revcomp ? (code | ((3 - base) << (2 * j))) : (code * 4 + base);
+        }
+        return code;
+    }
+    int row = lo / M.line_bases, col = lo - row * M.line_bases;
+    long long off = (long long)row * M.line_width + col;
+    for (int j = 0; j < M.k; ++j) {
+        const int ch = M.img[off] & 0xDF;
+        int base;
+        if (ch == 'A') base = 0;
+        else if (ch == 'C') base = 1;
+        else if (ch == 'G') base = 2;
+        else if (ch == 'T') base = 3;
+        else return -1;
+        code = revcomp ? (code | ((3 - base) << (2 * j))) : (code * 4 + base);
+        ++off;
+        if (++col == M.line_bases) { col = 0; off += M.line_width - M.line_bases; }
+    }
+    return code;
+}
+
 // What one window-feature launch computes (any combination, ONE pass over the fragments):
 //   coverage count + length histogram under `wp`  (frag/_coverage.py:117-130, _frag_length.py:147-153)
 //   DELFI short / long under `dp`                   (frag/_delfi.py:443-472)
 struct FeatParams {
     WinPred wp;
     DelfiPred dp;
+    MotifParams mp;  // CH == 2
     int do_cov, do_hist;
     int len_lo, n_bins;
     int64_t* cov_out;
@@ -279,15 +318,47 @@ struct FeatAcc {
     int cov = 0, over = 0, sh = 0, lg = 0;
 };
 
-template <bool CH, bool DF, bool BAM>
+template <int CH, bool DF, bool BAM>
 __device__ __forceinline__ void feat_element(const ContigView& cv, const FeatParams& P, int idx, int fs, int fe, int q,
                                              int ws, int we, int o0, int o1, uint32_t* h, FeatAcc& a) {
-    if (CH) {
+    if (CH == 1) {
         if (P.wp.test<BAM>(cv, idx, fs, fe, q, ws, we)) {
             ++a.cov;
             if (P.do_hist) {
                 const int b = (fe - fs) - P.len_lo;
                 if (b >= 0 && b < P.n_bins) atomicAdd(&h[b], 1u); else ++a.over;
+            }
+        }
+    }
+    if (CH == 2) {
+        // frag/_end_motifs.py:118-176, frag/_breakpoint_motifs.py:124-185: every fetched fragment
+        // (index overlap + mapq only) contributes the k-mer at its start and / or the reverse
+        // complement of the k-mer at its stop
+        if (P.wp.test<BAM>(cv, idx, fs, fe, q, ws, we)) {
+            ++a.cov;
+            const MotifParams& M = P.mp;
+            bool skip = M.guard > 0 && (fs - M.guard < 0 || fs + M.guard >= M.chrom_len);
+            if (!skip) {
+                const bool use_fwd = M.both || (!M.neg && cv.strand[idx] != 0);
+                const bool use_rev = M.both || M.neg;
+                if (use_fwd) {
+                    const int lo = fs + M.f_off;
+                    if (lo < 0 || lo + M.k > M.chrom_len) {
+                        skip = true;  // the reference's `continue` also drops this fragment's other end
+                    } else {
+                        const int code = kmer_code(M, lo, false);
+                        if (code >= 0) atomicAdd(&h[code], 1u);
+                    }
+                }
+                if (!skip && use_rev) {
+                    const int lo = fe + M.r_off;
+                    if (lo < 0 || lo + M.k > M.chrom_len) {
+                        if (M.rev_err) ++a.over;
+                    } else {
+                        const int code = kmer_code(M, lo, true);
+                        if (code >= 0) atomicAdd(&h[code], 1u);
+                    }
+                }
             }
         }
     }
@@ -301,7 +372,7 @@ __device__ __forceinline__ void feat_element(const ContigView& cv, const FeatPar
 // ---------------------------------------------------------------------------
 // window features, small path: one wave per window (candidate range <= kSmallMax)
 // ---------------------------------------------------------------------------
-template <bool CH, bool DF, bool BAM>
+template <int CH, bool DF, bool BAM>
 __global__ __launch_bounds__(256) void feat_small_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
                                                          int n_win, const int32_t* cand_lo, const int32_t* cand_hi,
                                                          const uint32_t* nchunks, FeatParams P) {
@@ -365,7 +436,7 @@ __global__ __launch_bounds__(256) void feat_small_kernel(ContigView cv, const in
 // chunks in order; a block keeps accumulating while the window stays the same
 // and issues one atomic per counter per (block, window).
 // ---------------------------------------------------------------------------
-template <bool CH, bool DF, bool BAM>
+template <int CH, bool DF, bool BAM>
 __global__ __launch_bounds__(256) void feat_large_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
                                                          int n_win, const int32_t* cand_lo, const int32_t* cand_hi,
                                                          const uint32_t* chunk_off, FeatParams P) {
@@ -958,7 +1029,7 @@ static WinPred make_win_pred(const ftk_filter& f) {
                    f.fetch_mode == FTK_FETCH_BAM_READ1};
 }
 
-template <bool CH, bool DF, bool BAM>
+template <int CH, bool DF, bool BAM>
 static void launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
                           int n_win, const WindowPlan& pl, const FeatParams& P, bool small_path) {
     const size_t lds1 = (CH && P.do_hist) ? (size_t)P.n_bins * sizeof(uint32_t) : 0;
@@ -1010,9 +1081,13 @@ void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv,
         if (bam) launch_feat_t<CH, DF, true>(s, grid_large, cv, ws, we, n_win, pl, P, small_path);    \
         else launch_feat_t<CH, DF, false>(s, grid_large, cv, ws, we, n_win, pl, P, small_path);       \
     } while (0)
-    if (ch && df) FTK_FEAT(true, true);
-    else if (ch) FTK_FEAT(true, false);
-    else if (df) FTK_FEAT(false, true);
+    if (r.motif) {
+        P.mp = *r.motif;
+        P.do_hist = 1;
+        FTK_FEAT(2, false);
+    } else if (ch && df) FTK_FEAT(1, true);
+    else if (ch) FTK_FEAT(1, false);
+    else if (df) FTK_FEAT(0, true);
 #undef FTK_FEAT
 }
 

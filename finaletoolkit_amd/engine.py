@@ -391,6 +391,35 @@ class Engine:
         refs[key] = rid
         return rid
 
+    def ref_set_layout(self, rid: int, chrom_len: int, line_bases: int = 0, line_width: int = 0, n_starts=None,
+                       n_ends=None):
+        """Geometry of an uploaded image: FASTA line layout or the 2bit record's N blocks."""
+        ns = np.ascontiguousarray(n_starts if n_starts is not None else [], dtype=np.int32)
+        ne = np.ascontiguousarray(n_ends if n_ends is not None else [], dtype=np.int32)
+        self._check(self.lib.ftk_ref_set_layout(self.ctx, rid, int(chrom_len), int(line_bases), int(line_width),
+                                                L.ptr(ns) if len(ns) else None, L.ptr(ne) if len(ne) else None,
+                                                len(ns)))
+
+    def motif_counts(self, name: str, rid: int, starts, stops, k: int, fwd_offset: int, rev_offset: int,
+                     both_strands: bool, negative_strand: bool, guard: int, rev_oob_is_error: bool,
+                     quality_threshold: int, bam: bool = False):
+        """k-mer histograms per window (frag/_end_motifs.py:118-176, frag/_breakpoint_motifs.py:124-185);
+        returns (counts uint32 [n_win, 4**k], fetched fragments per window, reverse-end errors per window)."""
+        ws = np.ascontiguousarray(starts, dtype=np.int32)
+        we = np.ascontiguousarray(stops, dtype=np.int32)
+        n = len(ws)
+        counts = np.zeros((n, 4 ** int(k)), np.uint32)
+        nfrag = np.zeros(n, np.int64)
+        err = np.zeros(n, np.int64)
+        if n:
+            m = L.Motif(int(k), int(fwd_offset), int(rev_offset), int(bool(both_strands)),
+                        int(bool(negative_strand)), int(guard), int(bool(rev_oob_is_error)))
+            self._check(self.lib.ftk_motif_counts(self.ctx, self.contig_id(name), rid, L.ptr(ws), L.ptr(we), n,
+                                                  C.byref(m), int(quality_threshold),
+                                                  L.FETCH_BAM_READ1 if bam else L.FETCH_TABIX, L.ptr(counts),
+                                                  L.ptr(nfrag), L.ptr(err)))
+        return counts, nfrag, err
+
     def ref_gc_counts(self, rid: int, lo, hi):
         lo = np.ascontiguousarray(lo, dtype=np.int64)
         hi = np.ascontiguousarray(hi, dtype=np.int64)

@@ -137,11 +137,9 @@ class ReferenceGenome:
         Same numbers as ``gc_count`` (which stays as the host-side definition used by the tests)."""
         starts = np.asarray(starts, dtype=np.int64)
         stops = np.asarray(stops, dtype=np.int64)
-        key = (self.path, contig)
+        rid = self.device_image(engine, contig)
         if self.is_2bit:
             size, n_starts, n_sizes, dna_off = self._records[contig]
-            self._fh.seek(dna_off)
-            rid = engine.ref_upload(key, np.frombuffer(self._fh.read((size + 3) // 4), dtype=np.uint8), 1)
             counts = engine.ref_gc_counts(rid, starts, stops)
             # bases inside N blocks count as neither (they are stored as some code): subtract their share
             for s0, n in zip(n_starts, n_sizes):
@@ -154,12 +152,35 @@ class ReferenceGenome:
         length, offset, linebases, linewidth = self._fai[contig]
         if linebases == 0:
             return np.zeros(len(starts), np.int64)
-        n_text = (length // linebases) * linewidth + length % linebases
-        self._fh.seek(offset)
-        rid = engine.ref_upload(key, np.frombuffer(self._fh.read(n_text), dtype=np.uint8), 0)
         lo = (starts // linebases) * linewidth + starts % linebases
         hi = (stops // linebases) * linewidth + stops % linebases
         return engine.ref_gc_counts(rid, lo, hi)
+
+    def device_image(self, engine, contig: str) -> int:
+        """Upload ``contig``'s sequence image once (cached on the engine) together with its geometry --
+        the packed DNA + N blocks of a 2bit record, or the raw FASTA text + line layout -- and return
+        the reference id the device calls take."""
+        key = (self.path, contig)
+        cached = engine.__dict__.get("_refs", {}).get(key)
+        if cached is not None:
+            return cached
+        if self.is_2bit:
+            size, n_starts, n_sizes, dna_off = self._records[contig]
+            self._fh.seek(dna_off)
+            rid = engine.ref_upload(key, np.frombuffer(self._fh.read((size + 3) // 4), dtype=np.uint8), 1)
+            order = np.argsort(n_starts, kind="stable")
+            engine.ref_set_layout(rid, size, 0, 0, n_starts[order], (n_starts + n_sizes)[order])
+            return rid
+        length, offset, linebases, linewidth = self._fai[contig]
+        if linebases == 0:
+            rid = engine.ref_upload(key, np.zeros(0, np.uint8), 0)
+            engine.ref_set_layout(rid, 0, 1, 1)
+            return rid
+        n_text = (length // linebases) * linewidth + length % linebases
+        self._fh.seek(offset)
+        rid = engine.ref_upload(key, np.frombuffer(self._fh.read(n_text), dtype=np.uint8), 0)
+        engine.ref_set_layout(rid, length, linebases, linewidth)
+        return rid
 
     def close(self):
         if self._fh:

@@ -269,6 +269,40 @@ int ftk_ref_release(ftk_ctx* ctx, int ref_id);
 int ftk_ref_gc_counts(ftk_ctx* ctx, int ref_id, const int64_t* range_lo, const int64_t* range_hi, int64_t n,
                       int64_t* gc_out);
 
+/* ---- next row: end-motif / breakpoint-motif k-mer histograms ----------
+ * frag/_end_motifs.py:51-187 (region_end_motifs) and frag/_breakpoint_motifs.py:53-196
+ * (region_breakpoint_motifs) per window: every fragment the index query returns for the window
+ * (overlap, or read1 overlap for BAM, and mapq >= mapq_min -- the reference applies NO length
+ * filter here) adds
+ *    forward: the k-mer ref[start + fwd_offset, +k)
+ *    reverse: the reverse complement of ref[stop + rev_offset, +k)
+ * to the window's histogram of 4^k bins in ACGT order (utils/utils.py:388-410, gen_kmers).
+ *    both_strands            both k-mers of every fragment
+ *    else negative_strand    only the reverse k-mer, of every fragment
+ *    else                    only the forward k-mer, of forward-strand fragments
+ * A k-mer holding anything but A/C/G/T (either case) is not counted.  A forward k-mer that falls
+ * off the contig drops the fragment; a reverse one that does is counted in err_out when
+ * rev_oob_is_error (the reference raises RuntimeError there, _end_motifs.py:137-145) and skipped
+ * otherwise.  guard > 0 drops fragments with start - guard < 0 or start + guard >= chrom_len
+ * (_breakpoint_motifs.py:127-135).
+ *   end motifs:        k,  fwd_offset 0,     rev_offset -k,    guard 0,   rev_oob_is_error = both_strands
+ *   breakpoint motifs: k (even), fwd_offset -k/2, rev_offset -k/2, guard k/2, rev_oob_is_error 0
+ * The reference image needs its geometry first (ftk_ref_set_layout): contig length, and the FASTA
+ * line layout (bases per line, bytes per line) or the 2bit record's N blocks (host arrays). */
+typedef struct ftk_motif {
+    int32_t k; /* 1..7 */
+    int32_t fwd_offset, rev_offset;
+    int32_t both_strands, negative_strand;
+    int32_t guard;
+    int32_t rev_oob_is_error;
+} ftk_motif;
+int ftk_ref_set_layout(ftk_ctx* ctx, int ref_id, int64_t chrom_len, int32_t line_bases, int32_t line_width,
+                       const int32_t* nblock_start, const int32_t* nblock_end, int64_t n_nblocks);
+int ftk_motif_counts(ftk_ctx* ctx, int contig_id, int ref_id, const int32_t* w_start, const int32_t* w_end,
+                     int64_t n_win, const ftk_motif* motif, int32_t mapq_min, int32_t fetch_mode,
+                     uint32_t* counts_out /* [n_win][4^k] */, int64_t* nfrag_out /* [n_win] or NULL */,
+                     int64_t* err_out /* [n_win] */);
+
 #ifdef __cplusplus
 }
 #endif

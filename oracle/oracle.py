@@ -351,3 +351,64 @@ def py_adjust_run(scores, window_size=1000, use_mean=False, edge_size=None, savg
         from scipy.signal import savgol_filter
         adj = savgol_filter(adj, savgol_window, savgol_deg)
     return adj
+
+
+# ---------------------------------------------------------------------------
+# end / breakpoint motifs (frag/_end_motifs.py:118-176, frag/_breakpoint_motifs.py:124-185)
+# ---------------------------------------------------------------------------
+_COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+
+def _py_sequence(seq, start, stop):
+    """io/reference.py:120-172: upper-cased slice, ValueError outside the contig."""
+    if seq is None or start < 0 or stop > len(seq) or start > stop:
+        raise ValueError("out of bounds")
+    return seq[start:stop].upper()
+
+
+def py_region_motifs(rows, seq, start, stop, k, kind="end", both_strands=True, negative_strand=False,
+                     quality_threshold=20):
+    """Counts per k-mer in gen_kmers order for one region.  ``rows``: the contig's
+    ``(fs, fe, mapq, fwd)`` in file order; ``seq``: the contig's reference sequence (None = contig
+    absent from the genome).  kind "end": k-mer at [fs, fs+k) and revcomp of [fe-k, fe);
+    kind "breakpoint": [fs-k//2, fs+k//2) and revcomp of [fe-k//2, fe+k//2) with the contig-end guard.
+    Raises RuntimeError where the reference does (end motifs, both strands, 3' k-mer off the contig)."""
+    import itertools
+    if both_strands and negative_strand:
+        raise ValueError("Cannot have both both_strands and negative_strand.")
+    kmers = ["".join(t) for t in itertools.product("ACGT", repeat=k)]
+    counts = dict.fromkeys(kmers, 0)
+    h = k // 2
+    chrom_len = len(seq) if seq is not None else 0
+    for fs, fe, _, fwd in py_fetch(rows, start, stop, quality_threshold):
+        if kind == "breakpoint":
+            if fs - h < 0 or fs + h >= chrom_len:
+                continue
+            use_fwd = both_strands or (fwd and not negative_strand)
+            use_rev = both_strands or negative_strand
+            f_lo, f_hi, r_lo, r_hi = fs - h, fs + h, fe - h, fe + h
+        else:
+            use_fwd = both_strands or (fwd and not negative_strand)
+            use_rev = both_strands or negative_strand
+            f_lo, f_hi, r_lo, r_hi = fs, fs + k, fe - k, fe
+        if use_fwd:
+            try:
+                kmer = _py_sequence(seq, f_lo, f_hi)
+            except ValueError:
+                continue
+            if len(kmer) != k:
+                continue
+            if "N" not in kmer:
+                counts[kmer] += 1
+        if use_rev:
+            try:
+                kmer = _py_sequence(seq, r_lo, r_hi)
+            except ValueError:
+                if kind == "end" and both_strands:
+                    raise RuntimeError("Error querying sequence")
+                continue
+            if len(kmer) != k:
+                continue
+            if "N" not in kmer:
+                counts["".join(_COMP[b] for b in reversed(kmer))] += 1
+    return np.array([counts[m] for m in kmers], np.int64)

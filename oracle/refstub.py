@@ -73,6 +73,34 @@ class _TabixFile:
         return False
 
 
+class _FastaFile:
+    """pysam.FastaFile stand-in: whole file in memory, ``fetch`` = plain slicing of the contig
+    (0-based half-open), case preserved -- what htslib's faidx returns."""
+
+    def __init__(self, filename, *args, **kwargs):
+        self.filename = str(filename)
+        seqs, name, parts = {}, None, []
+        with open(self.filename) as fh:
+            for line in fh:
+                if line.startswith(">"):
+                    if name is not None:
+                        seqs[name] = "".join(parts)
+                    name, parts = line[1:].split()[0], []
+                else:
+                    parts.append(line.strip())
+        if name is not None:
+            seqs[name] = "".join(parts)
+        self._seqs = seqs
+        self.references = tuple(seqs)
+        self.lengths = tuple(len(v) for v in seqs.values())
+
+    def fetch(self, reference=None, start=None, end=None, region=None):
+        return self._seqs[reference][start:end]
+
+    def close(self):
+        pass
+
+
 class _Dummy:
     def __init__(self, *a, **k):
         raise RuntimeError("not available in the oracle stub")
@@ -85,7 +113,7 @@ def install():
         pysam.TabixFile = _TabixFile
         pysam.AlignmentFile = type("AlignmentFile", (_Dummy,), {})
         pysam.AlignedSegment = type("AlignedSegment", (_Dummy,), {})
-        pysam.FastaFile = type("FastaFile", (_Dummy,), {})
+        pysam.FastaFile = _FastaFile
         pysam.asTuple = lambda *a, **k: None
         pysam.faidx = lambda *a, **k: None
         pysam.tabix_index = lambda *a, **k: None

@@ -106,3 +106,72 @@ def write_synthetic_bam(path, contigs, frags, junk=True, read_len=100):
     bgzf.write_bgzf(path, b"".join(out), level=1)
     open(str(path) + ".bai", "ab").close()
     return expected
+
+
+def read_fasta_gz(path):
+    """{contig: sequence} of a gzipped FASTA fixture."""
+    seqs, name, parts = {}, None, []
+    with gzip.open(path, "rt") as fh:
+        for line in fh:
+            if line.startswith(">"):
+                if name is not None:
+                    seqs[name] = "".join(parts)
+                name, parts = line[1:].split()[0], []
+            else:
+                parts.append(line.strip())
+    if name is not None:
+        seqs[name] = "".join(parts)
+    return seqs
+
+
+def write_fasta(path, seqs, width=60, fai=True):
+    """Plain FASTA (+ .fai) from {contig: sequence}."""
+    index = []
+    with open(path, "wb") as fh:
+        for name, s in seqs.items():
+            fh.write(f">{name}\n".encode())
+            off = fh.tell()
+            for i in range(0, len(s), width):
+                fh.write(s[i:i + width].encode() + b"\n")
+            index.append((name, len(s), off, width, width + 1))
+    if fai:
+        with open(str(path) + ".fai", "w") as fh:
+            for row in index:
+                fh.write("\t".join(map(str, row)) + "\n")
+
+
+def write_2bit(path, seqs):
+    """UCSC .2bit (little-endian, version 0) from {contig: sequence}: N runs -> N blocks,
+    lower-case runs -> mask blocks, bases packed T=0 C=1 A=2 G=3 (N packed as T)."""
+    import struct
+
+    def runs(mask):
+        d = np.diff(np.concatenate([[0], mask.astype(np.int8), [0]]))
+        return np.flatnonzero(d == 1), np.flatnonzero(d == -1)
+
+    records = []
+    for name, s in seqs.items():
+        b = np.frombuffer(s.encode(), np.uint8)
+        up = b & 0xDF
+        ns, ne = runs(up == ord("N"))
+        ms, me = runs((b & 0x20) != 0)
+        code = np.zeros(len(b), np.uint8)
+        code[up == ord("C")] = 1
+        code[up == ord("A")] = 2
+        code[up == ord("G")] = 3
+        pad = np.zeros((-len(b)) % 4, np.uint8)
+        c4 = np.concatenate([code, pad]).reshape(-1, 4)
+        packed = (c4[:, 0] << 6 | c4[:, 1] << 4 | c4[:, 2] << 2 | c4[:, 3]).astype(np.uint8)
+        rec = struct.pack("<II", len(b), len(ns)) + ns.astype("<u4").tobytes() + (ne - ns).astype("<u4").tobytes()
+        rec += struct.pack("<I", len(ms)) + ms.astype("<u4").tobytes() + (me - ms).astype("<u4").tobytes()
+        rec += struct.pack("<I", 0) + packed.tobytes()
+        records.append((name, rec))
+    head = struct.pack("<IIII", 0x1A412743, 0, len(records), 0)
+    index_len = sum(1 + len(n) + 4 for n, _ in records)
+    off = len(head) + index_len
+    index = b""
+    for name, rec in records:
+        index += bytes([len(name)]) + name.encode() + struct.pack("<I", off)
+        off += len(rec)
+    with open(path, "wb") as fh:
+        fh.write(head + index + b"".join(r for _, r in records))
