@@ -101,4 +101,21 @@ if "feat" in which:
         timeit(lambda: fused(**kw), "fused " + name, 10 * n)
         timeit(lambda: fused(**kw), "fused " + name + " COLD(read)", 10 * n, cold="read")
         timeit(lambda: fused(**kw), "fused " + name + " COLD(dirty)", 10 * n, cold=True)
+if "motif" in which:
+    # 1 Mb windows (end_motifs' tiling), random 2bit / FASTA-text images of the contig
+    mws, mwe = synth.tiling_windows(size, 1_000_000)
+    rng = np.random.default_rng(5)
+    packed = rng.integers(0, 256, (size + 3) // 4, dtype=np.uint8)
+    rid2 = eng.ref_upload(("kb", "2bit"), packed, 1)
+    eng.ref_set_layout(rid2, size, 0, 0, [10_000], [20_000])
+    text = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size + size // 60 + 1)].copy()
+    text[60::61] = 10
+    ridf = eng.ref_upload(("kb", "fa"), text, 0)
+    eng.ref_set_layout(ridf, size, 60, 61)
+    for rid, tag in ((rid2, "2bit"), (ridf, "fasta")):
+        for k in (4, 6):
+            f = lambda: eng.motif_counts("c", rid, mws, mwe, k, 0, -k, True, False, 0, False, 30)
+            timeit(f, f"end motifs k={k} {tag}", 10 * n)
+    c, nf, er = eng.motif_counts("c", rid2, mws, mwe, 4, 0, -4, True, False, 0, False, 30)
+    print("motif total", int(c.sum()), "fragments", int(nf.sum()))
 print("wps checksum", int(out[:5_000_000].sum().item()), "cov", int(cov.sum().item()))
