@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from finaletoolkit_amd import synth  # noqa: E402
-from finaletoolkit_amd.sharding import lpt_assign  # noqa: E402
+from finaletoolkit_amd.sharding import split_units, unit_halo  # noqa: E402
 
 WINDOW = 100_000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -107,8 +107,18 @@ def main():
     if args.contigs:
         sizes = {k: sizes[k] for k in args.contigs.split(",")}
     names = list(sizes)
-    owner = lpt_assign(sizes, world)
-    mine = [c for c in names if owner[c] == rank]
+    # Work units: whole contigs on one GPU; with N GPUs the genome is cut into N equal runs at window
+    # boundaries (a rank owns whole contigs plus at most two partial ones, sharding.split_units).  A
+    # partial unit holds the contig's fragments that start within `halo` of its range and computes
+    # exactly its own windows / bases, so there is still no data-path exchange.
+    units = split_units(sizes, world, WINDOW)
+    sim = os.environ.get("FTK_BENCH_SIM")  # "world:rank": run that rank's units of a world-GPU split alone
+    if sim:
+        sim_world, sim_rank = (int(x) for x in sim.split(":"))
+        units = [(0, c, a, b) for r, c, a, b in split_units(sizes, sim_world, WINDOW) if r == sim_rank]
+    ukey = lambda u: f"{u[1]}:{u[2]}-{u[3]}"
+    mine = [u for u in units if u[0] == rank]
+    halo = unit_halo(1000, WPS_W)
 
     eng = Engine(local)
     # one explicit stream for torch ops, RCCL and the ftk launches (a NULL handle would mean "ctx's own stream")
@@ -120,25 +130,40 @@ def main():
     # ---- resident inputs (untimed) -------------------------------------------
     t_load = time.time()
     per = {}
-    for c in mine:
+    cached = (None, None)
+    for u in mine:
+        _, c, a, b = u
         ci = names.index(c)
-        n = synth.n_fragments(sizes[c], args.depth)
-        s, e, q, st = gen_contig_device(torch, dev, sizes[c], n, synth.SEED_BASE + ci)
+        if cached[0] != c:
+            n_c = synth.n_fragments(sizes[c], args.depth)
+            cached = (None, None)
+            cached = (c, gen_contig_device(torch, dev, sizes[c], n_c, synth.SEED_BASE + ci))
+        s, e, q, st = cached[1]
+        if (a, b) != (0, sizes[c]):
+            lo = int(torch.searchsorted(s, torch.tensor([a - halo], dtype=torch.int32, device=dev)).item())
+            hi = int(torch.searchsorted(s, torch.tensor([b + halo], dtype=torch.int32, device=dev)).item())
+            s, e, q, st = (t[lo:hi].contiguous() for t in (s, e, q, st))
+        n = int(s.numel())
         torch.cuda.synchronize()
-        eng.load_contig_device(c, s, e, q, st, n)
+        eng.load_contig_device(ukey(u), s, e, q, st, n)
         ws, we = synth.tiling_windows(sizes[c], WINDOW)
+        inside = (ws >= a) & (ws < b)
+        ws, we = np.ascontiguousarray(ws[inside]), np.ascontiguousarray(we[inside])
         bl_s, bl_e = synth_blacklist(sizes[c], 77 + ci, max(8, int(2000 * sizes[c] / 3.1e9)))
         nw = len(ws)
-        per[c] = dict(
+        per[ukey(u)] = dict(
+            contig=c, a=a, b=b, size=sizes[c],
             n=n, ws=ws, we=we, nw=nw, bl=(bl_s, bl_e), gaps=synth_gaps(sizes[c]),
             d_ws=torch.from_numpy(ws).to(dev), d_we=torch.from_numpy(we).to(dev),
             cov=torch.zeros(nw, dtype=torch.int64, device=dev),
             hist=torch.zeros((nw, HIST_BINS), dtype=torch.int32, device=dev),
             over=torch.zeros(nw, dtype=torch.int64, device=dev),
-            wps=torch.empty(sizes[c], dtype=torch.int64, device=dev),
-            keep=(s, e, q, st) if c == mine[-1] else None,
+            wps=torch.empty(b - a, dtype=torch.int64, device=dev),
+            keep=(s, e, q, st) if u == mine[-1] else None,
         )
         del s, e, q, st
+    cached = (None, None)
+    mine = [ukey(u) for u in mine]
     torch.cuda.synchronize()
     t_load = time.time() - t_load
 
@@ -148,8 +173,9 @@ def main():
     flt = L.make_filter(MAPQ, None, None, "midpoint")
     for c in mine:
         per[c]["gaps_c"] = L.make_gaps(per[c]["gaps"])
-    bins_all = sum(int(np.ceil(sizes[c] / WINDOW)) for c in names)
-    max_bins_rank = max(sum(int(np.ceil(sizes[c] / WINDOW)) for c in names if owner[c] == r) for r in range(world))
+    unit_rows = lambda u: -(-u[3] // WINDOW) - u[2] // WINDOW
+    bins_all = sum(unit_rows(u) for u in units)
+    max_bins_rank = max(sum(unit_rows(u) for u in units if u[0] == r) for r in range(world))
     # The DELFI (short, long) vectors are written by the kernels straight into the all-gather send
     # buffer: row 0 = short, row 1 = long, this rank's contigs back to back (no packing kernels).
     gather_in = torch.zeros((2, max_bins_rank), dtype=torch.int64, device=dev)
@@ -160,8 +186,8 @@ def main():
         per[c]["long"] = gather_in[1, r0:r0 + per[c]["nw"]]
         r0 += per[c]["nw"]
     wps_ev = {}
-    per_rank_order = {r: [c for c in names if owner[c] == r] for r in range(world)}
-    per_rank_rows = {r: [int(np.ceil(sizes[c] / WINDOW)) for c in per_rank_order[r]] for r in range(world)}
+    per_rank_order = {r: [ukey(u) for u in units if u[0] == r] for r in range(world)}
+    per_rank_rows = {r: [unit_rows(u) for u in units if u[0] == r] for r in range(world)}
 
     def step(record_events=False):
         row = 0
@@ -182,7 +208,7 @@ def main():
                 if phase in (1, 2):
                     if record_events:
                         eng.event_record(ev)
-                    eng.wps(c, 0, sizes[c], sizes[c], WPS_W, WPS_MIN, WPS_MAX, MAPQ, out=p["wps"])
+                    eng.wps(c, p["a"], p["b"], p["size"], WPS_W, WPS_MIN, WPS_MAX, MAPQ, out=p["wps"])
                     if record_events:
                         eng.event_record(ev + 1)
                         wps_ev[c] = (ev, ev + 1)
@@ -196,12 +222,50 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    # The host enqueues a step (about 100 asynchronous launches) much faster than the GPU runs it; keep at
+    # most two steps in flight (wait for step i-2 before enqueuing step i) so the queue depth does not
+    # grow with --steps.
+    throttle = os.environ.get("FTK_BENCH_THROTTLE", "1") != "0"
+    done_ev = []
+
+    trace = [] if os.environ.get("FTK_BENCH_TRACE") else None
+
+    def run_steps(k, timed):
+        for i in range(k):
+            if throttle and len(done_ev) >= 2:
+                done_ev[-2].synchronize()
+            if trace is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                h0 = time.perf_counter()
+            # the last step carries the per-launch HIP events of the roofline; the last warm-up step does
+            # too, so that the lazily created event slots exist before the timed region starts
+            step(record_events=(i == k - 1))
+            if trace is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(stream)
+                trace.append((timed, time.perf_counter() - h0, e0, e1))
+            if throttle:
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                done_ev.append(ev)
+                del done_ev[:-2]
+
+    # One-time runtime effect, measured on this stack (ROCm 7.2): the ~830th kernel launch of a process stalls
+    # host and GPU for 35-50 ms (seen at step 8 of the 24-contig run and at step 52 of a 4-contig run, never
+    # again in 5 000+ launches).  Setup therefore primes the runtime with untimed steps until that many launches
+    # are behind us, so the stall cannot land in a short warm-up + timed region.  FTK_BENCH_PRIME=0 turns it off.
+    launches_per_step = 4 * len(mine) + 1
+    prime = 0
+    if os.environ.get("FTK_BENCH_PRIME", "1") != "0":
+        prime = min(256, -(-1200 // launches_per_step))
+        run_steps(prime, False)
+        barrier()
+        done_ev.clear()
+    run_steps(args.warmup, False)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(record_events=(i == args.steps - 1))
+    run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -209,6 +273,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt * 1e3 / args.steps
+    if trace is not None and rank == 0:
+        for timed, host_s, e0, e1 in trace:
+            sys.stderr.write(f"step timed={int(timed)} host_enqueue={host_s * 1e3:7.3f} ms  gpu={e0.elapsed_time(e1):7.3f} ms\n")
     value = bins_all * args.steps / dt
 
     # ---- roofline of the dominant kernel (WPS), from the last timed step -------
@@ -216,11 +283,11 @@ def main():
     wps_ms = 0.0
     for c, (a, b) in wps_ev.items():
         wps_ms += eng.event_elapsed_ms(a, b)
-        wps_bytes += 10 * per[c]["n"] + 8 * sizes[c]
+        wps_bytes += 10 * per[c]["n"] + 8 * (per[c]["b"] - per[c]["a"])
     achieved = wps_bytes / (wps_ms * 1e-3) / 1e9 if wps_ms > 0 else 0.0
     traffic = None  # HBM bytes per launch from the committed PMC passes (same workload only)
     tpath = os.path.join(ROOT, "profiles", "wps_traffic.json")
-    if world == 1 and not args.contigs and args.depth == 30.0 and os.path.exists(tpath):
+    if world == 1 and not sim and not args.contigs and args.depth == 30.0 and os.path.exists(tpath):
         traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
     roofline = dict(bound="hbm", kernel="wps_stream_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
@@ -249,7 +316,7 @@ def main():
     if rank == 0:
         cpu = None
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(torch, eng, per, mine, sizes, args.cpu_seconds, checks)
+            cpu = cpu_baseline(torch, eng, per, mine, args.cpu_seconds, checks)
         out = {
             "metric": "genomic windows/sec (coverage+WPS+DELFI) at 30x WGS",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
@@ -260,9 +327,11 @@ def main():
                                    f"{bins_all} x 100 kb windows: coverage + length histogram (1001 bins) + DELFI "
                                    f"short/long (blacklist+gaps) + WPS W=120 every base",
                        "contigs": len(names), "windows": bins_all, "depth": args.depth,
-                       "sharding": f"contigs LPT over {world} GPU(s); all-gather of DELFI bin vector" if world > 1
-                       else "single GPU"},
+                       "sharding": (f"genome cut into {world} equal window-aligned runs ({len(units)} units, halo "
+                                    f"{halo} bp); all-gather of DELFI bin vector") if world > 1
+                       else ("single GPU" if not sim else f"simulated rank {sim} alone")},
             "roofline": roofline, "cpu_baseline": cpu, "checks": checks, "load_s": round(t_load, 2),
+            "priming_steps": prime,
         }
     if use_dist:
         dist.barrier()
@@ -278,12 +347,13 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(torch, eng, per, mine, sizes, budget_s, checks):
+def cpu_baseline(torch, eng, per, mine, budget_s, checks):
     """C oracle (kind "port", 1 core) on a bounded sample of the same workload,
     checked against the GPU results for the same windows."""
     from oracle import oracle as O
     c = mine[-1]
     p = per[c]
+    size, a0 = p["size"], p["a"]  # a partial unit carries every fragment its windows / bases can see
     s, e, q, st = [t.cpu().numpy() for t in p["keep"]]
     fr = O.Frags(s, e, q, st)
     n_s = min(p["nw"], 600)
@@ -300,9 +370,9 @@ def cpu_baseline(torch, eng, per, mine, sizes, budget_s, checks):
     wps_gpu = None
     while done < n_s and (time.perf_counter() - t1) < budget_s:
         a, b = int(ws[done]), int(we[done])
-        ref = np.concatenate([O.c_wps(fr, x, min(x + 5000, b), sizes[c], WPS_W, WPS_MIN, WPS_MAX, MAPQ)
+        ref = np.concatenate([O.c_wps(fr, x, min(x + 5000, b), size, WPS_W, WPS_MIN, WPS_MAX, MAPQ)
                               for x in range(a, b, 5000)])
-        wps_gpu = p["wps"][a:b].cpu().numpy()
+        wps_gpu = p["wps"][a - a0:b - a0].cpu().numpy()
         ok_wps = ok_wps and bool(np.array_equal(ref, wps_gpu))
         done += 1
     t_wps = time.perf_counter() - t1
@@ -326,7 +396,8 @@ def cpu_baseline(torch, eng, per, mine, sizes, budget_s, checks):
     t3 = time.perf_counter()
     n_tiles_py = 2
     for k in range(n_tiles_py):
-        O.py_wps(rows, 5000 * k + 100_000, 5000 * k + 105_000, sizes[c], WPS_W, WPS_MIN, WPS_MAX, MAPQ)
+        x0 = int(ws[1]) + 5000 * k
+        O.py_wps(rows, x0, x0 + 5000, size, WPS_W, WPS_MIN, WPS_MAX, MAPQ)
     t_py_wps = (time.perf_counter() - t3) / n_tiles_py * (WINDOW / 5000)
     return {"value": round(1.0 / per_window, 3), "unit": "windows/s", "cores": 1, "kind": "port",
             "sample": f"C oracle (oracle/ftk_oracle.c, gcc -O2): coverage+hist+DELFI on {n_s} and WPS (5 kb tiles) on "

@@ -147,6 +147,10 @@ int upload_common(ftk_ctx* ctx, int contig_id, const int32_t* start, const int32
     uint8_t* d_strand = (uint8_t*)(base + 2 * b_i32 + b_u8);
     hipStream_t s = ctx->stream;
     hipError_t e = hipMemsetAsync(c.base, 0, total, s);
+    // padding fragments sit at 2^30, beyond every coordinate: no window test accepts them, so the
+    // feature kernels process whole groups of four without bounds checks
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(d_start + n), kPadCoord, n_pad - (size_t)n, s);
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(d_end + n), kPadCoord, n_pad - (size_t)n, s);
     if (e == hipSuccess && n > 0) {
         e = hipMemcpyAsync(d_start, start, n * 4, kind, s);
         if (e == hipSuccess) e = hipMemcpyAsync(d_end, end, n * 4, kind, s);
@@ -406,7 +410,7 @@ int ftk_frags_set_read1(ftk_ctx* ctx, int contig_id, const int32_t* r1_start, co
         c->r1 = nullptr;
     }
     HIPCHK(ctx, hipMalloc((void**)&c->r1, 2 * b));
-    HIPCHK(ctx, hipMemsetAsync(c->r1, 0, 2 * b, ctx->stream));
+    HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)c->r1, kPadCoord, 2 * b / 4, ctx->stream));
     hipMemcpyKind k = is_device_ptr(r1_start) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     if (n > 0) {
         HIPCHK(ctx, hipMemcpyAsync(c->r1, r1_start, n * 4, k, ctx->stream));

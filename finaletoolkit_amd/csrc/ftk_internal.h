@@ -18,6 +18,8 @@ constexpr int kBinShift = 9;
 constexpr int kChunk = 4096;
 // Candidate ranges up to this many fragments are handled one-wave-per-window.
 constexpr int kSmallMax = 1024;
+// start / end of the padding fragments behind every contig's columns (coordinates are < 2^30).
+constexpr int kPadCoord = 1 << 30;
 // Positions per WPS tile.
 constexpr int kWpsTile = 4096;
 

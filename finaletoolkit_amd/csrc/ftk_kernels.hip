@@ -198,23 +198,23 @@ __global__ __launch_bounds__(1024) void plan_kernel(ContigView cv, const int32_t
 // :245 read1 overlap for BAM).  Returns 1 when the fragment counts.
 struct WinPred {
     int mapq_min, min_len, max_len, policy, bam;
+    // Branch-free on purpose: the comparisons become v_cmp + scalar mask logic; a short-circuit chain
+    // costs an exec-mask save / branch per term (the fused pass was ALU-bound on exactly that).
     template <bool BAM>
     __device__ __forceinline__ int test(const ContigView& cv, int i, int fs, int fe, int q, int ws, int we) const {
         const int len = fe - fs;
-        bool ok = (q >= mapq_min) && (len >= min_len) && (len <= max_len);
+        bool ok = (q >= mapq_min) & (len >= min_len) & (len <= max_len);
+        const bool overlap = (fs < we) & (fe > ws);
         if (BAM) {
             const int rs = cv.r1_start[i], re = cv.r1_end[i];
-            ok = ok && (rs < we) && (re > ws);
+            ok &= (rs < we) & (re > ws);
         } else {
-            ok = ok && (fs < we) && (fe > ws);
+            ok &= overlap;
         }
-        if (policy == FTK_POLICY_MIDPOINT) {
-            const int mid = (int)(((unsigned)fs + (unsigned)fe) >> 1);  // coordinates < 2^30
-            ok = ok && (mid >= ws) && (mid < we);
-        } else {
-            ok = ok && (fe > ws) && (fs < we);
-        }
-        return ok ? 1 : 0;
+        const int mid = (int)(((unsigned)fs + (unsigned)fe) >> 1);  // coordinates < 2^30
+        const bool mid_in = (mid >= ws) & (mid < we);
+        ok &= (policy == FTK_POLICY_MIDPOINT) ? mid_in : overlap;
+        return ok;
     }
     __device__ __forceinline__ int operator()(const ContigView& cv, int i, int fs, int fe, int q, int ws, int we,
                                               int /*w*/) const {
@@ -236,27 +236,28 @@ struct DelfiPred {
     const int32_t* bl_pm;   // running maximum of the region stops inside each window
     template <bool BAM>
     __device__ __forceinline__ int test(const ContigView& cv, int i, int fs, int fe, int q, int ws, int we, int o0,
-                                        int o1) const {
+                                        int o1, bool valid = true) const {
         const int len = fe - fs;
         const int mid = (int)(((unsigned)fs + (unsigned)fe) >> 1);  // coordinates < 2^30
-        bool ok = (q >= mapq_min) && (len >= 100) && (len <= 220) && (mid >= ws) && (mid < we);
+        bool ok = valid & (q >= mapq_min) & ((unsigned)(len - 100) <= 120u) & (mid >= ws) & (mid < we);
         if (BAM) {
             const int rs = cv.r1_start[i], re = cv.r1_end[i];
-            ok = ok && (rs < we) && (re > ws);
+            ok &= (rs < we) & (re > ws);
         } else {
-            ok = ok && (fs < we) && (fe > ws);
+            ok &= (fs < we) & (fe > ws);
         }
-        ok = ok && !((fe > cen0) && (fs < cen1)) && !((fe > tel0) && (fs < tel1));
-        if (!ok) return 0;
-        if (o1 > o0) {  // frag/_delfi.py:455-462: blacklisted iff max{r1 : r0 <= fs} > fe
-            int lo = o0, hi = o1;  // upper bound: first region with r0 > fs
-            while (lo < hi) {
-                const int m = (lo + hi) >> 1;
-                if (bl_r0[m] <= fs) lo = m + 1; else hi = m;
+        ok &= !((fe > cen0) & (fs < cen1)) & !((fe > tel0) & (fs < tel1));
+        if (o1 > o0) {  // (uniform per window) frag/_delfi.py:455-462: blacklisted iff max{r1 : r0 <= fs} > fe
+            if (ok) {
+                int lo = o0, hi = o1;  // upper bound: first region with r0 > fs
+                while (lo < hi) {
+                    const int m = (lo + hi) >> 1;
+                    if (bl_r0[m] <= fs) lo = m + 1; else hi = m;
+                }
+                if (lo > o0 && bl_pm[lo - 1] > fe) ok = false;
             }
-            if (lo > o0 && bl_pm[lo - 1] > fe) return 0;
         }
-        return (len >= 151) ? 2 : 1;
+        return ok ? ((len >= 151) ? 2 : 1) : 0;
     }
 };
 
@@ -302,9 +303,13 @@ __device__ __forceinline__ int kmer_code(const MotifParams& M, int lo, bool revc
 //   coverage count + length histogram under `wp`  (frag/_coverage.py:117-130, _frag_length.py:147-153)
 //   DELFI short / long under `dp`                   (frag/_delfi.py:443-472)
 struct FeatParams {
-    WinPred wp;
-    DelfiPred dp;
+    WinPred wp;      // CH == 2 (motif pass) and the host-side description of the filter
+    DelfiPred dp;    // blacklist CSR pointers (bl_*) are read from here
     MotifParams mp;  // CH == 2
+    // CH == 1 / DF: sign-test constants, clamped on the host so that no difference below can overflow
+    // (coordinates are < 2^30, launch_window_features)
+    int ch_q, ch_min, ch_max, is_any;
+    int df_q, cen0, cen1, tel0, tel1;
     int do_cov, do_hist;
     int len_lo, n_bins;
     int64_t* cov_out;
@@ -314,27 +319,67 @@ struct FeatParams {
     int64_t* long_out;
 };
 
+// cov / sh / lg count REJECTED elements for CH == 1 / DF (passing = processed - rejected) and passing ones
+// for CH == 2; over: motif errors (CH == 2; the length histogram keeps its overflow in an extra LDS bin).
 struct FeatAcc {
-    int cov = 0, over = 0, sh = 0, lg = 0;
+    int n = 0, cov = 0, over = 0, sh = 0, lg = 0;
 };
 
-template <int CH, bool DF, bool BAM>
+// Every predicate of the coverage / histogram / DELFI pass is a conjunction of "a >= b" terms.  Each term is
+// written as a difference that is non-negative when it holds; OR-ing the differences leaves the sign bit
+// clear exactly when all hold ((a & b) >= 0 is "a >= 0 or b >= 0").  That is ~2 VALU operations per term and
+// no scalar mask logic or branches: the compare + s_and form of the same tests was issue-bound at
+// ~100 instructions per 64 fragments.  ws is the window start clamped to >= -1, we1 = min(window stop, 2^30) - 1.
+template <int CH, bool DF, bool BAM, bool BL>
 __device__ __forceinline__ void feat_element(const ContigView& cv, const FeatParams& P, int idx, int fs, int fe, int q,
-                                             int ws, int we, int o0, int o1, uint32_t* h, FeatAcc& a) {
-    if (CH == 1) {
-        if (P.wp.test<BAM>(cv, idx, fs, fe, q, ws, we)) {
-            ++a.cov;
-            if (P.do_hist) {
-                const int b = (fe - fs) - P.len_lo;
-                if (b >= 0 && b < P.n_bins) atomicAdd(&h[b], 1u); else ++a.over;
+                                             int ws, int we1, int o0, int o1, uint32_t* h, FeatAcc& a, bool valid) {
+    if (CH == 1 || DF) {
+        const int len = fe - fs;
+        const int mid = (int)(((unsigned)fs + (unsigned)fe) >> 1);
+        const int t_mid = (mid - ws) | (we1 - mid);  // ws <= mid < we  (implies fs < we)
+        const int t_lo = fe - 1 - ws;                // fe > ws
+        int t_fetch;                                 // the index query that produced the stream
+        if (BAM) {
+            const int rs = cv.r1_start[idx], re = cv.r1_end[idx];
+            t_fetch = (we1 - rs) | (re - 1 - ws);    // read1 overlaps the window (io/alignment.py:245)
+        } else {
+            t_fetch = t_lo;                          // with t_mid: the fragment overlaps it (:270-279)
+        }
+        if (CH == 1) {
+            int x = (q - P.ch_q) | (len - P.ch_min) | (P.ch_max - len);
+            const int t_any = t_lo | (we1 - fs);     // utils/_frag_generator.py:44-50
+            x |= P.is_any ? (BAM ? (t_any | t_fetch) : t_any) : (t_mid | t_fetch);
+            const unsigned bad = (unsigned)x >> 31;
+            a.cov += bad;
+            if (P.do_hist) {  // out-of-range lengths land in bin n_bins (the overflow count)
+                const unsigned b = min((unsigned)(len - P.len_lo), (unsigned)P.n_bins);
+                atomicAdd(&h[b], bad ^ 1u);
             }
         }
+        if (DF) {  // frag/_delfi.py:443-472
+            int y = (q - P.df_q) | (len - 100) | (220 - len) | t_mid | t_fetch;
+            y |= (P.cen0 - fe) & (fs - P.cen1);      // not (fe > cen0 and fs < cen1)
+            y |= (P.tel0 - fe) & (fs - P.tel1);
+            if (BL) {  // blacklisted iff max{r1 : r0 <= fs, region inside the window} > fe (:455-462)
+                if (y >= 0) {
+                    int lo = o0, hi = o1;  // upper bound: first region with r0 > fs
+                    while (lo < hi) {
+                        const int m = (lo + hi) >> 1;
+                        if (P.dp.bl_r0[m] <= fs) lo = m + 1; else hi = m;
+                    }
+                    if (lo > o0 && P.dp.bl_pm[lo - 1] > fe) y = -1;
+                }
+            }
+            a.sh += (unsigned)(y | (150 - len)) >> 31;
+            a.lg += (unsigned)(y | (len - 151)) >> 31;
+        }
+        a.n += 1;
     }
     if (CH == 2) {
         // frag/_end_motifs.py:118-176, frag/_breakpoint_motifs.py:124-185: every fetched fragment
         // (index overlap + mapq only) contributes the k-mer at its start and / or the reverse
-        // complement of the k-mer at its stop
-        if (P.wp.test<BAM>(cv, idx, fs, fe, q, ws, we)) {
+        // complement of the k-mer at its stop.  ws / we1 are the raw window bounds here.
+        if (valid && P.wp.test<BAM>(cv, idx, fs, fe, q, ws, we1)) {
             ++a.cov;
             const MotifParams& M = P.mp;
             bool skip = M.guard > 0 && (fs - M.guard < 0 || fs + M.guard >= M.chrom_len);
@@ -362,11 +407,27 @@ __device__ __forceinline__ void feat_element(const ContigView& cv, const FeatPar
             }
         }
     }
-    if (DF) {
-        const int r = P.dp.test<BAM>(cv, idx, fs, fe, q, ws, we, o0, o1);
-        a.sh += (r == 1);
-        a.lg += (r == 2);
-    }
+}
+
+// Window bounds as the element tests want them.
+template <int CH>
+__device__ __forceinline__ void window_bounds(int ws_raw, int we_raw, int& ws, int& we1) {
+    if (CH == 2) { ws = ws_raw; we1 = we_raw; return; }
+    ws = max(ws_raw, -1);
+    we1 = min(max(we_raw, -1), 1 << 30) - 1;
+}
+
+// Four fragments (one 16-byte load per column).  Fragments of the group outside [lo, hi) are real
+// neighbours or padding (start = end = 2^30): both fail every window test, so CH == 1 / DF need no
+// bounds check; the motif pass keeps one.
+template <int CH, bool DF, bool BAM, bool BL>
+__device__ __forceinline__ void feat_group(const ContigView& cv, const FeatParams& P, int i, int hi, const int4& s,
+                                           const int4& e, const uchar4& q, int ws, int we1, int o0, int o1,
+                                           uint32_t* h, FeatAcc& a) {
+    const int ss[4] = {s.x, s.y, s.z, s.w}, ee[4] = {e.x, e.y, e.z, e.w}, qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        feat_element<CH, DF, BAM, BL>(cv, P, i + j, ss[j], ee[j], qq[j], ws, we1, o0, o1, h, a, i + j < hi);
 }
 
 // ---------------------------------------------------------------------------
@@ -392,10 +453,11 @@ __global__ __launch_bounds__(256) void feat_small_kernel(ContigView cv, const in
         return;
     }
     const int lo = cand_lo[w], hi = cand_hi[w];
-    const int ws = ws_[w], we = we_[w];
-    uint32_t* h = lds_hist + (size_t)wv * P.n_bins;
+    int ws, we1;
+    window_bounds<CH>(ws_[w], we_[w], ws, we1);
+    uint32_t* h = lds_hist + (size_t)wv * (P.n_bins + 1);
     if (hist && lo < hi) {
-        for (int b = lane; b < P.n_bins; b += 64) h[b] = 0;
+        for (int b = lane; b <= P.n_bins; b += 64) h[b] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -406,28 +468,29 @@ __global__ __launch_bounds__(256) void feat_small_kernel(ContigView cv, const in
         const int4 s = *reinterpret_cast<const int4*>(cv.start + i);
         const int4 e = *reinterpret_cast<const int4*>(cv.end + i);
         const uchar4 q = *reinterpret_cast<const uchar4*>(cv.mapq + i);
-        const int ss[4] = {s.x, s.y, s.z, s.w}, ee[4] = {e.x, e.y, e.z, e.w}, qq[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i + j < hi) feat_element<CH, DF, BAM>(cv, P, i + j, ss[j], ee[j], qq[j], ws, we, o0, o1, h, a);
+        if (DF && o1 > o0) feat_group<CH, DF, BAM, true>(cv, P, i, hi, s, e, q, ws, we1, o0, o1, h, a);
+        else feat_group<CH, DF, BAM, false>(cv, P, i, hi, s, e, q, ws, we1, o0, o1, h, a);
     }
+    int over = 0;
     if (hist && lo < hi) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint32_t* dst = P.hist_out + (size_t)w * P.n_bins;
         for (int b = lane; b < P.n_bins; b += 64) dst[b] = h[b];  // full row: no pre-fill needed
+        if (CH == 1) over = (int)h[P.n_bins];
     } else if (hist) {
         uint32_t* dst = P.hist_out + (size_t)w * P.n_bins;
         for (int b = lane; b < P.n_bins; b += 64) dst[b] = 0;
     }
+    a.n = wave_reduce_add(a.n);
     a.cov = wave_reduce_add(a.cov);
-    a.over = wave_reduce_add(a.over);
+    if (CH == 2) over = wave_reduce_add(a.over);
     a.sh = wave_reduce_add(a.sh);
     a.lg = wave_reduce_add(a.lg);
     if (lane == 0) {
-        if (CH && P.do_cov) P.cov_out[w] = a.cov;
-        if (hist) P.over_out[w] = a.over;
-        if (DF) { P.short_out[w] = a.sh; P.long_out[w] = a.lg; }
+        if (CH && P.do_cov) P.cov_out[w] = CH == 1 ? a.n - a.cov : a.cov;
+        if (hist) P.over_out[w] = over;
+        if (DF) { P.short_out[w] = a.n - a.sh; P.long_out[w] = a.n - a.lg; }
     }
 }
 
@@ -436,12 +499,35 @@ __global__ __launch_bounds__(256) void feat_small_kernel(ContigView cv, const in
 // chunks in order; a block keeps accumulating while the window stays the same
 // and issues one atomic per counter per (block, window).
 // ---------------------------------------------------------------------------
+template <int CH, bool DF, bool BAM, bool BL>
+__device__ __forceinline__ void feat_chunk(const ContigView& cv, const FeatParams& P, int lo, int hi, int tid, int ws,
+                                           int we1, int o0, int o1, uint32_t* h, FeatAcc& a) {
+    // a whole chunk (4 x 1024 fragments) is requested before any of it is used
+    const int i0 = lo + 4 * tid;
+    int4 s4[4], e4[4];
+    uchar4 q4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 1024;
+        if (i < hi) {
+            s4[u] = *reinterpret_cast<const int4*>(cv.start + i);
+            e4[u] = *reinterpret_cast<const int4*>(cv.end + i);
+            q4[u] = *reinterpret_cast<const uchar4*>(cv.mapq + i);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 1024;
+        if (i < hi) feat_group<CH, DF, BAM, BL>(cv, P, i, hi, s4[u], e4[u], q4[u], ws, we1, o0, o1, h, a);
+    }
+}
+
 template <int CH, bool DF, bool BAM>
 __global__ __launch_bounds__(256) void feat_large_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
                                                          int n_win, const int32_t* cand_lo, const int32_t* cand_hi,
                                                          const uint32_t* chunk_off, FeatParams P) {
     extern __shared__ uint32_t lds_hist[];
-    __shared__ int red[4][4];
+    __shared__ int red[5][4];
     const uint32_t total = chunk_off[n_win];
     const uint32_t c0 = (uint32_t)(((unsigned long long)total * blockIdx.x) / gridDim.x);
     const uint32_t c1 = (uint32_t)(((unsigned long long)total * (blockIdx.x + 1)) / gridDim.x);
@@ -449,7 +535,7 @@ __global__ __launch_bounds__(256) void feat_large_kernel(ContigView cv, const in
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool hist = CH && P.do_hist;
     if (hist) {
-        for (int b = tid; b < P.n_bins; b += 256) lds_hist[b] = 0;
+        for (int b = tid; b <= P.n_bins; b += 256) lds_hist[b] = 0;
         __syncthreads();
     }
     int w;
@@ -466,7 +552,8 @@ __global__ __launch_bounds__(256) void feat_large_kernel(ContigView cv, const in
     while (c < c1) {
         const uint32_t w_first = chunk_off[w], w_next = chunk_off[w + 1];
         if (c >= w_next) { ++w; continue; }
-        const int ws = ws_[w], we = we_[w];
+        int ws, we1;
+        window_bounds<CH>(ws_[w], we_[w], ws, we1);
         const int wlo = cand_lo[w], whi = cand_hi[w];
         int o0 = 0, o1 = 0;
         if (DF && P.dp.bl_off) { o0 = P.dp.bl_off[w]; o1 = P.dp.bl_off[w + 1]; }
@@ -474,32 +561,8 @@ __global__ __launch_bounds__(256) void feat_large_kernel(ContigView cv, const in
         for (; c < c_end; ++c) {
             const int lo = wlo + (int)(c - w_first) * kChunk;  // multiple of 4 (planner)
             const int hi = min(lo + kChunk, whi);
-            // a whole chunk (4 x 1024 fragments) is requested before any of it is used
-            const int i0 = lo + 4 * tid;
-            int4 s4[4], e4[4];
-            uchar4 q4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 1024;
-                if (i < hi) {
-                    s4[u] = *reinterpret_cast<const int4*>(cv.start + i);
-                    e4[u] = *reinterpret_cast<const int4*>(cv.end + i);
-                    q4[u] = *reinterpret_cast<const uchar4*>(cv.mapq + i);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 1024;
-                if (i < hi) {
-                    const int ss[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w};
-                    const int ee[4] = {e4[u].x, e4[u].y, e4[u].z, e4[u].w};
-                    const int qq[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (i + j < hi)
-                            feat_element<CH, DF, BAM>(cv, P, i + j, ss[j], ee[j], qq[j], ws, we, o0, o1, lds_hist, a);
-                }
-            }
+            if (DF && o1 > o0) feat_chunk<CH, DF, BAM, true>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
+            else feat_chunk<CH, DF, BAM, false>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
         }
         // ---- flush this window's partial results -------------------------------------
         if (hist) {
@@ -510,14 +573,18 @@ __global__ __launch_bounds__(256) void feat_large_kernel(ContigView cv, const in
                 if (v) { atomicAdd(&dst[b], v); lds_hist[b] = 0; }
             }
         }
+        a.n = wave_reduce_add(a.n);
         a.cov = wave_reduce_add(a.cov);
         a.over = wave_reduce_add(a.over);
         a.sh = wave_reduce_add(a.sh);
         a.lg = wave_reduce_add(a.lg);
-        if (lane == 0) { red[0][wv] = a.cov; red[1][wv] = a.over; red[2][wv] = a.sh; red[3][wv] = a.lg; }
+        if (lane == 0) { red[0][wv] = a.cov; red[1][wv] = a.over; red[2][wv] = a.sh; red[3][wv] = a.lg; red[4][wv] = a.n; }
         __syncthreads();
         if (tid < 4) {
-            const int t = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+            int t = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+            const int n = red[4][0] + red[4][1] + red[4][2] + red[4][3];
+            if (tid == 1 && CH == 1 && hist) { t = (int)lds_hist[P.n_bins]; lds_hist[P.n_bins] = 0; }
+            else if (tid != 1 && (CH == 1 || tid >= 2)) t = n - t;  // rejected -> passing
             int64_t* dst = tid == 0 ? (CH && P.do_cov ? P.cov_out : nullptr)
                          : tid == 1 ? (hist ? P.over_out : nullptr)
                          : tid == 2 ? (DF ? P.short_out : nullptr) : (DF ? P.long_out : nullptr);
@@ -1032,7 +1099,7 @@ static WinPred make_win_pred(const ftk_filter& f) {
 template <int CH, bool DF, bool BAM>
 static void launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
                           int n_win, const WindowPlan& pl, const FeatParams& P, bool small_path) {
-    const size_t lds1 = (CH && P.do_hist) ? (size_t)P.n_bins * sizeof(uint32_t) : 0;
+    const size_t lds1 = (CH && P.do_hist) ? (size_t)(P.n_bins + 1) * sizeof(uint32_t) : 0;  // + overflow bin
     if (small_path)
         hipLaunchKernelGGL((feat_small_kernel<CH, DF, BAM>), dim3((n_win + 3) / 4), dim3(256), 4 * lds1, s, cv, ws, we,
                            n_win, pl.cand_lo, pl.cand_hi, pl.nchunks, P);
@@ -1074,6 +1141,21 @@ void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv,
             }
         }
         P.dp = DelfiPred{r.delfi_mapq_min, cen0, cen1, tel0, tel1, r.bl_off, r.bl_r0, r.bl_pm};
+        // the sign-test form of the same bounds: every value the kernels subtract from a coordinate
+        // (0 <= c < 2^30) is clamped to [-1, 2^30 + 1], which keeps each comparison's outcome
+        auto clamp_c = [](int v) { return std::min(std::max(v, -1), (1 << 30) + 1); };
+        P.cen0 = clamp_c(cen0);
+        P.cen1 = clamp_c(cen1);
+        P.tel0 = clamp_c(tel0);
+        P.tel1 = clamp_c(tel1);
+        P.df_q = std::min(std::max(r.delfi_mapq_min, 0), 256);
+    }
+    if (r.filter) {
+        const ftk_filter& f = *r.filter;
+        P.ch_q = std::min(std::max(f.mapq_min, 0), 256);
+        P.ch_min = f.min_len < 0 ? 0 : std::min(f.min_len, 1 << 30);
+        P.ch_max = f.max_len < 0 ? (1 << 30) : std::min(f.max_len, 1 << 30);
+        P.is_any = f.policy == FTK_POLICY_ANY;
     }
     const bool bam = cv.r1_start != nullptr && (!r.filter || r.filter->fetch_mode == FTK_FETCH_BAM_READ1);
 #define FTK_FEAT(CH, DF)                                                                              \

@@ -235,3 +235,34 @@ def test_contig_ids_are_not_reused_after_release(engine):
         assert engine.frag_select(k, None, None, 0)[0].tolist() == [v]
     for k in ("idB", "idC", "idD"):
         engine.release(k)
+
+
+@pytest.mark.parametrize("world", [2, 3, 7])
+def test_split_units_reproduce_the_whole_contig(engine, data, world):
+    """bench.py's multi-GPU split: a unit loaded with its halo of fragments gives exactly the
+    whole contig's windows / bases of its range (features under the midpoint policy, DELFI, WPS)."""
+    from finaletoolkit_amd.sharding import split_units, unit_halo
+    ws, we = synth.tiling_windows(CONTIG_LEN, 100_000)
+    rng = np.random.default_rng(3)
+    bl_s = np.sort(rng.integers(0, CONTIG_LEN - 5000, 80)).astype(np.int32)
+    bl_e = (bl_s + rng.integers(100, 4000, 80)).astype(np.int32)
+    gaps = (1_200_000, 1_500_000, [(0, 10_000), (CONTIG_LEN - 10_000, CONTIG_LEN)])
+    whole = engine.window_features("synA", ws, we, 30, hist=(0, 1001), delfi=dict(bl_start=bl_s, bl_end=bl_e, gaps=gaps))
+    whole_wps = engine.wps("synA", 0, CONTIG_LEN, CONTIG_LEN)
+    halo = unit_halo(int((data["e"] - data["s"]).max()), 120)
+    parts = {k: [] for k in whole}
+    wps_parts = []
+    for r, c, a, b in split_units({"synA": CONTIG_LEN}, world, 100_000):
+        lo, hi = np.searchsorted(data["s"], [a - halo, b + halo])
+        name = f"unit{r}"
+        engine.load_contig(name, data["s"][lo:hi], data["e"][lo:hi], data["q"][lo:hi], data["st"][lo:hi])
+        m = (ws >= a) & (ws < b)
+        got = engine.window_features(name, ws[m], we[m], 30, hist=(0, 1001),
+                                     delfi=dict(bl_start=bl_s, bl_end=bl_e, gaps=gaps))
+        for k in whole:
+            parts[k].append(got[k])
+        wps_parts.append(engine.wps(name, a, b, CONTIG_LEN))
+        engine.release(name)
+    for k in whole:
+        assert np.array_equal(np.concatenate(parts[k]), whole[k]), k
+    assert np.array_equal(np.concatenate(wps_parts), whole_wps)

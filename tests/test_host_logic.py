@@ -163,3 +163,28 @@ def test_cli_flag_surface():
                       "--short-threshold", "150"])
     assert (a.contig, a.start, a.stop, a.bin_size, a.summary_stats, a.short_fraction) == ("1", 5, 9, 5, True, 150)
     assert p.parse_args(["frag-length-intervals", "in", "iv"]).short_reads == 150
+
+
+def test_split_units_partition_and_balance():
+    from finaletoolkit_amd import synth
+    from finaletoolkit_amd.sharding import split_units, unit_halo
+    sizes = dict(synth.B37_SIZES)
+    genome = sum(sizes.values())
+    assert split_units(sizes, 1, 100_000) == [(0, c, 0, n) for c, n in sizes.items()]
+    for world in (2, 3, 4, 8, 16):
+        units = split_units(sizes, world, 100_000)
+        ranges = {}
+        for r, c, a, b in units:
+            assert 0 <= r < world and a % 100_000 == 0 and a < b <= sizes[c]
+            ranges.setdefault(c, []).append((a, b))
+        for c, v in ranges.items():  # every contig covered exactly once, in order
+            assert v[0][0] == 0 and v[-1][1] == sizes[c]
+            assert all(v[i][1] == v[i + 1][0] for i in range(len(v) - 1))
+        assert [u[0] for u in units] == sorted(u[0] for u in units)  # ranks own contiguous runs
+        loads = [sum(b - a for r, _, a, b in units if r == k) for k in range(world)]
+        assert genome / world / max(loads) > 0.999
+    assert unit_halo(1000, 120) == 1120
+    # more ranks than windows: every window still has exactly one owner
+    tiny = split_units({"a": 250_000, "b": 90_000}, 8, 100_000)
+    assert sorted((c, a, b) for _, c, a, b in tiny) == [("a", 0, 100_000), ("a", 100_000, 200_000),
+                                                        ("a", 200_000, 250_000), ("b", 0, 90_000)]
