@@ -242,7 +242,7 @@ size_t window_scratch_bytes(int64_t n_win) {
 }
 
 int window_prepare(ftk_ctx* ctx, ContigData* c, Arena& a, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
-                   int lmax, int small_max, WindowCall* wc, int64_t* const zero[4] = nullptr) {
+                   int lmax, int small_max, WindowCall* wc, int64_t* const zero[4] = nullptr, bool plan = true) {
     int32_t* b_ws = a.take<int32_t>(n_win);
     int32_t* b_we = a.take<int32_t>(n_win);
     wc->plan.cand_lo = a.take<int32_t>(n_win);
@@ -253,8 +253,24 @@ int window_prepare(ftk_ctx* ctx, ContigData* c, Arena& a, const int32_t* w_start
     if (rc) return rc;
     rc = stage_in(ctx, w_end, n_win, b_we, &wc->d_we);
     if (rc) return rc;
-    launch_plan(ctx->stream, c->v, wc->d_ws, wc->d_we, (int)n_win, lmax, small_max, wc->plan, zero);
+    if (plan) launch_plan(ctx->stream, c->v, wc->d_ws, wc->d_we, (int)n_win, lmax, small_max, wc->plan, zero);
     return FTK_OK;
+}
+
+// Many windows of similar length (a bin tiling): one block per window balances well and needs no
+// plan.  Host window arrays only (device arrays take the planned path: nothing is known about them here).
+bool windows_suit_block_path(const ftk_ctx* ctx, const int32_t* ws, const int32_t* we, int64_t n_win) {
+    static const int force = getenv("FTK_FEAT_BLOCK") ? atoi(getenv("FTK_FEAT_BLOCK")) : -1;
+    if (force >= 0) return force != 0;
+    if (n_win < ctx->n_cu) return false;
+    long long total = 0, longest = 0;
+    for (int64_t i = 0; i < n_win; ++i) {
+        const long long len = (long long)we[i] - (long long)ws[i];
+        if (len <= 0) continue;
+        total += len;
+        longest = std::max(longest, len);
+    }
+    return total > 0 && longest * n_win <= 8 * total;
 }
 
 }  // namespace
@@ -599,19 +615,22 @@ int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const i
     if (ch) lmax = std::max(lmax, eff_lmax(fc.f, *c));
     if (fc.delfi) lmax = std::max(lmax, std::max(0, std::min(220, c->max_len)));
     const bool small_path = !(fc.hist_out && fc.n_bins > kHistSmallMaxBins);
+    const bool block_path = !is_device_ptr(w_start) && !is_device_ptr(w_end) &&
+                            windows_suit_block_path(ctx, w_start, w_end, n_win);
     WindowCall wc;
     int64_t* zero[4] = {r.cov_out, r.short_out, r.long_out, nullptr};
     if ((rc = window_prepare(ctx, c, a, meta ? meta->d_ws : w_start, meta ? meta->d_we : w_end, n_win, lmax,
-                             small_path ? kSmallMax : -1, &wc, zero)))
+                             small_path ? kSmallMax : -1, &wc, zero, !block_path)))
         return rc;
-    if (r.hist_out && !small_path) {  // with the wave-per-window pass on, it writes / clears every row itself
+    if (r.hist_out && !small_path && !block_path) {  // with the wave-per-window pass on, it writes / clears every row itself
         HIPCHK(ctx, hipMemsetAsync(r.hist_out, 0, hist_elems * 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(r.over_out, 0, n_win * 8, ctx->stream));
     }
     // blocks per CU of the chunk walker: 8 are resident, 32 give shorter per-block chunk ranges and a
     // smoother tail (measured best of 2..256 on the whole-genome bench); FTK_FEAT_BPC for experiments
     static const int bpc = getenv("FTK_FEAT_BPC") ? atoi(getenv("FTK_FEAT_BPC")) : 32;
-    launch_window_features(ctx->stream, ctx->n_cu * bpc, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, r, small_path);
+    launch_window_features(ctx->stream, ctx->n_cu * bpc, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, r, small_path,
+                           block_path ? lmax : -1);
     if (d_nfrag) launch_add_i64(ctx->stream, r.short_out, r.long_out, d_nfrag, (int)n_win);
     HIPCHK(ctx, hipGetLastError());
     bool host_out = false;

@@ -77,8 +77,11 @@ struct FeatureRequest {
     // motif histogram instead of the length histogram (hist_out = [n_win][4^k], over_out = errors)
     const MotifParams* motif = nullptr;
 };
+// block_lmax >= 0: one block per window (feat_block_kernel, needs no plan and no zeroed outputs), with
+// block_lmax = longest fragment any requested feature can accept; < 0: the planned small + chunked passes.
 void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
-                            int n_win, const WindowPlan& pl, const FeatureRequest& r, bool small_path);
+                            int n_win, const WindowPlan& pl, const FeatureRequest& r, bool small_path,
+                            int block_lmax = -1);
 void launch_add_i64(hipStream_t s, const int64_t* a, const int64_t* b, int64_t* out, int n);
 void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t n_tiles, const int64_t* iv_start,
                 const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv, const int32_t* tile_k,

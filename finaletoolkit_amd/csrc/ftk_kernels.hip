@@ -595,6 +595,96 @@ __global__ __launch_bounds__(256) void feat_large_kernel(ContigView cv, const in
     }
 }
 
+// The whole candidate range [lo, hi) of a window as a software pipeline of 1024-fragment slabs
+// (256 threads x 4 fragments): four slabs are requested up front and each slab's registers are
+// re-filled with the slab four ahead as soon as it has been consumed, so three to four 16-byte
+// loads per column stay in flight behind the arithmetic for the whole range.
+template <int CH, bool DF, bool BAM, bool BL>
+__device__ __forceinline__ void feat_stream(const ContigView& cv, const FeatParams& P, int lo, int hi, int tid, int ws,
+                                            int we1, int o0, int o1, uint32_t* h, FeatAcc& a) {
+    int4 s4[4], e4[4];
+    uchar4 q4[4];
+    const int i0 = lo + 4 * tid;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 1024;
+        if (i < hi) {
+            s4[u] = *reinterpret_cast<const int4*>(cv.start + i);
+            e4[u] = *reinterpret_cast<const int4*>(cv.end + i);
+            q4[u] = *reinterpret_cast<const uchar4*>(cv.mapq + i);
+        }
+    }
+    for (int base = i0; base < hi; base += 4096) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * 1024;
+            if (i < hi) {
+                const int4 s = s4[u], e = e4[u];
+                const uchar4 q = q4[u];
+                const int nxt = i + 4096;
+                if (nxt < hi) {
+                    s4[u] = *reinterpret_cast<const int4*>(cv.start + nxt);
+                    e4[u] = *reinterpret_cast<const int4*>(cv.end + nxt);
+                    q4[u] = *reinterpret_cast<const uchar4*>(cv.mapq + nxt);
+                }
+                feat_group<CH, DF, BAM, BL>(cv, P, i, hi, s, e, q, ws, we1, o0, o1, h, a);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// window features, block path: one block per window, no planning pass.  Used when the windows are
+// many and of similar length (bin tilings): the block derives its window's candidate range from
+// the 512-bp index itself, walks it in 4096-fragment chunks and OWNS the window's outputs -- plain
+// stores, nothing to zero beforehand, no atomics.  One launch per call instead of three.
+// ---------------------------------------------------------------------------
+template <int CH, bool DF, bool BAM>
+__global__ __launch_bounds__(256) void feat_block_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
+                                                         int n_win, int lmax, FeatParams P) {
+    extern __shared__ uint32_t lds_hist[];
+    __shared__ int red[5][4];
+    const int w = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool hist = CH && P.do_hist;
+    int lo, hi;
+    uint32_t nc;
+    window_candidates(cv, ws_[w], we_[w], lmax, -1, lo, hi, nc);
+    if (hist) {
+        for (int b = tid; b <= P.n_bins; b += 256) lds_hist[b] = 0;
+        __syncthreads();
+    }
+    int ws, we1;
+    window_bounds<CH>(ws_[w], we_[w], ws, we1);
+    int o0 = 0, o1 = 0;
+    if (DF && P.dp.bl_off) { o0 = P.dp.bl_off[w]; o1 = P.dp.bl_off[w + 1]; }
+    FeatAcc a;
+    if (DF && o1 > o0) feat_stream<CH, DF, BAM, true>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
+    else feat_stream<CH, DF, BAM, false>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
+    if (hist) {
+        __syncthreads();
+        uint32_t* dst = P.hist_out + (size_t)w * P.n_bins;
+        for (int b = tid; b < P.n_bins; b += 256) dst[b] = lds_hist[b];
+    }
+    a.n = wave_reduce_add(a.n);
+    a.cov = wave_reduce_add(a.cov);
+    a.over = wave_reduce_add(a.over);
+    a.sh = wave_reduce_add(a.sh);
+    a.lg = wave_reduce_add(a.lg);
+    if (lane == 0) { red[0][wv] = a.cov; red[1][wv] = a.over; red[2][wv] = a.sh; red[3][wv] = a.lg; red[4][wv] = a.n; }
+    __syncthreads();
+    if (tid < 4) {
+        int t = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+        const int n = red[4][0] + red[4][1] + red[4][2] + red[4][3];
+        if (tid == 1 && CH == 1 && hist) t = (int)lds_hist[P.n_bins];
+        else if (tid != 1 && (CH == 1 || tid >= 2)) t = n - t;  // rejected -> passing
+        int64_t* dst = tid == 0 ? (CH && P.do_cov ? P.cov_out : nullptr)
+                     : tid == 1 ? (hist ? P.over_out : nullptr)
+                     : tid == 2 ? (DF ? P.short_out : nullptr) : (DF ? P.long_out : nullptr);
+        if (dst) dst[w] = t;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // WPS (frag/_wps.py:25-53,156-188): LDS difference array + scan per tile
 // ---------------------------------------------------------------------------
@@ -1098,8 +1188,13 @@ static WinPred make_win_pred(const ftk_filter& f) {
 
 template <int CH, bool DF, bool BAM>
 static void launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
-                          int n_win, const WindowPlan& pl, const FeatParams& P, bool small_path) {
+                          int n_win, const WindowPlan& pl, const FeatParams& P, bool small_path, int block_lmax) {
     const size_t lds1 = (CH && P.do_hist) ? (size_t)(P.n_bins + 1) * sizeof(uint32_t) : 0;  // + overflow bin
+    if (block_lmax >= 0) {
+        hipLaunchKernelGGL((feat_block_kernel<CH, DF, BAM>), dim3(n_win), dim3(256), lds1, s, cv, ws, we, n_win,
+                           block_lmax, P);
+        return;
+    }
     if (small_path)
         hipLaunchKernelGGL((feat_small_kernel<CH, DF, BAM>), dim3((n_win + 3) / 4), dim3(256), 4 * lds1, s, cv, ws, we,
                            n_win, pl.cand_lo, pl.cand_hi, pl.nchunks, P);
@@ -1111,7 +1206,7 @@ static void launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, c
 // short/long.  With small_path the wave-per-window kernel writes or clears every histogram row;
 // without it hist_out / over_out must be zero-filled by the caller.
 void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
-                            int n_win, const WindowPlan& pl, const FeatureRequest& r, bool small_path) {
+                            int n_win, const WindowPlan& pl, const FeatureRequest& r, bool small_path, int block_lmax) {
     FeatParams P{};
     const bool ch = r.cov_out || r.hist_out;
     const bool df = r.short_out != nullptr;
@@ -1160,8 +1255,8 @@ void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv,
     const bool bam = cv.r1_start != nullptr && (!r.filter || r.filter->fetch_mode == FTK_FETCH_BAM_READ1);
 #define FTK_FEAT(CH, DF)                                                                              \
     do {                                                                                              \
-        if (bam) launch_feat_t<CH, DF, true>(s, grid_large, cv, ws, we, n_win, pl, P, small_path);    \
-        else launch_feat_t<CH, DF, false>(s, grid_large, cv, ws, we, n_win, pl, P, small_path);       \
+        if (bam) launch_feat_t<CH, DF, true>(s, grid_large, cv, ws, we, n_win, pl, P, small_path, block_lmax);  \
+        else launch_feat_t<CH, DF, false>(s, grid_large, cv, ws, we, n_win, pl, P, small_path, block_lmax);     \
     } while (0)
     if (r.motif) {
         P.mp = *r.motif;
