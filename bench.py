@@ -131,6 +131,16 @@ def main():
     t_load = time.time()
     per = {}
     cached = (None, None)
+    # One buffer per output for the whole rank (its units back to back): the batched launches write rows
+    # / bases by global index, the per-unit calls get views.
+    rows_rank = sum(-(-u[3] // WINDOW) - u[2] // WINDOW for u in mine)
+    pad32 = lambda n: (n + 31) // 32 * 32  # every unit's scores start 256-byte aligned (16-byte vector stores)
+    bases_rank = sum(pad32(u[3] - u[2]) for u in mine)
+    all_cov = torch.zeros(rows_rank, dtype=torch.int64, device=dev)
+    all_hist = torch.zeros((rows_rank, HIST_BINS), dtype=torch.int32, device=dev)
+    all_over = torch.zeros(rows_rank, dtype=torch.int64, device=dev)
+    all_wps = torch.empty(bases_rank, dtype=torch.int64, device=dev)
+    row0 = base0 = 0
     for u in mine:
         _, c, a, b = u
         ci = names.index(c)
@@ -155,12 +165,12 @@ def main():
             contig=c, a=a, b=b, size=sizes[c],
             n=n, ws=ws, we=we, nw=nw, bl=(bl_s, bl_e), gaps=synth_gaps(sizes[c]),
             d_ws=torch.from_numpy(ws).to(dev), d_we=torch.from_numpy(we).to(dev),
-            cov=torch.zeros(nw, dtype=torch.int64, device=dev),
-            hist=torch.zeros((nw, HIST_BINS), dtype=torch.int32, device=dev),
-            over=torch.zeros(nw, dtype=torch.int64, device=dev),
-            wps=torch.empty(b - a, dtype=torch.int64, device=dev),
+            cov=all_cov[row0:row0 + nw], hist=all_hist[row0:row0 + nw], over=all_over[row0:row0 + nw],
+            wps=all_wps[base0:base0 + (b - a)], wps_off=base0,
             keep=(s, e, q, st) if u == mine[-1] else None,
         )
+        row0 += nw
+        base0 += pad32(b - a)
         del s, e, q, st
     cached = (None, None)
     mine = [ukey(u) for u in mine]
@@ -189,7 +199,55 @@ def main():
     per_rank_order = {r: [ukey(u) for u in units if u[0] == r] for r in range(world)}
     per_rank_rows = {r: [unit_rows(u) for u in units if u[0] == r] for r in range(world)}
 
+    # Launch shape.  Per unit (default for large units): features(c) then WPS(c), so WPS finds the contig's
+    # columns in the Infinity Cache.  Batched (default when the rank's units average < 70 Mb, i.e. a rank
+    # holding several small contigs): ONE window-feature launch and ONE WPS launch for all of the rank's
+    # units (ftk_window_features_batch / ftk_wps_batch) -- better occupancy than 500-window launches.
+    # Measured on simulated ranks: 8-GPU rank 7 (6 units) 0.717 -> 0.681 ms, 8-GPU rank 0 (2 units)
+    # 0.656 -> 0.667, whole genome on one GPU 5.26 -> 5.46.  FTK_BENCH_BATCH = 0 / 1 (features only) / 2 forces.
+    mode = os.environ.get("FTK_BENCH_BATCH", "auto")
+    if mode == "auto":
+        mode = "2" if mine and sum(per[c]["b"] - per[c]["a"] for c in mine) / len(mine) < 70e6 else "0"
+    batched = mode != "0"
+    fbatch = eng.feature_batch([dict(name=c, starts=per[c]["ws"], stops=per[c]["we"], bl_start=per[c]["bl"][0],
+                                     bl_end=per[c]["bl"][1], gaps=per[c]["gaps"]) for c in mine], MAPQ) if batched else None
+    wps_names = list(mine)
+    wps_a = [per[c]["a"] for c in mine]
+    wps_b = [per[c]["b"] for c in mine]
+    wps_cs = [per[c]["size"] for c in mine]
+    wps_off = [per[c]["wps_off"] for c in mine]
+
+    # mode 1 keeps WPS one launch per unit (the batched WPS kernel fetches its item -- contig view, interval --
+    # from memory at block start: 4.84 vs 4.25 ms for the whole genome).
+    batch_wps = mode == "2"
+
+    def step_batched(record_events=False):
+        eng.window_features_batch(fbatch, coverage=all_cov, hist=all_hist, hist_bins=(0, HIST_BINS), overflow=all_over,
+                                  delfi_q=MAPQ, short=gather_in[0], long=gather_in[1])
+        if batch_wps:
+            if record_events:
+                eng.event_record(0)
+            eng.wps_batch(wps_names, wps_a, wps_b, wps_cs, wps_off, all_wps, WPS_W, WPS_MIN, WPS_MAX, MAPQ)
+            if record_events:
+                eng.event_record(1)
+                wps_ev["batch"] = (0, 1)
+        else:
+            ev = 0
+            for c in mine:
+                p = per[c]
+                if record_events:
+                    eng.event_record(ev)
+                eng.wps(c, p["a"], p["b"], p["size"], WPS_W, WPS_MIN, WPS_MAX, MAPQ, out=p["wps"])
+                if record_events:
+                    eng.event_record(ev + 1)
+                    wps_ev[c] = (ev, ev + 1)
+                    ev += 2
+        if use_dist:
+            dist.all_gather(gather_out, gather_in)
+
     def step(record_events=False):
+        if batched:
+            return step_batched(record_events)
         row = 0
         ev = 0
         split = bool(os.environ.get("FTK_BENCH_SPLIT_ORDER"))  # experiment: all feature passes, then all WPS
@@ -255,10 +313,10 @@ def main():
     # host and GPU for 35-50 ms (seen at step 8 of the 24-contig run and at step 52 of a 4-contig run, never
     # again in 5 000+ launches).  Setup therefore primes the runtime with untimed steps until that many launches
     # are behind us, so the stall cannot land in a short warm-up + timed region.  FTK_BENCH_PRIME=0 turns it off.
-    launches_per_step = 4 * len(mine) + 1
+    launches_per_step = (3 if batch_wps else 2 + len(mine)) if batched else 4 * len(mine) + 1
     prime = 0
     if os.environ.get("FTK_BENCH_PRIME", "1") != "0":
-        prime = min(256, -(-1200 // launches_per_step))
+        prime = min(512, -(-1200 // launches_per_step))
         run_steps(prime, False)
         barrier()
         done_ev.clear()
@@ -283,12 +341,14 @@ def main():
     wps_ms = 0.0
     for c, (a, b) in wps_ev.items():
         wps_ms += eng.event_elapsed_ms(a, b)
-        wps_bytes += 10 * per[c]["n"] + 8 * (per[c]["b"] - per[c]["a"])
+        for u in (mine if c == "batch" else [c]):
+            wps_bytes += 10 * per[u]["n"] + 8 * (per[u]["b"] - per[u]["a"])
     achieved = wps_bytes / (wps_ms * 1e-3) / 1e9 if wps_ms > 0 else 0.0
     traffic = None  # HBM bytes per launch from the committed PMC passes (same workload only)
     tpath = os.path.join(ROOT, "profiles", "wps_traffic.json")
     if world == 1 and not sim and not args.contigs and args.depth == 30.0 and os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        tj = json.load(open(tpath))  # measured per step (all WPS launches of one step), reported per launch
+        traffic = int(tj["hbm_bytes_per_step"] / max(len(wps_ev), 1))
     roofline = dict(bound="hbm", kernel="wps_stream_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     algorithmic_bytes_per_launch=int(wps_bytes / max(len(wps_ev), 1)),
@@ -331,7 +391,8 @@ def main():
                                     f"{halo} bp); all-gather of DELFI bin vector") if world > 1
                        else ("single GPU" if not sim else f"simulated rank {sim} alone")},
             "roofline": roofline, "cpu_baseline": cpu, "checks": checks, "load_s": round(t_load, 2),
-            "priming_steps": prime,
+            "priming_steps": prime, "launches": ("1 batched feature launch + " + ("1 batched WPS launch" if batch_wps else "1 WPS launch per unit")
+                         + " per step") if batched else "per unit",
         }
     if use_dist:
         dist.barrier()

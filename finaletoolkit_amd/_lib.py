@@ -45,7 +45,8 @@ EXPORTS = [
     "ftk_fragtable_n_contigs", "ftk_fragtable_contig_name", "ftk_fragtable_contig_length",
     "ftk_fragtable_contig_rows", "ftk_fragtable_columns", "ftk_fragtable_is_pinned", "ftk_fragtable_free",
     "ftk_frags_from_table",
-    "ftk_window_counts", "ftk_delfi_counts", "ftk_fraglen_hist", "ftk_window_features", "ftk_frag_lengths",
+    "ftk_window_counts", "ftk_delfi_counts", "ftk_fraglen_hist", "ftk_window_features",
+    "ftk_window_features_batch", "ftk_wps_batch", "ftk_frag_lengths",
     "ftk_frag_select",
     "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals", "ftk_wps_adjust",
     "ftk_ref_upload", "ftk_ref_release", "ftk_ref_gc_counts", "ftk_ref_set_layout", "ftk_motif_counts",
@@ -68,6 +69,11 @@ class Gaps(C.Structure):
     _fields_ = [("has_gaps", C.c_int32), ("cen_start", C.c_int32), ("cen_stop", C.c_int32),
                 ("n_telo", C.c_int32), ("telo_start", C.c_int32 * MAX_TELOMERES),
                 ("telo_stop", C.c_int32 * MAX_TELOMERES)]
+
+
+class FeatureItem(C.Structure):
+    _fields_ = [("contig_id", C.c_int32), ("n_win", C.c_int64), ("w_start", C.c_void_p), ("w_end", C.c_void_p),
+                ("bl_start", C.c_void_p), ("bl_end", C.c_void_p), ("n_bl", C.c_int64), ("gaps", C.POINTER(Gaps))]
 
 
 class Motif(C.Structure):
@@ -144,6 +150,9 @@ def load() -> C.CDLL:
     lib.ftk_fraglen_hist.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), i32, i32, vp, vp]
     lib.ftk_window_features.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), vp, i32, i32, vp, vp, i32, vp, vp,
                                         i64, C.POINTER(Gaps), vp, vp]
+    lib.ftk_window_features_batch.argtypes = [vp, C.POINTER(FeatureItem), i32, C.POINTER(Filter), vp, i32, i32, vp, vp, i32,
+                                              vp, vp]
+    lib.ftk_wps_batch.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
     lib.ftk_frag_lengths.argtypes = [vp, C.c_int, i32, i32, C.POINTER(Filter), vp, i64, C.POINTER(i64)]
     lib.ftk_frag_select.argtypes = [vp, C.c_int, i32, i32, C.POINTER(Filter), vp, vp, vp, vp, i64, C.POINTER(i64)]
     lib.ftk_wps.argtypes = [vp, C.c_int, i64, i64, i64, i32, i32, i32, i32, vp]

@@ -327,6 +327,8 @@ void ftk_ctx_destroy(ftk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->contigs) free_contig(kv.second);
     for (auto& m : ctx->delfi_cache) (void)hipFree(m.base);
+    for (int k = 0; k < 2; ++k)
+        if (ctx->batch_dev[k]) (void)hipFree(ctx->batch_dev[k]);
     for (auto& kv : ctx->refs) {
         (void)hipFree(kv.second.d);
         if (kv.second.d_nblk) (void)hipFree(kv.second.d_nblk);
@@ -468,6 +470,30 @@ int ftk_frags_release(ftk_ctx* ctx, int contig_id) {
 // ---- window features: one implementation behind four entry points ----------------
 namespace {
 
+constexpr size_t kDelfiCacheMax = 256;
+constexpr int kBatchMaxItems = 64;
+
+// Device copy of a small host descriptor array, re-uploaded only when its bytes change.
+int upload_batch_descriptors(ftk_ctx* ctx, int slot, const void* host, size_t bytes, void** dev_out) {
+    std::vector<unsigned char>& last = ctx->batch_host[slot];
+    if (last.size() == bytes && bytes && memcmp(last.data(), host, bytes) == 0) {
+        *dev_out = ctx->batch_dev[slot];
+        return FTK_OK;
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // a launch may still read the previous copy
+    if (bytes > ctx->batch_cap[slot]) {
+        if (ctx->batch_dev[slot]) (void)hipFree(ctx->batch_dev[slot]);
+        ctx->batch_dev[slot] = nullptr;
+        ctx->batch_cap[slot] = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->batch_dev[slot], align_up(bytes, 4096)));
+        ctx->batch_cap[slot] = align_up(bytes, 4096);
+    }
+    HIPCHK(ctx, hipMemcpy(ctx->batch_dev[slot], host, bytes, hipMemcpyHostToDevice));
+    last.assign((const unsigned char*)host, (const unsigned char*)host + bytes);
+    *dev_out = ctx->batch_dev[slot];
+    return FTK_OK;
+}
+
 // Device-resident windows + per-window blacklist CSR, cached by content.
 int get_delfi_meta(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
                    const int32_t* bl_start, const int32_t* bl_end, int64_t n_bl, DelfiMeta** out) {
@@ -507,7 +533,7 @@ int get_delfi_meta(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const in
             off[w + 1] = (int32_t)r0.size();
         }
     }
-    if (ctx->delfi_cache.size() >= 64) {  // drop the oldest entry
+    if (ctx->delfi_cache.size() >= kDelfiCacheMax) {  // drop the oldest entry
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->delfi_cache.front().base);
         ctx->delfi_cache.erase(ctx->delfi_cache.begin());
@@ -650,6 +676,107 @@ int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const i
 }
 
 }  // namespace
+
+int ftk_window_features_batch(ftk_ctx* ctx, const ftk_feature_item* items, int32_t n_items, const ftk_filter* f,
+                              int64_t* count_out, int32_t len_lo, int32_t n_bins, uint32_t* hist_out,
+                              int64_t* overflow_out, int32_t delfi_mapq_min, int64_t* short_out, int64_t* long_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    if (n_items < 0 || n_items > kBatchMaxItems)
+        return fail(ctx, FTK_ERR_INVALID, "n_items must be in [0, %d]", kBatchMaxItems);
+    if (n_items == 0) return FTK_OK;
+    if (!items) return fail(ctx, FTK_ERR_INVALID, "items is NULL");
+    const bool ch = count_out || hist_out, df = short_out || long_out;
+    if (!ch && !df) return fail(ctx, FTK_ERR_INVALID, "no feature requested");
+    if (df && (!short_out || !long_out)) return fail(ctx, FTK_ERR_INVALID, "NULL DELFI output pointer");
+    if (hist_out && (n_bins <= 0 || n_bins > kHistMaxBins || !overflow_out))
+        return fail(ctx, FTK_ERR_INVALID, "histogram needs n_bins in [1, %d] and overflow_out", kHistMaxBins);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // make room first: an eviction in the middle of the loop below could free an earlier item's arrays
+    while (ctx->delfi_cache.size() + (size_t)n_items > kDelfiCacheMax) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->delfi_cache.front().base);
+        ctx->delfi_cache.erase(ctx->delfi_cache.begin());
+    }
+    std::vector<FeatItem> host(n_items);
+    int64_t total = 0;
+    int n_bam = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const ftk_feature_item& it = items[i];
+        ContigData* c;
+        int rc = get_contig(ctx, it.contig_id, &c);
+        if (rc) return rc;
+        if (ch && (rc = check_filter(ctx, f, *c))) return rc;
+        if (it.n_win <= 0 || it.n_win > (1 << 30) || !it.w_start || !it.w_end)
+            return fail(ctx, FTK_ERR_INVALID, "item %d: bad window arguments", i);
+        if (it.n_bl < 0 || (it.n_bl > 0 && (!it.bl_start || !it.bl_end)))
+            return fail(ctx, FTK_ERR_INVALID, "item %d: bad blacklist arguments", i);
+        if (is_device_ptr(it.w_start) || is_device_ptr(it.w_end) || is_device_ptr(it.bl_start))
+            return fail(ctx, FTK_ERR_INVALID, "item %d: windows and blacklist must be host arrays", i);
+        ftk_gaps g{};
+        if (it.gaps) g = *it.gaps;
+        if (g.has_gaps && (g.n_telo < 0 || g.n_telo > FTK_MAX_TELOMERES))
+            return fail(ctx, FTK_ERR_INVALID, "item %d: at most %d telomere intervals", i, FTK_MAX_TELOMERES);
+        DelfiMeta* meta = nullptr;
+        if ((rc = get_delfi_meta(ctx, it.contig_id, it.w_start, it.w_end, it.n_win, df ? it.bl_start : nullptr,
+                                 df ? it.bl_end : nullptr, df ? it.n_bl : 0, &meta)))
+            return rc;
+        FeatItem& h = host[i];
+        memset(&h, 0, sizeof(h));
+        h.cv = c->v;
+        h.ws = meta->d_ws;
+        h.we = meta->d_we;
+        if (df && meta->n_r) { h.bl_off = meta->d_off; h.bl_r0 = meta->d_r0; h.bl_pm = meta->d_pm; }
+        h.win_base = (int32_t)total;
+        h.n_win = (int32_t)it.n_win;
+        int lmax = 0;
+        if (ch) lmax = std::max(lmax, eff_lmax(f, *c));
+        if (df) lmax = std::max(lmax, std::max(0, std::min(220, c->max_len)));
+        h.lmax = lmax;
+        int gc[4];
+        gap_constants(g, gc);
+        h.cen0 = gc[0]; h.cen1 = gc[1]; h.tel0 = gc[2]; h.tel1 = gc[3];
+        total += it.n_win;
+        n_bam += c->v.r1_start != nullptr && (!f || f->fetch_mode == FTK_FETCH_BAM_READ1);
+        if (total > (1 << 30)) return fail(ctx, FTK_ERR_INVALID, "too many windows in one batch");
+    }
+    if (n_bam != 0 && n_bam != n_items)
+        return fail(ctx, FTK_ERR_INVALID, "a batch cannot mix contigs with and without read1 columns");
+    void* d_items = nullptr;
+    int rc = upload_batch_descriptors(ctx, 0, host.data(), host.size() * sizeof(FeatItem), &d_items);
+    if (rc) return rc;
+    const bool c_dev = is_device_ptr(count_out), h_dev = is_device_ptr(hist_out), o_dev = is_device_ptr(overflow_out),
+               s_dev = is_device_ptr(short_out), l_dev = is_device_ptr(long_out);
+    const size_t hist_elems = hist_out ? (size_t)total * (size_t)n_bins : 0;
+    if ((rc = reserve_scratch(ctx, 4 * align_up(total * 8) + (h_dev ? 0 : align_up(hist_elems * 4))))) return rc;
+    Arena a(ctx);
+    FeatureRequest r;
+    r.filter = f;
+    r.cov_out = count_out ? (c_dev ? count_out : a.take<int64_t>(total)) : nullptr;
+    r.hist_out = hist_out ? (h_dev ? hist_out : a.take<uint32_t>(hist_elems)) : nullptr;
+    r.over_out = hist_out ? (o_dev ? overflow_out : a.take<int64_t>(total)) : nullptr;
+    r.len_lo = len_lo;
+    r.n_bins = n_bins;
+    if (df) {
+        r.short_out = s_dev ? short_out : a.take<int64_t>(total);
+        r.long_out = l_dev ? long_out : a.take<int64_t>(total);
+        r.delfi_mapq_min = delfi_mapq_min;
+    }
+    launch_window_features_batch(ctx->stream, (const FeatItem*)d_items, n_items, (int)total, r, n_bam != 0);
+    HIPCHK(ctx, hipGetLastError());
+    bool host_out = false;
+    auto back = [&](void* dst, const void* src, size_t bytes, bool dev) -> hipError_t {
+        if (!dst || dev) return hipSuccess;
+        host_out = true;
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    };
+    HIPCHK(ctx, back(count_out, r.cov_out, total * 8, c_dev));
+    HIPCHK(ctx, back(hist_out, r.hist_out, hist_elems * 4, h_dev));
+    HIPCHK(ctx, back(hist_out ? overflow_out : nullptr, r.over_out, total * 8, o_dev));
+    HIPCHK(ctx, back(short_out, r.short_out, total * 8, s_dev));
+    HIPCHK(ctx, back(long_out, r.long_out, total * 8, l_dev));
+    if (host_out) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
 
 int ftk_window_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
                       const ftk_filter* f, int64_t* count_out) {
@@ -889,6 +1016,64 @@ int ftk_wps_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start, cons
     if (!out_dev) HIPCHK(ctx, hipMemcpyAsync(wps_out, d_out, total_out * 8, hipMemcpyDeviceToHost, ctx->stream));
     // tile descriptor vectors are pageable staging: wait before they go away
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
+int ftk_wps_batch(ftk_ctx* ctx, const int32_t* contig_ids, const int64_t* iv_start, const int64_t* iv_stop,
+                  const int64_t* chrom_size, const int64_t* out_offset, int64_t n_iv, int32_t window_size,
+                  int32_t min_len, int32_t max_len, int32_t mapq_min, int64_t* wps_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    if (n_iv < 0 || n_iv > kBatchMaxItems) return fail(ctx, FTK_ERR_INVALID, "n_iv must be in [0, %d]", kBatchMaxItems);
+    if (n_iv == 0) return FTK_OK;
+    if (!contig_ids || !iv_start || !iv_stop || !chrom_size || !out_offset || !wps_out)
+        return fail(ctx, FTK_ERR_INVALID, "NULL argument");
+    const bool out_dev = is_device_ptr(wps_out);
+    long long total_out = 0;
+    std::vector<WpsItem> host;
+    WpsParams p{};
+    long long tiles = 0;
+    for (int64_t i = 0; i < n_iv; ++i) {
+        ContigData* c;
+        int rc = get_contig(ctx, contig_ids[i], &c);
+        if (rc) return rc;
+        WpsParams pi{};
+        if ((rc = wps_params(ctx, *c, chrom_size[i], window_size, min_len, max_len, mapq_min, &pi))) return rc;
+        const long long len = iv_stop[i] - iv_start[i];
+        if (len <= 0) continue;
+        if (iv_start[i] < -(1LL << 30) || iv_stop[i] > (1LL << 31) || out_offset[i] < 0)
+            return fail(ctx, FTK_ERR_INVALID, "interval %lld out of range", (long long)i);
+        if (host.empty()) p = pi;
+        if ((c->v.r1_start != nullptr) != (host.empty() ? c->v.r1_start != nullptr : host[0].cv.r1_start != nullptr))
+            return fail(ctx, FTK_ERR_INVALID, "a batch cannot mix contigs with and without read1 columns");
+        WpsItem it{};
+        it.cv = c->v;
+        it.start = iv_start[i];
+        it.stop = iv_stop[i];
+        it.chrom_size = chrom_size[i];
+        it.out_off = out_offset[i];
+        it.tile_base = tiles;
+        it.lmax = pi.lmax;
+        host.push_back(it);
+        tiles += (len + kWpsTile - 1) / kWpsTile;
+        total_out = std::max(total_out, (long long)out_offset[i] + len);
+    }
+    if (host.empty()) return FTK_OK;
+    if (tiles > (long long)INT32_MAX) return fail(ctx, FTK_ERR_INVALID, "too many tiles in one call");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void* d_items = nullptr;
+    int rc = upload_batch_descriptors(ctx, 1, host.data(), host.size() * sizeof(WpsItem), &d_items);
+    if (rc) return rc;
+    int64_t* d_out = wps_out;
+    if (!out_dev) {
+        if ((rc = reserve_scratch(ctx, align_up((size_t)total_out * 8)))) return rc;
+        d_out = (int64_t*)ctx->scratch;
+    }
+    launch_wps_batch(ctx->stream, p, (const WpsItem*)d_items, (int)host.size(), tiles, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    if (!out_dev) {
+        HIPCHK(ctx, hipMemcpyAsync(wps_out, d_out, (size_t)total_out * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return FTK_OK;
 }
 

@@ -83,6 +83,10 @@ struct ftk_ctx {
         int32_t n_nblk = 0;
     };
     std::map<int, RefImage> refs;  // reference-sequence images for the DELFI GC count
+    // batched launches: the per-item descriptors last uploaded (re-used while the caller repeats the batch)
+    std::vector<unsigned char> batch_host[2];  // [0] window features, [1] WPS
+    void* batch_dev[2] = {nullptr, nullptr};
+    size_t batch_cap[2] = {0, 0};
     // grow-only device scratch, reused by every call (stream-ordered)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;

@@ -77,6 +77,22 @@ struct FeatureRequest {
     // motif histogram instead of the length histogram (hist_out = [n_win][4^k], over_out = errors)
     const MotifParams* motif = nullptr;
 };
+// One contig's share of a batched window-feature launch (device pointers).
+struct FeatItem {
+    ContigView cv;
+    const int32_t* ws;
+    const int32_t* we;
+    const int32_t* bl_off;  // per-window blacklist CSR of this item (NULL: none)
+    const int32_t* bl_r0;
+    const int32_t* bl_pm;
+    int32_t win_base;       // first row of this item in the concatenated outputs
+    int32_t n_win;
+    int32_t lmax;
+    int32_t cen0, cen1, tel0, tel1;  // gap constants, clamped (gap_constants)
+};
+void gap_constants(const ftk_gaps& g, int out[4]);
+void launch_window_features_batch(hipStream_t s, const FeatItem* d_items, int n_items, int total_win,
+                                  const FeatureRequest& r, bool bam);
 // block_lmax >= 0: one block per window (feat_block_kernel, needs no plan and no zeroed outputs), with
 // block_lmax = longest fragment any requested feature can accept; < 0: the planned small + chunked passes.
 void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
@@ -86,6 +102,17 @@ void launch_add_i64(hipStream_t s, const int64_t* a, const int64_t* b, int64_t* 
 void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t n_tiles, const int64_t* iv_start,
                 const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv, const int32_t* tile_k,
                 int64_t* out);
+// One (contig, interval) of a batched WPS launch.
+struct WpsItem {
+    ContigView cv;
+    long long start, stop, chrom_size;
+    long long out_off;    // index of the interval's first score in the output
+    long long tile_base;  // first tile of this item in the launch
+    int lmax;
+    int pad_;
+};
+void launch_wps_batch(hipStream_t s, const WpsParams& p, const WpsItem* d_items, int n_items, int64_t n_tiles,
+                      int64_t* out);
 void launch_cleavage(hipStream_t s, const ContigView& cv, const CleaveParams& p, int64_t n_tiles,
                      const int64_t* iv_start, const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv,
                      const int32_t* tile_k, double* out);

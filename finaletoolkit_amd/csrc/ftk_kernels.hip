@@ -640,30 +640,26 @@ __device__ __forceinline__ void feat_stream(const ContigView& cv, const FeatPara
 // stores, nothing to zero beforehand, no atomics.  One launch per call instead of three.
 // ---------------------------------------------------------------------------
 template <int CH, bool DF, bool BAM>
-__global__ __launch_bounds__(256) void feat_block_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
-                                                         int n_win, int lmax, FeatParams P) {
-    extern __shared__ uint32_t lds_hist[];
-    __shared__ int red[5][4];
-    const int w = blockIdx.x;
+__device__ __forceinline__ void feat_block_body(const ContigView& cv, int ws_raw, int we_raw, int lmax,
+                                                const FeatParams& P, int o0, int o1, size_t row,
+                                                uint32_t* lds_hist, int (*red)[4]) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool hist = CH && P.do_hist;
     int lo, hi;
     uint32_t nc;
-    window_candidates(cv, ws_[w], we_[w], lmax, -1, lo, hi, nc);
+    window_candidates(cv, ws_raw, we_raw, lmax, -1, lo, hi, nc);
     if (hist) {
         for (int b = tid; b <= P.n_bins; b += 256) lds_hist[b] = 0;
         __syncthreads();
     }
     int ws, we1;
-    window_bounds<CH>(ws_[w], we_[w], ws, we1);
-    int o0 = 0, o1 = 0;
-    if (DF && P.dp.bl_off) { o0 = P.dp.bl_off[w]; o1 = P.dp.bl_off[w + 1]; }
+    window_bounds<CH>(ws_raw, we_raw, ws, we1);
     FeatAcc a;
     if (DF && o1 > o0) feat_stream<CH, DF, BAM, true>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
     else feat_stream<CH, DF, BAM, false>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
     if (hist) {
         __syncthreads();
-        uint32_t* dst = P.hist_out + (size_t)w * P.n_bins;
+        uint32_t* dst = P.hist_out + row * P.n_bins;
         for (int b = tid; b < P.n_bins; b += 256) dst[b] = lds_hist[b];
     }
     a.n = wave_reduce_add(a.n);
@@ -681,8 +677,49 @@ __global__ __launch_bounds__(256) void feat_block_kernel(ContigView cv, const in
         int64_t* dst = tid == 0 ? (CH && P.do_cov ? P.cov_out : nullptr)
                      : tid == 1 ? (hist ? P.over_out : nullptr)
                      : tid == 2 ? (DF ? P.short_out : nullptr) : (DF ? P.long_out : nullptr);
-        if (dst) dst[w] = t;
+        if (dst) dst[row] = t;
     }
+}
+
+template <int CH, bool DF, bool BAM>
+__global__ __launch_bounds__(256) void feat_block_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
+                                                         int n_win, int lmax, FeatParams P) {
+    extern __shared__ uint32_t lds_hist[];
+    __shared__ int red[5][4];
+    const int w = blockIdx.x;
+    int o0 = 0, o1 = 0;
+    if (DF && P.dp.bl_off) { o0 = P.dp.bl_off[w]; o1 = P.dp.bl_off[w + 1]; }
+    feat_block_body<CH, DF, BAM>(cv, ws_[w], we_[w], lmax, P, o0, o1, (size_t)w, lds_hist, red);
+}
+
+// The same for the windows of SEVERAL contigs in one launch (ftk_window_features_batch): block b owns
+// window b of the concatenated list; its item (contig view, windows, blacklist CSR, gap constants) is
+// found by bisection on the items' first rows; outputs are indexed by the global row.
+template <int CH, bool DF, bool BAM>
+__global__ __launch_bounds__(256) void feat_batch_kernel(const FeatItem* __restrict__ items, int n_items,
+                                                         FeatParams P) {
+    extern __shared__ uint32_t lds_hist[];
+    __shared__ int red[5][4];
+    const int gw = blockIdx.x;
+    int it = 0;
+    {
+        int lo = 0, hi = n_items;  // largest item with win_base <= gw
+        while (hi - lo > 1) {
+            const int m = (lo + hi) >> 1;
+            if (items[m].win_base <= gw) lo = m; else hi = m;
+        }
+        it = lo;
+    }
+    const FeatItem& I = items[it];
+    const int w = gw - I.win_base;
+    FeatParams Q = P;
+    Q.cen0 = I.cen0; Q.cen1 = I.cen1; Q.tel0 = I.tel0; Q.tel1 = I.tel1;
+    Q.dp.bl_r0 = I.bl_r0;
+    Q.dp.bl_pm = I.bl_pm;
+    int o0 = 0, o1 = 0;
+    if (DF && I.bl_off) { o0 = I.bl_off[w]; o1 = I.bl_off[w + 1]; }
+    const ContigView cv = I.cv;
+    feat_block_body<CH, DF, BAM>(cv, I.ws[w], I.we[w], I.lmax, Q, o0, o1, (size_t)gw, lds_hist, red);
 }
 
 // ---------------------------------------------------------------------------
@@ -729,12 +766,15 @@ struct WpsTile {
 
 constexpr int kWpsPrefetch = 4;  // fragments per thread held in registers for the next tile
 
-template <bool MULTI>  // MULTI: a block walks several tiles and prefetches the next one's fragments
+// MULTI: a block walks several tiles and prefetches the next one's fragments.  BATCH: tiles of several
+// contigs in one launch (one tile per block; the kernel-argument view / limits are replaced by the item's).
+template <bool MULTI, bool BATCH>
 __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParams p, const int64_t* iv_start_,
                                                          const int64_t* iv_stop_, const int64_t* out_off_,
                                                          const int32_t* tile_iv, const int32_t* tile_k,
                                                          long long n_tiles, int tiles_per_block,
-                                                         int64_t* __restrict__ out) {
+                                                         int64_t* __restrict__ out,
+                                                         const WpsItem* __restrict__ items, int n_items) {
     constexpr int T = kWpsTile, NP = T / 1024, PF = kWpsPrefetch;
     __shared__ __attribute__((aligned(16))) int d[T];
     __shared__ int pre_s[2];
@@ -750,10 +790,28 @@ __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParam
     const long long tlast = min(tfirst + (long long)tiles_per_block, n_tiles);
     if (tfirst >= tlast) return;
 
+    // batched launch (ftk_wps_batch, one tile per block): the tile's interval, its contig's columns and
+    // limits come from the item that owns it (bisection on the items' first tiles)
+    long long b_start = 0, b_stop = 0, b_off = 0, b_tile0 = 0;
+    if (BATCH) {
+        int lo = 0, hi = n_items;
+        while (hi - lo > 1) {
+            const int m = (lo + hi) >> 1;
+            if (items[m].tile_base <= tfirst) lo = m; else hi = m;
+        }
+        const WpsItem& I = items[lo];
+        cv = I.cv;
+        p.chrom_size = I.chrom_size;
+        p.lmax = I.lmax;
+        b_start = I.start; b_stop = I.stop; b_off = I.out_off; b_tile0 = I.tile_base;
+    }
+
     auto tile_info = [&](long long t) {
         WpsTile ti;
         long long iv_start, iv_stop, out_off, k;
-        if (tile_iv) {
+        if (BATCH) {
+            iv_start = b_start; iv_stop = b_stop; out_off = b_off; k = t - b_tile0;
+        } else if (tile_iv) {
             const int iv = tile_iv[t];
             iv_start = iv_start_[iv]; iv_stop = iv_stop_[iv]; out_off = out_off_[iv]; k = tile_k[t];
         } else {
@@ -1221,28 +1279,10 @@ void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv,
     P.short_out = r.short_out;
     P.long_out = r.long_out;
     {
-        const ftk_gaps& g = r.gaps;
-        int cen0 = INT32_MAX, cen1 = INT32_MIN, tel0 = INT32_MAX, tel1 = INT32_MIN;
-        if (g.has_gaps) {
-            cen0 = g.cen_start;
-            cen1 = g.cen_stop;
-            if (g.n_telo > 0) {
-                tel0 = INT32_MIN;
-                tel1 = INT32_MAX;
-                for (int t = 0; t < g.n_telo; ++t) {
-                    tel0 = std::max(tel0, g.telo_start[t]);
-                    tel1 = std::min(tel1, g.telo_stop[t]);
-                }
-            }
-        }
-        P.dp = DelfiPred{r.delfi_mapq_min, cen0, cen1, tel0, tel1, r.bl_off, r.bl_r0, r.bl_pm};
-        // the sign-test form of the same bounds: every value the kernels subtract from a coordinate
-        // (0 <= c < 2^30) is clamped to [-1, 2^30 + 1], which keeps each comparison's outcome
-        auto clamp_c = [](int v) { return std::min(std::max(v, -1), (1 << 30) + 1); };
-        P.cen0 = clamp_c(cen0);
-        P.cen1 = clamp_c(cen1);
-        P.tel0 = clamp_c(tel0);
-        P.tel1 = clamp_c(tel1);
+        int gc[4];
+        gap_constants(r.gaps, gc);
+        P.cen0 = gc[0]; P.cen1 = gc[1]; P.tel0 = gc[2]; P.tel1 = gc[3];
+        P.dp = DelfiPred{r.delfi_mapq_min, gc[0], gc[1], gc[2], gc[3], r.bl_off, r.bl_r0, r.bl_pm};
         P.df_q = std::min(std::max(r.delfi_mapq_min, 0), 256);
     }
     if (r.filter) {
@@ -1268,6 +1308,61 @@ void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv,
 #undef FTK_FEAT
 }
 
+void gap_constants(const ftk_gaps& g, int out[4]) {
+    int cen0 = INT32_MAX, cen1 = INT32_MIN, tel0 = INT32_MAX, tel1 = INT32_MIN;
+    if (g.has_gaps) {
+        cen0 = g.cen_start;
+        cen1 = g.cen_stop;
+        if (g.n_telo > 0) {
+            tel0 = INT32_MIN;
+            tel1 = INT32_MAX;
+            for (int t = 0; t < g.n_telo; ++t) {
+                tel0 = std::max(tel0, g.telo_start[t]);
+                tel1 = std::min(tel1, g.telo_stop[t]);
+            }
+        }
+    }
+    auto clamp_c = [](int v) { return std::min(std::max(v, -1), (1 << 30) + 1); };
+    out[0] = clamp_c(cen0); out[1] = clamp_c(cen1); out[2] = clamp_c(tel0); out[3] = clamp_c(tel1);
+}
+
+void launch_window_features_batch(hipStream_t s, const FeatItem* d_items, int n_items, int total_win,
+                                  const FeatureRequest& r, bool bam) {
+    FeatParams P{};
+    const bool ch = r.cov_out || r.hist_out;
+    const bool df = r.short_out != nullptr;
+    if (r.filter) {
+        const ftk_filter& f = *r.filter;
+        P.wp = make_win_pred(f);
+        P.ch_q = std::min(std::max(f.mapq_min, 0), 256);
+        P.ch_min = f.min_len < 0 ? 0 : std::min(f.min_len, 1 << 30);
+        P.ch_max = f.max_len < 0 ? (1 << 30) : std::min(f.max_len, 1 << 30);
+        P.is_any = f.policy == FTK_POLICY_ANY;
+    }
+    P.df_q = std::min(std::max(r.delfi_mapq_min, 0), 256);
+    P.do_cov = r.cov_out != nullptr;
+    P.do_hist = r.hist_out != nullptr;
+    P.len_lo = r.len_lo;
+    P.n_bins = r.n_bins;
+    P.cov_out = r.cov_out;
+    P.hist_out = r.hist_out;
+    P.over_out = r.over_out;
+    P.short_out = r.short_out;
+    P.long_out = r.long_out;
+    const size_t lds1 = P.do_hist ? (size_t)(P.n_bins + 1) * sizeof(uint32_t) : 0;
+#define FTK_FEATB(CH, DF)                                                                                           \
+    do {                                                                                                            \
+        if (bam) hipLaunchKernelGGL((feat_batch_kernel<CH, DF, true>), dim3(total_win), dim3(256), lds1, s, d_items, \
+                                    n_items, P);                                                                    \
+        else hipLaunchKernelGGL((feat_batch_kernel<CH, DF, false>), dim3(total_win), dim3(256), lds1, s, d_items,   \
+                                n_items, P);                                                                        \
+    } while (0)
+    if (ch && df) FTK_FEATB(1, true);
+    else if (ch) FTK_FEATB(1, false);
+    else if (df) FTK_FEATB(0, true);
+#undef FTK_FEATB
+}
+
 void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t n_tiles, const int64_t* iv_start,
                 const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv, const int32_t* tile_k,
                 int64_t* out) {
@@ -1278,11 +1373,21 @@ void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t
     const long long tpb = tpb_env > 0 ? tpb_env : 1;
     const long long grid = (n_tiles + tpb - 1) / tpb;
     if (tpb == 1)
-        hipLaunchKernelGGL(wps_stream_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop,
-                           out_off, tile_iv, tile_k, (long long)n_tiles, (int)tpb, out);
+        hipLaunchKernelGGL((wps_stream_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop,
+                           out_off, tile_iv, tile_k, (long long)n_tiles, (int)tpb, out, (const WpsItem*)nullptr, 0);
     else
-        hipLaunchKernelGGL(wps_stream_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop,
-                           out_off, tile_iv, tile_k, (long long)n_tiles, (int)tpb, out);
+        hipLaunchKernelGGL((wps_stream_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop,
+                           out_off, tile_iv, tile_k, (long long)n_tiles, (int)tpb, out, (const WpsItem*)nullptr, 0);
+}
+
+// Several (contig, interval) items in one launch, one 4096-base tile per block.
+void launch_wps_batch(hipStream_t s, const WpsParams& p, const WpsItem* d_items, int n_items, int64_t n_tiles,
+                      int64_t* out) {
+    if (n_tiles <= 0) return;
+    ContigView none{};
+    hipLaunchKernelGGL((wps_stream_kernel<false, true>), dim3((unsigned)n_tiles), dim3(256), 0, s, none, p,
+                       (const int64_t*)nullptr, (const int64_t*)nullptr, (const int64_t*)nullptr,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, (long long)n_tiles, 1, out, d_items, n_items);
 }
 
 void launch_cleavage(hipStream_t s, const ContigView& cv, const CleaveParams& p, int64_t n_tiles,

@@ -253,6 +253,55 @@ class Engine:
             out["short"], out["long"] = sh, lg
         return out
 
+    def feature_batch(self, items, quality_threshold=30, min_length=None, max_length=None,
+                      intersect_policy="midpoint"):
+        """Prepare a multi-contig window-feature batch (``ftk_window_features_batch``): ``items`` is a list of
+        dicts ``name, starts, stops[, bl_start, bl_end, gaps]``.  Returns an opaque handle holding the C item
+        array (and the arrays it points to) for ``window_features_batch``."""
+        n = len(items)
+        arr = (L.FeatureItem * n)()
+        keep = []
+        for i, it in enumerate(items):
+            ws, we = _win(it["starts"], L.OPEN_LO), _win(it["stops"], L.OPEN_HI)
+            g = L.make_gaps(it.get("gaps"))
+            bs = be = None
+            if it.get("bl_start") is not None and len(it["bl_start"]):
+                bs = np.ascontiguousarray(it["bl_start"], dtype=np.int32)
+                be = np.ascontiguousarray(it["bl_end"], dtype=np.int32)
+            keep.append((ws, we, bs, be, g))
+            arr[i].contig_id = self.contig_id(it["name"])
+            arr[i].n_win = len(ws)
+            arr[i].w_start = ws.ctypes.data
+            arr[i].w_end = we.ctypes.data
+            arr[i].bl_start = None if bs is None else bs.ctypes.data
+            arr[i].bl_end = None if be is None else be.ctypes.data
+            arr[i].n_bl = 0 if bs is None else len(bs)
+            arr[i].gaps = C.pointer(g)
+        f = L.make_filter(quality_threshold, min_length, max_length, intersect_policy,
+                          L.FETCH_BAM_READ1 if items and self.is_bam(items[0]["name"]) else L.FETCH_TABIX)
+        return dict(arr=arr, n=n, keep=keep, filter=f, rows=int(sum(len(k[0]) for k in keep)))
+
+    def window_features_batch(self, batch, coverage=None, hist=None, hist_bins=None, overflow=None, delfi_q=30,
+                              short=None, long=None):
+        """Run a prepared batch; every output is a device pointer (int) or a host numpy array sized for
+        ``batch["rows"]`` rows (``hist``: rows x n_bins uint32 with ``hist_bins=(len_lo, n_bins)``), or None."""
+        len_lo, n_bins = hist_bins if hist_bins is not None else (0, 0)
+        self._check(self.lib.ftk_window_features_batch(
+            self.ctx, batch["arr"], batch["n"], C.byref(batch["filter"]), L.ptr(coverage), int(len_lo), int(n_bins),
+            L.ptr(hist), L.ptr(overflow), int(delfi_q), L.ptr(short), L.ptr(long)))
+
+    def wps_batch(self, names, starts, stops, chrom_sizes, out_offsets, out, window_size=120, min_length=120,
+                  max_length=180, quality_threshold=30):
+        """WPS of several (contig, interval) pairs in one launch into the device buffer ``out``."""
+        ids = np.array([self.contig_id(n) for n in names], np.int32)
+        s = np.ascontiguousarray(starts, dtype=np.int64)
+        e = np.ascontiguousarray(stops, dtype=np.int64)
+        cs = np.ascontiguousarray(chrom_sizes, dtype=np.int64)
+        oo = np.ascontiguousarray(out_offsets, dtype=np.int64)
+        self._check(self.lib.ftk_wps_batch(self.ctx, L.ptr(ids), L.ptr(s), L.ptr(e), L.ptr(cs), L.ptr(oo), len(ids),
+                                           int(window_size), int(min_length), int(max_length), int(quality_threshold),
+                                           L.ptr(out)))
+
     def frag_lengths(self, name: str, start, stop, quality_threshold=30, min_length=None, max_length=None,
                      intersect_policy="midpoint"):
         """Lengths of one window's passing fragments in file order."""

@@ -191,6 +191,25 @@ int ftk_window_features(ftk_ctx* ctx, int contig_id, const int32_t* w_start, con
                         int64_t* overflow_out, int32_t delfi_mapq_min, const int32_t* bl_start, const int32_t* bl_end,
                         int64_t n_bl, const ftk_gaps* gaps, int64_t* short_out, int64_t* long_out);
 
+/* The same pass for the windows of SEVERAL contigs in ONE launch (a genome-wide bin set: the
+ * reference's delfi() / coverage() loop over contigs, frag/_delfi.py:289-300, frag/_coverage.py:244-248).
+ * Item i holds contig items[i].contig_id's windows (host arrays; blacklist / gaps only matter for the
+ * DELFI outputs).  Outputs are concatenated in item order: row = sum of n_win of the items before + w.
+ * One block per window: meant for bin tilings (many windows of similar length). */
+typedef struct ftk_feature_item {
+    int32_t contig_id;
+    int64_t n_win;
+    const int32_t* w_start;
+    const int32_t* w_end;
+    const int32_t* bl_start; /* sorted by start; NULL = no blacklist */
+    const int32_t* bl_end;
+    int64_t n_bl;
+    const ftk_gaps* gaps;    /* NULL = no gap annotation */
+} ftk_feature_item;
+int ftk_window_features_batch(ftk_ctx* ctx, const ftk_feature_item* items, int32_t n_items, const ftk_filter* f,
+                              int64_t* count_out, int32_t len_lo, int32_t n_bins, uint32_t* hist_out,
+                              int64_t* overflow_out, int32_t delfi_mapq_min, int64_t* short_out, int64_t* long_out);
+
 /* frag/_frag_length.py:290-305 (frag_length): lengths of the fragments of ONE
  * window passing `f`, in file order.  Writes at most cap values to len_out
  * and always the true count to n_out. */
@@ -219,6 +238,13 @@ int ftk_wps(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t ch
 int ftk_wps_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start, const int64_t* iv_stop, int64_t n_iv,
                       const int64_t* out_offset, int64_t chrom_size, int32_t window_size, int32_t min_len,
                       int32_t max_len, int32_t mapq_min, int64_t* wps_out);
+
+/* Intervals of SEVERAL contigs in one launch: interval i is [iv_start[i], iv_stop[i]) of contig
+ * contig_ids[i] (length chrom_size[i]) and writes its scores at wps_out + out_offset[i].  All arrays
+ * except wps_out (host or device) are host arrays of n_iv entries (n_iv <= 64: whole contigs or large ranges). */
+int ftk_wps_batch(ftk_ctx* ctx, const int32_t* contig_ids, const int64_t* iv_start, const int64_t* iv_stop,
+                  const int64_t* chrom_size, const int64_t* out_offset, int64_t n_iv, int32_t window_size,
+                  int32_t min_len, int32_t max_len, int32_t mapq_min, int64_t* wps_out);
 
 /* ---- next row: cleavage profile ----------------------------------
  * frag/_cleavage_profile.py:33-90,204-216 for every base of [start, stop) (already

@@ -266,3 +266,44 @@ def test_split_units_reproduce_the_whole_contig(engine, data, world):
     for k in whole:
         assert np.array_equal(np.concatenate(parts[k]), whole[k]), k
     assert np.array_equal(np.concatenate(wps_parts), whole_wps)
+
+
+def test_batched_launches_equal_per_contig_calls(engine, data):
+    """ftk_window_features_batch / ftk_wps_batch over several contigs == the per-contig calls."""
+    rng = np.random.default_rng(11)
+    names, sizes = ["synA"], [CONTIG_LEN]
+    for k, size in enumerate((700_000, 1_250_000, 90_000)):
+        s, e, q, st = synth.synth_contig(size, depth=20.0 + 5 * k, seed=20 + k)
+        engine.load_contig(f"bat{k}", s, e, q, st)
+        names.append(f"bat{k}")
+        sizes.append(size)
+    items, want = [], []
+    for name, size in zip(names, sizes):
+        ws, we = synth.tiling_windows(size, 50_000)
+        bl_s = np.sort(rng.integers(0, size - 5000, 30)).astype(np.int32)
+        bl_e = (bl_s + rng.integers(100, 4000, 30)).astype(np.int32)
+        gaps = (size // 3, size // 3 + 40_000, [(0, 5_000), (size - 5_000, size)])
+        items.append(dict(name=name, starts=ws, stops=we, bl_start=bl_s, bl_end=bl_e, gaps=gaps))
+        want.append(engine.window_features(name, ws, we, 30, hist=(0, 601),
+                                           delfi=dict(bl_start=bl_s, bl_end=bl_e, gaps=gaps)))
+    batch = engine.feature_batch(items, quality_threshold=30)
+    rows = batch["rows"]
+    cov, over = np.zeros(rows, np.int64), np.zeros(rows, np.int64)
+    hist = np.zeros((rows, 601), np.uint32)
+    sh, lg = np.zeros(rows, np.int64), np.zeros(rows, np.int64)
+    for _ in range(2):  # second call re-uses the cached device descriptors
+        engine.window_features_batch(batch, coverage=cov, hist=hist, hist_bins=(0, 601), overflow=over, short=sh, long=lg)
+        for key, got in (("coverage", cov), ("hist", hist), ("overflow", over), ("short", sh), ("long", lg)):
+            assert np.array_equal(got, np.concatenate([w[key] for w in want])), key
+    cov2 = np.zeros(rows, np.int64)  # coverage only
+    engine.window_features_batch(batch, coverage=cov2)
+    assert np.array_equal(cov2, cov)
+    # WPS: whole contigs plus a sub-range, one launch
+    iv = [(n, 0, s, s) for n, s in zip(names, sizes)] + [("synA", 1_000_123, 1_004_500, CONTIG_LEN)]
+    offs = np.concatenate([[0], np.cumsum([b - a for _, a, b, _ in iv])]).astype(np.int64)
+    got = np.zeros(int(offs[-1]), np.int64)
+    engine.wps_batch([x[0] for x in iv], [x[1] for x in iv], [x[2] for x in iv], [x[3] for x in iv], offs[:-1], got)
+    for k, (n, a, b, cs) in enumerate(iv):
+        assert np.array_equal(got[offs[k]:offs[k + 1]], engine.wps(n, a, b, cs)), n
+    for n in names[1:]:
+        engine.release(n)
