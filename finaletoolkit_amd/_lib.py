@@ -41,7 +41,8 @@ EXPORTS = [
     "ftk_ctx_set_stream", "ftk_ctx_sync", "ftk_timer_start", "ftk_timer_stop", "ftk_event_record",
     "ftk_event_elapsed_ms",
     "ftk_frags_from_host", "ftk_frags_from_device", "ftk_frags_set_read1", "ftk_frags_info", "ftk_frags_release",
-    "ftk_fragfile_decode", "ftk_bam_decode", "ftk_fragtable_error", "ftk_fragtable_is_bed6",
+    "ftk_fragfile_decode", "ftk_bam_decode", "ftk_fragstream_open", "ftk_fragstream_next", "ftk_fragstream_n_refs",
+    "ftk_fragstream_ref_name", "ftk_fragstream_ref_length", "ftk_fragstream_close", "ftk_fragtable_error", "ftk_fragtable_is_bed6",
     "ftk_fragtable_n_contigs", "ftk_fragtable_contig_name", "ftk_fragtable_contig_length",
     "ftk_fragtable_contig_rows", "ftk_fragtable_columns", "ftk_fragtable_is_pinned", "ftk_fragtable_free",
     "ftk_frags_from_table",
@@ -132,6 +133,15 @@ def load() -> C.CDLL:
     lib.ftk_frags_release.argtypes = [vp, C.c_int]
     lib.ftk_fragfile_decode.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
     lib.ftk_bam_decode.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.ftk_fragstream_open.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.ftk_fragstream_next.argtypes = [vp, C.POINTER(vp)]
+    lib.ftk_fragstream_n_refs.argtypes = [vp]
+    lib.ftk_fragstream_ref_name.argtypes = [vp, C.c_int]
+    lib.ftk_fragstream_ref_name.restype = C.c_char_p
+    lib.ftk_fragstream_ref_length.argtypes = [vp, C.c_int]
+    lib.ftk_fragstream_ref_length.restype = i64
+    lib.ftk_fragstream_close.argtypes = [vp]
+    lib.ftk_fragstream_close.restype = None
     lib.ftk_fragtable_is_bed6.argtypes = [vp]
     lib.ftk_fragtable_n_contigs.argtypes = [vp]
     lib.ftk_fragtable_contig_name.argtypes = [vp, C.c_int]

@@ -8,12 +8,16 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <numeric>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -598,5 +602,527 @@ int ftk_fragtable_is_pinned(const ftk_fragtable* t, int i) {
     return (t && i >= 0 && i < (int)t->contigs.size() && t->contigs[i].p.pinned) ? 1 : 0;
 }
 void ftk_fragtable_free(ftk_fragtable* t) { delete t; }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// Streaming decoder: one contig at a time, decoded ahead of the consumer
+// ---------------------------------------------------------------------------------------
+// A producer thread reads the file in pieces of whole BGZF blocks, inflates and parses each
+// piece on the worker threads and hands every finished contig (coordinate-sorted files keep a
+// contig's rows together) to a bounded queue as a one-contig ftk_fragtable in page-locked
+// memory.  The consumer uploads / computes on contig k while contig k+1 is being decoded, and
+// host memory stays bounded by the piece size plus `max_queued` contigs however large the file.
+namespace {
+
+// compressed bytes read per piece (FTK_STREAM_PIECE overrides it: the tests use small pieces to
+// exercise blocks, lines and records that straddle a piece boundary)
+const size_t kStreamPiece = [] {
+    const char* e = getenv("FTK_STREAM_PIECE");
+    const long long v = e ? atoll(e) : 0;
+    return v >= (1 << 16) ? (size_t)v : (size_t)(48u << 20);
+}();
+
+struct BamRun {
+    int ref = -1;
+    Columns c;
+};
+
+int inflate_block_list(const uint8_t* p, const std::vector<Block>& blocks, int n_threads, uint8_t* out) {
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    auto work = [&]() {
+        z_stream zs;
+        for (;;) {
+            size_t i = next.fetch_add(1);
+            if (i >= blocks.size() || bad.load()) break;
+            const Block& b = blocks[i];
+            if (b.out_len == 0) continue;
+            memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; break; }
+            zs.next_in = const_cast<Bytef*>(p + b.in_off);
+            zs.avail_in = (uInt)b.in_len;
+            zs.next_out = out + b.out_off;
+            zs.avail_out = (uInt)b.out_len;
+            int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; break; }
+        }
+    };
+    int nt = std::max(1, std::min<int>(n_threads, (int)blocks.size()));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    return bad.load() ? FTK_ERR_FORMAT : FTK_OK;
+}
+
+// Complete text lines [b, e) -> runs in file order (segments parsed in parallel).
+void parse_text_parallel(const char* b, const char* e, bool bed6, const char* only, int n_threads,
+                         std::vector<Run>* out) {
+    const size_t n = (size_t)(e - b);
+    int nseg = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, n / (1 << 16) + 1));
+    std::vector<const char*> cut(nseg + 1);
+    cut[0] = b;
+    cut[nseg] = e;
+    for (int i = 1; i < nseg; ++i) {
+        const char* q = b + n * (size_t)i / (size_t)nseg;
+        if (q < cut[i - 1]) q = cut[i - 1];
+        const char* nl = (const char*)memchr(q, '\n', (size_t)(e - q));
+        cut[i] = nl ? nl + 1 : e;
+    }
+    std::vector<std::vector<Run>> seg(nseg);
+    std::vector<std::thread> th;
+    for (int i = 1; i < nseg; ++i) th.emplace_back(parse_segment, cut[i], cut[i + 1], bed6, only, &seg[i]);
+    parse_segment(cut[0], cut[1], bed6, only, &seg[0]);
+    for (auto& x : th) x.join();
+    for (auto& v : seg)
+        for (auto& r : v) out->push_back(std::move(r));
+}
+
+// One BAM alignment record -> fragment columns (io/alignment.py:60-71,242-268); false = not a fragment.
+inline bool bam_record(const uint8_t* r, uint32_t bs, Columns& c) {
+    const int32_t pos = rd_i32(r + 4);
+    const uint8_t l_read_name = r[8];
+    const uint8_t mapq = r[9];
+    const uint16_t n_cigar = rd_u16(r + 12);
+    const uint16_t flag = rd_u16(r + 14);
+    const int32_t tlen = rd_i32(r + 28);
+    if ((flag & 0x4) || (flag & 0x100) || !(flag & 0x1) || (flag & 0x8) || (flag & 0x400) || (flag & 0x200) ||
+        (flag & 0x800) || !(flag & 0x2))
+        return false;
+    if (flag & 0x80) return false;  // read1 only
+    if (tlen == 0 || n_cigar == 0) return false;
+    if (32 + (size_t)l_read_name + 4 * (size_t)n_cigar > bs) return false;
+    const uint8_t* cg = r + 32 + l_read_name;
+    int64_t ref_len = 0;
+    for (uint16_t k = 0; k < n_cigar; ++k) {
+        const uint32_t v = rd_u32(cg + 4 * k);
+        const uint32_t op = v & 15;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += v >> 4;
+    }
+    const int64_t ref_end = (int64_t)pos + ref_len;
+    int64_t fs, fe;
+    if (tlen > 0) { fs = pos; fe = (int64_t)pos + tlen; } else { fs = ref_end + tlen; fe = ref_end; }
+    if (fs < 0 || fe < 0 || fs > INT32_MAX || fe > INT32_MAX) return false;
+    c.start.push_back((int32_t)fs);
+    c.end.push_back((int32_t)fe);
+    c.mapq.push_back(mapq);
+    c.strand.push_back((flag & 0x10) ? 0 : 1);
+    c.r1s.push_back(pos);
+    c.r1e.push_back((int32_t)ref_end);
+    return true;
+}
+
+void sort_by_start(Columns& c) {
+    const size_t m = c.start.size();
+    if (std::is_sorted(c.start.begin(), c.start.end())) return;
+    std::vector<uint32_t> perm(m);
+    std::iota(perm.begin(), perm.end(), 0u);
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return c.start[a] < c.start[b]; });
+    Columns s;
+    const bool r1 = !c.r1s.empty();
+    s.start.resize(m); s.end.resize(m); s.mapq.resize(m); s.strand.resize(m);
+    if (r1) { s.r1s.resize(m); s.r1e.resize(m); }
+    for (size_t i = 0; i < m; ++i) {
+        const uint32_t j = perm[i];
+        s.start[i] = c.start[j]; s.end[i] = c.end[j]; s.mapq[i] = c.mapq[j]; s.strand[i] = c.strand[j];
+        if (r1) { s.r1s[i] = c.r1s[j]; s.r1e[i] = c.r1e[j]; }
+    }
+    c = std::move(s);
+}
+
+}  // namespace
+
+struct ftk_fragstream {
+    std::string path, only;
+    bool has_only = false, bam = false, bed6 = false;
+    int n_threads = 1;
+    size_t max_queued = 2;
+    FILE* fp = nullptr;
+    std::thread producer;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<ftk_fragtable*> ready;
+    bool finished = false, stop = false;
+    int err = FTK_OK;
+    std::string errmsg;
+    // BAM header
+    std::vector<std::string> ref_names;
+    std::vector<int64_t> ref_lens;
+    bool header_ready = false;
+
+    // hand one finished contig to the consumer (blocks while the queue is full)
+    bool emit(Contig&& ct) {
+        std::unique_ptr<ftk_fragtable> t(new ftk_fragtable());
+        t->bam = bam;
+        t->bed6 = bed6;
+        t->contigs.push_back(std::move(ct));
+        if (bam) sort_by_start(t->contigs[0].c);
+        pack(t->contigs[0]);
+        if (!t->contigs[0].p.base) return fail(FTK_ERR_OOM, "out of host memory");
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || ready.size() < max_queued; });
+        if (stop) return false;
+        ready.push_back(t.release());
+        cv.notify_all();
+        return true;
+    }
+    bool fail(int code, const char* msg) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (err == FTK_OK) { err = code; errmsg = msg; }
+        return false;
+    }
+    void run();
+    bool run_text(std::vector<uint8_t>& first, size_t first_n);
+    bool run_bam(std::vector<uint8_t>& first, size_t first_n);
+    // read the next piece after `carry` bytes already in buf; returns bytes now in buf
+    size_t fill(std::vector<uint8_t>& buf, size_t carry) {
+        if (buf.size() < carry + kStreamPiece) buf.resize(carry + kStreamPiece);
+        const size_t got = fread(buf.data() + carry, 1, kStreamPiece, fp);
+        return carry + got;
+    }
+    // complete BGZF blocks at the front of buf[0, n): block list + bytes consumed; false on corruption
+    bool whole_blocks(const uint8_t* p, size_t n, bool eof, std::vector<Block>* blocks, size_t* used, size_t* total) {
+        blocks->clear();
+        size_t off = 0, tot = 0;
+        while (off < n) {
+            size_t bs = 0;
+            if (off + 18 > n) break;
+            const size_t q = gzip_header(p, n, off, &bs);
+            if (q && bs && off + bs <= n) {
+                if (q + 8 > off + bs) return false;
+                const uint8_t* tr = p + off + bs - 8;
+                const size_t isize = (size_t)tr[4] | ((size_t)tr[5] << 8) | ((size_t)tr[6] << 16) | ((size_t)tr[7] << 24);
+                blocks->push_back({q, off + bs - 8 - q, tot, isize});
+                tot += isize;
+                off += bs;
+                continue;
+            }
+            if (p[off] != 31 || p[off + 1] != 139) return false;  // not at a block boundary
+            if (q && bs && off + bs > n) break;                     // block continues in the next piece
+            if (!q && n - off < (1u << 16)) break;                  // header itself is cut
+            return false;
+        }
+        if (eof && off != n) return false;  // trailing garbage / truncated last block
+        *used = off;
+        *total = tot;
+        return true;
+    }
+};
+
+void ftk_fragstream::run() {
+    std::vector<uint8_t> buf;
+    const size_t n = fill(buf, 0);
+    size_t bsize = 0;
+    const bool bgzf = n >= 18 && gzip_header(buf.data(), n, 0, &bsize) && bsize;
+    bool ok;
+    if (!bgzf) {
+        // not block-compressed (plain gzip): no block parallelism to stream; decode whole and hand out per contig
+        fclose(fp);
+        fp = nullptr;
+        ftk_fragtable* whole = nullptr;
+        const int rc = bam ? ftk_bam_decode(path.c_str(), has_only ? only.c_str() : nullptr, n_threads, &whole)
+                           : ftk_fragfile_decode(path.c_str(), has_only ? only.c_str() : nullptr, n_threads, &whole);
+        if (rc != FTK_OK) {
+            fail(rc, g_decode_err.c_str());
+        } else {
+            bed6 = whole->bed6;
+            if (bam) {
+                std::lock_guard<std::mutex> lk(mu);
+                for (auto& ct : whole->contigs) { ref_names.push_back(ct.name); ref_lens.push_back(ct.length); }
+                header_ready = true;
+                cv.notify_all();
+            }
+            for (auto& ct : whole->contigs) {
+                Contig copy;
+                copy.name = ct.name;
+                copy.length = ct.length;
+                const Packed& p = ct.p;
+                copy.c.start.assign(p.start, p.start + p.rows);
+                copy.c.end.assign(p.end, p.end + p.rows);
+                copy.c.mapq.assign(p.mapq, p.mapq + p.rows);
+                copy.c.strand.assign(p.strand, p.strand + p.rows);
+                if (p.r1s) { copy.c.r1s.assign(p.r1s, p.r1s + p.rows); copy.c.r1e.assign(p.r1e, p.r1e + p.rows); }
+                if (p.rows == 0) continue;
+                if (!emit(std::move(copy))) break;
+            }
+            delete whole;
+        }
+        ok = true;
+    } else {
+        ok = bam ? run_bam(buf, n) : run_text(buf, n);
+    }
+    (void)ok;
+    std::lock_guard<std::mutex> lk(mu);
+    finished = true;
+    header_ready = true;
+    cv.notify_all();
+}
+
+bool ftk_fragstream::run_text(std::vector<uint8_t>& buf, size_t n) {
+    std::vector<Block> blocks;
+    std::vector<char> text;       // carry (incomplete last line) + this piece's inflated text
+    size_t text_carry = 0;
+    bool layout_known = false;
+    Contig cur;
+    bool have_cur = false;
+    std::set<std::string> seen;
+    bool eof = n < kStreamPiece;
+    for (;;) {
+        size_t used = 0, total = 0;
+        if (!whole_blocks(buf.data(), n, eof, &blocks, &used, &total)) return fail(FTK_ERR_FORMAT, "corrupt BGZF block");
+        if (text.size() < text_carry + total + 1) text.resize(text_carry + total + 1);
+        if (!blocks.empty() && inflate_block_list(buf.data(), blocks, n_threads, (uint8_t*)text.data() + text_carry) != FTK_OK)
+            return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+        const char* b = text.data();
+        const char* e = b + text_carry + total;
+        if (!layout_known) {  // io/alignment.py:143-156: BED6 when the first data row has > 5 columns
+            const char* q = b;
+            while (q < e) {
+                const char* nl = (const char*)memchr(q, '\n', (size_t)(e - q));
+                const char* le = nl ? nl : e;
+                if (le > q && *q != '#') {
+                    int tabs = 0;
+                    for (const char* x = q; x < le; ++x) tabs += (*x == '\t');
+                    bed6 = (tabs + 1) > 5;
+                    layout_known = true;
+                    break;
+                }
+                if (!nl) break;
+                q = nl + 1;
+            }
+        }
+        // complete lines only; the rest waits for the next piece
+        const char* last = e;
+        if (!eof) {
+            while (last > b && last[-1] != '\n') --last;
+        }
+        std::vector<Run> runs;
+        if (last > b) parse_text_parallel(b, last, bed6, has_only ? only.c_str() : nullptr, n_threads, &runs);
+        for (auto& r : runs) {
+            if (have_cur && r.name != cur.name) {
+                if (!emit(std::move(cur))) return false;
+                cur = Contig{};
+                have_cur = false;
+            }
+            if (!have_cur) {
+                if (!seen.insert(r.name).second)
+                    return fail(FTK_ERR_UNSORTED, ("contig " + r.name + " appears in two separate runs: the file is not sorted").c_str());
+                cur.name = r.name;
+                have_cur = true;
+            }
+            cur.c.append(r.c);
+        }
+        text_carry = (size_t)(e - last);
+        if (text_carry) memmove(text.data(), last, text_carry);
+        if (eof) break;
+        const size_t raw_carry = n - used;
+        if (raw_carry) memmove(buf.data(), buf.data() + used, raw_carry);
+        n = fill(buf, raw_carry);
+        eof = n - raw_carry < kStreamPiece;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (stop) return false;
+        }
+    }
+    if (have_cur && !emit(std::move(cur))) return false;
+    return true;
+}
+
+bool ftk_fragstream::run_bam(std::vector<uint8_t>& buf, size_t n) {
+    std::vector<Block> blocks;
+    std::vector<uint8_t> data;  // carry (partial record / header) + this piece's inflated bytes
+    size_t carry = 0;
+    bool header_done = false;
+    std::vector<int> wanted;    // ref id -> 1 when selected
+    Contig cur;
+    int cur_ref = -1;
+    std::set<int> seen;
+    bool eof = n < kStreamPiece;
+    for (;;) {
+        size_t used = 0, total = 0;
+        if (!whole_blocks(buf.data(), n, eof, &blocks, &used, &total)) return fail(FTK_ERR_FORMAT, "corrupt BGZF block");
+        if (data.size() < carry + total + 1) data.resize(carry + total + 1);
+        if (!blocks.empty() && inflate_block_list(buf.data(), blocks, n_threads, data.data() + carry) != FTK_OK)
+            return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+        const uint8_t* p = data.data();
+        const size_t m = carry + total;
+        size_t off = 0;
+        if (!header_done) {
+            bool complete = false;
+            do {
+                if (m < 12) break;
+                if (memcmp(p, "BAM\1", 4) != 0) return fail(FTK_ERR_FORMAT, (path + " is not a BAM file").c_str());
+                size_t o = 4;
+                const uint32_t l_text = rd_u32(p + o);
+                o += 4 + (size_t)l_text;
+                if (o + 4 > m) break;
+                const uint32_t n_ref = rd_u32(p + o);
+                o += 4;
+                std::vector<std::string> names;
+                std::vector<int64_t> lens;
+                bool cut = false;
+                for (uint32_t r = 0; r < n_ref; ++r) {
+                    if (o + 4 > m) { cut = true; break; }
+                    const uint32_t l_name = rd_u32(p + o);
+                    o += 4;
+                    if (l_name == 0) return fail(FTK_ERR_FORMAT, "corrupt BAM reference list");
+                    if (o + l_name + 4 > m) { cut = true; break; }
+                    names.emplace_back((const char*)p + o, l_name - 1);
+                    o += l_name;
+                    lens.push_back(rd_i32(p + o));
+                    o += 4;
+                }
+                if (cut) break;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ref_names = names;
+                    ref_lens = lens;
+                    header_ready = true;
+                    cv.notify_all();
+                }
+                wanted.assign(n_ref, 0);
+                for (uint32_t r = 0; r < n_ref; ++r) wanted[r] = !has_only || names[r] == only;
+                off = o;
+                complete = true;
+            } while (false);
+            if (!complete) {
+                if (eof) return fail(FTK_ERR_FORMAT, "truncated BAM header");
+                carry = m;  // need more bytes: keep everything
+                goto next_piece;
+            }
+            header_done = true;
+        }
+        {
+            // index the complete records, parse them in parallel, merge the runs in order
+            std::vector<size_t> rec;
+            size_t o = off;
+            while (o + 4 <= m) {
+                const uint32_t bs = rd_u32(p + o);
+                if (bs < 32) return fail(FTK_ERR_FORMAT, "corrupt BAM record");
+                if (o + 4 + bs > m) break;
+                rec.push_back(o);
+                o += 4 + (size_t)bs;
+            }
+            if (eof && o != m) return fail(FTK_ERR_FORMAT, "truncated BAM record");
+            const int n_ref = (int)wanted.size();
+            int nseg = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, rec.size() / 4096 + 1));
+            std::vector<std::vector<BamRun>> seg(nseg);
+            auto work = [&](int sg) {
+                const size_t r0 = rec.size() * (size_t)sg / (size_t)nseg, r1 = rec.size() * (size_t)(sg + 1) / (size_t)nseg;
+                BamRun* run = nullptr;
+                for (size_t k = r0; k < r1; ++k) {
+                    const uint8_t* r = p + rec[k] + 4;
+                    const uint32_t bs = rd_u32(p + rec[k]);
+                    const int32_t ref_id = rd_i32(r);
+                    if (ref_id < 0 || ref_id >= n_ref || !wanted[ref_id]) continue;
+                    if (!run || run->ref != ref_id) {
+                        seg[sg].push_back(BamRun{ref_id, {}});
+                        run = &seg[sg].back();
+                    }
+                    bam_record(r, bs, run->c);
+                }
+            };
+            std::vector<std::thread> th;
+            for (int i = 1; i < nseg; ++i) th.emplace_back(work, i);
+            work(0);
+            for (auto& x : th) x.join();
+            for (auto& v : seg)
+                for (auto& r : v) {
+                    if (cur_ref >= 0 && r.ref != cur_ref) {
+                        if (!cur.c.start.empty() && !emit(std::move(cur))) return false;
+                        cur = Contig{};
+                        cur_ref = -1;
+                    }
+                    if (cur_ref < 0) {
+                        if (!seen.insert(r.ref).second)
+                            return fail(FTK_ERR_UNSORTED, ("contig " + ref_names[r.ref] + " appears in two separate runs: the BAM is not coordinate-sorted").c_str());
+                        cur_ref = r.ref;
+                        cur.name = ref_names[r.ref];
+                        cur.length = ref_lens[r.ref];
+                    }
+                    cur.c.append(r.c);
+                }
+            carry = m - o;
+            if (carry) memmove(data.data(), p + o, carry);
+        }
+    next_piece:
+        if (eof) break;
+        {
+            const size_t raw_carry = n - used;
+            if (raw_carry) memmove(buf.data(), buf.data() + used, raw_carry);
+            n = fill(buf, raw_carry);
+            eof = n - raw_carry < kStreamPiece;
+            std::lock_guard<std::mutex> lk(mu);
+            if (stop) return false;
+        }
+    }
+    if (cur_ref >= 0 && !cur.c.start.empty() && !emit(std::move(cur))) return false;
+    return true;
+}
+
+extern "C" {
+
+int ftk_fragstream_open(const char* path, const char* contig, int is_bam, int n_threads, int max_queued,
+                        ftk_fragstream** out) {
+    if (!path || !out) return dfail(FTK_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return dfail(FTK_ERR_IO, "cannot read %s", path);
+    ftk_fragstream* s = new ftk_fragstream();
+    s->path = path;
+    if (contig) { s->only = contig; s->has_only = true; }
+    s->bam = is_bam != 0;
+    s->n_threads = std::max(1, n_threads);
+    s->max_queued = (size_t)std::max(1, max_queued);
+    s->fp = fp;
+    s->producer = std::thread([s] { s->run(); });
+    *out = s;
+    return FTK_OK;
+}
+
+int ftk_fragstream_next(ftk_fragstream* s, ftk_fragtable** out) {
+    if (!s || !out) return dfail(FTK_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    std::unique_lock<std::mutex> lk(s->mu);
+    s->cv.wait(lk, [&] { return !s->ready.empty() || s->finished; });
+    if (!s->ready.empty()) {
+        *out = s->ready.front();
+        s->ready.pop_front();
+        s->cv.notify_all();
+        return FTK_OK;
+    }
+    if (s->err != FTK_OK) return dfail(s->err, "%s", s->errmsg.c_str());
+    return FTK_OK;  // end of file: *out stays NULL
+}
+
+int ftk_fragstream_n_refs(ftk_fragstream* s) {
+    if (!s) return 0;
+    std::unique_lock<std::mutex> lk(s->mu);
+    s->cv.wait(lk, [&] { return s->header_ready || s->finished; });
+    return (int)s->ref_names.size();
+}
+const char* ftk_fragstream_ref_name(ftk_fragstream* s, int i) {
+    if (!s || i < 0 || i >= ftk_fragstream_n_refs(s)) return nullptr;
+    return s->ref_names[i].c_str();
+}
+int64_t ftk_fragstream_ref_length(ftk_fragstream* s, int i) {
+    if (!s || i < 0 || i >= ftk_fragstream_n_refs(s)) return -1;
+    return s->ref_lens[i];
+}
+
+void ftk_fragstream_close(ftk_fragstream* s) {
+    if (!s) return;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->stop = true;
+        s->cv.notify_all();
+    }
+    if (s->producer.joinable()) s->producer.join();
+    for (auto* t : s->ready) delete t;
+    if (s->fp) fclose(s->fp);
+    delete s;
+}
 
 }  // extern "C"

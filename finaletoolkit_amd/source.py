@@ -123,8 +123,12 @@ def _columns(lib, table, i, rows):
             arr(ps[4], C.c_int32), arr(ps[5], C.c_int32))
 
 
-def open_source(input_file, workers: int | None = None, warn_bed6: bool = True) -> FragSource:
-    """Decode ``input_file`` (cached by path/mtime/size) and upload its contigs."""
+def stream_source(input_file, workers: int | None = None, queued: int = 2):
+    """Decode ``input_file`` with the streaming decoder (``ftk_fragstream_*``) and upload it contig by
+    contig: a generator yielding ``(src, contig)`` as soon as a contig is resident in HBM, while the
+    decoder threads already work on the next one (decode || H2D || the caller's kernels).  Host memory is
+    bounded by ``queued`` contigs whatever the file size.  The finished source is cached like
+    ``open_source``'s; if the file is already cached its contigs are yielded straight away."""
     global _NEXT_ID
     path, is_bam = _check_path(input_file)
     st = os.stat(path)
@@ -132,37 +136,75 @@ def open_source(input_file, workers: int | None = None, warn_bed6: bool = True) 
     src = _SOURCES.get(ckey)
     if src is not None:
         _SOURCES.move_to_end(ckey)
-        if src.bed6 and warn_bed6:
-            _warn_bed6()
-        return src
+        for c in src.contigs:
+            if c in src.loaded:
+                yield src, c
+        return
     eng = get_engine()  # fails loudly without the HIP library / a GPU
     lib = L.load()
-    table = C.c_void_p()
-    fn = lib.ftk_bam_decode if is_bam else lib.ftk_fragfile_decode
-    rc = fn(path.encode(), None, decode_threads(workers), C.byref(table))
+    stream = C.c_void_p()
+    rc = lib.ftk_fragstream_open(path.encode(), None, int(is_bam), decode_threads(workers), int(queued), C.byref(stream))
     if rc != L.FTK_OK:
         msg = lib.ftk_fragtable_error().decode()
-        if rc == L.FTK_ERR_IO:
-            raise FileNotFoundError(msg)
-        raise UnsupportedFormatError(msg)
+        raise FileNotFoundError(msg) if rc == L.FTK_ERR_IO else UnsupportedFormatError(msg)
+    src = FragSource(path, is_bam, False, [], {}, _NEXT_ID)
+    _NEXT_ID += 1
+    complete = False
     try:
-        n = lib.ftk_fragtable_n_contigs(table)
-        names = [lib.ftk_fragtable_contig_name(table, i).decode() for i in range(n)]
-        lengths = {names[i]: (lib.ftk_fragtable_contig_length(table, i) if is_bam else None) for i in range(n)}
-        src = FragSource(path, is_bam, bool(lib.ftk_fragtable_is_bed6(table)), names, lengths, _NEXT_ID)
-        _NEXT_ID += 1
-        for i, name in enumerate(names):
-            rows = lib.ftk_fragtable_contig_rows(table, i)
-            if rows == 0 and not is_bam:
-                continue
-            eng.load_contig_from_table(src.key(name), table, i, is_bam)
-            src.loaded.add(name)
+        if is_bam:  # header order and lengths are known up front
+            for i in range(lib.ftk_fragstream_n_refs(stream)):
+                name = lib.ftk_fragstream_ref_name(stream, i).decode()
+                src.contigs.append(name)
+                src.lengths[name] = lib.ftk_fragstream_ref_length(stream, i)
+        while True:
+            table = C.c_void_p()
+            rc = lib.ftk_fragstream_next(stream, C.byref(table))
+            if rc != L.FTK_OK:
+                msg = lib.ftk_fragtable_error().decode()
+                raise FileNotFoundError(msg) if rc == L.FTK_ERR_IO else UnsupportedFormatError(msg)
+            if not table.value:
+                break
+            try:
+                name = lib.ftk_fragtable_contig_name(table, 0).decode()
+                src.bed6 = bool(lib.ftk_fragtable_is_bed6(table))
+                if not is_bam:
+                    src.contigs.append(name)
+                    src.lengths[name] = None
+                eng.load_contig_from_table(src.key(name), table, 0, is_bam)
+                src.loaded.add(name)
+            finally:
+                lib.ftk_fragtable_free(table)
+            yield src, name
+        if is_bam:  # contigs of the header without a single usable read: valid, empty (pysam yields nothing)
+            empty32, empty8 = np.zeros(0, np.int32), np.zeros(0, np.uint8)
+            for name in src.contigs:
+                if name not in src.loaded:
+                    eng.load_contig(src.key(name), empty32, empty32, empty8, empty8, empty32, empty32)
+                    src.loaded.add(name)
+        complete = True
     finally:
-        lib.ftk_fragtable_free(table)
+        lib.ftk_fragstream_close(stream)
+        if not complete:  # consumer stopped early or the decode failed: do not cache a partial source
+            src.release()
     _SOURCES[ckey] = src
     while len(_SOURCES) > _MAX_SOURCES:
         _, old = _SOURCES.popitem(last=False)
         old.release()
+
+
+def open_source(input_file, workers: int | None = None, warn_bed6: bool = True) -> FragSource:
+    """Decode ``input_file`` (cached by path/mtime/size) and upload its contigs; decoding streams contig by
+    contig (``stream_source``), so the host never holds more than two contigs of the file."""
+    path, _ = _check_path(input_file)
+    st = os.stat(path)
+    ckey = (os.path.abspath(path), st.st_mtime_ns, st.st_size)
+    src = _SOURCES.get(ckey)
+    if src is None:
+        for _ in stream_source(input_file, workers):
+            pass
+        src = _SOURCES[ckey]
+    else:
+        _SOURCES.move_to_end(ckey)
     if src.bed6 and warn_bed6:
         _warn_bed6()
     return src

@@ -132,6 +132,22 @@ int ftk_frags_release(ftk_ctx* ctx, int contig_id);
  * read1 only, TLEN reconstruction); rows sorted by fragment start. */
 int ftk_fragfile_decode(const char* path, const char* contig /* NULL = all */, int n_threads, ftk_fragtable** out);
 int ftk_bam_decode(const char* path, const char* contig /* NULL = all */, int n_threads, ftk_fragtable** out);
+/* The same decoders as a stream: a producer thread decodes the file piece by piece (BGZF blocks in
+ * parallel on n_threads) and hands over every finished contig as a one-contig table in page-locked
+ * memory, at most max_queued contigs ahead of the caller -- so the caller uploads and computes on
+ * contig k while contig k+1 is being decoded, and host memory stays bounded for any file size.
+ * ftk_fragstream_next returns FTK_OK with *out == NULL at the end of the file; tables are freed with
+ * ftk_fragtable_free.  Input must keep each contig's rows together (coordinate-sorted), else
+ * FTK_ERR_UNSORTED.  BAM: ftk_fragstream_n_refs / _ref_name / _ref_length give the header's @SQ list
+ * (they wait for the header). */
+typedef struct ftk_fragstream ftk_fragstream;
+int ftk_fragstream_open(const char* path, const char* contig /* NULL = all */, int is_bam, int n_threads,
+                        int max_queued, ftk_fragstream** out);
+int ftk_fragstream_next(ftk_fragstream* s, ftk_fragtable** out);
+int ftk_fragstream_n_refs(ftk_fragstream* s);
+const char* ftk_fragstream_ref_name(ftk_fragstream* s, int i);
+int64_t ftk_fragstream_ref_length(ftk_fragstream* s, int i);
+void ftk_fragstream_close(ftk_fragstream* s);
 const char* ftk_fragtable_error(void); /* message for a failed decode call (thread-local) */
 int ftk_fragtable_is_bed6(const ftk_fragtable* t);
 int ftk_fragtable_n_contigs(const ftk_fragtable* t);

@@ -1,0 +1,162 @@
+"""CPU: the streaming decoder (ftk_fragstream_*) hands out, contig by contig, exactly what the
+whole-file decoders return -- also when BGZF blocks, text lines and BAM records straddle the
+boundaries of the pieces it reads (FTK_STREAM_PIECE makes the pieces small)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from finaletoolkit_amd import _lib as L
+from finaletoolkit_amd import bgzf, synth
+from tests.helpers import DATA, GOLDEN, ROOT, write_synthetic_bam
+from tests.test_abi import _decode
+
+
+def _stream(path, bam=False, contig=None, threads=3, queued=2):
+    lib = L.load()
+    s = C.c_void_p()
+    rc = lib.ftk_fragstream_open(path.encode(), None if contig is None else contig.encode(), int(bam), threads, queued,
+                                 C.byref(s))
+    if rc != 0:
+        raise RuntimeError((rc, lib.ftk_fragtable_error().decode()))
+    out, order = {}, []
+    try:
+        refs = [(lib.ftk_fragstream_ref_name(s, i).decode(), lib.ftk_fragstream_ref_length(s, i))
+                for i in range(lib.ftk_fragstream_n_refs(s))] if bam else []
+        while True:
+            t = C.c_void_p()
+            rc = lib.ftk_fragstream_next(s, C.byref(t))
+            if rc != 0:
+                raise RuntimeError((rc, lib.ftk_fragtable_error().decode()))
+            if not t.value:
+                break
+            try:
+                assert lib.ftk_fragtable_n_contigs(t) == 1
+                rows = lib.ftk_fragtable_contig_rows(t, 0)
+                name = lib.ftk_fragtable_contig_name(t, 0).decode()
+                ps = [C.c_void_p() for _ in range(6)]
+                assert lib.ftk_fragtable_columns(t, 0, *[C.byref(p) for p in ps]) == 0
+                cols = []
+                for p, ct in zip(ps, (C.c_int32, C.c_int32, C.c_uint8, C.c_uint8, C.c_int32, C.c_int32)):
+                    cols.append(None if not p.value or rows == 0
+                                else np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), (rows,)).copy())
+                assert name not in out
+                out[name] = (rows, cols, lib.ftk_fragtable_contig_length(t, 0))
+                order.append(name)
+                out["__bed6__"] = lib.ftk_fragtable_is_bed6(t)
+            finally:
+                lib.ftk_fragtable_free(t)
+    finally:
+        lib.ftk_fragstream_close(s)
+    return out, order, refs
+
+
+def _same(got, want):
+    names = [k for k in want if not k.startswith("__") and want[k][0] > 0]
+    assert sorted(k for k in got if not k.startswith("__")) == sorted(names)
+    for k in names:
+        assert got[k][0] == want[k][0] and got[k][2] == want[k][2], k
+        for a, b in zip(got[k][1], want[k][1]):
+            assert (a is None and b is None) or np.array_equal(a, b), k
+
+
+@pytest.mark.parametrize("name,bam", [("12.3444.b37.frag.gz", False), ("12.3444.b37.frag.bed.gz", False),
+                                      ("12.3444.b37.bam", True)])
+def test_stream_equals_whole_file_on_fixtures(name, bam):
+    path = os.path.join(DATA, name)
+    got, order, refs = _stream(path, bam=bam)
+    want = _decode(path, bam=bam)
+    _same(got, want)
+    assert got["__bed6__"] == want["__bed6__"]
+    if bam:
+        assert len(refs) == 84 and ("12", 133851895) in refs
+
+
+_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from tests.test_stream_decoder import _stream, _same
+from tests.test_abi import _decode
+path, bam = sys.argv[1], sys.argv[2] == "1"
+for threads in (1, 4):
+    got, order, refs = _stream(path, bam=bam, threads=threads, queued=1)
+    _same(got, _decode(path, bam=bam))
+only, _, _ = _stream(path, bam=bam, contig=sys.argv[3])
+assert [k for k in only if not k.startswith("__")] == [sys.argv[3]]
+print("ok", order)
+"""
+
+
+def _run_child(path, bam, contig):
+    env = dict(os.environ, FTK_STREAM_PIECE="65536")
+    r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT), path, "1" if bam else "0", contig], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+    return r.stdout
+
+
+def test_stream_small_pieces_text(tmp_path):
+    """Four contigs, ~6 MB compressed, read in 64 KB pieces: every kind of boundary straddle occurs."""
+    rows = []
+    for k, size in enumerate((2_000_000, 900_000, 50_000, 1_500_000)):
+        s, e, q, st = synth.synth_contig(size, depth=18.0, seed=40 + k)
+        rows.append((f"c{k}", s, e, q, st))
+    p = str(tmp_path / "multi.frag.gz")
+    bgzf.write_frag_gz(p, rows, level=1)
+    out = _run_child(p, False, "c2")
+    assert "['c0', 'c1', 'c2', 'c3']" in out
+
+
+def test_stream_small_pieces_bam(tmp_path):
+    rng = np.random.default_rng(9)
+    contigs = [("chrA", 3_000_000), ("chrEmpty", 1000), ("chrB", 1_000_000), ("chrC", 400_000)]
+    frags = {}
+    for name, size in contigs:
+        if name == "chrEmpty":
+            continue
+        n = size // 40
+        s = np.sort(rng.integers(0, size - 700, n))
+        frags[name] = (s, s + rng.integers(210, 600, n), rng.integers(0, 61, n), rng.integers(0, 2, n).astype(bool))
+    p = str(tmp_path / "multi.bam")
+    write_synthetic_bam(p, contigs, frags)
+    out = _run_child(p, True, "chrB")
+    assert "['chrA', 'chrB', 'chrC']" in out
+
+
+def test_stream_errors(tmp_path):
+    with pytest.raises(RuntimeError):
+        _stream(str(tmp_path / "absent.gz"))
+    junk = tmp_path / "junk.gz"
+    junk.write_bytes(b"this is not gzip")
+    with pytest.raises(RuntimeError):
+        _stream(str(junk))
+    # a contig that comes back after another one: not coordinate-sorted
+    s, e, q, st = synth.synth_contig(200_000, depth=5.0, seed=1)
+    p = str(tmp_path / "unsorted.frag.gz")
+    bgzf.write_frag_gz(p, [("a", s, e, q, st), ("b", s, e, q, st), ("a", s, e, q, st)], level=1)
+    with pytest.raises(RuntimeError) as ei:
+        _stream(p)
+    assert ei.value.args[0][0] == L.FTK_ERR_UNSORTED
+    # truncated BGZF file
+    data = open(os.path.join(GOLDEN, "synth.frag.gz"), "rb").read()
+    cut = tmp_path / "cut.frag.gz"
+    cut.write_bytes(data[: len(data) // 2])
+    with pytest.raises(RuntimeError):
+        _stream(str(cut))
+    # closing a stream that was never drained must not hang
+    lib = L.load()
+    h = C.c_void_p()
+    assert lib.ftk_fragstream_open(os.path.join(GOLDEN, "synth.frag.gz").encode(), None, 0, 2, 1, C.byref(h)) == 0
+    lib.ftk_fragstream_close(h)
+
+
+def test_stream_plain_gzip_falls_back(tmp_path):
+    import gzip
+    p = str(tmp_path / "plain.frag.gz")
+    with gzip.open(p, "wt") as fh:
+        fh.write("1\t10\t200\t60\t+\n1\t50\t260\t30\t-\n2\t5\t100\t9\t+\n")
+    got, order, _ = _stream(p)
+    assert order == ["1", "2"] and got["1"][1][0].tolist() == [10, 50] and got["2"][1][2].tolist() == [9]
