@@ -30,6 +30,31 @@ static int decode(const char* path, bool bam, int threads, long* rows_out) {
     return FTK_OK;
 }
 
+// the streaming decoder on the same file: rows must match (or fail cleanly); small pieces via FTK_STREAM_PIECE
+static int stream(const char* path, bool bam, int threads, long* rows_out) {
+    ftk_fragstream* s = nullptr;
+    int rc = ftk_fragstream_open(path, nullptr, bam ? 1 : 0, threads, 1, &s);
+    if (rc != FTK_OK) return rc;
+    long rows = 0;
+    if (bam) (void)ftk_fragstream_n_refs(s);
+    for (;;) {
+        ftk_fragtable* t = nullptr;
+        rc = ftk_fragstream_next(s, &t);
+        if (rc != FTK_OK || !t) break;
+        const int32_t *st, *en, *r1s, *r1e;
+        const uint8_t *q, *sd;
+        ftk_fragtable_columns(t, 0, &st, &en, &q, &sd, &r1s, &r1e);
+        long n = (long)ftk_fragtable_contig_rows(t, 0), acc = 0;
+        for (long k = 0; k < n; ++k) acc += st[k] + en[k] + q[k] + sd[k] + (r1s ? r1s[k] + r1e[k] : 0);
+        if (acc == 42) printf(" ");
+        rows += n;
+        ftk_fragtable_free(t);
+    }
+    ftk_fragstream_close(s);
+    *rows_out = rows;
+    return rc;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::string data = argv[1];
@@ -40,6 +65,10 @@ int main(int argc, char** argv) {
         for (int th : {1, 3}) {
             if (decode((data + c.f).c_str(), c.bam, th, &rows) != FTK_OK || rows != c.want) {
                 fprintf(stderr, "FAIL %s rows=%ld (%s)\n", c.f, rows, ftk_fragtable_error());
+                return 1;
+            }
+            if (stream((data + c.f).c_str(), c.bam, th, &rows) != FTK_OK || rows != c.want) {
+                fprintf(stderr, "FAIL stream %s rows=%ld (%s)\n", c.f, rows, ftk_fragtable_error());
                 return 1;
             }
         }
@@ -55,6 +84,7 @@ int main(int argc, char** argv) {
             fwrite(buf.data(), 1, cut, out);
             fclose(out);
             decode(tmp.c_str(), c.bam, 2, &rows);
+            stream(tmp.c_str(), c.bam, 2, &rows);
         }
         for (size_t pos = 0; pos < n; pos += 7) {
             std::vector<unsigned char> b2(buf.begin(), buf.begin() + n);
@@ -64,6 +94,7 @@ int main(int argc, char** argv) {
             fwrite(b2.data(), 1, n, out);
             fclose(out);
             decode(tmp.c_str(), c.bam, 2, &rows);
+            if (pos % 35 == 0) stream(tmp.c_str(), c.bam, 2, &rows);
         }
     }
     printf("decode_sanitize ok\n");
