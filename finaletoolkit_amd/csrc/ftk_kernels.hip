@@ -101,7 +101,9 @@ __global__ void bounds_kernel(ContigView cv, const int32_t* ws, const int32_t* w
     cand_lo[w] = lo;
     cand_hi[w] = hi;
     nchunks[w] = nc;
-    if (nc) {  // the chunked path accumulates with atomics: start from zero
+    // the chunked path accumulates with atomics: start from zero.  Without a wave-per-window pass
+    // (small_max < 0) nobody else writes the rows of windows that have no candidates at all.
+    if (nc || small_max < 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (z.p[k]) z.p[k][w] = 0;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(1024) void plan_kernel(ContigView cv, const int32_t
             cand_lo[w] = lo;
             cand_hi[w] = hi;
             nchunks[w] = vv[r];
-            if (vv[r]) {
+            if (vv[r] || small_max < 0) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (z.p[k]) z.p[k][w] = 0;

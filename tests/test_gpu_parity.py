@@ -307,3 +307,79 @@ def test_batched_launches_equal_per_contig_calls(engine, data):
         assert np.array_equal(got[offs[k]:offs[k + 1]], engine.wps(n, a, b, cs)), n
     for n in names[1:]:
         engine.release(n)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_feature_fuzz_extreme_parameters(engine, data, seed):
+    """Random filter / window / histogram parameters drawn from extreme values (open bounds, bounds beyond
+    2^30, negative and > 255 mapq cuts, inverted and negative windows) against the C oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    ext = [O.OPEN_LO, -(2 ** 30) - 5, -1, 0, 1, 5000, CONTIG_LEN - 1, CONTIG_LEN, CONTIG_LEN + 7, 2 ** 30 - 1, 2 ** 30,
+           2 ** 30 + 9, O.OPEN_HI]
+    for it in range(6):
+        n = int(rng.integers(1, 400))
+        ws = rng.integers(-50_000, CONTIG_LEN + 50_000, n).astype(np.int64)
+        we = ws + rng.integers(-2000, 300_000, n)
+        k = rng.integers(0, n, max(1, n // 5))
+        ws[k] = rng.choice(ext, len(k))
+        k = rng.integers(0, n, max(1, n // 5))
+        we[k] = rng.choice(ext, len(k))
+        ws = np.clip(ws, O.OPEN_LO, O.OPEN_HI).astype(np.int32)
+        we = np.clip(we, O.OPEN_LO, O.OPEN_HI).astype(np.int32)
+        if it == 0:  # a bin tiling large enough for the block-per-window path, with a few extremes mixed in
+            ws, we = synth.tiling_windows(CONTIG_LEN, 5_000)
+            ws, we = ws.copy(), we.copy()
+            ws[::97] = O.OPEN_LO
+            we[::89] = O.OPEN_HI
+        mapq = int(rng.choice([-5, 0, 1, 30, 59, 60, 61, 255, 256, 1000]))
+        mn = rng.choice([None, 0, 1, 100, 167, 1000, 2 ** 30, 2 ** 31 - 1])
+        mx = rng.choice([None, 0, 150, 167, 999, 1000, 2 ** 30, 2 ** 31 - 1])
+        mn = None if mn is None else int(mn)
+        mx = None if mx is None else int(mx)
+        policy = str(rng.choice(["midpoint", "any"]))
+        len_lo = int(rng.choice([-50, 0, 100, 167, 990, 5000]))
+        n_bins = int(rng.choice([1, 7, 64, 1001, 2500]))
+        flt = dict(mapq_min=mapq, min_len=mn, max_len=mx, policy=policy)
+        want_c = O.c_window_counts(data["fr"], ws, we, **flt)
+        want_h, want_o = O.c_fraglen_hist(data["fr"], ws, we, len_lo, n_bins, **flt)
+        got = engine.window_features("synA", ws, we, mapq, mn, mx, policy, hist=(len_lo, n_bins))
+        tag = (seed, it, flt, len_lo, n_bins)
+        assert np.array_equal(got["coverage"], want_c), tag
+        assert np.array_equal(got["hist"], want_h), tag
+        assert np.array_equal(got["overflow"], want_o), tag
+        dq = int(rng.choice([-1, 0, 30, 300]))
+        gaps = rng.choice([0, 1, 2])
+        g = None if gaps == 0 else ((int(rng.integers(0, CONTIG_LEN)), int(rng.integers(0, CONTIG_LEN)), [])
+                                    if gaps == 1 else (1_000_000, 1_400_000, [(0, 20_000), (CONTIG_LEN - 30_000, 2 ** 30)]))
+        want = O.c_delfi_counts(data["fr"], ws, we, dq, None, None, g)
+        got = engine.delfi_counts("synA", ws, we, dq, None, None, g)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), (tag, dq, g)
+
+
+def test_coordinates_near_the_upper_limit(engine):
+    """Fragments and windows just below 2^30 (the largest coordinate the SoA admits)."""
+    rng = np.random.default_rng(5)
+    top = 2 ** 30 - 1
+    n = 20_000
+    s = np.sort(rng.integers(top - 3_000_000, top - 600, n)).astype(np.int32)
+    e = np.minimum(s + rng.integers(0, 600, n), top).astype(np.int32)
+    q = rng.integers(0, 61, n).astype(np.uint8)
+    st = rng.integers(0, 2, n).astype(np.uint8)
+    s[-1], e[-1] = top, top  # zero-length fragment at the very end
+    engine.load_contig("hi", s, e, q, st)
+    fr = O.Frags(s, e, q, st)
+    ws = np.array([top - 3_000_000, top - 100_000, top - 1, top, O.OPEN_LO, top - 2_000_000], np.int32)
+    we = np.array([top - 2_000_000, top, top, top + 1, O.OPEN_HI, 2 ** 30 + 5], np.int32)
+    for policy in ("midpoint", "any"):
+        assert np.array_equal(engine.window_counts("hi", ws, we, 10, intersect_policy=policy),
+                              O.c_window_counts(fr, ws, we, mapq_min=10, policy=policy)), policy
+    h, o = engine.fraglen_hist("hi", ws, we, 0, 700, quality_threshold=0)
+    wh, wo = O.c_fraglen_hist(fr, ws, we, 0, 700, mapq_min=0)
+    assert np.array_equal(h, wh) and np.array_equal(o, wo)
+    g = (top - 1_000_000, top - 900_000, [(top - 50_000, top)])
+    for a, b in zip(engine.delfi_counts("hi", ws, we, 0, None, None, g), O.c_delfi_counts(fr, ws, we, 0, None, None, g)):
+        assert np.array_equal(a, b)
+    a, b = top - 20_000, top
+    assert np.array_equal(engine.wps("hi", a, b, 2 ** 30), O.c_wps(fr, a, b, 2 ** 30, 120, 120, 180, 30))
+    engine.release("hi")
