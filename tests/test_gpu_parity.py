@@ -383,3 +383,30 @@ def test_coordinates_near_the_upper_limit(engine):
     a, b = top - 20_000, top
     assert np.array_equal(engine.wps("hi", a, b, 2 ** 30), O.c_wps(fr, a, b, 2 ** 30, 120, 120, 180, 30))
     engine.release("hi")
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_wps_and_cleavage_fuzz(engine, data, seed):
+    """Random WPS / cleavage parameters incl. degenerate ones (window 1..2000, min > max, chrom_size inside the
+    data, intervals hanging over both contig ends) against the C oracle."""
+    rng = np.random.default_rng(2000 + seed)
+    for it in range(10):
+        W = int(rng.choice([1, 2, 3, 60, 119, 120, 121, 500, 2000]))
+        mn = int(rng.choice([0, 1, 100, 120, 167, 400]))
+        mx = int(rng.choice([0, 90, 150, 167, 180, 600, 5000]))
+        q = int(rng.choice([0, 1, 30, 60, 61]))
+        chrom = int(rng.choice([CONTIG_LEN, CONTIG_LEN - 123_456, 1_000_000, CONTIG_LEN + 5000]))
+        a = int(rng.choice([0, -300, 5, 999_000, CONTIG_LEN - 2000, int(rng.integers(0, CONTIG_LEN))]))
+        b = a + int(rng.choice([1, 2, 4095, 4096, 4097, 9000, 20_000]))
+        want = O.c_wps(data["fr"], a, b, chrom, W, mn, mx, q)
+        got = engine.wps("synA", a, b, chrom, W, mn, mx, q)
+        assert np.array_equal(got, want), ("wps", seed, it, W, mn, mx, q, chrom, a, b)
+        a2 = max(a, 0)
+        b2 = a2 + (b - a)
+        lo = rng.choice([None, 0, 100, 167])
+        hi = rng.choice([None, 150, 167, 600])
+        lo = None if lo is None else int(lo)
+        hi = None if hi is None else int(hi)
+        want = O.c_cleavage(data["fr"], a2, b2, lo, hi, q)[2]  # (depth, ends, proportion)
+        got = engine.cleavage("synA", a2, b2, lo, hi, q)
+        assert np.array_equal(got, want), ("cleavage", seed, it, lo, hi, q, a2, b2)
