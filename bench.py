@@ -98,10 +98,17 @@ def main():
     dev = torch.device("cuda", local)
     # FTK_BENCH_FORCE_DIST=1 drives the collective code path with a 1-rank RCCL group (1-GPU boxes)
     use_dist = world > 1 or bool(os.environ.get("FTK_BENCH_FORCE_DIST"))
+    # FTK_BENCH_DIST_BACKEND=gloo (test mode): collectives go through host copies, so several ranks can share
+    # one GPU (LOCAL_RANK=0 for all) and the multi-rank logic can be exercised on a 1-GPU box
+    backend = os.environ.get("FTK_BENCH_DIST_BACKEND", "nccl")
+    cdev = dev if backend == "nccl" else torch.device("cpu")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     sizes = dict(synth.B37_SIZES)
     if args.contigs:
@@ -189,7 +196,12 @@ def main():
     # The DELFI (short, long) vectors are written by the kernels straight into the all-gather send
     # buffer: row 0 = short, row 1 = long, this rank's contigs back to back (no packing kernels).
     gather_in = torch.zeros((2, max_bins_rank), dtype=torch.int64, device=dev)
-    gather_out = [torch.zeros_like(gather_in) for _ in range(world)] if use_dist else None
+    gather_out = [torch.zeros_like(gather_in, device=cdev) for _ in range(world)] if use_dist else None
+    collect = [True]  # priming steps skip the collective: their count differs from rank to rank
+
+    def exchange():
+        if use_dist and collect[0]:
+            dist.all_gather(gather_out, gather_in if backend == "nccl" else gather_in.cpu())
     r0 = 0
     for c in mine:
         per[c]["short"] = gather_in[0, r0:r0 + per[c]["nw"]]
@@ -242,8 +254,7 @@ def main():
                     eng.event_record(ev + 1)
                     wps_ev[c] = (ev, ev + 1)
                     ev += 2
-        if use_dist:
-            dist.all_gather(gather_out, gather_in)
+        exchange()
 
     def step(record_events=False):
         if batched:
@@ -271,8 +282,7 @@ def main():
                         eng.event_record(ev + 1)
                         wps_ev[c] = (ev, ev + 1)
                         ev += 2
-        if use_dist:
-            dist.all_gather(gather_out, gather_in)
+        exchange()
 
     def barrier():
         torch.cuda.synchronize()
@@ -317,7 +327,9 @@ def main():
     prime = 0
     if os.environ.get("FTK_BENCH_PRIME", "1") != "0":
         prime = min(512, -(-1200 // launches_per_step))
+        collect[0] = False
         run_steps(prime, False)
+        collect[0] = True
         barrier()
         done_ev.clear()
     run_steps(args.warmup, False)
@@ -327,7 +339,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt * 1e3 / args.steps
@@ -364,14 +376,18 @@ def main():
         ok = True
         for c in mine:
             o = sum(per_rank_rows[rank][:per_rank_order[rank].index(c)])
-            ok = ok and torch.equal(gather_out[rank][0, o:o + per[c]["nw"]], per[c]["short"]) \
-                and torch.equal(gather_out[rank][1, o:o + per[c]["nw"]], per[c]["long"])
+            ok = ok and torch.equal(gather_out[rank][0, o:o + per[c]["nw"]], per[c]["short"].to(cdev)) \
+                and torch.equal(gather_out[rank][1, o:o + per[c]["nw"]], per[c]["long"].to(cdev))
         checks["allgather_roundtrip"] = bool(ok)
         # every rank now holds the whole-genome vector: total DELFI fragments must match on all ranks
         tot = torch.stack([g.sum() for g in gather_out]).sum().reshape(1)
         tots = [torch.zeros_like(tot) for _ in range(world)]
         dist.all_gather(tots, tot)
         checks["allgather_same_on_all_ranks"] = bool(all(int(t.item()) == int(tot.item()) for t in tots))
+        # and it must be the whole genome's DELFI count: compare with the sum of what every rank computed itself
+        mine_tot = torch.stack([gather_in.sum()]).to(cdev)
+        dist.all_reduce(mine_tot)
+        checks["allgather_total_eq_sum_of_ranks"] = int(mine_tot.item()) == int(tot.item())
     out = None
     if rank == 0:
         cpu = None
