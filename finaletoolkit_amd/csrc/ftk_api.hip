@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "ftk_kernels.h"
 
@@ -86,6 +87,7 @@ int get_contig(ftk_ctx* ctx, int contig_id, ContigData** out) {
 void free_contig(ContigData& c) {
     if (c.base) (void)hipFree(c.base);
     if (c.r1) (void)hipFree(c.r1);
+    if (c.order) (void)hipFree(c.order);
     if (c.bin_idx) (void)hipFree(c.bin_idx);
     c = ContigData{};
 }
@@ -222,6 +224,7 @@ int upload_common(ftk_ctx* ctx, int contig_id, const int32_t* start, const int32
     c.v.strand = d_strand;
     c.v.r1_start = nullptr;
     c.v.r1_end = nullptr;
+    c.v.order = nullptr;
     c.v.bin_idx = c.bin_idx;
     c.v.n = (int32_t)n;
     c.v.n_bins = n_bins;
@@ -410,7 +413,30 @@ int ftk_frags_from_table(ftk_ctx* ctx, int contig_id, const ftk_fragtable* t, in
     int rc = upload_common(ctx, contig_id, s0, e0, q0, st0, n, hipMemcpyHostToDevice);
     if (rc) return rc;
     if (r1s && r1e) rc = ftk_frags_set_read1(ctx, contig_id, r1s, r1e, n);
+    const int32_t* ord = nullptr;
+    if (rc == FTK_OK && ftk_fragtable_order(t, i, &ord) == FTK_OK && ord) rc = ftk_frags_set_order(ctx, contig_id, ord, n);
     return rc;
+}
+
+int ftk_frags_set_order(ftk_ctx* ctx, int contig_id, const int32_t* order, int64_t n) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    ContigData* c;
+    int rc = get_contig(ctx, contig_id, &c);
+    if (rc) return rc;
+    if (n != c->n) return fail(ctx, FTK_ERR_INVALID, "order column has %lld rows, contig has %lld", (long long)n, (long long)c->n);
+    if (n > 0 && !order) return fail(ctx, FTK_ERR_INVALID, "order is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (c->order) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(c->order));
+        c->order = nullptr;
+        c->v.order = nullptr;
+    }
+    HIPCHK(ctx, hipMalloc((void**)&c->order, align_up((size_t)n * 4 + 16)));
+    if (n > 0)
+        HIPCHK(ctx, hipMemcpy(c->order, order, n * 4, is_device_ptr(order) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    c->v.order = c->order;
+    return FTK_OK;
 }
 
 int ftk_frags_set_read1(ftk_ctx* ctx, int contig_id, const int32_t* r1_start, const int32_t* r1_end, int64_t n) {
@@ -866,7 +892,7 @@ static int select_common(ftk_ctx* ctx, int contig_id, int32_t w_start, int32_t w
     }
     const int nb = (int)((n_cand + 255) / 256);
     const int64_t ncap = std::min<int64_t>(cap, n_cand);
-    size_t need = 2 * align_up((size_t)(nb + 1) * 4) + 3 * align_up(ncap * 4) + 2 * align_up(ncap);
+    size_t need = 2 * align_up((size_t)(nb + 1) * 4) + 4 * align_up(ncap * 4) + 2 * align_up(ncap);
     if ((rc = reserve_scratch(ctx, need))) return rc;
     Arena a(ctx);
     uint32_t* d_cnt = a.take<uint32_t>(nb + 1);
@@ -876,9 +902,10 @@ static int select_common(ftk_ctx* ctx, int contig_id, int32_t w_start, int32_t w
     int32_t* d_e = end_out ? a.take<int32_t>(ncap) : nullptr;
     uint8_t* d_q = mapq_out ? a.take<uint8_t>(ncap) : nullptr;
     uint8_t* d_st = strand_out ? a.take<uint8_t>(ncap) : nullptr;
+    int32_t* d_ord = c->v.order ? a.take<int32_t>(ncap) : nullptr;
     launch_select_count(ctx->stream, c->v, lo, hi, w_start, w_end, *f, d_cnt);
     launch_scan_u32(ctx->stream, d_cnt, nb, d_off);
-    launch_select_write(ctx->stream, c->v, lo, hi, w_start, w_end, *f, d_off, ncap, d_len, d_s, d_e, d_q, d_st);
+    launch_select_write(ctx->stream, c->v, lo, hi, w_start, w_end, *f, d_off, ncap, d_len, d_s, d_e, d_q, d_st, d_ord);
     HIPCHK(ctx, hipGetLastError());
     uint32_t total = 0;
     HIPCHK(ctx, hipMemcpyAsync(&total, d_off + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -891,7 +918,28 @@ static int select_common(ftk_ctx* ctx, int contig_id, int32_t w_start, int32_t w
         if (end_out) HIPCHK(ctx, hipMemcpyAsync(end_out, d_e, n_copy * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (mapq_out) HIPCHK(ctx, hipMemcpyAsync(mapq_out, d_q, n_copy, hipMemcpyDeviceToHost, ctx->stream));
         if (strand_out) HIPCHK(ctx, hipMemcpyAsync(strand_out, d_st, n_copy, hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<int32_t> ord;
+        if (d_ord) {
+            ord.resize(n_copy);
+            HIPCHK(ctx, hipMemcpyAsync(ord.data(), d_ord, n_copy * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (d_ord && !std::is_sorted(ord.begin(), ord.end())) {
+            // BAM: rows come out in start order; hand them back in the order pysam iterates them
+            std::vector<int32_t> perm(n_copy);
+            for (int64_t k = 0; k < n_copy; ++k) perm[k] = (int32_t)k;
+            std::sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return ord[x] < ord[y]; });
+            auto reorder = [&](auto* col) {
+                if (!col) return;
+                std::vector<std::remove_pointer_t<decltype(col)>> tmp(col, col + n_copy);
+                for (int64_t k = 0; k < n_copy; ++k) col[k] = tmp[perm[k]];
+            };
+            reorder(len_out);
+            reorder(start_out);
+            reorder(end_out);
+            reorder(mapq_out);
+            reorder(strand_out);
+        }
     }
     return FTK_OK;
 }

@@ -64,6 +64,7 @@ struct Stopwatch {  // FTK_DECODE_TIMING=1 prints stage times to stderr
 
 struct Columns {
     std::vector<int32_t> start, end, r1s, r1e;
+    std::vector<int32_t> ord;  // BAM: rank of the read1 record in the file (set by sort_by_start)
     std::vector<uint8_t> mapq, strand;
     void append(const Columns& o) {
         start.insert(start.end(), o.start.begin(), o.start.end());
@@ -81,7 +82,7 @@ struct Packed {
     void* base = nullptr;
     bool pinned = false;
     size_t rows = 0;
-    int32_t *start = nullptr, *end = nullptr, *r1s = nullptr, *r1e = nullptr;
+    int32_t *start = nullptr, *end = nullptr, *r1s = nullptr, *r1e = nullptr, *ord = nullptr;
     uint8_t *mapq = nullptr, *strand = nullptr;
 };
 
@@ -104,7 +105,7 @@ bool have_hip_device() {
 // Lay a contig's final columns out inside an existing block (no copy).
 size_t packed_bytes(size_t m, bool bam) {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    return (bam ? 4 : 2) * up(m * 4 + 16) + 2 * up(m + 16);
+    return (bam ? 5 : 2) * up(m * 4 + 16) + 2 * up(m + 16);
 }
 
 void place(Packed& p, char* q, size_t m, bool bam) {
@@ -113,7 +114,7 @@ void place(Packed& p, char* q, size_t m, bool bam) {
     p.rows = m;
     p.start = (int32_t*)q; q += b32;
     p.end = (int32_t*)q; q += b32;
-    if (bam) { p.r1s = (int32_t*)q; q += b32; p.r1e = (int32_t*)q; q += b32; }
+    if (bam) { p.r1s = (int32_t*)q; q += b32; p.r1e = (int32_t*)q; q += b32; p.ord = (int32_t*)q; q += b32; }
     p.mapq = (uint8_t*)q; q += b8;
     p.strand = (uint8_t*)q;
 }
@@ -124,7 +125,7 @@ void pack(Contig& ct) {
     const bool bam = !c.r1s.empty();
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t b32 = up(m * 4 + 16), b8 = up(m + 16);
-    const size_t total = (bam ? 4 : 2) * b32 + 2 * b8;
+    const size_t total = (bam ? 5 : 2) * b32 + 2 * b8;
     Packed& p = ct.p;
     p.rows = m;
     if (have_hip_device() && hipHostMalloc(&p.base, total, hipHostMallocDefault) == hipSuccess) {
@@ -138,7 +139,7 @@ void pack(Contig& ct) {
     char* q = (char*)p.base;
     p.start = (int32_t*)q; q += b32;
     p.end = (int32_t*)q; q += b32;
-    if (bam) { p.r1s = (int32_t*)q; q += b32; p.r1e = (int32_t*)q; q += b32; }
+    if (bam) { p.r1s = (int32_t*)q; q += b32; p.r1e = (int32_t*)q; q += b32; p.ord = (int32_t*)q; q += b32; }
     p.mapq = (uint8_t*)q; q += b8;
     p.strand = (uint8_t*)q;
     if (m) {
@@ -146,7 +147,12 @@ void pack(Contig& ct) {
         memcpy(p.end, c.end.data(), m * 4);
         memcpy(p.mapq, c.mapq.data(), m);
         memcpy(p.strand, c.strand.data(), m);
-        if (bam) { memcpy(p.r1s, c.r1s.data(), m * 4); memcpy(p.r1e, c.r1e.data(), m * 4); }
+        if (bam) {
+            memcpy(p.r1s, c.r1s.data(), m * 4);
+            memcpy(p.r1e, c.r1e.data(), m * 4);
+            if (c.ord.size() == m) memcpy(p.ord, c.ord.data(), m * 4);
+            else for (size_t i = 0; i < m; ++i) p.ord[i] = (int32_t)i;
+        }
     }
     c = Columns{};
 }
@@ -362,6 +368,30 @@ Contig* find_or_add(ftk_fragtable* t, const std::string& name) {
     return &t->contigs.back();
 }
 
+void sort_by_start(Columns& c) {
+    const size_t m = c.start.size();
+    const bool bam_cols = !c.r1s.empty() || m == 0;
+    if (bam_cols && c.ord.size() != m) {  // file order of the read1 records, to restore pysam's iteration order
+        c.ord.resize(m);
+        std::iota(c.ord.begin(), c.ord.end(), 0);
+    }
+    if (std::is_sorted(c.start.begin(), c.start.end())) return;
+    std::vector<uint32_t> perm(m);
+    std::iota(perm.begin(), perm.end(), 0u);
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return c.start[a] < c.start[b]; });
+    Columns s;
+    const bool r1 = !c.r1s.empty();
+    s.start.resize(m); s.end.resize(m); s.mapq.resize(m); s.strand.resize(m);
+    if (r1) { s.r1s.resize(m); s.r1e.resize(m); s.ord.resize(m); }
+    for (size_t i = 0; i < m; ++i) {
+        const uint32_t j = perm[i];
+        s.start[i] = c.start[j]; s.end[i] = c.end[j]; s.mapq[i] = c.mapq[j]; s.strand[i] = c.strand[j];
+        if (r1) { s.r1s[i] = c.r1s[j]; s.r1e[i] = c.r1e[j]; s.ord[i] = c.ord[j]; }
+    }
+    c = std::move(s);
+}
+
+
 inline int32_t rd_i32(const uint8_t* p) { return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
 inline uint32_t rd_u32(const uint8_t* p) { return (uint32_t)rd_i32(p); }
 inline uint16_t rd_u16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -549,23 +579,8 @@ int ftk_bam_decode(const char* path, const char* contig, int n_threads, ftk_frag
         c.r1s.push_back(pos);
         c.r1e.push_back((int32_t)ref_end);
     }
-    // the kernels need start-sorted fragments; read1 order is by read position
-    for (auto& ct : t->contigs) {
-        Columns& c = ct.c;
-        size_t m = c.start.size();
-        if (std::is_sorted(c.start.begin(), c.start.end())) continue;
-        std::vector<uint32_t> perm(m);
-        std::iota(perm.begin(), perm.end(), 0u);
-        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return c.start[a] < c.start[b]; });
-        Columns s;
-        s.start.resize(m); s.end.resize(m); s.mapq.resize(m); s.strand.resize(m); s.r1s.resize(m); s.r1e.resize(m);
-        for (size_t i = 0; i < m; ++i) {
-            uint32_t j = perm[i];
-            s.start[i] = c.start[j]; s.end[i] = c.end[j]; s.mapq[i] = c.mapq[j];
-            s.strand[i] = c.strand[j]; s.r1s[i] = c.r1s[j]; s.r1e[i] = c.r1e[j];
-        }
-        c = std::move(s);
-    }
+    // the kernels need start-sorted fragments; read1 order is by read position (kept in `ord`)
+    for (auto& ct : t->contigs) sort_by_start(ct.c);
     for (auto& ct : t->contigs) {
         pack(ct);
         if (!ct.p.base) return dfail(FTK_ERR_OOM, "out of host memory");
@@ -596,6 +611,11 @@ int ftk_fragtable_columns(const ftk_fragtable* t, int i, const int32_t** start, 
     if (strand) *strand = c.strand;
     if (r1_start) *r1_start = c.r1s;
     if (r1_end) *r1_end = c.r1e;
+    return FTK_OK;
+}
+int ftk_fragtable_order(const ftk_fragtable* t, int i, const int32_t** order) {
+    if (!t || i < 0 || i >= (int)t->contigs.size() || !order) return dfail(FTK_ERR_NO_CONTIG, "contig index %d out of range", i);
+    *order = t->contigs[i].p.ord;
     return FTK_OK;
 }
 int ftk_fragtable_is_pinned(const ftk_fragtable* t, int i) {
@@ -714,24 +734,6 @@ inline bool bam_record(const uint8_t* r, uint32_t bs, Columns& c) {
     return true;
 }
 
-void sort_by_start(Columns& c) {
-    const size_t m = c.start.size();
-    if (std::is_sorted(c.start.begin(), c.start.end())) return;
-    std::vector<uint32_t> perm(m);
-    std::iota(perm.begin(), perm.end(), 0u);
-    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return c.start[a] < c.start[b]; });
-    Columns s;
-    const bool r1 = !c.r1s.empty();
-    s.start.resize(m); s.end.resize(m); s.mapq.resize(m); s.strand.resize(m);
-    if (r1) { s.r1s.resize(m); s.r1e.resize(m); }
-    for (size_t i = 0; i < m; ++i) {
-        const uint32_t j = perm[i];
-        s.start[i] = c.start[j]; s.end[i] = c.end[j]; s.mapq[i] = c.mapq[j]; s.strand[i] = c.strand[j];
-        if (r1) { s.r1s[i] = c.r1s[j]; s.r1e[i] = c.r1e[j]; }
-    }
-    c = std::move(s);
-}
-
 }  // namespace
 
 struct ftk_fragstream {
@@ -844,6 +846,7 @@ void ftk_fragstream::run() {
                 copy.c.mapq.assign(p.mapq, p.mapq + p.rows);
                 copy.c.strand.assign(p.strand, p.strand + p.rows);
                 if (p.r1s) { copy.c.r1s.assign(p.r1s, p.r1s + p.rows); copy.c.r1e.assign(p.r1e, p.r1e + p.rows); }
+                if (p.ord) copy.c.ord.assign(p.ord, p.ord + p.rows);
                 if (p.rows == 0) continue;
                 if (!emit(std::move(copy))) break;
             }

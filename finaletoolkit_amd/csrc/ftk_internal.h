@@ -31,6 +31,7 @@ struct ContigView {
     const uint8_t* strand;
     const int32_t* r1_start;  // BAM only (else nullptr)
     const int32_t* r1_end;
+    const int32_t* order;     // BAM, optional: file-order rank (else nullptr)
     const int32_t* bin_idx;   // n_bins + 1 entries
     int32_t n;                // fragments
     int32_t n_bins;
@@ -41,6 +42,7 @@ struct ContigData {
     ContigView v{};
     void* base = nullptr;     // one allocation holding all columns
     int32_t* r1 = nullptr;    // optional allocation for read1 columns
+    int32_t* order = nullptr; // optional allocation for the file-order column
     int32_t* bin_idx = nullptr;
     int64_t n = 0;
     int32_t max_len = 0;

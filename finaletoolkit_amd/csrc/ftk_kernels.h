@@ -139,6 +139,6 @@ void launch_select_count(hipStream_t s, const ContigView& cv, int lo, int hi, in
 void launch_scan_u32(hipStream_t s, const uint32_t* in, int n, uint32_t* off);
 void launch_select_write(hipStream_t s, const ContigView& cv, int lo, int hi, int ws, int we, const ftk_filter& f,
                          const uint32_t* block_off, int64_t cap, int32_t* len_out, int32_t* start_out,
-                         int32_t* end_out, uint8_t* mapq_out, uint8_t* strand_out);
+                         int32_t* end_out, uint8_t* mapq_out, uint8_t* strand_out, int32_t* order_out = nullptr);
 
 }  // namespace ftk

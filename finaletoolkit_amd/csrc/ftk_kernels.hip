@@ -1180,7 +1180,8 @@ __global__ __launch_bounds__(256) void select_count_kernel(ContigView cv, int lo
 __global__ __launch_bounds__(256) void select_write_kernel(ContigView cv, int lo, int hi, int ws, int we,
                                                            WinPred pred, const uint32_t* block_off, int64_t cap,
                                                            int32_t* len_out, int32_t* start_out, int32_t* end_out,
-                                                           uint8_t* mapq_out, uint8_t* strand_out) {
+                                                           uint8_t* mapq_out, uint8_t* strand_out,
+                                                           int32_t* order_out) {
     __shared__ int wtot[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = lo + blockIdx.x * 256 + tid;
@@ -1202,6 +1203,7 @@ __global__ __launch_bounds__(256) void select_write_kernel(ContigView cv, int lo
         if (end_out) end_out[off] = fe;
         if (mapq_out) mapq_out[off] = (uint8_t)q;
         if (strand_out) strand_out[off] = cv.strand[i];
+        if (order_out) order_out[off] = cv.order[i];
     }
 }
 
@@ -1420,12 +1422,12 @@ void launch_scan_u32(hipStream_t s, const uint32_t* in, int n, uint32_t* off) {
 
 void launch_select_write(hipStream_t s, const ContigView& cv, int lo, int hi, int ws, int we, const ftk_filter& f,
                          const uint32_t* block_off, int64_t cap, int32_t* len_out, int32_t* start_out,
-                         int32_t* end_out, uint8_t* mapq_out, uint8_t* strand_out) {
+                         int32_t* end_out, uint8_t* mapq_out, uint8_t* strand_out, int32_t* order_out) {
     WinPred pred = make_win_pred(f);
     int nb = (hi - lo + 255) / 256;
     if (nb <= 0) return;
     hipLaunchKernelGGL(select_write_kernel, dim3(nb), dim3(256), 0, s, cv, lo, hi, ws, we, pred, block_off, cap,
-                       len_out, start_out, end_out, mapq_out, strand_out);
+                       len_out, start_out, end_out, mapq_out, strand_out, order_out);
 }
 
 }  // namespace ftk

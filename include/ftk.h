@@ -119,6 +119,9 @@ int ftk_frags_from_device(ftk_ctx* ctx, int contig_id, const int32_t* d_start, c
  * (io/alignment.py:245: pysam fetch returns read1 alignments overlapping the
  * window).  Arrays are parallel to the fragment arrays. */
 int ftk_frags_set_read1(ftk_ctx* ctx, int contig_id, const int32_t* r1_start, const int32_t* r1_end, int64_t n);
+/* BAM only, optional: file-order rank per fragment (ftk_fragtable_order).  With it ftk_frag_lengths /
+ * ftk_frag_select return their rows in file order (pysam's iteration order) instead of start order. */
+int ftk_frags_set_order(ftk_ctx* ctx, int contig_id, const int32_t* order, int64_t n);
 int ftk_frags_info(ftk_ctx* ctx, int contig_id, int64_t* n_out, int32_t* max_len_out, int32_t* max_end_out);
 int ftk_frags_release(ftk_ctx* ctx, int contig_id);
 
@@ -158,6 +161,9 @@ int ftk_fragtable_columns(const ftk_fragtable* t, int i, const int32_t** start, 
                           const uint8_t** mapq, const uint8_t** strand,
                           const int32_t** r1_start /* NULL for text */, const int32_t** r1_end);
 /* 1 when contig i's columns sit in page-locked host memory (a HIP device was present at decode time). */
+/* BAM tables: rank of each fragment's read1 record in the file (pysam iterates in that order, the
+ * columns are sorted by fragment start); NULL for text tables, whose rows already are in file order. */
+int ftk_fragtable_order(const ftk_fragtable* t, int i, const int32_t** order);
 int ftk_fragtable_is_pinned(const ftk_fragtable* t, int i);
 void ftk_fragtable_free(ftk_fragtable* t);
 /* Upload contig i of a decoded table (including the BAM read1 columns) as contig_id: the

@@ -61,8 +61,8 @@ def write_synthetic_bam(path, contigs, frags, junk=True, read_len=100):
     read1 at the fragment start (flag 99 / mate 147), reverse ones at its end (flag 83 / mate 163).  With
     ``junk`` a few records the reference must drop are mixed in (unmapped, secondary, duplicate, qc-fail,
     supplementary, improper pair, mate unmapped, unpaired, TLEN 0).  Returns the expected per-contig rows
-    ``(start, end, mapq, forward, r1_start, r1_end)`` in the decoder's order (stable sort by fragment start
-    of the read1 records in file order)."""
+    ``(start, end, mapq, forward, r1_start, r1_end, file_rank)`` in the decoder's order (stable sort by
+    fragment start of the read1 records in file order); ``file_rank`` restores the file order."""
     import struct
     from finaletoolkit_amd import bgzf
 
@@ -102,7 +102,8 @@ def write_synthetic_bam(path, contigs, frags, junk=True, read_len=100):
         out += [r[2] for r in records]
         rows = [r[3] for r in records if r[3] is not None]
         order = sorted(range(len(rows)), key=lambda j: rows[j][0])  # stable, like the decoder
-        expected[c] = [rows[j] for j in order]
+        # 7th column: rank of the read1 record in the file (the order pysam iterates in)
+        expected[c] = [rows[j] + (j,) for j in order]
     bgzf.write_bgzf(path, b"".join(out), level=1)
     open(str(path) + ".bai", "ab").close()
     return expected

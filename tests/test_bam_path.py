@@ -21,6 +21,22 @@ def _make(tmp_path, depth=6.0):
     return path, write_synthetic_bam(path, CONTIGS, frags)
 
 
+def _order(path, contig):
+    """File-order ranks of a BAM contig (ftk_fragtable_order)."""
+    import ctypes as C
+    from finaletoolkit_amd import _lib as L
+    lib = L.load()
+    t = C.c_void_p()
+    assert lib.ftk_bam_decode(path.encode(), contig.encode(), 2, C.byref(t)) == 0
+    try:
+        p = C.c_void_p()
+        assert lib.ftk_fragtable_order(t, 0, C.byref(p)) == 0 and p.value
+        n = lib.ftk_fragtable_contig_rows(t, 0)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), (n,)).astype(np.int64)
+    finally:
+        lib.ftk_fragtable_free(t)
+
+
 def test_bam_decoder_rules(tmp_path):
     path, expected = _make(tmp_path, depth=3.0)
     got = _decode(path, bam=True, threads=3)
@@ -31,6 +47,8 @@ def test_bam_decoder_rules(tmp_path):
         assert rows == len(want) and length == dict(CONTIGS)[c]
         for k in range(6):
             assert np.array_equal(np.asarray(cols[k], dtype=np.int64), want[:, k]), (c, k)
+        assert np.array_equal(_order(path, c), want[:, 6]), c
+        assert not np.array_equal(want[:, 6], np.arange(len(want)))  # start order != file order in this file
     only = _decode(path, bam=True, contig="chr2")
     assert [k for k in only if not k.startswith("__")] == ["chr2"]
 
@@ -65,3 +83,17 @@ def test_bam_file_path_read1_semantics(tmp_path):
     got = frag.single_coverage(path, "chr1", a, b).coverage
     assert got < tab_like
     assert frag.single_coverage(path, "chrEmpty", 0, None).coverage == 0
+    # frag_length / frag_generator / frag_array hand rows back in pysam's order (read1 position in the file),
+    # not in the start order the kernels work in
+    from finaletoolkit_amd.utils import frag_array, frag_generator
+    w = np.array(expected["chr2"], dtype=np.int64)
+    by_file = w[np.argsort(w[:, 6])]
+    keep = by_file[(by_file[:, 2] >= 20)]
+    assert np.array_equal(frag.frag_length(path, contig="chr2", quality_threshold=20), (keep[:, 1] - keep[:, 0]))
+    gen = list(frag_generator(path, "chr2", 20))
+    assert [(g[1], g[2]) for g in gen[:500]] == [(int(a), int(b)) for a, b in keep[:500, :2]]
+    a, b = 100_000, 140_000
+    sel = by_file[(by_file[:, 2] >= 30) & (by_file[:, 4] < b) & (by_file[:, 5] > a)
+                  & (((by_file[:, 0] + by_file[:, 1]) // 2) >= a) & (((by_file[:, 0] + by_file[:, 1]) // 2) < b)]
+    arr = frag_array(path, "chr2", 30, a, b)
+    assert np.array_equal(arr["start"], sel[:, 0]) and np.array_equal(arr["stop"], sel[:, 1])
