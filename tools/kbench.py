@@ -101,6 +101,11 @@ if "feat" in which:
         timeit(lambda: fused(**kw), "fused " + name, 10 * n)
         timeit(lambda: fused(**kw), "fused " + name + " COLD(read)", 10 * n, cold="read")
         timeit(lambda: fused(**kw), "fused " + name + " COLD(dirty)", 10 * n, cold=True)
+if "small" in which:
+    # window sizes from 500 bp to 100 kb over the same contig: which launch shape the host picks matters here
+    for wlen in (500, 2_000, 10_000, 20_000, 100_000):
+        sws, swe = synth.tiling_windows(size, wlen)
+        timeit(lambda: eng.window_counts("c", sws, swe, 30), f"window_counts {wlen} bp x{len(sws)}", 10 * n)
 if "motif" in which:
     # 1 Mb windows (end_motifs' tiling), random 2bit / FASTA-text images of the contig
     mws, mwe = synth.tiling_windows(size, 1_000_000)
