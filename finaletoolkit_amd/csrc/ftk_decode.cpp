@@ -863,7 +863,27 @@ void ftk_fragstream::run() {
     cv.notify_all();
 }
 
+namespace {
+struct StageClock {  // FTK_DECODE_TIMING=1: where the streaming decoder spends its time
+    bool on = getenv("FTK_DECODE_TIMING") != nullptr;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(int k) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        acc[k] += std::chrono::duration<double, std::milli>(now - t).count();
+        t = now;
+    }
+    void report(const char* what) {
+        if (!on) return;
+        fprintf(stderr, "[ftk stream %s] read %.1f  inflate %.1f  parse %.1f  merge %.1f  emit(pack+queue) %.1f  other %.1f ms\n",
+                what, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]);
+    }
+};
+}  // namespace
+
 bool ftk_fragstream::run_text(std::vector<uint8_t>& buf, size_t n) {
+    StageClock clk;
     std::vector<Block> blocks;
     std::vector<char> text;       // carry (incomplete last line) + this piece's inflated text
     size_t text_carry = 0;
@@ -876,8 +896,10 @@ bool ftk_fragstream::run_text(std::vector<uint8_t>& buf, size_t n) {
         size_t used = 0, total = 0;
         if (!whole_blocks(buf.data(), n, eof, &blocks, &used, &total)) return fail(FTK_ERR_FORMAT, "corrupt BGZF block");
         if (text.size() < text_carry + total + 1) text.resize(text_carry + total + 1);
+        clk.lap(5);
         if (!blocks.empty() && inflate_block_list(buf.data(), blocks, n_threads, (uint8_t*)text.data() + text_carry) != FTK_OK)
             return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+        clk.lap(1);
         const char* b = text.data();
         const char* e = b + text_carry + total;
         if (!layout_known) {  // io/alignment.py:143-156: BED6 when the first data row has > 5 columns
@@ -903,9 +925,12 @@ bool ftk_fragstream::run_text(std::vector<uint8_t>& buf, size_t n) {
         }
         std::vector<Run> runs;
         if (last > b) parse_text_parallel(b, last, bed6, has_only ? only.c_str() : nullptr, n_threads, &runs);
+        clk.lap(2);
         for (auto& r : runs) {
             if (have_cur && r.name != cur.name) {
+                clk.lap(3);
                 if (!emit(std::move(cur))) return false;
+                clk.lap(4);
                 cur = Contig{};
                 have_cur = false;
             }
@@ -917,19 +942,25 @@ bool ftk_fragstream::run_text(std::vector<uint8_t>& buf, size_t n) {
             }
             cur.c.append(r.c);
         }
+        clk.lap(3);
         text_carry = (size_t)(e - last);
         if (text_carry) memmove(text.data(), last, text_carry);
         if (eof) break;
         const size_t raw_carry = n - used;
         if (raw_carry) memmove(buf.data(), buf.data() + used, raw_carry);
+        clk.lap(5);
         n = fill(buf, raw_carry);
+        clk.lap(0);
         eof = n - raw_carry < kStreamPiece;
         {
             std::lock_guard<std::mutex> lk(mu);
             if (stop) return false;
         }
     }
+    clk.lap(5);
     if (have_cur && !emit(std::move(cur))) return false;
+    clk.lap(4);
+    clk.report("text");
     return true;
 }
 
