@@ -391,7 +391,7 @@ def main():
     out = None
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             cpu = cpu_baseline(torch, eng, per, mine, args.cpu_seconds, checks)
         out = {
             "metric": "genomic windows/sec (coverage+WPS+DELFI) at 30x WGS",
