@@ -179,3 +179,24 @@ def test_gpu_adjust_wps_file_to_file(engine, gold, tmp_path):
             st, en, v = bw.intervals(cs["run_contigs"][i], s, s + len(want))
             assert st[0] == s and len(st) == len(want) and np.all(np.diff(st) == 1)
             np.testing.assert_allclose(v.astype(np.float32), want, rtol=1e-6, atol=1e-6, err_msg=cs["key"])
+
+
+@pytest.mark.gpu
+def test_gpu_adjust_full_size_properties(engine):
+    """2 000 intervals x 5 kb (10 M scores): a sample of intervals against the oracle, and two
+    size-independent properties of the median path on integer-valued data -- adding a constant to the
+    input leaves the output unchanged, negating the input negates it (the window median of an even
+    window is the mean of the two middle values, so both are exact)."""
+    rng = np.random.default_rng(123)
+    n_iv, ilen, W = 2000, 5000, 1000
+    x = np.round(rng.normal(0, 40, n_iv * ilen))
+    offs = np.arange(n_iv + 1, dtype=np.int64) * ilen
+    got = engine.wps_adjust(x, offs, W, savgol=False)
+    m = ilen - W
+    for i in (0, 1, 777, n_iv - 1):
+        assert np.array_equal(got[i * m:(i + 1) * m], O.py_adjust_run(x[i * ilen:(i + 1) * ilen], W, savgol=False)), i
+    assert np.array_equal(engine.wps_adjust(x + 1234.0, offs, W, savgol=False), got)
+    assert np.array_equal(engine.wps_adjust(-x, offs, W, savgol=False), -got)
+    sg = engine.wps_adjust(x, offs, W)
+    i = 1500
+    np.testing.assert_allclose(sg[i * m:(i + 1) * m], O.py_adjust_run(x[i * ilen:(i + 1) * ilen], W), **TOL)
