@@ -199,9 +199,20 @@ def main():
     gather_out = [torch.zeros_like(gather_in, device=cdev) for _ in range(world)] if use_dist else None
     collect = [True]  # priming steps skip the collective: their count differs from rank to rank
 
-    def exchange():
-        if use_dist and collect[0]:
-            dist.all_gather(gather_out, gather_in if backend == "nccl" else gather_in.cpu())
+    # The all-gather only needs the DELFI rows, which are complete once the step's LAST window-feature launch
+    # is on the stream: it is started there (RCCL's own stream, ordered after the feature pass) and runs
+    # concurrently with the WPS launches that follow; the step ends by making the compute stream wait for it.
+    def exchange_start():
+        if not (use_dist and collect[0]):
+            return None
+        if backend != "nccl":  # test backend: host copies, synchronous
+            dist.all_gather(gather_out, gather_in.cpu())
+            return None
+        return dist.all_gather(gather_out, gather_in, async_op=True)
+
+    def exchange_finish(work):
+        if work is not None:
+            work.wait()
     r0 = 0
     for c in mine:
         per[c]["short"] = gather_in[0, r0:r0 + per[c]["nw"]]
@@ -236,6 +247,7 @@ def main():
     def step_batched(record_events=False):
         eng.window_features_batch(fbatch, coverage=all_cov, hist=all_hist, hist_bins=(0, HIST_BINS), overflow=all_over,
                                   delfi_q=MAPQ, short=gather_in[0], long=gather_in[1])
+        work = exchange_start()
         if batch_wps:
             if record_events:
                 eng.event_record(0)
@@ -254,13 +266,14 @@ def main():
                     eng.event_record(ev + 1)
                     wps_ev[c] = (ev, ev + 1)
                     ev += 2
-        exchange()
+        exchange_finish(work)
 
     def step(record_events=False):
         if batched:
             return step_batched(record_events)
         row = 0
         ev = 0
+        work = None
         split = bool(os.environ.get("FTK_BENCH_SPLIT_ORDER"))  # experiment: all feature passes, then all WPS
         for phase in ((0, 1) if split else (2,)):
             for c in mine:
@@ -274,6 +287,8 @@ def main():
                         eng.ctx, cid, L.ptr(p["ws"]), L.ptr(p["we"]), p["nw"], C.byref(flt), L.ptr(p["cov"]), 0,
                         HIST_BINS, L.ptr(p["hist"]), L.ptr(p["over"]), MAPQ, L.ptr(p["bl"][0]), L.ptr(p["bl"][1]),
                         len(p["bl"][0]), C.byref(p["gaps_c"]), L.ptr(p["short"]), L.ptr(p["long"])))
+                    if c == mine[-1]:  # the rank's DELFI rows are complete: start the exchange behind it
+                        work = exchange_start()
                 if phase in (1, 2):
                     if record_events:
                         eng.event_record(ev)
@@ -282,7 +297,7 @@ def main():
                         eng.event_record(ev + 1)
                         wps_ev[c] = (ev, ev + 1)
                         ev += 2
-        exchange()
+        exchange_finish(work)
 
     def barrier():
         torch.cuda.synchronize()
