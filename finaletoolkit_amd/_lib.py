@@ -40,7 +40,8 @@ EXPORTS = [
     "ftk_version", "ftk_device_count", "ftk_ctx_create", "ftk_ctx_destroy", "ftk_last_error",
     "ftk_ctx_set_stream", "ftk_ctx_sync", "ftk_timer_start", "ftk_timer_stop", "ftk_event_record",
     "ftk_event_elapsed_ms",
-    "ftk_frags_from_host", "ftk_frags_from_device", "ftk_frags_set_read1", "ftk_frags_set_order", "ftk_frags_info", "ftk_frags_release",
+    "ftk_frags_from_host", "ftk_frags_from_device", "ftk_frags_set_read1", "ftk_frags_set_order", "ftk_frags_load_fraggz", "ftk_frags_load_bam", "ftk_frags_name",
+    "ftk_frags_info", "ftk_frags_release",
     "ftk_fragfile_decode", "ftk_bam_decode", "ftk_fragstream_open", "ftk_fragstream_next", "ftk_fragstream_n_refs",
     "ftk_fragstream_ref_name", "ftk_fragstream_ref_length", "ftk_fragstream_close", "ftk_fragtable_error", "ftk_fragtable_is_bed6",
     "ftk_fragtable_n_contigs", "ftk_fragtable_contig_name", "ftk_fragtable_contig_length",
@@ -131,6 +132,10 @@ def load() -> C.CDLL:
     lib.ftk_frags_set_read1.argtypes = [vp, C.c_int, vp, vp, i64]
     lib.ftk_frags_set_order.argtypes = [vp, C.c_int, vp, i64]
     lib.ftk_fragtable_order.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    lib.ftk_frags_load_fraggz.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    lib.ftk_frags_load_bam.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    lib.ftk_frags_name.argtypes = [vp, C.c_int]
+    lib.ftk_frags_name.restype = C.c_char_p
     lib.ftk_frags_info.argtypes = [vp, C.c_int, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]
     lib.ftk_frags_release.argtypes = [vp, C.c_int]
     lib.ftk_fragfile_decode.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]

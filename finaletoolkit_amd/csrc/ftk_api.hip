@@ -423,6 +423,48 @@ int ftk_frags_from_table(ftk_ctx* ctx, int contig_id, const ftk_fragtable* t, in
     return rc;
 }
 
+static int load_file(ftk_ctx* ctx, const char* path, const char* contig, int is_bam, int n_threads,
+                     int first_contig_id, int* n_loaded_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    if (!path) return fail(ctx, FTK_ERR_INVALID, "path is NULL");
+    if (n_loaded_out) *n_loaded_out = 0;
+    ftk_fragstream* st = nullptr;
+    int rc = ftk_fragstream_open(path, contig, is_bam, n_threads, 2, &st);
+    if (rc != FTK_OK) return fail(ctx, rc, "%s", ftk_fragtable_error());
+    int id = first_contig_id, n = 0;
+    for (;;) {
+        ftk_fragtable* t = nullptr;
+        rc = ftk_fragstream_next(st, &t);
+        if (rc != FTK_OK) { fail(ctx, rc, "%s", ftk_fragtable_error()); break; }
+        if (!t) break;
+        rc = ftk_frags_from_table(ctx, id, t, 0);
+        if (rc == FTK_OK) ctx->names[id] = ftk_fragtable_contig_name(t, 0);
+        ftk_fragtable_free(t);
+        if (rc != FTK_OK) break;
+        ++id;
+        ++n;
+    }
+    ftk_fragstream_close(st);
+    if (n_loaded_out) *n_loaded_out = n;
+    return rc;
+}
+
+int ftk_frags_load_fraggz(ftk_ctx* ctx, const char* path, const char* contig, int n_threads, int first_contig_id,
+                          int* n_loaded_out) {
+    return load_file(ctx, path, contig, 0, n_threads, first_contig_id, n_loaded_out);
+}
+
+int ftk_frags_load_bam(ftk_ctx* ctx, const char* path, const char* contig, int n_threads, int first_contig_id,
+                       int* n_loaded_out) {
+    return load_file(ctx, path, contig, 1, n_threads, first_contig_id, n_loaded_out);
+}
+
+const char* ftk_frags_name(ftk_ctx* ctx, int contig_id) {
+    if (!ctx) return nullptr;
+    auto it = ctx->names.find(contig_id);
+    return it == ctx->names.end() ? nullptr : it->second.c_str();
+}
+
 int ftk_frags_set_order(ftk_ctx* ctx, int contig_id, const int32_t* order, int64_t n) {
     if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
     ContigData* c;

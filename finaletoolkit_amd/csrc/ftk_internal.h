@@ -72,6 +72,7 @@ struct ftk_ctx {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     std::vector<hipEvent_t> ev_slots;  // lazily created, FTK_MAX_EVENTS entries
     std::map<int, ftk::ContigData> contigs;
+    std::map<int, std::string> names;  // contigs loaded by ftk_frags_load_*
     std::string err;
     std::vector<ftk::DelfiMeta> delfi_cache;
     struct RefImage {

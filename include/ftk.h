@@ -170,6 +170,17 @@ void ftk_fragtable_free(ftk_fragtable* t);
  * decode -> pinned SoA -> hipMemcpyAsync leg of the pipeline, without a detour through the caller. */
 int ftk_frags_from_table(ftk_ctx* ctx, int contig_id, const ftk_fragtable* t, int i);
 
+/* File -> HBM in one call, for hosts that do not want to handle tables: the streaming decoder feeds
+ * every contig of the file (or only `contig`) to ftk_frags_from_table as it is decoded; contig ids are
+ * first_contig_id, first_contig_id + 1, ... in file order (BAM: contigs that have usable reads, in
+ * header order), *n_loaded_out of them; ftk_frags_name gives the contig name behind an id loaded this
+ * way.  (io/alignment.py:160-203 opens the same two kinds of input.) */
+int ftk_frags_load_fraggz(ftk_ctx* ctx, const char* path, const char* contig /* NULL = all */, int n_threads,
+                          int first_contig_id, int* n_loaded_out);
+int ftk_frags_load_bam(ftk_ctx* ctx, const char* path, const char* contig /* NULL = all */, int n_threads,
+                       int first_contig_id, int* n_loaded_out);
+const char* ftk_frags_name(ftk_ctx* ctx, int contig_id);
+
 /* ---- a5: coverage --------------------------------------------------------
  * frag/_coverage.py:117-130 (`for _ in frags: coverage += 1`) over
  * utils/_frag_generator.py:117-130, for n_win windows of one contig at once.

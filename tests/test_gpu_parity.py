@@ -410,3 +410,36 @@ def test_wps_and_cleavage_fuzz(engine, data, seed):
         want = O.c_cleavage(data["fr"], a2, b2, lo, hi, q)[2]  # (depth, ends, proportion)
         got = engine.cleavage("synA", a2, b2, lo, hi, q)
         assert np.array_equal(got, want), ("cleavage", seed, it, lo, hi, q, a2, b2)
+
+
+def test_one_call_file_loaders(engine, tmp_path):
+    """ftk_frags_load_fraggz / ftk_frags_load_bam: file -> HBM in one C call, contig ids in file order."""
+    import ctypes as C
+    import os
+    from finaletoolkit_amd import _lib as L
+    from tests.helpers import DATA, GOLDEN, read_frag_gz, write_synthetic_bam
+    lib = engine.lib
+    n = C.c_int()
+    base = 7000
+    assert lib.ftk_frags_load_fraggz(engine.ctx, os.path.join(GOLDEN, "synth.frag.gz").encode(), None, 4, base,
+                                     C.byref(n)) == 0
+    want = read_frag_gz(os.path.join(GOLDEN, "synth.frag.gz"))
+    assert n.value == len(want)
+    for k in range(n.value):
+        name = lib.ftk_frags_name(engine.ctx, base + k).decode()
+        rows = C.c_int64()
+        assert lib.ftk_frags_info(engine.ctx, base + k, C.byref(rows), None, None) == 0
+        assert rows.value == len(want[name][0])
+        f = L.make_filter(0, None, None, "any")
+        ws, we, out = np.array([O.OPEN_LO], np.int32), np.array([O.OPEN_HI], np.int32), np.zeros(1, np.int64)
+        assert lib.ftk_window_counts(engine.ctx, base + k, L.ptr(ws), L.ptr(we), 1, C.byref(f), L.ptr(out)) == 0
+        assert out[0] == rows.value
+        assert lib.ftk_frags_release(engine.ctx, base + k) == 0
+    assert lib.ftk_frags_name(engine.ctx, base + 99) is None
+    assert lib.ftk_frags_load_bam(engine.ctx, os.path.join(DATA, "12.3444.b37.bam").encode(), None, 2, base,
+                                  C.byref(n)) == 0
+    assert n.value == 1 and lib.ftk_frags_name(engine.ctx, base).decode() == "12"
+    rows = C.c_int64()
+    assert lib.ftk_frags_info(engine.ctx, base, C.byref(rows), None, None) == 0 and rows.value == 17
+    assert lib.ftk_frags_release(engine.ctx, base) == 0
+    assert lib.ftk_frags_load_fraggz(engine.ctx, str(tmp_path / "absent.gz").encode(), None, 2, base, C.byref(n)) == L.FTK_ERR_IO
