@@ -8,6 +8,9 @@
 #include <new>
 #include <type_traits>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include "ftk_kernels.h"
 
 using namespace ftk;
@@ -1464,6 +1467,152 @@ int ftk_ref_gc_counts(ftk_ctx* ctx, int ref_id, const int64_t* range_lo, const i
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     return FTK_OK;
+}
+
+}  // extern "C"
+
+// ---- RCCL-backed exchange (no link-time dependency: resolved at ftk_comm_create) ---------------
+struct ftk_comm {
+    ftk_ctx* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+namespace {
+
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi* rccl() {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        // a librccl already in the process (e.g. torch's) is re-used: same soname
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+        if (api.lib) {
+            api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+            api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+            api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+            api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+            api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+            api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+        }
+    }
+    const bool ok = api.lib && api.GetUniqueId && api.CommInitRank && api.AllGather && api.AllReduce && api.CommDestroy;
+    return ok ? &api : nullptr;
+}
+
+#define RCCLCHK(ctx, call)                                                                            \
+    do {                                                                                              \
+        ncclResult_t r_ = (call);                                                                     \
+        if (r_ != ncclSuccess)                                                                        \
+            return fail(ctx, FTK_ERR_HIP, "%s: %s", #call, rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "RCCL error"); \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int ftk_comm_unique_id(char id_out[128]) {
+    if (!id_out) return fail(nullptr, FTK_ERR_INVALID, "id_out is NULL");
+    RcclApi* a = rccl();
+    if (!a) return fail(nullptr, FTK_ERR_NO_DEVICE, "librccl could not be loaded");
+    ncclUniqueId id;
+    RCCLCHK(nullptr, a->GetUniqueId(&id));
+    memcpy(id_out, id.internal, 128);
+    return FTK_OK;
+}
+
+int ftk_comm_create(ftk_ctx* ctx, int rank, int world, const char id[128], ftk_comm** out) {
+    if (!ctx || !out || !id) return fail(ctx, FTK_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, FTK_ERR_INVALID, "bad rank / world");
+    RcclApi* a = rccl();
+    if (!a) return fail(ctx, FTK_ERR_NO_DEVICE, "librccl could not be loaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    memcpy(uid.internal, id, 128);
+    ftk_comm* c = new (std::nothrow) ftk_comm();
+    if (!c) return fail(ctx, FTK_ERR_OOM, "out of host memory");
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    ncclResult_t r = a->CommInitRank(&c->comm, world, uid, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return fail(ctx, FTK_ERR_HIP, "ncclCommInitRank: %s", a->GetErrorString ? a->GetErrorString(r) : "RCCL error");
+    }
+    *out = c;
+    return FTK_OK;
+}
+
+int ftk_allgather_i64(ftk_comm* comm, const int64_t* send, int64_t n, int64_t* recv) {
+    if (!comm) return fail(nullptr, FTK_ERR_INVALID, "comm is NULL");
+    ftk_ctx* ctx = comm->ctx;
+    if (n < 0 || (n > 0 && (!send || !recv))) return fail(ctx, FTK_ERR_INVALID, "bad arguments");
+    if (n == 0) return FTK_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool s_dev = is_device_ptr(send), r_dev = is_device_ptr(recv);
+    const size_t b = (size_t)n * 8;
+    int rc = reserve_scratch(ctx, (s_dev ? 0 : align_up(b)) + (r_dev ? 0 : align_up(b * comm->world)));
+    if (rc) return rc;
+    Arena a(ctx);
+    const int64_t* d_send = send;
+    if (!s_dev) {
+        int64_t* t = a.take<int64_t>(n);
+        HIPCHK(ctx, hipMemcpyAsync(t, send, b, hipMemcpyHostToDevice, ctx->stream));
+        d_send = t;
+    }
+    int64_t* d_recv = r_dev ? recv : a.take<int64_t>((size_t)n * comm->world);
+    RCCLCHK(ctx, rccl()->AllGather(d_send, d_recv, (size_t)n, ncclInt64, comm->comm, ctx->stream));
+    if (!r_dev) {
+        HIPCHK(ctx, hipMemcpyAsync(recv, d_recv, b * comm->world, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FTK_OK;
+}
+
+int ftk_allreduce_sum_i64(ftk_comm* comm, int64_t* values, int64_t n) {
+    if (!comm) return fail(nullptr, FTK_ERR_INVALID, "comm is NULL");
+    ftk_ctx* ctx = comm->ctx;
+    if (n < 0 || (n > 0 && !values)) return fail(ctx, FTK_ERR_INVALID, "bad arguments");
+    if (n == 0) return FTK_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool dev = is_device_ptr(values);
+    const size_t b = (size_t)n * 8;
+    int rc = reserve_scratch(ctx, dev ? 0 : align_up(b));
+    if (rc) return rc;
+    int64_t* d = values;
+    if (!dev) {
+        d = (int64_t*)ctx->scratch;
+        HIPCHK(ctx, hipMemcpyAsync(d, values, b, hipMemcpyHostToDevice, ctx->stream));
+    }
+    RCCLCHK(ctx, rccl()->AllReduce(d, d, (size_t)n, ncclInt64, ncclSum, comm->comm, ctx->stream));
+    if (!dev) {
+        HIPCHK(ctx, hipMemcpyAsync(values, d, b, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FTK_OK;
+}
+
+void ftk_comm_destroy(ftk_comm* comm) {
+    if (!comm) return;
+    if (comm->comm && rccl()) {
+        (void)hipStreamSynchronize(comm->ctx->stream);
+        (void)rccl()->CommDestroy(comm->comm);
+    }
+    delete comm;
 }
 
 }  // extern "C"

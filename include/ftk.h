@@ -362,6 +362,21 @@ int ftk_motif_counts(ftk_ctx* ctx, int contig_id, int ref_id, const int32_t* w_s
                      uint32_t* counts_out /* [n_win][4^k] */, int64_t* nfrag_out /* [n_win] or NULL */,
                      int64_t* err_out /* [n_win] */);
 
+/* ---- multi-GPU exchange for hosts without torch.distributed ------------------
+ * One process per GPU; contigs / genome runs are sharded by the host, no data-path collective.  The
+ * only exchanges of the path are the all-gather of the per-bin DELFI vector (frag/_delfi.py:289-300's
+ * pool.starmap result list, one rank per shard) and the all-reduce of the genome-wide total of
+ * coverage(normalize=True) (frag/_coverage.py:215-227).  These wrap RCCL (loaded with dlopen at
+ * ftk_comm_create; librccl is not a link-time dependency) on the ctx stream.  Rank 0 makes the id,
+ * the host shares its 128 bytes with the other ranks (file, environment, MPI ...).  Buffers may be
+ * host or device memory; n counts int64 elements PER RANK. */
+typedef struct ftk_comm ftk_comm;
+int ftk_comm_unique_id(char id_out[128]);
+int ftk_comm_create(ftk_ctx* ctx, int rank, int world, const char id[128], ftk_comm** out);
+int ftk_allgather_i64(ftk_comm* comm, const int64_t* send, int64_t n, int64_t* recv /* [world * n] */);
+int ftk_allreduce_sum_i64(ftk_comm* comm, int64_t* values, int64_t n);
+void ftk_comm_destroy(ftk_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif
