@@ -101,6 +101,26 @@ if "feat" in which:
         timeit(lambda: fused(**kw), "fused " + name, 10 * n)
         timeit(lambda: fused(**kw), "fused " + name + " COLD(read)", 10 * n, cold="read")
         timeit(lambda: fused(**kw), "fused " + name + " COLD(dirty)", 10 * n, cold=True)
+if "cleave" in which:
+    # whole-contig cleavage profile into a device buffer (float64 per base, like WPS's int64)
+    import ctypes as C
+    from finaletoolkit_amd import _lib as L
+    cl = torch.empty(size, dtype=torch.float64, device=dev)
+    s0 = np.array([0], np.int64); s1 = np.array([size], np.int64); so = np.array([0], np.int64)
+    f = lambda: eng._check(eng.lib.ftk_cleavage_intervals(eng.ctx, eng.contig_id("c"), L.ptr(s0), L.ptr(s1), 1, L.ptr(so),
+                                                          L.LEN_OPEN, L.LEN_OPEN, 20, L.ptr(cl)))
+    timeit(f, "cleavage whole contig", 10 * n + 8 * size)
+if "gc" in which:
+    rng = np.random.default_rng(6)
+    packed = rng.integers(0, 256, (size + 3) // 4, dtype=np.uint8)
+    rid = eng.ref_upload(("kb", "gc2bit"), packed, 1)
+    glo, ghi = synth.tiling_windows(size, 100_000)
+    d_lo = torch.from_numpy(glo.astype(np.int64)).to(dev); d_hi = torch.from_numpy(ghi.astype(np.int64)).to(dev)
+    d_gc = torch.zeros(len(glo), dtype=torch.int64, device=dev)
+    import ctypes as C
+    from finaletoolkit_amd import _lib as L
+    f = lambda: eng._check(eng.lib.ftk_ref_gc_counts(eng.ctx, rid, L.ptr(d_lo), L.ptr(d_hi), len(glo), L.ptr(d_gc)))
+    timeit(f, "GC count 100 kb bins (2bit)", size // 4)
 if "small" in which:
     # window sizes from 500 bp to 100 kb over the same contig: which launch shape the host picks matters here
     for wlen in (500, 2_000, 10_000, 20_000, 100_000):
