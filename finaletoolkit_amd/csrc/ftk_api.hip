@@ -1026,11 +1026,13 @@ static int wps_params(ftk_ctx* ctx, const ContigData& c, int64_t chrom_size, int
     // Scores are written once and not re-read by this library: non-temporal stores keep them from
     // displacing the fragment columns in the Infinity Cache and from leaving 256 MB of dirty lines for
     // the next kernel to wait on (measured: -8 % step time, +2 % WPS rate).  FTK_WPS_NT=0 turns it off.
-    p->nt_store = getenv("FTK_WPS_NT") ? atoi(getenv("FTK_WPS_NT")) : 1;
+    static const int nt_store = getenv("FTK_WPS_NT") ? atoi(getenv("FTK_WPS_NT")) : 1;
+    p->nt_store = nt_store;
     // XCD-contiguous tile ranges would let neighbouring tiles share halo fragments in one L2, but they
     // measured SLOWER (0.79 vs 0.835 of peak): eight far-apart write streams load the HBM channels less
     // evenly than the interleaved order.  Kept as an experiment switch (FTK_WPS_XCD=1), default off.
-    p->xcd_remap = getenv("FTK_WPS_XCD") ? atoi(getenv("FTK_WPS_XCD")) : 0;
+    static const int xcd_remap = getenv("FTK_WPS_XCD") ? atoi(getenv("FTK_WPS_XCD")) : 0;
+    p->xcd_remap = xcd_remap;
     return FTK_OK;
 }
 
