@@ -83,3 +83,43 @@ def test_config3_wps_whole_contig(engine, chr22):
         np.add.at(d, pos + off, val)
     ref = np.cumsum(d)[off:off + CHR22]
     assert np.array_equal(whole, ref)
+
+
+def test_next_rows_at_full_size(engine, chr22, tmp_path):
+    """chr22 at 30x through the next-row kernels: cleavage against oracle tiles, and the end-motif pass
+    against size-independent identities (no oracle run over 5 M fragments)."""
+    s, e, q = chr22["s"].astype(np.int64), chr22["e"].astype(np.int64), chr22["q"]
+    fr, size, name = chr22["fr"], CHR22, "chr22_30x"
+    prop = engine.cleavage(name, 0, size, None, None, 20)
+    for a in (0, 17_000_123, 33_333_333, size - 4_000):
+        assert np.array_equal(prop[a:a + 4_000], O.c_cleavage(fr, a, a + 4_000, None, None, 20)[2]), a
+    # motifs on a random genome with one N stripe
+    rng = np.random.default_rng(77)
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size)].copy()
+    n_lo, n_hi = 20_000_000, 20_000_500
+    seq[n_lo:n_hi] = ord("N")
+    from tests import helpers as H
+    H.write_2bit(tmp_path / "chr22.2bit", {"chr22": seq.tobytes().decode()})
+    from finaletoolkit_amd.reference import ReferenceGenome
+    ws = np.arange(0, size, 1_000_000, dtype=np.int64)
+    we = np.minimum(ws + 1_000_000, size)
+    k = 4
+    with ReferenceGenome(str(tmp_path / "chr22.2bit")) as ref:
+        rid = ref.device_image(engine, "chr22")
+        both, nf, err = engine.motif_counts(name, rid, ws, we, k, 0, -k, True, False, 0, False, 30)
+        rev, _, _ = engine.motif_counts(name, rid, ws, we, k, 0, -k, False, True, 0, False, 30)
+    assert err.sum() == 0
+    ok = q >= 30
+    # a fragment is fetched once per window it overlaps: twice when it crosses a 1 Mb boundary
+    edges = ws[1:]
+    idx = np.searchsorted(edges, s, side="right")                 # first boundary > start
+    crosses = (idx < len(edges)) & (edges[np.minimum(idx, len(edges) - 1)] < e)
+    w = 1 + crosses.astype(np.int64)
+    assert nf.sum() == int((w * ok).sum())
+    fwd_clean = ~((s + k > n_lo) & (s < n_hi))                    # 5' k-mer free of N
+    rev_clean = ~((e > n_lo) & (e - k < n_hi))                    # 3' k-mer free of N
+    assert int(rev.sum()) == int((w * (ok & rev_clean)).sum())
+    assert int(both.sum()) == int((w * (ok & fwd_clean)).sum()) + int((w * (ok & rev_clean)).sum())
+    # every 4-mer of a uniform random genome shows up about equally often
+    tot = both.sum(axis=0)
+    assert tot.min() > 0.9 * tot.mean() and tot.max() < 1.1 * tot.mean()
