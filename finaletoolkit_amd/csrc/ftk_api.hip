@@ -535,6 +535,7 @@ int ftk_frags_release(ftk_ctx* ctx, int contig_id) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     free_contig(it->second);
     ctx->contigs.erase(it);
+    ctx->names.erase(contig_id);
     for (size_t i = ctx->delfi_cache.size(); i-- > 0;)
         if (ctx->delfi_cache[i].contig_id == contig_id) {
             (void)hipFree(ctx->delfi_cache[i].base);
