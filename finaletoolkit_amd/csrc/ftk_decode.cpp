@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -21,6 +22,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <pthread.h>
 
 #include <hip/hip_runtime_api.h>
 
@@ -38,6 +41,73 @@ int dfail(int code, const char* fmt, ...) {
     va_end(ap);
     g_decode_err = buf;
     return code;
+}
+
+// Persistent worker threads for the decoders' parallel regions.  A decode of one file opens a few
+// dozen short regions (inflate / parse / pack per piece); creating up to 256 threads for each of them
+// cost more than the work itself.  Regions are serialised (one runs at a time); workers are created on
+// demand and live for the rest of the process (a forked child starts with a fresh pool).
+class WorkPool {
+    std::mutex mu, region;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> threads;
+    const std::function<void(int)>* fn = nullptr;
+    int want = 0, pending = 0;
+    unsigned long long gen = 0;
+
+    void worker(int idx, unsigned long long seen) {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_work.wait(lk, [&] { return gen != seen; });
+            seen = gen;
+            if (idx <= want) {
+                const std::function<void(int)>* f = fn;
+                lk.unlock();
+                (*f)(idx);
+                lk.lock();
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+
+public:
+    // fn(0) runs on the caller, fn(1..n-1) on pool threads; returns when all are done
+    void run(int n, const std::function<void(int)>& f) {
+        if (n <= 1) { f(0); return; }
+        std::lock_guard<std::mutex> one(region);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            while ((int)threads.size() < n - 1) {
+                const int idx = (int)threads.size() + 1;
+                const unsigned long long g = gen;
+                threads.emplace_back([this, idx, g] { worker(idx, g); });
+                threads.back().detach();
+            }
+            fn = &f;
+            want = n - 1;
+            pending = n - 1;
+            ++gen;
+        }
+        cv_work.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+
+WorkPool* g_pool = nullptr;
+std::once_flag g_pool_fork_once;
+
+void parallel_run(int n, const std::function<void(int)>& f) {
+    static std::mutex init;
+    WorkPool* p;
+    {
+        std::lock_guard<std::mutex> lk(init);
+        std::call_once(g_pool_fork_once, [] { pthread_atfork(nullptr, nullptr, [] { g_pool = nullptr; }); });
+        if (!g_pool) g_pool = new WorkPool();  // never destroyed: its threads end with the process
+        p = g_pool;
+    }
+    p->run(n, f);
 }
 
 // Byte buffer that is NOT zero-filled on allocation (a 9 GB text image would otherwise
@@ -272,10 +342,7 @@ int inflate_all(const Bytes& in, int n_threads, Bytes* out) {
             }
         };
         int nt = std::max(1, std::min<int>(n_threads, (int)blocks.size()));
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work);
-        work();
-        for (auto& t : th) t.join();
+        parallel_run(nt, [&](int) { work(); });
         if (bad.load()) return dfail(FTK_ERR_FORMAT, "BGZF inflate failed");
         return FTK_OK;
     }
@@ -453,11 +520,7 @@ int ftk_fragfile_decode(const char* path, const char* contig, int n_threads, ftk
         cut[i] = nl ? nl + 1 : e;
     }
     std::vector<std::vector<Run>> seg_runs(nseg);
-    std::vector<std::thread> th;
-    for (int i = 1; i < nseg; ++i)
-        th.emplace_back(parse_segment, cut[i], cut[i + 1], t->bed6, contig, &seg_runs[i]);
-    parse_segment(cut[0], cut[1], t->bed6, contig, &seg_runs[0]);
-    for (auto& x : th) x.join();
+    parallel_run(nseg, [&](int i) { parse_segment(cut[i], cut[i + 1], t->bed6, contig, &seg_runs[i]); });
     sw.lap("parse");
     // Assemble: row offsets of every run (serial, tiny), ONE block for the whole table (page-locked
     // when a HIP device is present), then every segment copies its runs to their final place in parallel.
@@ -501,10 +564,7 @@ int ftk_fragfile_decode(const char* path, const char* contig, int n_threads, ftk
         }
         std::vector<Run>().swap(seg_runs[sg]);
     };
-    th.clear();
-    for (int i = 1; i < nseg; ++i) th.emplace_back(assemble, i);
-    assemble(0);
-    for (auto& x : th) x.join();
+    parallel_run(nseg, [&](int i) { assemble(i); });
     sw.lap("assemble");
     *out = t.release();
     return FTK_OK;
@@ -706,10 +766,7 @@ void pack_parts(Contig& ct, int n_threads) {
         }
     };
     const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, ct.parts.size()));
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
+    parallel_run(nt, [&](int) { work(); });
     std::vector<Columns>().swap(ct.parts);
 }
 
@@ -735,10 +792,7 @@ int inflate_block_list(const uint8_t* p, const std::vector<Block>& blocks, int n
         }
     };
     int nt = std::max(1, std::min<int>(n_threads, (int)blocks.size()));
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
+    parallel_run(nt, [&](int) { work(); });
     return bad.load() ? FTK_ERR_FORMAT : FTK_OK;
 }
 
@@ -757,10 +811,7 @@ void parse_text_parallel(const char* b, const char* e, bool bed6, const char* on
         cut[i] = nl ? nl + 1 : e;
     }
     std::vector<std::vector<Run>> seg(nseg);
-    std::vector<std::thread> th;
-    for (int i = 1; i < nseg; ++i) th.emplace_back(parse_segment, cut[i], cut[i + 1], bed6, only, &seg[i]);
-    parse_segment(cut[0], cut[1], bed6, only, &seg[0]);
-    for (auto& x : th) x.join();
+    parallel_run(nseg, [&](int i) { parse_segment(cut[i], cut[i + 1], bed6, only, &seg[i]); });
     for (auto& v : seg)
         for (auto& r : v) out->push_back(std::move(r));
 }
@@ -1142,10 +1193,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
                     bam_record(r, bs, run->c);
                 }
             };
-            std::vector<std::thread> th;
-            for (int i = 1; i < nseg; ++i) th.emplace_back(work, i);
-            work(0);
-            for (auto& x : th) x.join();
+            parallel_run(nseg, [&](int i) { work(i); });
             for (auto& v : seg)
                 for (auto& r : v) {
                     if (cur_ref >= 0 && r.ref != cur_ref) {
