@@ -180,6 +180,65 @@ bool have_hip_device() {
     return yes;
 }
 
+// Page-locked blocks are recycled: hipHostMalloc has to pin every page (about 0.2 ms per MB), and a
+// streamed file asks for one block per contig and frees it a moment later.  A few freed blocks are kept
+// (at most 8, 2 GiB in total) and handed to the next request they fit without wasting more than half.
+struct PinnedCache {
+    struct Blk { void* p; size_t cap; };
+    std::mutex mu;
+    std::vector<Blk> free_list;
+    std::vector<Blk> live;  // capacity of the blocks handed out (needed when they come back)
+    size_t cached = 0;
+};
+PinnedCache& pinned_cache() {
+    static PinnedCache* c = new PinnedCache();  // leaked: the driver unpins at process exit
+    return *c;
+}
+
+void* pinned_alloc(size_t bytes) {
+    PinnedCache& c = pinned_cache();
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        int best = -1;
+        for (int i = 0; i < (int)c.free_list.size(); ++i)
+            if (c.free_list[i].cap >= bytes && c.free_list[i].cap <= 2 * bytes + (1 << 20) &&
+                (best < 0 || c.free_list[i].cap < c.free_list[best].cap))
+                best = i;
+        if (best >= 0) {
+            PinnedCache::Blk b = c.free_list[best];
+            c.free_list.erase(c.free_list.begin() + best);
+            c.cached -= b.cap;
+            c.live.push_back(b);
+            return b.p;
+        }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.live.push_back({p, bytes});
+    return p;
+}
+
+void pinned_free(void* p) {
+    if (!p) return;
+    PinnedCache& c = pinned_cache();
+    size_t cap = 0;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        for (size_t i = 0; i < c.live.size(); ++i)
+            if (c.live[i].p == p) { cap = c.live[i].cap; c.live.erase(c.live.begin() + i); break; }
+        if (cap && c.free_list.size() < 8 && c.cached + cap <= (2ull << 30)) {
+            c.free_list.push_back({p, cap});
+            c.cached += cap;
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
 // Lay a contig's final columns out inside an existing block (no copy).
 size_t packed_bytes(size_t m, bool bam) {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -206,10 +265,9 @@ void pack(Contig& ct) {
     const size_t total = (bam ? 5 : 2) * b32 + 2 * b8;
     Packed& p = ct.p;
     p.rows = m;
-    if (have_hip_device() && hipHostMalloc(&p.base, total, hipHostMallocDefault) == hipSuccess) {
+    if (have_hip_device() && (p.base = pinned_alloc(total)) != nullptr) {
         p.pinned = true;
     } else {
-        (void)hipGetLastError();
         p.base = malloc(total);
         p.pinned = false;
     }
@@ -244,10 +302,10 @@ struct ftk_fragtable {
     void* block = nullptr;  // one allocation holding every contig's columns (text decoder)
     bool block_pinned = false;
     ~ftk_fragtable() {
-        if (block) { if (block_pinned) (void)hipHostFree(block); else free(block); }
+        if (block) { if (block_pinned) pinned_free(block); else free(block); }
         for (auto& ct : contigs) {
             if (!ct.p.base) continue;
-            if (ct.p.pinned) (void)hipHostFree(ct.p.base); else free(ct.p.base);
+            if (ct.p.pinned) pinned_free(ct.p.base); else free(ct.p.base);
         }
     }
 };
@@ -539,10 +597,9 @@ int ftk_fragfile_decode(const char* path, const char* contig, int n_threads, ftk
     std::vector<size_t> base_of(t->contigs.size());
     for (size_t ci = 0; ci < t->contigs.size(); ++ci) { base_of[ci] = total; total += packed_bytes(rows_of[ci], false); }
     if (total == 0) total = 256;
-    if (have_hip_device() && hipHostMalloc(&t->block, total, hipHostMallocDefault) == hipSuccess) {
+    if (have_hip_device() && (t->block = pinned_alloc(total)) != nullptr) {
         t->block_pinned = true;
     } else {
-        (void)hipGetLastError();
         t->block = malloc(total);
     }
     if (!t->block) return dfail(FTK_ERR_OOM, "out of host memory (%zu bytes)", total);
@@ -742,10 +799,9 @@ void pack_parts(Contig& ct, int n_threads) {
     for (auto& c : ct.parts) { at.push_back(m); m += c.start.size(); }
     const size_t total = packed_bytes(m, false);
     Packed& p = ct.p;
-    if (have_hip_device() && hipHostMalloc(&p.base, total, hipHostMallocDefault) == hipSuccess) {
+    if (have_hip_device() && (p.base = pinned_alloc(total)) != nullptr) {
         p.pinned = true;
     } else {
-        (void)hipGetLastError();
         p.base = malloc(total);
         p.pinned = false;
     }
