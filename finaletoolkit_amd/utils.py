@@ -15,7 +15,7 @@ import numpy as np
 from .exceptions import InvalidInputError
 from .source import get_engine, open_source
 
-__all__ = ["chrom_sizes_to_list", "chrom_sizes_to_dict", "get_intervals", "overlaps", "frag_generator",
+__all__ = ["chrom_sizes_to_list", "chrom_sizes_to_dict", "get_intervals", "overlaps", "frags_in_region", "frag_generator",
            "frag_array"]
 
 FragTuple = Tuple[str, int, int, int, bool]
@@ -72,6 +72,13 @@ def overlaps(contigs_1, starts_1, stops_1, contigs_2, starts_2, stops_2):
         e1 = stops_1[m1][:, None]
         out[m1] = np.any((s1 < stops_2[m2][None]) & (e1 > starts_2[m2][None]), axis=1)
     return out
+
+
+def frags_in_region(frag_array, start: int, stop: int):
+    """Rows of a ``frag_array`` result with ``start < stop_`` and ``stop >= start_`` (utils/utils.py:160-183;
+    note the inclusive lower test)."""
+    keep = (frag_array["start"] < stop) & (frag_array["stop"] >= start)
+    return frag_array[keep]
 
 
 def _check_policy(intersect_policy: str):

@@ -72,6 +72,18 @@ class TestFragIO:  # reference tests/test_frag_io.py
         assert arr.dtype == np.dtype([("start", "<i8"), ("stop", "<i8"), ("strand", "?")])
         assert [[int(r["start"]), int(r["stop"]), bool(r["strand"])] for r in arr] == G["fixture"]["frag_array_120_180"]
 
+    def test_frag_array_and_frags_in_region_known_answers(self):  # reference tests/test_utils.py:26-60
+        from finaletoolkit_amd.utils import frags_in_region
+        dt = [("start", "<i8"), ("stop", "<i8"), ("strand", "?")]
+        want = np.array([(34443118, 34443284, True), (34443139, 34443300, True), (34443358, 34443538, False),
+                         (34443483, 34443660, True), (34444089, 34444252, True), (34444696, 34444863, True),
+                         (34444954, 34445075, True), (34444968, 34445105, True), (34445136, 34445288, True),
+                         (34445511, 34445672, False), (34445705, 34445852, True), (34445723, 34445893, True),
+                         (34446126, 34446261, False), (34446486, 34446653, True)], dtype=dt)
+        arr = frag_array(FIX, "12", min_length=120, max_length=180)
+        assert np.array_equal(arr, want)
+        assert np.array_equal(frags_in_region(arr, 34443119, 34445075), want[:8])
+
     def test_errors(self, tmp_path):
         with pytest.raises(InvalidInputError):
             list(frag_generator(FIX, None, start=5, stop=10))
