@@ -21,31 +21,74 @@ def _block(data: bytes, level: int) -> bytes:
     return head + payload + tail
 
 
-def write_bgzf(path, data: bytes, level: int = 6) -> None:
-    """Write ``data`` as a BGZF file with the standard empty EOF block."""
+def write_bgzf(path, data: bytes, level: int = 6) -> list[int]:
+    """Write ``data`` as a BGZF file with the standard empty EOF block; returns the file offset of every
+    data block (block ``k`` holds bytes ``[k * 0xFF00, (k + 1) * 0xFF00)`` of ``data``)."""
+    offsets = []
     with open(path, "wb") as fh:
         for off in range(0, len(data), _BLOCK):
+            offsets.append(fh.tell())
             fh.write(_block(data[off:off + _BLOCK], level))
+        offsets.append(fh.tell())  # the EOF block
         fh.write(_EOF)
+    return offsets
 
 
-def write_frag_gz(path, contig_rows, bed6: bool = False, with_tbi_stub: bool = True, level: int = 6) -> None:
+def virtual_offset(block_offsets: list[int], byte_pos: int) -> int:
+    """BGZF virtual offset of uncompressed byte ``byte_pos`` of a ``write_bgzf`` file."""
+    k, u = divmod(byte_pos, _BLOCK)
+    if k >= len(block_offsets) - 1:  # end of data: the EOF block
+        return block_offsets[-1] << 16
+    return (block_offsets[k] << 16) | u
+
+
+def write_index(path, bai: bool, spans: list[tuple[str, int, int]]) -> None:
+    """Minimal tabix (``bai=False``, BGZF-compressed) / BAI index: per reference one pseudo-bin 37450 whose
+    first chunk is the reference's virtual-offset span ``(name, v_begin, v_end)`` -- what a reader needs to
+    find a contig; ``v_begin == v_end`` marks a reference without records."""
+    body = b""
+    for _, vb, ve in spans:
+        if ve > vb:
+            body += struct.pack("<i", 1) + struct.pack("<Ii", 37450, 2) + struct.pack("<QQQQ", vb, ve, 0, 0)
+        else:
+            body += struct.pack("<i", 0)
+        body += struct.pack("<i", 0)  # no linear index
+    if bai:
+        with open(path, "wb") as fh:
+            fh.write(b"BAI\1" + struct.pack("<i", len(spans)) + body)
+        return
+    names = b"".join(n.encode() + b"\0" for n, _, _ in spans)
+    head = b"TBI\1" + struct.pack("<iiiiiiii", len(spans), 0x10000, 1, 2, 3, ord("#"), 0, len(names)) + names
+    write_bgzf(path, head + body)
+
+
+def write_frag_gz(path, contig_rows, bed6: bool = False, with_tbi_stub: bool = True, level: int = 6,
+                  with_index: bool = False) -> None:
     """Write a FinaleDB fragment file (``chrom start stop mapq strand``; BED6
     inserts a ``.`` name column).  ``contig_rows`` is an iterable of
     ``(name, start[], end[], mapq[], strand[])`` in file order.
 
-    ``with_tbi_stub`` drops an empty ``<path>.tbi`` next to it: the engine
-    decodes whole contigs and never reads the index, but keeps the reference's
-    "index must exist" check (io/alignment.py:191-201).
+    ``with_index`` writes a minimal tabix index (contig spans) next to it, which lets the engine decode
+    single contigs without reading the rest; otherwise ``with_tbi_stub`` drops an empty ``<path>.tbi``
+    (the engine then scans the file, but the reference's "index must exist" check,
+    io/alignment.py:191-201, is kept).
     """
     parts = []
+    marks = []  # (name, first byte, end byte) per run of a contig
+    pos = 0
     for name, start, end, mapq, strand in contig_rows:
+        first = pos
         for s, e, q, st in zip(start, end, mapq, strand):
             sign = "+" if st else "-"
             if bed6:
                 parts.append(f"{name}\t{int(s)}\t{int(e)}\t.\t{int(q)}\t{sign}\n")
             else:
                 parts.append(f"{name}\t{int(s)}\t{int(e)}\t{int(q)}\t{sign}\n")
-    write_bgzf(path, "".join(parts).encode(), level)
-    if with_tbi_stub:
+            pos += len(parts[-1])
+        marks.append((name, first, pos))
+    offsets = write_bgzf(path, "".join(parts).encode(), level)
+    if with_index:
+        write_index(str(path) + ".tbi", False,
+                    [(n, virtual_offset(offsets, a), virtual_offset(offsets, b)) for n, a, b in marks])
+    elif with_tbi_stub:
         open(str(path) + ".tbi", "ab").close()

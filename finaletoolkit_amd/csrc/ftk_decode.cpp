@@ -908,6 +908,105 @@ inline bool bam_record(const uint8_t* r, uint32_t bs, Columns& c) {
 
 }  // namespace
 
+// ---- tabix (.tbi) / BAM (.bai) index: where a contig's rows start and end in the file --------
+// Both hold, per reference, bins of chunks [virtual begin, virtual end) (virtual = block file
+// offset << 16 | offset inside the inflated block).  htslib's pseudo-bin 37450 carries the span of the
+// whole reference in its first chunk; without it the span is the hull of the chunks.
+namespace {
+
+struct IndexSpan {
+    bool usable = false;   // the index could be read
+    bool present = false;  // ... and lists the contig with at least one chunk
+    uint64_t beg = 0, end = 0;
+};
+
+inline uint64_t rd_u64(const uint8_t* p) { return (uint64_t)rd_u32(p) | ((uint64_t)rd_u32(p + 4) << 32); }
+
+// ref < 0: look the contig up by name (tabix); else by reference id (BAI)
+IndexSpan index_lookup(const std::string& index_path, bool bai, const std::string& name, int ref) {
+    IndexSpan out;
+    Bytes raw, img;
+    if (!read_file(index_path.c_str(), &raw) || raw.size() < 8) return out;
+    const uint8_t* p;
+    size_t n;
+    if (bai) {
+        p = raw.data();
+        n = raw.size();
+        if (memcmp(p, "BAI\1", 4) != 0) return out;
+    } else {
+        if (inflate_all(raw, 1, &img) != FTK_OK || img.size() < 36) return out;
+        p = img.data();
+        n = img.size();
+        if (memcmp(p, "TBI\1", 4) != 0) return out;
+    }
+    const int32_t n_ref = rd_i32(p + 4);
+    size_t o = 8;
+    if (!bai) {
+        const int32_t l_nm = rd_i32(p + 32);
+        o = 36;
+        if (l_nm < 0 || o + (size_t)l_nm > n) return out;
+        ref = -1;
+        int k = 0;
+        for (size_t a = o; a < o + (size_t)l_nm && k < n_ref; ++k) {
+            const char* nm = (const char*)p + a;
+            const size_t len = strnlen(nm, o + l_nm - a);
+            if (name.size() == len && memcmp(nm, name.data(), len) == 0) ref = k;
+            a += len + 1;
+        }
+        o += (size_t)l_nm;
+        out.usable = true;
+        if (ref < 0) return out;  // the file has no such contig
+    }
+    if (n_ref < 0 || ref >= n_ref) { out.usable = bai; return out; }
+    for (int r = 0; r <= ref; ++r) {
+        if (o + 4 > n) return IndexSpan{};
+        const int32_t n_bin = rd_i32(p + o);
+        o += 4;
+        uint64_t lo = UINT64_MAX, hi = 0;
+        bool pseudo = false;
+        for (int32_t b = 0; b < n_bin; ++b) {
+            if (o + 8 > n) return IndexSpan{};
+            const uint32_t bin = rd_u32(p + o);
+            const int32_t n_chunk = rd_i32(p + o + 4);
+            o += 8;
+            if (n_chunk < 0 || o + 16 * (size_t)n_chunk > n) return IndexSpan{};
+            if (r == ref) {
+                if (bin == 37450 && n_chunk >= 1) {
+                    lo = rd_u64(p + o);
+                    hi = rd_u64(p + o + 8);
+                    pseudo = true;
+                } else if (!pseudo && bin != 37450) {
+                    for (int32_t c = 0; c < n_chunk; ++c) {
+                        lo = std::min(lo, rd_u64(p + o + 16 * (size_t)c));
+                        hi = std::max(hi, rd_u64(p + o + 16 * (size_t)c + 8));
+                    }
+                }
+            }
+            o += 16 * (size_t)n_chunk;
+        }
+        if (o + 4 > n) return IndexSpan{};
+        const int32_t n_intv = rd_i32(p + o);
+        o += 4;
+        if (n_intv < 0 || o + 8 * (size_t)n_intv > n) return IndexSpan{};
+        o += 8 * (size_t)n_intv;
+        if (r == ref) {
+            out.usable = true;
+            if (lo != UINT64_MAX && hi > lo) { out.present = true; out.beg = lo; out.end = hi; }
+        }
+    }
+    return out;
+}
+
+std::string index_path_of(const std::string& path, bool bam) {
+    if (!bam) return path + ".tbi";
+    std::string a = path + ".bai";
+    if (FILE* f = fopen(a.c_str(), "rb")) { fclose(f); return a; }
+    if (path.size() > 4) return path.substr(0, path.size() - 4) + ".bai";
+    return a;
+}
+
+}  // namespace
+
 struct ftk_fragstream {
     std::string path, only;
     bool has_only = false, bam = false, bed6 = false;
@@ -968,11 +1067,28 @@ struct ftk_fragstream {
     void run();
     bool run_text(RawBuf& first, size_t first_n);
     bool run_bam(RawBuf& first, size_t first_n);
+    // single-contig requests with a usable index: read only the file range holding the contig
+    long long read_end = -1;      // file offset to stop reading at (-1: none)
+    bool partial_tail_ok = false;  // the range may end inside a block that belongs to the next contig
+    size_t first_skip = 0;        // bytes of the first inflated block that precede the contig
     // read the next piece after `carry` bytes already in buf; returns bytes now in buf
     size_t fill(RawBuf& buf, size_t carry) {
         if (!buf.reserve(carry + kStreamPiece)) return carry;
-        const size_t got = fread(buf.data() + carry, 1, kStreamPiece, fp);
+        size_t want = kStreamPiece;
+        if (read_end >= 0) {
+            const long long pos = ftell(fp);
+            want = pos >= read_end ? 0 : (size_t)std::min<long long>((long long)kStreamPiece, read_end - pos);
+        }
+        const size_t got = want ? fread(buf.data() + carry, 1, want, fp) : 0;
         return carry + got;
+    }
+    // seek to a contig's rows; false = index unusable (caller scans the whole file)
+    bool seek_to(const IndexSpan& sp) {
+        if (fseek(fp, (long)(sp.beg >> 16), SEEK_SET) != 0) return false;
+        first_skip = (size_t)(sp.beg & 0xffff);
+        read_end = (long long)(sp.end >> 16) + 0x10000 + 64;  // through the block that holds the last row
+        partial_tail_ok = true;
+        return true;
     }
     // complete BGZF blocks at the front of buf[0, n): block list + bytes consumed; false on corruption
     bool whole_blocks(const uint8_t* p, size_t n, bool eof, std::vector<Block>* blocks, size_t* used, size_t* total) {
@@ -996,7 +1112,7 @@ struct ftk_fragstream {
             if (!q && n - off < (1u << 16)) break;                  // header itself is cut
             return false;
         }
-        if (eof && off != n) return false;  // trailing garbage / truncated last block
+        if (eof && off != n && !partial_tail_ok) return false;  // trailing garbage / truncated last block
         *used = off;
         *total = tot;
         return true;
@@ -1005,6 +1121,17 @@ struct ftk_fragstream {
 
 void ftk_fragstream::run() {
     RawBuf buf;
+    if (has_only && !bam) {  // tabix index: jump straight to the contig's rows
+        const IndexSpan sp = index_lookup(index_path_of(path, false), false, only, -1);
+        if (sp.usable && !sp.present) {  // the file has no row of this contig
+            std::lock_guard<std::mutex> lk(mu);
+            finished = true;
+            header_ready = true;
+            cv.notify_all();
+            return;
+        }
+        if (sp.usable && !seek_to(sp)) { read_end = -1; partial_tail_ok = false; first_skip = 0; rewind(fp); }
+    }
     const size_t n = fill(buf, 0);
     size_t bsize = 0;
     const bool bgzf = n >= 18 && gzip_header(buf.data(), n, 0, &bsize) && bsize;
@@ -1093,6 +1220,10 @@ bool ftk_fragstream::run_text(RawBuf& buf, size_t n) {
         clk.lap(1);
         const char* b = (const char*)text.data();
         const char* e = b + text_carry + total;
+        if (first_skip) {  // after an index seek: the contig starts inside the first block
+            b += std::min<size_t>(first_skip, (size_t)(e - b));
+            first_skip = 0;
+        }
         if (!layout_known) {  // io/alignment.py:143-156: BED6 when the first data row has > 5 columns
             const char* q = b;
             while (q < e) {
@@ -1164,6 +1295,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
     Contig cur;
     int cur_ref = -1;
     std::set<int> seen;
+    size_t pending_skip = 0;
     bool eof = n < kStreamPiece;
     for (;;) {
         size_t used = 0, total = 0;
@@ -1173,7 +1305,8 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
             return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
         const uint8_t* p = data.data();
         const size_t m = carry + total;
-        size_t off = 0;
+        size_t off = pending_skip;
+        pending_skip = 0;
         if (!header_done) {
             bool complete = false;
             do {
@@ -1218,6 +1351,25 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
                 goto next_piece;
             }
             header_done = true;
+            if (has_only) {  // BAI: jump to the contig's records instead of walking the whole file
+                int target = -1;
+                for (size_t r = 0; r < ref_names.size(); ++r)
+                    if (ref_names[r] == only) target = (int)r;
+                if (target < 0) return true;  // not in the header: nothing to hand out
+                const IndexSpan sp = index_lookup(index_path_of(path, true), true, std::string(), target);
+                if (sp.usable && !sp.present) return true;  // no alignment on this contig
+                if (sp.usable && seek_to(sp)) {
+                    carry = 0;
+                    n = fill(buf, 0);
+                    eof = n < kStreamPiece;
+                    pending_skip = first_skip;
+                    first_skip = 0;
+                    continue;
+                }
+                read_end = -1;
+                partial_tail_ok = false;
+                first_skip = 0;
+            }
         }
         {
             // index the complete records, parse them in parallel, merge the runs in order
@@ -1230,7 +1382,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
                 rec.push_back(o);
                 o += 4 + (size_t)bs;
             }
-            if (eof && o != m) return fail(FTK_ERR_FORMAT, "truncated BAM record");
+            if (eof && o != m && !partial_tail_ok) return fail(FTK_ERR_FORMAT, "truncated BAM record");
             const int n_ref = (int)wanted.size();
             int nseg = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, rec.size() / 4096 + 1));
             std::vector<std::vector<BamRun>> seg(nseg);

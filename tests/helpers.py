@@ -54,7 +54,7 @@ def read_bed(path):
     return out
 
 
-def write_synthetic_bam(path, contigs, frags, junk=True, read_len=100):
+def write_synthetic_bam(path, contigs, frags, junk=True, read_len=100, index=True):
     """Write a coordinate-sorted BAM (+ empty .bai stub) holding one read pair per fragment.
 
     contigs: [(name, length)]; frags: {name: (start[], end[], mapq[], forward[])}.  Forward fragments put
@@ -78,6 +78,7 @@ def write_synthetic_bam(path, contigs, frags, junk=True, read_len=100):
     for c, n in contigs:
         out.append(struct.pack("<i", len(c) + 1) + c.encode() + b"\0" + struct.pack("<i", n))
     expected = {}
+    spans = []  # byte range of every contig's records in the uncompressed stream
     for ref_id, (c, _) in enumerate(contigs):
         s, e, q, fw = frags.get(c, ([], [], [], []))
         records = []  # (pos, order, bytes, read1 fragment or None)
@@ -99,13 +100,19 @@ def write_synthetic_bam(path, contigs, frags, junk=True, read_len=100):
                     records.append((fs, k, rec(ref_id, fs, mq, flag, tl, f"j{i}", rl, fs), None))
                     k += 1
         records.sort(key=lambda r: (r[0], r[1]))
+        first = sum(len(x) for x in out)
         out += [r[2] for r in records]
+        spans.append((c, first, sum(len(x) for x in out)))
         rows = [r[3] for r in records if r[3] is not None]
         order = sorted(range(len(rows)), key=lambda j: rows[j][0])  # stable, like the decoder
         # 7th column: rank of the read1 record in the file (the order pysam iterates in)
         expected[c] = [rows[j] + (j,) for j in order]
-    bgzf.write_bgzf(path, b"".join(out), level=1)
-    open(str(path) + ".bai", "ab").close()
+    offsets = bgzf.write_bgzf(path, b"".join(out), level=1)
+    if index:  # a real (minimal) BAI: lets the decoder jump to a contig
+        bgzf.write_index(str(path) + ".bai", True, [(c, bgzf.virtual_offset(offsets, a), bgzf.virtual_offset(offsets, b))
+                                                     for c, a, b in spans])
+    else:
+        open(str(path) + ".bai", "ab").close()
     return expected
 
 

@@ -160,3 +160,50 @@ def test_stream_plain_gzip_falls_back(tmp_path):
         fh.write("1\t10\t200\t60\t+\n1\t50\t260\t30\t-\n2\t5\t100\t9\t+\n")
     got, order, _ = _stream(p)
     assert order == ["1", "2"] and got["1"][1][0].tolist() == [10, 50] and got["2"][1][2].tolist() == [9]
+
+
+def test_single_contig_requests_use_the_index(tmp_path):
+    """With a tabix / BAI index a single-contig stream reads only that contig's blocks: same rows as a scan
+    of the whole file, contigs without rows or unknown to the file give nothing, a stub index falls back."""
+    rows = []
+    for k, size in enumerate((1_200_000, 300_000, 40_000, 900_000)):
+        s, e, q, st = synth.synth_contig(size, depth=15.0, seed=60 + k)
+        rows.append((f"c{k}", s, e, q, st))
+    pi, ps = str(tmp_path / "idx.frag.gz"), str(tmp_path / "stub.frag.gz")
+    bgzf.write_frag_gz(pi, rows, level=1, with_index=True)
+    bgzf.write_frag_gz(ps, rows, level=1)
+    want = _decode(ps)
+    for c in ("c0", "c1", "c2", "c3"):
+        for path in (pi, ps):
+            got, order, _ = _stream(path, contig=c)
+            assert order == [c]
+            for a, b in zip(got[c][1][:4], want[c][1][:4]):
+                assert np.array_equal(a, b), (path, c)
+    assert _stream(pi, contig="c9")[1] == [] and _stream(ps, contig="c9")[1] == []
+    # BAM + BAI, incl. a contig of the header without reads and one the header does not know
+    rng = np.random.default_rng(3)
+    contigs = [("chrA", 800_000), ("chrEmpty", 1000), ("chrB", 500_000), ("chrC", 100_000)]
+    frags = {}
+    for name, size in contigs:
+        if name == "chrEmpty":
+            continue
+        n = size // 50
+        s = np.sort(rng.integers(0, size - 700, n))
+        frags[name] = (s, s + rng.integers(210, 600, n), rng.integers(0, 61, n), rng.integers(0, 2, n).astype(bool))
+    bi, bs = str(tmp_path / "idx.bam"), str(tmp_path / "stub.bam")
+    write_synthetic_bam(bi, contigs, frags, index=True)
+    write_synthetic_bam(bs, contigs, frags, index=False)
+    wantb = _decode(bs, bam=True)
+    for c in ("chrA", "chrB", "chrC"):
+        for path in (bi, bs):
+            got, order, refs = _stream(path, bam=True, contig=c)
+            assert order == [c] and len(refs) == 4
+            for a, b in zip(got[c][1], wantb[c][1]):
+                assert np.array_equal(a, b), (path, c)
+    for path in (bi, bs):
+        assert _stream(path, bam=True, contig="chrEmpty")[1] == []
+        assert _stream(path, bam=True, contig="chrZ")[1] == []
+    # the fixtures' real htslib indexes
+    assert _stream(os.path.join(DATA, "12.3444.b37.frag.gz"), contig="12")[0]["12"][0] == 17
+    assert _stream(os.path.join(DATA, "12.3444.b37.bam"), bam=True, contig="12")[0]["12"][0] == 17
+    assert _stream(os.path.join(DATA, "12.3444.b37.bam"), bam=True, contig="1")[1] == []
