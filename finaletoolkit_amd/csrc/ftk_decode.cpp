@@ -1438,6 +1438,65 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
 
 extern "C" {
 
+int ftk_fragfile_index_contigs(const char* path, char* names_out, int64_t cap, int64_t* needed_out, int* is_bed6_out) {
+    if (!path || !needed_out) return dfail(FTK_ERR_INVALID, "NULL argument");
+    *needed_out = 0;
+    Bytes raw, img;
+    const std::string ipath = std::string(path) + ".tbi";
+    if (!read_file(ipath.c_str(), &raw) || raw.size() < 8) return dfail(FTK_ERR_FORMAT, "no usable tabix index at %s", ipath.c_str());
+    if (inflate_all(raw, 1, &img) != FTK_OK || img.size() < 36 || memcmp(img.data(), "TBI\1", 4) != 0)
+        return dfail(FTK_ERR_FORMAT, "%s is not a tabix index", ipath.c_str());
+    const uint8_t* p = img.data();
+    const int32_t n_ref = rd_i32(p + 4), l_nm = rd_i32(p + 32);
+    if (n_ref < 0 || l_nm < 0 || 36 + (size_t)l_nm > img.size()) return dfail(FTK_ERR_FORMAT, "corrupt tabix index");
+    // names of the references that hold at least one chunk, newline-separated
+    std::string joined;
+    size_t a = 36;
+    for (int k = 0; k < n_ref && a < 36 + (size_t)l_nm; ++k) {
+        const char* nm = (const char*)p + a;
+        const size_t len = strnlen(nm, 36 + (size_t)l_nm - a);
+        const IndexSpan sp = index_lookup(ipath, false, std::string(nm, len), -1);
+        if (!sp.usable) return dfail(FTK_ERR_FORMAT, "corrupt tabix index");
+        if (sp.present) { joined.append(nm, len); joined.push_back('\n'); }
+        a += len + 1;
+    }
+    *needed_out = (int64_t)joined.size() + 1;
+    if (names_out && cap >= (int64_t)joined.size() + 1) memcpy(names_out, joined.c_str(), joined.size() + 1);
+    if (is_bed6_out) {  // layout of the first data row (io/alignment.py:143-156), from the file's first block
+        *is_bed6_out = 0;
+        FILE* fp = fopen(path, "rb");
+        if (!fp) return dfail(FTK_ERR_IO, "cannot read %s", path);
+        Bytes head, text;
+        head.alloc(1 << 17);
+        const size_t got = fread(head.data(), 1, head.size(), fp);
+        fclose(fp);
+        size_t bs = 0;
+        const size_t q = gzip_header(head.data(), got, 0, &bs);
+        if (q && bs && bs <= got) {
+            Bytes one;
+            one.alloc(bs);
+            memcpy(one.data(), head.data(), bs);
+            if (inflate_all(one, 1, &text) == FTK_OK) {
+                const char* b = (const char*)text.data();
+                const char* e = b + text.size();
+                while (b < e) {
+                    const char* nl = (const char*)memchr(b, '\n', (size_t)(e - b));
+                    const char* le = nl ? nl : e;
+                    if (le > b && *b != '#') {
+                        int tabs = 0;
+                        for (const char* x = b; x < le; ++x) tabs += (*x == '\t');
+                        *is_bed6_out = (tabs + 1) > 5;
+                        break;
+                    }
+                    if (!nl) break;
+                    b = nl + 1;
+                }
+            }
+        }
+    }
+    return FTK_OK;
+}
+
 int ftk_fragstream_open(const char* path, const char* contig, int is_bam, int n_threads, int max_queued,
                         ftk_fragstream** out) {
     if (!path || !out) return dfail(FTK_ERR_INVALID, "NULL argument");

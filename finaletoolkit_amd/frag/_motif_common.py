@@ -283,13 +283,13 @@ def region_histograms(input_file, refseq_file, regions, spec: dict, quality_thre
         by_contig.setdefault(r[0], []).append(i)
     with ReferenceGenome(refseq_file) as ref:
         for contig, idx in by_contig.items():
-            if contig not in src.loaded or contig not in ref.chroms:
+            if not src.has(contig) or contig not in ref.chroms:
                 continue
             lim = 2 ** 31 - 1
             ws = np.clip([regions[i][1] for i in idx], -lim - 1, lim)
             we = np.clip([regions[i][2] for i in idx], -lim - 1, lim)
             rid = ref.device_image(eng, contig)
-            counts, _, err = eng.motif_counts(src.key(contig), rid, ws, we, k, spec["fwd_offset"],
+            counts, _, err = eng.motif_counts(src.require(contig), rid, ws, we, k, spec["fwd_offset"],
                                               spec["rev_offset"], spec["both_strands"], spec["negative_strand"],
                                               spec["guard"], spec["rev_oob_is_error"], quality_threshold,
                                               bam=src.is_bam)

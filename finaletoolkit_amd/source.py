@@ -46,16 +46,24 @@ def decode_threads(workers: int | None = None) -> int:
 
 
 class FragSource:
-    """One decoded input file; contig ``c`` lives on the engine as ``key(c)``."""
+    """One input file; contig ``c`` lives on the engine as ``key(c)`` once it has been decoded.
 
-    def __init__(self, path: str, is_bam: bool, bed6: bool, contigs, lengths, uid: int):
+    Files with a usable index (tabix ``.tbi`` / ``.bai``) are opened lazily: the contig list comes from the
+    index or the BAM header and a contig is decoded -- seeking through the index, so only its own blocks are
+    read -- the first time a feature asks for it; whole-file operations call ``load_all``.  Files without a
+    usable index are decoded in one streaming pass when they are opened."""
+
+    def __init__(self, path: str, is_bam: bool, bed6: bool, contigs, lengths, uid: int, lazy: bool = False,
+                 workers: int | None = None):
         self.path = path
         self.is_bam = is_bam
         self.bed6 = bed6
-        self.contigs = list(contigs)              # file order
+        self.contigs = list(contigs)              # file / header order
         self.lengths = dict(lengths)              # name -> length (BAM) / None
         self.uid = uid
         self.loaded = set()
+        self.lazy = lazy
+        self.workers = workers
 
     def key(self, contig: str) -> str:
         return f"{self.uid}:{contig}"
@@ -64,13 +72,50 @@ class FragSource:
     def chroms(self):
         return {c: self.lengths.get(c) for c in self.contigs}
 
+    def has(self, contig: str) -> bool:
+        return contig in self.loaded or (self.lazy and contig in self.contigs)
+
     def require(self, contig: str) -> str:
-        """Engine key of ``contig``; ValueError if the file has no such contig
-        (pysam raises ValueError for an unknown region, which the reference
-        lets propagate)."""
+        """Engine key of ``contig`` (decoding it now if the source is lazy); ValueError if the file has no
+        such contig (pysam raises ValueError for an unknown region, which the reference lets propagate)."""
         if contig not in self.loaded:
-            raise ValueError(f"could not create iterator for region '{contig}': contig not present in {self.path}")
+            if not (self.lazy and contig in self.contigs):
+                raise ValueError(f"could not create iterator for region '{contig}': contig not present in {self.path}")
+            self._load_one(contig)
         return self.key(contig)
+
+    def _load_one(self, contig: str):
+        eng = get_engine()
+        lib = L.load()
+        stream = C.c_void_p()
+        rc = lib.ftk_fragstream_open(self.path.encode(), contig.encode(), int(self.is_bam),
+                                     decode_threads(self.workers), 1, C.byref(stream))
+        if rc != L.FTK_OK:
+            raise UnsupportedFormatError(lib.ftk_fragtable_error().decode())
+        try:
+            table = C.c_void_p()
+            rc = lib.ftk_fragstream_next(stream, C.byref(table))
+            if rc != L.FTK_OK:
+                raise UnsupportedFormatError(lib.ftk_fragtable_error().decode())
+            if table.value:
+                try:
+                    eng.load_contig_from_table(self.key(contig), table, 0, self.is_bam)
+                finally:
+                    lib.ftk_fragtable_free(table)
+            else:  # listed, but without a usable row / read: valid and empty
+                e32, e8 = np.zeros(0, np.int32), np.zeros(0, np.uint8)
+                eng.load_contig(self.key(contig), e32, e32, e8, e8, *((e32, e32) if self.is_bam else ()))
+            self.loaded.add(contig)
+        finally:
+            lib.ftk_fragstream_close(stream)
+
+    def load_all(self):
+        """Make every contig resident (whole-file operations)."""
+        if not self.lazy:
+            return
+        for c in self.contigs:
+            if c not in self.loaded:
+                self._load_one(c)
 
     def release(self):
         eng = get_engine()
@@ -136,6 +181,7 @@ def stream_source(input_file, workers: int | None = None, queued: int = 2):
     src = _SOURCES.get(ckey)
     if src is not None:
         _SOURCES.move_to_end(ckey)
+        src.load_all()
         for c in src.contigs:
             if c in src.loaded:
                 yield src, c
@@ -192,17 +238,69 @@ def stream_source(input_file, workers: int | None = None, queued: int = 2):
         old.release()
 
 
+def _lazy_source(path: str, is_bam: bool, workers) -> Optional[FragSource]:
+    """A lazily loaded source when the file's index is usable, else None."""
+    global _NEXT_ID
+    lib = L.load()
+    if is_bam:
+        index = path + ".bai" if os.path.exists(path + ".bai") else path[:-4] + ".bai"
+        try:
+            if os.path.getsize(index) < 8 or open(index, "rb").read(4) != b"BAI\x01":
+                return None
+        except OSError:
+            return None
+        stream = C.c_void_p()  # header only: a contig filter no header can contain
+        rc = lib.ftk_fragstream_open(path.encode(), b"\x01", 1, 1, 1, C.byref(stream))
+        if rc != L.FTK_OK:
+            return None
+        try:
+            n = lib.ftk_fragstream_n_refs(stream)
+            names = [lib.ftk_fragstream_ref_name(stream, i).decode() for i in range(n)]
+            lengths = {names[i]: lib.ftk_fragstream_ref_length(stream, i) for i in range(n)}
+            table = C.c_void_p()
+            rc = lib.ftk_fragstream_next(stream, C.byref(table))
+            if table.value:
+                lib.ftk_fragtable_free(table)
+        finally:
+            lib.ftk_fragstream_close(stream)
+        if rc != L.FTK_OK or not names:
+            return None
+        src = FragSource(path, True, False, names, lengths, _NEXT_ID, lazy=True, workers=workers)
+    else:
+        need, bed6 = C.c_int64(), C.c_int()
+        if lib.ftk_fragfile_index_contigs(path.encode(), None, 0, C.byref(need), C.byref(bed6)) != L.FTK_OK:
+            return None
+        buf = C.create_string_buffer(max(int(need.value), 1))
+        if lib.ftk_fragfile_index_contigs(path.encode(), buf, len(buf), C.byref(need), None) != L.FTK_OK:
+            return None
+        names = [n for n in buf.value.decode().split("\n") if n]
+        src = FragSource(path, False, bool(bed6.value), names, {n: None for n in names}, _NEXT_ID, lazy=True,
+                         workers=workers)
+    _NEXT_ID += 1
+    return src
+
+
 def open_source(input_file, workers: int | None = None, warn_bed6: bool = True) -> FragSource:
-    """Decode ``input_file`` (cached by path/mtime/size) and upload its contigs; decoding streams contig by
-    contig (``stream_source``), so the host never holds more than two contigs of the file."""
-    path, _ = _check_path(input_file)
+    """The (cached) source of ``input_file``.  With a usable index nothing is decoded yet (``FragSource``);
+    otherwise the file is decoded now, streaming contig by contig (``stream_source``), so the host never
+    holds more than two contigs of it.  ``FTK_LAZY_SOURCE=0`` forces the one-pass decode."""
+    path, is_bam = _check_path(input_file)
     st = os.stat(path)
     ckey = (os.path.abspath(path), st.st_mtime_ns, st.st_size)
     src = _SOURCES.get(ckey)
     if src is None:
-        for _ in stream_source(input_file, workers):
-            pass
-        src = _SOURCES[ckey]
+        get_engine()  # fails loudly without the HIP library / a GPU
+        if os.environ.get("FTK_LAZY_SOURCE", "1") != "0":
+            src = _lazy_source(path, is_bam, workers)
+        if src is not None:
+            _SOURCES[ckey] = src
+            while len(_SOURCES) > _MAX_SOURCES:
+                _, old = _SOURCES.popitem(last=False)
+                old.release()
+        else:
+            for _ in stream_source(input_file, workers):
+                pass
+            src = _SOURCES[ckey]
     else:
         _SOURCES.move_to_end(ckey)
     if src.bed6 and warn_bed6:

@@ -98,6 +98,7 @@ def _region_contigs(src, contig):
     semantics: ``contig=None`` iterates the whole file and pysam ignores
     start/stop (io/alignment.py:245,273-279)."""
     if contig is None:
+        src.load_all()
         return [c for c in src.contigs if c in src.loaded], True
     return [contig], False
 

@@ -143,6 +143,11 @@ int ftk_bam_decode(const char* path, const char* contig /* NULL = all */, int n_
  * ftk_fragtable_free.  Input must keep each contig's rows together (coordinate-sorted), else
  * FTK_ERR_UNSORTED.  BAM: ftk_fragstream_n_refs / _ref_name / _ref_length give the header's @SQ list
  * (they wait for the header). */
+/* Contigs of a tabix-indexed fragment file according to its .tbi (those holding rows, newline-separated,
+ * NUL-terminated; *needed_out = bytes required) and the layout of its first data row -- enough to open a
+ * file lazily and decode single contigs on demand (a single-contig ftk_fragstream_open seeks through the
+ * index).  FTK_ERR_FORMAT when there is no usable index (callers then decode the file in one pass). */
+int ftk_fragfile_index_contigs(const char* path, char* names_out, int64_t cap, int64_t* needed_out, int* is_bed6_out);
 typedef struct ftk_fragstream ftk_fragstream;
 int ftk_fragstream_open(const char* path, const char* contig /* NULL = all */, int is_bam, int n_threads,
                         int max_queued, ftk_fragstream** out);

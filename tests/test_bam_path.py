@@ -97,3 +97,41 @@ def test_bam_file_path_read1_semantics(tmp_path):
                   & (((by_file[:, 0] + by_file[:, 1]) // 2) >= a) & (((by_file[:, 0] + by_file[:, 1]) // 2) < b)]
     arr = frag_array(path, "chr2", 30, a, b)
     assert np.array_equal(arr["start"], sel[:, 0]) and np.array_equal(arr["stop"], sel[:, 1])
+
+
+@pytest.mark.gpu
+def test_lazy_sources_decode_only_what_is_asked_for(tmp_path, monkeypatch):
+    """Indexed inputs are opened lazily: a region query decodes one contig (through the index), whole-file
+    operations load the rest, and the results equal the one-pass decode (FTK_LAZY_SOURCE=0)."""
+    from finaletoolkit_amd import bgzf, frag, source
+    path, expected = _make(tmp_path)                      # BAM + real (minimal) BAI
+    rows = []
+    for k, size in enumerate((600_000, 250_000, 90_000)):
+        s, e, q, st = synth.synth_contig(size, depth=10.0, seed=70 + k)
+        rows.append((f"t{k}", s, e, q, st))
+    text = str(tmp_path / "lazy.frag.gz")
+    bgzf.write_frag_gz(text, rows, level=1, with_index=True)
+
+    def run():
+        out = [frag.single_coverage(path, "chr2", 10_000, 200_000).coverage,
+               frag.single_coverage(text, "t1", 0, None, quality_threshold=0).coverage]
+        loaded = (set(source.open_source(path).loaded), set(source.open_source(text).loaded))
+        out.append(frag.single_coverage(path, None, 0, None, quality_threshold=0).coverage)   # whole file
+        out.append(frag.single_coverage(text, None, 0, None, quality_threshold=0).coverage)
+        out.append(len(frag.frag_length(text, contig="t2", quality_threshold=10)))
+        with pytest.raises(ValueError):
+            frag.single_coverage(text, "nope", 0, 10)
+        return out, loaded
+
+    source.close_all()
+    lazy, loaded = run()
+    assert loaded == ({"chr2"}, {"t1"})
+    assert set(source.open_source(path).loaded) == {"chr1", "chrEmpty", "chr2"}
+    assert set(source.open_source(text).loaded) == {"t0", "t1", "t2"}
+    assert lazy[1] == len(rows[1][1]) and lazy[3] == sum(len(r[1]) for r in rows)
+    source.close_all()
+    monkeypatch.setenv("FTK_LAZY_SOURCE", "0")
+    eager, loaded = run()
+    assert loaded[0] == {"chr1", "chrEmpty", "chr2"} and loaded[1] == {"t0", "t1", "t2"}
+    assert eager == lazy
+    source.close_all()
