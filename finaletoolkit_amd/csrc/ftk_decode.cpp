@@ -1305,7 +1305,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
             return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
         const uint8_t* p = data.data();
         const size_t m = carry + total;
-        size_t off = pending_skip;
+        size_t off = std::min(pending_skip, m);  // (a damaged index may point past the block)
         pending_skip = 0;
         if (!header_done) {
             bool complete = false;
