@@ -275,6 +275,8 @@ def main():
         ev = 0
         work = None
         split = bool(os.environ.get("FTK_BENCH_SPLIT_ORDER"))  # experiment: all feature passes, then all WPS
+        if record_events:
+            eng.event_record(4000)  # start of the step: the first unit's feature pass begins here
         for phase in ((0, 1) if split else (2,)):
             for c in mine:
                 p = per[c]
@@ -376,10 +378,27 @@ def main():
     if world == 1 and not sim and not args.contigs and args.depth == 30.0 and os.path.exists(tpath):
         tj = json.load(open(tpath))  # measured per step (all WPS launches of one step), reported per launch
         traffic = int(tj["hbm_bytes_per_step"] / max(len(wps_ev), 1))
+    # second kernel of the step: the fused window-feature pass of a unit runs between the previous unit's WPS
+    # stop event and this unit's WPS start event (per-unit launch shape only)
+    feat = None
+    if not batched and wps_ev and not os.environ.get("FTK_BENCH_SPLIT_ORDER"):
+        f_ms, f_bytes, prev = 0.0, 0, 4000
+        for c in mine:
+            a, b = wps_ev[c]
+            f_ms += eng.event_elapsed_ms(prev, a)
+            f_bytes += 10 * per[c]["n"] + 8 * per[c]["nw"] + per[c]["nw"] * (4 * HIST_BINS + 8 * 4)
+            prev = b
+        feat = dict(kernel="feat_block_kernel", achieved=round(f_bytes / (f_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(f_bytes / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    algorithmic_bytes_per_launch=int(f_bytes / len(mine)), launches=len(mine),
+                    avg_launch_ms=round(f_ms / len(mine), 4),
+                    note="follows a WPS launch: reads behind that kernel's write-back")
     roofline = dict(bound="hbm", kernel="wps_stream_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     algorithmic_bytes_per_launch=int(wps_bytes / max(len(wps_ev), 1)),
                     launches=len(wps_ev), avg_launch_ms=round(wps_ms / max(len(wps_ev), 1), 4))
+    if feat:
+        roofline["second_kernel"] = feat
 
     # ---- size-independent checks on the full workload ---------------------------
     checks = {}
