@@ -399,6 +399,11 @@ def main():
                     launches=len(wps_ev), avg_launch_ms=round(wps_ms / max(len(wps_ev), 1), 4))
     if feat:
         roofline["second_kernel"] = feat
+    # the whole step against the same roof: algorithmic bytes of every launch of this rank / wall time per step
+    step_bytes = sum(2 * 10 * per[c]["n"] + 8 * (per[c]["b"] - per[c]["a"]) + 8 * per[c]["nw"]
+                     + per[c]["nw"] * (4 * HIST_BINS + 8 * 4) for c in mine)
+    roofline["whole_step"] = dict(algorithmic_bytes=int(step_bytes), achieved=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                                  unit="GB/s", frac=round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
 
     # ---- size-independent checks on the full workload ---------------------------
     checks = {}
