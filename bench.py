@@ -268,7 +268,31 @@ def main():
                     ev += 2
         exchange_finish(work)
 
+    # FTK_BENCH_FUSED=1 (experiment / BASELINE config 5 shape): ONE launch per whole-contig unit computes WPS and
+    # the window features together (ftk_wps_window_features), reading the fragment columns once.
+    fused = os.environ.get("FTK_BENCH_FUSED", "0") == "1" and all(per[c]["a"] == 0 and per[c]["b"] == per[c]["size"]
+                                                                   for c in mine)
+
+    def step_fused(record_events=False):
+        ev = 0
+        for c in mine:
+            p = per[c]
+            if record_events:
+                eng.event_record(ev)
+            eng._check(lib.ftk_wps_window_features(
+                eng.ctx, eng.contig_id(c), 0, p["size"], p["size"], WPS_W, WPS_MIN, WPS_MAX, MAPQ, L.ptr(p["wps"]), 0,
+                WINDOW, p["nw"], C.byref(flt), L.ptr(p["cov"]), 0, HIST_BINS, L.ptr(p["hist"]), L.ptr(p["over"]), MAPQ,
+                L.ptr(p["bl"][0]), L.ptr(p["bl"][1]), len(p["bl"][0]), C.byref(p["gaps_c"]), L.ptr(p["short"]),
+                L.ptr(p["long"])))
+            if record_events:
+                eng.event_record(ev + 1)
+                wps_ev[c] = (ev, ev + 1)
+                ev += 2
+        exchange_finish(exchange_start())
+
     def step(record_events=False):
+        if fused:
+            return step_fused(record_events)
         if batched:
             return step_batched(record_events)
         row = 0
@@ -381,7 +405,7 @@ def main():
     # second kernel of the step: the fused window-feature pass of a unit runs between the previous unit's WPS
     # stop event and this unit's WPS start event (per-unit launch shape only)
     feat = None
-    if not batched and wps_ev and not os.environ.get("FTK_BENCH_SPLIT_ORDER"):
+    if not batched and not fused and wps_ev and not os.environ.get("FTK_BENCH_SPLIT_ORDER"):
         f_ms, f_bytes, prev = 0.0, 0, 4000
         for c in mine:
             a, b = wps_ev[c]
@@ -446,7 +470,7 @@ def main():
                                     f"{halo} bp); all-gather of DELFI bin vector") if world > 1
                        else ("single GPU" if not sim else f"simulated rank {sim} alone")},
             "roofline": roofline, "cpu_baseline": cpu, "checks": checks, "load_s": round(t_load, 2),
-            "priming_steps": prime, "launches": ("1 batched feature launch + " + ("1 batched WPS launch" if batch_wps else "1 WPS launch per unit")
+            "priming_steps": prime, "launches": "fused WPS + features, 1 launch per unit" if fused else ("1 batched feature launch + " + ("1 batched WPS launch" if batch_wps else "1 WPS launch per unit")
                          + " per step") if batched else "per unit",
         }
     if use_dist:

@@ -48,7 +48,7 @@ EXPORTS = [
     "ftk_fragtable_contig_rows", "ftk_fragtable_columns", "ftk_fragtable_order", "ftk_fragtable_is_pinned", "ftk_fragtable_free",
     "ftk_frags_from_table",
     "ftk_window_counts", "ftk_delfi_counts", "ftk_fraglen_hist", "ftk_window_features",
-    "ftk_window_features_batch", "ftk_wps_batch", "ftk_frag_lengths",
+    "ftk_window_features_batch", "ftk_wps_batch", "ftk_wps_window_features", "ftk_frag_lengths",
     "ftk_frag_select",
     "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals", "ftk_wps_adjust",
     "ftk_comm_unique_id", "ftk_comm_create", "ftk_allgather_i64", "ftk_allreduce_sum_i64", "ftk_comm_destroy",
@@ -172,6 +172,8 @@ def load() -> C.CDLL:
     lib.ftk_window_features_batch.argtypes = [vp, C.POINTER(FeatureItem), i32, C.POINTER(Filter), vp, i32, i32, vp, vp, i32,
                                               vp, vp]
     lib.ftk_wps_batch.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
+    lib.ftk_wps_window_features.argtypes = [vp, C.c_int, i64, i64, i64, i32, i32, i32, i32, vp, i32, i32, i32,
+                                            C.POINTER(Filter), vp, i32, i32, vp, vp, i32, vp, vp, i64, C.POINTER(Gaps), vp, vp]
     lib.ftk_frag_lengths.argtypes = [vp, C.c_int, i32, i32, C.POINTER(Filter), vp, i64, C.POINTER(i64)]
     lib.ftk_frag_select.argtypes = [vp, C.c_int, i32, i32, C.POINTER(Filter), vp, vp, vp, vp, i64, C.POINTER(i64)]
     lib.ftk_wps.argtypes = [vp, C.c_int, i64, i64, i64, i32, i32, i32, i32, vp]

@@ -1120,6 +1120,109 @@ int ftk_wps_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start, cons
     return FTK_OK;
 }
 
+int ftk_wps_window_features(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t chrom_size,
+                            int32_t window_size, int32_t min_len, int32_t max_len, int32_t mapq_min, int64_t* wps_out,
+                            int32_t win_start, int32_t win_len, int32_t n_win, const ftk_filter* f, int64_t* count_out,
+                            int32_t len_lo, int32_t n_bins, uint32_t* hist_out, int64_t* overflow_out,
+                            int32_t delfi_mapq_min, const int32_t* bl_start, const int32_t* bl_end, int64_t n_bl,
+                            const ftk_gaps* gaps, int64_t* short_out, int64_t* long_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    ContigData* c;
+    int rc = get_contig(ctx, contig_id, &c);
+    if (rc) return rc;
+    WpsParams p{};
+    if ((rc = wps_params(ctx, *c, chrom_size, window_size, min_len, max_len, mapq_min, &p))) return rc;
+    const bool ch = count_out || hist_out, df = short_out || long_out;
+    if (!wps_out || (!ch && !df)) return fail(ctx, FTK_ERR_INVALID, "needs wps_out and at least one feature output");
+    if (c->v.r1_start) return fail(ctx, FTK_ERR_INVALID, "the fused pass takes tabix-style contigs (no read1 columns)");
+    if (ch && (!f || f->policy != FTK_POLICY_MIDPOINT || f->fetch_mode != FTK_FETCH_TABIX))
+        return fail(ctx, FTK_ERR_INVALID, "the fused pass needs a midpoint-policy, tabix-fetch filter");
+    if (df && (!short_out || !long_out)) return fail(ctx, FTK_ERR_INVALID, "NULL DELFI output pointer");
+    if (hist_out && (n_bins <= 0 || n_bins > 8192 || !overflow_out))
+        return fail(ctx, FTK_ERR_INVALID, "histogram needs n_bins in [1, 8192] and overflow_out");
+    if (n_win <= 0 || win_start < 0 || win_len < kWpsTile + c->max_len || (int64_t)win_start + (int64_t)n_win * win_len > (1LL << 31))
+        return fail(ctx, FTK_ERR_INVALID, "bins must be at least %d bp long (tile + longest fragment) and end below 2^31",
+                    kWpsTile + c->max_len);
+    if (start > 0 || stop < (int64_t)c->max_end || stop <= start)
+        return fail(ctx, FTK_ERR_INVALID, "the WPS interval must cover every fragment of the contig (start <= 0, stop >= %d)",
+                    c->max_end);
+    if (start < -(1LL << 30) || stop > (1LL << 31)) return fail(ctx, FTK_ERR_INVALID, "interval out of range");
+    if (n_bl < 0 || (n_bl > 0 && (!bl_start || !bl_end)) || is_device_ptr(bl_start))
+        return fail(ctx, FTK_ERR_INVALID, "bad blacklist arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    FusedParams F{};
+    F.win_start = win_start;
+    F.win_len = win_len;
+    F.n_win = n_win;
+    if (ch) {
+        F.ch_q = std::min(std::max(f->mapq_min, 0), 256);
+        F.ch_min = f->min_len < 0 ? 0 : std::min(f->min_len, 1 << 30);
+        F.ch_max = f->max_len < 0 ? (1 << 30) : std::min(f->max_len, 1 << 30);
+    }
+    F.do_cov = count_out != nullptr;
+    F.do_hist = hist_out != nullptr;
+    F.len_lo = len_lo;
+    F.n_bins = n_bins;
+    F.do_delfi = df;
+    F.df_q = std::min(std::max(delfi_mapq_min, 0), 256);
+    ftk_gaps g{};
+    if (gaps) g = *gaps;
+    if (g.has_gaps && (g.n_telo < 0 || g.n_telo > FTK_MAX_TELOMERES))
+        return fail(ctx, FTK_ERR_INVALID, "at most %d telomere intervals per contig are supported", FTK_MAX_TELOMERES);
+    int gc[4];
+    gap_constants(g, gc);
+    F.cen0 = gc[0]; F.cen1 = gc[1]; F.tel0 = gc[2]; F.tel1 = gc[3];
+    if (df && n_bl > 0) {  // per-bin blacklist CSR, cached like ftk_delfi_counts' (same key: the bins' arrays)
+        std::vector<int32_t> ws(n_win), we(n_win);
+        for (int k = 0; k < n_win; ++k) { ws[k] = win_start + k * win_len; we[k] = ws[k] + win_len; }
+        DelfiMeta* meta = nullptr;
+        if ((rc = get_delfi_meta(ctx, contig_id, ws.data(), we.data(), n_win, bl_start, bl_end, n_bl, &meta))) return rc;
+        if (meta->n_r) { F.bl_off = meta->d_off; F.bl_r0 = meta->d_r0; F.bl_pm = meta->d_pm; }
+    }
+    const int64_t n_pos = stop - start;
+    const bool w_dev = is_device_ptr(wps_out), c_dev = is_device_ptr(count_out), h_dev = is_device_ptr(hist_out),
+               o_dev = is_device_ptr(overflow_out), s_dev = is_device_ptr(short_out), l_dev = is_device_ptr(long_out);
+    const size_t hist_elems = hist_out ? (size_t)n_win * (size_t)n_bins : 0;
+    if ((rc = reserve_scratch(ctx, (w_dev ? 0 : align_up(n_pos * 8)) + 4 * align_up((size_t)n_win * 8) +
+                                       (h_dev ? 0 : align_up(hist_elems * 4)))))
+        return rc;
+    Arena a(ctx);
+    int64_t* d_wps = w_dev ? wps_out : a.take<int64_t>(n_pos);
+    F.cov_out = count_out ? (c_dev ? count_out : a.take<int64_t>(n_win)) : nullptr;
+    F.hist_out = hist_out ? (h_dev ? hist_out : a.take<uint32_t>(hist_elems)) : nullptr;
+    F.over_out = hist_out ? (o_dev ? overflow_out : a.take<int64_t>(n_win)) : nullptr;
+    F.short_out = df ? (s_dev ? short_out : a.take<int64_t>(n_win)) : nullptr;
+    F.long_out = df ? (l_dev ? long_out : a.take<int64_t>(n_win)) : nullptr;
+    // every feature output is accumulated with atomics: start from zero
+    if (F.cov_out) HIPCHK(ctx, hipMemsetAsync(F.cov_out, 0, (size_t)n_win * 8, ctx->stream));
+    if (F.hist_out) {
+        HIPCHK(ctx, hipMemsetAsync(F.hist_out, 0, hist_elems * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(F.over_out, 0, (size_t)n_win * 8, ctx->stream));
+    }
+    if (df) {
+        HIPCHK(ctx, hipMemsetAsync(F.short_out, 0, (size_t)n_win * 8, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(F.long_out, 0, (size_t)n_win * 8, ctx->stream));
+    }
+    p.start = start;
+    p.stop = stop;
+    launch_wps_fused(ctx->stream, c->v, p, (n_pos + kWpsTile - 1) / kWpsTile, F, d_wps);
+    HIPCHK(ctx, hipGetLastError());
+    bool host_out = false;
+    auto back = [&](void* dst, const void* src, size_t bytes, bool dev) -> hipError_t {
+        if (!dst || dev) return hipSuccess;
+        host_out = true;
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    };
+    HIPCHK(ctx, back(wps_out, d_wps, (size_t)n_pos * 8, w_dev));
+    HIPCHK(ctx, back(count_out, F.cov_out, (size_t)n_win * 8, c_dev));
+    HIPCHK(ctx, back(hist_out, F.hist_out, hist_elems * 4, h_dev));
+    HIPCHK(ctx, back(hist_out ? overflow_out : nullptr, F.over_out, (size_t)n_win * 8, o_dev));
+    HIPCHK(ctx, back(short_out, F.short_out, (size_t)n_win * 8, s_dev));
+    HIPCHK(ctx, back(long_out, F.long_out, (size_t)n_win * 8, l_dev));
+    if (host_out) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return FTK_OK;
+}
+
 int ftk_wps_batch(ftk_ctx* ctx, const int32_t* contig_ids, const int64_t* iv_start, const int64_t* iv_stop,
                   const int64_t* chrom_size, const int64_t* out_offset, int64_t n_iv, int32_t window_size,
                   int32_t min_len, int32_t max_len, int32_t mapq_min, int64_t* wps_out) {

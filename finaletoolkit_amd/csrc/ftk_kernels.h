@@ -102,6 +102,23 @@ void launch_add_i64(hipStream_t s, const int64_t* a, const int64_t* b, int64_t* 
 void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t n_tiles, const int64_t* iv_start,
                 const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv, const int32_t* tile_k,
                 int64_t* out);
+// Window features computed inside the WPS pass (regular bin tiling, midpoint policy).
+struct FusedParams {
+    int win_start, win_len, n_win;
+    int ch_q, ch_min, ch_max;
+    int do_cov, do_hist, len_lo, n_bins;
+    int do_delfi, df_q, cen0, cen1, tel0, tel1;
+    const int32_t* bl_off;
+    const int32_t* bl_r0;
+    const int32_t* bl_pm;
+    int64_t* cov_out;
+    uint32_t* hist_out;
+    int64_t* over_out;
+    int64_t* short_out;
+    int64_t* long_out;
+};
+void launch_wps_fused(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t n_tiles, const FusedParams& F,
+                      int64_t* out);
 // One (contig, interval) of a batched WPS launch.
 struct WpsItem {
     ContigView cv;

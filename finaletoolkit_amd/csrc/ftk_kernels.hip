@@ -770,14 +770,22 @@ constexpr int kWpsPrefetch = 4;  // fragments per thread held in registers for t
 
 // MULTI: a block walks several tiles and prefetches the next one's fragments.  BATCH: tiles of several
 // contigs in one launch (one tile per block; the kernel-argument view / limits are replaced by the item's).
-template <bool MULTI, bool BATCH>
+// FUSED: the tile's block also runs the window features (coverage, length histogram, DELFI) of every
+// fragment that STARTS in its tile against a regular bin tiling, so the whole-contig pass reads the
+// fragment columns once (BASELINE config 5: all features in a single pass).  A fragment's bin is the one
+// holding its midpoint: the bin of the tile's first base or the next one (bins are longer than a tile plus
+// the longest fragment), counted in LDS / registers for the first and with global atomics for the second.
+template <bool MULTI, bool BATCH, bool FUSED>
 __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParams p, const int64_t* iv_start_,
                                                          const int64_t* iv_stop_, const int64_t* out_off_,
                                                          const int32_t* tile_iv, const int32_t* tile_k,
                                                          long long n_tiles, int tiles_per_block,
                                                          int64_t* __restrict__ out,
-                                                         const WpsItem* __restrict__ items, int n_items) {
+                                                         const WpsItem* __restrict__ items, int n_items,
+                                                         FusedParams F) {
     constexpr int T = kWpsTile, NP = T / 1024, PF = kWpsPrefetch;
+    extern __shared__ uint32_t fhist[];  // FUSED with a histogram: n_bins + 1 counters of the tile's first bin
+    __shared__ int fcnt[4];              // FUSED: rejected (coverage, short, long) and processed fragments
     __shared__ __attribute__((aligned(16))) int d[T];
     __shared__ int pre_s[2];
     __shared__ int rng_s[2];
@@ -858,7 +866,67 @@ __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParam
         if (e < 0) atomicAdd(&pre_s[par], 1); else if (e < T) atomicAdd(&d[e], 1);
     };
 
+    // ---- FUSED: window features of the fragments that start in this tile -------------------------
+    int f_w0 = 0, f_b1 = 0;              // first bin of the tile, start of the next bin
+    int f_n = 0, f_cov = 0, f_sh = 0, f_lg = 0;  // processed / rejected counters of bin f_w0 (registers)
+    auto feature = [&](long long t0, int len_t, int i, int fs, int fe, int q) {
+        if ((long long)fs < t0 || (long long)fs >= t0 + len_t) return;  // another tile owns this fragment
+        const int len = fe - fs;
+        const int mid = (int)(((unsigned)fs + (unsigned)fe) >> 1);
+        const int w = f_w0 + (mid >= f_b1);
+        if (w < 0 || w >= F.n_win) return;
+        const int ws = F.win_start + w * F.win_len;  // mid is inside [ws, ws + win_len) by construction
+        const int t_lo = fe - 1 - ws;                 // fe > ws (fs < we follows from the midpoint)
+        const bool primary = w == f_w0;
+        if (F.do_cov | F.do_hist) {
+            const int x = (q - F.ch_q) | (len - F.ch_min) | (F.ch_max - len) | t_lo;
+            const unsigned bad = (unsigned)x >> 31;
+            if (primary) {
+                f_cov += bad;
+                if (F.do_hist) atomicAdd(&fhist[min((unsigned)(len - F.len_lo), (unsigned)F.n_bins)], bad ^ 1u);
+            } else if (!bad) {
+                if (F.do_cov) atomicAdd(reinterpret_cast<unsigned long long*>(F.cov_out + w), 1ull);
+                if (F.do_hist) {
+                    const unsigned b = (unsigned)(len - F.len_lo);
+                    if (b < (unsigned)F.n_bins) atomicAdd(F.hist_out + (size_t)w * F.n_bins + b, 1u);
+                    else atomicAdd(reinterpret_cast<unsigned long long*>(F.over_out + w), 1ull);
+                }
+            }
+        }
+        if (F.do_delfi) {
+            int y = (q - F.df_q) | (len - 100) | (220 - len) | t_lo;
+            y |= (F.cen0 - fe) & (fs - F.cen1);
+            y |= (F.tel0 - fe) & (fs - F.tel1);
+            if (F.bl_off && y >= 0) {
+                const int o0 = F.bl_off[w], o1 = F.bl_off[w + 1];
+                if (o1 > o0) {
+                    int lo2 = o0, hi2 = o1;
+                    while (lo2 < hi2) {
+                        const int m = (lo2 + hi2) >> 1;
+                        if (F.bl_r0[m] <= fs) lo2 = m + 1; else hi2 = m;
+                    }
+                    if (lo2 > o0 && F.bl_pm[lo2 - 1] > fe) y = -1;
+                }
+            }
+            const unsigned sb = (unsigned)(y | (150 - len)) >> 31, lb = (unsigned)(y | (len - 151)) >> 31;
+            if (primary) { f_sh += sb; f_lg += lb; }
+            else {
+                if (!sb) atomicAdd(reinterpret_cast<unsigned long long*>(F.short_out + w), 1ull);
+                if (!lb) atomicAdd(reinterpret_cast<unsigned long long*>(F.long_out + w), 1ull);
+            }
+        }
+        if (primary) f_n += 1;
+    };
+
     WpsTile cur = tile_info(tfirst);
+    if (FUSED) {
+        const long long rel = cur.t0 - (long long)F.win_start;
+        f_w0 = rel >= 0 ? (int)(rel / F.win_len) : -1;
+        f_b1 = F.win_start + (f_w0 + 1) * F.win_len;
+        if (F.do_hist)
+            for (int b = tid; b <= F.n_bins; b += 256) fhist[b] = 0;
+        if (tid < 4) fcnt[tid] = 0;
+    }
     if (tid < 2) rng_s[tid] = cand_bound(cur, tid);
     if (tid == 2) { pre_s[0] = 0; pre_s[1] = 0; }
     {
@@ -893,10 +961,36 @@ __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParam
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             const int i = lo + tid + 256 * k;
-            if (i < hi) apply(cur, par, i, pfs[k], pfe[k], pfq[k]);
+            if (i < hi) {
+                apply(cur, par, i, pfs[k], pfe[k], pfq[k]);
+                if (FUSED) feature(cur.t0, cur.len_t, i, pfs[k], pfe[k], pfq[k]);
+            }
         }
-        for (int i = lo + PF * 256 + tid; i < hi; i += 256) apply(cur, par, i, cv.start[i], cv.end[i], cv.mapq[i]);
+        for (int i = lo + PF * 256 + tid; i < hi; i += 256) {
+            const int fs = cv.start[i], fe = cv.end[i], q = cv.mapq[i];
+            apply(cur, par, i, fs, fe, q);
+            if (FUSED) feature(cur.t0, cur.len_t, i, fs, fe, q);
+        }
+        if (FUSED) {  // counters of the tile's first bin: one LDS atomic per wave and counter
+            const int a0 = wave_reduce_add(f_cov), a1 = wave_reduce_add(f_sh), a2 = wave_reduce_add(f_lg),
+                      a3 = wave_reduce_add(f_n);
+            if (lane == 0) { atomicAdd(&fcnt[0], a0); atomicAdd(&fcnt[1], a1); atomicAdd(&fcnt[2], a2); atomicAdd(&fcnt[3], a3); }
+        }
         __syncthreads();
+        if (FUSED && f_w0 >= 0 && f_w0 < F.n_win) {  // hand the first bin's partial results over (fire and forget)
+            typedef unsigned long long ull;
+            if (F.do_hist) {
+                uint32_t* dst = F.hist_out + (size_t)f_w0 * F.n_bins;
+                for (int b = tid; b < F.n_bins; b += 256) {
+                    const uint32_t v = fhist[b];
+                    if (v) atomicAdd(&dst[b], v);
+                }
+                if (tid == 0 && fhist[F.n_bins]) atomicAdd(reinterpret_cast<ull*>(F.over_out + f_w0), (ull)fhist[F.n_bins]);
+            }
+            if (tid == 1 && F.do_cov && fcnt[3] - fcnt[0]) atomicAdd(reinterpret_cast<ull*>(F.cov_out + f_w0), (ull)(fcnt[3] - fcnt[0]));
+            if (tid == 2 && F.do_delfi && fcnt[3] - fcnt[1]) atomicAdd(reinterpret_cast<ull*>(F.short_out + f_w0), (ull)(fcnt[3] - fcnt[1]));
+            if (tid == 3 && F.do_delfi && fcnt[3] - fcnt[2]) atomicAdd(reinterpret_cast<ull*>(F.long_out + f_w0), (ull)(fcnt[3] - fcnt[2]));
+        }
         // ---- read the difference array (and clear it for the next tile), scan ---------
         int2 va[NP], vb[NP];
         int exa[NP], exb[NP];
@@ -1377,11 +1471,22 @@ void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t
     const long long tpb = tpb_env > 0 ? tpb_env : 1;
     const long long grid = (n_tiles + tpb - 1) / tpb;
     if (tpb == 1)
-        hipLaunchKernelGGL((wps_stream_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop,
-                           out_off, tile_iv, tile_k, (long long)n_tiles, (int)tpb, out, (const WpsItem*)nullptr, 0);
+        hipLaunchKernelGGL((wps_stream_kernel<false, false, false>), dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop,
+                           out_off, tile_iv, tile_k, (long long)n_tiles, (int)tpb, out, (const WpsItem*)nullptr, 0, FusedParams{});
     else
-        hipLaunchKernelGGL((wps_stream_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop,
-                           out_off, tile_iv, tile_k, (long long)n_tiles, (int)tpb, out, (const WpsItem*)nullptr, 0);
+        hipLaunchKernelGGL((wps_stream_kernel<true, false, false>), dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop,
+                           out_off, tile_iv, tile_k, (long long)n_tiles, (int)tpb, out, (const WpsItem*)nullptr, 0, FusedParams{});
+}
+
+// Whole-interval WPS with the window features of a regular bin tiling in the same pass.
+void launch_wps_fused(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t n_tiles, const FusedParams& F,
+                      int64_t* out) {
+    if (n_tiles <= 0) return;
+    const size_t lds = F.do_hist ? (size_t)(F.n_bins + 1) * 4 : 0;
+    hipLaunchKernelGGL((wps_stream_kernel<false, false, true>), dim3((unsigned)n_tiles), dim3(256), lds, s, cv, p,
+                       (const int64_t*)nullptr, (const int64_t*)nullptr, (const int64_t*)nullptr,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, (long long)n_tiles, 1, out,
+                       (const WpsItem*)nullptr, 0, F);
 }
 
 // Several (contig, interval) items in one launch, one 4096-base tile per block.
@@ -1389,9 +1494,9 @@ void launch_wps_batch(hipStream_t s, const WpsParams& p, const WpsItem* d_items,
                       int64_t* out) {
     if (n_tiles <= 0) return;
     ContigView none{};
-    hipLaunchKernelGGL((wps_stream_kernel<false, true>), dim3((unsigned)n_tiles), dim3(256), 0, s, none, p,
+    hipLaunchKernelGGL((wps_stream_kernel<false, true, false>), dim3((unsigned)n_tiles), dim3(256), 0, s, none, p,
                        (const int64_t*)nullptr, (const int64_t*)nullptr, (const int64_t*)nullptr,
-                       (const int32_t*)nullptr, (const int32_t*)nullptr, (long long)n_tiles, 1, out, d_items, n_items);
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, (long long)n_tiles, 1, out, d_items, n_items, FusedParams{});
 }
 
 void launch_cleavage(hipStream_t s, const ContigView& cv, const CleaveParams& p, int64_t n_tiles,

@@ -290,6 +290,32 @@ class Engine:
             self.ctx, batch["arr"], batch["n"], C.byref(batch["filter"]), L.ptr(coverage), int(len_lo), int(n_bins),
             L.ptr(hist), L.ptr(overflow), int(delfi_q), L.ptr(short), L.ptr(long)))
 
+    def wps_window_features(self, name: str, chrom_size: int, win_start: int, win_len: int, n_win: int,
+                            window_size=120, min_length=120, max_length=180, quality_threshold=30, wps_out=None,
+                            feat_quality=30, feat_min_length=None, feat_max_length=None, coverage=None, hist=None,
+                            hist_bins=None, overflow=None, delfi_q=30, bl_start=None, bl_end=None, gaps=None,
+                            short=None, long=None):
+        """Whole-contig WPS and the window features of the regular tiling ``[win_start + k*win_len, ...)`` in ONE
+        pass (``ftk_wps_window_features``).  Outputs: numpy arrays or device pointers; returns ``wps_out``
+        (allocated on the host when None)."""
+        if wps_out is None:
+            wps_out = np.zeros(int(chrom_size), np.int64)
+        f = L.make_filter(feat_quality, feat_min_length, feat_max_length, "midpoint")
+        len_lo, n_bins = hist_bins if hist_bins is not None else (0, 0)
+        bs = be = None
+        n_bl = 0
+        if bl_start is not None and len(bl_start):
+            bs = np.ascontiguousarray(bl_start, dtype=np.int32)
+            be = np.ascontiguousarray(bl_end, dtype=np.int32)
+            n_bl = len(bs)
+        g = L.make_gaps(gaps)
+        self._check(self.lib.ftk_wps_window_features(
+            self.ctx, self.contig_id(name), 0, int(chrom_size), int(chrom_size), int(window_size), int(min_length),
+            int(max_length), int(quality_threshold), L.ptr(wps_out), int(win_start), int(win_len), int(n_win),
+            C.byref(f), L.ptr(coverage), int(len_lo), int(n_bins), L.ptr(hist), L.ptr(overflow), int(delfi_q),
+            L.ptr(bs), L.ptr(be), n_bl, C.byref(g), L.ptr(short), L.ptr(long)))
+        return wps_out
+
     def wps_batch(self, names, starts, stops, chrom_sizes, out_offsets, out, window_size=120, min_length=120,
                   max_length=180, quality_threshold=30):
         """WPS of several (contig, interval) pairs in one launch into the device buffer ``out``."""

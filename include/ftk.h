@@ -277,6 +277,20 @@ int ftk_wps_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start, cons
                       const int64_t* out_offset, int64_t chrom_size, int32_t window_size, int32_t min_len,
                       int32_t max_len, int32_t mapq_min, int64_t* wps_out);
 
+/* WPS of a whole contig AND the window features of a regular bin tiling in ONE pass over the fragments
+ * (BASELINE config 5: coverage + WPS + length histogram + DELFI fused): bin k = [win_start + k * win_len,
+ * win_start + (k + 1) * win_len), k < n_win, midpoint policy, tabix fetch semantics.  The block that scores
+ * a 4096-base tile also classifies the fragments starting in it, so [start, stop) must cover every
+ * fragment start of the contig (start <= 0, stop > last start) and win_len must be at least 4096 + the
+ * longest fragment.  Outputs as in ftk_wps / ftk_window_features (NULL switches a feature off; results are
+ * identical to the separate calls). */
+int ftk_wps_window_features(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t chrom_size,
+                            int32_t window_size, int32_t min_len, int32_t max_len, int32_t mapq_min, int64_t* wps_out,
+                            int32_t win_start, int32_t win_len, int32_t n_win, const ftk_filter* f, int64_t* count_out,
+                            int32_t len_lo, int32_t n_bins, uint32_t* hist_out, int64_t* overflow_out,
+                            int32_t delfi_mapq_min, const int32_t* bl_start, const int32_t* bl_end, int64_t n_bl,
+                            const ftk_gaps* gaps, int64_t* short_out, int64_t* long_out);
+
 /* Intervals of SEVERAL contigs in one launch: interval i is [iv_start[i], iv_stop[i]) of contig
  * contig_ids[i] (length chrom_size[i]) and writes its scores at wps_out + out_offset[i].  All arrays
  * except wps_out (host or device) are host arrays of n_iv entries (n_iv <= 64: whole contigs or large ranges). */

@@ -468,3 +468,46 @@ def test_c_abi_collectives_single_rank(engine):
         assert lib.ftk_comm_create(engine.ctx, 3, 2, uid, C.byref(C.c_void_p())) == L.FTK_ERR_INVALID
     finally:
         lib.ftk_comm_destroy(comm)
+
+
+@pytest.mark.parametrize("win_len", [100_000, 5_200, 250_001])
+def test_fused_wps_and_window_features_equal_separate_calls(engine, data, win_len):
+    """ftk_wps_window_features (one pass) == ftk_wps + ftk_window_features, for bin lengths from just above
+    the minimum (tile + longest fragment) to odd sizes, with blacklist and gaps."""
+    rng = np.random.default_rng(win_len)
+    n_win = -(-CONTIG_LEN // win_len)
+    ws = (np.arange(n_win, dtype=np.int64) * win_len).astype(np.int32)
+    we = (ws.astype(np.int64) + win_len).astype(np.int32)
+    bl_s = np.sort(rng.integers(0, CONTIG_LEN - 5000, 120)).astype(np.int32)
+    bl_e = (bl_s + rng.integers(100, 4000, 120)).astype(np.int32)
+    gaps = (1_200_000, 1_500_000, [(0, 10_000), (CONTIG_LEN - 10_000, CONTIG_LEN)])
+    want = engine.window_features("synA", ws, we, 25, 50, 700, hist=(20, 640),
+                                  delfi=dict(quality_threshold=30, bl_start=bl_s, bl_end=bl_e, gaps=gaps))
+    want_wps = engine.wps("synA", 0, CONTIG_LEN, CONTIG_LEN)
+    cov, over = np.zeros(n_win, np.int64), np.zeros(n_win, np.int64)
+    hist = np.zeros((n_win, 640), np.uint32)
+    sh, lg = np.zeros(n_win, np.int64), np.zeros(n_win, np.int64)
+    got_wps = engine.wps_window_features("synA", CONTIG_LEN, 0, win_len, n_win, feat_quality=25, feat_min_length=50,
+                                         feat_max_length=700, coverage=cov, hist=hist, hist_bins=(20, 640),
+                                         overflow=over, delfi_q=30, bl_start=bl_s, bl_end=bl_e, gaps=gaps, short=sh,
+                                         long=lg)
+    assert np.array_equal(got_wps, want_wps)
+    for key, got in (("coverage", cov), ("hist", hist), ("overflow", over), ("short", sh), ("long", lg)):
+        assert np.array_equal(got, want[key]), (key, win_len)
+    # coverage only / DELFI only
+    cov2 = np.zeros(n_win, np.int64)
+    engine.wps_window_features("synA", CONTIG_LEN, 0, win_len, n_win, feat_quality=25, feat_min_length=50,
+                               feat_max_length=700, coverage=cov2)
+    assert np.array_equal(cov2, cov)
+    sh2, lg2 = np.zeros(n_win, np.int64), np.zeros(n_win, np.int64)
+    engine.wps_window_features("synA", CONTIG_LEN, 0, win_len, n_win, delfi_q=30, bl_start=bl_s, bl_end=bl_e,
+                               gaps=gaps, short=sh2, long=lg2)
+    assert np.array_equal(sh2, sh) and np.array_equal(lg2, lg)
+    # bins that start inside the contig and stop before its end: the rest of the contig is ignored
+    sub = np.zeros(5, np.int64)
+    engine.wps_window_features("synA", CONTIG_LEN, win_len, win_len, 5, feat_quality=25, feat_min_length=50,
+                               feat_max_length=700, coverage=sub)
+    assert np.array_equal(sub, cov[1:6])
+    from finaletoolkit_amd import _lib as L
+    with pytest.raises(L.FtkError):  # bins shorter than tile + longest fragment
+        engine.wps_window_features("synA", CONTIG_LEN, 0, 4_000, 10, coverage=np.zeros(10, np.int64))
