@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libftk_hip.so")
+LIB_PATH = os.environ.get("FTK_LIB") or os.path.join(_HERE, "libftk_hip.so")  # FTK_LIB: experiments with alternative builds
 CSRC = os.path.join(_HERE, "csrc")
 
 FTK_OK = 0

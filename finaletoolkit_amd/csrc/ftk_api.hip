@@ -732,6 +732,12 @@ int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const i
     // blocks per CU of the chunk walker: 8 are resident, 32 give shorter per-block chunk ranges and a
     // smoother tail (measured best of 2..256 on the whole-genome bench); FTK_FEAT_BPC for experiments
     static const int bpc = getenv("FTK_FEAT_BPC") ? atoi(getenv("FTK_FEAT_BPC")) : 32;
+    if (block_path && c->max_end > 0) {  // expected candidates per window from the contig's mean density
+        double span = 0;
+        for (int64_t i = 0; i < n_win; ++i) span += std::max(0.0, (double)w_end[i] - (double)w_start[i]);
+        const double est = (double)c->n / (double)c->max_end * (span / (double)n_win + lmax);
+        r.block_threads = est >= 4096.0 ? 512 : 256;
+    }
     launch_window_features(ctx->stream, ctx->n_cu * bpc, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, r, small_path,
                            block_path ? lmax : -1);
     if (d_nfrag) launch_add_i64(ctx->stream, r.short_out, r.long_out, d_nfrag, (int)n_win);

@@ -76,6 +76,7 @@ struct FeatureRequest {
     const int32_t* bl_pm = nullptr;
     // motif histogram instead of the length histogram (hist_out = [n_win][4^k], over_out = errors)
     const MotifParams* motif = nullptr;
+    int block_threads = 256;  // block-per-window path: 512 for windows of several thousand candidates
 };
 // One contig's share of a batched window-feature launch (device pointers).
 struct FeatItem {

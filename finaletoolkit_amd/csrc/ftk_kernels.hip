@@ -597,11 +597,14 @@ __global__ __launch_bounds__(256) void feat_large_kernel(ContigView cv, const in
     }
 }
 
-// The whole candidate range [lo, hi) of a window as a software pipeline of 1024-fragment slabs
-// (256 threads x 4 fragments): four slabs are requested up front and each slab's registers are
+// Threads per block of the block-per-window kernels: a template parameter.  512 threads keep twice the
+// fragments in flight per window, which pays once a window holds several thousand candidates (43 -> 40 us per
+// contig in the whole-genome bench; 128 / 64 threads: 62 / 91 us, 1024: 51 us); 256 for smaller windows.
+// The whole candidate range [lo, hi) of a window as a software pipeline of slabs of 4 * kFeatBS fragments
+// (one 16-byte load per column and thread): four slabs are requested up front and each slab's registers are
 // re-filled with the slab four ahead as soon as it has been consumed, so three to four 16-byte
 // loads per column stay in flight behind the arithmetic for the whole range.
-template <int CH, bool DF, bool BAM, bool BL>
+template <int kFeatBS, int CH, bool DF, bool BAM, bool BL>
 __device__ __forceinline__ void feat_stream(const ContigView& cv, const FeatParams& P, int lo, int hi, int tid, int ws,
                                             int we1, int o0, int o1, uint32_t* h, FeatAcc& a) {
     int4 s4[4], e4[4];
@@ -609,21 +612,21 @@ __device__ __forceinline__ void feat_stream(const ContigView& cv, const FeatPara
     const int i0 = lo + 4 * tid;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * 1024;
+        const int i = i0 + u * (4 * kFeatBS);
         if (i < hi) {
             s4[u] = *reinterpret_cast<const int4*>(cv.start + i);
             e4[u] = *reinterpret_cast<const int4*>(cv.end + i);
             q4[u] = *reinterpret_cast<const uchar4*>(cv.mapq + i);
         }
     }
-    for (int base = i0; base < hi; base += 4096) {
+    for (int base = i0; base < hi; base += 16 * kFeatBS) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = base + u * 1024;
+            const int i = base + u * (4 * kFeatBS);
             if (i < hi) {
                 const int4 s = s4[u], e = e4[u];
                 const uchar4 q = q4[u];
-                const int nxt = i + 4096;
+                const int nxt = i + 16 * kFeatBS;
                 if (nxt < hi) {
                     s4[u] = *reinterpret_cast<const int4*>(cv.start + nxt);
                     e4[u] = *reinterpret_cast<const int4*>(cv.end + nxt);
@@ -641,28 +644,28 @@ __device__ __forceinline__ void feat_stream(const ContigView& cv, const FeatPara
 // the 512-bp index itself, walks it in 4096-fragment chunks and OWNS the window's outputs -- plain
 // stores, nothing to zero beforehand, no atomics.  One launch per call instead of three.
 // ---------------------------------------------------------------------------
-template <int CH, bool DF, bool BAM>
+template <int kFeatBS, int CH, bool DF, bool BAM>
 __device__ __forceinline__ void feat_block_body(const ContigView& cv, int ws_raw, int we_raw, int lmax,
                                                 const FeatParams& P, int o0, int o1, size_t row,
-                                                uint32_t* lds_hist, int (*red)[4]) {
+                                                uint32_t* lds_hist, int (*red)[kFeatBS / 64]) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool hist = CH && P.do_hist;
     int lo, hi;
     uint32_t nc;
     window_candidates(cv, ws_raw, we_raw, lmax, -1, lo, hi, nc);
     if (hist) {
-        for (int b = tid; b <= P.n_bins; b += 256) lds_hist[b] = 0;
+        for (int b = tid; b <= P.n_bins; b += kFeatBS) lds_hist[b] = 0;
         __syncthreads();
     }
     int ws, we1;
     window_bounds<CH>(ws_raw, we_raw, ws, we1);
     FeatAcc a;
-    if (DF && o1 > o0) feat_stream<CH, DF, BAM, true>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
-    else feat_stream<CH, DF, BAM, false>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
+    if (DF && o1 > o0) feat_stream<kFeatBS, CH, DF, BAM, true>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
+    else feat_stream<kFeatBS, CH, DF, BAM, false>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
     if (hist) {
         __syncthreads();
         uint32_t* dst = P.hist_out + row * P.n_bins;
-        for (int b = tid; b < P.n_bins; b += 256) dst[b] = lds_hist[b];
+        for (int b = tid; b < P.n_bins; b += kFeatBS) dst[b] = lds_hist[b];
     }
     a.n = wave_reduce_add(a.n);
     a.cov = wave_reduce_add(a.cov);
@@ -672,8 +675,9 @@ __device__ __forceinline__ void feat_block_body(const ContigView& cv, int ws_raw
     if (lane == 0) { red[0][wv] = a.cov; red[1][wv] = a.over; red[2][wv] = a.sh; red[3][wv] = a.lg; red[4][wv] = a.n; }
     __syncthreads();
     if (tid < 4) {
-        int t = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
-        const int n = red[4][0] + red[4][1] + red[4][2] + red[4][3];
+        int t = 0, n = 0;
+#pragma unroll
+        for (int k = 0; k < kFeatBS / 64; ++k) { t += red[tid][k]; n += red[4][k]; }
         if (tid == 1 && CH == 1 && hist) t = (int)lds_hist[P.n_bins];
         else if (tid != 1 && (CH == 1 || tid >= 2)) t = n - t;  // rejected -> passing
         int64_t* dst = tid == 0 ? (CH && P.do_cov ? P.cov_out : nullptr)
@@ -683,25 +687,25 @@ __device__ __forceinline__ void feat_block_body(const ContigView& cv, int ws_raw
     }
 }
 
-template <int CH, bool DF, bool BAM>
-__global__ __launch_bounds__(256) void feat_block_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
+template <int kFeatBS, int CH, bool DF, bool BAM>
+__global__ __launch_bounds__(kFeatBS) void feat_block_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
                                                          int n_win, int lmax, FeatParams P) {
     extern __shared__ uint32_t lds_hist[];
-    __shared__ int red[5][4];
+    __shared__ int red[5][kFeatBS / 64];
     const int w = blockIdx.x;
     int o0 = 0, o1 = 0;
     if (DF && P.dp.bl_off) { o0 = P.dp.bl_off[w]; o1 = P.dp.bl_off[w + 1]; }
-    feat_block_body<CH, DF, BAM>(cv, ws_[w], we_[w], lmax, P, o0, o1, (size_t)w, lds_hist, red);
+    feat_block_body<kFeatBS, CH, DF, BAM>(cv, ws_[w], we_[w], lmax, P, o0, o1, (size_t)w, lds_hist, red);
 }
 
 // The same for the windows of SEVERAL contigs in one launch (ftk_window_features_batch): block b owns
 // window b of the concatenated list; its item (contig view, windows, blacklist CSR, gap constants) is
 // found by bisection on the items' first rows; outputs are indexed by the global row.
-template <int CH, bool DF, bool BAM>
-__global__ __launch_bounds__(256) void feat_batch_kernel(const FeatItem* __restrict__ items, int n_items,
+template <int kFeatBS, int CH, bool DF, bool BAM>
+__global__ __launch_bounds__(kFeatBS) void feat_batch_kernel(const FeatItem* __restrict__ items, int n_items,
                                                          FeatParams P) {
     extern __shared__ uint32_t lds_hist[];
-    __shared__ int red[5][4];
+    __shared__ int red[5][kFeatBS / 64];
     const int gw = blockIdx.x;
     int it = 0;
     {
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(256) void feat_batch_kernel(const FeatItem* __restr
     int o0 = 0, o1 = 0;
     if (DF && I.bl_off) { o0 = I.bl_off[w]; o1 = I.bl_off[w + 1]; }
     const ContigView cv = I.cv;
-    feat_block_body<CH, DF, BAM>(cv, I.ws[w], I.we[w], I.lmax, Q, o0, o1, (size_t)gw, lds_hist, red);
+    feat_block_body<kFeatBS, CH, DF, BAM>(cv, I.ws[w], I.we[w], I.lmax, Q, o0, o1, (size_t)gw, lds_hist, red);
 }
 
 // ---------------------------------------------------------------------------
@@ -1344,11 +1348,16 @@ static WinPred make_win_pred(const ftk_filter& f) {
 
 template <int CH, bool DF, bool BAM>
 static void launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
-                          int n_win, const WindowPlan& pl, const FeatParams& P, bool small_path, int block_lmax) {
+                          int n_win, const WindowPlan& pl, const FeatParams& P, bool small_path, int block_lmax,
+                          int block_threads) {
     const size_t lds1 = (CH && P.do_hist) ? (size_t)(P.n_bins + 1) * sizeof(uint32_t) : 0;  // + overflow bin
     if (block_lmax >= 0) {
-        hipLaunchKernelGGL((feat_block_kernel<CH, DF, BAM>), dim3(n_win), dim3(256), lds1, s, cv, ws, we, n_win,
-                           block_lmax, P);
+        if (block_threads >= 512)
+            hipLaunchKernelGGL((feat_block_kernel<512, CH, DF, BAM>), dim3(n_win), dim3(512), lds1, s, cv, ws, we, n_win,
+                               block_lmax, P);
+        else
+            hipLaunchKernelGGL((feat_block_kernel<256, CH, DF, BAM>), dim3(n_win), dim3(256), lds1, s, cv, ws, we, n_win,
+                               block_lmax, P);
         return;
     }
     if (small_path)
@@ -1393,8 +1402,8 @@ void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv,
     const bool bam = cv.r1_start != nullptr && (!r.filter || r.filter->fetch_mode == FTK_FETCH_BAM_READ1);
 #define FTK_FEAT(CH, DF)                                                                              \
     do {                                                                                              \
-        if (bam) launch_feat_t<CH, DF, true>(s, grid_large, cv, ws, we, n_win, pl, P, small_path, block_lmax);  \
-        else launch_feat_t<CH, DF, false>(s, grid_large, cv, ws, we, n_win, pl, P, small_path, block_lmax);     \
+        if (bam) launch_feat_t<CH, DF, true>(s, grid_large, cv, ws, we, n_win, pl, P, small_path, block_lmax, r.block_threads);  \
+        else launch_feat_t<CH, DF, false>(s, grid_large, cv, ws, we, n_win, pl, P, small_path, block_lmax, r.block_threads);     \
     } while (0)
     if (r.motif) {
         P.mp = *r.motif;
@@ -1450,9 +1459,9 @@ void launch_window_features_batch(hipStream_t s, const FeatItem* d_items, int n_
     const size_t lds1 = P.do_hist ? (size_t)(P.n_bins + 1) * sizeof(uint32_t) : 0;
 #define FTK_FEATB(CH, DF)                                                                                           \
     do {                                                                                                            \
-        if (bam) hipLaunchKernelGGL((feat_batch_kernel<CH, DF, true>), dim3(total_win), dim3(256), lds1, s, d_items, \
+        if (bam) hipLaunchKernelGGL((feat_batch_kernel<512, CH, DF, true>), dim3(total_win), dim3(512), lds1, s, d_items, \
                                     n_items, P);                                                                    \
-        else hipLaunchKernelGGL((feat_batch_kernel<CH, DF, false>), dim3(total_win), dim3(256), lds1, s, d_items,   \
+        else hipLaunchKernelGGL((feat_batch_kernel<512, CH, DF, false>), dim3(total_win), dim3(512), lds1, s, d_items,   \
                                 n_items, P);                                                                        \
     } while (0)
     if (ch && df) FTK_FEATB(1, true);
