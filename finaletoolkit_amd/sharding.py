@@ -25,27 +25,31 @@ def lpt_assign(weights: Dict[str, float], n_ranks: int) -> Dict[str, int]:
     return owner
 
 
-def split_units(sizes: Dict[str, int], n_ranks: int, window: int):
+def split_units(sizes: Dict[str, int], n_ranks: int, window: int, unit_overhead_windows: int = 50):
     """Work units of every rank: the genome (contigs in the given order, laid end to end) is cut into
-    ``n_ranks`` runs of equal length at window boundaries, so a rank owns whole contigs plus at most
-    two partial ones (whole-contig LPT caps 8 GPUs at 0.96 of ideal on b37: chr1 alone is 8 % of the
-    genome).  Returns ``[(rank, contig, start, stop), ...]`` in genome order; ``start`` is a multiple
-    of ``window``.  A unit needs the contig's fragments starting in ``[start - halo, stop + halo)``
-    (``unit_halo``) and produces exactly the windows / bases of its own range: units never exchange
-    data."""
-    units = []
+    ``n_ranks`` runs of equal COST at window boundaries, so a rank owns whole contigs plus at most two
+    partial ones (whole-contig LPT caps 8 GPUs at 0.96 of ideal on b37: chr1 alone is 8 % of the
+    genome).  Cost = windows + ``unit_overhead_windows`` per contig: every unit pays launch ramps and
+    tails worth about 5 Mb of streaming (measured on simulated ranks: a rank of six small contigs ran
+    6 % longer than one of two large ones with equal bases).  Returns ``[(rank, contig, start, stop),
+    ...]`` in genome order; ``start`` is a multiple of ``window``.  A unit needs the contig's fragments
+    starting in ``[start - halo, stop + halo)`` (``unit_halo``) and produces exactly the windows / bases
+    of its own range: units never exchange data."""
     if n_ranks <= 1:
         return [(0, c, 0, int(n)) for c, n in sizes.items()]
     n_win = {c: -(-int(n) // window) for c, n in sizes.items()}
-    total = sum(n_win.values())
-    done = 0  # windows before the current contig
+    ov = max(0, int(unit_overhead_windows))
+    total = sum(n_win.values()) + ov * len(n_win)
+    units = []
+    done = 0.0  # cost before the current contig
     for c, n in sizes.items():
+        done += ov  # the contig's fixed cost sits in front of its first window
         w0 = 0
         while w0 < n_win[c]:
-            r = min(n_ranks - 1, (done + w0) * n_ranks // total)
-            # first window (genome-wide index) that belongs to the next rank
-            nxt = -(-(r + 1) * total // n_ranks) if r + 1 < n_ranks else total
-            w1 = min(n_win[c], max(w0 + 1, nxt - done))
+            r = min(n_ranks - 1, int((done + w0) * n_ranks // total))
+            # first window of this contig whose cost position belongs to the next rank
+            nxt = -(-(r + 1) * total // n_ranks) if r + 1 < n_ranks else total + n_win[c]
+            w1 = min(n_win[c], max(w0 + 1, int(nxt - done)))
             units.append((r, c, w0 * window, min(w1 * window, int(n))))
             w0 = w1
         done += n_win[c]

@@ -181,7 +181,15 @@ def test_split_units_partition_and_balance():
             assert v[0][0] == 0 and v[-1][1] == sizes[c]
             assert all(v[i][1] == v[i + 1][0] for i in range(len(v) - 1))
         assert [u[0] for u in units] == sorted(u[0] for u in units)  # ranks own contiguous runs
+        # equal COST per rank: windows + 50 per unit (every contig pays launch ramps / tails)
+        cost = [sum((b - a + 99_999) // 100_000 for r, _, a, b in units if r == k)
+                + 50 * sum(1 for r, c, a, _ in units if r == k and a == 0) for k in range(world)]
+        assert max(cost) / (sum(cost) / world) < 1.02
         loads = [sum(b - a for r, _, a, b in units if r == k) for k in range(world)]
+        assert genome / world / max(loads) > 0.97
+        # without the per-unit term the split is by length alone
+        plain = split_units(sizes, world, 100_000, unit_overhead_windows=0)
+        loads = [sum(b - a for r, _, a, b in plain if r == k) for k in range(world)]
         assert genome / world / max(loads) > 0.999
     assert unit_halo(1000, 120) == 1120
     # more ranks than windows: every window still has exactly one owner
