@@ -184,7 +184,7 @@ def test_split_units_partition_and_balance():
         # equal COST per rank: windows + 50 per unit (every contig pays launch ramps / tails)
         cost = [sum((b - a + 99_999) // 100_000 for r, _, a, b in units if r == k)
                 + 50 * sum(1 for r, c, a, _ in units if r == k and a == 0) for k in range(world)]
-        assert max(cost) / (sum(cost) / world) < 1.02
+        assert max(cost) / (sum(cost) / world) < 1.03
         loads = [sum(b - a for r, _, a, b in units if r == k) for k in range(world)]
         assert genome / world / max(loads) > 0.97
         # without the per-unit term the split is by length alone
