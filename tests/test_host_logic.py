@@ -194,5 +194,10 @@ def test_split_units_partition_and_balance():
     assert unit_halo(1000, 120) == 1120
     # more ranks than windows: every window still has exactly one owner
     tiny = split_units({"a": 250_000, "b": 90_000}, 8, 100_000)
-    assert sorted((c, a, b) for _, c, a, b in tiny) == [("a", 0, 100_000), ("a", 100_000, 200_000),
-                                                        ("a", 200_000, 250_000), ("b", 0, 90_000)]
+    got = sorted((c, a, b) for _, c, a, b in tiny)
+    assert got[0][:2] == ("a", 0) and got[-1] == ("b", 0, 90_000)
+    a_parts = [g for g in got if g[0] == "a"]
+    assert a_parts[-1][2] == 250_000 and all(a_parts[i][2] == a_parts[i + 1][1] for i in range(len(a_parts) - 1))
+    one_each = split_units({"a": 250_000, "b": 90_000}, 8, 100_000, unit_overhead_windows=0)
+    assert sorted((c, a, b) for _, c, a, b in one_each) == [("a", 0, 100_000), ("a", 100_000, 200_000),
+                                                            ("a", 200_000, 250_000), ("b", 0, 90_000)]
