@@ -557,7 +557,15 @@ def cpu_baseline(torch, eng, per, mine, budget_s, checks):
         x0 = int(ws[1]) + 5000 * k
         O.py_wps(rows, x0, x0 + 5000, size, WPS_W, WPS_MIN, WPS_MAX, MAPQ)
     t_py_wps = (time.perf_counter() - t3) / n_tiles_py * (WINDOW / 5000)
-    return {"value": round(1.0 / per_window, 3), "unit": "windows/s", "cores": 1, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(1.0 / per_window, 3), "unit": "windows/s", "cores": 1, "kind": "port", "host_cpu": cpu_model,
             "sample": f"C oracle (oracle/ftk_oracle.c, gcc -O2): coverage+hist+DELFI on {n_s} and WPS (5 kb tiles) on "
                       f"{done} x 100 kb windows of contig {c}; extrapolated per window",
             "all_cores": {"value": round(n_all / t_all, 2), "unit": "windows/s", "cores": n_cores, "kind": "port",
