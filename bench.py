@@ -522,24 +522,12 @@ def cpu_baseline(torch, eng, per, mine, budget_s, checks):
     checks["sample_delfi"] = bool(np.array_equal(sh, p["short"][:n_s].cpu().numpy())
                                   and np.array_equal(lg, p["long"][:n_s].cpu().numpy()))
     checks["sample_wps"] = ok_wps
-    # the same C restatement on every host core (one window per task, threads: ctypes releases the GIL)
-    from concurrent.futures import ThreadPoolExecutor
-    n_cores = os.cpu_count() or 1
-    n_all = int(min(p["nw"], max(64, 4 * n_cores)))
-
-    def one_window(w):
-        a, b = int(p["ws"][w]), int(p["we"][w])
-        wa, wb = p["ws"][w:w + 1], p["we"][w:w + 1]
-        O.c_window_counts(fr, wa, wb, mapq_min=MAPQ)
-        O.c_fraglen_hist(fr, wa, wb, 0, HIST_BINS, mapq_min=MAPQ)
-        O.c_delfi_counts(fr, wa, wb, MAPQ, p["bl"][0], p["bl"][1], p["gaps"])
-        for x in range(a, b, 5000):
-            O.c_wps(fr, x, min(x + 5000, b), size, WPS_W, WPS_MIN, WPS_MAX, MAPQ)
-
-    t_all = time.perf_counter()
-    with ThreadPoolExecutor(n_cores) as ex:
-        list(ex.map(one_window, range(n_all)))
-    t_all = time.perf_counter() - t_all
+    # the same C restatement on every host core: one 100 kb window per task, pthreads inside the oracle library
+    from finaletoolkit_amd.source import usable_cores
+    n_cores = usable_cores()
+    n_all = int(min(p["nw"], max(64, 8 * n_cores)))
+    t_all = O.c_all_cores(fr, p["ws"][:n_all], p["we"][:n_all], HIST_BINS, MAPQ, p["bl"][0], p["bl"][1], p["gaps"], size,
+                          WPS_W, WPS_MIN, WPS_MAX, n_cores)
     # reference-shaped single-thread baseline: the pure-Python restatement that
     # follows the reference loop for loop, on a few windows / WPS tiles
     rows = list(zip(s[:40_000].tolist(), e[:40_000].tolist(), q[:40_000].tolist(), st[:40_000].tolist()))
@@ -569,7 +557,8 @@ def cpu_baseline(torch, eng, per, mine, budget_s, checks):
             "sample": f"C oracle (oracle/ftk_oracle.c, gcc -O2): coverage+hist+DELFI on {n_s} and WPS (5 kb tiles) on "
                       f"{done} x 100 kb windows of contig {c}; extrapolated per window",
             "all_cores": {"value": round(n_all / t_all, 2), "unit": "windows/s", "cores": n_cores, "kind": "port",
-                          "sample": f"the same C restatement, one 100 kb window per task on a {n_cores}-thread pool, "
+                          "sample": f"the same C restatement, one 100 kb window per task on {n_cores} pthreads (usable cores of "
+                                    f"{os.cpu_count()} logical CPUs), "
                                     f"{n_all} windows of contig {c}"},
             "reference_shaped_python": {
                 "value": round(1.0 / (t_py_count + t_py_wps), 4), "unit": "windows/s", "cores": 1,

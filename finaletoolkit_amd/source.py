@@ -39,10 +39,30 @@ def get_engine() -> Engine:
     return _ENGINE
 
 
+def usable_cores() -> int:
+    """Host cores this process may really use: scheduler affinity, capped by the cgroup CPU quota (a
+    container can see 256 logical CPUs and own 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def decode_threads(workers: int | None = None) -> int:
+    """Decoder threads: ``workers`` when given, else the usable cores (at most 64)."""
     if workers and workers > 0:
         return int(workers)
-    return max(1, min(16, os.cpu_count() or 1))
+    return max(1, min(64, usable_cores()))
 
 
 class FragSource:

@@ -295,3 +295,70 @@ void orc_cleavage(const orc_frags* f, int64_t adj_start, int64_t adj_stop, int32
     for (int64_t k = 0; k < n; ++k) { run += diff[k]; depth_out[k] = run; }             /* cumsum(diff[:-1]) */
     free(diff);
 }
+
+/* ---- all host cores: the per-window work of the functions above on a pthread pool -----------
+ * Timed CPU baseline only (bench.py cpu_baseline.all_cores): every task is one window -- coverage
+ * count, length histogram, DELFI counts and WPS in 5 kb tiles, exactly the single-thread calls --
+ * tasks are handed out through an atomic counter.  Results are thrown away (the single-thread run
+ * is the one checked against the GPU); returns the elapsed seconds, or -1. */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+    const orc_frags* f;
+    const int32_t *ws, *we;
+    int64_t n_win;
+    const orc_filter* flt;
+    int32_t n_bins, delfi_q;
+    const int32_t *bl_start, *bl_end;
+    int64_t n_bl;
+    const orc_gaps* g;
+    int64_t chrom_size;
+    int32_t wps_w, wps_min, wps_max, wps_q;
+    int64_t next;
+    int failed;
+} orc_job;
+
+static void* orc_worker(void* arg) {
+    orc_job* j = (orc_job*)arg;
+    uint32_t* hist = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)j->n_bins);
+    int64_t* wps = (int64_t*)malloc(sizeof(int64_t) * 5000);
+    if (!hist || !wps) { j->failed = 1; free(hist); free(wps); return NULL; }
+    for (;;) {
+        int64_t w = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
+        if (w >= j->n_win) break;
+        int64_t cov, over, sh, lg, nf;
+        orc_window_counts(j->f, j->ws + w, j->we + w, 1, j->flt, &cov);
+        orc_fraglen_hist(j->f, j->ws + w, j->we + w, 1, j->flt, 0, j->n_bins, hist, &over);
+        orc_delfi_counts(j->f, j->ws + w, j->we + w, 1, j->delfi_q, j->bl_start, j->bl_end, j->n_bl, j->g, &sh, &lg, &nf);
+        for (int64_t x = j->ws[w]; x < j->we[w]; x += 5000) {
+            int64_t y = x + 5000 < j->we[w] ? x + 5000 : j->we[w];
+            if (orc_wps(j->f, x, y, j->chrom_size, j->wps_w, j->wps_min, j->wps_max, j->wps_q, wps) != 0) j->failed = 1;
+        }
+    }
+    free(hist);
+    free(wps);
+    return NULL;
+}
+
+double orc_all_cores(const orc_frags* f, const int32_t* ws, const int32_t* we, int64_t n_win, const orc_filter* flt,
+                     int32_t n_bins, int32_t delfi_q, const int32_t* bl_start, const int32_t* bl_end, int64_t n_bl,
+                     const orc_gaps* g, int64_t chrom_size, int32_t wps_w, int32_t wps_min, int32_t wps_max,
+                     int32_t wps_q, int32_t n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    orc_job job = {f, ws, we, n_win, flt, n_bins, delfi_q, bl_start, bl_end, n_bl, g, chrom_size,
+                   wps_w, wps_min, wps_max, wps_q, 0, 0};
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    if (!th) return -1.0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    int started = 0;
+    for (int i = 0; i < n_threads; ++i)
+        if (pthread_create(&th[i], NULL, orc_worker, &job) == 0) ++started; else break;
+    if (started == 0) orc_worker(&job);
+    for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(th);
+    if (job.failed) return -1.0;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

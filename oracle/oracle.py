@@ -156,6 +156,23 @@ def c_delfi_counts(fr: Frags, ws, we, mapq_min=30, bl_start=None, bl_end=None, g
     return sh, lg, nf
 
 
+def c_all_cores(fr: Frags, ws, we, n_bins, mapq_min, bl_start, bl_end, gaps, chrom_size, wps_w, wps_min, wps_max,
+                n_threads):
+    """Seconds the per-window work (counts + histogram + DELFI + WPS in 5 kb tiles) of ``len(ws)`` windows takes
+    on ``n_threads`` pthreads (timed CPU baseline; results are not returned)."""
+    ws, we = _windows(ws, we)
+    n_bl = 0 if bl_start is None else len(bl_start)
+    bs = None if n_bl == 0 else np.ascontiguousarray(bl_start, dtype=np.int32)
+    be = None if n_bl == 0 else np.ascontiguousarray(bl_end, dtype=np.int32)
+    f = _filter(mapq_min=mapq_min, bam=fr.r1s is not None)
+    g = make_gaps(gaps)
+    fn = _lib().orc_all_cores
+    fn.restype = C.c_double
+    return float(fn(C.byref(fr.c), _p(ws), _p(we), C.c_int64(len(ws)), C.byref(f), C.c_int32(n_bins), C.c_int32(mapq_min),
+                    _p(bs), _p(be), C.c_int64(n_bl), C.byref(g), C.c_int64(chrom_size), C.c_int32(wps_w),
+                    C.c_int32(wps_min), C.c_int32(wps_max), C.c_int32(mapq_min), C.c_int32(n_threads)))
+
+
 def c_wps(fr: Frags, start, stop, chrom_size, window_size=120, min_len=120, max_len=180, mapq_min=30):
     out = np.zeros(max(int(stop) - int(start), 0), np.int64)
     rc = _lib().orc_wps(C.byref(fr.c), C.c_int64(start), C.c_int64(stop), C.c_int64(chrom_size),

@@ -13,11 +13,18 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+def source_threads():
+    from finaletoolkit_amd.source import usable_cores
+    return usable_cores()
+
+
 from finaletoolkit_amd import _lib as L, bgzf, synth  # noqa: E402
 from finaletoolkit_amd.engine import Engine  # noqa: E402
 
 contig = sys.argv[1] if len(sys.argv) > 1 else "22"
-threads = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 8)
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else source_threads()
 size = synth.B37_SIZES[contig]
 s, e, q, st = synth.synth_contig(size, 30.0, synth.SEED_BASE + 21)
 n = len(s)

@@ -14,10 +14,17 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+def source_threads():
+    from finaletoolkit_amd.source import usable_cores
+    return usable_cores()
+
+
 from finaletoolkit_amd import _lib as L, bgzf, source, synth  # noqa: E402
 
 names = (sys.argv[1] if len(sys.argv) > 1 else "19,20,21,22").split(",")
-threads = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 8)
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else source_threads()
 import pandas as pd  # noqa: E402
 
 tmp = tempfile.mkdtemp()
