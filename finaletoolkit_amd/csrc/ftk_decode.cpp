@@ -23,7 +23,9 @@
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
 #include <pthread.h>
+#include <sys/mman.h>
 
 #include <hip/hip_runtime_api.h>
 
@@ -110,21 +112,80 @@ void parallel_run(int n, const std::function<void(int)>& f) {
     p->run(n, f);
 }
 
-// Byte buffer that is NOT zero-filled on allocation (a 9 GB text image would otherwise
-// be memset by one thread before the inflaters overwrite it).
-// Map fresh pages from ONE thread before the worker threads write into a buffer: dozens of threads
-// faulting pages of the same mapping in at once serialise on the process's memory-map lock (measured:
-// 690 ms instead of 85 ms to inflate 200 MB on 8 threads).
+// Map fresh pages before the worker threads write into a buffer: dozens of threads faulting 4 KB pages
+// of the same mapping in at once serialise on the process's memory-map lock (measured: 690 ms instead
+// of 85 ms to inflate 200 MB on 8 threads).  The mappings ask for 2 MB pages, so a first pass touches
+// one byte per 2 MB from a few threads (a few hundred faults, each zeroing 2 MB - bandwidth, not lock,
+// bound); the 4 KB pass after it finds the pages present unless the kernel had no huge page to give.
 inline void touch_pages(uint8_t* p, size_t from, size_t to) {
+    constexpr size_t kStride = size_t(2) << 20;
+    if (to > from && to - from >= 32 * kStride) {
+        const size_t first = (from + kStride - 1) / kStride, last = (to + kStride - 1) / kStride;
+        const int nt = 8;
+        parallel_run(nt, [&](int t) {
+            for (size_t c = first + (size_t)t; c < last; c += nt)
+                if (c * kStride < to) p[c * kStride] = 0;
+        });
+    }
     for (size_t o = from; o < to; o += 4096) p[o] = 0;
 }
 
+// Large scratch buffers (the inflated text / BAM image) come from anonymous mappings that ask for
+// transparent huge pages: a 650 MB text image is 160 K page faults on 4 KB pages (80+ ms on the one
+// touching thread) and ~320 on 2 MB pages.
+#if defined(__SANITIZE_ADDRESS__)
+#define FTK_ASAN_BUILD 1
+#elif defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define FTK_ASAN_BUILD 1
+#endif
+#endif
+#if defined(FTK_ASAN_BUILD)
+// sanitizer build: heap blocks of the exact size, so that the redzones stay around the parsers' inputs
+inline size_t huge_round(size_t n) { return n; }
+inline uint8_t* huge_map(size_t bytes) { return (uint8_t*)malloc(bytes ? bytes : 1); }
+inline void huge_unmap(uint8_t* p, size_t) { free(p); }
+inline uint8_t* huge_remap(uint8_t* p, size_t, size_t bytes) { return (uint8_t*)realloc(p, bytes); }
+#else
+constexpr size_t kHugePage = size_t(2) << 20;
+inline size_t huge_round(size_t n) { return (n + kHugePage - 1) / kHugePage * kHugePage; }
+inline uint8_t* huge_map(size_t bytes) {  // bytes: a multiple of kHugePage
+    void* q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (q == MAP_FAILED) return nullptr;
+    (void)madvise(q, bytes, MADV_HUGEPAGE);
+    return (uint8_t*)q;
+}
+inline void huge_unmap(uint8_t* p, size_t bytes) { munmap(p, bytes); }
+inline uint8_t* huge_remap(uint8_t* p, size_t old_bytes, size_t bytes) {  // keeps the pages, no copy
+    void* r = mremap(p, old_bytes, bytes, MREMAP_MAYMOVE);
+    if (r == MAP_FAILED) return nullptr;
+    (void)madvise(r, bytes, MADV_HUGEPAGE);
+    return (uint8_t*)r;
+}
+#endif
+
 struct Bytes {
-    std::unique_ptr<uint8_t[]> p;
-    size_t n = 0;
-    void alloc(size_t m) { p.reset(new uint8_t[m ? m : 1]); n = m; touch_pages(p.get(), 0, m); }
-    uint8_t* data() { return p.get(); }
-    const uint8_t* data() const { return p.get(); }
+    uint8_t* p = nullptr;
+    size_t n = 0, mapped = 0;
+    Bytes() = default;
+    Bytes(const Bytes&) = delete;
+    Bytes& operator=(const Bytes&) = delete;
+    ~Bytes() { release(); }
+    void release() {
+        if (p) huge_unmap(p, mapped);
+        p = nullptr;
+        n = mapped = 0;
+    }
+    void alloc(size_t m) {
+        release();
+        mapped = huge_round(m ? m : 1);
+        p = huge_map(mapped);
+        if (!p) throw std::bad_alloc();
+        n = m;
+        touch_pages(p, 0, m);
+    }
+    uint8_t* data() { return p; }
+    const uint8_t* data() const { return p; }
     size_t size() const { return n; }
 };
 
@@ -357,6 +418,85 @@ size_t gzip_header(const uint8_t* p, size_t n, size_t off, size_t* bsize) {
     return q <= n ? q : 0;
 }
 
+// Raw-deflate payload of one BGZF block -> exactly out_len bytes.  libdeflate (present in the image as
+// a runtime library without headers, so bound with dlopen; its three entry points have been stable
+// since 1.0) inflates 2-3x faster than zlib; zlib with one reused stream per worker is the other path.
+// FTK_NO_LIBDEFLATE=1 forces zlib.
+struct DeflateLib {
+    void* (*alloc)() = nullptr;
+    int (*run)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*release)(void*) = nullptr;
+    DeflateLib() {
+        if (getenv("FTK_NO_LIBDEFLATE")) return;
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        auto a = (void* (*)())dlsym(h, "libdeflate_alloc_decompressor");
+        auto r = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_deflate_decompress");
+        auto f = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
+        if (a && r && f) { alloc = a; run = r; release = f; }
+    }
+};
+const DeflateLib& deflate_lib() {
+    static const DeflateLib lib;
+    return lib;
+}
+
+class BlockInflater {
+    void* fast = nullptr;
+    z_stream zs;
+    bool z_ready = false;
+
+public:
+    BlockInflater() {
+        memset(&zs, 0, sizeof(zs));
+        if (deflate_lib().alloc) fast = deflate_lib().alloc();
+    }
+    BlockInflater(const BlockInflater&) = delete;
+    BlockInflater& operator=(const BlockInflater&) = delete;
+    ~BlockInflater() {
+        if (fast) deflate_lib().release(fast);
+        if (z_ready) inflateEnd(&zs);
+    }
+    bool operator()(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len) {
+        if (fast) {
+            size_t got = 0;
+            return deflate_lib().run(fast, in, in_len, out, out_len, &got) == 0 && got == out_len;
+        }
+        if (!z_ready) {
+            if (inflateInit2(&zs, -15) != Z_OK) return false;
+            z_ready = true;
+        } else if (inflateReset(&zs) != Z_OK) {
+            return false;
+        }
+        zs.next_in = const_cast<Bytef*>(in);
+        zs.avail_in = (uInt)in_len;
+        zs.next_out = out;
+        zs.avail_out = (uInt)out_len;
+        return inflate(&zs, Z_FINISH) == Z_STREAM_END && zs.avail_out == 0;
+    }
+};
+
+int inflate_block_list(const uint8_t* p, const std::vector<Block>& blocks, int n_threads, uint8_t* out) {
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    auto work = [&]() {
+        BlockInflater inf;
+        for (;;) {
+            // a few blocks per grab: 64 KB blocks finish in ~30 us and the counter is shared by all workers
+            const size_t i0 = next.fetch_add(4);
+            if (i0 >= blocks.size() || bad.load()) break;
+            for (size_t i = i0; i < std::min(i0 + 4, blocks.size()); ++i) {
+                const Block& b = blocks[i];
+                if (b.out_len == 0) continue;
+                if (!inf(p + b.in_off, b.in_len, out + b.out_off, b.out_len)) { bad = 1; break; }
+            }
+        }
+    };
+    int nt = std::max(1, std::min<int>(n_threads, (int)blocks.size()));
+    parallel_run(nt, [&](int) { work(); });
+    return bad.load() ? FTK_ERR_FORMAT : FTK_OK;
+}
+
 // Inflate a BGZF (block-parallel) or plain gzip (serial) file image.
 int inflate_all(const Bytes& in, int n_threads, Bytes* out) {
     const uint8_t* p = in.data();
@@ -379,29 +519,7 @@ int inflate_all(const Bytes& in, int n_threads, Bytes* out) {
             off += bs;
         }
         out->alloc(total);
-        std::atomic<size_t> next{0};
-        std::atomic<int> bad{0};
-        auto work = [&]() {
-            z_stream zs;
-            for (;;) {
-                size_t i = next.fetch_add(1);
-                if (i >= blocks.size() || bad.load()) break;
-                const Block& b = blocks[i];
-                if (b.out_len == 0) continue;
-                memset(&zs, 0, sizeof(zs));
-                if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; break; }
-                zs.next_in = const_cast<Bytef*>(p + b.in_off);
-                zs.avail_in = (uInt)b.in_len;
-                zs.next_out = out->data() + b.out_off;
-                zs.avail_out = (uInt)b.out_len;
-                int rc = inflate(&zs, Z_FINISH);
-                inflateEnd(&zs);
-                if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; break; }
-            }
-        };
-        int nt = std::max(1, std::min<int>(n_threads, (int)blocks.size()));
-        parallel_run(nt, [&](int) { work(); });
-        if (bad.load()) return dfail(FTK_ERR_FORMAT, "BGZF inflate failed");
+        if (inflate_block_list(p, blocks, n_threads, out->data()) != FTK_OK) return dfail(FTK_ERR_FORMAT, "BGZF inflate failed");
         return FTK_OK;
     }
     // plain (possibly multi-member) gzip
@@ -454,11 +572,61 @@ struct Run {
     Columns c;
 };
 
+// 1..10 decimal digits followed by `term`; returns the byte after `term`, nullptr for anything else.
+// Stops at the first non-digit, so the caller only has to guarantee a '\n' somewhere ahead.
+inline const char* plain_digits(const char* p, char term, uint64_t* v) {
+    const char* s = p;
+    uint64_t x = 0;
+    unsigned d;
+    while ((d = (unsigned)(unsigned char)*p - (unsigned)'0') <= 9) { x = x * 10 + d; ++p; }
+    if (p == s || p - s > 10 || *p != term) return nullptr;
+    *v = x;
+    return p + 1;
+}
+
+// The row nearly every line is: the current contig's name, plain unsigned decimal fields, a one-character
+// strand and the line end.  One forward pass, no per-field searches.  Returns the start of the next line,
+// or nullptr when the general parser below has to look at the row (other contig, signs, blanks, a longer
+// strand field, more columns, 11+ digits ...).  `lim` points at a '\n' at or after `p`.
+inline const char* plain_row(const char* p, const char* lim, const std::string& name, bool bed6, Columns& c) {
+    const size_t cl = name.size();
+    if ((size_t)(lim - p) <= cl || memcmp(p, name.data(), cl) != 0 || p[cl] != '\t') return nullptr;
+    p += cl + 1;
+    uint64_t s, t, m;
+    if (!(p = plain_digits(p, '\t', &s)) || !(p = plain_digits(p, '\t', &t))) return nullptr;
+    if (bed6) {  // column 3 (a name) is not read
+        while (*p != '\t' && *p != '\n') ++p;
+        if (*p != '\t') return nullptr;
+        ++p;
+    }
+    if (!(p = plain_digits(p, '\t', &m))) return nullptr;
+    const char strand = *p;
+    if (strand == '\n' || strand == '\t' || strand == '\r') return nullptr;
+    ++p;
+    if (*p == '\r') ++p;
+    if (*p != '\n') return nullptr;
+    if (s <= (uint64_t)INT32_MAX && t <= (uint64_t)INT32_MAX) {
+        c.start.push_back((int32_t)s);
+        c.end.push_back((int32_t)t);
+        c.mapq.push_back((uint8_t)std::min<uint64_t>(m, 255));
+        c.strand.push_back(strand == '+' ? 1 : 0);
+    }
+    return p + 1;
+}
+
 void parse_segment(const char* b, const char* e, bool bed6, const char* only, std::vector<Run>* runs) {
     const int mq_col = bed6 ? 4 : 3, st_col = bed6 ? 5 : 4;
     const size_t only_len = only ? strlen(only) : 0;
     Run* cur = nullptr;
+    // last line end of the segment: rows before it may be scanned without a bound per byte
+    const char* lim = e;
+    while (lim > b && lim[-1] != '\n') --lim;
+    lim = lim > b ? lim - 1 : nullptr;
     while (b < e) {
+        if (cur && lim && b <= lim) {
+            const char* next = plain_row(b, lim, cur->name, bed6, cur->c);
+            if (next) { b = next; continue; }
+        }
         const char* nl = (const char*)memchr(b, '\n', (size_t)(e - b));
         const char* le = nl ? nl : e;
         const char* line = b;
@@ -486,6 +654,12 @@ void parse_segment(const char* b, const char* e, bool bed6, const char* only, st
         if (!cur || cur->name.size() != cl || memcmp(cur->name.data(), fb[0], cl) != 0) {
             runs->push_back(Run{std::string(fb[0], cl), {}});
             cur = &runs->back();
+            // room for the rest of the segment at ~20 bytes a row: no regrowth copies in the common case
+            const size_t guess = (size_t)(e - line) / 20 + 16;
+            cur->c.start.reserve(guess);
+            cur->c.end.reserve(guess);
+            cur->c.mapq.reserve(guess);
+            cur->c.strand.reserve(guess);
         }
         cur->c.start.push_back((int32_t)s);
         cur->c.end.push_back((int32_t)t);
@@ -535,7 +709,7 @@ extern "C" {
 
 const char* ftk_fragtable_error(void) { return g_decode_err.c_str(); }
 
-int ftk_fragfile_decode(const char* path, const char* contig, int n_threads, ftk_fragtable** out) {
+static int ftk_fragfile_decode_impl(const char* path, const char* contig, int n_threads, ftk_fragtable** out) {
     if (!path || !out) return dfail(FTK_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (n_threads < 1) n_threads = 1;
@@ -627,7 +801,7 @@ int ftk_fragfile_decode(const char* path, const char* contig, int n_threads, ftk
     return FTK_OK;
 }
 
-int ftk_bam_decode(const char* path, const char* contig, int n_threads, ftk_fragtable** out) {
+static int ftk_bam_decode_impl(const char* path, const char* contig, int n_threads, ftk_fragtable** out) {
     if (!path || !out) return dfail(FTK_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (n_threads < 1) n_threads = 1;
@@ -714,6 +888,25 @@ int ftk_bam_decode(const char* path, const char* contig, int n_threads, ftk_frag
     return FTK_OK;
 }
 
+// The C boundary never lets a C++ exception through: running out of host memory is an error code.
+int ftk_fragfile_decode(const char* path, const char* contig, int n_threads, ftk_fragtable** out) {
+    try {
+        return ftk_fragfile_decode_impl(path, contig, n_threads, out);
+    } catch (const std::exception& ex) {
+        if (out) *out = nullptr;
+        return dfail(FTK_ERR_OOM, ex.what());
+    }
+}
+
+int ftk_bam_decode(const char* path, const char* contig, int n_threads, ftk_fragtable** out) {
+    try {
+        return ftk_bam_decode_impl(path, contig, n_threads, out);
+    } catch (const std::exception& ex) {
+        if (out) *out = nullptr;
+        return dfail(FTK_ERR_OOM, ex.what());
+    }
+}
+
 int ftk_fragtable_is_bed6(const ftk_fragtable* t) { return t && t->bed6 ? 1 : 0; }
 int ftk_fragtable_n_contigs(const ftk_fragtable* t) { return t ? (int)t->contigs.size() : 0; }
 const char* ftk_fragtable_contig_name(const ftk_fragtable* t, int i) {
@@ -777,13 +970,16 @@ struct BamRun {
 struct RawBuf {
     uint8_t* p = nullptr;
     size_t cap = 0;
-    ~RawBuf() { free(p); }
+    RawBuf() = default;
+    RawBuf(const RawBuf&) = delete;
+    RawBuf& operator=(const RawBuf&) = delete;
+    ~RawBuf() { if (p) huge_unmap(p, cap); }
     bool reserve(size_t n) {
         if (n <= cap) return true;
-        size_t want = std::max(n, cap + cap / 2);
-        void* q = realloc(p, want);
+        const size_t want = huge_round(std::max(n, cap + cap / 2));
+        uint8_t* q = p ? huge_remap(p, cap, want) : huge_map(want);
         if (!q) return false;
-        p = (uint8_t*)q;
+        p = q;
         touch_pages(p, cap, want);
         cap = want;
         return true;
@@ -824,32 +1020,6 @@ void pack_parts(Contig& ct, int n_threads) {
     const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, ct.parts.size()));
     parallel_run(nt, [&](int) { work(); });
     std::vector<Columns>().swap(ct.parts);
-}
-
-int inflate_block_list(const uint8_t* p, const std::vector<Block>& blocks, int n_threads, uint8_t* out) {
-    std::atomic<size_t> next{0};
-    std::atomic<int> bad{0};
-    auto work = [&]() {
-        z_stream zs;
-        for (;;) {
-            size_t i = next.fetch_add(1);
-            if (i >= blocks.size() || bad.load()) break;
-            const Block& b = blocks[i];
-            if (b.out_len == 0) continue;
-            memset(&zs, 0, sizeof(zs));
-            if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; break; }
-            zs.next_in = const_cast<Bytef*>(p + b.in_off);
-            zs.avail_in = (uInt)b.in_len;
-            zs.next_out = out + b.out_off;
-            zs.avail_out = (uInt)b.out_len;
-            int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; break; }
-        }
-    };
-    int nt = std::max(1, std::min<int>(n_threads, (int)blocks.size()));
-    parallel_run(nt, [&](int) { work(); });
-    return bad.load() ? FTK_ERR_FORMAT : FTK_OK;
 }
 
 // Complete text lines [b, e) -> runs in file order (segments parsed in parallel).
@@ -1064,7 +1234,8 @@ struct ftk_fragstream {
         if (err == FTK_OK) { err = code; errmsg = msg; }
         return false;
     }
-    void run();
+    void run();          // producer thread body: run_guarded() with exceptions turned into a stream error
+    void run_guarded();
     bool run_text(RawBuf& first, size_t first_n);
     bool run_bam(RawBuf& first, size_t first_n);
     // single-contig requests with a usable index: read only the file range holding the contig
@@ -1119,7 +1290,7 @@ struct ftk_fragstream {
     }
 };
 
-void ftk_fragstream::run() {
+void ftk_fragstream::run_guarded() {
     RawBuf buf;
     if (has_only && !bam) {  // tabix index: jump straight to the contig's rows
         const IndexSpan sp = index_lookup(index_path_of(path, false), false, only, -1);
@@ -1175,6 +1346,19 @@ void ftk_fragstream::run() {
     }
     (void)ok;
     flush();
+    std::lock_guard<std::mutex> lk(mu);
+    finished = true;
+    header_ready = true;
+    cv.notify_all();
+}
+
+void ftk_fragstream::run() {
+    try {
+        run_guarded();
+        return;
+    } catch (const std::exception& ex) {
+        fail(FTK_ERR_OOM, ex.what());
+    }
     std::lock_guard<std::mutex> lk(mu);
     finished = true;
     header_ready = true;

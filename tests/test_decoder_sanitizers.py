@@ -17,11 +17,14 @@ def test_decoder_under_asan_ubsan(tmp_path):
            "-D__HIP_PLATFORM_AMD__", f"-I{ROOT}/include", "-I/opt/rocm/include",
            os.path.join(ROOT, "tests", "native", "decode_sanitize.cpp"),
            os.path.join(ROOT, "finaletoolkit_amd", "csrc", "ftk_decode.cpp"),
-           "-o", exe, "-lz", "-lpthread", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"]
+           "-o", exe, "-lz", "-lpthread", "-ldl", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         pytest.skip("sanitizer build unavailable: " + r.stderr[-300:])
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    # 1 MB pieces: the harness opens several hundred streams, and each would otherwise map and fault
+    # a 48 MB piece buffer in (minutes of kernel time under the sanitizer's allocator)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
+               FTK_STREAM_PIECE=str(1 << 20))
     r = subprocess.run([exe, DATA, str(tmp_path)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "decode_sanitize ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-2000:]

@@ -207,3 +207,114 @@ def test_single_contig_requests_use_the_index(tmp_path):
     assert _stream(os.path.join(DATA, "12.3444.b37.frag.gz"), contig="12")[0]["12"][0] == 17
     assert _stream(os.path.join(DATA, "12.3444.b37.bam"), bam=True, contig="12")[0]["12"][0] == 17
     assert _stream(os.path.join(DATA, "12.3444.b37.bam"), bam=True, contig="1")[1] == []
+
+
+def _int_rule(f):
+    """The decoder's integer field rule (csrc/ftk_decode.cpp parse_int): blanks around, one sign, digits."""
+    f = f.strip(" \r")
+    body = f[1:] if f[:1] in "+-" else f
+    if not body or not body.isascii() or not body.isdigit():
+        raise ValueError(f)
+    v = int(f)
+    if abs(v) > (1 << 40):
+        raise ValueError(f)
+    return v
+
+
+def _rows_by_rule(text, bed6):
+    mq_col, st_col = (4, 5) if bed6 else (3, 4)
+    out = {}
+    for line in text.split("\n"):
+        if line.endswith("\r"):
+            line = line[:-1]
+        if not line or line.startswith("#"):
+            continue
+        p = line.split("\t")
+        if len(p) <= st_col:
+            continue
+        try:
+            s, t, m = _int_rule(p[1]), _int_rule(p[2]), _int_rule(p[mq_col])
+        except ValueError:
+            continue
+        if s < 0 or t < 0 or s > 2**31 - 1 or t > 2**31 - 1 or m < 0:
+            continue
+        out.setdefault(p[0], []).append((s, t, min(m, 255), 1 if "+" in p[st_col] else 0))
+    return out
+
+
+@pytest.mark.parametrize("bed6", [False, True])
+def test_text_rows_plain_fast_path_equals_general_rules(tmp_path, bed6):
+    """Mostly plain rows (the one-pass fast path) with every kind of odd row mixed in: the decoded columns
+    must be what the field rules give row by row, whole-file and streamed, at several thread counts."""
+    rng = np.random.default_rng(77 + bed6)
+    odd = [
+        lambda c, s, e, q, st: [c, " %d" % s, str(e), str(q), st],
+        lambda c, s, e, q, st: [c, str(s), "+%d" % e, str(q), st],
+        lambda c, s, e, q, st: [c, "-%d" % s, str(e), str(q), st],
+        lambda c, s, e, q, st: [c, str(s), str(e), "6x", st],
+        lambda c, s, e, q, st: [c, "00000000%d" % (s % 1000), str(e), str(q), st],     # 11 digits, small value
+        lambda c, s, e, q, st: [c, "123456789012345", str(e), str(q), st],
+        lambda c, s, e, q, st: [c, "2147483648", str(e), str(q), st],
+        lambda c, s, e, q, st: [c, str(s), "2147483647", str(q), st],
+        lambda c, s, e, q, st: [c, str(s), str(e), "300", st],
+        lambda c, s, e, q, st: [c, str(s), str(e), " %d " % q, st],
+        lambda c, s, e, q, st: [c, str(s), str(e), str(q), "+-"],
+        lambda c, s, e, q, st: [c, str(s), str(e), str(q), "."],
+        lambda c, s, e, q, st: [c, str(s), str(e), str(q), st, "extra", "more", "cols", "here"],
+        lambda c, s, e, q, st: [c, str(s), str(e), str(q)],
+        lambda c, s, e, q, st: [c, "", str(e), str(q), st],
+        lambda c, s, e, q, st: [c, str(s), str(e), str(q), ""],
+        lambda c, s, e, q, st: ["#" + c, str(s), str(e), str(q), st],
+        lambda c, s, e, q, st: [""],
+        lambda c, s, e, q, st: [c + "x", str(s), str(e), str(q), st],                 # a one-row run of another name
+    ]
+    lines = []
+    for c in ("chr1", "chr10", "2"):
+        n = 40_000
+        s = np.sort(rng.integers(0, 50_000_000, n))
+        e = s + rng.integers(1, 600, n)
+        q = rng.integers(0, 61, n)
+        st = rng.integers(0, 2, n)
+        pick = rng.random(n)
+        for i in range(n):
+            f = [c, str(s[i]), str(e[i]), str(q[i]), "+" if st[i] else "-"]
+            if pick[i] < 0.05:
+                f = odd[int(rng.integers(len(odd)))](c, int(s[i]), int(e[i]), int(q[i]), f[4])
+            if bed6 and len(f) >= 4:
+                f = f[:3] + ["frag %d" % i] + f[3:]
+            lines.append("\t".join(f) + ("\r" if pick[i] > 0.97 else ""))
+    # the first data row fixes the layout (io/alignment.py:143-156): make it a plain one
+    first = ["chr1", "5", "170", "name", "60", "+"] if bed6 else ["chr1", "5", "170", "60", "+"]
+    text = "\t".join(first) + "\n" + "\n".join(lines)      # no newline after the last row
+    want = _rows_by_rule(text, bed6)
+    # names such as "chr1x" come back as separate one-row runs between two runs of "chr1": not a sorted file for the
+    # streaming decoder, so compare run-insensitive through the whole-file decoder and stream a file without them
+    p = str(tmp_path / "rows.frag.gz")
+    bgzf.write_bgzf(p, text.encode(), level=1)
+    for threads in (1, 4):
+        got = _decode(p, threads=threads)
+        assert got["__bed6__"] == int(bed6)
+        assert sorted(k for k in got if not k.startswith("__")) == sorted(want)
+        for c, rows in want.items():
+            a = np.array(rows, dtype=np.int64)
+            assert got[c][0] == len(rows), c
+            for k in range(4):
+                assert np.array_equal(got[c][1][k].astype(np.int64), a[:, k]), (c, k)
+    sorted_text = "\n".join(ln for ln in text.split("\n") if not ln.split("\t")[0].endswith("x")) + "\n"
+    want = _rows_by_rule(sorted_text, bed6)
+    p2 = str(tmp_path / "rows_sorted.frag.gz")
+    bgzf.write_bgzf(p2, sorted_text.encode(), level=1)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tests.test_stream_decoder import _stream\n"
+            "import numpy as np, pickle\n"
+            "got, order, _ = _stream(%r, threads=3)\n"
+            "pickle.dump({k: v for k, v in got.items()}, open(%r, 'wb'))\n") % (ROOT, p2, str(tmp_path / "got.pkl"))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, FTK_STREAM_PIECE=str(1 << 16)))
+    import pickle
+    got = pickle.load(open(tmp_path / "got.pkl", "rb"))
+    assert sorted(k for k in got if not k.startswith("__")) == sorted(want)
+    for c, rows in want.items():
+        a = np.array(rows, dtype=np.int64)
+        assert got[c][0] == len(rows), c
+        for k in range(4):
+            assert np.array_equal(got[c][1][k].astype(np.int64), a[:, k]), (c, k)
