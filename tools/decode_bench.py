@@ -20,13 +20,23 @@ def child(path, threads):
     from finaletoolkit_amd import _lib as L
     lib = L.load()
     out = {"whole": [], "stream": []}
+    cold = os.environ.get("FTK_BENCH_COLD") == "1"
+
+    def evict():  # clean page-cache pages of the file are dropped (the file was fsync'ed by the parent)
+        if cold:
+            fd = os.open(path, os.O_RDONLY)
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+            os.close(fd)
+
     for _ in range(3):
+        evict()
         t0 = time.perf_counter()
         table = C.c_void_p()
         assert lib.ftk_fragfile_decode(path.encode(), None, threads, C.byref(table)) == 0
         rows = sum(lib.ftk_fragtable_contig_rows(table, i) for i in range(lib.ftk_fragtable_n_contigs(table)))
         out["whole"].append(round(time.perf_counter() - t0, 4))
         lib.ftk_fragtable_free(table)
+        evict()
         t0 = time.perf_counter()
         s = C.c_void_p()
         assert lib.ftk_fragstream_open(path.encode(), None, 0, threads, 2, C.byref(s)) == 0
@@ -62,11 +72,14 @@ def main():
         parts.append(buf.getvalue().encode())
     text = b"".join(parts)
     bgzf.write_bgzf(path, text, level=1)
+    fd = os.open(path, os.O_RDONLY)
+    os.fsync(fd)
+    os.close(fd)
     print(json.dumps({"text_MB": round(len(text) / 1e6, 1), "file_MB": round(os.path.getsize(path) / 1e6, 1)}))
     del text, parts
     for nodeflate in ("", "1"):
         for th in thread_list:
-            env = dict(os.environ, FTK_DECODE_TIMING="1")
+            env = dict(os.environ, FTK_DECODE_TIMING="1")  # FTK_BENCH_COLD=1: evict the file before every decode
             if nodeflate:
                 env["FTK_NO_LIBDEFLATE"] = "1"
             r = subprocess.run([sys.executable, __file__, "--child", path, str(th)], env=env, capture_output=True, text=True)
