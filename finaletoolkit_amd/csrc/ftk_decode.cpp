@@ -703,7 +703,11 @@ Contig* find_or_add(ftk_fragtable* t, const std::string& name) {
     return &t->contigs.back();
 }
 
-void sort_by_start(Columns& c) {
+// Stable order by fragment start.  BAM fragments arrive in read1-position order, i.e. nearly sorted
+// (a reverse-strand read1 sits at the far end of its fragment), millions per contig: the keys
+// (start << 32 | file rank) are sorted in one chunk per thread, the chunks merged pairwise level by
+// level, and the columns gathered in parallel.
+void sort_by_start(Columns& c, int n_threads = 1) {
     const size_t m = c.start.size();
     const bool bam_cols = !c.r1s.empty() || m == 0;
     if (bam_cols && c.ord.size() != m) {  // file order of the read1 records, to restore pysam's iteration order
@@ -711,21 +715,46 @@ void sort_by_start(Columns& c) {
         std::iota(c.ord.begin(), c.ord.end(), 0);
     }
     if (std::is_sorted(c.start.begin(), c.start.end())) return;
-    std::vector<uint32_t> perm(m);
-    std::iota(perm.begin(), perm.end(), 0u);
-    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return c.start[a] < c.start[b]; });
+    std::vector<uint64_t> key(m), tmp;
+    for (size_t i = 0; i < m; ++i) key[i] = ((uint64_t)(uint32_t)c.start[i] << 32) | (uint64_t)i;  // starts are >= 0
+    int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(n_threads, 1), m / 65536));
+    if (nt == 1) {
+        std::sort(key.begin(), key.end());
+    } else {
+        std::vector<size_t> cut(nt + 1);
+        for (int t = 0; t <= nt; ++t) cut[t] = m * (size_t)t / (size_t)nt;
+        parallel_run(nt, [&](int t) { std::sort(key.begin() + cut[t], key.begin() + cut[t + 1]); });
+        tmp.resize(m);
+        uint64_t* src = key.data();
+        uint64_t* dst = tmp.data();
+        while (cut.size() > 2) {  // merge neighbours; an odd last chunk is copied through
+            const size_t n_chunks = cut.size() - 1, n_pairs = n_chunks / 2;
+            parallel_run((int)((n_chunks + 1) / 2), [&](int t) {
+                const size_t a = cut[2 * t], mid = cut[2 * t + 1];
+                if ((size_t)t < n_pairs) std::merge(src + a, src + mid, src + mid, src + cut[2 * t + 2], dst + a);
+                else std::copy(src + a, src + mid, dst + a);
+            });
+            std::vector<size_t> next;
+            for (size_t k = 0; k < cut.size(); k += 2) next.push_back(cut[k]);
+            if (next.back() != m) next.push_back(m);
+            cut.swap(next);
+            std::swap(src, dst);
+        }
+        if (src != key.data()) key.swap(tmp);
+    }
     Columns s;
     const bool r1 = !c.r1s.empty();
     s.start.resize(m); s.end.resize(m); s.mapq.resize(m); s.strand.resize(m);
     if (r1) { s.r1s.resize(m); s.r1e.resize(m); s.ord.resize(m); }
-    for (size_t i = 0; i < m; ++i) {
-        const uint32_t j = perm[i];
-        s.start[i] = c.start[j]; s.end[i] = c.end[j]; s.mapq[i] = c.mapq[j]; s.strand[i] = c.strand[j];
-        if (r1) { s.r1s[i] = c.r1s[j]; s.r1e[i] = c.r1e[j]; s.ord[i] = c.ord[j]; }
-    }
+    parallel_run(nt, [&](int t) {
+        for (size_t i = m * (size_t)t / (size_t)nt, e = m * (size_t)(t + 1) / (size_t)nt; i < e; ++i) {
+            const uint32_t j = (uint32_t)key[i];
+            s.start[i] = c.start[j]; s.end[i] = c.end[j]; s.mapq[i] = c.mapq[j]; s.strand[i] = c.strand[j];
+            if (r1) { s.r1s[i] = c.r1s[j]; s.r1e[i] = c.r1e[j]; s.ord[i] = c.ord[j]; }
+        }
+    });
     c = std::move(s);
 }
-
 
 inline int32_t rd_i32(const uint8_t* p) { return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)); }
 inline uint32_t rd_u32(const uint8_t* p) { return (uint32_t)rd_i32(p); }
@@ -834,10 +863,13 @@ static int ftk_bam_decode_impl(const char* path, const char* contig, int n_threa
     *out = nullptr;
     if (n_threads < 1) n_threads = 1;
     Bytes raw, bam;
+    Stopwatch sw;
     if (!read_file(path, &raw)) return dfail(FTK_ERR_IO, "cannot read %s", path);
+    sw.lap("read file");
     int rc = inflate_all(raw, n_threads, &bam);
     if (rc) return rc;
     raw.alloc(0);
+    sw.lap("inflate");
     const uint8_t* p = bam.data();
     const size_t n = bam.size();
     if (n < 12 || memcmp(p, "BAM\1", 4) != 0) return dfail(FTK_ERR_FORMAT, "%s is not a BAM file", path);
@@ -906,12 +938,15 @@ static int ftk_bam_decode_impl(const char* path, const char* contig, int n_threa
         c.r1s.push_back(pos);
         c.r1e.push_back((int32_t)ref_end);
     }
+    sw.lap("records");
     // the kernels need start-sorted fragments; read1 order is by read position (kept in `ord`)
-    for (auto& ct : t->contigs) sort_by_start(ct.c);
+    for (auto& ct : t->contigs) sort_by_start(ct.c, n_threads);
+    sw.lap("sort by start");
     for (auto& ct : t->contigs) {
         pack(ct);
         if (!ct.p.base) return dfail(FTK_ERR_OOM, "out of host memory");
     }
+    sw.lap("pack");
     *out = t.release();
     return FTK_OK;
 }
@@ -987,6 +1022,14 @@ const size_t kStreamPiece = [] {
     const char* e = getenv("FTK_STREAM_PIECE");
     const long long v = e ? atoll(e) : 0;
     return v >= (1 << 16) ? (size_t)v : (size_t)(48u << 20);
+}();
+
+// bytes of inflated BAM per speculative stretch of the record chain (FTK_BAM_STRETCH: the tests make the
+// stretches tiny so that small files exercise the guess / check / redo logic)
+const size_t kBamStretch = [] {
+    const char* e = getenv("FTK_BAM_STRETCH");
+    const long long v = e ? atoll(e) : 0;
+    return v >= 64 ? (size_t)v : (size_t)(1u << 20);
 }();
 
 struct BamRun {
@@ -1068,6 +1111,39 @@ void parse_text_parallel(const char* b, const char* e, bool bed6, const char* on
     parallel_run(nseg, [&](int i) { parse_segment(cut[i], cut[i + 1], bed6, only, &seg[i]); });
     for (auto& v : seg)
         for (auto& r : v) out->push_back(std::move(r));
+}
+
+// Does p[o..) look like the start of a BAM alignment record?  Only used to GUESS where a thread may
+// enter the record chain in the middle of a piece (run_bam); a wrong guess is detected and redone.
+inline bool plausible_record(const uint8_t* p, size_t o, size_t m, int n_ref) {
+    if (o + 36 > m) return false;
+    const uint32_t bs = rd_u32(p + o);
+    if (bs < 32 || bs > (1u << 24)) return false;
+    const uint8_t* r = p + o + 4;
+    const int32_t ref = rd_i32(r), pos = rd_i32(r + 4), next_ref = rd_i32(r + 20), next_pos = rd_i32(r + 24);
+    if (ref < -1 || ref >= n_ref || next_ref < -1 || next_ref >= n_ref || pos < -1 || next_pos < -1) return false;
+    const uint32_t l_name = r[8], n_cigar = rd_u16(r + 12);
+    const int32_t l_seq = rd_i32(r + 16);
+    if (l_name == 0 || l_seq < 0) return false;
+    const uint64_t need = 32 + (uint64_t)l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
+    if (need > bs) return false;
+    if (o + 36 + l_name <= m && r[32 + l_name - 1] != 0) return false;  // the read name is NUL-terminated
+    return true;
+}
+
+inline size_t guess_record_start(const uint8_t* p, size_t from, size_t m, int n_ref) {
+    for (size_t o = from; o + 36 <= m; ++o) {
+        if (!plausible_record(p, o, m, n_ref)) continue;
+        size_t o2 = o + 4 + (size_t)rd_u32(p + o);
+        bool ok = true;
+        for (int k = 0; k < 2; ++k) {  // two more links must hold, unless the piece ends first
+            if (o2 + 36 > m) break;
+            if (!plausible_record(p, o2, m, n_ref)) { ok = false; break; }
+            o2 += 4 + (size_t)rd_u32(p + o2);
+        }
+        if (ok) return o;
+    }
+    return SIZE_MAX;
 }
 
 // One BAM alignment record -> fragment columns (io/alignment.py:60-71,242-268); false = not a fragment.
@@ -1238,11 +1314,15 @@ struct ftk_fragstream {
             t->bed6 = bed6;
             t->contigs.push_back(std::move(*held));
             Contig& c = t->contigs[0];
+            Stopwatch sw;
             if (!c.parts.empty()) {
                 pack_parts(c, n_threads);
+                sw.lap("packer: pack runs");
             } else {
-                if (bam) sort_by_start(c.c);
+                if (bam) sort_by_start(c.c, n_threads);
+                sw.lap("packer: sort by start");
                 pack(c);
+                sw.lap("packer: pack");
             }
             if (!c.p.base) { fail(FTK_ERR_OOM, "out of host memory"); packer_ok = 0; return; }
             std::unique_lock<std::mutex> lk(mu);
@@ -1505,6 +1585,8 @@ bool ftk_fragstream::run_text(RawBuf& buf, size_t n) {
 }
 
 bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
+    StageClock clk;
+    size_t n_stretches = 0, n_redone = 0;
     std::vector<Block> blocks;
     RawBuf data;                // carry (partial record / header) + this piece's inflated bytes
     size_t carry = 0;
@@ -1519,8 +1601,10 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
         size_t used = 0, total = 0;
         if (!whole_blocks(buf.data(), n, eof, &blocks, &used, &total)) return fail(FTK_ERR_FORMAT, "corrupt BGZF block");
         if (!data.reserve(carry + total + 1)) return fail(FTK_ERR_OOM, "out of host memory");
+        clk.lap(5);
         if (!blocks.empty() && inflate_block_list(buf.data(), blocks, n_threads, data.data() + carry) != FTK_OK)
             return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+        clk.lap(1);
         const uint8_t* p = data.data();
         const size_t m = carry + total;
         size_t off = std::min(pending_skip, m);  // (a damaged index may point past the block)
@@ -1590,40 +1674,68 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
             }
         }
         {
-            // index the complete records, parse them in parallel, merge the runs in order
-            std::vector<size_t> rec;
+            // The records form a chain (each starts where the previous one ends), and walking it is one
+            // dependent cache miss per record - ~80 ns x millions.  So the piece is cut into byte ranges:
+            // every thread GUESSES the first record start in its range (header plausibility, three links
+            // deep), walks and parses from there; afterwards the chain is checked range by range - a range
+            // whose guessed start is not where the previous range's walk ended is redone from the true
+            // offset.  The result never depends on the guess, only the speed does.
+            const int n_ref = (int)wanted.size();
+            const int nseg = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, (m - off) / kBamStretch + 1));
+            struct Stretch {
+                size_t start = SIZE_MAX, landing = 0;
+                bool bad = false;
+                std::vector<BamRun> runs;
+            };
+            std::vector<Stretch> seg(nseg);
+            auto walk = [&](size_t from, size_t until, Stretch& st) {
+                st.runs.clear();
+                st.bad = false;
+                st.start = from;
+                BamRun* run = nullptr;
+                size_t o = from;
+                while (o < until && o + 4 <= m) {
+                    const uint32_t bs = rd_u32(p + o);
+                    if (bs < 32) { st.bad = true; break; }
+                    if (o + 4 + (size_t)bs > m) break;  // incomplete: waits for the next piece
+                    const uint8_t* r = p + o + 4;
+                    const int32_t ref_id = rd_i32(r);
+                    if (ref_id >= 0 && ref_id < n_ref && wanted[ref_id]) {
+                        if (!run || run->ref != ref_id) {
+                            st.runs.push_back(BamRun{ref_id, {}});
+                            run = &st.runs.back();
+                        }
+                        bam_record(r, bs, run->c);
+                    }
+                    o += 4 + (size_t)bs;
+                }
+                st.landing = o;
+            };
+            auto bound = [&](int k) { return k >= nseg ? m : off + (m - off) * (size_t)k / (size_t)nseg; };
+            parallel_run(nseg, [&](int k) {
+                const size_t from = k == 0 ? off : guess_record_start(p, bound(k), m, n_ref);
+                if (from == SIZE_MAX) return;  // nothing that looks like a record: settled by the check below
+                walk(from, bound(k + 1), seg[k]);
+            });
+            clk.lap(2);
             size_t o = off;
-            while (o + 4 <= m) {
-                const uint32_t bs = rd_u32(p + o);
-                if (bs < 32) return fail(FTK_ERR_FORMAT, "corrupt BAM record");
-                if (o + 4 + bs > m) break;
-                rec.push_back(o);
-                o += 4 + (size_t)bs;
+            for (int k = 0; k < nseg; ++k) {
+                ++n_stretches;
+                if (seg[k].start != o || seg[k].bad) {
+                    ++n_redone;
+                    walk(o, bound(k + 1), seg[k]);
+                    if (seg[k].bad) return fail(FTK_ERR_FORMAT, "corrupt BAM record");
+                }
+                o = seg[k].landing;
             }
             if (eof && o != m && !partial_tail_ok) return fail(FTK_ERR_FORMAT, "truncated BAM record");
-            const int n_ref = (int)wanted.size();
-            int nseg = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, rec.size() / 4096 + 1));
-            std::vector<std::vector<BamRun>> seg(nseg);
-            auto work = [&](int sg) {
-                const size_t r0 = rec.size() * (size_t)sg / (size_t)nseg, r1 = rec.size() * (size_t)(sg + 1) / (size_t)nseg;
-                BamRun* run = nullptr;
-                for (size_t k = r0; k < r1; ++k) {
-                    const uint8_t* r = p + rec[k] + 4;
-                    const uint32_t bs = rd_u32(p + rec[k]);
-                    const int32_t ref_id = rd_i32(r);
-                    if (ref_id < 0 || ref_id >= n_ref || !wanted[ref_id]) continue;
-                    if (!run || run->ref != ref_id) {
-                        seg[sg].push_back(BamRun{ref_id, {}});
-                        run = &seg[sg].back();
-                    }
-                    bam_record(r, bs, run->c);
-                }
-            };
-            parallel_run(nseg, [&](int i) { work(i); });
-            for (auto& v : seg)
-                for (auto& r : v) {
+            clk.lap(5);  // "other" holds the chain check (and any redone range)
+            for (auto& st : seg)
+                for (auto& r : st.runs) {
                     if (cur_ref >= 0 && r.ref != cur_ref) {
+                        clk.lap(3);
                         if (!cur.c.start.empty() && !emit(std::move(cur))) return false;
+                        clk.lap(4);
                         cur = Contig{};
                         cur_ref = -1;
                     }
@@ -1636,6 +1748,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
                     }
                     cur.c.append(r.c);
                 }
+            clk.lap(3);
             carry = m - o;
             if (carry) memmove(data.data(), p + o, carry);
         }
@@ -1644,13 +1757,19 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
         {
             const size_t raw_carry = n - used;
             if (raw_carry) memmove(buf.data(), buf.data() + used, raw_carry);
+            clk.lap(5);
             n = fill(buf, raw_carry);
+            clk.lap(0);
             eof = n - raw_carry < kStreamPiece;
             std::lock_guard<std::mutex> lk(mu);
             if (stop) return false;
         }
     }
+    clk.lap(5);
     if (cur_ref >= 0 && !cur.c.start.empty() && !emit(std::move(cur))) return false;
+    clk.lap(4);
+    clk.report("bam");
+    if (clk.on) fprintf(stderr, "[ftk stream bam] %zu stretches of the record chain, %zu redone after the chain check\n", n_stretches, n_redone);
     return true;
 }
 

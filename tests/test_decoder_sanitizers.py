@@ -24,7 +24,8 @@ def test_decoder_under_asan_ubsan(tmp_path):
     # 1 MB pieces: the harness opens several hundred streams, and each would otherwise map and fault
     # a 48 MB piece buffer in (minutes of kernel time under the sanitizer's allocator)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
-               FTK_STREAM_PIECE=str(1 << 20))
+               FTK_STREAM_PIECE=str(1 << 20),
+               FTK_BAM_STRETCH="256")  # the BAM record chain is entered speculatively every 256 bytes
     r = subprocess.run([exe, DATA, str(tmp_path)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "decode_sanitize ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-2000:]

@@ -90,8 +90,8 @@ print("ok", order)
 """
 
 
-def _run_child(path, bam, contig):
-    env = dict(os.environ, FTK_STREAM_PIECE="65536")
+def _run_child(path, bam, contig, **extra):
+    env = dict(os.environ, FTK_STREAM_PIECE="65536", **extra)
     r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT), path, "1" if bam else "0", contig], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
@@ -124,6 +124,59 @@ def test_stream_small_pieces_bam(tmp_path):
     write_synthetic_bam(p, contigs, frags)
     out = _run_child(p, True, "chrB")
     assert "['chrA', 'chrB', 'chrC']" in out
+    # the record chain walked as many speculative stretches per piece (4 KB: a dozen records each; 100 bytes:
+    # shorter than a record, most stretches hold no record start)
+    for stretch in ("4096", "100"):
+        assert "['chrA', 'chrB', 'chrC']" in _run_child(p, True, "chrB", FTK_BAM_STRETCH=stretch)
+
+
+def test_bam_stretch_guess_survives_decoy_records(tmp_path):
+    """Every record carries, in its quality string, three chained byte patterns that look exactly like BAM
+    records of a proper read1 (the stretch-start guesser accepts them).  A thread that enters the chain there
+    must be caught by the chain check and its stretch redone: the fragments are those of the real records."""
+    import struct
+    read = 150
+    rng = np.random.default_rng(5)
+    n = 6000
+    size = 2_000_000
+    s = np.sort(rng.integers(1000, size - 2000, n))
+    length = rng.integers(160, 500, n)
+    rec = np.dtype([("block_size", "<i4"), ("ref", "<i4"), ("pos", "<i4"), ("l_name", "u1"), ("mapq", "u1"),
+                    ("bin", "<u2"), ("n_cigar", "<u2"), ("flag", "<u2"), ("l_seq", "<i4"), ("next_ref", "<i4"),
+                    ("next_pos", "<i4"), ("tlen", "<i4"), ("name", "S8"), ("cigar", "<u4"),
+                    ("seq", "u1", (read // 2,)), ("qual", "u1", (read,))])
+    a = np.zeros(n, rec)  # forward read1 records only: fragment = [pos, pos + tlen)
+    a["block_size"] = rec.itemsize - 4
+    a["l_name"], a["n_cigar"], a["l_seq"], a["cigar"] = 8, 1, read, read << 4
+    a["pos"], a["next_pos"], a["tlen"], a["flag"], a["mapq"] = s, s + length - read, length, 99, 60
+    a["name"] = np.char.zfill(np.arange(n).astype("U7"), 7).astype("S8")
+    decoy = struct.pack("<iiiBBHHHiiii", 33, 0, 777, 1, 60, 0, 0, 99, 0, 0, 900, 222) + b"\0"  # 37 bytes, a valid chain link
+    assert len(decoy) == 37
+    q = np.full(read, 30, np.uint8)
+    q[20:20 + 111] = np.frombuffer(decoy * 3, np.uint8)
+    a["qual"] = q
+    text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chrD\tLN:%d\n" % size
+    head = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1)
+    head += struct.pack("<i", 5) + b"chrD\0" + struct.pack("<i", size)
+    p = str(tmp_path / "decoy.bam")
+    bgzf.write_bgzf(p, head + a.tobytes(), level=1)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tests.test_stream_decoder import _stream\n"
+            "import pickle\n"
+            "got, order, _ = _stream(%r, bam=True, threads=16)\n"
+            "pickle.dump(got, open(%r, 'wb'))\n") % (ROOT, p, str(tmp_path / "got.pkl"))
+    import pickle
+    import re
+    for stretch in ("1000", "4096", "70000"):
+        r = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True,
+                           env=dict(os.environ, FTK_BAM_STRETCH=stretch, FTK_STREAM_PIECE=str(1 << 16),
+                                    FTK_DECODE_TIMING="1"))
+        m = re.search(r"(\d+) stretches of the record chain, (\d+) redone", r.stderr)
+        assert m and int(m.group(1)) >= 16 and int(m.group(2)) >= 1, r.stderr[-500:]  # decoys were entered
+        got = pickle.load(open(tmp_path / "got.pkl", "rb"))
+        rows, cols, length_ = got["chrD"]
+        assert rows == n and length_ == size, (stretch, rows)
+        assert np.array_equal(cols[0], s) and np.array_equal(cols[1], s + length)
 
 
 def test_stream_errors(tmp_path):
