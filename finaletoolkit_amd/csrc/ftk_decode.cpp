@@ -15,6 +15,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -1041,6 +1042,7 @@ struct BamRun {
 struct RawBuf {
     uint8_t* p = nullptr;
     size_t cap = 0;
+    size_t head = 0;  // data() starts here (the read-ahead piece leaves room in front for carried bytes)
     RawBuf() = default;
     RawBuf(const RawBuf&) = delete;
     RawBuf& operator=(const RawBuf&) = delete;
@@ -1055,7 +1057,12 @@ struct RawBuf {
         cap = want;
         return true;
     }
-    uint8_t* data() { return p; }
+    uint8_t* data() { return p + head; }
+    void swap(RawBuf& o) {
+        std::swap(p, o.p);
+        std::swap(cap, o.cap);
+        std::swap(head, o.head);
+    }
 };
 
 // Pack a contig held as a list of runs: one block (page-locked when a device is present), the runs
@@ -1350,25 +1357,62 @@ struct ftk_fragstream {
     long long read_end = -1;      // file offset to stop reading at (-1: none)
     bool partial_tail_ok = false;  // the range may end inside a block that belongs to the next contig
     size_t first_skip = 0;        // bytes of the first inflated block that precede the contig
-    // read the next piece after `carry` bytes already in buf; returns bytes now in buf
-    size_t fill(RawBuf& buf, size_t carry) {
-        if (!buf.reserve(carry + kStreamPiece)) return carry;
+    // One piece of the file -> dst; returns the bytes read (short at the end of the file / of the range).
+    size_t read_piece(uint8_t* dst) {
         size_t want = kStreamPiece;
         if (read_end >= 0) {
             const long long pos = ftell(fp);
             want = pos >= read_end ? 0 : (size_t)std::min<long long>((long long)kStreamPiece, read_end - pos);
         }
-        const size_t got = want ? fread(buf.data() + carry, 1, want, fp) : 0;
+        const size_t got = want ? fread(dst, 1, want, fp) : 0;
         if (got == want && want) {
-            // ask the kernel for the next piece now: a cold file is then read while this piece is
-            // inflated and parsed (a hint only; failure is ignored)
+            // ask the kernel for the piece after this one (a hint only; failure is ignored)
             const long long pos = ftell(fp);
             if (pos >= 0) (void)posix_fadvise(fileno(fp), (off_t)pos, (off_t)kStreamPiece, POSIX_FADV_WILLNEED);
         }
+        return got;
+    }
+    // Read-ahead: while a piece is inflated and parsed, a helper thread reads the next one into `ahead`,
+    // kHead bytes in: the bytes carried over (less than one BGZF block) are put in front of it and the two
+    // buffers trade places - the file read (12 GB/s from the page cache, far less from a cold disk)
+    // leaves the producer's critical path.  Only the helper touches `fp` while a read is in flight.
+    static constexpr size_t kHead = size_t(1) << 16;
+    RawBuf ahead;
+    std::future<size_t> ahead_got;
+    bool ahead_ok = true;  // false while the BAM header is probed before an index seek (the read would be thrown away)
+    void start_ahead() {
+        if (!ahead_ok || !ahead.reserve(kHead + kStreamPiece)) return;
+        ahead.head = 0;
+        ahead_got = std::async(std::launch::async, [this] { return read_piece(ahead.p + kHead); });
+    }
+    void drain_ahead() {  // before anything else moves the file position
+        if (ahead_got.valid()) (void)ahead_got.get();
+    }
+    // read the next piece after the `carry` bytes at the front of buf; returns bytes now in buf
+    size_t fill(RawBuf& buf, size_t carry) {
+        size_t got;
+        if (ahead_got.valid()) {
+            got = ahead_got.get();
+            if (carry <= kHead) {
+                if (carry) memcpy(ahead.p + kHead - carry, buf.data(), carry);
+                ahead.head = kHead - carry;
+            } else {  // (not with BGZF blocks, which are at most 64 KB)
+                if (!ahead.reserve(carry + kStreamPiece)) return carry;
+                memmove(ahead.p + carry, ahead.p + kHead, got);
+                memcpy(ahead.p, buf.data(), carry);
+                ahead.head = 0;
+            }
+            buf.swap(ahead);
+        } else {
+            if (!buf.reserve(buf.head + carry + kStreamPiece)) return carry;
+            got = read_piece(buf.data() + carry);
+        }
+        if (got == kStreamPiece) start_ahead();
         return carry + got;
     }
     // seek to a contig's rows; false = index unusable (caller scans the whole file)
     bool seek_to(const IndexSpan& sp) {
+        drain_ahead();
         if (fseek(fp, (long)(sp.beg >> 16), SEEK_SET) != 0) return false;
         first_skip = (size_t)(sp.beg & 0xffff);
         read_end = (long long)(sp.end >> 16) + 0x10000 + 64;  // through the block that holds the last row
@@ -1406,6 +1450,7 @@ struct ftk_fragstream {
 
 void ftk_fragstream::run_guarded() {
     RawBuf buf;
+    ahead_ok = !(bam && has_only);  // run_bam decides about the index seek after the header
     if (has_only && !bam) {  // tabix index: jump straight to the contig's rows
         const IndexSpan sp = index_lookup(index_path_of(path, false), false, only, -1);
         if (sp.usable && !sp.present) {  // the file has no row of this contig
@@ -1423,6 +1468,7 @@ void ftk_fragstream::run_guarded() {
     bool ok;
     if (!bgzf) {
         // not block-compressed (plain gzip): no block parallelism to stream; decode whole and hand out per contig
+        drain_ahead();
         fclose(fp);
         fp = nullptr;
         ftk_fragtable* whole = nullptr;
@@ -1653,6 +1699,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
                 goto next_piece;
             }
             header_done = true;
+            ahead_ok = true;
             if (has_only) {  // BAI: jump to the contig's records instead of walking the whole file
                 int target = -1;
                 for (size_t r = 0; r < ref_names.size(); ++r)
@@ -1890,6 +1937,7 @@ void ftk_fragstream_close(ftk_fragstream* s) {
         s->cv.notify_all();
     }
     if (s->producer.joinable()) s->producer.join();
+    s->drain_ahead();
     for (auto* t : s->ready) delete t;
     if (s->fp) fclose(s->fp);
     delete s;

@@ -55,8 +55,26 @@ static int stream(const char* path, bool bam, int threads, long* rows_out) {
     return rc;
 }
 
+// extra mode (the ThreadSanitizer run): `prog --files a.frag.gz b.bam ...` decodes each file whole and
+// streamed (many pieces when FTK_STREAM_PIECE is small) on several threads; the row counts must agree
+static int files_mode(int argc, char** argv) {
+    for (int i = 2; i < argc; ++i) {
+        const std::string f = argv[i];
+        const bool bam = f.size() > 4 && f.compare(f.size() - 4, 4, ".bam") == 0;
+        long whole = -1, streamed = -2;
+        if (decode(f.c_str(), bam, 4, &whole) != FTK_OK || stream(f.c_str(), bam, 4, &streamed) != FTK_OK || whole != streamed ||
+            whole <= 0) {
+            fprintf(stderr, "FAIL %s whole=%ld streamed=%ld (%s)\n", f.c_str(), whole, streamed, ftk_fragtable_error());
+            return 1;
+        }
+    }
+    printf("decode_sanitize ok\n");
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
+    if (std::string(argv[1]) == "--files") return files_mode(argc, argv);
     std::string data = argv[1];
     long rows = 0;
     struct { const char* f; bool bam; long want; } cases[] = {
