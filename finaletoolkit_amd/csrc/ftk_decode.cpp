@@ -1751,6 +1751,14 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
                         if (!run || run->ref != ref_id) {
                             st.runs.push_back(BamRun{ref_id, {}});
                             run = &st.runs.back();
+                            // both mates of a pair are at least ~150 bytes each: room for the rest of the stretch
+                            const size_t guess = (until > o ? until - o : 0) / 300 + 16;
+                            run->c.start.reserve(guess);
+                            run->c.end.reserve(guess);
+                            run->c.mapq.reserve(guess);
+                            run->c.strand.reserve(guess);
+                            run->c.r1s.reserve(guess);
+                            run->c.r1e.reserve(guess);
                         }
                         bam_record(r, bs, run->c);
                     }
