@@ -704,6 +704,37 @@ Contig* find_or_add(ftk_fragtable* t, const std::string& name) {
     return &t->contigs.back();
 }
 
+// Sort 64-bit keys: one chunk per thread, then pairwise merges level by level.  Returns the thread count used.
+int sort_keys(std::vector<uint64_t>& key, int n_threads) {
+    const size_t m = key.size();
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(n_threads, 1), m / 65536));
+    if (nt == 1) {
+        std::sort(key.begin(), key.end());
+        return nt;
+    }
+    std::vector<uint64_t> tmp(m);
+    std::vector<size_t> cut(nt + 1);
+    for (int t = 0; t <= nt; ++t) cut[t] = m * (size_t)t / (size_t)nt;
+    parallel_run(nt, [&](int t) { std::sort(key.begin() + cut[t], key.begin() + cut[t + 1]); });
+    uint64_t* src = key.data();
+    uint64_t* dst = tmp.data();
+    while (cut.size() > 2) {  // merge neighbours; an odd last chunk is copied through
+        const size_t n_chunks = cut.size() - 1, n_pairs = n_chunks / 2;
+        parallel_run((int)((n_chunks + 1) / 2), [&](int t) {
+            const size_t a = cut[2 * t], mid = cut[2 * t + 1];
+            if ((size_t)t < n_pairs) std::merge(src + a, src + mid, src + mid, src + cut[2 * t + 2], dst + a);
+            else std::copy(src + a, src + mid, dst + a);
+        });
+        std::vector<size_t> next;
+        for (size_t k = 0; k < cut.size(); k += 2) next.push_back(cut[k]);
+        if (next.back() != m) next.push_back(m);
+        cut.swap(next);
+        std::swap(src, dst);
+    }
+    if (src != key.data()) key.swap(tmp);
+    return nt;
+}
+
 // Stable order by fragment start.  BAM fragments arrive in read1-position order, i.e. nearly sorted
 // (a reverse-strand read1 sits at the far end of its fragment), millions per contig: the keys
 // (start << 32 | file rank) are sorted in one chunk per thread, the chunks merged pairwise level by
@@ -716,33 +747,9 @@ void sort_by_start(Columns& c, int n_threads = 1) {
         std::iota(c.ord.begin(), c.ord.end(), 0);
     }
     if (std::is_sorted(c.start.begin(), c.start.end())) return;
-    std::vector<uint64_t> key(m), tmp;
+    std::vector<uint64_t> key(m);
     for (size_t i = 0; i < m; ++i) key[i] = ((uint64_t)(uint32_t)c.start[i] << 32) | (uint64_t)i;  // starts are >= 0
-    int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(n_threads, 1), m / 65536));
-    if (nt == 1) {
-        std::sort(key.begin(), key.end());
-    } else {
-        std::vector<size_t> cut(nt + 1);
-        for (int t = 0; t <= nt; ++t) cut[t] = m * (size_t)t / (size_t)nt;
-        parallel_run(nt, [&](int t) { std::sort(key.begin() + cut[t], key.begin() + cut[t + 1]); });
-        tmp.resize(m);
-        uint64_t* src = key.data();
-        uint64_t* dst = tmp.data();
-        while (cut.size() > 2) {  // merge neighbours; an odd last chunk is copied through
-            const size_t n_chunks = cut.size() - 1, n_pairs = n_chunks / 2;
-            parallel_run((int)((n_chunks + 1) / 2), [&](int t) {
-                const size_t a = cut[2 * t], mid = cut[2 * t + 1];
-                if ((size_t)t < n_pairs) std::merge(src + a, src + mid, src + mid, src + cut[2 * t + 2], dst + a);
-                else std::copy(src + a, src + mid, dst + a);
-            });
-            std::vector<size_t> next;
-            for (size_t k = 0; k < cut.size(); k += 2) next.push_back(cut[k]);
-            if (next.back() != m) next.push_back(m);
-            cut.swap(next);
-            std::swap(src, dst);
-        }
-        if (src != key.data()) key.swap(tmp);
-    }
+    const int nt = sort_keys(key, n_threads);
     Columns s;
     const bool r1 = !c.r1s.empty();
     s.start.resize(m); s.end.resize(m); s.mapq.resize(m); s.strand.resize(m);
@@ -1100,6 +1107,61 @@ void pack_parts(Contig& ct, int n_threads) {
     std::vector<Columns>().swap(ct.parts);
 }
 
+// A BAM contig held as runs in read1-position order -> its page-locked block in fragment-start order:
+// keys (start << 32 | file rank) built, sorted and merged in parallel, then every column gathered from
+// the runs straight into its final place - no concatenated or sorted intermediate copy of the contig.
+void pack_bam_parts(Contig& ct, int n_threads) {
+    std::vector<size_t> at;
+    size_t m = 0;
+    for (auto& c : ct.parts) { at.push_back(m); m += c.start.size(); }
+    at.push_back(m);
+    const size_t total = packed_bytes(m, true);
+    Packed& p = ct.p;
+    if (have_hip_device() && (p.base = pinned_alloc(total)) != nullptr) {
+        p.pinned = true;
+    } else {
+        p.base = malloc(total);
+        p.pinned = false;
+    }
+    if (!p.base) return;
+    place(p, (char*)p.base, m, true);
+    const size_t np = ct.parts.size();
+    if (m) {
+        std::vector<uint64_t> key(m);
+        {
+            std::atomic<size_t> next{0};
+            parallel_run((int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, np)), [&](int) {
+                for (;;) {
+                    const size_t k = next.fetch_add(1);
+                    if (k >= np) break;
+                    const std::vector<int32_t>& st = ct.parts[k].start;
+                    for (size_t i = 0; i < st.size(); ++i) key[at[k] + i] = ((uint64_t)(uint32_t)st[i] << 32) | (uint64_t)(at[k] + i);
+                }
+            });
+        }
+        int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(n_threads, 1), m / 65536));
+        if (!std::is_sorted(key.begin(), key.end())) nt = sort_keys(key, n_threads);
+        parallel_run(nt, [&](int t) {
+            size_t k = 0;
+            for (size_t i = m * (size_t)t / (size_t)nt, e = m * (size_t)(t + 1) / (size_t)nt; i < e; ++i) {
+                const size_t j = (size_t)(uint32_t)key[i];
+                while (j < at[k]) --k;            // nearly sorted: the run changes rarely
+                while (j >= at[k + 1]) ++k;
+                const Columns& c = ct.parts[k];
+                const size_t o = j - at[k];
+                p.start[i] = c.start[o];
+                p.end[i] = c.end[o];
+                p.mapq[i] = c.mapq[o];
+                p.strand[i] = c.strand[o];
+                p.r1s[i] = c.r1s[o];
+                p.r1e[i] = c.r1e[o];
+                p.ord[i] = (int32_t)j;
+            }
+        });
+    }
+    std::vector<Columns>().swap(ct.parts);
+}
+
 // Complete text lines [b, e) -> runs in file order (segments parsed in parallel).
 void parse_text_parallel(const char* b, const char* e, bool bed6, const char* only, int n_threads,
                          std::vector<Run>* out) {
@@ -1323,8 +1385,9 @@ struct ftk_fragstream {
             Contig& c = t->contigs[0];
             Stopwatch sw;
             if (!c.parts.empty()) {
-                pack_parts(c, n_threads);
-                sw.lap("packer: pack runs");
+                if (bam) pack_bam_parts(c, n_threads);
+                else pack_parts(c, n_threads);
+                sw.lap(bam ? "packer: sort + gather runs" : "packer: pack runs");
             } else {
                 if (bam) sort_by_start(c.c, n_threads);
                 sw.lap("packer: sort by start");
@@ -1639,6 +1702,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
     bool header_done = false;
     std::vector<int> wanted;    // ref id -> 1 when selected
     Contig cur;
+    size_t cur_rows = 0;
     int cur_ref = -1;
     std::set<int> seen;
     size_t pending_skip = 0;
@@ -1789,9 +1853,10 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
                 for (auto& r : st.runs) {
                     if (cur_ref >= 0 && r.ref != cur_ref) {
                         clk.lap(3);
-                        if (!cur.c.start.empty() && !emit(std::move(cur))) return false;
+                        if (cur_rows && !emit(std::move(cur))) return false;
                         clk.lap(4);
                         cur = Contig{};
+                        cur_rows = 0;
                         cur_ref = -1;
                     }
                     if (cur_ref < 0) {
@@ -1801,7 +1866,8 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
                         cur.name = ref_names[r.ref];
                         cur.length = ref_lens[r.ref];
                     }
-                    cur.c.append(r.c);
+                    cur_rows += r.c.start.size();
+                    if (!r.c.start.empty()) cur.parts.push_back(std::move(r.c));  // sorted / gathered by the packer
                 }
             clk.lap(3);
             carry = m - o;
@@ -1821,7 +1887,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
         }
     }
     clk.lap(5);
-    if (cur_ref >= 0 && !cur.c.start.empty() && !emit(std::move(cur))) return false;
+    if (cur_ref >= 0 && cur_rows && !emit(std::move(cur))) return false;
     clk.lap(4);
     clk.report("bam");
     if (clk.on) fprintf(stderr, "[ftk stream bam] %zu stretches of the record chain, %zu redone after the chain check\n", n_stretches, n_redone);
