@@ -1012,6 +1012,18 @@ int ftk_fragtable_is_pinned(const ftk_fragtable* t, int i) {
 }
 void ftk_fragtable_free(ftk_fragtable* t) { delete t; }
 
+int ftk_host_alloc(int64_t bytes, void** out) {
+    if (!out || bytes < 0) return dfail(FTK_ERR_INVALID, "ftk_host_alloc: bad argument");
+    *out = nullptr;
+    if (!have_hip_device()) return dfail(FTK_ERR_NO_DEVICE, "ftk_host_alloc: no HIP device (page-locked memory needs the driver)");
+    void* p = pinned_alloc((size_t)std::max<int64_t>(bytes, 1));
+    if (!p) return dfail(FTK_ERR_OOM, "ftk_host_alloc: cannot page-lock %lld bytes", (long long)bytes);
+    *out = p;
+    return FTK_OK;
+}
+
+void ftk_host_free(void* p) { pinned_free(p); }
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------

@@ -51,6 +51,29 @@ def savgol_operators(window: int, deg: int):
     return _SAVGOL[key]
 
 
+class _HostBlock:
+    """Owner of one page-locked host block (``ftk_host_alloc``); numpy arrays made from it keep it alive
+    through ``__array_interface__`` and the block goes back to the library's cache with the last of them."""
+
+    def __init__(self, lib, nbytes: int):
+        p = C.c_void_p()
+        rc = lib.ftk_host_alloc(int(nbytes), C.byref(p))
+        if rc != 0:
+            raise L.FtkError(rc, lib.ftk_fragtable_error().decode())
+        self._lib, self._ptr = lib, p.value
+        self.__array_interface__ = {"data": (p.value, False), "shape": (int(nbytes),), "typestr": "|u1", "version": 3}
+
+    def __del__(self):
+        if getattr(self, "_ptr", None):
+            self._lib.ftk_host_free(self._ptr)
+            self._ptr = None
+
+
+# results of at least this many bytes are handed out in page-locked memory (their device -> host copy is the
+# long leg of a per-base call); smaller ones are ordinary numpy arrays
+PINNED_RESULT_MIN = 8 << 20
+
+
 class Engine:
     def __init__(self, device: int = 0):
         self.lib = L.load()
@@ -81,6 +104,16 @@ class Engine:
 
     def __exit__(self, *exc):
         self.close()
+
+    def result_array(self, n: int, dtype) -> np.ndarray:
+        """Uninitialised result array of ``n`` elements: page-locked (``ftk_host_alloc``) when large, so that
+        the copy back from the device is one DMA; the memory returns to the library's cache when the array
+        (and every view of it) is gone."""
+        dt = np.dtype(dtype)
+        nbytes = int(n) * dt.itemsize
+        if nbytes < PINNED_RESULT_MIN:
+            return np.empty(int(n), dt)
+        return np.asarray(_HostBlock(self.lib, nbytes)).view(dt)
 
     def _check(self, rc):
         if rc != L.FTK_OK:
@@ -369,7 +402,7 @@ class Engine:
             max_length=180, quality_threshold=30, out=None):
         """a7: WPS per base of [start, stop) (frag/_wps.py:156-188)."""
         n_pos = max(int(stop) - int(start), 0)
-        res = np.zeros(n_pos, np.int64) if out is None else out
+        res = self.result_array(n_pos, np.int64) if out is None else out  # every element is written by the call
         self._check(self.lib.ftk_wps(self.ctx, self.contig_id(name), int(start), int(stop), int(chrom_size),
                                      int(window_size), int(min_length), int(max_length), int(quality_threshold),
                                      L.ptr(res)))

@@ -126,6 +126,42 @@ def test_wps_whole_contig_sum_property(engine, data):
     assert np.array_equal(whole, tiled)
 
 
+def test_large_results_come_back_in_page_locked_memory(engine, data):
+    """Results of 8 MB and more are handed out in ftk_host_alloc memory (one DMA instead of a staged copy):
+    same values as a caller-provided pageable array, alive after the owner is dropped, block recycled."""
+    import ctypes as C
+    import gc
+    from finaletoolkit_amd import engine as E
+    n = 1_500_000  # 12 MB of int64
+    got = engine.wps("synA", 100_000, 100_000 + n, CONTIG_LEN, 120, 120, 180, 30)
+    base = got
+    while isinstance(base, np.ndarray) and base.base is not None:
+        base = base.base
+    assert isinstance(base, E._HostBlock) and got.nbytes >= E.PINNED_RESULT_MIN
+    plain = np.empty(n, np.int64)
+    engine.wps("synA", 100_000, 100_000 + n, CONTIG_LEN, 120, 120, 180, 30, out=plain)
+    assert np.array_equal(got, plain)
+    part = got[1000:2000].copy()
+    view = got[1000:2000]
+    ptr = base._ptr
+    del got, base
+    gc.collect()
+    assert np.array_equal(view, part)      # the view keeps the block alive
+    del view
+    gc.collect()
+    again = engine.result_array(n, np.int64)  # (the freed block, or another cached one of that size)
+    again[:] = 7
+    assert ptr and int(again.sum()) == 7 * n
+    small = engine.result_array(100, np.int64)
+    assert small.base is None
+    # C ABI edge cases
+    lib = engine.lib
+    p = C.c_void_p()
+    assert lib.ftk_host_alloc(-1, C.byref(p)) != 0 and lib.ftk_host_alloc(0, C.byref(p)) == 0
+    lib.ftk_host_free(p)
+    lib.ftk_host_free(None)
+
+
 @pytest.mark.parametrize("policy", ["midpoint", "any"])
 def test_frag_select_and_lengths(engine, data, policy):
     for (a, b) in [(100_000, 160_000), (None, 5000), (2_990_000, None), (7, 8), (None, None)]:
