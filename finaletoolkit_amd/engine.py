@@ -72,6 +72,7 @@ class _HostBlock:
 # results of at least this many bytes are handed out in page-locked memory (their device -> host copy is the
 # long leg of a per-base call); smaller ones are ordinary numpy arrays
 PINNED_RESULT_MIN = 8 << 20
+_PINNED_RESULTS = __import__("os").environ.get("FTK_PINNED_RESULTS", "1") != "0"
 
 
 class Engine:
@@ -111,7 +112,7 @@ class Engine:
         (and every view of it) is gone."""
         dt = np.dtype(dtype)
         nbytes = int(n) * dt.itemsize
-        if nbytes < PINNED_RESULT_MIN:
+        if nbytes < PINNED_RESULT_MIN or not _PINNED_RESULTS:
             return np.empty(int(n), dt)
         return np.asarray(_HostBlock(self.lib, nbytes)).view(dt)
 
