@@ -418,7 +418,7 @@ class Engine:
         lens = np.maximum(e - s, 0)
         offs = np.zeros(len(s) + 1, np.int64)
         np.cumsum(lens, out=offs[1:])
-        out = np.zeros(int(offs[-1]), np.int64)
+        out = self.result_array(int(offs[-1]), np.int64)  # the intervals tile it: every element is written
         if len(s) and offs[-1] > 0:
             self._check(self.lib.ftk_wps_intervals(self.ctx, self.contig_id(name), L.ptr(s), L.ptr(e), len(s),
                                                    L.ptr(np.ascontiguousarray(offs[:-1])), int(chrom_size),
@@ -433,7 +433,7 @@ class Engine:
         e = np.ascontiguousarray(stops, dtype=np.int64)
         offs = np.zeros(len(s) + 1, np.int64)
         np.cumsum(np.maximum(e - s, 0), out=offs[1:])
-        out = np.zeros(int(offs[-1]), np.float64)
+        out = self.result_array(int(offs[-1]), np.float64)  # the intervals tile it: every element is written
         if len(s) and offs[-1] > 0:
             self._check(self.lib.ftk_cleavage_intervals(
                 self.ctx, self.contig_id(name), L.ptr(s), L.ptr(e), len(s), L.ptr(np.ascontiguousarray(offs[:-1])),
