@@ -248,60 +248,89 @@ bool have_hip_device() {
 // Page-locked blocks are recycled: hipHostMalloc has to pin every page (about 0.2 ms per MB), and a
 // streamed file asks for one block per contig and frees it a moment later.  A few freed blocks are kept
 // (at most 8, 2 GiB in total) and handed to the next request they fit without wasting more than half.
+// Page-locked blocks are recycled: pinning costs ~0.07-0.2 ms per MB, unpinning about as much.  Two
+// caches: the decoder's contig tables (a block is reused for a request of at least half its size, so that
+// a small table does not sit on a huge block), and the callers' result arrays (ftk_host_alloc: any block
+// that is large enough - results shrink from contig to contig and one block then serves them all).
 struct PinnedCache {
     struct Blk { void* p; size_t cap; };
+    const bool any_larger;   // reuse a block of any size >= the request
+    const size_t max_bytes;  // held in the free list at most
+    const size_t max_live;   // handed out at most (0: no limit); beyond it alloc() fails and the caller uses pageable memory
+    size_t live_bytes = 0;
     std::mutex mu;
     std::vector<Blk> free_list;
     std::vector<Blk> live;  // capacity of the blocks handed out (needed when they come back)
     size_t cached = 0;
+    PinnedCache(bool any, size_t cap, size_t live_cap) : any_larger(any), max_bytes(cap), max_live(live_cap) {}
+
+    void* alloc(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (max_live && live_bytes + bytes > max_live) return nullptr;
+            int best = -1;
+            for (int i = 0; i < (int)free_list.size(); ++i)
+                if (free_list[i].cap >= bytes && (any_larger || free_list[i].cap <= 2 * bytes + (1 << 20)) &&
+                    (best < 0 || free_list[i].cap < free_list[best].cap))
+                    best = i;
+            if (best >= 0) {
+                Blk b = free_list[best];
+                free_list.erase(free_list.begin() + best);
+                cached -= b.cap;
+                live.push_back(b);
+                live_bytes += b.cap;
+                return b.p;
+            }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        live.push_back({p, bytes});
+        live_bytes += bytes;
+        return p;
+    }
+
+    bool release(void* p) {  // false: not one of this cache's blocks
+        size_t cap = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < live.size(); ++i)
+                if (live[i].p == p) { cap = live[i].cap; live.erase(live.begin() + i); break; }
+            if (!cap) return false;
+            live_bytes -= cap;
+            if (free_list.size() < 8 && cached + cap <= max_bytes) {
+                free_list.push_back({p, cap});
+                cached += cap;
+                return true;
+            }
+        }
+        (void)hipHostFree(p);
+        return true;
+    }
 };
-PinnedCache& pinned_cache() {
-    static PinnedCache* c = new PinnedCache();  // leaked: the driver unpins at process exit
+// leaked on purpose: the driver unpins at process exit
+PinnedCache& table_cache() {
+    static PinnedCache* c = new PinnedCache(false, size_t(2) << 30, 0);
+    return *c;
+}
+PinnedCache& result_cache() {
+    // at most 8 GB of result arrays are page-locked at a time (a caller that keeps every contig's per-base
+    // scores would otherwise lock tens of GB); FTK_PINNED_RESULT_LIMIT_MB overrides
+    static PinnedCache* c = [] {
+        const char* e = getenv("FTK_PINNED_RESULT_LIMIT_MB");
+        const long long mb = e ? atoll(e) : 8192;
+        return new PinnedCache(true, size_t(6) << 30, (size_t)std::max<long long>(mb, 1) << 20);
+    }();
     return *c;
 }
 
-void* pinned_alloc(size_t bytes) {
-    PinnedCache& c = pinned_cache();
-    {
-        std::lock_guard<std::mutex> lk(c.mu);
-        int best = -1;
-        for (int i = 0; i < (int)c.free_list.size(); ++i)
-            if (c.free_list[i].cap >= bytes && c.free_list[i].cap <= 2 * bytes + (1 << 20) &&
-                (best < 0 || c.free_list[i].cap < c.free_list[best].cap))
-                best = i;
-        if (best >= 0) {
-            PinnedCache::Blk b = c.free_list[best];
-            c.free_list.erase(c.free_list.begin() + best);
-            c.cached -= b.cap;
-            c.live.push_back(b);
-            return b.p;
-        }
-    }
-    void* p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    std::lock_guard<std::mutex> lk(c.mu);
-    c.live.push_back({p, bytes});
-    return p;
-}
+void* pinned_alloc(size_t bytes) { return table_cache().alloc(bytes); }
 
 void pinned_free(void* p) {
-    if (!p) return;
-    PinnedCache& c = pinned_cache();
-    size_t cap = 0;
-    {
-        std::lock_guard<std::mutex> lk(c.mu);
-        for (size_t i = 0; i < c.live.size(); ++i)
-            if (c.live[i].p == p) { cap = c.live[i].cap; c.live.erase(c.live.begin() + i); break; }
-        if (cap && c.free_list.size() < 8 && c.cached + cap <= (2ull << 30)) {
-            c.free_list.push_back({p, cap});
-            c.cached += cap;
-            return;
-        }
-    }
-    (void)hipHostFree(p);
+    if (p) (void)table_cache().release(p);
 }
 
 // Lay a contig's final columns out inside an existing block (no copy).
@@ -1016,13 +1045,15 @@ int ftk_host_alloc(int64_t bytes, void** out) {
     if (!out || bytes < 0) return dfail(FTK_ERR_INVALID, "ftk_host_alloc: bad argument");
     *out = nullptr;
     if (!have_hip_device()) return dfail(FTK_ERR_NO_DEVICE, "ftk_host_alloc: no HIP device (page-locked memory needs the driver)");
-    void* p = pinned_alloc((size_t)std::max<int64_t>(bytes, 1));
-    if (!p) return dfail(FTK_ERR_OOM, "ftk_host_alloc: cannot page-lock %lld bytes", (long long)bytes);
+    void* p = result_cache().alloc((size_t)std::max<int64_t>(bytes, 1));
+    if (!p) return dfail(FTK_ERR_OOM, "ftk_host_alloc: cannot page-lock %lld more bytes (driver refusal or the limit on page-locked results)", (long long)bytes);
     *out = p;
     return FTK_OK;
 }
 
-void ftk_host_free(void* p) { pinned_free(p); }
+void ftk_host_free(void* p) {
+    if (p) (void)result_cache().release(p);  // a pointer that is not one of ours is ignored
+}
 
 }  // extern "C"
 

@@ -114,7 +114,12 @@ class Engine:
         nbytes = int(n) * dt.itemsize
         if nbytes < PINNED_RESULT_MIN or not _PINNED_RESULTS:
             return np.empty(int(n), dt)
-        return np.asarray(_HostBlock(self.lib, nbytes)).view(dt)
+        try:
+            return np.asarray(_HostBlock(self.lib, nbytes)).view(dt)
+        except L.FtkError as e:
+            if e.code != L.FTK_ERR_OOM:
+                raise
+            return np.empty(int(n), dt)  # the limit on page-locked results is reached: ordinary memory
 
     def _check(self, rc):
         if rc != L.FTK_OK:

@@ -175,7 +175,8 @@ void ftk_fragtable_free(ftk_fragtable* t);
 /* Page-locked host memory for large result arrays (the per-base scores of frag/_wps.py:181-188 are
  * 8 bytes a base): a device -> host copy into it is one DMA at PCIe speed, into pageable memory a staged
  * copy at a third to half of that.  Blocks are recycled by ftk_host_free (pinning costs ~0.2 ms per MB).
- * FTK_ERR_NO_DEVICE without a HIP device, FTK_ERR_OOM when the driver refuses. */
+ * FTK_ERR_NO_DEVICE without a HIP device; FTK_ERR_OOM when the driver refuses or more than 8 GB
+ * (FTK_PINNED_RESULT_LIMIT_MB) would be outstanding - the caller then uses ordinary memory. */
 int ftk_host_alloc(int64_t bytes, void** out);
 void ftk_host_free(void* p);
 /* Upload contig i of a decoded table (including the BAM read1 columns) as contig_id: the

@@ -2,12 +2,15 @@
 GPU parity: every kernel, through the C ABI, against the C oracle on the same
 seeded synthetic fragments.  Integer results must be bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 
 from finaletoolkit_amd import synth
 from oracle import oracle as O
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 CONTIG_LEN = 3_000_000
@@ -156,12 +159,49 @@ def test_large_results_come_back_in_page_locked_memory(engine, data):
     assert ptr and int(again.sum()) == 7 * n
     small = engine.result_array(100, np.int64)
     assert small.base is None
+    del again
+    gc.collect()
+    # a smaller request takes the cached larger block (results shrink from contig to contig)
+    smaller = engine.result_array(n // 3 + 2_000_000 // 8, np.int64)
+    b3 = smaller
+    while isinstance(b3, np.ndarray) and b3.base is not None:
+        b3 = b3.base
+    assert isinstance(b3, E._HostBlock)
+    del smaller, b3
+    gc.collect()
     # C ABI edge cases
     lib = engine.lib
     p = C.c_void_p()
     assert lib.ftk_host_alloc(-1, C.byref(p)) != 0 and lib.ftk_host_alloc(0, C.byref(p)) == 0
     lib.ftk_host_free(p)
     lib.ftk_host_free(None)
+    junk = (C.c_char * 64)()
+    lib.ftk_host_free(C.cast(junk, C.c_void_p))  # not one of the library's blocks: ignored
+
+
+def test_page_locked_result_limit_falls_back_to_ordinary_memory():
+    """Beyond FTK_PINNED_RESULT_LIMIT_MB of outstanding results ftk_host_alloc refuses and result_array hands
+    out an ordinary numpy array (child process: the limit is read once)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from finaletoolkit_amd import engine as E\n"
+            "eng = E.Engine(0)\n"
+            "def owner(a):\n"
+            "    while isinstance(a, np.ndarray) and a.base is not None: a = a.base\n"
+            "    return a\n"
+            "a = eng.result_array(3 << 20, np.int64)   # 24 MB: page-locked\n"
+            "b = eng.result_array(3 << 20, np.int64)   # 48 MB outstanding > 40 MB: ordinary\n"
+            "assert isinstance(owner(a), E._HostBlock) and not isinstance(owner(b), E._HostBlock)\n"
+            "a[:] = 1; b[:] = 2\n"
+            "del a\n"
+            "c = eng.result_array(3 << 20, np.int64)   # room again\n"
+            "assert isinstance(owner(c), E._HostBlock)\n"
+            "print('ok')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                       env=dict(os.environ, FTK_PINNED_RESULT_LIMIT_MB="40"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("policy", ["midpoint", "any"])
