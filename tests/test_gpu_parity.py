@@ -162,7 +162,7 @@ def test_large_results_come_back_in_page_locked_memory(engine, data):
     del again
     gc.collect()
     # a smaller request takes the cached larger block (results shrink from contig to contig)
-    smaller = engine.result_array(n // 3 + 2_000_000 // 8, np.int64)
+    smaller = engine.result_array(3 * n // 4, np.int64)  # 9 MB
     b3 = smaller
     while isinstance(b3, np.ndarray) and b3.base is not None:
         b3 = b3.base
