@@ -418,6 +418,12 @@ int ftk_frags_from_table(ftk_ctx* ctx, int contig_id, const ftk_fragtable* t, in
     if (ftk_fragtable_columns(t, i, &s0, &e0, &q0, &st0, &r1s, &r1e) != FTK_OK)
         return fail(ctx, FTK_ERR_NO_CONTIG, "table has no contig %d", i);
     const int64_t n = ftk_fragtable_contig_rows(t, i);
+    if (ftk_fragtable_is_device(t, i)) {
+        // columns parsed on the GPU (ftk_fragstream_open_device): ordered behind the parse stream's last write
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)ftk_fragtable_ready_event(t, i), 0));
+        return upload_common(ctx, contig_id, s0, e0, q0, st0, n, hipMemcpyDeviceToDevice);
+    }
     int rc = upload_common(ctx, contig_id, s0, e0, q0, st0, n, hipMemcpyHostToDevice);
     if (rc) return rc;
     if (r1s && r1e) rc = ftk_frags_set_read1(ctx, contig_id, r1s, r1e, n);
@@ -432,7 +438,8 @@ static int load_file(ftk_ctx* ctx, const char* path, const char* contig, int is_
     if (!path) return fail(ctx, FTK_ERR_INVALID, "path is NULL");
     if (n_loaded_out) *n_loaded_out = 0;
     ftk_fragstream* st = nullptr;
-    int rc = ftk_fragstream_open(path, contig, is_bam, n_threads, 2, &st);
+    int rc = is_bam ? ftk_fragstream_open(path, contig, is_bam, n_threads, 2, &st)
+                    : ftk_fragstream_open_device(ctx->device, path, contig, 0, n_threads, 2, &st);
     if (rc != FTK_OK) return fail(ctx, rc, "%s", ftk_fragtable_error());
     int id = first_contig_id, n = 0;
     for (;;) {

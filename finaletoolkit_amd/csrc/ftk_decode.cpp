@@ -34,6 +34,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "ftk.h"
+#include "ftk_textparse.h"
 
 namespace {
 
@@ -228,9 +229,74 @@ struct Packed {
     uint8_t *mapq = nullptr, *strand = nullptr;
 };
 
+// A contig whose columns live in device memory (the streaming text decoder with the GPU row parser):
+// grown piece by piece with device-to-device copies on the parse stream; `ready` is recorded behind the
+// last copy and waited for by the stream that consumes the columns.
+struct DevColumns {
+    int32_t *start = nullptr, *end = nullptr;
+    uint8_t *mapq = nullptr, *strand = nullptr;
+    size_t rows = 0, cap = 0;
+    int device = 0;
+    hipEvent_t ready = nullptr;
+    DevColumns() = default;
+    DevColumns(const DevColumns&) = delete;
+    DevColumns& operator=(const DevColumns&) = delete;
+    ~DevColumns() {
+        (void)hipSetDevice(device);
+        if (start) (void)hipFree(start);
+        if (end) (void)hipFree(end);
+        if (mapq) (void)hipFree(mapq);
+        if (strand) (void)hipFree(strand);
+        if (ready) (void)hipEventDestroy(ready);
+    }
+    // room for `more` rows; existing rows are moved on `s` (which is drained before the old arrays go)
+    bool reserve(size_t more, hipStream_t s) {
+        if (rows + more <= cap) return true;
+        const size_t want = std::max<size_t>(std::max(rows + more, 2 * cap), size_t(1) << 20);
+        int32_t *ns = nullptr, *ne = nullptr;
+        uint8_t *nq = nullptr, *nt = nullptr;
+        bool ok = hipMalloc((void**)&ns, want * 4) == hipSuccess && hipMalloc((void**)&ne, want * 4) == hipSuccess &&
+                  hipMalloc((void**)&nq, want) == hipSuccess && hipMalloc((void**)&nt, want) == hipSuccess;
+        if (ok && rows) {
+            ok = hipMemcpyAsync(ns, start, rows * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(ne, end, rows * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(nq, mapq, rows, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(nt, strand, rows, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                 hipStreamSynchronize(s) == hipSuccess;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            if (ns) (void)hipFree(ns);
+            if (ne) (void)hipFree(ne);
+            if (nq) (void)hipFree(nq);
+            if (nt) (void)hipFree(nt);
+            return false;
+        }
+        if (start) { (void)hipFree(start); (void)hipFree(end); (void)hipFree(mapq); (void)hipFree(strand); }
+        start = ns; end = ne; mapq = nq; strand = nt;
+        cap = want;
+        return true;
+    }
+    // append n rows from device (kind D2D) or host (H2D; the call returns when the source may be released)
+    bool append(const int32_t* s0, const int32_t* e0, const uint8_t* q0, const uint8_t* t0, size_t n, hipMemcpyKind kind,
+                hipStream_t s) {
+        if (!n) return true;
+        if (!reserve(n, s)) return false;
+        bool ok = hipMemcpyAsync(start + rows, s0, n * 4, kind, s) == hipSuccess &&
+                  hipMemcpyAsync(end + rows, e0, n * 4, kind, s) == hipSuccess &&
+                  hipMemcpyAsync(mapq + rows, q0, n, kind, s) == hipSuccess &&
+                  hipMemcpyAsync(strand + rows, t0, n, kind, s) == hipSuccess;
+        if (ok && kind == hipMemcpyHostToDevice) ok = hipStreamSynchronize(s) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); return false; }
+        rows += n;
+        return true;
+    }
+};
+
 struct Contig {
     std::string name;
     int64_t length = -1;
+    std::shared_ptr<DevColumns> dev;  // set instead of c / parts / p.base when the columns are device-resident
     Columns c;   // parse-time storage, emptied by pack()
     std::vector<Columns> parts;  // streaming text decoder: the contig's runs in order, packed without merging
     Packed p;
@@ -1041,6 +1107,39 @@ int ftk_fragtable_is_pinned(const ftk_fragtable* t, int i) {
 }
 void ftk_fragtable_free(ftk_fragtable* t) { delete t; }
 
+int ftk_fragtable_is_device(const ftk_fragtable* t, int i) {
+    return (t && i >= 0 && i < (int)t->contigs.size() && t->contigs[i].dev) ? 1 : 0;
+}
+
+void* ftk_fragtable_ready_event(const ftk_fragtable* t, int i) {
+    return ftk_fragtable_is_device(t, i) ? (void*)t->contigs[i].dev->ready : nullptr;
+}
+
+int ftk_fragtable_columns_to_host(const ftk_fragtable* t, int i, int32_t* start, int32_t* end, uint8_t* mapq,
+                                  uint8_t* strand) {
+    if (!t || i < 0 || i >= (int)t->contigs.size()) return dfail(FTK_ERR_NO_CONTIG, "contig index %d out of range", i);
+    const Contig& ct = t->contigs[i];
+    const size_t n = ct.p.rows;
+    if (!ct.dev) {
+        if (start && n) memcpy(start, ct.p.start, n * 4);
+        if (end && n) memcpy(end, ct.p.end, n * 4);
+        if (mapq && n) memcpy(mapq, ct.p.mapq, n);
+        if (strand && n) memcpy(strand, ct.p.strand, n);
+        return FTK_OK;
+    }
+    const DevColumns& d = *ct.dev;
+    bool ok = hipSetDevice(d.device) == hipSuccess && hipEventSynchronize(d.ready) == hipSuccess;
+    if (ok && start && n) ok = hipMemcpy(start, d.start, n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && end && n) ok = hipMemcpy(end, d.end, n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && mapq && n) ok = hipMemcpy(mapq, d.mapq, n, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && strand && n) ok = hipMemcpy(strand, d.strand, n, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        return dfail(FTK_ERR_HIP, "cannot copy the device columns to the host");
+    }
+    return FTK_OK;
+}
+
 int ftk_host_alloc(int64_t bytes, void** out) {
     if (!out || bytes < 0) return dfail(FTK_ERR_INVALID, "ftk_host_alloc: bad argument");
     *out = nullptr;
@@ -1411,6 +1510,13 @@ struct ftk_fragstream {
     std::vector<int64_t> ref_lens;
     bool header_ready = false;
 
+    // Text files on a stream opened with ftk_fragstream_open_on: the rows are parsed on this GPU
+    // (run_text_device) and the tables handed out hold device columns.
+    int device = -1;
+    hipStream_t pstream = nullptr;
+    bool emit_device(Contig&& ct);
+    bool run_text_device(RawBuf& first, size_t first_n);
+
     // Hand one finished contig to the consumer.  Sorting (BAM), packing into page-locked memory and
     // waiting for queue space happen on a helper thread, one contig at a time (so the order is kept),
     // while the producer already decodes the next contig's pieces.
@@ -1608,7 +1714,7 @@ void ftk_fragstream::run_guarded() {
         }
         ok = true;
     } else {
-        ok = bam ? run_bam(buf, n) : run_text(buf, n);
+        ok = bam ? run_bam(buf, n) : device >= 0 ? run_text_device(buf, n) : run_text(buf, n);
     }
     (void)ok;
     flush();
@@ -1733,6 +1839,250 @@ bool ftk_fragstream::run_text(RawBuf& buf, size_t n) {
     if (have_cur && !emit(std::move(cur))) return false;
     clk.lap(4);
     clk.report("text");
+    return true;
+}
+
+namespace {
+// One of the two buffer sets of the device row parser: page-locked host text (the inflate target and the
+// DMA source), the device copy, the kernels' scratch and outputs, and the summary that comes back.
+struct DevSet {
+    uint8_t* h_text = nullptr;
+    uint8_t* d_text = nullptr;
+    size_t cap = 0, max_lines = 0;
+    uint32_t *d_blocks = nullptr, *d_lines = nullptr;
+    int32_t *d_s = nullptr, *d_e = nullptr;
+    uint8_t *d_q = nullptr, *d_t = nullptr;
+    ftk::TextSummary* d_sum = nullptr;
+    ftk::TextSummary* h_sum = nullptr;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+    size_t off = 0, len = 0;  // the launched range of h_text (complete lines)
+
+    void release() {
+        if (h_text) (void)hipHostFree(h_text);
+        if (h_sum) (void)hipHostFree(h_sum);
+        for (void* q : {(void*)d_text, (void*)d_blocks, (void*)d_lines, (void*)d_s, (void*)d_e, (void*)d_q, (void*)d_t, (void*)d_sum})
+            if (q) (void)hipFree(q);
+        if (done) (void)hipEventDestroy(done);
+        *this = DevSet{};
+    }
+    // room for `bytes` of text; false: out of (page-locked or device) memory
+    bool ensure(size_t bytes) {
+        if (bytes <= cap) return true;
+        release();
+        const size_t want = bytes + bytes / 4 + 4096;
+        const size_t lines = want / 10 + 1;  // a plain row is at least 10 bytes; more lines -> the host parses the piece
+        bool ok = hipHostMalloc((void**)&h_text, want, hipHostMallocDefault) == hipSuccess &&
+                  hipHostMalloc((void**)&h_sum, sizeof(ftk::TextSummary), hipHostMallocDefault) == hipSuccess &&
+                  hipMalloc((void**)&d_text, want) == hipSuccess &&
+                  hipMalloc((void**)&d_blocks, (want / ftk::kTextBlockBytes + 2) * 4) == hipSuccess &&
+                  hipMalloc((void**)&d_lines, (lines + 2) * 4) == hipSuccess &&
+                  hipMalloc((void**)&d_s, lines * 4) == hipSuccess && hipMalloc((void**)&d_e, lines * 4) == hipSuccess &&
+                  hipMalloc((void**)&d_q, lines) == hipSuccess && hipMalloc((void**)&d_t, lines) == hipSuccess &&
+                  hipMalloc((void**)&d_sum, sizeof(ftk::TextSummary)) == hipSuccess &&
+                  hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            release();
+            return false;
+        }
+        cap = want;
+        max_lines = lines;
+        return true;
+    }
+};
+}  // namespace
+
+bool ftk_fragstream::emit_device(Contig&& ct) {
+    DevColumns& d = *ct.dev;
+    if (hipEventCreateWithFlags(&d.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(d.ready, pstream) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FTK_ERR_HIP, "cannot record the contig's ready event");
+    }
+    std::unique_ptr<ftk_fragtable> t(new ftk_fragtable());
+    t->bed6 = bed6;
+    ct.p.rows = d.rows;
+    ct.p.start = d.start;
+    ct.p.end = d.end;
+    ct.p.mapq = d.mapq;
+    ct.p.strand = d.strand;
+    t->contigs.push_back(std::move(ct));
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return stop || ready.size() < max_queued; });
+    if (stop) return false;
+    ready.push_back(t.release());
+    cv.notify_all();
+    return true;
+}
+
+// run_text with the row parser on the GPU.  Per piece: inflate into page-locked text (host threads), one
+// DMA, four kernels, 8 KB of summary back - all asynchronous on the parse stream, and while they run the
+// host already inflates the next piece into the other buffer set.  When a piece's summary says "plain
+// rows only" its columns are appended to the current contig device-to-device, split at the contig runs the
+// kernel listed (the names are read from the host copy of the text); any other piece goes through the
+// host's field-rule parser (parse_text_parallel) and its columns are uploaded - same rows either way.
+bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
+    StageClock clk;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FTK_ERR_HIP, "cannot create the parse stream");
+    }
+    DevSet sets[2];
+    struct Cleanup {
+        DevSet* s;
+        ~Cleanup() { s[0].release(); s[1].release(); }
+    } cleanup{sets};
+    std::vector<Block> blocks;
+    size_t carry = 0;
+    const uint8_t* carry_src = nullptr;
+    bool layout_known = false;
+    Contig cur;
+    bool have_cur = false;
+    std::set<std::string> seen;
+    size_t gpu_pieces = 0, host_pieces = 0;
+
+    // one contig run of a piece: n rows at the given column pointers (device or host)
+    auto take_run = [&](const std::string& name, const int32_t* s0, const int32_t* e0, const uint8_t* q0, const uint8_t* t0,
+                        size_t rows, hipMemcpyKind kind) -> bool {
+        if (has_only && name != only) return true;
+        if (have_cur && name != cur.name) {
+            if (!emit_device(std::move(cur))) return false;
+            cur = Contig{};
+            have_cur = false;
+        }
+        if (!have_cur) {
+            if (!seen.insert(name).second)
+                return fail(FTK_ERR_UNSORTED, ("contig " + name + " appears in two separate runs: the file is not sorted").c_str());
+            cur.name = name;
+            cur.dev.reset(new DevColumns());
+            cur.dev->device = device;
+            have_cur = true;
+        }
+        if (!cur.dev->append(s0, e0, q0, t0, rows, kind, pstream)) return fail(FTK_ERR_OOM, "out of device memory for the contig's columns");
+        return true;
+    };
+
+    auto collect = [&](DevSet& S) -> bool {
+        if (hipEventSynchronize(S.done) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(FTK_ERR_HIP, "the device row parser failed");
+        }
+        S.pending = false;
+        const ftk::TextSummary& sum = *S.h_sum;
+        const char* b = (const char*)S.h_text + S.off;
+        const bool plain = !sum.overflow && sum.n_bad == 0 && sum.n_runs >= 1 && sum.n_runs <= (unsigned)ftk::kTextMaxRuns &&
+                           sum.n_lines <= S.max_lines;
+        if (plain) {
+            ++gpu_pieces;
+            std::vector<std::pair<unsigned, unsigned>> runs(sum.n_runs);
+            for (unsigned r = 0; r < sum.n_runs; ++r) runs[r] = {sum.run_line[r], sum.run_off[r]};
+            std::sort(runs.begin(), runs.end());
+            for (size_t r = 0; r < runs.size(); ++r) {
+                const char* nb = b + runs[r].second;
+                const char* tab = (const char*)memchr(nb, '\t', S.len - runs[r].second);
+                if (!tab) return fail(FTK_ERR_FORMAT, "device row parser: run without a name");
+                const size_t l0 = runs[r].first, l1 = r + 1 < runs.size() ? runs[r + 1].first : (size_t)sum.n_lines;
+                if (!take_run(std::string(nb, (size_t)(tab - nb)), S.d_s + l0, S.d_e + l0, S.d_q + l0, S.d_t + l0, l1 - l0,
+                              hipMemcpyDeviceToDevice))
+                    return false;
+            }
+        } else {
+            ++host_pieces;
+            std::vector<Run> runs;
+            parse_text_parallel(b, b + S.len, bed6, has_only ? only.c_str() : nullptr, n_threads, &runs);
+            for (auto& r : runs)
+                if (!take_run(r.name, r.c.start.data(), r.c.end.data(), r.c.mapq.data(), r.c.strand.data(), r.c.start.size(),
+                              hipMemcpyHostToDevice))
+                    return false;
+        }
+        return true;
+    };
+
+    bool eof = n < kStreamPiece;
+    DevSet* prev = nullptr;
+    for (int k = 0;; ++k) {
+        size_t used = 0, total = 0;
+        if (!whole_blocks(buf.data(), n, eof, &blocks, &used, &total)) return fail(FTK_ERR_FORMAT, "corrupt BGZF block");
+        DevSet& S = sets[k & 1];
+        if (S.pending && !collect(S)) return false;
+        if (!S.ensure(carry + total + 2)) return fail(FTK_ERR_OOM, "out of page-locked / device memory for the text piece");
+        if (carry) memcpy(S.h_text, carry_src, carry);
+        clk.lap(5);
+        if (!blocks.empty() && inflate_block_list(buf.data(), blocks, n_threads, S.h_text + carry) != FTK_OK)
+            return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+        clk.lap(1);
+        char* b = (char*)S.h_text;
+        char* e = b + carry + total;
+        if (first_skip) {  // after an index seek: the contig starts inside the first block
+            b += std::min<size_t>(first_skip, (size_t)(e - b));
+            first_skip = 0;
+        }
+        if (!layout_known) {  // io/alignment.py:143-156: BED6 when the first data row has > 5 columns
+            const char* q = b;
+            while (q < e) {
+                const char* nl = (const char*)memchr(q, '\n', (size_t)(e - q));
+                const char* le = nl ? nl : e;
+                if (le > q && *q != '#') {
+                    int tabs = 0;
+                    for (const char* x = q; x < le; ++x) tabs += (*x == '\t');
+                    bed6 = (tabs + 1) > 5;
+                    layout_known = true;
+                    break;
+                }
+                if (!nl) break;
+                q = nl + 1;
+            }
+        }
+        char* last = e;
+        if (!eof) {
+            while (last > b && last[-1] != '\n') --last;
+        } else if (e > b && e[-1] != '\n') {
+            *e++ = '\n';  // the last row of the file has no line end: give it one (the buffer has the room)
+            last = e;
+        }
+        if (last > b) {
+            S.off = (size_t)(b - (char*)S.h_text);
+            S.len = (size_t)(last - b);
+            bool ok = hipMemsetAsync(S.d_sum, 0, sizeof(ftk::TextSummary), pstream) == hipSuccess &&
+                      hipMemcpyAsync(S.d_text, b, S.len, hipMemcpyHostToDevice, pstream) == hipSuccess;
+            if (ok) {
+                ftk::textparse_launch(pstream, S.d_text, S.len, bed6, S.d_blocks, S.d_lines, S.max_lines, S.d_s, S.d_e, S.d_q,
+                                      S.d_t, S.d_sum);
+                ok = hipGetLastError() == hipSuccess &&
+                     hipMemcpyAsync(S.h_sum, S.d_sum, sizeof(ftk::TextSummary), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
+                     hipEventRecord(S.done, pstream) == hipSuccess;
+            }
+            if (!ok) {
+                (void)hipGetLastError();
+                return fail(FTK_ERR_HIP, "cannot launch the device row parser");
+            }
+            S.pending = true;
+        }
+        clk.lap(2);
+        carry = (size_t)(e - last);
+        carry_src = (const uint8_t*)last;
+        // the GPU is busy with this piece: settle the previous one
+        if (prev && prev->pending && !collect(*prev)) return false;
+        clk.lap(3);
+        prev = &S;
+        if (eof) break;
+        const size_t raw_carry = n - used;
+        if (raw_carry) memmove(buf.data(), buf.data() + used, raw_carry);
+        clk.lap(5);
+        n = fill(buf, raw_carry);
+        clk.lap(0);
+        eof = n - raw_carry < kStreamPiece;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (stop) return false;
+        }
+    }
+    if (prev && prev->pending && !collect(*prev)) return false;
+    clk.lap(3);
+    if (have_cur && !emit_device(std::move(cur))) return false;
+    clk.lap(4);
+    clk.report("text, device rows (parse = launch, merge = collect)");
+    if (clk.on) fprintf(stderr, "[ftk stream text] %zu pieces parsed on the device, %zu by the host\n", gpu_pieces, host_pieces);
     return true;
 }
 
@@ -1998,8 +2348,8 @@ int ftk_fragfile_index_contigs(const char* path, char* names_out, int64_t cap, i
     return FTK_OK;
 }
 
-int ftk_fragstream_open(const char* path, const char* contig, int is_bam, int n_threads, int max_queued,
-                        ftk_fragstream** out) {
+static int fragstream_open_impl(const char* path, const char* contig, int is_bam, int n_threads, int max_queued,
+                                int device, ftk_fragstream** out) {
     if (!path || !out) return dfail(FTK_ERR_INVALID, "NULL argument");
     *out = nullptr;
     FILE* fp = fopen(path, "rb");
@@ -2011,9 +2361,23 @@ int ftk_fragstream_open(const char* path, const char* contig, int is_bam, int n_
     s->n_threads = std::max(1, n_threads);
     s->max_queued = (size_t)std::max(1, max_queued);
     s->fp = fp;
+    // BAM records are parsed by the host; FTK_DEVICE_PARSE=0 keeps text rows there too
+    static const bool device_parse = !(getenv("FTK_DEVICE_PARSE") && atoi(getenv("FTK_DEVICE_PARSE")) == 0);
+    s->device = (!s->bam && device_parse) ? device : -1;
     s->producer = std::thread([s] { s->run(); });
     *out = s;
     return FTK_OK;
+}
+
+int ftk_fragstream_open(const char* path, const char* contig, int is_bam, int n_threads, int max_queued,
+                        ftk_fragstream** out) {
+    return fragstream_open_impl(path, contig, is_bam, n_threads, max_queued, -1, out);
+}
+
+int ftk_fragstream_open_device(int device_id, const char* path, const char* contig, int is_bam, int n_threads,
+                               int max_queued, ftk_fragstream** out) {
+    if (device_id < 0 || !have_hip_device()) return dfail(FTK_ERR_NO_DEVICE, "ftk_fragstream_open_device: no HIP device");
+    return fragstream_open_impl(path, contig, is_bam, n_threads, max_queued, device_id, out);
 }
 
 int ftk_fragstream_next(ftk_fragstream* s, ftk_fragtable** out) {
@@ -2056,6 +2420,11 @@ void ftk_fragstream_close(ftk_fragstream* s) {
     if (s->producer.joinable()) s->producer.join();
     s->drain_ahead();
     for (auto* t : s->ready) delete t;
+    if (s->pstream) {
+        (void)hipSetDevice(s->device);
+        (void)hipStreamSynchronize(s->pstream);
+        (void)hipStreamDestroy(s->pstream);
+    }
     if (s->fp) fclose(s->fp);
     delete s;
 }

@@ -108,8 +108,9 @@ class FragSource:
         eng = get_engine()
         lib = L.load()
         stream = C.c_void_p()
-        rc = lib.ftk_fragstream_open(self.path.encode(), contig.encode(), int(self.is_bam),
-                                     decode_threads(self.workers), 1, C.byref(stream))
+        # text rows are parsed on the engine's GPU (ftk_fragstream_open_device; BAM records on the host)
+        rc = lib.ftk_fragstream_open_device(eng.device, self.path.encode(), contig.encode(), int(self.is_bam),
+                                            decode_threads(self.workers), 1, C.byref(stream))
         if rc != L.FTK_OK:
             raise UnsupportedFormatError(lib.ftk_fragtable_error().decode())
         try:
@@ -209,7 +210,9 @@ def stream_source(input_file, workers: int | None = None, queued: int = 2):
     eng = get_engine()  # fails loudly without the HIP library / a GPU
     lib = L.load()
     stream = C.c_void_p()
-    rc = lib.ftk_fragstream_open(path.encode(), None, int(is_bam), decode_threads(workers), int(queued), C.byref(stream))
+    # text rows are parsed on the engine's GPU (ftk_fragstream_open_device; BAM records on the host)
+    rc = lib.ftk_fragstream_open_device(eng.device, path.encode(), None, int(is_bam), decode_threads(workers), int(queued),
+                                        C.byref(stream))
     if rc != L.FTK_OK:
         msg = lib.ftk_fragtable_error().decode()
         raise FileNotFoundError(msg) if rc == L.FTK_ERR_IO else UnsupportedFormatError(msg)

@@ -149,6 +149,20 @@ int ftk_bam_decode(const char* path, const char* contig /* NULL = all */, int n_
  * index).  FTK_ERR_FORMAT when there is no usable index (callers then decode the file in one pass). */
 int ftk_fragfile_index_contigs(const char* path, char* names_out, int64_t cap, int64_t* needed_out, int* is_bed6_out);
 typedef struct ftk_fragstream ftk_fragstream;
+/* ftk_fragstream_open_device: the same stream with the ROW PARSER ON THE GPU for text files (BAM records stay
+ * on the host): the host threads only inflate, each piece of text goes to device `device_id` in one DMA, four
+ * small kernels find the lines and parse the plain rows, and the tables handed out hold DEVICE columns
+ * (ftk_fragtable_is_device; ftk_fragtable_columns then returns device pointers, ftk_fragtable_columns_to_host
+ * copies them out).  A piece that holds anything but plain rows (comments, signs, blanks, short lines ...) is
+ * parsed by the host's field-rule parser, so the rows are the same as ftk_fragstream_open's.  ftk_frags_from_table
+ * takes both kinds.  FTK_DEVICE_PARSE=0 makes it behave like ftk_fragstream_open. */
+int ftk_fragstream_open_device(int device_id, const char* path, const char* contig /* NULL = all */, int is_bam,
+                               int n_threads, int max_queued, ftk_fragstream** out);
+int ftk_fragtable_is_device(const ftk_fragtable* t, int i);
+/* hipEvent_t recorded behind the last write to a device table's columns (NULL for host tables) */
+void* ftk_fragtable_ready_event(const ftk_fragtable* t, int i);
+int ftk_fragtable_columns_to_host(const ftk_fragtable* t, int i, int32_t* start, int32_t* end, uint8_t* mapq,
+                                  uint8_t* strand);
 int ftk_fragstream_open(const char* path, const char* contig /* NULL = all */, int is_bam, int n_threads,
                         int max_queued, ftk_fragstream** out);
 int ftk_fragstream_next(ftk_fragstream* s, ftk_fragtable** out);

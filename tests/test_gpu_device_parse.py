@@ -1,0 +1,188 @@
+"""GPU: the streaming text decoder with the row parser on the device (ftk_fragstream_open_device,
+csrc/ftk_textparse.hip) hands out exactly the rows of the host decoders - on the fixtures, on multi-contig
+files read in 64 KB pieces (contig runs inside a piece, lines straddling pieces), on files full of odd rows
+(those pieces go through the host's field-rule parser), with CRLF line ends, without a final newline, and for
+single-contig requests through the index."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from finaletoolkit_amd import _lib as L
+from finaletoolkit_amd import bgzf, synth
+from tests.helpers import DATA, GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream_device(path, contig=None, threads=3, queued=2):
+    lib = L.load()
+    s = C.c_void_p()
+    rc = lib.ftk_fragstream_open_device(0, path.encode(), None if contig is None else contig.encode(), 0, threads, queued,
+                                        C.byref(s))
+    if rc != 0:
+        raise RuntimeError((rc, lib.ftk_fragtable_error().decode()))
+    out, order, n_dev = {}, [], 0
+    try:
+        while True:
+            t = C.c_void_p()
+            rc = lib.ftk_fragstream_next(s, C.byref(t))
+            if rc != 0:
+                raise RuntimeError((rc, lib.ftk_fragtable_error().decode()))
+            if not t.value:
+                break
+            try:
+                rows = lib.ftk_fragtable_contig_rows(t, 0)
+                name = lib.ftk_fragtable_contig_name(t, 0).decode()
+                n_dev += lib.ftk_fragtable_is_device(t, 0)
+                cols = [np.empty(rows, np.int32), np.empty(rows, np.int32), np.empty(rows, np.uint8), np.empty(rows, np.uint8)]
+                assert lib.ftk_fragtable_columns_to_host(t, 0, *[c.ctypes.data_as(C.c_void_p) for c in cols]) == 0
+                assert name not in out
+                out[name] = (rows, cols)
+                order.append(name)
+                out["__bed6__"] = lib.ftk_fragtable_is_bed6(t)
+            finally:
+                lib.ftk_fragtable_free(t)
+    finally:
+        lib.ftk_fragstream_close(s)
+    return out, order, n_dev
+
+
+def _whole(path, contig=None):
+    from tests.test_abi import _decode
+    return _decode(path, contig=contig)
+
+
+def _same(got, want):
+    names = [k for k in want if not k.startswith("__") and want[k][0] > 0]
+    assert sorted(k for k in got if not k.startswith("__")) == sorted(names)
+    assert got.get("__bed6__", want["__bed6__"]) == want["__bed6__"]
+    for k in names:
+        assert got[k][0] == want[k][0], k
+        for a, b in zip(got[k][1], want[k][1][:4]):
+            assert np.array_equal(a, b), k
+
+
+_CHILD = """
+import sys
+sys.path.insert(0, {root!r})
+from tests.test_gpu_device_parse import _stream_device, _whole, _same
+path = sys.argv[1]
+got, order, n_dev = _stream_device(path, threads=int(sys.argv[2]))
+_same(got, _whole(path))
+if len(sys.argv) > 3:
+    only, _, _ = _stream_device(path, contig=sys.argv[3])
+    assert [k for k in only if not k.startswith("__")] == [sys.argv[3]]
+    _same(only, _whole(path, contig=sys.argv[3]))
+print("ok", order, n_dev)
+"""
+
+
+def _child(path, threads=3, contig=None, **env):
+    args = [sys.executable, "-c", _CHILD.format(root=ROOT), path, str(threads)] + ([contig] if contig else [])
+    r = subprocess.run(args, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-3000:]
+    return r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("name", ["12.3444.b37.frag.gz", "12.3444.b37.frag.bed.gz"])
+def test_device_rows_equal_host_rows_on_fixtures(name):
+    path = os.path.join(DATA, name)
+    got, order, n_dev = _stream_device(path)
+    _same(got, _whole(path))
+    assert n_dev == len(order) == 1
+    got, order, _ = _stream_device(os.path.join(GOLDEN, "synth.frag.gz"), threads=4)
+    _same(got, _whole(os.path.join(GOLDEN, "synth.frag.gz")))
+
+
+def test_device_rows_multi_contig_small_pieces(tmp_path):
+    rows = []
+    for k, size in enumerate((2_000_000, 900_000, 50_000, 1_500_000)):
+        s, e, q, st = synth.synth_contig(size, depth=18.0, seed=40 + k)
+        rows.append((f"c{k}", s, e, q, st))
+    p = str(tmp_path / "multi.frag.gz")
+    bgzf.write_frag_gz(p, rows, level=1)
+    out = _child(p, contig="c2", FTK_STREAM_PIECE="65536", FTK_DECODE_TIMING="1")
+    assert "['c0', 'c1', 'c2', 'c3']" in out
+    import re
+    m = re.search(r"(\d+) pieces parsed on the device, (\d+) by the host", out)
+    assert m and int(m.group(1)) > 20 and int(m.group(2)) == 0, out[-600:]
+    # whole pieces (one 48 MB piece holds the file) and the switch that keeps the rows on the host
+    assert "['c0', 'c1', 'c2', 'c3']" in _child(p, threads=8)
+    assert "] 0" in _child(p, FTK_DEVICE_PARSE="0").splitlines()[0]  # no device table handed out
+
+
+@pytest.mark.parametrize("bed6", [False, True])
+def test_device_rows_with_odd_rows_crlf_and_no_final_newline(tmp_path, bed6):
+    """Plain pieces stay on the device, pieces with odd rows go through the host's field rules; the rows are
+    the rules' rows either way (the same generator as tests/test_stream_decoder.py)."""
+    from tests.test_stream_decoder import _rows_by_rule
+    rng = np.random.default_rng(5 + bed6)
+    lines = []
+    for c in ("chr1", "chr10", "2"):
+        n = 60_000
+        s = np.sort(rng.integers(0, 50_000_000, n))
+        e = s + rng.integers(1, 600, n)
+        q = rng.integers(0, 300, n)
+        st = rng.integers(0, 2, n)
+        pick = rng.random(n)
+        # odd rows only in the middle third of every contig: the pieces before and after are plain
+        for i in range(n):
+            f = [c, str(s[i]), str(e[i]), str(q[i]), "+" if st[i] else "-"]
+            if n // 3 < i < 2 * n // 3 and pick[i] < 0.01:
+                f = [[c, " %d" % s[i], str(e[i]), str(q[i]), f[4]], [c, str(s[i]), "+%d" % e[i], str(q[i]), f[4]],
+                     [c, str(s[i]), str(e[i]), "6x", f[4]], [c, "2147483648", str(e[i]), str(q[i]), f[4]],
+                     [c, str(s[i]), str(e[i]), str(q[i]), "+-"], [c, str(s[i]), str(e[i]), str(q[i])],
+                     ["#" + c, str(s[i]), str(e[i]), str(q[i]), f[4]], [""],
+                     [c, str(s[i]), str(e[i]), str(q[i]), f[4], "extra"]][int(rng.integers(9))]
+            if bed6 and len(f) >= 4:
+                f = f[:3] + ["frag %d" % i] + f[3:]
+            lines.append("\t".join(f) + ("\r" if pick[i] > 0.9 else ""))
+    first = ["chr1", "5", "170", "name", "60", "+"] if bed6 else ["chr1", "5", "170", "60", "+"]
+    text = "\t".join(first) + "\n" + "\n".join(lines)  # no newline after the last row
+    want = _rows_by_rule(text, bed6)
+    p = str(tmp_path / "rows.frag.gz")
+    bgzf.write_bgzf(p, text.encode(), level=1)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tests.test_gpu_device_parse import _stream_device\n"
+            "import pickle\n"
+            "got, order, n_dev = _stream_device(%r, threads=3)\n"
+            "pickle.dump(got, open(%r, 'wb'))\n") % (ROOT, p, str(tmp_path / "got.pkl"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                       env=dict(os.environ, FTK_STREAM_PIECE=str(1 << 16), FTK_DECODE_TIMING="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    import pickle
+    import re
+    got = pickle.load(open(tmp_path / "got.pkl", "rb"))
+    assert got["__bed6__"] == int(bed6)
+    assert sorted(k for k in got if not k.startswith("__")) == sorted(want)
+    for c, rows in want.items():
+        a = np.array(rows, dtype=np.int64)
+        assert got[c][0] == len(rows), c
+        for k in range(4):
+            assert np.array_equal(got[c][1][k].astype(np.int64), a[:, k]), (c, k)
+    m = re.search(r"(\d+) pieces parsed on the device, (\d+) by the host", r.stderr)
+    assert m and int(m.group(1)) >= 3 and int(m.group(2)) >= 3, r.stderr[-600:]  # both paths were taken
+
+
+def test_sources_opened_from_text_files_use_the_device_rows(tmp_path):
+    """open_source / stream_source (the reference-shaped API's way in) on a text file: fragments identical to
+    an upload of the host-decoded columns."""
+    from finaletoolkit_amd import source
+    s, e, q, st = synth.synth_contig(3_000_000, depth=12.0, seed=9)
+    p = str(tmp_path / "one.frag.gz")
+    bgzf.write_frag_gz(p, [("chrT", s, e, q, st)], level=1)
+    eng = source.get_engine()
+    src = source.open_source(p)
+    ws, we = synth.tiling_windows(3_000_000, 100_000)
+    got = eng.window_features(src.require("chrT"), ws, we, 30, hist=(0, 600))
+    eng.load_contig("ref:chrT", s, e, q, st)
+    want = eng.window_features("ref:chrT", ws, we, 30, hist=(0, 600))
+    assert np.array_equal(got["coverage"], want["coverage"]) and np.array_equal(got["hist"], want["hist"])
+    gs, ge, gq, gst = eng.frag_select(src.require("chrT"), None, None, 0, None, None, "any")
+    assert np.array_equal(gs, s) and np.array_equal(ge, e) and np.array_equal(gq, q) and np.array_equal(gst, st)
+    eng.release("ref:chrT")
+    source.close_all()
