@@ -229,10 +229,60 @@ struct Packed {
     uint8_t *mapq = nullptr, *strand = nullptr;
 };
 
-// A contig whose columns live in device memory (the streaming text decoder with the GPU row parser):
-// grown piece by piece with device-to-device copies on the parse stream; `ready` is recorded behind the
-// last copy and waited for by the stream that consumes the columns.
+// Device blocks of the contigs parsed on the GPU are recycled: hipFree waits for ALL work on the device - the
+// consumer's 2 GB copy-back included - so a producer that frees and allocates per contig would run in lock
+// step with the consumer.  Any cached block that is large enough is reused (contigs shrink along a genome).
+struct DeviceBlockCache {
+    struct Blk { void* p; size_t cap; int device; };
+    std::mutex mu;
+    std::vector<Blk> free_list;
+    size_t cached = 0;
+    // smallest adequate block, or (largest = true: a contig's first block, which will grow) the largest
+    void* take(size_t bytes, int device, size_t* cap_out, bool largest) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            int best = -1;
+            for (int i = 0; i < (int)free_list.size(); ++i)
+                if (free_list[i].device == device && free_list[i].cap >= bytes &&
+                    (best < 0 || (largest ? free_list[i].cap > free_list[best].cap : free_list[i].cap < free_list[best].cap)))
+                    best = i;
+            if (best >= 0) {
+                Blk b = free_list[best];
+                free_list.erase(free_list.begin() + best);
+                cached -= b.cap;
+                *cap_out = b.cap;
+                return b.p;
+            }
+        }
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        *cap_out = bytes;
+        return p;
+    }
+    void give(void* p, size_t cap, int device) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (free_list.size() < 8 && cached + cap <= (size_t(4) << 30)) {
+                free_list.push_back({p, cap, device});
+                cached += cap;
+                return;
+            }
+        }
+        (void)hipFree(p);
+    }
+};
+DeviceBlockCache& device_cache() {
+    static DeviceBlockCache* c = new DeviceBlockCache();  // leaked: the driver frees at process exit
+    return *c;
+}
+
+// A contig whose columns live in device memory (the streaming text decoder with the GPU row parser): ONE
+// block (start | end | mapq | strand at the block's row capacity), grown piece by piece with device-to-device
+// copies on the parse stream; `ready` is recorded behind the last copy and waited for by the consumer's stream.
 struct DevColumns {
+    void* base = nullptr;
+    size_t bytes = 0;
     int32_t *start = nullptr, *end = nullptr;
     uint8_t *mapq = nullptr, *strand = nullptr;
     size_t rows = 0, cap = 0;
@@ -243,38 +293,40 @@ struct DevColumns {
     DevColumns& operator=(const DevColumns&) = delete;
     ~DevColumns() {
         (void)hipSetDevice(device);
-        if (start) (void)hipFree(start);
-        if (end) (void)hipFree(end);
-        if (mapq) (void)hipFree(mapq);
-        if (strand) (void)hipFree(strand);
-        if (ready) (void)hipEventDestroy(ready);
+        if (ready) {
+            (void)hipEventSynchronize(ready);  // the block may be handed out again right away
+            (void)hipEventDestroy(ready);
+        }
+        device_cache().give(base, bytes, device);
     }
-    // room for `more` rows; existing rows are moved on `s` (which is drained before the old arrays go)
+    // room for `more` rows; existing rows are moved on `s` (which is drained before the old block is given back)
     bool reserve(size_t more, hipStream_t s) {
         if (rows + more <= cap) return true;
         const size_t want = std::max<size_t>(std::max(rows + more, 2 * cap), size_t(1) << 20);
-        int32_t *ns = nullptr, *ne = nullptr;
-        uint8_t *nq = nullptr, *nt = nullptr;
-        bool ok = hipMalloc((void**)&ns, want * 4) == hipSuccess && hipMalloc((void**)&ne, want * 4) == hipSuccess &&
-                  hipMalloc((void**)&nq, want) == hipSuccess && hipMalloc((void**)&nt, want) == hipSuccess;
-        if (ok && rows) {
-            ok = hipMemcpyAsync(ns, start, rows * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-                 hipMemcpyAsync(ne, end, rows * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-                 hipMemcpyAsync(nq, mapq, rows, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-                 hipMemcpyAsync(nt, strand, rows, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-                 hipStreamSynchronize(s) == hipSuccess;
+        size_t got_bytes = 0;
+        void* nb = device_cache().take(want * 10 + 1024, device, &got_bytes, rows == 0);
+        if (!nb) return false;
+        const size_t ncap = (got_bytes - 1024) / 10 / 64 * 64;  // rows the block holds (arrays 256-byte aligned)
+        int32_t* ns = (int32_t*)nb;
+        int32_t* ne = ns + ncap;
+        uint8_t* nq = (uint8_t*)(ne + ncap);
+        uint8_t* nt = nq + ncap;
+        if (rows) {
+            const bool ok = hipMemcpyAsync(ns, start, rows * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                            hipMemcpyAsync(ne, end, rows * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                            hipMemcpyAsync(nq, mapq, rows, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                            hipMemcpyAsync(nt, strand, rows, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                            hipStreamSynchronize(s) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                device_cache().give(nb, got_bytes, device);
+                return false;
+            }
         }
-        if (!ok) {
-            (void)hipGetLastError();
-            if (ns) (void)hipFree(ns);
-            if (ne) (void)hipFree(ne);
-            if (nq) (void)hipFree(nq);
-            if (nt) (void)hipFree(nt);
-            return false;
-        }
-        if (start) { (void)hipFree(start); (void)hipFree(end); (void)hipFree(mapq); (void)hipFree(strand); }
+        device_cache().give(base, bytes, device);
+        base = nb; bytes = got_bytes;
         start = ns; end = ne; mapq = nq; strand = nt;
-        cap = want;
+        cap = ncap;
         return true;
     }
     // append n rows from device (kind D2D) or host (H2D; the call returns when the source may be released)
