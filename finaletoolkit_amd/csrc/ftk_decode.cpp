@@ -302,11 +302,17 @@ struct DevColumns {
     // room for `more` rows; existing rows are moved on `s` (which is drained before the old block is given back)
     bool reserve(size_t more, hipStream_t s) {
         if (rows + more <= cap) return true;
-        const size_t want = std::max<size_t>(std::max(rows + more, 2 * cap), size_t(1) << 20);
+        // (a multiple of 64 rows: the four arrays then start 256-byte aligned and the capacity computed back
+        // from the block's size is never below the request)
+        const size_t want = (std::max<size_t>(std::max(rows + more, 2 * cap), size_t(1) << 20) + 63) / 64 * 64;
         size_t got_bytes = 0;
         void* nb = device_cache().take(want * 10 + 1024, device, &got_bytes, rows == 0);
         if (!nb) return false;
-        const size_t ncap = (got_bytes - 1024) / 10 / 64 * 64;  // rows the block holds (arrays 256-byte aligned)
+        const size_t ncap = (got_bytes - 1024) / 10 / 64 * 64;  // rows the block holds
+        if (ncap < rows + more) {  // cannot happen; never write past a block
+            device_cache().give(nb, got_bytes, device);
+            return false;
+        }
         int32_t* ns = (int32_t*)nb;
         int32_t* ne = ns + ncap;
         uint8_t* nq = (uint8_t*)(ne + ncap);

@@ -115,6 +115,21 @@ def test_device_rows_multi_contig_small_pieces(tmp_path):
     assert "] 0" in _child(p, FTK_DEVICE_PARSE="0").splitlines()[0]  # no device table handed out
 
 
+def test_device_contigs_growing_over_many_pieces(tmp_path):
+    """Contigs of 2.5 M rows arriving in ~150 k-row pieces: the device block of a contig is regrown (1 M -> 2 M ->
+    4 M rows) while it fills, and blocks are recycled from contig to contig."""
+    rows = []
+    for k in range(3):
+        s, e, q, st = synth.synth_contig(60_000_000, seed=70 + k, n=2_500_037 - 400_011 * k)
+        rows.append((f"g{k}", s, e, q, st))
+    p = str(tmp_path / "grow.frag.gz")
+    bgzf.write_frag_gz(p, rows, level=1)
+    out = _child(p, threads=8, FTK_STREAM_PIECE=str(1 << 20))
+    assert "['g0', 'g1', 'g2']" in out
+    # one piece per file: a contig's first block is sized by an arbitrary row count (not a multiple of 64)
+    assert "['g0', 'g1', 'g2']" in _child(p, threads=8)
+
+
 @pytest.mark.parametrize("bed6", [False, True])
 def test_device_rows_with_odd_rows_crlf_and_no_final_newline(tmp_path, bed6):
     """Plain pieces stay on the device, pieces with odd rows go through the host's field rules; the rows are
