@@ -1949,6 +1949,39 @@ struct DevSet {
         return true;
     }
 };
+// The two buffer sets of a finished stream wait here for the next one: allocating them costs ~100 ms (400 MB
+// of page-locked memory, ~1 GB of device memory, the frees synchronise the device) - more than a small file
+// takes to decode.  At most two idle sets are kept (per process, any device).
+struct DevSetPool {
+    std::mutex mu;
+    std::vector<std::pair<int, DevSet>> idle;
+    DevSet take(int device) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < idle.size(); ++i)
+            if (idle[i].first == device) {
+                DevSet s = idle[i].second;
+                idle.erase(idle.begin() + i);
+                return s;
+            }
+        return DevSet{};
+    }
+    void give(int device, DevSet& s) {
+        s.pending = false;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (s.cap && idle.size() < 2) {
+                idle.emplace_back(device, s);
+                s = DevSet{};
+                return;
+            }
+        }
+        s.release();
+    }
+};
+DevSetPool& devset_pool() {
+    static DevSetPool* p = new DevSetPool();  // leaked: the driver frees at process exit
+    return *p;
+}
 }  // namespace
 
 bool ftk_fragstream::emit_device(Contig&& ct) {
@@ -1985,11 +2018,17 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         (void)hipGetLastError();
         return fail(FTK_ERR_HIP, "cannot create the parse stream");
     }
-    DevSet sets[2];
+    DevSet sets[2] = {devset_pool().take(device), devset_pool().take(device)};
     struct Cleanup {
         DevSet* s;
-        ~Cleanup() { s[0].release(); s[1].release(); }
-    } cleanup{sets};
+        int device;
+        hipStream_t stream;
+        ~Cleanup() {
+            (void)hipStreamSynchronize(stream);  // nothing in flight touches the sets any more
+            devset_pool().give(device, s[0]);
+            devset_pool().give(device, s[1]);
+        }
+    } cleanup{sets, device, pstream};
     std::vector<Block> blocks;
     size_t carry = 0;
     const uint8_t* carry_src = nullptr;
