@@ -12,7 +12,7 @@ from collections import defaultdict
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
     for p in ("void ", "ftk::"):
         name = name.replace(p, "")
     return name[:70]
