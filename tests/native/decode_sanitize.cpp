@@ -9,6 +9,17 @@
 #include <vector>
 
 #include "ftk.h"
+#include "ftk_textparse.h"
+
+// The device row parser's kernels are not part of this host-only build; the harness opens host-mode
+// streams only, so the launcher is never reached.
+namespace ftk {
+void textparse_launch(hipStream_t, const uint8_t*, size_t, bool, uint32_t*, uint32_t*, size_t, int32_t*, int32_t*, uint8_t*,
+                      uint8_t*, TextSummary*) {
+    fprintf(stderr, "textparse_launch called in the sanitizer harness\n");
+    abort();
+}
+}  // namespace ftk
 
 static int decode(const char* path, bool bam, int threads, long* rows_out) {
     ftk_fragtable* t = nullptr;
