@@ -296,6 +296,8 @@ struct DevColumns {
         if (ready) {
             (void)hipEventSynchronize(ready);  // the block may be handed out again right away
             (void)hipEventDestroy(ready);
+        } else if (base) {
+            (void)hipDeviceSynchronize();  // a contig abandoned half way (error / close): copies may be in flight
         }
         device_cache().give(base, bytes, device);
     }
