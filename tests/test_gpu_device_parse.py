@@ -201,3 +201,39 @@ def test_sources_opened_from_text_files_use_the_device_rows(tmp_path):
     assert np.array_equal(gs, s) and np.array_equal(ge, e) and np.array_equal(gq, q) and np.array_equal(gst, st)
     eng.release("ref:chrT")
     source.close_all()
+
+
+def test_device_stream_errors_and_early_close(tmp_path):
+    """Closing a device-mode stream before it is drained, a truncated file and an unsorted file: clean errors,
+    no hang, and the next stream works (the buffer sets and device blocks go back to their pools)."""
+    lib = L.load()
+    rows = []
+    for k in range(4):
+        s, e, q, st = synth.synth_contig(2_000_000, depth=10.0, seed=20 + k)
+        rows.append((f"e{k}", s, e, q, st))
+    good = str(tmp_path / "good.frag.gz")
+    bgzf.write_frag_gz(good, rows, level=1)
+    # (a) close after the first contig / without reading anything (the producer is waiting for queue space)
+    for take in (0, 1):
+        s = C.c_void_p()
+        assert lib.ftk_fragstream_open_device(0, good.encode(), None, 0, 4, 1, C.byref(s)) == 0
+        for _ in range(take):
+            t = C.c_void_p()
+            assert lib.ftk_fragstream_next(s, C.byref(t)) == 0 and t.value
+            lib.ftk_fragtable_free(t)
+        lib.ftk_fragstream_close(s)
+    # (b) truncated in the middle of a BGZF block
+    raw = open(good, "rb").read()
+    cut = str(tmp_path / "cut.frag.gz")
+    open(cut, "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(RuntimeError):
+        _stream_device(cut)
+    # (c) a contig that comes back after another one
+    unsorted = str(tmp_path / "unsorted.frag.gz")
+    bgzf.write_frag_gz(unsorted, [rows[0], rows[1], (rows[0][0],) + rows[2][1:]], level=1)
+    with pytest.raises(RuntimeError) as ei:
+        _stream_device(unsorted)
+    assert "two separate runs" in str(ei.value)
+    got, order, n_dev = _stream_device(good)
+    assert order == ["e0", "e1", "e2", "e3"] and n_dev == 4
+    _same(got, _whole(good))
