@@ -340,6 +340,23 @@ class BigWigFile:
         return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
 
 
+    def values(self, contig, start, stop):
+        """Per-base values of ``[start, stop)`` as float64, NaN where the file has no entry; RuntimeError for
+        an unknown contig or bounds outside it (pyBigWig's ``values``, utils/_agg_bw.py:87)."""
+        got = self.intervals(contig, int(start), int(stop))
+        out = np.full(int(stop) - int(start), np.nan)
+        if got is not None:
+            st, en, v = got
+            s0 = np.maximum(st, start) - start
+            lens = np.minimum(en, stop) - start - s0
+            if np.all(lens == 1):  # per-base tracks (what the WPS writers produce)
+                out[s0] = v
+            else:
+                first = np.cumsum(lens) - lens
+                out[np.repeat(s0 - first, lens) + np.arange(int(lens.sum()))] = np.repeat(v, lens)
+        return out
+
+
 def read_bigwig(path):
     """Return ``(chroms, intervals)``: ``chroms`` = {name: (id, size)};
     ``intervals`` = list of ``(chrom_name, start, end, value)`` decoded from

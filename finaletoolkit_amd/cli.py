@@ -2,7 +2,7 @@
 Command line for the hot-path commands, flag-compatible with the reference's
 ``finaletoolkit`` CLI (``cli/commands/__init__.py:92-127,130-232,280-324,415-479`` and ``cli/_args.py``):
 ``coverage``, ``frag-length-bins``, ``frag-length-intervals``, ``wps``, ``delfi`` (+ ``cleavage-profile``,
-``adjust-wps``, ``end-motifs``, ``interval-end-motifs``, ``breakpoint-motifs``, ``interval-breakpoint-motifs``,
+``adjust-wps``, ``agg-bw``, ``end-motifs``, ``interval-end-motifs``, ``breakpoint-motifs``, ``interval-breakpoint-motifs``,
 ``mds``, ``regional-mds``).
 
     python -m finaletoolkit_amd.cli coverage INPUT INTERVALS -o out.bed
@@ -79,6 +79,14 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--subtract-edges", dest="subtract_edges", action="store_true")
     p.add_argument("--edge-size", dest="edge_size", type=int, default=500)
     p.add_argument("-t", "--threads", dest="workers", type=int, default=1, metavar="N")
+    p.add_argument("-v", "--verbose", action="count", default=0)
+
+    p = sub.add_parser("agg-bw", help="aggregate a bigWig signal over constant-length, strand-annotated BED intervals")
+    p.add_argument("input_file", metavar="INPUT")
+    p.add_argument("interval_file", metavar="REGIONS")
+    p.add_argument("-o", "--output", dest="output_file", required=True, metavar="FILE")
+    p.add_argument("-m", "--median-window-size", dest="median_window_size", type=int, default=1, metavar="BP")
+    p.add_argument("--mean", dest="mean", action="store_true")
     p.add_argument("-v", "--verbose", action="count", default=0)
 
     p = sub.add_parser("cleavage-profile", help="cleavage proportion over BED intervals")
@@ -169,6 +177,10 @@ def main(argv=None) -> int:
                         savgol_poly_deg=a.savgol_poly_deg, savgol=a.savgol, mean=a.mean,
                         subtract_edges=a.subtract_edges, edge_size=a.edge_size, workers=a.workers,
                         verbose=a.verbose)
+    elif a.command == "agg-bw":
+        from .utils import agg_bw
+        agg_bw(a.input_file, a.interval_file, a.output_file, median_window_size=a.median_window_size, mean=a.mean,
+               verbose=a.verbose)
     elif a.command == "cleavage-profile":
         frag.multi_cleavage_profile(a.input_file, a.interval_file, a.chrom_sizes, left=a.left, right=a.right,
                                     min_length=a.min_length, max_length=a.max_length,

@@ -140,3 +140,60 @@ def frag_array(input_file, contig: str, quality_threshold: int = 30, start=None,
     if not parts:
         return np.zeros(0, dtype=[("start", "i8"), ("stop", "i8"), ("strand", "?")])
     return np.concatenate(parts)
+
+
+def agg_bw(input_file, interval_file, output_file, median_window_size: int = 1, mean: bool = False,
+           verbose: bool = False) -> np.ndarray:
+    """Aggregate a bigWig signal across strand-oriented intervals (reference: ``utils/_agg_bw.py:18-146``):
+    every interval's per-base values (NaN -> 0) are trimmed by the upstream median filter's window
+    (``values[w // 2 : -w // 2]`` - with ``w = 0`` that slice is empty and every interval is skipped, as in the
+    reference), flipped for ``-`` strand intervals, and summed; ``mean`` divides by the intervals added.  A host
+    utility downstream of ``adjust_wps`` - file reading and a few vector additions, no kernel."""
+    import gzip
+    import time
+    from sys import stderr
+
+    from .bigwig import BigWigFile
+    t0 = time.time()
+    if not (str(interval_file).endswith(".bed") or str(interval_file).endswith(".bed.gz")):
+        raise ValueError("Invalid filetype for interval_file.")
+    intervals = []
+    opener = gzip.open if str(interval_file).endswith(".gz") else open
+    with opener(interval_file, "rt") as fh:
+        for line in fh:
+            f = line.split("\t")
+            intervals.append((f[0], int(f[1]), int(f[2]), f[5].strip()))
+    with BigWigFile(str(input_file)) as bw:
+        interval_size = intervals[0][2] - intervals[0][1] - median_window_size
+        agg = np.zeros(interval_size, dtype=np.int64)
+        added = 0
+        for contig, start, stop, strand in intervals:
+            try:
+                values = np.nan_to_num(bw.values(contig, start, stop), nan=0)
+            except RuntimeError as e:
+                print(e)
+                continue
+            trimmed = values[median_window_size // 2: -median_window_size // 2]
+            if trimmed.shape[0] != interval_size:
+                print(f"Trimmed size {trimmed.shape[0]} for {contig}:{start}-{stop} is not equal to "
+                      f"interval size {interval_size}. Skipping.")
+                continue
+            if strand == "+":
+                agg = agg + trimmed
+                added += 1
+            elif strand == "-":
+                agg = agg + np.flip(trimmed)
+                added += 1
+            elif verbose:
+                stderr.write("A segment without strand was encountered. Skipping.")
+    if mean:
+        agg = agg / added
+    if not str(output_file).endswith("wig"):
+        raise ValueError("The output_file is an unaccepted type. Must be a wiggle file ending in .wig")
+    with open(output_file, "wt") as out:
+        out.write(f"fixedStep\tchrom=.\tstart={-interval_size // 2}\tstep={1}\tspan={interval_size}\n")
+        for score in agg:
+            out.write(f"{score}\n")
+    if verbose:
+        stderr.write(f"Aggregating bigWig took {time.time() - t0} s to complete\n")
+    return agg
