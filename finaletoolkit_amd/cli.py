@@ -2,7 +2,7 @@
 Command line for the hot-path commands, flag-compatible with the reference's
 ``finaletoolkit`` CLI (``cli/commands/__init__.py:92-127,130-232,280-324,415-479`` and ``cli/_args.py``):
 ``coverage``, ``frag-length-bins``, ``frag-length-intervals``, ``wps``, ``delfi`` (+ ``cleavage-profile``,
-``adjust-wps``, ``agg-bw``, ``end-motifs``, ``interval-end-motifs``, ``breakpoint-motifs``, ``interval-breakpoint-motifs``,
+``adjust-wps``, ``agg-bw``, ``gap-bed``, ``end-motifs``, ``interval-end-motifs``, ``breakpoint-motifs``, ``interval-breakpoint-motifs``,
 ``mds``, ``regional-mds``).
 
     python -m finaletoolkit_amd.cli coverage INPUT INTERVALS -o out.bed
@@ -88,6 +88,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("-m", "--median-window-size", dest="median_window_size", type=int, default=1, metavar="BP")
     p.add_argument("--mean", dest="mean", action="store_true")
     p.add_argument("-v", "--verbose", action="count", default=0)
+
+    p = sub.add_parser("gap-bed", help="BED4 of centromeres, telomeres and short-arm intervals of a reference genome")
+    p.add_argument("reference_genome", metavar="GENOME", choices=["hg19", "b37", "human_g1k_v37", "hg38", "GRCh38"])
+    p.add_argument("output_file", metavar="OUTPUT")
 
     p = sub.add_parser("cleavage-profile", help="cleavage proportion over BED intervals")
     p.add_argument("input_file", metavar="INPUT")
@@ -181,6 +185,9 @@ def main(argv=None) -> int:
         from .utils import agg_bw
         agg_bw(a.input_file, a.interval_file, a.output_file, median_window_size=a.median_window_size, mean=a.mean,
                verbose=a.verbose)
+    elif a.command == "gap-bed":
+        from .genome.gaps import _cli_gap_bed
+        _cli_gap_bed(a.reference_genome, a.output_file)
     elif a.command == "cleavage-profile":
         frag.multi_cleavage_profile(a.input_file, a.interval_file, a.chrom_sizes, left=a.left, right=a.right,
                                     min_length=a.min_length, max_length=a.max_length,

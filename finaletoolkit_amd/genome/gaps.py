@@ -133,3 +133,32 @@ class ContigGaps:
     def as_kernel_constants(self):
         """(cen_start, cen_stop, [(t0, t1), ...]) for ``ftk_gaps``."""
         return (self.centromere[0], self.centromere[1], list(self.telomeres))
+
+
+def ucsc_hg19_gap_bed(output_file) -> None:
+    """BED4 of the UCSC hg19 centromeres / telomeres / short arms (genome/gaps.py:270-272)."""
+    return GenomeGaps.ucsc_hg19().to_bed(output_file)
+
+
+def b37_gap_bed(output_file) -> None:
+    """The same for Broad b37 / human_g1k_v37 contig names (genome/gaps.py:275-280)."""
+    return GenomeGaps.b37().to_bed(output_file)
+
+
+def ucsc_hg38_gap_bed(output_file) -> None:
+    """The same for UCSC hg38 (genome/gaps.py:283-285)."""
+    return GenomeGaps.hg38().to_bed(output_file)
+
+
+def _cli_gap_bed(reference_genome: str, output_file: str) -> None:
+    """CLI ``gap-bed`` (genome/gaps.py:288-302)."""
+    if reference_genome == "hg19":
+        ucsc_hg19_gap_bed(output_file)
+    elif reference_genome in ("b37", "human_g1k_v37"):
+        b37_gap_bed(output_file)
+    elif reference_genome in ("hg38", "GRCh38"):
+        ucsc_hg38_gap_bed(output_file)
+    else:
+        raise ValueError(f"Gap track for {reference_genome} is currently unavailable. It is possible to create a gap "
+                         "track de novo if interval data for centromeres, telomeres, and short_arms exist for the "
+                         "reference sequence of interest.")

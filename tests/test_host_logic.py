@@ -201,3 +201,20 @@ def test_split_units_partition_and_balance():
     one_each = split_units({"a": 250_000, "b": 90_000}, 8, 100_000, unit_overhead_windows=0)
     assert sorted((c, a, b) for _, c, a, b in one_each) == [("a", 0, 100_000), ("a", 100_000, 200_000),
                                                             ("a", 200_000, 250_000), ("b", 0, 90_000)]
+
+
+def test_gap_bed_files_equal_the_references(tmp_path):
+    """``gap-bed`` (genome/gaps.py:270-302): byte-identical to what the imported reference writes
+    (oracle/gen_golden_gaps.py -> tests/golden/gap_bed_sha256.json)."""
+    import hashlib
+    import json
+    from finaletoolkit_amd import cli
+    want = json.load(open(os.path.join(GOLDEN, "gap_bed_sha256.json")))
+    for genome, w in want.items():
+        out = tmp_path / (genome + ".bed")
+        cli.main(["gap-bed", genome, str(out)])
+        data = out.read_bytes()
+        assert len(data) == w["bytes"] and hashlib.sha256(data).hexdigest() == w["sha256"], genome
+    from finaletoolkit_amd.genome.gaps import _cli_gap_bed
+    with pytest.raises(ValueError):
+        _cli_gap_bed("mm10", str(tmp_path / "x.bed"))
