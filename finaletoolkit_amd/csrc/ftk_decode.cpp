@@ -1916,6 +1916,7 @@ struct DevSet {
     ftk::TextSummary* h_sum = nullptr;
     hipEvent_t done = nullptr;
     bool pending = false;
+    bool host_only = false;   // the piece was not sent to the device (4 GB or more: the kernels index with 32 bits)
     size_t off = 0, len = 0;  // the launched range of h_text (complete lines)
 
     void release() {
@@ -2062,14 +2063,14 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     };
 
     auto collect = [&](DevSet& S) -> bool {
-        if (hipEventSynchronize(S.done) != hipSuccess) {
+        if (!S.host_only && hipEventSynchronize(S.done) != hipSuccess) {
             (void)hipGetLastError();
             return fail(FTK_ERR_HIP, "the device row parser failed");
         }
         S.pending = false;
         const ftk::TextSummary& sum = *S.h_sum;
         const char* b = (const char*)S.h_text + S.off;
-        const bool plain = !sum.overflow && sum.n_bad == 0 && sum.n_runs >= 1 && sum.n_runs <= (unsigned)ftk::kTextMaxRuns &&
+        const bool plain = !S.host_only && !sum.overflow && sum.n_bad == 0 && sum.n_runs >= 1 && sum.n_runs <= (unsigned)ftk::kTextMaxRuns &&
                            sum.n_lines <= S.max_lines;
         if (plain) {
             ++gpu_pieces;
@@ -2142,9 +2143,10 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         if (last > b) {
             S.off = (size_t)(b - (char*)S.h_text);
             S.len = (size_t)(last - b);
-            bool ok = hipMemsetAsync(S.d_sum, 0, sizeof(ftk::TextSummary), pstream) == hipSuccess &&
-                      hipMemcpyAsync(S.d_text, b, S.len, hipMemcpyHostToDevice, pstream) == hipSuccess;
-            if (ok) {
+            S.host_only = S.len >= (size_t(1) << 32) - 4096;
+            bool ok = S.host_only || (hipMemsetAsync(S.d_sum, 0, sizeof(ftk::TextSummary), pstream) == hipSuccess &&
+                                      hipMemcpyAsync(S.d_text, b, S.len, hipMemcpyHostToDevice, pstream) == hipSuccess);
+            if (ok && !S.host_only) {
                 ftk::textparse_launch(pstream, S.d_text, S.len, bed6, S.d_blocks, S.d_lines, S.max_lines, S.d_s, S.d_e, S.d_q,
                                       S.d_t, S.d_sum);
                 ok = hipGetLastError() == hipSuccess &&
