@@ -65,7 +65,10 @@ class _HostBlock:
 
     def __del__(self):
         if getattr(self, "_ptr", None):
-            self._lib.ftk_host_free(self._ptr)
+            try:
+                self._lib.ftk_host_free(self._ptr)
+            except Exception:  # interpreter shutdown: the library object may already be gone
+                pass
             self._ptr = None
 
 
