@@ -306,7 +306,11 @@ struct DevColumns {
         if (rows + more <= cap) return true;
         // (a multiple of 64 rows: the four arrays then start 256-byte aligned and the capacity computed back
         // from the block's size is never below the request)
-        const size_t want = (std::max<size_t>(std::max(rows + more, 2 * cap), size_t(1) << 20) + 63) / 64 * 64;
+        // A contig's first block takes four pieces' worth of rows (chr1 at 30x is four pieces): growing a block
+        // means draining the parse stream - with the next piece's DMA and kernels already in it - and blocks are
+        // recycled, so the generous first size is paid once.
+        const size_t first = rows == 0 ? 4 * more : 0;
+        const size_t want = (std::max<size_t>(std::max(std::max(rows + more, 2 * cap), first), size_t(1) << 20) + 63) / 64 * 64;
         size_t got_bytes = 0;
         void* nb = device_cache().take(want * 10 + 1024, device, &got_bytes, rows == 0);
         if (!nb) return false;
