@@ -345,6 +345,15 @@ void ftk_ctx_destroy(ftk_ctx* ctx) {
         if (kv.second.d_nblk) (void)hipFree(kv.second.d_nblk);
     }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->abuf[k]) (void)hipFree(ctx->abuf[k]);
+        if (ctx->a_kernel_done[k]) (void)hipEventDestroy(ctx->a_kernel_done[k]);
+        if (ctx->a_copy_done[k]) (void)hipEventDestroy(ctx->a_copy_done[k]);
+    }
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     for (hipEvent_t e : ctx->ev_slots)
@@ -365,6 +374,10 @@ int ftk_ctx_set_stream(ftk_ctx* ctx, void* hip_stream) {
 int ftk_ctx_sync(ftk_ctx* ctx) {
     if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->copy_stream) {  // asynchronous host results (ftk_wps_async)
+        HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+        ctx->a_pending[0] = ctx->a_pending[1] = false;
+    }
     return FTK_OK;
 }
 
@@ -1074,6 +1087,68 @@ int ftk_wps(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t ch
     if (!out_dev) {
         HIPCHK(ctx, hipMemcpyAsync(wps_out, d_out, n_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FTK_OK;
+}
+
+int ftk_wps_async(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t chrom_size, int32_t window_size,
+                  int32_t min_len, int32_t max_len, int32_t mapq_min, int64_t* wps_out_host, int* token_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    ContigData* c;
+    int rc = get_contig(ctx, contig_id, &c);
+    if (rc) return rc;
+    WpsParams p{};
+    if ((rc = wps_params(ctx, *c, chrom_size, window_size, min_len, max_len, mapq_min, &p))) return rc;
+    if (!token_out) return fail(ctx, FTK_ERR_INVALID, "token_out is NULL");
+    *token_out = -1;
+    if (stop <= start) return FTK_OK;  // degenerate interval: empty result, nothing to wait for
+    if (start < -(1LL << 30) || stop > (1LL << 31)) return fail(ctx, FTK_ERR_INVALID, "interval out of range");
+    if (!wps_out_host || is_device_ptr(wps_out_host)) return fail(ctx, FTK_ERR_INVALID, "wps_out_host must be a host array");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy_stream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->a_kernel_done[k], hipEventDisableTiming));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->a_copy_done[k], hipEventDisableTiming));
+        }
+    }
+    const int k = ctx->a_next;
+    ctx->a_next ^= 1;
+    if (ctx->a_pending[k]) {  // the buffer's previous result is still on its way to the host
+        HIPCHK(ctx, hipEventSynchronize(ctx->a_copy_done[k]));
+        ctx->a_pending[k] = false;
+    }
+    const int64_t n_pos = stop - start;
+    const size_t need = align_up((size_t)n_pos * 8);
+    if (need > ctx->abuf_bytes[k]) {
+        if (ctx->abuf[k]) HIPCHK(ctx, hipFree(ctx->abuf[k]));
+        ctx->abuf[k] = nullptr;
+        ctx->abuf_bytes[k] = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->abuf[k], need));
+        ctx->abuf_bytes[k] = need;
+    }
+    p.start = start;
+    p.stop = stop;
+    const int64_t n_tiles = (n_pos + kWpsTile - 1) / kWpsTile;
+    launch_wps(ctx->stream, c->v, p, n_tiles, nullptr, nullptr, nullptr, nullptr, nullptr, (int64_t*)ctx->abuf[k]);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->a_kernel_done[k], ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->a_kernel_done[k], 0));
+    HIPCHK(ctx, hipMemcpyAsync(wps_out_host, ctx->abuf[k], (size_t)n_pos * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
+    HIPCHK(ctx, hipEventRecord(ctx->a_copy_done[k], ctx->copy_stream));
+    ctx->a_pending[k] = true;
+    *token_out = k;
+    return FTK_OK;
+}
+
+int ftk_result_wait(ftk_ctx* ctx, int token) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    if (token < 0) return FTK_OK;  // an empty result
+    if (token > 1) return fail(ctx, FTK_ERR_INVALID, "bad result token %d", token);
+    if (ctx->a_pending[token]) {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        HIPCHK(ctx, hipEventSynchronize(ctx->a_copy_done[token]));
+        ctx->a_pending[token] = false;
     }
     return FTK_OK;
 }

@@ -93,4 +93,12 @@ struct ftk_ctx {
     // grow-only device scratch, reused by every call (stream-ordered)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
+    // asynchronous host results (ftk_wps_async): two device buffers, each copied back on the copy stream behind
+    // its kernel; a buffer is reused once its copy has finished
+    hipStream_t copy_stream = nullptr;
+    void* abuf[2] = {nullptr, nullptr};
+    size_t abuf_bytes[2] = {0, 0};
+    hipEvent_t a_kernel_done[2] = {nullptr, nullptr}, a_copy_done[2] = {nullptr, nullptr};
+    bool a_pending[2] = {false, false};
+    int a_next = 0;
 };

@@ -417,6 +417,22 @@ class Engine:
                                      L.ptr(res)))
         return res
 
+    def wps_async(self, name: str, start: int, stop: int, chrom_size: int, window_size=120, min_length=120,
+                  max_length=180, quality_threshold=30):
+        """``wps`` with the copy-back off the caller's path (``ftk_wps_async``): returns ``(scores, token)``
+        at once; ``scores`` (page-locked) is valid after ``result_wait(token)``.  Loading and scoring the next
+        contig overlaps the copy of this one; two results can be in flight."""
+        n_pos = max(int(stop) - int(start), 0)
+        res = self.result_array(n_pos, np.int64)
+        tok = C.c_int(-1)
+        self._check(self.lib.ftk_wps_async(self.ctx, self.contig_id(name), int(start), int(stop), int(chrom_size),
+                                           int(window_size), int(min_length), int(max_length), int(quality_threshold),
+                                           L.ptr(res), C.byref(tok)))
+        return res, int(tok.value)
+
+    def result_wait(self, token: int):
+        self._check(self.lib.ftk_result_wait(self.ctx, int(token)))
+
     def wps_intervals(self, name: str, starts, stops, chrom_size: int, window_size=120, min_length=120,
                       max_length=180, quality_threshold=30):
         """a8: WPS of many intervals of one contig in one launch; returns

@@ -295,6 +295,15 @@ int ftk_wps(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t ch
 /* frag/_multi_wps.py:196-198: the same for n_iv intervals of one contig in
  * one launch; interval i writes iv_stop[i] - iv_start[i] values at
  * wps_out + out_offset[i].  iv_* / out_offset are host arrays. */
+/* ftk_wps with the copy-back taken off the caller's path: returns once the kernel (ctx stream) and the copy of
+ * the scores into wps_out_host (the ctx's copy stream, behind the kernel) are enqueued; the next calls on the ctx
+ * - loading and scoring the next contig - overlap the copy.  *token_out identifies the result: the array is
+ * valid after ftk_result_wait(ctx, token) (or ftk_ctx_sync).  Two results can be in flight; a third call
+ * waits for the older one's copy.  wps_out_host should come from ftk_host_alloc (a pageable array is copied
+ * through a staging buffer and gains nothing).  A degenerate interval gives token -1 (nothing to wait for). */
+int ftk_wps_async(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t chrom_size, int32_t window_size,
+                  int32_t min_len, int32_t max_len, int32_t mapq_min, int64_t* wps_out_host, int* token_out);
+int ftk_result_wait(ftk_ctx* ctx, int token);
 int ftk_wps_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start, const int64_t* iv_stop, int64_t n_iv,
                       const int64_t* out_offset, int64_t chrom_size, int32_t window_size, int32_t min_len,
                       int32_t max_len, int32_t mapq_min, int64_t* wps_out);

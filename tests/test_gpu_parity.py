@@ -179,6 +179,29 @@ def test_large_results_come_back_in_page_locked_memory(engine, data):
     lib.ftk_host_free(C.cast(junk, C.c_void_p))  # not one of the library's blocks: ignored
 
 
+def test_wps_async_results_equal_the_synchronous_call(engine, data):
+    """ftk_wps_async: kernel on the ctx stream, copy-back on the copy stream; several results in flight (the third
+    call waits for the first buffer), tokens, the degenerate interval, ftk_ctx_sync as the catch-all wait."""
+    spans = [(0, 1_200_000), (900_000, 2_950_000), (5, 77), (1_000_000, 2_300_000), (2_990_000, 3_000_000)]
+    want = [engine.wps("synA", a, b, CONTIG_LEN, 120, 120, 180, 30) for a, b in spans]
+    got = [engine.wps_async("synA", a, b, CONTIG_LEN, 120, 120, 180, 30) for a, b in spans]  # never more than 2 pending
+    for (arr, tok), w in zip(got, want):
+        assert tok in (0, 1)
+        engine.result_wait(tok)
+        assert np.array_equal(arr, w)
+    arr, tok = engine.wps_async("synA", 500, 500, CONTIG_LEN)
+    assert tok == -1 and len(arr) == 0
+    engine.result_wait(tok)
+    a1, _ = engine.wps_async("synA", 0, 1_500_000, CONTIG_LEN, 120, 120, 180, 30)
+    a2, _ = engine.wps_async("synA", 1_500_000, 3_000_000, CONTIG_LEN, 120, 120, 180, 30)
+    cov = engine.window_features("synA", np.array([0], np.int32), np.array([CONTIG_LEN], np.int32), 30)["coverage"]  # overlaps the copies
+    engine.sync()
+    whole = engine.wps("synA", 0, 3_000_000, CONTIG_LEN, 120, 120, 180, 30)
+    assert np.array_equal(np.concatenate([a1, a2]), whole) and int(cov[0]) > 0
+    with pytest.raises(Exception):
+        engine.result_wait(7)
+
+
 def test_page_locked_result_limit_falls_back_to_ordinary_memory():
     """Beyond FTK_PINNED_RESULT_LIMIT_MB of outstanding results ftk_host_alloc refuses and result_array hands
     out an ordinary numpy array (child process: the limit is read once)."""
