@@ -168,15 +168,16 @@ int upload_common(ftk_ctx* ctx, int contig_id, const int32_t* start, const int32
         return fail(ctx, FTK_ERR_HIP, "fragment upload failed: %s", hipGetErrorString(e));
     }
     // validate + summarise on the device
+    // (the summary lives in a device word block kept by the ctx: a hipMalloc / hipFree pair per contig made every
+    // load wait for the whole device - an asynchronous copy-back of the previous contig's scores included)
     FragStats init{0, INT32_MIN, INT32_MAX, INT32_MIN, INT32_MAX};
-    FragStats* d_st = nullptr;
     FragStats h_st = init;
-    e = hipMalloc((void**)&d_st, sizeof(FragStats));
+    if (!ctx->d_stats) e = hipMalloc(&ctx->d_stats, sizeof(FragStats));
+    FragStats* d_st = (FragStats*)ctx->d_stats;
     if (e == hipSuccess) e = hipMemcpyAsync(d_st, &init, sizeof(init), hipMemcpyHostToDevice, s);
     if (e == hipSuccess && n > 0) launch_stats(s, d_start, d_end, (int)n, d_st);
     if (e == hipSuccess) e = hipMemcpyAsync(&h_st, d_st, sizeof(h_st), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (d_st) (void)hipFree(d_st);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         free_contig(c);
@@ -345,6 +346,7 @@ void ftk_ctx_destroy(ftk_ctx* ctx) {
         if (kv.second.d_nblk) (void)hipFree(kv.second.d_nblk);
     }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->copy_stream) {
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);

@@ -93,6 +93,7 @@ struct ftk_ctx {
     // grow-only device scratch, reused by every call (stream-ordered)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
+    void* d_stats = nullptr;  // load-time validation summary (upload_common)
     // asynchronous host results (ftk_wps_async): two device buffers, each copied back on the copy stream behind
     // its kernel; a buffer is reused once its copy has finished
     hipStream_t copy_stream = nullptr;
