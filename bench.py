@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from finaletoolkit_amd import synth  # noqa: E402
-from finaletoolkit_amd.sharding import split_units, unit_halo  # noqa: E402
+from finaletoolkit_amd.sharding import launch_ranks, split_units, unit_halo  # noqa: E402
 
 WINDOW = 100_000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -82,7 +82,14 @@ def main():
     ap.add_argument("--contigs", type=str, default="", help="comma list (default: b37 1-22,X,Y)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the file -> result legs (end_to_end in the JSON)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N fresh rank processes
+        # (it has not touched the GPU and never will) and exits with their status
+        raise SystemExit(launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                      share_gpu=os.environ.get("FTK_BENCH_SHARE_GPU") == "1"))
 
     import torch
     import torch.distributed as dist
@@ -92,8 +99,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; "
+                         f"they must agree (one rank per GPU)")
+    share = os.environ.get("FTK_BENCH_SHARE_GPU") == "1"  # test mode: every rank on GPU 0, gloo exchange
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    if not share and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} visible MI355X devices, found "
+                         f"{torch.cuda.device_count()} (one rank per GPU; no fallback to fewer)")
+    if share:
+        local = 0
+        os.environ.setdefault("FTK_BENCH_DIST_BACKEND", "gloo")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # FTK_BENCH_FORCE_DIST=1 drives the collective code path with a 1-rank RCCL group (1-GPU boxes)
@@ -458,7 +475,10 @@ def main():
             cpu = cpu_baseline(torch, eng, per, mine, args.cpu_seconds, checks)
         out = {
             "metric": "genomic windows/sec (coverage+WPS+DELFI) at 30x WGS",
-            "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 1), "unit": "windows/s", "n_gpus": world,
+            "rccl_ranks": (dist.get_world_size() if use_dist and backend == "nccl" else None),
+            "exchange": (f"torch.distributed/{backend} all-gather, {dist.get_world_size()} ranks" if use_dist else "none (1 rank)"),
+            "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "int32/int64", "data": "synthetic",
             "config": {"workload": f"whole-genome b37 1-22,X,Y synthetic {args.depth:g}x fragments "

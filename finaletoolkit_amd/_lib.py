@@ -51,7 +51,6 @@ EXPORTS = [
     "ftk_window_features_batch", "ftk_wps_batch", "ftk_wps_window_features", "ftk_frag_lengths",
     "ftk_frag_select",
     "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals", "ftk_wps_adjust",
-    "ftk_comm_unique_id", "ftk_comm_create", "ftk_allgather_i64", "ftk_allreduce_sum_i64", "ftk_comm_destroy",
     "ftk_ref_upload", "ftk_ref_release", "ftk_ref_gc_counts", "ftk_ref_set_layout", "ftk_motif_counts",
 ]
 
@@ -191,12 +190,6 @@ def load() -> C.CDLL:
     lib.ftk_cleavage.argtypes = [vp, C.c_int, i64, i64, i32, i32, i32, vp]
     lib.ftk_cleavage_intervals.argtypes = [vp, C.c_int, vp, vp, i64, vp, i32, i32, i32, vp]
     lib.ftk_wps_adjust.argtypes = [vp, vp, vp, i64, i32, C.c_int, vp, i32, vp, vp, vp]
-    lib.ftk_comm_unique_id.argtypes = [C.c_char_p]
-    lib.ftk_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]
-    lib.ftk_allgather_i64.argtypes = [vp, vp, i64, vp]
-    lib.ftk_allreduce_sum_i64.argtypes = [vp, vp, i64]
-    lib.ftk_comm_destroy.argtypes = [vp]
-    lib.ftk_comm_destroy.restype = None
     lib.ftk_ref_upload.argtypes = [vp, C.c_int, vp, i64, C.c_int]
     lib.ftk_ref_release.argtypes = [vp, C.c_int]
     lib.ftk_ref_gc_counts.argtypes = [vp, C.c_int, vp, vp, i64, vp]

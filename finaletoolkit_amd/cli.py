@@ -30,6 +30,9 @@ def _shared(p, min_default, max_default=None, threads=True, policy=True, output_
 
 def build_parser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser(prog="finaletoolkit-amd", description="MI355X fragment-feature engine")
+    ap.add_argument("--gpus", type=int, default=1, metavar="N",
+                    help="run `coverage` / `delfi` as N ranks, one per MI355X (contigs dealt to the ranks, one "
+                         "RCCL all-gather of the bin vector); also honoured under torchrun")
     sub = ap.add_subparsers(dest="command", required=True)
 
     p = sub.add_parser("coverage", help="fragment coverage over BED intervals")
@@ -152,7 +155,16 @@ def build_parser() -> argparse.ArgumentParser:
 
 
 def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
     a = build_parser().parse_args(argv)
+    import os
+    from . import sharding
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one rank per GPU (the reference's Pool(workers) fan-out): this process only launches them
+        return sharding.launch_ranks([sys.executable, "-m", "finaletoolkit_amd.cli"] + argv, a.gpus,
+                                     share_gpu=os.environ.get("FTK_SHARE_GPU") == "1")
+    if a.command in ("coverage", "delfi"):  # the commands whose work is dealt to the ranks
+        sharding.init_from_env()
     from . import frag
     if a.command == "coverage":
         frag.coverage(a.input_file, a.interval_file, a.output_file, scale_factor=a.scale_factor,
@@ -211,6 +223,7 @@ def main(argv=None) -> int:
                    gap_file=a.gap_file, output_file=a.output_file, no_gc_correct=a.no_gc_correct,
                    remove_nocov=a.remove_nocov, merge_bins=a.merge_bins, window_size=a.window_size,
                    quality_threshold=a.quality_threshold, workers=a.workers, verbose=a.verbose)
+    sharding.finalize()
     return 0
 
 

@@ -9,7 +9,6 @@
 #include <type_traits>
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include "ftk_kernels.h"
 
@@ -596,10 +595,17 @@ int upload_batch_descriptors(ftk_ctx* ctx, int slot, const void* host, size_t by
 // Device-resident windows + per-window blacklist CSR, cached by content.
 int get_delfi_meta(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
                    const int32_t* bl_start, const int32_t* bl_end, int64_t n_bl, DelfiMeta** out) {
-    uint64_t key = 1469598103934665603ull;
-    auto mix = [&key](const void* p, size_t n) {
+    // two independent 64-bit digests of the content (FNV-1a over bytes, a multiply-rotate mix over bytes with
+    // a different constant and position weighting): an entry is reused only when both agree, together with the
+    // contig and both counts
+    uint64_t key = 1469598103934665603ull, key2 = 0x9E3779B97F4A7C15ull;
+    auto mix = [&key, &key2](const void* p, size_t n) {
         const unsigned char* b = (const unsigned char*)p;
-        for (size_t i = 0; i < n; ++i) key = (key ^ b[i]) * 1099511628211ull;
+        for (size_t i = 0; i < n; ++i) {
+            key = (key ^ b[i]) * 1099511628211ull;
+            key2 = (key2 + b[i] + 1) * 0xD6E8FEB86659FD93ull;
+            key2 ^= key2 >> 29;
+        }
     };
     mix(&contig_id, sizeof(contig_id));
     mix(&n_win, sizeof(n_win));
@@ -608,7 +614,10 @@ int get_delfi_meta(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const in
     mix(w_end, n_win * 4);
     if (n_bl) { mix(bl_start, n_bl * 4); mix(bl_end, n_bl * 4); }
     for (auto& m : ctx->delfi_cache)
-        if (m.key == key && m.contig_id == contig_id && m.n_win == n_win) { *out = &m; return FTK_OK; }
+        if (m.key == key && m.key2 == key2 && m.contig_id == contig_id && m.n_win == n_win && m.n_bl == n_bl) {
+            *out = &m;
+            return FTK_OK;
+        }
     // Blacklist regions fully inside each window (frag/_delfi.py:110-126):
     // region start >= w_start (bisect on the sorted starts) and stop <= w_end.
     // Per window keep (r0, running max of r1); a fragment is blacklisted iff
@@ -639,8 +648,10 @@ int get_delfi_meta(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const in
     }
     DelfiMeta m;
     m.key = key;
+    m.key2 = key2;
     m.contig_id = contig_id;
     m.n_win = n_win;
+    m.n_bl = n_bl;
     m.n_r = r0.size();
     const size_t b_w = align_up(n_win * 4), b_o = align_up((n_win + 1) * 4), b_r = align_up(std::max<size_t>(m.n_r, 1) * 4);
     HIPCHK(ctx, hipMalloc(&m.base, 2 * b_w + b_o + 2 * b_r));
@@ -1663,152 +1674,6 @@ int ftk_ref_gc_counts(ftk_ctx* ctx, int ref_id, const int64_t* range_lo, const i
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     return FTK_OK;
-}
-
-}  // extern "C"
-
-// ---- RCCL-backed exchange (no link-time dependency: resolved at ftk_comm_create) ---------------
-struct ftk_comm {
-    ftk_ctx* ctx = nullptr;
-    ncclComm_t comm = nullptr;
-    int rank = 0, world = 1;
-};
-
-namespace {
-
-struct RcclApi {
-    void* lib = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
-};
-
-RcclApi* rccl() {
-    static RcclApi api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
-        // a librccl already in the process (e.g. torch's) is re-used: same soname
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (api.lib) break;
-        }
-        if (api.lib) {
-            api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
-            api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
-            api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
-            api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
-            api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
-            api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
-        }
-    }
-    const bool ok = api.lib && api.GetUniqueId && api.CommInitRank && api.AllGather && api.AllReduce && api.CommDestroy;
-    return ok ? &api : nullptr;
-}
-
-#define RCCLCHK(ctx, call)                                                                            \
-    do {                                                                                              \
-        ncclResult_t r_ = (call);                                                                     \
-        if (r_ != ncclSuccess)                                                                        \
-            return fail(ctx, FTK_ERR_HIP, "%s: %s", #call, rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "RCCL error"); \
-    } while (0)
-
-}  // namespace
-
-extern "C" {
-
-int ftk_comm_unique_id(char id_out[128]) {
-    if (!id_out) return fail(nullptr, FTK_ERR_INVALID, "id_out is NULL");
-    RcclApi* a = rccl();
-    if (!a) return fail(nullptr, FTK_ERR_NO_DEVICE, "librccl could not be loaded");
-    ncclUniqueId id;
-    RCCLCHK(nullptr, a->GetUniqueId(&id));
-    memcpy(id_out, id.internal, 128);
-    return FTK_OK;
-}
-
-int ftk_comm_create(ftk_ctx* ctx, int rank, int world, const char id[128], ftk_comm** out) {
-    if (!ctx || !out || !id) return fail(ctx, FTK_ERR_INVALID, "NULL argument");
-    *out = nullptr;
-    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, FTK_ERR_INVALID, "bad rank / world");
-    RcclApi* a = rccl();
-    if (!a) return fail(ctx, FTK_ERR_NO_DEVICE, "librccl could not be loaded");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    ncclUniqueId uid;
-    memcpy(uid.internal, id, 128);
-    ftk_comm* c = new (std::nothrow) ftk_comm();
-    if (!c) return fail(ctx, FTK_ERR_OOM, "out of host memory");
-    c->ctx = ctx;
-    c->rank = rank;
-    c->world = world;
-    ncclResult_t r = a->CommInitRank(&c->comm, world, uid, rank);
-    if (r != ncclSuccess) {
-        delete c;
-        return fail(ctx, FTK_ERR_HIP, "ncclCommInitRank: %s", a->GetErrorString ? a->GetErrorString(r) : "RCCL error");
-    }
-    *out = c;
-    return FTK_OK;
-}
-
-int ftk_allgather_i64(ftk_comm* comm, const int64_t* send, int64_t n, int64_t* recv) {
-    if (!comm) return fail(nullptr, FTK_ERR_INVALID, "comm is NULL");
-    ftk_ctx* ctx = comm->ctx;
-    if (n < 0 || (n > 0 && (!send || !recv))) return fail(ctx, FTK_ERR_INVALID, "bad arguments");
-    if (n == 0) return FTK_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    const bool s_dev = is_device_ptr(send), r_dev = is_device_ptr(recv);
-    const size_t b = (size_t)n * 8;
-    int rc = reserve_scratch(ctx, (s_dev ? 0 : align_up(b)) + (r_dev ? 0 : align_up(b * comm->world)));
-    if (rc) return rc;
-    Arena a(ctx);
-    const int64_t* d_send = send;
-    if (!s_dev) {
-        int64_t* t = a.take<int64_t>(n);
-        HIPCHK(ctx, hipMemcpyAsync(t, send, b, hipMemcpyHostToDevice, ctx->stream));
-        d_send = t;
-    }
-    int64_t* d_recv = r_dev ? recv : a.take<int64_t>((size_t)n * comm->world);
-    RCCLCHK(ctx, rccl()->AllGather(d_send, d_recv, (size_t)n, ncclInt64, comm->comm, ctx->stream));
-    if (!r_dev) {
-        HIPCHK(ctx, hipMemcpyAsync(recv, d_recv, b * comm->world, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    return FTK_OK;
-}
-
-int ftk_allreduce_sum_i64(ftk_comm* comm, int64_t* values, int64_t n) {
-    if (!comm) return fail(nullptr, FTK_ERR_INVALID, "comm is NULL");
-    ftk_ctx* ctx = comm->ctx;
-    if (n < 0 || (n > 0 && !values)) return fail(ctx, FTK_ERR_INVALID, "bad arguments");
-    if (n == 0) return FTK_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    const bool dev = is_device_ptr(values);
-    const size_t b = (size_t)n * 8;
-    int rc = reserve_scratch(ctx, dev ? 0 : align_up(b));
-    if (rc) return rc;
-    int64_t* d = values;
-    if (!dev) {
-        d = (int64_t*)ctx->scratch;
-        HIPCHK(ctx, hipMemcpyAsync(d, values, b, hipMemcpyHostToDevice, ctx->stream));
-    }
-    RCCLCHK(ctx, rccl()->AllReduce(d, d, (size_t)n, ncclInt64, ncclSum, comm->comm, ctx->stream));
-    if (!dev) {
-        HIPCHK(ctx, hipMemcpyAsync(values, d, b, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    return FTK_OK;
-}
-
-void ftk_comm_destroy(ftk_comm* comm) {
-    if (!comm) return;
-    if (comm->comm && rccl()) {
-        (void)hipStreamSynchronize(comm->ctx->stream);
-        (void)rccl()->CommDestroy(comm->comm);
-    }
-    delete comm;
 }
 
 }  // extern "C"

@@ -398,9 +398,14 @@ struct PinnedCache {
         {
             std::lock_guard<std::mutex> lk(mu);
             if (max_live && live_bytes + bytes > max_live) return nullptr;
+            // smallest block that fits; a block may exceed the request by 2x (tables) or 8x + 64 MB (results:
+            // they shrink from contig to contig, chr1's block serves chrY) -- never an 8 MB request on a 2 GB
+            // block -- and what it pins in full must fit under the limit, since that is what gets accounted
+            const size_t slack = any_larger ? 8 * bytes + (size_t(64) << 20) : 2 * bytes + (1 << 20);
             int best = -1;
             for (int i = 0; i < (int)free_list.size(); ++i)
-                if (free_list[i].cap >= bytes && (any_larger || free_list[i].cap <= 2 * bytes + (1 << 20)) &&
+                if (free_list[i].cap >= bytes && free_list[i].cap <= slack &&
+                    (!max_live || live_bytes + free_list[i].cap <= max_live) &&
                     (best < 0 || free_list[i].cap < free_list[best].cap))
                     best = i;
             if (best >= 0) {

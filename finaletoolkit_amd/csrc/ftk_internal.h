@@ -54,9 +54,9 @@ struct ContigData {
 // caller keeps passing the same arrays (the reference parses its blacklist
 // once per worker too, frag/_delfi.py:65-107).
 struct DelfiMeta {
-    uint64_t key = 0;
+    uint64_t key = 0, key2 = 0;
     int contig_id = -1;
-    int64_t n_win = 0;
+    int64_t n_win = 0, n_bl = 0;
     size_t n_r = 0;
     void* base = nullptr;  // one allocation
     int32_t *d_ws = nullptr, *d_we = nullptr, *d_off = nullptr, *d_r0 = nullptr, *d_pm = nullptr;

@@ -90,10 +90,16 @@ class Engine:
         self._ids: dict[str, int] = {}
         self._next_id = 0
         self._bam: dict[str, bool] = {}
+        # results whose device -> host copy may still be in flight (wps_async), by token: the engine keeps
+        # the page-locked block alive until the copy is known to be done, whatever the caller drops
+        self._pending: dict[int, np.ndarray] = {}
 
     # -- plumbing -------------------------------------------------------------
     def close(self):
         if getattr(self, "ctx", None):
+            if self._pending:
+                self.lib.ftk_ctx_sync(self.ctx)  # no DMA may outlive its target block
+                self._pending.clear()
             self.lib.ftk_ctx_destroy(self.ctx)
             self.ctx = None
 
@@ -133,6 +139,7 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.ftk_ctx_sync(self.ctx))
+        self._pending.clear()
 
     def timer_start(self):
         self._check(self.lib.ftk_timer_start(self.ctx))
@@ -428,10 +435,15 @@ class Engine:
         self._check(self.lib.ftk_wps_async(self.ctx, self.contig_id(name), int(start), int(stop), int(chrom_size),
                                            int(window_size), int(min_length), int(max_length), int(quality_threshold),
                                            L.ptr(res), C.byref(tok)))
+        if tok.value >= 0:
+            # a token is the copy slot (0 / 1) and is reused every second call; the library waited for the
+            # slot's previous copy before reusing it, so the array registered under it before is complete
+            self._pending[int(tok.value)] = res
         return res, int(tok.value)
 
     def result_wait(self, token: int):
         self._check(self.lib.ftk_result_wait(self.ctx, int(token)))
+        self._pending.pop(int(token), None)
 
     def wps_intervals(self, name: str, starts, stops, chrom_size: int, window_size=120, min_length=120,
                       max_length=180, quality_threshold=30):

@@ -16,6 +16,7 @@ from typing import NamedTuple, Union
 
 import numpy as np
 
+from .. import sharding
 from ..source import get_engine, open_source
 from ..utils import _check_policy, _check_region, _region_contigs, get_intervals
 
@@ -32,14 +33,27 @@ class CoverageResult(NamedTuple):
     coverage: float
 
 
-def _total(src, contig, start, stop, min_length, max_length, intersect_policy, quality_threshold) -> int:
+def _weights(src, names, extent=None):
+    """Cost estimate per contig for the rank assignment: its length when the file knows it (BAM header), else
+    the furthest interval stop, else 1."""
+    return {c: float(src.lengths.get(c) or (extent or {}).get(c) or 1) for c in names}
+
+
+def _total(src, contig, start, stop, min_length, max_length, intersect_policy, quality_threshold,
+           sharded=False) -> int:
+    """Fragments of the region (the whole file when ``contig`` is None).  ``sharded``: the contigs are dealt to
+    the ranks of the process group and the per-rank sums meet in one int64 all-reduce."""
     eng = get_engine()
     names, whole = _region_contigs(src, contig)
+    rank, world = sharding.rank_world() if sharded else (0, 1)
+    owner = sharding.lpt_assign(_weights(src, names), world)
     total = 0
     for c in names:
+        if owner[c] != rank:
+            continue
         total += int(eng.window_counts(src.require(c), [None if whole else start], [None if whole else stop],
                                        quality_threshold, min_length, max_length, intersect_policy)[0])
-    return total
+    return sharding.allreduce_sum(total) if world > 1 else total
 
 
 def single_coverage(input_file: Union[str, Path], contig: str | None = None, start: int | None = 0,
@@ -61,17 +75,31 @@ def single_coverage(input_file: Union[str, Path], contig: str | None = None, sta
 
 
 def _interval_counts(src, intervals, min_length, max_length, intersect_policy, quality_threshold):
-    """Counts for every interval, in interval order (the ``imap`` of :244-248)."""
+    """Counts for every interval, in interval order (the ``imap`` of :244-248).  The reference spreads the
+    intervals over ``Pool(workers)``; here every rank of the process group counts the intervals of ITS
+    contigs (one launch per contig) and one all-gather hands every rank the full vector."""
     eng = get_engine()
     counts = np.zeros(len(intervals), np.int64)
     by_contig: dict[str, list[int]] = {}
-    for i, (c, _, _, _) in enumerate(intervals):
+    extent: dict[str, int] = {}
+    for i, (c, _, b, _) in enumerate(intervals):
         by_contig.setdefault(c, []).append(i)
+        extent[c] = max(extent.get(c, 0), int(b))
+    rank, world = sharding.rank_world()
+    names = list(by_contig)
+    weights = _weights(src, names, extent)
+    owner = sharding.lpt_assign(weights, world)
+    local = {}
     for c, idx in by_contig.items():
+        if owner[c] != rank:
+            continue
         ws = np.array([intervals[i][1] for i in idx], np.int64)
         we = np.array([intervals[i][2] for i in idx], np.int64)
-        counts[idx] = eng.window_counts(src.require(c), ws.astype(np.int32), we.astype(np.int32), quality_threshold,
-                                        min_length, max_length, intersect_policy)
+        local[c] = eng.window_counts(src.require(c), ws.astype(np.int32), we.astype(np.int32), quality_threshold,
+                                     min_length, max_length, intersect_policy).reshape(-1, 1)
+    full = sharding.gather_bin_vectors(local, names, {c: len(by_contig[c]) for c in names}, weights, k=1)
+    for c, idx in by_contig.items():
+        counts[idx] = np.asarray(full[c]).reshape(-1)
     return counts
 
 
@@ -88,7 +116,8 @@ def coverage(input_file: Union[str, Path], interval_file: str, output_file: str,
     src = open_source(input_file, workers)
     if normalize:
         # single_coverage(input_file, None, 0, None, "."): the whole file (:215-227)
-        total = _total(src, None, 0, None, min_length, max_length, intersect_policy, quality_threshold)
+        total = _total(src, None, 0, None, min_length, max_length, intersect_policy, quality_threshold,
+                       sharded=True)
     intervals = get_intervals(interval_file)
     counts = _interval_counts(src, intervals, min_length, max_length, intersect_policy, quality_threshold)
     if normalize:
@@ -96,6 +125,11 @@ def coverage(input_file: Union[str, Path], interval_file: str, output_file: str,
             sys.stderr.write(f"Total coverage is {total}\n")
         scale_factor /= total
 
+    if output_file is not None and sharding.rank_world()[0] != 0:
+        # every rank returns the same list; rank 0 alone writes the file / stdout
+        if not (output_file.endswith((".bed", ".bedgraph", ".bed.gz")) or output_file == "-"):
+            raise ValueError("output_file should have .bed or .bed.gz as suffix")
+        output_file = None
     return_val: list[CoverageResult] = []
     output_is_file = False
     if output_file is not None:

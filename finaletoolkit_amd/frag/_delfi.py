@@ -22,6 +22,7 @@ import pandas
 from ..genome.gaps import GenomeGaps
 from ..reference import ReferenceGenome
 from ..source import get_engine, open_source
+from .. import sharding
 from ..utils import chrom_sizes_to_list, overlaps
 from ._delfi_gc_correct import delfi_gc_correct
 from ._delfi_merge_bins import delfi_merge_bins
@@ -80,9 +81,9 @@ def _valid_interval(chroms: dict, contig, start, stop) -> bool:
     return True
 
 
-def _contig_windows(src, eng, ref, contig, starts, stops, contig_gaps, blacklist, quality_threshold):
-    """Rows ``(contig, start, stop, arm, short, long, gc, num_frags)`` for the
-    bins of one contig, in bin order (frag/_delfi.py:404-511)."""
+def _gate_windows(contig, starts, stops, contig_gaps):
+    """Window-level gating of frag/_delfi.py:416-428 (host, every rank): arm label per bin and which bins go
+    to the device."""
     n = len(starts)
     arms = [contig] * n
     live = np.ones(n, dtype=bool)
@@ -95,28 +96,50 @@ def _contig_windows(src, eng, ref, contig, starts, stops, contig_gaps, blacklist
             arms[i] = arm
             if arm == "NOARM":
                 live[i] = False
-    rows = [None] * n
+    return arms, live
+
+
+def _contig_counts(src, eng, ref, contig, starts, stops, live, ok, contig_gaps, blacklist, quality_threshold):
+    """Device part of one contig (the rank that owns it): ``[n_live, 4]`` int64 rows
+    ``(short, long, num_frags, num_gc)`` of its live bins -- one ``ftk_delfi_counts`` launch and one GC-count
+    launch (frag/_delfi.py:443-490)."""
     idx = np.nonzero(live)[0]
+    out = np.zeros((len(idx), 4), np.int64)
     if len(idx):
         bl = blacklist.get(contig)
         sh, lg, nf = eng.delfi_counts(
             src.require(contig), starts[idx].astype(np.int32), stops[idx].astype(np.int32), quality_threshold,
             None if bl is None else bl[0], None if bl is None else bl[1],
             None if contig_gaps is None else contig_gaps.as_kernel_constants())
-        # GC count of every live bin in one device launch (frag/_delfi.py:476-490)
-        ok = np.array([_valid_interval(ref.chroms, contig, int(starts[i]), int(stops[i])) for i in idx], dtype=bool)
-        num_gc = np.zeros(len(idx), np.int64)
+        out[:, 0], out[:, 1], out[:, 2] = sh, lg, nf
         if ok.any():
-            num_gc[ok] = ref.gc_counts(eng, contig, starts[idx][ok], stops[idx][ok])
-        for k, i in enumerate(idx):
-            ws, we = int(starts[i]), int(stops[i])
-            if not ok[k]:
-                warnings.warn(f"Invalid interval {contig}:{ws}-{we} for reference. Skipping GC calculation.")
-            gc = int(num_gc[k]) / (we - ws) if nf[k] > 0 else np.nan
-            rows[i] = (contig, ws, we, arms[i], int(sh[k]), int(lg[k]), gc, int(nf[k]))
+            out[ok, 3] = ref.gc_counts(eng, contig, starts[idx][ok], stops[idx][ok])
+    return out
+
+
+def _contig_rows(contig, starts, stops, arms, live, ok, counts):
+    """Rows ``(contig, start, stop, arm, short, long, gc, num_frags)`` of one contig's bins in bin order
+    (frag/_delfi.py:404-511), from the gathered device counts (host, every rank)."""
+    rows = [None] * len(starts)
+    for k, i in enumerate(np.nonzero(live)[0]):
+        ws, we = int(starts[i]), int(stops[i])
+        if not ok[k]:
+            warnings.warn(f"Invalid interval {contig}:{ws}-{we} for reference. Skipping GC calculation.")
+        sh, lg, nf, num_gc = (int(v) for v in counts[k])
+        gc = num_gc / (we - ws) if nf > 0 else np.nan
+        rows[i] = (contig, ws, we, arms[i], sh, lg, gc, nf)
     for i in np.nonzero(~live)[0]:
         rows[i] = (contig, int(starts[i]), int(stops[i]), "NOARM", np.nan, np.nan, np.nan, 0)
     return rows
+
+
+def _contig_windows(src, eng, ref, contig, starts, stops, contig_gaps, blacklist, quality_threshold):
+    """One contig start to finish on this GPU: gate, count, assemble (what a 1-rank ``delfi`` does per contig)."""
+    arms, live = _gate_windows(contig, starts, stops, contig_gaps)
+    ok = np.array([_valid_interval(ref.chroms, contig, int(starts[i]), int(stops[i])) for i in np.nonzero(live)[0]],
+                  dtype=bool)
+    counts = _contig_counts(src, eng, ref, contig, starts, stops, live, ok, contig_gaps, blacklist, quality_threshold)
+    return _contig_rows(contig, starts, stops, arms, live, ok, counts)
 
 
 def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str, blacklist_file: str = None,
@@ -153,16 +176,38 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
 
     src = open_source(input_file, workers)
     eng = get_engine()
-    windows = []
+    # The reference fans the bins out over Pool(workers) (frag/_delfi.py:289-300).  Here the fan-out is one
+    # rank per GPU: contigs are dealt to the ranks of the initialised process group (LPT on bin counts), a
+    # rank decodes and counts only its own contigs, and ONE all-gather of the per-bin
+    # (short, long, num_frags, num_gc) vector gives every rank the whole table -- the frame returned is
+    # the same on all ranks and equal to the single-GPU one.
+    rank, world = sharding.rank_world()
+    plan = []  # (contig, starts, stops, arms, live, ok) in chrom.sizes order, bins in file order (:269-283)
     with ReferenceGenome(reference_file) as ref:
-        for contig, _size in contigs:  # chrom.sizes order, bins in file order (:269-283)
+        for contig, _size in contigs:
             sel = gapless_bins.loc[gapless_bins["contig"] == contig]
             if sel.shape[0] == 0:
                 continue
-            windows += _contig_windows(src, eng, ref, contig, sel["start"].to_numpy().astype(np.int64),
-                                       sel["stop"].to_numpy().astype(np.int64),
-                                       contig_gaps.get(contig) if gaps is not None else None, blacklist,
-                                       quality_threshold)
+            starts = sel["start"].to_numpy().astype(np.int64)
+            stops = sel["stop"].to_numpy().astype(np.int64)
+            arms, live = _gate_windows(contig, starts, stops, contig_gaps.get(contig) if gaps is not None else None)
+            ok = np.array([_valid_interval(ref.chroms, contig, int(starts[i]), int(stops[i]))
+                           for i in np.nonzero(live)[0]], dtype=bool)
+            plan.append((contig, starts, stops, arms, live, ok))
+        names = [p[0] for p in plan]
+        weights = {p[0]: float(len(p[1])) for p in plan}
+        owner = sharding.lpt_assign(weights, world)
+        local = {}
+        for contig, starts, stops, arms, live, ok in plan:
+            if owner[contig] == rank:
+                local[contig] = _contig_counts(src, eng, ref, contig, starts, stops, live, ok,
+                                               contig_gaps.get(contig) if gaps is not None else None, blacklist,
+                                               quality_threshold)
+    n_live = {p[0]: int(p[4].sum()) for p in plan}
+    counts = sharding.gather_bin_vectors(local, names, n_live, weights, k=4)
+    windows = []
+    for contig, starts, stops, arms, live, ok in plan:
+        windows += _contig_rows(contig, starts, stops, arms, live, ok, counts[contig])
 
     window_df = pandas.DataFrame(windows, columns=["contig", "start", "stop", "arm", "short", "long", "gc",
                                                    "num_frags"])
@@ -178,7 +223,7 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
         final = delfi_gc_correct(final, 0.75, 8, verbose)
     if merge_bins:
         final = delfi_merge_bins(final, gc_correct, verbose=verbose)
-    if output_file is not None:
+    if output_file is not None and rank == 0:  # every rank holds the same frame; one of them writes it
         _write_delfi(final, output_file)
     if verbose:
         stderr.write(f"{sum(w[7] for w in windows)} fragments included.\n")

@@ -9,9 +9,118 @@ transport; payloads are a few hundred KB, i.e. latency-bound.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
+
+
+def launch_ranks(cmd: Sequence[str], n: int, share_gpu: bool = False) -> int:
+    """Start ``n`` fresh rank processes of ``cmd`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, one GPU each) and wait for them; rank 0 inherits stdout, the other ranks' stdout is dropped.
+    The calling process must not have initialised the GPU and does not here
+    (``torch.cuda.device_count()`` does not).  Returns the exit status: 2 when fewer than ``n`` devices are
+    visible, else the first failing rank's (a failed rank ends the others, which would wait in a collective
+    forever).  ``share_gpu`` (tests on a 1-GPU box): every rank on GPU 0, exchange through gloo."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    if not share_gpu:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write(f"--gpus {n} needs {n} visible MI355X devices, found {have} "
+                             f"(one rank per GPU; no fallback to fewer)\n")
+            return 2
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(s.getsockname()[1])
+        s.close()
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if share_gpu:
+        env.setdefault("FTK_DIST_BACKEND", "gloo")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(0 if share_gpu else r))
+        procs.append(subprocess.Popen(list(cmd), env=e, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            if p.poll() is not None:
+                live.remove(p)
+                rc = rc or p.returncode
+        if rc:
+            for p in live:
+                p.kill()
+                p.wait()
+            break
+    return rc
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int]:
+    """Join the job's process group when this process was started as one rank of several (``torchrun``, or
+    ``python -m finaletoolkit_amd.cli --gpus N``: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in the
+    environment): backend ``nccl`` (= RCCL over xGMI) bound to GPU ``LOCAL_RANK`` unless ``FTK_DIST_BACKEND``
+    / ``backend`` says ``gloo`` (CPU tests; several ranks sharing one GPU).  Returns ``(rank, world)``;
+    a plain single process returns ``(0, 1)`` and starts nothing.  This is the counterpart of the
+    reference's ``Pool(workers)`` (frag/_delfi.py:289, frag/_coverage.py:212): one rank per GPU."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        backend = backend or os.environ.get("FTK_DIST_BACKEND", "nccl")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        rank = int(os.environ["RANK"])
+        if backend == "nccl":
+            local = int(os.environ.get("FTK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            if torch.cuda.device_count() <= local:
+                raise RuntimeError(f"rank {rank}: GPU {local} is not visible ({torch.cuda.device_count()} devices); "
+                                   f"one rank per GPU, no fallback")
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def finalize():
+    """Leave the process group (end of a multi-rank command)."""
+    try:
+        import torch.distributed as dist
+    except ImportError:  # pragma: no cover
+        return
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def rank_world(group=None) -> Tuple[int, int]:
+    """``(rank, world)`` of the initialised process group, ``(0, 1)`` without one."""
+    try:
+        import torch.distributed as dist
+    except ImportError:  # pragma: no cover
+        return 0, 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def exchange_device(group=None):
+    """Where collective payloads live: the rank's GPU under RCCL, host memory under gloo."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return None
 
 
 def lpt_assign(weights: Dict[str, float], n_ranks: int) -> Dict[str, int]:
@@ -68,7 +177,7 @@ def shard_contigs(names: Sequence[str], weights: Dict[str, float], rank: int, wo
 
 
 def gather_bin_vectors(local: Dict[str, np.ndarray], names: Sequence[str], n_bins: Dict[str, int],
-                       weights: Dict[str, float], group=None, device=None) -> Dict[str, np.ndarray]:
+                       weights: Dict[str, float], group=None, device=None, k: Optional[int] = None) -> Dict[str, np.ndarray]:
     """All-gather per-contig integer vectors (shape [n_bins[c], k]) so every rank
     holds all contigs.  ``local`` has this rank's contigs; ``n_bins`` the row
     count of EVERY contig (known from the bin file on all ranks)."""
@@ -79,13 +188,16 @@ def gather_bin_vectors(local: Dict[str, np.ndarray], names: Sequence[str], n_bin
         return dict(local)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if device is None:
+        device = exchange_device(group)
     owner = lpt_assign({n: weights[n] for n in names}, world)
-    k = next((v.shape[1] for v in local.values()), None)
-    ks = [None] * world
-    dist.all_gather_object(ks, k, group=group)
-    k = next(x for x in ks if x is not None)
+    if k is None:
+        k = next((v.shape[1] for v in local.values()), None)
+        ks = [None] * world
+        dist.all_gather_object(ks, k, group=group)
+        k = next(x for x in ks if x is not None)
     rows = [sum(n_bins[n] for n in names if owner[n] == r) for r in range(world)]
-    pad = max(rows)
+    pad = max(max(rows), 1)  # RCCL does not take empty buffers
     send = torch.zeros((pad, k), dtype=torch.int64)
     off = 0
     for n in names:
@@ -112,6 +224,8 @@ def allreduce_sum(value: int, group=None, device=None) -> int:
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return int(value)
+    if device is None:
+        device = exchange_device(group)
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return int(t.item())

@@ -295,18 +295,20 @@ int ftk_wps(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t ch
 /* frag/_multi_wps.py:196-198: the same for n_iv intervals of one contig in
  * one launch; interval i writes iv_stop[i] - iv_start[i] values at
  * wps_out + out_offset[i].  iv_* / out_offset are host arrays. */
+int ftk_wps_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start, const int64_t* iv_stop, int64_t n_iv,
+                      const int64_t* out_offset, int64_t chrom_size, int32_t window_size, int32_t min_len,
+                      int32_t max_len, int32_t mapq_min, int64_t* wps_out);
+
 /* ftk_wps with the copy-back taken off the caller's path: returns once the kernel (ctx stream) and the copy of
  * the scores into wps_out_host (the ctx's copy stream, behind the kernel) are enqueued; the next calls on the ctx
  * - loading and scoring the next contig - overlap the copy.  *token_out identifies the result: the array is
  * valid after ftk_result_wait(ctx, token) (or ftk_ctx_sync).  Two results can be in flight; a third call
- * waits for the older one's copy.  wps_out_host should come from ftk_host_alloc (a pageable array is copied
+ * waits for the older one's copy.  A token is the index of the copy slot (0 or 1) and is REUSED every second
+ * call: wait for a result before issuing the call after next, or its token names the newer result in that slot.  wps_out_host should come from ftk_host_alloc (a pageable array is copied
  * through a staging buffer and gains nothing).  A degenerate interval gives token -1 (nothing to wait for). */
 int ftk_wps_async(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t chrom_size, int32_t window_size,
                   int32_t min_len, int32_t max_len, int32_t mapq_min, int64_t* wps_out_host, int* token_out);
 int ftk_result_wait(ftk_ctx* ctx, int token);
-int ftk_wps_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start, const int64_t* iv_stop, int64_t n_iv,
-                      const int64_t* out_offset, int64_t chrom_size, int32_t window_size, int32_t min_len,
-                      int32_t max_len, int32_t mapq_min, int64_t* wps_out);
 
 /* WPS of a whole contig AND the window features of a regular bin tiling in ONE pass over the fragments
  * (BASELINE config 5: coverage + WPS + length histogram + DELFI fused): bin k = [win_start + k * win_len,
@@ -412,20 +414,14 @@ int ftk_motif_counts(ftk_ctx* ctx, int contig_id, int ref_id, const int32_t* w_s
                      uint32_t* counts_out /* [n_win][4^k] */, int64_t* nfrag_out /* [n_win] or NULL */,
                      int64_t* err_out /* [n_win] */);
 
-/* ---- multi-GPU exchange for hosts without torch.distributed ------------------
- * One process per GPU; contigs / genome runs are sharded by the host, no data-path collective.  The
- * only exchanges of the path are the all-gather of the per-bin DELFI vector (frag/_delfi.py:289-300's
- * pool.starmap result list, one rank per shard) and the all-reduce of the genome-wide total of
- * coverage(normalize=True) (frag/_coverage.py:215-227).  These wrap RCCL (loaded with dlopen at
- * ftk_comm_create; librccl is not a link-time dependency) on the ctx stream.  Rank 0 makes the id,
- * the host shares its 128 bytes with the other ranks (file, environment, MPI ...).  Buffers may be
- * host or device memory; n counts int64 elements PER RANK. */
-typedef struct ftk_comm ftk_comm;
-int ftk_comm_unique_id(char id_out[128]);
-int ftk_comm_create(ftk_ctx* ctx, int rank, int world, const char id[128], ftk_comm** out);
-int ftk_allgather_i64(ftk_comm* comm, const int64_t* send, int64_t n, int64_t* recv /* [world * n] */);
-int ftk_allreduce_sum_i64(ftk_comm* comm, int64_t* values, int64_t n);
-void ftk_comm_destroy(ftk_comm* comm);
+/* ---- multi-GPU -----------------------------------------------------------
+ * One process and one ftk_ctx per GPU.  Contigs / genome runs are dealt to the ranks by the host; no
+ * entry point of this library exchanges data between GPUs.  The only exchanges of the path -- the
+ * all-gather of the per-bin DELFI vector (frag/_delfi.py:289-300's pool.starmap result list) and the
+ * all-reduce of the genome-wide total of coverage(normalize=True) (frag/_coverage.py:215-227) -- are
+ * the host's: torch.distributed over RCCL (finaletoolkit_amd/sharding.py), on buffers this library
+ * wrote through device pointers (outputs of ftk_window_features / ftk_delfi_counts may be device
+ * memory, ordered on the ctx stream; ftk_ctx_set_stream puts the launches on the collective's stream). */
 
 #ifdef __cplusplus
 }

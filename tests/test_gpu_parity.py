@@ -546,31 +546,6 @@ def test_one_call_file_loaders(engine, tmp_path):
     assert lib.ftk_frags_load_fraggz(engine.ctx, str(tmp_path / "absent.gz").encode(), None, 2, base, C.byref(n)) == L.FTK_ERR_IO
 
 
-def test_c_abi_collectives_single_rank(engine):
-    """ftk_comm_* / ftk_allgather_i64 / ftk_allreduce_sum_i64 on a 1-rank RCCL communicator (the box has one
-    GPU): identity results, host and device buffers.  Multi-rank behaviour is RCCL's."""
-    import ctypes as C
-    from finaletoolkit_amd import _lib as L
-    lib = engine.lib
-    uid = C.create_string_buffer(128)
-    assert lib.ftk_comm_unique_id(uid) == 0
-    comm = C.c_void_p()
-    rc = lib.ftk_comm_create(engine.ctx, 0, 1, uid, C.byref(comm))
-    assert rc == 0, lib.ftk_last_error(engine.ctx)
-    try:
-        send = np.arange(1000, dtype=np.int64) * 3 - 7
-        recv = np.zeros(1000, np.int64)
-        assert lib.ftk_allgather_i64(comm, L.ptr(send), 1000, L.ptr(recv)) == 0
-        assert np.array_equal(recv, send)
-        v = np.array([5, -9, 2 ** 40], np.int64)
-        assert lib.ftk_allreduce_sum_i64(comm, L.ptr(v), 3) == 0
-        assert v.tolist() == [5, -9, 2 ** 40]
-        assert lib.ftk_allgather_i64(comm, None, 0, None) == 0
-        assert lib.ftk_comm_create(engine.ctx, 3, 2, uid, C.byref(C.c_void_p())) == L.FTK_ERR_INVALID
-    finally:
-        lib.ftk_comm_destroy(comm)
-
-
 @pytest.mark.parametrize("win_len", [100_000, 5_200, 250_001])
 def test_fused_wps_and_window_features_equal_separate_calls(engine, data, win_len):
     """ftk_wps_window_features (one pass) == ftk_wps + ftk_window_features, for bin lengths from just above

@@ -87,3 +87,137 @@ def test_lpt_balance_on_b37():
         owner = sharding.lpt_assign(sizes, world)
         loads = [sum(sizes[c] for c in sizes if owner[c] == r) for r in range(world)]
         assert sum(loads) == tot and (tot / world) / max(loads) >= ceiling
+
+
+# ---- the sharded product entry points (frag.delfi / frag.coverage), host logic on CPU -----------------------
+# The device is replaced by a stand-in that answers the two engine calls from the oracle, so what runs here
+# is exactly the rank logic of the product: contig dealing, per-rank work, all-gather / all-reduce, rank-0 writer.
+
+def _fake_device(sizes):
+    from finaletoolkit_amd import synth
+    from oracle import oracle as O
+    frs = {c: O.Frags(*synth.synth_contig(n, depth=3.0, seed=70 + i)) for i, (c, n) in enumerate(sizes.items())}
+    asked = []
+
+    class Src:
+        contigs = list(sizes)
+        loaded = set(sizes)
+        lengths = {c: None for c in sizes}
+
+        def load_all(self):
+            pass
+
+        def require(self, c):
+            asked.append(c)
+            return c
+
+    class Eng:
+        def window_counts(self, name, starts, stops, q=30, lo=None, hi=None, policy="midpoint", out=None):
+            return O.c_window_counts(frs[name], starts, stops, mapq_min=q, min_len=lo, max_len=hi, policy=policy)
+
+        def delfi_counts(self, name, starts, stops, q=30, bs=None, be=None, gaps=None):
+            return O.c_delfi_counts(frs[name], starts, stops, q, bs, be, gaps)
+
+    class Ref:
+        chroms = dict(sizes)
+
+        def __init__(self, *_):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            pass
+
+        def gc_counts(self, eng, contig, starts, stops):
+            return (np.asarray(starts) // 7 + np.asarray(stops) % 11).astype(np.int64)
+
+    return Src(), Eng(), Ref, asked
+
+
+SIZES_P = {"a": 900_000, "b": 700_000, "c": 400_000, "d": 350_000, "e": 120_000}
+
+
+def _product_worker(rank, world, port, d, q):
+    sys.path.insert(0, ROOT)
+    import warnings
+    from finaletoolkit_amd import sharding
+    from finaletoolkit_amd.frag import _coverage as Cv, _delfi as Df
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          FTK_DIST_BACKEND="gloo")
+        assert sharding.init_from_env() == (rank, world)
+    src, eng, Ref, asked = _fake_device(SIZES_P)
+    for mod in (Cv, Df):
+        mod.open_source = lambda *a, **k: src
+        mod.get_engine = lambda: eng
+    Df.ReferenceGenome = Ref
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        df = Df.delfi("x", f"{d}/cs.genome", f"{d}/bins.txt", "ref", blacklist_file=f"{d}/bl.bed", gap_file=f"{d}/gaps.bed",
+                      no_gc_correct=True, remove_nocov=False, merge_bins=False, output_file=f"{d}/delfi_w{world}.tsv")
+    counted = sorted(set(asked))
+    cov = Cv.coverage("x", f"{d}/iv.bed", f"{d}/cov_w{world}.bed", normalize=True, scale_factor=1e6)
+    sharding.finalize()
+    q.put((rank, df.to_csv(), [tuple(c) for c in cov], counted))
+
+
+def test_sharded_delfi_and_coverage_equal_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    d = tmp_path
+    rng = np.random.default_rng(3)
+    (d / "cs.genome").write_text("".join(f"{c}\t{n}\n" for c, n in SIZES_P.items()))
+    (d / "bins.txt").write_text("".join(f"{c}\t{a}\t{min(a + 9_999, n)}\n" for c, n in SIZES_P.items()
+                                        for a in range(0, n, 10_000)))
+    (d / "gaps.bed").write_text("".join(f"{c}\t0\t10000\ttelomere\n{c}\t{n // 20000 * 10000}\t{n // 20000 * 10000 + 30000}"
+                                        f"\tcentromere\n{c}\t{n - 10000}\t{n}\ttelomere\n" for c, n in SIZES_P.items()))
+    (d / "bl.bed").write_text("".join(f"{c}\t{int(a)}\t{int(a) + 900}\n" for c, n in SIZES_P.items()
+                                      for a in rng.integers(0, n - 1000, 20)))
+    iv = [f"{c}\t{int(a)}\t{int(a) + int(rng.integers(1, 4000))}\t{c}{k}\n" for c, n in SIZES_P.items()
+          for k, a in enumerate(rng.integers(0, n - 4000, 30))]
+    rng.shuffle(iv)
+    (d / "iv.bed").write_text("".join(iv))
+    ctx = mp.get_context("spawn")
+    res = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_product_worker, args=(r, world, port, str(d), q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res[world] = sorted(q.get(timeout=300) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    one = res[1][0]
+    assert one[3] == sorted(SIZES_P) and len(one[2]) == 150 and one[1].count("\n") > 200
+    for r in res[2]:
+        assert r[1] == one[1] and r[2] == one[2]  # same frame, same coverage list on every rank
+    a, b = set(res[2][0][3]), set(res[2][1][3])
+    assert a and b and not (a & b) and a | b == set(SIZES_P)  # each contig counted by exactly one rank
+    assert (d / "delfi_w2.tsv").read_text() == (d / "delfi_w1.tsv").read_text()
+    assert (d / "cov_w2.bed").read_text() == (d / "cov_w1.bed").read_text()
+
+
+def test_launch_ranks_starts_n_ranks_and_propagates_failure(tmp_path):
+    from finaletoolkit_amd import sharding
+    ok = tmp_path / "ok.py"
+    ok.write_text(f"import os, sys\nsys.path.insert(0, {ROOT!r})\nfrom finaletoolkit_amd import sharding\n"
+                  "r, w = sharding.init_from_env()\nassert sharding.allreduce_sum(r + 1) == w * (w + 1) // 2\n"
+                  f"open({str(tmp_path)!r} + f'/seen{{r}}', 'w').write(os.environ['LOCAL_RANK'])\nsharding.finalize()\n")
+    env_keep = {k: os.environ.pop(k, None) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    try:
+        assert sharding.launch_ranks([sys.executable, str(ok)], 3, share_gpu=True) == 0
+        assert sorted(p.name for p in tmp_path.glob("seen*")) == ["seen0", "seen1", "seen2"]
+        bad = tmp_path / "bad.py"
+        bad.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(600)\n")
+        assert sharding.launch_ranks([sys.executable, str(bad)], 2, share_gpu=True) == 7  # rank 0 is ended, not waited for
+        # without share_gpu the device count decides: this container has no GPU at all
+        import torch
+        if torch.cuda.device_count() < 2:
+            assert sharding.launch_ranks([sys.executable, str(ok)], 2) == 2
+    finally:
+        for k, v in env_keep.items():
+            if v is not None:
+                os.environ[k] = v
