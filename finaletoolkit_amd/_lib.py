@@ -52,6 +52,8 @@ EXPORTS = [
     "ftk_frag_select",
     "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals", "ftk_wps_adjust",
     "ftk_ref_upload", "ftk_ref_release", "ftk_ref_gc_counts", "ftk_ref_set_layout", "ftk_motif_counts",
+    "ftk_format_wig_i64", "ftk_format_bedgraph_i64", "ftk_format_bedgraph_f64", "ftk_buffer_free", "ftk_file_write",
+    "ftk_bigwig_fixedstep_sections", "ftk_format_frag_rows", "ftk_bgzf_write",
 ]
 
 
@@ -118,6 +120,17 @@ def load() -> C.CDLL:
     lib.ftk_last_error.argtypes = [vp]
     lib.ftk_fragtable_error.restype = C.c_char_p
     lib.ftk_device_count.argtypes = [C.POINTER(C.c_int)]
+    pp, pi64 = C.POINTER(C.c_void_p), C.POINTER(C.c_int64)
+    lib.ftk_format_wig_i64.argtypes = [vp, i64, C.c_int, pp, pi64]
+    lib.ftk_format_bedgraph_i64.argtypes = [C.c_char_p, vp, vp, i64, vp, C.c_int, pp, pi64]
+    lib.ftk_format_bedgraph_f64.argtypes = [C.c_char_p, vp, vp, i64, vp, C.c_int, pp, pi64]
+    lib.ftk_buffer_free.argtypes = [vp]
+    lib.ftk_buffer_free.restype = None
+    lib.ftk_format_frag_rows.argtypes = [C.c_char_p, vp, vp, vp, vp, i64, C.c_int, C.c_int, pp, pi64]
+    lib.ftk_bgzf_write.argtypes = [C.c_char_p, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.ftk_file_write.argtypes = [C.c_char_p, vp, i64, C.c_int, C.c_int, C.c_int]
+    lib.ftk_bigwig_fixedstep_sections.argtypes = [C.c_uint32, vp, vp, i64, vp, C.c_int, i32, C.c_int, C.c_int, pp, pi64,
+                                                  pi64, pp, pp]
     lib.ftk_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.ftk_ctx_destroy.argtypes = [vp]
     lib.ftk_ctx_destroy.restype = None

@@ -73,6 +73,27 @@ def write_frag_gz(path, contig_rows, bed6: bool = False, with_tbi_stub: bool = T
     (the engine then scans the file, but the reference's "index must exist" check,
     io/alignment.py:191-201, is kept).
     """
+    contig_rows = list(contig_rows)
+    if sum(len(r[1]) for r in contig_rows) > 50_000:
+        # large files: rows formatted and BGZF blocks deflated by the library's host threads, one contig after
+        # the other (a contig starts on a fresh block, so its virtual offset is just the block's file offset)
+        from . import writers
+        spans = []
+        first = True
+        end_off = 0
+        for name, start, end, mapq, strand in contig_rows:
+            with writers.frag_rows(name, start, end, mapq, strand, bed6) as rows:
+                offs = writers.bgzf_write(path, rows, level, append=not first, write_eof=False)
+            spans.append((name, int(offs[0]), int(offs[-1])))
+            end_off = int(offs[-1])
+            first = False
+        with open(path, "ab") as fh:
+            fh.write(_EOF)
+        if with_index:
+            write_index(str(path) + ".tbi", False, [(n, a << 16, b << 16) for n, a, b in spans])
+        elif with_tbi_stub:
+            open(str(path) + ".tbi", "ab").close()
+        return
     parts = []
     marks = []  # (name, first byte, end byte) per run of a contig
     pos = 0

@@ -127,6 +127,20 @@ def write_fixed_step_bigwig(output_file, header, interval_scores) -> None:
     ``(contig, start, values)`` in header order.  An out-of-order or overlapping
     interval is skipped with a note on stderr (pyBigWig raises RuntimeError there
     and the reference skips the interval, frag/_multi_wps.py:319-325)."""
+    def runs():
+        for contig, start, values in interval_scores:
+            values = np.asarray(values)
+            yield contig, [int(start)], values, np.array([0, len(values)], np.int64)
+    write_fixed_step_bigwig_runs(output_file, header, runs())
+
+
+def write_fixed_step_bigwig_runs(output_file, header, contig_runs, threads: int = 0) -> None:
+    """The same from runs of intervals: ``contig_runs`` yields ``(contig, starts, values, offsets)`` with interval
+    ``k`` = ``values[offsets[k]:offsets[k+1]]`` at ``starts[k]`` (what one ``ftk_wps_intervals`` launch returns).
+    The data sections -- float32 conversion, section headers, zlib, per-section summaries -- are built by
+    the library's host threads (``writers.bigwig_sections``) and streamed to the file; this function keeps the
+    container: header, chromosome tree, R-tree index, one zoom level, total summary."""
+    from . import writers
     chrom_id = {c: i for i, (c, _) in enumerate(header)}
     tree, reloc = _chrom_tree(header)
     n_zoom = 1
@@ -138,71 +152,89 @@ def write_fixed_step_bigwig(output_file, header, interval_scores) -> None:
         (v,) = struct.unpack_from("<Q", tree, r)
         struct.pack_into("<Q", tree, r, v + chrom_tree_off)
 
-    sections = bytearray()
     leaf_items = []
-    zoom_recs = []
+    zoom_parts = []  # per run batch: (cid, table, stats)
     last = (-1, -1)
     n_valid, vmin, vmax, vsum, vsq, max_raw = 0, np.inf, -np.inf, 0.0, 0.0, 0
     pos = data_off + 8
-    for contig, start, values in interval_scores:
-        values = np.asarray(values)
-        if len(values) == 0:
-            continue
-        cid = chrom_id.get(contig)
-        if cid is None or (cid, int(start)) < last:
-            sys.stderr.write(f"{contig}:{start}-{start + len(values)}\n invalid or out of order interval "
-                             "encountered. Skipping to next.\n")
-            continue
-        v32 = values.astype(np.float64).astype("<f4")
-        for o in range(0, len(v32), _ITEMS_PER_SECTION):
-            chunk = v32[o:o + _ITEMS_PER_SECTION]
-            s0 = int(start) + o
-            raw = struct.pack("<IIIIIBBH", cid, s0, s0 + len(chunk), 1, 1, 3, 0, len(chunk)) + chunk.tobytes()
-            comp = zlib.compress(raw, 6)
-            sections += comp
-            leaf_items.append((cid, s0, cid, s0 + len(chunk), pos, len(comp)))
-            pos += len(comp)
-            max_raw = max(max_raw, len(raw))
-            c64 = chunk.astype(np.float64)
-            zoom_recs.append((cid, s0, s0 + len(chunk), len(chunk), float(c64.min()), float(c64.max()),
-                              float(c64.sum()), float((c64 * c64).sum())))
-            n_valid += len(chunk)
-            vmin, vmax = min(vmin, zoom_recs[-1][4]), max(vmax, zoom_recs[-1][5])
-            vsum += zoom_recs[-1][6]
-            vsq += zoom_recs[-1][7]
-        last = (cid, int(start) + len(values))
-    if n_valid == 0:
-        vmin = vmax = 0.0
-    index_off = pos
-    index = _rtree(leaf_items, index_off)
-    # zoom level: one summary record per data section, in blocks of 512 records
-    zoom_data_off = index_off + len(index)
-    zdata = bytearray(struct.pack("<I", len(zoom_recs)))
-    zleaf = []
-    zpos = zoom_data_off + 4
-    for o in range(0, len(zoom_recs), 512):
-        blk = zoom_recs[o:o + 512]
-        raw = b"".join(struct.pack("<IIIIffff", *r) for r in blk)
-        comp = zlib.compress(raw, 6)
-        zdata += comp
-        zleaf.append((blk[0][0], blk[0][1], blk[-1][0], blk[-1][2], zpos, len(comp)))
-        zpos += len(comp)
-        max_raw = max(max_raw, len(raw))
-    zoom_index_off = zpos
-    zindex = _rtree(zleaf, zoom_index_off)
-
     with open(output_file, "wb") as fh:
+        fh.write(b"\0" * pos)  # header, zoom header, chromosome tree, summary, section count: patched at the end
+        for contig, starts, values, offsets in contig_runs:
+            values = np.asarray(values)
+            offsets = np.asarray(offsets, dtype=np.int64)
+            starts = np.asarray(starts, dtype=np.int64)
+            cid = chrom_id.get(contig)
+            keep = []
+            for k in range(len(starts)):
+                n_k = int(offsets[k + 1] - offsets[k])
+                if n_k == 0:
+                    continue
+                if cid is None or (cid, int(starts[k])) < last:
+                    sys.stderr.write(f"{contig}:{int(starts[k])}-{int(starts[k]) + n_k}\n invalid or out of order interval "
+                                     "encountered. Skipping to next.\n")
+                    continue
+                keep.append(k)
+                last = (cid, int(starts[k]) + n_k)
+            if not keep:
+                continue
+            if len(keep) != len(starts):  # drop the skipped intervals' values
+                values = np.concatenate([values[offsets[k]:offsets[k + 1]] for k in keep])
+                lens = np.array([offsets[k + 1] - offsets[k] for k in keep], np.int64)
+                starts = starts[keep]
+                offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            blob, table, stats = writers.bigwig_sections(cid, starts, values, offsets, _ITEMS_PER_SECTION, 6, threads)
+            fh.write(blob)
+            sizes = table[:, 2]
+            offs = pos + np.concatenate([[0], np.cumsum(sizes)[:-1]])
+            leaf_items.extend(zip([cid] * len(table), table[:, 0].tolist(), [cid] * len(table), table[:, 1].tolist(),
+                                  offs.tolist(), sizes.tolist()))
+            pos += int(sizes.sum())
+            zoom_parts.append((cid, table, stats))
+            counts = table[:, 1] - table[:, 0]
+            n_valid += int(counts.sum())
+            max_raw = max(max_raw, 24 + 4 * int(counts.max()))
+            vmin, vmax = min(vmin, float(stats[:, 0].min())), max(vmax, float(stats[:, 1].max()))
+            vsum += float(stats[:, 2].sum())
+            vsq += float(stats[:, 3].sum())
+        if n_valid == 0:
+            vmin = vmax = 0.0
+        index_off = pos
+        index = _rtree(leaf_items, index_off)
+        fh.write(index)
+        # zoom level: one summary record per data section, in blocks of 512 records
+        zoom_data_off = index_off + len(index)
+        rec_dt = np.dtype([("cid", "<u4"), ("s", "<u4"), ("e", "<u4"), ("n", "<u4"), ("mn", "<f4"), ("mx", "<f4"),
+                           ("sum", "<f4"), ("sq", "<f4")])
+        recs = np.zeros(sum(len(t) for _, t, _ in zoom_parts), rec_dt)
+        o = 0
+        for cid, table, stats in zoom_parts:
+            r = recs[o:o + len(table)]
+            r["cid"], r["s"], r["e"], r["n"] = cid, table[:, 0], table[:, 1], table[:, 1] - table[:, 0]
+            r["mn"], r["mx"], r["sum"], r["sq"] = stats[:, 0], stats[:, 1], stats[:, 2], stats[:, 3]
+            o += len(table)
+        zdata = bytearray(struct.pack("<I", len(recs)))
+        zleaf = []
+        zpos = zoom_data_off + 4
+        for o in range(0, len(recs), 512):
+            blk = recs[o:o + 512]
+            raw = blk.tobytes()
+            comp = zlib.compress(raw, 6)
+            zdata += comp
+            zleaf.append((int(blk["cid"][0]), int(blk["s"][0]), int(blk["cid"][-1]), int(blk["e"][-1]), zpos, len(comp)))
+            zpos += len(comp)
+            max_raw = max(max_raw, len(raw))
+        zoom_index_off = zpos
+        zindex = _rtree(zleaf, zoom_index_off)
+        fh.write(bytes(zdata))
+        fh.write(zindex)
+        fh.write(struct.pack("<I", _BW_MAGIC))
+        fh.seek(0)
         fh.write(struct.pack("<IHHQQQHHQQIQ", _BW_MAGIC, 4, n_zoom, chrom_tree_off, data_off, index_off, 0, 0, 0,
                              total_summary_off, max(max_raw, 1), 0))
         fh.write(struct.pack("<IIQQ", _ITEMS_PER_SECTION, 0, zoom_data_off, zoom_index_off))
         fh.write(bytes(tree))
         fh.write(struct.pack("<Qdddd", n_valid, vmin, vmax, vsum, vsq))
         fh.write(struct.pack("<Q", len(leaf_items)))
-        fh.write(bytes(sections))
-        fh.write(index)
-        fh.write(bytes(zdata))
-        fh.write(zindex)
-        fh.write(struct.pack("<I", _BW_MAGIC))
 
 
 # ---------------------------------------------------------------------------

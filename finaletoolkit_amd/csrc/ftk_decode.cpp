@@ -34,6 +34,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "ftk.h"
+#include "ftk_host.h"
 #include "ftk_textparse.h"
 
 namespace {
@@ -523,6 +524,31 @@ void pack(Contig& ct) {
 }
 
 }  // namespace
+
+namespace ftk_host {
+
+void parallel_run(int n, const std::function<void(int)>& fn) { ::parallel_run(n, fn); }
+
+void set_decode_error(const char* msg) { g_decode_err = msg ? msg : ""; }
+
+int default_threads() {
+    static const int n = [] {
+        int c = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) c = CPU_COUNT(&set);
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2 quota: "max" or "<quota> <period>"
+            char q[32];
+            long long period = 0;
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+                c = std::min<long long>(c, std::max<long long>(1, (atoll(q) + period / 2) / period));
+            fclose(f);
+        }
+        return std::max(1, std::min(c, 64));
+    }();
+    return n;
+}
+
+}  // namespace ftk_host
 
 struct ftk_fragtable {
     std::vector<Contig> contigs;

@@ -726,6 +726,204 @@ __global__ __launch_bounds__(kFeatBS) void feat_block_kernel(ContigView cv, cons
     feat_block_body<kFeatBS, CH, DF, BAM>(cv, ws_[w], we_[w], lmax, P, o0, o1, (size_t)w, lds_hist, red);
 }
 
+// ---------------------------------------------------------------------------
+// window features, block path, FAST form: the common request -- tabix fetch semantics, midpoint policy, no
+// length bounds on the coverage / histogram filter, one mapq cut for coverage and DELFI -- with every shared
+// term computed once.  The general element (feat_element) costs ~45 VALU instructions per fragment for the
+// fused pass and the CU has 64 lane-operations per clock for the one fragment per clock that 5.5 TB/s feed
+// it: the pass was issue-bound, not bandwidth-bound (63 us fused vs 48 us coverage-only on a chr2-sized
+// contig).  Here:
+//   * the midpoint test works on m2 = fs + fe against doubled bounds (floor(m2/2) >= ws <=> m2 >= 2 ws;
+//     floor(m2/2) <= we-1 <=> m2 <= 2(we-1)+1): no shift;
+//   * x = (q - q_min) | (m2 - 2 ws) | (2 we - 1 - m2) | (fe - 1 - ws) is the coverage predicate AND the
+//     common part of the DELFI predicate: y = x | (len - 100) | (220 - len);
+//   * the centromere / telomere terms are only compiled into the loop of a window that lies within reach of
+//     one of those intervals (block-uniform choice, like the blacklist bisection);
+//   * DELFI keeps two counters: rejected (sign of y) and passing-and-long (sign of ~y & (150 - len));
+//     short = processed - rejected - long;
+//   * the number of processed fragments is 4 * ceil((hi - lo) / 4) -- not counted.
+// Overflow analysis (coordinates < 2^30; padding fragments sit at 2^30): bounds are clamped to ws in
+// [0, 2^30] for the doubled test, we - 1 in [-1, 2^30 - 1]; m2 - 2 ws and 2 we - 1 - m2 then stay inside int32
+// for every real fragment; a padding fragment (m2 = 2^31 wraps to INT32_MIN) fails the first test when
+// ws = 0 and the second one otherwise (2 we - 1 - m2 wraps negative for we >= 1; we <= 0 windows have no
+// candidate range at all).
+// ---------------------------------------------------------------------------
+struct FastAcc {
+    int cov = 0, rej = 0, lg = 0;
+};
+
+struct FastWin {
+    int ws2, we2, wsm1;  // 2 * max(ws, 0); 2 * (we - 1) + 1; -1 - max(ws, -1)
+};
+
+template <bool CHK, bool HIST, bool DF, bool BL, bool GAPS>
+__device__ __forceinline__ void fast_element(const FeatParams& P, int fs, int fe, int q, const FastWin& W, int o0,
+                                             int o1, uint32_t* h, FastAcc& a) {
+    const int len = fe - fs;
+    const int m2 = fs + fe;
+    const int x = (q - P.ch_q) | (m2 - W.ws2) | (W.we2 - m2) | (fe + W.wsm1);
+    if (CHK) {
+        const unsigned bad = (unsigned)x >> 31;
+        a.cov += bad;
+        if (HIST) {  // out-of-range lengths land in bin n_bins (the overflow count)
+            const unsigned b = min((unsigned)(len - P.len_lo), (unsigned)P.n_bins);
+            atomicAdd(&h[b], bad ^ 1u);
+        }
+    }
+    if (DF) {  // frag/_delfi.py:443-472
+        int y = x | (len - 100) | (220 - len);
+        if (GAPS) {
+            y |= (P.cen0 - fe) & (fs - P.cen1);      // not (fe > cen0 and fs < cen1)
+            y |= (P.tel0 - fe) & (fs - P.tel1);
+        }
+        if (BL) {  // blacklisted iff max{r1 : r0 <= fs, region inside the window} > fe (:455-462)
+            if (y >= 0) {
+                int lo = o0, hi = o1;
+                while (lo < hi) {
+                    const int m = (lo + hi) >> 1;
+                    if (P.dp.bl_r0[m] <= fs) lo = m + 1; else hi = m;
+                }
+                if (lo > o0 && P.dp.bl_pm[lo - 1] > fe) y = -1;
+            }
+        }
+        a.rej += (unsigned)y >> 31;
+        a.lg += (unsigned)(~y & (150 - len)) >> 31;  // passes and len >= 151
+    }
+}
+
+template <int kFeatBS, bool CHK, bool HIST, bool DF, bool BL, bool GAPS>
+__device__ __forceinline__ void fast_stream(const ContigView& cv, const FeatParams& P, int lo, int hi, int tid,
+                                            const FastWin& W, int o0, int o1, uint32_t* h, FastAcc& a) {
+    int4 s4[4], e4[4];
+    uchar4 q4[4];
+    const int i0 = lo + 4 * tid;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * (4 * kFeatBS);
+        if (i < hi) {
+            s4[u] = *reinterpret_cast<const int4*>(cv.start + i);
+            e4[u] = *reinterpret_cast<const int4*>(cv.end + i);
+            q4[u] = *reinterpret_cast<const uchar4*>(cv.mapq + i);
+        }
+    }
+    for (int base = i0; base < hi; base += 16 * kFeatBS) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * (4 * kFeatBS);
+            if (i < hi) {
+                const int4 s = s4[u], e = e4[u];
+                const uchar4 q = q4[u];
+                const int nxt = i + 16 * kFeatBS;
+                if (nxt < hi) {
+                    s4[u] = *reinterpret_cast<const int4*>(cv.start + nxt);
+                    e4[u] = *reinterpret_cast<const int4*>(cv.end + nxt);
+                    q4[u] = *reinterpret_cast<const uchar4*>(cv.mapq + nxt);
+                }
+                fast_element<CHK, HIST, DF, BL, GAPS>(P, s.x, e.x, q.x, W, o0, o1, h, a);
+                fast_element<CHK, HIST, DF, BL, GAPS>(P, s.y, e.y, q.y, W, o0, o1, h, a);
+                fast_element<CHK, HIST, DF, BL, GAPS>(P, s.z, e.z, q.z, W, o0, o1, h, a);
+                fast_element<CHK, HIST, DF, BL, GAPS>(P, s.w, e.w, q.w, W, o0, o1, h, a);
+            }
+        }
+    }
+}
+
+template <int kFeatBS, bool CHK, bool HIST, bool DF>
+__device__ __forceinline__ void feat_fast_body(const ContigView& cv, int ws_raw, int we_raw, int lmax,
+                                               const FeatParams& P, int o0, int o1, size_t row, uint32_t* lds_hist,
+                                               int (*red)[kFeatBS / 64]) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int lo, hi;
+    uint32_t nc;
+    window_candidates(cv, ws_raw, we_raw, lmax, -1, lo, hi, nc);
+    if (HIST) {
+        for (int b = tid; b <= P.n_bins; b += kFeatBS) lds_hist[b] = 0;
+        __syncthreads();
+    }
+    FastWin W;
+    {
+        const int ws = min(max(ws_raw, -1), 1 << 30);
+        const int we1 = min(max(we_raw, 0), 1 << 30) - 1;
+        W.ws2 = (int)(2u * (unsigned)max(ws, 0));
+        W.we2 = 2 * we1 + 1;
+        W.wsm1 = -1 - ws;
+    }
+    // a DELFI fragment of this window (midpoint inside, 100 <= len <= 220) lies within 110 bp of it: the gap
+    // terms can only matter when the window, widened by a safe 256 bp, touches one of the two intervals
+    bool gaps = false;
+    if (DF) {
+        const long long a0 = (long long)ws_raw - 256, a1 = (long long)we_raw + 256;
+        gaps = (a1 > P.cen0 && a0 < P.cen1) || (a1 > P.tel0 && a0 < P.tel1);
+    }
+    FastAcc a;
+    const bool bl = DF && o1 > o0;
+    if (bl) {
+        if (gaps) fast_stream<kFeatBS, CHK, HIST, DF, true, true>(cv, P, lo, hi, tid, W, o0, o1, lds_hist, a);
+        else fast_stream<kFeatBS, CHK, HIST, DF, true, false>(cv, P, lo, hi, tid, W, o0, o1, lds_hist, a);
+    } else {
+        if (gaps) fast_stream<kFeatBS, CHK, HIST, DF, false, true>(cv, P, lo, hi, tid, W, o0, o1, lds_hist, a);
+        else fast_stream<kFeatBS, CHK, HIST, DF, false, false>(cv, P, lo, hi, tid, W, o0, o1, lds_hist, a);
+    }
+    if (HIST) {
+        __syncthreads();
+        uint32_t* dst = P.hist_out + row * P.n_bins;
+        for (int b = tid; b < P.n_bins; b += kFeatBS) dst[b] = lds_hist[b];
+    }
+    a.cov = wave_reduce_add(a.cov);
+    a.rej = wave_reduce_add(a.rej);
+    a.lg = wave_reduce_add(a.lg);
+    if (lane == 0) { red[0][wv] = a.cov; red[1][wv] = a.rej; red[2][wv] = a.lg; }
+    __syncthreads();
+    if (tid < 4) {
+        const int n = (hi - lo + 3) & ~3;  // fragments processed by the block: whole groups of four
+        int cov = 0, rej = 0, lg = 0;
+#pragma unroll
+        for (int k = 0; k < kFeatBS / 64; ++k) { cov += red[0][k]; rej += red[1][k]; lg += red[2][k]; }
+        if (tid == 0 && CHK && P.do_cov) P.cov_out[row] = n - cov;
+        if (tid == 1 && HIST) P.over_out[row] = (int)lds_hist[P.n_bins];
+        if (tid == 2 && DF) P.short_out[row] = n - rej - lg;
+        if (tid == 3 && DF) P.long_out[row] = lg;
+    }
+}
+
+template <int kFeatBS, bool CHK, bool HIST, bool DF>
+__global__ __launch_bounds__(kFeatBS) void feat_fast_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
+                                                        int n_win, int lmax, FeatParams P) {
+    extern __shared__ uint32_t lds_hist[];
+    __shared__ int red[5][kFeatBS / 64];
+    const int w = blockIdx.x;
+    int o0 = 0, o1 = 0;
+    if (DF && P.dp.bl_off) { o0 = P.dp.bl_off[w]; o1 = P.dp.bl_off[w + 1]; }
+    feat_fast_body<kFeatBS, CHK, HIST, DF>(cv, ws_[w], we_[w], lmax, P, o0, o1, (size_t)w, lds_hist, red);
+}
+
+template <int kFeatBS, bool CHK, bool HIST, bool DF>
+__global__ __launch_bounds__(kFeatBS) void feat_fast_batch_kernel(const FeatItem* __restrict__ items, int n_items,
+                                                              FeatParams P) {
+    extern __shared__ uint32_t lds_hist[];
+    __shared__ int red[5][kFeatBS / 64];
+    const int gw = blockIdx.x;
+    int it = 0;
+    {
+        int lo = 0, hi = n_items;  // largest item with win_base <= gw
+        while (hi - lo > 1) {
+            const int m = (lo + hi) >> 1;
+            if (items[m].win_base <= gw) lo = m; else hi = m;
+        }
+        it = lo;
+    }
+    const FeatItem& I = items[it];
+    const int w = gw - I.win_base;
+    FeatParams Q = P;
+    Q.cen0 = I.cen0; Q.cen1 = I.cen1; Q.tel0 = I.tel0; Q.tel1 = I.tel1;
+    Q.dp.bl_r0 = I.bl_r0;
+    Q.dp.bl_pm = I.bl_pm;
+    int o0 = 0, o1 = 0;
+    if (DF && I.bl_off) { o0 = I.bl_off[w]; o1 = I.bl_off[w + 1]; }
+    const ContigView cv = I.cv;
+    feat_fast_body<kFeatBS, CHK, HIST, DF>(cv, I.ws[w], I.we[w], I.lmax, Q, o0, o1, (size_t)gw, lds_hist, red);
+}
+
 // The same for the windows of SEVERAL contigs in one launch (ftk_window_features_batch): block b owns
 // window b of the concatenated list; its item (contig view, windows, blacklist CSR, gap constants) is
 // found by bisection on the items' first rows; outputs are indexed by the global row.
@@ -1374,11 +1572,39 @@ static WinPred make_win_pred(const ftk_filter& f) {
                    f.fetch_mode == FTK_FETCH_BAM_READ1};
 }
 
+// The FAST block kernels serve the common request: midpoint policy, no length bounds on the coverage /
+// histogram filter, and (when coverage and DELFI run together) one mapq cut for both.  FTK_FEAT_FAST=0
+// keeps the general kernels (tests run both).
+static bool feat_fast_ok(const FeatParams& P, bool ch, bool df) {
+    static const int allow = getenv("FTK_FEAT_FAST") ? atoi(getenv("FTK_FEAT_FAST")) : 1;
+    if (!allow) return false;
+    if (ch && (P.is_any || P.ch_min > 0 || P.ch_max < (1 << 30))) return false;
+    if (ch && df && P.ch_q != P.df_q) return false;
+    return true;
+}
+
 template <int CH, bool DF, bool BAM>
 static void launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
                           int n_win, const WindowPlan& pl, const FeatParams& P, bool small_path, int block_lmax,
                           int block_threads) {
     const size_t lds1 = (CH && P.do_hist) ? (size_t)(P.n_bins + 1) * sizeof(uint32_t) : 0;  // + overflow bin
+    if (block_lmax >= 0 && CH != 2 && !BAM && feat_fast_ok(P, CH != 0, DF)) {
+#define FTK_FAST(BS)                                                                                                \
+    do {                                                                                                            \
+        if (CH && P.do_hist)                                                                                        \
+            hipLaunchKernelGGL((feat_fast_kernel<BS, CH != 0, true, DF>), dim3(n_win), dim3(BS), lds1, s, cv, ws, we,   \
+                               n_win, block_lmax, Pf);                                                              \
+        else                                                                                                        \
+            hipLaunchKernelGGL((feat_fast_kernel<BS, CH != 0, false, DF>), dim3(n_win), dim3(BS), lds1, s, cv, ws, we,  \
+                               n_win, block_lmax, Pf);                                                              \
+    } while (0)
+        FeatParams Pf = P;
+        if (!CH) Pf.ch_q = P.df_q;  // the shared mapq term
+        if (block_threads >= 512) FTK_FAST(512);
+        else FTK_FAST(256);
+#undef FTK_FAST
+        return;
+    }
     if (block_lmax >= 0) {
         if (block_threads >= 512)
             hipLaunchKernelGGL((feat_block_kernel<512, CH, DF, BAM>), dim3(n_win), dim3(512), lds1, s, cv, ws, we, n_win,
@@ -1485,6 +1711,18 @@ void launch_window_features_batch(hipStream_t s, const FeatItem* d_items, int n_
     P.short_out = r.short_out;
     P.long_out = r.long_out;
     const size_t lds1 = P.do_hist ? (size_t)(P.n_bins + 1) * sizeof(uint32_t) : 0;
+    if (!bam && feat_fast_ok(P, ch, df)) {
+        FeatParams Pf = P;
+        if (!ch) Pf.ch_q = P.df_q;
+#define FTK_FASTB(CHK, HIST, DF)                                                                                   \
+    hipLaunchKernelGGL((feat_fast_batch_kernel<512, CHK, HIST, DF>), dim3(total_win), dim3(512), lds1, s, d_items, \
+                       n_items, Pf)
+        if (ch && df) { if (P.do_hist) FTK_FASTB(true, true, true); else FTK_FASTB(true, false, true); }
+        else if (ch) { if (P.do_hist) FTK_FASTB(true, true, false); else FTK_FASTB(true, false, false); }
+        else if (df) FTK_FASTB(false, false, true);
+#undef FTK_FASTB
+        return;
+    }
 #define FTK_FEATB(CH, DF)                                                                                           \
     do {                                                                                                            \
         if (bam) hipLaunchKernelGGL((feat_batch_kernel<512, CH, DF, true>), dim3(total_win), dim3(512), lds1, s, d_items, \

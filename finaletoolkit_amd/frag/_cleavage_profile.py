@@ -8,7 +8,6 @@ kernel, which shares the WPS tile skeleton.
 """
 from __future__ import annotations
 
-import gzip
 import time
 import warnings
 from pathlib import Path
@@ -94,7 +93,7 @@ def multi_cleavage_profile(input_file, interval_file, chrom_sizes, left: int = 0
     src = open_source(input_file, workers)
     eng = get_engine()
 
-    def interval_scores():
+    def contig_runs():
         i, n = 0, len(contigs)
         while i < n:  # one launch per run of intervals on the same contig
             j = i
@@ -102,19 +101,25 @@ def multi_cleavage_profile(input_file, interval_file, chrom_sizes, left: int = 0
                 j += 1
             vals, offs = eng.cleavage_intervals(src.require(contigs[i]), starts[i:j], stops[i:j], min_length,
                                                 max_length, quality_threshold)
-            for k in range(i, j):
-                yield contigs[i], starts[k], vals[offs[k - i]:offs[k - i + 1]]
+            yield contigs[i], starts[i:j], vals, offs
             i = j
 
     if isinstance(output_file, str):
         if output_file.endswith(".bw"):
-            from ..bigwig import write_fixed_step_bigwig
-            write_fixed_step_bigwig(output_file, header, interval_scores())
+            from ..bigwig import write_fixed_step_bigwig_runs
+            write_fixed_step_bigwig_runs(output_file, header, contig_runs())
         elif output_file.endswith(".bed.gz") or output_file.endswith("bedgraph.gz") or output_file == "-":
-            with gzip.open(output_file, "wt") as bedgraph:
-                for contig, start, values in interval_scores():
-                    pos = range(start, start + len(values))
-                    bedgraph.write("".join(f"{contig}\t{p}\t{p + 1}\t{v}\n" for p, v in zip(pos, values)))
+            # rows "contig  pos  pos+1  proportion" with the floats printed as Python prints them, formatted by
+            # the library's host threads; gzip members compressed in parallel
+            from .. import writers
+            writers.write_text(output_file, b"", writers.GZIP_LEVEL)
+            first = True
+            for contig, st, values, offs in contig_runs():
+                for rows in writers.bedgraph_batches(contig, st, values, offs):
+                    with rows:
+                        if rows.n:
+                            rows.write(output_file, writers.GZIP_LEVEL, append=not first)
+                            first = False
         else:
             raise ValueError("output_file can only have suffix .bw, .bedgraph.gz, or .bed.gz.")
     elif output_file is not None:

@@ -33,27 +33,35 @@ class CoverageResult(NamedTuple):
     coverage: float
 
 
-def _weights(src, names, extent=None):
-    """Cost estimate per contig for the rank assignment: its length when the file knows it (BAM header), else
-    the furthest interval stop, else 1."""
-    return {c: float(src.lengths.get(c) or (extent or {}).get(c) or 1) for c in names}
+def _owners(src, names, extent=None):
+    """Rank of every contig of ``names`` under the initialised process group (LPT on a cost estimate: the
+    contig's length when the file knows it -- BAM header -- else the furthest interval stop, else 1) and
+    the weights used.  One map per call, shared by the genome-wide total and the interval counts, so a rank
+    decodes only the contigs it owns."""
+    rank, world = sharding.rank_world()
+    weights = {c: float(src.lengths.get(c) or (extent or {}).get(c) or 1) for c in names}
+    return rank, world, sharding.lpt_assign(weights, world), weights
 
 
 def _total(src, contig, start, stop, min_length, max_length, intersect_policy, quality_threshold,
-           sharded=False) -> int:
-    """Fragments of the region (the whole file when ``contig`` is None).  ``sharded``: the contigs are dealt to
-    the ranks of the process group and the per-rank sums meet in one int64 all-reduce."""
+           shard=None) -> int:
+    """Fragments of the region (the whole file when ``contig`` is None).  ``shard = (rank, world, owner)``:
+    every rank sums the contigs it owns and the sums meet in one int64 all-reduce."""
     eng = get_engine()
+    if shard is not None and contig is None and shard[1] > 1:
+        rank, world, owner = shard
+        total = 0
+        for c in src.contigs:  # no load_all: a rank decodes only what it owns
+            if owner.get(c, 0) == rank and src.has(c):
+                total += int(eng.window_counts(src.require(c), [None], [None], quality_threshold, min_length,
+                                               max_length, intersect_policy)[0])
+        return sharding.allreduce_sum(total)
     names, whole = _region_contigs(src, contig)
-    rank, world = sharding.rank_world() if sharded else (0, 1)
-    owner = sharding.lpt_assign(_weights(src, names), world)
     total = 0
     for c in names:
-        if owner[c] != rank:
-            continue
         total += int(eng.window_counts(src.require(c), [None if whole else start], [None if whole else stop],
                                        quality_threshold, min_length, max_length, intersect_policy)[0])
-    return sharding.allreduce_sum(total) if world > 1 else total
+    return total
 
 
 def single_coverage(input_file: Union[str, Path], contig: str | None = None, start: int | None = 0,
@@ -74,21 +82,24 @@ def single_coverage(input_file: Union[str, Path], contig: str | None = None, sta
     return CoverageResult(contig, start, stop, "." if name is None else name, cov)
 
 
-def _interval_counts(src, intervals, min_length, max_length, intersect_policy, quality_threshold):
-    """Counts for every interval, in interval order (the ``imap`` of :244-248).  The reference spreads the
-    intervals over ``Pool(workers)``; here every rank of the process group counts the intervals of ITS
-    contigs (one launch per contig) and one all-gather hands every rank the full vector."""
-    eng = get_engine()
-    counts = np.zeros(len(intervals), np.int64)
+def _by_contig(intervals):
     by_contig: dict[str, list[int]] = {}
     extent: dict[str, int] = {}
     for i, (c, _, b, _) in enumerate(intervals):
         by_contig.setdefault(c, []).append(i)
         extent[c] = max(extent.get(c, 0), int(b))
-    rank, world = sharding.rank_world()
+    return by_contig, extent
+
+
+def _interval_counts(src, intervals, by_contig, shard, weights, min_length, max_length, intersect_policy,
+                     quality_threshold):
+    """Counts for every interval, in interval order (the ``imap`` of :244-248).  The reference spreads the
+    intervals over ``Pool(workers)``; here every rank of the process group counts the intervals of ITS
+    contigs (one launch per contig) and one all-gather hands every rank the full vector."""
+    eng = get_engine()
+    rank, world, owner = shard
+    counts = np.zeros(len(intervals), np.int64)
     names = list(by_contig)
-    weights = _weights(src, names, extent)
-    owner = sharding.lpt_assign(weights, world)
     local = {}
     for c, idx in by_contig.items():
         if owner[c] != rank:
@@ -97,7 +108,8 @@ def _interval_counts(src, intervals, min_length, max_length, intersect_policy, q
         we = np.array([intervals[i][2] for i in idx], np.int64)
         local[c] = eng.window_counts(src.require(c), ws.astype(np.int32), we.astype(np.int32), quality_threshold,
                                      min_length, max_length, intersect_policy).reshape(-1, 1)
-    full = sharding.gather_bin_vectors(local, names, {c: len(by_contig[c]) for c in names}, weights, k=1)
+    full = sharding.gather_bin_vectors(local, names, {c: len(by_contig[c]) for c in names}, weights, k=1,
+                                       owner=owner)
     for c, idx in by_contig.items():
         counts[idx] = np.asarray(full[c]).reshape(-1)
     return counts
@@ -114,12 +126,18 @@ def coverage(input_file: Union[str, Path], interval_file: str, output_file: str,
         sys.stderr.write(f"coverage: {input_file} over {interval_file}\n")
     _check_policy(intersect_policy)
     src = open_source(input_file, workers)
+    intervals = get_intervals(interval_file)
+    by_contig, extent = _by_contig(intervals)
+    # one contig -> rank map for the whole call: the file's contigs first, then any interval contig it lacks
+    # (asking for those raises, as the reference's fetch does)
+    names = list(dict.fromkeys(list(src.contigs) + list(by_contig)))
+    rank, world, owner, weights = _owners(src, names, extent)
     if normalize:
         # single_coverage(input_file, None, 0, None, "."): the whole file (:215-227)
         total = _total(src, None, 0, None, min_length, max_length, intersect_policy, quality_threshold,
-                       sharded=True)
-    intervals = get_intervals(interval_file)
-    counts = _interval_counts(src, intervals, min_length, max_length, intersect_policy, quality_threshold)
+                       shard=(rank, world, owner))
+    counts = _interval_counts(src, intervals, by_contig, (rank, world, owner), weights, min_length, max_length,
+                              intersect_policy, quality_threshold)
     if normalize:
         if verbose:
             sys.stderr.write(f"Total coverage is {total}\n")

@@ -8,7 +8,6 @@ sorted into header order.  All windows of a contig are scored in ONE
 """
 from __future__ import annotations
 
-import gzip
 import time
 import warnings
 from os import PathLike
@@ -110,8 +109,9 @@ def multi_wps(input_file, site_bed, chrom_sizes=None, output_file: str | None = 
                          "applicable). Please ensure that all files use the same reference genome and chromosome "
                          "naming conventions.")
 
-    def interval_scores():
-        """(contig, start, values) per interval, in order; one launch per contig run."""
+    def contig_runs():
+        """(contig, starts, values, offsets) per run of intervals on one contig, in order: one launch each;
+        interval k of the run is values[offsets[k]:offsets[k+1]]."""
         i = 0
         n = len(contigs)
         while i < n:
@@ -122,16 +122,15 @@ def multi_wps(input_file, site_bed, chrom_sizes=None, output_file: str | None = 
             vals, offs = eng.wps_intervals(src.require(c), starts[i:j], stops[i:j], chrom_sizes_dict[c],
                                            int(window_size), 0 if min_length is None else int(min_length),
                                            int(max_length), int(quality_threshold))
-            for k in range(i, j):
-                yield c, starts[k], vals[offs[k - i]:offs[k - i + 1]]
+            yield c, starts[i:j], vals, offs
             i = j
 
     if isinstance(output_file, str):
         if output_file.endswith(".bw"):
-            from ..bigwig import write_fixed_step_bigwig
-            write_fixed_step_bigwig(output_file, header, interval_scores())
+            from ..bigwig import write_fixed_step_bigwig_runs
+            write_fixed_step_bigwig_runs(output_file, header, contig_runs())
         elif output_file.endswith(".bed.gz") or output_file.endswith("bedGraph.gz"):
-            _write_bedgraph_gz(output_file, interval_scores())
+            _write_bedgraph_gz(output_file, contig_runs())
         else:
             raise ValueError("output_file can only have suffix .bw")
     elif output_file is not None:
@@ -142,9 +141,15 @@ def multi_wps(input_file, site_bed, chrom_sizes=None, output_file: str | None = 
     return output_file
 
 
-def _write_bedgraph_gz(output_file, interval_scores) -> None:
-    """``contig  pos  pos+1  wps`` rows (frag/_multi_wps.py:328-341)."""
-    with gzip.open(output_file, "wt") as bedgraph:
-        for contig, start, values in interval_scores:
-            pos = np.arange(start, start + len(values), dtype=np.int64)
-            bedgraph.write("".join(f"{contig}\t{p}\t{p + 1}\t{v}\n" for p, v in zip(pos.tolist(), values.tolist())))
+def _write_bedgraph_gz(output_file, contig_runs) -> None:
+    """``contig  pos  pos+1  wps`` rows (frag/_multi_wps.py:328-341), a contig's intervals at a time: rows
+    formatted by the library's host threads, written as gzip members compressed in parallel."""
+    from .. import writers
+    writers.write_text(output_file, b"", writers.GZIP_LEVEL)  # gzip.open(..., "wt") of nothing: a valid empty file
+    first = True
+    for contig, starts, values, offsets in contig_runs:
+        for rows in writers.bedgraph_batches(contig, starts, values, offsets):
+            with rows:
+                if rows.n:
+                    rows.write(output_file, writers.GZIP_LEVEL, append=not first)
+                    first = False

@@ -6,7 +6,6 @@ loop (``:180-188``) is the ``ftk_wps`` kernel.
 """
 from __future__ import annotations
 
-import gzip
 import time
 import warnings
 from pathlib import Path
@@ -82,20 +81,18 @@ def wps(input_file: Union[str, Path], chrom: str, start: int, stop: int, chrom_s
 
 
 def _write_wig(output_file, chrom, start, stop, scores) -> None:
-    """fixedStep WIG (frag/_wps.py:208-229)."""
+    """fixedStep WIG (frag/_wps.py:208-229): the header line, then one score per line -- the lines are
+    formatted by the library's host threads (``writers.wig_body``), ``.wig.gz`` as parallel gzip members."""
+    from .. import writers
     header = f"fixedStep\tchrom={chrom}\tstart={start}\tstep={1}\tspan={stop - start}\n"
-    body = "".join(f"{score}\n" for score in scores["wps"])
-    if output_file.endswith(".wig.gz"):
-        with gzip.open(output_file, "wt") as out:
-            out.write(header)
-            out.write(body)
-    elif output_file.endswith(".wig"):
-        with open(output_file, "wt") as out:
-            out.write(header)
-            out.write(body)
-    elif output_file == "-":
-        stdout.write(header)
-        stdout.write(body)
-        stdout.flush()
-    else:
+    if not (output_file.endswith((".wig.gz", ".wig")) or output_file == "-"):
         raise ValueError("output_file can only have suffixes .wig or .wig.gz.")
+    with writers.wig_body(scores["wps"]) as body:
+        if output_file == "-":
+            stdout.write(header)
+            stdout.write(body.tobytes().decode())
+            stdout.flush()
+            return
+        level = writers.GZIP_LEVEL if output_file.endswith(".wig.gz") else 0
+        writers.write_text(output_file, header.encode(), level)
+        body.write(output_file, level, append=True)

@@ -177,7 +177,8 @@ def shard_contigs(names: Sequence[str], weights: Dict[str, float], rank: int, wo
 
 
 def gather_bin_vectors(local: Dict[str, np.ndarray], names: Sequence[str], n_bins: Dict[str, int],
-                       weights: Dict[str, float], group=None, device=None, k: Optional[int] = None) -> Dict[str, np.ndarray]:
+                       weights: Dict[str, float], group=None, device=None, k: Optional[int] = None,
+                       owner: Optional[Dict[str, int]] = None) -> Dict[str, np.ndarray]:
     """All-gather per-contig integer vectors (shape [n_bins[c], k]) so every rank
     holds all contigs.  ``local`` has this rank's contigs; ``n_bins`` the row
     count of EVERY contig (known from the bin file on all ranks)."""
@@ -190,7 +191,8 @@ def gather_bin_vectors(local: Dict[str, np.ndarray], names: Sequence[str], n_bin
     rank = dist.get_rank(group)
     if device is None:
         device = exchange_device(group)
-    owner = lpt_assign({n: weights[n] for n in names}, world)
+    if owner is None:
+        owner = lpt_assign({n: weights[n] for n in names}, world)
     if k is None:
         k = next((v.shape[1] for v in local.values()), None)
         ks = [None] * world

@@ -1,0 +1,173 @@
+"""
+Output writers of the per-base features on the library's host threads (``csrc/ftk_writers.cpp``).
+
+The reference prints one Python f-string per base (``frag/_wps.py:208-229``, ``frag/_multi_wps.py:328-341``) and
+hands bigWig entries to pyBigWig (``:300-325``); after a 0.2 ms kernel that is seconds to minutes of
+interpreter time for a chromosome.  Here the same bytes are formatted in C on all usable cores, ``.gz``
+outputs are written as gzip members compressed in parallel (the decompressed stream is identical; a gzip
+file carries a timestamp, so compressed bytes never were reproducible), and bigWig data sections are built
+and deflated natively.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+GZIP_LEVEL = 6
+
+
+class TextBuffer:
+    """Bytes formatted by the library (owned by it until ``free``)."""
+
+    def __init__(self, lib, ptr, n):
+        self._lib, self.ptr, self.n = lib, ptr, int(n)
+
+    def tobytes(self) -> bytes:
+        return C.string_at(self.ptr, self.n)
+
+    def write(self, path: str, gzip_level: int = 0, append: bool = False, threads: int = 0):
+        rc = self._lib.ftk_file_write(str(path).encode(), self.ptr, self.n, int(gzip_level), int(threads), int(append))
+        if rc != L.FTK_OK:
+            raise OSError(self._lib.ftk_fragtable_error().decode())
+
+    def free(self):
+        if self.ptr:
+            self._lib.ftk_buffer_free(self.ptr)
+            self.ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _call(fn, *args) -> TextBuffer:
+    lib = L.load()
+    out, n = C.c_void_p(), C.c_int64()
+    rc = getattr(lib, fn)(*args, C.byref(out), C.byref(n))
+    if rc != L.FTK_OK:
+        raise L.FtkError(rc, lib.ftk_fragtable_error().decode())
+    return TextBuffer(lib, out.value, n.value)
+
+
+def wig_body(values, threads: int = 0) -> TextBuffer:
+    """``"".join(f"{v}\\n" for v in values)`` for int64 values."""
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    return _call("ftk_format_wig_i64", L.ptr(v), len(v), int(threads))
+
+
+def _runs(starts, offsets, n_values):
+    st = np.ascontiguousarray(starts, dtype=np.int64)
+    if offsets is None:
+        offs = np.array([0, n_values], np.int64)
+    else:
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+    if len(offs) != len(st) + 1:
+        raise ValueError("offsets must hold one entry more than starts")
+    return st, offs
+
+
+def bedgraph_rows(contig: str, starts, values, offsets=None, threads: int = 0) -> TextBuffer:
+    """``contig  pos  pos+1  value`` per base of every run (run ``k`` = ``values[offsets[k]:offsets[k+1]]``
+    starting at ``starts[k]``; one run when ``offsets`` is None and ``starts`` a single position); int64 values
+    as ``str(int)``, float64 values as ``repr(float)``."""
+    v = np.asarray(values)
+    flt = v.dtype.kind == "f"
+    v = np.ascontiguousarray(v, dtype=np.float64 if flt else np.int64)
+    st, offs = _runs(np.atleast_1d(starts), offsets, len(v))
+    return _call("ftk_format_bedgraph_f64" if flt else "ftk_format_bedgraph_i64", str(contig).encode(), L.ptr(st),
+                 L.ptr(offs), len(st), L.ptr(v), int(threads))
+
+
+def bedgraph_batches(contig: str, starts, values, offsets=None, max_values: int = 8 << 20, threads: int = 0):
+    """``bedgraph_rows`` in pieces of at most ``max_values`` rows (about 25 bytes each), cut at run boundaries
+    and inside runs longer than that: a generator of ``TextBuffer`` whose concatenation is the full text, so a
+    whole chromosome of per-base rows never sits in memory at once."""
+    v = np.asarray(values)
+    st, offs = _runs(np.atleast_1d(starts), offsets, len(v))
+    k, n_runs = 0, len(st)
+    while k < n_runs:
+        a = int(offs[k])
+        if offs[k + 1] - a > max_values:  # one long run: its own pieces
+            for o in range(a, int(offs[k + 1]), max_values):
+                e = min(o + max_values, int(offs[k + 1]))
+                yield bedgraph_rows(contig, [int(st[k]) + (o - a)], v[o:e], None, threads)
+            k += 1
+            continue
+        j = int(np.searchsorted(offs, a + max_values, side="right")) - 1  # last run end within the budget
+        j = min(max(j, k + 1), n_runs)
+        yield bedgraph_rows(contig, st[k:j], v[a:int(offs[j])], offs[k:j + 1] - a, threads)
+        k = j
+
+
+def write_text(path: str, data: bytes, gzip_level: int = 0, append: bool = False, threads: int = 0):
+    """Plain or gzip-member write of a Python bytes object (headers and other small pieces)."""
+    lib = L.load()
+    rc = lib.ftk_file_write(str(path).encode(), data, len(data), int(gzip_level), int(threads), int(append))
+    if rc != L.FTK_OK:
+        raise OSError(lib.ftk_fragtable_error().decode())
+
+
+def bigwig_sections(chrom_id: int, starts, values, offsets=None, items_per_section: int = 16384, level: int = 6,
+                    threads: int = 0):
+    """fixedStep data sections of one ``addEntries(chrom, start, values=..., span=1, step=1)`` call per run.
+    Returns ``(blob bytes, table int64[n_sec, 3] = start end compressed_bytes, stats float64[n_sec, 4] = min max
+    sum sumsq)``."""
+    lib = L.load()
+    v = np.asarray(values)
+    kind = 1 if v.dtype.kind == "f" else 0
+    v = np.ascontiguousarray(v, dtype=np.float64 if kind else np.int64)
+    st, offs = _runs(np.atleast_1d(starts), offsets, len(v))
+    out, out_len, n_sec = C.c_void_p(), C.c_int64(), C.c_int64()
+    table, stats = C.c_void_p(), C.c_void_p()
+    rc = lib.ftk_bigwig_fixedstep_sections(int(chrom_id), L.ptr(st), L.ptr(offs), len(st), L.ptr(v), kind,
+                                           int(items_per_section), int(level), int(threads), C.byref(out),
+                                           C.byref(out_len), C.byref(n_sec), C.byref(table), C.byref(stats))
+    if rc != L.FTK_OK:
+        raise L.FtkError(rc, lib.ftk_fragtable_error().decode())
+    try:
+        blob = C.string_at(out.value, out_len.value)
+        k = int(n_sec.value)
+        tab = np.ctypeslib.as_array(C.cast(table, C.POINTER(C.c_int64)), (max(k, 1) * 3,))[:k * 3].reshape(k, 3).copy()
+        sts = np.ctypeslib.as_array(C.cast(stats, C.POINTER(C.c_double)), (max(k, 1) * 4,))[:k * 4].reshape(k, 4).copy()
+    finally:
+        for q in (out, table, stats):
+            lib.ftk_buffer_free(q.value)
+    return blob, tab, sts
+
+
+def frag_rows(contig: str, start, end, mapq, strand, bed6: bool = False, threads: int = 0) -> TextBuffer:
+    """Fragment-file rows ``contig  start  end  mapq  +|-`` (``bed6``: a ``.`` name column before mapq)."""
+    s_ = np.ascontiguousarray(start, dtype=np.int32)
+    e_ = np.ascontiguousarray(end, dtype=np.int32)
+    q_ = np.ascontiguousarray(mapq, dtype=np.uint8)
+    t_ = np.ascontiguousarray(strand, dtype=np.uint8)
+    if not (len(s_) == len(e_) == len(q_) == len(t_)):
+        raise ValueError("fragment columns differ in length")
+    return _call("ftk_format_frag_rows", str(contig).encode(), L.ptr(s_), L.ptr(e_), L.ptr(q_), L.ptr(t_), len(s_),
+                 int(bool(bed6)), int(threads))
+
+
+def bgzf_write(path: str, data, level: int = 6, append: bool = False, write_eof: bool = True, threads: int = 0):
+    """Write ``data`` (bytes or a ``TextBuffer``) as BGZF blocks compressed in parallel; returns the file offset
+    of every data block plus the offset behind the last one (int64 array)."""
+    lib = L.load()
+    if isinstance(data, TextBuffer):
+        ptr, n = C.c_void_p(data.ptr), data.n
+    else:
+        ptr, n = data, len(data)
+    offs = np.zeros(-(-n // 0xFF00) + 1, np.int64)
+    rc = lib.ftk_bgzf_write(str(path).encode(), ptr, n, int(level), int(threads), int(append), int(write_eof), L.ptr(offs))
+    if rc != L.FTK_OK:
+        raise OSError(lib.ftk_fragtable_error().decode())
+    return offs

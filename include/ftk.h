@@ -414,6 +414,47 @@ int ftk_motif_counts(ftk_ctx* ctx, int contig_id, int ref_id, const int32_t* w_s
                      uint32_t* counts_out /* [n_win][4^k] */, int64_t* nfrag_out /* [n_win] or NULL */,
                      int64_t* err_out /* [n_win] */);
 
+/* ---- output writers (host only; no ctx / GPU needed) ---------------------------------------------
+ * The reference prints per-base results one Python f-string at a time (frag/_wps.py:208-229 WIG,
+ * frag/_multi_wps.py:328-341 bedGraph) and hands bigWig entries to pyBigWig (:300-325).  These format the
+ * same bytes on all host threads.  Buffers and arrays returned through `out` pointers are owned by the
+ * library until ftk_buffer_free.  n_threads <= 0: all usable cores.  Errors: ftk_fragtable_error().
+ * Several results are laid end to end as RUNS: run k = values[offsets[k] .. offsets[k+1]) starts at base
+ * iv_start[k] (what ftk_wps_intervals / ftk_cleavage_intervals produce; one run = one interval).
+ *   ftk_format_wig_i64       "<v>\n" per value (the body of a fixedStep WIG)
+ *   ftk_format_bedgraph_i64  "<contig>\t<pos>\t<pos+1>\t<v>\n" per value of every run
+ *   ftk_format_bedgraph_f64  the same for float64 values printed as Python's repr(float) prints them
+ *                            (shortest round-trip digits; exponent form outside 1e-4 <= |v| < 1e16)
+ *   ftk_file_write           data -> path (truncate or append); gzip_level > 0 writes gzip members of 1 MB
+ *                            of text each, compressed in parallel (a valid multi-member .gz: gzip.open,
+ *                            zcat, bgzip -d read it as one stream)
+ *   ftk_bigwig_fixedstep_sections  the data sections of one `addEntries(chrom, start, values=..., span=1,
+ *                            step=1)` call PER RUN: values (value_kind 0 = int64, 1 = float64) cut into
+ *                            sections of items_per_section float32 items (never across runs), each with
+ *                            its 24-byte section header, zlib-compressed; *out holds the sections back to
+ *                            back; section_table_out[3s..3s+2] = chromStart, chromEnd, compressed bytes of
+ *                            section s; section_stats_out[4s..4s+3] = min, max, sum, sum of squares of its
+ *                            float32 values (inputs of the zoom level and the total summary). */
+int ftk_format_wig_i64(const int64_t* values, int64_t n, int n_threads, char** out, int64_t* out_len);
+int ftk_format_bedgraph_i64(const char* contig, const int64_t* iv_start, const int64_t* offsets, int64_t n_iv,
+                            const int64_t* values, int n_threads, char** out, int64_t* out_len);
+int ftk_format_bedgraph_f64(const char* contig, const int64_t* iv_start, const int64_t* offsets, int64_t n_iv,
+                            const double* values, int n_threads, char** out, int64_t* out_len);
+void ftk_buffer_free(void* p);
+int ftk_file_write(const char* path, const char* data, int64_t n, int gzip_level, int n_threads, int append);
+/* Fragment-file output (what the decoders read, io/alignment.py:270-302): rows "<contig>\t<start>\t<end>\t<mapq>\t<+|->\n"
+ * (bed6: a "." name column before mapq), and a BGZF container writer (blocks of 0xFF00 bytes of data compressed in
+ * parallel, the standard EOF block when write_eof): block_offsets[k] = file offset of the block holding data bytes
+ * [k * 0xFF00, ...), block_offsets[n_blocks] = offset behind the last data block -- what a tabix / BAI index needs. */
+int ftk_format_frag_rows(const char* contig, const int32_t* start, const int32_t* end, const uint8_t* mapq,
+                         const uint8_t* strand, int64_t n, int bed6, int n_threads, char** out, int64_t* out_len);
+int ftk_bgzf_write(const char* path, const char* data, int64_t n, int level, int n_threads, int append, int write_eof,
+                   int64_t* block_offsets);
+int ftk_bigwig_fixedstep_sections(uint32_t chrom_id, const int64_t* iv_start, const int64_t* offsets, int64_t n_iv,
+                                  const void* values, int value_kind, int32_t items_per_section, int level,
+                                  int n_threads, char** out, int64_t* out_len, int64_t* n_sections_out,
+                                  int64_t** section_table_out, double** section_stats_out);
+
 /* ---- multi-GPU -----------------------------------------------------------
  * One process and one ftk_ctx per GPU.  Contigs / genome runs are dealt to the ranks by the host; no
  * entry point of this library exchanges data between GPUs.  The only exchanges of the path -- the

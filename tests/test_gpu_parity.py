@@ -458,6 +458,107 @@ def test_feature_fuzz_extreme_parameters(engine, data, seed):
             assert np.array_equal(a, b), (tag, dq, g)
 
 
+# FTK_FEAT_BLOCK=1 makes the library take the block-per-window kernels for ANY window set (the host otherwise
+# reserves them for many windows of similar length); test_block_kernels_forced_* re-runs the feature tests
+# of this module that way, with the FAST kernels on and off.
+FORCED_BLOCK_PATH = os.environ.get("FTK_FEAT_BLOCK") == "1"
+
+
+@pytest.mark.parametrize("fast", ["1", "0"])
+def test_block_kernels_forced_on_every_window_set(fast):
+    if FORCED_BLOCK_PATH:
+        pytest.skip("this is the forced run")
+    import subprocess
+    import sys
+    env = dict(os.environ, FTK_FEAT_BLOCK="1", FTK_FEAT_FAST=fast)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "fast_block_kernels or feature_fuzz or window_counts or fraglen_hist or delfi_counts or upper_limit"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_fast_block_kernels_against_the_oracle(engine, data, seed):
+    """The FAST block-per-window kernels (midpoint policy, no length bounds, one mapq cut: the request of the
+    whole-genome pass) on tilings of several bin widths with extreme and inverted windows mixed in; coverage,
+    histogram and DELFI separately and fused, blacklist CSR and gap intervals near and far from the windows."""
+    rng = np.random.default_rng(3000 + seed)
+    for width in (100_000, 5_000, 1_237, 20_000):
+        ws, we = synth.tiling_windows(CONTIG_LEN, width)
+        ws, we = ws.copy(), we.copy()
+        if len(ws) < 300:  # the block path wants at least one window per CU: repeat the tiling, shifted
+            reps = -(-300 // len(ws))
+            ws = np.concatenate([np.clip(ws + 977 * r, 0, CONTIG_LEN) for r in range(reps)]).astype(np.int32)
+            we = np.concatenate([np.clip(we + 977 * r, 0, CONTIG_LEN) for r in range(reps)]).astype(np.int32)
+        k = rng.integers(0, len(ws), 12)
+        ws[k[8]], we[k[8]] = 500_000, 400_000          # inverted
+        ws[k[9]], we[k[9]] = 123_456, 123_456          # empty
+        ws[k[10]], we[k[10]] = -7, width // 2          # hangs over the contig start
+        ws[k[11]], we[k[11]] = 2 ** 30, 2 ** 30 + 99   # beyond every coordinate
+        if FORCED_BLOCK_PATH:  # open and huge windows: the host's shape heuristic would send these to the planner
+            ws[k[:4]] = [O.OPEN_LO, -7, 0, 2 ** 30]
+            we[k[4:8]] = [O.OPEN_HI, 2 ** 30 + 3, 0, -5]
+        q = int(rng.choice([0, 1, 30, 60, 61, 255, 300, -3]))
+        len_lo = int(rng.choice([0, 0, 100, 167, -20]))
+        n_bins = int(rng.choice([1001, 1001, 64, 1, 2047]))
+        tag = (seed, width, q, len_lo, n_bins)
+        want_c = O.c_window_counts(data["fr"], ws, we, mapq_min=q)
+        want_h, want_o = O.c_fraglen_hist(data["fr"], ws, we, len_lo, n_bins, mapq_min=q)
+        assert np.array_equal(engine.window_counts("synA", ws, we, q), want_c), tag
+        gh, go = engine.fraglen_hist("synA", ws, we, len_lo, n_bins, q)
+        assert np.array_equal(gh, want_h) and np.array_equal(go, want_o), tag
+        bl_s = np.sort(rng.integers(0, CONTIG_LEN - 6000, 300)).astype(np.int32)
+        bl_e = (bl_s + rng.integers(1, 5000, 300)).astype(np.int32)
+        order = np.lexsort((bl_e, bl_s))
+        bl_s, bl_e = bl_s[order], bl_e[order]
+        for gaps in (None, (1_000_050, 1_400_020, [(0, 20_010), (CONTIG_LEN - 30_000, 2 ** 30)]),
+                     (int(rng.integers(0, CONTIG_LEN)), int(rng.integers(0, CONTIG_LEN)), []),
+                     (700_000, 650_000, [(5, 2_000_000), (1_900_000, 2_100_000)])):
+            for bl in ((None, None), (bl_s, bl_e)):
+                want = O.c_delfi_counts(data["fr"], ws, we, q, bl[0], bl[1], gaps)
+                got = engine.delfi_counts("synA", ws, we, q, bl[0], bl[1], gaps)
+                for a, b in zip(got, want):
+                    assert np.array_equal(a, b), (tag, gaps, bl[0] is None)
+            fused = engine.window_features("synA", ws, we, q, hist=(len_lo, n_bins),
+                                           delfi=dict(quality_threshold=q, bl_start=bl_s, bl_end=bl_e, gaps=gaps))
+            want = O.c_delfi_counts(data["fr"], ws, we, q, bl_s, bl_e, gaps)
+            assert np.array_equal(fused["coverage"], want_c) and np.array_equal(fused["hist"], want_h), (tag, gaps)
+            assert np.array_equal(fused["overflow"], want_o), (tag, gaps)
+            assert np.array_equal(fused["short"], want[0]) and np.array_equal(fused["long"], want[1]), (tag, gaps)
+        # a different DELFI mapq cut takes the general kernels: same answers
+        fused = engine.window_features("synA", ws, we, q, hist=(len_lo, n_bins), delfi=dict(quality_threshold=17))
+        want = O.c_delfi_counts(data["fr"], ws, we, 17)
+        assert np.array_equal(fused["coverage"], want_c) and np.array_equal(fused["short"], want[0]), tag
+        assert np.array_equal(fused["long"], want[1]), tag
+
+
+def test_fast_block_kernels_near_the_upper_limit(engine):
+    """Fragments just below 2^30 on a tiling wide enough for the block path: the doubled midpoint test must
+    not overflow (m2 = fs + fe reaches 2^31 - 2)."""
+    rng = np.random.default_rng(6)
+    top = 2 ** 30 - 1
+    n = 60_000
+    s = np.sort(rng.integers(top - 3_000_000, top - 600, n)).astype(np.int32)
+    e = np.minimum(s + rng.integers(0, 600, n), top).astype(np.int32)
+    q = rng.integers(0, 61, n).astype(np.uint8)
+    s[-1], e[-1] = top, top
+    engine.load_contig("hi2", s, e, q, np.zeros(n, np.uint8))
+    fr = O.Frags(s, e, q, np.zeros(n, np.uint8))
+    ws = np.arange(top - 3_000_000, top + 1, 9_973, dtype=np.int64)
+    we = np.minimum(ws + 9_973, 2 ** 30 + 5)
+    ws, we = ws.astype(np.int32), we.astype(np.int32)
+    ws[0], we[-1] = O.OPEN_LO, O.OPEN_HI
+    assert len(ws) >= 300
+    assert np.array_equal(engine.window_counts("hi2", ws, we, 10), O.c_window_counts(fr, ws, we, mapq_min=10))
+    h, o = engine.fraglen_hist("hi2", ws, we, 0, 700, 0)
+    wh, wo = O.c_fraglen_hist(fr, ws, we, 0, 700, mapq_min=0)
+    assert np.array_equal(h, wh) and np.array_equal(o, wo)
+    g = (top - 1_000_000, top - 900_000, [(top - 50_000, top)])
+    for a, b in zip(engine.delfi_counts("hi2", ws, we, 0, None, None, g), O.c_delfi_counts(fr, ws, we, 0, None, None, g)):
+        assert np.array_equal(a, b)
+    engine.release("hi2")
+
+
 def test_coordinates_near_the_upper_limit(engine):
     """Fragments and windows just below 2^30 (the largest coordinate the SoA admits)."""
     rng = np.random.default_rng(5)

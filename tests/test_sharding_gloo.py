@@ -107,6 +107,9 @@ def _fake_device(sizes):
         def load_all(self):
             pass
 
+        def has(self, c):
+            return c in self.contigs
+
         def require(self, c):
             asked.append(c)
             return c
