@@ -1604,6 +1604,7 @@ struct ftk_fragstream {
     std::vector<std::string> ref_names;
     std::vector<int64_t> ref_lens;
     bool header_ready = false;
+    double stage_ms[6] = {0, 0, 0, 0, 0, 0};  // read, inflate, parse, merge, emit, other: set when the producer is done
 
     // Text files on a stream opened with ftk_fragstream_open_on: the rows are parsed on this GPU
     // (run_text_device) and the tables handed out hold device columns.
@@ -1833,17 +1834,23 @@ void ftk_fragstream::run() {
 }
 
 namespace {
-struct StageClock {  // FTK_DECODE_TIMING=1: where the streaming decoder spends its time
+struct StageClock {  // where the producer thread of the streaming decoder spends its time (ftk_fragstream_stage_ms;
+                     // FTK_DECODE_TIMING=1 also prints it)
     bool on = getenv("FTK_DECODE_TIMING") != nullptr;
+    ftk_fragstream* owner;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    explicit StageClock(ftk_fragstream* s) : owner(s) {}
     void lap(int k) {
-        if (!on) return;
         auto now = std::chrono::steady_clock::now();
         acc[k] += std::chrono::duration<double, std::milli>(now - t).count();
         t = now;
     }
     void report(const char* what) {
+        {
+            std::lock_guard<std::mutex> lk(owner->mu);
+            for (int k = 0; k < 6; ++k) owner->stage_ms[k] = acc[k];
+        }
         if (!on) return;
         fprintf(stderr, "[ftk stream %s] read %.1f  inflate %.1f  parse %.1f  merge %.1f  emit(pack+queue) %.1f  other %.1f ms\n",
                 what, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]);
@@ -1852,7 +1859,7 @@ struct StageClock {  // FTK_DECODE_TIMING=1: where the streaming decoder spends 
 }  // namespace
 
 bool ftk_fragstream::run_text(RawBuf& buf, size_t n) {
-    StageClock clk;
+    StageClock clk(this);
     std::vector<Block> blocks;
     RawBuf text;                  // carry (incomplete last line) + this piece's inflated text
     size_t text_carry = 0;
@@ -2051,7 +2058,7 @@ bool ftk_fragstream::emit_device(Contig&& ct) {
 // kernel listed (the names are read from the host copy of the text); any other piece goes through the
 // host's field-rule parser (parse_text_parallel) and its columns are uploaded - same rows either way.
 bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
-    StageClock clk;
+    StageClock clk(this);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking) != hipSuccess) {
         (void)hipGetLastError();
         return fail(FTK_ERR_HIP, "cannot create the parse stream");
@@ -2223,7 +2230,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
 }
 
 bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
-    StageClock clk;
+    StageClock clk(this);
     size_t n_stretches = 0, n_redone = 0;
     std::vector<Block> blocks;
     RawBuf data;                // carry (partial record / header) + this piece's inflated bytes
@@ -2544,6 +2551,13 @@ const char* ftk_fragstream_ref_name(ftk_fragstream* s, int i) {
 int64_t ftk_fragstream_ref_length(ftk_fragstream* s, int i) {
     if (!s || i < 0 || i >= ftk_fragstream_n_refs(s)) return -1;
     return s->ref_lens[i];
+}
+
+int ftk_fragstream_stage_ms(ftk_fragstream* s, double out[6]) {
+    if (!s || !out) return FTK_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(s->mu);
+    for (int k = 0; k < 6; ++k) out[k] = s->stage_ms[k];
+    return FTK_OK;
 }
 
 void ftk_fragstream_close(ftk_fragstream* s) {

@@ -84,6 +84,7 @@ class FragSource:
         self.loaded = set()
         self.lazy = lazy
         self.workers = workers
+        self.decode_stage_ms = None               # set by stream_source when the whole file has been decoded
 
     def key(self, contig: str) -> str:
         return f"{self.uid}:{contig}"
@@ -250,6 +251,10 @@ def stream_source(input_file, workers: int | None = None, queued: int = 2):
                 if name not in src.loaded:
                     eng.load_contig(src.key(name), empty32, empty32, empty8, empty8, empty32, empty32)
                     src.loaded.add(name)
+        stage = (C.c_double * 6)()
+        if lib.ftk_fragstream_stage_ms(stream, C.byref(stage)) == L.FTK_OK:
+            # wall time of the producer thread per stage (ms): what the decode of this file cost
+            src.decode_stage_ms = dict(zip(("read", "inflate", "parse", "merge", "emit", "other"), (round(x, 2) for x in stage)))
         complete = True
     finally:
         lib.ftk_fragstream_close(stream)

@@ -46,3 +46,44 @@ def tiling_windows(contig_len: int, width: int):
     ws = np.arange(0, contig_len, width, dtype=np.int64)
     we = np.minimum(ws + width, contig_len)
     return ws.astype(np.int32), we.astype(np.int32)
+
+
+# ---- whole-genome workload pieces (bench.py, tools/, the full-size GPU tests) ---------------------------------
+_WINDOW = 100_000
+
+
+def gen_contig_device(torch, dev, contig_len, n, seed):
+    """Seeded device-side generator of the BASELINE.md mixture; start-sorted SoA tensors."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    start = torch.randint(0, max(contig_len - 1000, 1), (n,), generator=g, device=dev, dtype=torch.int64)
+    u = torch.rand(n, generator=g, device=dev)
+    z = torch.randn(n, generator=g, device=dev)
+    v = torch.rand(n, generator=g, device=dev)
+    length = torch.where(u < 0.85, 167.0 + 12.0 * z, torch.where(u < 0.97, 334.0 + 25.0 * z, 30.0 + 570.0 * v))
+    length = torch.clamp(torch.round(length), 30, 1000).to(torch.int64)
+    del u, z, v
+    key, _ = torch.sort(start * 2048 + length)  # sort by (start, end)
+    del start, length
+    s = (key >> 11).to(torch.int32)
+    e = (s + (key & 2047).to(torch.int32)).contiguous()
+    del key
+    m = torch.rand(n, generator=g, device=dev)
+    mapq = torch.where(m < 0.85, torch.full((n,), 60, device=dev, dtype=torch.int64),
+                       torch.randint(0, 60, (n,), generator=g, device=dev)).to(torch.uint8)
+    strand = (torch.rand(n, generator=g, device=dev) < 0.5).to(torch.uint8)
+    return s, e, mapq, strand
+
+
+def synth_gaps(contig_len):
+    """Synthetic centromere / telomere constants (hg19-like proportions)."""
+    c0 = int(contig_len * 0.40) // _WINDOW * _WINDOW
+    return (c0, c0 + 3_000_000, [(0, 10_000), (contig_len - 10_000, contig_len)])
+
+
+def synth_blacklist(contig_len, seed, n_regions):
+    rng = np.random.default_rng(seed)
+    s = np.sort(rng.integers(0, contig_len - 6000, n_regions)).astype(np.int32)
+    e = (s + rng.integers(200, 5000, n_regions)).astype(np.int32)
+    order = np.lexsort((e, s))
+    return s[order], e[order]

@@ -169,6 +169,11 @@ int ftk_fragstream_next(ftk_fragstream* s, ftk_fragtable** out);
 int ftk_fragstream_n_refs(ftk_fragstream* s);
 const char* ftk_fragstream_ref_name(ftk_fragstream* s, int i);
 int64_t ftk_fragstream_ref_length(ftk_fragstream* s, int i);
+/* Wall time (ms) the stream's producer thread spent per stage, complete once ftk_fragstream_next has returned the
+ * end of the file: out[0..5] = file read, BGZF inflate, row / record parse (device parser: launch), run merge /
+ * collect, hand-over (pack + waiting for queue space), everything else.  The stages of one piece run one after
+ * the other on the producer; their work is spread over n_threads (and the GPU for the device row parser). */
+int ftk_fragstream_stage_ms(ftk_fragstream* s, double out[6]);
 void ftk_fragstream_close(ftk_fragstream* s);
 const char* ftk_fragtable_error(void); /* message for a failed decode call (thread-local) */
 int ftk_fragtable_is_bed6(const ftk_fragtable* t);

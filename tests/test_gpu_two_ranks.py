@@ -121,7 +121,7 @@ def test_cli_gpus_2_writes_the_single_process_file(dataset, tmp_path):
             env.pop(k, None)
         r = subprocess.run([sys.executable, "-m", "finaletoolkit_amd.cli", "--gpus", str(world), "delfi",
                             str(d / "g.frag.gz"), str(d / "cs.genome"), str(d / "ref.fa"), str(d / "bins.txt"),
-                            "-b", str(d / "bl.bed"), "-g", str(d / "gaps.bed"), "--no-gc-correct", "--no-remove-nocov",
+                            "-b", str(d / "bl.bed"), "-g", str(d / "gaps.bed"), "--no-gc-correct", "--no-remove-nocov", "--no-merge-bins",
                             "-o", str(out)],
                            cwd=ROOT, env=env, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
