@@ -635,22 +635,37 @@ def cpu_baseline(torch, eng, per, mine, budget_s, checks):
     t_all = O.c_all_cores(fr, p["ws"][:n_all], p["we"][:n_all], HIST_BINS, MAPQ, p["bl"][0], p["bl"][1], p["gaps"], size,
                           WPS_W, WPS_MIN, WPS_MAX, n_cores)
     # reference-shaped single-thread baseline: the pure-Python restatement that
-    # follows the reference loop for loop, on a few windows / WPS tiles
-    rows = list(zip(s[:40_000].tolist(), e[:40_000].tolist(), q[:40_000].tolist(), st[:40_000].tolist()))
+    # follows the reference loop for loop.  Every window / WPS tile gets the rows its index query would return
+    # (the contig's fragments overlapping it, at full depth); as many windows and tiles as fit in ~6 s each.
+    s64, e64 = s.astype(np.int64), e.astype(np.int64)
+
+    def fetched(a, b):  # rows of a tabix query [a, b): start < b and end > a
+        lo = int(np.searchsorted(s64, a - 1000, side="left"))  # fragments are at most 1000 bp long
+        hi = int(np.searchsorted(s64, b, side="left"))
+        k = np.flatnonzero(e64[lo:hi] > a) + lo
+        return list(zip(s[k].tolist(), e[k].tolist(), q[k].tolist(), st[k].tolist()))
+
+    bl_rows = list(zip(p["bl"][0].tolist(), p["bl"][1].tolist()))
     t2 = time.perf_counter()
-    n_py = 3
-    for w in range(n_py):
-        a, b = int(ws[w]), int(we[w])
+    n_py = 0
+    while n_py < min(n_s, 400) and time.perf_counter() - t2 < 6.0:
+        a, b = int(ws[n_py]), int(we[n_py])
+        rows = fetched(a, b)
         O.py_single_coverage(rows, a, b, None, None, "midpoint", MAPQ)
         O.py_distribution(rows, a, b, None, None, "midpoint", MAPQ)
-        O.py_delfi_single_window(rows, a, b, MAPQ, list(zip(p["bl"][0].tolist(), p["bl"][1].tolist())), p["gaps"])
-    t_py_count = (time.perf_counter() - t2) / n_py
+        O.py_delfi_single_window(rows, a, b, MAPQ, bl_rows, p["gaps"])
+        n_py += 1
+    t_py_count = (time.perf_counter() - t2) / max(n_py, 1)
     t3 = time.perf_counter()
-    n_tiles_py = 2
-    for k in range(n_tiles_py):
-        x0 = int(ws[1]) + 5000 * k
-        O.py_wps(rows, x0, x0 + 5000, size, WPS_W, WPS_MIN, WPS_MAX, MAPQ)
-    t_py_wps = (time.perf_counter() - t3) / n_tiles_py * (WINDOW / 5000)
+    n_tiles_py = 0
+    x0 = int(ws[min(1, n_s - 1)])
+    while n_tiles_py < 2000 and time.perf_counter() - t3 < 6.0:
+        a = x0 + 5000 * n_tiles_py
+        if a + 5000 > size:
+            break
+        O.py_wps(fetched(max(a - WPS_MAX, 0), a + 5000 + WPS_MAX), a, a + 5000, size, WPS_W, WPS_MIN, WPS_MAX, MAPQ)
+        n_tiles_py += 1
+    t_py_wps = (time.perf_counter() - t3) / max(n_tiles_py, 1) * (WINDOW / 5000)
     cpu_model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -669,8 +684,8 @@ def cpu_baseline(torch, eng, per, mine, budget_s, checks):
             "reference_shaped_python": {
                 "value": round(1.0 / (t_py_count + t_py_wps), 4), "unit": "windows/s", "cores": 1,
                 "sample": f"oracle/oracle.py py_* (per-window fetch + per-fragment Python predicate, numpy "
-                          f"_single_nt_wps): {n_py} windows of counters, {n_tiles_py} x 5 kb WPS tiles, over the first "
-                          f"40 000 fragments of contig {c}; extrapolated per 100 kb window"}}
+                          f"_single_nt_wps) on the rows an index query returns at full depth: counters of {n_py} windows, "
+                          f"{n_tiles_py} x 5 kb WPS tiles of contig {c}; per 100 kb window = counters + 20 tiles"}}
 
 
 if __name__ == "__main__":

@@ -53,7 +53,7 @@ EXPORTS = [
     "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals", "ftk_wps_adjust",
     "ftk_ref_upload", "ftk_ref_release", "ftk_ref_gc_counts", "ftk_ref_set_layout", "ftk_motif_counts",
     "ftk_format_wig_i64", "ftk_format_bedgraph_i64", "ftk_format_bedgraph_f64", "ftk_buffer_free", "ftk_file_write",
-    "ftk_bigwig_fixedstep_sections", "ftk_format_frag_rows", "ftk_bgzf_write",
+    "ftk_bigwig_fixedstep_sections", "ftk_format_frag_rows", "ftk_bgzf_write", "ftk_fill_wps_records",
 ]
 
 
@@ -99,6 +99,33 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` / ``libhsa-runtime64.so``
+    (soname ``libamdhip64.so.7``, the one ``libftk_hip.so`` asks for).  When torch is imported first, the dynamic
+    linker hands that copy to ``libftk_hip.so`` too; when ``libftk_hip.so`` comes first it would bind ``/opt/rocm``'s
+    copy and a later ``import torch`` would bring a second runtime into the process, which then finds no device.
+    So, if torch is installed but not imported yet, its bundled runtime is loaded first (no torch import: only
+    the two shared objects).  ``FTK_SYSTEM_HIP=1`` keeps the system runtime (processes that never import torch)."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("FTK_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if not spec or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load() -> C.CDLL:
     """Load the HIP library; raises if it has not been built."""
     global _lib
@@ -113,6 +140,7 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
             "finaletoolkit_amd has no CPU fallback.")
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.ftk_version.restype = C.c_char_p
@@ -127,6 +155,7 @@ def load() -> C.CDLL:
     lib.ftk_buffer_free.argtypes = [vp]
     lib.ftk_buffer_free.restype = None
     lib.ftk_format_frag_rows.argtypes = [C.c_char_p, vp, vp, vp, vp, i64, C.c_int, C.c_int, pp, pi64]
+    lib.ftk_fill_wps_records.argtypes = [vp, i64, vp, i64, vp, C.c_int]
     lib.ftk_bgzf_write.argtypes = [C.c_char_p, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.ftk_file_write.argtypes = [C.c_char_p, vp, i64, C.c_int, C.c_int, C.c_int]
     lib.ftk_bigwig_fixedstep_sections.argtypes = [C.c_uint32, vp, vp, i64, vp, C.c_int, i32, C.c_int, C.c_int, pp, pi64,

@@ -334,6 +334,23 @@ int ftk_file_write(const char* path, const char* data, int64_t n, int gzip_level
     return rc;
 }
 
+int ftk_fill_wps_records(void* dst, int64_t n, const uint32_t contig_ucs4[16], int64_t start, const int64_t* values,
+                         int n_threads) {
+    if (n < 0 || (n > 0 && (!dst || !values || !contig_ucs4))) return wfail(FTK_ERR_INVALID, "bad arguments");
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads > 0 ? n_threads : ftk_host::default_threads(), (n + 65535) / 65536));
+    ftk_host::parallel_run(nt, [&](int t) {
+        const int64_t a = n * t / nt, b = n * (t + 1) / nt;
+        uint8_t* p = (uint8_t*)dst + (size_t)a * 80;
+        for (int64_t i = a; i < b; ++i, p += 80) {  // ('contig', 'U16'), ('start', 'i8'), ('wps', 'i8'): 64 + 8 + 8 bytes
+            memcpy(p, contig_ucs4, 64);
+            const int64_t pos = start + i;
+            memcpy(p + 64, &pos, 8);
+            memcpy(p + 72, values + i, 8);
+        }
+    });
+    return FTK_OK;
+}
+
 int ftk_format_frag_rows(const char* contig, const int32_t* start, const int32_t* end, const uint8_t* mapq,
                          const uint8_t* strand, int64_t n, int bed6, int n_threads, char** out, int64_t* out_len) {
     if (!contig || !out || !out_len || (n > 0 && (!start || !end || !mapq || !strand)))

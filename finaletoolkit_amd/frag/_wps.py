@@ -41,9 +41,22 @@ def _resolve_aliases(min_length, max_length, fraction_low, fraction_high):
 
 
 def _scores_array(chrom, start, values):
-    scores = np.zeros(len(values), dtype=_WPS_DTYPE)
+    """The reference's result array (frag/_wps.py:181-188): 80-byte records, gigabytes for a chromosome -- large
+    ones are filled by the library's host threads (``ftk_fill_wps_records``), small ones by numpy."""
+    n = len(values)
+    if n >= 1 << 20:
+        import ctypes as C
+        from .. import _lib as L
+        scores = np.empty(n, dtype=_WPS_DTYPE)
+        name = np.zeros(1, dtype="U16")
+        name[0] = chrom  # numpy's own truncation / padding of the name
+        vals = np.ascontiguousarray(values, dtype=np.int64)
+        rc = L.load().ftk_fill_wps_records(L.ptr(scores), n, L.ptr(name.view(np.uint32)), int(start), L.ptr(vals), 0)
+        if rc == L.FTK_OK:
+            return scores
+    scores = np.zeros(n, dtype=_WPS_DTYPE)
     scores["contig"] = chrom
-    scores["start"] = np.arange(start, start + len(values), dtype=np.int64)
+    scores["start"] = np.arange(start, start + n, dtype=np.int64)
     scores["wps"] = values
     return scores
 

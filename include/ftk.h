@@ -447,6 +447,11 @@ int ftk_format_bedgraph_f64(const char* contig, const int64_t* iv_start, const i
                             const double* values, int n_threads, char** out, int64_t* out_len);
 void ftk_buffer_free(void* p);
 int ftk_file_write(const char* path, const char* data, int64_t n, int gzip_level, int n_threads, int append);
+/* The array frag/_wps.py:181-188 returns -- numpy records ('contig', 'U16'), ('start', 'i8'), ('wps', 'i8'), 80 bytes
+ * each: contig name as 16 UCS-4 code points (zero padded), start + i, values[i] -- filled by the host threads (for a
+ * chromosome that array is gigabytes; one numpy thread takes longer over it than the GPU over the scores). */
+int ftk_fill_wps_records(void* dst, int64_t n, const uint32_t contig_ucs4[16], int64_t start, const int64_t* values,
+                         int n_threads);
 /* Fragment-file output (what the decoders read, io/alignment.py:270-302): rows "<contig>\t<start>\t<end>\t<mapq>\t<+|->\n"
  * (bed6: a "." name column before mapq), and a BGZF container writer (blocks of 0xFF00 bytes of data compressed in
  * parallel, the standard EOF block when write_eof): block_offsets[k] = file offset of the block holding data bytes

@@ -4,8 +4,8 @@ TEST INFRASTRUCTURE ONLY -- never imported by the product path.
 Stand-in modules that let the *reference* package (``/root/reference/src``)
 be imported in the build container, where its compiled third-party
 dependencies (pysam, numba, pyBigWig, py2bit, loess) are absent.  Used only by
-``oracle/gen_golden.py`` to emit golden vectors and by
-``oracle/check_against_reference.py`` to validate the restatement.  Nothing
+``oracle/gen_golden*.py`` to emit the golden vectors that ``tests/test_oracle_golden.py`` replays
+against the restatement.  Nothing
 here travels to the GPU box as a dependency of any test: the reference source
 is not in this repository and ``/root/reference`` does not exist there.
 

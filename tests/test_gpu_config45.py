@@ -145,10 +145,16 @@ def test_config4_whole_contigs_against_the_oracle(engine, genome, contig):
         rng = np.random.default_rng(4)
         for a in [0, p["size"] - 5000] + [int(x) for x in rng.integers(0, p["size"] - 5000, 6)]:
             assert np.array_equal(out[a:a + 5000].cpu().numpy(), O.c_wps(fr, a, a + 5000, p["size"], 120, 120, 180, 30)), a
+        # sum over all 249 M bases: a passing fragment gives 1 to [fs+61, fe-60] and takes 1 from [fs-59, fs+60] and
+        # [fe-59, fe+60], each clipped to the contig
         keep = (q >= 30) & (e - s >= 120) & (e - s <= 180)
-        # sum over all bases: every passing fragment adds (len - 120) spanning and takes 2 * 120 end positions
-        ln = (e - s)[keep].astype(np.int64)
-        assert int(out.sum().item()) == int((ln - 120 - 240).sum())  # no fragment within 120 bp of either contig end
+        fs, fe = s[keep].astype(np.int64), e[keep].astype(np.int64)
+        size = p["size"]
+
+        def clipped(a, b):  # bases of the closed range [a, b] inside [0, size)
+            return np.maximum(np.minimum(b, size - 1) - np.maximum(a, 0) + 1, 0)
+        want_sum = int((clipped(fs + 61, fe - 60) - clipped(fs - 59, fs + 60) - clipped(fe - 59, fe + 60)).sum())
+        assert int(out.sum().item()) == want_sum
 
 
 # ---- config 5 -------------------------------------------------------------------------------------------
