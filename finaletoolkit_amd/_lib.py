@@ -53,7 +53,7 @@ EXPORTS = [
     "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals", "ftk_wps_adjust",
     "ftk_ref_upload", "ftk_ref_release", "ftk_ref_gc_counts", "ftk_ref_set_layout", "ftk_motif_counts",
     "ftk_format_wig_i64", "ftk_format_bedgraph_i64", "ftk_format_bedgraph_f64", "ftk_buffer_free", "ftk_file_write",
-    "ftk_bigwig_fixedstep_sections", "ftk_format_frag_rows", "ftk_bgzf_write", "ftk_fill_wps_records",
+    "ftk_bigwig_fixedstep_sections", "ftk_format_frag_rows", "ftk_bgzf_write", "ftk_fill_wps_records", "ftk_bgzf_inflate_device",
 ]
 
 
@@ -155,6 +155,7 @@ def load() -> C.CDLL:
     lib.ftk_buffer_free.argtypes = [vp]
     lib.ftk_buffer_free.restype = None
     lib.ftk_format_frag_rows.argtypes = [C.c_char_p, vp, vp, vp, vp, i64, C.c_int, C.c_int, pp, pi64]
+    lib.ftk_bgzf_inflate_device.argtypes = [vp, vp, i64, vp, i64, pi64]
     lib.ftk_fill_wps_records.argtypes = [vp, i64, vp, i64, vp, C.c_int]
     lib.ftk_bgzf_write.argtypes = [C.c_char_p, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.ftk_file_write.argtypes = [C.c_char_p, vp, i64, C.c_int, C.c_int, C.c_int]

@@ -10,6 +10,7 @@
 
 #include <dlfcn.h>
 
+#include "ftk_inflate.h"
 #include "ftk_kernels.h"
 
 using namespace ftk;
@@ -1673,6 +1674,73 @@ int ftk_ref_gc_counts(ftk_ctx* ctx, int ref_id, const int64_t* range_lo, const i
         HIPCHK(ctx, hipMemcpyAsync(gc_out, d_out, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return FTK_OK;
+}
+
+// ---- DEFLATE on the device (csrc/ftk_inflate.hip) -------------------------------------------------------
+int ftk_bgzf_inflate_device(ftk_ctx* ctx, const uint8_t* file_bytes, int64_t n, uint8_t* out, int64_t cap, int64_t* n_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    if (!file_bytes || n < 0 || (cap > 0 && !out) || !n_out) return fail(ctx, FTK_ERR_INVALID, "bad arguments");
+    if (n >= (int64_t(1) << 32) - 65536) return fail(ctx, FTK_ERR_INVALID, "at most 4 GB per call");
+    // walk the BGZF blocks: 12-byte gzip header with FEXTRA, the BC subfield gives the block size
+    std::vector<ftk::InflateBlock> tab;
+    std::vector<uint32_t> want_crc;
+    uint64_t off = 0, total = 0;
+    while (off < (uint64_t)n) {
+        const uint8_t* p = file_bytes + off;
+        if (off + 18 > (uint64_t)n || p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4))
+            return fail(ctx, FTK_ERR_FORMAT, "not a BGZF block at byte %llu", (unsigned long long)off);
+        const unsigned xlen = p[10] | (p[11] << 8);
+        unsigned bsize = 0;
+        for (unsigned x = 0; x + 4 <= xlen && off + 12 + x + 4 <= (uint64_t)n;) {
+            const uint8_t* f = p + 12 + x;
+            const unsigned slen = f[2] | (f[3] << 8);
+            if (f[0] == 66 && f[1] == 67 && slen == 2 && off + 12 + x + 6 <= (uint64_t)n) bsize = (f[4] | (f[5] << 8)) + 1u;
+            x += 4 + slen;
+        }
+        const uint64_t q = off + 12 + xlen;
+        if (!bsize || off + bsize > (uint64_t)n || q + 8 > off + bsize)
+            return fail(ctx, FTK_ERR_FORMAT, "corrupt BGZF block at byte %llu", (unsigned long long)off);
+        const uint8_t* tr = p + bsize - 8;
+        const uint32_t isize = (uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+        if (isize > 65536u || total + isize >= (uint64_t(1) << 32)) return fail(ctx, FTK_ERR_FORMAT, "BGZF block too large");
+        tab.push_back({(uint32_t)q, (uint32_t)(off + bsize - 8 - q), (uint32_t)total, isize});
+        want_crc.push_back((uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24));
+        total += isize;
+        off += bsize;
+    }
+    *n_out = (int64_t)total;
+    if ((int64_t)total > cap) return fail(ctx, FTK_ERR_INVALID, "output holds %lld bytes, %lld needed", (long long)cap, (long long)total);
+    if (tab.empty() || total == 0) return FTK_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = reserve_scratch(ctx, align_up((size_t)n + 8) + align_up(tab.size() * sizeof(tab[0])) + align_up(tab.size() * 4) +
+                                      align_up((size_t)total + 8192) + 4096);
+    if (rc) return rc;
+    Arena a(ctx);
+    uint8_t* d_comp = a.take<uint8_t>((size_t)n + 8);
+    ftk::InflateBlock* d_tab = a.take<ftk::InflateBlock>(tab.size());
+    ftk::InflateStatus* d_st = a.take<ftk::InflateStatus>(1);
+    uint32_t* d_crc = a.take<uint32_t>(tab.size());
+    uint8_t* d_out = a.take<uint8_t>((size_t)total + 4096 + 16);
+    d_out = (uint8_t*)(((uintptr_t)d_out + 4095) & ~(uintptr_t)4095);
+    HIPCHK(ctx, hipMemcpyAsync(d_comp, file_bytes, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_st, 0, sizeof(*d_st), ctx->stream));
+    ftk::inflate_launch(ctx->stream, d_comp, d_tab, (int)tab.size(), d_out, d_st, d_crc);
+    HIPCHK(ctx, hipGetLastError());
+    ftk::InflateStatus st{};
+    std::vector<uint32_t> got_crc(tab.size());
+    HIPCHK(ctx, hipMemcpyAsync(&st, d_st, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(got_crc.data(), d_crc, tab.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out, d_out, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (st.n_bad)
+        return fail(ctx, FTK_ERR_FORMAT, "device inflate: %u of %zu BGZF blocks did not decode (block %u: reason %u)", st.n_bad,
+                    tab.size(), st.first_bad, st.reason);
+    for (size_t k = 0; k < tab.size(); ++k)  // the gzip trailer's CRC-32 against the one computed on the device
+        if (got_crc[k] != want_crc[k])
+            return fail(ctx, FTK_ERR_FORMAT, "device inflate: CRC mismatch in BGZF block %zu (%08x, trailer says %08x)", k,
+                        got_crc[k], want_crc[k]);
     return FTK_OK;
 }
 

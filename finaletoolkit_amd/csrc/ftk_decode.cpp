@@ -35,6 +35,7 @@
 
 #include "ftk.h"
 #include "ftk_host.h"
+#include "ftk_inflate.h"
 #include "ftk_textparse.h"
 
 namespace {
@@ -1960,14 +1961,62 @@ struct DevSet {
     bool pending = false;
     bool host_only = false;   // the piece was not sent to the device (4 GB or more: the kernels index with 32 bits)
     size_t off = 0, len = 0;  // the launched range of h_text (complete lines)
+    // pieces inflated on the device (FTK_DEVICE_INFLATE): compressed bytes, block table, per-block CRCs, status
+    bool inflated = false;
+    uint8_t* d_comp = nullptr;
+    size_t comp_cap = 0, tab_cap = 0, n_tab = 0;
+    ftk::InflateBlock *d_tab = nullptr, *h_tab = nullptr;
+    uint32_t *d_crc = nullptr, *h_crc = nullptr, *want_crc = nullptr;  // want_crc: the blocks' trailers (plain host memory)
+    ftk::InflateStatus *d_ist = nullptr, *h_ist = nullptr;
 
+    void release_inflate() {
+        for (void* q : {(void*)d_comp, (void*)d_tab, (void*)d_crc, (void*)d_ist})
+            if (q) (void)hipFree(q);
+        for (void* q : {(void*)h_tab, (void*)h_crc, (void*)h_ist})
+            if (q) (void)hipHostFree(q);
+        free(want_crc);
+        d_comp = nullptr; d_tab = h_tab = nullptr; d_crc = h_crc = want_crc = nullptr; d_ist = h_ist = nullptr;
+        comp_cap = tab_cap = 0;
+    }
     void release() {
+        release_inflate();
         if (h_text) (void)hipHostFree(h_text);
         if (h_sum) (void)hipHostFree(h_sum);
         for (void* q : {(void*)d_text, (void*)d_blocks, (void*)d_lines, (void*)d_s, (void*)d_e, (void*)d_q, (void*)d_t, (void*)d_sum})
             if (q) (void)hipFree(q);
         if (done) (void)hipEventDestroy(done);
         *this = DevSet{};
+    }
+    // room for a piece of comp_bytes of BGZF data in n_blocks blocks
+    bool ensure_inflate(size_t comp_bytes, size_t n_blocks) {
+        bool ok = true;
+        if (comp_bytes + 64 > comp_cap) {
+            if (d_comp) (void)hipFree(d_comp);
+            d_comp = nullptr;
+            comp_cap = comp_bytes + comp_bytes / 4 + 4096;
+            ok = hipMalloc((void**)&d_comp, comp_cap) == hipSuccess;
+        }
+        if (ok && n_blocks > tab_cap) {
+            const size_t cc = comp_cap;
+            uint8_t* keep = d_comp;
+            d_comp = nullptr;
+            release_inflate();
+            d_comp = keep;
+            comp_cap = cc;
+            tab_cap = n_blocks + n_blocks / 4 + 64;
+            want_crc = (uint32_t*)malloc(tab_cap * 4);
+            ok = want_crc && hipMalloc((void**)&d_tab, tab_cap * sizeof(ftk::InflateBlock)) == hipSuccess &&
+                 hipHostMalloc((void**)&h_tab, tab_cap * sizeof(ftk::InflateBlock), hipHostMallocDefault) == hipSuccess &&
+                 hipMalloc((void**)&d_crc, tab_cap * 4) == hipSuccess &&
+                 hipHostMalloc((void**)&h_crc, tab_cap * 4, hipHostMallocDefault) == hipSuccess &&
+                 hipMalloc((void**)&d_ist, sizeof(ftk::InflateStatus)) == hipSuccess &&
+                 hipHostMalloc((void**)&h_ist, sizeof(ftk::InflateStatus), hipHostMallocDefault) == hipSuccess;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            release_inflate();
+        }
+        return ok;
     }
     // room for `bytes` of text; false: out of (page-locked or device) memory
     bool ensure(size_t bytes) {
@@ -2082,6 +2131,8 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     bool have_cur = false;
     std::set<std::string> seen;
     size_t gpu_pieces = 0, host_pieces = 0;
+    // FTK_DEVICE_INFLATE=1: the BGZF blocks are inflated on the GPU too (ftk_inflate.hip); the host only reads the file
+    static const bool dev_inflate = getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) != 0;
 
     // one contig run of a piece: n rows at the given column pointers (device or host)
     auto take_run = [&](const std::string& name, const int32_t* s0, const int32_t* e0, const uint8_t* q0, const uint8_t* t0,
@@ -2111,6 +2162,45 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         }
         S.pending = false;
         const ftk::TextSummary& sum = *S.h_sum;
+        if (S.inflated) {
+            if (S.h_ist->n_bad)
+                return fail(FTK_ERR_FORMAT, ("BGZF inflate failed: a block did not decode to its ISIZE (device inflate, reason " +
+                                             std::to_string(S.h_ist->reason) + ")").c_str());
+            for (size_t i = 0; i < S.n_tab; ++i)
+                if (S.h_crc[i] != S.want_crc[i]) return fail(FTK_ERR_FORMAT, "BGZF block CRC mismatch (device inflate)");
+            if (sum.carry_overflow) return fail(FTK_ERR_FORMAT, "a row longer than 64 KB");
+            if (sum.text_len == 0) return true;
+            const bool plain_d = !sum.overflow && sum.n_bad == 0 && sum.n_runs >= 1 && sum.n_runs <= (unsigned)ftk::kTextNamedRuns &&
+                                 !sum.name_overflow && sum.n_lines <= S.max_lines;
+            if (plain_d) {
+                ++gpu_pieces;
+                std::vector<std::pair<unsigned, unsigned>> runs(sum.n_runs);  // (first line, slot)
+                for (unsigned r = 0; r < sum.n_runs; ++r) runs[r] = {sum.run_line[r], r};
+                std::sort(runs.begin(), runs.end());
+                for (size_t r = 0; r < runs.size(); ++r) {
+                    const size_t l0 = runs[r].first, l1 = r + 1 < runs.size() ? runs[r + 1].first : (size_t)sum.n_lines;
+                    if (!take_run(std::string((const char*)sum.run_name[runs[r].second]), S.d_s + l0, S.d_e + l0, S.d_q + l0,
+                                  S.d_t + l0, l1 - l0, hipMemcpyDeviceToDevice))
+                        return false;
+                }
+                return true;
+            }
+            // anything but plain rows: the host's field-rule parser reads the text (copied back for this piece only)
+            ++host_pieces;
+            if (hipMemcpyAsync(S.h_text, S.d_text + sum.text_off, sum.text_len, hipMemcpyDeviceToHost, pstream) != hipSuccess ||
+                hipStreamSynchronize(pstream) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(FTK_ERR_HIP, "cannot copy a text piece back");
+            }
+            std::vector<Run> runs;
+            const char* tb = (const char*)S.h_text;
+            parse_text_parallel(tb, tb + sum.text_len, bed6, has_only ? only.c_str() : nullptr, n_threads, &runs);
+            for (auto& r : runs)
+                if (!take_run(r.name, r.c.start.data(), r.c.end.data(), r.c.mapq.data(), r.c.strand.data(), r.c.start.size(),
+                              hipMemcpyHostToDevice))
+                    return false;
+            return true;
+        }
         const char* b = (const char*)S.h_text + S.off;
         const bool plain = !S.host_only && !sum.overflow && sum.n_bad == 0 && sum.n_runs >= 1 && sum.n_runs <= (unsigned)ftk::kTextMaxRuns &&
                            sum.n_lines <= S.max_lines;
@@ -2147,6 +2237,95 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         if (!whole_blocks(buf.data(), n, eof, &blocks, &used, &total)) return fail(FTK_ERR_FORMAT, "corrupt BGZF block");
         DevSet& S = sets[k & 1];
         if (S.pending && !collect(S)) return false;
+        if (dev_inflate && total + ftk::kTextCarryMax + 64 < (size_t(1) << 32)) {
+            // ---- the piece is inflated ON THE DEVICE: compressed bytes up, one wave per BGZF block, then the carry /
+            // line-end set-up and the row parser on the text where it lies; the host never sees the text
+            if (!layout_known) {  // BED6 or not: the first data row, from the first blocks inflated here
+                std::vector<uint8_t> head;
+                size_t nb = 0, bytes = 0;
+                while (nb < blocks.size() && bytes < (size_t(1) << 18)) bytes += blocks[nb++].out_len;
+                head.resize(bytes + 1);
+                std::vector<Block> first(blocks.begin(), blocks.begin() + nb);
+                if (nb && inflate_block_list(buf.data(), first, n_threads, head.data()) != FTK_OK)
+                    return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+                const char* q = (const char*)head.data() + std::min(first_skip, bytes);
+                const char* e = (const char*)head.data() + bytes;
+                while (q < e) {
+                    const char* nl = (const char*)memchr(q, '\n', (size_t)(e - q));
+                    const char* le = nl ? nl : e;
+                    if (le > q && *q != '#' && (nl || eof)) {
+                        int tabs = 0;
+                        for (const char* x = q; x < le; ++x) tabs += (*x == '\t');
+                        bed6 = (tabs + 1) > 5;
+                        layout_known = true;
+                        break;
+                    }
+                    if (!nl) break;
+                    q = nl + 1;
+                }
+            }
+            if (!S.ensure(ftk::kTextCarryMax + total + 64) || !S.ensure_inflate(used, blocks.size()))
+                return fail(FTK_ERR_OOM, "out of page-locked / device memory for the text piece");
+            clk.lap(5);
+            {
+                const int nt = std::max(1, std::min(n_threads, (int)(used >> 20) + 1));
+                const uint8_t* src = buf.data();
+                uint8_t* dst = S.h_text;
+                parallel_run(nt, [&](int t) {
+                    const size_t a = used * (size_t)t / nt, b2 = used * (size_t)(t + 1) / nt;
+                    memcpy(dst + a, src + a, b2 - a);
+                });
+            }
+            for (size_t i = 0; i < blocks.size(); ++i) {
+                const Block& bl = blocks[i];
+                S.h_tab[i] = {(uint32_t)bl.in_off, (uint32_t)bl.in_len, (uint32_t)(ftk::kTextCarryMax + bl.out_off), (uint32_t)bl.out_len};
+                const uint8_t* tr = buf.data() + bl.in_off + bl.in_len;
+                S.want_crc[i] = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+            }
+            S.n_tab = blocks.size();
+            S.inflated = true;
+            S.host_only = false;
+            DevSet* P = (k > 0 && sets[(k - 1) & 1].inflated) ? &sets[(k - 1) & 1] : nullptr;
+            bool ok = hipMemsetAsync(S.d_sum, 0, sizeof(ftk::TextSummary), pstream) == hipSuccess &&
+                      hipMemsetAsync(S.d_ist, 0, sizeof(ftk::InflateStatus), pstream) == hipSuccess &&
+                      (used == 0 || hipMemcpyAsync(S.d_comp, S.h_text, used, hipMemcpyHostToDevice, pstream) == hipSuccess) &&
+                      (blocks.empty() || hipMemcpyAsync(S.d_tab, S.h_tab, blocks.size() * sizeof(ftk::InflateBlock),
+                                                        hipMemcpyHostToDevice, pstream) == hipSuccess);
+            if (ok) {
+                ftk::inflate_launch(pstream, S.d_comp, S.d_tab, (int)blocks.size(), S.d_text, S.d_ist, S.d_crc);
+                ftk::textparse_launch_inflated(pstream, S.d_text, ftk::kTextCarryMax, (uint32_t)total, P ? P->d_text : nullptr,
+                                               P ? P->d_sum : nullptr, (uint32_t)std::min<size_t>(first_skip, total), eof, bed6,
+                                               S.d_blocks, S.d_lines, S.max_lines, S.d_s, S.d_e, S.d_q, S.d_t, S.d_sum);
+                ok = hipGetLastError() == hipSuccess &&
+                     hipMemcpyAsync(S.h_sum, S.d_sum, sizeof(ftk::TextSummary), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
+                     hipMemcpyAsync(S.h_ist, S.d_ist, sizeof(ftk::InflateStatus), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
+                     (blocks.empty() || hipMemcpyAsync(S.h_crc, S.d_crc, blocks.size() * 4, hipMemcpyDeviceToHost, pstream) == hipSuccess) &&
+                     hipEventRecord(S.done, pstream) == hipSuccess;
+            }
+            if (!ok) {
+                (void)hipGetLastError();
+                return fail(FTK_ERR_HIP, "cannot launch the device inflate / row parser");
+            }
+            first_skip = 0;
+            S.pending = true;
+            clk.lap(1);
+            if (prev && prev->pending && !collect(*prev)) return false;
+            clk.lap(3);
+            prev = &S;
+            if (eof) break;
+            const size_t raw_carry_d = n - used;
+            if (raw_carry_d) memmove(buf.data(), buf.data() + used, raw_carry_d);
+            clk.lap(5);
+            n = fill(buf, raw_carry_d);
+            clk.lap(0);
+            eof = n - raw_carry_d < kStreamPiece;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (stop) return false;
+            }
+            continue;
+        }
+        S.inflated = false;
         if (!S.ensure(carry + total + 2)) return fail(FTK_ERR_OOM, "out of page-locked / device memory for the text piece");
         if (carry) memcpy(S.h_text, carry_src, carry);
         clk.lap(5);

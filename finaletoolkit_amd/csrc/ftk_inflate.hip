@@ -1,0 +1,489 @@
+// DEFLATE (RFC 1951) decoder for BGZF blocks on gfx950: one wavefront per block (see ftk_inflate.h).
+//
+// Shape of the work.  A BGZF block is an independent DEFLATE stream of at most 64 KB of data; a 48 MB piece of a
+// fragment file holds ~3 000 of them.  Inside a block the Huffman decoding is a serial chain (the position of a
+// code is only known once the previous one has been decoded), so it runs as UNIFORM work of the wave: the bit
+// buffer, positions and table entries live in scalar registers (values fetched from LDS / VGPRs come back through
+// v_readfirstlane / v_readlane), and the 64 lanes are used where there is width: building the decoding tables
+// (ballot-ranked canonical codes, one symbol per lane), the LZ77 copies (up to 64 bytes per step), the input
+// prefetch (256 bytes of the payload per vector load, handed to the bit buffer word by word with v_readlane) and
+// the write-behind of finished output.  The chip is filled by running thousands of such waves side by side:
+// 12 KB of LDS per wave -> 13 waves per CU.
+//
+// Output window.  The last 8 KB of a block's output live in an LDS ring indexed by the absolute output address,
+// so nearly every match (fragment rows repeat the previous line, 30-60 bytes back) is an LDS-to-LDS copy;
+// finished 2 KB granules are streamed to HBM with 16-byte stores as soon as the write position passes them, and a
+// match that reaches further back than the ring reads the bytes it needs from there (they were stored at least
+// 5 KB of output earlier).
+#include <hip/hip_runtime.h>
+
+#include "ftk_inflate.h"
+
+namespace ftk {
+namespace {
+
+#ifndef FTK_INFLATE_RING
+#define FTK_INFLATE_RING 4096
+#endif
+#ifndef FTK_INFLATE_ROOT
+#define FTK_INFLATE_ROOT 10
+#endif
+constexpr int kRing = FTK_INFLATE_RING, kRingMask = kRing - 1;
+constexpr int kGranShift = kRing >= 8192 ? 11 : 10, kGran = 1 << kGranShift;  // write-behind granule: a quarter of the ring
+constexpr int kLitRoot = FTK_INFLATE_ROOT, kDistRoot = 9, kPreRoot = 7;
+constexpr int kFarDist = kRing - 258 - 64;    // matches further back than this read from HBM
+
+struct __align__(16) WaveLds {
+    uint8_t ring[kRing];
+    uint32_t pair[1 << kLitRoot];    // the look-up of the symbol loop: up to TWO literals per entry (see build_pairs);
+                                     // its first half doubles as the one-symbol table (uint16: symbol << 4 | code
+                                     // length, 0 = longer than the root) while a block's tables are being built
+    uint16_t dist[1 << kDistRoot];
+    uint16_t pre[1 << kPreRoot];
+    uint16_t sorted[2][288];         // symbols in canonical order (by length, then value): [0] lit/len, [1] distance
+    uint16_t cnt[2][16];             // symbols per code length
+    uint16_t next_code[16], offs[16];
+    uint8_t lens[320 + 19];
+};
+
+#define UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
+
+// Lane `idx` of `old` becomes `value` (both uniform): a compare and a select on the vector unit -- which the
+// decode loop, all scalar otherwise, leaves idle (v_writelane_b32 would take a scalar move to M0 as well: two
+// scalar registers exceed the constant bus).
+__device__ __forceinline__ int write_lane(int old, int value, int idx, int lane) { return lane == idx ? value : old; }
+
+struct Bits {
+    const uint32_t* w;  // the compressed buffer as aligned words
+    uint32_t end_word;  // first word index behind the payload
+    uint32_t widx;      // next word to append
+    uint32_t cbase;     // word index held by lane 0 of `cache`
+    uint32_t cache;     // per lane: w[cbase + lane]
+    uint64_t buf;
+    int cnt;
+
+    __device__ __forceinline__ void load_cache(int lane) {
+        const uint32_t i = cbase + (uint32_t)lane;
+        cache = i < end_word ? w[i] : 0u;
+    }
+    __device__ __forceinline__ void refill(int lane) {  // afterwards at least 32 valid bits
+        if (cnt < 32) {
+            if (widx - cbase >= 64u) {
+                cbase = widx;
+                load_cache(lane);
+            }
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)cache, (int)(widx - cbase));
+            ++widx;
+            buf |= (uint64_t)v << cnt;
+            cnt += 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)buf & ((1u << n) - 1u); }
+    __device__ __forceinline__ void drop(int n) { buf >>= n; cnt -= n; }
+    __device__ __forceinline__ uint32_t take(int n) { const uint32_t v = peek(n); drop(n); return v; }
+};
+
+// Canonical Huffman decoding tables from code lengths lens[0, n) (in LDS): `table` (1 << root entries) resolves
+// codes up to `root` bits in one look-up; `sorted` / `cnt` serve the bit-by-bit path for longer ones.  Returns
+// false for an over-subscribed set of lengths.  Lane-parallel: one symbol per lane, ranks among equal lengths from
+// ballots.
+__device__ __forceinline__ bool build_table(WaveLds& L, const uint8_t* lens, int n, int root, uint16_t* table, int which, int lane) {
+    const int size = 1 << root;
+    for (int i = lane; i < size; i += 64) table[i] = 0;
+    int count[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) count[l] = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int sym = base + lane;
+        const int l = sym < n ? lens[sym] : 0;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) count[k] += __popcll(__ballot(l == k));
+    }
+    int left = 1, code = 0, off = 0;
+    bool ok = true;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        left = (left << 1) - count[k];
+        ok = ok && left >= 0;
+        code = (code + count[k - 1]) << 1;  // count[0] is 0 here
+        if (lane == 0) {
+            L.next_code[k] = (uint16_t)code;
+            L.offs[k] = (uint16_t)off;
+            L.cnt[which][k] = (uint16_t)count[k];
+        }
+        off += count[k];
+    }
+    if (!ok) return false;
+    int run[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) run[l] = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = 0; base < n; base += 64) {
+        const int sym = base + lane;
+        const int l = sym < n ? lens[sym] : 0;
+        int rank = 0;
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            const unsigned long long m = __ballot(l == k);
+            if (l == k) rank = run[k] + __popcll(m & lt);
+            run[k] += __popcll(m);
+        }
+        if (l) {
+            const unsigned c = (unsigned)L.next_code[l] + (unsigned)rank;
+            L.sorted[which][L.offs[l] + rank] = (uint16_t)sym;
+            if (l <= root) {
+                const unsigned rev = __brev(c) >> (32 - l);  // codes are packed most significant bit first
+                const uint16_t e = (uint16_t)((sym << 4) | l);
+                for (unsigned k = rev; k < (unsigned)size; k += 1u << l) table[k] = e;
+            }
+        }
+    }
+    return true;
+}
+
+// The symbol loop's table.  The decode is bound by instruction issue (a wave issues one instruction every four
+// cycles, and the chain per symbol is look-up, classify, consume, store), so the table resolves as much as 11
+// bits can hold in ONE look-up: entry = total bits | kind << 5 | a << 8 | b << 20 with
+//   kind 2: two literals a, b (both codes fit in the 11 bits: the common case for text, whose frequent
+//           characters have 4-6 bit codes);  kind 1: one literal a;
+//   kind 0: a = a length symbol or end-of-block (256..285); entry 0: a code longer than 11 bits (or none).
+__device__ __forceinline__ void build_pairs(WaveLds& L, int lane) {
+    constexpr int size = 1 << kLitRoot;
+    const uint16_t* one = reinterpret_cast<const uint16_t*>(L.pair);  // the one-symbol table, converted in place:
+    // entry e of the pair table covers one-symbol entries 2e and 2e+1, and needs entries e and e >> l1 <= e / 2,
+    // so going down from the top no step overwrites what a later one reads (within a step every lane has read
+    // before any lane writes)
+    for (int base = size - 64; base >= 0; base -= 64) {
+        const int e = base + lane;
+        const unsigned t = one[e];
+        const unsigned l1 = t & 15u, s1 = t >> 4;
+        unsigned v = 0;
+        if (l1) {
+            if (s1 >= 256u) v = l1 | (s1 << 8);
+            else {
+                v = l1 | (1u << 5) | (s1 << 8);
+                const unsigned t2 = one[e >> l1];  // the bits behind the first code, zero-extended: valid for a code
+                const unsigned l2 = t2 & 15u, s2 = t2 >> 4;  // that fits into what is left of the root bits
+                if (l2 && l1 + l2 <= (unsigned)kLitRoot && s2 < 256u) v = (l1 + l2) | (2u << 5) | (s1 << 8) | (s2 << 20);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        L.pair[e] = v;
+    }
+}
+
+// one code from the bit buffer (>= 15 valid bits), length by length (codes longer than a table's root)
+__device__ __forceinline__ int decode_long(const WaveLds& L, Bits& b, int which) {
+    unsigned v = (unsigned)b.buf;
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= 15; ++len) {
+        code |= (int)(v & 1u);
+        v >>= 1;
+        const int count = UNI(L.cnt[which][len]);
+        if (code - count < first) {
+            b.drop(len);
+            return UNI(L.sorted[which][index + (code - first)]);
+        }
+        index += count;
+        first = (first + count) << 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+// the same through a one-symbol table first
+__device__ __forceinline__ int decode_sym(const WaveLds& L, Bits& b, const uint16_t* table, int root, int which) {
+    const int e = UNI(table[b.peek(root)]);
+    const int l = e & 15;
+    if (l) {
+        b.drop(l);
+        return e >> 4;
+    }
+    return decode_long(L, b, which);
+}
+
+__global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp,
+                                                          const InflateBlock* __restrict__ tab, int n_blocks,
+                                                          uint8_t* __restrict__ out, InflateStatus* __restrict__ status) {
+    __shared__ WaveLds L;
+    const int lane = threadIdx.x;
+    const int blk = blockIdx.x;
+    if (blk >= n_blocks) return;
+    const uint32_t in_off = tab[blk].in_off, in_len = tab[blk].in_len;
+    const uint32_t out_off = tab[blk].out_off, out_len = tab[blk].out_len;
+    Bits b;
+    b.w = reinterpret_cast<const uint32_t*>(comp);
+    b.end_word = (in_off + in_len + 3u) >> 2;
+    b.widx = in_off >> 2;
+    b.cbase = b.widx;
+    b.load_cache(lane);
+    b.buf = 0;
+    b.cnt = 0;
+    b.refill(lane);
+    b.drop((int)(in_off & 3u) * 8);
+    uint32_t A = out_off;                 // absolute address of the next output byte
+    const uint32_t A_end = out_off + out_len;
+    unsigned err = kInflateOk;
+    bool final_seen = false;
+
+    // write-behind: granule g = absolute [g * kGran, (g + 1) * kGran), clipped to this block's range
+    auto flush = [&](uint32_t g) {
+        const uint32_t a0 = g << kGranShift;
+        if (a0 >= out_off && a0 + kGran <= A_end) {
+#pragma unroll
+            for (int h = 0; h < kGran / 1024; ++h) {
+                const uint32_t a = a0 + (uint32_t)h * 1024u + (uint32_t)lane * 16u;
+                *reinterpret_cast<uint4*>(out + a) = *reinterpret_cast<const uint4*>(&L.ring[a & kRingMask]);
+            }
+        } else {
+            for (uint32_t a = a0 + (uint32_t)lane; a < a0 + kGran; a += 64)
+                if (a >= out_off && a < A_end) out[a] = L.ring[a & kRingMask];
+        }
+    };
+
+    while (!final_seen && err == kInflateOk) {
+        b.refill(lane);
+        final_seen = b.take(1) != 0;
+        const unsigned type = b.take(2);
+        if (type == 0) {  // stored: to the byte boundary, LEN, NLEN, LEN bytes
+            b.drop(b.cnt & 7);
+            b.refill(lane);
+            const unsigned len = b.take(16);
+            b.refill(lane);
+            const unsigned nlen = b.take(16);
+            if ((len ^ nlen) != 0xffffu) { err = kInflateBadStored; break; }
+            if (A + len > A_end) { err = kInflateOverrun; break; }
+            for (unsigned k = 0; k < len; ++k) {
+                b.refill(lane);
+                const unsigned v = b.take(8);
+                if (lane == 0) L.ring[A & kRingMask] = (uint8_t)v;
+                ++A;
+                if ((A & (kGran - 1)) == 0) flush((A >> kGranShift) - 1);
+            }
+            continue;
+        }
+        if (type == 3) { err = kInflateBadBlockType; break; }
+        int hlit = 288, hdist = 30;
+        if (type == 1) {  // fixed code (RFC 1951 3.2.6)
+            for (int i = lane; i < 288; i += 64) L.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+            if (lane < 30) L.lens[288 + lane] = 5;
+        } else {          // dynamic code: the code lengths themselves are Huffman coded (3.2.7)
+            hlit = (int)b.take(5) + 257;
+            hdist = (int)b.take(5) + 1;
+            const int hclen = (int)b.take(4) + 4;
+            if (hlit > 286 || hdist > 30) { err = kInflateBadLengths; break; }
+            if (lane < 19) L.lens[320 + lane] = 0;
+            for (int i = 0; i < hclen; ++i) {
+                b.refill(lane);
+                const unsigned v = b.take(3);
+                // order of the code-length code lengths: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+                const unsigned long long order = 0xf1e2d3c4b5a69780ull;  // entries 3..18, one nibble each, lowest first
+                const int sym = i < 3 ? 16 + i : (int)((order >> (4 * (i - 3))) & 15ull);
+                if (lane == 0) L.lens[320 + sym] = (uint8_t)v;
+            }
+            if (!build_table(L, &L.lens[320], 19, kPreRoot, L.pre, 0, lane)) { err = kInflateBadLengths; break; }
+            const int total = hlit + hdist;
+            int i = 0, prev = 0;
+            while (i < total && err == kInflateOk) {
+                b.refill(lane);
+                const int e = UNI(L.pre[b.peek(kPreRoot)]);
+                const int l = e & 15, s = e >> 4;
+                if (l == 0) { err = kInflateBadSymbol; break; }
+                b.drop(l);
+                if (s < 16) {
+                    if (lane == 0) L.lens[i] = (uint8_t)s;
+                    prev = s;
+                    ++i;
+                    continue;
+                }
+                int rep, val = 0;
+                if (s == 16) {
+                    if (i == 0) { err = kInflateBadLengths; break; }
+                    rep = 3 + (int)b.take(2);
+                    val = prev;
+                } else if (s == 17) {
+                    rep = 3 + (int)b.take(3);
+                } else {
+                    rep = 11 + (int)b.take(7);
+                }
+                if (i + rep > total) { err = kInflateBadLengths; break; }
+                for (int k = lane; k < rep; k += 64) L.lens[i + k] = (uint8_t)val;
+                i += rep;
+                prev = val;
+            }
+            if (err != kInflateOk) break;
+            if (UNI(L.lens[256]) == 0) { err = kInflateBadLengths; break; }
+            // distance lengths behind the literal / length ones, as build_table wants them: contiguous
+            if (hlit != 288)
+                for (int k = lane; k < hdist; k += 64) L.lens[288 + k] = L.lens[hlit + k];
+        }
+        if (!build_table(L, L.lens, hlit, kLitRoot, reinterpret_cast<uint16_t*>(L.pair), 0, lane) ||
+            !build_table(L, &L.lens[288], hdist, kDistRoot, L.dist, 1, lane)) {
+            err = kInflateBadLengths;
+            break;
+        }
+        build_pairs(L, lane);
+        // ---- the symbols of this DEFLATE block --------------------------------------------------------
+        // Literals collect in a register (lane k = k-th pending byte, v_writelane) and go to the ring 63-64 at a time.
+        int vlit = 0, nlit = 0;
+        auto put_literals = [&]() {
+            if (A + (uint32_t)nlit > A_end) { err = kInflateOverrun; nlit = 0; return; }
+            if (lane < nlit) L.ring[(A + (uint32_t)lane) & kRingMask] = (uint8_t)vlit;
+            const uint32_t A0 = A;
+            A += (uint32_t)nlit;
+            nlit = 0;
+            if ((A >> kGranShift) != (A0 >> kGranShift)) flush(A0 >> kGranShift);
+        };
+        for (;;) {
+            b.refill(lane);
+            const unsigned e = (unsigned)UNI(L.pair[b.peek(kLitRoot)]);
+            const unsigned kind = (e >> 5) & 3u;
+            if (kind) {
+                b.drop((int)(e & 31u));
+                vlit = write_lane(vlit, (int)((e >> 8) & 255u), nlit, lane);
+                if (kind == 2u) vlit = write_lane(vlit, (int)(e >> 20), nlit + 1, lane);
+                nlit += (int)kind;
+                if (nlit >= 63) {
+                    put_literals();
+                    if (err != kInflateOk) break;
+                }
+                continue;
+            }
+            int sym;
+            if (e) {
+                b.drop((int)(e & 31u));
+                sym = (int)(e >> 8);
+            } else {
+                sym = decode_long(L, b, 0);  // a code longer than the root: bit by bit
+                if (sym < 0) { err = kInflateBadSymbol; break; }
+                if (sym < 256) {
+                    vlit = write_lane(vlit, sym, nlit, lane);
+                    if (++nlit >= 63) {
+                        put_literals();
+                        if (err != kInflateOk) break;
+                    }
+                    continue;
+                }
+            }
+            if (nlit) {
+                put_literals();
+                if (err != kInflateOk) break;
+            }
+            if (sym == 256) break;
+            const int ls = sym - 257;
+            if (ls > 28) { err = kInflateBadSymbol; break; }
+            int len;
+            if (ls < 8) len = ls + 3;
+            else if (ls == 28) len = 258;
+            else {
+                const int eb = (ls >> 2) - 1;
+                len = ((4 + (ls & 3)) << eb) + 3 + (int)b.take(eb);
+            }
+            b.refill(lane);
+            const int ds = decode_sym(L, b, L.dist, kDistRoot, 1);
+            if (ds < 0 || ds > 29) { err = kInflateBadSymbol; break; }
+            int d;
+            if (ds < 4) d = ds + 1;
+            else {
+                const int eb = (ds >> 1) - 1;
+                d = ((2 + (ds & 1)) << eb) + 1 + (int)b.take(eb);
+            }
+            if ((uint32_t)d > A - out_off) { err = kInflateBadDistance; break; }
+            if (A + (uint32_t)len > A_end) { err = kInflateOverrun; break; }
+            const uint32_t A0 = A;
+            if (d <= kFarDist) {
+                // LDS to LDS.  The pattern has period d: after `done` bytes, [A0 - d, A0 + done) is valid, so a
+                // step may copy up to D bytes from D back for any multiple D of d with D <= done + d; D doubles.
+                int done = 0, D = d;
+                while (done < len) {
+                    const int n = min(min(len - done, D), 64);
+                    if (lane < n) {
+                        const uint32_t a = A0 + (uint32_t)(done + lane);
+                        L.ring[a & kRingMask] = L.ring[(a - (uint32_t)D) & kRingMask];
+                    }
+                    done += n;
+                    if (2 * D <= done + d) D *= 2;
+                }
+            } else {
+                // further back than the ring: those bytes went to HBM at least 5 KB of output ago
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                for (int o = lane; o < len; o += 64) {
+                    const uint32_t a = A0 + (uint32_t)o;
+                    L.ring[a & kRingMask] = out[a - (uint32_t)d];
+                }
+            }
+            A = A0 + (uint32_t)len;
+            if ((A >> kGranShift) != (A0 >> kGranShift)) flush(A0 >> kGranShift);
+        }
+        if (nlit && err == kInflateOk) put_literals();
+    }
+    if (err == kInflateOk && A != A_end) err = kInflateShort;
+    // the unfinished granule
+    if ((A & (kGran - 1)) != 0 || A == out_off) flush(A >> kGranShift);
+    if (err != kInflateOk && lane == 0) {
+        if (atomicAdd(&status->n_bad, 1u) == 0) {
+            status->first_bad = (unsigned)blk;
+            status->reason = err;
+        }
+    }
+}
+
+// ---- CRC-32 of every block's data (the gzip trailer carries the expected value; the host compares) ----------
+// One wave per block: every lane takes a contiguous stripe of ceil(len / 64) bytes (bit-serial CRC: no table, the
+// pass is a rounding error next to the decode), then the 64 stripe CRCs are folded pairwise with
+// crc(A || B) = crc(A) * x^(8 |B|) mod P  xor  crc(B)   (polynomial arithmetic in the reflected representation).
+__device__ __forceinline__ uint32_t gf2_mul(uint32_t a, uint32_t b) {  // a * b mod P
+    uint32_t p = 0;
+    for (uint32_t m = 1u << 31; m; m >>= 1) {
+        if (a & m) p ^= b;
+        b = (b & 1u) ? (b >> 1) ^ 0xedb88320u : b >> 1;
+    }
+    return p;
+}
+
+__device__ __forceinline__ uint32_t gf2_x_pow_8n(uint32_t n) {  // x^(8 n) mod P
+    uint32_t p = 1u << 31;        // x^0
+    uint32_t sq = 0x00800000u;    // x^8
+    while (n) {
+        if (n & 1u) p = gf2_mul(sq, p);
+        sq = gf2_mul(sq, sq);
+        n >>= 1;
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(64) void bgzf_crc_kernel(const InflateBlock* __restrict__ tab, int n_blocks,
+                                                      const uint8_t* __restrict__ out, uint32_t* __restrict__ crc_out) {
+    const int lane = threadIdx.x, blk = blockIdx.x;
+    if (blk >= n_blocks) return;
+    const uint32_t base = tab[blk].out_off, len = tab[blk].out_len;
+    const uint32_t stripe = (len + 63u) / 64u;
+    const uint32_t a = min((uint32_t)lane * stripe, len), e = min(a + stripe, len);
+    uint32_t c = 0xffffffffu;
+    for (uint32_t i = a; i < e; ++i) {
+        c ^= out[base + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+    }
+    c = (e > a) ? ~c : 0u;      // CRC of the stripe (0 for an empty one: the neutral element of the fold)
+    uint32_t n = e - a;         // bytes this lane's value covers
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t c_r = __shfl_down(c, d, 64), n_r = __shfl_down(n, d, 64);
+        if ((lane & (2 * d - 1)) == 0) {
+            if (n_r) c = n ? (gf2_mul(gf2_x_pow_8n(n_r), c) ^ c_r) : c_r;
+            n += n_r;
+        }
+    }
+    if (lane == 0) crc_out[blk] = c;
+}
+
+}  // namespace
+
+void inflate_launch(hipStream_t s, const uint8_t* d_comp, const InflateBlock* d_tab, int n_blocks, uint8_t* d_out,
+                    InflateStatus* d_status, uint32_t* d_crc) {
+    if (n_blocks <= 0) return;
+    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(n_blocks), dim3(64), 0, s, d_comp, d_tab, n_blocks, d_out, d_status);
+    if (d_crc) hipLaunchKernelGGL(bgzf_crc_kernel, dim3(n_blocks), dim3(64), 0, s, d_tab, n_blocks, d_out, d_crc);
+}
+
+}  // namespace ftk

@@ -20,6 +20,20 @@ constexpr int kT = 256;  // threads per block of the newline kernels
 constexpr int kB = 16;   // bytes per thread
 static_assert(kT * kB == kTextBlockBytes, "block geometry");
 
+// The range a kernel works on: its arguments, or (device-inflated pieces) the one the set-up kernel recorded in the
+// summary.  The range then starts at any byte: the kernels work from the 16-byte boundary below it (`lead` bytes
+// earlier) and ignore line ends in front of the first line.
+struct Range {
+    const uint8_t* text;
+    size_t n;
+    unsigned lead;
+};
+__device__ __forceinline__ Range range_of(const uint8_t* text, size_t n, const TextSummary* ind) {
+    if (!ind) return {text, n, 0u};
+    const unsigned off = ind->text_off, lead = off & 15u;
+    return {text + (off - lead), ind->text_len ? (size_t)ind->text_len + lead : 0, lead};
+}
+
 __device__ __forceinline__ unsigned nl_mask16(const uint8_t* __restrict__ text, size_t off, size_t n) {
     unsigned m = 0;
     if (off + kB <= n) {
@@ -53,12 +67,17 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
     return v;
 }
 
-__global__ __launch_bounds__(kT) void nl_count_kernel(const uint8_t* __restrict__ text, size_t n,
-                                                      uint32_t* __restrict__ block_count) {
+__global__ __launch_bounds__(kT) void nl_count_kernel(const uint8_t* __restrict__ text_, size_t n_,
+                                                      uint32_t* __restrict__ block_count, const TextSummary* ind) {
     __shared__ unsigned part[kT / 64];
+    const Range R = range_of(text_, n_, ind);
+    const uint8_t* __restrict__ text = R.text;
+    const size_t n = R.n;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t off = ((size_t)blockIdx.x * kT + tid) * kB;
-    unsigned c = off < n ? __popc(nl_mask16(text, off, n)) : 0;
+    unsigned m0 = off < n ? nl_mask16(text, off, n) : 0;
+    if (off == 0) m0 &= ~0u << R.lead;
+    unsigned c = __popc(m0);
     c = wave_sum(c);
     if (lane == 0) part[wv] = c;
     __syncthreads();
@@ -71,9 +90,14 @@ __global__ __launch_bounds__(kT) void nl_count_kernel(const uint8_t* __restrict_
 }
 
 // exclusive scan of block_count[0, n_blocks) in place; block_count[n_blocks] = total = sum->n_lines
-__global__ __launch_bounds__(1024) void nl_scan_kernel(uint32_t* __restrict__ block_count, int n_blocks,
-                                                       TextSummary* __restrict__ sum) {
+__global__ __launch_bounds__(1024) void nl_scan_kernel(uint32_t* __restrict__ block_count, int n_blocks_,
+                                                       TextSummary* __restrict__ sum, int indirect) {
     __shared__ unsigned wave_tot[16];
+    int n_blocks = n_blocks_;
+    if (indirect) {
+        const Range R = range_of(nullptr, 0, sum);
+        n_blocks = (int)((R.n + kTextBlockBytes - 1) / kTextBlockBytes);
+    }
     __shared__ unsigned base_of_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int per = (n_blocks + 1023) / 1024;
@@ -98,13 +122,18 @@ __global__ __launch_bounds__(1024) void nl_scan_kernel(uint32_t* __restrict__ bl
     }
 }
 
-__global__ __launch_bounds__(kT) void nl_pos_kernel(const uint8_t* __restrict__ text, size_t n,
+__global__ __launch_bounds__(kT) void nl_pos_kernel(const uint8_t* __restrict__ text_, size_t n_,
                                                     const uint32_t* __restrict__ block_base,
-                                                    uint32_t* __restrict__ line_start, size_t max_lines) {
+                                                    uint32_t* __restrict__ line_start, size_t max_lines,
+                                                    const TextSummary* ind) {
     __shared__ unsigned wave_tot[kT / 64];
+    const Range R = range_of(text_, n_, ind);
+    const uint8_t* __restrict__ text = R.text;
+    const size_t n = R.n;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t off = ((size_t)blockIdx.x * kT + tid) * kB;
     unsigned m = off < n ? nl_mask16(text, off, n) : 0;
+    if (off == 0) m &= ~0u << R.lead;
     const unsigned c = __popc(m);
     const unsigned incl = wave_incl_scan(c, lane);
     if (lane == 63) wave_tot[wv] = incl;
@@ -112,7 +141,7 @@ __global__ __launch_bounds__(kT) void nl_pos_kernel(const uint8_t* __restrict__ 
     unsigned before = 0;
     for (int k = 0; k < wv; ++k) before += wave_tot[k];
     size_t idx = (size_t)block_base[blockIdx.x] + before + incl - c;  // newlines before this thread's bytes
-    if (blockIdx.x == 0 && tid == 0) line_start[0] = 0;
+    if (blockIdx.x == 0 && tid == 0) line_start[0] = R.lead;
     while (m) {
         const int j = __ffs(m) - 1;
         m &= m - 1;
@@ -139,11 +168,13 @@ __device__ __forceinline__ bool dev_digits(const uint8_t* __restrict__ t, uint32
 }
 
 // The same row the host's one-pass parser accepts (plain_row in ftk_decode.cpp), with any contig name.
-__global__ __launch_bounds__(256) void parse_rows_kernel(const uint8_t* __restrict__ t,
+__global__ __launch_bounds__(256) void parse_rows_kernel(const uint8_t* __restrict__ t_,
                                                          const uint32_t* __restrict__ line_start, size_t max_lines,
                                                          int bed6, int32_t* __restrict__ o_start,
                                                          int32_t* __restrict__ o_end, uint8_t* __restrict__ o_mapq,
-                                                         uint8_t* __restrict__ o_strand, TextSummary* __restrict__ sum) {
+                                                         uint8_t* __restrict__ o_strand, TextSummary* __restrict__ sum,
+                                                         int indirect) {
+    const uint8_t* __restrict__ t = indirect ? range_of(t_, 0, sum).text : t_;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long n_lines = sum->n_lines;
     if (n_lines > max_lines) {
@@ -198,6 +229,14 @@ __global__ __launch_bounds__(256) void parse_rows_kernel(const uint8_t* __restri
                     sum->run_line[slot] = (unsigned)i;
                     sum->run_off[slot] = b;
                 }
+                if (indirect) {  // the host has no copy of this text: hand it the name
+                    if (slot < (unsigned)kTextNamedRuns && name_len < (uint32_t)kTextNameBytes) {
+                        for (uint32_t k = 0; k < name_len; ++k) sum->run_name[slot][k] = t[b + k];
+                        sum->run_name[slot][name_len] = 0;
+                    } else {
+                        sum->name_overflow = 1;
+                    }
+                }
             }
         }
         bad = !ok;
@@ -206,19 +245,84 @@ __global__ __launch_bounds__(256) void parse_rows_kernel(const uint8_t* __restri
     if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&sum->n_bad, (unsigned long long)__popcll(mask));
 }
 
+// Device-inflated pieces: carry, skip, last line end (see textparse_launch_inflated).  One block.
+__global__ __launch_bounds__(256) void piece_setup_kernel(uint8_t* __restrict__ text, uint32_t data_off, uint32_t data_len,
+                                                          const uint8_t* __restrict__ prev_text,
+                                                          const TextSummary* __restrict__ prev_sum, uint32_t first_skip,
+                                                          int eof, TextSummary* __restrict__ sum) {
+    __shared__ unsigned best;
+    const int tid = threadIdx.x;
+    unsigned tail_prev = 0, prev_end = 0;
+    if (prev_sum) {
+        tail_prev = prev_sum->tail_len;
+        prev_end = prev_sum->text_off + prev_sum->text_len;
+    }
+    if (tail_prev > kTextCarryMax || tail_prev > data_off) {  // (the previous piece already said carry_overflow)
+        if (tid == 0) sum->carry_overflow = 1;
+        tail_prev = 0;
+    }
+    for (unsigned k = tid; k < tail_prev; k += 256) text[data_off - tail_prev + k] = prev_text[prev_end + k];
+    const unsigned off = data_off - tail_prev + (prev_sum ? 0u : min(first_skip, data_len));
+    unsigned end = data_off + data_len;
+    if (tid == 0) best = 0;  // position behind the last '\n' in [off, end), 0 = none
+    __syncthreads();
+    // the last line end lies within kTextCarryMax of the end, or the unfinished line is too long to carry
+    const unsigned lo = end - off > kTextCarryMax ? end - kTextCarryMax : off;
+    unsigned mine = 0;
+    for (unsigned p = lo + tid; p < end; p += 256)
+        if (text[p] == '\n') mine = p + 1;
+    atomicMax(&best, mine);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned last = best;
+        if (eof && end > off && last != end) {  // the file's last row has no line end: give it one (the buffer has the room)
+            text[end] = '\n';
+            last = ++end;
+        }
+        if (last == 0) {
+            sum->text_off = off;
+            sum->text_len = 0;
+            sum->tail_len = end - off;
+            if (end - off > kTextCarryMax) sum->carry_overflow = 1;
+        } else {
+            sum->text_off = off;
+            sum->text_len = last - off;
+            sum->tail_len = end - last;
+        }
+    }
+}
+
 }  // namespace
+
+void textparse_launch_inflated(hipStream_t s, uint8_t* d_text, uint32_t data_off, uint32_t data_len,
+                               const uint8_t* prev_text, const TextSummary* prev_sum, uint32_t first_skip, bool eof, bool bed6,
+                               uint32_t* d_block_count, uint32_t* d_line_start, size_t max_lines, int32_t* d_start,
+                               int32_t* d_end, uint8_t* d_mapq, uint8_t* d_strand, TextSummary* d_sum) {
+    hipLaunchKernelGGL(piece_setup_kernel, dim3(1), dim3(256), 0, s, d_text, data_off, data_len, prev_text, prev_sum,
+                       first_skip, eof ? 1 : 0, d_sum);
+    const size_t n_max = (size_t)kTextCarryMax + data_len + 32;  // the range is only known on the device: launch for the most
+    const int n_blocks = (int)((n_max + kTextBlockBytes - 1) / kTextBlockBytes);
+    hipLaunchKernelGGL(nl_count_kernel, dim3(n_blocks), dim3(kT), 0, s, d_text, (size_t)0, d_block_count, d_sum);
+    hipLaunchKernelGGL(nl_scan_kernel, dim3(1), dim3(1024), 0, s, d_block_count, n_blocks, d_sum, 1);
+    hipLaunchKernelGGL(nl_pos_kernel, dim3(n_blocks), dim3(kT), 0, s, d_text, (size_t)0, d_block_count, d_line_start, max_lines,
+                       d_sum);
+    const size_t row_blocks = (max_lines + 255) / 256;
+    hipLaunchKernelGGL(parse_rows_kernel, dim3((unsigned)row_blocks), dim3(256), 0, s, d_text, d_line_start, max_lines,
+                       bed6 ? 1 : 0, d_start, d_end, d_mapq, d_strand, d_sum, 1);
+}
 
 void textparse_launch(hipStream_t s, const uint8_t* d_text, size_t n, bool bed6, uint32_t* d_block_count,
                       uint32_t* d_line_start, size_t max_lines, int32_t* d_start, int32_t* d_end, uint8_t* d_mapq,
                       uint8_t* d_strand, TextSummary* d_sum) {
     if (n == 0) return;
     const int n_blocks = (int)((n + kTextBlockBytes - 1) / kTextBlockBytes);
-    hipLaunchKernelGGL(nl_count_kernel, dim3(n_blocks), dim3(kT), 0, s, d_text, n, d_block_count);
-    hipLaunchKernelGGL(nl_scan_kernel, dim3(1), dim3(1024), 0, s, d_block_count, n_blocks, d_sum);
-    hipLaunchKernelGGL(nl_pos_kernel, dim3(n_blocks), dim3(kT), 0, s, d_text, n, d_block_count, d_line_start, max_lines);
+    hipLaunchKernelGGL(nl_count_kernel, dim3(n_blocks), dim3(kT), 0, s, d_text, n, d_block_count, (const TextSummary*)nullptr);
+    hipLaunchKernelGGL(nl_scan_kernel, dim3(1), dim3(1024), 0, s, d_block_count, n_blocks, d_sum, 0);
+    hipLaunchKernelGGL(nl_pos_kernel, dim3(n_blocks), dim3(kT), 0, s, d_text, n, d_block_count, d_line_start, max_lines,
+                       (const TextSummary*)nullptr);
     const size_t row_blocks = (max_lines + 255) / 256;
     hipLaunchKernelGGL(parse_rows_kernel, dim3((unsigned)row_blocks), dim3(256), 0, s, d_text, d_line_start, max_lines,
-                       bed6 ? 1 : 0, d_start, d_end, d_mapq, d_strand, d_sum);
+                       bed6 ? 1 : 0, d_start, d_end, d_mapq, d_strand, d_sum, 0);
 }
 
 }  // namespace ftk

@@ -87,3 +87,52 @@ def synth_blacklist(contig_len, seed, n_regions):
     e = (s + rng.integers(200, 5000, n_regions)).astype(np.int32)
     order = np.lexsort((e, s))
     return s[order], e[order]
+
+
+def write_paired_bam(path, contig, size, depth, seed, read_len=50):
+    """Coordinate-sorted paired-end BAM, one pair per synthetic fragment (numpy-built fixed-size records,
+    BGZF blocks deflated by the library's writer).  Returns the decoder's expected columns: fragments in
+    start order with their read1 span."""
+    import os
+    import struct
+    from . import bgzf, writers
+    s, e, q, st = synth_contig(size, depth, seed)
+    e = np.maximum(e, s + read_len).astype(np.int32)
+    n = len(s)
+    ln = (e - s).astype(np.int64)
+    fwd = st == 1
+    r1_pos = np.where(fwd, s, e - read_len).astype(np.int64)
+    r2_pos = np.where(fwd, e - read_len, s).astype(np.int64)
+    rec = np.dtype([("block_size", "<i4"), ("ref", "<i4"), ("pos", "<i4"), ("l_name", "u1"), ("mapq", "u1"),
+                    ("bin", "<u2"), ("n_cigar", "<u2"), ("flag", "<u2"), ("l_seq", "<i4"), ("next_ref", "<i4"),
+                    ("next_pos", "<i4"), ("tlen", "<i4"), ("name", "S8"), ("cigar", "<u4"),
+                    ("seq", "u1", (read_len // 2,)), ("qual", "u1", (read_len,))])
+    a = np.zeros(2 * n, rec)
+    a["block_size"] = rec.itemsize - 4
+    a["l_name"], a["n_cigar"], a["l_seq"], a["cigar"] = 8, 1, read_len, read_len << 4
+    a["pos"][:n], a["pos"][n:] = r1_pos, r2_pos
+    a["next_pos"][:n], a["next_pos"][n:] = r2_pos, r1_pos
+    a["mapq"][:n] = a["mapq"][n:] = q
+    a["tlen"][:n], a["tlen"][n:] = np.where(fwd, ln, -ln), np.where(fwd, -ln, ln)
+    a["flag"][:n], a["flag"][n:] = np.where(fwd, 99, 83), np.where(fwd, 147, 163)
+    digits = (np.arange(n, dtype=np.int64)[:, None] // 10 ** np.arange(7, -1, -1, dtype=np.int64)[None, :] % 10 + 48).astype(np.uint8)
+    a["name"][:n] = a["name"][n:] = digits.view("S8")[:, 0]  # the pair's number, eight digits
+    rng = np.random.default_rng(seed)
+    a["seq"] = rng.integers(0, 256, (2 * n, read_len // 2), dtype=np.uint8)
+    lut = np.repeat(np.array([2, 11, 25, 37], np.uint8), [8, 18, 51, 179])  # 3 / 7 / 20 / 70 % of the qualities
+    a["qual"] = lut[rng.integers(0, 256, (2 * n, read_len), dtype=np.uint8)]
+    order = np.argsort(a["pos"], kind="stable")
+    a = a[order]
+    text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:%s\tLN:%d\n" % (contig.encode(), size)
+    head = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1)
+    head += struct.pack("<i", len(contig) + 1) + contig.encode() + b"\0" + struct.pack("<i", size)
+    offs = writers.bgzf_write(path, head, level=1, write_eof=False)
+    offs2 = writers.bgzf_write(path, a.tobytes(), level=1, append=True)
+    bgzf.write_index(str(path) + ".bai", True, [(contig, int(offs2[0]) << 16, int(offs2[-1]) << 16)])
+    # read1 records in file order -> stable sort by fragment start = the decoder's row order
+    is_r1 = order < n
+    file_rank = order[is_r1]                          # fragment index of every read1 record, in file order
+    by_start = np.argsort(s[file_rank], kind="stable")
+    rows = file_rank[by_start]
+    return dict(s=s[rows], e=e[rows], q=q[rows], st=st[rows], r1s=r1_pos[rows].astype(np.int32),
+                r1e=(r1_pos[rows] + read_len).astype(np.int32), n=n, file_bytes=os.path.getsize(path))

@@ -419,6 +419,15 @@ int ftk_motif_counts(ftk_ctx* ctx, int contig_id, int ref_id, const int32_t* w_s
                      uint32_t* counts_out /* [n_win][4^k] */, int64_t* nfrag_out /* [n_win] or NULL */,
                      int64_t* err_out /* [n_win] */);
 
+/* ---- BGZF inflate on the device -------------------------------------------------------------------
+ * The streaming decoder's host threads spend most of a fragment file's decode in DEFLATE; BGZF blocks are
+ * independent streams of at most 64 KB of data, decoded here one wavefront per block (csrc/ftk_inflate.hip).
+ * This entry point inflates a whole BGZF image (every block a BGZF member, as bgzip / htslib write them) held
+ * in host memory and returns the data in host memory: *n_out = sum of the blocks' ISIZE fields; FTK_ERR_INVALID
+ * when cap is too small (with *n_out set), FTK_ERR_FORMAT for anything that is not BGZF or does not decode to
+ * its ISIZE.  (The fragment stream uses the same kernel on device-resident pieces: FTK_DEVICE_INFLATE.) */
+int ftk_bgzf_inflate_device(ftk_ctx* ctx, const uint8_t* file_bytes, int64_t n, uint8_t* out, int64_t cap, int64_t* n_out);
+
 /* ---- output writers (host only; no ctx / GPU needed) ---------------------------------------------
  * The reference prints per-base results one Python f-string at a time (frag/_wps.py:208-229 WIG,
  * frag/_multi_wps.py:328-341 bedGraph) and hands bigWig entries to pyBigWig (:300-325).  These format the

@@ -10,9 +10,6 @@ Config 5: a 60x coordinate-sorted paired-end BAM of one contig through the strea
 (decode || H2D || kernels), then all features in one sweep -- coverage + 1001-bin length histogram + DELFI
 counts + per-base WPS, fused and as separate calls -- bit-exact against the oracle in read1-fetch mode
 (io/alignment.py:242-268)."""
-import os
-import struct
-
 import numpy as np
 import pandas
 import pytest
@@ -158,59 +155,11 @@ def test_config4_whole_contigs_against_the_oracle(engine, genome, contig):
 
 
 # ---- config 5 -------------------------------------------------------------------------------------------
-READ = 50
-
-
-def _write_bam_60x(path, contig, size, depth, seed):
-    """Coordinate-sorted paired-end BAM, one pair per synthetic fragment (numpy-built fixed-size records,
-    BGZF blocks deflated by the library's writer).  Returns the decoder's expected columns: fragments in
-    start order with their read1 span."""
-    from finaletoolkit_amd import bgzf, writers
-    s, e, q, st = synth.synth_contig(size, depth, seed)
-    e = np.maximum(e, s + READ).astype(np.int32)
-    n = len(s)
-    ln = (e - s).astype(np.int64)
-    fwd = st == 1
-    r1_pos = np.where(fwd, s, e - READ).astype(np.int64)
-    r2_pos = np.where(fwd, e - READ, s).astype(np.int64)
-    rec = np.dtype([("block_size", "<i4"), ("ref", "<i4"), ("pos", "<i4"), ("l_name", "u1"), ("mapq", "u1"),
-                    ("bin", "<u2"), ("n_cigar", "<u2"), ("flag", "<u2"), ("l_seq", "<i4"), ("next_ref", "<i4"),
-                    ("next_pos", "<i4"), ("tlen", "<i4"), ("name", "S8"), ("cigar", "<u4"),
-                    ("seq", "u1", (READ // 2,)), ("qual", "u1", (READ,))])
-    a = np.zeros(2 * n, rec)
-    a["block_size"] = rec.itemsize - 4
-    a["l_name"], a["n_cigar"], a["l_seq"], a["cigar"] = 8, 1, READ, READ << 4
-    a["pos"][:n], a["pos"][n:] = r1_pos, r2_pos
-    a["next_pos"][:n], a["next_pos"][n:] = r2_pos, r1_pos
-    a["mapq"][:n] = a["mapq"][n:] = q
-    a["tlen"][:n], a["tlen"][n:] = np.where(fwd, ln, -ln), np.where(fwd, -ln, ln)
-    a["flag"][:n], a["flag"][n:] = np.where(fwd, 99, 83), np.where(fwd, 147, 163)
-    a["name"][:n] = a["name"][n:] = np.char.zfill(np.arange(n).astype("U7"), 7).astype("S8")
-    rng = np.random.default_rng(seed)
-    a["seq"] = rng.integers(0, 256, (2 * n, READ // 2), dtype=np.uint8)
-    a["qual"] = rng.choice(np.array([2, 11, 25, 37], np.uint8), p=[0.03, 0.07, 0.2, 0.7], size=(2 * n, READ))
-    order = np.argsort(a["pos"], kind="stable")
-    a = a[order]
-    text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:%s\tLN:%d\n" % (contig.encode(), size)
-    head = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1)
-    head += struct.pack("<i", len(contig) + 1) + contig.encode() + b"\0" + struct.pack("<i", size)
-    offs = writers.bgzf_write(path, head, level=1, write_eof=False)
-    offs2 = writers.bgzf_write(path, a.tobytes(), level=1, append=True)
-    bgzf.write_index(str(path) + ".bai", True, [(contig, int(offs2[0]) << 16, int(offs2[-1]) << 16)])
-    # read1 records in file order -> stable sort by fragment start = the decoder's row order
-    is_r1 = order < n
-    file_rank = order[is_r1]                          # fragment index of every read1 record, in file order
-    by_start = np.argsort(s[file_rank], kind="stable")
-    rows = file_rank[by_start]
-    return dict(s=s[rows], e=e[rows], q=q[rows], st=st[rows], r1s=r1_pos[rows].astype(np.int32),
-                r1e=(r1_pos[rows] + READ).astype(np.int32), n=n, file_bytes=os.path.getsize(path))
-
-
 def test_config5_bam_60x_stream_all_features(engine, tmp_path):
     from finaletoolkit_amd import source
     size, contig = 24_000_000, "mid"
     bam = tmp_path / "mid60x.bam"
-    exp = _write_bam_60x(str(bam), contig, size, 60.0, 31)
+    exp = synth.write_paired_bam(str(bam), contig, size, 60.0, 31)
     assert exp["n"] == 4_800_000
     got_contigs = []
     for src, name in source.stream_source(str(bam)):

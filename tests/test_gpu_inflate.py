@@ -1,0 +1,134 @@
+"""GPU: DEFLATE on the device (csrc/ftk_inflate.hip, one wavefront per BGZF block) against zlib on the host:
+every block type (stored, fixed, dynamic), compressors and levels (zlib 0-9 with its strategies, libdeflate through
+the library's own BGZF writer), data shapes (fragment rows, incompressible bytes, long runs, matches that reach
+back further than the LDS window), block sizes from empty to 0xFF00, and damaged payloads (an error, not a hang)."""
+import ctypes as C
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from finaletoolkit_amd import _lib as L, bgzf, synth, writers
+
+pytestmark = pytest.mark.gpu
+
+
+def _member(data: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, extra=b"") -> bytes:
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    payload = c.compress(data) + c.flush()
+    xlen = 6 + len(extra)
+    bsize = 12 + xlen + len(payload) + 8
+    if bsize > 65536:
+        return None  # does not fit a BGZF block (expanding strategy on incompressible data)
+    head = struct.pack("<BBBBIBBH", 31, 139, 8, 4, 0, 0, 255, xlen) + extra + struct.pack("<BBHH", 66, 67, 2, bsize - 1)
+    return head + payload + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))
+
+
+def _inflate(engine, image: bytes):
+    lib = engine.lib
+    n_out = C.c_int64()
+    buf = np.zeros(1, np.uint8)
+    rc = lib.ftk_bgzf_inflate_device(engine.ctx, image, len(image), L.ptr(buf), 0, C.byref(n_out))
+    if rc == L.FTK_ERR_INVALID and n_out.value > 0:
+        buf = np.zeros(n_out.value, np.uint8)
+        rc = lib.ftk_bgzf_inflate_device(engine.ctx, image, len(image), L.ptr(buf), len(buf), C.byref(n_out))
+    return rc, buf[:n_out.value].tobytes()
+
+
+def _rows(n, seed):
+    s, e, q, st = synth.synth_contig(max(2000, n * 10), 30.0, seed)
+    return "".join(f"chr{seed}\t{a}\t{b}\t{m}\t{'+' if t else '-'}\n" for a, b, m, t in
+                   zip(s[:n].tolist(), e[:n].tolist(), q[:n].tolist(), st[:n].tolist())).encode()
+
+
+def test_block_types_levels_and_shapes(engine):
+    rng = np.random.default_rng(1)
+    text = _rows(2300, 3)[:0xFF00]
+    noise = rng.integers(0, 256, 0xFF00, dtype=np.uint8).tobytes()
+    far = rng.integers(0, 256, 30_000, dtype=np.uint8).tobytes()
+    shapes = {
+        "rows": text, "noise": noise, "zeros": bytes(0xFF00), "run_pattern": (b"abcdefg" * 10_000)[:0xFF00],
+        "far_matches": (far + far)[:0xFF00],            # distance 30 000: beyond the LDS ring
+        "mid_matches": (far[:7_000] + far[:7_000] * 8)[:0xFF00],  # distance 7 000..: ring edge
+        "one_byte": b"x", "empty": b"", "short": b"hello, hello, hello\n",
+        "digits": "".join(str(v) for v in rng.integers(0, 10 ** 9, 7000)).encode()[:0xFF00],
+    }
+    members, want = [], []
+    for name, data in shapes.items():
+        for level, strategy in [(0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY),
+                                (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE),
+                                (6, zlib.Z_FILTERED)]:
+            m = _member(data, level, strategy)
+            if m is not None:
+                members.append(m)
+                want.append(data)
+    members.append(_member(text[:5000], 6, extra=struct.pack("<BBH", 88, 89, 3) + b"abc"))  # another extra subfield first
+    want.append(text[:5000])
+    image = b"".join(members) + bgzf._EOF
+    rc, got = _inflate(engine, image)
+    assert rc == 0, engine.lib.ftk_last_error(engine.ctx)
+    assert got == b"".join(want)
+    # every member alone too (an error names the block)
+    for m, w in zip(members[:12], want[:12]):
+        rc, got = _inflate(engine, m)
+        assert rc == 0 and got == w
+
+
+def test_many_blocks_from_the_library_writer(engine, tmp_path):
+    """A 40 MB fragment text through the library's BGZF writer (libdeflate) at three levels: ~600 blocks each."""
+    rows = _rows(1_300_000, 5)
+    for level in (1, 6, 12):
+        p = tmp_path / f"l{level}.gz"
+        writers.bgzf_write(str(p), rows, level)
+        image = open(p, "rb").read()
+        rc, got = _inflate(engine, image)
+        assert rc == 0, engine.lib.ftk_last_error(engine.ctx)
+        assert got == rows, level
+
+
+def test_damaged_payloads_are_errors(engine):
+    text = _rows(2000, 9)
+    good = _member(text, 6)
+    rng = np.random.default_rng(2)
+    bad = 0
+    for k in range(40):
+        m = bytearray(good)
+        pos = int(rng.integers(18, len(m) - 8))
+        m[pos] ^= 1 << int(rng.integers(0, 8))
+        rc, got = _inflate(engine, bytes(m))
+        # a flipped bit may well decode to the right number of bytes (a different literal): the CRC catches those
+        assert rc == L.FTK_ERR_FORMAT, (k, pos)
+        bad += 1
+    assert bad == 40
+    m = bytearray(good)
+    m[-8] ^= 1  # the trailer's CRC itself
+    assert _inflate(engine, bytes(m))[0] == L.FTK_ERR_FORMAT
+    # wrong ISIZE, truncated payload, reserved block type
+    m = bytearray(good)
+    m[-4:] = struct.pack("<I", len(text) + 5)
+    assert _inflate(engine, bytes(m))[0] == L.FTK_ERR_FORMAT
+    m = bytearray(good)
+    m[-4:] = struct.pack("<I", len(text) - 5)
+    assert _inflate(engine, bytes(m))[0] == L.FTK_ERR_FORMAT
+    reserved = bytearray(_member(b"abc", 6))
+    reserved[18] |= 0x06  # BTYPE = 3
+    assert _inflate(engine, bytes(reserved))[0] == L.FTK_ERR_FORMAT
+    assert _inflate(engine, b"\x1f\x8b\x08\x00" + bytes(30))[0] == L.FTK_ERR_FORMAT  # gzip without the BGZF field
+
+
+@pytest.mark.parametrize("module", ["tests/test_gpu_device_parse.py", "tests/test_gpu_api_golden.py tests/test_gpu_cli.py"])
+def test_decoder_suites_with_device_inflate(module):
+    """The streaming decoder with FTK_DEVICE_INFLATE=1 (BGZF blocks inflated on the GPU, carry and line ends found
+    there, the host never sees the text): the decoder's own test suites -- fixtures, BED6, CRLF, no final newline,
+    contig runs inside pieces, host-parser fall-backs, index-driven single contigs, truncated / unsorted files, and
+    the reference-shaped API goldens on top -- must pass unchanged."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("FTK_DEVICE_INFLATE") == "1":
+        pytest.skip("this is the inner run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", *module.split()], cwd=root,
+                       env=dict(os.environ, FTK_DEVICE_INFLATE="1"), capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
