@@ -2131,8 +2131,9 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     bool have_cur = false;
     std::set<std::string> seen;
     size_t gpu_pieces = 0, host_pieces = 0;
-    // FTK_DEVICE_INFLATE=1: the BGZF blocks are inflated on the GPU too (ftk_inflate.hip); the host only reads the file
-    static const bool dev_inflate = getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) != 0;
+    // The BGZF blocks are inflated on the GPU too (ftk_inflate.hip): the host only reads the file and copies it into
+    // page-locked memory.  FTK_DEVICE_INFLATE=0 keeps the inflate on the host threads (libdeflate / zlib).
+    static const bool dev_inflate = !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
 
     // one contig run of a piece: n rows at the given column pointers (device or host)
     auto take_run = [&](const std::string& name, const int32_t* s0, const int32_t* e0, const uint8_t* q0, const uint8_t* t0,

@@ -115,8 +115,9 @@ def write_paired_bam(path, contig, size, depth, seed, read_len=50):
     a["mapq"][:n] = a["mapq"][n:] = q
     a["tlen"][:n], a["tlen"][n:] = np.where(fwd, ln, -ln), np.where(fwd, -ln, ln)
     a["flag"][:n], a["flag"][n:] = np.where(fwd, 99, 83), np.where(fwd, 147, 163)
-    digits = (np.arange(n, dtype=np.int64)[:, None] // 10 ** np.arange(7, -1, -1, dtype=np.int64)[None, :] % 10 + 48).astype(np.uint8)
-    a["name"][:n] = a["name"][n:] = digits.view("S8")[:, 0]  # the pair's number, eight digits
+    digits = np.zeros((n, 8), np.uint8)  # the pair's number as seven digits and the NUL that l_read_name counts
+    digits[:, :7] = np.arange(n, dtype=np.int64)[:, None] // 10 ** np.arange(6, -1, -1, dtype=np.int64)[None, :] % 10 + 48
+    a["name"][:n] = a["name"][n:] = digits.view("S8")[:, 0]
     rng = np.random.default_rng(seed)
     a["seq"] = rng.integers(0, 256, (2 * n, read_len // 2), dtype=np.uint8)
     lut = np.repeat(np.array([2, 11, 25, 37], np.uint8), [8, 18, 51, 179])  # 3 / 7 / 20 / 70 % of the qualities

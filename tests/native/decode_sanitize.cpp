@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "ftk.h"
+#include "ftk_inflate.h"
 #include "ftk_textparse.h"
 
 // The device row parser's kernels are not part of this host-only build; the harness opens host-mode
@@ -17,6 +18,15 @@ namespace ftk {
 void textparse_launch(hipStream_t, const uint8_t*, size_t, bool, uint32_t*, uint32_t*, size_t, int32_t*, int32_t*, uint8_t*,
                       uint8_t*, TextSummary*) {
     fprintf(stderr, "textparse_launch called in the sanitizer harness\n");
+    abort();
+}
+void textparse_launch_inflated(hipStream_t, uint8_t*, uint32_t, uint32_t, const uint8_t*, const TextSummary*, uint32_t, bool, bool,
+                               uint32_t*, uint32_t*, size_t, int32_t*, int32_t*, uint8_t*, uint8_t*, TextSummary*) {
+    fprintf(stderr, "textparse_launch_inflated called in the sanitizer harness\n");
+    abort();
+}
+void inflate_launch(hipStream_t, const uint8_t*, const InflateBlock*, int, uint8_t*, InflateStatus*, uint32_t*) {
+    fprintf(stderr, "inflate_launch called in the sanitizer harness\n");
     abort();
 }
 }  // namespace ftk
