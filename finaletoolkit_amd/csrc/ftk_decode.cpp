@@ -1961,6 +1961,7 @@ struct DevSet {
     bool pending = false;
     bool host_only = false;   // the piece was not sent to the device (4 GB or more: the kernels index with 32 bits)
     size_t off = 0, len = 0;  // the launched range of h_text (complete lines)
+    bool cut_tail = false;    // last piece of an index-driven read that may stop inside a row (ignore that one row)
     // pieces inflated on the device (FTK_DEVICE_INFLATE): compressed bytes, block table, per-block CRCs, status
     bool inflated = false;
     uint8_t* d_comp = nullptr;
@@ -2171,15 +2172,17 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
                 if (S.h_crc[i] != S.want_crc[i]) return fail(FTK_ERR_FORMAT, "BGZF block CRC mismatch (device inflate)");
             if (sum.carry_overflow) return fail(FTK_ERR_FORMAT, "a row longer than 64 KB");
             if (sum.text_len == 0) return true;
-            const bool plain_d = !sum.overflow && sum.n_bad == 0 && sum.n_runs >= 1 && sum.n_runs <= (unsigned)ftk::kTextNamedRuns &&
-                                 !sum.name_overflow && sum.n_lines <= S.max_lines;
+            const bool drop_last = S.cut_tail && sum.last_line_bad && sum.n_bad == 1;  // the row the read stopped in
+            const size_t n_rows = (size_t)sum.n_lines - (drop_last ? 1 : 0);
+            const bool plain_d = !sum.overflow && (sum.n_bad == 0 || drop_last) && sum.n_runs >= 1 &&
+                                 sum.n_runs <= (unsigned)ftk::kTextNamedRuns && !sum.name_overflow && sum.n_lines <= S.max_lines;
             if (plain_d) {
                 ++gpu_pieces;
                 std::vector<std::pair<unsigned, unsigned>> runs(sum.n_runs);  // (first line, slot)
                 for (unsigned r = 0; r < sum.n_runs; ++r) runs[r] = {sum.run_line[r], r};
                 std::sort(runs.begin(), runs.end());
                 for (size_t r = 0; r < runs.size(); ++r) {
-                    const size_t l0 = runs[r].first, l1 = r + 1 < runs.size() ? runs[r + 1].first : (size_t)sum.n_lines;
+                    const size_t l0 = runs[r].first, l1 = r + 1 < runs.size() ? runs[r + 1].first : n_rows;
                     if (!take_run(std::string((const char*)sum.run_name[runs[r].second]), S.d_s + l0, S.d_e + l0, S.d_q + l0,
                                   S.d_t + l0, l1 - l0, hipMemcpyDeviceToDevice))
                         return false;
@@ -2203,8 +2206,9 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             return true;
         }
         const char* b = (const char*)S.h_text + S.off;
-        const bool plain = !S.host_only && !sum.overflow && sum.n_bad == 0 && sum.n_runs >= 1 && sum.n_runs <= (unsigned)ftk::kTextMaxRuns &&
-                           sum.n_lines <= S.max_lines;
+        const bool drop_last_h = S.cut_tail && sum.last_line_bad && sum.n_bad == 1;  // the row an index-driven read stopped in
+        const bool plain = !S.host_only && !sum.overflow && (sum.n_bad == 0 || drop_last_h) && sum.n_runs >= 1 &&
+                           sum.n_runs <= (unsigned)ftk::kTextMaxRuns && sum.n_lines <= S.max_lines;
         if (plain) {
             ++gpu_pieces;
             std::vector<std::pair<unsigned, unsigned>> runs(sum.n_runs);
@@ -2214,7 +2218,8 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
                 const char* nb = b + runs[r].second;
                 const char* tab = (const char*)memchr(nb, '\t', S.len - runs[r].second);
                 if (!tab) return fail(FTK_ERR_FORMAT, "device row parser: run without a name");
-                const size_t l0 = runs[r].first, l1 = r + 1 < runs.size() ? runs[r + 1].first : (size_t)sum.n_lines;
+                const size_t l0 = runs[r].first,
+                             l1 = r + 1 < runs.size() ? runs[r + 1].first : (size_t)sum.n_lines - (drop_last_h ? 1 : 0);
                 if (!take_run(std::string(nb, (size_t)(tab - nb)), S.d_s + l0, S.d_e + l0, S.d_q + l0, S.d_t + l0, l1 - l0,
                               hipMemcpyDeviceToDevice))
                     return false;
@@ -2284,6 +2289,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
                 S.want_crc[i] = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
             }
             S.n_tab = blocks.size();
+            S.cut_tail = eof && partial_tail_ok;
             S.inflated = true;
             S.host_only = false;
             DevSet* P = (k > 0 && sets[(k - 1) & 1].inflated) ? &sets[(k - 1) & 1] : nullptr;
@@ -2363,6 +2369,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             last = e;
         }
         if (last > b) {
+            S.cut_tail = eof && partial_tail_ok;
             S.off = (size_t)(b - (char*)S.h_text);
             S.len = (size_t)(last - b);
             S.host_only = S.len >= (size_t(1) << 32) - 4096;

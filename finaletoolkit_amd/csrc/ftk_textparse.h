@@ -30,6 +30,8 @@ struct TextSummary {
     unsigned int text_off, text_len, tail_len;
     unsigned int name_overflow;   // a run beyond kTextNamedRuns or a name that does not fit: the host reads the text
     unsigned int carry_overflow;  // an unfinished line longer than kTextCarryMax
+    unsigned int last_line_bad;   // the piece's LAST line is one of the n_bad (a row cut off by an index-driven read
+                                  // that stops inside a block: the host may ignore exactly that one)
     unsigned char run_name[kTextNamedRuns][kTextNameBytes];  // NUL-terminated, indexed like run_line / run_off
 };
 

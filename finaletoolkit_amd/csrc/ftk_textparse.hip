@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void parse_rows_kernel(const uint8_t* __restri
             }
         }
         bad = !ok;
+        if (bad && i + 1 == n_lines) sum->last_line_bad = 1;
     }
     const unsigned long long mask = __ballot(bad);
     if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&sum->n_bad, (unsigned long long)__popcll(mask));

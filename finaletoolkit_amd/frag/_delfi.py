@@ -197,6 +197,8 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
         names = [p[0] for p in plan]
         weights = {p[0]: float(len(p[1])) for p in plan}
         owner = sharding.lpt_assign(weights, world)
+        if world == 1 and 2 * len(names) >= len(src.contigs):
+            src.load_all()  # most of the file is needed: one streaming pass instead of one index seek per contig
         local = {}
         for contig, starts, stops, arms, live, ok in plan:
             if owner[contig] == rank:

@@ -132,12 +132,43 @@ class FragSource:
             lib.ftk_fragstream_close(stream)
 
     def load_all(self):
-        """Make every contig resident (whole-file operations)."""
+        """Make every contig resident (whole-file operations).  When most of the file is still missing, ONE
+        streaming pass over it (decode of contig k+1 overlapped with the upload of contig k) replaces one index
+        seek and stream per contig."""
         if not self.lazy:
             return
+        missing = [c for c in self.contigs if c not in self.loaded]
+        if len(missing) > 1 and 2 * len(missing) >= len(self.contigs):
+            self._stream_missing(set(missing))
         for c in self.contigs:
             if c not in self.loaded:
                 self._load_one(c)
+
+    def _stream_missing(self, missing):
+        eng = get_engine()
+        lib = L.load()
+        stream = C.c_void_p()
+        rc = lib.ftk_fragstream_open_device(eng.device, self.path.encode(), None, int(self.is_bam),
+                                            decode_threads(self.workers), 2, C.byref(stream))
+        if rc != L.FTK_OK:
+            raise UnsupportedFormatError(lib.ftk_fragtable_error().decode())
+        try:
+            while True:
+                table = C.c_void_p()
+                rc = lib.ftk_fragstream_next(stream, C.byref(table))
+                if rc != L.FTK_OK:
+                    raise UnsupportedFormatError(lib.ftk_fragtable_error().decode())
+                if not table.value:
+                    break
+                try:
+                    name = lib.ftk_fragtable_contig_name(table, 0).decode()
+                    if name in missing and name not in self.loaded:
+                        eng.load_contig_from_table(self.key(name), table, 0, self.is_bam)
+                        self.loaded.add(name)
+                finally:
+                    lib.ftk_fragtable_free(table)
+        finally:
+            lib.ftk_fragstream_close(stream)
 
     def release(self):
         eng = get_engine()
