@@ -68,6 +68,31 @@ def _stats_from_dist(values: np.ndarray, freq: np.ndarray, short_cut):
     return mean, median, variance ** 0.5, vals[0], vals[-1], total_count, n_short
 
 
+def _stats_rows(h: np.ndarray, lo: int, short_cut):
+    """``_stats_from_dist`` for every row of a dense histogram block ``h[r, b]`` = count of length ``lo + b``
+    at once (numpy over the block instead of a Python loop per interval and per length): arrays
+    ``(mean, median, stdev, min, max, total, n_short)``; rows without fragments have total 0 (other entries
+    undefined).  Same formulas: the mean from exact integer sums, the median by the reference's search (odd
+    totals look for ``total // 2``), the variance around that mean (numpy's summation order instead of
+    ascending lengths: ~1e-16 relative)."""
+    n_rows, n_b = h.shape
+    v = lo + np.arange(n_b, dtype=np.int64)
+    tot = h.sum(axis=1)
+    safe = np.maximum(tot, 1)
+    present = h > 0
+    first = present.argmax(axis=1)
+    last = n_b - 1 - present[:, ::-1].argmax(axis=1)
+    mean = (h @ v) / safe
+    var = (((v[None, :] - mean[:, None]) ** 2) * h).sum(axis=1) / safe
+    cdf = np.cumsum(h, axis=1)
+    k1 = tot // 2
+    i1 = np.where(k1 == 0, first, (cdf >= k1[:, None]).argmax(axis=1))  # searchsorted(cdf, 0) is the first value
+    i2 = (cdf >= (k1 + 1)[:, None]).argmax(axis=1)
+    median = np.where(tot % 2 == 1, v[i1].astype(np.float64), (v[i1] + v[i2]) / 2.0)
+    n_short = None if short_cut is None else h[:, v <= short_cut].sum(axis=1)
+    return mean, median, np.sqrt(var), v[first], v[last], tot, n_short
+
+
 def _length_range(eng, key, min_length, max_length):
     _, data_max, _ = eng.info(key)
     lo = 0 if min_length is None else max(int(min_length), 0)
@@ -226,15 +251,22 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
         for w0 in range(0, len(idx), step):
             h = _window_hists(eng, key, ws[w0:w0 + step], we[w0:w0 + step], lo, hi, quality_threshold, min_length,
                               max_length, intersect_policy)
-            for j in range(h.shape[0]):
-                contig, start, stop, name = intervals[idx[w0 + j]]
-                nz = np.nonzero(h[j])[0] if h.shape[1] else np.zeros(0, np.int64)
-                if len(nz) == 0:
+            if h.shape[1] == 0:
+                for j in range(h.shape[0]):
+                    contig, start, stop, name = intervals[idx[w0 + j]]
                     results[idx[w0 + j]] = FragLengthStats(contig, start, stop, name, -1, -1, -1, -1, -1, -1, -1)
-                    continue
-                mean, median, stdev, vmin, vmax, total, n_short = _stats_from_dist(nz + lo, h[j][nz], short_reads)
-                results[idx[w0 + j]] = FragLengthStats(contig, start, stop, name, mean, median, stdev, vmin, vmax,
-                                                       total, n_short / total)
+                continue
+            rows_per = max(1, (1 << 22) // h.shape[1])  # statistics of a few thousand intervals at a time
+            for r0 in range(0, h.shape[0], rows_per):
+                blk = h[r0:r0 + rows_per]
+                mean, median, stdev, vmin, vmax, total, n_short = (a.tolist() for a in _stats_rows(blk, lo, short_reads))
+                for j in range(blk.shape[0]):
+                    contig, start, stop, name = intervals[idx[w0 + r0 + j]]
+                    if total[j] == 0:
+                        results[idx[w0 + r0 + j]] = FragLengthStats(contig, start, stop, name, -1, -1, -1, -1, -1, -1, -1)
+                    else:
+                        results[idx[w0 + r0 + j]] = FragLengthStats(contig, start, stop, name, mean[j], median[j], stdev[j],
+                                                                    vmin[j], vmax[j], total[j], n_short[j] / total[j])
 
     output_is_file = False
     if output_file is not None:

@@ -218,3 +218,32 @@ def test_gap_bed_files_equal_the_references(tmp_path):
     from finaletoolkit_amd.genome.gaps import _cli_gap_bed
     with pytest.raises(ValueError):
         _cli_gap_bed("mm10", str(tmp_path / "x.bed"))
+
+
+def test_interval_statistics_block_form_equals_the_per_interval_form():
+    """frag_length_intervals computes the statistics of a block of intervals with numpy at once (`_stats_rows`);
+    the per-interval statement (`_stats_from_dist`, the reference's formulas incl. the odd-count median search)
+    must give the same numbers: exactly for mean / median / min / max / count / short count, 1e-12 for stdev."""
+    from finaletoolkit_amd.frag import _frag_length as FL
+    rng = np.random.default_rng(12)
+    lo, n_b = 37, 400
+    h = np.zeros((300, n_b), np.int64)
+    for r in range(300):
+        kind = r % 6
+        if kind == 0:
+            continue                                   # empty interval
+        k = [0, 1, 2, 3, 50, 400][kind]
+        if kind == 1:
+            h[r, rng.integers(0, n_b)] = 1               # a single fragment: total // 2 == 0
+        else:
+            pos = rng.integers(0, n_b, k)
+            np.add.at(h[r], pos, rng.integers(1, 30, k))
+    mean, median, stdev, vmin, vmax, tot, n_short = FL._stats_rows(h, lo, 150)
+    for r in range(300):
+        nz = np.nonzero(h[r])[0]
+        if len(nz) == 0:
+            assert tot[r] == 0
+            continue
+        m, md, sd, a, b, t, ns = FL._stats_from_dist(nz + lo, h[r][nz], 150)
+        assert (mean[r], median[r], vmin[r], vmax[r], tot[r], n_short[r]) == (m, md, a, b, t, ns), r
+        assert stdev[r] == pytest.approx(sd, rel=1e-12, abs=1e-12)
