@@ -1610,6 +1610,7 @@ struct ftk_fragstream {
     // Text files on a stream opened with ftk_fragstream_open_on: the rows are parsed on this GPU
     // (run_text_device) and the tables handed out hold device columns.
     int device = -1;
+    int inflate_device = -1;  // BAM streams opened with a device: where run_bam inflates the pieces
     hipStream_t pstream = nullptr;
     bool emit_device(Contig&& ct);
     bool run_text_device(RawBuf& first, size_t first_n);
@@ -1965,6 +1966,8 @@ struct DevSet {
     // pieces inflated on the device (FTK_DEVICE_INFLATE): compressed bytes, block table, per-block CRCs, status
     bool inflated = false;
     uint8_t* d_comp = nullptr;
+    uint8_t* h_comp = nullptr;  // page-locked copy of the compressed piece (BAM path; text pieces stage in h_text)
+    size_t h_comp_cap = 0;
     size_t comp_cap = 0, tab_cap = 0, n_tab = 0;
     ftk::InflateBlock *d_tab = nullptr, *h_tab = nullptr;
     uint32_t *d_crc = nullptr, *h_crc = nullptr, *want_crc = nullptr;  // want_crc: the blocks' trailers (plain host memory)
@@ -1973,11 +1976,11 @@ struct DevSet {
     void release_inflate() {
         for (void* q : {(void*)d_comp, (void*)d_tab, (void*)d_crc, (void*)d_ist})
             if (q) (void)hipFree(q);
-        for (void* q : {(void*)h_tab, (void*)h_crc, (void*)h_ist})
+        for (void* q : {(void*)h_tab, (void*)h_crc, (void*)h_ist, (void*)h_comp})
             if (q) (void)hipHostFree(q);
         free(want_crc);
-        d_comp = nullptr; d_tab = h_tab = nullptr; d_crc = h_crc = want_crc = nullptr; d_ist = h_ist = nullptr;
-        comp_cap = tab_cap = 0;
+        d_comp = h_comp = nullptr; d_tab = h_tab = nullptr; d_crc = h_crc = want_crc = nullptr; d_ist = h_ist = nullptr;
+        comp_cap = tab_cap = h_comp_cap = 0;
     }
     void release() {
         release_inflate();
@@ -1987,6 +1990,19 @@ struct DevSet {
             if (q) (void)hipFree(q);
         if (done) (void)hipEventDestroy(done);
         *this = DevSet{};
+    }
+    bool ensure_host_comp(size_t comp_bytes) {
+        if (comp_bytes <= h_comp_cap) return true;
+        if (h_comp) (void)hipHostFree(h_comp);
+        h_comp = nullptr;
+        h_comp_cap = comp_bytes + comp_bytes / 4 + 4096;
+        if (hipHostMalloc((void**)&h_comp, h_comp_cap, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            h_comp = nullptr;
+            h_comp_cap = 0;
+            return false;
+        }
+        return true;
     }
     // room for a piece of comp_bytes of BGZF data in n_blocks blocks
     bool ensure_inflate(size_t comp_bytes, size_t n_blocks) {
@@ -1998,12 +2014,14 @@ struct DevSet {
             ok = hipMalloc((void**)&d_comp, comp_cap) == hipSuccess;
         }
         if (ok && n_blocks > tab_cap) {
-            const size_t cc = comp_cap;
-            uint8_t* keep = d_comp;
-            d_comp = nullptr;
+            const size_t cc = comp_cap, hc = h_comp_cap;
+            uint8_t *keep = d_comp, *keep_h = h_comp;
+            d_comp = h_comp = nullptr;
             release_inflate();
             d_comp = keep;
             comp_cap = cc;
+            h_comp = keep_h;
+            h_comp_cap = hc;
             tab_cap = n_blocks + n_blocks / 4 + 64;
             want_crc = (uint32_t*)malloc(tab_cap * 4);
             ok = want_crc && hipMalloc((void**)&d_tab, tab_cap * sizeof(ftk::InflateBlock)) == hipSuccess &&
@@ -2416,11 +2434,11 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     return true;
 }
 
-bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
+bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
     StageClock clk(this);
     size_t n_stretches = 0, n_redone = 0;
-    std::vector<Block> blocks;
-    RawBuf data;                // carry (partial record / header) + this piece's inflated bytes
+    RawBuf data;                // carry (partial record / header) + this piece's inflated bytes (host inflate)
+    std::vector<uint8_t> carry_buf;  // the same carry while the pieces are inflated on the device
     size_t carry = 0;
     bool header_done = false;
     std::vector<int> wanted;    // ref id -> 1 when selected
@@ -2429,16 +2447,136 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
     int cur_ref = -1;
     std::set<int> seen;
     size_t pending_skip = 0;
-    bool eof = n < kStreamPiece;
+    // One piece of the file: compressed bytes in buf[0, n), its whole BGZF blocks, and (device inflate) the slot
+    // that inflates it.
+    struct Piece {
+        size_t n = 0, used = 0, total = 0;
+        bool eof = false, listed = false;
+        std::vector<Block> blocks;
+        int slot = -1;
+    };
+    // Device inflate (default on a stream that knows its GPU; FTK_DEVICE_INFLATE=0: host threads): the blocks of
+    // piece k+1 are inflated on the GPU and copied back while the host walks the records of piece k.  Two slots;
+    // a slot's output is page-locked memory with room in front for the carry.
+    constexpr size_t kRoom = size_t(32) << 20;
+    static const bool want_dinf = !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
+    const int device = inflate_device;  // (shadows the member: this path's GPU)
+    bool dinf = want_dinf && device >= 0;
+    if (dinf && (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking) != hipSuccess)) {
+        (void)hipGetLastError();
+        dinf = false;
+    }
+    DevSet sets[2];
+    if (dinf) { sets[0] = devset_pool().take(device); sets[1] = devset_pool().take(device); }
+    struct Cleanup {
+        DevSet* s;
+        int device;
+        hipStream_t* stream;
+        bool on;
+        ~Cleanup() {
+            if (!on) return;
+            (void)hipStreamSynchronize(*stream);
+            devset_pool().give(device, s[0]);
+            devset_pool().give(device, s[1]);
+        }
+    } cleanup{sets, device, &pstream, dinf};
+    auto submit = [&](Piece& pc, int slot) -> bool {
+        DevSet& S = sets[slot];
+        if (pc.total + kRoom + 64 >= (size_t(1) << 32)) return fail(FTK_ERR_FORMAT, "BGZF piece too large");
+        if (!S.ensure(kRoom + pc.total + 64) || !S.ensure_inflate(pc.used, pc.blocks.size()) || !S.ensure_host_comp(pc.used + 64))
+            return fail(FTK_ERR_OOM, "out of page-locked / device memory for the BAM piece");
+        {
+            const size_t used = pc.used;
+            const int nt = std::max(1, std::min(n_threads, (int)(used >> 20) + 1));
+            const uint8_t* src = buf.data();
+            uint8_t* dst = S.h_comp;
+            parallel_run(nt, [&](int t) {
+                const size_t a = used * (size_t)t / nt, b2 = used * (size_t)(t + 1) / nt;
+                memcpy(dst + a, src + a, b2 - a);
+            });
+        }
+        for (size_t i = 0; i < pc.blocks.size(); ++i) {
+            const Block& bl = pc.blocks[i];
+            S.h_tab[i] = {(uint32_t)bl.in_off, (uint32_t)bl.in_len, (uint32_t)(kRoom + bl.out_off), (uint32_t)bl.out_len};
+            const uint8_t* tr = buf.data() + bl.in_off + bl.in_len;
+            S.want_crc[i] = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+        }
+        S.n_tab = pc.blocks.size();
+        bool ok = hipMemsetAsync(S.d_ist, 0, sizeof(ftk::InflateStatus), pstream) == hipSuccess &&
+                  (pc.used == 0 || hipMemcpyAsync(S.d_comp, S.h_comp, pc.used, hipMemcpyHostToDevice, pstream) == hipSuccess) &&
+                  (pc.blocks.empty() || hipMemcpyAsync(S.d_tab, S.h_tab, pc.blocks.size() * sizeof(ftk::InflateBlock),
+                                                       hipMemcpyHostToDevice, pstream) == hipSuccess);
+        if (ok) {
+            ftk::inflate_launch(pstream, S.d_comp, S.d_tab, (int)pc.blocks.size(), S.d_text, S.d_ist, S.d_crc);
+            ok = hipGetLastError() == hipSuccess &&
+                 (pc.total == 0 || hipMemcpyAsync(S.h_text + kRoom, S.d_text + kRoom, pc.total, hipMemcpyDeviceToHost, pstream) == hipSuccess) &&
+                 hipMemcpyAsync(S.h_ist, S.d_ist, sizeof(ftk::InflateStatus), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
+                 (pc.blocks.empty() || hipMemcpyAsync(S.h_crc, S.d_crc, pc.blocks.size() * 4, hipMemcpyDeviceToHost, pstream) == hipSuccess) &&
+                 hipEventRecord(S.done, pstream) == hipSuccess;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            return fail(FTK_ERR_HIP, "cannot launch the device inflate");
+        }
+        pc.slot = slot;
+        return true;
+    };
+    auto wait_slot = [&](int slot) -> bool {
+        DevSet& S = sets[slot];
+        if (hipEventSynchronize(S.done) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(FTK_ERR_HIP, "the device inflate failed");
+        }
+        if (S.h_ist->n_bad) return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+        for (size_t i = 0; i < S.n_tab; ++i)
+            if (S.h_crc[i] != S.want_crc[i]) return fail(FTK_ERR_FORMAT, "BGZF block CRC mismatch (device inflate)");
+        return true;
+    };
+    auto list_blocks = [&](Piece& pc) -> bool {
+        if (pc.listed) return true;
+        if (!whole_blocks(buf.data(), pc.n, pc.eof, &pc.blocks, &pc.used, &pc.total)) return fail(FTK_ERR_FORMAT, "corrupt BGZF block");
+        pc.listed = true;
+        return true;
+    };
+    Piece curp, nxt;
+    curp.n = n_first;
+    curp.eof = n_first < kStreamPiece;
+    int piece_no = 0;
     for (;;) {
-        size_t used = 0, total = 0;
-        if (!whole_blocks(buf.data(), n, eof, &blocks, &used, &total)) return fail(FTK_ERR_FORMAT, "corrupt BGZF block");
-        if (!data.reserve(carry + total + 1)) return fail(FTK_ERR_OOM, "out of host memory");
+        if (!list_blocks(curp)) return false;
+        if (dinf && curp.slot < 0 && !submit(curp, piece_no & 1)) return false;
+        // read the next piece and start its inflate before this piece's records are walked (not while the header is
+        // still being probed: an index seek may throw that read away)
+        bool have_next = false;
+        if (dinf && header_done && !curp.eof) {
+            const size_t raw_carry = curp.n - curp.used;
+            if (raw_carry) memmove(buf.data(), buf.data() + curp.used, raw_carry);
+            clk.lap(5);
+            nxt = Piece{};
+            nxt.n = fill(buf, raw_carry);
+            clk.lap(0);
+            nxt.eof = nxt.n - raw_carry < kStreamPiece;
+            if (!list_blocks(nxt) || !submit(nxt, (piece_no + 1) & 1)) return false;
+            have_next = true;
+        }
+        size_t& n = curp.n;
+        bool& eof = curp.eof;
+        const size_t used = curp.used, total = curp.total;
+        const uint8_t* p;
         clk.lap(5);
-        if (!blocks.empty() && inflate_block_list(buf.data(), blocks, n_threads, data.data() + carry) != FTK_OK)
-            return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+        if (dinf) {
+            if (carry > kRoom) return fail(FTK_ERR_FORMAT, "a BAM header or record of more than 32 MB: set FTK_DEVICE_INFLATE=0");
+            if (!wait_slot(curp.slot)) return false;
+            uint8_t* base = sets[curp.slot].h_text + kRoom - carry;
+            if (carry) memcpy(base, carry_buf.data(), carry);
+            p = base;
+        } else {
+            if (!data.reserve(carry + total + 1)) return fail(FTK_ERR_OOM, "out of host memory");
+            if (!curp.blocks.empty() && inflate_block_list(buf.data(), curp.blocks, n_threads, data.data() + carry) != FTK_OK)
+                return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+            p = data.data();
+        }
         clk.lap(1);
-        const uint8_t* p = data.data();
         const size_t m = carry + total;
         size_t off = std::min(pending_skip, m);  // (a damaged index may point past the block)
         pending_skip = 0;
@@ -2483,6 +2621,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
             if (!complete) {
                 if (eof) return fail(FTK_ERR_FORMAT, "truncated BAM header");
                 carry = m;  // need more bytes: keep everything
+                if (dinf) carry_buf.assign(p, p + m);
                 goto next_piece;
             }
             header_done = true;
@@ -2496,8 +2635,10 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
                 if (sp.usable && !sp.present) return true;  // no alignment on this contig
                 if (sp.usable && seek_to(sp)) {
                     carry = 0;
-                    n = fill(buf, 0);
-                    eof = n < kStreamPiece;
+                    curp = Piece{};
+                    curp.n = fill(buf, 0);
+                    curp.eof = curp.n < kStreamPiece;
+                    ++piece_no;
                     pending_skip = first_skip;
                     first_skip = 0;
                     continue;
@@ -2594,17 +2735,25 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n) {
                 }
             clk.lap(3);
             carry = m - o;
-            if (carry) memmove(data.data(), p + o, carry);
+            if (dinf) carry_buf.assign(p + o, p + o + carry);
+            else if (carry) memmove(data.data(), p + o, carry);
         }
     next_piece:
         if (eof) break;
-        {
+        if (have_next) {
+            curp = std::move(nxt);
+        } else {
             const size_t raw_carry = n - used;
             if (raw_carry) memmove(buf.data(), buf.data() + used, raw_carry);
             clk.lap(5);
-            n = fill(buf, raw_carry);
+            Piece np;
+            np.n = fill(buf, raw_carry);
             clk.lap(0);
-            eof = n - raw_carry < kStreamPiece;
+            np.eof = np.n - raw_carry < kStreamPiece;
+            curp = std::move(np);
+        }
+        ++piece_no;
+        {
             std::lock_guard<std::mutex> lk(mu);
             if (stop) return false;
         }
@@ -2694,6 +2843,7 @@ static int fragstream_open_impl(const char* path, const char* contig, int is_bam
     // BAM records are parsed by the host; FTK_DEVICE_PARSE=0 keeps text rows there too
     static const bool device_parse = !(getenv("FTK_DEVICE_PARSE") && atoi(getenv("FTK_DEVICE_PARSE")) == 0);
     s->device = (!s->bam && device_parse) ? device : -1;
+    s->inflate_device = s->bam ? device : -1;  // BAM: records stay on the host, the BGZF inflate may use the GPU
     s->producer = std::thread([s] { s->run(); });
     *out = s;
     return FTK_OK;
@@ -2758,7 +2908,7 @@ void ftk_fragstream_close(ftk_fragstream* s) {
     s->drain_ahead();
     for (auto* t : s->ready) delete t;
     if (s->pstream) {
-        (void)hipSetDevice(s->device);
+        (void)hipSetDevice(s->device >= 0 ? s->device : s->inflate_device);
         (void)hipStreamSynchronize(s->pstream);
         (void)hipStreamDestroy(s->pstream);
     }
