@@ -38,7 +38,8 @@ struct __align__(16) WaveLds {
     uint32_t pair[1 << kLitRoot];    // the look-up of the symbol loop: up to TWO literals per entry (see build_pairs);
                                      // its first half doubles as the one-symbol table (uint16: symbol << 4 | code
                                      // length, 0 = longer than the root) while a block's tables are being built
-    uint16_t dist[1 << kDistRoot];
+    uint32_t dist[1 << kDistRoot];   // code length | extra bits << 4 | base distance << 8 (the first half holds the
+                                     // one-symbol uint16 table while it is being built); 0 = longer than the root
     uint16_t pre[1 << kPreRoot];
     uint16_t sorted[2][288];         // symbols in canonical order (by length, then value): [0] lit/len, [1] distance
     uint16_t cnt[2][16];             // symbols per code length
@@ -159,8 +160,16 @@ __device__ __forceinline__ void build_pairs(WaveLds& L, int lane) {
         const unsigned l1 = t & 15u, s1 = t >> 4;
         unsigned v = 0;
         if (l1) {
-            if (s1 >= 256u) v = l1 | (s1 << 8);
-            else {
+            if (s1 >= 256u) {  // end of block (base 0) or a length symbol: base length and extra bits in the entry
+                const unsigned ls = s1 - 257u;
+                unsigned base = 0, eb = 0;
+                if (s1 == 256u) base = 0;
+                else if (ls < 8u) base = ls + 3u;
+                else if (ls == 28u) base = 258u;
+                else if (ls < 28u) { eb = (ls >> 2) - 1u; base = ((4u + (ls & 3u)) << eb) + 3u; }
+                else base = 511u;  // 286 / 287: no such length (the decoder reports it)
+                v = l1 | (base << 8) | (eb << 20);
+            } else {
                 v = l1 | (1u << 5) | (s1 << 8);
                 const unsigned t2 = one[e >> l1];  // the bits behind the first code, zero-extended: valid for a code
                 const unsigned l2 = t2 & 15u, s2 = t2 >> 4;  // that fits into what is left of the root bits
@@ -169,6 +178,27 @@ __device__ __forceinline__ void build_pairs(WaveLds& L, int lane) {
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         L.pair[e] = v;
+    }
+}
+
+// the distance table in place: uint16 symbol << 4 | length -> length | extra bits << 4 | base << 8
+__device__ __forceinline__ unsigned dist_entry(unsigned l, unsigned ds) {
+    unsigned base, eb = 0;
+    if (ds < 4u) base = ds + 1u;
+    else if (ds < 30u) { eb = (ds >> 1) - 1u; base = ((2u + (ds & 1u)) << eb) + 1u; }
+    else base = 0x7fffffu;  // 30 / 31: no such distance
+    return l | (eb << 4) | (base << 8);
+}
+__device__ __forceinline__ void build_dist(WaveLds& L, int lane) {
+    constexpr int size = 1 << kDistRoot;
+    const uint16_t* one = reinterpret_cast<const uint16_t*>(L.dist);
+    for (int base = size - 64; base >= 0; base -= 64) {
+        const int e = base + lane;
+        const unsigned t = one[e];
+        const unsigned l = t & 15u;
+        const unsigned v = l ? dist_entry(l, t >> 4) : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        L.dist[e] = v;
     }
 }
 
@@ -189,17 +219,6 @@ __device__ __forceinline__ int decode_long(const WaveLds& L, Bits& b, int which)
         code <<= 1;
     }
     return -1;
-}
-
-// the same through a one-symbol table first
-__device__ __forceinline__ int decode_sym(const WaveLds& L, Bits& b, const uint16_t* table, int root, int which) {
-    const int e = UNI(table[b.peek(root)]);
-    const int l = e & 15;
-    if (l) {
-        b.drop(l);
-        return e >> 4;
-    }
-    return decode_long(L, b, which);
 }
 
 __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp,
@@ -318,11 +337,12 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                 for (int k = lane; k < hdist; k += 64) L.lens[288 + k] = L.lens[hlit + k];
         }
         if (!build_table(L, L.lens, hlit, kLitRoot, reinterpret_cast<uint16_t*>(L.pair), 0, lane) ||
-            !build_table(L, &L.lens[288], hdist, kDistRoot, L.dist, 1, lane)) {
+            !build_table(L, &L.lens[288], hdist, kDistRoot, reinterpret_cast<uint16_t*>(L.dist), 1, lane)) {
             err = kInflateBadLengths;
             break;
         }
         build_pairs(L, lane);
+        build_dist(L, lane);
         // ---- the symbols of this DEFLATE block --------------------------------------------------------
         // Literals collect in a register (lane k = k-th pending byte, v_writelane) and go to the ring 63-64 at a time.
         int vlit = 0, nlit = 0;
@@ -349,12 +369,11 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                 }
                 continue;
             }
-            int sym;
+            unsigned le = e;  // length entry: bits | base << 8 | extra bits << 20 (base 0: end of block)
             if (e) {
                 b.drop((int)(e & 31u));
-                sym = (int)(e >> 8);
             } else {
-                sym = decode_long(L, b, 0);  // a code longer than the root: bit by bit
+                const int sym = decode_long(L, b, 0);  // a code longer than the root: bit by bit
                 if (sym < 0) { err = kInflateBadSymbol; break; }
                 if (sym < 256) {
                     vlit = write_lane(vlit, sym, nlit, lane);
@@ -364,34 +383,44 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                     }
                     continue;
                 }
+                const unsigned ls = (unsigned)sym - 257u;
+                unsigned base = 0, eb = 0;
+                if (sym == 256) base = 0;
+                else if (ls < 8u) base = ls + 3u;
+                else if (ls == 28u) base = 258u;
+                else if (ls < 28u) { eb = (ls >> 2) - 1u; base = ((4u + (ls & 3u)) << eb) + 3u; }
+                else base = 511u;
+                le = (base << 8) | (eb << 20);
             }
             if (nlit) {
                 put_literals();
                 if (err != kInflateOk) break;
             }
-            if (sym == 256) break;
-            const int ls = sym - 257;
-            if (ls > 28) { err = kInflateBadSymbol; break; }
-            int len;
-            if (ls < 8) len = ls + 3;
-            else if (ls == 28) len = 258;
-            else {
-                const int eb = (ls >> 2) - 1;
-                len = ((4 + (ls & 3)) << eb) + 3 + (int)b.take(eb);
-            }
+            const unsigned lbase = (le >> 8) & 511u;
+            if (lbase == 0) break;  // end of block
+            if (lbase == 511u) { err = kInflateBadSymbol; break; }
+            const int len = (int)(lbase + b.take((int)(le >> 20)));
             b.refill(lane);
-            const int ds = decode_sym(L, b, L.dist, kDistRoot, 1);
-            if (ds < 0 || ds > 29) { err = kInflateBadSymbol; break; }
-            int d;
-            if (ds < 4) d = ds + 1;
-            else {
-                const int eb = (ds >> 1) - 1;
-                d = ((2 + (ds & 1)) << eb) + 1 + (int)b.take(eb);
+            unsigned de = (unsigned)UNI(L.dist[b.peek(kDistRoot)]);
+            if (de) {
+                b.drop((int)(de & 15u));
+            } else {
+                const int ds = decode_long(L, b, 1);
+                if (ds < 0) { err = kInflateBadSymbol; break; }
+                de = dist_entry(0u, (unsigned)ds);
             }
+            if ((de >> 8) == 0x7fffffu) { err = kInflateBadSymbol; break; }
+            const int d = (int)((de >> 8) + b.take((int)((de >> 4) & 15u)));
             if ((uint32_t)d > A - out_off) { err = kInflateBadDistance; break; }
             if (A + (uint32_t)len > A_end) { err = kInflateOverrun; break; }
             const uint32_t A0 = A;
-            if (d <= kFarDist) {
+            if (d >= len && len <= 64 && d <= kFarDist) {
+                // the common case (a row repeats part of an earlier one): one step, sources all older than the match
+                if (lane < len) {
+                    const uint32_t a = A0 + (uint32_t)lane;
+                    L.ring[a & kRingMask] = L.ring[(a - (uint32_t)d) & kRingMask];
+                }
+            } else if (d <= kFarDist) {
                 // LDS to LDS.  The pattern has period d: after `done` bytes, [A0 - d, A0 + done) is valid, so a
                 // step may copy up to D bytes from D back for any multiple D of d with D <= done + d; D doubles.
                 int done = 0, D = d;
