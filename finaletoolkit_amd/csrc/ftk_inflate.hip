@@ -356,19 +356,32 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
         };
         for (;;) {
             b.refill(lane);
-            const unsigned e = (unsigned)UNI(L.pair[b.peek(kLitRoot)]);
-            const unsigned kind = (e >> 5) & 3u;
-            if (kind) {
-                b.drop((int)(e & 31u));
+            // Lane k looks up the symbol that would start k bits ahead; the wave then hops from symbol to symbol
+            // through that register (one v_readlane per hop instead of one LDS round trip) for as long as the
+            // symbols are literals and their root bits lie inside the valid part of the bit buffer.
+            const unsigned E = L.pair[(unsigned)(b.buf >> lane) & ((1u << kLitRoot) - 1u)];
+            const int limit = b.cnt - kLitRoot;
+            int pos = 0;
+            unsigned e, kind;
+            for (;;) {
+                e = (unsigned)__builtin_amdgcn_readlane((int)E, pos);
+                kind = (e >> 5) & 3u;
+                if (!kind) break;
                 vlit = write_lane(vlit, (int)((e >> 8) & 255u), nlit, lane);
                 if (kind == 2u) vlit = write_lane(vlit, (int)(e >> 20), nlit + 1, lane);
                 nlit += (int)kind;
+                pos += (int)(e & 31u);
+                if (nlit >= 63 || pos > limit) break;
+            }
+            b.drop(pos);
+            if (kind) {
                 if (nlit >= 63) {
                     put_literals();
                     if (err != kInflateOk) break;
                 }
                 continue;
             }
+            b.refill(lane);  // the symbol at the front is no literal: its code and extra bits take up to 20
             unsigned le = e;  // length entry: bits | base << 8 | extra bits << 20 (base 0: end of block)
             if (e) {
                 b.drop((int)(e & 31u));
@@ -484,15 +497,35 @@ __global__ __launch_bounds__(64) void bgzf_crc_kernel(const InflateBlock* __rest
                                                       const uint8_t* __restrict__ out, uint32_t* __restrict__ crc_out) {
     const int lane = threadIdx.x, blk = blockIdx.x;
     if (blk >= n_blocks) return;
-    const uint32_t base = tab[blk].out_off, len = tab[blk].out_len;
-    const uint32_t stripe = (len + 63u) / 64u;
-    const uint32_t a = min((uint32_t)lane * stripe, len), e = min(a + stripe, len);
+    const uint32_t len = tab[blk].out_len;
+    const uint8_t* p = out + tab[blk].out_off;
+    // stripes of whole 16-byte groups of the ADDRESS space (one aligned 16-byte load per 16 bytes; with byte loads
+    // every 128-byte line was fetched 128 times and a launch of 9 000 blocks ran at a third of the rate of one of
+    // 1 900: 64 lines per wave x 32 waves do not stay in a CU's L1); block start and end are the ragged ones
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u);
+    const uint32_t total = len + mis;
+    const uint32_t stripe = (((total + 63u) / 64u) + 15u) & ~15u;
+    p -= mis;
+    const uint32_t a = min(max((uint32_t)lane * stripe, mis), total), e = min(((uint32_t)lane + 1u) * stripe, total);
     uint32_t c = 0xffffffffu;
-    for (uint32_t i = a; i < e; ++i) {  // bit-serial on the vector unit: 190 GB/s of text; a byte-wise table in LDS measured
-        c ^= out[base + i];             // 70 GB/s (every lane looks up another word: bank conflicts)
+    auto byte_step = [&](uint32_t i) {  // bit-serial on the vector unit (a byte-wise table in LDS measured 70 GB/s:
+        c ^= p[i];                       // every lane looks up another word, bank conflicts)
 #pragma unroll
         for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+    };
+    uint32_t i = a;
+    for (; i < e && (i & 15u); ++i) byte_step(i);
+    for (; i + 16u <= e; i += 16u) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p + i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            c ^= w[q];
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+        }
     }
+    for (; i < e; ++i) byte_step(i);
     c = (e > a) ? ~c : 0u;      // CRC of the stripe (0 for an empty one: the neutral element of the fold)
     uint32_t n = e - a;         // bytes this lane's value covers
     for (int d = 1; d < 64; d <<= 1) {
