@@ -2064,7 +2064,7 @@ struct DevSet {
 };
 // The two buffer sets of a finished stream wait here for the next one: allocating them costs ~100 ms (400 MB
 // of page-locked memory, ~1 GB of device memory, the frees synchronise the device) - more than a small file
-// takes to decode.  At most two idle sets are kept (per process, any device).
+// takes to decode.  At most four idle sets are kept (per process, any device): what a BAM stream's look-ahead uses.
 struct DevSetPool {
     std::mutex mu;
     std::vector<std::pair<int, DevSet>> idle;
@@ -2082,7 +2082,7 @@ struct DevSetPool {
         s.pending = false;
         {
             std::lock_guard<std::mutex> lk(mu);
-            if (s.cap && idle.size() < 2) {
+            if (s.cap && idle.size() < 4) {
                 idle.emplace_back(device, s);
                 s = DevSet{};
                 return;
@@ -2456,32 +2456,48 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
         int slot = -1;
     };
     // Device inflate (default on a stream that knows its GPU; FTK_DEVICE_INFLATE=0: host threads): the blocks of
-    // piece k+1 are inflated on the GPU and copied back while the host walks the records of piece k.  Two slots;
-    // a slot's output is page-locked memory with room in front for the carry.
+    // pieces k+1 .. k+kAhead are inflated on the GPU and copied back while the host walks the records of piece k.
+    // One slot and one HIP stream per piece in flight: a 48 MB piece holds ~800 blocks = 800 wavefronts, a
+    // quarter of what the chip holds at this kernel's occupancy, and a block's decode chain takes the same ~6.5 ms
+    // whether the chip is full or not - so three pieces' kernels (and their copies, either direction) run side by
+    // side.  A slot's output is page-locked memory with room in front for the carry.
     constexpr size_t kRoom = size_t(32) << 20;
+    constexpr int kAhead = 3, kSlots = kAhead + 1;
     static const bool want_dinf = !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
     const int device = inflate_device;  // (shadows the member: this path's GPU)
     bool dinf = want_dinf && device >= 0;
-    if (dinf && (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking) != hipSuccess)) {
-        (void)hipGetLastError();
-        dinf = false;
+    hipStream_t streams[kSlots] = {};  // streams[0] is the member pstream (destroyed with the stream object)
+    if (dinf) {
+        bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking) == hipSuccess;
+        streams[0] = pstream;
+        for (int k = 1; ok && k < kSlots; ++k) ok = hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            for (int k = 1; k < kSlots; ++k)
+                if (streams[k]) (void)hipStreamDestroy(streams[k]);
+            dinf = false;
+        }
     }
-    DevSet sets[2];
-    if (dinf) { sets[0] = devset_pool().take(device); sets[1] = devset_pool().take(device); }
+    DevSet sets[kSlots];
+    if (dinf)
+        for (auto& S : sets) S = devset_pool().take(device);
     struct Cleanup {
         DevSet* s;
         int device;
-        hipStream_t* stream;
+        hipStream_t* streams;
         bool on;
         ~Cleanup() {
             if (!on) return;
-            (void)hipStreamSynchronize(*stream);
-            devset_pool().give(device, s[0]);
-            devset_pool().give(device, s[1]);
+            for (int k = 0; k < kSlots; ++k) {
+                (void)hipStreamSynchronize(streams[k]);
+                if (k) (void)hipStreamDestroy(streams[k]);
+                devset_pool().give(device, s[k]);
+            }
         }
-    } cleanup{sets, device, &pstream, dinf};
+    } cleanup{sets, device, streams, dinf};
     auto submit = [&](Piece& pc, int slot) -> bool {
         DevSet& S = sets[slot];
+        hipStream_t pstream = streams[slot];  // (shadows the member: this slot's stream)
         if (pc.total + kRoom + 64 >= (size_t(1) << 32)) return fail(FTK_ERR_FORMAT, "BGZF piece too large");
         if (!S.ensure(kRoom + pc.total + 64) || !S.ensure_inflate(pc.used, pc.blocks.size()) || !S.ensure_host_comp(pc.used + 64))
             return fail(FTK_ERR_OOM, "out of page-locked / device memory for the BAM piece");
@@ -2538,26 +2554,31 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
         pc.listed = true;
         return true;
     };
-    Piece curp, nxt;
+    Piece curp;
+    std::deque<Piece> ahead;  // pieces behind curp that are already on the device, in file order
     curp.n = n_first;
     curp.eof = n_first < kStreamPiece;
-    int piece_no = 0;
+    int n_submitted = 0;
     for (;;) {
         if (!list_blocks(curp)) return false;
-        if (dinf && curp.slot < 0 && !submit(curp, piece_no & 1)) return false;
-        // read the next piece and start its inflate before this piece's records are walked (not while the header is
-        // still being probed: an index seek may throw that read away)
-        bool have_next = false;
-        if (dinf && header_done && !curp.eof) {
-            const size_t raw_carry = curp.n - curp.used;
-            if (raw_carry) memmove(buf.data(), buf.data() + curp.used, raw_carry);
-            clk.lap(5);
-            nxt = Piece{};
-            nxt.n = fill(buf, raw_carry);
-            clk.lap(0);
-            nxt.eof = nxt.n - raw_carry < kStreamPiece;
-            if (!list_blocks(nxt) || !submit(nxt, (piece_no + 1) & 1)) return false;
-            have_next = true;
+        if (dinf && curp.slot < 0 && !submit(curp, n_submitted++ % kSlots)) return false;
+        // read the next pieces and start their inflate before this piece's records are walked (not while the header
+        // is still being probed: an index seek may throw those reads away).  `buf` holds the compressed bytes of the
+        // piece read last - the newest of `ahead`, or curp.
+        if (dinf && header_done) {
+            while ((int)ahead.size() < kAhead) {
+                const Piece& last = ahead.empty() ? curp : ahead.back();
+                if (last.eof) break;
+                const size_t raw_carry = last.n - last.used;
+                if (raw_carry) memmove(buf.data(), buf.data() + last.used, raw_carry);
+                clk.lap(5);
+                Piece np;
+                np.n = fill(buf, raw_carry);
+                clk.lap(0);
+                np.eof = np.n - raw_carry < kStreamPiece;
+                if (!list_blocks(np) || !submit(np, n_submitted++ % kSlots)) return false;
+                ahead.push_back(std::move(np));
+            }
         }
         size_t& n = curp.n;
         bool& eof = curp.eof;
@@ -2638,7 +2659,6 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
                     curp = Piece{};
                     curp.n = fill(buf, 0);
                     curp.eof = curp.n < kStreamPiece;
-                    ++piece_no;
                     pending_skip = first_skip;
                     first_skip = 0;
                     continue;
@@ -2740,8 +2760,9 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
         }
     next_piece:
         if (eof) break;
-        if (have_next) {
-            curp = std::move(nxt);
+        if (!ahead.empty()) {
+            curp = std::move(ahead.front());
+            ahead.pop_front();
         } else {
             const size_t raw_carry = n - used;
             if (raw_carry) memmove(buf.data(), buf.data() + used, raw_carry);
@@ -2752,7 +2773,6 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
             np.eof = np.n - raw_carry < kStreamPiece;
             curp = std::move(np);
         }
-        ++piece_no;
         {
             std::lock_guard<std::mutex> lk(mu);
             if (stop) return false;

@@ -221,6 +221,11 @@ __device__ __forceinline__ int decode_long(const WaveLds& L, Bits& b, int which)
     return -1;
 }
 
+#ifdef FTK_INFLATE_TIMING
+// tools/inflate_block_times.py builds the library with this: start / end of every block's wavefront (100 MHz ticks)
+__device__ unsigned long long g_block_ticks[2 * 65536];
+#endif
+
 __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp,
                                                           const InflateBlock* __restrict__ tab, int n_blocks,
                                                           uint8_t* __restrict__ out, InflateStatus* __restrict__ status) {
@@ -228,6 +233,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
     if (blk >= n_blocks) return;
+#ifdef FTK_INFLATE_TIMING
+    if (lane == 0 && blk < 65536) g_block_ticks[2 * blk] = wall_clock64();
+#endif
     const uint32_t in_off = tab[blk].in_off, in_len = tab[blk].in_len;
     const uint32_t out_off = tab[blk].out_off, out_len = tab[blk].out_len;
     Bits b;
@@ -462,6 +470,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
     if (err == kInflateOk && A != A_end) err = kInflateShort;
     // the unfinished granule
     if ((A & (kGran - 1)) != 0 || A == out_off) flush(A >> kGranShift);
+#ifdef FTK_INFLATE_TIMING
+    if (lane == 0 && blk < 65536) g_block_ticks[2 * blk + 1] = wall_clock64();
+#endif
     if (err != kInflateOk && lane == 0) {
         if (atomicAdd(&status->n_bad, 1u) == 0) {
             status->first_bad = (unsigned)blk;
@@ -539,6 +550,12 @@ __global__ __launch_bounds__(64) void bgzf_crc_kernel(const InflateBlock* __rest
 }
 
 }  // namespace
+
+#ifdef FTK_INFLATE_TIMING
+extern "C" int ftk_debug_inflate_ticks(unsigned long long* out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_ticks), sizeof(unsigned long long) * 2 * (size_t)n_blocks);
+}
+#endif
 
 void inflate_launch(hipStream_t s, const uint8_t* d_comp, const InflateBlock* d_tab, int n_blocks, uint8_t* d_out,
                     InflateStatus* d_status, uint32_t* d_crc) {

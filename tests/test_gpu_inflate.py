@@ -133,3 +133,49 @@ def test_decoder_suites_with_host_inflate(module):
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", *module.split()], cwd=root,
                        env=dict(os.environ, FTK_DEVICE_INFLATE="0"), capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+_BAM_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from finaletoolkit_amd import source, synth
+from oracle import oracle as O
+size = {size}
+exp = synth.write_paired_bam({bam!r}, "mid", size, 60.0, 17)
+names = []
+for src, name in source.stream_source({bam!r}):
+    names.append(name)
+assert names == ["mid"], names
+eng = source.get_engine()
+key = src.key("mid")
+assert eng.info(key)[0] == exp["n"], (eng.info(key)[0], exp["n"])
+fr = O.Frags(exp["s"], exp["e"], exp["q"], exp["st"], exp["r1s"], exp["r1e"])
+ws, we = synth.tiling_windows(size, 20_000)
+f = eng.window_features(key, ws, we, 30, hist=(0, 1001))
+h, o = O.c_fraglen_hist(fr, ws, we, 0, 1001, mapq_min=30)
+assert np.array_equal(f["coverage"], O.c_window_counts(fr, ws, we, mapq_min=30))
+assert np.array_equal(f["hist"], h) and np.array_equal(f["overflow"], o)
+a = size // 3
+assert np.array_equal(eng.wps(key, a, a + 50_000, size), O.c_wps(fr, a, a + 50_000, size))
+print("ok", exp["n"])
+"""
+
+
+@pytest.mark.parametrize("piece", [1 << 17, 3 << 20])
+def test_bam_stream_many_pieces_through_the_slot_ring(tmp_path, piece):
+    """A BAM stream inflates its pieces on the device with several pieces in flight (run_bam: a ring of slots, one
+    HIP stream each).  Small pieces make one file go round the ring dozens of times - records cut by piece ends
+    (carried on the host), the header in the first piece, speculative stretches of the record chain - and the
+    fragments must be the ones the synthesizer wrote; with the inflate on the host threads likewise."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _BAM_CHILD.format(root=root, size=600_000, bam=str(tmp_path / "ring.bam"))
+    outs = []
+    for dinf in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, FTK_STREAM_PIECE=str(piece), FTK_BAM_STRETCH="65536", FTK_DEVICE_INFLATE=dinf))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and outs[0].startswith("ok")
