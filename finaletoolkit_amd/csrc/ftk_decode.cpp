@@ -1959,6 +1959,9 @@ struct DevSet {
     ftk::TextSummary* d_sum = nullptr;
     ftk::TextSummary* h_sum = nullptr;
     hipEvent_t done = nullptr;
+    hipEvent_t front = nullptr;  // the piece's bytes are on the device, inflated, CRCs computed (the set's own stream)
+    hipEvent_t freed = nullptr;  // the appends that read the set's columns last have run (parse stream)
+    bool freed_valid = false;
     bool pending = false;
     bool host_only = false;   // the piece was not sent to the device (4 GB or more: the kernels index with 32 bits)
     size_t off = 0, len = 0;  // the launched range of h_text (complete lines)
@@ -1988,7 +1991,8 @@ struct DevSet {
         if (h_sum) (void)hipHostFree(h_sum);
         for (void* q : {(void*)d_text, (void*)d_blocks, (void*)d_lines, (void*)d_s, (void*)d_e, (void*)d_q, (void*)d_t, (void*)d_sum})
             if (q) (void)hipFree(q);
-        if (done) (void)hipEventDestroy(done);
+        for (hipEvent_t ev : {done, front, freed})
+            if (ev) (void)hipEventDestroy(ev);
         *this = DevSet{};
     }
     bool ensure_host_comp(size_t comp_bytes) {
@@ -2051,7 +2055,9 @@ struct DevSet {
                   hipMalloc((void**)&d_s, lines * 4) == hipSuccess && hipMalloc((void**)&d_e, lines * 4) == hipSuccess &&
                   hipMalloc((void**)&d_q, lines) == hipSuccess && hipMalloc((void**)&d_t, lines) == hipSuccess &&
                   hipMalloc((void**)&d_sum, sizeof(ftk::TextSummary)) == hipSuccess &&
-                  hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess;
+                  hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&front, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&freed, hipEventDisableTiming) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
             release();
@@ -2080,6 +2086,7 @@ struct DevSetPool {
     }
     void give(int device, DevSet& s) {
         s.pending = false;
+        s.freed_valid = false;  // (the giver has synchronised its streams)
         {
             std::lock_guard<std::mutex> lk(mu);
             if (s.cap && idle.size() < 4) {
@@ -2131,17 +2138,45 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         (void)hipGetLastError();
         return fail(FTK_ERR_HIP, "cannot create the parse stream");
     }
-    DevSet sets[2] = {devset_pool().take(device), devset_pool().take(device)};
+    // Four buffer sets in a ring, settled two pieces behind the one being launched: while the parse stream works on
+    // piece k-1 (set-up, row parser, the appends of k-2), the FRONT of piece k - compressed bytes up, inflate and CRC
+    // kernels, nothing that depends on another piece - runs on the set's own stream beside piece k-1's front.
+    constexpr int kSets = 4, kLag = 2;
+    DevSet sets[kSets];
+    for (auto& S : sets) S = devset_pool().take(device);
+    hipStream_t fstream[kSets] = {};
+    for (auto& f : fstream)
+        if (hipStreamCreateWithFlags(&f, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            for (auto& g : fstream)
+                if (g) (void)hipStreamDestroy(g);
+            for (auto& S : sets) devset_pool().give(device, S);
+            return fail(FTK_ERR_HIP, "cannot create the inflate streams");
+        }
+    // FTK_DECODE_TIMING: the device time of every piece's front (copy up + inflate + CRC) and back (set-up + rows)
+    hipEvent_t tev[kSets][5] = {};  // front start, front end, back start, back end, bytes up
+    double front_ms = 0, front_max = 0, back_ms = 0, back_max = 0;
+    size_t n_timed = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    std::string trail;  // FTK_DECODE_TIMING=2: one line per settled piece
+    if (clk.on)
+        for (auto& row : tev)
+            for (auto& ev : row) (void)hipEventCreate(&ev);
     struct Cleanup {
         DevSet* s;
         int device;
         hipStream_t stream;
+        hipStream_t* fs;
         ~Cleanup() {
+            for (int k = 0; k < kSets; ++k) {
+                (void)hipStreamSynchronize(fs[k]);
+                (void)hipStreamDestroy(fs[k]);
+            }
             (void)hipStreamSynchronize(stream);  // nothing in flight touches the sets any more
-            devset_pool().give(device, s[0]);
-            devset_pool().give(device, s[1]);
+            for (int k = 0; k < kSets; ++k) devset_pool().give(device, s[k]);
         }
-    } cleanup{sets, device, pstream};
+    } cleanup{sets, device, pstream, fstream};
     std::vector<Block> blocks;
     size_t carry = 0;
     const uint8_t* carry_src = nullptr;
@@ -2175,7 +2210,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         return true;
     };
 
-    auto collect = [&](DevSet& S) -> bool {
+    auto collect_rows = [&](DevSet& S) -> bool {
         if (!S.host_only && hipEventSynchronize(S.done) != hipSuccess) {
             (void)hipGetLastError();
             return fail(FTK_ERR_HIP, "the device row parser failed");
@@ -2254,13 +2289,41 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         return true;
     };
 
+    // settle a piece: its rows to the current contig (device to device, on the parse stream), and behind them the
+    // event the set's next front waits for before it overwrites the buffers
+    auto collect = [&](DevSet& S) -> bool {
+        if (!collect_rows(S)) return false;
+        if (clk.on && S.inflated) {
+            const int j = (int)(&S - sets);
+            float f = 0, bk = 0, gap = 0;
+            if (hipEventElapsedTime(&f, tev[j][0], tev[j][1]) == hipSuccess && hipEventElapsedTime(&bk, tev[j][2], tev[j][3]) == hipSuccess) {
+                float up = 0;
+                (void)hipEventElapsedTime(&gap, tev[j][1], tev[j][2]);
+                (void)hipEventElapsedTime(&up, tev[j][0], tev[j][4]);
+                char line[200];
+                snprintf(line, sizeof line, "  settled at %.1f ms: front %.2f (bytes up %.2f), front end -> back start %.2f, back %.2f ms\n", now_ms(), f, up, gap, bk);
+                trail += line;
+                front_ms += f; front_max = std::max(front_max, (double)f);
+                back_ms += bk; back_max = std::max(back_max, (double)bk);
+                ++n_timed;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        S.freed_valid = hipEventRecord(S.freed, pstream) == hipSuccess;
+        if (!S.freed_valid) {
+            (void)hipGetLastError();
+            return fail(FTK_ERR_HIP, "cannot record a buffer set's release");
+        }
+        return true;
+    };
     bool eof = n < kStreamPiece;
-    DevSet* prev = nullptr;
-    for (int k = 0;; ++k) {
+    int k = 0;
+    for (;; ++k) {
         size_t used = 0, total = 0;
         if (!whole_blocks(buf.data(), n, eof, &blocks, &used, &total)) return fail(FTK_ERR_FORMAT, "corrupt BGZF block");
-        DevSet& S = sets[k & 1];
-        if (S.pending && !collect(S)) return false;
+        DevSet& S = sets[k % kSets];
+        if (S.pending) return fail(FTK_ERR_HIP, "buffer ring out of step");
         if (dev_inflate && total + ftk::kTextCarryMax + 64 < (size_t(1) << 32)) {
             // ---- the piece is inflated ON THE DEVICE: compressed bytes up, one wave per BGZF block, then the carry /
             // line-end set-up and the row parser on the text where it lies; the host never sees the text
@@ -2310,14 +2373,26 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             S.cut_tail = eof && partial_tail_ok;
             S.inflated = true;
             S.host_only = false;
-            DevSet* P = (k > 0 && sets[(k - 1) & 1].inflated) ? &sets[(k - 1) & 1] : nullptr;
-            bool ok = hipMemsetAsync(S.d_sum, 0, sizeof(ftk::TextSummary), pstream) == hipSuccess &&
-                      hipMemsetAsync(S.d_ist, 0, sizeof(ftk::InflateStatus), pstream) == hipSuccess &&
-                      (used == 0 || hipMemcpyAsync(S.d_comp, S.h_text, used, hipMemcpyHostToDevice, pstream) == hipSuccess) &&
+            DevSet* P = (k > 0 && sets[(k - 1) % kSets].inflated) ? &sets[(k - 1) % kSets] : nullptr;
+            hipStream_t front = fstream[k % kSets];
+            // front (this set's stream): behind the appends that read the set last, bytes up, inflate, CRC
+            bool ok = (!S.freed_valid || hipStreamWaitEvent(front, S.freed, 0) == hipSuccess) &&
+                      (!clk.on || hipEventRecord(tev[k % kSets][0], front) == hipSuccess) &&
+                      hipMemsetAsync(S.d_ist, 0, sizeof(ftk::InflateStatus), front) == hipSuccess &&
+                      (used == 0 || hipMemcpyAsync(S.d_comp, S.h_text, used, hipMemcpyHostToDevice, front) == hipSuccess) &&
                       (blocks.empty() || hipMemcpyAsync(S.d_tab, S.h_tab, blocks.size() * sizeof(ftk::InflateBlock),
-                                                        hipMemcpyHostToDevice, pstream) == hipSuccess);
+                                                        hipMemcpyHostToDevice, front) == hipSuccess);
+            if (ok && clk.on) ok = hipEventRecord(tev[k % kSets][4], front) == hipSuccess;
             if (ok) {
-                ftk::inflate_launch(pstream, S.d_comp, S.d_tab, (int)blocks.size(), S.d_text, S.d_ist, S.d_crc);
+                ftk::inflate_launch(front, S.d_comp, S.d_tab, (int)blocks.size(), S.d_text, S.d_ist, S.d_crc);
+                ok = hipGetLastError() == hipSuccess && (!clk.on || hipEventRecord(tev[k % kSets][1], front) == hipSuccess) &&
+                     hipEventRecord(S.front, front) == hipSuccess &&
+                     // back (the parse stream, piece after piece): carry from the previous piece, line ends, rows
+                     hipMemsetAsync(S.d_sum, 0, sizeof(ftk::TextSummary), pstream) == hipSuccess &&
+                     hipStreamWaitEvent(pstream, S.front, 0) == hipSuccess &&
+                     (!clk.on || hipEventRecord(tev[k % kSets][2], pstream) == hipSuccess);
+            }
+            if (ok) {
                 ftk::textparse_launch_inflated(pstream, S.d_text, ftk::kTextCarryMax, (uint32_t)total, P ? P->d_text : nullptr,
                                                P ? P->d_sum : nullptr, (uint32_t)std::min<size_t>(first_skip, total), eof, bed6,
                                                S.d_blocks, S.d_lines, S.max_lines, S.d_s, S.d_e, S.d_q, S.d_t, S.d_sum);
@@ -2325,6 +2400,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
                      hipMemcpyAsync(S.h_sum, S.d_sum, sizeof(ftk::TextSummary), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
                      hipMemcpyAsync(S.h_ist, S.d_ist, sizeof(ftk::InflateStatus), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
                      (blocks.empty() || hipMemcpyAsync(S.h_crc, S.d_crc, blocks.size() * 4, hipMemcpyDeviceToHost, pstream) == hipSuccess) &&
+                     (!clk.on || hipEventRecord(tev[k % kSets][3], pstream) == hipSuccess) &&
                      hipEventRecord(S.done, pstream) == hipSuccess;
             }
             if (!ok) {
@@ -2334,9 +2410,9 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             first_skip = 0;
             S.pending = true;
             clk.lap(1);
-            if (prev && prev->pending && !collect(*prev)) return false;
+            // this piece is on its way: settle the one two back (its set is the one piece k+2 stages into)
+            if (k >= kLag && sets[(k - kLag) % kSets].pending && !collect(sets[(k - kLag) % kSets])) return false;
             clk.lap(3);
-            prev = &S;
             if (eof) break;
             const size_t raw_carry_d = n - used;
             if (raw_carry_d) memmove(buf.data(), buf.data() + used, raw_carry_d);
@@ -2409,10 +2485,8 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         clk.lap(2);
         carry = (size_t)(e - last);
         carry_src = (const uint8_t*)last;
-        // the GPU is busy with this piece: settle the previous one
-        if (prev && prev->pending && !collect(*prev)) return false;
+        if (k >= kLag && sets[(k - kLag) % kSets].pending && !collect(sets[(k - kLag) % kSets])) return false;
         clk.lap(3);
-        prev = &S;
         if (eof) break;
         const size_t raw_carry = n - used;
         if (raw_carry) memmove(buf.data(), buf.data() + used, raw_carry);
@@ -2425,12 +2499,20 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             if (stop) return false;
         }
     }
-    if (prev && prev->pending && !collect(*prev)) return false;
+    for (int j = std::max(0, k - kLag + 1); j <= k; ++j)  // the pieces still in flight, in file order
+        if (sets[j % kSets].pending && !collect(sets[j % kSets])) return false;
     clk.lap(3);
     if (have_cur && !emit_device(std::move(cur))) return false;
     clk.lap(4);
     clk.report("text, device rows (parse = launch, merge = collect)");
     if (clk.on) fprintf(stderr, "[ftk stream text] %zu pieces parsed on the device, %zu by the host\n", gpu_pieces, host_pieces);
+    if (clk.on && n_timed)
+        fprintf(stderr, "[ftk stream text] device time per piece: front (copy up, inflate, CRC) avg %.2f max %.2f ms, back (set-up, rows) avg %.2f max %.2f ms, %zu pieces\n",
+                front_ms / n_timed, front_max, back_ms / n_timed, back_max, n_timed);
+    if (clk.on && atoi(getenv("FTK_DECODE_TIMING")) >= 2) fputs(trail.c_str(), stderr);
+    for (auto& row : tev)
+        for (auto& ev : row)
+            if (ev) (void)hipEventDestroy(ev);
     return true;
 }
 
