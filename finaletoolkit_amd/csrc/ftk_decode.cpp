@@ -2168,15 +2168,20 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         int device;
         hipStream_t stream;
         hipStream_t* fs;
+        hipEvent_t (*tev)[5];
         ~Cleanup() {
             for (int k = 0; k < kSets; ++k) {
                 (void)hipStreamSynchronize(fs[k]);
                 (void)hipStreamDestroy(fs[k]);
             }
             (void)hipStreamSynchronize(stream);  // nothing in flight touches the sets any more
-            for (int k = 0; k < kSets; ++k) devset_pool().give(device, s[k]);
+            for (int k = 0; k < kSets; ++k) {
+                devset_pool().give(device, s[k]);
+                for (hipEvent_t ev : tev[k])
+                    if (ev) (void)hipEventDestroy(ev);
+            }
         }
-    } cleanup{sets, device, pstream, fstream};
+    } cleanup{sets, device, pstream, fstream, tev};
     std::vector<Block> blocks;
     size_t carry = 0;
     const uint8_t* carry_src = nullptr;
@@ -2510,9 +2515,6 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         fprintf(stderr, "[ftk stream text] device time per piece: front (copy up, inflate, CRC) avg %.2f max %.2f ms, back (set-up, rows) avg %.2f max %.2f ms, %zu pieces\n",
                 front_ms / n_timed, front_max, back_ms / n_timed, back_max, n_timed);
     if (clk.on && atoi(getenv("FTK_DECODE_TIMING")) >= 2) fputs(trail.c_str(), stderr);
-    for (auto& row : tev)
-        for (auto& ev : row)
-            if (ev) (void)hipEventDestroy(ev);
     return true;
 }
 
