@@ -49,11 +49,6 @@ struct __align__(16) WaveLds {
 
 #define UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
 
-// Lane `idx` of `old` becomes `value` (both uniform): a compare and a select on the vector unit -- which the
-// decode loop, all scalar otherwise, leaves idle (v_writelane_b32 would take a scalar move to M0 as well: two
-// scalar registers exceed the constant bus).
-__device__ __forceinline__ int write_lane(int old, int value, int idx, int lane) { return lane == idx ? value : old; }
-
 struct Bits {
     const uint32_t* w;  // the compressed buffer as aligned words
     uint32_t end_word;  // first word index behind the payload
@@ -352,43 +347,46 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
         build_pairs(L, lane);
         build_dist(L, lane);
         // ---- the symbols of this DEFLATE block --------------------------------------------------------
-        // Literals collect in a register (lane k = k-th pending byte, v_writelane) and go to the ring 63-64 at a time.
-        int vlit = 0, nlit = 0;
-        auto put_literals = [&]() {
-            if (A + (uint32_t)nlit > A_end) { err = kInflateOverrun; nlit = 0; return; }
-            if (lane < nlit) L.ring[(A + (uint32_t)lane) & kRingMask] = (uint8_t)vlit;
+        // Literals: lane k looks up the symbol that would start k bits ahead (one LDS gather); the wave then hops from
+        // symbol to symbol through that register - one v_readlane and a handful of scalar operations per hop, the
+        // hops marked in two 64-bit masks (on the chain / a pair of literals) - for as long as the symbols are
+        // literals and their root bits lie inside the valid part of the bit buffer.  Then the marked lanes write
+        // their own one or two bytes to the ring, at the rank the masks give them (v_mbcnt): no per-literal vector
+        // work, no pending-literal register.
+        auto advance = [&](uint32_t n) {  // n bytes were written at A
             const uint32_t A0 = A;
-            A += (uint32_t)nlit;
-            nlit = 0;
+            A += n;
             if ((A >> kGranShift) != (A0 >> kGranShift)) flush(A0 >> kGranShift);
         };
         for (;;) {
             b.refill(lane);
-            // Lane k looks up the symbol that would start k bits ahead; the wave then hops from symbol to symbol
-            // through that register (one v_readlane per hop instead of one LDS round trip) for as long as the
-            // symbols are literals and their root bits lie inside the valid part of the bit buffer.
             const unsigned E = L.pair[(unsigned)(b.buf >> lane) & ((1u << kLitRoot) - 1u)];
             const int limit = b.cnt - kLitRoot;
             int pos = 0;
-            unsigned e, kind;
+            uint64_t on_chain = 0, pairs = 0;
+            unsigned e;
             for (;;) {
                 e = (unsigned)__builtin_amdgcn_readlane((int)E, pos);
-                kind = (e >> 5) & 3u;
-                if (!kind) break;
-                vlit = write_lane(vlit, (int)((e >> 8) & 255u), nlit, lane);
-                if (kind == 2u) vlit = write_lane(vlit, (int)(e >> 20), nlit + 1, lane);
-                nlit += (int)kind;
+                if (!(e & 0x60u)) break;  // no literal entry
+                on_chain |= 1ull << pos;
+                pairs |= (uint64_t)((e >> 6) & 1u) << pos;
                 pos += (int)(e & 31u);
-                if (nlit >= 63 || pos > limit) break;
+                if (pos > limit) break;
             }
-            b.drop(pos);
-            if (kind) {
-                if (nlit >= 63) {
-                    put_literals();
-                    if (err != kInflateOk) break;
+            if (on_chain) {
+                const uint32_t total = (uint32_t)(__popcll(on_chain) + __popcll(pairs));
+                if (A + total > A_end) { err = kInflateOverrun; break; }
+                const unsigned before = __builtin_amdgcn_mbcnt_hi((unsigned)(on_chain >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)on_chain, 0u)) +
+                                        __builtin_amdgcn_mbcnt_hi((unsigned)(pairs >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pairs, 0u));
+                if ((on_chain >> lane) & 1ull) {
+                    const uint32_t at = A + before;
+                    L.ring[at & kRingMask] = (uint8_t)(E >> 8);
+                    if ((pairs >> lane) & 1ull) L.ring[(at + 1u) & kRingMask] = (uint8_t)(E >> 20);
                 }
-                continue;
+                advance(total);
+                b.drop(pos);
             }
+            if (e & 0x60u) continue;  // out of valid bits, not of literals
             b.refill(lane);  // the symbol at the front is no literal: its code and extra bits take up to 20
             unsigned le = e;  // length entry: bits | base << 8 | extra bits << 20 (base 0: end of block)
             if (e) {
@@ -397,11 +395,9 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                 const int sym = decode_long(L, b, 0);  // a code longer than the root: bit by bit
                 if (sym < 0) { err = kInflateBadSymbol; break; }
                 if (sym < 256) {
-                    vlit = write_lane(vlit, sym, nlit, lane);
-                    if (++nlit >= 63) {
-                        put_literals();
-                        if (err != kInflateOk) break;
-                    }
+                    if (A + 1u > A_end) { err = kInflateOverrun; break; }
+                    if (lane == 0) L.ring[A & kRingMask] = (uint8_t)sym;
+                    advance(1u);
                     continue;
                 }
                 const unsigned ls = (unsigned)sym - 257u;
@@ -412,10 +408,6 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                 else if (ls < 28u) { eb = (ls >> 2) - 1u; base = ((4u + (ls & 3u)) << eb) + 3u; }
                 else base = 511u;
                 le = (base << 8) | (eb << 20);
-            }
-            if (nlit) {
-                put_literals();
-                if (err != kInflateOk) break;
             }
             const unsigned lbase = (le >> 8) & 511u;
             if (lbase == 0) break;  // end of block
@@ -465,7 +457,6 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
             A = A0 + (uint32_t)len;
             if ((A >> kGranShift) != (A0 >> kGranShift)) flush(A0 >> kGranShift);
         }
-        if (nlit && err == kInflateOk) put_literals();
     }
     if (err == kInflateOk && A != A_end) err = kInflateShort;
     // the unfinished granule
