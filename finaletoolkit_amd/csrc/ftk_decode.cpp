@@ -896,19 +896,76 @@ Contig* find_or_add(ftk_fragtable* t, const std::string& name) {
 }
 
 // Sort 64-bit keys: one chunk per thread, then pairwise merges level by level.  Returns the thread count used.
-int sort_keys(std::vector<uint64_t>& key, int n_threads) {
-    const size_t m = key.size();
+// Keys are (fragment start << 32 | file rank).  Large inputs go through one counting pass on 4 096-base buckets of
+// the start coordinate (per-thread histograms, a stable scatter) and a small sort per bucket, every step on all
+// threads: 2 passes over the keys instead of a chunk sort and log2(threads) merge levels of which the last run on one
+// or two threads (4.8 M keys of a 60x BAM slice on 16 threads: 25 -> 6 ms).
+bool bucket_sort_keys(uint64_t* key, size_t m, int nt) {
+    constexpr int kShift = 32 + 12;
+    uint64_t top = 0;
+    {
+        std::vector<uint64_t> tmax(nt, 0);
+        parallel_run(nt, [&](int t) {
+            uint64_t mx = 0;
+            for (size_t i = m * (size_t)t / (size_t)nt, e = m * (size_t)(t + 1) / (size_t)nt; i < e; ++i) mx = std::max(mx, key[i]);
+            tmax[t] = mx;
+        });
+        for (uint64_t v : tmax) top = std::max(top, v);
+    }
+    const size_t nb = (size_t)(top >> kShift) + 1;
+    if (nb > (size_t(1) << 20) || nb * (size_t)nt > m) return false;  // few keys per bucket: the histograms would dominate
+    std::vector<uint32_t> cnt(nb * (size_t)nt, 0);
+    parallel_run(nt, [&](int t) {
+        uint32_t* c = cnt.data() + nb * (size_t)t;
+        for (size_t i = m * (size_t)t / (size_t)nt, e = m * (size_t)(t + 1) / (size_t)nt; i < e; ++i) ++c[key[i] >> kShift];
+    });
+    std::vector<size_t> first(nb + 1);
+    size_t run = 0;
+    for (size_t b = 0; b < nb; ++b) {  // bucket by bucket, thread by thread inside: stable
+        first[b] = run;
+        for (int t = 0; t < nt; ++t) {
+            const uint32_t c = cnt[nb * (size_t)t + b];
+            cnt[nb * (size_t)t + b] = (uint32_t)(run - first[b]);  // the thread's offset inside the bucket
+            run += c;
+        }
+    }
+    first[nb] = run;
+    std::unique_ptr<uint64_t[]> tmp(new uint64_t[m]);  // (not zeroed: the scatter's threads touch its pages first)
+    parallel_run(nt, [&](int t) {
+        uint32_t* c = cnt.data() + nb * (size_t)t;
+        for (size_t i = m * (size_t)t / (size_t)nt, e = m * (size_t)(t + 1) / (size_t)nt; i < e; ++i) {
+            const size_t b = (size_t)(key[i] >> kShift);
+            tmp[first[b] + c[b]++] = key[i];
+        }
+    });
+    parallel_run(nt, [&](int t) {  // buckets dealt by position in the output: equal shares of the keys
+        const size_t lo = m * (size_t)t / (size_t)nt, hi = m * (size_t)(t + 1) / (size_t)nt;
+        size_t b = (size_t)(std::upper_bound(first.begin(), first.end(), lo) - first.begin());
+        if (b) --b;
+        if (first[b] < lo) ++b;  // a bucket belongs to the thread its first key falls to
+        for (; b < nb && first[b] < hi; ++b) {
+            uint64_t* a = tmp.get() + first[b];
+            uint64_t* z = tmp.get() + first[b + 1];
+            if (z - a > 1 && !std::is_sorted(a, z)) std::sort(a, z);
+            std::copy(a, z, key + first[b]);
+        }
+    });
+    return true;
+}
+
+int sort_keys(uint64_t* key, size_t m, int n_threads) {
     const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(n_threads, 1), m / 65536));
     if (nt == 1) {
-        std::sort(key.begin(), key.end());
+        std::sort(key, key + m);
         return nt;
     }
-    std::vector<uint64_t> tmp(m);
+    if (bucket_sort_keys(key, m, nt)) return nt;
+    std::unique_ptr<uint64_t[]> tmp(new uint64_t[m]);
     std::vector<size_t> cut(nt + 1);
     for (int t = 0; t <= nt; ++t) cut[t] = m * (size_t)t / (size_t)nt;
-    parallel_run(nt, [&](int t) { std::sort(key.begin() + cut[t], key.begin() + cut[t + 1]); });
-    uint64_t* src = key.data();
-    uint64_t* dst = tmp.data();
+    parallel_run(nt, [&](int t) { std::sort(key + cut[t], key + cut[t + 1]); });
+    uint64_t* src = key;
+    uint64_t* dst = tmp.get();
     while (cut.size() > 2) {  // merge neighbours; an odd last chunk is copied through
         const size_t n_chunks = cut.size() - 1, n_pairs = n_chunks / 2;
         parallel_run((int)((n_chunks + 1) / 2), [&](int t) {
@@ -922,7 +979,7 @@ int sort_keys(std::vector<uint64_t>& key, int n_threads) {
         cut.swap(next);
         std::swap(src, dst);
     }
-    if (src != key.data()) key.swap(tmp);
+    if (src != key) memcpy(key, src, m * sizeof(uint64_t));
     return nt;
 }
 
@@ -940,7 +997,7 @@ void sort_by_start(Columns& c, int n_threads = 1) {
     if (std::is_sorted(c.start.begin(), c.start.end())) return;
     std::vector<uint64_t> key(m);
     for (size_t i = 0; i < m; ++i) key[i] = ((uint64_t)(uint32_t)c.start[i] << 32) | (uint64_t)i;  // starts are >= 0
-    const int nt = sort_keys(key, n_threads);
+    const int nt = sort_keys(key.data(), m, n_threads);
     Columns s;
     const bool r1 = !c.r1s.empty();
     s.start.resize(m); s.end.resize(m); s.mapq.resize(m); s.strand.resize(m);
@@ -1349,6 +1406,7 @@ void pack_parts(Contig& ct, int n_threads) {
 // keys (start << 32 | file rank) built, sorted and merged in parallel, then every column gathered from
 // the runs straight into its final place - no concatenated or sorted intermediate copy of the contig.
 void pack_bam_parts(Contig& ct, int n_threads) {
+    Stopwatch sw;
     std::vector<size_t> at;
     size_t m = 0;
     for (auto& c : ct.parts) { at.push_back(m); m += c.start.size(); }
@@ -1363,22 +1421,33 @@ void pack_bam_parts(Contig& ct, int n_threads) {
     }
     if (!p.base) return;
     place(p, (char*)p.base, m, true);
+    sw.lap("  packer: block");
     const size_t np = ct.parts.size();
     if (m) {
-        std::vector<uint64_t> key(m);
+        std::unique_ptr<uint64_t[]> key(new uint64_t[m]);  // (not zeroed: the threads below write every key)
+        std::atomic<int> unsorted{0};
         {
             std::atomic<size_t> next{0};
             parallel_run((int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, np)), [&](int) {
+                bool bad = false;
                 for (;;) {
                     const size_t k = next.fetch_add(1);
                     if (k >= np) break;
                     const std::vector<int32_t>& st = ct.parts[k].start;
-                    for (size_t i = 0; i < st.size(); ++i) key[at[k] + i] = ((uint64_t)(uint32_t)st[i] << 32) | (uint64_t)(at[k] + i);
+                    for (size_t i = 0; i < st.size(); ++i) {
+                        key[at[k] + i] = ((uint64_t)(uint32_t)st[i] << 32) | (uint64_t)(at[k] + i);
+                        bad |= i > 0 && st[i] < st[i - 1];
+                    }
+                    // (across parts: the first start of this one against the last of the one before)
+                    if (k > 0 && !st.empty() && !ct.parts[k - 1].start.empty()) bad |= st.front() < ct.parts[k - 1].start.back();
                 }
+                if (bad) unsorted.store(1);
             });
         }
         int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(n_threads, 1), m / 65536));
-        if (!std::is_sorted(key.begin(), key.end())) nt = sort_keys(key, n_threads);
+        sw.lap("  packer: keys");
+        if (unsorted.load()) nt = sort_keys(key.get(), m, n_threads);
+        sw.lap("  packer: sort");
         parallel_run(nt, [&](int t) {
             size_t k = 0;
             for (size_t i = m * (size_t)t / (size_t)nt, e = m * (size_t)(t + 1) / (size_t)nt; i < e; ++i) {
@@ -1397,7 +1466,9 @@ void pack_bam_parts(Contig& ct, int n_threads) {
             }
         });
     }
+    sw.lap("  packer: gather");
     std::vector<Columns>().swap(ct.parts);
+    sw.lap("  packer: free parts");
 }
 
 // Complete text lines [b, e) -> runs in file order (segments parsed in parallel).
@@ -1431,26 +1502,41 @@ inline bool plausible_record(const uint8_t* p, size_t o, size_t m, int n_ref) {
     if (ref < -1 || ref >= n_ref || next_ref < -1 || next_ref >= n_ref || pos < -1 || next_pos < -1) return false;
     const uint32_t l_name = r[8], n_cigar = rd_u16(r + 12);
     const int32_t l_seq = rd_i32(r + 16);
-    if (l_name == 0 || l_seq < 0) return false;
+    if (l_name < 2 || l_seq < 0) return false;  // (a missing name is "*": never empty)
+    if (rd_u16(r + 14) & 0xf000) return false;   // undefined flag bits
     const uint64_t need = 32 + (uint64_t)l_name + 4ull * n_cigar + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq;
     if (need > bs) return false;
-    if (o + 36 + l_name <= m && r[32 + l_name - 1] != 0) return false;  // the read name is NUL-terminated
+    if (o + 36 + l_name <= m) {  // the read name: printable characters, NUL-terminated
+        if (r[32 + l_name - 1] != 0) return false;
+        for (uint32_t k = 0; k + 1 < l_name; ++k)
+            if (r[32 + k] < 33 || r[32 + k] > 126) return false;
+    }
     return true;
 }
 
 inline size_t guess_record_start(const uint8_t* p, size_t from, size_t m, int n_ref) {
+    // A candidate whose very first link leaves the piece proves nothing - and two bytes in front of a real record
+    // of reference 0 there is one: the low half of the real block_size lands in the high half of a 32-bit size of
+    // megabytes, the zeros behind it read as reference 0 (11 % of the stretches of a 60x file were redone for
+    // that).  Such a candidate is kept only as a fallback for when nothing checkable follows.
+    size_t fallback = SIZE_MAX;
     for (size_t o = from; o + 36 <= m; ++o) {
         if (!plausible_record(p, o, m, n_ref)) continue;
         size_t o2 = o + 4 + (size_t)rd_u32(p + o);
         bool ok = true;
+        int checked = 0;
         for (int k = 0; k < 2; ++k) {  // two more links must hold, unless the piece ends first
             if (o2 + 36 > m) break;
             if (!plausible_record(p, o2, m, n_ref)) { ok = false; break; }
+            ++checked;
             o2 += 4 + (size_t)rd_u32(p + o2);
         }
-        if (ok) return o;
+        if (!ok) continue;
+        if (checked) return o;
+        if (fallback == SIZE_MAX) fallback = o;
+        if (o - from > (size_t(1) << 16)) break;  // (do not scan a long unverifiable tail byte by byte)
     }
-    return SIZE_MAX;
+    return fallback;
 }
 
 // One BAM alignment record -> fragment columns (io/alignment.py:60-71,242-268); false = not a fragment.
@@ -1674,7 +1760,39 @@ struct ftk_fragstream {
             const long long pos = ftell(fp);
             want = pos >= read_end ? 0 : (size_t)std::min<long long>((long long)kStreamPiece, read_end - pos);
         }
-        const size_t got = want ? fread(dst, 1, want, fp) : 0;
+        size_t got = 0;
+        bool done = false;
+        if (want >= (size_t(8) << 20)) {
+            // a large piece of a regular file: four threads pread their quarters (one thread copies ~6 GB/s out of
+            // the page cache - 8 ms per 48 MB piece, as long as the GPU takes to inflate it)
+            const long long pos = ftell(fp);
+            struct stat sb;
+            if (pos >= 0 && fstat(fileno(fp), &sb) == 0 && S_ISREG(sb.st_mode) && (long long)sb.st_size > pos) {
+                const size_t n = (size_t)std::min<long long>((long long)want, (long long)sb.st_size - pos);
+                constexpr int kReaders = 4;
+                std::atomic<int> failed{0};
+                auto part = [&](int t) {
+                    size_t a = n * (size_t)t / kReaders;
+                    const size_t b = n * (size_t)(t + 1) / kReaders;
+                    while (a < b) {
+                        const ssize_t r = pread(fileno(fp), dst + a, b - a, (off_t)(pos + (long long)a));
+                        if (r <= 0) { failed.store(1); return; }
+                        a += (size_t)r;
+                    }
+                };
+                std::thread helpers[kReaders - 1];
+                for (int t = 1; t < kReaders; ++t) helpers[t - 1] = std::thread(part, t);
+                part(0);
+                for (auto& h : helpers) h.join();
+                if (!failed.load() && fseek(fp, (long)(pos + (long long)n), SEEK_SET) == 0) {
+                    got = n;
+                    done = true;
+                } else if (fseek(fp, (long)pos, SEEK_SET) != 0) {
+                    return 0;
+                }
+            }
+        }
+        if (!done) got = want ? fread(dst, 1, want, fp) : 0;
         if (got == want && want) {
             // ask the kernel for the piece after this one (a hint only; failure is ignored)
             const long long pos = ftell(fp);
@@ -2810,6 +2928,9 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
                 ++n_stretches;
                 if (seg[k].start != o || seg[k].bad) {
                     ++n_redone;
+                    if (clk.on && getenv("FTK_DECODE_TIMING")[0] >= '2')
+                        fprintf(stderr, "[ftk stream bam] stretch %d of %d redone: guessed %zd, chain at %zu, bound %zu, piece %zu bytes%s\n", k, nseg,
+                                seg[k].start == SIZE_MAX ? (ssize_t)-1 : (ssize_t)seg[k].start, o, bound(k), m, seg[k].bad ? " (bad)" : "");
                     walk(o, bound(k + 1), seg[k]);
                     if (seg[k].bad) return fail(FTK_ERR_FORMAT, "corrupt BAM record");
                 }

@@ -150,10 +150,11 @@ def test_bam_stretch_guess_survives_decoy_records(tmp_path):
     a["l_name"], a["n_cigar"], a["l_seq"], a["cigar"] = 8, 1, read, read << 4
     a["pos"], a["next_pos"], a["tlen"], a["flag"], a["mapq"] = s, s + length - read, length, 99, 60
     a["name"] = np.char.zfill(np.arange(n).astype("U7"), 7).astype("S8")
-    decoy = struct.pack("<iiiBBHHHiiii", 33, 0, 777, 1, 60, 0, 0, 99, 0, 0, 900, 222) + b"\0"  # 37 bytes, a valid chain link
-    assert len(decoy) == 37
+    # 38 bytes, a valid chain link: block_size 34, a one-letter read name, flags of a proper read1
+    decoy = struct.pack("<iiiBBHHHiiii", 34, 0, 777, 2, 60, 0, 0, 99, 0, 0, 900, 222) + b"A\0"
+    assert len(decoy) == 38
     q = np.full(read, 30, np.uint8)
-    q[20:20 + 111] = np.frombuffer(decoy * 3, np.uint8)
+    q[20:20 + 114] = np.frombuffer(decoy * 3, np.uint8)
     a["qual"] = q
     text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chrD\tLN:%d\n" % size
     head = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1)
