@@ -2440,6 +2440,24 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         }
         return true;
     };
+    // Settle, in file order, every piece up to k whose results are already back, and wait for those that are kLag
+    // or more behind (their sets come up for reuse).
+    int settled = 0;
+    auto settle = [&](int k, bool all) -> bool {
+        while (settled <= k) {
+            DevSet& Q = sets[settled % kSets];
+            if (Q.pending) {
+                const bool must = all || settled <= k - kLag;
+                if (!must && !Q.host_only && hipEventQuery(Q.done) != hipSuccess) {
+                    (void)hipGetLastError();  // (not ready is no error)
+                    break;
+                }
+                if (!collect(Q)) return false;
+            }
+            ++settled;
+        }
+        return true;
+    };
     bool eof = n < kStreamPiece;
     int k = 0;
     for (;; ++k) {
@@ -2533,8 +2551,9 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             first_skip = 0;
             S.pending = true;
             clk.lap(1);
-            // this piece is on its way: settle the one two back (its set is the one piece k+2 stages into)
-            if (k >= kLag && sets[(k - kLag) % kSets].pending && !collect(sets[(k - kLag) % kSets])) return false;
+            // this piece is on its way: settle what is back already, and the piece two back in any case (its set is
+            // the one piece k+2 stages into)
+            if (!settle(k, false)) return false;
             clk.lap(3);
             if (eof) break;
             const size_t raw_carry_d = n - used;
@@ -2608,7 +2627,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         clk.lap(2);
         carry = (size_t)(e - last);
         carry_src = (const uint8_t*)last;
-        if (k >= kLag && sets[(k - kLag) % kSets].pending && !collect(sets[(k - kLag) % kSets])) return false;
+        if (!settle(k, false)) return false;
         clk.lap(3);
         if (eof) break;
         const size_t raw_carry = n - used;
@@ -2622,8 +2641,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             if (stop) return false;
         }
     }
-    for (int j = std::max(0, k - kLag + 1); j <= k; ++j)  // the pieces still in flight, in file order
-        if (sets[j % kSets].pending && !collect(sets[j % kSets])) return false;
+    if (!settle(k, true)) return false;  // the pieces still in flight, in file order
     clk.lap(3);
     if (have_cur && !emit_device(std::move(cur))) return false;
     clk.lap(4);
