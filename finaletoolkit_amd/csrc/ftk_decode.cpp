@@ -696,7 +696,9 @@ public:
     }
 };
 
-int inflate_block_list(const uint8_t* p, const std::vector<Block>& blocks, int n_threads, uint8_t* out) {
+// own_threads: threads of this call's own (the pool runs one region at a time; a job beside the producer's regions
+// must not hold it for the length of a whole piece)
+int inflate_block_list(const uint8_t* p, const std::vector<Block>& blocks, int n_threads, uint8_t* out, bool own_threads = false) {
     std::atomic<size_t> next{0};
     std::atomic<int> bad{0};
     auto work = [&]() {
@@ -713,7 +715,14 @@ int inflate_block_list(const uint8_t* p, const std::vector<Block>& blocks, int n
         }
     };
     int nt = std::max(1, std::min<int>(n_threads, (int)blocks.size()));
-    parallel_run(nt, [&](int) { work(); });
+    if (own_threads) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+    } else {
+        parallel_run(nt, [&](int) { work(); });
+    }
     return bad.load() ? FTK_ERR_FORMAT : FTK_OK;
 }
 
@@ -2715,10 +2724,50 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
             }
         }
     } cleanup{sets, device, streams, dinf};
-    auto submit = [&](Piece& pc, int slot) -> bool {
+    // Every third piece of the look-ahead is inflated by the host threads instead (straight into its slot's
+    // page-locked output, while the GPU works on the two in front of it): the chip turns a 64 KB block of BAM over
+    // every 2.7 us = 24 GB/s of records, the 16 threads manage 11 GB/s, and between record walks they have nothing
+    // else to do.  FTK_BAM_HOST_SHARE=<n>: every n-th piece (0: none).
+    static const int host_share = [] {
+        const char* e = getenv("FTK_BAM_HOST_SHARE");
+        return e ? atoi(e) : 3;
+    }();
+    bool slot_on_host[kSlots] = {};
+    std::future<int> host_job[kSlots];  // the host threads' inflate of a slot's piece (from the slot's own copy of the bytes)
+    struct JobGuard {  // no job outlives the buffers it works on
+        std::future<int>* j;
+        ~JobGuard() {
+            for (int k = 0; k < kSlots; ++k)
+                if (j[k].valid()) (void)j[k].get();
+        }
+    } job_guard{host_job};
+    auto submit = [&](Piece& pc, int index) -> bool {  // index: the piece's number among the submitted ones
+        const int slot = index % kSlots;
         DevSet& S = sets[slot];
         hipStream_t pstream = streams[slot];  // (shadows the member: this slot's stream)
         if (pc.total + kRoom + 64 >= (size_t(1) << 32)) return fail(FTK_ERR_FORMAT, "BGZF piece too large");
+        slot_on_host[slot] = host_share > 0 && header_done && (index % host_share) == host_share - 1;
+        if (slot_on_host[slot]) {
+            if (!S.ensure(kRoom + pc.total + 64) || !S.ensure_host_comp(pc.used + 64))
+                return fail(FTK_ERR_OOM, "out of page-locked memory for the BAM piece");
+            {
+                const size_t used = pc.used;
+                const int nt = std::max(1, std::min(n_threads, (int)(used >> 20) + 1));
+                const uint8_t* src = buf.data();
+                uint8_t* dst = S.h_comp;
+                parallel_run(nt, [&](int t) {
+                    const size_t a = used * (size_t)t / nt, b2 = used * (size_t)(t + 1) / nt;
+                    memcpy(dst + a, src + a, b2 - a);
+                });
+            }
+            // (the job owns its block list; the bytes stay in the slot until the piece has been walked)
+            host_job[slot] = std::async(std::launch::async, [blocks = pc.blocks, comp = (const uint8_t*)S.h_comp,
+                                                             out = S.h_text + kRoom, nt = std::max(1, n_threads - 2)] {
+                return blocks.empty() ? (int)FTK_OK : inflate_block_list(comp, blocks, nt, out, true);
+            });
+            pc.slot = slot;
+            return true;
+        }
         if (!S.ensure(kRoom + pc.total + 64) || !S.ensure_inflate(pc.used, pc.blocks.size()) || !S.ensure_host_comp(pc.used + 64))
             return fail(FTK_ERR_OOM, "out of page-locked / device memory for the BAM piece");
         {
@@ -2759,6 +2808,10 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
     };
     auto wait_slot = [&](int slot) -> bool {
         DevSet& S = sets[slot];
+        if (slot_on_host[slot]) {  // inflated by the host threads
+            if (host_job[slot].valid() && host_job[slot].get() != FTK_OK) return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+            return true;
+        }
         if (hipEventSynchronize(S.done) != hipSuccess) {
             (void)hipGetLastError();
             return fail(FTK_ERR_HIP, "the device inflate failed");
@@ -2781,7 +2834,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
     int n_submitted = 0;
     for (;;) {
         if (!list_blocks(curp)) return false;
-        if (dinf && curp.slot < 0 && !submit(curp, n_submitted++ % kSlots)) return false;
+        if (dinf && curp.slot < 0 && !submit(curp, n_submitted++)) return false;
         // read the next pieces and start their inflate before this piece's records are walked (not while the header
         // is still being probed: an index seek may throw those reads away).  `buf` holds the compressed bytes of the
         // piece read last - the newest of `ahead`, or curp.
@@ -2796,7 +2849,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
                 np.n = fill(buf, raw_carry);
                 clk.lap(0);
                 np.eof = np.n - raw_carry < kStreamPiece;
-                if (!list_blocks(np) || !submit(np, n_submitted++ % kSlots)) return false;
+                if (!list_blocks(np) || !submit(np, n_submitted++)) return false;
                 ahead.push_back(std::move(np));
             }
         }
