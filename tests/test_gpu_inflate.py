@@ -179,3 +179,76 @@ def test_bam_stream_many_pieces_through_the_slot_ring(tmp_path, piece):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] and outs[0].startswith("ok")
+
+
+_BAM_MULTI_CHILD = r"""
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, {root!r})
+import torch  # noqa: F401  (one HIP runtime in the process)
+from finaletoolkit_amd import _lib as L
+from tests.test_stream_decoder import _same
+from tests.test_abi import _decode
+lib = L.load()
+path = sys.argv[1]
+
+
+def stream(contig=None, threads=4):
+    s = C.c_void_p()
+    rc = lib.ftk_fragstream_open_device(0, path.encode(), None if contig is None else contig.encode(), 1, threads, 2, C.byref(s))
+    assert rc == 0, lib.ftk_fragtable_error().decode()
+    out, order = {{}}, []
+    while True:
+        t = C.c_void_p()
+        rc = lib.ftk_fragstream_next(s, C.byref(t))
+        assert rc == 0, lib.ftk_fragtable_error().decode()
+        if not t.value:
+            break
+        rows = lib.ftk_fragtable_contig_rows(t, 0)
+        name = lib.ftk_fragtable_contig_name(t, 0).decode()
+        ps = [C.c_void_p() for _ in range(6)]
+        assert lib.ftk_fragtable_columns(t, 0, *[C.byref(p) for p in ps]) == 0
+        cols = [None if not p.value or rows == 0 else np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), (rows,)).copy()
+                for p, ct in zip(ps, (C.c_int32, C.c_int32, C.c_uint8, C.c_uint8, C.c_int32, C.c_int32))]
+        out[name] = (rows, cols, lib.ftk_fragtable_contig_length(t, 0))
+        order.append(name)
+        lib.ftk_fragtable_free(t)
+    lib.ftk_fragstream_close(s)
+    return out, order
+
+
+want = _decode(path, bam=True)
+for threads in (1, 8):
+    got, order = stream(threads=threads)
+    _same(got, want)
+only, order1 = stream("chrB")
+assert order1 == ["chrB"], order1
+_same(only, {{k: v for k, v in want.items() if k in ("chrB",) or k.startswith("__")}})
+print("ok", order)
+"""
+
+
+@pytest.mark.parametrize("piece,host_share", [(1 << 16, "3"), (1 << 16, "0"), (1 << 16, "1"), (1 << 18, "2")])
+def test_bam_multi_contig_through_the_slot_ring(tmp_path, piece, host_share):
+    """Three contigs with fragments and one without, unmapped / secondary / duplicate records in between
+    (tests/helpers.write_synthetic_bam), read in 64 KB pieces through ftk_fragstream_open_device: contig changes inside
+    pieces, records cut by piece ends, the BAI seek for one contig, every share of the pieces inflated by the host
+    threads beside the GPU (FTK_BAM_HOST_SHARE 0 / 1 / 2 / 3) - the tables are those of the whole-file host decoder."""
+    import os
+    import subprocess
+    import sys
+    from tests.helpers import write_synthetic_bam
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(19)
+    contigs = [("chrA", 3_000_000), ("chrEmpty", 1000), ("chrB", 1_000_000), ("chrC", 400_000)]
+    frags = {}
+    for name, size in contigs:
+        if name == "chrEmpty":
+            continue
+        n = size // 40
+        s = np.sort(rng.integers(0, size - 700, n))
+        frags[name] = (s, s + rng.integers(210, 600, n), rng.integers(0, 61, n), rng.integers(0, 2, n).astype(bool))
+    p = str(tmp_path / "multi.bam")
+    write_synthetic_bam(p, contigs, frags)
+    r = subprocess.run([sys.executable, "-c", _BAM_MULTI_CHILD.format(root=root), p], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, FTK_STREAM_PIECE=str(piece), FTK_BAM_STRETCH="4096", FTK_BAM_HOST_SHARE=host_share))
+    assert r.returncode == 0 and "ok ['chrA', 'chrB', 'chrC']" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
