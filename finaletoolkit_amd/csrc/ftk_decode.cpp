@@ -646,6 +646,7 @@ struct DeflateLib {
     void* (*alloc)() = nullptr;
     int (*run)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
     void (*release)(void*) = nullptr;
+    uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;  // libdeflate_crc32 (several GB/s per thread), else zlib's
     DeflateLib() {
         if (getenv("FTK_NO_LIBDEFLATE")) return;
         void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
@@ -654,12 +655,19 @@ struct DeflateLib {
         auto r = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_deflate_decompress");
         auto f = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
         if (a && r && f) { alloc = a; run = r; release = f; }
+        crc = (uint32_t (*)(uint32_t, const void*, size_t))dlsym(h, "libdeflate_crc32");
     }
 };
+
 const DeflateLib& deflate_lib() {
     static const DeflateLib lib;
     return lib;
 }
+inline uint32_t crc32_of(const uint8_t* p, size_t n) {
+    if (deflate_lib().crc) return deflate_lib().crc(0, p, n);
+    return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
+}
+inline uint32_t trailer_crc(const uint8_t* t) { return (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24); }
 
 class BlockInflater {
     void* fast = nullptr;
@@ -698,7 +706,9 @@ public:
 
 // own_threads: threads of this call's own (the pool runs one region at a time; a job beside the producer's regions
 // must not hold it for the length of a whole piece)
-int inflate_block_list(const uint8_t* p, const std::vector<Block>& blocks, int n_threads, uint8_t* out, bool own_threads = false) {
+// check_crc: compare every block's data with the CRC-32 of its gzip trailer (the 4 bytes behind the payload)
+int inflate_block_list(const uint8_t* p, const std::vector<Block>& blocks, int n_threads, uint8_t* out, bool own_threads = false,
+                       bool check_crc = false) {
     std::atomic<size_t> next{0};
     std::atomic<int> bad{0};
     auto work = [&]() {
@@ -711,6 +721,7 @@ int inflate_block_list(const uint8_t* p, const std::vector<Block>& blocks, int n
                 const Block& b = blocks[i];
                 if (b.out_len == 0) continue;
                 if (!inf(p + b.in_off, b.in_len, out + b.out_off, b.out_len)) { bad = 1; break; }
+                if (check_crc && crc32_of(out + b.out_off, b.out_len) != trailer_crc(p + b.in_off + b.in_len)) { bad = 1; break; }
             }
         }
     };
@@ -2763,7 +2774,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
             // (the job owns its block list; the bytes stay in the slot until the piece has been walked)
             host_job[slot] = std::async(std::launch::async, [blocks = pc.blocks, comp = (const uint8_t*)S.h_comp,
                                                              out = S.h_text + kRoom, nt = std::max(1, n_threads - 2)] {
-                return blocks.empty() ? (int)FTK_OK : inflate_block_list(comp, blocks, nt, out, true);
+                return blocks.empty() ? (int)FTK_OK : inflate_block_list(comp, blocks, nt, out, true, true);  // CRCs checked like the GPU's pieces
             });
             pc.slot = slot;
             return true;
@@ -2809,7 +2820,8 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
     auto wait_slot = [&](int slot) -> bool {
         DevSet& S = sets[slot];
         if (slot_on_host[slot]) {  // inflated by the host threads
-            if (host_job[slot].valid() && host_job[slot].get() != FTK_OK) return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+            if (host_job[slot].valid() && host_job[slot].get() != FTK_OK)
+                return fail(FTK_ERR_FORMAT, "BGZF inflate failed or block CRC mismatch (host share of a device stream)");
             return true;
         }
         if (hipEventSynchronize(S.done) != hipSuccess) {

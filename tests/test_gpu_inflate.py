@@ -252,3 +252,59 @@ def test_bam_multi_contig_through_the_slot_ring(tmp_path, piece, host_share):
     r = subprocess.run([sys.executable, "-c", _BAM_MULTI_CHILD.format(root=root), p], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, FTK_STREAM_PIECE=str(piece), FTK_BAM_STRETCH="4096", FTK_BAM_HOST_SHARE=host_share))
     assert r.returncode == 0 and "ok ['chrA', 'chrB', 'chrC']" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
+_BAM_DAMAGED_CHILD = r"""
+import sys, ctypes as C
+sys.path.insert(0, {root!r})
+import torch  # noqa: F401
+from finaletoolkit_amd import _lib as L
+lib = L.load()
+s = C.c_void_p()
+rc = lib.ftk_fragstream_open_device(0, sys.argv[1].encode(), None, 1, 4, 2, C.byref(s))
+assert rc == 0
+n = 0
+while True:
+    t = C.c_void_p()
+    rc = lib.ftk_fragstream_next(s, C.byref(t))
+    if rc != 0:
+        print("error", rc, lib.ftk_fragtable_error().decode())
+        break
+    if not t.value:
+        print("complete", n)
+        break
+    n += 1
+    lib.ftk_fragtable_free(t)
+lib.ftk_fragstream_close(s)
+"""
+
+
+@pytest.mark.parametrize("host_share", ["0", "1", "3"])
+def test_bam_stream_with_a_damaged_block_is_an_error(tmp_path, host_share):
+    """One flipped payload byte somewhere in the middle of a BAM: whichever side inflates that piece (the GPU, checked
+    by its CRC kernel, or the host threads beside it), the stream ends with a format error - no crash, no hang, no
+    silently different fragments."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    good = str(tmp_path / "good.bam")
+    synth.write_paired_bam(good, "mid", 400_000, 60.0, 23)
+    image = bytearray(open(good, "rb").read())
+    # the payload of the block that holds the middle of the file: flip a byte well inside it
+    off, blocks = 0, []
+    while off < len(image):
+        bs = int.from_bytes(image[off + 16:off + 18], "little") + 1
+        blocks.append((off, bs))
+        off += bs
+    o, bs = blocks[len(blocks) // 2]
+    image[o + 18 + (bs - 26) // 2] ^= 0x5A
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(image))
+    code = _BAM_DAMAGED_CHILD.format(root=root)
+    env = dict(os.environ, FTK_STREAM_PIECE=str(1 << 17), FTK_BAM_HOST_SHARE=host_share)
+    r = subprocess.run([sys.executable, "-c", code, good], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "complete 1" in r.stdout, r.stdout + r.stderr[-1500:]
+    r = subprocess.run([sys.executable, "-c", code, bad], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.startswith("error"), r.stdout + r.stderr[-1500:]
+    assert str(L.FTK_ERR_FORMAT) in r.stdout.split()[1]
