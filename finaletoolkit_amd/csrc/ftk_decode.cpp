@@ -921,6 +921,7 @@ Contig* find_or_add(ftk_fragtable* t, const std::string& name) {
 // threads: 2 passes over the keys instead of a chunk sort and log2(threads) merge levels of which the last run on one
 // or two threads (4.8 M keys of a 60x BAM slice on 16 threads: 25 -> 6 ms).
 bool bucket_sort_keys(uint64_t* key, size_t m, int nt) {
+    Stopwatch sw;
     constexpr int kShift = 32 + 12;
     uint64_t top = 0;
     {
@@ -932,6 +933,7 @@ bool bucket_sort_keys(uint64_t* key, size_t m, int nt) {
         });
         for (uint64_t v : tmax) top = std::max(top, v);
     }
+    sw.lap("    sort: max");
     const size_t nb = (size_t)(top >> kShift) + 1;
     if (nb > (size_t(1) << 20) || nb * (size_t)nt > m) return false;  // few keys per bucket: the histograms would dominate
     std::vector<uint32_t> cnt(nb * (size_t)nt, 0);
@@ -939,6 +941,7 @@ bool bucket_sort_keys(uint64_t* key, size_t m, int nt) {
         uint32_t* c = cnt.data() + nb * (size_t)t;
         for (size_t i = m * (size_t)t / (size_t)nt, e = m * (size_t)(t + 1) / (size_t)nt; i < e; ++i) ++c[key[i] >> kShift];
     });
+    sw.lap("    sort: count");
     std::vector<size_t> first(nb + 1);
     size_t run = 0;
     for (size_t b = 0; b < nb; ++b) {  // bucket by bucket, thread by thread inside: stable
@@ -950,6 +953,7 @@ bool bucket_sort_keys(uint64_t* key, size_t m, int nt) {
         }
     }
     first[nb] = run;
+    sw.lap("    sort: offsets");
     std::unique_ptr<uint64_t[]> tmp(new uint64_t[m]);  // (not zeroed: the scatter's threads touch its pages first)
     parallel_run(nt, [&](int t) {
         uint32_t* c = cnt.data() + nb * (size_t)t;
@@ -958,6 +962,7 @@ bool bucket_sort_keys(uint64_t* key, size_t m, int nt) {
             tmp[first[b] + c[b]++] = key[i];
         }
     });
+    sw.lap("    sort: scatter");
     parallel_run(nt, [&](int t) {  // buckets dealt by position in the output: equal shares of the keys
         const size_t lo = m * (size_t)t / (size_t)nt, hi = m * (size_t)(t + 1) / (size_t)nt;
         size_t b = (size_t)(std::upper_bound(first.begin(), first.end(), lo) - first.begin());
@@ -970,6 +975,7 @@ bool bucket_sort_keys(uint64_t* key, size_t m, int nt) {
             std::copy(a, z, key + first[b]);
         }
     });
+    sw.lap("    sort: buckets");
     return true;
 }
 
