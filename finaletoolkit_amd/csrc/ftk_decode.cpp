@@ -273,6 +273,21 @@ struct DeviceBlockCache {
         }
         (void)hipFree(p);
     }
+    size_t trim() {  // free every idle block; returns the bytes released
+        std::vector<Blk> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            drop.swap(free_list);
+            cached = 0;
+        }
+        size_t n = 0;
+        for (auto& b : drop) {
+            (void)hipSetDevice(b.device);
+            (void)hipFree(b.p);
+            n += b.cap;
+        }
+        return n;
+    }
 };
 DeviceBlockCache& device_cache() {
     static DeviceBlockCache* c = new DeviceBlockCache();  // leaked: the driver frees at process exit
@@ -446,6 +461,20 @@ struct PinnedCache {
         }
         (void)hipHostFree(p);
         return true;
+    }
+    size_t trim() {  // unpin every idle block; returns the bytes released
+        std::vector<Blk> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            drop.swap(free_list);
+            cached = 0;
+        }
+        size_t n = 0;
+        for (auto& b : drop) {
+            (void)hipHostFree(b.p);
+            n += b.cap;
+        }
+        return n;
     }
 };
 // leaked on purpose: the driver unpins at process exit
@@ -2241,6 +2270,20 @@ struct DevSetPool {
         }
         s.release();
     }
+    size_t trim() {  // release every idle set; returns their page-locked + device bytes (text buffers only: a lower bound)
+        std::vector<std::pair<int, DevSet>> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            drop.swap(idle);
+        }
+        size_t n = 0;
+        for (auto& d : drop) {
+            (void)hipSetDevice(d.first);
+            n += 2 * d.second.cap + d.second.h_comp_cap + d.second.comp_cap;
+            d.second.release();
+        }
+        return n;
+    }
 };
 DevSetPool& devset_pool() {
     static DevSetPool* p = new DevSetPool();  // leaked: the driver frees at process exit
@@ -3081,6 +3124,14 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
 }
 
 extern "C" {
+
+// Give back what the library keeps for reuse between calls: idle page-locked blocks (decoded tables, result arrays),
+// idle device blocks of parsed contigs, the streams' idle buffer sets.  Nothing in use is touched.
+int64_t ftk_cache_trim(void) {
+    size_t n = table_cache().trim() + result_cache().trim();
+    if (have_hip_device()) n += device_cache().trim() + devset_pool().trim();
+    return (int64_t)n;
+}
 
 int ftk_fragfile_index_contigs(const char* path, char* names_out, int64_t cap, int64_t* needed_out, int* is_bed6_out) {
     if (!path || !needed_out) return dfail(FTK_ERR_INVALID, "NULL argument");

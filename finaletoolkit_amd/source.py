@@ -386,3 +386,11 @@ def close_all():
     if _ENGINE is not None:
         _ENGINE.close()
         _ENGINE = None
+
+
+def release_caches() -> int:
+    """Give back what the library keeps between calls (idle page-locked blocks, idle device blocks, the streams'
+    idle buffer sets: ``ftk_cache_trim``); returns the bytes released.  For long-lived hosts between jobs -
+    nothing in use is touched, the next call allocates again."""
+    from . import _lib
+    return int(_lib.load().ftk_cache_trim())

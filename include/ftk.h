@@ -198,6 +198,12 @@ void ftk_fragtable_free(ftk_fragtable* t);
  * (FTK_PINNED_RESULT_LIMIT_MB) would be outstanding - the caller then uses ordinary memory. */
 int ftk_host_alloc(int64_t bytes, void** out);
 void ftk_host_free(void* p);
+/* Give back everything the library keeps for reuse between calls - idle page-locked blocks (decoded tables, result
+ * arrays from ftk_host_alloc), idle device blocks of contigs parsed on the GPU, the streaming decoders' idle buffer
+ * sets (up to four per process, ~1 GB of page-locked and ~2 GB of device memory after a large text stream).  Blocks
+ * in use are not touched.  Returns the bytes released (a lower bound).  For long-lived processes between jobs; the
+ * next call that needs a block allocates it again (page-locking costs ~0.1-0.2 ms per MB). */
+int64_t ftk_cache_trim(void);
 /* Upload contig i of a decoded table (including the BAM read1 columns) as contig_id: the
  * decode -> pinned SoA -> hipMemcpyAsync leg of the pipeline, without a detour through the caller. */
 int ftk_frags_from_table(ftk_ctx* ctx, int contig_id, const ftk_fragtable* t, int i);

@@ -131,3 +131,12 @@ def test_bam_decoder_fixture():
     assert np.array_equal(cols[0], want[0]) and np.array_equal(cols[1], want[1]) and np.array_equal(cols[3], want[3])
     assert np.all(cols[4] >= cols[0]) and np.all(cols[5] <= cols[1])  # read1 inside its fragment
     assert len([k for k in got if not k.startswith("__")]) == 84  # @SQ lines
+
+
+def test_cache_trim_without_a_gpu_is_a_no_op():
+    """ftk_cache_trim gives idle cached blocks back; with nothing cached (and no device) it returns 0 and the
+    library goes on working."""
+    lib = L.load()
+    assert lib.ftk_cache_trim() == 0
+    t = _decode(os.path.join(DATA, "12.3444.b37.frag.gz"))
+    assert t["12"][0] == 17 and lib.ftk_cache_trim() >= 0

@@ -308,3 +308,31 @@ def test_bam_stream_with_a_damaged_block_is_an_error(tmp_path, host_share):
     r = subprocess.run([sys.executable, "-c", code, bad], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.startswith("error"), r.stdout + r.stderr[-1500:]
     assert str(L.FTK_ERR_FORMAT) in r.stdout.split()[1]
+
+
+def test_cache_trim_releases_the_streams_idle_buffers(tmp_path):
+    """After a stream the library holds its buffer sets, page-locked tables and result blocks for the next one;
+    ftk_cache_trim gives them back (bytes > 0), a second trim finds nothing, and the next stream works as before."""
+    from finaletoolkit_amd import source
+    size = 3_000_000
+    s, e, q, st = synth.synth_contig(size, 30.0, 77)
+    p = str(tmp_path / "t.frag.gz")
+    bgzf.write_frag_gz(p, [("c", s, e, q, st)], level=1, with_index=False)
+    ws, we = synth.tiling_windows(size, 100_000)
+
+    def run():
+        source.close_all()
+        eng = source.get_engine()
+        for src, name in source.stream_source(p):
+            r = eng.window_features(src.key(name), ws, we, 30)
+            w = eng.wps(src.key(name), 0, size, size)
+        cov = int(r["coverage"].sum())
+        del r, w
+        source.close_all()
+        return cov
+
+    a = run()
+    freed = source.release_caches()
+    assert freed > 0
+    assert source.release_caches() == 0
+    assert run() == a
