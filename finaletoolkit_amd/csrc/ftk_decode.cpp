@@ -1740,6 +1740,7 @@ struct ftk_fragstream {
     std::condition_variable cv;
     std::deque<ftk_fragtable*> ready;
     bool finished = false, stop = false;
+    bool consumer_waiting = false;  // ftk_fragstream_next is blocked on an empty queue
     int err = FTK_OK;
     std::string errmsg;
     // BAM header
@@ -1817,14 +1818,18 @@ struct ftk_fragstream {
         }
         size_t got = 0;
         bool done = false;
-        if (want >= (size_t(8) << 20)) {
+        static const int n_readers = [] {  // FTK_READ_THREADS=<1..8>
+            const char* e = getenv("FTK_READ_THREADS");
+            return e ? std::max(1, std::min(8, atoi(e))) : 4;
+        }();
+        if (want >= (size_t(8) << 20) && n_readers > 1) {
             // a large piece of a regular file: four threads pread their quarters (one thread copies ~6 GB/s out of
             // the page cache - 8 ms per 48 MB piece, as long as the GPU takes to inflate it)
             const long long pos = ftell(fp);
             struct stat sb;
             if (pos >= 0 && fstat(fileno(fp), &sb) == 0 && S_ISREG(sb.st_mode) && (long long)sb.st_size > pos) {
                 const size_t n = (size_t)std::min<long long>((long long)want, (long long)sb.st_size - pos);
-                constexpr int kReaders = 4;
+                const int kReaders = n_readers;
                 std::atomic<int> failed{0};
                 auto part = [&](int t) {
                     size_t a = n * (size_t)t / kReaders;
@@ -1835,8 +1840,8 @@ struct ftk_fragstream {
                         a += (size_t)r;
                     }
                 };
-                std::thread helpers[kReaders - 1];
-                for (int t = 1; t < kReaders; ++t) helpers[t - 1] = std::thread(part, t);
+                std::vector<std::thread> helpers;
+                for (int t = 1; t < kReaders; ++t) helpers.emplace_back(part, t);
                 part(0);
                 for (auto& h : helpers) h.join();
                 if (!failed.load() && fseek(fp, (long)(pos + (long long)n), SEEK_SET) == 0) {
@@ -2517,6 +2522,10 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             DevSet& Q = sets[settled % kSets];
             if (Q.pending) {
                 const bool must = all || settled <= k - kLag;
+                if (!must) {  // ahead of need only while the consumer is blocked waiting for a contig
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (!consumer_waiting) break;
+                }
                 if (!must && !Q.host_only && hipEventQuery(Q.done) != hipSuccess) {
                     (void)hipGetLastError();  // (not ready is no error)
                     break;
@@ -3229,7 +3238,9 @@ int ftk_fragstream_next(ftk_fragstream* s, ftk_fragtable** out) {
     if (!s || !out) return dfail(FTK_ERR_INVALID, "NULL argument");
     *out = nullptr;
     std::unique_lock<std::mutex> lk(s->mu);
+    s->consumer_waiting = true;
     s->cv.wait(lk, [&] { return !s->ready.empty() || s->finished; });
+    s->consumer_waiting = false;
     if (!s->ready.empty()) {
         *out = s->ready.front();
         s->ready.pop_front();

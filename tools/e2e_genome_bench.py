@@ -4,7 +4,7 @@ coverage + length histogram + DELFI per 100 kb bin and WPS for every base -> res
 contig (decode of contig k+1 runs while contig k is on the GPU; every contig's results are dropped after they
 have arrived and been checked, as a writer would after writing them; the copy-back of contig k overlaps the work
 on contig k+1: Engine.wps_async).
-usage: tools/e2e_genome_bench.py [contigs=all] [depth=30] [workers=12]
+usage: tools/e2e_genome_bench.py [contigs=all] [depth=30] [workers=12] [delfi]   (delfi: DELFI bins only, no per-base WPS)
 The file is written by `workers` processes (row ranges of a contig -> BGZF pieces, concatenated in order)."""
 import json
 import os
@@ -23,6 +23,7 @@ def main():
     from finaletoolkit_amd import synth, writers
     contigs = (sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] != "all" else ",".join(synth.B37_SIZES)).split(",")
     depth = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0
+    no_wps = len(sys.argv) > 4 and sys.argv[4] == "delfi"
     tmp = tempfile.mkdtemp()
     path = os.path.join(tmp, "genome.frag.gz")
     t0 = time.time()
@@ -43,7 +44,7 @@ def main():
     open(path + ".tbi", "wb").close()
     res = {"contigs": len(contigs), "fragments": rows, "text_GB": round(text_bytes / 1e9, 2),
            "file_GB": round(os.path.getsize(path) / 1e9, 2), "write_s": round(time.time() - t0, 1),
-           "FTK_DEVICE_INFLATE": os.environ.get("FTK_DEVICE_INFLATE", "1")}
+           "FTK_DEVICE_INFLATE": os.environ.get("FTK_DEVICE_INFLATE", "1"), "mode": "delfi bins only" if no_wps else "all features + WPS"}
     print(json.dumps(res), flush=True)
 
     from finaletoolkit_amd import source
@@ -78,6 +79,13 @@ def main():
             wait_s += ta - tb
             size = synth.B37_SIZES[c]
             ws, we = synth.tiling_windows(size, 100_000)
+            if no_wps:  # BASELINE config 4's own shape: the DELFI bins of the whole genome, no per-base output
+                sh, lg, nf = eng.delfi_counts(src.key(c), ws, we, 30, None, None, synth.synth_gaps(size))
+                assert bool(np.array_equal(sh + lg, nf)), c
+                tb = time.perf_counter()
+                compute_s += tb - ta
+                marks.append((c, round(ta - t1, 3), round(tb - t1, 3)))
+                continue
             r = eng.window_features(src.key(c), ws, we, 30, hist=(0, 1001), delfi=dict(quality_threshold=30))
             w, tok = eng.wps_async(src.key(c), 0, size, size)
             if pending is not None:
