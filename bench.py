@@ -500,13 +500,15 @@ def main():
 def end_to_end(torch, reps: int = 3):
     """File -> results on the host, through the product's own path (source.stream_source: host threads inflate,
     the GPU parses the rows, contigs become resident one after the other; then the kernels and the copy back).
-    Three legs, files synthesised beforehand (not timed), `reps` repetitions each, the best one reported with its
+    Four legs, files synthesised beforehand (not timed), `reps` repetitions each, the best one reported with its
     stage times:
       chr22_all_features  BASELINE configs 2/3: chr22 at 30x -> coverage + 1001-bin histogram + DELFI per 100 kb
                           window and WPS of every base, all results in host memory;
       delfi_4_contigs     config 4's shape on four contigs (19-22): DELFI short/long per 100 kb bin only;
       bam_60x_slice       config 5's input: a 60x paired-end BAM slice of 24 Mb (9.6 M records) -> read1 fragments ->
-                          every feature and WPS of every base."""
+                          every feature and WPS of every base;
+      genome_delfi_bins   config 4 itself: ONE whole-genome 30x frag.gz (309.6 M rows, 8 GB of text) -> DELFI
+                          short / long / fragment counts of all 30 970 bins (two repetitions; FTK_BENCH_GENOME_E2E=0 skips)."""
     import shutil
     import tempfile
     from finaletoolkit_amd import bgzf, source
@@ -615,6 +617,55 @@ def end_to_end(torch, reps: int = 3):
                 best = cur
         res["bam_60x_slice"] = dict(file_MB=round(exp["file_bytes"] / 1e6, 1), fragments=exp["n"], records=2 * exp["n"],
                                     file_write_s=round(t_write, 2), decoder_threads=threads, repetitions=reps, **best)
+        # BASELINE config 4 itself, file to feature vector: ONE whole-genome 30x frag.gz -> DELFI bins of every contig
+        if os.environ.get("FTK_BENCH_GENOME_E2E", "1") != "0":
+            from finaletoolkit_amd import writers
+            pg = os.path.join(tmp, "genome.frag.gz")
+            names = list(synth.B37_SIZES)
+            t0 = time.perf_counter()
+            truth, rows_total, text_bytes = {}, 0, 0
+            for k, c in enumerate(names):
+                size = synth.B37_SIZES[c]
+                n = synth.n_fragments(size, 30.0)
+                s, e, q, st = (t.cpu().numpy() for t in gen_contig_device(torch, dev, size, n, synth.SEED_BASE + k))
+                ln = e - s
+                truth[c] = int(((q >= MAPQ) & (ln >= 100) & (ln <= 220)).sum())
+                with writers.frag_rows(c, s, e, q, st) as text:
+                    writers.bgzf_write(pg, text, 1, append=k > 0, write_eof=k == len(names) - 1)
+                    text_bytes += text.n
+                rows_total += n
+                del s, e, q, st, ln
+            open(pg + ".tbi", "wb").close()  # (the reader streams the whole file; the index only has to exist)
+            t_write = time.perf_counter() - t0
+            n_win_total = sum(-(-synth.B37_SIZES[c] // WINDOW) for c in names)
+            best = None
+            for _ in range(2):
+                source.close_all()
+                eng = source.get_engine()
+                t0 = time.perf_counter()
+                ok, seen, t_wait, tb, src = True, [], 0.0, t0, None
+                for src, c in source.stream_source(pg, threads):
+                    ta = time.perf_counter()
+                    t_wait += ta - tb
+                    size = synth.B37_SIZES[c]
+                    ws, we = synth.tiling_windows(size, WINDOW)
+                    sh, lg, nf = eng.delfi_counts(src.key(c), ws, we, MAPQ, None, None, synth_gaps(size))
+                    ok = ok and bool(np.array_equal(sh + lg, nf)) and 0 < int(nf.sum()) <= truth[c]
+                    seen.append(c)
+                    tb = time.perf_counter()
+                total = tb - t0
+                cur = dict(total_s=round(total, 4), windows=n_win_total, windows_per_s=round(n_win_total / total, 1),
+                           fragments_per_s_M=round(rows_total / total / 1e6, 1), text_GB_per_s=round(text_bytes / total / 1e9, 2),
+                           waiting_for_resident_contigs_s=round(t_wait, 4),
+                           decoder_producer_stage_ms=src.decode_stage_ms if src is not None else None,
+                           results_ok=bool(ok and seen == names))
+                if best is None or cur["total_s"] < best["total_s"]:
+                    best = cur
+            res["genome_delfi_bins"] = dict(file_GB=round(os.path.getsize(pg) / 1e9, 2), text_GB=round(text_bytes / 1e9, 2),
+                                            fragments=rows_total, file_write_s=round(t_write, 1), decoder_threads=threads,
+                                            repetitions=2, **best)
+            os.remove(pg)
+            os.remove(pg + ".tbi")
         res["note"] = ("best of %d repetitions per leg (the first one of a process also pays thread-pool start, page-locked "
                        "allocations and the file's first read); PCIe transfers included; never the headline value" % reps)
         source.close_all()
