@@ -22,15 +22,21 @@
 namespace ftk {
 namespace {
 
+// The output window held in LDS.  2 KB: 9 KB of LDS per wave, 17 waves per CU - on pieces that fill the chip (BAM, text
+// streams with two pieces in flight) 17 % / 8 % faster than 4 KB (14 waves per CU): matches further back than ~1.7 KB
+// read HBM instead, rare in fragment rows and BAM records.  (A launch of fewer blocks than the chip holds is 2 % slower.)
 #ifndef FTK_INFLATE_RING
-#define FTK_INFLATE_RING 4096
+#define FTK_INFLATE_RING 2048
 #endif
 #ifndef FTK_INFLATE_ROOT
 #define FTK_INFLATE_ROOT 10
 #endif
 constexpr int kRing = FTK_INFLATE_RING, kRingMask = kRing - 1;
 constexpr int kGranShift = kRing >= 8192 ? 11 : 10, kGran = 1 << kGranShift;  // write-behind granule: a quarter of the ring
-constexpr int kLitRoot = FTK_INFLATE_ROOT, kDistRoot = 9, kPreRoot = 7;
+#ifndef FTK_INFLATE_DIST_ROOT
+#define FTK_INFLATE_DIST_ROOT 9
+#endif
+constexpr int kLitRoot = FTK_INFLATE_ROOT, kDistRoot = FTK_INFLATE_DIST_ROOT, kPreRoot = 7;
 constexpr int kFarDist = kRing - 258 - 64;    // matches further back than this read from HBM
 
 struct __align__(16) WaveLds {

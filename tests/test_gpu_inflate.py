@@ -51,6 +51,11 @@ def test_block_types_levels_and_shapes(engine):
         "rows": text, "noise": noise, "zeros": bytes(0xFF00), "run_pattern": (b"abcdefg" * 10_000)[:0xFF00],
         "far_matches": (far + far)[:0xFF00],            # distance 30 000: beyond the LDS ring
         "mid_matches": (far[:7_000] + far[:7_000] * 8)[:0xFF00],  # distance 7 000..: ring edge
+        # distances on both sides of the LDS-to-LDS limit (ring size - 322) and of the ring size, for a 2 KB and a 4 KB ring:
+        # 258-byte matches whose sources straddle the line between "still in the ring" and "read back from HBM"
+        **{f"edge_{d}": (far[:d] + far[:d] * 40)[:0xFF00] for d in (1_700, 1_726, 1_727, 1_800, 2_047, 2_048, 2_049, 2_300,
+                                                                 3_774, 3_775, 4_095, 4_096, 4_097)},
+        "edge_mixed": b"".join(far[k:k + 300] for k in (0, 1_400, 0, 1_700, 0, 2_000, 1_400, 2_100, 0)) * 12,
         "one_byte": b"x", "empty": b"", "short": b"hello, hello, hello\n",
         "digits": "".join(str(v) for v in rng.integers(0, 10 ** 9, 7000)).encode()[:0xFF00],
     }
