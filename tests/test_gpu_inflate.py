@@ -80,6 +80,47 @@ def test_block_types_levels_and_shapes(engine):
         assert rc == 0 and got == w
 
 
+def test_inflate_fuzz_random_mixtures(engine):
+    """300 blocks of random make-up - stretches of random bytes, of a few symbols, of one byte, and copies of earlier
+    stretches from random distances (1 byte to 40 KB back: inside the LDS window, at its edge, beyond it) - through
+    random zlib levels and strategies: byte-equal to the input, block after block."""
+    rng = np.random.default_rng(77)
+    members, want = [], []
+    while len(members) < 300:
+        out = bytearray()
+        target = int(rng.integers(1, 0xFF00))
+        while len(out) < target:
+            kind = int(rng.integers(0, 5))
+            n = int(rng.integers(1, 3000))
+            if kind == 0:
+                out += rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+            elif kind == 1:
+                out += rng.integers(48, 58, n, dtype=np.uint8).tobytes()
+            elif kind == 2:
+                out += bytes([int(rng.integers(0, 256))]) * n
+            elif out:
+                d = int(min(len(out), rng.choice([1, 2, 3, 7, 64, 258, 700, 1_700, 1_726, 1_727, 2_048, 2_049, 3_775, 4_096,
+                                                   4_097, 9_000, 32_768, 40_000])))
+                for _ in range(n // d + 1):  # (overlapping copies when n > d)
+                    out += out[len(out) - d:len(out) - d + min(d, n)]
+        data = bytes(out[:target])
+        level = int(rng.integers(0, 10))
+        strategy = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY][int(rng.integers(0, 5))]
+        m = _member(data, level, strategy)
+        if m is not None:
+            members.append(m)
+            want.append(data)
+    rc, got = _inflate(engine, b"".join(members) + bgzf._EOF)
+    assert rc == 0, engine.lib.ftk_last_error(engine.ctx)
+    expect = b"".join(want)
+    if got != expect:  # name the first block that differs
+        off = 0
+        for k, w in enumerate(want):
+            assert got[off:off + len(w)] == w, f"block {k} ({len(w)} bytes) differs"
+            off += len(w)
+    assert got == expect
+
+
 def test_many_blocks_from_the_library_writer(engine, tmp_path):
     """A 40 MB fragment text through the library's BGZF writer (libdeflate) at three levels: ~600 blocks each."""
     rows = _rows(1_300_000, 5)
