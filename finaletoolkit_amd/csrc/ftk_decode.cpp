@@ -2294,6 +2294,58 @@ DevSetPool& devset_pool() {
     static DevSetPool* p = new DevSetPool();  // leaked: the driver frees at process exit
     return *p;
 }
+
+// HIP streams of finished decoder streams wait here for the next one: creating one costs ~1 ms, destroying it as
+// much, a decoder stream uses five - a fifth of the time a small file takes from disk to results.  A stream is idle
+// (synchronised) when it is given back.
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> idle;
+    hipStream_t take(int device) {  // nullptr: cannot create one
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < idle.size(); ++i)
+                if (idle[i].first == device) {
+                    hipStream_t s = idle[i].second;
+                    idle.erase(idle.begin() + i);
+                    return s;
+                }
+        }
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        return s;
+    }
+    void give(int device, hipStream_t s) {
+        if (!s) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (idle.size() < 16) {
+                idle.emplace_back(device, s);
+                return;
+            }
+        }
+        (void)hipStreamDestroy(s);
+    }
+    size_t trim() {
+        std::vector<std::pair<int, hipStream_t>> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            drop.swap(idle);
+        }
+        for (auto& d : drop) {
+            (void)hipSetDevice(d.first);
+            (void)hipStreamDestroy(d.second);
+        }
+        return drop.size();
+    }
+};
+StreamPool& stream_pool() {
+    static StreamPool* p = new StreamPool();  // leaked: the driver frees at process exit
+    return *p;
+}
 }  // namespace
 
 bool ftk_fragstream::emit_device(Contig&& ct) {
@@ -2326,7 +2378,7 @@ bool ftk_fragstream::emit_device(Contig&& ct) {
 // host's field-rule parser (parse_text_parallel) and its columns are uploaded - same rows either way.
 bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     StageClock clk(this);
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || (pstream = stream_pool().take(device)) == nullptr) {
         (void)hipGetLastError();
         return fail(FTK_ERR_HIP, "cannot create the parse stream");
     }
@@ -2338,10 +2390,8 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     for (auto& S : sets) S = devset_pool().take(device);
     hipStream_t fstream[kSets] = {};
     for (auto& f : fstream)
-        if (hipStreamCreateWithFlags(&f, hipStreamNonBlocking) != hipSuccess) {
-            (void)hipGetLastError();
-            for (auto& g : fstream)
-                if (g) (void)hipStreamDestroy(g);
+        if ((f = stream_pool().take(device)) == nullptr) {
+            for (auto& g : fstream) stream_pool().give(device, g);
             for (auto& S : sets) devset_pool().give(device, S);
             return fail(FTK_ERR_HIP, "cannot create the inflate streams");
         }
@@ -2364,7 +2414,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         ~Cleanup() {
             for (int k = 0; k < kSets; ++k) {
                 (void)hipStreamSynchronize(fs[k]);
-                (void)hipStreamDestroy(fs[k]);
+                stream_pool().give(device, fs[k]);
             }
             (void)hipStreamSynchronize(stream);  // nothing in flight touches the sets any more
             for (int k = 0; k < kSets; ++k) {
@@ -2766,13 +2816,12 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
     bool dinf = want_dinf && device >= 0;
     hipStream_t streams[kSlots] = {};  // streams[0] is the member pstream (destroyed with the stream object)
     if (dinf) {
-        bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking) == hipSuccess;
+        bool ok = hipSetDevice(device) == hipSuccess && (pstream = stream_pool().take(device)) != nullptr;
         streams[0] = pstream;
-        for (int k = 1; ok && k < kSlots; ++k) ok = hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking) == hipSuccess;
+        for (int k = 1; ok && k < kSlots; ++k) ok = (streams[k] = stream_pool().take(device)) != nullptr;
         if (!ok) {
             (void)hipGetLastError();
-            for (int k = 1; k < kSlots; ++k)
-                if (streams[k]) (void)hipStreamDestroy(streams[k]);
+            for (int k = 1; k < kSlots; ++k) stream_pool().give(device, streams[k]);
             dinf = false;
         }
     }
@@ -2788,7 +2837,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
             if (!on) return;
             for (int k = 0; k < kSlots; ++k) {
                 (void)hipStreamSynchronize(streams[k]);
-                if (k) (void)hipStreamDestroy(streams[k]);
+                if (k) stream_pool().give(device, streams[k]);
                 devset_pool().give(device, s[k]);
             }
         }
@@ -3138,7 +3187,10 @@ extern "C" {
 // idle device blocks of parsed contigs, the streams' idle buffer sets.  Nothing in use is touched.
 int64_t ftk_cache_trim(void) {
     size_t n = table_cache().trim() + result_cache().trim();
-    if (have_hip_device()) n += device_cache().trim() + devset_pool().trim();
+    if (have_hip_device()) {
+        n += device_cache().trim() + devset_pool().trim();
+        (void)stream_pool().trim();
+    }
     return (int64_t)n;
 }
 
@@ -3286,7 +3338,7 @@ void ftk_fragstream_close(ftk_fragstream* s) {
     if (s->pstream) {
         (void)hipSetDevice(s->device >= 0 ? s->device : s->inflate_device);
         (void)hipStreamSynchronize(s->pstream);
-        (void)hipStreamDestroy(s->pstream);
+        stream_pool().give(s->device >= 0 ? s->device : s->inflate_device, s->pstream);
     }
     if (s->fp) fclose(s->fp);
     delete s;
