@@ -177,6 +177,11 @@ int upload_common(ftk_ctx* ctx, int contig_id, const int32_t* start, const int32
     if (e == hipSuccess) e = hipMemcpyAsync(d_st, &init, sizeof(init), hipMemcpyHostToDevice, s);
     if (e == hipSuccess && n > 0) launch_stats(s, d_start, d_end, (int)n, d_st);
     if (e == hipSuccess) e = hipMemcpyAsync(&h_st, d_st, sizeof(h_st), hipMemcpyDeviceToHost, s);
+    // the last start (the largest: the columns are sorted) for the position index below - on the ctx stream with the
+    // summary: a synchronous hipMemcpy here waited for whatever transfer the device had in flight, 7-29 ms per contig
+    // behind the previous contig's per-base results (the whole-genome run with WPS: 0.6 -> see DESIGN section 5)
+    int32_t max_start = 0;
+    if (e == hipSuccess && n > 0) e = hipMemcpyAsync(&max_start, d_start + (n - 1), 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -198,16 +203,6 @@ int upload_common(ftk_ctx* ctx, int contig_id, const int32_t* start, const int32
         c.max_end = h_st.max_end;
     }
     // coarse position index
-    int32_t max_start = 0;
-    if (n > 0) {
-        // sorted: the last start is the largest
-        e = hipMemcpy(&max_start, d_start + (n - 1), 4, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            free_contig(c);
-            return fail(ctx, FTK_ERR_HIP, "index build failed: %s", hipGetErrorString(e));
-        }
-    }
     int n_bins = (max_start >> kBinShift) + 1;
     e = hipMalloc((void**)&c.bin_idx, (size_t)(n_bins + 1) * 4);
     if (e != hipSuccess) {
@@ -662,11 +657,15 @@ int get_delfi_meta(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const in
     m.d_off = (int32_t*)(q + 2 * b_w);
     m.d_r0 = (int32_t*)(q + 2 * b_w + b_o);
     m.d_pm = (int32_t*)(q + 2 * b_w + b_o + b_r);
-    hipError_t e = hipMemcpy(m.d_ws, w_start, n_win * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(m.d_we, w_end, n_win * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(m.d_off, off.data(), (n_win + 1) * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && m.n_r) e = hipMemcpy(m.d_r0, r0.data(), m.n_r * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && m.n_r) e = hipMemcpy(m.d_pm, pm.data(), m.n_r * 4, hipMemcpyHostToDevice);
+    // on the ctx stream, one wait for that stream at the end: a synchronous hipMemcpy waits for whatever transfer
+    // the device has in flight - a previous contig's per-base results on their way to the host, tens of ms
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipMemcpyAsync(m.d_ws, w_start, n_win * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(m.d_we, w_end, n_win * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(m.d_off, off.data(), (n_win + 1) * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && m.n_r) e = hipMemcpyAsync(m.d_r0, r0.data(), m.n_r * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && m.n_r) e = hipMemcpyAsync(m.d_pm, pm.data(), m.n_r * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // (the sources are the caller's arrays and locals of this call)
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(m.base);
