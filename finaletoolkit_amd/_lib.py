@@ -52,7 +52,7 @@ EXPORTS = [
     "ftk_frag_select",
     "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals", "ftk_wps_adjust",
     "ftk_ref_upload", "ftk_ref_release", "ftk_ref_gc_counts", "ftk_ref_set_layout", "ftk_motif_counts",
-    "ftk_format_wig_i64", "ftk_format_bedgraph_i64", "ftk_format_bedgraph_f64", "ftk_buffer_free", "ftk_file_write",
+    "ftk_format_wig_i64", "ftk_format_bedgraph_i64", "ftk_format_bedgraph_f64", "ftk_buffer_free", "ftk_file_write", "ftk_gzip_members",
     "ftk_bigwig_fixedstep_sections", "ftk_format_frag_rows", "ftk_bgzf_write", "ftk_fill_wps_records", "ftk_bgzf_inflate_device",
 ]
 
@@ -91,11 +91,12 @@ _lib = None
 
 def build(force: bool = False) -> str:
     """Compile libftk_hip.so for gfx950 with hipcc (in-tree)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "ftk.h")]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))]
+    srcs.append(os.path.join(_HERE, "..", "include", "ftk.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.exists(s))
     if force or stale:
-        subprocess.check_call(["make", "-C", CSRC], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=subprocess.DEVNULL)
     return LIB_PATH
 
 
@@ -126,6 +127,35 @@ def _share_torch_hip_runtime():
                 return
 
 
+def hip_runtimes_mapped():
+    """Paths of every ``libamdhip64`` mapped into this process (``/proc/self/maps``)."""
+    found = []
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                path = line.rsplit(None, 1)[-1]
+                if "libamdhip64" in os.path.basename(path) and os.path.realpath(path) not in found:
+                    found.append(os.path.realpath(path))
+    except OSError:
+        pass
+    return found
+
+
+def _check_single_hip_runtime():
+    """``_share_torch_hip_runtime`` relies on torch's bundled runtime carrying the soname ``libftk_hip.so`` was linked
+    against.  If it does not (a torch wheel of another ROCm major), the linker maps /opt/rocm's copy as well and the
+    process holds two HIP runtimes - the "finds no device" failure.  Say so instead of failing later."""
+    found = hip_runtimes_mapped()
+    if len(found) > 1:
+        import warnings
+        warnings.warn(
+            "finaletoolkit_amd: two HIP runtimes are mapped into this process (" + ", ".join(found) + "); "
+            "libftk_hip.so and torch would each see their own and one of them finds no device.  Set FTK_SYSTEM_HIP=1 "
+            "in processes that do not import torch, or rebuild libftk_hip.so against the ROCm version torch bundles.",
+            RuntimeWarning, stacklevel=3)
+    return found
+
+
 def load() -> C.CDLL:
     """Load the HIP library; raises if it has not been built."""
     global _lib
@@ -142,6 +172,7 @@ def load() -> C.CDLL:
             "finaletoolkit_amd has no CPU fallback.")
     _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
+    _check_single_hip_runtime()
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.ftk_version.restype = C.c_char_p
     lib.ftk_last_error.restype = C.c_char_p
@@ -159,6 +190,7 @@ def load() -> C.CDLL:
     lib.ftk_fill_wps_records.argtypes = [vp, i64, vp, i64, vp, C.c_int]
     lib.ftk_bgzf_write.argtypes = [C.c_char_p, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.ftk_file_write.argtypes = [C.c_char_p, vp, i64, C.c_int, C.c_int, C.c_int]
+    lib.ftk_gzip_members.argtypes = [vp, i64, C.c_int, C.c_int, pp, pi64]
     lib.ftk_bigwig_fixedstep_sections.argtypes = [C.c_uint32, vp, vp, i64, vp, C.c_int, i32, C.c_int, C.c_int, pp, pi64,
                                                   pi64, pp, pp]
     lib.ftk_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]

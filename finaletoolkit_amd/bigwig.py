@@ -134,80 +134,99 @@ def write_fixed_step_bigwig(output_file, header, interval_scores) -> None:
     write_fixed_step_bigwig_runs(output_file, header, runs())
 
 
-def write_fixed_step_bigwig_runs(output_file, header, contig_runs, threads: int = 0) -> None:
-    """The same from runs of intervals: ``contig_runs`` yields ``(contig, starts, values, offsets)`` with interval
-    ``k`` = ``values[offsets[k]:offsets[k+1]]`` at ``starts[k]`` (what one ``ftk_wps_intervals`` launch returns).
-    The data sections -- float32 conversion, section headers, zlib, per-section summaries -- are built by
-    the library's host threads (``writers.bigwig_sections``) and streamed to the file; this function keeps the
-    container: header, chromosome tree, R-tree index, one zoom level, total summary."""
-    from . import writers
-    chrom_id = {c: i for i, (c, _) in enumerate(header)}
-    tree, reloc = _chrom_tree(header)
-    n_zoom = 1
-    chrom_tree_off = 64 + 24 * n_zoom
-    total_summary_off = chrom_tree_off + len(tree)
-    data_off = total_summary_off + 40
-    tree = bytearray(tree)
-    for r in reloc:
-        (v,) = struct.unpack_from("<Q", tree, r)
-        struct.pack_into("<Q", tree, r, v + chrom_tree_off)
+class RunOrder:
+    """pyBigWig's ordering rule for ``addEntries`` as the reference meets it (frag/_multi_wps.py:319-325,
+    frag/_cleavage_profile.py:470-486): an interval on an unknown contig, or one that starts before the end of
+    the last accepted one, raises there and is skipped with a note on stderr.  The decision needs only the
+    intervals' coordinates, so every rank of a multi-GPU run can take it before anything is computed."""
 
-    leaf_items = []
-    zoom_parts = []  # per run batch: (cid, table, stats)
-    last = (-1, -1)
-    n_valid, vmin, vmax, vsum, vsq, max_raw = 0, np.inf, -np.inf, 0.0, 0.0, 0
-    pos = data_off + 8
-    with open(output_file, "wb") as fh:
-        fh.write(b"\0" * pos)  # header, zoom header, chromosome tree, summary, section count: patched at the end
-        for contig, starts, values, offsets in contig_runs:
-            values = np.asarray(values)
-            offsets = np.asarray(offsets, dtype=np.int64)
-            starts = np.asarray(starts, dtype=np.int64)
-            cid = chrom_id.get(contig)
-            keep = []
-            for k in range(len(starts)):
-                n_k = int(offsets[k + 1] - offsets[k])
-                if n_k == 0:
-                    continue
-                if cid is None or (cid, int(starts[k])) < last:
-                    sys.stderr.write(f"{contig}:{int(starts[k])}-{int(starts[k]) + n_k}\n invalid or out of order interval "
-                                     "encountered. Skipping to next.\n")
-                    continue
-                keep.append(k)
-                last = (cid, int(starts[k]) + n_k)
-            if not keep:
+    def __init__(self, header, quiet: bool = False):
+        self.chrom_id = {c: i for i, (c, _) in enumerate(header)}
+        self.last = (-1, -1)
+        self.quiet = quiet
+
+    def keep(self, contig, starts, lengths) -> list:
+        """Indices of the run's intervals that are written (empty intervals are dropped silently)."""
+        cid = self.chrom_id.get(contig)
+        kept = []
+        for k, (st, n_k) in enumerate(zip(starts, lengths)):
+            st, n_k = int(st), int(n_k)
+            if n_k == 0:
                 continue
-            if len(keep) != len(starts):  # drop the skipped intervals' values
-                values = np.concatenate([values[offsets[k]:offsets[k + 1]] for k in keep])
-                lens = np.array([offsets[k + 1] - offsets[k] for k in keep], np.int64)
-                starts = starts[keep]
-                offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-            blob, table, stats = writers.bigwig_sections(cid, starts, values, offsets, _ITEMS_PER_SECTION, 6, threads)
-            fh.write(blob)
-            sizes = table[:, 2]
-            offs = pos + np.concatenate([[0], np.cumsum(sizes)[:-1]])
-            leaf_items.extend(zip([cid] * len(table), table[:, 0].tolist(), [cid] * len(table), table[:, 1].tolist(),
-                                  offs.tolist(), sizes.tolist()))
-            pos += int(sizes.sum())
-            zoom_parts.append((cid, table, stats))
-            counts = table[:, 1] - table[:, 0]
-            n_valid += int(counts.sum())
-            max_raw = max(max_raw, 24 + 4 * int(counts.max()))
-            vmin, vmax = min(vmin, float(stats[:, 0].min())), max(vmax, float(stats[:, 1].max()))
-            vsum += float(stats[:, 2].sum())
-            vsq += float(stats[:, 3].sum())
-        if n_valid == 0:
+            if cid is None or (cid, st) < self.last:
+                if not self.quiet:
+                    sys.stderr.write(f"{contig}:{st}-{st + n_k}\n invalid or out of order interval "
+                                     "encountered. Skipping to next.\n")
+                continue
+            kept.append(k)
+            self.last = (cid, st + n_k)
+        return kept
+
+
+def fixed_step_payload(cid: int, starts, values, offsets, threads: int = 0):
+    """Data sections of one run of intervals on chromosome ``cid``: ``(blob, table, stats)`` of
+    ``writers.bigwig_sections`` -- everything the container needs from the run, and what a rank that does not
+    own the output file ships to the one that does."""
+    from . import writers
+    return writers.bigwig_sections(cid, starts, values, offsets, _ITEMS_PER_SECTION, 6, threads)
+
+
+class FixedStepBigWigWriter:
+    """The container around the runs' data sections: header, chromosome tree, R-tree index, one zoom level,
+    total summary.  ``add`` takes the payloads in file order; ``close`` writes the indexes and patches the
+    header."""
+
+    def __init__(self, output_file, header):
+        self.header = header
+        tree, reloc = _chrom_tree(header)
+        self.n_zoom = 1
+        self.chrom_tree_off = 64 + 24 * self.n_zoom
+        self.total_summary_off = self.chrom_tree_off + len(tree)
+        self.data_off = self.total_summary_off + 40
+        tree = bytearray(tree)
+        for r in reloc:
+            (v,) = struct.unpack_from("<Q", tree, r)
+            struct.pack_into("<Q", tree, r, v + self.chrom_tree_off)
+        self.tree = tree
+        self.leaf_items = []
+        self.zoom_parts = []  # per run: (cid, table, stats)
+        self.n_valid, self.vmin, self.vmax, self.vsum, self.vsq, self.max_raw = 0, np.inf, -np.inf, 0.0, 0.0, 0
+        self.pos = self.data_off + 8
+        self.fh = open(output_file, "wb")
+        self.fh.write(b"\0" * self.pos)  # header, zoom header, chromosome tree, summary, section count: patched at the end
+
+    def add(self, cid, blob, table, stats) -> None:
+        if len(table) == 0:
+            return
+        self.fh.write(blob)
+        sizes = table[:, 2]
+        offs = self.pos + np.concatenate([[0], np.cumsum(sizes)[:-1]])
+        self.leaf_items.extend(zip([cid] * len(table), table[:, 0].tolist(), [cid] * len(table), table[:, 1].tolist(),
+                                   offs.tolist(), sizes.tolist()))
+        self.pos += int(sizes.sum())
+        self.zoom_parts.append((cid, table, stats))
+        counts = table[:, 1] - table[:, 0]
+        self.n_valid += int(counts.sum())
+        self.max_raw = max(self.max_raw, 24 + 4 * int(counts.max()))
+        self.vmin, self.vmax = min(self.vmin, float(stats[:, 0].min())), max(self.vmax, float(stats[:, 1].max()))
+        self.vsum += float(stats[:, 2].sum())
+        self.vsq += float(stats[:, 3].sum())
+
+    def close(self) -> None:
+        fh = self.fh
+        vmin, vmax = self.vmin, self.vmax
+        if self.n_valid == 0:
             vmin = vmax = 0.0
-        index_off = pos
-        index = _rtree(leaf_items, index_off)
+        index_off = self.pos
+        index = _rtree(self.leaf_items, index_off)
         fh.write(index)
         # zoom level: one summary record per data section, in blocks of 512 records
         zoom_data_off = index_off + len(index)
         rec_dt = np.dtype([("cid", "<u4"), ("s", "<u4"), ("e", "<u4"), ("n", "<u4"), ("mn", "<f4"), ("mx", "<f4"),
                            ("sum", "<f4"), ("sq", "<f4")])
-        recs = np.zeros(sum(len(t) for _, t, _ in zoom_parts), rec_dt)
+        recs = np.zeros(sum(len(t) for _, t, _ in self.zoom_parts), rec_dt)
         o = 0
-        for cid, table, stats in zoom_parts:
+        for cid, table, stats in self.zoom_parts:
             r = recs[o:o + len(table)]
             r["cid"], r["s"], r["e"], r["n"] = cid, table[:, 0], table[:, 1], table[:, 1] - table[:, 0]
             r["mn"], r["mx"], r["sum"], r["sq"] = stats[:, 0], stats[:, 1], stats[:, 2], stats[:, 3]
@@ -215,6 +234,7 @@ def write_fixed_step_bigwig_runs(output_file, header, contig_runs, threads: int 
         zdata = bytearray(struct.pack("<I", len(recs)))
         zleaf = []
         zpos = zoom_data_off + 4
+        max_raw = self.max_raw
         for o in range(0, len(recs), 512):
             blk = recs[o:o + 512]
             raw = blk.tobytes()
@@ -229,12 +249,53 @@ def write_fixed_step_bigwig_runs(output_file, header, contig_runs, threads: int 
         fh.write(zindex)
         fh.write(struct.pack("<I", _BW_MAGIC))
         fh.seek(0)
-        fh.write(struct.pack("<IHHQQQHHQQIQ", _BW_MAGIC, 4, n_zoom, chrom_tree_off, data_off, index_off, 0, 0, 0,
-                             total_summary_off, max(max_raw, 1), 0))
+        fh.write(struct.pack("<IHHQQQHHQQIQ", _BW_MAGIC, 4, self.n_zoom, self.chrom_tree_off, self.data_off, index_off,
+                             0, 0, 0, self.total_summary_off, max(max_raw, 1), 0))
         fh.write(struct.pack("<IIQQ", _ITEMS_PER_SECTION, 0, zoom_data_off, zoom_index_off))
-        fh.write(bytes(tree))
-        fh.write(struct.pack("<Qdddd", n_valid, vmin, vmax, vsum, vsq))
-        fh.write(struct.pack("<Q", len(leaf_items)))
+        fh.write(bytes(self.tree))
+        fh.write(struct.pack("<Qdddd", self.n_valid, vmin, vmax, self.vsum, self.vsq))
+        fh.write(struct.pack("<Q", len(self.leaf_items)))
+        fh.close()
+        self.fh = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, *exc):
+        if self.fh is not None:
+            if exc_type is None:
+                self.close()
+            else:
+                self.fh.close()
+
+
+def select_intervals(keep, starts, values, offsets):
+    """The kept intervals of a run, laid end to end again: ``(starts, values, offsets)``."""
+    starts = np.asarray(starts, dtype=np.int64)
+    offsets = np.asarray(offsets, dtype=np.int64)
+    values = np.asarray(values)
+    if len(keep) == len(starts):
+        return starts, values, offsets
+    vals = np.concatenate([values[offsets[k]:offsets[k + 1]] for k in keep]) if keep else values[:0]
+    lens = np.array([offsets[k + 1] - offsets[k] for k in keep], np.int64)
+    return starts[keep], vals, np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+
+
+def write_fixed_step_bigwig_runs(output_file, header, contig_runs, threads: int = 0) -> None:
+    """The same from runs of intervals: ``contig_runs`` yields ``(contig, starts, values, offsets)`` with interval
+    ``k`` = ``values[offsets[k]:offsets[k+1]]`` at ``starts[k]`` (what one ``ftk_wps_intervals`` launch returns).
+    The data sections -- float32 conversion, section headers, zlib, per-section summaries -- are built by
+    the library's host threads (``writers.bigwig_sections``) and streamed to the file; ``FixedStepBigWigWriter``
+    keeps the container."""
+    order = RunOrder(header)
+    with FixedStepBigWigWriter(output_file, header) as bw:
+        for contig, starts, values, offsets in contig_runs:
+            offsets = np.asarray(offsets, dtype=np.int64)
+            keep = order.keep(contig, starts, np.diff(offsets))
+            if not keep:
+                continue
+            starts, values, offsets = select_intervals(keep, starts, values, offsets)
+            bw.add(order.chrom_id[contig], *fixed_step_payload(order.chrom_id[contig], starts, values, offsets, threads))
 
 
 # ---------------------------------------------------------------------------

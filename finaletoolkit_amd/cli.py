@@ -28,11 +28,21 @@ def _shared(p, min_default, max_default=None, threads=True, policy=True, output_
     p.add_argument("-v", "--verbose", action="count", default=0)
 
 
+# commands whose work is dealt to the ranks of a process group (the reference's Pool(workers) fan-outs:
+# frag/_coverage.py:212-248, _delfi.py:289-300, _multi_wps.py:196-198, _frag_length.py:571-593,
+# _cleavage_profile.py:372, _motif_common.py:635-685); every other command is one process on one GPU
+SHARDED_COMMANDS = ("coverage", "delfi", "wps", "cleavage-profile", "frag-length-bins", "frag-length-intervals",
+                    "end-motifs", "interval-end-motifs", "breakpoint-motifs", "interval-breakpoint-motifs")
+
+
 def build_parser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser(prog="finaletoolkit-amd", description="MI355X fragment-feature engine")
     ap.add_argument("--gpus", type=int, default=1, metavar="N",
-                    help="run `coverage` / `delfi` as N ranks, one per MI355X (contigs dealt to the ranks, one "
-                         "RCCL all-gather of the bin vector); also honoured under torchrun")
+                    help="run the command as N ranks, one per MI355X: contigs are dealt to the ranks, every rank "
+                         "decodes and computes its own, the per-bin / per-interval vectors meet in one RCCL "
+                         "all-gather (per-base outputs: compressed sections sent to rank 0) and rank 0 writes.  "
+                         "Commands: " + ", ".join(SHARDED_COMMANDS) + "; any other command refuses N > 1.  Also "
+                         "honoured under torchrun")
     sub = ap.add_subparsers(dest="command", required=True)
 
     p = sub.add_parser("coverage", help="fragment coverage over BED intervals")
@@ -142,7 +152,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("-b", "--blacklist", dest="blacklist_file", default=None)
     p.add_argument("-g", "--gap-file", dest="gap_file", default=None)
     p.add_argument("-o", "--output", dest="output_file", default="-")
-    p.add_argument("--no-gc-correct", dest="no_gc_correct", action="store_true")
+    p.add_argument("--no-gc-correct", dest="no_gc_correct", action="store_true",
+                   help="skip the LOESS GC correction.  The correction itself is delegated to the third-party "
+                        "`loess` package exactly as in the reference (frag/_delfi_gc_correct.py:71-77); it is not "
+                        "part of this engine, so without that package installed this flag is required")
     p.add_argument("--remove-nocov", dest="remove_nocov", action="store_true", default=True)
     p.add_argument("--no-remove-nocov", dest="remove_nocov", action="store_false")
     p.add_argument("--merge-bins", dest="merge_bins", action="store_true", default=True)
@@ -159,11 +172,17 @@ def main(argv=None) -> int:
     a = build_parser().parse_args(argv)
     import os
     from . import sharding
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if (a.gpus > 1 or world_env > 1) and a.command not in SHARDED_COMMANDS:
+        # never N duplicate runs writing one output file: a command that does not shard runs as ONE process
+        sys.stderr.write(f"`{a.command}` does not shard over GPUs: run it without --gpus / outside torchrun "
+                         f"(sharded commands: {', '.join(SHARDED_COMMANDS)})\n")
+        return 2
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # one rank per GPU (the reference's Pool(workers) fan-out): this process only launches them
         return sharding.launch_ranks([sys.executable, "-m", "finaletoolkit_amd.cli"] + argv, a.gpus,
                                      share_gpu=os.environ.get("FTK_SHARE_GPU") == "1")
-    if a.command in ("coverage", "delfi"):  # the commands whose work is dealt to the ranks
+    if a.command in SHARDED_COMMANDS:
         sharding.init_from_env()
     from . import frag
     if a.command == "coverage":

@@ -1756,6 +1756,11 @@ struct ftk_fragstream {
     hipStream_t pstream = nullptr;
     bool emit_device(Contig&& ct);
     bool run_text_device(RawBuf& first, size_t first_n);
+    // A row / comment line longer than the device carry (kTextCarryMax) cannot be moved from piece to piece on the
+    // device: run_text_device then asks for a second pass over the file with the inflate on the host threads (whose
+    // carry has no limit); the contigs already handed out are skipped in that pass.
+    bool want_host_restart = false, host_inflate_only = false;
+    std::set<std::string> emitted_names;
 
     // Hand one finished contig to the consumer.  Sorting (BAM), packing into page-locked memory and
     // waiting for queue space happen on a helper thread, one contig at a time (so the order is kept),
@@ -1919,6 +1924,7 @@ struct ftk_fragstream {
                 if (q + 8 > off + bs) return false;
                 const uint8_t* tr = p + off + bs - 8;
                 const size_t isize = (size_t)tr[4] | ((size_t)tr[5] << 8) | ((size_t)tr[6] << 16) | ((size_t)tr[7] << 24);
+                if (isize > (size_t(1) << 16)) return false;  // a BGZF block holds at most 64 KB of data (htslib refuses more too)
                 blocks->push_back({q, off + bs - 8 - q, tot, isize});
                 tot += isize;
                 off += bs;
@@ -1991,6 +1997,27 @@ void ftk_fragstream::run_guarded() {
         ok = true;
     } else {
         ok = bam ? run_bam(buf, n) : device >= 0 ? run_text_device(buf, n) : run_text(buf, n);
+        bool stopped;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stopped = stop || err != FTK_OK;
+        }
+        if (!ok && want_host_restart && !stopped) {
+            // (see want_host_restart) the same range of the file once more, inflated by the host threads
+            drain_ahead();
+            (void)hipStreamSynchronize(pstream);
+            host_inflate_only = true;
+            read_end = -1;
+            partial_tail_ok = false;
+            first_skip = 0;
+            rewind(fp);
+            if (has_only) {
+                const IndexSpan sp = index_lookup(index_path_of(path, false), false, only, -1);
+                if (sp.usable && sp.present && !seek_to(sp)) { read_end = -1; partial_tail_ok = false; first_skip = 0; rewind(fp); }
+            }
+            const size_t n2 = fill(buf, 0);
+            ok = run_text_device(buf, n2);
+        }
     }
     (void)ok;
     flush();
@@ -2361,6 +2388,7 @@ bool ftk_fragstream::emit_device(Contig&& ct) {
     ct.p.end = d.end;
     ct.p.mapq = d.mapq;
     ct.p.strand = d.strand;
+    emitted_names.insert(ct.name);
     t->contigs.push_back(std::move(ct));
     std::unique_lock<std::mutex> lk(mu);
     cv.wait(lk, [&] { return stop || ready.size() < max_queued; });
@@ -2378,7 +2406,7 @@ bool ftk_fragstream::emit_device(Contig&& ct) {
 // host's field-rule parser (parse_text_parallel) and its columns are uploaded - same rows either way.
 bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     StageClock clk(this);
-    if (hipSetDevice(device) != hipSuccess || (pstream = stream_pool().take(device)) == nullptr) {
+    if (hipSetDevice(device) != hipSuccess || (!pstream && (pstream = stream_pool().take(device)) == nullptr)) {
         (void)hipGetLastError();
         return fail(FTK_ERR_HIP, "cannot create the parse stream");
     }
@@ -2434,12 +2462,14 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     size_t gpu_pieces = 0, host_pieces = 0;
     // The BGZF blocks are inflated on the GPU too (ftk_inflate.hip): the host only reads the file and copies it into
     // page-locked memory.  FTK_DEVICE_INFLATE=0 keeps the inflate on the host threads (libdeflate / zlib).
-    static const bool dev_inflate = !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
+    static const bool dev_inflate_env = !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
+    const bool dev_inflate = dev_inflate_env && !host_inflate_only;
 
     // one contig run of a piece: n rows at the given column pointers (device or host)
     auto take_run = [&](const std::string& name, const int32_t* s0, const int32_t* e0, const uint8_t* q0, const uint8_t* t0,
                         size_t rows, hipMemcpyKind kind) -> bool {
         if (has_only && name != only) return true;
+        if (host_inflate_only && emitted_names.count(name)) return true;  // second pass: handed out by the first
         if (have_cur && name != cur.name) {
             if (!emit_device(std::move(cur))) return false;
             cur = Contig{};
@@ -2470,7 +2500,10 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
                                              std::to_string(S.h_ist->reason) + ")").c_str());
             for (size_t i = 0; i < S.n_tab; ++i)
                 if (S.h_crc[i] != S.want_crc[i]) return fail(FTK_ERR_FORMAT, "BGZF block CRC mismatch (device inflate)");
-            if (sum.carry_overflow) return fail(FTK_ERR_FORMAT, "a row longer than 64 KB");
+            if (sum.carry_overflow) {  // a line too long for the device carry: the host-inflate pass takes the file
+                want_host_restart = true;
+                return false;
+            }
             if (sum.text_len == 0) return true;
             const bool drop_last = S.cut_tail && sum.last_line_bad && sum.n_bad == 1;  // the row the read stopped in
             const size_t n_rows = (size_t)sum.n_lines - (drop_last ? 1 : 0);
@@ -2620,7 +2653,9 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
                     q = nl + 1;
                 }
             }
-            if (!S.ensure(ftk::kTextCarryMax + total + 64) || !S.ensure_inflate(used, blocks.size()))
+            // h_text also stages the piece's COMPRESSED bytes on their way up: many tiny blocks (or small ISIZE
+            // trailers) make `used` larger than the text, so the buffer is sized for whichever is larger
+            if (!S.ensure(std::max(ftk::kTextCarryMax + total + 64, used + 64)) || !S.ensure_inflate(used, blocks.size()))
                 return fail(FTK_ERR_OOM, "out of page-locked / device memory for the text piece");
             clk.lap(5);
             {

@@ -8,13 +8,17 @@
 // (ballot-ranked canonical codes, one symbol per lane), the LZ77 copies (up to 64 bytes per step), the input
 // prefetch (256 bytes of the payload per vector load, handed to the bit buffer word by word with v_readlane) and
 // the write-behind of finished output.  The chip is filled by running thousands of such waves side by side:
-// 12 KB of LDS per wave -> 13 waves per CU.
+// ~10 KB of LDS per wave (kRing = 2048) -> 16 waves per CU.
 //
-// Output window.  The last 8 KB of a block's output live in an LDS ring indexed by the absolute output address,
-// so nearly every match (fragment rows repeat the previous line, 30-60 bytes back) is an LDS-to-LDS copy;
-// finished 2 KB granules are streamed to HBM with 16-byte stores as soon as the write position passes them, and a
-// match that reaches further back than the ring reads the bytes it needs from there (they were stored at least
-// 5 KB of output earlier).
+// Output window.  The last kRing bytes (2 KB by default) of a block's output live in an LDS ring indexed by the
+// absolute output address, so nearly every match (fragment rows repeat the previous line, 30-60 bytes back) is an
+// LDS-to-LDS copy; finished kGran-byte granules (1 KB: half the ring) are streamed to HBM with 16-byte stores as
+// soon as the write position passes them, and a match that reaches further back than kFarDist (1 726 bytes) reads
+// the bytes it needs from HBM.  Why that is safe (the static_asserts below pin it): such a match's newest source
+// byte is A0 + len - 1 - d <= A0 - (kFarDist - 256), and every granule below floor(A0 / kGran) * kGran >=
+// A0 - (kGran - 1) has been flushed, so with kFarDist - 257 >= kGran - 1 all of its sources are in HBM (behind a
+// workgroup fence); and an LDS-to-LDS match (d <= kFarDist) never has its sources overwritten by its own stores,
+// which reach at most 258 + 64 bytes past A0: kFarDist + 258 + 64 <= kRing.
 #include <hip/hip_runtime.h>
 
 #include "ftk_inflate.h"
@@ -32,12 +36,15 @@ namespace {
 #define FTK_INFLATE_ROOT 10
 #endif
 constexpr int kRing = FTK_INFLATE_RING, kRingMask = kRing - 1;
-constexpr int kGranShift = kRing >= 8192 ? 11 : 10, kGran = 1 << kGranShift;  // write-behind granule: a quarter of the ring
+constexpr int kGranShift = kRing >= 8192 ? 11 : 10, kGran = 1 << kGranShift;  // write-behind granule: at most half the ring
 #ifndef FTK_INFLATE_DIST_ROOT
 #define FTK_INFLATE_DIST_ROOT 9
 #endif
 constexpr int kLitRoot = FTK_INFLATE_ROOT, kDistRoot = FTK_INFLATE_DIST_ROOT, kPreRoot = 7;
 constexpr int kFarDist = kRing - 258 - 64;    // matches further back than this read from HBM
+static_assert((kRing & (kRing - 1)) == 0 && kGran <= kRing / 2, "the write-behind granule must be at most half the ring");
+static_assert(kFarDist + 258 + 64 <= kRing, "an LDS-to-LDS match must not overwrite its own sources");
+static_assert(kFarDist - 257 >= kGran - 1, "the sources of a far match must already be flushed to HBM");
 
 struct __align__(16) WaveLds {
     uint8_t ring[kRing];
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                     if (2 * D <= done + d) D *= 2;
                 }
             } else {
-                // further back than the ring: those bytes went to HBM at least 5 KB of output ago
+                // further back than kFarDist: those bytes are in HBM already (see the header comment)
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 for (int o = lane; o < len; o += 64) {
                     const uint32_t a = A0 + (uint32_t)o;

@@ -251,6 +251,46 @@ int write_all(int fd, const char* p, size_t n) {
 
 }  // namespace
 
+// Independent gzip members of 1 MB of text each, compressed in parallel, handed to `sink` in order (the body of
+// ftk_file_write's .gz mode and of ftk_gzip_members: the same bytes either way).
+template <class Sink>
+static int gzip_members_to(const char* data, int64_t n, int gzip_level, int n_threads, Sink&& sink) {
+    constexpr size_t kBlock = size_t(1) << 20;
+    const int64_t n_blocks = (n + (int64_t)kBlock - 1) / (int64_t)kBlock;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads > 0 ? n_threads : ftk_host::default_threads(), n_blocks));
+    const size_t bound = deflate_bound(true, kBlock);
+    const int64_t batch = (int64_t)nt * 4;  // blocks per round
+    std::vector<uint8_t> outbuf((size_t)std::min<int64_t>(batch, n_blocks) * bound);
+    std::vector<size_t> sizes((size_t)std::min<int64_t>(batch, n_blocks));
+    const Deflater& D = deflater();
+    std::vector<void*> comps(nt, nullptr);
+    if (D.ok)
+        for (auto& c : comps) c = D.alloc(std::min(gzip_level, 12));
+    int rc = FTK_OK;
+    for (int64_t b0 = 0; b0 < n_blocks && rc == FTK_OK; b0 += batch) {
+        const int64_t nb = std::min(batch, n_blocks - b0);
+        std::atomic<int64_t> next{0};
+        std::atomic<bool> bad{false};
+        ftk_host::parallel_run(nt, [&](int t) {
+            for (;;) {
+                const int64_t k = next.fetch_add(1);
+                if (k >= nb) break;
+                const size_t off = (size_t)(b0 + k) * kBlock;
+                const size_t len = std::min(kBlock, (size_t)n - off);
+                sizes[k] = deflate_block(comps[t], true, gzip_level, (const uint8_t*)data + off, len,
+                                         outbuf.data() + (size_t)k * bound, bound);
+                if (!sizes[k]) bad = true;
+            }
+        });
+        if (bad) { rc = wfail(FTK_ERR_OOM, "deflate failed"); break; }
+        for (int64_t k = 0; k < nb && rc == FTK_OK; ++k) rc = sink((const char*)outbuf.data() + (size_t)k * bound, sizes[k]);
+    }
+    if (D.ok)
+        for (auto c : comps)
+            if (c) D.release(c);
+    return rc;
+}
+
 extern "C" {
 
 int ftk_format_wig_i64(const int64_t* values, int64_t n, int n_threads, char** out, int64_t* out_len) {
@@ -292,46 +332,32 @@ int ftk_file_write(const char* path, const char* data, int64_t n, int gzip_level
             if (!got || write_all(fd, (const char*)buf, got)) rc = wfail(FTK_ERR_IO, "write to %s failed", path);
         }
     } else {
-        // independent gzip members of 1 MB of text each, compressed in parallel, written in order
-        constexpr size_t kBlock = size_t(1) << 20;
-        const int64_t n_blocks = (n + (int64_t)kBlock - 1) / (int64_t)kBlock;
-        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads > 0 ? n_threads : ftk_host::default_threads(), n_blocks));
-        const size_t bound = deflate_bound(true, kBlock);
-        const int64_t batch = (int64_t)nt * 4;  // blocks per round
-        std::vector<uint8_t> outbuf((size_t)std::min<int64_t>(batch, n_blocks) * bound);
-        std::vector<size_t> sizes((size_t)std::min<int64_t>(batch, n_blocks));
-        const Deflater& D = deflater();
-        std::vector<void*> comps(nt, nullptr);
-        if (D.ok)
-            for (auto& c : comps) c = D.alloc(std::min(gzip_level, 12));
-        for (int64_t b0 = 0; b0 < n_blocks && rc == FTK_OK; b0 += batch) {
-            const int64_t nb = std::min(batch, n_blocks - b0);
-            std::atomic<int64_t> next{0};
-            std::atomic<bool> bad{false};
-            ftk_host::parallel_run(nt, [&](int t) {
-                for (;;) {
-                    const int64_t k = next.fetch_add(1);
-                    if (k >= nb) break;
-                    const size_t off = (size_t)(b0 + k) * kBlock;
-                    const size_t len = std::min(kBlock, (size_t)n - off);
-                    sizes[k] = deflate_block(comps[t], true, gzip_level, (const uint8_t*)data + off, len,
-                                             outbuf.data() + (size_t)k * bound, bound);
-                    if (!sizes[k]) bad = true;
-                }
-            });
-            if (bad) { rc = wfail(FTK_ERR_OOM, "deflate failed"); break; }
-            for (int64_t k = 0; k < nb; ++k)
-                if (write_all(fd, (const char*)outbuf.data() + (size_t)k * bound, sizes[k])) {
-                    rc = wfail(FTK_ERR_IO, "write to %s failed: %s", path, strerror(errno));
-                    break;
-                }
-        }
-        if (D.ok)
-            for (auto c : comps)
-                if (c) D.release(c);
+        rc = gzip_members_to(data, n, gzip_level, n_threads, [&](const char* p, size_t len) {
+            return write_all(fd, p, len) ? wfail(FTK_ERR_IO, "write to %s failed: %s", path, strerror(errno)) : FTK_OK;
+        });
     }
     if (close(fd) && rc == FTK_OK) rc = wfail(FTK_ERR_IO, "close of %s failed: %s", path, strerror(errno));
     return rc;
+}
+
+int ftk_gzip_members(const char* data, int64_t n, int gzip_level, int n_threads, char** out, int64_t* out_len) {
+    if (!out || !out_len || n < 0 || (n > 0 && !data) || gzip_level <= 0) return wfail(FTK_ERR_INVALID, "bad arguments");
+    *out = nullptr;
+    *out_len = 0;
+    std::vector<char> acc;
+    if (n > 0) {
+        const int rc = gzip_members_to(data, n, gzip_level, n_threads, [&](const char* p, size_t len) {
+            acc.insert(acc.end(), p, p + len);
+            return (int)FTK_OK;
+        });
+        if (rc != FTK_OK) return rc;
+    }
+    char* buf = (char*)malloc(acc.size() + 1);
+    if (!buf) return wfail(FTK_ERR_OOM, "out of host memory");
+    if (!acc.empty()) memcpy(buf, acc.data(), acc.size());
+    *out = buf;
+    *out_len = (int64_t)acc.size();
+    return FTK_OK;
 }
 
 int ftk_fill_wps_records(void* dst, int64_t n, const uint32_t contig_ucs4[16], int64_t start, const int64_t* values,

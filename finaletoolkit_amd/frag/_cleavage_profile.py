@@ -18,6 +18,7 @@ import numpy as np
 
 from ..source import get_engine, open_source
 from ..utils import chrom_sizes_to_dict, chrom_sizes_to_list
+from ._runs import write_per_base_runs
 from ._wps import _resolve_aliases
 
 __all__ = ["cleavage_profile", "multi_cleavage_profile"]
@@ -93,33 +94,18 @@ def multi_cleavage_profile(input_file, interval_file, chrom_sizes, left: int = 0
     src = open_source(input_file, workers)
     eng = get_engine()
 
-    def contig_runs():
-        i, n = 0, len(contigs)
-        while i < n:  # one launch per run of intervals on the same contig
-            j = i
-            while j < n and contigs[j] == contigs[i]:
-                j += 1
-            vals, offs = eng.cleavage_intervals(src.require(contigs[i]), starts[i:j], stops[i:j], min_length,
-                                                max_length, quality_threshold)
-            yield contigs[i], starts[i:j], vals, offs
-            i = j
+    def score_run(c, run_starts, run_stops):  # one launch per run of intervals on the same contig
+        return eng.cleavage_intervals(src.require(c), run_starts, run_stops, min_length, max_length,
+                                      quality_threshold)
 
+    # Pool(workers) of the reference (:372-395) = one rank per GPU here: contigs dealt to the ranks, rank 0 writes
     if isinstance(output_file, str):
         if output_file.endswith(".bw"):
-            from ..bigwig import write_fixed_step_bigwig_runs
-            write_fixed_step_bigwig_runs(output_file, header, contig_runs())
+            write_per_base_runs(output_file, "bw", header, contigs, starts, stops, score_run)
         elif output_file.endswith(".bed.gz") or output_file.endswith("bedgraph.gz") or output_file == "-":
             # rows "contig  pos  pos+1  proportion" with the floats printed as Python prints them, formatted by
             # the library's host threads; gzip members compressed in parallel
-            from .. import writers
-            writers.write_text(output_file, b"", writers.GZIP_LEVEL)
-            first = True
-            for contig, st, values, offs in contig_runs():
-                for rows in writers.bedgraph_batches(contig, st, values, offs):
-                    with rows:
-                        if rows.n:
-                            rows.write(output_file, writers.GZIP_LEVEL, append=not first)
-                            first = False
+            write_per_base_runs(output_file, "bedgraph.gz", header, contigs, starts, stops, score_run)
         else:
             raise ValueError("output_file can only have suffix .bw, .bedgraph.gz, or .bed.gz.")
     elif output_file is not None:

@@ -20,6 +20,7 @@ from typing import NamedTuple, Union
 
 import numpy as np
 
+from .. import sharding
 from ..source import get_engine, open_source
 from ..utils import _check_policy, _check_region, _region_contigs, get_intervals
 
@@ -135,14 +136,16 @@ def frag_length(input_file: Union[str, Path], contig: str | None = None, start: 
     lengths = np.concatenate(parts).astype(np.int32) if parts else np.zeros(0, np.int32)
 
     if isinstance(output_file, str):
-        if output_file.endswith(".bin"):
+        if not (output_file.endswith(".bin") or output_file == "-"):
+            raise ValueError("output_file can only have suffixes .wig or .wig.gz.")
+        if not sharding.is_writer():
+            pass  # a region query is not sharded: every rank holds the result, rank 0 alone writes it
+        elif output_file.endswith(".bin"):
             with open(output_file, "wb") as out:
                 lengths.tofile(out)
-        elif output_file == "-":
+        else:
             for line in lengths:
                 stdout.write(f"{line}\n")
-        else:
-            raise ValueError("output_file can only have suffixes .wig or .wig.gz.")
     elif output_file is not None:
         raise TypeError(f'output_file is unsupported type "{type(input_file)}". output_file should be a string '
                         "specifying the path of the file to write output scores to.")
@@ -167,15 +170,35 @@ def frag_length_bins(input_file, contig: str | None = None, start: int | None = 
     src = open_source(input_file)
     eng = get_engine()
     names, whole = _region_contigs(src, contig)
+    # the whole file: contigs dealt to the ranks of the process group (one per GPU), the sparse length -> count
+    # maps meet in one all-gather of small objects; a single contig / region is counted by every rank alike
+    rank, world, owner = sharding.contig_owner({c: float(src.lengths.get(c) or 1) for c in names})
+    shard = world > 1 and len(names) > 1
     dist: dict[int, int] = {}
-    for c in names:
-        key = src.require(c)
-        lo, hi = _length_range(eng, key, min_length, max_length)
-        h = _window_hists(eng, key, [None if whole else start], [None if whole else stop], lo, hi, quality_threshold,
-                          min_length, max_length, intersect_policy)
-        if h.shape[1]:
-            for b in np.nonzero(h[0])[0]:
-                dist[lo + int(b)] = dist.get(lo + int(b), 0) + int(h[0, b])
+    err = None
+    try:
+        for c in names:
+            if shard and owner[c] != rank:
+                continue
+            key = src.require(c)
+            lo, hi = _length_range(eng, key, min_length, max_length)
+            h = _window_hists(eng, key, [None if whole else start], [None if whole else stop], lo, hi,
+                              quality_threshold, min_length, max_length, intersect_policy)
+            if h.shape[1]:
+                for b in np.nonzero(h[0])[0]:
+                    dist[lo + int(b)] = dist.get(lo + int(b), 0) + int(h[0, b])
+    except Exception as e:  # noqa: BLE001 - every rank learns of it below
+        err = e
+    if world > 1:
+        sharding.agree(err)
+    elif err is not None:
+        raise err
+    if shard:
+        merged: dict[int, int] = {}
+        for part in sharding.allgather_object(dist):
+            for length, count in part.items():
+                merged[length] = merged.get(length, 0) + count
+        dist = merged
     total_count = sum(dist.values())
     if total_count == 0:
         warnings.warn("No fragments found in the specified region. Returning empty result.", RuntimeWarning,
@@ -197,7 +220,7 @@ def frag_length_bins(input_file, contig: str | None = None, start: int | None = 
     np.add.at(counts_arr, (values - bin_start) // bin_size, freq)
     counts = counts_arr.tolist()
 
-    if output_file is not None:
+    if output_file is not None and sharding.is_writer():
         out_is_file = False
         try:
             if output_file == "-":
@@ -239,9 +262,20 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
     intervals = get_intervals(interval_file)
     results: list = [None] * len(intervals)
     by_contig: dict[str, list[int]] = {}
-    for i, (c, _, _, _) in enumerate(intervals):
+    extent: dict[str, int] = {}
+    for i, (c, _, b, _) in enumerate(intervals):
         by_contig.setdefault(c, []).append(i)
-    for c, idx in by_contig.items():
+        extent[c] = max(extent.get(c, 0), int(b))
+    # Pool(workers) of the reference (:571-593) = one rank per GPU: the contigs are dealt to the ranks, a rank
+    # decodes and counts only its own, and one all-gather of the seven statistics per interval (float64 bit
+    # patterns) gives every rank the whole list; rank 0 writes.
+    names = list(by_contig)
+    rank, world, owner = sharding.contig_owner(
+        {c: float(src.lengths.get(c) or extent.get(c) or 1) * (1.0 + len(by_contig[c]) / 1000.0) for c in names})
+
+    def contig_stats(c, idx):
+        """float64 [len(idx), 7]: mean median stdev min max total n_short; total 0 = no fragment"""
+        out = np.zeros((len(idx), 7), np.float64)
         key = src.require(c)
         lo, hi = _length_range(eng, key, min_length, max_length)
         ws = np.array([intervals[i][1] for i in idx], np.int64).astype(np.int32)
@@ -252,22 +286,46 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
             h = _window_hists(eng, key, ws[w0:w0 + step], we[w0:w0 + step], lo, hi, quality_threshold, min_length,
                               max_length, intersect_policy)
             if h.shape[1] == 0:
-                for j in range(h.shape[0]):
-                    contig, start, stop, name = intervals[idx[w0 + j]]
-                    results[idx[w0 + j]] = FragLengthStats(contig, start, stop, name, -1, -1, -1, -1, -1, -1, -1)
                 continue
             rows_per = max(1, (1 << 22) // h.shape[1])  # statistics of a few thousand intervals at a time
             for r0 in range(0, h.shape[0], rows_per):
                 blk = h[r0:r0 + rows_per]
-                mean, median, stdev, vmin, vmax, total, n_short = (a.tolist() for a in _stats_rows(blk, lo, short_reads))
-                for j in range(blk.shape[0]):
-                    contig, start, stop, name = intervals[idx[w0 + r0 + j]]
-                    if total[j] == 0:
-                        results[idx[w0 + r0 + j]] = FragLengthStats(contig, start, stop, name, -1, -1, -1, -1, -1, -1, -1)
-                    else:
-                        results[idx[w0 + r0 + j]] = FragLengthStats(contig, start, stop, name, mean[j], median[j], stdev[j],
-                                                                    vmin[j], vmax[j], total[j], n_short[j] / total[j])
+                cols = _stats_rows(blk, lo, short_reads)
+                dst = out[w0 + r0:w0 + r0 + blk.shape[0]]
+                for k in range(7):
+                    if cols[k] is not None:
+                        dst[:, k] = cols[k]
+                dst[cols[5] == 0] = 0.0
+        return out
 
+    local, err = {}, None
+    try:
+        for c, idx in by_contig.items():
+            if owner[c] == rank:
+                local[c] = contig_stats(c, idx)
+    except Exception as e:  # noqa: BLE001 - every rank learns of it below
+        err = e
+    if world > 1:
+        sharding.agree(err)
+        stats = sharding.gather_float_rows(local, names, {c: len(by_contig[c]) for c in names}, owner, 7)
+    elif err is not None:
+        raise err
+    else:
+        stats = local
+    for c, idx in by_contig.items():
+        mean, median, stdev, vmin, vmax, total, n_short = (stats[c][:, k].tolist() for k in range(7))
+        for j, i in enumerate(idx):
+            contig, start, stop, name = intervals[i]
+            if total[j] == 0:
+                results[i] = FragLengthStats(contig, start, stop, name, -1, -1, -1, -1, -1, -1, -1)
+            else:
+                results[i] = FragLengthStats(contig, start, stop, name, mean[j], median[j], stdev[j], int(vmin[j]),
+                                             int(vmax[j]), int(total[j]), int(n_short[j]) / int(total[j]))
+
+    if output_file is not None and not sharding.is_writer():
+        if not (output_file.endswith((".bed", ".bedgraph", ".bed.gz")) or output_file == "-"):
+            raise ValueError("The output file should have .bed or .bed.gz as as suffix.")
+        output_file = None
     output_is_file = False
     if output_file is not None:
         try:

@@ -19,6 +19,7 @@ from sys import stdin, stdout
 
 import numpy as np
 
+from .. import sharding
 from ..reference import ReferenceGenome
 from ..source import get_engine, open_source
 
@@ -279,33 +280,56 @@ def region_histograms(input_file, refseq_file, regions, spec: dict, quality_thre
     src = open_source(input_file, workers, warn_bed6=True)
     eng = get_engine()
     by_contig: dict[str, list[int]] = {}
+    extent: dict[str, int] = {}
     for i, r in enumerate(regions):
         by_contig.setdefault(r[0], []).append(i)
-    with ReferenceGenome(refseq_file) as ref:
-        for contig, idx in by_contig.items():
-            if not src.has(contig) or contig not in ref.chroms:
-                continue
-            lim = 2 ** 31 - 1
-            ws = np.clip([regions[i][1] for i in idx], -lim - 1, lim)
-            we = np.clip([regions[i][2] for i in idx], -lim - 1, lim)
-            rid = ref.device_image(eng, contig)
-            counts, _, err = eng.motif_counts(src.require(contig), rid, ws, we, k, spec["fwd_offset"],
-                                              spec["rev_offset"], spec["both_strands"], spec["negative_strand"],
-                                              spec["guard"], spec["rev_oob_is_error"], quality_threshold,
-                                              bam=src.is_bam)
-            if err.any():
-                j = idx[int(np.flatnonzero(err)[0])]
-                raise RuntimeError(
-                    f"Error querying sequence at the 3' end of a fragment in {contig}:{regions[j][1]}-"
-                    f"{regions[j][2]}. Chrom length: {ref.chroms.get(contig, 'unknown')}. Please verify that the "
-                    "reference file matches the fragment file.")
-            out[idx] = counts
+        extent[r[0]] = max(extent.get(r[0], 0), int(min(r[2], 2 ** 31 - 1)))
+    # The reference hands the regions to Pool(workers) (_motif_common.py:635-685); here the contigs are dealt to
+    # the ranks of the process group (one per GPU; a k-mer count depends only on its own contig's fragments and
+    # reference), a rank decodes / uploads / counts only its own, and one all-gather of the count rows gives
+    # every rank the whole table.
+    names = list(by_contig)
+    rank, world, owner = sharding.contig_owner({c: float(extent[c]) + 1.0 for c in names})
+    local, err = {}, None
+    try:
+        with ReferenceGenome(refseq_file) as ref:
+            for contig, idx in by_contig.items():
+                if owner[contig] != rank:
+                    continue
+                local[contig] = np.zeros((len(idx), 4 ** k), np.int64)
+                if not src.has(contig) or contig not in ref.chroms:
+                    continue
+                lim = 2 ** 31 - 1
+                ws = np.clip([regions[i][1] for i in idx], -lim - 1, lim)
+                we = np.clip([regions[i][2] for i in idx], -lim - 1, lim)
+                rid = ref.device_image(eng, contig)
+                counts, _, errs = eng.motif_counts(src.require(contig), rid, ws, we, k, spec["fwd_offset"],
+                                                   spec["rev_offset"], spec["both_strands"], spec["negative_strand"],
+                                                   spec["guard"], spec["rev_oob_is_error"], quality_threshold,
+                                                   bam=src.is_bam)
+                if errs.any():
+                    j = idx[int(np.flatnonzero(errs)[0])]
+                    raise RuntimeError(
+                        f"Error querying sequence at the 3' end of a fragment in {contig}:{regions[j][1]}-"
+                        f"{regions[j][2]}. Chrom length: {ref.chroms.get(contig, 'unknown')}. Please verify that the "
+                        "reference file matches the fragment file.")
+                local[contig][:] = counts
+    except Exception as e:  # noqa: BLE001 - every rank learns of it below
+        err = e
+    if world > 1:
+        sharding.agree(err)
+        local = sharding.gather_bin_vectors(local, names, {c: len(by_contig[c]) for c in names},
+                                            {c: 1.0 for c in names}, k=4 ** k, owner=owner)
+    elif err is not None:
+        raise err
+    for contig, idx in by_contig.items():
+        out[idx] = local[contig]
     return out
 
 
 def write_motif_freqs(results, output_file) -> None:
     """TSV, or CSV for a ``.csv`` suffix (_motif_common.py:688-697)."""
-    if output_file is None:
+    if output_file is None or not sharding.is_writer():  # every rank holds the result; rank 0 alone writes it
         return
     if output_file.endswith(".csv"):
         results.to_tsv(output_file, sep=",")

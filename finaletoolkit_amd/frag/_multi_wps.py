@@ -4,7 +4,8 @@ site handling (``src/finaletoolkit/frag/_multi_wps.py:31-341``): each site is
 replaced by an ``interval_size`` window centred on its midpoint, clipped to the
 contig, the previous window truncated where the next one starts, intervals
 sorted into header order.  All windows of a contig are scored in ONE
-``ftk_wps_intervals`` launch instead of a process pool of ``wps`` calls.
+``ftk_wps_intervals`` launch instead of a process pool of ``wps`` calls; with
+several ranks (one per GPU) the contigs are dealt to the ranks and rank 0 writes.
 """
 from __future__ import annotations
 
@@ -19,6 +20,7 @@ import numpy as np
 
 from ..source import get_engine, open_source
 from ..utils import chrom_sizes_to_list
+from ._runs import write_per_base_runs
 from ._wps import _resolve_aliases
 
 __all__ = ["multi_wps"]
@@ -109,28 +111,20 @@ def multi_wps(input_file, site_bed, chrom_sizes=None, output_file: str | None = 
                          "applicable). Please ensure that all files use the same reference genome and chromosome "
                          "naming conventions.")
 
-    def contig_runs():
-        """(contig, starts, values, offsets) per run of intervals on one contig, in order: one launch each;
-        interval k of the run is values[offsets[k]:offsets[k+1]]."""
-        i = 0
-        n = len(contigs)
-        while i < n:
-            j = i
-            while j < n and contigs[j] == contigs[i]:
-                j += 1
-            c = contigs[i]
-            vals, offs = eng.wps_intervals(src.require(c), starts[i:j], stops[i:j], chrom_sizes_dict[c],
-                                           int(window_size), 0 if min_length is None else int(min_length),
-                                           int(max_length), int(quality_threshold))
-            yield c, starts[i:j], vals, offs
-            i = j
+    def score_run(c, run_starts, run_stops):
+        """All intervals of one run in ONE launch; interval k of the run is values[offsets[k]:offsets[k+1]]."""
+        return eng.wps_intervals(src.require(c), run_starts, run_stops, chrom_sizes_dict[c], int(window_size),
+                                 0 if min_length is None else int(min_length), int(max_length),
+                                 int(quality_threshold))
 
+    # The reference scores the intervals in Pool(workers) and the parent writes them in order (:196-198,
+    # :300-341).  Here the contigs are dealt to the ranks of the process group (one per GPU), every rank scores,
+    # formats and compresses its own, rank 0 lays the pieces into the file (frag/_runs.py).
     if isinstance(output_file, str):
         if output_file.endswith(".bw"):
-            from ..bigwig import write_fixed_step_bigwig_runs
-            write_fixed_step_bigwig_runs(output_file, header, contig_runs())
+            write_per_base_runs(output_file, "bw", header, contigs, starts, stops, score_run)
         elif output_file.endswith(".bed.gz") or output_file.endswith("bedGraph.gz"):
-            _write_bedgraph_gz(output_file, contig_runs())
+            write_per_base_runs(output_file, "bedgraph.gz", header, contigs, starts, stops, score_run)
         else:
             raise ValueError("output_file can only have suffix .bw")
     elif output_file is not None:
@@ -139,17 +133,3 @@ def multi_wps(input_file, site_bed, chrom_sizes=None, output_file: str | None = 
     if verbose:
         stderr.write(f"multi_wps took {time.time() - t0} s to complete\n")
     return output_file
-
-
-def _write_bedgraph_gz(output_file, contig_runs) -> None:
-    """``contig  pos  pos+1  wps`` rows (frag/_multi_wps.py:328-341), a contig's intervals at a time: rows
-    formatted by the library's host threads, written as gzip members compressed in parallel."""
-    from .. import writers
-    writers.write_text(output_file, b"", writers.GZIP_LEVEL)  # gzip.open(..., "wt") of nothing: a valid empty file
-    first = True
-    for contig, starts, values, offsets in contig_runs:
-        for rows in writers.bedgraph_batches(contig, starts, values, offsets):
-            with rows:
-                if rows.n:
-                    rows.write(output_file, writers.GZIP_LEVEL, append=not first)
-                    first = False

@@ -14,6 +14,7 @@ from typing import Union
 
 import numpy as np
 
+from .. import sharding
 from ..source import get_engine, open_source
 
 __all__ = ["wps"]
@@ -84,7 +85,10 @@ def wps(input_file: Union[str, Path], chrom: str, start: int, stop: int, chrom_s
     scores = _scores_array(chrom, start, values)
 
     if isinstance(output_file, str):
-        _write_wig(output_file, chrom, start, stop, scores)
+        if not (output_file.endswith((".wig.gz", ".wig")) or output_file == "-"):
+            raise ValueError("output_file can only have suffixes .wig or .wig.gz.")
+        if sharding.is_writer():  # one region is not sharded: under several ranks rank 0 alone writes it
+            _write_wig(output_file, chrom, start, stop, scores)
     elif output_file is not None:
         raise TypeError(f'output_file is unsupported type "{type(input_file)}". output_file should be a string '
                         "specifying the path of the file to output scores to.")

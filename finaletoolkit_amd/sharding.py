@@ -231,3 +231,101 @@ def allreduce_sum(value: int, group=None, device=None) -> int:
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return int(t.item())
+
+
+def contig_owner(weights: Dict[str, float], group=None) -> Tuple[int, int, Dict[str, int]]:
+    """``(rank, world, owner)``: the contigs of ``weights`` dealt to the ranks of the initialised process group
+    by LPT (everything on rank 0 without one).  Every rank computes the same map from the same inputs."""
+    rank, world = rank_world(group)
+    return rank, world, lpt_assign(weights, world)
+
+
+def is_writer(group=None) -> bool:
+    """True on the one rank that writes output files / stdout (rank 0; a plain single process)."""
+    return rank_world(group)[0] == 0
+
+
+def agree(error: Optional[BaseException] = None, group=None) -> None:
+    """Collective check-point of a sharded command: every rank passes the exception its share of the work
+    raised (or None).  If any rank failed, ALL ranks raise -- the failing rank its own exception, the others a
+    ``RuntimeError`` naming it -- instead of the healthy ranks waiting forever in the next collective."""
+    rank, world = rank_world(group)
+    if world == 1:
+        if error is not None:
+            raise error
+        return
+    import torch.distributed as dist
+    said = [None] * world
+    dist.all_gather_object(said, None if error is None else f"{type(error).__name__}: {error}", group=group)
+    if error is not None:
+        raise error
+    for r, msg in enumerate(said):
+        if msg is not None:
+            raise RuntimeError(f"rank {r} failed: {msg}")
+
+
+def allgather_object(obj, group=None) -> list:
+    """Small Python objects of every rank, in rank order (``[obj]`` without a process group)."""
+    rank, world = rank_world(group)
+    if world == 1:
+        return [obj]
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, obj, group=group)
+    return out
+
+
+_P2P_CHUNK = 1 << 30
+
+
+def gather_payloads(local: Dict[int, bytes], owner: Sequence[int], group=None, device=None) -> Optional[List[bytes]]:
+    """Byte payloads of numbered work items to rank 0: item ``k`` was produced by rank ``owner[k]``
+    (``local[k]`` there).  Rank 0 returns the list of all payloads in item order, the other ranks ``None``.
+    Transport: one size exchange, then one point-to-point message per sending rank (RCCL send / recv of a
+    uint8 tensor over xGMI; gloo in CPU tests) -- compressed output sections, a few hundred MB at most."""
+    rank, world = rank_world(group)
+    n = len(owner)
+    if world == 1:
+        return [local[k] for k in range(n)]
+    import torch
+    import torch.distributed as dist
+    if device is None:
+        device = exchange_device(group)
+    mine = [k for k in range(n) if owner[k] == rank]
+    sizes = [None] * world
+    dist.all_gather_object(sizes, [len(local[k]) for k in mine], group=group)
+
+    def chunks(total):
+        return [(o, min(o + _P2P_CHUNK, total)) for o in range(0, total, _P2P_CHUNK)]
+
+    if rank != 0:
+        blob = np.frombuffer(b"".join(bytes(local[k]) for k in mine), dtype=np.uint8).copy()
+        for a, b in chunks(len(blob)):
+            t = torch.from_numpy(blob[a:b])
+            dist.send(t.to(device) if device is not None else t, dst=0, group=group)
+        return None
+    out: List[Optional[bytes]] = [None] * n
+    for k in mine:
+        out[k] = bytes(local[k])
+    for r in range(1, world):
+        total = int(sum(sizes[r]))
+        buf = np.empty(total, np.uint8)
+        for a, b in chunks(total):
+            t = torch.empty(b - a, dtype=torch.uint8, device=device if device is not None else "cpu")
+            dist.recv(t, src=r, group=group)
+            buf[a:b] = t.cpu().numpy()
+        off = 0
+        items = [k for k in range(n) if owner[k] == r]
+        for k, sz in zip(items, sizes[r]):
+            out[k] = buf[off:off + sz].tobytes()
+            off += sz
+    return out
+
+
+def gather_float_rows(local: Dict[str, np.ndarray], names: Sequence[str], n_rows: Dict[str, int],
+                      owner: Dict[str, int], k: int, group=None) -> Dict[str, np.ndarray]:
+    """``gather_bin_vectors`` for float64 rows (bit patterns travel as int64, so every rank holds exactly the
+    numbers the owner computed)."""
+    as_int = {c: np.ascontiguousarray(v, dtype=np.float64).view(np.int64).reshape(-1, k) for c, v in local.items()}
+    got = gather_bin_vectors(as_int, names, n_rows, {c: 1.0 for c in names}, group=group, k=k, owner=owner)
+    return {c: np.ascontiguousarray(v, dtype=np.int64).view(np.float64).reshape(-1, k) for c, v in got.items()}

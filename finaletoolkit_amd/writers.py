@@ -33,6 +33,20 @@ class TextBuffer:
         if rc != L.FTK_OK:
             raise OSError(self._lib.ftk_fragtable_error().decode())
 
+    def gzip_bytes(self, gzip_level: int = GZIP_LEVEL, threads: int = 0) -> bytes:
+        """The gzip members ``write(path, gzip_level)`` would put into the file, as bytes (a rank that does not own
+        the output file hands them to the one that does)."""
+        if self.n == 0:
+            return b""
+        out, n = C.c_void_p(), C.c_int64()
+        rc = self._lib.ftk_gzip_members(self.ptr, self.n, int(gzip_level), int(threads), C.byref(out), C.byref(n))
+        if rc != L.FTK_OK:
+            raise L.FtkError(rc, self._lib.ftk_fragtable_error().decode())
+        try:
+            return C.string_at(out.value, n.value)
+        finally:
+            self._lib.ftk_buffer_free(out.value)
+
     def free(self):
         if self.ptr:
             self._lib.ftk_buffer_free(self.ptr)

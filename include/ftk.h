@@ -448,6 +448,10 @@ int ftk_bgzf_inflate_device(ftk_ctx* ctx, const uint8_t* file_bytes, int64_t n, 
  *   ftk_file_write           data -> path (truncate or append); gzip_level > 0 writes gzip members of 1 MB
  *                            of text each, compressed in parallel (a valid multi-member .gz: gzip.open,
  *                            zcat, bgzip -d read it as one stream)
+ *   ftk_gzip_members         the same gzip members into memory (*out, ftk_buffer_free): what a rank that does
+ *                            not own the output file hands to the rank that writes it (multi-GPU runs of
+ *                            multi_wps / multi_cleavage_profile: every rank formats and compresses the rows of
+ *                            its own contigs, rank 0 concatenates the members in order)
  *   ftk_bigwig_fixedstep_sections  the data sections of one `addEntries(chrom, start, values=..., span=1,
  *                            step=1)` call PER RUN: values (value_kind 0 = int64, 1 = float64) cut into
  *                            sections of items_per_section float32 items (never across runs), each with
@@ -462,6 +466,7 @@ int ftk_format_bedgraph_f64(const char* contig, const int64_t* iv_start, const i
                             const double* values, int n_threads, char** out, int64_t* out_len);
 void ftk_buffer_free(void* p);
 int ftk_file_write(const char* path, const char* data, int64_t n, int gzip_level, int n_threads, int append);
+int ftk_gzip_members(const char* data, int64_t n, int gzip_level, int n_threads, char** out, int64_t* out_len);
 /* The array frag/_wps.py:181-188 returns -- numpy records ('contig', 'U16'), ('start', 'i8'), ('wps', 'i8'), 80 bytes
  * each: contig name as 16 UCS-4 code points (zero padded), start + i, values[i] -- filled by the host threads (for a
  * chromosome that array is gigabytes; one numpy thread takes longer over it than the GPU over the scores). */

@@ -140,3 +140,20 @@ def test_cache_trim_without_a_gpu_is_a_no_op():
     assert lib.ftk_cache_trim() == 0
     t = _decode(os.path.join(DATA, "12.3444.b37.frag.gz"))
     assert t["12"][0] == 17 and lib.ftk_cache_trim() >= 0
+
+
+def test_one_hip_runtime_in_the_process():
+    """libftk_hip.so and torch share ONE libamdhip64 whichever is loaded first (_lib._share_torch_hip_runtime);
+    _lib.hip_runtimes_mapped is what load() checks and warns about."""
+    import subprocess
+    import sys
+    code = ("import sys, warnings; sys.path.insert(0, %r)\n"
+            "warnings.simplefilter('error')\n"
+            "from finaletoolkit_amd import _lib\n"
+            "_lib.load()\n"
+            "import torch\n"
+            "found = _lib.hip_runtimes_mapped()\n"
+            "assert len(found) == 1, found\n"
+            "print('ok')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-2000:]

@@ -237,3 +237,65 @@ def test_device_stream_errors_and_early_close(tmp_path):
     got, order, n_dev = _stream_device(good)
     assert order == ["e0", "e1", "e2", "e3"] and n_dev == 4
     _same(got, _whole(good))
+
+
+def test_one_row_per_bgzf_block(tmp_path):
+    """A valid BGZF file of many tiny blocks: the compressed piece is LARGER than its text (26 bytes of container
+    per 20-byte row), and the compressed bytes are staged in the text buffer on their way up (round-2 advisor
+    finding: that buffer was sized from the text alone).  Also blocks with nothing in them between the rows."""
+    from finaletoolkit_amd.bgzf import _EOF, _block
+    rng = np.random.default_rng(77)
+    n = 16_000
+    s = np.sort(rng.integers(0, 40_000_000, n))
+    e = s + rng.integers(30, 600, n)
+    q = rng.integers(0, 61, n)
+    rows = ["tiny\t%d\t%d\t%d\t%s\n" % (s[i], e[i], q[i], "+-"[i & 1]) for i in range(n)]
+    p = str(tmp_path / "tiny_blocks.frag.gz")
+    with open(p, "wb") as fh:
+        for i, r in enumerate(rows):
+            fh.write(_block(r.encode(), 1))
+            if i % 97 == 0:
+                fh.write(_EOF)  # an empty block in the middle of the file is legal
+        fh.write(_EOF)
+    assert os.path.getsize(p) > sum(map(len, rows))
+    got, order, n_dev = _stream_device(p, threads=4)
+    assert order == ["tiny"] and n_dev == 1 and got["tiny"][0] == n
+    assert np.array_equal(got["tiny"][1][0], s) and np.array_equal(got["tiny"][1][1], e)
+    assert np.array_equal(got["tiny"][1][2], q) and np.array_equal(got["tiny"][1][3], (np.arange(n) & 1) == 0)
+    out = _child(p, threads=4, FTK_STREAM_PIECE=str(1 << 17))  # the same over several pieces
+    assert "['tiny']" in out
+
+
+def test_a_block_claiming_more_than_64k_is_refused(tmp_path):
+    import struct
+    from finaletoolkit_amd.bgzf import _EOF, _block
+    blk = bytearray(_block(b"c\t1\t200\t60\t+\n" * 100, 6))
+    blk[-4:] = struct.pack("<I", 70_000)  # ISIZE beyond what a BGZF block may hold
+    p = str(tmp_path / "isize.frag.gz")
+    open(p, "wb").write(bytes(blk) + _EOF)
+    with pytest.raises(RuntimeError):
+        _stream_device(p)
+
+
+@pytest.mark.parametrize("where", ["header", "middle"])
+def test_lines_longer_than_the_device_carry(tmp_path, where):
+    """A comment line of 100-300 KB (longer than the 64 KB an unfinished line may be carried on the device): the
+    stream falls back to the host-inflate pass for the file instead of failing (round-2 advisor finding), hands
+    out every contig exactly once and the rows are those of the whole-file decoder."""
+    rows = []
+    for k in range(3):
+        s, e, q, st = synth.synth_contig(900_000, depth=15.0, seed=300 + k)
+        rows.append((f"L{k}", s, e, q, st))
+    text = []
+    for name, s, e, q, st in rows:
+        lines = ["%s\t%d\t%d\t%d\t%s\n" % (name, s[i], e[i], q[i], "+" if st[i] else "-") for i in range(len(s))]
+        if where == "middle" and name == "L1":
+            lines.insert(len(lines) // 2, "#" + "x" * 300_000 + "\n")
+        text.append("".join(lines))
+    head = "#" + "h" * 100_000 + "\n" if where == "header" else ""
+    p = str(tmp_path / f"long_{where}.frag.gz")
+    bgzf.write_bgzf(p, (head + "".join(text)).encode(), level=1)
+    open(p + ".tbi", "ab").close()
+    for piece in (1 << 16, 1 << 20, 48 << 20):
+        out = _child(p, threads=4, FTK_STREAM_PIECE=str(piece))
+        assert "['L0', 'L1', 'L2']" in out, out

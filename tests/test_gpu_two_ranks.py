@@ -39,6 +39,43 @@ pickle.dump(dict(rank=rank, world=world, delfi=df, merged=merged, cov=[tuple(c) 
 sharding.finalize()
 """
 
+# the other fan-outs of the reference (frag/_multi_wps.py:196-198, _frag_length.py:571-593, _cleavage_profile.py:372,
+# _motif_common.py:635-685): per-base outputs assembled by rank 0 from the ranks' compressed pieces, statistics and
+# k-mer tables gathered
+WORKER2 = r"""
+import os, pickle, sys, warnings
+sys.path.insert(0, {root!r})
+from finaletoolkit_amd import frag, sharding, source
+rank, world = sharding.init_from_env()
+d = {tmp!r}
+o = d + f"/w{{world}}_"
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    frag.multi_wps(d + "/g.frag.gz", d + "/sites.bed", d + "/cs.genome", o + "wps.bw", interval_size=3000)
+    frag.multi_wps(d + "/g.frag.gz", d + "/sites.bed", d + "/cs.genome", o + "wps.bed.gz", interval_size=800,
+                   window_size=61, min_length=100, max_length=200)
+    frag.multi_cleavage_profile(d + "/g.frag.gz", d + "/clv.bed", d + "/cs.genome", left=20, right=30,
+                                output_file=o + "clv.bw")
+    frag.multi_cleavage_profile(d + "/g.frag.gz", d + "/clv_unsorted.bed", d + "/cs.genome", output_file=o + "clv2.bw")
+    frag.multi_cleavage_profile(d + "/g.frag.gz", d + "/clv.bed", d + "/cs.genome", min_length=100, max_length=250,
+                                output_file=o + "clv.bed.gz")
+    fli = frag.frag_length_intervals(d + "/g.frag.gz", d + "/iv.bed", o + "fli.bed", min_length=50, max_length=400)
+    flb = frag.frag_length_bins(d + "/g.frag.gz", output_file=o + "flb.tsv", bin_size=5, summary_stats=True,
+                                short_fraction=150)
+    flb1 = frag.frag_length_bins(d + "/g.frag.gz", contig="c3", start=1000, stop=300000, output_file=o + "flb1.tsv")
+    em = frag.end_motifs(d + "/g.frag.gz", d + "/ref.fa", k=3, output_file=o + "em.tsv")
+    iem = frag.interval_end_motifs(d + "/g.frag.gz", d + "/ref.fa", d + "/iv.bed", k=2, both_strands=False,
+                                   output_file=o + "iem.tsv")
+    ibm = frag.interval_breakpoint_motifs(d + "/g.frag.gz", d + "/ref.fa", d + "/iv.bed", k=4, output_file=o + "ibm.csv")
+    one = frag.wps(d + "/g.frag.gz", "c2", 5000, 9000, 700000, output_file=o + "one.wig")
+loaded = sorted(k.split(":", 1)[1] for k in source.get_engine().contigs)
+pickle.dump(dict(rank=rank, world=world, fli=[tuple(x) for x in fli], flb=(list(map(int, flb[0])), list(flb[1])),
+                 flb1=(list(map(int, flb1[0])), list(flb1[1])), em=list(em), iem=[(iv, dict(f)) for iv, f in iem],
+                 ibm=[(iv, dict(f)) for iv, f in ibm], one=one.tolist(), loaded=loaded),
+            open(d + f"/out2_w{{world}}_r{{rank}}.pkl", "wb"))
+sharding.finalize()
+"""
+
 
 @pytest.fixture(scope="module")
 def dataset(tmp_path_factory):
@@ -73,25 +110,45 @@ def dataset(tmp_path_factory):
     rng.shuffle(iv)  # interval order is file order, not contig order
     (d / "iv.bed").write_text("".join(iv))
     (d / "worker.py").write_text(WORKER.format(root=ROOT, tmp=str(d)))
+    (d / "worker2.py").write_text(WORKER2.format(root=ROOT, tmp=str(d)))
+    # WPS sites in file (not contig) order, some overlapping their neighbours, one on a contig the genome lacks
+    sites = []
+    for c, n in sizes.items():
+        for a in np.sort(rng.integers(0, n - 2000, 30)):
+            sites.append(f"{c}\t{int(a)}\t{int(a) + int(rng.integers(1, 1500))}\n")
+    sites.insert(7, "cX\t100\t200\n")
+    order = rng.permutation(len(sizes))
+    names = list(sizes)
+    by_c = {c: [x for x in sites if x.split("\t")[0] == c] for c in names + ["cX"]}
+    (d / "sites.bed").write_text("".join("".join(by_c[names[i]]) for i in order) + "".join(by_c["cX"]))
+    # cleavage intervals: sorted and merged-on-overlap in one file; contigs out of header order in the other (pyBigWig
+    # refuses a contig that comes back: those intervals are skipped with a note)
+    clv = []
+    for c, n in sizes.items():
+        for a in np.sort(rng.integers(0, n - 3000, 25)):
+            clv.append((c, int(a), int(a) + int(rng.integers(10, 2500))))
+    (d / "clv.bed").write_text("".join(f"{c}\t{a}\t{b}\n" for c, a, b in clv))
+    back = [x for x in clv if x[0] == "c4"] + [x for x in clv if x[0] == "c2"] + [x for x in clv if x[0] == "c5"]
+    (d / "clv_unsorted.bed").write_text("".join(f"{c}\t{a}\t{b}\n" for c, a, b in back))
     return d
 
 
-def _run_world(d, world):
+def _run_world(d, world, script="worker.py", out="out"):
     from finaletoolkit_amd import sharding
     env_keep = {k: os.environ.get(k) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     for k in env_keep:
         os.environ.pop(k, None)
     try:
         if world == 1:
-            rc = subprocess.run([sys.executable, str(d / "worker.py")], cwd=ROOT).returncode
+            rc = subprocess.run([sys.executable, str(d / script)], cwd=ROOT).returncode
         else:
-            rc = sharding.launch_ranks([sys.executable, str(d / "worker.py")], world, share_gpu=True)
+            rc = sharding.launch_ranks([sys.executable, str(d / script)], world, share_gpu=True)
     finally:
         for k, v in env_keep.items():
             if v is not None:
                 os.environ[k] = v
     assert rc == 0
-    return [pickle.load(open(d / f"out_w{world}_r{r}.pkl", "rb")) for r in range(world)]
+    return [pickle.load(open(d / f"{out}_w{world}_r{r}.pkl", "rb")) for r in range(world)]
 
 
 def test_two_ranks_equal_one_process(dataset):
@@ -109,6 +166,65 @@ def test_two_ranks_equal_one_process(dataset):
     # the work really was dealt out: each rank decoded only its own contigs, together all of them
     a, b = set(two[0]["loaded"]), set(two[1]["loaded"])
     assert a and b and not (a & b) and a | b == set(one["loaded"]) == {"c1", "c2", "c3", "c4", "c5"}
+
+
+def test_two_ranks_write_the_single_process_files_for_every_sharded_command(dataset):
+    """multi_wps, multi_cleavage_profile, frag_length_intervals, genome-wide frag_length_bins and the motif
+    drivers: two ranks on GPU 0 return what one process returns and rank 0 writes byte-identical files (.bw and
+    .bed.gz assembled from the ranks' compressed pieces)."""
+    import gzip
+    d = dataset
+    one = _run_world(d, 1, "worker2.py", "out2")[0]
+    two = _run_world(d, 2, "worker2.py", "out2")
+    for r in two:
+        for key in ("fli", "flb", "flb1", "em", "iem", "ibm", "one"):
+            assert r[key] == one[key], key
+    assert len(one["fli"]) == 200 and sum(x[9] for x in one["fli"] if x[9] > 0) > 1000
+    for name in ("wps.bw", "clv.bw", "clv2.bw", "fli.bed", "flb.tsv", "flb1.tsv", "em.tsv", "iem.tsv", "ibm.csv", "one.wig"):
+        a, b = open(d / f"w1_{name}", "rb").read(), open(d / f"w2_{name}", "rb").read()
+        assert a == b and len(a) > 100, name
+    for name in ("wps.bed.gz", "clv.bed.gz"):
+        a, b = gzip.open(d / f"w1_{name}").read(), gzip.open(d / f"w2_{name}").read()
+        assert a == b and a.count(b"\n") > 10_000, name
+        assert open(d / f"w1_{name}", "rb").read() == open(d / f"w2_{name}", "rb").read(), name  # members too
+    # the bigWigs hold what the kernels computed (the reader is the product's own, validated against pyBigWig files)
+    from finaletoolkit_amd.bigwig import BigWigFile
+    with BigWigFile(d / "w2_clv2.bw") as bw:
+        assert bw.intervals("c4", 0, 350_000) is not None and bw.intervals("c5", 0, 130_000) is not None
+        assert bw.intervals("c2", 0, 700_000) is None  # c2 came back after c4: skipped, as pyBigWig's addEntries raises
+    # each contig's fragments were decoded by exactly one rank
+    a, b = set(two[0]["loaded"]), set(two[1]["loaded"])
+    assert a | b == {"c1", "c2", "c3", "c4", "c5"} and (a & b) <= {"c2", "c3"}  # (the two single-region calls run on every rank)
+
+
+def test_cli_refuses_gpus_on_commands_that_do_not_shard(tmp_path):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = tmp_path / "gaps.bed"
+    r = subprocess.run([sys.executable, "-m", "finaletoolkit_amd.cli", "--gpus", "2", "gap-bed", "hg19", str(out)],
+                       cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "does not shard" in r.stderr and not out.exists()
+    r = subprocess.run([sys.executable, "-m", "finaletoolkit_amd.cli", "adjust-wps", "x.bw", "y.bed", "z.sizes", "-o",
+                        str(tmp_path / "o.bw")], cwd=ROOT, env=dict(env, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1"),
+                       capture_output=True, text=True)
+    assert r.returncode == 2 and "does not shard" in r.stderr
+
+
+def test_cli_gpus_2_wps_and_frag_length_intervals(dataset, tmp_path):
+    d = dataset
+    for cmd, tail, name in (("wps", [str(d / "sites.bed"), "--chrom-sizes", str(d / "cs.genome"), "-i", "2000"], "w.bw"),
+                            ("frag-length-intervals", [str(d / "iv.bed")], "f.bed")):
+        outs = {}
+        for world in (1, 2):
+            out = tmp_path / f"w{world}_{name}"
+            env = dict(os.environ, FTK_SHARE_GPU="1")
+            for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+                env.pop(k, None)
+            r = subprocess.run([sys.executable, "-m", "finaletoolkit_amd.cli", "--gpus", str(world), cmd,
+                                str(d / "g.frag.gz")] + tail + ["-o", str(out)], cwd=ROOT, env=env, capture_output=True,
+                               text=True)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[world] = open(out, "rb").read()
+        assert outs[1] == outs[2] and len(outs[1]) > 1000, cmd
 
 
 def test_cli_gpus_2_writes_the_single_process_file(dataset, tmp_path):

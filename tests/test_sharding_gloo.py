@@ -224,3 +224,107 @@ def test_launch_ranks_starts_n_ranks_and_propagates_failure(tmp_path):
         for k, v in env_keep.items():
             if v is not None:
                 os.environ[k] = v
+
+
+# ---- the helpers behind the other sharded commands (multi_wps, cleavage, frag_length_*, motifs) --------------
+
+def _helpers_worker(rank, world, port, d, q):
+    sys.path.insert(0, ROOT)
+    from finaletoolkit_amd import sharding
+    from finaletoolkit_amd.frag import _runs
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          FTK_DIST_BACKEND="gloo")
+        sharding.init_from_env()
+    # payload gather: item k made by rank k % world, sizes from 0 to a few hundred KB
+    owner = [k % world for k in range(7)]
+    local = {k: bytes([k]) * (k * 50_021) for k in range(7) if owner[k] == rank}
+    got = sharding.gather_payloads(local, owner)
+    assert (got is None) == (rank != 0)
+    if rank == 0:
+        assert [len(g) for g in got] == [k * 50_021 for k in range(7)] and all(set(g) <= {k} for k, g in enumerate(got))
+    # float rows travel as bit patterns
+    names = ["x", "y", "z"]
+    own = {"x": 0, "y": world - 1, "z": 0}
+    rows = {c: np.array([[np.pi * (i + 1), -0.0, np.nan, 1e-310, float(i), 3.0, 2.0 ** 60]], np.float64).repeat(i + 2, 0)
+            for i, c in enumerate(names)}
+    full = sharding.gather_float_rows({c: v for c, v in rows.items() if own[c] == rank}, names,
+                                      {c: len(rows[c]) for c in names}, own, 7)
+    for c in names:
+        assert full[c].tobytes() == rows[c].tobytes()
+    assert sharding.allgather_object({"r": rank}) == [{"r": r} for r in range(world)]
+    # agree(): one failing rank makes every rank raise
+    try:
+        sharding.agree(ValueError("boom") if rank == world - 1 else None)
+        raised = None
+    except ValueError as e:
+        raised = "own:" + str(e)
+    except RuntimeError as e:
+        raised = "other:" + str(e)
+    # per-base run outputs: every rank "scores" its contigs, rank 0 writes
+    header = [("a", 50_000), ("b", 40_000), ("c", 30_000)]
+    contigs = ["a"] * 3 + ["b"] * 2 + ["c"] * 4 + ["a"]  # the last run comes back to `a`: skipped in the bigWig
+    starts = [100, 5000, 20_000, 10, 9000, 0, 300, 7000, 29_000, 40_000]
+    stops = [1100, 5000, 21_500, 4010, 9100, 200, 1300, 7001, 30_000, 41_000]
+    asked = []
+
+    def compute(c, st, sp):
+        asked.append(c)
+        offs = np.concatenate([[0], np.cumsum([b - a for a, b in zip(st, sp)])]).astype(np.int64)
+        vals = np.concatenate([np.arange(a, b, dtype=np.int64) * (ord(c) - 96) - 7 for a, b in zip(st, sp)] or
+                              [np.zeros(0, np.int64)])
+        return vals, offs
+
+    _runs.write_per_base_runs(f"{d}/w{world}.bw", "bw", header, contigs, starts, stops, compute)
+    _runs.write_per_base_runs(f"{d}/w{world}.bed.gz", "bedgraph.gz", header, contigs, starts, stops,
+                              lambda c, st, sp: (compute(c, st, sp)[0].astype(np.float64) / 3.0, compute(c, st, sp)[1]))
+    sharding.finalize()
+    q.put((rank, raised, sorted(set(asked))))
+
+
+def test_payload_gather_float_rows_agree_and_run_outputs(tmp_path):
+    import gzip
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    res = {}
+    for world in (1, 2, 3):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_helpers_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res[world] = sorted(q.get(timeout=300) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    assert res[1][0][1] == "own:boom"
+    assert [r[1][:6] for r in res[2]] == ["other:", "own:bo"] and "rank 1 failed: ValueError: boom" in res[2][0][1]
+    for world in (2, 3):
+        owned = [set(r[2]) for r in res[world]]
+        assert set().union(*owned) == {"a", "b", "c"} and sum(map(len, owned)) == 3  # each contig scored by one rank
+        assert (tmp_path / f"w{world}.bw").read_bytes() == (tmp_path / "w1.bw").read_bytes()
+        assert (tmp_path / f"w{world}.bed.gz").read_bytes() == (tmp_path / "w1.bed.gz").read_bytes()
+    from finaletoolkit_amd.bigwig import BigWigFile
+    with BigWigFile(tmp_path / "w1.bw") as bw:
+        s, e, v = bw.intervals("a", 0, 50_000)
+        assert len(s) == 1000 + 1500 and s[0] == 100 and v[0] == 93.0  # the run that came back to `a` is not there
+        s, e, v = bw.intervals("c", 0, 30_000)
+        assert len(s) == 200 + 1000 + 1 + 1000 and v[0] == -7.0
+    text = gzip.open(tmp_path / "w1.bed.gz", "rt").read().splitlines()
+    assert len(text) == 1000 + 1500 + 4000 + 100 + 200 + 1000 + 1 + 1000 + 1000
+    assert text[0] == f"a\t100\t101\t{93 / 3.0!r}" and text[-1] == f"a\t40999\t41000\t{(40999 - 7) / 3.0!r}"
+
+
+def test_cli_refuses_gpus_for_unsharded_commands(tmp_path):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = tmp_path / "gaps.bed"
+    r = subprocess.run([sys.executable, "-m", "finaletoolkit_amd.cli", "--gpus", "2", "gap-bed", "hg19", str(out)],
+                       cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "does not shard" in r.stderr and not out.exists()
+    r = subprocess.run([sys.executable, "-m", "finaletoolkit_amd.cli", "gap-bed", "hg19", str(out)], cwd=ROOT,
+                       env=dict(env, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1"), capture_output=True, text=True)
+    assert r.returncode == 2 and not out.exists()
+    r = subprocess.run([sys.executable, "-m", "finaletoolkit_amd.cli", "gap-bed", "hg19", str(out)], cwd=ROOT, env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and out.exists()
