@@ -42,10 +42,38 @@ class _TabixFile:
             if row[0] not in seen:
                 seen.append(row[0])
         self.contigs = seen
+        # per-contig index for region queries on start-sorted files (the whole-genome DELFI goldens ask tens of
+        # thousands of windows): rows of the contig, their starts, the longest row -- the filter below is unchanged,
+        # the index only narrows the rows it is applied to
+        self._by_contig = {}
+        for row in self._rows:
+            self._by_contig.setdefault(row[0], []).append(row)
+        self._index = {}
+        for name, rows in self._by_contig.items():
+            try:
+                st = [int(r[1]) for r in rows]
+                ln = max(int(r[2]) - int(r[1]) for r in rows)
+            except (ValueError, IndexError):
+                continue
+            if all(a <= b for a, b in zip(st, st[1:])):
+                self._index[name] = (st, ln)
+
+    def _candidates(self, reference, start, end):
+        if reference is None:
+            return self._rows
+        rows = self._by_contig.get(reference, [])
+        idx = self._index.get(reference)
+        if idx is None:
+            return rows
+        import bisect
+        st, ln = idx
+        lo = 0 if start is None else bisect.bisect_left(st, start - ln)
+        hi = len(rows) if end is None else bisect.bisect_left(st, end)
+        return rows[lo:hi]
 
     def fetch(self, reference=None, start=None, end=None, region=None,
               parser=None, multiple_iterators=False):
-        for row in self._rows:
+        for row in self._candidates(reference, start, end):
             if reference is not None:
                 if row[0] != reference:
                     continue

@@ -183,3 +183,44 @@ def write_2bit(path, seqs):
         off += len(rec)
     with open(path, "wb") as fh:
         fh.write(head + index + b"".join(r for _, r in records))
+
+
+def synth_reference(path, contigs, seed=20261002):
+    """Seeded synthetic reference genome as FASTA (+ .fai) for ``contigs = {name: length}``: random bases with
+    GC-rich and GC-poor stretches, soft-masked (lower-case) runs and N runs.  Returns the sha256 of the FASTA
+    bytes, which ``tests/golden/delfi_driver.json`` pins (the goldens were produced by the reference on exactly
+    this file; it is regenerated instead of committed)."""
+    import hashlib
+    seqs = {}
+    for i, (name, n) in enumerate(contigs.items()):
+        rng = np.random.default_rng(seed + i)
+        # piecewise GC content: blocks of 2-20 kb with their own G+C probability
+        gc = np.empty(n, np.float64)
+        pos = 0
+        while pos < n:
+            ln = int(rng.integers(2_000, 20_000))
+            gc[pos:pos + ln] = rng.uniform(0.25, 0.65)
+            pos += ln
+        is_gc = rng.random(n) < gc
+        pick = rng.integers(0, 2, n)
+        codes = np.where(is_gc, np.where(pick == 1, ord("G"), ord("C")), np.where(pick == 1, ord("A"), ord("T"))).astype(np.uint8)
+        for _ in range(6):  # N runs
+            a = int(rng.integers(0, n - 3000))
+            codes[a:a + int(rng.integers(50, 3000))] = ord("N")
+        for _ in range(25):  # soft-masked runs
+            a = int(rng.integers(0, n - 2000))
+            b = a + int(rng.integers(100, 2000))
+            codes[a:b] |= 0x20
+        seqs[name] = codes.tobytes().decode()
+    write_fasta(path, seqs)
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def write_bins20(path, contigs):
+    """The 20 bp bin tiling of the DELFI driver goldens (27 500 rows for the synthetic genome): a comment line, then
+    chrB BEFORE chrA -- the driver orders by chrom.sizes, not by the bins file."""
+    with open(path, "w") as fh:
+        fh.write("# 20 bp tiling\n")
+        for c in sorted(contigs, reverse=True):
+            for a in range(0, contigs[c], 20):
+                fh.write(f"{c}\t{a}\t{min(a + 19, contigs[c])}\n")
