@@ -462,7 +462,7 @@ def main():
                     per[c].pop(k, None)
             torch.cuda.synchronize()
             torch.cuda.empty_cache()
-            e2e = end_to_end(torch)
+            e2e = end_to_end(torch, cpu=cpu)
         out = {
             "metric": "genomic windows/sec (coverage+WPS+DELFI) at 30x WGS",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world,
@@ -497,7 +497,7 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def end_to_end(torch, reps: int = 3):
+def end_to_end(torch, reps: int = 3, cpu=None):
     """File -> results on the host, through the product's own path (source.stream_source: host threads inflate,
     the GPU parses the rows, contigs become resident one after the other; then the kernels and the copy back).
     Four legs, files synthesised beforehand (not timed), `reps` repetitions each, the best one reported with its
@@ -664,6 +664,11 @@ def end_to_end(torch, reps: int = 3):
             res["genome_delfi_bins"] = dict(file_GB=round(os.path.getsize(pg) / 1e9, 2), text_GB=round(text_bytes / 1e9, 2),
                                             fragments=rows_total, file_write_s=round(t_write, 1), decoder_threads=threads,
                                             repetitions=2, **best)
+            # The north-star's own figure, on the PRODUCT FUNCTION: the same file -> frag.delfi() with a bins file,
+            # blacklist, gap annotation, a 2bit reference (per-bin GC counted on the device), the 100 kb -> 5 Mb
+            # merge and the TSV written -- everything reference frag/_delfi.py:129-401 does around its per-bin loop.
+            res["genome_frag_delfi_api"] = frag_delfi_api_leg(torch, tmp, pg, threads, n_win_total, rows_total,
+                                                             res["genome_delfi_bins"], cpu)
             os.remove(pg)
             os.remove(pg + ".tbi")
         res["note"] = ("best of %d repetitions per leg (the first one of a process also pays thread-pool start, page-locked "
@@ -674,6 +679,68 @@ def end_to_end(torch, reps: int = 3):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return res
+
+
+def frag_delfi_api_leg(torch, tmp, genome_file, threads, n_win_total, rows_total, raw_leg, cpu):
+    """`frag.delfi()` on the whole-genome 30x file (30 970 x 100 kb bins merged to 5 Mb): wall time with the stage split
+    of frag/_delfi.py's LAST_STAGE_S, the ratio to the raw engine leg, the x-factor against the reference-shaped
+    single-thread Python rate of the same bins (cpu_baseline), and a check of one whole contig of the unmerged frame
+    against the C oracle (checker only)."""
+    import pandas
+    from finaletoolkit_amd import frag, source
+    from finaletoolkit_amd.frag import _delfi as FD
+    sizes = dict(synth.B37_SIZES)
+    t0 = time.perf_counter()
+    cs, bins, bl, gapbed = synth.write_genome_delfi_inputs(tmp, sizes, WINDOW)
+    ref2bit = os.path.join(tmp, "genome.2bit")
+    synth.write_random_2bit(ref2bit, sizes)
+    t_inputs = time.perf_counter() - t0
+    out_tsv = os.path.join(tmp, "delfi_5mb.tsv")
+    best, df = None, None
+    import warnings
+    for _ in range(2):
+        source.close_all()
+        ta = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            df = frag.delfi(genome_file, cs, bins, ref2bit, blacklist_file=bl, gap_file=gapbed, output_file=out_tsv,
+                            no_gc_correct=True, merge_bins=True, workers=threads)
+        total = time.perf_counter() - ta
+        if best is None or total < best["total_s"]:
+            best = dict(total_s=round(total, 4), stages_s=dict(FD.LAST_STAGE_S))
+    # checker (untimed): the unmerged frame of one whole contig against the C oracle, and the merged file's shape
+    ok = df.shape[0] > 400 and os.path.getsize(out_tsv) > 10_000 and list(df.columns)[:4] == ["contig", "start", "stop", "arm"]
+    try:
+        from oracle import oracle as O
+        c, ci = "21", list(sizes).index("21")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            un = frag.delfi(genome_file, cs, bins, ref2bit, blacklist_file=bl, gap_file=gapbed, no_gc_correct=True,
+                            merge_bins=False, remove_nocov=False, workers=threads)
+        rows = un.loc[un["contig"] == c]
+        dev = torch.device("cuda", torch.cuda.current_device())
+        s, e, q, st = (t.cpu().numpy() for t in gen_contig_device(torch, dev, sizes[c], synth.n_fragments(sizes[c], 30.0),
+                                                                 synth.SEED_BASE + ci))
+        b = pandas.read_csv(bl, sep="\t", names=["c", "s", "e"], dtype={"c": str})
+        b = b.loc[b["c"] == c].sort_values(["s", "e"])
+        sh, lg, nf = O.c_delfi_counts(O.Frags(s, e, q, st), rows["start"].to_numpy(), rows["stop"].to_numpy(), MAPQ,
+                                      b["s"].to_numpy(), b["e"].to_numpy(), synth_gaps(sizes[c]))
+        ok = ok and len(rows) > 300 and bool(np.array_equal(rows["short"].to_numpy().astype(np.int64), sh)
+                                             and np.array_equal(rows["long"].to_numpy().astype(np.int64), lg)
+                                             and np.array_equal(rows["num_frags"].to_numpy(), nf))
+        checked = f"contig {c}: {len(rows)} unmerged rows equal to the C oracle"
+    except Exception as exc:  # noqa: BLE001
+        ok, checked = False, f"{type(exc).__name__}: {exc}"
+    leg = dict(bins_100kb=n_win_total, merged_rows=int(df.shape[0]), fragments=rows_total, decoder_threads=threads,
+               repetitions=2, side_files_write_s=round(t_inputs, 2), **best,
+               windows_per_s=round(n_win_total / best["total_s"], 1),
+               vs_raw_engine_leg=round(best["total_s"] / raw_leg["total_s"], 3), results_ok=bool(ok), checked=checked)
+    py = (cpu or {}).get("reference_shaped_python_delfi")
+    if py:
+        # the target of BASELINE.json's north_star: >= 50x the reference's single-thread rate on these bins
+        leg["reference_shaped_python_windows_per_s"] = py["value"]
+        leg["x_vs_reference_shaped_python"] = round(n_win_total / best["total_s"] / py["value"], 1)
+    return leg
 
 
 def cpu_baseline(torch, eng, per, mine, budget_s, checks):
@@ -739,6 +806,15 @@ def cpu_baseline(torch, eng, per, mine, budget_s, checks):
         O.py_delfi_single_window(rows, a, b, MAPQ, bl_rows, p["gaps"])
         n_py += 1
     t_py_count = (time.perf_counter() - t2) / max(n_py, 1)
+    # DELFI alone (frag/_delfi.py:404-511 per 100 kb bin: fetch + per-fragment Python loop), for the whole-genome
+    # frag.delfi() leg of end_to_end
+    t2d = time.perf_counter()
+    n_pyd = 0
+    while n_pyd < min(n_s, 400) and time.perf_counter() - t2d < 4.0:
+        a, b = int(ws[n_pyd]), int(we[n_pyd])
+        O.py_delfi_single_window(fetched(a, b), a, b, MAPQ, bl_rows, p["gaps"])
+        n_pyd += 1
+    t_py_delfi = (time.perf_counter() - t2d) / max(n_pyd, 1)
     t3 = time.perf_counter()
     n_tiles_py = 0
     x0 = int(ws[min(1, n_s - 1)])
@@ -764,6 +840,10 @@ def cpu_baseline(torch, eng, per, mine, budget_s, checks):
                           "sample": f"the same C restatement, one 100 kb window per task on {n_cores} pthreads (usable cores of "
                                     f"{os.cpu_count()} logical CPUs), "
                                     f"{n_all} windows of contig {c}"},
+            "reference_shaped_python_delfi": {
+                "value": round(1.0 / t_py_delfi, 3), "unit": "windows/s", "cores": 1,
+                "sample": f"oracle/oracle.py py_delfi_single_window on the rows an index query returns at full depth, "
+                          f"{n_pyd} x 100 kb bins of contig {c} (a 5 Mb bin = 50 of them)"},
             "reference_shaped_python": {
                 "value": round(1.0 / (t_py_count + t_py_wps), 4), "unit": "windows/s", "cores": 1,
                 "sample": f"oracle/oracle.py py_* (per-window fetch + per-fragment Python predicate, numpy "

@@ -21,7 +21,7 @@ import pandas
 
 from ..genome.gaps import GenomeGaps
 from ..reference import ReferenceGenome
-from ..source import get_engine, open_source
+from ..source import get_engine, resident_contigs
 from .. import sharding
 from ..utils import chrom_sizes_to_list, overlaps
 from ._delfi_gc_correct import delfi_gc_correct
@@ -71,75 +71,134 @@ def _resolve_gaps(gap_file):
     raise TypeError(f"{type(gap_file)} is not accepted type for gap_file")
 
 
-def _valid_interval(chroms: dict, contig, start, stop) -> bool:
-    """utils/validation.py:111-183 for a dict of contig lengths."""
+def _valid_mask(chroms: dict, contig, starts, stops) -> np.ndarray:
+    """utils/validation.py:111-183 for a dict of contig lengths, all bins of a contig at once."""
     if contig not in chroms:
-        return False
+        return np.zeros(len(starts), dtype=bool)
     length = chroms[contig]
-    if start < 0 or start >= length or stop < 0 or stop > length or start >= stop:
-        return False
-    return True
+    return ~((starts < 0) | (starts >= length) | (stops < 0) | (stops > length) | (starts >= stops))
 
 
 def _gate_windows(contig, starts, stops, contig_gaps):
-    """Window-level gating of frag/_delfi.py:416-428 (host, every rank): arm label per bin and which bins go
-    to the device."""
+    """Window-level gating of frag/_delfi.py:416-428 (host, every rank) for all bins of a contig at once: arm
+    label per bin (object array) and which bins go to the device.  ``ContigGaps.in_tcmere`` / ``get_arm`` as
+    array expressions: inside the centromere or overlapping EVERY telomere -> NOARM; else left of the
+    centromere -> ``p`` (NOARM on a short-arm contig), right of it -> ``q``, else NOARM."""
     n = len(starts)
-    arms = [contig] * n
-    live = np.ones(n, dtype=bool)
-    if contig_gaps is not None:
-        for i in range(n):
-            if contig_gaps.in_tcmere(starts[i], stops[i]):
-                arms[i], live[i] = "NOARM", False
-                continue
-            arm = contig_gaps.get_arm(starts[i], stops[i])
-            arms[i] = arm
-            if arm == "NOARM":
-                live[i] = False
-    return arms, live
+    if contig_gaps is None:
+        arms = np.empty(n, dtype=object)
+        arms[:] = contig
+        return arms, np.ones(n, dtype=bool)
+    c0, c1 = contig_gaps.centromere
+    tcmere = (stops > c0) & (starts < c1)
+    if contig_gaps.telomeres:
+        every = np.ones(n, dtype=bool)
+        for t0, t1 in contig_gaps.telomeres:
+            every &= (stops > t0) & (starts < t1)
+        tcmere |= every
+    if np.any(~tcmere & (stops < starts)):
+        raise ValueError("start must be less than stop")
+    left = ~tcmere & (stops < c0)
+    p_arm = left & (not contig_gaps.has_short_arm)
+    q_arm = ~tcmere & ~left & (starts > c1)
+    name = contig.replace("chr", "")
+    arms = np.empty(n, dtype=object)
+    arms[:] = "NOARM"
+    arms[p_arm] = f"{name}p"
+    arms[q_arm] = f"{name}q"
+    return arms, p_arm | q_arm
 
 
-def _contig_counts(src, eng, ref, contig, starts, stops, live, ok, contig_gaps, blacklist, quality_threshold):
+def _contig_counts(src, eng, ref, contig, starts, stops, live, ok, contig_gaps, blacklist, quality_threshold,
+                   clock=None):
     """Device part of one contig (the rank that owns it): ``[n_live, 4]`` int64 rows
     ``(short, long, num_frags, num_gc)`` of its live bins -- one ``ftk_delfi_counts`` launch and one GC-count
     launch (frag/_delfi.py:443-490)."""
     idx = np.nonzero(live)[0]
     out = np.zeros((len(idx), 4), np.int64)
     if len(idx):
+        t0 = time.perf_counter()
+        key = src.require(contig)
+        t1 = time.perf_counter()
         bl = blacklist.get(contig)
         sh, lg, nf = eng.delfi_counts(
-            src.require(contig), starts[idx].astype(np.int32), stops[idx].astype(np.int32), quality_threshold,
+            key, starts[idx].astype(np.int32), stops[idx].astype(np.int32), quality_threshold,
             None if bl is None else bl[0], None if bl is None else bl[1],
             None if contig_gaps is None else contig_gaps.as_kernel_constants())
         out[:, 0], out[:, 1], out[:, 2] = sh, lg, nf
+        t2 = time.perf_counter()
         if ok.any():
             out[ok, 3] = ref.gc_counts(eng, contig, starts[idx][ok], stops[idx][ok])
+        if clock is not None:
+            clock["decode_wait"] += t1 - t0
+            clock["count_kernels"] += t2 - t1
+            clock["gc_count"] += time.perf_counter() - t2
     return out
 
 
-def _contig_rows(contig, starts, stops, arms, live, ok, counts):
-    """Rows ``(contig, start, stop, arm, short, long, gc, num_frags)`` of one contig's bins in bin order
-    (frag/_delfi.py:404-511), from the gathered device counts (host, every rank)."""
-    rows = [None] * len(starts)
-    for k, i in enumerate(np.nonzero(live)[0]):
-        ws, we = int(starts[i]), int(stops[i])
-        if not ok[k]:
-            warnings.warn(f"Invalid interval {contig}:{ws}-{we} for reference. Skipping GC calculation.")
-        sh, lg, nf, num_gc = (int(v) for v in counts[k])
-        gc = num_gc / (we - ws) if nf > 0 else np.nan
-        rows[i] = (contig, ws, we, arms[i], sh, lg, gc, nf)
-    for i in np.nonzero(~live)[0]:
-        rows[i] = (contig, int(starts[i]), int(stops[i]), "NOARM", np.nan, np.nan, np.nan, 0)
-    return rows
+_COLUMNS = ["contig", "start", "stop", "arm", "short", "long", "gc", "num_frags"]
+
+
+def _contig_columns(contig, starts, stops, arms, live, ok, counts):
+    """Columns of one contig's bins in bin order (frag/_delfi.py:404-511), from the gathered device counts (host,
+    every rank): NOARM bins carry NaN / NaN / NaN / 0; a live bin's ``gc`` is ``num_gc / (stop - start)`` when it
+    holds a fragment, else NaN.  A live bin outside the reference warns and keeps ``num_gc = 0``."""
+    n = len(starts)
+    idx = np.nonzero(live)[0]
+    for k in np.nonzero(~ok)[0]:
+        warnings.warn(f"Invalid interval {contig}:{int(starts[idx[k]])}-{int(stops[idx[k]])} for reference. "
+                      "Skipping GC calculation.")
+    short = np.full(n, np.nan)
+    long_ = np.full(n, np.nan)
+    gc = np.full(n, np.nan)
+    nfrag = np.zeros(n, np.int64)
+    if len(idx):
+        counts = np.asarray(counts, dtype=np.int64).reshape(-1, 4)
+        short[idx], long_[idx], nfrag[idx] = counts[:, 0], counts[:, 1], counts[:, 2]
+        width = (stops[idx] - starts[idx]).astype(np.int64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            gc[idx] = np.where(counts[:, 2] > 0, counts[:, 3] / width, np.nan)
+    names = np.empty(n, dtype=object)
+    names[:] = contig
+    return names, starts.astype(np.int64), stops.astype(np.int64), arms, short, long_, gc, nfrag
+
+
+def _window_frame(parts) -> pandas.DataFrame:
+    """The frame ``pandas.DataFrame(windows, columns=...)`` builds from the reference's list of row tuples
+    (frag/_delfi.py:303-315), from per-contig columns: ``short`` / ``long`` are integer columns unless a NOARM
+    row put a NaN into them (then float64, printed as ``12.0``) -- the same inference, without 30 970 tuples."""
+    if not parts:
+        return pandas.DataFrame([], columns=_COLUMNS)
+    cols = [np.concatenate([p[k] for p in parts]) for k in range(8)]
+    if not len(cols[0]):
+        return pandas.DataFrame([], columns=_COLUMNS)
+    for k in (4, 5):
+        if not np.isnan(cols[k]).any():
+            cols[k] = cols[k].astype(np.int64)
+    return pandas.DataFrame(dict(zip(_COLUMNS, cols)), columns=_COLUMNS)
 
 
 def _contig_windows(src, eng, ref, contig, starts, stops, contig_gaps, blacklist, quality_threshold):
-    """One contig start to finish on this GPU: gate, count, assemble (what a 1-rank ``delfi`` does per contig)."""
+    """One contig start to finish on this GPU: gate, count, assemble -- the rows
+    ``(contig, start, stop, arm, short, long, gc, num_frags)`` a 1-rank ``delfi`` produces for it."""
+    starts = np.asarray(starts, np.int64)
+    stops = np.asarray(stops, np.int64)
     arms, live = _gate_windows(contig, starts, stops, contig_gaps)
-    ok = np.array([_valid_interval(ref.chroms, contig, int(starts[i]), int(stops[i])) for i in np.nonzero(live)[0]],
-                  dtype=bool)
+    ok = _valid_mask(ref.chroms, contig, starts[live], stops[live])
     counts = _contig_counts(src, eng, ref, contig, starts, stops, live, ok, contig_gaps, blacklist, quality_threshold)
-    return _contig_rows(contig, starts, stops, arms, live, ok, counts)
+    cols = _contig_columns(contig, starts, stops, arms, live, ok, counts)
+    rows = []
+    for i in range(len(starts)):
+        if live[i]:
+            rows.append((contig, int(starts[i]), int(stops[i]), arms[i], int(cols[4][i]), int(cols[5][i]),
+                         float(cols[6][i]), int(cols[7][i])))
+        else:
+            rows.append((contig, int(starts[i]), int(stops[i]), "NOARM", np.nan, np.nan, np.nan, 0))
+    return rows
+
+
+# wall time of the last delfi() call by stage (seconds): what bench.py's `genome_frag_delfi_api` leg reports
+LAST_STAGE_S: dict = {}
 
 
 def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str, blacklist_file: str = None,
@@ -148,6 +207,9 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
           window_size: int = 5000000, quality_threshold: int = 30, workers: int = 1,
           verbose: Union[int, bool] = False) -> pandas.DataFrame:
     """DELFI features (Cristiano et al., 2019); returns the result frame."""
+    t_begin = time.perf_counter()
+    clock = dict(read_inputs=0.0, gate=0.0, decode_wait=0.0, count_kernels=0.0, gc_count=0.0, gather=0.0, frame=0.0,
+                 merge=0.0, write=0.0)
     if verbose:
         t0 = time.time()
         stderr.write(f"delfi: {input_file} bins {bins_file}\n")
@@ -173,8 +235,8 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
     if gaps is not None:
         for contig, _size in contigs:
             contig_gaps[contig] = gaps.get_contig_gaps(contig)
+    clock["read_inputs"] = time.perf_counter() - t_begin
 
-    src = open_source(input_file, workers)
     eng = get_engine()
     # The reference fans the bins out over Pool(workers) (frag/_delfi.py:289-300).  Here the fan-out is one
     # rank per GPU: contigs are dealt to the ranks of the initialised process group (LPT on bin counts), a
@@ -182,37 +244,50 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
     # (short, long, num_frags, num_gc) vector gives every rank the whole table -- the frame returned is
     # the same on all ranks and equal to the single-GPU one.
     rank, world = sharding.rank_world()
-    plan = []  # (contig, starts, stops, arms, live, ok) in chrom.sizes order, bins in file order (:269-283)
+    plan = {}  # contig -> (starts, stops, arms, live, ok), chrom.sizes order, bins in file order (:269-283)
+    bin_contig = gapless_bins["contig"].to_numpy()
+    bin_start = gapless_bins["start"].to_numpy().astype(np.int64)
+    bin_stop = gapless_bins["stop"].to_numpy().astype(np.int64)
     with ReferenceGenome(reference_file) as ref:
+        tg = time.perf_counter()
         for contig, _size in contigs:
-            sel = gapless_bins.loc[gapless_bins["contig"] == contig]
-            if sel.shape[0] == 0:
+            if contig in plan:
                 continue
-            starts = sel["start"].to_numpy().astype(np.int64)
-            stops = sel["stop"].to_numpy().astype(np.int64)
+            sel = np.nonzero(bin_contig == contig)[0]
+            if len(sel) == 0:
+                continue
+            starts, stops = bin_start[sel], bin_stop[sel]
             arms, live = _gate_windows(contig, starts, stops, contig_gaps.get(contig) if gaps is not None else None)
-            ok = np.array([_valid_interval(ref.chroms, contig, int(starts[i]), int(stops[i]))
-                           for i in np.nonzero(live)[0]], dtype=bool)
-            plan.append((contig, starts, stops, arms, live, ok))
-        names = [p[0] for p in plan]
-        weights = {p[0]: float(len(p[1])) for p in plan}
+            plan[contig] = (starts, stops, arms, live, _valid_mask(ref.chroms, contig, starts[live], stops[live]))
+        clock["gate"] = time.perf_counter() - tg
+        names = list(plan)
+        weights = {c: float(len(plan[c][0])) for c in names}
         owner = sharding.lpt_assign(weights, world)
-        if world == 1 and 2 * len(names) >= len(src.contigs):
-            src.load_all()  # most of the file is needed: one streaming pass instead of one index seek per contig
+        mine = [c for c in names if owner[c] == rank]
         local = {}
-        for contig, starts, stops, arms, live, ok in plan:
-            if owner[contig] == rank:
-                local[contig] = _contig_counts(src, eng, ref, contig, starts, stops, live, ok,
-                                               contig_gaps.get(contig) if gaps is not None else None, blacklist,
-                                               quality_threshold)
-    n_live = {p[0]: int(p[4].sum()) for p in plan}
+        # contigs are counted as they become resident: a file without a usable index is decoded in ONE streaming
+        # pass (decode of contig k+1 beside the kernels / the reference upload of contig k); an indexed file is
+        # read contig by contig through the index, so a rank touches only its own blocks
+        tw = time.perf_counter()
+        for src, contig in resident_contigs(input_file, mine, workers, stream_all=world == 1):
+            clock["decode_wait"] += time.perf_counter() - tw
+            starts, stops, arms, live, ok = plan[contig]
+            local[contig] = _contig_counts(src, eng, ref, contig, starts, stops, live, ok,
+                                           contig_gaps.get(contig) if gaps is not None else None, blacklist,
+                                           quality_threshold, clock)
+            tw = time.perf_counter()
+        clock["decode_wait"] += time.perf_counter() - tw
+        for contig in mine:  # a planned contig the file does not hold: pysam raises for the unknown region
+            if contig not in local and plan[contig][3].any():
+                raise ValueError(f"could not create iterator for region '{contig}': contig not present in {input_file}")
+            local.setdefault(contig, np.zeros((0, 4), np.int64))
+    tg = time.perf_counter()
+    n_live = {c: int(plan[c][3].sum()) for c in names}
     counts = sharding.gather_bin_vectors(local, names, n_live, weights, k=4)
-    windows = []
-    for contig, starts, stops, arms, live, ok in plan:
-        windows += _contig_rows(contig, starts, stops, arms, live, ok, counts[contig])
-
-    window_df = pandas.DataFrame(windows, columns=["contig", "start", "stop", "arm", "short", "long", "gc",
-                                                   "num_frags"])
+    clock["gather"] = time.perf_counter() - tg
+    tg = time.perf_counter()
+    parts = [_contig_columns(c, plan[c][0], plan[c][1], plan[c][2], plan[c][3], plan[c][4], counts[c]) for c in names]
+    window_df = _window_frame(parts)
     trimmed = window_df.loc[window_df["arm"] != "NOARM", :].copy()
     trimmed["ratio"] = np.where(trimmed["long"] == 0, np.nan, trimmed["short"] / trimmed["long"])
 
@@ -221,14 +296,22 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
         final = trimmed.loc[np.logical_and(pos != 8779, pos != 13664)].reset_index()
     else:
         final = trimmed
+    clock["frame"] = time.perf_counter() - tg
     if gc_correct:
         final = delfi_gc_correct(final, 0.75, 8, verbose)
     if merge_bins:
+        tg = time.perf_counter()
         final = delfi_merge_bins(final, gc_correct, verbose=verbose)
+        clock["merge"] = time.perf_counter() - tg
     if output_file is not None and rank == 0:  # every rank holds the same frame; one of them writes it
+        tg = time.perf_counter()
         _write_delfi(final, output_file)
+        clock["write"] = time.perf_counter() - tg
+    clock["total"] = time.perf_counter() - t_begin
+    LAST_STAGE_S.clear()
+    LAST_STAGE_S.update({k: round(v, 4) for k, v in clock.items()})
     if verbose:
-        stderr.write(f"{sum(w[7] for w in windows)} fragments included.\n")
+        stderr.write(f"{int(window_df['num_frags'].sum()) if len(window_df) else 0} fragments included.\n")
         stderr.write(f"delfi took {time.time() - t0} s to complete\n")
     return final
 

@@ -145,6 +145,12 @@ class FragSource:
                 self._load_one(c)
 
     def _stream_missing(self, missing):
+        for _ in self._stream_missing_iter(missing):
+            pass
+
+    def _stream_missing_iter(self, missing):
+        """One streaming pass over the file; yields the name of every contig of ``missing`` as soon as it is
+        resident (the decoder is already in the next contig)."""
         eng = get_engine()
         lib = L.load()
         stream = C.c_void_p()
@@ -162,11 +168,14 @@ class FragSource:
                     break
                 try:
                     name = lib.ftk_fragtable_contig_name(table, 0).decode()
-                    if name in missing and name not in self.loaded:
+                    fresh = name in missing and name not in self.loaded
+                    if fresh:
                         eng.load_contig_from_table(self.key(name), table, 0, self.is_bam)
                         self.loaded.add(name)
                 finally:
                     lib.ftk_fragtable_free(table)
+                if fresh:
+                    yield name
         finally:
             lib.ftk_fragstream_close(stream)
 
@@ -365,6 +374,54 @@ def open_source(input_file, workers: int | None = None, warn_bed6: bool = True) 
     if src.bed6 and warn_bed6:
         _warn_bed6()
     return src
+
+
+def resident_contigs(input_file, names, workers: int | None = None, stream_all: bool = True, warn_bed6: bool = True):
+    """Generator of ``(src, contig)`` over the contigs of ``names`` the file holds, each yielded as soon as it is
+    resident in HBM -- the way in for whole-genome drivers (``frag.delfi``): the caller's kernels for contig k run
+    while the decoder is already in contig k+1.  A file without a usable index is decoded in ONE streaming pass
+    (``stream_source``); a lazily indexed one in one streaming pass too when ``stream_all`` and most of it is
+    wanted, else contig by contig through the index (a rank of a multi-GPU run reads only its own blocks); a
+    cached source yields straight away.  Contigs the file lacks are not yielded (the caller decides)."""
+    path, is_bam = _check_path(input_file)
+    st = os.stat(path)
+    ckey = (os.path.abspath(path), st.st_mtime_ns, st.st_size)
+    wanted = list(dict.fromkeys(names))
+    want_set = set(wanted)
+    src = _SOURCES.get(ckey)
+    if src is None:
+        get_engine()  # fails loudly without the HIP library / a GPU
+        if os.environ.get("FTK_LAZY_SOURCE", "1") != "0":
+            src = _lazy_source(path, is_bam, workers)
+            if src is not None:
+                _SOURCES[ckey] = src
+                while len(_SOURCES) > _MAX_SOURCES:
+                    _, old = _SOURCES.popitem(last=False)
+                    old.release()
+    else:
+        _SOURCES.move_to_end(ckey)
+    if src is not None:
+        if src.bed6 and warn_bed6:
+            _warn_bed6()
+        have = [c for c in wanted if src.has(c)]
+        missing = [c for c in have if c not in src.loaded]
+        done = set()
+        if src.lazy and stream_all and len(missing) > 1 and 2 * len(missing) >= len(src.contigs):
+            for c in src._stream_missing_iter(set(missing)):
+                done.add(c)
+                yield src, c
+        for c in have:
+            if c not in done:
+                src.require(c)
+                yield src, c
+        return
+    warned = False
+    for src, c in stream_source(input_file, workers):
+        if src.bed6 and warn_bed6 and not warned:
+            _warn_bed6()
+            warned = True
+        if c in want_set:
+            yield src, c
 
 
 def _warn_bed6():

@@ -137,3 +137,65 @@ def write_paired_bam(path, contig, size, depth, seed, read_len=50):
     rows = file_rank[by_start]
     return dict(s=s[rows], e=e[rows], q=q[rows], st=st[rows], r1s=r1_pos[rows].astype(np.int32),
                 r1e=(r1_pos[rows] + read_len).astype(np.int32), n=n, file_bytes=os.path.getsize(path))
+
+
+def write_random_2bit(path, sizes, seed=SEED_BASE, n_blocks=True):
+    """A UCSC ``.2bit`` reference of random bases for ``sizes = {contig: length}`` (little endian, version 0): the
+    packed DNA is written as random bytes (T=0 C=1 A=2 G=3, four bases per byte, first base in the high bits), each
+    contig gets N blocks over its synthetic telomeres (``synth_gaps``) when ``n_blocks``, no mask blocks.  Written in
+    pieces, so a whole genome (775 MB) needs no more than 64 MB of memory.  Returns ``{contig: (N starts, N sizes)}``."""
+    import struct
+    names = list(sizes)
+    head = struct.pack("<IIII", 0x1A412743, 0, len(names), 0)
+    index_len = sum(1 + len(n.encode()) + 4 for n in names)
+    blocks = {}
+    for n in names:
+        if n_blocks and sizes[n] > 40_000:
+            blocks[n] = ([0, sizes[n] - 10_000], [10_000, 10_000])
+        else:
+            blocks[n] = ([], [])
+    off = len(head) + index_len
+    offsets = {}
+    for n in names:
+        offsets[n] = off
+        off += 4 + 4 + 8 * len(blocks[n][0]) + 4 + 4 + (sizes[n] + 3) // 4
+    with open(path, "wb") as fh:
+        fh.write(head)
+        for n in names:
+            fh.write(bytes([len(n.encode())]) + n.encode() + struct.pack("<I", offsets[n]))
+        for k, n in enumerate(names):
+            st, sz = blocks[n]
+            fh.write(struct.pack("<II", sizes[n], len(st)))
+            fh.write(np.asarray(st, "<u4").tobytes() + np.asarray(sz, "<u4").tobytes())
+            fh.write(struct.pack("<II", 0, 0))
+            rng = np.random.default_rng(seed + 7919 * k)
+            left = (sizes[n] + 3) // 4
+            while left > 0:
+                m = min(left, 64 << 20)
+                fh.write(rng.integers(0, 256, m, dtype=np.uint8).tobytes())
+                left -= m
+    return blocks
+
+
+def write_genome_delfi_inputs(directory, sizes, window=_WINDOW, n_blacklist=2000, seed=77):
+    """The side files of a whole-genome DELFI run over ``sizes`` (BASELINE config 4): chrom.sizes, the ``window`` bp
+    bins file, a blacklist BED (``n_blacklist`` regions spread by contig length, ``synth_blacklist``) and a BED4 gap
+    file with every contig's synthetic centromere / telomeres (``synth_gaps``).  Returns the four paths."""
+    import os
+    total = float(sum(sizes.values()))
+    cs, bins, bl, gaps = (os.path.join(directory, f) for f in ("genome.chrom.sizes", "bins.bed", "blacklist.bed", "gaps.bed"))
+    with open(cs, "w") as fh:
+        fh.write("".join(f"{c}\t{n}\n" for c, n in sizes.items()))
+    with open(bins, "w") as fh:
+        for c, n in sizes.items():
+            ws, we = tiling_windows(n, window)
+            fh.write("".join(f"{c}\t{a}\t{b}\n" for a, b in zip(ws.tolist(), we.tolist())))
+    with open(bl, "w") as fh:
+        for i, (c, n) in enumerate(sizes.items()):
+            s, e = synth_blacklist(n, seed + i, max(8, int(n_blacklist * n / total)))
+            fh.write("".join(f"{c}\t{a}\t{b}\n" for a, b in zip(s.tolist(), e.tolist())))
+    with open(gaps, "w") as fh:
+        for c, n in sizes.items():
+            c0, c1, telo = synth_gaps(n)
+            fh.write(f"{c}\t{c0}\t{c1}\tcentromere\n" + "".join(f"{c}\t{a}\t{b}\ttelomere\n" for a, b in telo))
+    return cs, bins, bl, gaps

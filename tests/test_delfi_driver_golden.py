@@ -130,7 +130,7 @@ def host_delfi(monkeypatch):
             s = self.seqs[contig]
             return np.array([s[a:b].count("G") + s[a:b].count("C") for a, b in zip(starts, stops)], np.int64)
 
-    monkeypatch.setattr(D, "open_source", lambda *a, **k: Src())
+    monkeypatch.setattr(D, "resident_contigs", lambda path, names, *a, **k: ((Src(), c) for c in names if c in cols))
     monkeypatch.setattr(D, "get_engine", lambda: Eng())
     monkeypatch.setattr(D, "ReferenceGenome", Ref)
     return D.delfi

@@ -152,8 +152,9 @@ def _product_worker(rank, world, port, d, q):
                           FTK_DIST_BACKEND="gloo")
         assert sharding.init_from_env() == (rank, world)
     src, eng, Ref, asked = _fake_device(SIZES_P)
+    Cv.open_source = lambda *a, **k: src
+    Df.resident_contigs = lambda path, names, *a, **k: ((src, c) for c in names if src.has(c))
     for mod in (Cv, Df):
-        mod.open_source = lambda *a, **k: src
         mod.get_engine = lambda: eng
     Df.ReferenceGenome = Ref
     with warnings.catch_warnings():
