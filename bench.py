@@ -271,11 +271,35 @@ def main():
                 ev += 2
         exchange_finish(exchange_start())
 
+    # FTK_BENCH_MERGED (default 1): ONE launch per unit whose grid holds the window-feature blocks first and the WPS
+    # tiles behind them (ftk_window_features_wps / feat_then_wps_kernel): the feature pass's tail and the WPS ramp
+    # overlap instead of adding up.  0 = the two launches per unit of rounds 1-2.
+    merged = os.environ.get("FTK_BENCH_MERGED", "1") != "0"
+
+    def step_merged(record_events=False):
+        ev = 0
+        for c in mine:
+            p = per[c]
+            if record_events:
+                eng.event_record(ev)
+            eng._check(lib.ftk_window_features_wps(
+                eng.ctx, eng.contig_id(c), L.ptr(p["ws"]), L.ptr(p["we"]), p["nw"], C.byref(flt), L.ptr(p["cov"]), 0,
+                HIST_BINS, L.ptr(p["hist"]), L.ptr(p["over"]), MAPQ, L.ptr(p["bl"][0]), L.ptr(p["bl"][1]),
+                len(p["bl"][0]), C.byref(p["gaps_c"]), L.ptr(p["short"]), L.ptr(p["long"]), p["a"], p["b"], p["size"],
+                WPS_W, WPS_MIN, WPS_MAX, MAPQ, L.ptr(p["wps"])))
+            if record_events:
+                eng.event_record(ev + 1)
+                wps_ev[c] = (ev, ev + 1)
+                ev += 2
+        exchange_finish(exchange_start())
+
     def step(record_events=False):
         if fused:
             return step_fused(record_events)
         if batched:
             return step_batched(record_events)
+        if merged:
+            return step_merged(record_events)
         row = 0
         ev = 0
         work = None
@@ -345,7 +369,7 @@ def main():
     # host and GPU for 35-50 ms (seen at step 8 of the 24-contig run and at step 52 of a 4-contig run, never
     # again in 5 000+ launches).  Setup therefore primes the runtime with untimed steps until that many launches
     # are behind us, so the stall cannot land in a short warm-up + timed region.  FTK_BENCH_PRIME=0 turns it off.
-    launches_per_step = (3 if batch_wps else 2 + len(mine)) if batched else 4 * len(mine) + 1
+    launches_per_step = (3 if batch_wps else 2 + len(mine)) if batched else (2 if merged else 4) * len(mine) + 1
     prime = 0
     if os.environ.get("FTK_BENCH_PRIME", "1") != "0":
         prime = min(512, -(-1200 // launches_per_step))
@@ -373,20 +397,25 @@ def main():
     # ---- roofline of the dominant kernel (WPS), from the last timed step -------
     wps_bytes = 0
     wps_ms = 0.0
+    one_launch = merged and not batched and not fused  # the events bracket feature blocks + WPS tiles of a unit
+    feat_unit_bytes = lambda u: 10 * per[u]["n"] + 8 * per[u]["nw"] + per[u]["nw"] * (4 * HIST_BINS + 8 * 4)
     for c, (a, b) in wps_ev.items():
         wps_ms += eng.event_elapsed_ms(a, b)
         for u in (mine if c == "batch" else [c]):
             wps_bytes += 10 * per[u]["n"] + 8 * (per[u]["b"] - per[u]["a"])
+            if one_launch:
+                wps_bytes += feat_unit_bytes(u)
     achieved = wps_bytes / (wps_ms * 1e-3) / 1e9 if wps_ms > 0 else 0.0
     traffic = None  # HBM bytes per launch from the committed PMC passes (same workload only)
     tpath = os.path.join(ROOT, "profiles", "wps_traffic.json")
     if world == 1 and not sim and not args.contigs and args.depth == 30.0 and os.path.exists(tpath):
-        tj = json.load(open(tpath))  # measured per step (all WPS launches of one step), reported per launch
-        traffic = int(tj["hbm_bytes_per_step"] / max(len(wps_ev), 1))
+        tj = json.load(open(tpath))  # measured per step (the dominant kernel's launches of one step), reported per launch
+        if tj.get("kernel", "wps_stream_kernel") == ("feat_then_wps_kernel" if one_launch else "wps_stream_kernel"):
+            traffic = int(tj["hbm_bytes_per_step"] / max(len(wps_ev), 1))
     # second kernel of the step: the fused window-feature pass of a unit runs between the previous unit's WPS
     # stop event and this unit's WPS start event (per-unit launch shape only)
     feat = None
-    if not batched and not fused and wps_ev and not os.environ.get("FTK_BENCH_SPLIT_ORDER"):
+    if not batched and not fused and not one_launch and wps_ev and not os.environ.get("FTK_BENCH_SPLIT_ORDER"):
         f_ms, f_bytes, prev = 0.0, 0, 4000
         for c in mine:
             a, b = wps_ev[c]
@@ -398,7 +427,7 @@ def main():
                     algorithmic_bytes_per_launch=int(f_bytes / len(mine)), launches=len(mine),
                     avg_launch_ms=round(f_ms / len(mine), 4),
                     note="follows a WPS launch: reads behind that kernel's write-back")
-    if os.environ.get("FTK_BENCH_DETAIL") and rank == 0 and not batched and not fused:
+    if os.environ.get("FTK_BENCH_DETAIL") and rank == 0 and not batched and not fused and not one_launch:
         prev = 4000
         for c in mine:  # per unit: fragments, feature-pass and WPS launch durations of the last timed step
             a, b = wps_ev[c]
@@ -408,7 +437,8 @@ def main():
             sys.stderr.write(f"unit {c:>24s} frags {per[c]['n']:>9d} feat {f_us:7.1f} us {fb / f_us / 1e6:6.2f} TB/s   "
                              f"wps {w_us:7.1f} us {wb / w_us / 1e6:6.2f} TB/s\n")
             prev = b
-    roofline = dict(bound="hbm", kernel="wps_stream_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+    roofline = dict(bound="hbm", kernel="feat_then_wps_kernel" if one_launch else "wps_stream_kernel",
+                    achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     algorithmic_bytes_per_launch=int(wps_bytes / max(len(wps_ev), 1)),
                     launches=len(wps_ev), avg_launch_ms=round(wps_ms / max(len(wps_ev), 1), 4))
@@ -442,6 +472,20 @@ def main():
         mine_tot = torch.stack([gather_in.sum()]).to(cdev)
         dist.all_reduce(mine_tot)
         checks["allgather_total_eq_sum_of_ranks"] = int(mine_tot.item()) == int(tot.item())
+    file_leg = None
+    if use_dist and world > 1 and not sim and not args.no_end_to_end:
+        # N ranks, ONE file: BASELINE config 4 end to end through the product function (every rank index-seeks and
+        # decodes its own contigs, counts them, one all-gather, rank 0 merges and writes).  The resident workload of
+        # the timed steps is released first, on every rank.
+        keep_last = per[mine[-1]]["keep"] if mine else None
+        for c in list(per):
+            eng.release(c)
+            for k in ("cov", "hist", "over", "wps", "short", "long", "d_ws", "d_we", "keep"):
+                per[c].pop(k, None)
+        del all_wps, all_hist, all_cov, all_over
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        file_leg = multi_rank_file_leg(torch, dist, rank, world, {c: sizes[c] for c in names}, args.depth)
     e2e = None
     if rank == 0 and world == 1 and not sim and not args.no_end_to_end:
         # file -> result legs (SURVEY 8-d's second figure).  The resident workload is released first.
@@ -479,8 +523,8 @@ def main():
                        "sharding": (f"genome cut into {world} equal window-aligned runs ({len(units)} units, halo "
                                     f"{halo} bp); all-gather of DELFI bin vector") if world > 1
                        else ("single GPU" if not sim else f"simulated rank {sim} alone")},
-            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e, "checks": checks, "load_s": round(t_load, 2),
-            "priming_steps": prime, "launches": "fused WPS + features, 1 launch per unit" if fused else ("1 batched feature launch + " + ("1 batched WPS launch" if batch_wps else "1 WPS launch per unit")
+            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e if world == 1 else file_leg, "checks": checks, "load_s": round(t_load, 2),
+            "priming_steps": prime, "launches": "fused WPS + features, 1 launch per unit" if fused else "1 launch per unit: feature blocks, then WPS tiles" if one_launch else ("1 batched feature launch + " + ("1 batched WPS launch" if batch_wps else "1 WPS launch per unit")
                          + " per step") if batched else "per unit",
         }
     if use_dist:
@@ -495,6 +539,92 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+
+
+def multi_rank_file_leg(torch, dist, rank, world, sizes, depth, reps: int = 2):
+    """BASELINE config 4 with N ranks: rank 0 writes ONE indexed fragment file of the run's contigs (not timed), then
+    every rank calls the product's ``frag.delfi`` on it under the bench's process group: contigs dealt by LPT, a rank
+    reads its contigs' blocks through the tabix index and inflates / parses / counts them on ITS GPU with its share
+    of the host cores, one all-gather of the bin vectors, rank 0 merges to 5 Mb and writes the TSV.  Reported: the
+    slowest rank's wall time (best of ``reps``), every rank's stage split, and whether all ranks hold the same frame."""
+    import hashlib
+    import shutil
+    import tempfile
+    import warnings
+    from finaletoolkit_amd import bgzf, frag, source, writers
+    from finaletoolkit_amd.frag import _delfi as FD
+    box = [None]
+    t_write = 0.0
+    rows_total = 0
+    try:
+        if rank == 0:
+            tmp = tempfile.mkdtemp(prefix="ftk_bench_ranks_")
+            dev = torch.device("cuda", torch.cuda.current_device())
+            t0 = time.perf_counter()
+            pg = os.path.join(tmp, "genome.frag.gz")
+            spans = []
+            names = list(sizes)
+            for k, c in enumerate(names):
+                n = synth.n_fragments(sizes[c], depth)
+                s, e, q, st = (t.cpu().numpy() for t in gen_contig_device(torch, dev, sizes[c], n, synth.SEED_BASE + k))
+                with writers.frag_rows(c, s, e, q, st) as text:
+                    offs = writers.bgzf_write(pg, text, 1, append=k > 0, write_eof=k == len(names) - 1)
+                spans.append((c, int(offs[0]) << 16, int(offs[-1]) << 16))
+                rows_total += n
+                del s, e, q, st
+            bgzf.write_index(pg + ".tbi", False, spans)
+            synth.write_genome_delfi_inputs(tmp, sizes, WINDOW)
+            synth.write_random_2bit(os.path.join(tmp, "genome.2bit"), sizes)
+            t_write = time.perf_counter() - t0
+            box[0] = (tmp, rows_total)
+        dist.broadcast_object_list(box, src=0)
+        tmp, rows_total = box[0]
+        pg = os.path.join(tmp, "genome.frag.gz")
+        side = [os.path.join(tmp, f) for f in ("genome.chrom.sizes", "bins.bed", "blacklist.bed", "gaps.bed", "genome.2bit")]
+        n_win = sum(-(-n // WINDOW) for n in sizes.values())
+        threads = source.usable_cores()
+        best = None
+        for _ in range(reps):
+            source.close_all()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                df = frag.delfi(pg, side[0], side[1], side[4], blacklist_file=side[2], gap_file=side[3],
+                                output_file=os.path.join(tmp, "delfi_5mb.tsv"), no_gc_correct=True, merge_bins=True,
+                                workers=threads)
+            mine_s = time.perf_counter() - t0
+            decoded = sorted(k.split(":", 1)[1] for k in source.get_engine().contigs)
+            said = [None] * world
+            dist.all_gather_object(said, dict(rank=rank, total_s=round(mine_s, 4), stages_s=dict(FD.LAST_STAGE_S),
+                                              contigs_decoded=len(decoded), decoder_threads=threads,
+                                              frame_sha=hashlib.sha256(df.to_csv(index=False).encode()).hexdigest(),
+                                              rows=int(df.shape[0])))
+            slowest = max(x["total_s"] for x in said)
+            if best is None or slowest < best["total_s"]:
+                same = len({x["frame_sha"] for x in said}) == 1
+                parted = sum(x["contigs_decoded"] for x in said) == len(sizes)
+                best = dict(total_s=slowest, windows=n_win, windows_per_s=round(n_win / slowest, 1),
+                            fragments_per_s_M=round(rows_total / slowest / 1e6, 1), merged_rows=said[0]["rows"],
+                            per_rank=[{k: v for k, v in x.items() if k != "frame_sha"} for x in said],
+                            results_ok=bool(same and parted and said[0]["rows"] > 0),
+                            checked="every rank holds the same merged frame; each contig was decoded by exactly one rank")
+        source.close_all()
+        out = None
+        if rank == 0:
+            out = {"genome_frag_delfi_api_ranks": dict(
+                ranks=world, fragments=rows_total, file_GB=round(os.path.getsize(pg) / 1e9, 3),
+                file_and_side_files_write_s=round(t_write, 1), repetitions=reps, **best),
+                "note": "one indexed file read by all ranks through frag.delfi; wall time of the slowest rank; PCIe and "
+                        "the all-gather included; never the headline value"}
+        dist.barrier()
+        return out
+    except Exception as exc:  # the headline line must still be printed
+        return {"error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        if rank == 0 and box[0]:
+            shutil.rmtree(box[0][0], ignore_errors=True)
 
 
 def end_to_end(torch, reps: int = 3, cpu=None):

@@ -48,10 +48,10 @@ EXPORTS = [
     "ftk_fragtable_contig_rows", "ftk_fragtable_columns", "ftk_fragtable_order", "ftk_fragtable_is_pinned", "ftk_fragtable_free",
     "ftk_frags_from_table",
     "ftk_window_counts", "ftk_delfi_counts", "ftk_fraglen_hist", "ftk_window_features",
-    "ftk_window_features_batch", "ftk_wps_batch", "ftk_wps_window_features", "ftk_frag_lengths",
+    "ftk_window_features_batch", "ftk_wps_batch", "ftk_wps_window_features", "ftk_window_features_wps", "ftk_frag_lengths",
     "ftk_frag_select",
     "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals", "ftk_wps_adjust",
-    "ftk_ref_upload", "ftk_ref_release", "ftk_ref_gc_counts", "ftk_ref_set_layout", "ftk_motif_counts",
+    "ftk_ref_upload", "ftk_ref_upload_file", "ftk_ref_release", "ftk_ref_gc_counts", "ftk_ref_set_layout", "ftk_motif_counts",
     "ftk_format_wig_i64", "ftk_format_bedgraph_i64", "ftk_format_bedgraph_f64", "ftk_buffer_free", "ftk_file_write", "ftk_gzip_members",
     "ftk_bigwig_fixedstep_sections", "ftk_format_frag_rows", "ftk_bgzf_write", "ftk_fill_wps_records", "ftk_bgzf_inflate_device",
 ]
@@ -254,6 +254,8 @@ def load() -> C.CDLL:
     lib.ftk_fraglen_hist.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), i32, i32, vp, vp]
     lib.ftk_window_features.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), vp, i32, i32, vp, vp, i32, vp, vp,
                                         i64, C.POINTER(Gaps), vp, vp]
+    lib.ftk_window_features_wps.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), vp, i32, i32, vp, vp, i32, vp, vp,
+                                            i64, C.POINTER(Gaps), vp, vp, i64, i64, i64, i32, i32, i32, i32, vp]
     lib.ftk_window_features_batch.argtypes = [vp, C.POINTER(FeatureItem), i32, C.POINTER(Filter), vp, i32, i32, vp, vp, i32,
                                               vp, vp]
     lib.ftk_wps_batch.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]
@@ -269,6 +271,7 @@ def load() -> C.CDLL:
     lib.ftk_cleavage_intervals.argtypes = [vp, C.c_int, vp, vp, i64, vp, i32, i32, i32, vp]
     lib.ftk_wps_adjust.argtypes = [vp, vp, vp, i64, i32, C.c_int, vp, i32, vp, vp, vp]
     lib.ftk_ref_upload.argtypes = [vp, C.c_int, vp, i64, C.c_int]
+    lib.ftk_ref_upload_file.argtypes = [vp, C.c_int, C.c_char_p, i64, i64, C.c_int]
     lib.ftk_ref_release.argtypes = [vp, C.c_int]
     lib.ftk_ref_gc_counts.argtypes = [vp, C.c_int, vp, vp, i64, vp]
     lib.ftk_ref_set_layout.argtypes = [vp, C.c_int, i64, i32, i32, vp, vp, i64]

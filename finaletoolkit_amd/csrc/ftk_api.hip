@@ -1,6 +1,8 @@
 // C-ABI implementation (include/ftk.h): contexts, HBM residency of fragments,
 // and the host side of every feature call.  No CPU compute fallback exists.
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -9,7 +11,10 @@
 #include <type_traits>
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 
+#include "ftk_host.h"
 #include "ftk_inflate.h"
 #include "ftk_kernels.h"
 
@@ -339,6 +344,11 @@ void ftk_ctx_destroy(ftk_ctx* ctx) {
     for (auto& kv : ctx->refs) {
         (void)hipFree(kv.second.d);
         if (kv.second.d_nblk) (void)hipFree(kv.second.d_nblk);
+    }
+    for (auto& b : ctx->ref_pool) (void)hipFree(b.first);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->ref_stage[k]) (void)hipHostFree(ctx->ref_stage[k]);
+        if (ctx->ref_stage_done[k]) (void)hipEventDestroy(ctx->ref_stage_done[k]);
     }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
@@ -693,7 +703,7 @@ struct FeatCall {
 };
 
 int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
-                    const FeatCall& fc) {
+                    const FeatCall& fc, const WpsTail* tail = nullptr, bool* tail_merged = nullptr) {
     if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
     ContigData* c;
     int rc = get_contig(ctx, contig_id, &c);
@@ -771,8 +781,10 @@ int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const i
         const double est = (double)c->n / (double)c->max_end * (span / (double)n_win + lmax);
         r.block_threads = est >= 4096.0 ? 512 : 256;
     }
-    launch_window_features(ctx->stream, ctx->n_cu * bpc, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan, r, small_path,
-                           block_path ? lmax : -1);
+    if (tail) r.block_threads = 256;
+    const bool merged = launch_window_features(ctx->stream, ctx->n_cu * bpc, c->v, wc.d_ws, wc.d_we, (int)n_win, wc.plan,
+                                               r, small_path, block_path ? lmax : -1, tail);
+    if (tail_merged) *tail_merged = merged;
     if (d_nfrag) launch_add_i64(ctx->stream, r.short_out, r.long_out, d_nfrag, (int)n_win);
     HIPCHK(ctx, hipGetLastError());
     bool host_out = false;
@@ -1102,6 +1114,49 @@ int ftk_wps(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t ch
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     return FTK_OK;
+}
+
+// ftk_window_features followed by ftk_wps on the same contig, as ONE launch when the request takes the FAST block
+// path (grid = the feature blocks, then the WPS tiles: feat_then_wps_kernel); otherwise the two launches.
+int ftk_window_features_wps(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                            const ftk_filter* f, int64_t* count_out, int32_t len_lo, int32_t n_bins, uint32_t* hist_out,
+                            int64_t* overflow_out, int32_t delfi_mapq_min, const int32_t* bl_start, const int32_t* bl_end,
+                            int64_t n_bl, const ftk_gaps* gaps, int64_t* short_out, int64_t* long_out, int64_t start,
+                            int64_t stop, int64_t chrom_size, int32_t window_size, int32_t min_len, int32_t max_len,
+                            int32_t mapq_min, int64_t* wps_out) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    ContigData* c;
+    int rc = get_contig(ctx, contig_id, &c);
+    if (rc) return rc;
+    WpsTail tail{};
+    if ((rc = wps_params(ctx, *c, chrom_size, window_size, min_len, max_len, mapq_min, &tail.p))) return rc;
+    const bool wps_ok = stop > start && start >= -(1LL << 30) && stop <= (1LL << 31) && wps_out && is_device_ptr(wps_out) &&
+                        n_win > 0;
+    FeatCall fc;
+    fc.f = f;
+    fc.count_out = count_out;
+    fc.hist_out = hist_out;
+    fc.overflow_out = overflow_out;
+    fc.len_lo = len_lo;
+    fc.n_bins = n_bins;
+    fc.delfi = short_out || long_out;
+    fc.mapq_min = delfi_mapq_min;
+    fc.bl_start = bl_start;
+    fc.bl_end = bl_end;
+    fc.n_bl = n_bl;
+    fc.gaps = gaps;
+    fc.short_out = short_out;
+    fc.long_out = long_out;
+    bool merged = false;
+    if (wps_ok) {
+        tail.p.start = start;
+        tail.p.stop = stop;
+        tail.n_tiles = (stop - start + kWpsTile - 1) / kWpsTile;
+        tail.out = wps_out;
+    }
+    if ((rc = features_common(ctx, contig_id, w_start, w_end, n_win, fc, wps_ok ? &tail : nullptr, &merged))) return rc;
+    if (merged) return FTK_OK;
+    return ftk_wps(ctx, contig_id, start, stop, chrom_size, window_size, min_len, max_len, mapq_min, wps_out);
 }
 
 int ftk_wps_async(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t chrom_size, int32_t window_size,
@@ -1527,25 +1582,71 @@ int ftk_wps_adjust(ftk_ctx* ctx, const double* scores, const int64_t* offsets, i
     return FTK_OK;
 }
 
+namespace {
+
+constexpr size_t kRefStageBytes = size_t(16) << 20;
+constexpr size_t kRefPoolMax = 4;
+
+// a device block of at least `bytes` for a reference image: the smallest pooled one that fits, else a fresh one
+int ref_block_take(ftk_ctx* ctx, size_t bytes, void** out, size_t* cap) {
+    int best = -1;
+    for (size_t i = 0; i < ctx->ref_pool.size(); ++i)
+        if (ctx->ref_pool[i].second >= bytes && (best < 0 || ctx->ref_pool[i].second < ctx->ref_pool[best].second)) best = (int)i;
+    if (best >= 0) {
+        *out = ctx->ref_pool[best].first;
+        *cap = ctx->ref_pool[best].second;
+        ctx->ref_pool.erase(ctx->ref_pool.begin() + best);
+        return FTK_OK;
+    }
+    const size_t want = align_up(bytes + bytes / 8, 1 << 20);  // a little slack: the next contig is often slightly larger
+    HIPCHK(ctx, hipMalloc(out, want));
+    *cap = want;
+    return FTK_OK;
+}
+
+void ref_block_give(ftk_ctx* ctx, void* d, size_t cap) {
+    if (!d) return;
+    ctx->ref_pool.emplace_back(d, cap);
+    while (ctx->ref_pool.size() > kRefPoolMax) {  // keep the largest blocks
+        size_t k = 0;
+        for (size_t i = 1; i < ctx->ref_pool.size(); ++i)
+            if (ctx->ref_pool[i].second < ctx->ref_pool[k].second) k = i;
+        (void)hipFree(ctx->ref_pool[k].first);
+        ctx->ref_pool.erase(ctx->ref_pool.begin() + (long)k);
+    }
+}
+
+int ref_drop(ftk_ctx* ctx, int ref_id) {  // an image about to be replaced / released: its blocks go back to the pool
+    auto it = ctx->refs.find(ref_id);
+    if (it == ctx->refs.end()) return FTK_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // launches that read it have finished
+    ref_block_give(ctx, it->second.d, (size_t)it->second.cap);
+    if (it->second.d_nblk) (void)hipFree(it->second.d_nblk);
+    ctx->refs.erase(it);
+    return FTK_OK;
+}
+
+}  // namespace
+
 int ftk_ref_upload(ftk_ctx* ctx, int ref_id, const uint8_t* image, int64_t n_bytes, int kind) {
     if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
     if (n_bytes < 0 || (n_bytes > 0 && !image) || (kind != FTK_REF_FASTA_TEXT && kind != FTK_REF_2BIT))
         return fail(ctx, FTK_ERR_INVALID, "bad reference image arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    auto it = ctx->refs.find(ref_id);
-    if (it != ctx->refs.end()) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(it->second.d);
-        if (it->second.d_nblk) (void)hipFree(it->second.d_nblk);
-        ctx->refs.erase(it);
-    }
+    int rc = ref_drop(ctx, ref_id);
+    if (rc) return rc;
     ftk_ctx::RefImage r;
     r.bytes = n_bytes;
     r.kind = kind;
-    HIPCHK(ctx, hipMalloc(&r.d, (size_t)n_bytes + 32));  // padded: 16-byte loads never leave the block
-    hipError_t e = hipMemset((char*)r.d + n_bytes, 0, 32);
+    size_t cap = 0;
+    if ((rc = ref_block_take(ctx, (size_t)n_bytes + 32, &r.d, &cap))) return rc;  // padded: 16-byte loads never leave the block
+    r.cap = (int64_t)cap;
+    // on the ctx stream, one wait for THAT stream at the end (a synchronous hipMemcpy waits for every transfer the
+    // device has in flight)
+    hipError_t e = hipMemsetAsync((char*)r.d + n_bytes, 0, 32, ctx->stream);
     if (e == hipSuccess && n_bytes)
-        e = hipMemcpy(r.d, image, n_bytes, is_device_ptr(image) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+        e = hipMemcpyAsync(r.d, image, n_bytes, is_device_ptr(image) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(r.d);
@@ -1555,15 +1656,71 @@ int ftk_ref_upload(ftk_ctx* ctx, int ref_id, const uint8_t* image, int64_t n_byt
     return FTK_OK;
 }
 
+int ftk_ref_upload_file(ftk_ctx* ctx, int ref_id, const char* path, int64_t file_offset, int64_t n_bytes, int kind) {
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    if (!path || file_offset < 0 || n_bytes < 0 || (kind != FTK_REF_FASTA_TEXT && kind != FTK_REF_2BIT))
+        return fail(ctx, FTK_ERR_INVALID, "bad reference image arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(ctx, FTK_ERR_IO, "cannot open %s: %s", path, strerror(errno));
+    struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
+    int rc = ref_drop(ctx, ref_id);
+    if (rc) return rc;
+    for (int k = 0; k < 2; ++k) {
+        if (!ctx->ref_stage[k]) HIPCHK(ctx, hipHostMalloc(&ctx->ref_stage[k], kRefStageBytes, hipHostMallocDefault));
+        if (!ctx->ref_stage_done[k]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ref_stage_done[k], hipEventDisableTiming));
+    }
+    ftk_ctx::RefImage r;
+    r.bytes = n_bytes;
+    r.kind = kind;
+    size_t cap = 0;
+    if ((rc = ref_block_take(ctx, (size_t)n_bytes + 32, &r.d, &cap))) return rc;
+    r.cap = (int64_t)cap;
+    bool used[2] = {false, false};
+    hipError_t e = hipMemsetAsync((char*)r.d + n_bytes, 0, 32, ctx->stream);
+    int k = 0;
+    // the file (page cache) -> a page-locked chunk on four pread threads -> the device, the next chunk read while the
+    // previous one is on its way
+    for (int64_t off = 0; off < n_bytes && e == hipSuccess; off += (int64_t)kRefStageBytes, k ^= 1) {
+        const size_t n = (size_t)std::min<int64_t>((int64_t)kRefStageBytes, n_bytes - off);
+        if (used[k]) e = hipEventSynchronize(ctx->ref_stage_done[k]);
+        if (e != hipSuccess) break;
+        std::atomic<int> bad{0};
+        const int nt = n >= (size_t(4) << 20) ? 4 : 1;
+        char* dst = (char*)ctx->ref_stage[k];
+        ftk_host::parallel_run(nt, [&](int t) {
+            size_t a = n * (size_t)t / nt;
+            const size_t b = n * (size_t)(t + 1) / nt;
+            while (a < b) {
+                const ssize_t got = pread(fd, dst + a, b - a, (off_t)(file_offset + off + (int64_t)a));
+                if (got <= 0) { bad.store(1); return; }
+                a += (size_t)got;
+            }
+        });
+        if (bad.load()) {
+            (void)hipStreamSynchronize(ctx->stream);
+            ref_block_give(ctx, r.d, cap);
+            return fail(ctx, FTK_ERR_IO, "%s is shorter than the reference image it should hold", path);
+        }
+        e = hipMemcpyAsync((char*)r.d + off, dst, n, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ref_stage_done[k], ctx->stream);
+        used[k] = true;
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(ctx->stream);
+        ref_block_give(ctx, r.d, cap);
+        return fail(ctx, FTK_ERR_HIP, "reference upload failed: %s", hipGetErrorString(e));
+    }
+    ctx->refs[ref_id] = r;  // (kernels of this stream run behind the copies; the staging chunks wait on their events)
+    return FTK_OK;
+}
+
 int ftk_ref_release(ftk_ctx* ctx, int ref_id) {
     if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
-    auto it = ctx->refs.find(ref_id);
-    if (it == ctx->refs.end()) return fail(ctx, FTK_ERR_NO_CONTIG, "reference image %d is not loaded", ref_id);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(it->second.d);
-    if (it->second.d_nblk) (void)hipFree(it->second.d_nblk);
-    ctx->refs.erase(it);
-    return FTK_OK;
+    if (ctx->refs.find(ref_id) == ctx->refs.end()) return fail(ctx, FTK_ERR_NO_CONTIG, "reference image %d is not loaded", ref_id);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return ref_drop(ctx, ref_id);
 }
 
 int ftk_ref_set_layout(ftk_ctx* ctx, int ref_id, int64_t chrom_len, int32_t line_bases, int32_t line_width,

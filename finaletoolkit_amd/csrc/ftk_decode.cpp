@@ -573,6 +573,13 @@ int default_threads() {
                 c = std::min<long long>(c, std::max<long long>(1, (atoll(q) + period / 2) / period));
             fclose(f);
         }
+        // one rank per GPU on one node: every rank takes its share of the host cores (LOCAL_WORLD_SIZE is set by
+        // torchrun and by sharding.launch_ranks), so 8 ranks do not start 8 x 16 threads on a 16-core quota;
+        // FTK_HOST_THREADS overrides
+        if (const char* w = getenv("LOCAL_WORLD_SIZE"))
+            if (atoi(w) > 1) c = std::max(1, c / atoi(w));
+        if (const char* t = getenv("FTK_HOST_THREADS"))
+            if (atoi(t) > 0) c = atoi(t);
         return std::max(1, std::min(c, 64));
     }();
     return n;

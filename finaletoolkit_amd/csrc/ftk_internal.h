@@ -78,6 +78,7 @@ struct ftk_ctx {
     struct RefImage {
         void* d = nullptr;
         int64_t bytes = 0;
+        int64_t cap = 0;  // size of the device block (>= bytes + 32; blocks are recycled through ref_pool)
         int kind = 0;
         // ftk_ref_set_layout (needed by the motif pass)
         int64_t chrom_len = -1;
@@ -86,6 +87,12 @@ struct ftk_ctx {
         int32_t n_nblk = 0;
     };
     std::map<int, RefImage> refs;  // reference-sequence images for the DELFI GC count
+    // released images' device blocks, kept for the next upload (hipMalloc / hipFree wait for the whole device - the
+    // decoder's kernels included - and a genome-wide DELFI run uploads one image per contig), and the two
+    // page-locked staging chunks ftk_ref_upload_file reads the file through
+    std::vector<std::pair<void*, size_t>> ref_pool;
+    void* ref_stage[2] = {nullptr, nullptr};
+    hipEvent_t ref_stage_done[2] = {nullptr, nullptr};
     // batched launches: the per-item descriptors last uploaded (re-used while the caller repeats the batch)
     std::vector<unsigned char> batch_host[2];  // [0] window features, [1] WPS
     void* batch_dev[2] = {nullptr, nullptr};

@@ -96,9 +96,16 @@ void launch_window_features_batch(hipStream_t s, const FeatItem* d_items, int n_
                                   const FeatureRequest& r, bool bam);
 // block_lmax >= 0: one block per window (feat_block_kernel, needs no plan and no zeroed outputs), with
 // block_lmax = longest fragment any requested feature can accept; < 0: the planned small + chunked passes.
-void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
+// tail: a whole-interval WPS of the same contig to run in the SAME launch behind the feature blocks (FAST block
+// path only); returns true when it was merged, false when the caller has to launch it itself.
+struct WpsTail {
+    WpsParams p;
+    int64_t n_tiles;
+    int64_t* out;
+};
+bool launch_window_features(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
                             int n_win, const WindowPlan& pl, const FeatureRequest& r, bool small_path,
-                            int block_lmax = -1);
+                            int block_lmax = -1, const WpsTail* tail = nullptr);
 void launch_add_i64(hipStream_t s, const int64_t* a, const int64_t* b, int64_t* out, int n);
 void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t n_tiles, const int64_t* iv_start,
                 const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv, const int32_t* tile_k,

@@ -1005,14 +1005,14 @@ constexpr int kWpsPrefetch = 4;  // fragments per thread held in registers for t
 // fragment columns once (BASELINE config 5: all features in a single pass).  A fragment's bin is the one
 // holding its midpoint: the bin of the tile's first base or the next one (bins are longer than a tile plus
 // the longest fragment), counted in LDS / registers for the first and with global atomics for the second.
+// The block's work as a device function (block `block_id` of `n_blocks`), so that a launch may put other blocks
+// in front of the WPS tiles (feat_then_wps_kernel below).
 template <bool MULTI, bool BATCH, bool FUSED>
-__global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParams p, const int64_t* iv_start_,
-                                                         const int64_t* iv_stop_, const int64_t* out_off_,
-                                                         const int32_t* tile_iv, const int32_t* tile_k,
-                                                         long long n_tiles, int tiles_per_block,
-                                                         int64_t* __restrict__ out,
-                                                         const WpsItem* __restrict__ items, int n_items,
-                                                         FusedParams F) {
+__device__ __forceinline__ void wps_block(const unsigned block_id, const unsigned n_blocks, ContigView cv, WpsParams p,
+                                          const int64_t* iv_start_, const int64_t* iv_stop_, const int64_t* out_off_,
+                                          const int32_t* tile_iv, const int32_t* tile_k, long long n_tiles,
+                                          int tiles_per_block, int64_t* __restrict__ out,
+                                          const WpsItem* __restrict__ items, int n_items, const FusedParams& F) {
     constexpr int T = kWpsTile, NP = T / 1024, PF = kWpsPrefetch;
     extern __shared__ uint32_t fhist[];  // FUSED with a histogram: n_bins + 1 counters of the tile's first bin
     __shared__ int fcnt[4];              // FUSED: rejected (coverage, short, long) and processed fragments
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParam
 
     // Optional XCD-contiguous block -> tile map (blocks are dealt round-robin to the 8 XCDs; this gives
     // each XCD one contiguous run of tiles so halos share an L2).  Off by default: measured slower.
-    const long long bid = p.xcd_remap ? xcd_contiguous(blockIdx.x, gridDim.x) : (long long)blockIdx.x;
+    const long long bid = p.xcd_remap ? xcd_contiguous(block_id, n_blocks) : (long long)block_id;
     const long long tfirst = bid * tiles_per_block;
     const long long tlast = min(tfirst + (long long)tiles_per_block, n_tiles);
     if (tfirst >= tlast) return;
@@ -1303,6 +1303,41 @@ __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParam
 #pragma unroll
         for (int k = 0; k < PF; ++k) { pfs[k] = nfs[k]; pfe[k] = nfe[k]; pfq[k] = nfq[k]; }
     }
+}
+
+template <bool MULTI, bool BATCH, bool FUSED>
+__global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParams p, const int64_t* iv_start_,
+                                                         const int64_t* iv_stop_, const int64_t* out_off_,
+                                                         const int32_t* tile_iv, const int32_t* tile_k,
+                                                         long long n_tiles, int tiles_per_block,
+                                                         int64_t* __restrict__ out,
+                                                         const WpsItem* __restrict__ items, int n_items,
+                                                         FusedParams F) {
+    wps_block<MULTI, BATCH, FUSED>(blockIdx.x, gridDim.x, cv, p, iv_start_, iv_stop_, out_off_, tile_iv, tile_k, n_tiles,
+                                   tiles_per_block, out, items, n_items, F);
+}
+
+// ONE launch for a contig's step: the grid holds the window-feature blocks FIRST (block w = window w: the FAST
+// block path, feat_fast_body with 256 threads) and the WPS tiles behind them (block n_win + t = tile t).  Blocks
+// are dispatched in index order, so the feature pass starts alone, WPS tiles fill the chip as feature blocks
+// retire (the feature pass's tail and the WPS ramp overlap instead of adding up), and WPS finds the contig's
+// columns in the Infinity Cache behind the feature blocks that just read them.  The two kinds of block share
+// nothing: results are those of the two separate launches.
+template <bool CHK, bool HIST, bool DF>
+__global__ __launch_bounds__(256) void feat_then_wps_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
+                                                            int n_win, int lmax, FeatParams P, WpsParams p,
+                                                            long long n_tiles, int64_t* __restrict__ out) {
+    if (blockIdx.x < (unsigned)n_win) {
+        extern __shared__ uint32_t lds_hist[];
+        __shared__ int red[5][4];
+        const int w = blockIdx.x;
+        int o0 = 0, o1 = 0;
+        if (DF && P.dp.bl_off) { o0 = P.dp.bl_off[w]; o1 = P.dp.bl_off[w + 1]; }
+        feat_fast_body<256, CHK, HIST, DF>(cv, ws_[w], we_[w], lmax, P, o0, o1, (size_t)w, lds_hist, red);
+        return;
+    }
+    wps_block<false, false, false>(blockIdx.x - (unsigned)n_win, gridDim.x - (unsigned)n_win, cv, p, nullptr, nullptr,
+                                   nullptr, nullptr, nullptr, n_tiles, 1, out, nullptr, 0, FusedParams{});
 }
 
 // ---------------------------------------------------------------------------
@@ -1584,10 +1619,24 @@ static bool feat_fast_ok(const FeatParams& P, bool ch, bool df) {
 }
 
 template <int CH, bool DF, bool BAM>
-static void launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
+static bool launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
                           int n_win, const WindowPlan& pl, const FeatParams& P, bool small_path, int block_lmax,
-                          int block_threads) {
+                          int block_threads, const WpsTail* tail) {
     const size_t lds1 = (CH && P.do_hist) ? (size_t)(P.n_bins + 1) * sizeof(uint32_t) : 0;  // + overflow bin
+    if (tail && tail->n_tiles > 0 && block_lmax >= 0 && CH != 2 && !BAM && feat_fast_ok(P, CH != 0, DF) &&
+        (long long)n_win + tail->n_tiles < (1LL << 31)) {
+        // the merged launch: feature blocks first, the WPS tiles behind them (feat_then_wps_kernel)
+        FeatParams Pf = P;
+        if (!CH) Pf.ch_q = P.df_q;
+        const dim3 grid((unsigned)((long long)n_win + tail->n_tiles));
+        if (CH && P.do_hist)
+            hipLaunchKernelGGL((feat_then_wps_kernel<CH != 0, true, DF>), grid, dim3(256), lds1, s, cv, ws, we, n_win,
+                               block_lmax, Pf, tail->p, (long long)tail->n_tiles, tail->out);
+        else
+            hipLaunchKernelGGL((feat_then_wps_kernel<CH != 0, false, DF>), grid, dim3(256), lds1, s, cv, ws, we, n_win,
+                               block_lmax, Pf, tail->p, (long long)tail->n_tiles, tail->out);
+        return true;
+    }
     if (block_lmax >= 0 && CH != 2 && !BAM && feat_fast_ok(P, CH != 0, DF)) {
 #define FTK_FAST(BS)                                                                                                \
     do {                                                                                                            \
@@ -1603,7 +1652,7 @@ static void launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, c
         if (block_threads >= 512) FTK_FAST(512);
         else FTK_FAST(256);
 #undef FTK_FAST
-        return;
+        return false;
     }
     if (block_lmax >= 0) {
         if (block_threads >= 512)
@@ -1612,20 +1661,24 @@ static void launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, c
         else
             hipLaunchKernelGGL((feat_block_kernel<256, CH, DF, BAM>), dim3(n_win), dim3(256), lds1, s, cv, ws, we, n_win,
                                block_lmax, P);
-        return;
+        return false;
     }
     if (small_path)
         hipLaunchKernelGGL((feat_small_kernel<CH, DF, BAM>), dim3((n_win + 3) / 4), dim3(256), 4 * lds1, s, cv, ws, we,
                            n_win, pl.cand_lo, pl.cand_hi, pl.nchunks, P);
     hipLaunchKernelGGL((feat_large_kernel<CH, DF, BAM>), dim3(grid_large), dim3(256), lds1, s, cv, ws, we, n_win,
                        pl.cand_lo, pl.cand_hi, pl.chunk_off, P);
+    return false;
 }
 
 // One pass computing any combination of {coverage, length histogram} (filter `f`) and DELFI
 // short/long.  With small_path the wave-per-window kernel writes or clears every histogram row;
 // without it hist_out / over_out must be zero-filled by the caller.
-void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
-                            int n_win, const WindowPlan& pl, const FeatureRequest& r, bool small_path, int block_lmax) {
+// `tail`: a whole-interval WPS launch of the same contig that should run in the SAME launch behind the feature blocks
+// (taken on the FAST block path only); returns true when it did, false when the caller must launch it itself.
+bool launch_window_features(hipStream_t s, int grid_large, const ContigView& cv, const int32_t* ws, const int32_t* we,
+                            int n_win, const WindowPlan& pl, const FeatureRequest& r, bool small_path, int block_lmax,
+                            const WpsTail* tail) {
     FeatParams P{};
     const bool ch = r.cov_out || r.hist_out;
     const bool df = r.short_out != nullptr;
@@ -1656,9 +1709,10 @@ void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv,
     const bool bam = cv.r1_start != nullptr && (!r.filter || r.filter->fetch_mode == FTK_FETCH_BAM_READ1);
 #define FTK_FEAT(CH, DF)                                                                              \
     do {                                                                                              \
-        if (bam) launch_feat_t<CH, DF, true>(s, grid_large, cv, ws, we, n_win, pl, P, small_path, block_lmax, r.block_threads);  \
-        else launch_feat_t<CH, DF, false>(s, grid_large, cv, ws, we, n_win, pl, P, small_path, block_lmax, r.block_threads);     \
+        if (bam) merged = launch_feat_t<CH, DF, true>(s, grid_large, cv, ws, we, n_win, pl, P, small_path, block_lmax, r.block_threads, tail);  \
+        else merged = launch_feat_t<CH, DF, false>(s, grid_large, cv, ws, we, n_win, pl, P, small_path, block_lmax, r.block_threads, tail);     \
     } while (0)
+    bool merged = false;
     if (r.motif) {
         P.mp = *r.motif;
         P.do_hist = 1;
@@ -1667,6 +1721,7 @@ void launch_window_features(hipStream_t s, int grid_large, const ContigView& cv,
     else if (ch) FTK_FEAT(1, false);
     else if (df) FTK_FEAT(0, true);
 #undef FTK_FEAT
+    return merged;
 }
 
 void gap_constants(const ftk_gaps& g, int out[4]) {

@@ -302,6 +302,31 @@ class Engine:
             out["short"], out["long"] = sh, lg
         return out
 
+    def window_features_wps(self, name: str, starts, stops, wps_out, wps_start: int, wps_stop: int, chrom_size: int,
+                            quality_threshold=30, min_length=None, max_length=None, intersect_policy="midpoint",
+                            coverage=None, hist=None, hist_bins=None, overflow=None, delfi_q=30, bl_start=None,
+                            bl_end=None, gaps=None, short=None, long=None, window_size=120, wps_min_length=120,
+                            wps_max_length=180, wps_quality=30):
+        """``window_features`` followed by ``wps`` of the same contig as ONE launch when the request allows it
+        (``ftk_window_features_wps``: feature blocks first, WPS tiles behind them); every output is a device
+        pointer / tensor or a host numpy array the caller allocated, ``wps_out`` must live on the device for the
+        merged launch (a host array runs the two launches)."""
+        ws, we = _win(starts, L.OPEN_LO), _win(stops, L.OPEN_HI)
+        f = self._filter(name, quality_threshold, min_length, max_length, intersect_policy)
+        len_lo, n_bins = hist_bins if hist_bins is not None else (0, 0)
+        bs = be = None
+        n_bl = 0
+        if bl_start is not None and len(bl_start):
+            bs = np.ascontiguousarray(bl_start, dtype=np.int32)
+            be = np.ascontiguousarray(bl_end, dtype=np.int32)
+            n_bl = len(bs)
+        g = L.make_gaps(gaps)
+        self._check(self.lib.ftk_window_features_wps(
+            self.ctx, self.contig_id(name), L.ptr(ws), L.ptr(we), len(ws), C.byref(f), L.ptr(coverage), int(len_lo),
+            int(n_bins), L.ptr(hist), L.ptr(overflow), int(delfi_q), L.ptr(bs), L.ptr(be), n_bl, C.byref(g), L.ptr(short),
+            L.ptr(long), int(wps_start), int(wps_stop), int(chrom_size), int(window_size), int(wps_min_length),
+            int(wps_max_length), int(wps_quality), L.ptr(wps_out)))
+
     def feature_batch(self, items, quality_threshold=30, min_length=None, max_length=None,
                       intersect_policy="midpoint"):
         """Prepare a multi-contig window-feature batch (``ftk_window_features_batch``): ``items`` is a list of
@@ -528,11 +553,28 @@ class Engine:
             return refs[key]
         while len(refs) >= 2:  # images are up to ~250 MB each
             old_key = next(iter(refs))
+            self.__dict__.setdefault("_ref_layouts", set()).discard(refs[old_key])
             self._check(self.lib.ftk_ref_release(self.ctx, refs.pop(old_key)))
         rid = self.__dict__.setdefault("_next_ref", 0)
         self._next_ref = rid + 1
         image = np.ascontiguousarray(image, dtype=np.uint8)
         self._check(self.lib.ftk_ref_upload(self.ctx, rid, L.ptr(image), len(image), int(kind)))
+        refs[key] = rid
+        return rid
+
+    def ref_upload_file(self, key, path: str, offset: int, n_bytes: int, kind: int) -> int:
+        """``ref_upload`` of ``n_bytes`` at ``offset`` of a file, read by the library (several read threads,
+        page-locked chunks, asynchronous copies); cached by ``key`` like ``ref_upload``."""
+        refs = self.__dict__.setdefault("_refs", {})
+        if key in refs:
+            return refs[key]
+        while len(refs) >= 2:
+            old_key = next(iter(refs))
+            self.__dict__.setdefault("_ref_layouts", set()).discard(refs[old_key])
+            self._check(self.lib.ftk_ref_release(self.ctx, refs.pop(old_key)))
+        rid = self.__dict__.setdefault("_next_ref", 0)
+        self._next_ref = rid + 1
+        self._check(self.lib.ftk_ref_upload_file(self.ctx, rid, str(path).encode(), int(offset), int(n_bytes), int(kind)))
         refs[key] = rid
         return rid
 

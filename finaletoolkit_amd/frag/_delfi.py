@@ -268,19 +268,28 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
         # contigs are counted as they become resident: a file without a usable index is decoded in ONE streaming
         # pass (decode of contig k+1 beside the kernels / the reference upload of contig k); an indexed file is
         # read contig by contig through the index, so a rank touches only its own blocks
-        tw = time.perf_counter()
-        for src, contig in resident_contigs(input_file, mine, workers, stream_all=world == 1):
-            clock["decode_wait"] += time.perf_counter() - tw
-            starts, stops, arms, live, ok = plan[contig]
-            local[contig] = _contig_counts(src, eng, ref, contig, starts, stops, live, ok,
-                                           contig_gaps.get(contig) if gaps is not None else None, blacklist,
-                                           quality_threshold, clock)
+        err = None
+        try:
             tw = time.perf_counter()
-        clock["decode_wait"] += time.perf_counter() - tw
-        for contig in mine:  # a planned contig the file does not hold: pysam raises for the unknown region
-            if contig not in local and plan[contig][3].any():
-                raise ValueError(f"could not create iterator for region '{contig}': contig not present in {input_file}")
-            local.setdefault(contig, np.zeros((0, 4), np.int64))
+            for src, contig in resident_contigs(input_file, mine, workers, stream_all=world == 1):
+                clock["decode_wait"] += time.perf_counter() - tw
+                starts, stops, arms, live, ok = plan[contig]
+                local[contig] = _contig_counts(src, eng, ref, contig, starts, stops, live, ok,
+                                               contig_gaps.get(contig) if gaps is not None else None, blacklist,
+                                               quality_threshold, clock)
+                tw = time.perf_counter()
+            clock["decode_wait"] += time.perf_counter() - tw
+            for contig in mine:  # a planned contig the file does not hold: pysam raises for the unknown region
+                if contig not in local and plan[contig][3].any():
+                    raise ValueError(f"could not create iterator for region '{contig}': contig not present in "
+                                     f"{input_file}")
+                local.setdefault(contig, np.zeros((0, 4), np.int64))
+        except Exception as e:  # noqa: BLE001 - with several ranks every rank must learn of it (sharding.agree)
+            err = e
+        if world > 1:
+            sharding.agree(err)
+        elif err is not None:
+            raise err
     tg = time.perf_counter()
     n_live = {c: int(plan[c][3].sum()) for c in names}
     counts = sharding.gather_bin_vectors(local, names, n_live, weights, k=4)

@@ -137,7 +137,7 @@ class ReferenceGenome:
         Same numbers as ``gc_count`` (which stays as the host-side definition used by the tests)."""
         starts = np.asarray(starts, dtype=np.int64)
         stops = np.asarray(stops, dtype=np.int64)
-        rid = self.device_image(engine, contig)
+        rid = self.device_image(engine, contig, with_layout=False)
         if self.is_2bit:
             size, n_starts, n_sizes, dna_off = self._records[contig]
             counts = engine.ref_gc_counts(rid, starts, stops)
@@ -156,30 +156,40 @@ class ReferenceGenome:
         hi = (stops // linebases) * linewidth + stops % linebases
         return engine.ref_gc_counts(rid, lo, hi)
 
-    def device_image(self, engine, contig: str) -> int:
-        """Upload ``contig``'s sequence image once (cached on the engine) together with its geometry --
-        the packed DNA + N blocks of a 2bit record, or the raw FASTA text + line layout -- and return
-        the reference id the device calls take."""
+    def device_image(self, engine, contig: str, with_layout: bool = True) -> int:
+        """Upload ``contig``'s sequence image once (cached on the engine) -- the packed DNA of a 2bit record or the
+        raw FASTA text, read from the file by the library (``ftk_ref_upload_file``) -- and return the reference id
+        the device calls take.  ``with_layout`` also hands over its geometry (N blocks / FASTA line layout), which
+        the motif kernels need and the GC count does not."""
         key = (self.path, contig)
-        cached = engine.__dict__.get("_refs", {}).get(key)
-        if cached is not None:
-            return cached
+        rid = engine.__dict__.get("_refs", {}).get(key)
+        done = engine.__dict__.setdefault("_ref_layouts", set())
+        if rid is not None and (not with_layout or rid in done):
+            return rid
         if self.is_2bit:
             size, n_starts, n_sizes, dna_off = self._records[contig]
-            self._fh.seek(dna_off)
-            rid = engine.ref_upload(key, np.frombuffer(self._fh.read((size + 3) // 4), dtype=np.uint8), 1)
-            order = np.argsort(n_starts, kind="stable")
-            engine.ref_set_layout(rid, size, 0, 0, n_starts[order], (n_starts + n_sizes)[order])
+            if rid is None:
+                rid = engine.ref_upload_file(key, self.path, dna_off, (size + 3) // 4, 1)
+                done.discard(rid)
+            if with_layout:
+                order = np.argsort(n_starts, kind="stable")
+                engine.ref_set_layout(rid, size, 0, 0, n_starts[order], (n_starts + n_sizes)[order])
+                done.add(rid)
             return rid
         length, offset, linebases, linewidth = self._fai[contig]
         if linebases == 0:
-            rid = engine.ref_upload(key, np.zeros(0, np.uint8), 0)
+            if rid is None:
+                rid = engine.ref_upload(key, np.zeros(0, np.uint8), 0)
             engine.ref_set_layout(rid, 0, 1, 1)
+            done.add(rid)
             return rid
         n_text = (length // linebases) * linewidth + length % linebases
-        self._fh.seek(offset)
-        rid = engine.ref_upload(key, np.frombuffer(self._fh.read(n_text), dtype=np.uint8), 0)
-        engine.ref_set_layout(rid, length, linebases, linewidth)
+        if rid is None:
+            rid = engine.ref_upload_file(key, self.path, offset, n_text, 0)
+            done.discard(rid)
+        if with_layout:
+            engine.ref_set_layout(rid, length, linebases, linewidth)
+            done.add(rid)
         return rid
 
     def close(self):

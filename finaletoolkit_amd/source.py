@@ -41,7 +41,8 @@ def get_engine() -> Engine:
 
 def usable_cores() -> int:
     """Host cores this process may really use: scheduler affinity, capped by the cgroup CPU quota (a
-    container can see 256 logical CPUs and own 16)."""
+    container can see 256 logical CPUs and own 16), divided by ``LOCAL_WORLD_SIZE`` when this process is one rank
+    of several on the node; ``FTK_HOST_THREADS`` overrides."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -55,6 +56,16 @@ def usable_cores() -> int:
                 n = min(n, max(1, int(quota / period + 0.5)))
         except (OSError, ValueError):
             pass
+    # one rank per GPU on one node: a rank's share of the host cores (the native side applies the same rule,
+    # ftk_host::default_threads)
+    try:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    except ValueError:
+        local_world = 1
+    if local_world > 1:
+        n = max(1, n // local_world)
+    if os.environ.get("FTK_HOST_THREADS", "").isdigit() and int(os.environ["FTK_HOST_THREADS"]) > 0:
+        n = int(os.environ["FTK_HOST_THREADS"])
     return max(1, n)
 
 

@@ -321,6 +321,19 @@ int ftk_wps_async(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int6
                   int32_t min_len, int32_t max_len, int32_t mapq_min, int64_t* wps_out_host, int* token_out);
 int ftk_result_wait(ftk_ctx* ctx, int token);
 
+/* ftk_window_features (all arguments as there) FOLLOWED BY ftk_wps (all arguments as there) on the same contig, as
+ * ONE launch when the feature request takes the FAST block path (tabix fetch, midpoint policy, no length bounds on
+ * the coverage filter, one mapq cut, a bin tiling) and wps_out is a device pointer: the grid holds the feature
+ * blocks first and the WPS tiles behind them, so the feature pass's tail and the WPS ramp overlap and WPS finds the
+ * contig's columns in the Infinity Cache.  Any other request runs as the two launches.  Results are those of the
+ * two calls (reference: frag/_coverage.py:117-130, _frag_length.py:147-153, _delfi.py:443-472, _wps.py:156-188). */
+int ftk_window_features_wps(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                            const ftk_filter* f, int64_t* count_out, int32_t len_lo, int32_t n_bins, uint32_t* hist_out,
+                            int64_t* overflow_out, int32_t delfi_mapq_min, const int32_t* bl_start, const int32_t* bl_end,
+                            int64_t n_bl, const ftk_gaps* gaps, int64_t* short_out, int64_t* long_out, int64_t start,
+                            int64_t stop, int64_t chrom_size, int32_t window_size, int32_t min_len, int32_t max_len,
+                            int32_t mapq_min, int64_t* wps_out);
+
 /* WPS of a whole contig AND the window features of a regular bin tiling in ONE pass over the fragments
  * (BASELINE config 5: coverage + WPS + length histogram + DELFI fused): bin k = [win_start + k * win_len,
  * win_start + (k + 1) * win_len), k < n_win, midpoint policy, tabix fetch semantics.  The block that scores
@@ -387,6 +400,10 @@ int ftk_wps_adjust(ftk_ctx* ctx, const double* scores, const int64_t* offsets, i
 #define FTK_REF_FASTA_TEXT 0
 #define FTK_REF_2BIT 1
 int ftk_ref_upload(ftk_ctx* ctx, int ref_id, const uint8_t* image, int64_t n_bytes, int kind);
+/* The same image read straight from a file: n_bytes at file_offset of `path` (the packed DNA of a 2bit record, the
+ * text of a FASTA record), through page-locked chunks on several read threads, copies asynchronous on the ctx
+ * stream.  Device blocks of released images are recycled (no device-wide synchronisation per contig). */
+int ftk_ref_upload_file(ftk_ctx* ctx, int ref_id, const char* path, int64_t file_offset, int64_t n_bytes, int kind);
 int ftk_ref_release(ftk_ctx* ctx, int ref_id);
 int ftk_ref_gc_counts(ftk_ctx* ctx, int ref_id, const int64_t* range_lo, const int64_t* range_hi, int64_t n,
                       int64_t* gc_out);

@@ -688,3 +688,61 @@ def test_fused_wps_and_window_features_equal_separate_calls(engine, data, win_le
     from finaletoolkit_amd import _lib as L
     with pytest.raises(L.FtkError):  # bins shorter than tile + longest fragment
         engine.wps_window_features("synA", CONTIG_LEN, 0, 4_000, 10, coverage=np.zeros(10, np.int64))
+
+
+@pytest.mark.parametrize("win_len", [100_000, 37_777])
+def test_features_and_wps_in_one_launch_equal_the_two_calls(engine, data, win_len):
+    """ftk_window_features_wps: the merged launch (feature blocks first, WPS tiles behind them in the same grid)
+    gives exactly the results of ftk_window_features followed by ftk_wps -- coverage + histogram + DELFI with
+    blacklist and gaps, coverage alone, DELFI alone; a request the FAST block path does not serve (length bounds
+    on the coverage filter, `any` policy) and a host WPS array fall back to the two launches with the same results;
+    an interval that is a sub-range of the contig; odd W."""
+    import torch
+    rng = np.random.default_rng(win_len)
+    ws, we = synth.tiling_windows(CONTIG_LEN, win_len)
+    n_win = len(ws)
+    bl_s = np.sort(rng.integers(0, CONTIG_LEN - 5000, 150)).astype(np.int32)
+    bl_e = (bl_s + rng.integers(100, 4000, 150)).astype(np.int32)
+    gaps = (1_200_000, 1_500_000, [(0, 10_000), (CONTIG_LEN - 10_000, CONTIG_LEN)])
+    dev = torch.device("cuda", 0)
+
+    def outs():
+        return dict(coverage=torch.full((n_win,), -7, dtype=torch.int64, device=dev),
+                    hist=torch.full((n_win, 640), 9, dtype=torch.int32, device=dev),
+                    overflow=torch.full((n_win,), -7, dtype=torch.int64, device=dev),
+                    short=torch.full((n_win,), -7, dtype=torch.int64, device=dev),
+                    long=torch.full((n_win,), -7, dtype=torch.int64, device=dev))
+
+    for kw, a, b, W in ((dict(quality_threshold=30), 0, CONTIG_LEN, 120),
+                        (dict(quality_threshold=30), 123_457, 2_000_001, 121),
+                        (dict(quality_threshold=25, min_length=50, max_length=700), 0, CONTIG_LEN, 120),  # general kernels
+                        (dict(quality_threshold=30, intersect_policy="any"), 5_000, 900_000, 60)):
+        want = engine.window_features("synA", ws, we, hist=(20, 640),
+                                      delfi=dict(quality_threshold=30, bl_start=bl_s, bl_end=bl_e, gaps=gaps), **kw)
+        want_wps = engine.wps("synA", a, b, CONTIG_LEN, W, 100, 200, 20)
+        o = outs()
+        w = torch.full((b - a,), -99, dtype=torch.int64, device=dev)
+        engine.window_features_wps("synA", ws, we, w, a, b, CONTIG_LEN, coverage=o["coverage"], hist=o["hist"],
+                                   hist_bins=(20, 640), overflow=o["overflow"], delfi_q=30, bl_start=bl_s, bl_end=bl_e,
+                                   gaps=gaps, short=o["short"], long=o["long"], window_size=W, wps_min_length=100,
+                                   wps_max_length=200, wps_quality=20, **kw)
+        torch.cuda.synchronize()
+        assert np.array_equal(w.cpu().numpy(), want_wps), kw
+        for key in ("coverage", "overflow", "short", "long"):
+            assert np.array_equal(o[key].cpu().numpy(), want[key]), (key, kw)
+        assert np.array_equal(o["hist"].cpu().numpy().astype(np.uint32), want["hist"]), kw
+    # one feature at a time, and a host WPS array (two launches)
+    o = outs()
+    w = torch.empty(CONTIG_LEN, dtype=torch.int64, device=dev)
+    engine.window_features_wps("synA", ws, we, w, 0, CONTIG_LEN, CONTIG_LEN, coverage=o["coverage"])
+    assert np.array_equal(o["coverage"].cpu().numpy(), engine.window_counts("synA", ws, we, 30))
+    engine.window_features_wps("synA", ws, we, w, 0, CONTIG_LEN, CONTIG_LEN, delfi_q=30, bl_start=bl_s, bl_end=bl_e, gaps=gaps,
+                               short=o["short"], long=o["long"])
+    sh, lg, _ = engine.delfi_counts("synA", ws, we, 30, bl_s, bl_e, gaps)
+    assert np.array_equal(o["short"].cpu().numpy(), sh) and np.array_equal(o["long"].cpu().numpy(), lg)
+    assert np.array_equal(w.cpu().numpy(), engine.wps("synA", 0, CONTIG_LEN, CONTIG_LEN))
+    host = np.zeros(CONTIG_LEN, np.int64)
+    cov = np.zeros(n_win, np.int64)
+    engine.window_features_wps("synA", ws, we, host, 0, CONTIG_LEN, CONTIG_LEN, coverage=cov)
+    assert np.array_equal(host, engine.wps("synA", 0, CONTIG_LEN, CONTIG_LEN))
+    assert np.array_equal(cov, engine.window_counts("synA", ws, we, 30))

@@ -265,9 +265,14 @@ def test_bench_two_ranks_share_the_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(FTK_BENCH_SHARE_GPU="1")
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--contigs",
-                        "20,21,22", "--no-cpu-baseline", "--no-end-to-end"], cwd=ROOT, env=env, capture_output=True, text=True,
-                       timeout=900)
+                        "20,21,22", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["checks"] and all(line["checks"].values()), line["checks"]
     assert "gloo" in line["exchange"] and "2 ranks" in line["exchange"]
+    # the N-rank file leg: ONE indexed file -> frag.delfi on both ranks (each decodes its own contigs), same frame
+    leg = line["end_to_end"]["genome_frag_delfi_api_ranks"]
+    assert leg["ranks"] == 2 and leg["results_ok"] and leg["merged_rows"] > 10, line["end_to_end"]
+    assert sorted(r["contigs_decoded"] for r in leg["per_rank"]) == [1, 2]
+    assert all(r["decoder_threads"] >= 1 and r["stages_s"]["total"] > 0 for r in leg["per_rank"])
