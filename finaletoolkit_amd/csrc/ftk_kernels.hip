@@ -1007,7 +1007,11 @@ constexpr int kWpsPrefetch = 4;  // fragments per thread held in registers for t
 // the longest fragment), counted in LDS / registers for the first and with global atomics for the second.
 // The block's work as a device function (block `block_id` of `n_blocks`), so that a launch may put other blocks
 // in front of the WPS tiles (feat_then_wps_kernel below).
-template <bool MULTI, bool BATCH, bool FUSED>
+// NT: the scores leave with non-temporal 16-byte stores.  A compile-time switch on purpose: as a run-time
+// `if (p.nt_store) nt-store else store` the two branches differ only in the !nontemporal metadata, and the optimiser
+// may sink them into ONE plain store (it did once this body became a device function: WPS 175 -> 197 us per launch,
+// the feature pass behind it 37 -> 53 us).
+template <bool MULTI, bool BATCH, bool FUSED, bool NT>
 __device__ __forceinline__ void wps_block(const unsigned block_id, const unsigned n_blocks, ContigView cv, WpsParams p,
                                           const int64_t* iv_start_, const int64_t* iv_stop_, const int64_t* out_off_,
                                           const int32_t* tile_iv, const int32_t* tile_k, long long n_tiles,
@@ -1286,7 +1290,7 @@ __device__ __forceinline__ void wps_block(const unsigned block_id, const unsigne
                     if (vec_ok) {
                         typedef long long ll2 __attribute__((ext_vector_type(2)));
                         ll2 v2 = {o0, o1};
-                        if (p.nt_store) __builtin_nontemporal_store(v2, reinterpret_cast<ll2*>(dst + i0));
+                        if (NT) __builtin_nontemporal_store(v2, reinterpret_cast<ll2*>(dst + i0));
                         else *reinterpret_cast<ll2*>(dst + i0) = v2;
                     } else {
                         dst[i0] = o0;
@@ -1305,7 +1309,7 @@ __device__ __forceinline__ void wps_block(const unsigned block_id, const unsigne
     }
 }
 
-template <bool MULTI, bool BATCH, bool FUSED>
+template <bool MULTI, bool BATCH, bool FUSED, bool NT>
 __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParams p, const int64_t* iv_start_,
                                                          const int64_t* iv_stop_, const int64_t* out_off_,
                                                          const int32_t* tile_iv, const int32_t* tile_k,
@@ -1313,7 +1317,7 @@ __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParam
                                                          int64_t* __restrict__ out,
                                                          const WpsItem* __restrict__ items, int n_items,
                                                          FusedParams F) {
-    wps_block<MULTI, BATCH, FUSED>(blockIdx.x, gridDim.x, cv, p, iv_start_, iv_stop_, out_off_, tile_iv, tile_k, n_tiles,
+    wps_block<MULTI, BATCH, FUSED, NT>(blockIdx.x, gridDim.x, cv, p, iv_start_, iv_stop_, out_off_, tile_iv, tile_k, n_tiles,
                                    tiles_per_block, out, items, n_items, F);
 }
 
@@ -1323,8 +1327,8 @@ __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParam
 // retire (the feature pass's tail and the WPS ramp overlap instead of adding up), and WPS finds the contig's
 // columns in the Infinity Cache behind the feature blocks that just read them.  The two kinds of block share
 // nothing: results are those of the two separate launches.
-template <bool CHK, bool HIST, bool DF>
-__global__ __launch_bounds__(256) void feat_then_wps_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
+template <bool CHK, bool HIST, bool DF, bool NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void feat_then_wps_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
                                                             int n_win, int lmax, FeatParams P, WpsParams p,
                                                             long long n_tiles, int64_t* __restrict__ out) {
     if (blockIdx.x < (unsigned)n_win) {
@@ -1336,7 +1340,7 @@ __global__ __launch_bounds__(256) void feat_then_wps_kernel(ContigView cv, const
         feat_fast_body<256, CHK, HIST, DF>(cv, ws_[w], we_[w], lmax, P, o0, o1, (size_t)w, lds_hist, red);
         return;
     }
-    wps_block<false, false, false>(blockIdx.x - (unsigned)n_win, gridDim.x - (unsigned)n_win, cv, p, nullptr, nullptr,
+    wps_block<false, false, false, NT>(blockIdx.x - (unsigned)n_win, gridDim.x - (unsigned)n_win, cv, p, nullptr, nullptr,
                                    nullptr, nullptr, nullptr, n_tiles, 1, out, nullptr, 0, FusedParams{});
 }
 
@@ -1629,12 +1633,12 @@ static bool launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, c
         FeatParams Pf = P;
         if (!CH) Pf.ch_q = P.df_q;
         const dim3 grid((unsigned)((long long)n_win + tail->n_tiles));
-        if (CH && P.do_hist)
-            hipLaunchKernelGGL((feat_then_wps_kernel<CH != 0, true, DF>), grid, dim3(256), lds1, s, cv, ws, we, n_win,
-                               block_lmax, Pf, tail->p, (long long)tail->n_tiles, tail->out);
-        else
-            hipLaunchKernelGGL((feat_then_wps_kernel<CH != 0, false, DF>), grid, dim3(256), lds1, s, cv, ws, we, n_win,
-                               block_lmax, Pf, tail->p, (long long)tail->n_tiles, tail->out);
+#define FTK_MERGED(HIST, NT)                                                                                         \
+    hipLaunchKernelGGL((feat_then_wps_kernel<CH != 0, HIST, DF, NT>), grid, dim3(256), lds1, s, cv, ws, we, n_win,   \
+                       block_lmax, Pf, tail->p, (long long)tail->n_tiles, tail->out)
+        if (CH && P.do_hist) { if (tail->p.nt_store) FTK_MERGED(true, true); else FTK_MERGED(true, false); }
+        else { if (tail->p.nt_store) FTK_MERGED(false, true); else FTK_MERGED(false, false); }
+#undef FTK_MERGED
         return true;
     }
     if (block_lmax >= 0 && CH != 2 && !BAM && feat_fast_ok(P, CH != 0, DF)) {
@@ -1800,12 +1804,13 @@ void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t
     static const long long tpb_env = getenv("FTK_WPS_TPB") ? atoll(getenv("FTK_WPS_TPB")) : 0;
     const long long tpb = tpb_env > 0 ? tpb_env : 1;
     const long long grid = (n_tiles + tpb - 1) / tpb;
-    if (tpb == 1)
-        hipLaunchKernelGGL((wps_stream_kernel<false, false, false>), dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop,
-                           out_off, tile_iv, tile_k, (long long)n_tiles, (int)tpb, out, (const WpsItem*)nullptr, 0, FusedParams{});
-    else
-        hipLaunchKernelGGL((wps_stream_kernel<true, false, false>), dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, iv_stop,
-                           out_off, tile_iv, tile_k, (long long)n_tiles, (int)tpb, out, (const WpsItem*)nullptr, 0, FusedParams{});
+#define FTK_WPS(MULTI, NT)                                                                                              \
+    hipLaunchKernelGGL((wps_stream_kernel<MULTI, false, false, NT>), dim3((unsigned)grid), dim3(256), 0, s, cv, p, iv_start, \
+                       iv_stop, out_off, tile_iv, tile_k, (long long)n_tiles, (int)tpb, out, (const WpsItem*)nullptr, 0,    \
+                       FusedParams{})
+    if (tpb == 1) { if (p.nt_store) FTK_WPS(false, true); else FTK_WPS(false, false); }
+    else { if (p.nt_store) FTK_WPS(true, true); else FTK_WPS(true, false); }
+#undef FTK_WPS
 }
 
 // Whole-interval WPS with the window features of a regular bin tiling in the same pass.
@@ -1813,10 +1818,13 @@ void launch_wps_fused(hipStream_t s, const ContigView& cv, const WpsParams& p, i
                       int64_t* out) {
     if (n_tiles <= 0) return;
     const size_t lds = F.do_hist ? (size_t)(F.n_bins + 1) * 4 : 0;
-    hipLaunchKernelGGL((wps_stream_kernel<false, false, true>), dim3((unsigned)n_tiles), dim3(256), lds, s, cv, p,
-                       (const int64_t*)nullptr, (const int64_t*)nullptr, (const int64_t*)nullptr,
-                       (const int32_t*)nullptr, (const int32_t*)nullptr, (long long)n_tiles, 1, out,
-                       (const WpsItem*)nullptr, 0, F);
+#define FTK_WPSF(NT)                                                                                               \
+    hipLaunchKernelGGL((wps_stream_kernel<false, false, true, NT>), dim3((unsigned)n_tiles), dim3(256), lds, s, cv, p, \
+                       (const int64_t*)nullptr, (const int64_t*)nullptr, (const int64_t*)nullptr,                      \
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, (long long)n_tiles, 1, out,                   \
+                       (const WpsItem*)nullptr, 0, F)
+    if (p.nt_store) FTK_WPSF(true); else FTK_WPSF(false);
+#undef FTK_WPSF
 }
 
 // Several (contig, interval) items in one launch, one 4096-base tile per block.
@@ -1824,9 +1832,13 @@ void launch_wps_batch(hipStream_t s, const WpsParams& p, const WpsItem* d_items,
                       int64_t* out) {
     if (n_tiles <= 0) return;
     ContigView none{};
-    hipLaunchKernelGGL((wps_stream_kernel<false, true, false>), dim3((unsigned)n_tiles), dim3(256), 0, s, none, p,
-                       (const int64_t*)nullptr, (const int64_t*)nullptr, (const int64_t*)nullptr,
-                       (const int32_t*)nullptr, (const int32_t*)nullptr, (long long)n_tiles, 1, out, d_items, n_items, FusedParams{});
+#define FTK_WPSB(NT)                                                                                                \
+    hipLaunchKernelGGL((wps_stream_kernel<false, true, false, NT>), dim3((unsigned)n_tiles), dim3(256), 0, s, none, p,  \
+                       (const int64_t*)nullptr, (const int64_t*)nullptr, (const int64_t*)nullptr,                       \
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, (long long)n_tiles, 1, out, d_items, n_items,  \
+                       FusedParams{})
+    if (p.nt_store) FTK_WPSB(true); else FTK_WPSB(false);
+#undef FTK_WPSB
 }
 
 void launch_cleavage(hipStream_t s, const ContigView& cv, const CleaveParams& p, int64_t n_tiles,
