@@ -157,3 +157,38 @@ def test_one_hip_runtime_in_the_process():
             "print('ok')\n") % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+def test_wps_kernels_keep_their_non_temporal_stores(tmp_path):
+    """ISA contract of the built code object (no GPU needed): the NT variants of the WPS kernels write their scores
+    with `global_store_dwordx4 ... nt`, the plain variants do not.  As a run-time branch the two stores differed only
+    in metadata and the optimiser folded them into one plain store when the kernel body became a device function
+    (round 3: WPS 175 -> 197 us per launch, the feature pass behind it 37 -> 53 us) -- nothing but the disassembly shows that."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    so = tmp_path / "libftk_hip.so"
+    shutil.copy(L.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", str(so)], capture_output=True, check=True)
+    text = ""
+    for f in sorted(tmp_path.iterdir()):
+        if "gfx950" in f.name:
+            text += subprocess.run([objdump, "-d", str(f)], capture_output=True, text=True, check=True).stdout
+    bodies = {}
+    for m in re.finditer(r"^[0-9a-f]+ <(_ZN3ftk(?:17wps_stream_kernel|20feat_then_wps_kernel)[^>]*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", text, re.S | re.M):
+        bodies[m.group(1)] = m.group(2)
+    assert len(bodies) >= 10, sorted(bodies)
+    seen_nt = seen_plain = 0
+    for name, body in bodies.items():
+        flags = re.search(r"kernelI((?:Lb[01]E)+)", name).group(1)
+        nt_variant = flags.endswith("Lb1E")  # the last template parameter
+        n_nt = len(re.findall(r"global_store_dwordx4 .*\bnt\b", body))
+        if nt_variant:
+            assert n_nt >= 4, (name, n_nt)
+            seen_nt += 1
+        else:
+            assert n_nt == 0, (name, n_nt)
+            seen_plain += 1
+    assert seen_nt >= 5 and seen_plain >= 5
