@@ -442,7 +442,13 @@ int ftk_frags_from_table(ftk_ctx* ctx, int contig_id, const ftk_fragtable* t, in
         // columns parsed on the GPU (ftk_fragstream_open_device): ordered behind the parse stream's last write
         HIPCHK(ctx, hipSetDevice(ctx->device));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)ftk_fragtable_ready_event(t, i), 0));
-        return upload_common(ctx, contig_id, s0, e0, q0, st0, n, hipMemcpyDeviceToDevice);
+        int rc = upload_common(ctx, contig_id, s0, e0, q0, st0, n, hipMemcpyDeviceToDevice);
+        if (rc) return rc;
+        // BAM records parsed on the device (run_bam_device): the read1 span and the file-order rank are device columns too
+        if (r1s && r1e) rc = ftk_frags_set_read1(ctx, contig_id, r1s, r1e, n);
+        const int32_t* dord = nullptr;
+        if (rc == FTK_OK && r1s && ftk_fragtable_order(t, i, &dord) == FTK_OK && dord) rc = ftk_frags_set_order(ctx, contig_id, dord, n);
+        return rc;
     }
     int rc = upload_common(ctx, contig_id, s0, e0, q0, st0, n, hipMemcpyHostToDevice);
     if (rc) return rc;

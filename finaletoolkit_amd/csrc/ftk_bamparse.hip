@@ -12,7 +12,10 @@
 // the host walks that piece instead.
 #include <hip/hip_runtime.h>
 
-#include <rocprim/rocprim.hpp>
+#include <algorithm>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "ftk_bamparse.h"
 

@@ -36,6 +36,7 @@
 #include "ftk.h"
 #include "ftk_host.h"
 #include "ftk_inflate.h"
+#include "ftk_bamparse.h"
 #include "ftk_textparse.h"
 
 namespace {
@@ -302,6 +303,10 @@ struct DevColumns {
     size_t bytes = 0;
     int32_t *start = nullptr, *end = nullptr;
     uint8_t *mapq = nullptr, *strand = nullptr;
+    // BAM contigs (parsed on the device, ftk_bamparse.hip): the read1 span of every fragment and, once the rows
+    // have been sorted by fragment start, their file-order rank
+    bool bam = false;
+    int32_t *r1s = nullptr, *r1e = nullptr, *ord = nullptr;
     size_t rows = 0, cap = 0;
     int device = 0;
     hipEvent_t ready = nullptr;
@@ -318,34 +323,48 @@ struct DevColumns {
         }
         device_cache().give(base, bytes, device);
     }
+    size_t row_bytes() const { return bam ? 22 : 10; }
     // room for `more` rows; existing rows are moved on `s` (which is drained before the old block is given back)
-    bool reserve(size_t more, hipStream_t s) {
+    bool reserve(size_t more, hipStream_t s, bool exact = false) {
         if (rows + more <= cap) return true;
-        // (a multiple of 64 rows: the four arrays then start 256-byte aligned and the capacity computed back
+        // (a multiple of 64 rows: the arrays then start 256-byte aligned and the capacity computed back
         // from the block's size is never below the request)
         // A contig's first block takes four pieces' worth of rows (chr1 at 30x is four pieces): growing a block
         // means draining the parse stream - with the next piece's DMA and kernels already in it - and blocks are
         // recycled, so the generous first size is paid once.
-        const size_t first = rows == 0 ? 4 * more : 0;
-        const size_t want = (std::max<size_t>(std::max(std::max(rows + more, 2 * cap), first), size_t(1) << 20) + 63) / 64 * 64;
+        // (exact: a block that will not grow - the sorted copy of a finished BAM contig)
+        const size_t first = rows == 0 && !exact ? 4 * more : 0;
+        const size_t want = (std::max<size_t>(std::max(std::max(rows + more, exact ? 0 : 2 * cap), first), exact ? 64 : size_t(1) << 20) + 63) / 64 * 64;
         size_t got_bytes = 0;
-        void* nb = device_cache().take(want * 10 + 1024, device, &got_bytes, rows == 0);
+        const size_t rb = row_bytes();
+        void* nb = device_cache().take(want * rb + 1024, device, &got_bytes, rows == 0 && !exact);
         if (!nb) return false;
-        const size_t ncap = (got_bytes - 1024) / 10 / 64 * 64;  // rows the block holds
+        const size_t ncap = (got_bytes - 1024) / rb / 64 * 64;  // rows the block holds
         if (ncap < rows + more) {  // cannot happen; never write past a block
             device_cache().give(nb, got_bytes, device);
             return false;
         }
         int32_t* ns = (int32_t*)nb;
         int32_t* ne = ns + ncap;
-        uint8_t* nq = (uint8_t*)(ne + ncap);
+        int32_t *n1s = nullptr, *n1e = nullptr, *nord = nullptr;
+        int32_t* tail = ne + ncap;
+        if (bam) {
+            n1s = tail;
+            n1e = n1s + ncap;
+            nord = n1e + ncap;
+            tail = nord + ncap;
+        }
+        uint8_t* nq = (uint8_t*)tail;
         uint8_t* nt = nq + ncap;
         if (rows) {
-            const bool ok = hipMemcpyAsync(ns, start, rows * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-                            hipMemcpyAsync(ne, end, rows * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-                            hipMemcpyAsync(nq, mapq, rows, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-                            hipMemcpyAsync(nt, strand, rows, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-                            hipStreamSynchronize(s) == hipSuccess;
+            bool ok = hipMemcpyAsync(ns, start, rows * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                      hipMemcpyAsync(ne, end, rows * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                      hipMemcpyAsync(nq, mapq, rows, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                      hipMemcpyAsync(nt, strand, rows, hipMemcpyDeviceToDevice, s) == hipSuccess;
+            if (ok && bam)
+                ok = hipMemcpyAsync(n1s, r1s, rows * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+                     hipMemcpyAsync(n1e, r1e, rows * 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
+            ok = ok && hipStreamSynchronize(s) == hipSuccess;
             if (!ok) {
                 (void)hipGetLastError();
                 device_cache().give(nb, got_bytes, device);
@@ -355,18 +374,22 @@ struct DevColumns {
         device_cache().give(base, bytes, device);
         base = nb; bytes = got_bytes;
         start = ns; end = ne; mapq = nq; strand = nt;
+        r1s = n1s; r1e = n1e; ord = nord;
         cap = ncap;
         return true;
     }
     // append n rows from device (kind D2D) or host (H2D; the call returns when the source may be released)
     bool append(const int32_t* s0, const int32_t* e0, const uint8_t* q0, const uint8_t* t0, size_t n, hipMemcpyKind kind,
-                hipStream_t s) {
+                hipStream_t s, const int32_t* a0 = nullptr, const int32_t* b0 = nullptr) {
         if (!n) return true;
         if (!reserve(n, s)) return false;
         bool ok = hipMemcpyAsync(start + rows, s0, n * 4, kind, s) == hipSuccess &&
                   hipMemcpyAsync(end + rows, e0, n * 4, kind, s) == hipSuccess &&
                   hipMemcpyAsync(mapq + rows, q0, n, kind, s) == hipSuccess &&
                   hipMemcpyAsync(strand + rows, t0, n, kind, s) == hipSuccess;
+        if (ok && bam)
+            ok = a0 && b0 && hipMemcpyAsync(r1s + rows, a0, n * 4, kind, s) == hipSuccess &&
+                 hipMemcpyAsync(r1e + rows, b0, n * 4, kind, s) == hipSuccess;
         if (ok && kind == hipMemcpyHostToDevice) ok = hipStreamSynchronize(s) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); return false; }
         rows += n;
@@ -1330,6 +1353,32 @@ void* ftk_fragtable_ready_event(const ftk_fragtable* t, int i) {
     return ftk_fragtable_is_device(t, i) ? (void*)t->contigs[i].dev->ready : nullptr;
 }
 
+int ftk_fragtable_read1_to_host(const ftk_fragtable* t, int i, int32_t* r1_start, int32_t* r1_end, int32_t* order) {
+    if (!t || i < 0 || i >= (int)t->contigs.size()) return dfail(FTK_ERR_NO_CONTIG, "contig index %d out of range", i);
+    const Contig& ct = t->contigs[i];
+    const size_t n = ct.p.rows;
+    if (!ct.p.r1s || !ct.p.r1e) return dfail(FTK_ERR_INVALID, "the table holds no read1 columns (not a BAM table)");
+    if (!ct.dev) {
+        if (r1_start && n) memcpy(r1_start, ct.p.r1s, n * 4);
+        if (r1_end && n) memcpy(r1_end, ct.p.r1e, n * 4);
+        if (order && n) {
+            if (!ct.p.ord) return dfail(FTK_ERR_INVALID, "the table holds no order column");
+            memcpy(order, ct.p.ord, n * 4);
+        }
+        return FTK_OK;
+    }
+    const DevColumns& d = *ct.dev;
+    bool ok = hipSetDevice(d.device) == hipSuccess && hipEventSynchronize(d.ready) == hipSuccess;
+    if (ok && r1_start && n) ok = hipMemcpy(r1_start, d.r1s, n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && r1_end && n) ok = hipMemcpy(r1_end, d.r1e, n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && order && n) ok = d.ord && hipMemcpy(order, d.ord, n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        return dfail(FTK_ERR_HIP, "cannot copy the read1 columns back");
+    }
+    return FTK_OK;
+}
+
 int ftk_fragtable_columns_to_host(const ftk_fragtable* t, int i, int32_t* start, int32_t* end, uint8_t* mapq,
                                   uint8_t* strand) {
     if (!t || i < 0 || i >= (int)t->contigs.size()) return dfail(FTK_ERR_NO_CONTIG, "contig index %d out of range", i);
@@ -1817,6 +1866,13 @@ struct ftk_fragstream {
     void run_guarded();
     bool run_text(RawBuf& first, size_t first_n);
     bool run_bam(RawBuf& first, size_t first_n);
+    // BAM with the records parsed ON THE DEVICE (ftk_bamparse.hip): the inflated bytes stay in HBM, the tables handed
+    // out hold device columns sorted by fragment start.  A piece whose record chain the device cannot settle (or a
+    // header larger than a piece) makes the stream start over on the host path (run_bam), which skips the contigs
+    // already handed out (emitted_refs).
+    bool run_bam_device(RawBuf& first, size_t first_n);
+    bool emit_device_bam(Contig&& ct);
+    std::set<int> emitted_refs;
     // single-contig requests with a usable index: read only the file range holding the contig
     long long read_end = -1;      // file offset to stop reading at (-1: none)
     bool partial_tail_ok = false;  // the range may end inside a block that belongs to the next contig
@@ -2003,13 +2059,28 @@ void ftk_fragstream::run_guarded() {
         }
         ok = true;
     } else {
-        ok = bam ? run_bam(buf, n) : device >= 0 ? run_text_device(buf, n) : run_text(buf, n);
+        static const bool dev_bam_parse = !(getenv("FTK_DEVICE_BAM_PARSE") && atoi(getenv("FTK_DEVICE_BAM_PARSE")) == 0) &&
+                                          !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
+        const bool bam_on_device = bam && inflate_device >= 0 && dev_bam_parse;
+        ok = bam ? (bam_on_device ? run_bam_device(buf, n) : run_bam(buf, n)) : device >= 0 ? run_text_device(buf, n) : run_text(buf, n);
         bool stopped;
         {
             std::lock_guard<std::mutex> lk(mu);
             stopped = stop || err != FTK_OK;
         }
-        if (!ok && want_host_restart && !stopped) {
+        if (!ok && want_host_restart && !stopped && bam) {
+            // (see run_bam_device) the file once more on the host decoder; contigs handed out already are skipped
+            drain_ahead();
+            if (pstream) (void)hipStreamSynchronize(pstream);
+            want_host_restart = false;
+            read_end = -1;
+            partial_tail_ok = false;
+            first_skip = 0;
+            ahead_ok = !has_only;
+            rewind(fp);
+            const size_t n2 = fill(buf, 0);
+            ok = run_bam(buf, n2);
+        } else if (!ok && want_host_restart && !stopped) {
             // (see want_host_restart) the same range of the file once more, inflated by the host threads
             drain_ahead();
             (void)hipStreamSynchronize(pstream);
@@ -2188,6 +2259,40 @@ struct DevSet {
     uint32_t *d_crc = nullptr, *h_crc = nullptr, *want_crc = nullptr;  // want_crc: the blocks' trailers (plain host memory)
     ftk::InflateStatus *d_ist = nullptr, *h_ist = nullptr;
 
+    // BAM pieces parsed on the device (ftk_bamparse.hip): the extra row columns, the stretch scratch, the summary
+    int32_t *d_r1s = nullptr, *d_r1e = nullptr, *d_ref = nullptr;
+    uint32_t* d_stretch = nullptr;
+    size_t stretch_words = 0, bam_rows = 0;
+    ftk::BamSummary *d_bsum = nullptr, *h_bsum = nullptr;
+    void release_bam() {
+        for (void* q : {(void*)d_r1s, (void*)d_r1e, (void*)d_ref, (void*)d_stretch, (void*)d_bsum})
+            if (q) (void)hipFree(q);
+        if (h_bsum) (void)hipHostFree(h_bsum);
+        d_r1s = d_r1e = d_ref = nullptr;
+        d_stretch = nullptr;
+        d_bsum = h_bsum = nullptr;
+        stretch_words = bam_rows = 0;
+    }
+    // call after ensure(): columns for max_lines rows, stretch scratch for `bytes` of records
+    bool ensure_bam(size_t bytes, uint32_t stretch_bytes) {
+        const size_t words = ftk::bam_stretch_words(bytes, stretch_bytes);
+        if (bam_rows >= max_lines && stretch_words >= words && d_bsum) return true;
+        release_bam();
+        const bool ok = hipMalloc((void**)&d_r1s, max_lines * 4) == hipSuccess && hipMalloc((void**)&d_r1e, max_lines * 4) == hipSuccess &&
+                        hipMalloc((void**)&d_ref, max_lines * 4) == hipSuccess &&
+                        hipMalloc((void**)&d_stretch, (words + words / 4) * 4) == hipSuccess &&
+                        hipMalloc((void**)&d_bsum, sizeof(ftk::BamSummary)) == hipSuccess &&
+                        hipHostMalloc((void**)&h_bsum, sizeof(ftk::BamSummary), hipHostMallocDefault) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            release_bam();
+            return false;
+        }
+        bam_rows = max_lines;
+        stretch_words = words + words / 4;
+        return true;
+    }
+
     void release_inflate() {
         for (void* q : {(void*)d_comp, (void*)d_tab, (void*)d_crc, (void*)d_ist})
             if (q) (void)hipFree(q);
@@ -2199,6 +2304,7 @@ struct DevSet {
     }
     void release() {
         release_inflate();
+        release_bam();
         if (h_text) (void)hipHostFree(h_text);
         if (h_sum) (void)hipHostFree(h_sum);
         for (void* q : {(void*)d_text, (void*)d_blocks, (void*)d_lines, (void*)d_s, (void*)d_e, (void*)d_q, (void*)d_t, (void*)d_sum})
@@ -2858,7 +2964,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
     bool dinf = want_dinf && device >= 0;
     hipStream_t streams[kSlots] = {};  // streams[0] is the member pstream (destroyed with the stream object)
     if (dinf) {
-        bool ok = hipSetDevice(device) == hipSuccess && (pstream = stream_pool().take(device)) != nullptr;
+        bool ok = hipSetDevice(device) == hipSuccess && (pstream || (pstream = stream_pool().take(device)) != nullptr);
         streams[0] = pstream;
         for (int k = 1; ok && k < kSlots; ++k) ok = (streams[k] = stream_pool().take(device)) != nullptr;
         if (!ok) {
@@ -3172,6 +3278,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
             clk.lap(5);  // "other" holds the chain check (and any redone range)
             for (auto& st : seg)
                 for (auto& r : st.runs) {
+                    if (emitted_refs.count(r.ref)) continue;  // handed out by the device pass this one replaces
                     if (cur_ref >= 0 && r.ref != cur_ref) {
                         clk.lap(3);
                         if (cur_rows && !emit(std::move(cur))) return false;
@@ -3220,6 +3327,389 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
     clk.lap(4);
     clk.report("bam");
     if (clk.on) fprintf(stderr, "[ftk stream bam] %zu stretches of the record chain, %zu redone after the chain check\n", n_stretches, n_redone);
+    return true;
+}
+
+// Sorted, device-resident BAM contig -> the consumer (the counterpart of emit_device for text contigs).
+bool ftk_fragstream::emit_device_bam(Contig&& ct) {
+    DevColumns& d = *ct.dev;
+    if (hipEventCreateWithFlags(&d.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(d.ready, pstream) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FTK_ERR_HIP, "cannot record the contig's ready event");
+    }
+    std::unique_ptr<ftk_fragtable> t(new ftk_fragtable());
+    t->bam = true;
+    ct.p.rows = d.rows;
+    ct.p.start = d.start;
+    ct.p.end = d.end;
+    ct.p.mapq = d.mapq;
+    ct.p.strand = d.strand;
+    ct.p.r1s = d.r1s;
+    ct.p.r1e = d.r1e;
+    ct.p.ord = d.ord;
+    t->contigs.push_back(std::move(ct));
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return stop || ready.size() < max_queued; });
+    if (stop) return false;
+    ready.push_back(t.release());
+    cv.notify_all();
+    return true;
+}
+
+bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
+    StageClock clk(this);
+    const int device = inflate_device;
+    constexpr size_t kRoom = size_t(32) << 20;
+    constexpr int kAhead = 3, kSlots = kAhead + 1;
+    static const uint32_t stretch_bytes = [] {  // FTK_BAM_DEV_STRETCH: tests walk tiny stretches
+        const char* e = getenv("FTK_BAM_DEV_STRETCH");
+        const long v = e ? atol(e) : 0;
+        return (uint32_t)(v >= 64 ? v : 16384);
+    }();
+    if (hipSetDevice(device) != hipSuccess || (!pstream && (pstream = stream_pool().take(device)) == nullptr)) {
+        (void)hipGetLastError();
+        return fail(FTK_ERR_HIP, "cannot create the parse stream");
+    }
+    hipStream_t streams[kSlots] = {};
+    for (auto& f : streams)
+        if ((f = stream_pool().take(device)) == nullptr) {
+            for (auto& g : streams) stream_pool().give(device, g);
+            return fail(FTK_ERR_HIP, "cannot create the inflate streams");
+        }
+    DevSet sets[kSlots];
+    for (auto& S : sets) S = devset_pool().take(device);
+    uint8_t* d_wanted = nullptr;
+    struct Cleanup {
+        DevSet* s;
+        int device;
+        hipStream_t pst;
+        hipStream_t* streams;
+        uint8_t** wanted;
+        ~Cleanup() {
+            for (int k = 0; k < kSlots; ++k) {
+                (void)hipStreamSynchronize(streams[k]);
+                stream_pool().give(device, streams[k]);
+            }
+            (void)hipStreamSynchronize(pst);
+            for (int k = 0; k < kSlots; ++k) devset_pool().give(device, s[k]);
+            if (*wanted) (void)hipFree(*wanted);
+        }
+    } cleanup{sets, device, pstream, streams, &d_wanted};
+
+    struct Piece {
+        size_t n = 0, used = 0, total = 0;
+        bool eof = false;
+        std::vector<Block> blocks;
+        int slot = -1;
+        uint32_t first_off = 0;
+        bool has_prev = false;
+        int prev_slot = -1;
+    };
+    auto list_blocks = [&](Piece& pc) -> bool {
+        if (!whole_blocks(buf.data(), pc.n, pc.eof, &pc.blocks, &pc.used, &pc.total)) return fail(FTK_ERR_FORMAT, "corrupt BGZF block");
+        return true;
+    };
+    // front of a piece (its slot's own stream): compressed bytes up, inflate, CRC
+    auto submit_front = [&](Piece& pc, int index) -> bool {
+        const int slot = index % kSlots;
+        DevSet& S = sets[slot];
+        hipStream_t st = streams[slot];
+        if (S.pending) return fail(FTK_ERR_HIP, "buffer ring out of step");
+        if (pc.total + kRoom + 64 >= (size_t(1) << 32)) return fail(FTK_ERR_FORMAT, "BGZF piece too large");
+        if (!S.ensure(kRoom + pc.total + 64) || !S.ensure_inflate(pc.used, pc.blocks.size()) || !S.ensure_host_comp(pc.used + 64) ||
+            !S.ensure_bam(kRoom + pc.total + 64, stretch_bytes))
+            return fail(FTK_ERR_OOM, "out of page-locked / device memory for the BAM piece");
+        {
+            const size_t used = pc.used;
+            const int nt = std::max(1, std::min(n_threads, (int)(used >> 20) + 1));
+            const uint8_t* src = buf.data();
+            uint8_t* dst = S.h_comp;
+            parallel_run(nt, [&](int t) {
+                const size_t a = used * (size_t)t / nt, b2 = used * (size_t)(t + 1) / nt;
+                memcpy(dst + a, src + a, b2 - a);
+            });
+        }
+        for (size_t i = 0; i < pc.blocks.size(); ++i) {
+            const Block& bl = pc.blocks[i];
+            S.h_tab[i] = {(uint32_t)bl.in_off, (uint32_t)bl.in_len, (uint32_t)(kRoom + bl.out_off), (uint32_t)bl.out_len};
+            const uint8_t* tr = buf.data() + bl.in_off + bl.in_len;
+            S.want_crc[i] = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+        }
+        S.n_tab = pc.blocks.size();
+        bool ok = (!S.freed_valid || hipStreamWaitEvent(st, S.freed, 0) == hipSuccess) &&
+                  hipMemsetAsync(S.d_ist, 0, sizeof(ftk::InflateStatus), st) == hipSuccess &&
+                  (pc.used == 0 || hipMemcpyAsync(S.d_comp, S.h_comp, pc.used, hipMemcpyHostToDevice, st) == hipSuccess) &&
+                  (pc.blocks.empty() || hipMemcpyAsync(S.d_tab, S.h_tab, pc.blocks.size() * sizeof(ftk::InflateBlock),
+                                                       hipMemcpyHostToDevice, st) == hipSuccess);
+        if (ok) {
+            ftk::inflate_launch(st, S.d_comp, S.d_tab, (int)pc.blocks.size(), S.d_text, S.d_ist, S.d_crc);
+            ok = hipGetLastError() == hipSuccess && hipEventRecord(S.front, st) == hipSuccess;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            return fail(FTK_ERR_HIP, "cannot launch the device inflate");
+        }
+        pc.slot = slot;
+        return true;
+    };
+    // back of a piece (the parse stream, piece after piece): the record chain behind the previous piece's
+    int n_ref = 0;
+    auto submit_back = [&](Piece& pc) -> bool {
+        DevSet& S = sets[pc.slot];
+        DevSet* P = pc.has_prev ? &sets[pc.prev_slot] : nullptr;
+        bool ok = hipMemsetAsync(S.d_bsum, 0, sizeof(ftk::BamSummary), pstream) == hipSuccess &&
+                  hipStreamWaitEvent(pstream, S.front, 0) == hipSuccess;
+        if (ok) {
+            ftk::bamparse_launch(pstream, S.d_text, (uint32_t)kRoom, (uint32_t)pc.total, P ? P->d_text : nullptr, P ? P->d_bsum : nullptr,
+                                 pc.first_off, d_wanted, n_ref, stretch_bytes, S.d_stretch, S.stretch_words, S.max_lines, S.d_s,
+                                 S.d_e, S.d_q, S.d_t, S.d_r1s, S.d_r1e, S.d_ref, S.d_bsum);
+            ok = hipGetLastError() == hipSuccess &&
+                 hipMemcpyAsync(S.h_bsum, S.d_bsum, sizeof(ftk::BamSummary), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
+                 hipMemcpyAsync(S.h_ist, S.d_ist, sizeof(ftk::InflateStatus), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
+                 (pc.blocks.empty() || hipMemcpyAsync(S.h_crc, S.d_crc, pc.blocks.size() * 4, hipMemcpyDeviceToHost, pstream) == hipSuccess) &&
+                 hipEventRecord(S.done, pstream) == hipSuccess;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            return fail(FTK_ERR_HIP, "cannot launch the device record parser");
+        }
+        S.pending = true;
+        return true;
+    };
+
+    // ---- the header: the first piece is inflated on the device, its head copied back until the header is complete
+    Piece curp;
+    curp.n = n_first;
+    curp.eof = n_first < kStreamPiece;
+    int n_submitted = 0;
+    if (!list_blocks(curp) || !submit_front(curp, n_submitted++)) return false;
+    std::vector<int> wanted;
+    {
+        DevSet& S = sets[curp.slot];
+        size_t have = 0, o = 0;
+        bool complete = false;
+        while (!complete) {
+            const size_t want = std::min(curp.total, std::max<size_t>(have * 4, size_t(1) << 20));
+            if (want > have) {
+                if (hipMemcpyAsync(S.h_text + kRoom + have, S.d_text + kRoom + have, want - have, hipMemcpyDeviceToHost, streams[curp.slot]) != hipSuccess ||
+                    hipStreamSynchronize(streams[curp.slot]) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return fail(FTK_ERR_HIP, "cannot copy the BAM header back");
+                }
+                have = want;
+            }
+            if (S.h_ist) {  // (a block that did not inflate would show up as a garbled header)
+                if (hipMemcpy(S.h_ist, S.d_ist, sizeof(ftk::InflateStatus), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); }
+                else if (S.h_ist->n_bad) return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+            }
+            const uint8_t* p = S.h_text + kRoom;
+            const size_t m = have;
+            do {
+                if (m < 12) break;
+                if (memcmp(p, "BAM\1", 4) != 0) return fail(FTK_ERR_FORMAT, (path + " is not a BAM file").c_str());
+                o = 4;
+                const uint32_t l_text = rd_u32(p + o);
+                o += 4 + (size_t)l_text;
+                if (o + 4 > m) break;
+                const uint32_t nr = rd_u32(p + o);
+                o += 4;
+                std::vector<std::string> names;
+                std::vector<int64_t> lens;
+                bool cut = false;
+                for (uint32_t r = 0; r < nr; ++r) {
+                    if (o + 4 > m) { cut = true; break; }
+                    const uint32_t l_name = rd_u32(p + o);
+                    o += 4;
+                    if (l_name == 0) return fail(FTK_ERR_FORMAT, "corrupt BAM reference list");
+                    if (o + l_name + 4 > m) { cut = true; break; }
+                    names.emplace_back((const char*)p + o, l_name - 1);
+                    o += l_name;
+                    lens.push_back(rd_i32(p + o));
+                    o += 4;
+                }
+                if (cut) break;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ref_names = names;
+                    ref_lens = lens;
+                    header_ready = true;
+                    cv.notify_all();
+                }
+                wanted.assign(nr, 0);
+                for (uint32_t r = 0; r < nr; ++r) wanted[r] = !has_only || names[r] == only;
+                complete = true;
+            } while (false);
+            if (!complete && have >= curp.total) {  // a header that does not end inside the first piece: the host path
+                if (curp.eof) return fail(FTK_ERR_FORMAT, "truncated BAM header");
+                want_host_restart = true;
+                return false;
+            }
+        }
+        n_ref = (int)wanted.size();
+        std::vector<uint8_t> w8(std::max<size_t>(wanted.size(), 1), 0);
+        for (size_t r = 0; r < wanted.size(); ++r) w8[r] = (uint8_t)wanted[r];
+        if (hipMalloc((void**)&d_wanted, w8.size()) != hipSuccess ||
+            hipMemcpy(d_wanted, w8.data(), w8.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(FTK_ERR_OOM, "out of device memory");
+        }
+        curp.first_off = (uint32_t)o;
+        ahead_ok = true;
+        if (has_only) {  // BAI: jump to the contig's records instead of walking the whole file
+            int target = -1;
+            for (size_t r = 0; r < ref_names.size(); ++r)
+                if (ref_names[r] == only) target = (int)r;
+            if (target < 0) return true;
+            const IndexSpan sp = index_lookup(index_path_of(path, true), true, std::string(), target);
+            if (sp.usable && !sp.present) return true;
+            if (sp.usable && seek_to(sp)) {
+                if (hipStreamSynchronize(streams[curp.slot]) != hipSuccess) (void)hipGetLastError();
+                curp = Piece{};
+                curp.n = fill(buf, 0);
+                curp.eof = curp.n < kStreamPiece;
+                curp.first_off = (uint32_t)first_skip;
+                first_skip = 0;
+                if (!list_blocks(curp) || !submit_front(curp, n_submitted++)) return false;
+            } else {
+                read_end = -1;
+                partial_tail_ok = false;
+                first_skip = 0;
+            }
+        }
+    }
+    if (!submit_back(curp)) return false;
+
+    // ---- the pieces ---------------------------------------------------------------------------------------------
+    Contig cur;
+    bool have_cur = false;
+    int cur_ref = -1;
+    std::set<int> seen;
+    size_t n_pieces = 0, n_rows_total = 0, n_records = 0;
+    auto finish_contig = [&]() -> bool {  // sort the finished contig's rows by fragment start and hand it out
+        if (!have_cur) return true;
+        clk.lap(3);
+        DevColumns& U = *cur.dev;
+        const size_t n = U.rows;
+        bool ok = true;
+        if (n) {
+            std::shared_ptr<DevColumns> sorted(new DevColumns());
+            sorted->device = device;
+            sorted->bam = true;
+            const size_t tmp_bytes = ftk::bam_sort_tmp_bytes(n);
+            size_t tmp_cap = 0;
+            void* tmp = device_cache().take(tmp_bytes, device, &tmp_cap, false);
+            ok = tmp && sorted->reserve(n, pstream, true) &&
+                 ftk::bam_sort_contig(pstream, n, U.start, U.end, U.mapq, U.strand, U.r1s, U.r1e, sorted->start, sorted->end,
+                                      sorted->mapq, sorted->strand, sorted->r1s, sorted->r1e, sorted->ord, tmp, tmp_bytes) == 0 &&
+                 hipGetLastError() == hipSuccess && hipStreamSynchronize(pstream) == hipSuccess;  // the unsorted block and the scratch go back
+            if (tmp) device_cache().give(tmp, tmp_cap, device);
+            if (!ok) {
+                (void)hipGetLastError();
+                return fail(FTK_ERR_OOM, "cannot sort the contig's rows on the device");
+            }
+            sorted->rows = n;
+            if (hipEventCreateWithFlags(&U.ready, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(U.ready, pstream);
+            cur.dev = sorted;
+            emitted_refs.insert(cur_ref);
+            if (!emit_device_bam(std::move(cur))) return false;
+        }
+        cur = Contig{};
+        have_cur = false;
+        cur_ref = -1;
+        clk.lap(4);
+        return true;
+    };
+    auto take_run = [&](int ref, DevSet& S, size_t r0, size_t r1) -> bool {
+        if (r1 <= r0) return true;
+        if (have_cur && ref != cur_ref && !finish_contig()) return false;
+        if (!have_cur) {
+            if (!seen.insert(ref).second)
+                return fail(FTK_ERR_UNSORTED, ("contig " + ref_names[ref] + " appears in two separate runs: the BAM is not coordinate-sorted").c_str());
+            cur_ref = ref;
+            cur.name = ref_names[ref];
+            cur.length = ref_lens[ref];
+            cur.dev.reset(new DevColumns());
+            cur.dev->device = device;
+            cur.dev->bam = true;
+            have_cur = true;
+        }
+        if (!cur.dev->append(S.d_s + r0, S.d_e + r0, S.d_q + r0, S.d_t + r0, r1 - r0, hipMemcpyDeviceToDevice, pstream, S.d_r1s + r0,
+                             S.d_r1e + r0))
+            return fail(FTK_ERR_OOM, "out of device memory for the contig's columns");
+        return true;
+    };
+    auto settle = [&](Piece& pc) -> bool {
+        DevSet& S = sets[pc.slot];
+        if (hipEventSynchronize(S.done) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(FTK_ERR_HIP, "the device record parser failed");
+        }
+        clk.lap(1);
+        S.pending = false;
+        if (S.h_ist->n_bad) return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+        for (size_t i = 0; i < S.n_tab; ++i)
+            if (S.h_crc[i] != S.want_crc[i]) return fail(FTK_ERR_FORMAT, "BGZF block CRC mismatch (device inflate)");
+        const ftk::BamSummary& B = *S.h_bsum;
+        if (B.carry_overflow || !B.consistent || B.n_runs > (uint32_t)ftk::kBamMaxRuns || B.n_rows > S.max_lines) {
+            want_host_restart = true;  // the host decoder takes the file (contigs handed out so far are skipped)
+            return false;
+        }
+        if (B.bad) return fail(FTK_ERR_FORMAT, "corrupt BAM record");
+        if (pc.eof && B.landing != B.m && !partial_tail_ok) return fail(FTK_ERR_FORMAT, "truncated BAM record");
+        std::vector<std::pair<uint32_t, int>> runs(B.n_runs);
+        for (uint32_t r = 0; r < B.n_runs; ++r) runs[r] = {B.run_row[r], B.run_ref[r]};
+        std::sort(runs.begin(), runs.end());
+        for (size_t r = 0; r < runs.size(); ++r) {
+            const size_t r0 = runs[r].first, r1 = r + 1 < runs.size() ? runs[r + 1].first : (size_t)B.n_rows;
+            if (!take_run(runs[r].second, S, r0, r1)) return false;
+        }
+        ++n_pieces;
+        n_rows_total += B.n_rows;
+        n_records += B.n_records;
+        S.freed_valid = hipEventRecord(S.freed, pstream) == hipSuccess;
+        if (!S.freed_valid) {
+            (void)hipGetLastError();
+            return fail(FTK_ERR_HIP, "cannot record a buffer set's release");
+        }
+        clk.lap(2);
+        return true;
+    };
+
+    std::deque<Piece> ahead;  // pieces behind curp whose fronts and backs are enqueued, in file order
+    for (;;) {
+        // read and enqueue the next pieces before this one is settled
+        while ((int)ahead.size() < kAhead) {
+            const Piece& last = ahead.empty() ? curp : ahead.back();
+            if (last.eof) break;
+            const size_t raw_carry = last.n - last.used;
+            if (raw_carry) memmove(buf.data(), buf.data() + last.used, raw_carry);
+            clk.lap(5);
+            Piece np;
+            np.n = fill(buf, raw_carry);
+            clk.lap(0);
+            np.eof = np.n - raw_carry < kStreamPiece;
+            np.has_prev = true;
+            np.prev_slot = last.slot;
+            if (!list_blocks(np) || !submit_front(np, n_submitted++) || !submit_back(np)) return false;
+            ahead.push_back(std::move(np));
+        }
+        clk.lap(5);
+        if (!settle(curp)) return false;
+        if (curp.eof) break;
+        if (ahead.empty()) return fail(FTK_ERR_HIP, "piece queue out of step");
+        curp = std::move(ahead.front());
+        ahead.pop_front();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (stop) return false;
+        }
+    }
+    if (!finish_contig()) return false;
+    clk.lap(4);
+    clk.report("bam, records parsed on the device (inflate = waiting for a piece, parse = appends, merge = sort)");
+    if (clk.on)
+        fprintf(stderr, "[ftk stream bam] %zu pieces, %zu records, %zu fragments parsed on the device (stretch %u bytes)\n", n_pieces,
+                n_records, n_rows_total, stretch_bytes);
     return true;
 }
 

@@ -163,6 +163,9 @@ int ftk_fragtable_is_device(const ftk_fragtable* t, int i);
 void* ftk_fragtable_ready_event(const ftk_fragtable* t, int i);
 int ftk_fragtable_columns_to_host(const ftk_fragtable* t, int i, int32_t* start, int32_t* end, uint8_t* mapq,
                                   uint8_t* strand);
+/* The read1 span and the file-order rank of a BAM table's rows into host arrays (any may be NULL), wherever the
+ * table's columns live (BAM records parsed on the device hand out device columns: ftk_fragtable_is_device). */
+int ftk_fragtable_read1_to_host(const ftk_fragtable* t, int i, int32_t* r1_start, int32_t* r1_end, int32_t* order);
 int ftk_fragstream_open(const char* path, const char* contig /* NULL = all */, int is_bam, int n_threads,
                         int max_queued, ftk_fragstream** out);
 int ftk_fragstream_next(ftk_fragstream* s, ftk_fragtable** out);

@@ -219,12 +219,14 @@ def test_bam_stream_many_pieces_through_the_slot_ring(tmp_path, piece):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = _BAM_CHILD.format(root=root, size=600_000, bam=str(tmp_path / "ring.bam"))
     outs = []
-    for dinf in ("1", "0"):
+    # records parsed on the device (the default) / inflate on the device, records walked by the host / all on the host
+    for dinf, drec in (("1", "1"), ("1", "0"), ("0", "0")):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, FTK_STREAM_PIECE=str(piece), FTK_BAM_STRETCH="65536", FTK_DEVICE_INFLATE=dinf))
+                           env=dict(os.environ, FTK_STREAM_PIECE=str(piece), FTK_BAM_STRETCH="65536", FTK_DEVICE_INFLATE=dinf,
+                                    FTK_DEVICE_BAM_PARSE=drec, FTK_BAM_DEV_STRETCH="2048"))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
-    assert outs[0] == outs[1] and outs[0].startswith("ok")
+    assert outs[0] == outs[1] == outs[2] and outs[0].startswith("ok")
 
 
 _BAM_MULTI_CHILD = r"""
@@ -236,6 +238,7 @@ from tests.test_stream_decoder import _same
 from tests.test_abi import _decode
 lib = L.load()
 path = sys.argv[1]
+n_device = [0]
 
 
 def stream(contig=None, threads=4):
@@ -251,10 +254,20 @@ def stream(contig=None, threads=4):
             break
         rows = lib.ftk_fragtable_contig_rows(t, 0)
         name = lib.ftk_fragtable_contig_name(t, 0).decode()
-        ps = [C.c_void_p() for _ in range(6)]
-        assert lib.ftk_fragtable_columns(t, 0, *[C.byref(p) for p in ps]) == 0
-        cols = [None if not p.value or rows == 0 else np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), (rows,)).copy()
-                for p, ct in zip(ps, (C.c_int32, C.c_int32, C.c_uint8, C.c_uint8, C.c_int32, C.c_int32))]
+        if lib.ftk_fragtable_is_device(t, 0):  # records parsed on the device: the columns live in HBM
+            cols = [np.empty(rows, dt) for dt in (np.int32, np.int32, np.uint8, np.uint8, np.int32, np.int32)]
+            assert lib.ftk_fragtable_columns_to_host(t, 0, *[c.ctypes.data_as(C.c_void_p) for c in cols[:4]]) == 0
+            order = np.empty(rows, np.int32)
+            assert lib.ftk_fragtable_read1_to_host(t, 0, cols[4].ctypes.data_as(C.c_void_p), cols[5].ctypes.data_as(C.c_void_p),
+                                                   order.ctypes.data_as(C.c_void_p)) == 0
+            # the file-order rank is a permutation and the rows are in stable start order
+            assert rows == 0 or (np.array_equal(np.sort(order), np.arange(rows)) and np.all(np.diff(cols[0]) >= 0))
+            n_device[0] += 1
+        else:
+            ps = [C.c_void_p() for _ in range(6)]
+            assert lib.ftk_fragtable_columns(t, 0, *[C.byref(p) for p in ps]) == 0
+            cols = [None if not p.value or rows == 0 else np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), (rows,)).copy()
+                    for p, ct in zip(ps, (C.c_int32, C.c_int32, C.c_uint8, C.c_uint8, C.c_int32, C.c_int32))]
         out[name] = (rows, cols, lib.ftk_fragtable_contig_length(t, 0))
         order.append(name)
         lib.ftk_fragtable_free(t)
@@ -269,8 +282,38 @@ for threads in (1, 8):
 only, order1 = stream("chrB")
 assert order1 == ["chrB"], order1
 _same(only, {{k: v for k, v in want.items() if k in ("chrB",) or k.startswith("__")}})
-print("ok", order)
+print("ok", order, "device_tables", n_device[0])
 """
+
+
+@pytest.mark.parametrize("piece,stretch", [(1 << 16, "64"), (1 << 16, "700"), (1 << 18, "4096"), (1 << 20, "16384"), (48 << 20, "16384")])
+def test_bam_records_parsed_on_the_device(tmp_path, piece, stretch):
+    """The same file with the RECORDS PARSED ON THE DEVICE (run_bam_device, ftk_bamparse.hip; the default): stretches
+    from 64 bytes (several per record: most guesses are wrong and the fix passes settle the chain) to 16 KB, pieces from
+    64 KB (records and the header's tail cut by piece ends, contig changes inside pieces) to one piece for the file; the
+    tables hold device columns in stable fragment-start order and equal the whole-file host decoder's; one contig
+    through the BAI."""
+    import os
+    import subprocess
+    import sys
+    from tests.helpers import write_synthetic_bam
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(29)
+    contigs = [("chrA", 3_000_000), ("chrEmpty", 1000), ("chrB", 1_000_000), ("chrC", 400_000)]
+    frags = {}
+    for name, size in contigs:
+        if name == "chrEmpty":
+            continue
+        n = size // 40
+        s = np.sort(rng.integers(0, size - 700, n))
+        frags[name] = (s, s + rng.integers(210, 600, n), rng.integers(0, 61, n), rng.integers(0, 2, n).astype(bool))
+    p = str(tmp_path / "multi.bam")
+    write_synthetic_bam(p, contigs, frags)
+    r = subprocess.run([sys.executable, "-c", _BAM_MULTI_CHILD.format(root=root), p], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, FTK_STREAM_PIECE=str(piece), FTK_BAM_DEV_STRETCH=stretch, FTK_DECODE_TIMING="1"))
+    assert r.returncode == 0 and "ok ['chrA', 'chrB', 'chrC']" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+    assert "device_tables 7" in r.stdout, r.stdout[-500:]  # 3 + 3 + 1 tables, none through the host fall-back
+    assert "parsed on the device" in r.stderr and "stretches of the record chain" not in r.stderr, r.stderr[-1500:]
 
 
 @pytest.mark.parametrize("piece,host_share", [(1 << 16, "3"), (1 << 16, "0"), (1 << 16, "1"), (1 << 18, "2")])
@@ -296,7 +339,8 @@ def test_bam_multi_contig_through_the_slot_ring(tmp_path, piece, host_share):
     p = str(tmp_path / "multi.bam")
     write_synthetic_bam(p, contigs, frags)
     r = subprocess.run([sys.executable, "-c", _BAM_MULTI_CHILD.format(root=root), p], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, FTK_STREAM_PIECE=str(piece), FTK_BAM_STRETCH="4096", FTK_BAM_HOST_SHARE=host_share))
+                       env=dict(os.environ, FTK_STREAM_PIECE=str(piece), FTK_BAM_STRETCH="4096", FTK_BAM_HOST_SHARE=host_share,
+                                FTK_DEVICE_BAM_PARSE="0"))
     assert r.returncode == 0 and "ok ['chrA', 'chrB', 'chrC']" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
 
 
@@ -325,8 +369,8 @@ lib.ftk_fragstream_close(s)
 """
 
 
-@pytest.mark.parametrize("host_share", ["0", "1", "3"])
-def test_bam_stream_with_a_damaged_block_is_an_error(tmp_path, host_share):
+@pytest.mark.parametrize("host_share,device_records", [("0", "0"), ("1", "0"), ("3", "0"), ("0", "1")])
+def test_bam_stream_with_a_damaged_block_is_an_error(tmp_path, host_share, device_records):
     """One flipped payload byte somewhere in the middle of a BAM: whichever side inflates that piece (the GPU, checked
     by its CRC kernel, or the host threads beside it), the stream ends with a format error - no crash, no hang, no
     silently different fragments."""
@@ -348,7 +392,7 @@ def test_bam_stream_with_a_damaged_block_is_an_error(tmp_path, host_share):
     bad = str(tmp_path / "bad.bam")
     open(bad, "wb").write(bytes(image))
     code = _BAM_DAMAGED_CHILD.format(root=root)
-    env = dict(os.environ, FTK_STREAM_PIECE=str(1 << 17), FTK_BAM_HOST_SHARE=host_share)
+    env = dict(os.environ, FTK_STREAM_PIECE=str(1 << 17), FTK_BAM_HOST_SHARE=host_share, FTK_DEVICE_BAM_PARSE=device_records)
     r = subprocess.run([sys.executable, "-c", code, good], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "complete 1" in r.stdout, r.stdout + r.stderr[-1500:]
     r = subprocess.run([sys.executable, "-c", code, bad], capture_output=True, text=True, timeout=600, env=env)
