@@ -257,11 +257,11 @@ def stream(contig=None, threads=4):
         if lib.ftk_fragtable_is_device(t, 0):  # records parsed on the device: the columns live in HBM
             cols = [np.empty(rows, dt) for dt in (np.int32, np.int32, np.uint8, np.uint8, np.int32, np.int32)]
             assert lib.ftk_fragtable_columns_to_host(t, 0, *[c.ctypes.data_as(C.c_void_p) for c in cols[:4]]) == 0
-            order = np.empty(rows, np.int32)
+            rank = np.empty(rows, np.int32)
             assert lib.ftk_fragtable_read1_to_host(t, 0, cols[4].ctypes.data_as(C.c_void_p), cols[5].ctypes.data_as(C.c_void_p),
-                                                   order.ctypes.data_as(C.c_void_p)) == 0
+                                                   rank.ctypes.data_as(C.c_void_p)) == 0
             # the file-order rank is a permutation and the rows are in stable start order
-            assert rows == 0 or (np.array_equal(np.sort(order), np.arange(rows)) and np.all(np.diff(cols[0]) >= 0))
+            assert rows == 0 or (np.array_equal(np.sort(rank), np.arange(rows)) and np.all(np.diff(cols[0]) >= 0))
             n_device[0] += 1
         else:
             ps = [C.c_void_p() for _ in range(6)]
