@@ -26,6 +26,9 @@ struct BamSummary {
     uint32_t n_records;       // records on the chain, any reference
     uint32_t n_runs;          // contig runs among the fragments (> kBamMaxRuns: too many to list)
     uint32_t n_stretch;       // stretches the range was cut into
+    uint32_t n_repairs;       // stretches the last kernel had to walk again serially
+    uint32_t first_unsettled; // (when not consistent) the first stretch that does not start where its predecessor landed
+    uint32_t dbg[4];          // its start, the predecessor's landing, the predecessor's start, the landing before that
     uint32_t run_row[kBamMaxRuns];
     int32_t run_ref[kBamMaxRuns];
 };

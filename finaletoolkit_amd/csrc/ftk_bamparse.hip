@@ -180,7 +180,10 @@ __global__ __launch_bounds__(256) void bam_setup_kernel(uint8_t* __restrict__ te
     }
 }
 
-// pass 0: guess + walk every stretch; pass >= 1: walk again the stretches that do not start where their predecessor landed
+// pass 0: guess + walk every stretch.  pass >= 1 (Jacobi): a stretch that does not start where its predecessor landed
+// is walked again from there - but only when that predecessor itself starts where ITS predecessor landed: a landing
+// is as good as the start it was walked from, and following the landing of a stretch whose own guess was wrong would
+// replace a good start by a bad one and push the damage one stretch further per pass.
 __global__ __launch_bounds__(64) void bam_walk_kernel(const uint8_t* __restrict__ text, const BamSummary* __restrict__ sum,
                                                       const uint8_t* __restrict__ wanted, int n_ref, uint32_t stretch_bytes,
                                                       uint32_t* __restrict__ st, int pass) {
@@ -202,43 +205,84 @@ __global__ __launch_bounds__(64) void bam_walk_kernel(const uint8_t* __restrict_
                 continue;
             }
         } else {
-            from = k == 0 ? 0u : __builtin_nontemporal_load(&st_land[k - 1]);
+            if (k == 0) continue;  // (walked from 0 in pass 0: final)
+            from = st_land[k - 1];
             if (from == kBamNoStart || from == st_start[k]) continue;
+            if (k >= 2 && st_start[k - 1] != st_land[k - 2]) continue;  // the predecessor is not settled itself
         }
         uint32_t n_frag, n_rec;
         bool bad;
         const uint32_t land = walk<false>(p, m, from, until, wanted, n_ref, n_frag, n_rec, bad, Out{}, 0, 0);
         st_start[k] = from;
         st_cnt[k] = n_frag | (bad ? 0x80000000u : 0u);
-        __builtin_nontemporal_store(land, &st_land[k]);
+        st_land[k] = land;
     }
 }
 
-// one block: is the chain consistent, how many rows, where does every stretch's first row go
-__global__ __launch_bounds__(1024) void bam_scan_kernel(BamSummary* __restrict__ sum, uint32_t* __restrict__ st) {
+// one block: settle what the Jacobi passes left (serially, from the first stretch that does not start where its
+// predecessor landed - every stretch before it is final), then: is the chain consistent, how many rows, where does
+// every stretch's first row go
+constexpr int kBamSerialRepairs = 4096;
+
+__global__ __launch_bounds__(1024) void bam_scan_kernel(const uint8_t* __restrict__ text, BamSummary* __restrict__ sum,
+                                                        const uint8_t* __restrict__ wanted, int n_ref, uint32_t stretch_bytes,
+                                                        uint32_t* __restrict__ st) {
     __shared__ uint32_t part[1024];
-    __shared__ uint32_t base_s, ok_s, bad_s;
-    const uint32_t n_stretch = sum->n_stretch;
-    const uint32_t* st_start = st;
-    const uint32_t* st_land = st + (size_t)n_stretch;
-    const uint32_t* st_cnt = st + 2 * (size_t)n_stretch;
+    __shared__ uint32_t base_s, ok_s, bad_s, first_s;
+    const uint32_t n_stretch = sum->n_stretch, m = sum->m;
+    const uint8_t* p = text + sum->base_off;
+    uint32_t* st_start = st;
+    uint32_t* st_land = st + (size_t)n_stretch;
+    uint32_t* st_cnt = st + 2 * (size_t)n_stretch;
     uint32_t* st_off = st + 3 * (size_t)n_stretch;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) { base_s = 0; ok_s = 1; bad_s = 0; }
+    // ---- serial repair: the first unsettled stretch has a settled predecessor ---------------------------------
+    uint32_t cursor = 1;
+    int rep = 0;
+    for (; rep < kBamSerialRepairs; ++rep) {
+        if (tid == 0) first_s = 0xffffffffu;
+        __syncthreads();
+        uint32_t mine = 0xffffffffu;
+        for (uint32_t k = cursor + tid; k < n_stretch; k += 1024)
+            if (st_start[k] != st_land[k - 1]) { mine = k; break; }
+        if (mine != 0xffffffffu) atomicMin(&first_s, mine);
+        __syncthreads();
+        const uint32_t f = first_s;
+        if (f == 0xffffffffu) break;
+        if (tid == 0) {
+            const uint32_t from = st_land[f - 1];
+            if (from != kBamNoStart) {
+                const uint64_t b1 = ((uint64_t)f + 1) * stretch_bytes;
+                const uint32_t until = b1 < m ? (uint32_t)b1 : m;
+                uint32_t n_frag, n_rec;
+                bool bad;
+                const uint32_t land = walk<false>(p, m, from, until, wanted, n_ref, n_frag, n_rec, bad, Out{}, 0, 0);
+                st_start[f] = from;
+                st_cnt[f] = n_frag | (bad ? 0x80000000u : 0u);
+                st_land[f] = land;
+            }
+            __threadfence_block();
+        }
+        __syncthreads();
+        if (st_land[f - 1] == kBamNoStart) break;  // nothing to walk from: reported as inconsistent below
+        cursor = f + 1;
+    }
+    __syncthreads();
+    if (tid == 0) { base_s = 0; ok_s = 1; bad_s = 0; first_s = 0xffffffffu; sum->n_repairs = (uint32_t)rep; }
     __syncthreads();
     for (uint32_t c0 = 0; c0 < n_stretch; c0 += 1024) {
         const uint32_t k = c0 + tid;
         uint32_t cnt = 0;
         if (k < n_stretch) {
             const uint32_t want = k == 0 ? 0u : st_land[k - 1];
-            if (st_start[k] != want || want == kBamNoStart) atomicAnd(&ok_s, 0u);
+            if (st_start[k] != want || want == kBamNoStart) { atomicAnd(&ok_s, 0u); atomicMin(&first_s, k); }
             const uint32_t c = st_cnt[k];
             if (c & 0x80000000u) atomicOr(&bad_s, 1u);
             cnt = c & 0x7fffffffu;
         }
         part[tid] = cnt;
         __syncthreads();
-        for (uint32_t d = 1; d < 1024; d <<= 1) {  // inclusive scan (Hillis-Steele; 12 rounds of a rare kernel)
+        for (uint32_t d = 1; d < 1024; d <<= 1) {  // inclusive scan (Hillis-Steele; 10 rounds of a rare kernel)
             const uint32_t v = tid >= d ? part[tid - d] : 0u;
             __syncthreads();
             part[tid] += v;
@@ -254,6 +298,14 @@ __global__ __launch_bounds__(1024) void bam_scan_kernel(BamSummary* __restrict__
         sum->consistent = ok_s;
         sum->bad = bad_s;
         sum->landing = ok_s ? st_land[n_stretch - 1] : 0u;
+        sum->first_unsettled = first_s;
+        if (!ok_s && first_s < n_stretch) {
+            const uint32_t f = first_s;
+            sum->dbg[0] = st_start[f];
+            sum->dbg[1] = f ? st_land[f - 1] : 0u;
+            sum->dbg[2] = f ? st_start[f - 1] : 0u;
+            sum->dbg[3] = f > 1 ? st_land[f - 2] : 0u;
+        }
     }
 }
 
@@ -328,10 +380,10 @@ void bamparse_launch(hipStream_t s, uint8_t* d_text, uint32_t data_off, uint32_t
     // (the range is only known on the device: launch for the data plus a 1 MB carry, the kernels stride over more)
     const size_t est = ((size_t)data_len + (size_t(1) << 20)) / stretch_bytes + 1;
     const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((est + 63) / 64, 1u << 16));
-    constexpr int kFixPasses = 4;
+    constexpr int kFixPasses = 3;
     for (int pass = 0; pass <= kFixPasses; ++pass)
         hipLaunchKernelGGL(bam_walk_kernel, dim3(blocks), dim3(64), 0, s, d_text, d_sum, d_wanted, n_ref, stretch_bytes, d_stretch, pass);
-    hipLaunchKernelGGL(bam_scan_kernel, dim3(1), dim3(1024), 0, s, d_sum, d_stretch);
+    hipLaunchKernelGGL(bam_scan_kernel, dim3(1), dim3(1024), 0, s, d_text, d_sum, d_wanted, n_ref, stretch_bytes, d_stretch);
     Out out{d_start, d_end, d_r1s, d_r1e, d_ref, d_mapq, d_strand};
     hipLaunchKernelGGL(bam_emit_kernel, dim3(blocks), dim3(64), 0, s, d_text, d_sum, d_wanted, n_ref, stretch_bytes, d_stretch, out,
                        max_rows);

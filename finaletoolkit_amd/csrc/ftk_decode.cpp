@@ -1452,16 +1452,34 @@ struct BamRun {
 };
 
 // Growable byte buffer without zero-fill (a std::vector would memset every piece it grows by).
+// `pinned`: page-locked memory from the library's recycled blocks instead - the pieces of a BAM stream whose records
+// are parsed on the device go up straight from the buffer they were read into.
 struct RawBuf {
     uint8_t* p = nullptr;
     size_t cap = 0;
     size_t head = 0;  // data() starts here (the read-ahead piece leaves room in front for carried bytes)
+    bool pinned = false;
     RawBuf() = default;
     RawBuf(const RawBuf&) = delete;
     RawBuf& operator=(const RawBuf&) = delete;
-    ~RawBuf() { if (p) huge_unmap(p, cap); }
+    ~RawBuf() {
+        if (!p) return;
+        if (pinned) pinned_free(p); else huge_unmap(p, cap);
+    }
     bool reserve(size_t n) {
         if (n <= cap) return true;
+        if (pinned) {
+            const size_t want = std::max(n, cap + cap / 2);
+            uint8_t* q = (uint8_t*)pinned_alloc(want);
+            if (!q) return false;
+            if (p) {
+                memcpy(q, p, cap);
+                pinned_free(p);
+            }
+            p = q;
+            cap = want;
+            return true;
+        }
         const size_t want = huge_round(std::max(n, cap + cap / 2));
         uint8_t* q = p ? huge_remap(p, cap, want) : huge_map(want);
         if (!q) return false;
@@ -1475,6 +1493,7 @@ struct RawBuf {
         std::swap(p, o.p);
         std::swap(cap, o.cap);
         std::swap(head, o.head);
+        std::swap(pinned, o.pinned);
     }
 };
 
@@ -2018,6 +2037,11 @@ void ftk_fragstream::run_guarded() {
             return;
         }
         if (sp.usable && !seek_to(sp)) { read_end = -1; partial_tail_ok = false; first_skip = 0; rewind(fp); }
+    }
+    {
+        static const bool dev_bam = !(getenv("FTK_DEVICE_BAM_PARSE") && atoi(getenv("FTK_DEVICE_BAM_PARSE")) == 0) &&
+                                    !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
+        if (bam && inflate_device >= 0 && dev_bam && have_hip_device()) buf.pinned = ahead.pinned = true;  // (see RawBuf)
     }
     const size_t n = fill(buf, 0);
     size_t bsize = 0;
@@ -3404,6 +3428,46 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         uint32_t first_off = 0;
         bool has_prev = false;
         int prev_slot = -1;
+        long long file_off = -1; // where the piece's first byte lies in the file (-1: unknown)
+        bool on_host = false;    // inflated by the host threads (its text goes up before the parse)
+        bool back_done = false;  // the parse is on the parse stream
+    };
+    // Every third piece is inflated by the host threads beside the GPU (the chip turns BAM blocks over at ~24 GB/s,
+    // the 16 threads manage ~11 GB/s and have nothing else to do now that the records stay on the device); its text
+    // goes up in one DMA before its parse.  FTK_BAM_HOST_SHARE=<n>: every n-th piece (0: none).
+    static const int host_share = [] {
+        const char* e = getenv("FTK_BAM_HOST_SHARE");
+        return e ? atoi(e) : 3;
+    }();
+    std::future<int> host_job[kSlots];
+    struct JobGuard {  // no job outlives the buffers it works on
+        std::future<int>* j;
+        ~JobGuard() {
+            for (int k = 0; k < kSlots; ++k)
+                if (j[k].valid()) (void)j[k].get();
+        }
+    } job_guard{host_job};
+    // the read buffer's bytes are on their way up (a GPU piece's copy reads them where they were read): wait before the
+    // buffer is touched again
+    hipEvent_t up_done = nullptr;
+    bool up_pending = false;
+    if (hipEventCreateWithFlags(&up_done, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FTK_ERR_HIP, "cannot create an event");
+    }
+    struct EventGuard { hipEvent_t* e; ~EventGuard() { if (*e) { (void)hipEventSynchronize(*e); (void)hipEventDestroy(*e); } } } up_guard{&up_done};
+    double t_upwait = 0, t_jobwait = 0, t_front = 0, t_header = 0;  // FTK_DECODE_TIMING: what "other" is made of
+    auto tick = [] { return std::chrono::steady_clock::now(); };
+    auto since = [](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    auto buffer_free = [&]() {
+        if (up_pending) {
+            const auto t0 = tick();
+            if (hipEventSynchronize(up_done) != hipSuccess) (void)hipGetLastError();
+            up_pending = false;
+            t_upwait += since(t0);
+        }
     };
     auto list_blocks = [&](Piece& pc) -> bool {
         if (!whole_blocks(buf.data(), pc.n, pc.eof, &pc.blocks, &pc.used, &pc.total)) return fail(FTK_ERR_FORMAT, "corrupt BGZF block");
@@ -3411,15 +3475,22 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
     };
     // front of a piece (its slot's own stream): compressed bytes up, inflate, CRC
     auto submit_front = [&](Piece& pc, int index) -> bool {
+        const auto t_in = tick();
+        struct Acc { double* d; std::chrono::steady_clock::time_point t0; ~Acc() { *d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } acc{&t_front, t_in};
         const int slot = index % kSlots;
         DevSet& S = sets[slot];
         hipStream_t st = streams[slot];
         if (S.pending) return fail(FTK_ERR_HIP, "buffer ring out of step");
         if (pc.total + kRoom + 64 >= (size_t(1) << 32)) return fail(FTK_ERR_FORMAT, "BGZF piece too large");
-        if (!S.ensure(kRoom + pc.total + 64) || !S.ensure_inflate(pc.used, pc.blocks.size()) || !S.ensure_host_comp(pc.used + 64) ||
-            !S.ensure_bam(kRoom + pc.total + 64, stretch_bytes))
+        pc.on_host = host_share > 0 && index > 0 && (index % host_share) == host_share - 1;
+        // a GPU piece goes up straight from the (page-locked) read buffer; the host threads work on their own copy of
+        // theirs, which they read from the file (page cache) themselves when the piece's file offset is known
+        const bool direct = buf.pinned && !pc.on_host;
+        const bool job_reads = pc.on_host && pc.file_off >= 0;
+        if (!S.ensure(kRoom + pc.total + 64) || !S.ensure_inflate(pc.used, pc.blocks.size()) ||
+            (!direct && !S.ensure_host_comp(pc.used + 64)) || !S.ensure_bam(kRoom + pc.total + 64, stretch_bytes))
             return fail(FTK_ERR_OOM, "out of page-locked / device memory for the BAM piece");
-        {
+        if (!direct && !job_reads) {
             const size_t used = pc.used;
             const int nt = std::max(1, std::min(n_threads, (int)(used >> 20) + 1));
             const uint8_t* src = buf.data();
@@ -3436,11 +3507,42 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
             S.want_crc[i] = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
         }
         S.n_tab = pc.blocks.size();
-        bool ok = (!S.freed_valid || hipStreamWaitEvent(st, S.freed, 0) == hipSuccess) &&
+        if (pc.on_host) {
+            // (the job owns its block list; compressed bytes and output are the slot's page-locked buffers)
+            host_job[slot] = std::async(std::launch::async, [blocks = pc.blocks, comp = S.h_comp, out = S.h_text + kRoom,
+                                                             nt = std::max(1, n_threads - 2), fd = fileno(fp), used = pc.used,
+                                                             off = pc.file_off, job_reads] {
+                if (job_reads) {  // its own copy of the compressed bytes, four pread threads
+                    std::atomic<int> bad{0};
+                    std::vector<std::thread> th;
+                    auto part = [&](int t) {
+                        size_t a = used * (size_t)t / 4;
+                        const size_t e = used * (size_t)(t + 1) / 4;
+                        while (a < e) {
+                            const ssize_t r = pread(fd, comp + a, e - a, (off_t)(off + (long long)a));
+                            if (r <= 0) { bad.store(1); return; }
+                            a += (size_t)r;
+                        }
+                    };
+                    for (int t = 1; t < 4; ++t) th.emplace_back(part, t);
+                    part(0);
+                    for (auto& t : th) t.join();
+                    if (bad.load()) return (int)FTK_ERR_IO;
+                }
+                return blocks.empty() ? (int)FTK_OK : inflate_block_list(comp, blocks, nt, out, true, true);  // CRCs checked
+            });
+            pc.slot = slot;
+            return true;
+        }
+        // (the compressed bytes go up at once - nothing of the slot's previous piece uses d_comp any more - and only
+        // the inflate, which overwrites the text the appends may still read, waits for the slot's release)
+        bool ok = (pc.used == 0 || hipMemcpyAsync(S.d_comp, direct ? buf.data() : S.h_comp, pc.used, hipMemcpyHostToDevice, st) == hipSuccess) &&
+                  (!direct || hipEventRecord(up_done, st) == hipSuccess) &&
+                  (!S.freed_valid || hipStreamWaitEvent(st, S.freed, 0) == hipSuccess) &&
                   hipMemsetAsync(S.d_ist, 0, sizeof(ftk::InflateStatus), st) == hipSuccess &&
-                  (pc.used == 0 || hipMemcpyAsync(S.d_comp, S.h_comp, pc.used, hipMemcpyHostToDevice, st) == hipSuccess) &&
                   (pc.blocks.empty() || hipMemcpyAsync(S.d_tab, S.h_tab, pc.blocks.size() * sizeof(ftk::InflateBlock),
                                                        hipMemcpyHostToDevice, st) == hipSuccess);
+        if (ok && direct) up_pending = true;
         if (ok) {
             ftk::inflate_launch(st, S.d_comp, S.d_tab, (int)pc.blocks.size(), S.d_text, S.d_ist, S.d_crc);
             ok = hipGetLastError() == hipSuccess && hipEventRecord(S.front, st) == hipSuccess;
@@ -3457,6 +3559,23 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
     auto submit_back = [&](Piece& pc) -> bool {
         DevSet& S = sets[pc.slot];
         DevSet* P = pc.has_prev ? &sets[pc.prev_slot] : nullptr;
+        if (pc.on_host) {  // the host threads' text goes up on the slot's stream (behind the appends that read the set last)
+            hipStream_t st = streams[pc.slot];
+            const auto t0 = tick();
+            const int jrc = host_job[pc.slot].valid() ? host_job[pc.slot].get() : (int)FTK_OK;
+            t_jobwait += since(t0);
+            if (jrc != FTK_OK)
+                return fail(FTK_ERR_FORMAT, "BGZF inflate failed or block CRC mismatch (host share of a device stream)");
+            const bool up = (!S.freed_valid || hipStreamWaitEvent(st, S.freed, 0) == hipSuccess) &&
+                            hipMemsetAsync(S.d_ist, 0, sizeof(ftk::InflateStatus), st) == hipSuccess &&
+                            (pc.total == 0 || hipMemcpyAsync(S.d_text + kRoom, S.h_text + kRoom, pc.total, hipMemcpyHostToDevice, st) == hipSuccess) &&
+                            hipEventRecord(S.front, st) == hipSuccess;
+            if (!up) {
+                (void)hipGetLastError();
+                return fail(FTK_ERR_HIP, "cannot send a host-inflated piece to the device");
+            }
+            S.n_tab = 0;  // (its CRCs were checked by the host job)
+        }
         bool ok = hipMemsetAsync(S.d_bsum, 0, sizeof(ftk::BamSummary), pstream) == hipSuccess &&
                   hipStreamWaitEvent(pstream, S.front, 0) == hipSuccess;
         if (ok) {
@@ -3466,14 +3585,22 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
             ok = hipGetLastError() == hipSuccess &&
                  hipMemcpyAsync(S.h_bsum, S.d_bsum, sizeof(ftk::BamSummary), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
                  hipMemcpyAsync(S.h_ist, S.d_ist, sizeof(ftk::InflateStatus), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
-                 (pc.blocks.empty() || hipMemcpyAsync(S.h_crc, S.d_crc, pc.blocks.size() * 4, hipMemcpyDeviceToHost, pstream) == hipSuccess) &&
+                 (S.n_tab == 0 || hipMemcpyAsync(S.h_crc, S.d_crc, S.n_tab * 4, hipMemcpyDeviceToHost, pstream) == hipSuccess) &&
                  hipEventRecord(S.done, pstream) == hipSuccess;
         }
         if (!ok) {
             (void)hipGetLastError();
             return fail(FTK_ERR_HIP, "cannot launch the device record parser");
         }
+        if (P) {  // the previous piece's text has been read (the carry): its slot may take a new piece behind this point
+            P->freed_valid = hipEventRecord(P->freed, pstream) == hipSuccess;
+            if (!P->freed_valid) {
+                (void)hipGetLastError();
+                return fail(FTK_ERR_HIP, "cannot record a buffer set's release");
+            }
+        }
         S.pending = true;
+        pc.back_done = true;
         return true;
     };
 
@@ -3481,29 +3608,53 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
     Piece curp;
     curp.n = n_first;
     curp.eof = n_first < kStreamPiece;
+    curp.file_off = 0;  // (run_guarded read the first piece from the start of the file)
     int n_submitted = 0;
-    if (!list_blocks(curp) || !submit_front(curp, n_submitted++)) return false;
+    if (!list_blocks(curp)) return false;
+    std::deque<Piece> ahead;  // pieces behind curp whose fronts (and, in file order, backs) are enqueued
+    auto read_ahead_fronts = [&]() -> bool {  // read the next pieces and start their inflate
+        while ((int)ahead.size() < kAhead) {
+            const Piece& last = ahead.empty() ? curp : ahead.back();
+            if (last.eof) break;
+            const size_t raw_carry = last.n - last.used;
+            buffer_free();
+            if (raw_carry) memmove(buf.data(), buf.data() + last.used, raw_carry);
+            clk.lap(5);
+            Piece np;
+            np.n = fill(buf, raw_carry);
+            clk.lap(0);
+            np.eof = np.n - raw_carry < kStreamPiece;
+            np.has_prev = true;
+            np.prev_slot = last.slot;
+            np.file_off = last.file_off >= 0 ? last.file_off + (long long)last.used : -1;
+            if (!list_blocks(np) || !submit_front(np, n_submitted++)) return false;
+            ahead.push_back(std::move(np));
+        }
+        return true;
+    };
+
     std::vector<int> wanted;
+    const auto t_head0 = tick();
     {
-        DevSet& S = sets[curp.slot];
-        size_t have = 0, o = 0;
+        // The header sits in the first BGZF blocks: those are inflated right here on the host (a few blocks of 64 KB,
+        // microseconds) so that the pipeline does not wait for the first piece's trip through the device.
+        std::vector<uint8_t> head;
+        size_t nb = 0, o = 0;
         bool complete = false;
         while (!complete) {
-            const size_t want = std::min(curp.total, std::max<size_t>(have * 4, size_t(1) << 20));
-            if (want > have) {
-                if (hipMemcpyAsync(S.h_text + kRoom + have, S.d_text + kRoom + have, want - have, hipMemcpyDeviceToHost, streams[curp.slot]) != hipSuccess ||
-                    hipStreamSynchronize(streams[curp.slot]) != hipSuccess) {
-                    (void)hipGetLastError();
-                    return fail(FTK_ERR_HIP, "cannot copy the BAM header back");
-                }
-                have = want;
+            const size_t take = std::min(curp.blocks.size(), std::max<size_t>(2 * nb, 4));
+            if (take == nb) {  // the header does not end inside the first piece: the host path
+                if (curp.eof) return fail(FTK_ERR_FORMAT, "truncated BAM header");
+                want_host_restart = true;
+                return false;
             }
-            if (S.h_ist) {  // (a block that did not inflate would show up as a garbled header)
-                if (hipMemcpy(S.h_ist, S.d_ist, sizeof(ftk::InflateStatus), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); }
-                else if (S.h_ist->n_bad) return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
-            }
-            const uint8_t* p = S.h_text + kRoom;
-            const size_t m = have;
+            nb = take;
+            std::vector<Block> first(curp.blocks.begin(), curp.blocks.begin() + nb);
+            const size_t m = first.back().out_off + first.back().out_len;
+            head.resize(m + 1);
+            if (inflate_block_list(buf.data(), first, std::min(n_threads, 4), head.data()) != FTK_OK)
+                return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+            const uint8_t* p = head.data();
             do {
                 if (m < 12) break;
                 if (memcmp(p, "BAM\1", 4) != 0) return fail(FTK_ERR_FORMAT, (path + " is not a BAM file").c_str());
@@ -3539,11 +3690,6 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
                 for (uint32_t r = 0; r < nr; ++r) wanted[r] = !has_only || names[r] == only;
                 complete = true;
             } while (false);
-            if (!complete && have >= curp.total) {  // a header that does not end inside the first piece: the host path
-                if (curp.eof) return fail(FTK_ERR_FORMAT, "truncated BAM header");
-                want_host_restart = true;
-                return false;
-            }
         }
         n_ref = (int)wanted.size();
         std::vector<uint8_t> w8(std::max<size_t>(wanted.size(), 1), 0);
@@ -3563,13 +3709,14 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
             const IndexSpan sp = index_lookup(index_path_of(path, true), true, std::string(), target);
             if (sp.usable && !sp.present) return true;
             if (sp.usable && seek_to(sp)) {
-                if (hipStreamSynchronize(streams[curp.slot]) != hipSuccess) (void)hipGetLastError();
+                const long long seek_pos = ftell(fp);
                 curp = Piece{};
                 curp.n = fill(buf, 0);
                 curp.eof = curp.n < kStreamPiece;
+                curp.file_off = seek_pos;
                 curp.first_off = (uint32_t)first_skip;
                 first_skip = 0;
-                if (!list_blocks(curp) || !submit_front(curp, n_submitted++)) return false;
+                if (!list_blocks(curp)) return false;
             } else {
                 read_end = -1;
                 partial_tail_ok = false;
@@ -3577,7 +3724,8 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
             }
         }
     }
-    if (!submit_back(curp)) return false;
+    if (!submit_front(curp, n_submitted++) || !submit_back(curp)) return false;
+    t_header = since(t_head0);
 
     // ---- the pieces ---------------------------------------------------------------------------------------------
     Contig cur;
@@ -3646,11 +3794,18 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         }
         clk.lap(1);
         S.pending = false;
-        if (S.h_ist->n_bad) return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+        if (!pc.on_host && S.h_ist->n_bad) return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
         for (size_t i = 0; i < S.n_tab; ++i)
             if (S.h_crc[i] != S.want_crc[i]) return fail(FTK_ERR_FORMAT, "BGZF block CRC mismatch (device inflate)");
         const ftk::BamSummary& B = *S.h_bsum;
         if (B.carry_overflow || !B.consistent || B.n_runs > (uint32_t)ftk::kBamMaxRuns || B.n_rows > S.max_lines) {
+            if (clk.on)
+                fprintf(stderr, "[ftk stream bam] piece %zu: the device could not settle the record chain (carry overflow %u, "
+                                "consistent %u, runs %u, rows %u of %zu, range %u bytes in %u stretches, %u serial repairs, first "
+                                "unsettled stretch %u: start %u, predecessor landed %u started %u, before it landed %u%s): the host "
+                                "decoder takes over\n",
+                        n_pieces, B.carry_overflow, B.consistent, B.n_runs, B.n_rows, S.max_lines, B.m, B.n_stretch, B.n_repairs,
+                        B.first_unsettled, B.dbg[0], B.dbg[1], B.dbg[2], B.dbg[3], pc.on_host ? ", host-inflated" : "");
             want_host_restart = true;  // the host decoder takes the file (contigs handed out so far are skipped)
             return false;
         }
@@ -3675,23 +3830,27 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         return true;
     };
 
-    std::deque<Piece> ahead;  // pieces behind curp whose fronts and backs are enqueued, in file order
     for (;;) {
+        // The backs go onto the parse stream in file order: curp's now (waiting for the host threads if they hold
+        // it), the following ones as far as they are ready without waiting.  BEFORE any new front: the piece read
+        // next goes into the slot of the piece settled last, whose text the parse of ITS successor (curp) still
+        // reads the carry from - submit_back re-records that slot's `freed` behind curp's parse.
+        if (!curp.back_done && !submit_back(curp)) return false;
+        for (auto& pc : ahead) {
+            if (pc.back_done) continue;
+            if (pc.on_host && host_job[pc.slot].valid() &&
+                host_job[pc.slot].wait_for(std::chrono::seconds(0)) != std::future_status::ready)
+                break;
+            if (!submit_back(pc)) return false;
+        }
         // read and enqueue the next pieces before this one is settled
-        while ((int)ahead.size() < kAhead) {
-            const Piece& last = ahead.empty() ? curp : ahead.back();
-            if (last.eof) break;
-            const size_t raw_carry = last.n - last.used;
-            if (raw_carry) memmove(buf.data(), buf.data() + last.used, raw_carry);
-            clk.lap(5);
-            Piece np;
-            np.n = fill(buf, raw_carry);
-            clk.lap(0);
-            np.eof = np.n - raw_carry < kStreamPiece;
-            np.has_prev = true;
-            np.prev_slot = last.slot;
-            if (!list_blocks(np) || !submit_front(np, n_submitted++) || !submit_back(np)) return false;
-            ahead.push_back(std::move(np));
+        if (!read_ahead_fronts()) return false;
+        for (auto& pc : ahead) {  // (the fronts just enqueued: GPU pieces' backs follow at once)
+            if (pc.back_done) continue;
+            if (pc.on_host && host_job[pc.slot].valid() &&
+                host_job[pc.slot].wait_for(std::chrono::seconds(0)) != std::future_status::ready)
+                break;
+            if (!submit_back(pc)) return false;
         }
         clk.lap(5);
         if (!settle(curp)) return false;
@@ -3708,8 +3867,10 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
     clk.lap(4);
     clk.report("bam, records parsed on the device (inflate = waiting for a piece, parse = appends, merge = sort)");
     if (clk.on)
-        fprintf(stderr, "[ftk stream bam] %zu pieces, %zu records, %zu fragments parsed on the device (stretch %u bytes)\n", n_pieces,
-                n_records, n_rows_total, stretch_bytes);
+        fprintf(stderr, "[ftk stream bam] %zu pieces, %zu records, %zu fragments parsed on the device (stretch %u bytes); of \"other\": "
+                        "header piece %.1f ms, fronts enqueued %.1f ms, waiting for a piece's bytes to be up %.1f ms, for the host "
+                        "threads' inflate %.1f ms\n",
+                n_pieces, n_records, n_rows_total, stretch_bytes, t_header, t_front, t_upwait, t_jobwait);
     return true;
 }
 
