@@ -21,6 +21,7 @@ python tools/prof_summary.py pmc $OUT/sq_* > $OUT/pmc_sq_feature_kernels.txt
 python tools/prof_summary.py stats $OUT/e2e_stats > $OUT/e2e_kernel_stats.txt
 FTK_BENCH_FORCE_DIST=1 $B --no-cpu-baseline --no-end-to-end > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err
 KBENCH=feat python tools/kbench.py > $OUT/kbench_feat_fast.txt 2>&1
+FTK_BENCH_MERGED=0 $B --no-cpu-baseline --no-end-to-end > $OUT/bench_two_launches.json 2> /dev/null
 FTK_FEAT_FAST=0 KBENCH=feat python tools/kbench.py > $OUT/kbench_feat_general.txt 2>&1
 FTK_BENCH_DETAIL=1 $B --no-cpu-baseline --no-end-to-end > $OUT/bench_detail.json 2> $OUT/bench_detail.err
 rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/sq_SQ_* $OUT/e2e_stats
