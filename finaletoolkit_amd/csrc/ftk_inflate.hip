@@ -376,16 +376,35 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
             const unsigned E = L.pair[(unsigned)(b.buf >> lane) & ((1u << kLitRoot) - 1u)];
             const int limit = b.cnt - kLitRoot;
             int pos = 0;
-            uint64_t on_chain = 0, pairs = 0;
-            unsigned e;
-            for (;;) {
-                e = (unsigned)__builtin_amdgcn_readlane((int)E, pos);
-                if (!(e & 0x60u)) break;  // no literal entry
-                on_chain |= 1ull << pos;
-                pairs |= (uint64_t)((e >> 6) & 1u) << pos;
-                pos += (int)(e & 31u);
-                if (pos > limit) break;
-            }
+            // The hops are marked ON THE VECTOR UNIT: the lane whose bit offset a hop lands on keeps the entry's kind
+            // (1: one literal, 2: a pair).  The scalar unit - one per CU, shared by every wave of it, and what bounds
+            // this kernel - is left with the chain itself (entry -> test -> length -> position); the two masks come
+            // out of two ballots after the loop instead of four 64-bit shift / or instructions per hop.
+            // The loop is written out: as C++ the compiler keeps a 64-bit "which exit" flag alive across the back
+            // edge (s_mov_b64 / s_cselect_b64 / s_andn2_b64 per hop).  Nine instructions per hop: four scalar, two
+            // branches, three vector.  (No manual wait states are needed: the lane select of v_readlane is written
+            // by the scalar unit, v_cmp -> v_cndmask through VCC is interlocked.)
+            const unsigned kindv = (E >> 5) & 3u;  // every lane's own entry kind: the lane a hop lands on keeps it
+            unsigned mark, e;
+            int t;
+            asm volatile(
+                "s_mov_b32 %[pos], 0\n\t"
+                "v_mov_b32 %[mark], 0\n"
+                "1:\n\t"
+                "v_readlane_b32 %[e], %[E], %[pos]\n\t"
+                "s_and_b32 %[t], %[e], 0x60\n\t"
+                "s_cbranch_scc0 2f\n\t"
+                "v_cmp_eq_u32 vcc, %[pos], %[lane]\n\t"
+                "v_cndmask_b32 %[mark], %[mark], %[kindv], vcc\n\t"
+                "s_and_b32 %[t], %[e], 31\n\t"
+                "s_add_i32 %[pos], %[pos], %[t]\n\t"
+                "s_cmp_le_i32 %[pos], %[limit]\n\t"
+                "s_cbranch_scc1 1b\n"
+                "2:\n\t"
+                : [pos] "=&s"(pos), [mark] "=&v"(mark), [e] "=&s"(e), [t] "=&s"(t)
+                : [E] "v"(E), [lane] "v"(lane), [kindv] "v"(kindv), [limit] "s"(limit)
+                : "vcc", "scc");
+            const uint64_t on_chain = __ballot(mark != 0u), pairs = __ballot(mark == 2u);
             if (on_chain) {
                 const uint32_t total = (uint32_t)(__popcll(on_chain) + __popcll(pairs));
                 if (A + total > A_end) { err = kInflateOverrun; break; }

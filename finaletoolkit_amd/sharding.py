@@ -94,6 +94,9 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int]:
 
 def finalize():
     """Leave the process group (end of a multi-rank command)."""
+    import sys
+    if "torch.distributed" not in sys.modules:
+        return
     try:
         import torch.distributed as dist
     except ImportError:  # pragma: no cover
@@ -104,7 +107,12 @@ def finalize():
 
 
 def rank_world(group=None) -> Tuple[int, int]:
-    """``(rank, world)`` of the initialised process group, ``(0, 1)`` without one."""
+    """``(rank, world)`` of the initialised process group, ``(0, 1)`` without one.  A process that has not imported
+    ``torch.distributed`` cannot have one: torch is not imported just to find that out (seconds on a fresh box, and
+    every writer asks)."""
+    import sys
+    if "torch.distributed" not in sys.modules:
+        return 0, 1
     try:
         import torch.distributed as dist
     except ImportError:  # pragma: no cover
