@@ -638,7 +638,9 @@ def end_to_end(torch, reps: int = 3, cpu=None):
       bam_60x_slice       config 5's input: a 60x paired-end BAM slice of 24 Mb (9.6 M records) -> read1 fragments ->
                           every feature and WPS of every base;
       genome_delfi_bins   config 4 itself: ONE whole-genome 30x frag.gz (309.6 M rows, 8 GB of text) -> DELFI
-                          short / long / fragment counts of all 30 970 bins (two repetitions; FTK_BENCH_GENOME_E2E=0 skips)."""
+                          short / long / fragment counts of all 30 970 bins (two repetitions; FTK_BENCH_GENOME_E2E=0 skips);
+      genome_all_features_wps  the same file -> every feature of every window and the WPS of every base on the host;
+      genome_frag_delfi_api    the same file -> the product's frag.delfi() with its side files (frag_delfi_api_leg)."""
     import shutil
     import tempfile
     from finaletoolkit_amd import bgzf, source
@@ -753,13 +755,14 @@ def end_to_end(torch, reps: int = 3, cpu=None):
             pg = os.path.join(tmp, "genome.frag.gz")
             names = list(synth.B37_SIZES)
             t0 = time.perf_counter()
-            truth, rows_total, text_bytes = {}, 0, 0
+            truth, truth_all, rows_total, text_bytes = {}, {}, 0, 0
             for k, c in enumerate(names):
                 size = synth.B37_SIZES[c]
                 n = synth.n_fragments(size, 30.0)
                 s, e, q, st = (t.cpu().numpy() for t in gen_contig_device(torch, dev, size, n, synth.SEED_BASE + k))
                 ln = e - s
                 truth[c] = int(((q >= MAPQ) & (ln >= 100) & (ln <= 220)).sum())
+                truth_all[c] = dict(n=n, cov=int((q >= 30).sum()), delfi=truth[c])
                 with writers.frag_rows(c, s, e, q, st) as text:
                     writers.bgzf_write(pg, text, 1, append=k > 0, write_eof=k == len(names) - 1)
                     text_bytes += text.n
@@ -794,6 +797,12 @@ def end_to_end(torch, reps: int = 3, cpu=None):
             res["genome_delfi_bins"] = dict(file_GB=round(os.path.getsize(pg) / 1e9, 2), text_GB=round(text_bytes / 1e9, 2),
                                             fragments=rows_total, file_write_s=round(t_write, 1), decoder_threads=threads,
                                             repetitions=2, **best)
+            # BASELINE config 5's shape on one GPU from the text file: every feature of every 100 kb window AND the WPS
+            # of every base of the genome in host memory, contig by contig (24.8 GB of int64 scores cross PCIe)
+            res["genome_all_features_wps"] = dict(file_GB=round(os.path.getsize(pg) / 1e9, 2), fragments=rows_total,
+                                                  decoder_threads=threads, repetitions=reps,
+                                                  scores_to_host_GB=round(8 * sum(synth.B37_SIZES.values()) / 1e9, 1),
+                                                  **run(pg, names, truth_all, True))
             # The north-star's own figure, on the PRODUCT FUNCTION: the same file -> frag.delfi() with a bins file,
             # blacklist, gap annotation, a 2bit reference (per-bin GC counted on the device), the 100 kb -> 5 Mb
             # merge and the TSV written -- everything reference frag/_delfi.py:129-401 does around its per-bin loop.
