@@ -3435,10 +3435,13 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
     // Every third piece is inflated by the host threads beside the GPU (the chip turns BAM blocks over at ~24 GB/s,
     // the 16 threads manage ~11 GB/s and have nothing else to do now that the records stay on the device); its text
     // goes up in one DMA before its parse.  FTK_BAM_HOST_SHARE=<n>: every n-th piece (0: none).
-    static const int host_share = [] {
+    // Only with enough threads to keep up: a rank of eight on a 16-core quota has two, and a piece that took 10 ms
+    // on fourteen threads would hold the pipeline for 70.
+    static const int host_share_env = [] {
         const char* e = getenv("FTK_BAM_HOST_SHARE");
-        return e ? atoi(e) : 3;
+        return e ? atoi(e) : -1;
     }();
+    const int host_share = host_share_env >= 0 ? host_share_env : (n_threads >= 8 ? 3 : 0);
     std::future<int> host_job[kSlots];
     struct JobGuard {  // no job outlives the buffers it works on
         std::future<int>* j;
