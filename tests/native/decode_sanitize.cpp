@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "ftk.h"
+#include "ftk_bamparse.h"
 #include "ftk_inflate.h"
 #include "ftk_textparse.h"
 
@@ -27,6 +28,18 @@ void textparse_launch_inflated(hipStream_t, uint8_t*, uint32_t, uint32_t, const 
 }
 void inflate_launch(hipStream_t, const uint8_t*, const InflateBlock*, int, uint8_t*, InflateStatus*, uint32_t*) {
     fprintf(stderr, "inflate_launch called in the sanitizer harness\n");
+    abort();
+}
+void bamparse_launch(hipStream_t, uint8_t*, uint32_t, uint32_t, const uint8_t*, const BamSummary*, uint32_t, const uint8_t*, int,
+                     uint32_t, uint32_t*, size_t, size_t, int32_t*, int32_t*, uint8_t*, uint8_t*, int32_t*, int32_t*, int32_t*,
+                     BamSummary*) {
+    fprintf(stderr, "bamparse_launch called in the sanitizer harness\n");
+    abort();
+}
+size_t bam_sort_tmp_bytes(size_t) { return 0; }
+int bam_sort_contig(hipStream_t, size_t, const int32_t*, const int32_t*, const uint8_t*, const uint8_t*, const int32_t*,
+                    const int32_t*, int32_t*, int32_t*, uint8_t*, uint8_t*, int32_t*, int32_t*, int32_t*, void*, size_t) {
+    fprintf(stderr, "bam_sort_contig called in the sanitizer harness\n");
     abort();
 }
 }  // namespace ftk
