@@ -426,3 +426,58 @@ def test_cache_trim_releases_the_streams_idle_buffers(tmp_path):
     assert freed > 0
     assert source.release_caches() == 0
     assert run() == a
+
+
+def _multi_child(tmp_path, bam_path, want_order, env):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = _BAM_MULTI_CHILD.replace('only, order1 = stream("chrB")', 'only, order1 = stream(%r)' % want_order[1]) \
+                            .replace('assert order1 == ["chrB"], order1', 'assert order1 == [%r], order1' % want_order[1]) \
+                            .replace('if k in ("chrB",)', 'if k in (%r,)' % want_order[1])
+    r = subprocess.run([sys.executable, "-c", child.format(root=root), bam_path], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, FTK_DECODE_TIMING="1", **env))
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout[-1500:] + r.stderr[-2500:]
+    return r
+
+
+def test_bam_device_parser_hands_over_to_the_host_decoder(tmp_path):
+    """More contig runs in one piece than the device summary lists (a BAM's decoy / alt contigs: 150 contigs with a
+    handful of reads each, all in one 64 KB piece) - the stream starts over on the host decoder, which skips the
+    contigs the device pass had already handed out; the consumer sees every contig once, with the whole-file
+    decoder's rows."""
+    from tests.helpers import write_synthetic_bam
+    rng = np.random.default_rng(41)
+    contigs = [("big0", 600_000)] + [(f"alt{k:03d}", 20_000) for k in range(150)] + [("big1", 300_000)]
+    frags = {}
+    for name, size in contigs:
+        n = size // 50 if name.startswith("big") else 6
+        s = np.sort(rng.integers(0, size - 700, n))
+        frags[name] = (s, s + rng.integers(210, 600, n), rng.integers(0, 61, n), rng.integers(0, 2, n).astype(bool))
+    p = str(tmp_path / "alts.bam")
+    write_synthetic_bam(p, contigs, frags)
+    r = _multi_child(tmp_path, p, ("big0", "alt077"), dict(FTK_STREAM_PIECE=str(1 << 16)))
+    assert "the host decoder takes over" in r.stderr, r.stderr[-1500:]
+    assert "'big0', 'alt000'" in r.stdout and "'alt149', 'big1']" in r.stdout, r.stdout[-600:]
+    # with pieces that hold fewer runs than the limit the device parses the whole file
+    r = _multi_child(tmp_path, p, ("big0", "alt077"), dict(FTK_STREAM_PIECE=str(1 << 16), FTK_BAM_DEV_STRETCH="512"))
+    assert "'alt149', 'big1']" in r.stdout
+
+
+def test_bam_device_parser_with_records_longer_than_a_stretch(tmp_path):
+    """Long reads: records of 6-8 KB (read length 4 000) against stretches of 1 KB and 16 KB - most stretches hold no
+    record start at all, the guesses land inside sequence bytes, and the chain still settles on the device."""
+    from tests.helpers import write_synthetic_bam
+    rng = np.random.default_rng(43)
+    contigs = [("chrL", 4_000_000), ("chrM", 900_000)]
+    frags = {}
+    for name, size in contigs:
+        n = size // 2_000
+        s = np.sort(rng.integers(0, size - 12_000, n))
+        frags[name] = (s, s + rng.integers(4_100, 9_000, n), rng.integers(0, 61, n), rng.integers(0, 2, n).astype(bool))
+    p = str(tmp_path / "long.bam")
+    write_synthetic_bam(p, contigs, frags, read_len=4_000)
+    for stretch in ("1024", "16384"):
+        r = _multi_child(tmp_path, p, ("chrL", "chrM"), dict(FTK_STREAM_PIECE=str(1 << 18), FTK_BAM_DEV_STRETCH=stretch))
+        assert "['chrL', 'chrM']" in r.stdout and "the host decoder takes over" not in r.stderr, r.stdout[-400:] + r.stderr[-1500:]
