@@ -1896,6 +1896,7 @@ struct ftk_fragstream {
     long long read_end = -1;      // file offset to stop reading at (-1: none)
     bool partial_tail_ok = false;  // the range may end inside a block that belongs to the next contig
     size_t first_skip = 0;        // bytes of the first inflated block that precede the contig
+    long long first_piece_off = -1;  // file offset of the first piece handed to run_* (-1: unknown)
     // One piece of the file -> dst; returns the bytes read (short at the end of the file / of the range).
     size_t read_piece(uint8_t* dst) {
         size_t want = kStreamPiece;
@@ -2042,7 +2043,14 @@ void ftk_fragstream::run_guarded() {
         static const bool dev_bam = !(getenv("FTK_DEVICE_BAM_PARSE") && atoi(getenv("FTK_DEVICE_BAM_PARSE")) == 0) &&
                                     !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
         if (bam && inflate_device >= 0 && dev_bam && have_hip_device()) buf.pinned = ahead.pinned = true;  // (see RawBuf)
+        // (a text stream stages its GPU pieces in the buffer sets' own page-locked memory instead: FTK_TEXT_DIRECT_UP=1
+        // sends them up from a page-locked read buffer like the BAM stream's, which measured slower - the producer then
+        // waits 2-3 ms per piece for the copy before it may read on, with 190 MB text uploads of the host threads'
+        // pieces in the same queues)
+        static const bool text_direct = getenv("FTK_TEXT_DIRECT_UP") && atoi(getenv("FTK_TEXT_DIRECT_UP")) == 1;
+        if (!bam && device >= 0 && text_direct && have_hip_device()) buf.pinned = ahead.pinned = true;
     }
+    first_piece_off = ftell(fp);
     const size_t n = fill(buf, 0);
     size_t bsize = 0;
     const bool bgzf = n >= 18 && gzip_header(buf.data(), n, 0, &bsize) && bsize;
@@ -2117,6 +2125,7 @@ void ftk_fragstream::run_guarded() {
                 const IndexSpan sp = index_lookup(index_path_of(path, false), false, only, -1);
                 if (sp.usable && sp.present && !seek_to(sp)) { read_end = -1; partial_tail_ok = false; first_skip = 0; rewind(fp); }
             }
+            first_piece_off = ftell(fp);
             const size_t n2 = fill(buf, 0);
             ok = run_text_device(buf, n2);
         }
@@ -2412,7 +2421,7 @@ struct DevSet {
 };
 // The two buffer sets of a finished stream wait here for the next one: allocating them costs ~100 ms (400 MB
 // of page-locked memory, ~1 GB of device memory, the frees synchronise the device) - more than a small file
-// takes to decode.  At most four idle sets are kept (per process, any device): what a BAM stream's look-ahead uses.
+// takes to decode.  At most eight idle sets are kept (per process, any device): the ring of a text stream.
 struct DevSetPool {
     std::mutex mu;
     std::vector<std::pair<int, DevSet>> idle;
@@ -2431,7 +2440,7 @@ struct DevSetPool {
         s.freed_valid = false;  // (the giver has synchronised its streams)
         {
             std::lock_guard<std::mutex> lk(mu);
-            if (s.cap && idle.size() < 4) {
+            if (s.cap && idle.size() < 8) {
                 idle.emplace_back(device, s);
                 s = DevSet{};
                 return;
@@ -2550,7 +2559,10 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     // Four buffer sets in a ring, settled two pieces behind the one being launched: while the parse stream works on
     // piece k-1 (set-up, row parser, the appends of k-2), the FRONT of piece k - compressed bytes up, inflate and CRC
     // kernels, nothing that depends on another piece - runs on the set's own stream beside piece k-1's front.
-    constexpr int kSets = 4, kLag = 2;
+    // With the host threads taking a share of the pieces (below) the ring is longer: a host piece's parse - and, the
+    // parse stream being in file order, those of the pieces behind it - goes onto the stream when its inflate is done,
+    // at the latest kHostLag pieces later.
+    constexpr int kSets = 8, kHostLag = 5;
     DevSet sets[kSets];
     for (auto& S : sets) S = devset_pool().take(device);
     hipStream_t fstream[kSets] = {};
@@ -2566,7 +2578,14 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     size_t n_timed = 0;
     const auto t_begin = std::chrono::steady_clock::now();
     auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-    std::string trail;  // FTK_DECODE_TIMING=2: one line per settled piece
+    std::string trail;  // FTK_DECODE_TIMING=2: one line per settled piece, and the producer's own steps
+    const bool trail_on = clk.on && atoi(getenv("FTK_DECODE_TIMING")) >= 2;
+    auto mark = [&](int piece, const char* what) {
+        if (!trail_on) return;
+        char line[120];
+        snprintf(line, sizeof line, "  piece %d %s at %.2f ms\n", piece, what, now_ms());
+        trail += line;
+    };
     if (clk.on)
         for (auto& row : tev)
             for (auto& ev : row) (void)hipEventCreate(&ev);
@@ -2601,6 +2620,57 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     // page-locked memory.  FTK_DEVICE_INFLATE=0 keeps the inflate on the host threads (libdeflate / zlib).
     static const bool dev_inflate_env = !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
     const bool dev_inflate = dev_inflate_env && !host_inflate_only;
+    // The host threads inflate pieces beside the GPU: the chip turns fragment rows over at ~30 GB/s of text (one
+    // dependent Huffman chain per block), 14 threads manage ~19 GB/s and have nothing else to do while
+    // the rows are parsed on the device; a host piece's text goes up in one DMA before its parse.  They take the next
+    // piece whenever their previous one is done (one job at a time), so the split follows the two rates.
+    // FTK_TEXT_HOST_SHARE=<n>: every n-th piece instead (0: none, 1: as the threads are free = the default).  Only
+    // with enough threads to keep up (a rank of eight on a 16-core quota has two).
+    static const int host_share_env = [] {
+        const char* e = getenv("FTK_TEXT_HOST_SHARE");
+        return e ? atoi(e) : -1;
+    }();
+    const int host_share = !dev_inflate ? 0 : host_share_env >= 0 ? host_share_env : (n_threads >= 8 ? 1 : 0);
+    const int kLag = host_share > 0 ? kHostLag + 1 : 2;
+    struct PieceMeta {
+        bool on_host = false, eof = false, has_prev = false, back_done = true;
+        size_t total = 0;
+        uint32_t first_skip = 0;
+    } meta[kSets];
+    std::future<int> host_job[kSets];
+    struct JobGuard {  // no job outlives the buffers it works on
+        std::future<int>* j;
+        ~JobGuard() {
+            for (int i = 0; i < kSets; ++i)
+                if (j[i].valid()) (void)j[i].get();
+        }
+    } job_guard{host_job};
+    double t_jobwait = 0, t_upwait = 0;
+    size_t host_inflated = 0;
+    // a GPU piece's compressed bytes go up straight from the (page-locked) read buffer: wait for that copy before the
+    // buffer is touched again
+    hipEvent_t up_done = nullptr;
+    bool up_pending = false;
+    if (buf.pinned && hipEventCreateWithFlags(&up_done, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FTK_ERR_HIP, "cannot create an event");
+    }
+    struct EventGuard { hipEvent_t* e; ~EventGuard() { if (*e) { (void)hipEventSynchronize(*e); (void)hipEventDestroy(*e); } } } up_guard{&up_done};
+    auto buffer_free = [&]() {
+        if (!up_pending) return;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (hipEventSynchronize(up_done) != hipSuccess) (void)hipGetLastError();
+        up_pending = false;
+        t_upwait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    long long piece_off = first_piece_off;  // where buf's first byte lies in the file (-1: unknown)
+    int last_host_set = -1;  // the set of the piece the host threads took last
+    auto host_takes = [&](int k) -> bool {
+        if (host_share <= 0 || k == 0) return false;
+        if (host_share > 1) return (k % host_share) == host_share - 1;
+        return last_host_set < 0 || !host_job[last_host_set].valid() ||
+               host_job[last_host_set].wait_for(std::chrono::seconds(0)) == std::future_status::ready;
+    };
 
     // one contig run of a piece: n rows at the given column pointers (device or host)
     auto take_run = [&](const std::string& name, const int32_t* s0, const int32_t* e0, const uint8_t* q0, const uint8_t* t0,
@@ -2736,9 +2806,9 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     };
     // Settle, in file order, every piece up to k whose results are already back, and wait for those that are kLag
     // or more behind (their sets come up for reuse).
-    int settled = 0;
+    int settled = 0, backs = 0;  // pieces settled / pieces whose back is on the parse stream
     auto settle = [&](int k, bool all) -> bool {
-        while (settled <= k) {
+        while (settled <= k && settled < backs) {
             DevSet& Q = sets[settled % kSets];
             if (Q.pending) {
                 const bool must = all || settled <= k - kLag;
@@ -2753,6 +2823,67 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
                 if (!collect(Q)) return false;
             }
             ++settled;
+        }
+        return true;
+    };
+    // The back of piece j (the parse stream, piece after piece): a host piece's text up first (on the set's own stream,
+    // behind the appends that read the set last), then carry from the previous piece, line ends, rows.
+    auto submit_back = [&](int j) -> bool {
+        const int sj = j % kSets;
+        DevSet& S = sets[sj];
+        PieceMeta& M = meta[sj];
+        DevSet* P = M.has_prev ? &sets[(j - 1) % kSets] : nullptr;
+        bool ok = true;
+        if (M.on_host) {
+            hipStream_t front = fstream[sj];
+            const auto t0 = std::chrono::steady_clock::now();
+            const int jrc = host_job[sj].valid() ? host_job[sj].get() : (int)FTK_OK;
+            t_jobwait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (jrc != FTK_OK) return fail(FTK_ERR_FORMAT, "BGZF inflate failed or block CRC mismatch (host share of a device stream)");
+            ok = (!S.freed_valid || hipStreamWaitEvent(front, S.freed, 0) == hipSuccess) &&
+                 (!clk.on || hipEventRecord(tev[sj][0], front) == hipSuccess) &&
+                 hipMemsetAsync(S.d_ist, 0, sizeof(ftk::InflateStatus), front) == hipSuccess &&
+                 (M.total == 0 || hipMemcpyAsync(S.d_text + ftk::kTextCarryMax, S.h_text + ftk::kTextCarryMax, M.total,
+                                                 hipMemcpyHostToDevice, front) == hipSuccess) &&
+                 (!clk.on || (hipEventRecord(tev[sj][4], front) == hipSuccess && hipEventRecord(tev[sj][1], front) == hipSuccess)) &&
+                 hipEventRecord(S.front, front) == hipSuccess;
+        }
+        ok = ok && hipMemsetAsync(S.d_sum, 0, sizeof(ftk::TextSummary), pstream) == hipSuccess &&
+             hipStreamWaitEvent(pstream, S.front, 0) == hipSuccess && (!clk.on || hipEventRecord(tev[sj][2], pstream) == hipSuccess);
+        if (ok) {
+            ftk::textparse_launch_inflated(pstream, S.d_text, ftk::kTextCarryMax, (uint32_t)M.total, P ? P->d_text : nullptr,
+                                           P ? P->d_sum : nullptr, M.first_skip, M.eof, bed6, S.d_blocks, S.d_lines, S.max_lines,
+                                           S.d_s, S.d_e, S.d_q, S.d_t, S.d_sum);
+            ok = hipGetLastError() == hipSuccess &&
+                 hipMemcpyAsync(S.h_sum, S.d_sum, sizeof(ftk::TextSummary), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
+                 hipMemcpyAsync(S.h_ist, S.d_ist, sizeof(ftk::InflateStatus), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
+                 (S.n_tab == 0 || hipMemcpyAsync(S.h_crc, S.d_crc, S.n_tab * 4, hipMemcpyDeviceToHost, pstream) == hipSuccess) &&
+                 (!clk.on || hipEventRecord(tev[sj][3], pstream) == hipSuccess) && hipEventRecord(S.done, pstream) == hipSuccess;
+        }
+        if (ok && P) {
+            // the previous piece's text has been read (the carry): its set may take a new piece behind THIS point,
+            // wherever the piece itself was settled
+            P->freed_valid = hipEventRecord(P->freed, pstream) == hipSuccess;
+            ok = P->freed_valid;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            return fail(FTK_ERR_HIP, "cannot launch the device row parser");
+        }
+        S.pending = true;
+        M.back_done = true;
+        return true;
+    };
+    // backs up to piece k, in file order; a host piece whose job is still running holds them up until it is kHostLag
+    // pieces behind (or `all`)
+    auto submit_backs = [&](int k, bool all) -> bool {
+        while (backs <= k) {
+            const int sj = backs % kSets;
+            if (!all && meta[sj].on_host && backs > k - kHostLag && host_job[sj].valid() &&
+                host_job[sj].wait_for(std::chrono::seconds(0)) != std::future_status::ready)
+                break;
+            if (!meta[sj].back_done && !submit_back(backs)) return false;
+            ++backs;
         }
         return true;
     };
@@ -2792,13 +2923,20 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             }
             // h_text also stages the piece's COMPRESSED bytes on their way up: many tiny blocks (or small ISIZE
             // trailers) make `used` larger than the text, so the buffer is sized for whichever is larger
-            if (!S.ensure(std::max(ftk::kTextCarryMax + total + 64, used + 64)) || !S.ensure_inflate(used, blocks.size()))
+            const bool to_host = host_takes(k);
+            // a GPU piece goes up straight from the read buffer when that is page-locked; the host threads work on their
+            // own copy of theirs, which they read from the file (page cache) themselves when its offset is known
+            const bool direct = buf.pinned && up_done && !to_host;
+            const bool job_reads = to_host && piece_off >= 0;
+            if (!S.ensure(std::max(ftk::kTextCarryMax + total + 64, used + 64)) || !S.ensure_inflate(used, blocks.size()) ||
+                (to_host && !S.ensure_host_comp(used + 64)))
                 return fail(FTK_ERR_OOM, "out of page-locked / device memory for the text piece");
             clk.lap(5);
-            {
+            mark(k, to_host ? "(host) blocks listed, buffers ready" : "blocks listed, buffers ready");
+            if (!direct && !job_reads) {
                 const int nt = std::max(1, std::min(n_threads, (int)(used >> 20) + 1));
                 const uint8_t* src = buf.data();
-                uint8_t* dst = S.h_text;
+                uint8_t* dst = to_host ? S.h_comp : S.h_text;
                 parallel_run(nt, [&](int t) {
                     const size_t a = used * (size_t)t / nt, b2 = used * (size_t)(t + 1) / nt;
                     memcpy(dst + a, src + a, b2 - a);
@@ -2814,53 +2952,89 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             S.cut_tail = eof && partial_tail_ok;
             S.inflated = true;
             S.host_only = false;
-            DevSet* P = (k > 0 && sets[(k - 1) % kSets].inflated) ? &sets[(k - 1) % kSets] : nullptr;
+            mark(k, "staged");
+            PieceMeta& M = meta[k % kSets];
+            M = PieceMeta{};
+            M.on_host = to_host;
+            M.eof = eof;
+            M.has_prev = k > 0 && sets[(k - 1) % kSets].inflated;
+            M.back_done = false;
+            M.total = total;
+            M.first_skip = (uint32_t)std::min<size_t>(first_skip, total);
             hipStream_t front = fstream[k % kSets];
-            // front (this set's stream): behind the appends that read the set last, bytes up, inflate, CRC
-            bool ok = (!S.freed_valid || hipStreamWaitEvent(front, S.freed, 0) == hipSuccess) &&
-                      (!clk.on || hipEventRecord(tev[k % kSets][0], front) == hipSuccess) &&
-                      hipMemsetAsync(S.d_ist, 0, sizeof(ftk::InflateStatus), front) == hipSuccess &&
-                      (used == 0 || hipMemcpyAsync(S.d_comp, S.h_text, used, hipMemcpyHostToDevice, front) == hipSuccess) &&
-                      (blocks.empty() || hipMemcpyAsync(S.d_tab, S.h_tab, blocks.size() * sizeof(ftk::InflateBlock),
-                                                        hipMemcpyHostToDevice, front) == hipSuccess);
-            if (ok && clk.on) ok = hipEventRecord(tev[k % kSets][4], front) == hipSuccess;
-            if (ok) {
-                ftk::inflate_launch(front, S.d_comp, S.d_tab, (int)blocks.size(), S.d_text, S.d_ist, S.d_crc);
-                ok = hipGetLastError() == hipSuccess && (!clk.on || hipEventRecord(tev[k % kSets][1], front) == hipSuccess) &&
-                     hipEventRecord(S.front, front) == hipSuccess &&
-                     // back (the parse stream, piece after piece): carry from the previous piece, line ends, rows
-                     hipMemsetAsync(S.d_sum, 0, sizeof(ftk::TextSummary), pstream) == hipSuccess &&
-                     hipStreamWaitEvent(pstream, S.front, 0) == hipSuccess &&
-                     (!clk.on || hipEventRecord(tev[k % kSets][2], pstream) == hipSuccess);
-            }
-            if (ok) {
-                ftk::textparse_launch_inflated(pstream, S.d_text, ftk::kTextCarryMax, (uint32_t)total, P ? P->d_text : nullptr,
-                                               P ? P->d_sum : nullptr, (uint32_t)std::min<size_t>(first_skip, total), eof, bed6,
-                                               S.d_blocks, S.d_lines, S.max_lines, S.d_s, S.d_e, S.d_q, S.d_t, S.d_sum);
-                ok = hipGetLastError() == hipSuccess &&
-                     hipMemcpyAsync(S.h_sum, S.d_sum, sizeof(ftk::TextSummary), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
-                     hipMemcpyAsync(S.h_ist, S.d_ist, sizeof(ftk::InflateStatus), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
-                     (blocks.empty() || hipMemcpyAsync(S.h_crc, S.d_crc, blocks.size() * 4, hipMemcpyDeviceToHost, pstream) == hipSuccess) &&
-                     (!clk.on || hipEventRecord(tev[k % kSets][3], pstream) == hipSuccess) &&
-                     hipEventRecord(S.done, pstream) == hipSuccess;
+            bool ok = true;
+            if (M.on_host) {
+                // (the job owns its block list and works from its own copy of the bytes - the staging above - straight
+                // into the set's page-locked text buffer; CRCs checked like the GPU's pieces)
+                S.n_tab = 0;
+                ++host_inflated;
+                last_host_set = k % kSets;
+                host_job[k % kSets] = std::async(std::launch::async, [bl = blocks, comp = S.h_comp, out = S.h_text + ftk::kTextCarryMax,
+                                                                      nt = std::max(1, n_threads - 2), fd = fileno(fp), used,
+                                                                      off = piece_off, job_reads] {
+                    if (job_reads) {  // its own copy of the compressed bytes, four pread threads
+                        std::atomic<int> bad{0};
+                        std::vector<std::thread> th;
+                        auto part = [&](int t) {
+                            size_t a = used * (size_t)t / 4;
+                            const size_t e = used * (size_t)(t + 1) / 4;
+                            while (a < e) {
+                                const ssize_t r = pread(fd, comp + a, e - a, (off_t)(off + (long long)a));
+                                if (r <= 0) { bad.store(1); return; }
+                                a += (size_t)r;
+                            }
+                        };
+                        for (int t = 1; t < 4; ++t) th.emplace_back(part, t);
+                        part(0);
+                        for (auto& t : th) t.join();
+                        if (bad.load()) return (int)FTK_ERR_IO;
+                    }
+                    return bl.empty() ? (int)FTK_OK : inflate_block_list(comp, bl, nt, out, true, true);
+                });
+            } else {
+                // front (this set's stream): behind the appends that read the set last, bytes up, inflate, CRC
+                // (the compressed bytes go up at once - nothing of the set's previous piece uses d_comp any more - and
+                // only the inflate, which overwrites the text the appends may still read, waits for the set's release)
+                ok = (!clk.on || hipEventRecord(tev[k % kSets][0], front) == hipSuccess) &&
+                     (used == 0 || hipMemcpyAsync(S.d_comp, direct ? buf.data() : S.h_text, used, hipMemcpyHostToDevice, front) == hipSuccess) &&
+                     (!direct || hipEventRecord(up_done, front) == hipSuccess) &&
+                     (!S.freed_valid || hipStreamWaitEvent(front, S.freed, 0) == hipSuccess) &&
+                     hipMemsetAsync(S.d_ist, 0, sizeof(ftk::InflateStatus), front) == hipSuccess &&
+                     (blocks.empty() || hipMemcpyAsync(S.d_tab, S.h_tab, blocks.size() * sizeof(ftk::InflateBlock),
+                                                       hipMemcpyHostToDevice, front) == hipSuccess);
+                if (ok && direct) up_pending = true;
+                if (ok && clk.on) ok = hipEventRecord(tev[k % kSets][4], front) == hipSuccess;
+                if (ok) {
+                    ftk::inflate_launch(front, S.d_comp, S.d_tab, (int)blocks.size(), S.d_text, S.d_ist, S.d_crc);
+                    ok = hipGetLastError() == hipSuccess && (!clk.on || hipEventRecord(tev[k % kSets][1], front) == hipSuccess) &&
+                         hipEventRecord(S.front, front) == hipSuccess;
+                }
             }
             if (!ok) {
                 (void)hipGetLastError();
-                return fail(FTK_ERR_HIP, "cannot launch the device inflate / row parser");
+                return fail(FTK_ERR_HIP, "cannot launch the device inflate");
             }
+            // the backs, in file order: every piece whose text is (about to be) on the device - a host piece when its
+            // job is done, or kHostLag pieces later at the latest
+            mark(k, "front enqueued");
+            if (!submit_backs(k, false)) return false;
             first_skip = 0;
-            S.pending = true;
             clk.lap(1);
+            mark(k, "backs enqueued");
             // this piece is on its way: settle what is back already, and the piece two back in any case (its set is
             // the one piece k+2 stages into)
             if (!settle(k, false)) return false;
             clk.lap(3);
+            mark(k, "settle done");
             if (eof) break;
             const size_t raw_carry_d = n - used;
+            if (piece_off >= 0) piece_off += (long long)used;
+            buffer_free();
             if (raw_carry_d) memmove(buf.data(), buf.data() + used, raw_carry_d);
             clk.lap(5);
             n = fill(buf, raw_carry_d);
             clk.lap(0);
+            mark(k, "next piece read");
             eof = n - raw_carry_d < kStreamPiece;
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -2868,6 +3042,9 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             }
             continue;
         }
+        if (!submit_backs(k - 1, true)) return false;
+        backs = k + 1;  // (this piece goes onto the parse stream right here)
+        meta[k % kSets] = PieceMeta{};
         S.inflated = false;
         if (!S.ensure(carry + total + 2)) return fail(FTK_ERR_OOM, "out of page-locked / device memory for the text piece");
         if (carry) memcpy(S.h_text, carry_src, carry);
@@ -2941,12 +3118,14 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             if (stop) return false;
         }
     }
-    if (!settle(k, true)) return false;  // the pieces still in flight, in file order
+    if (!submit_backs(k, true) || !settle(k, true)) return false;  // the pieces still in flight, in file order
     clk.lap(3);
     if (have_cur && !emit_device(std::move(cur))) return false;
     clk.lap(4);
     clk.report("text, device rows (parse = launch, merge = collect)");
-    if (clk.on) fprintf(stderr, "[ftk stream text] %zu pieces parsed on the device, %zu by the host\n", gpu_pieces, host_pieces);
+    if (clk.on)
+        fprintf(stderr, "[ftk stream text] %zu pieces parsed on the device, %zu by the host; %zu inflated by the host threads beside the GPU "
+                        "(waited %.1f ms for them, %.1f ms for pieces' bytes to be up)\n", gpu_pieces, host_pieces, host_inflated, t_jobwait, t_upwait);
     if (clk.on && n_timed)
         fprintf(stderr, "[ftk stream text] device time per piece: front (copy up, inflate, CRC) avg %.2f max %.2f ms, back (set-up, rows) avg %.2f max %.2f ms, %zu pieces\n",
                 front_ms / n_timed, front_max, back_ms / n_timed, back_max, n_timed);

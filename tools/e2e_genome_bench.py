@@ -53,7 +53,7 @@ def main():
     eng = source.get_engine()
     n_win_total = sum(-(-synth.B37_SIZES[c] // 100_000) for c in contigs)
     bases_total = sum(synth.B37_SIZES[c] for c in contigs)
-    for rep in range(2):
+    for rep in range(int(os.environ.get("FTK_E2E_REPS", "2"))):
         t1 = time.perf_counter()
         marks = []
         wait_s = compute_s = 0.0
