@@ -37,6 +37,9 @@ namespace {
 #endif
 constexpr int kRing = FTK_INFLATE_RING, kRingMask = kRing - 1;
 constexpr int kGranShift = kRing >= 8192 ? 11 : 10, kGran = 1 << kGranShift;  // write-behind granule: at most half the ring
+#ifndef FTK_INFLATE_WINDOWED
+#define FTK_INFLATE_WINDOWED 1
+#endif
 #ifndef FTK_INFLATE_DIST_ROOT
 #define FTK_INFLATE_DIST_ROOT 9
 #endif
@@ -45,6 +48,23 @@ constexpr int kFarDist = kRing - 258 - 64;    // matches further back than this 
 static_assert((kRing & (kRing - 1)) == 0 && kGran <= kRing / 2, "the write-behind granule must be at most half the ring");
 static_assert(kFarDist + 258 + 64 <= kRing, "an LDS-to-LDS match must not overwrite its own sources");
 static_assert(kFarDist - 257 >= kGran - 1, "the sources of a far match must already be flushed to HBM");
+
+// Bytes one window of the symbol loop may produce: its literals are stored before its matches copy, up to kWinCap - 1
+// bytes ahead of the write position, and must not land on ring slots an LDS-to-LDS match of the window still reads
+// (>= kFarDist back from ITS start, which is not before the window's): kFarDist + kWinCap < kRing.
+constexpr int kWinCap = kRing - kFarDist - 2;
+static_assert(kFarDist + kWinCap < kRing && kWinCap >= 258, "a window's literals must not overwrite a match's sources");
+static_assert(kFarDist - 256 - kWinCap >= kGran - 1, "the sources of a window's far matches must already be flushed");
+
+__device__ __forceinline__ int wave_incl_scan(int x) {  // inclusive prefix sum over the 64 lanes (DPP)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
 
 struct __align__(16) WaveLds {
     uint8_t ring[kRing];
@@ -86,6 +106,21 @@ struct Bits {
             buf |= (uint64_t)v << cnt;
             cnt += 32;
         }
+    }
+    // absolute position (in bits from the start of the compressed buffer) of the next unread bit
+    __device__ __forceinline__ uint32_t bitpos() const { return widx * 32u - (uint32_t)cnt; }
+    __device__ __forceinline__ void seek(uint32_t bp, int lane) {  // afterwards 33 .. 64 valid bits from bit bp on
+        const uint32_t w0 = bp >> 5;
+        if (w0 - cbase > 62u) {  // (also w0 < cbase: a refill moved the cache past bits still in the buffer)
+            cbase = w0;
+            load_cache(lane);
+        }
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)cache, (int)(w0 - cbase));
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)cache, (int)(w0 + 1u - cbase));
+        const int sh = (int)(bp & 31u);
+        buf = (((uint64_t)hi << 32) | lo) >> sh;
+        cnt = 64 - sh;
+        widx = w0 + 2u;
     }
     __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)buf & ((1u << n) - 1u); }
     __device__ __forceinline__ void drop(int n) { buf >>= n; cnt -= n; }
@@ -229,6 +264,24 @@ __device__ __forceinline__ int decode_long(const WaveLds& L, Bits& b, int which)
     return -1;
 }
 
+#ifdef FTK_INFLATE_PROFILE
+// tools/inflate_symbol_cost.py (library built with -DFTK_INFLATE_TIMING -DFTK_INFLATE_PROFILE): shader-clock cycles the
+// waves spent in each section of the symbol loop, and how often they went through it
+__device__ unsigned long long g_prof[32];
+#define PROF_DECL unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = 0
+#define PROF(i, dep)                                                                                                   \
+    {                                                                                                                  \
+        unsigned long long t_;                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(dep)::"memory"); \
+        prof_acc[i] += t_ - prof_last;                                                                                 \
+        prof_n[i] += 1;                                                                                                \
+        prof_last = t_;                                                                                                \
+    }
+#else
+#define PROF_DECL
+#define PROF(i, dep)
+#endif
+
 #ifdef FTK_INFLATE_TIMING
 // tools/inflate_block_times.py builds the library with this: start / end of every block's wavefront (100 MHz ticks)
 __device__ unsigned long long g_block_ticks[2 * 65536];
@@ -260,6 +313,12 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
     const uint32_t A_end = out_off + out_len;
     unsigned err = kInflateOk;
     bool final_seen = false;
+    PROF_DECL;
+#ifdef FTK_INFLATE_PROFILE
+    int lane_dep = lane;
+    PROF(7, lane_dep);
+    prof_acc[7] = 0;
+#endif
 
     // write-behind: granule g = absolute [g * kGran, (g + 1) * kGran), clipped to this block's range
     auto flush = [&](uint32_t g) {
@@ -371,7 +430,162 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
             A += n;
             if ((A >> kGranShift) != (A0 >> kGranShift)) flush(A0 >> kGranShift);
         };
+#if FTK_INFLATE_WINDOWED
+        uint32_t bp = b.bitpos();  // the windows work from the absolute bit position; `b` follows when the serial path needs it
+        bool b_moved = false;
+#endif
         for (;;) {
+            PROF(7, lane_dep);  // (whatever ran since the last mark: the serial path, the loop's bookkeeping)
+#if FTK_INFLATE_WINDOWED
+            // ---- a window of symbols at once.  Every lane decodes, COMPLETELY and on the vector unit, the symbol that
+            // would start at its bit offset: one or two literals, or a match with its extra bits and its distance (a
+            // second gather, from the distance table, at the offset the length code ends at).  Each lane builds its
+            // own 64 bits from three words of the input cache (ds_bpermute), so all 64 offsets are good and a window
+            // consumes 64 bits or more - no scalar bit buffer, no refill.  What is left for the scalar unit - one per
+            // CU, shared by all its waves, and what bounds this kernel - is the chain through the bit lengths:
+            // v_readlane, test, add, test per symbol of ANY kind.  Then: a prefix sum of the output lengths of the
+            // lanes on the chain gives every symbol its place; the literal lanes store their bytes; the matches copy
+            // in stream order (each may read what the one before it wrote).  A symbol the window cannot take - a code
+            // longer than a table's root, end of block, a distance outside the block, output beyond kWinCap bytes or
+            // the block's end - ends the window in front of it; when it is the first, the serial path below takes it.
+            if (b_moved) {
+                bp = b.bitpos();
+                b_moved = false;
+            }
+            unsigned e;
+            {
+                if ((bp >> 5) - b.cbase > 59u) {  // the lanes need words (bp >> 5) .. ((bp + 63) >> 5) + 2 of the cache
+                    b.cbase = bp >> 5;
+                    b.load_cache(lane);
+                }
+                PROF(0, lane_dep);  // cache
+                const uint32_t bo = bp + (uint32_t)lane;
+                const int wi = (int)(((bo >> 5) - b.cbase) << 2);
+                const unsigned c_lo = (unsigned)__builtin_amdgcn_ds_bpermute(wi, (int)b.cache);
+                const unsigned c_mid = (unsigned)__builtin_amdgcn_ds_bpermute(wi + 4, (int)b.cache);
+                const unsigned c_hi = (unsigned)__builtin_amdgcn_ds_bpermute(wi + 8, (int)b.cache);
+                const unsigned sh = bo & 31u;
+                const unsigned w0 = __builtin_amdgcn_alignbit(c_mid, c_lo, sh), w1 = __builtin_amdgcn_alignbit(c_hi, c_mid, sh);
+                const unsigned E = L.pair[w0 & ((1u << kLitRoot) - 1u)];
+                const unsigned k1 = (E >> 5) & 3u, lb = E & 31u, lbase = (E >> 8) & 511u, xb = (E >> 20) & 7u;
+                const unsigned wl = __builtin_amdgcn_alignbit(w1, w0, lb);  // (behind the length code: 5 + 9 + 13 bits at most)
+                const unsigned mlen = lbase + (wl & ((1u << xb) - 1u));
+                const unsigned wd = wl >> xb;
+                const unsigned D = L.dist[wd & ((1u << kDistRoot) - 1u)];
+                const unsigned dbits = D & 15u, dxb = (D >> 4) & 15u, dbase = D >> 8;
+                const unsigned mdist = dbase + ((wd >> dbits) & ((1u << dxb) - 1u));
+                const bool is_match = k1 == 0u && lbase != 0u && lbase != 511u && D != 0u && dbase != 0x7fffffu;
+                unsigned kind = is_match ? 3u : k1;  // 0: end of block, a long code, no such symbol
+                unsigned NB = kind ? (is_match ? lb + xb + dbits + dxb : lb) : 0u;
+                PROF(1, NB);  // the lanes' bits, the two gathers and the decode
+                unsigned mark, t;
+                int pos;
+                asm volatile(
+                    "s_mov_b32 %[pos], 0\n\t"
+                    "v_mov_b32 %[mark], 0\n"
+                    "1:\n\t"
+                    "v_readlane_b32 %[t], %[NB], %[pos]\n\t"
+                    "s_cmp_eq_u32 %[t], 0\n\t"
+                    "s_cbranch_scc1 2f\n\t"
+                    "v_cmp_eq_u32 vcc, %[pos], %[lane]\n\t"
+                    "v_cndmask_b32 %[mark], %[mark], %[kind], vcc\n\t"
+                    "s_add_i32 %[pos], %[pos], %[t]\n\t"
+                    "s_cmp_lt_u32 %[pos], 64\n\t"
+                    "s_cbranch_scc1 1b\n"
+                    "2:\n\t"
+                    : [pos] "=&s"(pos), [mark] "=&v"(mark), [t] "=&s"(t)
+                    : [NB] "v"(NB), [lane] "v"(lane), [kind] "v"(kind)
+                    : "vcc", "scc");
+                PROF(2, mark);  // the chain
+                pos = UNI(pos);
+                const uint64_t on = __ballot(mark != 0u);
+                if (on) {
+                    const int olen = mark == 3u ? (int)mlen : (int)mark;
+                    const int inc = wave_incl_scan(olen);
+                    const uint32_t off = (uint32_t)(inc - olen);
+                    const uint32_t room = min((uint32_t)kWinCap, A_end - A);
+                    // the first symbol that does not fit or points outside the block ends the window in front of it
+                    const uint64_t bad = __ballot(mark != 0u && ((uint32_t)inc > room || (mark == 3u && mdist > (A - out_off) + off)));
+                    uint32_t T;
+                    if (bad) {
+                        const int cut = __ffsll((unsigned long long)bad) - 1;
+                        if (lane >= cut) mark = 0u;
+                        pos = cut;
+                        T = (uint32_t)__builtin_amdgcn_readlane((int)off, cut);
+                    } else {
+                        T = (uint32_t)__builtin_amdgcn_readlane(inc, 63);
+                    }
+                    if (T) {
+                        if (mark == 1u || mark == 2u) {
+                            const uint32_t at = A + off;
+                            L.ring[at & kRingMask] = (uint8_t)(E >> 8);
+                            if (mark == 2u) L.ring[(at + 1u) & kRingMask] = (uint8_t)(E >> 20);
+                        }
+                        // the matches, in stream order; what kind of copy each needs was worked out by its lane
+                        const unsigned ccase = (mdist >= mlen && mlen <= 64u && mdist <= (unsigned)kFarDist) ? 0u
+                                               : mdist <= (unsigned)kFarDist                                ? 1u
+                                                                                                            : 2u;
+                        const unsigned lenc = mlen | (ccase << 16);
+                        const uint32_t M0v = A + off;
+                        PROF(3, mark);  // prefix sum, checks, literal stores
+                        uint64_t mm = __ballot(mark == 3u);
+                        while (mm) {
+                            const int l = __ffsll((unsigned long long)mm) - 1;
+                            mm &= mm - 1ull;
+                            const unsigned lc = (unsigned)__builtin_amdgcn_readlane((int)lenc, l);
+                            const int d = __builtin_amdgcn_readlane((int)mdist, l);
+                            const uint32_t M0 = (uint32_t)__builtin_amdgcn_readlane((int)M0v, l);
+                            const int len = (int)(lc & 0xffffu);
+                            if ((lc >> 16) == 0u) {
+                                // the common case (a row repeats part of an earlier one): one step, sources all older than the match
+                                if (lane < len) {
+                                    const uint32_t a = M0 + (uint32_t)lane;
+                                    L.ring[a & kRingMask] = L.ring[(a - (uint32_t)d) & kRingMask];
+                                }
+                            } else if ((lc >> 16) == 1u) {
+                                // LDS to LDS, period d (see the serial path)
+                                int done = 0, DD = d;
+                                while (done < len) {
+                                    const int n = min(min(len - done, DD), 64);
+                                    if (lane < n) {
+                                        const uint32_t a = M0 + (uint32_t)(done + lane);
+                                        L.ring[a & kRingMask] = L.ring[(a - (uint32_t)DD) & kRingMask];
+                                    }
+                                    done += n;
+                                    if (2 * DD <= done + d) DD *= 2;
+                                }
+                            } else {
+                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                                for (int o = lane; o < len; o += 64) {
+                                    const uint32_t a = M0 + (uint32_t)o;
+                                    L.ring[a & kRingMask] = out[a - (uint32_t)d];
+                                }
+                            }
+                        }
+                        PROF(4, mark);  // the matches' copies
+                        advance(T);
+                        bp += (uint32_t)pos;
+                        PROF(5, mark);  // write-behind
+                        continue;
+                    }
+                }
+                e = (unsigned)__builtin_amdgcn_readlane((int)E, 0);
+                PROF(6, mark);  // a window that was not taken
+            }
+            b.seek(bp, lane);
+            b_moved = true;
+            if (e & 0x60u) {  // (cannot happen unless the block is out of room: the serial path reports it) literal(s) at the front
+                const uint32_t n = (e >> 5) & 3u;
+                if (A + n > A_end) { err = kInflateOverrun; break; }
+                if (lane == 0) {
+                    L.ring[A & kRingMask] = (uint8_t)(e >> 8);
+                    if (n == 2u) L.ring[(A + 1u) & kRingMask] = (uint8_t)(e >> 20);
+                }
+                advance(n);
+                b.drop((int)(e & 31u));
+                continue;
+            }
+#else
             b.refill(lane);
             const unsigned E = L.pair[(unsigned)(b.buf >> lane) & ((1u << kLitRoot) - 1u)];
             const int limit = b.cnt - kLitRoot;
@@ -419,6 +633,7 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
                 b.drop(pos);
             }
             if (e & 0x60u) continue;  // out of valid bits, not of literals
+#endif
             b.refill(lane);  // the symbol at the front is no literal: its code and extra bits take up to 20
             unsigned le = e;  // length entry: bits | base << 8 | extra bits << 20 (base 0: end of block)
             if (e) {
@@ -490,6 +705,14 @@ __global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restr
             if ((A >> kGranShift) != (A0 >> kGranShift)) flush(A0 >> kGranShift);
         }
     }
+#ifdef FTK_INFLATE_PROFILE
+    PROF(7, lane_dep);
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) {
+            atomicAdd(&g_prof[i], prof_acc[i]);
+            atomicAdd(&g_prof[8 + i], prof_n[i]);
+        }
+#endif
     if (err == kInflateOk && A != A_end) err = kInflateShort;
     // the unfinished granule
     if ((A & (kGran - 1)) != 0 || A == out_off) flush(A >> kGranShift);
@@ -574,6 +797,16 @@ __global__ __launch_bounds__(64) void bgzf_crc_kernel(const InflateBlock* __rest
 
 }  // namespace
 
+#ifdef FTK_INFLATE_PROFILE
+extern "C" int ftk_debug_inflate_profile(unsigned long long* out, int reset) {  // out[0..8): cycles, out[8..16): passes
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[32] = {};
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z);
+    }
+    return rc;
+}
+#endif
 #ifdef FTK_INFLATE_TIMING
 extern "C" int ftk_debug_inflate_ticks(unsigned long long* out, int n_blocks) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_ticks), sizeof(unsigned long long) * 2 * (size_t)n_blocks);

@@ -42,6 +42,9 @@ for label, (data, strategy) in cases.items():
     image = m * 64
     out = np.zeros(len(data) * 64, np.uint8)
     got = C.c_int64()
+    if hasattr(eng.lib, "ftk_debug_inflate_profile"):
+        eng.lib.ftk_debug_inflate_profile.argtypes = [C.c_void_p, C.c_int]
+        eng.lib.ftk_debug_inflate_profile(np.zeros(16, np.uint64).ctypes.data, 1)
     for _ in range(2):
         rc = eng.lib.ftk_bgzf_inflate_device(eng.ctx, image, len(image), L.ptr(out), len(out), C.byref(got))
         assert rc == 0, eng.lib.ftk_last_error(eng.ctx)
@@ -50,5 +53,13 @@ for label, (data, strategy) in cases.items():
     assert eng.lib.ftk_debug_inflate_ticks(ticks.ctypes.data, 64) == 0
     t = ticks.reshape(-1, 2).astype(np.int64)
     us = np.median(t[:, 1] - t[:, 0]) / 100.0
+    if hasattr(eng.lib, "ftk_debug_inflate_profile"):
+        prof = np.zeros(16, np.uint64)
+        eng.lib.ftk_debug_inflate_profile.argtypes = [C.c_void_p, C.c_int]
+        assert eng.lib.ftk_debug_inflate_profile(prof.ctypes.data, 1) == 0
+        names = ["refill", "gathers+decode", "chain", "scan+stores", "match copies", "flush+drop", "window not taken", "other"]
+        tot = float(prof[:8].sum())
+        print("   " + "; ".join(f"{nm} {100 * float(prof[i]) / tot:.0f}% ({float(prof[i]) / max(1, int(prof[8 + i])):.0f} cyc x {int(prof[8 + i]) // 128})"
+                                for i, nm in enumerate(names)), f"; {tot / 128 / len(data):.1f} cyc per output byte")
     print(f"{label}: {len(data)} B from {plen} B of payload, block lifetime {us:.0f} us = {us * 1e3 / len(data):.1f} ns per output byte, "
           f"{us * 1e3 / (plen * 8):.2f} ns per payload bit")
