@@ -2664,10 +2664,14 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         t_upwait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     };
     long long piece_off = first_piece_off;  // where buf's first byte lies in the file (-1: unknown)
+    int settled = 0, backs = 0;  // pieces settled / pieces whose back is on the parse stream
     int last_host_set = -1;  // the set of the piece the host threads took last
     auto host_takes = [&](int k) -> bool {
         if (host_share <= 0 || k == 0) return false;
         if (host_share > 1) return (k % host_share) == host_share - 1;
+        // (only with a backlog on the GPU: the first pieces of a stream - all of a small file - are back sooner from the
+        // chip, 3 ms a piece against the threads' 12)
+        if (k - settled < 3) return false;
         return last_host_set < 0 || !host_job[last_host_set].valid() ||
                host_job[last_host_set].wait_for(std::chrono::seconds(0)) == std::future_status::ready;
     };
@@ -2806,7 +2810,6 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     };
     // Settle, in file order, every piece up to k whose results are already back, and wait for those that are kLag
     // or more behind (their sets come up for reuse).
-    int settled = 0, backs = 0;  // pieces settled / pieces whose back is on the parse stream
     auto settle = [&](int k, bool all) -> bool {
         while (settled <= k && settled < backs) {
             DevSet& Q = sets[settled % kSets];
@@ -3620,7 +3623,7 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         const char* e = getenv("FTK_BAM_HOST_SHARE");
         return e ? atoi(e) : -1;
     }();
-    const int host_share = host_share_env >= 0 ? host_share_env : (n_threads >= 8 ? 3 : 0);
+    const int host_share = host_share_env >= 0 ? host_share_env : (n_threads >= 8 ? 6 : 0);
     std::future<int> host_job[kSlots];
     struct JobGuard {  // no job outlives the buffers it works on
         std::future<int>* j;
