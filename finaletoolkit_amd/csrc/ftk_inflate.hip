@@ -8,7 +8,9 @@
 // (ballot-ranked canonical codes, one symbol per lane), the LZ77 copies (up to 64 bytes per step), the input
 // prefetch (256 bytes of the payload per vector load, handed to the bit buffer word by word with v_readlane) and
 // the write-behind of finished output.  The chip is filled by running thousands of such waves side by side:
-// ~10 KB of LDS per wave (kRing = 2048) -> 16 waves per CU.
+// 7.5 KB of LDS per wave (kRing = 2048, 9-bit literal root) -> 20 waves per CU.
+// Since round 3 the symbols themselves are decoded by the lanes too, a window of 64 bit offsets at a time (see the
+// symbol loop): the scalar chain only walks the symbols' bit lengths.
 //
 // Output window.  The last kRing bytes (2 KB by default) of a block's output live in an LDS ring indexed by the
 // absolute output address, so nearly every match (fragment rows repeat the previous line, 30-60 bytes back) is an
@@ -32,8 +34,14 @@ namespace {
 #ifndef FTK_INFLATE_RING
 #define FTK_INFLATE_RING 2048
 #endif
+// Root of the literal / length look-up: 9 bits = a 2 KB pair table, 7.5 KB of LDS per wave, 20 waves per CU (then the
+// 87 VGPRs bound it).  With the windowed symbol loop the waves a CU holds set the throughput of a chip-filling launch:
+// 10 bits (4 KB, 17 waves) 9.5 ms per 650 MB of text and 12.7 ms per 590 MB of BAM records, 9 bits 7.6 / 10.4 ms;
+// a launch of fewer blocks than the chip holds is unchanged (3.0 ms: one block's chain).  Forcing 24 waves (78 VGPRs,
+// distance root 8) gains nothing more, 25 waves at 72 VGPRs lose 5 % (tools/inflate_variants.sh).  Codes longer than
+// the root - rare symbols - end a window and take the serial path.
 #ifndef FTK_INFLATE_ROOT
-#define FTK_INFLATE_ROOT 10
+#define FTK_INFLATE_ROOT 9
 #endif
 constexpr int kRing = FTK_INFLATE_RING, kRingMask = kRing - 1;
 constexpr int kGranShift = kRing >= 8192 ? 11 : 10, kGran = 1 << kGranShift;  // write-behind granule: at most half the ring
@@ -74,7 +82,7 @@ struct __align__(16) WaveLds {
     uint32_t dist[1 << kDistRoot];   // code length | extra bits << 4 | base distance << 8 (the first half holds the
                                      // one-symbol uint16 table while it is being built); 0 = longer than the root
     uint16_t pre[1 << kPreRoot];
-    uint16_t sorted[2][288];         // symbols in canonical order (by length, then value): [0] lit/len, [1] distance
+    uint16_t sorted[288 + 32];       // symbols in canonical order (by length, then value): lit/len at 0, distance at 288
     uint16_t cnt[2][16];             // symbols per code length
     uint16_t next_code[16], offs[16];
     uint8_t lens[320 + 19];
@@ -174,7 +182,7 @@ __device__ __forceinline__ bool build_table(WaveLds& L, const uint8_t* lens, int
         }
         if (l) {
             const unsigned c = (unsigned)L.next_code[l] + (unsigned)rank;
-            L.sorted[which][L.offs[l] + rank] = (uint16_t)sym;
+            L.sorted[which * 288 + L.offs[l] + rank] = (uint16_t)sym;
             if (l <= root) {
                 const unsigned rev = __brev(c) >> (32 - l);  // codes are packed most significant bit first
                 const uint16_t e = (uint16_t)((sym << 4) | l);
@@ -255,7 +263,7 @@ __device__ __forceinline__ int decode_long(const WaveLds& L, Bits& b, int which)
         const int count = UNI(L.cnt[which][len]);
         if (code - count < first) {
             b.drop(len);
-            return UNI(L.sorted[which][index + (code - first)]);
+            return UNI(L.sorted[which * 288 + index + (code - first)]);
         }
         index += count;
         first = (first + count) << 1;
@@ -287,7 +295,12 @@ __device__ unsigned long long g_prof[32];
 __device__ unsigned long long g_block_ticks[2 * 65536];
 #endif
 
-__global__ __launch_bounds__(64) void bgzf_inflate_kernel(const uint8_t* __restrict__ comp,
+#ifdef FTK_INFLATE_WAVES
+#define FTK_INFLATE_OCC __attribute__((amdgpu_waves_per_eu(FTK_INFLATE_WAVES, FTK_INFLATE_WAVES)))
+#else
+#define FTK_INFLATE_OCC
+#endif
+__global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const uint8_t* __restrict__ comp,
                                                           const InflateBlock* __restrict__ tab, int n_blocks,
                                                           uint8_t* __restrict__ out, InflateStatus* __restrict__ status) {
     __shared__ WaveLds L;
