@@ -1964,22 +1964,80 @@ struct ftk_fragstream {
     void drain_ahead() {  // before anything else moves the file position
         if (ahead_got.valid()) (void)ahead_got.get();
     }
-    // read the next piece after the `carry` bytes at the front of buf; returns bytes now in buf
-    size_t fill(RawBuf& buf, size_t carry) {
+    // A text stream sends its GPU pieces up straight from the (page-locked) buffer they were read into.  The copy is
+    // asynchronous: the caller hands fill() the event recorded behind it (buf_in_flight), the buffer rests until the
+    // event is done, and the next read goes into one that has rested (up to three rest, so the producer never waits).
+    struct Resting {
+        std::unique_ptr<RawBuf> b;
+        hipEvent_t ev;
+    };
+    std::deque<Resting> resting;
+    std::vector<hipEvent_t> up_events;  // idle events of rested buffers
+    hipEvent_t buf_in_flight = nullptr;
+    hipEvent_t take_up_event() {
+        if (!up_events.empty()) {
+            hipEvent_t e = up_events.back();
+            up_events.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        return e;
+    }
+    void drop_resting() {
+        for (auto& r : resting) {
+            if (hipEventSynchronize(r.ev) != hipSuccess) (void)hipGetLastError();
+            up_events.push_back(r.ev);
+        }
+        resting.clear();
+        if (buf_in_flight) {
+            if (hipEventSynchronize(buf_in_flight) != hipSuccess) (void)hipGetLastError();
+            up_events.push_back(buf_in_flight);
+        }
+        buf_in_flight = nullptr;
+        for (hipEvent_t e : up_events) (void)hipEventDestroy(e);
+        up_events.clear();
+    }
+    // read the next piece after the `carry` bytes at the front of buf (at carry_off of buf when a copy of buf is in
+    // flight and the caller could not move them); returns bytes now in buf
+    size_t fill(RawBuf& buf, size_t carry, size_t carry_off = 0) {
         size_t got;
+        if (buf_in_flight && !ahead_got.valid()) {  // no read-ahead to trade places with: wait for the copy
+            if (hipEventSynchronize(buf_in_flight) != hipSuccess) (void)hipGetLastError();
+            up_events.push_back(buf_in_flight);
+            buf_in_flight = nullptr;
+        }
         if (ahead_got.valid()) {
             got = ahead_got.get();
             if (carry <= kHead) {
-                if (carry) memcpy(ahead.p + kHead - carry, buf.data(), carry);
+                if (carry) memcpy(ahead.p + kHead - carry, buf.data() + carry_off, carry);
                 ahead.head = kHead - carry;
             } else {  // (not with BGZF blocks, which are at most 64 KB)
                 if (!ahead.reserve(carry + kStreamPiece)) return carry;
                 memmove(ahead.p + carry, ahead.p + kHead, got);
-                memcpy(ahead.p, buf.data(), carry);
+                memcpy(ahead.p, buf.data() + carry_off, carry);
                 ahead.head = 0;
             }
             buf.swap(ahead);
+            if (buf_in_flight) {  // the old buffer rests; the next read goes into one that has rested, or a new one
+                resting.push_back({std::unique_ptr<RawBuf>(new RawBuf()), buf_in_flight});
+                resting.back().b->swap(ahead);
+                buf_in_flight = nullptr;
+                ahead.pinned = true;
+                if (resting.size() > 3 || hipEventQuery(resting.front().ev) == hipSuccess) {
+                    if (hipEventSynchronize(resting.front().ev) != hipSuccess) (void)hipGetLastError();
+                    ahead.swap(*resting.front().b);
+                    up_events.push_back(resting.front().ev);
+                    resting.pop_front();
+                } else {
+                    (void)hipGetLastError();  // (not ready is no error)
+                }
+            }
         } else {
+            if (carry && carry_off) memmove(buf.data(), buf.data() + carry_off, carry);
             if (!buf.reserve(buf.head + carry + kStreamPiece)) return carry;
             got = read_piece(buf.data() + carry);
         }
@@ -2043,11 +2101,11 @@ void ftk_fragstream::run_guarded() {
         static const bool dev_bam = !(getenv("FTK_DEVICE_BAM_PARSE") && atoi(getenv("FTK_DEVICE_BAM_PARSE")) == 0) &&
                                     !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
         if (bam && inflate_device >= 0 && dev_bam && have_hip_device()) buf.pinned = ahead.pinned = true;  // (see RawBuf)
-        // (a text stream stages its GPU pieces in the buffer sets' own page-locked memory instead: FTK_TEXT_DIRECT_UP=1
-        // sends them up from a page-locked read buffer like the BAM stream's, which measured slower - the producer then
-        // waits 2-3 ms per piece for the copy before it may read on, with 190 MB text uploads of the host threads'
-        // pieces in the same queues)
-        static const bool text_direct = getenv("FTK_TEXT_DIRECT_UP") && atoi(getenv("FTK_TEXT_DIRECT_UP")) == 1;
+        // a text stream's GPU pieces go up straight from the read buffer too (FTK_TEXT_DIRECT_UP=0: staged in the buffer
+        // sets' own page-locked memory by a copy of the producer's - 0.8 ms per 48 MB piece on 16 threads, and in the
+        // way of the host threads' inflate jobs)
+        static const bool text_direct = !(getenv("FTK_TEXT_DIRECT_UP") && atoi(getenv("FTK_TEXT_DIRECT_UP")) == 0) &&
+                                        !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
         if (!bam && device >= 0 && text_direct && have_hip_device()) buf.pinned = ahead.pinned = true;
     }
     first_piece_off = ftell(fp);
@@ -2647,22 +2705,12 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     } job_guard{host_job};
     double t_jobwait = 0, t_upwait = 0;
     size_t host_inflated = 0;
-    // a GPU piece's compressed bytes go up straight from the (page-locked) read buffer: wait for that copy before the
-    // buffer is touched again
-    hipEvent_t up_done = nullptr;
-    bool up_pending = false;
-    if (buf.pinned && hipEventCreateWithFlags(&up_done, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(FTK_ERR_HIP, "cannot create an event");
-    }
-    struct EventGuard { hipEvent_t* e; ~EventGuard() { if (*e) { (void)hipEventSynchronize(*e); (void)hipEventDestroy(*e); } } } up_guard{&up_done};
-    auto buffer_free = [&]() {
-        if (!up_pending) return;
-        const auto t0 = std::chrono::steady_clock::now();
-        if (hipEventSynchronize(up_done) != hipSuccess) (void)hipGetLastError();
-        up_pending = false;
-        t_upwait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    };
+    // (a GPU piece's compressed bytes go up straight from the page-locked read buffer; fill() lets that buffer rest
+    // until the copy is done - see buf_in_flight)
+    struct RestGuard {
+        ftk_fragstream* s;
+        ~RestGuard() { s->drop_resting(); }
+    } rest_guard{this};  // (waits for the copies that still read a resting buffer)
     long long piece_off = first_piece_off;  // where buf's first byte lies in the file (-1: unknown)
     int settled = 0, backs = 0;  // pieces settled / pieces whose back is on the parse stream
     int last_host_set = -1;  // the set of the piece the host threads took last
@@ -2929,7 +2977,8 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             const bool to_host = host_takes(k);
             // a GPU piece goes up straight from the read buffer when that is page-locked; the host threads work on their
             // own copy of theirs, which they read from the file (page cache) themselves when its offset is known
-            const bool direct = buf.pinned && up_done && !to_host;
+            hipEvent_t up_ev = (buf.pinned && !to_host) ? take_up_event() : nullptr;
+            const bool direct = up_ev != nullptr;
             const bool job_reads = to_host && piece_off >= 0;
             if (!S.ensure(std::max(ftk::kTextCarryMax + total + 64, used + 64)) || !S.ensure_inflate(used, blocks.size()) ||
                 (to_host && !S.ensure_host_comp(used + 64)))
@@ -3000,12 +3049,12 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
                 // only the inflate, which overwrites the text the appends may still read, waits for the set's release)
                 ok = (!clk.on || hipEventRecord(tev[k % kSets][0], front) == hipSuccess) &&
                      (used == 0 || hipMemcpyAsync(S.d_comp, direct ? buf.data() : S.h_text, used, hipMemcpyHostToDevice, front) == hipSuccess) &&
-                     (!direct || hipEventRecord(up_done, front) == hipSuccess) &&
+                     (!direct || hipEventRecord(up_ev, front) == hipSuccess) &&
                      (!S.freed_valid || hipStreamWaitEvent(front, S.freed, 0) == hipSuccess) &&
                      hipMemsetAsync(S.d_ist, 0, sizeof(ftk::InflateStatus), front) == hipSuccess &&
                      (blocks.empty() || hipMemcpyAsync(S.d_tab, S.h_tab, blocks.size() * sizeof(ftk::InflateBlock),
                                                        hipMemcpyHostToDevice, front) == hipSuccess);
-                if (ok && direct) up_pending = true;
+                if (direct) buf_in_flight = up_ev;  // (fill() parks the buffer behind it; an unrecorded event reads as done)
                 if (ok && clk.on) ok = hipEventRecord(tev[k % kSets][4], front) == hipSuccess;
                 if (ok) {
                     ftk::inflate_launch(front, S.d_comp, S.d_tab, (int)blocks.size(), S.d_text, S.d_ist, S.d_crc);
@@ -3032,10 +3081,10 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             if (eof) break;
             const size_t raw_carry_d = n - used;
             if (piece_off >= 0) piece_off += (long long)used;
-            buffer_free();
-            if (raw_carry_d) memmove(buf.data(), buf.data() + used, raw_carry_d);
+            // (with a copy of buf in flight the carried bytes are only read here: fill() moves them into the next buffer)
+            if (raw_carry_d && !buf_in_flight) memmove(buf.data(), buf.data() + used, raw_carry_d);
             clk.lap(5);
-            n = fill(buf, raw_carry_d);
+            n = fill(buf, raw_carry_d, buf_in_flight ? used : 0);
             clk.lap(0);
             mark(k, "next piece read");
             eof = n - raw_carry_d < kStreamPiece;
