@@ -1351,44 +1351,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 // array for the depth + LDS counters for the ends, DPP scan, 1 KB-contiguous
 // float64 stores.  Fragments are selected like frag_array(start, stop, "any").
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cleavage_kernel(ContigView cv, CleaveParams p, const int64_t* iv_start_,
-                                                       const int64_t* iv_stop_, const int64_t* out_off_,
-                                                       const int32_t* tile_iv, const int32_t* tile_k,
-                                                       double* __restrict__ out) {
-    constexpr int T = kWpsTile, NP = T / 1024;
-    __shared__ __attribute__((aligned(16))) int dd[T];
-    __shared__ __attribute__((aligned(16))) int en[T];
-    __shared__ int pre_s;
-    __shared__ int rng_s[2];
-    __shared__ int wtot[NP][4];
+// One (sub-)tile of TT bases starting at t0.  NARROW: the two LDS arrays hold 16-bit counters, two to a 32-bit word
+// (element 2i in the low half, 2i + 1 in the high half; an atomic add of +-1 or +-65536; the low half read back as
+// int16, the high half as (word - low) >> 16, which undoes the borrow a negative low half takes) - exact while every
+// counter stays inside int16, which fewer than 32 768 candidate fragments guarantee.  8 KB per array instead of 16:
+// the tile of 4 096 bases fits in 16 KB and a CU holds eight blocks instead of four.
+template <bool NARROW, int TT>
+__device__ __forceinline__ void cleave_tile(const ContigView& cv, const CleaveParams& p, long long iv_start, long long iv_stop,
+                                            long long t0, int len_t, int lo, int hi, double* __restrict__ dst, int* dd,
+                                            int* en, int& pre_s, int (*wtot)[4]) {
+    constexpr int NP = TT / 1024, NW = NARROW ? TT / 2 : TT;  // 32-bit words per array
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    long long iv_start, iv_stop, out_off, k;
-    if (tile_iv) {
-        const int iv = tile_iv[blockIdx.x];
-        iv_start = iv_start_[iv]; iv_stop = iv_stop_[iv]; out_off = out_off_[iv]; k = tile_k[blockIdx.x];
-    } else {
-        iv_start = p.start; iv_stop = p.stop; out_off = 0; k = blockIdx.x;
-    }
-    const long long t0 = iv_start + k * T;
-    const int len_t = (int)(min(t0 + (long long)T, iv_stop) - t0);
-    if (tid < 2) {
-        // candidates: fs < t1 and fe >= t0 (a - fragment ending exactly at t0 still puts an end there)
-        const long long q = tid == 0 ? t0 - (long long)p.lmax : t0 + len_t;
-        int r;
-        if (q <= 0) r = 0;
-        else { const long long kb = q >> kBinShift; r = kb >= cv.n_bins ? cv.n : cv.bin_idx[kb + tid]; }
-        rng_s[tid] = r;
-    }
     if (tid == 2) pre_s = 0;
     {
         const int4 z = make_int4(0, 0, 0, 0);
         int4* a4 = reinterpret_cast<int4*>(dd);
         int4* b4 = reinterpret_cast<int4*>(en);
 #pragma unroll
-        for (int j = 0; j < T / 4 / 256; ++j) { a4[j * 256 + tid] = z; b4[j * 256 + tid] = z; }
+        for (int j = 0; j < NW / 4 / 256; ++j) { a4[j * 256 + tid] = z; b4[j * 256 + tid] = z; }
     }
     __syncthreads();
-    const int lo = rng_s[0], hi = rng_s[1];
+    auto add = [&](int* arr, int idx, int v) {
+        if (NARROW) atomicAdd(&arr[idx >> 1], (idx & 1) ? v * 65536 : v);
+        else atomicAdd(&arr[idx], v);
+    };
     for (int i = lo + tid; i < hi; i += 256) {
         const int fs = cv.start[i], fe = cv.end[i], q = cv.mapq[i];
         const int len = fe - fs;
@@ -1397,21 +1383,29 @@ __global__ __launch_bounds__(256) void cleavage_kernel(ContigView cv, CleavePara
         if (cv.r1_start && !((long long)cv.r1_start[i] < iv_stop && (long long)cv.r1_end[i] > iv_start)) continue;
         const long long a = (long long)fs - t0, b = (long long)fe - t0;
         if (b > 0 && a < len_t) {  // covers [max(a,0), min(b,len_t))
-            if (a <= 0) atomicAdd(&pre_s, 1); else atomicAdd(&dd[a], 1);
-            if (b < len_t) atomicAdd(&dd[b], -1);
+            if (a <= 0) atomicAdd(&pre_s, 1); else add(dd, (int)a, 1);
+            if (b < len_t) add(dd, (int)b, -1);
         }
         const long long e = cv.strand[i] ? a : b;
-        if (e >= 0 && e < len_t) atomicAdd(&en[e], 1);
+        if (e >= 0 && e < len_t) add(en, (int)e, 1);
     }
     __syncthreads();
+    // element pair (2i, 2i + 1) of an array, whichever way it is stored
+    auto pair_at = [&](const int* arr, int i) -> int2 {
+        if (NARROW) {
+            const int w = arr[i];
+            const int x = (int)(short)(w & 0xffff);
+            return make_int2(x, (w - x) >> 16);
+        }
+        return reinterpret_cast<const int2*>(arr)[i];
+    };
     int2 va[NP], vb[NP];
     int exa[NP], exb[NP];
-    const int2* d2 = reinterpret_cast<const int2*>(dd);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int ia = j * 512 + wv * 128 + lane;
-        va[j] = d2[ia];
-        vb[j] = d2[ia + 64];
+        va[j] = pair_at(dd, ia);
+        vb[j] = pair_at(dd, ia + 64);
         const int sa = va[j].x + va[j].y, sb2 = vb[j].x + vb[j].y;
         const int ia_incl = wave_incl_scan_dpp(sa);
         const int ib_incl = wave_incl_scan_dpp(sb2);
@@ -1423,9 +1417,7 @@ __global__ __launch_bounds__(256) void cleavage_kernel(ContigView cv, CleavePara
     }
     __syncthreads();
     int base = pre_s;
-    double* dst = out + out_off + k * T;
     const bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
-    const int2* e2 = reinterpret_cast<const int2*>(en);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         int carry = base;
@@ -1438,7 +1430,7 @@ __global__ __launch_bounds__(256) void cleavage_kernel(ContigView cv, CleavePara
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int2 v = h ? vb[j] : va[j];
-            const int2 ends = e2[j * 512 + wv * 128 + h * 64 + lane];
+            const int2 ends = pair_at(en, j * 512 + wv * 128 + h * 64 + lane);
             const int g0 = carry + (h ? exb[j] : exa[j]) + v.x, g1 = g0 + v.y;
             const int i0 = j * 1024 + wv * 256 + h * 128 + 2 * lane;
             // numpy: ends / depth * 100 in float64, 0 where depth == 0 (frag/_cleavage_profile.py:208-210)
@@ -1455,6 +1447,56 @@ __global__ __launch_bounds__(256) void cleavage_kernel(ContigView cv, CleavePara
                 dst[i0] = o0;
             }
         }
+    }
+}
+
+// candidates of the bases [t0, t0 + len_t): fs < t0 + len_t and fe >= t0 (a - fragment ending exactly at t0 still
+// puts an end there)
+__device__ __forceinline__ int cleave_bound(const ContigView& cv, long long q, int which) {
+    if (q <= 0) return 0;
+    const long long kb = q >> kBinShift;
+    return kb >= cv.n_bins ? cv.n : cv.bin_idx[kb + which];
+}
+
+__global__ __launch_bounds__(256) void cleavage_kernel(ContigView cv, CleaveParams p, const int64_t* iv_start_,
+                                                       const int64_t* iv_stop_, const int64_t* out_off_,
+                                                       const int32_t* tile_iv, const int32_t* tile_k,
+                                                       double* __restrict__ out) {
+    constexpr int T = kWpsTile, H = T / 2;
+    // 16 KB for both layouts: 2 x T 16-bit counters, or (a tile with 32 768 candidates or more: ~900x depth,
+    // chrM) 2 x T/2 32-bit counters for one half of the tile after the other
+    __shared__ __attribute__((aligned(16))) int dd[H];
+    __shared__ __attribute__((aligned(16))) int en[H];
+    __shared__ int pre_s;
+    __shared__ int rng_s[2];
+    __shared__ int wtot[T / 1024][4];
+    const int tid = threadIdx.x;
+    long long iv_start, iv_stop, out_off, k;
+    if (tile_iv) {
+        const int iv = tile_iv[blockIdx.x];
+        iv_start = iv_start_[iv]; iv_stop = iv_stop_[iv]; out_off = out_off_[iv]; k = tile_k[blockIdx.x];
+    } else {
+        iv_start = p.start; iv_stop = p.stop; out_off = 0; k = blockIdx.x;
+    }
+    const long long t0 = iv_start + k * T;
+    const int len_t = (int)(min(t0 + (long long)T, iv_stop) - t0);
+    if (tid < 2) rng_s[tid] = cleave_bound(cv, tid == 0 ? t0 - (long long)p.lmax : t0 + len_t, tid);
+    __syncthreads();
+    const int lo = rng_s[0], hi = rng_s[1];
+    double* dst = out + out_off + k * T;
+    if (hi - lo < 32768) {
+        cleave_tile<true, T>(cv, p, iv_start, iv_stop, t0, len_t, lo, hi, dst, dd, en, pre_s, wtot);
+        return;
+    }
+    for (int half = 0; half < 2; ++half) {
+        const long long th = t0 + (long long)half * H;
+        const int len_h = min(len_t - half * H, H);
+        if (len_h <= 0) break;
+        __syncthreads();  // (the arrays and rng_s of the first half are done with)
+        if (tid < 2) rng_s[tid] = cleave_bound(cv, tid == 0 ? th - (long long)p.lmax : th + len_h, tid);
+        __syncthreads();
+        cleave_tile<false, H>(cv, p, iv_start, iv_stop, th, len_h, rng_s[0], rng_s[1], dst + (long long)half * H, dd, en, pre_s,
+                              wtot);
     }
 }
 
