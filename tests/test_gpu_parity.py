@@ -614,6 +614,31 @@ def test_wps_and_cleavage_fuzz(engine, data, seed):
         assert np.array_equal(got, want), ("cleavage", seed, it, lo, hi, q, a2, b2)
 
 
+def test_cleavage_of_a_very_deep_region(engine):
+    """chrM-like depth: 120 000 fragments over 12 kb (> 32 768 candidates per 4 096-base tile, where the kernel's packed
+    16-bit LDS counters would not be exact: those tiles take the 32-bit half-tile path), beside an ordinary region of
+    the same contig (16-bit path), a pile of 70 000 fragment ends on ONE base, and intervals that start inside a tile."""
+    rng = np.random.default_rng(77)
+    deep_s = rng.integers(20_000, 32_000, 120_000)
+    pile_s = np.full(70_000, 50_000)
+    calm_s = rng.integers(60_000, 400_000, 60_000)
+    s = np.concatenate([deep_s, pile_s, calm_s])
+    e = s + np.concatenate([rng.integers(60, 400, len(deep_s)), rng.integers(100, 300, len(pile_s)), rng.integers(60, 400, len(calm_s))])
+    order = np.argsort(s, kind="stable")
+    s, e = s[order].astype(np.int32), e[order].astype(np.int32)
+    q = rng.integers(0, 61, len(s)).astype(np.uint8)
+    st = rng.integers(0, 2, len(s)).astype(np.uint8)
+    st[(s == 50_000)] = 1  # the pile: + strand, so 70 000 ends land on base 50 000
+    engine.load_contig("deep", s, e, q, st)
+    fr = O.Frags(s, e, q, st)
+    for a, b, lo, hi, mq in ((0, 420_000, None, None, 0), (19_000, 36_000, 100, 300, 20), (49_000, 53_000, None, None, 0),
+                             (25_000, 25_001, None, None, 0), (23_456, 31_111, 0, 167, 30)):
+        want = O.c_cleavage(fr, a, b, lo, hi, mq)[2]
+        got = engine.cleavage("deep", a, b, lo, hi, mq)
+        assert np.array_equal(got, want), (a, b, lo, hi, mq)
+    engine.release("deep")
+
+
 def test_one_call_file_loaders(engine, tmp_path):
     """ftk_frags_load_fraggz / ftk_frags_load_bam: file -> HBM in one C call, contig ids in file order."""
     import ctypes as C
