@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
             // own 64 bits from three words of the input cache (ds_bpermute), so all 64 offsets are good and a window
             // consumes 64 bits or more - no scalar bit buffer, no refill.  What is left for the scalar unit - one per
             // CU, shared by all its waves, and what bounds this kernel - is the chain through the bit lengths:
-            // v_readlane, test, add, test per symbol of ANY kind.  Then: a prefix sum of the output lengths of the
+            // v_readlane, add, test per symbol of ANY kind (six instructions a hop, three of them the scalar unit's).  Then: a prefix sum of the output lengths of the
             // lanes on the chain gives every symbol its place; the literal lanes store their bytes; the matches copy
             // in stream order (each may read what the one before it wrote).  A symbol the window cannot take - a code
             // longer than a table's root, end of block, a distance outside the block, output beyond kWinCap bytes or
@@ -489,7 +489,9 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                 const unsigned mdist = dbase + ((wd >> dbits) & ((1u << dxb) - 1u));
                 const bool is_match = k1 == 0u && lbase != 0u && lbase != 511u && D != 0u && dbase != 0x7fffffu;
                 unsigned kind = is_match ? 3u : k1;  // 0: end of block, a long code, no such symbol
-                unsigned NB = kind ? (is_match ? lb + xb + dbits + dxb : lb) : 0u;
+                // (a lane the chain must stop at says 64 bits: the add carries the position out of the window, one test
+                // serves both ends of the loop, and the store of its kind - 0 - marks nothing)
+                unsigned NB = kind ? (is_match ? lb + xb + dbits + dxb : lb) : 64u;
                 PROF(1, NB);  // the lanes' bits, the two gathers and the decode
                 unsigned mark, t;
                 int pos;
@@ -498,19 +500,17 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     "v_mov_b32 %[mark], 0\n"
                     "1:\n\t"
                     "v_readlane_b32 %[t], %[NB], %[pos]\n\t"
-                    "s_cmp_eq_u32 %[t], 0\n\t"
-                    "s_cbranch_scc1 2f\n\t"
                     "v_cmp_eq_u32 vcc, %[pos], %[lane]\n\t"
                     "v_cndmask_b32 %[mark], %[mark], %[kind], vcc\n\t"
                     "s_add_i32 %[pos], %[pos], %[t]\n\t"
                     "s_cmp_lt_u32 %[pos], 64\n\t"
-                    "s_cbranch_scc1 1b\n"
-                    "2:\n\t"
+                    "s_cbranch_scc1 1b\n\t"
                     : [pos] "=&s"(pos), [mark] "=&v"(mark), [t] "=&s"(t)
                     : [NB] "v"(NB), [lane] "v"(lane), [kind] "v"(kind)
                     : "vcc", "scc");
                 PROF(2, mark);  // the chain
                 pos = UNI(pos);
+                if ((unsigned)UNI(t) == 64u) pos -= 64;  // stopped in front of a lane, not beyond the window
                 const uint64_t on = __ballot(mark != 0u);
                 if (on) {
                     const int olen = mark == 3u ? (int)mlen : (int)mark;
@@ -542,7 +542,40 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         const uint32_t M0v = A + off;
                         PROF(3, mark);  // prefix sum, checks, literal stores
                         uint64_t mm = __ballot(mark == 3u);
-                        if (mm) {
+                        if (mm && __ballot(mark == 3u && ccase != 0u) == 0ull) {
+                            // Every match of the window is of the common kind (one step, LDS to LDS): the loop without
+                            // the kind test and without touching EXEC - the lanes beyond a match's length read and
+                            // write a spare LDS byte instead (the code-length array, idle while symbols are decoded).
+                            // 17 instructions a match, five of them the scalar unit's (find-first, clear, wait, test,
+                            // branch); the loop below spends nine there.
+                            unsigned lc, md, m0, va, vs, vx;
+                            int l;
+                            const unsigned spare = (unsigned)offsetof(WaveLds, lens);
+                            asm volatile(
+                                "1:\n\t"
+                                "s_ff1_i32_b64 %[l], %[mm]\n\t"
+                                "s_bitset0_b64 %[mm], %[l]\n\t"
+                                "v_readlane_b32 %[lc], %[lenc], %[l]\n\t"
+                                "v_readlane_b32 %[md], %[mdist], %[l]\n\t"
+                                "v_readlane_b32 %[m0], %[M0v], %[l]\n\t"
+                                "v_cmp_gt_u32 vcc, %[lc], %[lane]\n\t"
+                                "v_add_u32 %[va], %[m0], %[lane]\n\t"
+                                "v_subrev_u32 %[vs], %[md], %[va]\n\t"
+                                "v_and_b32 %[vs], %[mask], %[vs]\n\t"
+                                "v_and_b32 %[va], %[mask], %[va]\n\t"
+                                "v_cndmask_b32 %[vs], %[spare], %[vs], vcc\n\t"
+                                "v_cndmask_b32 %[va], %[spare], %[va], vcc\n\t"
+                                "ds_read_u8 %[vx], %[vs]\n\t"
+                                "s_waitcnt lgkmcnt(0)\n\t"
+                                "ds_write_b8 %[va], %[vx]\n\t"
+                                "s_cmp_lg_u64 %[mm], 0\n\t"
+                                "s_cbranch_scc1 1b\n\t"
+                                : [mm] "+s"(mm), [lc] "=&s"(lc), [md] "=&s"(md), [m0] "=&s"(m0), [l] "=&s"(l), [va] "=&v"(va),
+                                  [vs] "=&v"(vs), [vx] "=&v"(vx)
+                                : [lenc] "v"(lenc), [mdist] "v"(mdist), [M0v] "v"(M0v), [lane] "v"(lane), [mask] "i"(kRingMask),
+                                  [spare] "v"(spare)  // (a VGPR: with VCC the instruction may read no other scalar)
+                                : "vcc", "scc", "memory");
+                        } else if (mm) {
                             for (;;) {
                                 // The common matches (one step, LDS to LDS) in stream order, written out: 19 instructions
                                 // each (find-first, clear, three v_readlane, test, lane mask, two addresses, read, wait,
