@@ -299,3 +299,62 @@ def test_lines_longer_than_the_device_carry(tmp_path, where):
     for piece in (1 << 16, 1 << 20, 48 << 20):
         out = _child(p, threads=4, FTK_STREAM_PIECE=str(piece))
         assert "['L0', 'L1', 'L2']" in out, out
+
+
+def _many_contig_file(tmp_path, name="hs.frag.gz", rows_per_contig=60_000, n_contigs=5, seed=9):
+    rng = np.random.default_rng(seed)
+    lines = []
+    for c in range(n_contigs):
+        s = np.sort(rng.integers(0, 40_000_000, rows_per_contig))
+        e = s + rng.integers(30, 600, rows_per_contig)
+        q = rng.integers(0, 61, rows_per_contig)
+        t = rng.integers(0, 2, rows_per_contig)
+        lines += [f"c{c}\t{a}\t{b}\t{m}\t{'+' if k else '-'}\n" for a, b, m, k in zip(s.tolist(), e.tolist(), q.tolist(), t.tolist())]
+    p = str(tmp_path / name)
+    bgzf.write_bgzf(p, "".join(lines).encode())
+    return p
+
+
+@pytest.mark.parametrize("mode", [dict(FTK_TEXT_HOST_SHARE="2"), dict(FTK_TEXT_HOST_SHARE="1"), dict(FTK_TEXT_HOST_SHARE="0"),
+                                  dict(FTK_TEXT_HOST_SHARE="3", FTK_TEXT_DIRECT_UP="0"), dict(FTK_TEXT_DIRECT_UP="0")])
+def test_text_pieces_shared_with_the_host_threads(tmp_path, mode):
+    """A text stream of ~40 pieces of 64 KB: every second / third piece (or whichever the idle host threads take)
+    inflated by the host threads beside the GPU with the backs of the pieces behind it deferred, compressed bytes sent
+    up from resting read buffers or staged by a copy - the rows are those of the whole-file decoder in every mode."""
+    p = _many_contig_file(tmp_path)
+    out = _child(p, threads=8, contig="c3", FTK_STREAM_PIECE="65536", FTK_DECODE_TIMING="1", **mode)
+    assert "['c0', 'c1', 'c2', 'c3', 'c4']" in out
+    share = mode.get("FTK_TEXT_HOST_SHARE", "1")
+    took = [int(line.split(";")[1].split()[0]) for line in out.splitlines() if "inflated by the host threads" in line]
+    assert took, out[-2000:]
+    if share in ("2", "3"):
+        assert took[0] >= 10, took  # (the whole-file pass: every 2nd / 3rd of ~40 pieces)
+    if share == "0":
+        assert took[0] == 0, took
+
+
+@pytest.mark.parametrize("share", ["0", "2"])
+def test_text_stream_with_a_damaged_block_is_an_error(tmp_path, share):
+    """One flipped payload byte in the middle of a fragment file: whichever side inflates that piece - the GPU (CRC
+    kernel) or the host threads (libdeflate + CRC) - the stream ends with a format error."""
+    good = _many_contig_file(tmp_path, "good.frag.gz", rows_per_contig=20_000, n_contigs=3)
+    image = bytearray(open(good, "rb").read())
+    off, blocks = 0, []
+    while off < len(image):
+        bs = int.from_bytes(image[off + 16:off + 18], "little") + 1
+        blocks.append((off, bs))
+        off += bs
+    env = dict(FTK_STREAM_PIECE="65536", FTK_TEXT_HOST_SHARE=share)
+    _child(good, threads=8, **env)
+    for which in (len(blocks) // 2, len(blocks) // 2 + 1, len(blocks) // 2 + 2, len(blocks) // 2 + 3):  # (pieces of either side)
+        img = bytearray(image)
+        o, bs = blocks[which]
+        img[o + 18 + (bs - 26) // 2] ^= 0x5A
+        bad = str(tmp_path / f"bad{which}.frag.gz")
+        open(bad, "wb").write(bytes(img))
+        code = ("import sys\nsys.path.insert(0, %r)\nfrom tests.test_gpu_device_parse import _stream_device\n"
+                "try:\n    _stream_device(sys.argv[1], threads=8)\n    print('decoded')\n"
+                "except RuntimeError as e:\n    print('error', e)\n" % ROOT)
+        r = subprocess.run([sys.executable, "-c", code, bad], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.startswith("error"), (which, r.stdout, r.stderr[-1500:])
+        assert str(L.FTK_ERR_FORMAT) in r.stdout, r.stdout
