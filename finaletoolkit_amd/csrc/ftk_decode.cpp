@@ -2324,7 +2324,9 @@ namespace {
 // One of the two buffer sets of the device row parser: page-locked host text (the inflate target and the
 // DMA source), the device copy, the kernels' scratch and outputs, and the summary that comes back.
 struct DevSet {
-    uint8_t* h_text = nullptr;
+    uint8_t* h_text = nullptr;  // page-locked twin of d_text: only where the host touches a piece's text (its own share
+                                // of the inflate, a piece of odd rows, the host-parse streams) - see ensure_host_text
+    size_t h_text_cap = 0;
     uint8_t* d_text = nullptr;
     size_t cap = 0, max_lines = 0;
     uint32_t *d_blocks = nullptr, *d_lines = nullptr;
@@ -2397,6 +2399,7 @@ struct DevSet {
         release_inflate();
         release_bam();
         if (h_text) (void)hipHostFree(h_text);
+        h_text_cap = 0;
         if (h_sum) (void)hipHostFree(h_sum);
         for (void* q : {(void*)d_text, (void*)d_blocks, (void*)d_lines, (void*)d_s, (void*)d_e, (void*)d_q, (void*)d_t, (void*)d_sum})
             if (q) (void)hipFree(q);
@@ -2450,13 +2453,29 @@ struct DevSet {
         }
         return ok;
     }
+    // page-locked room for `bytes` of text on the host side (page-locking 250 MB takes ~25 ms: a text stream whose
+    // pieces stay on the device never pays it - the first whole-genome pass of a process spent 0.2 s here for its
+    // eight sets)
+    bool ensure_host_text(size_t bytes) {
+        if (bytes <= h_text_cap) return true;
+        if (h_text) (void)hipHostFree(h_text);
+        h_text = nullptr;
+        h_text_cap = std::max(bytes + bytes / 4 + 4096, cap);
+        if (hipHostMalloc((void**)&h_text, h_text_cap, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            h_text = nullptr;
+            h_text_cap = 0;
+            return false;
+        }
+        return true;
+    }
     // room for `bytes` of text; false: out of (page-locked or device) memory
-    bool ensure(size_t bytes) {
-        if (bytes <= cap) return true;
+    bool ensure(size_t bytes, bool with_host_text = true) {
+        if (bytes <= cap) return !with_host_text || ensure_host_text(bytes);
         release();
         const size_t want = bytes + bytes / 4 + 4096;
         const size_t lines = want / 10 + 1;  // a plain row is at least 10 bytes; more lines -> the host parses the piece
-        bool ok = hipHostMalloc((void**)&h_text, want, hipHostMallocDefault) == hipSuccess &&
+        bool ok = (!with_host_text || ensure_host_text(want)) &&
                   hipHostMalloc((void**)&h_sum, sizeof(ftk::TextSummary), hipHostMallocDefault) == hipSuccess &&
                   hipMalloc((void**)&d_text, want) == hipSuccess &&
                   hipMalloc((void**)&d_blocks, (want / ftk::kTextBlockBytes + 2) * 4) == hipSuccess &&
@@ -2515,7 +2534,7 @@ struct DevSetPool {
         size_t n = 0;
         for (auto& d : drop) {
             (void)hipSetDevice(d.first);
-            n += 2 * d.second.cap + d.second.h_comp_cap + d.second.comp_cap;
+            n += d.second.cap + d.second.h_text_cap + d.second.h_comp_cap + d.second.comp_cap;
             d.second.release();
         }
         return n;
@@ -2783,6 +2802,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             }
             // anything but plain rows: the host's field-rule parser reads the text (copied back for this piece only)
             ++host_pieces;
+            if (!S.ensure_host_text(sum.text_len + 64)) return fail(FTK_ERR_OOM, "out of page-locked memory for a text piece");
             if (hipMemcpyAsync(S.h_text, S.d_text + sum.text_off, sum.text_len, hipMemcpyDeviceToHost, pstream) != hipSuccess ||
                 hipStreamSynchronize(pstream) != hipSuccess) {
                 (void)hipGetLastError();
@@ -2980,8 +3000,9 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             hipEvent_t up_ev = (buf.pinned && !to_host) ? take_up_event() : nullptr;
             const bool direct = up_ev != nullptr;
             const bool job_reads = to_host && piece_off >= 0;
-            if (!S.ensure(std::max(ftk::kTextCarryMax + total + 64, used + 64)) || !S.ensure_inflate(used, blocks.size()) ||
-                (to_host && !S.ensure_host_comp(used + 64)))
+            if (!S.ensure(std::max(ftk::kTextCarryMax + total + 64, used + 64), false) || !S.ensure_inflate(used, blocks.size()) ||
+                (to_host && (!S.ensure_host_comp(used + 64) || !S.ensure_host_text(ftk::kTextCarryMax + total + 64))) ||
+                (!to_host && !direct && !S.ensure_host_text(used + 64)))
                 return fail(FTK_ERR_OOM, "out of page-locked / device memory for the text piece");
             clk.lap(5);
             mark(k, to_host ? "(host) blocks listed, buffers ready" : "blocks listed, buffers ready");
@@ -3101,8 +3122,8 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         if (!S.ensure(carry + total + 2)) return fail(FTK_ERR_OOM, "out of page-locked / device memory for the text piece");
         if (carry) memcpy(S.h_text, carry_src, carry);
         clk.lap(5);
-        if (!blocks.empty() && inflate_block_list(buf.data(), blocks, n_threads, S.h_text + carry) != FTK_OK)
-            return fail(FTK_ERR_FORMAT, "BGZF inflate failed");
+        if (!blocks.empty() && inflate_block_list(buf.data(), blocks, n_threads, S.h_text + carry, false, true) != FTK_OK)
+            return fail(FTK_ERR_FORMAT, "BGZF inflate failed or block CRC mismatch");  // (CRCs checked like the GPU's pieces)
         clk.lap(1);
         char* b = (char*)S.h_text;
         char* e = b + carry + total;
@@ -3721,8 +3742,9 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         // theirs, which they read from the file (page cache) themselves when the piece's file offset is known
         const bool direct = buf.pinned && !pc.on_host;
         const bool job_reads = pc.on_host && pc.file_off >= 0;
-        if (!S.ensure(kRoom + pc.total + 64) || !S.ensure_inflate(pc.used, pc.blocks.size()) ||
-            (!direct && !S.ensure_host_comp(pc.used + 64)) || !S.ensure_bam(kRoom + pc.total + 64, stretch_bytes))
+        if (!S.ensure(kRoom + pc.total + 64, false) || (pc.on_host && !S.ensure_host_text(kRoom + pc.total + 64)) ||
+            !S.ensure_inflate(pc.used, pc.blocks.size()) || (!direct && !S.ensure_host_comp(pc.used + 64)) ||
+            !S.ensure_bam(kRoom + pc.total + 64, stretch_bytes))
             return fail(FTK_ERR_OOM, "out of page-locked / device memory for the BAM piece");
         if (!direct && !job_reads) {
             const size_t used = pc.used;

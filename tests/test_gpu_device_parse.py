@@ -327,7 +327,9 @@ def test_text_pieces_shared_with_the_host_threads(tmp_path, mode):
     share = mode.get("FTK_TEXT_HOST_SHARE", "1")
     took = [int(line.split(";")[1].split()[0]) for line in out.splitlines() if "inflated by the host threads" in line]
     assert took, out[-2000:]
-    if share in ("2", "3"):
+    if os.environ.get("FTK_DEVICE_INFLATE") == "0":
+        assert took[0] == 0, took  # (the suite's inner run with the inflate on the host threads: nothing to share)
+    elif share in ("2", "3"):
         assert took[0] >= 10, took  # (the whole-file pass: every 2nd / 3rd of ~40 pieces)
     if share == "0":
         assert took[0] == 0, took
