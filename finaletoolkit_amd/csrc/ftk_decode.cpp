@@ -2739,6 +2739,9 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         // (only with a backlog on the GPU: the first pieces of a stream - all of a small file - are back sooner from the
         // chip, 3 ms a piece against the threads' 12)
         if (k - settled < 3) return false;
+        // (and only pieces of two of the eight sets: a host piece needs 250 MB of page-locked text behind its set -
+        // 25 ms to lock - and at the two rates the threads take about every fifth piece anyway)
+        if ((k & 3) != 0) return false;
         return last_host_set < 0 || !host_job[last_host_set].valid() ||
                host_job[last_host_set].wait_for(std::chrono::seconds(0)) == std::future_status::ready;
     };
