@@ -3237,7 +3237,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
     // whether the chip is full or not - so three pieces' kernels (and their copies, either direction) run side by
     // side.  A slot's output is page-locked memory with room in front for the carry.
     constexpr size_t kRoom = size_t(32) << 20;
-    constexpr int kAhead = 3, kSlots = kAhead + 1;
+    constexpr int kAhead = 7, kSlots = kAhead + 1;
     static const bool want_dinf = !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
     const int device = inflate_device;  // (shadows the member: this path's GPU)
     bool dinf = want_dinf && device >= 0;
@@ -3639,7 +3639,7 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
     StageClock clk(this);
     const int device = inflate_device;
     constexpr size_t kRoom = size_t(32) << 20;
-    constexpr int kAhead = 3, kSlots = kAhead + 1;
+    constexpr int kAhead = 7, kSlots = kAhead + 1;  // (3 ahead: the 60x slice 0.050 s; 5: 0.038-0.044; 7: 0.036-0.042)
     static const uint32_t stretch_bytes = [] {  // FTK_BAM_DEV_STRETCH: tests walk tiny stretches
         const char* e = getenv("FTK_BAM_DEV_STRETCH");
         const long v = e ? atol(e) : 0;
@@ -3705,27 +3705,16 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
                 if (j[k].valid()) (void)j[k].get();
         }
     } job_guard{host_job};
-    // the read buffer's bytes are on their way up (a GPU piece's copy reads them where they were read): wait before the
-    // buffer is touched again
-    hipEvent_t up_done = nullptr;
-    bool up_pending = false;
-    if (hipEventCreateWithFlags(&up_done, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(FTK_ERR_HIP, "cannot create an event");
-    }
-    struct EventGuard { hipEvent_t* e; ~EventGuard() { if (*e) { (void)hipEventSynchronize(*e); (void)hipEventDestroy(*e); } } } up_guard{&up_done};
+    // (a GPU piece's compressed bytes go up straight from the page-locked read buffer; fill() lets that buffer rest
+    // until the copy is done - see buf_in_flight)
+    struct RestGuard {
+        ftk_fragstream* s;
+        ~RestGuard() { s->drop_resting(); }
+    } rest_guard{this};
     double t_upwait = 0, t_jobwait = 0, t_front = 0, t_header = 0;  // FTK_DECODE_TIMING: what "other" is made of
     auto tick = [] { return std::chrono::steady_clock::now(); };
     auto since = [](std::chrono::steady_clock::time_point t0) {
         return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    };
-    auto buffer_free = [&]() {
-        if (up_pending) {
-            const auto t0 = tick();
-            if (hipEventSynchronize(up_done) != hipSuccess) (void)hipGetLastError();
-            up_pending = false;
-            t_upwait += since(t0);
-        }
     };
     auto list_blocks = [&](Piece& pc) -> bool {
         if (!whole_blocks(buf.data(), pc.n, pc.eof, &pc.blocks, &pc.used, &pc.total)) return fail(FTK_ERR_FORMAT, "corrupt BGZF block");
@@ -3743,7 +3732,8 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         pc.on_host = host_share > 0 && index > 0 && (index % host_share) == host_share - 1;
         // a GPU piece goes up straight from the (page-locked) read buffer; the host threads work on their own copy of
         // theirs, which they read from the file (page cache) themselves when the piece's file offset is known
-        const bool direct = buf.pinned && !pc.on_host;
+        hipEvent_t up_ev = (buf.pinned && !pc.on_host) ? take_up_event() : nullptr;
+        const bool direct = up_ev != nullptr;
         const bool job_reads = pc.on_host && pc.file_off >= 0;
         if (!S.ensure(kRoom + pc.total + 64, false) || (pc.on_host && !S.ensure_host_text(kRoom + pc.total + 64)) ||
             !S.ensure_inflate(pc.used, pc.blocks.size()) || (!direct && !S.ensure_host_comp(pc.used + 64)) ||
@@ -3796,12 +3786,12 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         // (the compressed bytes go up at once - nothing of the slot's previous piece uses d_comp any more - and only
         // the inflate, which overwrites the text the appends may still read, waits for the slot's release)
         bool ok = (pc.used == 0 || hipMemcpyAsync(S.d_comp, direct ? buf.data() : S.h_comp, pc.used, hipMemcpyHostToDevice, st) == hipSuccess) &&
-                  (!direct || hipEventRecord(up_done, st) == hipSuccess) &&
+                  (!direct || hipEventRecord(up_ev, st) == hipSuccess) &&
                   (!S.freed_valid || hipStreamWaitEvent(st, S.freed, 0) == hipSuccess) &&
                   hipMemsetAsync(S.d_ist, 0, sizeof(ftk::InflateStatus), st) == hipSuccess &&
                   (pc.blocks.empty() || hipMemcpyAsync(S.d_tab, S.h_tab, pc.blocks.size() * sizeof(ftk::InflateBlock),
                                                        hipMemcpyHostToDevice, st) == hipSuccess);
-        if (ok && direct) up_pending = true;
+        if (direct) buf_in_flight = up_ev;  // (fill() parks the buffer behind it)
         if (ok) {
             ftk::inflate_launch(st, S.d_comp, S.d_tab, (int)pc.blocks.size(), S.d_text, S.d_ist, S.d_crc);
             ok = hipGetLastError() == hipSuccess && hipEventRecord(S.front, st) == hipSuccess;
@@ -3876,11 +3866,12 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
             const Piece& last = ahead.empty() ? curp : ahead.back();
             if (last.eof) break;
             const size_t raw_carry = last.n - last.used;
-            buffer_free();
-            if (raw_carry) memmove(buf.data(), buf.data() + last.used, raw_carry);
+            // (with a copy of buf in flight the carried bytes are only read: fill() moves them into the next buffer)
+            const size_t carry_at = buf_in_flight ? last.used : 0;
+            if (raw_carry && !buf_in_flight) memmove(buf.data(), buf.data() + last.used, raw_carry);
             clk.lap(5);
             Piece np;
-            np.n = fill(buf, raw_carry);
+            np.n = fill(buf, raw_carry, carry_at);
             clk.lap(0);
             np.eof = np.n - raw_carry < kStreamPiece;
             np.has_prev = true;
