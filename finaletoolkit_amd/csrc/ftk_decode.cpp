@@ -2455,7 +2455,7 @@ struct DevSet {
     }
     // page-locked room for `bytes` of text on the host side (page-locking 250 MB takes ~25 ms: a text stream whose
     // pieces stay on the device never pays it - the first whole-genome pass of a process spent 0.2 s here for its
-    // eight sets)
+    // sets)
     bool ensure_host_text(size_t bytes) {
         if (bytes <= h_text_cap) return true;
         if (h_text) (void)hipHostFree(h_text);
@@ -2498,7 +2498,7 @@ struct DevSet {
 };
 // The two buffer sets of a finished stream wait here for the next one: allocating them costs ~100 ms (400 MB
 // of page-locked memory, ~1 GB of device memory, the frees synchronise the device) - more than a small file
-// takes to decode.  At most eight idle sets are kept (per process, any device): the ring of a text stream.
+// takes to decode.  At most twelve idle sets are kept (per process, any device): the ring of a text stream.
 struct DevSetPool {
     std::mutex mu;
     std::vector<std::pair<int, DevSet>> idle;
@@ -2517,7 +2517,7 @@ struct DevSetPool {
         s.freed_valid = false;  // (the giver has synchronised its streams)
         {
             std::lock_guard<std::mutex> lk(mu);
-            if (s.cap && idle.size() < 8) {
+            if (s.cap && idle.size() < 12) {
                 idle.emplace_back(device, s);
                 s = DevSet{};
                 return;
@@ -2639,7 +2639,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     // With the host threads taking a share of the pieces (below) the ring is longer: a host piece's parse - and, the
     // parse stream being in file order, those of the pieces behind it - goes onto the stream when its inflate is done,
     // at the latest kHostLag pieces later.
-    constexpr int kSets = 8, kHostLag = 5;
+    constexpr int kSets = 12, kHostLag = 8;
     DevSet sets[kSets];
     for (auto& S : sets) S = devset_pool().take(device);
     hipStream_t fstream[kSets] = {};
@@ -2739,7 +2739,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         // (only with a backlog on the GPU: the first pieces of a stream - all of a small file - are back sooner from the
         // chip, 3 ms a piece against the threads' 12)
         if (k - settled < 3) return false;
-        // (and only pieces of two of the eight sets: a host piece needs 250 MB of page-locked text behind its set -
+        // (and only pieces of three of the twelve sets: a host piece needs 250 MB of page-locked text behind its set -
         // 25 ms to lock - and at the two rates the threads take about every fifth piece anyway)
         if ((k & 3) != 0) return false;
         return last_host_set < 0 || !host_job[last_host_set].valid() ||
