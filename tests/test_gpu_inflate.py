@@ -121,6 +121,74 @@ def test_inflate_fuzz_random_mixtures(engine):
     assert got == expect
 
 
+def test_windowed_symbol_loop_edges(engine):
+    """Payloads aimed at the windowed symbol loop: alphabets skewed so that rare literals and rare lengths get codes longer
+    than the 9-bit root (a window stops in front of them, the serial path takes one symbol); windows whose matches add up to
+    more than the 320 bytes a window may produce (258-byte matches back to back, cut between symbols); many short matches
+    that read what the previous match of the same window wrote (distance 1-8 behind a literal); matches with every length
+    3-258 at distances on both sides of the window's start; members made of many small DEFLATE blocks (Z_FULL_FLUSH
+    every few hundred bytes: new tables in the middle of a window's worth of bits); a block that ends exactly where a
+    window would."""
+    rng = np.random.default_rng(5)
+    shapes = {}
+    # 1. geometric alphabet: symbol k with probability ~ 2^-k/3 over 200 symbols -> code lengths 1..15
+    p = 0.79 ** np.arange(200)
+    shapes["skewed"] = rng.choice(200, 60_000, p=p / p.sum()).astype(np.uint8).tobytes()
+    # ... and the same with stretches copied from a little earlier (rare lengths, rare distances)
+    sk = bytearray(shapes["skewed"][:20_000])
+    for _ in range(900):
+        a = int(rng.integers(0, len(sk) - 300))
+        n = int(rng.choice([3, 4, 5, 9, 17, 33, 65, 129, 200, 257, 258]))
+        sk += sk[a:a + n] + bytes(rng.integers(0, 200, int(rng.integers(0, 4)), dtype=np.uint8))
+    shapes["skewed_matches"] = bytes(sk[:0xFF00])
+    # 2. back-to-back long matches
+    unit = rng.integers(0, 256, 300, dtype=np.uint8).tobytes()
+    shapes["long_matches"] = (unit * 220)[:0xFF00]
+    # 3. short dependent matches: x, then x repeated (distance 1), then a 2-byte pattern, ... separated by fresh literals
+    dep = bytearray()
+    while len(dep) < 60_000:
+        k = int(rng.integers(1, 9))
+        pat = rng.integers(0, 256, k, dtype=np.uint8).tobytes()
+        dep += pat * int(rng.integers(2, 12)) + rng.integers(0, 256, int(rng.integers(1, 5)), dtype=np.uint8).tobytes()
+    shapes["dependent_matches"] = bytes(dep[:60_000])
+    # 4. every match length at assorted distances
+    base = rng.integers(0, 256, 4_000, dtype=np.uint8).tobytes()
+    ev = bytearray(base)
+    for n in range(3, 259):
+        d = int(rng.choice([n, n + 1, 2 * n, 300, 1_000, 1_726, 1_727, 3_000]))
+        d = min(d, len(ev))
+        ev += ev[len(ev) - d:len(ev) - d + n] if d >= n else (ev[len(ev) - d:] * (n // d + 1))[:n]
+        ev += bytes([n & 255, 255 - (n & 255)])
+    shapes["every_length"] = bytes(ev[:0xFF00])
+    members, want = [], []
+    for name, data in shapes.items():
+        for level, strategy in [(6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY),
+                                (6, zlib.Z_FILTERED), (6, zlib.Z_HUFFMAN_ONLY)]:
+            m = _member(data, level, strategy)
+            if m is not None:
+                members.append(m)
+                want.append(data)
+    # 5. many small DEFLATE blocks inside one member
+    text = _rows(2000, 9)[:50_000]
+    for step in (97, 256, 1000):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        payload = b"".join(c.compress(text[i:i + step]) + c.flush(zlib.Z_FULL_FLUSH if (i // step) % 3 else zlib.Z_SYNC_FLUSH)
+                           for i in range(0, len(text), step)) + c.flush()
+        bsize = 12 + 6 + len(payload) + 8
+        if bsize <= 65536:
+            head = struct.pack("<BBBBIBBH", 31, 139, 8, 4, 0, 0, 255, 6) + struct.pack("<BBHH", 66, 67, 2, bsize - 1)
+            members.append(head + payload + struct.pack("<II", zlib.crc32(text) & 0xFFFFFFFF, len(text)))
+            want.append(text)
+    assert len(members) >= 20
+    rc, got = _inflate(engine, b"".join(members) + bgzf._EOF)
+    assert rc == 0, engine.lib.ftk_last_error(engine.ctx)
+    off = 0
+    for k, w in enumerate(want):
+        assert got[off:off + len(w)] == w, f"member {k} ({len(w)} bytes) differs"
+        off += len(w)
+    assert off == len(got)
+
+
 def test_many_blocks_from_the_library_writer(engine, tmp_path):
     """A 40 MB fragment text through the library's BGZF writer (libdeflate) at three levels: ~600 blocks each."""
     rows = _rows(1_300_000, 5)
