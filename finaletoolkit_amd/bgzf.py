@@ -42,17 +42,67 @@ def virtual_offset(block_offsets: list[int], byte_pos: int) -> int:
     return (block_offsets[k] << 16) | u
 
 
-def write_index(path, bai: bool, spans: list[tuple[str, int, int]]) -> None:
+def row_lengths(name: str, start, end, mapq, bed6: bool = False):
+    """Bytes of every row ``name start end [. ]mapq strand`` of a fragment file (decimal digits counted, not
+    formatted): what ``linear_index`` needs to place the rows of a contig in its text."""
+    import numpy as np
+
+    def digits(x):
+        x = np.asarray(x, dtype=np.int64)
+        d = np.ones(len(x), np.int64)
+        for p in (10, 100, 1_000, 10_000, 100_000, 1_000_000, 10_000_000, 100_000_000, 1_000_000_000):
+            d += x >= p
+        return d
+    return len(name.encode()) + 1 + digits(start) + 1 + digits(end) + 1 + (2 if bed6 else 0) + digits(mapq) + 1 + 1 + 1
+
+
+def linear_index(start, end, row_bytes, block_offsets, first_byte: int = 0):
+    """tabix linear index of one contig's rows (sorted by start): for every 16 kb window the virtual offset of the
+    first row that overlaps it; a window without rows takes the next window's value, as htslib writes it.  Rows lie
+    back to back from uncompressed byte ``first_byte`` of a ``write_bgzf``-shaped stream (0xFF00 bytes per block)
+    whose blocks start at ``block_offsets``."""
+    import numpy as np
+    start = np.asarray(start, dtype=np.int64)
+    end = np.asarray(end, dtype=np.int64)
+    if len(start) == 0:
+        return np.zeros(0, np.uint64)
+    pos = first_byte + np.concatenate(([0], np.cumsum(np.asarray(row_bytes, dtype=np.int64))[:-1]))
+    blk, within = np.divmod(pos, _BLOCK)
+    voff = (np.asarray(block_offsets, dtype=np.int64)[blk].astype(np.uint64) << np.uint64(16)) | within.astype(np.uint64)
+    n_win = int((max(int(end.max()), 1) - 1) >> 14) + 1
+    w0 = np.arange(n_win, dtype=np.int64) << 14
+    # first row (file order) with end > window start; it overlaps the window iff it starts before the window's end
+    first = np.searchsorted(np.maximum.accumulate(end), w0, side="right")
+    ok = first < len(start)
+    ok[ok] &= start[first[ok]] < w0[ok] + (1 << 14)
+    out = np.zeros(n_win, np.uint64)
+    out[ok] = voff[first[ok]]
+    nxt = np.uint64(0)
+    for w in range(n_win - 1, -1, -1):  # (htslib: an empty window points at the next one's rows)
+        if ok[w]:
+            nxt = out[w]
+        else:
+            out[w] = nxt
+    return out
+
+
+def write_index(path, bai: bool, spans: list[tuple[str, int, int]], linear=None) -> None:
     """Minimal tabix (``bai=False``, BGZF-compressed) / BAI index: per reference one pseudo-bin 37450 whose
     first chunk is the reference's virtual-offset span ``(name, v_begin, v_end)`` -- what a reader needs to
-    find a contig; ``v_begin == v_end`` marks a reference without records."""
+    find a contig; ``v_begin == v_end`` marks a reference without records.  ``linear``: per reference the 16 kb
+    linear index (``linear_index``) or None -- what a reader needs to start inside a contig."""
     body = b""
-    for _, vb, ve in spans:
+    for k, (_, vb, ve) in enumerate(spans):
         if ve > vb:
             body += struct.pack("<i", 1) + struct.pack("<Ii", 37450, 2) + struct.pack("<QQQQ", vb, ve, 0, 0)
         else:
             body += struct.pack("<i", 0)
-        body += struct.pack("<i", 0)  # no linear index
+        lin = None if linear is None else linear[k]
+        if lin is None or len(lin) == 0:
+            body += struct.pack("<i", 0)  # no linear index
+        else:
+            import numpy as np
+            body += struct.pack("<i", len(lin)) + np.asarray(lin, dtype="<u8").tobytes()
     if bai:
         with open(path, "wb") as fh:
             fh.write(b"BAI\1" + struct.pack("<i", len(spans)) + body)
@@ -78,19 +128,21 @@ def write_frag_gz(path, contig_rows, bed6: bool = False, with_tbi_stub: bool = T
         # large files: rows formatted and BGZF blocks deflated by the library's host threads, one contig after
         # the other (a contig starts on a fresh block, so its virtual offset is just the block's file offset)
         from . import writers
-        spans = []
+        spans, linear = [], []
         first = True
         end_off = 0
         for name, start, end, mapq, strand in contig_rows:
             with writers.frag_rows(name, start, end, mapq, strand, bed6) as rows:
                 offs = writers.bgzf_write(path, rows, level, append=not first, write_eof=False)
             spans.append((name, int(offs[0]), int(offs[-1])))
+            if with_index:
+                linear.append(linear_index(start, end, row_lengths(name, start, end, mapq, bed6), offs))
             end_off = int(offs[-1])
             first = False
         with open(path, "ab") as fh:
             fh.write(_EOF)
         if with_index:
-            write_index(str(path) + ".tbi", False, [(n, a << 16, b << 16) for n, a, b in spans])
+            write_index(str(path) + ".tbi", False, [(n, a << 16, b << 16) for n, a, b in spans], linear)
         elif with_tbi_stub:
             open(str(path) + ".tbi", "ab").close()
         return
@@ -109,7 +161,9 @@ def write_frag_gz(path, contig_rows, bed6: bool = False, with_tbi_stub: bool = T
         marks.append((name, first, pos))
     offsets = write_bgzf(path, "".join(parts).encode(), level)
     if with_index:
+        linear = [linear_index(r[1], r[2], row_lengths(r[0], r[1], r[2], r[3], bed6), offsets, m[1])
+                  for r, m in zip(contig_rows, marks)]
         write_index(str(path) + ".tbi", False,
-                    [(n, virtual_offset(offsets, a), virtual_offset(offsets, b)) for n, a, b in marks])
+                    [(n, virtual_offset(offsets, a), virtual_offset(offsets, b)) for n, a, b in marks], linear)
     elif with_tbi_stub:
         open(str(path) + ".tbi", "ab").close()

@@ -1715,12 +1715,17 @@ struct IndexSpan {
     bool usable = false;   // the index could be read
     bool present = false;  // ... and lists the contig with at least one chunk
     uint64_t beg = 0, end = 0;
+    // region look-ups (tabix): where the rows that overlap the region start, and where - by the 16 kb linear index -
+    // the rows that start behind the region begin (a hint: a row longer than an index window can sit behind it)
+    bool region = false;
+    uint64_t reg_beg = 0, reg_soft_end = 0;
 };
 
 inline uint64_t rd_u64(const uint8_t* p) { return (uint64_t)rd_u32(p) | ((uint64_t)rd_u32(p + 4) << 32); }
 
 // ref < 0: look the contig up by name (tabix); else by reference id (BAI)
-IndexSpan index_lookup(const std::string& index_path, bool bai, const std::string& name, int ref) {
+IndexSpan index_lookup(const std::string& index_path, bool bai, const std::string& name, int ref, long long reg_start = -1,
+                       long long reg_stop = -1) {
     IndexSpan out;
     Bytes raw, img;
     if (!read_file(index_path.c_str(), &raw) || raw.size() < 8) return out;
@@ -1785,10 +1790,23 @@ IndexSpan index_lookup(const std::string& index_path, bool bai, const std::strin
         const int32_t n_intv = rd_i32(p + o);
         o += 4;
         if (n_intv < 0 || o + 8 * (size_t)n_intv > n) return IndexSpan{};
+        const uint8_t* ioff = p + o;
         o += 8 * (size_t)n_intv;
         if (r == ref) {
             out.usable = true;
             if (lo != UINT64_MAX && hi > lo) { out.present = true; out.beg = lo; out.end = hi; }
+            if (out.present && !bai && reg_start >= 0 && reg_stop > reg_start && n_intv > 0) {
+                // linear index: ioff[w] = the smallest virtual offset of a row that overlaps [w * 16384, (w + 1) * 16384)
+                // (0: none seen up to there).  Every row overlapping the region's first base overlaps its window, so
+                // nothing before ioff[w0] is needed; rows that START in window w1 = (stop >> 14) + 1 or later lie
+                // behind the region.
+                const long long w0 = std::min<long long>(reg_start >> 14, n_intv - 1), w1 = (reg_stop >> 14) + 1;
+                uint64_t b = rd_u64(ioff + 8 * (size_t)w0);
+                out.reg_beg = b >= lo && b < hi ? b : lo;
+                uint64_t e = w1 < n_intv ? rd_u64(ioff + 8 * (size_t)w1) : 0;
+                out.reg_soft_end = e >= out.reg_beg && e < hi ? e : hi;  // (== : the region lies in a stretch without rows)
+                out.region = true;
+            }
         }
     }
     return out;
@@ -1897,12 +1915,23 @@ struct ftk_fragstream {
     bool partial_tail_ok = false;  // the range may end inside a block that belongs to the next contig
     size_t first_skip = 0;        // bytes of the first inflated block that precede the contig
     long long first_piece_off = -1;  // file offset of the first piece handed to run_* (-1: unknown)
+    // Region reads (ftk_fragstream_open_region, text files with a tabix index): the stream hands out the contig's rows
+    // from the first that can overlap [reg_start, reg_stop) to the last that starts before reg_stop - a superset is
+    // allowed, nothing of the region may be missing.  The read first stops at the linear index's hint
+    // (read_end < hard_read_end); the device parser's rows then say whether the region is complete (a row starting at
+    // or behind reg_stop, or another contig's rows, were seen) and the read goes on in steps if not.
+    bool has_region = false;
+    long long reg_start = 0, reg_stop = 0;
+    long long hard_read_end = -1;  // where the contig's rows end (read_end of a whole-contig read)
+    bool range_limited = false;    // the last read_piece() came back short because of read_end, not the file's end
     // One piece of the file -> dst; returns the bytes read (short at the end of the file / of the range).
     size_t read_piece(uint8_t* dst) {
         size_t want = kStreamPiece;
+        range_limited = false;
         if (read_end >= 0) {
             const long long pos = ftell(fp);
             want = pos >= read_end ? 0 : (size_t)std::min<long long>((long long)kStreamPiece, read_end - pos);
+            range_limited = want < kStreamPiece;
         }
         size_t got = 0;
         bool done = false;
@@ -2050,6 +2079,7 @@ struct ftk_fragstream {
         if (fseek(fp, (long)(sp.beg >> 16), SEEK_SET) != 0) return false;
         first_skip = (size_t)(sp.beg & 0xffff);
         read_end = (long long)(sp.end >> 16) + 0x10000 + 64;  // through the block that holds the last row
+        hard_read_end = read_end;
         partial_tail_ok = true;
         return true;
     }
@@ -2086,8 +2116,15 @@ struct ftk_fragstream {
 void ftk_fragstream::run_guarded() {
     RawBuf buf;
     ahead_ok = !(bam && has_only);  // run_bam decides about the index seek after the header
+    {
+        // a region is read as one only where the device inflates and parses the rows (run_text_device tells from the
+        // parsed rows whether the region is complete); elsewhere the stream hands out the whole contig - a superset
+        static const bool dev_inf = !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
+        if (device < 0 || bam || !dev_inf || !has_only) has_region = false;
+    }
     if (has_only && !bam) {  // tabix index: jump straight to the contig's rows
-        const IndexSpan sp = index_lookup(index_path_of(path, false), false, only, -1);
+        IndexSpan sp = index_lookup(index_path_of(path, false), false, only, -1, has_region ? reg_start : -1, has_region ? reg_stop : -1);
+        if (has_region && !(sp.usable && sp.present && sp.region)) has_region = false;  // (the whole contig: a superset)
         if (sp.usable && !sp.present) {  // the file has no row of this contig
             std::lock_guard<std::mutex> lk(mu);
             finished = true;
@@ -2095,7 +2132,12 @@ void ftk_fragstream::run_guarded() {
             cv.notify_all();
             return;
         }
-        if (sp.usable && !seek_to(sp)) { read_end = -1; partial_tail_ok = false; first_skip = 0; rewind(fp); }
+        if (sp.usable && has_region) {
+            // start at the region's first row; stop - for now - where the linear index says the rows behind it begin
+            sp.beg = sp.reg_beg;
+            if (!seek_to(sp)) { read_end = -1; partial_tail_ok = false; first_skip = 0; has_region = false; rewind(fp); }
+            else read_end = std::min(hard_read_end, (long long)(sp.reg_soft_end >> 16) + 0x10000 + 64);
+        } else if (sp.usable && !seek_to(sp)) { read_end = -1; partial_tail_ok = false; first_skip = 0; rewind(fp); }
     }
     {
         static const bool dev_bam = !(getenv("FTK_DEVICE_BAM_PARSE") && atoi(getenv("FTK_DEVICE_BAM_PARSE")) == 0) &&
@@ -2175,6 +2217,7 @@ void ftk_fragstream::run_guarded() {
             drain_ahead();
             (void)hipStreamSynchronize(pstream);
             host_inflate_only = true;
+            has_region = false;  // (the second pass hands out the whole contig)
             read_end = -1;
             partial_tail_ok = false;
             first_skip = 0;
@@ -2429,7 +2472,7 @@ struct DevSet {
             comp_cap = comp_bytes + comp_bytes / 4 + 4096;
             ok = hipMalloc((void**)&d_comp, comp_cap) == hipSuccess;
         }
-        if (ok && n_blocks > tab_cap) {
+        if (ok && (n_blocks > tab_cap || !d_ist)) {  // (also a piece without a complete block: the status words are still used)
             const size_t cc = comp_cap, hc = h_comp_cap;
             uint8_t *keep = d_comp, *keep_h = h_comp;
             d_comp = h_comp = nullptr;
@@ -2691,6 +2734,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     bool layout_known = false;
     Contig cur;
     bool have_cur = false;
+    bool saw_other = false;
     std::set<std::string> seen;
     size_t gpu_pieces = 0, host_pieces = 0;
     // The BGZF blocks are inflated on the GPU too (ftk_inflate.hip): the host only reads the file and copies it into
@@ -2749,7 +2793,10 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     // one contig run of a piece: n rows at the given column pointers (device or host)
     auto take_run = [&](const std::string& name, const int32_t* s0, const int32_t* e0, const uint8_t* q0, const uint8_t* t0,
                         size_t rows, hipMemcpyKind kind) -> bool {
-        if (has_only && name != only) return true;
+        if (has_only && name != only) {
+            saw_other = true;  // (rows behind the wanted contig's: a region read is complete)
+            return true;
+        }
         if (host_inflate_only && emitted_names.count(name)) return true;  // second pass: handed out by the first
         if (have_cur && name != cur.name) {
             if (!emit_device(std::move(cur))) return false;
@@ -2962,6 +3009,13 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         return true;
     };
     bool eof = n < kStreamPiece;
+    // (region reads) this short read stopped at the linear index's hint, not at the end of the contig's rows: the piece
+    // is parsed as one with more behind it, and the rows then say whether to read on
+    auto at_soft_end = [&](size_t n_now) {
+        return eof && has_region && read_end >= 0 && read_end < hard_read_end && piece_off >= 0 &&
+               piece_off + (long long)n_now >= read_end;
+    };
+    bool soft = at_soft_end(n);
     int k = 0;
     for (;; ++k) {
         size_t used = 0, total = 0;
@@ -3025,14 +3079,14 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
                 S.want_crc[i] = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
             }
             S.n_tab = blocks.size();
-            S.cut_tail = eof && partial_tail_ok;
+            S.cut_tail = eof && !soft && partial_tail_ok;
             S.inflated = true;
             S.host_only = false;
             mark(k, "staged");
             PieceMeta& M = meta[k % kSets];
             M = PieceMeta{};
             M.on_host = to_host;
-            M.eof = eof;
+            M.eof = eof && !soft;
             M.has_prev = k > 0 && sets[(k - 1) % kSets].inflated;
             M.back_done = false;
             M.total = total;
@@ -3087,8 +3141,10 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
                 }
             }
             if (!ok) {
-                (void)hipGetLastError();
-                return fail(FTK_ERR_HIP, "cannot launch the device inflate");
+                const hipError_t he = hipGetLastError();
+                return fail(FTK_ERR_HIP, (std::string("cannot launch the device inflate (") + hipGetErrorName(he) + ", piece " +
+                                          std::to_string(k) + ", " + std::to_string(blocks.size()) + " blocks, " +
+                                          std::to_string(used) + " bytes)").c_str());
             }
             // the backs, in file order: every piece whose text is (about to be) on the device - a host piece when its
             // job is done, or kHostLag pieces later at the latest
@@ -3102,7 +3158,28 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             if (!settle(k, false)) return false;
             clk.lap(3);
             mark(k, "settle done");
-            if (eof) break;
+            if (eof) {
+                if (!soft) break;
+                // the region's rows so far: complete when a row starts at or behind the region's end (or another
+                // contig's rows came); else a row longer than an index window hid the true end - read on
+                if (!submit_backs(k, true) || !settle(k, true)) return false;
+                bool complete = saw_other;
+                if (!complete && have_cur && cur.dev->rows) {
+                    int32_t last = 0;
+                    if (hipMemcpyAsync(&last, cur.dev->start + (cur.dev->rows - 1), 4, hipMemcpyDeviceToHost, pstream) != hipSuccess ||
+                        hipStreamSynchronize(pstream) != hipSuccess) {
+                        (void)hipGetLastError();
+                        return fail(FTK_ERR_HIP, "cannot read the last row of a region");
+                    }
+                    complete = (long long)last >= reg_stop;
+                }
+                if (clk.on)
+                    fprintf(stderr, "[ftk stream text] region %lld-%lld: piece %d ends at file offset %lld (hint %lld, contig ends %lld): %s\n",
+                            reg_start, reg_stop, k, piece_off + (long long)n, read_end, hard_read_end,
+                            complete ? "complete" : "a long row hides the end, reading on");
+                if (complete) break;
+                read_end = std::min(hard_read_end, read_end + (long long)(size_t(8) << 20));
+            }
             const size_t raw_carry_d = n - used;
             if (piece_off >= 0) piece_off += (long long)used;
             // (with a copy of buf in flight the carried bytes are only read here: fill() moves them into the next buffer)
@@ -3112,6 +3189,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             clk.lap(0);
             mark(k, "next piece read");
             eof = n - raw_carry_d < kStreamPiece;
+            soft = at_soft_end(n);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (stop) return false;
@@ -4197,7 +4275,7 @@ int ftk_fragfile_index_contigs(const char* path, char* names_out, int64_t cap, i
 }
 
 static int fragstream_open_impl(const char* path, const char* contig, int is_bam, int n_threads, int max_queued,
-                                int device, ftk_fragstream** out) {
+                                int device, ftk_fragstream** out, long long reg_start = -1, long long reg_stop = -1) {
     if (!path || !out) return dfail(FTK_ERR_INVALID, "NULL argument");
     *out = nullptr;
     FILE* fp = fopen(path, "rb");
@@ -4205,6 +4283,11 @@ static int fragstream_open_impl(const char* path, const char* contig, int is_bam
     ftk_fragstream* s = new ftk_fragstream();
     s->path = path;
     if (contig) { s->only = contig; s->has_only = true; }
+    if (contig && reg_start >= 0 && reg_stop > reg_start) {
+        s->has_region = true;
+        s->reg_start = reg_start;
+        s->reg_stop = reg_stop;
+    }
     s->bam = is_bam != 0;
     s->n_threads = std::max(1, n_threads);
     s->max_queued = (size_t)std::max(1, max_queued);
@@ -4227,6 +4310,12 @@ int ftk_fragstream_open_device(int device_id, const char* path, const char* cont
                                int max_queued, ftk_fragstream** out) {
     if (device_id < 0 || !have_hip_device()) return dfail(FTK_ERR_NO_DEVICE, "ftk_fragstream_open_device: no HIP device");
     return fragstream_open_impl(path, contig, is_bam, n_threads, max_queued, device_id, out);
+}
+
+int ftk_fragstream_open_region(int device_id, const char* path, const char* contig, int64_t start, int64_t stop, int is_bam,
+                               int n_threads, int max_queued, ftk_fragstream** out) {
+    if (!contig || start < 0 || stop <= start) return dfail(FTK_ERR_INVALID, "a region needs a contig and 0 <= start < stop");
+    return fragstream_open_impl(path, contig, is_bam, n_threads, max_queued, device_id, out, (long long)start, (long long)stop);
 }
 
 int ftk_fragstream_next(ftk_fragstream* s, ftk_fragtable** out) {

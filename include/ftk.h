@@ -158,6 +158,18 @@ typedef struct ftk_fragstream ftk_fragstream;
  * takes both kinds.  FTK_DEVICE_PARSE=0 makes it behave like ftk_fragstream_open. */
 int ftk_fragstream_open_device(int device_id, const char* path, const char* contig /* NULL = all */, int is_bam,
                                int n_threads, int max_queued, ftk_fragstream** out);
+
+/* A stream over the rows of ONE REGION of a contig (the reference's per-window `fetch(contig, start, stop)`,
+ * io/alignment.py:205-268, at the granularity a rank of a multi-GPU run needs: frag/_delfi.py's ranks each take a
+ * window-aligned share of the genome).  The single table it hands out holds EVERY row of `contig` that overlaps
+ * [start, stop) - and may hold more (rows before the region from the first block read; the whole contig for BAM input,
+ * files without a usable tabix index, streams without a device or with FTK_DEVICE_INFLATE=0).  With a tabix index the
+ * read starts at the linear index's offset for `start` and ends where the parsed rows say the region is complete: a
+ * row that starts at or behind `stop`, or another contig's rows, were seen (the index's 16 kb windows give a first
+ * guess; a row longer than a window makes the read go on in 8 MB steps).  Arguments otherwise as
+ * ftk_fragstream_open_device. */
+int ftk_fragstream_open_region(int device_id, const char* path, const char* contig, int64_t start, int64_t stop, int is_bam,
+                               int n_threads, int max_queued, ftk_fragstream** out);
 int ftk_fragtable_is_device(const ftk_fragtable* t, int i);
 /* hipEvent_t recorded behind the last write to a device table's columns (NULL for host tables) */
 void* ftk_fragtable_ready_event(const ftk_fragtable* t, int i);

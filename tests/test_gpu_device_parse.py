@@ -360,3 +360,105 @@ def test_text_stream_with_a_damaged_block_is_an_error(tmp_path, share):
         r = subprocess.run([sys.executable, "-c", code, bad], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and r.stdout.startswith("error"), (which, r.stdout, r.stderr[-1500:])
         assert str(L.FTK_ERR_FORMAT) in r.stdout, r.stdout
+
+
+def _stream_region(path, contig, start, stop, threads=4):
+    lib = L.load()
+    s = C.c_void_p()
+    rc = lib.ftk_fragstream_open_region(0, path.encode(), contig.encode(), start, stop, 0, threads, 1, C.byref(s))
+    if rc != 0:
+        raise RuntimeError((rc, lib.ftk_fragtable_error().decode()))
+    tables = []
+    try:
+        while True:
+            t = C.c_void_p()
+            rc = lib.ftk_fragstream_next(s, C.byref(t))
+            if rc != 0:
+                raise RuntimeError((rc, lib.ftk_fragtable_error().decode()))
+            if not t.value:
+                break
+            try:
+                rows = lib.ftk_fragtable_contig_rows(t, 0)
+                name = lib.ftk_fragtable_contig_name(t, 0).decode()
+                cols = [np.empty(rows, np.int32), np.empty(rows, np.int32), np.empty(rows, np.uint8), np.empty(rows, np.uint8)]
+                assert lib.ftk_fragtable_columns_to_host(t, 0, *[c.ctypes.data_as(C.c_void_p) for c in cols]) == 0
+                tables.append((name, cols))
+            finally:
+                lib.ftk_fragtable_free(t)
+    finally:
+        lib.ftk_fragstream_close(s)
+    return tables
+
+
+_REGION_CHILD = """
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from tests.test_gpu_device_parse import _stream_region, _whole
+path = sys.argv[1]
+whole = _whole(path)
+report = []
+for spec in sys.argv[2:]:
+    contig, a, b = spec.split(":")
+    a, b = int(a), int(b)
+    got = _stream_region(path, contig, a, b)
+    n_all, (S, E, Q, T) = whole[contig][0], whole[contig][1][:4]
+    need = np.nonzero((S < b) & (E > a))[0]
+    if not got:
+        assert len(need) == 0, (spec, len(need))
+        report.append((spec, 0, n_all))
+        continue
+    assert len(got) == 1 and got[0][0] == contig, (spec, [g[0] for g in got])
+    s, e, q, t = got[0][1]
+    # a contiguous slice of the contig's rows ...
+    i0 = int(np.searchsorted(S, s[0], side="left"))
+    while i0 < n_all and not (S[i0] == s[0] and E[i0] == e[0] and Q[i0] == q[0] and T[i0] == t[0]):
+        i0 += 1
+    assert i0 + len(s) <= n_all and np.array_equal(S[i0:i0 + len(s)], s) and np.array_equal(E[i0:i0 + len(s)], e) and \\
+        np.array_equal(Q[i0:i0 + len(s)], q) and np.array_equal(T[i0:i0 + len(s)], t), spec
+    # ... that holds every row overlapping the region
+    if len(need):
+        assert i0 <= need[0] and need[-1] < i0 + len(s), (spec, i0, len(s), int(need[0]), int(need[-1]))
+    report.append((spec, len(s), n_all))
+print("ok", report)
+"""
+
+
+def test_region_streams_hold_every_overlapping_row(tmp_path):
+    """ftk_fragstream_open_region on a three-contig file with a full tabix index (16 kb linear index): regions at the
+    contig's ends, in its middle, across a stretch without rows, one base wide, beyond the last row, and - the case the
+    linear index cannot promise - rows up to 60 kb long, which hide where the rows behind the region begin (the
+    stream reads on until a parsed row starts behind the region).  Each table is a contiguous slice of the contig's
+    rows with every overlapping row in it, and a small region reads a small part of the contig."""
+    rng = np.random.default_rng(21)
+    rows = []
+    for name, n, size, long_rows in (("c1", 400_000, 60_000_000, False), ("c2", 300_000, 40_000_000, True), ("c3", 50_000, 5_000_000, False)):
+        s = np.sort(rng.integers(0, size, n))
+        if name == "c1":
+            s = s[(s < 20_000_000) | (s > 23_000_000)]  # a stretch without rows
+        e = s + rng.integers(30, 600, len(s))
+        if long_rows:
+            pick = rng.random(len(s)) < 0.002
+            e[pick] = s[pick] + rng.integers(20_000, 60_000, int(pick.sum()))
+        rows.append((name, s, e, rng.integers(0, 61, len(s)), rng.integers(0, 2, len(s))))
+    # c4: two rows 5 Mb long - the linear index's windows behind a region inside them point at THEM, far in front of the
+    # rows that start just before the region's end: the hint falls short and the stream has to read on
+    s = np.sort(np.concatenate([rng.integers(0, 20_000_000, 300_000), [2_000_000, 9_000_000]]))
+    e = s + rng.integers(30, 600, len(s))
+    e[np.searchsorted(s, 2_000_000)] = 7_000_000
+    e[np.searchsorted(s, 9_000_000)] = 14_000_000
+    rows.append(("c4", s, e, rng.integers(0, 61, len(s)), rng.integers(0, 2, len(s))))
+    p = str(tmp_path / "reg.frag.gz")
+    bgzf.write_frag_gz(p, rows, with_index=True)
+    specs = ["c4:6000000:6100000", "c4:13000000:13500000", "c4:1990000:2010000", "c1:0:100000", "c1:30000000:31000000", "c1:19990000:23010000", "c1:21000000:22000000", "c1:59000000:70000000",
+             "c1:12345678:12345679", "c2:0:1", "c2:10000000:10100000", "c2:25000000:25016384", "c2:39000000:40000000",
+             "c2:5000000:30000000", "c3:0:5000000", "c3:4999000:5000000", "c1:70000000:80000000"]
+    for env in (dict(), dict(FTK_STREAM_PIECE=str(1 << 16))):
+        r = subprocess.run([sys.executable, "-c", _REGION_CHILD.format(root=ROOT), p] + specs,
+                           env=dict(os.environ, FTK_DECODE_TIMING="1", **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
+        assert "region 6000000-6100000" in r.stderr and "a long row hides the end, reading on" in r.stderr, r.stderr[-3000:]
+        rep = {k: (a, b) for k, a, b in eval(r.stdout[r.stdout.index("ok") + 3:])}
+        assert rep["c1:30000000:31000000"][0] < rep["c1:30000000:31000000"][1] // 20  # ~1.7 % of the contig's rows wanted
+        assert rep["c2:10000000:10100000"][0] < rep["c2:10000000:10100000"][1] // 20
+        assert rep["c3:0:5000000"][0] == rep["c3:0:5000000"][1]
