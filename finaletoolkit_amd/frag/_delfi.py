@@ -21,7 +21,7 @@ import pandas
 
 from ..genome.gaps import GenomeGaps
 from ..reference import ReferenceGenome
-from ..source import get_engine, resident_contigs
+from ..source import get_engine, region_contig, resident_contigs
 from .. import sharding
 from ..utils import chrom_sizes_to_list, overlaps
 from ._delfi_gc_correct import delfi_gc_correct
@@ -110,15 +110,20 @@ def _gate_windows(contig, starts, stops, contig_gaps):
 
 
 def _contig_counts(src, eng, ref, contig, starts, stops, live, ok, contig_gaps, blacklist, quality_threshold,
-                   clock=None):
-    """Device part of one contig (the rank that owns it): ``[n_live, 4]`` int64 rows
-    ``(short, long, num_frags, num_gc)`` of its live bins -- one ``ftk_delfi_counts`` launch and one GC-count
-    launch (frag/_delfi.py:443-490)."""
+                   clock=None, key=None, i0=0, i1=None):
+    """Device part of one contig (the rank that owns it) - or of the bins ``[i0, i1)`` of it, counted on the table
+    ``key`` (a region of the contig: ``FragSource.require_region``): ``[n_live, 4]`` int64 rows
+    ``(short, long, num_frags, num_gc)`` of the live bins among them -- one ``ftk_delfi_counts`` launch and one
+    GC-count launch (frag/_delfi.py:443-490)."""
     idx = np.nonzero(live)[0]
+    if i0 or i1 is not None:
+        part = (idx >= i0) & (idx < (len(live) if i1 is None else i1))
+        idx, ok = idx[part], ok[part]
     out = np.zeros((len(idx), 4), np.int64)
     if len(idx):
         t0 = time.perf_counter()
-        key = src.require(contig)
+        if key is None:
+            key = src.require(contig)
         t1 = time.perf_counter()
         bl = blacklist.get(contig)
         sh, lg, nf = eng.delfi_counts(
@@ -261,9 +266,17 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
             plan[contig] = (starts, stops, arms, live, _valid_mask(ref.chroms, contig, starts[live], stops[live]))
         clock["gate"] = time.perf_counter() - tg
         names = list(plan)
-        weights = {c: float(len(plan[c][0])) for c in names}
-        owner = sharding.lpt_assign(weights, world)
-        mine = [c for c in names if owner[c] == rank]
+        # The ranks' shares: the bins of all contigs laid end to end and cut into runs of equal cost
+        # (sharding.split_counts - the partition bench.py's steps use), so a rank owns whole contigs plus at most two
+        # partial ones; a partial one is read through the index as a REGION of the contig (source.region_contig).
+        # BAM input cannot be entered in the middle of a contig: whole contigs there, dealt heaviest first.
+        if world > 1 and not str(input_file).lower().endswith(".bam"):
+            units = sharding.split_counts({c: len(plan[c][0]) for c in names}, world)
+        else:
+            owner = sharding.lpt_assign({c: float(len(plan[c][0])) for c in names}, world)
+            units = [(owner[c], c, 0, len(plan[c][0])) for c in names]
+        mine = [(c, i0, i1) for r, c, i0, i1 in units if r == rank]
+        whole = [c for c, i0, i1 in mine if i0 == 0 and i1 == len(plan[c][0])]
         local = {}
         # contigs are counted as they become resident: a file without a usable index is decoded in ONE streaming
         # pass (decode of contig k+1 beside the kernels / the reference upload of contig k); an indexed file is
@@ -271,19 +284,39 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
         err = None
         try:
             tw = time.perf_counter()
-            for src, contig in resident_contigs(input_file, mine, workers, stream_all=world == 1):
+            for src, contig in resident_contigs(input_file, whole, workers, stream_all=world == 1):
                 clock["decode_wait"] += time.perf_counter() - tw
                 starts, stops, arms, live, ok = plan[contig]
-                local[contig] = _contig_counts(src, eng, ref, contig, starts, stops, live, ok,
-                                               contig_gaps.get(contig) if gaps is not None else None, blacklist,
-                                               quality_threshold, clock)
+                local[(contig, 0, len(starts))] = _contig_counts(src, eng, ref, contig, starts, stops, live, ok,
+                                                                 contig_gaps.get(contig) if gaps is not None else None,
+                                                                 blacklist, quality_threshold, clock)
                 tw = time.perf_counter()
             clock["decode_wait"] += time.perf_counter() - tw
-            for contig in mine:  # a planned contig the file does not hold: pysam raises for the unknown region
-                if contig not in local and plan[contig][3].any():
-                    raise ValueError(f"could not create iterator for region '{contig}': contig not present in "
-                                     f"{input_file}")
-                local.setdefault(contig, np.zeros((0, 4), np.int64))
+            for contig, i0, i1 in mine:
+                starts, stops, arms, live, ok = plan[contig]
+                if (contig, i0, i1) in local:
+                    continue
+                if i0 == 0 and i1 == len(starts):
+                    # a planned contig the file does not hold: pysam raises for the unknown region
+                    if live.any():
+                        raise ValueError(f"could not create iterator for region '{contig}': contig not present in "
+                                         f"{input_file}")
+                    local[(contig, i0, i1)] = np.zeros((0, 4), np.int64)
+                    continue
+                if not live[i0:i1].any():
+                    local[(contig, i0, i1)] = np.zeros((0, 4), np.int64)
+                    continue
+                tw = time.perf_counter()
+                sel = np.nonzero(live[i0:i1])[0] + i0
+                src, key = region_contig(input_file, contig, int(starts[sel].min()), int(stops[sel].max()), workers)
+                clock["decode_wait"] += time.perf_counter() - tw
+                try:
+                    local[(contig, i0, i1)] = _contig_counts(src, eng, ref, contig, starts, stops, live, ok,
+                                                             contig_gaps.get(contig) if gaps is not None else None,
+                                                             blacklist, quality_threshold, clock, key=key, i0=i0, i1=i1)
+                finally:
+                    if hasattr(src, "release_region"):
+                        src.release_region(key)
         except Exception as e:  # noqa: BLE001 - with several ranks every rank must learn of it (sharding.agree)
             err = e
         if world > 1:
@@ -291,8 +324,10 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
         elif err is not None:
             raise err
     tg = time.perf_counter()
-    n_live = {c: int(plan[c][3].sum()) for c in names}
-    counts = sharding.gather_bin_vectors(local, names, n_live, weights, k=4)
+    n_rows = {(c, i0, i1): int(plan[c][3][i0:i1].sum()) for _, c, i0, i1 in units}
+    counts = sharding.gather_unit_rows(local, units, n_rows, 4)
+    for c in names:
+        counts.setdefault(c, np.zeros((0, 4), np.int64))
     clock["gather"] = time.perf_counter() - tg
     tg = time.perf_counter()
     parts = [_contig_columns(c, plan[c][0], plan[c][1], plan[c][2], plan[c][3], plan[c][4], counts[c]) for c in names]

@@ -142,35 +142,45 @@ def lpt_assign(weights: Dict[str, float], n_ranks: int) -> Dict[str, int]:
     return owner
 
 
+def split_counts(counts: Dict[str, int], n_ranks: int, overhead: int = 50):
+    """THE partition of the product and the bench: contigs in the given order, each with ``counts[c]`` items (the
+    windows of a tiling, the rows of a bins file), laid end to end and cut into ``n_ranks`` runs of equal COST, so a
+    rank owns whole contigs plus at most two partial ones (whole-contig LPT caps 8 GPUs at 0.96 of ideal on b37:
+    chr1 alone is 8 % of the genome).  Cost = items + ``overhead`` per contig: every unit pays launch ramps, an index
+    seek and a first block worth about 50 windows of streaming (measured on simulated ranks: a rank of six small
+    contigs ran 6 % longer than one of two large ones with equal bases).  Returns ``[(rank, contig, i0, i1), ...]``
+    in the given order: items ``[i0, i1)`` of ``contig`` belong to ``rank``; every item belongs to exactly one unit."""
+    if n_ranks <= 1:
+        return [(0, c, 0, int(n)) for c, n in counts.items() if int(n) > 0]
+    n_it = {c: int(n) for c, n in counts.items()}
+    ov = max(0, int(overhead))
+    total = sum(n_it.values()) + ov * len(n_it)
+    units = []
+    done = 0.0  # cost before the current contig
+    for c in counts:
+        done += ov  # the contig's fixed cost sits in front of its first item
+        w0 = 0
+        while w0 < n_it[c]:
+            r = min(n_ranks - 1, int((done + w0) * n_ranks // total))
+            # first item of this contig whose cost position belongs to the next rank
+            nxt = -(-(r + 1) * total // n_ranks) if r + 1 < n_ranks else total + n_it[c]
+            w1 = min(n_it[c], max(w0 + 1, int(nxt - done)))
+            units.append((r, c, w0, w1))
+            w0 = w1
+        done += n_it[c]
+    return units
+
+
 def split_units(sizes: Dict[str, int], n_ranks: int, window: int, unit_overhead_windows: int = 50):
-    """Work units of every rank: the genome (contigs in the given order, laid end to end) is cut into
-    ``n_ranks`` runs of equal COST at window boundaries, so a rank owns whole contigs plus at most two
-    partial ones (whole-contig LPT caps 8 GPUs at 0.96 of ideal on b37: chr1 alone is 8 % of the
-    genome).  Cost = windows + ``unit_overhead_windows`` per contig: every unit pays launch ramps and
-    tails worth about 5 Mb of streaming (measured on simulated ranks: a rank of six small contigs ran
-    6 % longer than one of two large ones with equal bases).  Returns ``[(rank, contig, start, stop),
-    ...]`` in genome order; ``start`` is a multiple of ``window``.  A unit needs the contig's fragments
-    starting in ``[start - halo, stop + halo)`` (``unit_halo``) and produces exactly the windows / bases
-    of its own range: units never exchange data."""
+    """``split_counts`` for a tiling of ``window`` bases (``bench.py``'s steps): ``[(rank, contig, start, stop), ...]``
+    in genome order, ``start`` a multiple of ``window``.  A unit needs the contig's fragments starting in
+    ``[start - halo, stop + halo)`` (``unit_halo``) and produces exactly the windows / bases of its own range:
+    units never exchange data."""
     if n_ranks <= 1:
         return [(0, c, 0, int(n)) for c, n in sizes.items()]
     n_win = {c: -(-int(n) // window) for c, n in sizes.items()}
-    ov = max(0, int(unit_overhead_windows))
-    total = sum(n_win.values()) + ov * len(n_win)
-    units = []
-    done = 0.0  # cost before the current contig
-    for c, n in sizes.items():
-        done += ov  # the contig's fixed cost sits in front of its first window
-        w0 = 0
-        while w0 < n_win[c]:
-            r = min(n_ranks - 1, int((done + w0) * n_ranks // total))
-            # first window of this contig whose cost position belongs to the next rank
-            nxt = -(-(r + 1) * total // n_ranks) if r + 1 < n_ranks else total + n_win[c]
-            w1 = min(n_win[c], max(w0 + 1, int(nxt - done)))
-            units.append((r, c, w0 * window, min(w1 * window, int(n))))
-            w0 = w1
-        done += n_win[c]
-    return units
+    return [(r, c, w0 * window, min(w1 * window, int(sizes[c])))
+            for r, c, w0, w1 in split_counts(n_win, n_ranks, unit_overhead_windows)]
 
 
 def unit_halo(max_fragment_len: int, wps_window: int) -> int:
@@ -225,6 +235,47 @@ def gather_bin_vectors(local: Dict[str, np.ndarray], names: Sequence[str], n_bin
         out[n] = recv[r][offs[r]:offs[r] + n_bins[n]].cpu().numpy()
         offs[r] += n_bins[n]
     return out
+
+
+def gather_unit_rows(local: Dict[tuple, np.ndarray], units, n_rows: Dict[tuple, int], k: int, group=None,
+                     device=None) -> Dict[str, np.ndarray]:
+    """All-gather the integer rows of ``split_counts`` units: ``local[(contig, i0, i1)]`` holds this rank's units
+    (shape ``[n_rows[unit], k]``; every rank knows every unit's row count), the result maps each contig to its units'
+    rows concatenated in unit order - on every rank.  One collective, like ``gather_bin_vectors``."""
+    import torch
+    import torch.distributed as dist
+
+    keys = [(c, i0, i1) for _, c, i0, i1 in units]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        got = {key: np.asarray(local[key], dtype=np.int64).reshape(-1, k) for key in keys}
+    else:
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        if device is None:
+            device = exchange_device(group)
+        rows = [sum(n_rows[(c, i0, i1)] for r, c, i0, i1 in units if r == q) for q in range(world)]
+        pad = max(max(rows), 1)  # RCCL does not take empty buffers
+        send = torch.zeros((pad, k), dtype=torch.int64)
+        off = 0
+        for r, c, i0, i1 in units:
+            if r == rank:
+                n = n_rows[(c, i0, i1)]
+                send[off:off + n] = torch.from_numpy(np.ascontiguousarray(local[(c, i0, i1)], dtype=np.int64).reshape(n, k))
+                off += n
+        if device is not None:
+            send = send.to(device)
+        recv = [torch.zeros_like(send) for _ in range(world)]
+        dist.all_gather(recv, send, group=group)
+        offs = [0] * world
+        got = {}
+        for r, c, i0, i1 in units:
+            n = n_rows[(c, i0, i1)]
+            got[(c, i0, i1)] = recv[r][offs[r]:offs[r] + n].cpu().numpy()
+            offs[r] += n
+    out: Dict[str, list] = {}
+    for key in keys:
+        out.setdefault(key[0], []).append(got[key])
+    return {c: np.concatenate(parts, axis=0) if parts else np.zeros((0, k), np.int64) for c, parts in out.items()}
 
 
 def allreduce_sum(value: int, group=None, device=None) -> int:

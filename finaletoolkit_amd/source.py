@@ -28,6 +28,7 @@ _ENGINE: Optional[Engine] = None
 _SOURCES: "OrderedDict[tuple, FragSource]" = OrderedDict()
 _MAX_SOURCES = 4
 _NEXT_ID = 0
+REGION_READS: list = []  # (path, contig, start, stop) of every region stream opened by this process (diagnostics, tests)
 
 
 def get_engine() -> Engine:
@@ -93,6 +94,7 @@ class FragSource:
         self.lengths = dict(lengths)              # name -> length (BAM) / None
         self.uid = uid
         self.loaded = set()
+        self.regions = set()                      # engine keys of partial tables (require_region)
         self.lazy = lazy
         self.workers = workers
         self.decode_stage_ms = None               # set by stream_source when the whole file has been decoded
@@ -141,6 +143,55 @@ class FragSource:
             self.loaded.add(contig)
         finally:
             lib.ftk_fragstream_close(stream)
+
+    def require_region(self, contig: str, start: int, stop: int) -> str:
+        """Engine key of a table that holds EVERY fragment of ``contig`` overlapping ``[start, stop)`` - the whole
+        contig when that is resident already (or when the file cannot be entered in the middle of a contig: BAM
+        input, no usable tabix index), else the rows ``ftk_fragstream_open_region`` reads for the region (index seek
+        to its first row, the parsed rows say where it is complete).  A rank of a multi-GPU run loads its share of a
+        contig this way (``sharding.split_counts``); ``release_region`` drops the table."""
+        if contig in self.loaded or self.is_bam or not self.lazy:
+            return self.require(contig)
+        if contig not in self.contigs:
+            raise ValueError(f"could not create iterator for region '{contig}': contig not present in {self.path}")
+        start, stop = max(0, int(start)), int(stop)
+        if stop <= start:
+            return self.require(contig)
+        key = f"{self.uid}:{contig}@{start}-{stop}"
+        if key in self.regions:
+            return key
+        eng = get_engine()
+        lib = L.load()
+        stream = C.c_void_p()
+        REGION_READS.append((self.path, contig, start, stop))
+        rc = lib.ftk_fragstream_open_region(eng.device, self.path.encode(), contig.encode(), start, stop, 0,
+                                            decode_threads(self.workers), 1, C.byref(stream))
+        if rc != L.FTK_OK:
+            raise UnsupportedFormatError(lib.ftk_fragtable_error().decode())
+        try:
+            table = C.c_void_p()
+            rc = lib.ftk_fragstream_next(stream, C.byref(table))
+            if rc != L.FTK_OK:
+                raise UnsupportedFormatError(lib.ftk_fragtable_error().decode())
+            if table.value:
+                try:
+                    eng.load_contig_from_table(key, table, 0, False)
+                finally:
+                    lib.ftk_fragtable_free(table)
+            else:
+                e32, e8 = np.zeros(0, np.int32), np.zeros(0, np.uint8)
+                eng.load_contig(key, e32, e32, e8, e8)
+            self.regions.add(key)
+        finally:
+            lib.ftk_fragstream_close(stream)
+        return key
+
+    def release_region(self, key: str):
+        if key in self.regions:
+            self.regions.discard(key)
+            eng = get_engine()
+            if eng.has_contig(key):
+                eng.release(key)
 
     def load_all(self):
         """Make every contig resident (whole-file operations).  When most of the file is still missing, ONE
@@ -196,6 +247,10 @@ class FragSource:
             if eng.has_contig(self.key(c)):
                 eng.release(self.key(c))
         self.loaded.clear()
+        for key in list(self.regions):
+            if eng.has_contig(key):
+                eng.release(key)
+        self.regions.clear()
 
 
 def _check_path(input_file) -> tuple[str, bool]:
@@ -433,6 +488,14 @@ def resident_contigs(input_file, names, workers: int | None = None, stream_all: 
             warned = True
         if c in want_set:
             yield src, c
+
+
+def region_contig(input_file, contig: str, start: int, stop: int, workers: int | None = None, warn_bed6: bool = True):
+    """``(src, key)``: the source of ``input_file`` and the engine key of a table with every fragment of ``contig``
+    that overlaps ``[start, stop)`` (``FragSource.require_region``) - the way in for a rank that owns PART of a
+    contig."""
+    src = open_source(input_file, workers, warn_bed6)
+    return src, src.require_region(contig, start, stop)
 
 
 def _warn_bed6():

@@ -28,6 +28,9 @@ with warnings.catch_warnings():
     df = frag.delfi(d + "/g.frag.gz", d + "/cs.genome", d + "/bins.txt", d + "/ref.fa", blacklist_file=d + "/bl.bed",
                     gap_file=d + "/gaps.bed", no_gc_correct=True, remove_nocov=False, merge_bins=False,
                     output_file=d + f"/delfi_w{{world}}.tsv")
+    from finaletoolkit_amd import source as _src
+    loaded_delfi = sorted(k.split(":", 1)[1] for k in _src.get_engine().contigs)  # whole contigs this rank decoded for it
+    regions = [r[1:] for r in _src.REGION_READS]                                   # ... and the parts of contigs
     merged = frag.delfi(d + "/g.frag.gz", d + "/cs.genome", d + "/bins.txt", d + "/ref.fa", gap_file=d + "/gaps.bed",
                         no_gc_correct=True, remove_nocov=False, merge_bins=True)
 cov = frag.coverage(d + "/g.frag.gz", d + "/iv.bed", d + f"/cov_w{{world}}.bed", normalize=True, scale_factor=1e6)
@@ -35,7 +38,8 @@ raw = frag.coverage(d + "/g.frag.gz", d + "/iv.bed", None, intersect_policy="any
 from finaletoolkit_amd.source import get_engine
 loaded = sorted(k.split(":", 1)[1] for k in get_engine().contigs)
 pickle.dump(dict(rank=rank, world=world, delfi=df, merged=merged, cov=[tuple(c) for c in cov],
-                 raw=[tuple(c) for c in raw], loaded=loaded), open(d + f"/out_w{{world}}_r{{rank}}.pkl", "wb"))
+                 raw=[tuple(c) for c in raw], loaded=loaded, loaded_delfi=loaded_delfi, regions=regions),
+            open(d + f"/out_w{{world}}_r{{rank}}.pkl", "wb"))
 sharding.finalize()
 """
 
@@ -163,9 +167,15 @@ def test_two_ranks_equal_one_process(dataset):
     # and rank 0 alone wrote the files, identical to the single-process ones
     assert open(d / "delfi_w2.tsv").read() == open(d / "delfi_w1.tsv").read()
     assert open(d / "cov_w2.bed").read() == open(d / "cov_w1.bed").read()
-    # the work really was dealt out: each rank decoded only its own contigs, together all of them
-    a, b = set(two[0]["loaded"]), set(two[1]["loaded"])
-    assert a and b and not (a & b) and a | b == set(one["loaded"]) == {"c1", "c2", "c3", "c4", "c5"}
+    # the work really was dealt out.  delfi: the bins of all contigs cut into two runs of equal cost
+    # (sharding.split_counts) - each rank decoded its whole contigs and read its PART of the contig the cut falls
+    # into as a region through the index (the table dropped again); no contig decoded whole by both
+    a, b = set(two[0]["loaded_delfi"]), set(two[1]["loaded_delfi"])
+    ra, rb = two[0]["regions"], two[1]["regions"]
+    assert a and b and not (a & b), (a, b)
+    assert len(ra) == 1 and len(rb) == 1 and ra[0][0] == rb[0][0] and ra[0][0] not in a | b, (ra, rb)
+    assert ra[0][2] <= rb[0][1] + 20_000 and a | b | {ra[0][0]} == {"c1", "c2", "c3", "c4", "c5"}  # (the two parts meet)
+    assert one["regions"] == [] and set(one["loaded"]) == {"c1", "c2", "c3", "c4", "c5"}
 
 
 def test_two_ranks_write_the_single_process_files_for_every_sharded_command(dataset):
@@ -274,5 +284,8 @@ def test_bench_two_ranks_share_the_gpu():
     # the N-rank file leg: ONE indexed file -> frag.delfi on both ranks (each decodes its own contigs), same frame
     leg = line["end_to_end"]["genome_frag_delfi_api_ranks"]
     assert leg["ranks"] == 2 and leg["results_ok"] and leg["merged_rows"] > 10, line["end_to_end"]
-    assert sorted(r["contigs_decoded"] for r in leg["per_rank"]) == [1, 2]
+    # three contigs, two equal-cost runs of bins: a whole contig and a region of the middle one for each rank
+    assert sorted(r["contigs_decoded"] for r in leg["per_rank"]) == [1, 1]
+    assert [len(r["regions_read"]) for r in leg["per_rank"]] == [1, 1] and \
+        leg["per_rank"][0]["regions_read"][0][0] == leg["per_rank"][1]["regions_read"][0][0]
     assert all(r["decoder_threads"] >= 1 and r["stages_s"]["total"] > 0 for r in leg["per_rank"])

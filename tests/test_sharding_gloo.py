@@ -154,6 +154,7 @@ def _product_worker(rank, world, port, d, q):
     src, eng, Ref, asked = _fake_device(SIZES_P)
     Cv.open_source = lambda *a, **k: src
     Df.resident_contigs = lambda path, names, *a, **k: ((src, c) for c in names if src.has(c))
+    Df.region_contig = lambda path, c, lo, hi, *a, **k: (src, src.require(c))  # (the whole contig: a superset of the region)
     for mod in (Cv, Df):
         mod.get_engine = lambda: eng
     Df.ReferenceGenome = Ref
@@ -199,7 +200,9 @@ def test_sharded_delfi_and_coverage_equal_single_process(tmp_path):
     for r in res[2]:
         assert r[1] == one[1] and r[2] == one[2]  # same frame, same coverage list on every rank
     a, b = set(res[2][0][3]), set(res[2][1][3])
-    assert a and b and not (a & b) and a | b == set(SIZES_P)  # each contig counted by exactly one rank
+    # the bins were cut into two runs of equal cost (sharding.split_counts): one contig is shared, the others counted by
+    # exactly one rank
+    assert a and b and len(a & b) == 1 and a | b == set(SIZES_P), (a, b)
     assert (d / "delfi_w2.tsv").read_text() == (d / "delfi_w1.tsv").read_text()
     assert (d / "cov_w2.bed").read_text() == (d / "cov_w1.bed").read_text()
 
@@ -254,6 +257,18 @@ def _helpers_worker(rank, world, port, d, q):
     for c in names:
         assert full[c].tobytes() == rows[c].tobytes()
     assert sharding.allgather_object({"r": rank}) == [{"r": r} for r in range(world)]
+    # unit rows: the bins of three contigs cut into `world` runs of equal cost; every rank makes the rows of its units
+    # (a function of the unit), one all-gather hands every rank every contig's rows in order
+    counts = {"x": 37, "y": 5, "z": 22}
+    units = sharding.split_counts(counts, world, overhead=2)
+    assert sorted((c, i) for _, c, i0, i1 in units for i in range(i0, i1)) == sorted((c, i) for c, n in counts.items() for i in range(n))
+    assert [u[0] for u in units] == sorted(u[0] for u in units) and {u[0] for u in units} == set(range(world))
+    n_rows = {(c, i0, i1): (i1 - i0) - (i1 - i0) // 3 for _, c, i0, i1 in units}  # (some bins are not live)
+    make = lambda c, i0, i1: (np.arange(n_rows[(c, i0, i1)] * 4, dtype=np.int64).reshape(-1, 4) + 1000 * i0 + ord(c))  # noqa: E731
+    got_rows = sharding.gather_unit_rows({(c, i0, i1): make(c, i0, i1) for r, c, i0, i1 in units if r == rank}, units, n_rows, 4)
+    for c in counts:
+        want = np.concatenate([make(cc, i0, i1) for _, cc, i0, i1 in units if cc == c])
+        assert np.array_equal(got_rows[c], want), c
     # agree(): one failing rank makes every rank raise
     try:
         sharding.agree(ValueError("boom") if rank == world - 1 else None)
