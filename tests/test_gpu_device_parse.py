@@ -457,6 +457,8 @@ def test_region_streams_hold_every_overlapping_row(tmp_path):
         r = subprocess.run([sys.executable, "-c", _REGION_CHILD.format(root=ROOT), p] + specs,
                            env=dict(os.environ, FTK_DECODE_TIMING="1", **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
+        if os.environ.get("FTK_DEVICE_INFLATE") == "0":
+            continue  # (the suite's inner run with the inflate on the host threads: regions are whole contigs there)
         assert "region 6000000-6100000" in r.stderr and "a long row hides the end, reading on" in r.stderr, r.stderr[-3000:]
         rep = {k: (a, b) for k, a, b in eval(r.stdout[r.stdout.index("ok") + 3:])}
         assert rep["c1:30000000:31000000"][0] < rep["c1:30000000:31000000"][1] // 20  # ~1.7 % of the contig's rows wanted
