@@ -45,7 +45,7 @@ def cleavage_profile(input_file, chrom_size: int, contig: str, start: int, stop:
     adj_start = max(start - left, 0)
     adj_stop = min(stop + right, chrom_size)
     src = open_source(input_file)
-    props = get_engine().cleavage(src.require(contig), adj_start, adj_stop, min_length, max_length, quality_threshold)
+    props = get_engine().cleavage(src.require_interval(contig, adj_start, adj_stop, 1), adj_start, adj_stop, min_length, max_length, quality_threshold)
     if verbose:
         stderr.write(f"cleavage_profile took {time.time() - t0} s to complete\n")
     return _result(contig, adj_start, props)

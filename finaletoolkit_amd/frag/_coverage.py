@@ -59,7 +59,7 @@ def _total(src, contig, start, stop, min_length, max_length, intersect_policy, q
     names, whole = _region_contigs(src, contig)
     total = 0
     for c in names:
-        total += int(eng.window_counts(src.require(c), [None if whole else start], [None if whole else stop],
+        total += int(eng.window_counts(src.require(c) if whole else src.require_interval(c, start, stop, 1), [None if whole else start], [None if whole else stop],
                                        quality_threshold, min_length, max_length, intersect_policy)[0])
     return total
 

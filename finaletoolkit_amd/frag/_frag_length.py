@@ -131,7 +131,7 @@ def frag_length(input_file: Union[str, Path], contig: str | None = None, start: 
     src = open_source(input_file)
     eng = get_engine()
     names, whole = _region_contigs(src, contig)
-    parts = [eng.frag_lengths(src.require(c), None if whole else start, None if whole else stop, quality_threshold,
+    parts = [eng.frag_lengths(src.require(c) if whole else src.require_interval(c, start, stop, 1), None if whole else start, None if whole else stop, quality_threshold,
                               0, 1000000000, intersect_policy) for c in names]
     lengths = np.concatenate(parts).astype(np.int32) if parts else np.zeros(0, np.int32)
 

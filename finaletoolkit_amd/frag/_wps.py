@@ -80,7 +80,7 @@ def wps(input_file: Union[str, Path], chrom: str, start: int, stop: int, chrom_s
         return np.zeros(0, dtype=_WPS_DTYPE)
     src = open_source(input_file)
     eng = get_engine()
-    values = eng.wps(src.require(chrom), start, stop, int(chrom_size), int(window_size),
+    values = eng.wps(src.require_interval(chrom, start, stop, int(window_size) + 1), start, stop, int(chrom_size), int(window_size),
                      0 if min_length is None else int(min_length), int(max_length), int(quality_threshold))
     scores = _scores_array(chrom, start, values)
 

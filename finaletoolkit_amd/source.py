@@ -95,6 +95,8 @@ class FragSource:
         self.uid = uid
         self.loaded = set()
         self.regions = set()                      # engine keys of partial tables (require_region)
+        self._interval_hits = {}                  # contig -> single-interval calls that found it not resident
+        self._recent_regions = []                 # region tables kept for require_interval (most recent last)
         self.lazy = lazy
         self.workers = workers
         self.decode_stage_ms = None               # set by stream_source when the whole file has been decoded
@@ -184,6 +186,28 @@ class FragSource:
             self.regions.add(key)
         finally:
             lib.ftk_fragstream_close(stream)
+        return key
+
+    def require_interval(self, contig: str, start, stop, pad: int = 0) -> str:
+        """Engine key for ONE call about ``contig:[start - pad, stop + pad)`` (``frag.wps``, ``single_coverage``,
+        ``frag_length`` ... on an interval).  A contig that is resident is used as it is; one that is not is not
+        decoded whole for a first or second small interval (a 30x chr1 is 25 M rows for a call that needs a few
+        thousand) - the interval's rows come through the index as a region, the two most recent region tables are
+        kept - but from the third call on it is, since whoever asks three times will ask again."""
+        if start is None or stop is None or contig in self.loaded or self.is_bam or not self.lazy:
+            return self.require(contig)
+        start, stop = int(start) - int(pad), int(stop) + int(pad)
+        hits = self._interval_hits.get(contig, 0) + 1
+        self._interval_hits[contig] = hits
+        if hits >= 3 or stop - start > 20_000_000:
+            return self.require(contig)
+        key = self.require_region(contig, start, stop)
+        if key in self.regions:
+            if key in self._recent_regions:
+                self._recent_regions.remove(key)
+            self._recent_regions.append(key)
+            while len(self._recent_regions) > 2:
+                self.release_region(self._recent_regions.pop(0))
         return key
 
     def release_region(self, key: str):

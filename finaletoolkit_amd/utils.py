@@ -132,7 +132,7 @@ def frag_array(input_file, contig: str, quality_threshold: int = 30, start=None,
     names, whole = _region_contigs(src, contig)
     parts = []
     for c in names:
-        s, e, _, st = eng.frag_select(src.require(c), None if whole else start, None if whole else stop,
+        s, e, _, st = eng.frag_select(src.require(c) if whole else src.require_interval(c, start, stop, 1), None if whole else start, None if whole else stop,
                                       quality_threshold, min_length, max_length, intersect_policy)
         a = np.zeros(len(s), dtype=[("start", "i8"), ("stop", "i8"), ("strand", "?")])
         a["start"], a["stop"], a["strand"] = s, e, st.astype(bool)

@@ -464,3 +464,42 @@ def test_region_streams_hold_every_overlapping_row(tmp_path):
         assert rep["c1:30000000:31000000"][0] < rep["c1:30000000:31000000"][1] // 20  # ~1.7 % of the contig's rows wanted
         assert rep["c2:10000000:10100000"][0] < rep["c2:10000000:10100000"][1] // 20
         assert rep["c3:0:5000000"][0] == rep["c3:0:5000000"][1]
+
+
+def test_interval_calls_read_a_region_not_the_contig(tmp_path):
+    """frag.wps / cleavage_profile / frag_length / single_coverage / frag_array on an interval of a contig that is not
+    resident: the first two calls read the interval's rows through the index (a region table; the contig is NOT
+    decoded), the third decodes the contig - and every answer equals the one computed on the whole contig."""
+    from finaletoolkit_amd import frag, source
+    from finaletoolkit_amd.utils import frag_array
+    rng = np.random.default_rng(8)
+    rows = []
+    for name, n, size in (("c1", 500_000, 50_000_000), ("c2", 200_000, 20_000_000)):
+        s = np.sort(rng.integers(0, size, n))
+        rows.append((name, s, s + rng.integers(40, 500, n), rng.integers(0, 61, n), rng.integers(0, 2, n)))
+    p = str(tmp_path / "iv.frag.gz")
+    bgzf.write_frag_gz(p, rows, with_index=True)
+
+    def calls():
+        return dict(
+            wps=frag.wps(p, "c1", 30_000_000, 30_020_000, 50_000_000)["wps"].tolist(),
+            clv=frag.cleavage_profile(p, 50_000_000, "c1", 12_000_000, 12_003_000)["proportion"].tolist(),
+            fl=frag.frag_length(p, "c2", 5_000_000, 5_400_000, intersect_policy="any").tolist(),
+            cov=frag.single_coverage(p, "c2", 100_000, 900_000)[-1],
+            arr=frag_array(p, "c1", 0, 49_990_000, 50_000_000, intersect_policy="any").tolist())
+
+    source.close_all()
+    del source.REGION_READS[:]
+    first = calls()
+    src = source.open_source(p)
+    # c1: wps + cleavage as regions, the third call (frag_array) decoded the contig; c2: two region calls
+    assert [r[1] for r in source.REGION_READS] == ["c1", "c1", "c2", "c2"], source.REGION_READS
+    assert src.loaded == {"c1"} and len(src.regions) == 2
+    source.close_all()
+    for c in ("c1", "c2"):
+        source.open_source(p).require(c)
+    n_before = len(source.REGION_READS)
+    whole = calls()
+    assert len(source.REGION_READS) == n_before  # (resident contigs are used as they are)
+    assert first == whole and len(first["wps"]) == 20_000 and any(first["wps"]) and first["cov"] > 2_000 and len(first["arr"]) > 50
+    source.close_all()

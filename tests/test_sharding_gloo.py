@@ -114,6 +114,9 @@ def _fake_device(sizes):
             asked.append(c)
             return c
 
+        def require_interval(self, c, *a, **k):
+            return self.require(c)
+
     class Eng:
         def window_counts(self, name, starts, stops, q=30, lo=None, hi=None, policy="midpoint", out=None):
             return O.c_window_counts(frs[name], starts, stops, mapq_min=q, min_len=lo, max_len=hi, policy=policy)
