@@ -29,6 +29,9 @@ struct BamSummary {
     uint32_t n_repairs;       // stretches the last kernel had to walk again serially
     uint32_t first_unsettled; // (when not consistent) the first stretch that does not start where its predecessor landed
     uint32_t dbg[4];          // its start, the predecessor's landing, the predecessor's start, the landing before that
+    unsigned long long last_key;  // (reference id as uint32) << 32 | position of the LAST record on the chain in this piece
+                                  // (0: no record; unmapped reads at the end of the file carry reference 0xffffffff):
+                                  // region reads stop when it passes the region's end
     uint32_t run_row[kBamMaxRuns];
     int32_t run_ref[kBamMaxRuns];
 };

@@ -122,7 +122,8 @@ struct Out {
 // row `row0`...; returns the landing offset, the fragment count and whether a bad block_size ended the walk.
 template <bool EMIT>
 __device__ uint32_t walk(const uint8_t* p, uint32_t m, uint32_t from, uint32_t until, const uint8_t* wanted, int n_ref,
-                         uint32_t& n_frag, uint32_t& n_rec, bool& bad, const Out& out, uint32_t row0, size_t max_rows) {
+                         uint32_t& n_frag, uint32_t& n_rec, bool& bad, const Out& out, uint32_t row0, size_t max_rows,
+                         unsigned long long* last_key = nullptr) {
     uint64_t o = from;
     n_frag = 0;
     n_rec = 0;
@@ -134,6 +135,7 @@ __device__ uint32_t walk(const uint8_t* p, uint32_t m, uint32_t from, uint32_t u
         const uint8_t* r = p + o + 4;
         const int32_t ref_id = rd_i32(r);
         ++n_rec;
+        if (EMIT && last_key) *last_key = ((unsigned long long)(uint32_t)ref_id << 32) | (uint32_t)max(rd_i32(r + 4), 0);
         if (ref_id >= 0 && ref_id < n_ref && wanted[ref_id]) {
             Frag f;
             if (bam_fragment(r, bs, f)) {
@@ -323,8 +325,10 @@ __global__ __launch_bounds__(64) void bam_emit_kernel(const uint8_t* __restrict_
         const uint32_t until = b1 < m ? (uint32_t)b1 : m;
         uint32_t n_frag, n_rec;
         bool bad;
-        (void)walk<true>(p, m, st_start[k], until, wanted, n_ref, n_frag, n_rec, bad, out, st_off[k], max_rows);
+        unsigned long long key = 0;
+        (void)walk<true>(p, m, st_start[k], until, wanted, n_ref, n_frag, n_rec, bad, out, st_off[k], max_rows, &key);
         recs += n_rec;
+        if (n_rec) atomicMax(&sum->last_key, key);  // (records are sorted by reference and position: the last one's)
     }
     if (recs) atomicAdd(&sum->n_records, recs);
 }

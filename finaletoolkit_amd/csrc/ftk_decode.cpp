@@ -1795,7 +1795,7 @@ IndexSpan index_lookup(const std::string& index_path, bool bai, const std::strin
         if (r == ref) {
             out.usable = true;
             if (lo != UINT64_MAX && hi > lo) { out.present = true; out.beg = lo; out.end = hi; }
-            if (out.present && !bai && reg_start >= 0 && reg_stop > reg_start && n_intv > 0) {
+            if (out.present && reg_start >= 0 && reg_stop > reg_start && n_intv > 0) {
                 // linear index: ioff[w] = the smallest virtual offset of a row that overlaps [w * 16384, (w + 1) * 16384)
                 // (0: none seen up to there).  Every row overlapping the region's first base overlaps its window, so
                 // nothing before ioff[w0] is needed; rows that START in window w1 = (stop >> 14) + 1 or later lie
@@ -2120,7 +2120,8 @@ void ftk_fragstream::run_guarded() {
         // a region is read as one only where the device inflates and parses the rows (run_text_device tells from the
         // parsed rows whether the region is complete); elsewhere the stream hands out the whole contig - a superset
         static const bool dev_inf = !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
-        if (device < 0 || bam || !dev_inf || !has_only) has_region = false;
+        static const bool dev_bam_rec = !(getenv("FTK_DEVICE_BAM_PARSE") && atoi(getenv("FTK_DEVICE_BAM_PARSE")) == 0);
+        if (!dev_inf || !has_only || (bam ? (inflate_device < 0 || !dev_bam_rec) : device < 0)) has_region = false;
     }
     if (has_only && !bam) {  // tabix index: jump straight to the contig's rows
         IndexSpan sp = index_lookup(index_path_of(path, false), false, only, -1, has_region ? reg_start : -1, has_region ? reg_stop : -1);
@@ -2205,6 +2206,7 @@ void ftk_fragstream::run_guarded() {
             drain_ahead();
             if (pstream) (void)hipStreamSynchronize(pstream);
             want_host_restart = false;
+            has_region = false;  // (the host decoder hands out the whole contig)
             read_end = -1;
             partial_tail_ok = false;
             first_skip = 0;
@@ -3932,6 +3934,8 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
     };
 
     // ---- the header: the first piece is inflated on the device, its head copied back until the header is complete
+    int region_ref = -1;                // (region reads) the reference the region lies on
+    unsigned long long last_key = 0;    // the last record settled so far: (reference << 32) | position
     Piece curp;
     curp.n = n_first;
     curp.eof = n_first < kStreamPiece;
@@ -4034,9 +4038,15 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
             for (size_t r = 0; r < ref_names.size(); ++r)
                 if (ref_names[r] == only) target = (int)r;
             if (target < 0) return true;
-            const IndexSpan sp = index_lookup(index_path_of(path, true), true, std::string(), target);
+            IndexSpan sp = index_lookup(index_path_of(path, true), true, std::string(), target, has_region ? reg_start : -1,
+                                        has_region ? reg_stop : -1);
             if (sp.usable && !sp.present) return true;
+            if (has_region && !(sp.usable && sp.region)) has_region = false;  // (the whole contig: a superset)
+            if (has_region) sp.beg = sp.reg_beg;  // start at the first record that overlaps the region ...
+            region_ref = target;
             if (sp.usable && seek_to(sp)) {
+                // ... and stop - for now - where the linear index says the records behind it begin
+                if (has_region) read_end = std::min(hard_read_end, (long long)(sp.reg_soft_end >> 16) + 0x10000 + 64);
                 const long long seek_pos = ftell(fp);
                 curp = Piece{};
                 curp.n = fill(buf, 0);
@@ -4049,7 +4059,10 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
                 read_end = -1;
                 partial_tail_ok = false;
                 first_skip = 0;
+                has_region = false;
             }
+        } else {
+            has_region = false;
         }
     }
     if (!submit_front(curp, n_submitted++) || !submit_back(curp)) return false;
@@ -4149,6 +4162,7 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         ++n_pieces;
         n_rows_total += B.n_rows;
         n_records += B.n_records;
+        last_key = std::max(last_key, (unsigned long long)B.last_key);
         S.freed_valid = hipEventRecord(S.freed, pstream) == hipSuccess;
         if (!S.freed_valid) {
             (void)hipGetLastError();
@@ -4182,7 +4196,23 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         }
         clk.lap(5);
         if (!settle(curp)) return false;
-        if (curp.eof) break;
+        if (curp.eof) {
+            // (region reads) the read stopped at the linear index's hint: complete when the last record lies at or behind
+            // the region's end or on a later reference; else a record longer than an index window hid the true end
+            const bool soft = has_region && read_end >= 0 && read_end < hard_read_end && curp.file_off >= 0 &&
+                              curp.file_off + (long long)curp.n >= read_end;
+            if (!soft) break;
+            const long long lref = (long long)(uint32_t)(last_key >> 32), lpos = (long long)(uint32_t)last_key;
+            const bool complete = last_key != 0 && (lref != (long long)region_ref || lpos >= reg_stop);
+            if (clk.on)
+                fprintf(stderr, "[ftk stream bam] region %lld-%lld: piece ends at file offset %lld (hint %lld, contig ends %lld): %s\n",
+                        reg_start, reg_stop, curp.file_off + (long long)curp.n, read_end, hard_read_end,
+                        complete ? "complete" : "a long record hides the end, reading on");
+            if (complete) break;
+            read_end = std::min(hard_read_end, read_end + (long long)(size_t(8) << 20));
+            curp.eof = false;
+            if (!read_ahead_fronts()) return false;
+        }
         if (ahead.empty()) return fail(FTK_ERR_HIP, "piece queue out of step");
         curp = std::move(ahead.front());
         ahead.pop_front();

@@ -269,8 +269,7 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
         # The ranks' shares: the bins of all contigs laid end to end and cut into runs of equal cost
         # (sharding.split_counts - the partition bench.py's steps use), so a rank owns whole contigs plus at most two
         # partial ones; a partial one is read through the index as a REGION of the contig (source.region_contig).
-        # BAM input cannot be entered in the middle of a contig: whole contigs there, dealt heaviest first.
-        if world > 1 and not str(input_file).lower().endswith(".bam"):
+        if world > 1:
             units = sharding.split_counts({c: len(plan[c][0]) for c in names}, world)
         else:
             owner = sharding.lpt_assign({c: float(len(plan[c][0])) for c in names}, world)

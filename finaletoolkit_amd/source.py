@@ -148,11 +148,12 @@ class FragSource:
 
     def require_region(self, contig: str, start: int, stop: int) -> str:
         """Engine key of a table that holds EVERY fragment of ``contig`` overlapping ``[start, stop)`` - the whole
-        contig when that is resident already (or when the file cannot be entered in the middle of a contig: BAM
-        input, no usable tabix index), else the rows ``ftk_fragstream_open_region`` reads for the region (index seek
-        to its first row, the parsed rows say where it is complete).  A rank of a multi-GPU run loads its share of a
+        contig when that is resident already (or when the file cannot be entered in the middle of a contig: an index
+        without the 16 kb linear index), else the rows / records ``ftk_fragstream_open_region`` reads for the region
+        (index seek to its first row, the parsed rows say where it is complete; for a BAM: every fragment whose read1
+        overlaps the region).  A rank of a multi-GPU run loads its share of a
         contig this way (``sharding.split_counts``); ``release_region`` drops the table."""
-        if contig in self.loaded or self.is_bam or not self.lazy:
+        if contig in self.loaded or not self.lazy:
             return self.require(contig)
         if contig not in self.contigs:
             raise ValueError(f"could not create iterator for region '{contig}': contig not present in {self.path}")
@@ -166,7 +167,7 @@ class FragSource:
         lib = L.load()
         stream = C.c_void_p()
         REGION_READS.append((self.path, contig, start, stop))
-        rc = lib.ftk_fragstream_open_region(eng.device, self.path.encode(), contig.encode(), start, stop, 0,
+        rc = lib.ftk_fragstream_open_region(eng.device, self.path.encode(), contig.encode(), start, stop, int(self.is_bam),
                                             decode_threads(self.workers), 1, C.byref(stream))
         if rc != L.FTK_OK:
             raise UnsupportedFormatError(lib.ftk_fragtable_error().decode())
@@ -177,12 +178,12 @@ class FragSource:
                 raise UnsupportedFormatError(lib.ftk_fragtable_error().decode())
             if table.value:
                 try:
-                    eng.load_contig_from_table(key, table, 0, False)
+                    eng.load_contig_from_table(key, table, 0, self.is_bam)
                 finally:
                     lib.ftk_fragtable_free(table)
             else:
                 e32, e8 = np.zeros(0, np.int32), np.zeros(0, np.uint8)
-                eng.load_contig(key, e32, e32, e8, e8)
+                eng.load_contig(key, e32, e32, e8, e8, *((e32, e32) if self.is_bam else ()))
             self.regions.add(key)
         finally:
             lib.ftk_fragstream_close(stream)
@@ -194,7 +195,7 @@ class FragSource:
         decoded whole for a first or second small interval (a 30x chr1 is 25 M rows for a call that needs a few
         thousand) - the interval's rows come through the index as a region, the two most recent region tables are
         kept - but from the third call on it is, since whoever asks three times will ask again."""
-        if start is None or stop is None or contig in self.loaded or self.is_bam or not self.lazy:
+        if start is None or stop is None or contig in self.loaded or not self.lazy:
             return self.require(contig)
         start, stop = int(start) - int(pad), int(stop) + int(pad)
         hits = self._interval_hits.get(contig, 0) + 1

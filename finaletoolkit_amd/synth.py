@@ -129,7 +129,9 @@ def write_paired_bam(path, contig, size, depth, seed, read_len=50):
     head += struct.pack("<i", len(contig) + 1) + contig.encode() + b"\0" + struct.pack("<i", size)
     offs = writers.bgzf_write(path, head, level=1, write_eof=False)
     offs2 = writers.bgzf_write(path, a.tobytes(), level=1, append=True)
-    bgzf.write_index(str(path) + ".bai", True, [(contig, int(offs2[0]) << 16, int(offs2[-1]) << 16)])
+    # (with the 16 kb linear index: a reader may start inside the contig - ftk_fragstream_open_region)
+    linear = bgzf.linear_index(a["pos"], a["pos"].astype(np.int64) + read_len, np.full(2 * n, rec.itemsize, np.int64), offs2)
+    bgzf.write_index(str(path) + ".bai", True, [(contig, int(offs2[0]) << 16, int(offs2[-1]) << 16)], [linear])
     # read1 records in file order -> stable sort by fragment start = the decoder's row order
     is_r1 = order < n
     file_rank = order[is_r1]                          # fragment index of every read1 record, in file order

@@ -101,8 +101,8 @@ def test_bam_file_path_read1_semantics(tmp_path):
 
 @pytest.mark.gpu
 def test_lazy_sources_decode_only_what_is_asked_for(tmp_path, monkeypatch):
-    """Indexed inputs are opened lazily: a region query decodes one contig (through the index), whole-file
-    operations load the rest, and the results equal the one-pass decode (FTK_LAZY_SOURCE=0)."""
+    """Indexed inputs are opened lazily: an interval query reads the interval's records through the index (or decodes one
+    contig when the interval is open-ended), whole-file operations load the rest, and the results equal the one-pass decode (FTK_LAZY_SOURCE=0)."""
     from finaletoolkit_amd import bgzf, frag, source
     path, expected = _make(tmp_path)                      # BAM + real (minimal) BAI
     rows = []
@@ -125,7 +125,8 @@ def test_lazy_sources_decode_only_what_is_asked_for(tmp_path, monkeypatch):
 
     source.close_all()
     lazy, loaded = run()
-    assert loaded == ({"chr2"}, {"t1"})
+    # the BAM interval came through the BAI as a region of chr2 (no contig decoded); the open-ended text query loaded t1
+    assert loaded == (set(), {"t1"}) and source.REGION_READS[-1][1:] == ("chr2", 9_999, 200_001)  # (one base of padding)
     assert set(source.open_source(path).loaded) == {"chr1", "chrEmpty", "chr2"}
     assert set(source.open_source(text).loaded) == {"t0", "t1", "t2"}
     assert lazy[1] == len(rows[1][1]) and lazy[3] == sum(len(r[1]) for r in rows)

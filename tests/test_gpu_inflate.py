@@ -549,3 +549,77 @@ def test_bam_device_parser_with_records_longer_than_a_stretch(tmp_path):
     for stretch in ("1024", "16384"):
         r = _multi_child(tmp_path, p, ("chrL", "chrM"), dict(FTK_STREAM_PIECE=str(1 << 18), FTK_BAM_DEV_STRETCH=stretch))
         assert "['chrL', 'chrM']" in r.stdout and "the host decoder takes over" not in r.stderr, r.stdout[-400:] + r.stderr[-1500:]
+
+
+_BAM_REGION_CHILD = """
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from finaletoolkit_amd import _lib as L
+lib = L.load()
+
+def table_rows(t):
+    rows = lib.ftk_fragtable_contig_rows(t, 0)
+    cols = [np.empty(rows, np.int32), np.empty(rows, np.int32), np.empty(rows, np.uint8), np.empty(rows, np.uint8)]
+    assert lib.ftk_fragtable_columns_to_host(t, 0, *[c.ctypes.data_as(C.c_void_p) for c in cols]) == 0
+    r1 = [np.empty(rows, np.int32), np.empty(rows, np.int32)]
+    assert lib.ftk_fragtable_read1_to_host(t, 0, *[c.ctypes.data_as(C.c_void_p) for c in r1], None) == 0
+    return np.stack([c.astype(np.int64) for c in cols + r1], 1)
+
+def stream(path, contig, a=None, b=None):
+    s = C.c_void_p()
+    if a is None:
+        rc = lib.ftk_fragstream_open_device(0, path.encode(), contig.encode(), 1, 8, 1, C.byref(s))
+    else:
+        rc = lib.ftk_fragstream_open_region(0, path.encode(), contig.encode(), a, b, 1, 8, 1, C.byref(s))
+    assert rc == 0, lib.ftk_fragtable_error().decode()
+    out = None
+    while True:
+        t = C.c_void_p()
+        rc = lib.ftk_fragstream_next(s, C.byref(t))
+        assert rc == 0, lib.ftk_fragtable_error().decode()
+        if not t.value:
+            break
+        assert out is None
+        out = table_rows(t)
+        lib.ftk_fragtable_free(t)
+    lib.ftk_fragstream_close(s)
+    return np.zeros((0, 6), np.int64) if out is None else out
+
+path = sys.argv[1]
+from collections import Counter
+whole = stream(path, "mid")
+keys = Counter(map(tuple, whole.tolist()))
+report = []
+for spec in sys.argv[2:]:
+    a, b = map(int, spec.split(":"))
+    got = stream(path, "mid", a, b)
+    gk = Counter(map(tuple, got.tolist()))
+    assert not (gk - keys), spec                                          # rows of the contig, none more often than there
+    need = whole[(whole[:, 4] < b) & (whole[:, 5] > a)]                   # read1 overlaps the region
+    assert not (Counter(map(tuple, need.tolist())) - gk), (spec, len(need), len(got))
+    assert np.all(np.diff(got[:, 0]) >= 0), spec                          # sorted by fragment start like the whole table
+    report.append((spec, len(got), len(whole), len(need)))
+print("ok", report)
+"""
+
+
+def test_bam_region_streams_hold_every_read1_that_overlaps(tmp_path):
+    """ftk_fragstream_open_region on a BAM with a linear index in its BAI: the records are read from the first that
+    overlaps the region to the first behind it (the device parser's summary carries the last record's position), the
+    table holds every fragment whose read1 overlaps the region, sorted by fragment start, and a small region reads a
+    small part of the contig - with 48 MB and 128 KB pieces."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = str(tmp_path / "reg.bam")
+    synth.write_paired_bam(p, "mid", 6_000_000, 30.0, 17)
+    specs = ["0:50000", "3000000:3100000", "5950000:6000000", "2500000:2500001", "1000000:4000000", "5999999:7000000"]
+    for env in (dict(), dict(FTK_STREAM_PIECE=str(1 << 17))):
+        r = subprocess.run([sys.executable, "-c", _BAM_REGION_CHILD.format(root=root), p] + specs, capture_output=True, text=True,
+                           timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+        rep = {k: (a, b, c) for k, a, b, c in eval(r.stdout[r.stdout.index("ok") + 3:])}
+        assert rep["3000000:3100000"][0] < rep["3000000:3100000"][1] // 10 and rep["3000000:3100000"][2] > 1000
+        assert rep["1000000:4000000"][0] > rep["1000000:4000000"][1] // 2 - 1000
