@@ -162,8 +162,9 @@ int ftk_fragstream_open_device(int device_id, const char* path, const char* cont
 /* A stream over the rows of ONE REGION of a contig (the reference's per-window `fetch(contig, start, stop)`,
  * io/alignment.py:205-268, at the granularity a rank of a multi-GPU run needs: frag/_delfi.py's ranks each take a
  * window-aligned share of the genome).  The single table it hands out holds EVERY row of `contig` that overlaps
- * [start, stop) - and may hold more (rows before the region from the first block read; the whole contig for BAM input,
- * files without a usable tabix index, streams without a device or with FTK_DEVICE_INFLATE=0).  With a tabix index the
+ * [start, stop) - for a BAM: every fragment whose read1 record overlaps it - and may hold more (rows before the region
+ * from the first block read; the whole contig for files whose index has no linear index, streams without a device or
+ * with FTK_DEVICE_INFLATE=0 / FTK_DEVICE_BAM_PARSE=0).  With a tabix index (a BAI for BAM input) the
  * read starts at the linear index's offset for `start` and ends where the parsed rows say the region is complete: a
  * row that starts at or behind `stop`, or another contig's rows, were seen (the index's 16 kb windows give a first
  * guess; a row longer than a window makes the read go on in 8 MB steps).  Arguments otherwise as
