@@ -167,6 +167,8 @@ class FragSource:
         lib = L.load()
         stream = C.c_void_p()
         REGION_READS.append((self.path, contig, start, stop))
+        if len(REGION_READS) > 4096:  # (a diagnostic trail, not a log: a long-lived host keeps the most recent ones)
+            del REGION_READS[:2048]
         rc = lib.ftk_fragstream_open_region(eng.device, self.path.encode(), contig.encode(), start, stop, int(self.is_bam),
                                             decode_threads(self.workers), 1, C.byref(stream))
         if rc != L.FTK_OK:
