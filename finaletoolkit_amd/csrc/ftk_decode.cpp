@@ -2768,7 +2768,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
                 if (j[i].valid()) (void)j[i].get();
         }
     } job_guard{host_job};
-    double t_jobwait = 0, t_upwait = 0;
+    double t_jobwait = 0;
     size_t host_inflated = 0;
     // (a GPU piece's compressed bytes go up straight from the page-locked read buffer; fill() lets that buffer rest
     // until the copy is done - see buf_in_flight)
@@ -3281,7 +3281,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     clk.report("text, device rows (parse = launch, merge = collect)");
     if (clk.on)
         fprintf(stderr, "[ftk stream text] %zu pieces parsed on the device, %zu by the host; %zu inflated by the host threads beside the GPU "
-                        "(waited %.1f ms for them, %.1f ms for pieces' bytes to be up)\n", gpu_pieces, host_pieces, host_inflated, t_jobwait, t_upwait);
+                        "(waited %.1f ms for them)\n", gpu_pieces, host_pieces, host_inflated, t_jobwait);
     if (clk.on && n_timed)
         fprintf(stderr, "[ftk stream text] device time per piece: front (copy up, inflate, CRC) avg %.2f max %.2f ms, back (set-up, rows) avg %.2f max %.2f ms, %zu pieces\n",
                 front_ms / n_timed, front_max, back_ms / n_timed, back_max, n_timed);
@@ -3791,7 +3791,7 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         ftk_fragstream* s;
         ~RestGuard() { s->drop_resting(); }
     } rest_guard{this};
-    double t_upwait = 0, t_jobwait = 0, t_front = 0, t_header = 0;  // FTK_DECODE_TIMING: what "other" is made of
+    double t_jobwait = 0, t_front = 0, t_header = 0;  // FTK_DECODE_TIMING: what "other" is made of
     auto tick = [] { return std::chrono::steady_clock::now(); };
     auto since = [](std::chrono::steady_clock::time_point t0) {
         return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -4226,9 +4226,8 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
     clk.report("bam, records parsed on the device (inflate = waiting for a piece, parse = appends, merge = sort)");
     if (clk.on)
         fprintf(stderr, "[ftk stream bam] %zu pieces, %zu records, %zu fragments parsed on the device (stretch %u bytes); of \"other\": "
-                        "header piece %.1f ms, fronts enqueued %.1f ms, waiting for a piece's bytes to be up %.1f ms, for the host "
-                        "threads' inflate %.1f ms\n",
-                n_pieces, n_records, n_rows_total, stretch_bytes, t_header, t_front, t_upwait, t_jobwait);
+                        "header piece %.1f ms, fronts enqueued %.1f ms, waiting for the host threads' inflate %.1f ms\n",
+                n_pieces, n_records, n_rows_total, stretch_bytes, t_header, t_front, t_jobwait);
     return true;
 }
 
