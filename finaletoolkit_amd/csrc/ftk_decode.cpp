@@ -1727,20 +1727,47 @@ inline uint64_t rd_u64(const uint8_t* p) { return (uint64_t)rd_u32(p) | ((uint64
 IndexSpan index_lookup(const std::string& index_path, bool bai, const std::string& name, int ref, long long reg_start = -1,
                        long long reg_stop = -1) {
     IndexSpan out;
-    Bytes raw, img;
-    if (!read_file(index_path.c_str(), &raw) || raw.size() < 8) return out;
-    const uint8_t* p;
-    size_t n;
-    if (bai) {
-        p = raw.data();
-        n = raw.size();
-        if (memcmp(p, "BAI\1", 4) != 0) return out;
-    } else {
-        if (inflate_all(raw, 1, &img) != FTK_OK || img.size() < 36) return out;
-        p = img.data();
-        n = img.size();
-        if (memcmp(p, "TBI\1", 4) != 0) return out;
+    // The index image (a tabix index inflated) of the file asked for last stays in memory: a whole-genome .tbi is
+    // ~1.5 MB to read and inflate - 3 ms on one thread - and region reads ask for it once per region (a rank's two
+    // partial contigs, every one-interval API call).  Keyed by path, size and modification time.
+    struct Cached {
+        std::string path;
+        long long size = -1, mtime_ns = 0;
+        std::shared_ptr<std::vector<uint8_t>> image;
+    };
+    static std::mutex cache_mu;
+    static Cached cache[2];
+    static unsigned cache_turn = 0;
+    std::shared_ptr<std::vector<uint8_t>> image;
+    struct stat ist;
+    if (stat(index_path.c_str(), &ist) != 0) return out;
+    const long long isize = (long long)ist.st_size,
+                    imtime = (long long)ist.st_mtim.tv_sec * 1000000000LL + (long long)ist.st_mtim.tv_nsec;
+    {
+        std::lock_guard<std::mutex> lk(cache_mu);
+        for (auto& c : cache)
+            if (c.image && c.path == index_path && c.size == isize && c.mtime_ns == imtime) image = c.image;
     }
+    if (!image) {
+        Bytes raw, img;
+        if (!read_file(index_path.c_str(), &raw) || raw.size() < 8) return out;
+        const Bytes* src = &raw;
+        if (!bai) {
+            if (inflate_all(raw, 1, &img) != FTK_OK || img.size() < 36) return out;
+            src = &img;
+        }
+        image = std::make_shared<std::vector<uint8_t>>(src->data(), src->data() + src->size());
+        std::lock_guard<std::mutex> lk(cache_mu);
+        Cached& slot = cache[cache_turn++ & 1u];
+        slot.path = index_path;
+        slot.size = isize;
+        slot.mtime_ns = imtime;
+        slot.image = image;
+    }
+    const uint8_t* p = image->data();
+    const size_t n = image->size();
+    if (n < 8 || memcmp(p, bai ? "BAI\1" : "TBI\1", 4) != 0) return out;
+    if (!bai && n < 36) return out;
     const int32_t n_ref = rd_i32(p + 4);
     size_t o = 8;
     if (!bai) {
