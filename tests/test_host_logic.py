@@ -247,3 +247,56 @@ def test_interval_statistics_block_form_equals_the_per_interval_form():
         m, md, sd, a, b, t, ns = FL._stats_from_dist(nz + lo, h[r][nz], 150)
         assert (mean[r], median[r], vmin[r], vmax[r], tot[r], n_short[r]) == (m, md, a, b, t, ns), r
         assert stdev[r] == pytest.approx(sd, rel=1e-12, abs=1e-12)
+
+
+def test_linear_index_of_the_synthetic_files_is_tabix_s(tmp_path):
+    """bgzf.write_frag_gz(with_index=True) writes the 16 kb linear index a region read starts from
+    (ftk_fragstream_open_region): for every window the virtual offset of the FIRST row that overlaps it - checked
+    against a brute-force scan of the rows and against the bytes at that offset - and an empty window points at the next
+    window's rows, as htslib writes it."""
+    import gzip
+    import struct
+    from finaletoolkit_amd import bgzf
+    rng = np.random.default_rng(1)
+    rows = []
+    for name, n, size in (("c1", 3000, 900_000), ("c2", 2000, 300_000)):
+        s = np.sort(rng.integers(0, size, n))
+        if name == "c1":
+            s = s[(s < 200_000) | (s > 420_000)]  # thirteen windows without a row start
+        e = s + rng.integers(30, 40_000, len(s))
+        rows.append((name, s, e, rng.integers(0, 61, len(s)), rng.integers(0, 2, len(s))))
+    p = str(tmp_path / "x.frag.gz")
+    bgzf.write_frag_gz(p, rows, with_index=True)
+    raw = gzip.open(p + ".tbi").read()
+    assert raw[:4] == b"TBI\1" and struct.unpack("<i", raw[4:8])[0] == 2
+    o = 36 + struct.unpack("<i", raw[32:36])[0]
+    data = gzip.open(p).read()
+    img = open(p, "rb").read()
+    offs, off = [], 0
+    while off < len(img):
+        offs.append(off)
+        off += int.from_bytes(img[off + 16:off + 18], "little") + 1
+    for r, (name, s, e, q, t) in enumerate(rows):
+        n_bin = struct.unpack("<i", raw[o:o + 4])[0]
+        o += 4
+        for _ in range(n_bin):
+            _, nc = struct.unpack("<Ii", raw[o:o + 8])
+            o += 8 + 16 * nc
+        n_intv = struct.unpack("<i", raw[o:o + 4])[0]
+        o += 4
+        lin = np.frombuffer(raw[o:o + 8 * n_intv], "<u8")
+        o += 8 * n_intv
+        assert n_intv == ((int(e.max()) - 1) >> 14) + 1
+        first_byte = data.find((name + "\t").encode()) if r == 0 else data.find(("\n" + name + "\t").encode()) + 1
+        lens = bgzf.row_lengths(name, s, e, q)
+        pos = first_byte + np.concatenate(([0], np.cumsum(lens)[:-1]))
+        voff = np.array([(offs[int(x) // 0xFF00] << 16) | (int(x) % 0xFF00) for x in pos], np.uint64)
+        for i in (0, 1, len(s) // 2, len(s) - 1):
+            assert data[pos[i]:pos[i] + lens[i]].decode() == f"{name}\t{s[i]}\t{e[i]}\t{q[i]}\t{'+' if t[i] else '-'}\n"
+        nxt = None
+        for w in range(n_intv - 1, -1, -1):
+            ov = np.nonzero((s < (w + 1) << 14) & (e > w << 14))[0]
+            if len(ov):
+                nxt = voff[ov[0]]
+            assert lin[w] == nxt, (name, w)
+        assert np.all(np.diff(lin.astype(np.int64)) >= 0)  # offsets never go back
