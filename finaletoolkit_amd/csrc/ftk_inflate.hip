@@ -820,14 +820,34 @@ __device__ __forceinline__ uint32_t gf2_mul(uint32_t a, uint32_t b) {  // a * b 
     return p;
 }
 
-__device__ __forceinline__ uint32_t gf2_x_pow_8n(uint32_t n) {  // x^(8 n) mod P
-    uint32_t p = 1u << 31;        // x^0
-    uint32_t sq = 0x00800000u;    // x^8
-    while (n) {
-        if (n & 1u) p = gf2_mul(sq, p);
-        sq = gf2_mul(sq, sq);
-        n >>= 1;
+// x^(8 * 2^k) mod P for k = 0..16 (a block holds at most 2^16 bytes), worked out by the compiler: the fold's powers
+// are products of these - no squaring chain at run time (the chain was 15 x 2 multiplications of ~190 operations per
+// level of the fold: as much work as the bit-serial stripes themselves)
+constexpr uint32_t gf2_mul_c(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (uint32_t m = 1u << 31; m; m >>= 1) {
+        if (a & m) p ^= b;
+        b = (b & 1u) ? (b >> 1) ^ 0xedb88320u : b >> 1;
     }
+    return p;
+}
+struct Pow8Table {
+    uint32_t v[17];
+    constexpr Pow8Table() : v{} {
+        uint32_t sq = 0x00800000u;  // x^8
+        for (int k = 0; k < 17; ++k) {
+            v[k] = sq;
+            sq = gf2_mul_c(sq, sq);
+        }
+    }
+};
+constexpr Pow8Table kPow8{};
+
+__device__ __forceinline__ uint32_t gf2_x_pow_8n(uint32_t n) {  // x^(8 n) mod P, n < 2^17
+    uint32_t p = 1u << 31;  // x^0
+#pragma unroll
+    for (int k = 0; k < 17; ++k)
+        if ((n >> k) & 1u) p = gf2_mul(kPow8.v[k], p);
     return p;
 }
 
