@@ -23,6 +23,8 @@
 // which reach at most 258 + 64 bytes past A0: kFarDist + 258 + 64 <= kRing.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "ftk_inflate.h"
 
 namespace ftk {
@@ -851,49 +853,90 @@ __device__ __forceinline__ uint32_t gf2_x_pow_8n(uint32_t n) {  // x^(8 n) mod P
     return p;
 }
 
-__global__ __launch_bounds__(64) void bgzf_crc_kernel(const InflateBlock* __restrict__ tab, int n_blocks,
-                                                      const uint8_t* __restrict__ out, uint32_t* __restrict__ crc_out) {
-    const int lane = threadIdx.x, blk = blockIdx.x;
-    if (blk >= n_blocks) return;
-    const uint32_t len = tab[blk].out_len;
-    const uint8_t* p = out + tab[blk].out_off;
-    // stripes of whole 16-byte groups of the ADDRESS space (one aligned 16-byte load per 16 bytes; with byte loads
-    // every 128-byte line was fetched 128 times and a launch of 9 000 blocks ran at a third of the rate of one of
-    // 1 900: 64 lines per wave x 32 waves do not stay in a CU's L1); block start and end are the ragged ones
-    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u);
-    const uint32_t total = len + mis;
-    const uint32_t stripe = (((total + 63u) / 64u) + 15u) & ~15u;
-    p -= mis;
-    const uint32_t a = min(max((uint32_t)lane * stripe, mis), total), e = min(((uint32_t)lane + 1u) * stripe, total);
-    uint32_t c = 0xffffffffu;
-    auto byte_step = [&](uint32_t i) {  // bit-serial on the vector unit (a byte-wise table in LDS measured 70 GB/s:
-        c ^= p[i];                       // every lane looks up another word, bank conflicts)
+// Four waves per workgroup share four 256-entry tables in LDS (slicing-by-4: one 32-bit word of data per four look-ups;
+// the tables are built by the workgroup itself, 8 bit-steps per entry); each wave takes BGZF blocks of its own.  The
+// bit-serial stripes this replaces spent 32 vector operations per byte (1.1 TB/s with the table-driven fold); a lane's
+// look-ups go to random entries, so a wave's ds_read meets bank conflicts (256 words over 32 banks) - still a fraction of
+// the bit-serial cost.
+constexpr int kCrcWaves = 4;
+
+__global__ __launch_bounds__(64 * kCrcWaves) void bgzf_crc_kernel(const InflateBlock* __restrict__ tab, int n_blocks,
+                                                                  const uint8_t* __restrict__ out, uint32_t* __restrict__ crc_out) {
+    __shared__ uint32_t T[4][256];
+    {
+        const int i = threadIdx.x;  // 256 threads: one entry of each table
+        uint32_t c = (uint32_t)i;
 #pragma unroll
         for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
-    };
-    uint32_t i = a;
-    for (; i < e && (i & 15u); ++i) byte_step(i);
-    for (; i + 16u <= e; i += 16u) {
-        const uint4 v = *reinterpret_cast<const uint4*>(p + i);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        T[0][i] = c;
+        __syncthreads();
+        uint32_t t1 = (c >> 8) ^ T[0][c & 255u];
+        uint32_t t2 = (t1 >> 8) ^ T[0][t1 & 255u];
+        uint32_t t3 = (t2 >> 8) ^ T[0][t2 & 255u];
+        T[1][i] = t1;
+        T[2][i] = t2;
+        T[3][i] = t3;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int blk = blockIdx.x * kCrcWaves + wv; blk < n_blocks; blk += gridDim.x * kCrcWaves) {
+        const uint32_t len = tab[blk].out_len;
+        const uint8_t* p = out + tab[blk].out_off;
+        // 64 stripes of `stripe` bytes cut from the END of the block's data: lane 63 ends where the data ends, every
+        // stripe to the right of a non-empty one is full, the ragged (or empty) ones are the first.  The fold's
+        // multiplier - x^(8 * bytes to the right) - is then the same for every lane of a level, x^(8 * d * stripe):
+        // one squaring per level instead of a power per lane.  (Cut from the start, as the first version did, the
+        // ragged stripe was on the right and every level paid for two different powers.)
+        const uint32_t stripe = max((((len + 63u) / 64u) + 15u) & ~15u, 16u);
+        const long long hi = (long long)len - (long long)(63 - lane) * stripe, lo = hi - stripe;
+        const uint32_t a = (uint32_t)max(lo, 0ll), e = (uint32_t)max(hi, 0ll);
+        uint32_t c = 0xffffffffu;
+        auto byte_step = [&](uint32_t i) { c = T[0][(c ^ p[i]) & 255u] ^ (c >> 8); };
+        uint32_t i = a;
+        // one aligned 16-byte load per 16 bytes (with byte loads every 128-byte line was fetched 128 times and a launch
+        // of 9 000 blocks ran at a third of the rate of one of 1 900: the lines do not stay in a CU's L1)
+        auto word_step = [&](uint32_t w) {
+            const uint32_t x = c ^ w;
+            c = T[3][x & 255u] ^ T[2][(x >> 8) & 255u] ^ T[1][(x >> 16) & 255u] ^ T[0][x >> 24];
+        };
+        for (; i < e && ((reinterpret_cast<uintptr_t>(p) + i) & 15u); ++i) byte_step(i);
+        // 128 bytes - a cache line's worth - per lane at a time: the lanes' stripes lie a kilobyte apart, so a wave's
+        // load touches 64 lines; taking a line in one burst of eight loads keeps it from being fetched eight times
+        // (a chip-filling launch has 64 MB of such lines in flight, more than the L2s hold)
+        for (; i + 128u <= e; i += 128u) {
+            uint4 v[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            c ^= w[q];
-#pragma unroll 8
-            for (int k = 0; k < 32; ++k) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const uint4*>(p + i + 16 * q);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                word_step(v[q].x);
+                word_step(v[q].y);
+                word_step(v[q].z);
+                word_step(v[q].w);
+            }
         }
-    }
-    for (; i < e; ++i) byte_step(i);
-    c = (e > a) ? ~c : 0u;      // CRC of the stripe (0 for an empty one: the neutral element of the fold)
-    uint32_t n = e - a;         // bytes this lane's value covers
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t c_r = __shfl_down(c, d, 64), n_r = __shfl_down(n, d, 64);
-        if ((lane & (2 * d - 1)) == 0) {
-            if (n_r) c = n ? (gf2_mul(gf2_x_pow_8n(n_r), c) ^ c_r) : c_r;
-            n += n_r;
+        for (; i + 16u <= e; i += 16u) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p + i);
+            word_step(v.x);
+            word_step(v.y);
+            word_step(v.z);
+            word_step(v.w);
         }
+        for (; i < e; ++i) byte_step(i);
+        bool have = e > a;
+        c = have ? ~c : 0u;  // CRC of the stripe (0 for an empty one: the neutral element of the fold)
+        uint32_t pw = gf2_x_pow_8n(stripe);
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t c_r = __shfl_down(c, d, 64);
+            const bool have_r = __shfl_down((int)have, d, 64) != 0;
+            if ((lane & (2 * d - 1)) == 0 && have_r) {  // crc(A || B) = crc(A) * x^(8 |B|) xor crc(B); |B| = d stripes
+                c = have ? (gf2_mul(pw, c) ^ c_r) : c_r;
+                have = true;
+            }
+            pw = gf2_mul(pw, pw);
+        }
+        if (lane == 0) crc_out[blk] = c;
     }
-    if (lane == 0) crc_out[blk] = c;
 }
 
 }  // namespace
@@ -918,7 +961,11 @@ void inflate_launch(hipStream_t s, const uint8_t* d_comp, const InflateBlock* d_
                     InflateStatus* d_status, uint32_t* d_crc) {
     if (n_blocks <= 0) return;
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(n_blocks), dim3(64), 0, s, d_comp, d_tab, n_blocks, d_out, d_status);
-    if (d_crc) hipLaunchKernelGGL(bgzf_crc_kernel, dim3(n_blocks), dim3(64), 0, s, d_tab, n_blocks, d_out, d_crc);
+    if (d_crc) {
+        // (workgroups of four waves, a block per wave)
+        const int groups = std::min((n_blocks + kCrcWaves - 1) / kCrcWaves, 1 << 20);
+        hipLaunchKernelGGL(bgzf_crc_kernel, dim3(groups), dim3(64 * kCrcWaves), 0, s, d_tab, n_blocks, d_out, d_crc);
+    }
 }
 
 }  // namespace ftk
