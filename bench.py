@@ -58,8 +58,10 @@ def main():
     import torch
     import torch.distributed as dist
 
+    from finaletoolkit_amd import _lib
     from finaletoolkit_amd.engine import Engine
 
+    _lib.load()  # before the first HIP call of this process: loading sets the decoder's hardware-queue count (FTK_HW_QUEUES)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -6,17 +6,83 @@ Host Python keeps the ``finaletoolkit.frag.*`` surface
 (``finaletoolkit_amd.frag``); the per-fragment loops run as HIP kernels behind
 the C ABI of ``include/ftk.h`` (``libftk_hip.so``).  No CPU fallback.
 """
-import os as _os
-
-# The streaming decoder keeps up to eight pieces of a file in flight on HIP streams of their own (inflate kernels of two or
-# three pieces side by side, the row parser behind them on another stream); the HIP runtime multiplexes all streams of
-# a process onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on one queue run strictly one after the
-# other.  Measured on the whole-genome DELFI leg (tools/e2e_genome_bench.py): 4 queues 0.176-0.183 s, 8: 0.161-0.181 s,
-# 16: 0.151-0.162 s.  Read when the runtime initialises (first HIP call), so it is set here, before any; an explicit
-# setting of the user's wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+import importlib as _importlib
+import importlib.util as _importlib_util
+import sys as _sys
 
 from .exceptions import (FinaleToolkitError, InvalidInputError, MissingIndexError,  # noqa: F401
                          UnsupportedFormatError)
 
 __version__ = "0.1.0"
+
+# Flat namespace of the reference (``finaletoolkit.<name>``, src/finaletoolkit/__init__.py:49-128), resolved on first
+# use (PEP 562) so that importing the package for its names loads neither pandas nor the HIP library.  Listed per
+# submodule: every hot-path export that exists here.  Reference exports outside the path (``filter_file``,
+# ``frag_bam_to_bed``, ``low_quality_read_pairs``, ``reverse_complement``, the pysam wrappers) are named in
+# ``_OUT_OF_SCOPE`` so that asking for one says why it is absent.
+_SUBMODULES = ("cli", "frag", "genome", "io", "utils")
+_FLAT_BY_MODULE = {
+    "frag": ("frag_length", "frag_length_bins", "frag_length_intervals", "coverage", "single_coverage", "wps",
+             "multi_wps", "adjust_wps", "cleavage_profile", "multi_cleavage_profile", "delfi", "delfi_gc_correct",
+             "delfi_merge_bins", "end_motifs", "region_end_motifs", "interval_end_motifs", "EndMotifFreqs",
+             "EndMotifsIntervals", "breakpoint_motifs", "region_breakpoint_motifs", "interval_breakpoint_motifs",
+             "BreakpointMotifFreqs", "BreakpointMotifsIntervals", "CoverageResult", "FragLengthStats"),
+    "utils": ("frag_generator", "frag_array", "frags_in_region", "agg_bw", "get_intervals", "overlaps", "gen_kmers",
+              "chrom_sizes_to_dict", "chrom_sizes_to_list"),
+    "genome": ("GenomeGaps", "ContigGaps", "ucsc_hg19_gap_bed", "b37_gap_bed", "ucsc_hg38_gap_bed"),
+    "io": ("Fragment",),
+}
+_FLAT = {name: module for module, names in _FLAT_BY_MODULE.items() for name in names}
+_SINGULAR = {"end_motif": "end_motifs", "breakpoint_motif": "breakpoint_motifs"}
+_OUT_OF_SCOPE = ("filter_file", "frag_bam_to_bed", "low_quality_read_pairs", "reverse_complement", "ReferenceWrapper",
+                 "AlignmentWrapper")
+
+
+def __getattr__(name):
+    if name in _SUBMODULES:
+        return _importlib.import_module("." + name, __name__)
+    module = _FLAT.get(_SINGULAR.get(name, name))
+    if module is not None:
+        value = getattr(_importlib.import_module("." + module, __name__), _SINGULAR.get(name, name))
+        globals()[name] = value
+        return value
+    if name in _OUT_OF_SCOPE:
+        raise AttributeError(f"{__name__}.{name}: this reference utility is outside the accelerated hot path "
+                             "(SURVEY.md section 8) and is not provided; use the reference package for it")
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
+def __dir__():
+    return sorted(set(globals()) | set(_SUBMODULES) | set(_FLAT) | set(_SINGULAR))
+
+
+def install_alias(name: str = "finaletoolkit", force: bool = False):
+    """Make ``import finaletoolkit`` (and ``finaletoolkit.frag`` / ``.utils`` / ``.genome`` / ``.io`` / ``.cli`` /
+    ``.exceptions``) resolve to this package, so a script written against the reference runs unchanged:
+
+        import finaletoolkit_amd; finaletoolkit_amd.install_alias()
+        import finaletoolkit as ft; ft.frag.delfi(...); ft.coverage(...)
+        from finaletoolkit.frag import wps
+
+    Opt-in, per process.  Refuses (``ImportError``) when a real ``finaletoolkit`` distribution is importable, unless
+    ``force`` - two packages answering to one name is the caller's decision.  Returns the package."""
+    this = _sys.modules[__name__]
+    have = _sys.modules.get(name)
+    if have is not None and have is not this and not force:
+        raise ImportError(f"a different module is already imported as {name!r}; pass force=True to shadow it")
+    if have is None and not force:
+        try:
+            found = _importlib_util.find_spec(name)
+        except (ImportError, ValueError):
+            found = None
+        if found is not None:
+            raise ImportError(f"{name!r} is installed ({found.origin}); pass force=True to shadow it in this process")
+    _sys.modules[name] = this
+    for sub in _SUBMODULES + ("exceptions",):
+        module = _importlib.import_module("." + sub, __name__)
+        _sys.modules[f"{name}.{sub}"] = module
+    # the reference keeps its utilities in a package; ``finaletoolkit.utils.utils`` is the one deep path scripts use
+    utils = _sys.modules[f"{name}.utils"]
+    _sys.modules[f"{name}.utils.utils"] = utils
+    utils.utils = utils
+    return this

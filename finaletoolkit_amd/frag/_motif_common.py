@@ -22,16 +22,10 @@ import numpy as np
 from .. import sharding
 from ..reference import ReferenceGenome
 from ..source import get_engine, open_source
+from ..utils import gen_kmers  # noqa: F401  (the reference keeps it in utils; re-exported here for the motif modules)
 
 MIN_QUALITY = 20           # Jiang et al. (2020); _motif_common.py:30 of the reference
 _WINDOW_SIZE = 1_000_000   # genome-wide features are summed over 1 Mb windows (:33)
-
-
-def gen_kmers(k: int, bases: str = "ACGT") -> list[str]:
-    """All ``len(bases)**k`` k-mers in lexicographic order (utils/utils.py:388-410)."""
-    if k < 0:
-        raise ValueError("k must be non-negative")
-    return ["".join(t) for t in itertools.product(bases, repeat=k)]
 
 
 def normalized_shannon_mds(freq, k: int, miller_madow: bool = False, n=None) -> float:

@@ -81,6 +81,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         rank = int(os.environ["RANK"])
         if backend == "nccl":
+            from . import _lib
+            _lib._hardware_queues()  # torch starts the HIP runtime below; the decoder's queue count must be set before
             local = int(os.environ.get("FTK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
             if torch.cuda.device_count() <= local:
                 raise RuntimeError(f"rank {rank}: GPU {local} is not visible ({torch.cuda.device_count()} devices); "

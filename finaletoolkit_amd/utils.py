@@ -7,6 +7,7 @@ selection (``ftk_frag_select``) instead of a per-row Python predicate.
 """
 from __future__ import annotations
 
+import itertools
 from pathlib import Path
 from typing import Generator, Tuple
 
@@ -16,7 +17,7 @@ from .exceptions import InvalidInputError
 from .source import get_engine, open_source
 
 __all__ = ["chrom_sizes_to_list", "chrom_sizes_to_dict", "get_intervals", "overlaps", "frags_in_region", "frag_generator",
-           "frag_array"]
+           "frag_array", "agg_bw", "gen_kmers"]
 
 FragTuple = Tuple[str, int, int, int, bool]
 
@@ -72,6 +73,13 @@ def overlaps(contigs_1, starts_1, stops_1, contigs_2, starts_2, stops_2):
         e1 = stops_1[m1][:, None]
         out[m1] = np.any((s1 < stops_2[m2][None]) & (e1 > starts_2[m2][None]), axis=1)
     return out
+
+
+def gen_kmers(k: int, bases: str = "ACGT") -> list[str]:
+    """All ``len(bases)**k`` k-mers in lexicographic order (utils/utils.py:388-410)."""
+    if k < 0:
+        raise ValueError("k must be non-negative")
+    return ["".join(t) for t in itertools.product(bases, repeat=k)]
 
 
 def frags_in_region(frag_array, start: int, stop: int):
