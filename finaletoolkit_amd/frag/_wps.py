@@ -80,7 +80,11 @@ def wps(input_file: Union[str, Path], chrom: str, start: int, stop: int, chrom_s
         return np.zeros(0, dtype=_WPS_DTYPE)
     src = open_source(input_file)
     eng = get_engine()
-    values = eng.wps(src.require_interval(chrom, start, stop, int(window_size) + 1), start, stop, int(chrom_size), int(window_size),
+    # rows the call can need: tabix rows overlapping a base's window (window_size / 2 either side); for a BAM the
+    # read1 alignments overlapping the reference's fetch window [start - max_length, stop + max_length)
+    # (frag/_wps.py:156-157) - a read1 up to max_length outside the interval still brings its fragment in
+    pad = max(int(window_size), int(max_length)) + 1
+    values = eng.wps(src.require_interval(chrom, start, stop, pad), start, stop, int(chrom_size), int(window_size),
                      0 if min_length is None else int(min_length), int(max_length), int(quality_threshold))
     scores = _scores_array(chrom, start, values)
 

@@ -141,6 +141,97 @@ def write_paired_bam(path, contig, size, depth, seed, read_len=50):
                 r1e=(r1_pos[rows] + read_len).astype(np.int32), n=n, file_bytes=os.path.getsize(path))
 
 
+def write_paired_bam_contigs(path, contigs, depth, seed, read_len=50, step=8_388_608):
+    """Coordinate-sorted paired-end BAM of SEVERAL contigs at any size (BASELINE config 5 at real scale: a chr1-sized
+    60x contig is 5.7 GB on disk): records are built and written in position windows of ``step`` bases, so host memory
+    stays bounded by one window's records whatever the file size.  ``contigs``: ``[(name, length)]`` in header order;
+    fragments of contig ``k`` are ``synth_contig(length, depth, seed + k)`` (ends stretched to ``read_len``).  The
+    ``.bai`` carries every contig's span and its 16 kb linear index, so a reader may start inside a contig
+    (``ftk_fragstream_open_region``).  Returns ``{name: dict(s, e, q, st, r1s, r1e, n, first_off, end_off)}``: the
+    fragments in start order with their read1 span, and the file offsets of the contig's first block / the end of its
+    last one (which, with the 16 kb ``linear`` index, say whether a region read lies behind the 4 GiB mark)."""
+    import os
+    import struct
+    from . import bgzf, writers
+    name_len = 10
+    rec = np.dtype([("block_size", "<i4"), ("ref", "<i4"), ("pos", "<i4"), ("l_name", "u1"), ("mapq", "u1"),
+                    ("bin", "<u2"), ("n_cigar", "<u2"), ("flag", "<u2"), ("l_seq", "<i4"), ("next_ref", "<i4"),
+                    ("next_pos", "<i4"), ("tlen", "<i4"), ("name", f"S{name_len}"), ("cigar", "<u4"),
+                    ("seq", "u1", (read_len // 2,)), ("qual", "u1", (read_len,))])
+    text = b"@HD\tVN:1.6\tSO:coordinate\n" + b"".join(b"@SQ\tSN:%s\tLN:%d\n" % (c.encode(), n) for c, n in contigs)
+    head = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(contigs))
+    for c, n in contigs:
+        head += struct.pack("<i", len(c) + 1) + c.encode() + b"\0" + struct.pack("<i", n)
+    writers.bgzf_write(path, head, level=1, write_eof=False)
+    lut = np.repeat(np.array([2, 11, 25, 37], np.uint8), [8, 18, 51, 179])  # 3 / 7 / 20 / 70 % of the qualities
+    rng = np.random.default_rng(seed)
+    powers = 10 ** np.arange(name_len - 2, -1, -1, dtype=np.int64)
+    out, spans, linear = {}, [], []
+    for k, (c, size) in enumerate(contigs):
+        s, e, q, st = synth_contig(size, depth, seed + k)
+        e = np.maximum(e, s + read_len).astype(np.int32)
+        fwd = st == 1
+        ln = (e - s).astype(np.int64)
+        r1_pos = np.where(fwd, s, e - read_len).astype(np.int64)
+        r2_pos = np.where(fwd, e - read_len, s).astype(np.int64)
+        never = np.uint64(0xFFFFFFFFFFFFFFFF)
+        lin = np.full(((size + read_len) >> 14) + 1, never, np.uint64)
+        first_off = end_off = None
+        n_records = 0
+        for a in range(0, size, step):
+            b = min(a + step, size)
+            lo, hi = int(np.searchsorted(s, a - 1000)), int(np.searchsorted(s, b))  # (fragments are <= 1000 long)
+            idx = np.arange(lo, hi)
+            m = len(idx)
+            blk = np.zeros(2 * m, rec)
+            blk["block_size"] = rec.itemsize - 4
+            blk["ref"] = blk["next_ref"] = k
+            blk["l_name"], blk["n_cigar"], blk["l_seq"], blk["cigar"] = name_len, 1, read_len, read_len << 4
+            blk["pos"][:m], blk["pos"][m:] = r1_pos[idx], r2_pos[idx]
+            blk["next_pos"][:m], blk["next_pos"][m:] = r2_pos[idx], r1_pos[idx]
+            blk["mapq"][:m] = blk["mapq"][m:] = q[idx]
+            blk["tlen"][:m], blk["tlen"][m:] = np.where(fwd[idx], ln[idx], -ln[idx]), np.where(fwd[idx], -ln[idx], ln[idx])
+            blk["flag"][:m], blk["flag"][m:] = np.where(fwd[idx], 99, 83), np.where(fwd[idx], 147, 163)
+            digits = np.zeros((m, name_len), np.uint8)  # the pair's number in decimal + the NUL l_read_name counts
+            digits[:, :name_len - 1] = idx[:, None] // powers[None, :] % 10 + 48
+            blk["name"][:m] = blk["name"][m:] = digits.view(f"S{name_len}")[:, 0]
+            blk = blk[(blk["pos"] >= a) & (blk["pos"] < b)]
+            blk["seq"] = rng.integers(0, 256, (len(blk), read_len // 2), dtype=np.uint8)
+            blk["qual"] = lut[rng.integers(0, 256, (len(blk), read_len), dtype=np.uint8)]
+            blk = blk[np.argsort(blk["pos"], kind="stable")]
+            if not len(blk):
+                continue
+            n_records += len(blk)
+            offs = writers.bgzf_write(path, blk.tobytes(), level=1, append=True, write_eof=False)
+            if first_off is None:
+                first_off = int(offs[0])
+            end_off = int(offs[-1])
+            # linear index: the first record (lowest virtual offset) overlapping every 16 kb window; a record covers at
+            # most two windows, records of a window come in file order, windows only ever see later chunks afterwards
+            at = np.arange(len(blk), dtype=np.int64) * rec.itemsize
+            voff = (offs[at // 0xFF00].astype(np.uint64) << np.uint64(16)) | (at % 0xFF00).astype(np.uint64)
+            pos = blk["pos"].astype(np.int64)
+            for w in (pos >> 14, (pos + read_len - 1) >> 14):
+                uw, first = np.unique(w, return_index=True)
+                lin[uw] = np.minimum(lin[uw], voff[first])
+            del blk, digits
+        assert n_records == 2 * len(s)
+        nxt = np.uint64(0)
+        for w in range(len(lin) - 1, -1, -1):  # (htslib: a window without records points at the next one's)
+            if lin[w] == never:
+                lin[w] = nxt
+            else:
+                nxt = lin[w]
+        spans.append((c, (first_off or 0) << 16, (end_off or 0) << 16))
+        linear.append(lin)
+        out[c] = dict(s=s, e=e, q=q, st=st, r1s=r1_pos.astype(np.int32), r1e=(r1_pos + read_len).astype(np.int32),
+                      n=len(s), first_off=first_off, end_off=end_off, linear=lin)
+    with open(path, "ab") as fh:
+        fh.write(bgzf._EOF)
+    bgzf.write_index(str(path) + ".bai", True, spans, linear)
+    return out
+
+
 def write_random_2bit(path, sizes, seed=SEED_BASE, n_blocks=True):
     """A UCSC ``.2bit`` reference of random bases for ``sizes = {contig: length}`` (little endian, version 0): the
     packed DNA is written as random bytes (T=0 C=1 A=2 G=3, four bases per byte, first base in the high bits), each

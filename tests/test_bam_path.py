@@ -136,3 +136,42 @@ def test_lazy_sources_decode_only_what_is_asked_for(tmp_path, monkeypatch):
     assert loaded[0] == {"chr1", "chrEmpty", "chr2"} and loaded[1] == {"t0", "t1", "t2"}
     assert eager == lazy
     source.close_all()
+
+
+@pytest.mark.gpu
+def test_bam_wps_interval_calls_through_the_index_equal_the_whole_contig(tmp_path):
+    """frag.wps on an interval of a BAM contig that is not resident reads a REGION through the BAI.  The reference's
+    fetch window for WPS is [start - max_length, stop + max_length) (frag/_wps.py:156-157) and a BAM query returns
+    read1 ALIGNMENTS overlapping it, so with 50 bp reads a read1 lying up to 180 bp outside the interval still brings its
+    fragment in: the region must be padded by max_length, not by the WPS window.  Intervals end within 180 bp of a
+    16 kb linear-index boundary (where a narrower pad would lose records); every answer must equal the call on the
+    resident contig and the oracle."""
+    from finaletoolkit_amd import frag, source
+    from oracle import oracle as O
+    size = 1_500_000
+    path = str(tmp_path / "r50.bam")
+    exp = synth.write_paired_bam(path, "w", size, 120.0, 77, read_len=50)
+    fr = O.Frags(exp["s"], exp["e"], exp["q"], exp["st"], exp["r1s"], exp["r1e"])
+    cases = []
+    for k in (5, 23, 41, 60, 77):
+        for d in (0, 35, 120, 150, 179):
+            cases.append((k * 16384 - d - 3000, k * 16384 - d))       # the interval ENDS d bases before a boundary
+            cases.append((k * 16384 + d, k * 16384 + d + 2500))       # ... or STARTS d bases behind one
+    got_region = []
+    for a, b in cases:
+        source.close_all()                                            # a fresh source: its first interval call -> region
+        del source.REGION_READS[:]
+        got_region.append(frag.wps(path, "w", a, b, size)["wps"])
+        assert len(source.REGION_READS) == 1 and source.REGION_READS[0][2:] == (a - 181, b + 181)
+        assert not source.open_source(path).loaded
+    source.close_all()
+    source.open_source(path).require("w")
+    differ_from_slice = 0
+    for (a, b), r in zip(cases, got_region):
+        whole = frag.wps(path, "w", a, b, size)["wps"]
+        want = O.c_wps(fr, a, b, size, 120, 120, 180, 30)
+        assert np.array_equal(whole, want), (a, b)
+        assert np.array_equal(r, want), (a, b)
+        differ_from_slice += int(r.any())
+    assert differ_from_slice == len(cases)
+    source.close_all()
