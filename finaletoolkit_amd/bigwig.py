@@ -151,7 +151,7 @@ class RunOrder:
         kept = []
         for k, (st, n_k) in enumerate(zip(starts, lengths)):
             st, n_k = int(st), int(n_k)
-            if n_k == 0:
+            if n_k <= 0:  # (stop < start: a site whose midpoint lies beyond the contig end - as empty as stop == start)
                 continue
             if cid is None or (cid, st) < self.last:
                 if not self.quiet:

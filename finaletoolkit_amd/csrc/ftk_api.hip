@@ -1682,14 +1682,15 @@ int ftk_ref_upload_file(ftk_ctx* ctx, int ref_id, const char* path, int64_t file
     size_t cap = 0;
     if ((rc = ref_block_take(ctx, (size_t)n_bytes + 32, &r.d, &cap))) return rc;
     r.cap = (int64_t)cap;
-    bool used[2] = {false, false};
+    // (a chunk is only rewritten once the copy that last read it has finished - the event of a PREVIOUS call's last
+    // chunks included: the call returns with its final copies still in flight; an event never recorded is complete)
     hipError_t e = hipMemsetAsync((char*)r.d + n_bytes, 0, 32, ctx->stream);
     int k = 0;
     // the file (page cache) -> a page-locked chunk on four pread threads -> the device, the next chunk read while the
     // previous one is on its way
     for (int64_t off = 0; off < n_bytes && e == hipSuccess; off += (int64_t)kRefStageBytes, k ^= 1) {
         const size_t n = (size_t)std::min<int64_t>((int64_t)kRefStageBytes, n_bytes - off);
-        if (used[k]) e = hipEventSynchronize(ctx->ref_stage_done[k]);
+        e = hipEventSynchronize(ctx->ref_stage_done[k]);
         if (e != hipSuccess) break;
         std::atomic<int> bad{0};
         const int nt = n >= (size_t(4) << 20) ? 4 : 1;
@@ -1710,7 +1711,6 @@ int ftk_ref_upload_file(ftk_ctx* ctx, int ref_id, const char* path, int64_t file
         }
         e = hipMemcpyAsync((char*)r.d + off, dst, n, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(ctx->ref_stage_done[k], ctx->stream);
-        used[k] = true;
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();

@@ -329,7 +329,10 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
         counts.setdefault(c, np.zeros((0, 4), np.int64))
     clock["gather"] = time.perf_counter() - tg
     tg = time.perf_counter()
-    parts = [_contig_columns(c, plan[c][0], plan[c][1], plan[c][2], plan[c][3], plan[c][4], counts[c]) for c in names]
+    # a contig listed twice in chrom.sizes has its bins once per listing (the reference loops over the listing,
+    # frag/_delfi.py:269-283); it is counted once and laid down as often as it is listed
+    listing = [c for c, _size in contigs if c in plan]
+    parts = [_contig_columns(c, plan[c][0], plan[c][1], plan[c][2], plan[c][3], plan[c][4], counts[c]) for c in listing]
     window_df = _window_frame(parts)
     trimmed = window_df.loc[window_df["arm"] != "NOARM", :].copy()
     trimmed["ratio"] = np.where(trimmed["long"] == 0, np.nan, trimmed["short"] / trimmed["long"])

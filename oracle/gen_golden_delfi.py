@@ -11,7 +11,7 @@ and through every writer.  Outputs (tests/golden/):
     delfi_driver.json          the cases: arguments, frame shapes, the reference's error types
     delfi_driver_<case>.csv.gz the returned frame as ``to_csv(index=False)`` text (gzip, mtime 0)
     delfi_driver_out.*         the files / stdout ``_write_delfi`` produced for one case
-    synth_gaps.bed, synth_gaps_shortarm.bed, synth_bins_mixed.bed   (chrom.sizes: the existing synth.chrom.sizes)
+    synth_gaps.bed, synth_gaps_shortarm.bed, synth_bins_mixed.bed, synth_dup.chrom.sizes   (else: the existing synth.chrom.sizes)
 
 Neither the FASTA nor the 27 500-row 20 bp bins file is committed: ``tests/helpers.synth_reference`` /
 ``tests/helpers.write_bins20`` regenerate them (the FASTA checked by sha256 here and in the tests).  Usage:  python oracle/gen_golden_delfi.py
@@ -52,6 +52,8 @@ def write_inputs():
             for a in range(0, CONTIGS[c] + 20_000, 10_000):
                 fh.write(f"{c}\t{a}\t{a + 9_999}\textra\n")
         fh.write("chrZ\t0\t9999\n")
+    with open(os.path.join(GOLD, "synth_dup.chrom.sizes"), "w") as fh:  # a contig listed twice: its bins once per listing
+        fh.write("chrB\t150000\nchrA\t400000\nchrB\t150000\n")
     with open(os.path.join(GOLD, "synth_gaps.bed"), "w") as fh:
         fh.write("chrA\t0\t10000\ttelomere\nchrA\t180000\t230000\tcentromere\nchrA\t390000\t400000\ttelomere\n"
                  "chrB\t0\t5000\ttelomere\nchrB\t60000\t80000\tcentromere\nchrB\t145000\t150000\ttelomere\n")
@@ -87,10 +89,12 @@ def main():
         "bins20_shortarm": dict(bins="synth_bins20.bed", gaps="synth_gaps_shortarm.bed", bl=True, merge=True, nocov=True),
         "mixed_gaps": dict(bins="synth_bins_mixed.bed", gaps="synth_gaps.bed", bl=True, merge=False, nocov=True),
         "mixed_plain_q0": dict(bins="synth_bins_mixed.bed", gaps=None, bl=False, merge=False, nocov=False, q=0),
+        "mixed_dup_listing": dict(bins="synth_bins_mixed.bed", gaps="synth_gaps.bed", bl=True, merge=False, nocov=True,
+                                  sizes="synth_dup.chrom.sizes"),
     }
     J = {"fasta_sha256": sha, "cases": {}}
     for name, c in cases.items():
-        df = F.delfi(frag, g("synth.chrom.sizes"), g(c["bins"]), fasta,
+        df = F.delfi(frag, g(c.get("sizes", "synth.chrom.sizes")), g(c["bins"]), fasta,
                      blacklist_file=g("synth_blacklist.bed") if c["bl"] else None,
                      gap_file=g(c["gaps"]) if c["gaps"] else None, output_file=None, no_gc_correct=True,
                      remove_nocov=c["nocov"], merge_bins=c["merge"], quality_threshold=c.get("q", 30), workers=1)

@@ -44,7 +44,7 @@ def _golden_text(name):
 def _run(delfi, d, fasta, c, output_file=None):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return delfi(os.path.join(GOLD, "synth.frag.gz"), os.path.join(GOLD, "synth.chrom.sizes"), _path(d, c["bins"]),
+        return delfi(os.path.join(GOLD, "synth.frag.gz"), os.path.join(GOLD, c.get("sizes", "synth.chrom.sizes")), _path(d, c["bins"]),
                      fasta, blacklist_file=os.path.join(GOLD, "synth_blacklist.bed") if c["bl"] else None,
                      gap_file=_path(d, c["gaps"]) if c["gaps"] else None, output_file=output_file, no_gc_correct=True,
                      remove_nocov=c["nocov"], merge_bins=c["merge"], quality_threshold=c.get("q", 30), workers=1)
