@@ -383,6 +383,14 @@ struct DevColumns {
                 hipStream_t s, const int32_t* a0 = nullptr, const int32_t* b0 = nullptr) {
         if (!n) return true;
         if (!reserve(n, s)) return false;
+        if (kind == hipMemcpyDeviceToDevice) {  // one launch instead of four to six copies (ftk_textparse.h)
+            if (bam && !(a0 && b0)) return false;
+            ftk::append_rows_launch(s, start + rows, end + rows, mapq + rows, strand + rows, bam ? r1s + rows : nullptr,
+                                    bam ? r1e + rows : nullptr, s0, e0, q0, t0, a0, b0, n);
+            if (hipGetLastError() != hipSuccess) return false;
+            rows += n;
+            return true;
+        }
         bool ok = hipMemcpyAsync(start + rows, s0, n * 4, kind, s) == hipSuccess &&
                   hipMemcpyAsync(end + rows, e0, n * 4, kind, s) == hipSuccess &&
                   hipMemcpyAsync(mapq + rows, q0, n, kind, s) == hipSuccess &&
@@ -2401,7 +2409,7 @@ struct DevSet {
     size_t h_text_cap = 0;
     uint8_t* d_text = nullptr;
     size_t cap = 0, max_lines = 0;
-    uint32_t *d_blocks = nullptr, *d_lines = nullptr;
+    void* d_blocks = nullptr;   // the row parser's scan state (ftk::textparse_scratch_bytes)
     int32_t *d_s = nullptr, *d_e = nullptr;
     uint8_t *d_q = nullptr, *d_t = nullptr;
     ftk::TextSummary* d_sum = nullptr;
@@ -2473,7 +2481,7 @@ struct DevSet {
         if (h_text) (void)hipHostFree(h_text);
         h_text_cap = 0;
         if (h_sum) (void)hipHostFree(h_sum);
-        for (void* q : {(void*)d_text, (void*)d_blocks, (void*)d_lines, (void*)d_s, (void*)d_e, (void*)d_q, (void*)d_t, (void*)d_sum})
+        for (void* q : {(void*)d_text, (void*)d_blocks, (void*)d_s, (void*)d_e, (void*)d_q, (void*)d_t, (void*)d_sum})
             if (q) (void)hipFree(q);
         for (hipEvent_t ev : {done, front, freed})
             if (ev) (void)hipEventDestroy(ev);
@@ -2550,8 +2558,7 @@ struct DevSet {
         bool ok = (!with_host_text || ensure_host_text(want)) &&
                   hipHostMalloc((void**)&h_sum, sizeof(ftk::TextSummary), hipHostMallocDefault) == hipSuccess &&
                   hipMalloc((void**)&d_text, want) == hipSuccess &&
-                  hipMalloc((void**)&d_blocks, (want / ftk::kTextBlockBytes + 2) * 4) == hipSuccess &&
-                  hipMalloc((void**)&d_lines, (lines + 2) * 4) == hipSuccess &&
+                  hipMalloc((void**)&d_blocks, ftk::textparse_scratch_bytes(want)) == hipSuccess &&
                   hipMalloc((void**)&d_s, lines * 4) == hipSuccess && hipMalloc((void**)&d_e, lines * 4) == hipSuccess &&
                   hipMalloc((void**)&d_q, lines) == hipSuccess && hipMalloc((void**)&d_t, lines) == hipSuccess &&
                   hipMalloc((void**)&d_sum, sizeof(ftk::TextSummary)) == hipSuccess &&
@@ -3002,7 +3009,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
              hipStreamWaitEvent(pstream, S.front, 0) == hipSuccess && (!clk.on || hipEventRecord(tev[sj][2], pstream) == hipSuccess);
         if (ok) {
             ftk::textparse_launch_inflated(pstream, S.d_text, ftk::kTextCarryMax, (uint32_t)M.total, P ? P->d_text : nullptr,
-                                           P ? P->d_sum : nullptr, M.first_skip, M.eof, bed6, S.d_blocks, S.d_lines, S.max_lines,
+                                           P ? P->d_sum : nullptr, M.first_skip, M.eof, bed6, S.d_blocks, S.max_lines,
                                            S.d_s, S.d_e, S.d_q, S.d_t, S.d_sum);
             ok = hipGetLastError() == hipSuccess &&
                  hipMemcpyAsync(S.h_sum, S.d_sum, sizeof(ftk::TextSummary), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
@@ -3272,7 +3279,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             bool ok = S.host_only || (hipMemsetAsync(S.d_sum, 0, sizeof(ftk::TextSummary), pstream) == hipSuccess &&
                                       hipMemcpyAsync(S.d_text, b, S.len, hipMemcpyHostToDevice, pstream) == hipSuccess);
             if (ok && !S.host_only) {
-                ftk::textparse_launch(pstream, S.d_text, S.len, bed6, S.d_blocks, S.d_lines, S.max_lines, S.d_s, S.d_e, S.d_q,
+                ftk::textparse_launch(pstream, S.d_text, S.len, bed6, S.d_blocks, S.max_lines, S.d_s, S.d_e, S.d_q,
                                       S.d_t, S.d_sum);
                 ok = hipGetLastError() == hipSuccess &&
                      hipMemcpyAsync(S.h_sum, S.d_sum, sizeof(ftk::TextSummary), hipMemcpyDeviceToHost, pstream) == hipSuccess &&

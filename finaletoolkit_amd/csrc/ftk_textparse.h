@@ -12,7 +12,7 @@
 namespace ftk {
 
 constexpr int kTextMaxRuns = 1024;      // contig runs reported per piece (more: the host parses the piece)
-constexpr int kTextBlockBytes = 4096;   // bytes per block of the newline kernels
+constexpr int kTextBlockBytes = 4096;   // bytes of text per block of the line finder
 
 constexpr int kTextNamedRuns = 64;      // runs whose contig name the device reports itself (device-inflated pieces)
 constexpr int kTextNameBytes = 48;      // longest such name + 1
@@ -35,22 +35,35 @@ struct TextSummary {
     unsigned char run_name[kTextNamedRuns][kTextNameBytes];  // NUL-terminated, indexed like run_line / run_off
 };
 
+// Device scratch the parse of a piece of `text_bytes` of text needs (the line finder's scan state).
+size_t textparse_scratch_bytes(size_t text_bytes);
+
 // Enqueue the whole parse of text[0, n) (complete lines, the last byte is '\n') on `s`.
-//   d_block_count: ceil(n / kTextBlockBytes) + 1 words of scratch; d_line_start: max_lines + 2 words;
-//   outputs hold max_lines rows; *d_sum must be zeroed by the caller (stream-ordered) beforehand.
-void textparse_launch(hipStream_t s, const uint8_t* d_text, size_t n, bool bed6, uint32_t* d_block_count,
-                      uint32_t* d_line_start, size_t max_lines, int32_t* d_start, int32_t* d_end, uint8_t* d_mapq,
-                      uint8_t* d_strand, TextSummary* d_sum);
+//   d_scratch: textparse_scratch_bytes(n); outputs hold max_lines rows; *d_sum must be zeroed by the caller
+//   (stream-ordered) beforehand.
+void textparse_launch(hipStream_t s, const uint8_t* d_text, size_t n, bool bed6, void* d_scratch, size_t max_lines,
+                      int32_t* d_start, int32_t* d_end, uint8_t* d_mapq, uint8_t* d_strand, TextSummary* d_sum);
 
 // The same for a piece whose text was INFLATED ON THE DEVICE into d_text[data_off, data_off + data_len) (data_off >=
 // kTextCarryMax): a set-up kernel first moves the unfinished last line of the previous piece (prev_text / prev_sum,
 // NULL for the first piece) in front of the data, skips first_skip bytes (first piece after an index seek), finds
 // the last line end -- at the end of the file a missing one is appended -- and records the range in *d_sum
-// (text_off, text_len, tail_len); the parse kernels then take the range from there.  Run names go to
+// (text_off, text_len, tail_len); the parse kernel then takes the range from there.  Run names go to
 // d_sum->run_name.  *d_sum must be zeroed beforehand.  run_off values are relative to text_off & ~15.
+// d_scratch: textparse_scratch_bytes(data_len).
 void textparse_launch_inflated(hipStream_t s, uint8_t* d_text, uint32_t data_off, uint32_t data_len,
                                const uint8_t* prev_text, const TextSummary* prev_sum, uint32_t first_skip, bool eof, bool bed6,
-                               uint32_t* d_block_count, uint32_t* d_line_start, size_t max_lines, int32_t* d_start,
-                               int32_t* d_end, uint8_t* d_mapq, uint8_t* d_strand, TextSummary* d_sum);
+                               void* d_scratch, size_t max_lines, int32_t* d_start, int32_t* d_end, uint8_t* d_mapq,
+                               uint8_t* d_strand, TextSummary* d_sum);
+
+// Rows of a parsed piece behind a contig's columns, device to device, in ONE launch: n rows of (start, end, mapq,
+// strand) and - BAM contigs - (r1_start, r1_end; NULL otherwise) from the piece's buffers to the contig's block at its
+// current row count.  Neither side is aligned beyond its element size (a contig run starts at any row of a piece and
+// lands at any row of the block).  Replaces four to six hipMemcpyAsync per run: the runtime's copy kernel moved the
+// genome's 6 GB of appends at 0.15 TB/s, 15 % of the file -> HBM leg's GPU time (profiles/r3_g_genome_leg_kernel_stats.txt).
+void append_rows_launch(hipStream_t s, int32_t* dst_start, int32_t* dst_end, uint8_t* dst_mapq, uint8_t* dst_strand,
+                        int32_t* dst_r1s, int32_t* dst_r1e, const int32_t* src_start, const int32_t* src_end,
+                        const uint8_t* src_mapq, const uint8_t* src_strand, const int32_t* src_r1s, const int32_t* src_r1e,
+                        size_t n);
 
 }  // namespace ftk

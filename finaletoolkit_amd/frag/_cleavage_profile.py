@@ -94,18 +94,19 @@ def multi_cleavage_profile(input_file, interval_file, chrom_sizes, left: int = 0
     src = open_source(input_file, workers)
     eng = get_engine()
 
-    def score_run(c, run_starts, run_stops):  # one launch per run of intervals on the same contig
-        return eng.cleavage_intervals(src.require(c), run_starts, run_stops, min_length, max_length,
+    def score_run(key, c, run_starts, run_stops):  # one launch per unit of intervals on the same contig
+        return eng.cleavage_intervals(key, run_starts, run_stops, min_length, max_length,
                                       quality_threshold)
 
-    # Pool(workers) of the reference (:372-395) = one rank per GPU here: contigs dealt to the ranks, rank 0 writes
+    # Pool(workers) of the reference (:372-395) = one rank per GPU here: the intervals cut into equal-cost shares over
+    # the ranks (frag/_runs.py; a partial share of a contig scored from a region of it), rank 0 writes
     if isinstance(output_file, str):
         if output_file.endswith(".bw"):
-            write_per_base_runs(output_file, "bw", header, contigs, starts, stops, score_run)
+            write_per_base_runs(output_file, "bw", header, contigs, starts, stops, score_run, src, 1)
         elif output_file.endswith(".bed.gz") or output_file.endswith("bedgraph.gz") or output_file == "-":
             # rows "contig  pos  pos+1  proportion" with the floats printed as Python prints them, formatted by
             # the library's host threads; gzip members compressed in parallel
-            write_per_base_runs(output_file, "bedgraph.gz", header, contigs, starts, stops, score_run)
+            write_per_base_runs(output_file, "bedgraph.gz", header, contigs, starts, stops, score_run, src, 1)
         else:
             raise ValueError("output_file can only have suffix .bw, .bedgraph.gz, or .bed.gz.")
     elif output_file is not None:

@@ -91,28 +91,27 @@ def _by_contig(intervals):
     return by_contig, extent
 
 
-def _interval_counts(src, intervals, by_contig, shard, weights, min_length, max_length, intersect_policy,
-                     quality_threshold):
+def _interval_counts(src, intervals, min_length, max_length, intersect_policy, quality_threshold):
     """Counts for every interval, in interval order (the ``imap`` of :244-248).  The reference spreads the
-    intervals over ``Pool(workers)``; here every rank of the process group counts the intervals of ITS
-    contigs (one launch per contig) and one all-gather hands every rank the full vector."""
+    intervals over ``Pool(workers)``; here the intervals are cut into equal-cost runs over the ranks of the process
+    group (``sharding.IntervalPlan``: whole contigs, a region of the contig a cut falls into), every rank counts its
+    share with one launch per unit and one all-gather hands every rank the full vector."""
     eng = get_engine()
-    rank, world, owner = shard
-    counts = np.zeros(len(intervals), np.int64)
-    names = list(by_contig)
-    local = {}
-    for c, idx in by_contig.items():
-        if owner[c] != rank:
-            continue
-        ws = np.array([intervals[i][1] for i in idx], np.int64)
-        we = np.array([intervals[i][2] for i in idx], np.int64)
-        local[c] = eng.window_counts(src.require(c), ws.astype(np.int32), we.astype(np.int32), quality_threshold,
-                                     min_length, max_length, intersect_policy).reshape(-1, 1)
-    full = sharding.gather_bin_vectors(local, names, {c: len(by_contig[c]) for c in names}, weights, k=1,
-                                       owner=owner)
-    for c, idx in by_contig.items():
-        counts[idx] = np.asarray(full[c]).reshape(-1)
-    return counts
+    plan = sharding.IntervalPlan([iv[0] for iv in intervals], [iv[1] for iv in intervals], [iv[2] for iv in intervals])
+    local, err = {}, None
+    try:
+        for unit in plan.mine:
+            idx = plan.intervals(unit)
+            key = plan.unit_key(src, unit, 1)
+            try:
+                local[unit] = eng.window_counts(key, plan.starts[idx].astype(np.int32), plan.stops[idx].astype(np.int32),
+                                                quality_threshold, min_length, max_length, intersect_policy).reshape(-1, 1)
+            finally:
+                plan.release(src, key)
+    except Exception as e:  # noqa: BLE001 - with several ranks every rank must learn of it
+        err = e
+    sharding.agree(err)
+    return plan.gather(local, 1).reshape(-1)
 
 
 def coverage(input_file: Union[str, Path], interval_file: str, output_file: str, scale_factor: float = 1.0,
@@ -127,17 +126,16 @@ def coverage(input_file: Union[str, Path], interval_file: str, output_file: str,
     _check_policy(intersect_policy)
     src = open_source(input_file, workers)
     intervals = get_intervals(interval_file)
-    by_contig, extent = _by_contig(intervals)
-    # one contig -> rank map for the whole call: the file's contigs first, then any interval contig it lacks
-    # (asking for those raises, as the reference's fetch does)
-    names = list(dict.fromkeys(list(src.contigs) + list(by_contig)))
-    rank, world, owner, weights = _owners(src, names, extent)
     if normalize:
-        # single_coverage(input_file, None, 0, None, "."): the whole file (:215-227)
+        # single_coverage(input_file, None, 0, None, "."): the whole file (:215-227).  Every fragment counts once, so
+        # this part is dealt by whole contigs (LPT on their lengths; a region read returns a fragment to every rank
+        # whose region it overlaps), one int64 all-reduce.
+        by_contig, extent = _by_contig(intervals)
+        names = list(dict.fromkeys(list(src.contigs) + list(by_contig)))
+        rank, world, owner, _weights = _owners(src, names, extent)
         total = _total(src, None, 0, None, min_length, max_length, intersect_policy, quality_threshold,
                        shard=(rank, world, owner))
-    counts = _interval_counts(src, intervals, by_contig, (rank, world, owner), weights, min_length, max_length,
-                              intersect_policy, quality_threshold)
+    counts = _interval_counts(src, intervals, min_length, max_length, intersect_policy, quality_threshold)
     if normalize:
         if verbose:
             sys.stderr.write(f"Total coverage is {total}\n")

@@ -10,6 +10,7 @@ bins.  Window gating (``:423-428``), GC fraction (``:476-490``), ratio and the
 """
 from __future__ import annotations
 
+import threading
 import time
 import warnings
 from collections import defaultdict
@@ -21,7 +22,8 @@ import pandas
 
 from ..genome.gaps import GenomeGaps
 from ..reference import ReferenceGenome
-from ..source import get_engine, region_contig, resident_contigs
+from ..engine import Engine
+from ..source import get_engine, get_side_engine, region_contig, resident_contigs
 from .. import sharding
 from ..utils import chrom_sizes_to_list, overlaps
 from ._delfi_gc_correct import delfi_gc_correct
@@ -109,16 +111,68 @@ def _gate_windows(contig, starts, stops, contig_gaps):
     return arms, p_arm | q_arm
 
 
-def _contig_counts(src, eng, ref, contig, starts, stops, live, ok, contig_gaps, blacklist, quality_threshold,
-                   clock=None, key=None, i0=0, i1=None):
-    """Device part of one contig (the rank that owns it) - or of the bins ``[i0, i1)`` of it, counted on the table
-    ``key`` (a region of the contig: ``FragSource.require_region``): ``[n_live, 4]`` int64 rows
-    ``(short, long, num_frags, num_gc)`` of the live bins among them -- one ``ftk_delfi_counts`` launch and one
-    GC-count launch (frag/_delfi.py:443-490)."""
+def _unit_bins(live, ok, i0=0, i1=None):
+    """Indices (into the contig's bins) of the live bins of unit ``[i0, i1)`` and, for each, whether the reference
+    covers it (``ok`` is indexed like the contig's live bins)."""
     idx = np.nonzero(live)[0]
     if i0 or i1 is not None:
         part = (idx >= i0) & (idx < (len(live) if i1 is None else i1))
         idx, ok = idx[part], ok[part]
+    return idx, ok
+
+
+class _GCAhead:
+    """G + C per bin (frag/_delfi.py:476-490) of every unit this rank owns, counted BESIDE the decode: the counts need
+    the reference and the bins, not the fragments, so a worker thread uploads each contig's reference image and counts
+    on a second context of the same GPU (``source.get_side_engine``) while the main thread waits for contigs to become
+    resident - in round 3 the same 43 ms per genome sat on the consumer thread between the count kernels.  ``jobs``:
+    ``[(unit key, contig, starts, stops)]`` in the order the units will be asked for.  With a stand-in device (host
+    logic tests) the counts are taken on demand on the caller's thread."""
+
+    def __init__(self, ref, eng, jobs):
+        self.ref, self.eng = ref, eng
+        self.jobs = {key: (contig, starts, stops) for key, contig, starts, stops in jobs}
+        self.done = {key: threading.Event() for key in self.jobs}
+        self.out, self.err, self.thread = {}, None, None
+        if isinstance(eng, Engine) and jobs:
+            self.thread = threading.Thread(target=self._run, args=([j[0] for j in jobs],), name="ftk-delfi-gc", daemon=True)
+            self.thread.start()
+
+    def _run(self, order):
+        try:
+            side = get_side_engine()
+            for key in order:
+                contig, starts, stops = self.jobs[key]
+                self.out[key] = self.ref.gc_counts(side, contig, starts, stops) if len(starts) else np.zeros(0, np.int64)
+                self.done[key].set()
+        except BaseException as e:  # noqa: BLE001 - re-raised on the caller's thread by get()
+            self.err = e
+        finally:
+            for ev in self.done.values():
+                ev.set()
+
+    def get(self, key):
+        if self.thread is None:
+            contig, starts, stops = self.jobs[key]
+            return self.ref.gc_counts(self.eng, contig, starts, stops) if len(starts) else np.zeros(0, np.int64)
+        self.done[key].wait()
+        if key not in self.out:
+            raise self.err if self.err is not None else RuntimeError("the G + C worker stopped early")
+        return self.out.pop(key)
+
+    def close(self):
+        if self.thread is not None:
+            self.thread.join()
+
+
+def _contig_counts(src, eng, ref, contig, starts, stops, live, ok, contig_gaps, blacklist, quality_threshold,
+                   clock=None, key=None, i0=0, i1=None, gc_ahead=None):
+    """Device part of one contig (the rank that owns it) - or of the bins ``[i0, i1)`` of it, counted on the table
+    ``key`` (a region of the contig: ``FragSource.require_region``): ``[n_live, 4]`` int64 rows
+    ``(short, long, num_frags, num_gc)`` of the live bins among them -- one ``ftk_delfi_counts`` launch and the
+    G + C counts (frag/_delfi.py:443-490; ``gc_ahead``: taken from the worker that counted them beside the decode)."""
+    unit = (contig, i0, len(live) if i1 is None else i1)
+    idx, ok = _unit_bins(live, ok, i0, i1)
     out = np.zeros((len(idx), 4), np.int64)
     if len(idx):
         t0 = time.perf_counter()
@@ -133,7 +187,8 @@ def _contig_counts(src, eng, ref, contig, starts, stops, live, ok, contig_gaps, 
         out[:, 0], out[:, 1], out[:, 2] = sh, lg, nf
         t2 = time.perf_counter()
         if ok.any():
-            out[ok, 3] = ref.gc_counts(eng, contig, starts[idx][ok], stops[idx][ok])
+            out[ok, 3] = (gc_ahead.get(unit) if gc_ahead is not None
+                          else ref.gc_counts(eng, contig, starts[idx][ok], stops[idx][ok]))
         if clock is not None:
             clock["decode_wait"] += t1 - t0
             clock["count_kernels"] += t2 - t1
@@ -277,6 +332,15 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
         mine = [(c, i0, i1) for r, c, i0, i1 in units if r == rank]
         whole = [c for c, i0, i1 in mine if i0 == 0 and i1 == len(plan[c][0])]
         local = {}
+        # the bins' G + C: counted on a second context by a worker thread, in the order the units are taken below
+        # (whole contigs in file order ~ chrom.sizes order, then the partial ones)
+        gc_jobs = []
+        for contig, i0, i1 in sorted(mine, key=lambda u: not (u[1] == 0 and u[2] == len(plan[u[0]][0]))):
+            starts, stops, _arms, live, ok = plan[contig]
+            idx, okp = _unit_bins(live, ok, i0, i1)
+            if len(idx) and okp.any():
+                gc_jobs.append(((contig, i0, i1), contig, starts[idx][okp], stops[idx][okp]))
+        gc_ahead = _GCAhead(ref, eng, gc_jobs)
         # contigs are counted as they become resident: a file without a usable index is decoded in ONE streaming
         # pass (decode of contig k+1 beside the kernels / the reference upload of contig k); an indexed file is
         # read contig by contig through the index, so a rank touches only its own blocks
@@ -288,7 +352,7 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
                 starts, stops, arms, live, ok = plan[contig]
                 local[(contig, 0, len(starts))] = _contig_counts(src, eng, ref, contig, starts, stops, live, ok,
                                                                  contig_gaps.get(contig) if gaps is not None else None,
-                                                                 blacklist, quality_threshold, clock)
+                                                                 blacklist, quality_threshold, clock, gc_ahead=gc_ahead)
                 tw = time.perf_counter()
             clock["decode_wait"] += time.perf_counter() - tw
             for contig, i0, i1 in mine:
@@ -312,12 +376,15 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
                 try:
                     local[(contig, i0, i1)] = _contig_counts(src, eng, ref, contig, starts, stops, live, ok,
                                                              contig_gaps.get(contig) if gaps is not None else None,
-                                                             blacklist, quality_threshold, clock, key=key, i0=i0, i1=i1)
+                                                             blacklist, quality_threshold, clock, key=key, i0=i0, i1=i1,
+                                                             gc_ahead=gc_ahead)
                 finally:
                     if hasattr(src, "release_region"):
                         src.release_region(key)
         except Exception as e:  # noqa: BLE001 - with several ranks every rank must learn of it (sharding.agree)
             err = e
+        finally:
+            gc_ahead.close()  # (the worker reads the reference file: joined before it is closed)
         if world > 1:
             sharding.agree(err)
         elif err is not None:

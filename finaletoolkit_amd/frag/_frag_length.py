@@ -261,25 +261,18 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
     eng = get_engine()
     intervals = get_intervals(interval_file)
     results: list = [None] * len(intervals)
-    by_contig: dict[str, list[int]] = {}
-    extent: dict[str, int] = {}
-    for i, (c, _, b, _) in enumerate(intervals):
-        by_contig.setdefault(c, []).append(i)
-        extent[c] = max(extent.get(c, 0), int(b))
-    # Pool(workers) of the reference (:571-593) = one rank per GPU: the contigs are dealt to the ranks, a rank
-    # decodes and counts only its own, and one all-gather of the seven statistics per interval (float64 bit
-    # patterns) gives every rank the whole list; rank 0 writes.
-    names = list(by_contig)
-    rank, world, owner = sharding.contig_owner(
-        {c: float(src.lengths.get(c) or extent.get(c) or 1) * (1.0 + len(by_contig[c]) / 1000.0) for c in names})
+    # Pool(workers) of the reference (:571-593) = one rank per GPU: the intervals are cut into equal-cost runs over the
+    # ranks (sharding.IntervalPlan: whole contigs, a region of the contig a cut falls into), a rank decodes and counts
+    # only its share, and one all-gather of the seven statistics per interval (float64 bit patterns) gives every rank
+    # the whole list; rank 0 writes.
+    plan = sharding.IntervalPlan([iv[0] for iv in intervals], [iv[1] for iv in intervals], [iv[2] for iv in intervals])
 
-    def contig_stats(c, idx):
+    def unit_stats(key, idx):
         """float64 [len(idx), 7]: mean median stdev min max total n_short; total 0 = no fragment"""
         out = np.zeros((len(idx), 7), np.float64)
-        key = src.require(c)
         lo, hi = _length_range(eng, key, min_length, max_length)
-        ws = np.array([intervals[i][1] for i in idx], np.int64).astype(np.int32)
-        we = np.array([intervals[i][2] for i in idx], np.int64).astype(np.int32)
+        ws = plan.starts[idx].astype(np.int32)
+        we = plan.stops[idx].astype(np.int32)
         n_total = max(hi - lo + 1, 1)
         step = max(1, _HIST_BYTES_PER_CALL // (8 * n_total))
         for w0 in range(0, len(idx), step):
@@ -300,27 +293,23 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
 
     local, err = {}, None
     try:
-        for c, idx in by_contig.items():
-            if owner[c] == rank:
-                local[c] = contig_stats(c, idx)
+        for unit in plan.mine:
+            key = plan.unit_key(src, unit, 1)
+            try:
+                local[unit] = unit_stats(key, plan.intervals(unit))
+            finally:
+                plan.release(src, key)
     except Exception as e:  # noqa: BLE001 - every rank learns of it below
         err = e
-    if world > 1:
-        sharding.agree(err)
-        stats = sharding.gather_float_rows(local, names, {c: len(by_contig[c]) for c in names}, owner, 7)
-    elif err is not None:
-        raise err
-    else:
-        stats = local
-    for c, idx in by_contig.items():
-        mean, median, stdev, vmin, vmax, total, n_short = (stats[c][:, k].tolist() for k in range(7))
-        for j, i in enumerate(idx):
-            contig, start, stop, name = intervals[i]
-            if total[j] == 0:
-                results[i] = FragLengthStats(contig, start, stop, name, -1, -1, -1, -1, -1, -1, -1)
-            else:
-                results[i] = FragLengthStats(contig, start, stop, name, mean[j], median[j], stdev[j], int(vmin[j]),
-                                             int(vmax[j]), int(total[j]), int(n_short[j]) / int(total[j]))
+    sharding.agree(err)
+    stats = plan.gather(local, 7, np.float64)
+    mean, median, stdev, vmin, vmax, total, n_short = (stats[:, k].tolist() for k in range(7))
+    for i, (contig, start, stop, name) in enumerate(intervals):
+        if total[i] == 0:
+            results[i] = FragLengthStats(contig, start, stop, name, -1, -1, -1, -1, -1, -1, -1)
+        else:
+            results[i] = FragLengthStats(contig, start, stop, name, mean[i], median[i], stdev[i], int(vmin[i]),
+                                         int(vmax[i]), int(total[i]), int(n_short[i]) / int(total[i]))
 
     if output_file is not None and not sharding.is_writer():
         if not (output_file.endswith((".bed", ".bedgraph", ".bed.gz")) or output_file == "-"):

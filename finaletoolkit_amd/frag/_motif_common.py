@@ -273,51 +273,43 @@ def region_histograms(input_file, refseq_file, regions, spec: dict, quality_thre
         return out
     src = open_source(input_file, workers, warn_bed6=True)
     eng = get_engine()
-    by_contig: dict[str, list[int]] = {}
-    extent: dict[str, int] = {}
-    for i, r in enumerate(regions):
-        by_contig.setdefault(r[0], []).append(i)
-        extent[r[0]] = max(extent.get(r[0], 0), int(min(r[2], 2 ** 31 - 1)))
-    # The reference hands the regions to Pool(workers) (_motif_common.py:635-685); here the contigs are dealt to
-    # the ranks of the process group (one per GPU; a k-mer count depends only on its own contig's fragments and
-    # reference), a rank decodes / uploads / counts only its own, and one all-gather of the count rows gives
-    # every rank the whole table.
-    names = list(by_contig)
-    rank, world, owner = sharding.contig_owner({c: float(extent[c]) + 1.0 for c in names})
+    # The reference hands the regions to Pool(workers) (_motif_common.py:635-685); here they are cut into equal-cost runs
+    # over the ranks of the process group (sharding.IntervalPlan: whole contigs, a region of the contig a cut falls
+    # into; a k-mer count depends only on its own contig's fragments and reference), a rank decodes / uploads / counts
+    # only its share, and one all-gather of the count rows gives every rank the whole table.
+    lim = 2 ** 31 - 1
+    plan = sharding.IntervalPlan([r[0] for r in regions], np.clip([int(r[1]) for r in regions], -lim - 1, lim),
+                                 np.clip([int(r[2]) for r in regions], -lim - 1, lim))
     local, err = {}, None
     try:
         with ReferenceGenome(refseq_file) as ref:
-            for contig, idx in by_contig.items():
-                if owner[contig] != rank:
-                    continue
-                local[contig] = np.zeros((len(idx), 4 ** k), np.int64)
+            for unit in plan.mine:
+                contig = unit[0]
+                idx = plan.intervals(unit)
+                local[unit] = np.zeros((len(idx), 4 ** k), np.int64)
                 if not src.has(contig) or contig not in ref.chroms:
                     continue
-                lim = 2 ** 31 - 1
-                ws = np.clip([regions[i][1] for i in idx], -lim - 1, lim)
-                we = np.clip([regions[i][2] for i in idx], -lim - 1, lim)
                 rid = ref.device_image(eng, contig)
-                counts, _, errs = eng.motif_counts(src.require(contig), rid, ws, we, k, spec["fwd_offset"],
-                                                   spec["rev_offset"], spec["both_strands"], spec["negative_strand"],
-                                                   spec["guard"], spec["rev_oob_is_error"], quality_threshold,
-                                                   bam=src.is_bam)
+                # (a fragment end reads up to k bases beyond the fragment: a region's table holds whole fragments)
+                key = plan.unit_key(src, unit, 1)
+                try:
+                    counts, _, errs = eng.motif_counts(key, rid, plan.starts[idx], plan.stops[idx], k, spec["fwd_offset"],
+                                                       spec["rev_offset"], spec["both_strands"], spec["negative_strand"],
+                                                       spec["guard"], spec["rev_oob_is_error"], quality_threshold,
+                                                       bam=src.is_bam)
+                finally:
+                    plan.release(src, key)
                 if errs.any():
-                    j = idx[int(np.flatnonzero(errs)[0])]
+                    j = int(idx[int(np.flatnonzero(errs)[0])])
                     raise RuntimeError(
                         f"Error querying sequence at the 3' end of a fragment in {contig}:{regions[j][1]}-"
                         f"{regions[j][2]}. Chrom length: {ref.chroms.get(contig, 'unknown')}. Please verify that the "
                         "reference file matches the fragment file.")
-                local[contig][:] = counts
+                local[unit][:] = counts
     except Exception as e:  # noqa: BLE001 - every rank learns of it below
         err = e
-    if world > 1:
-        sharding.agree(err)
-        local = sharding.gather_bin_vectors(local, names, {c: len(by_contig[c]) for c in names},
-                                            {c: 1.0 for c in names}, k=4 ** k, owner=owner)
-    elif err is not None:
-        raise err
-    for contig, idx in by_contig.items():
-        out[idx] = local[contig]
+    sharding.agree(err)
+    out[:] = plan.gather(local, 4 ** k)
     return out
 
 

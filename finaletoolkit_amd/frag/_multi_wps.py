@@ -111,20 +111,24 @@ def multi_wps(input_file, site_bed, chrom_sizes=None, output_file: str | None = 
                          "applicable). Please ensure that all files use the same reference genome and chromosome "
                          "naming conventions.")
 
-    def score_run(c, run_starts, run_stops):
-        """All intervals of one run in ONE launch; interval k of the run is values[offsets[k]:offsets[k+1]]."""
-        return eng.wps_intervals(src.require(c), run_starts, run_stops, chrom_sizes_dict[c], int(window_size),
+    def score_run(key, c, run_starts, run_stops):
+        """All intervals of one unit in ONE launch; interval k of the unit is values[offsets[k]:offsets[k+1]]."""
+        return eng.wps_intervals(key, run_starts, run_stops, chrom_sizes_dict[c], int(window_size),
                                  0 if min_length is None else int(min_length), int(max_length),
                                  int(quality_threshold))
 
     # The reference scores the intervals in Pool(workers) and the parent writes them in order (:196-198,
-    # :300-341).  Here the contigs are dealt to the ranks of the process group (one per GPU), every rank scores,
-    # formats and compresses its own, rank 0 lays the pieces into the file (frag/_runs.py).
+    # :300-341).  Here the intervals are cut into equal-cost consecutive shares over the ranks of the process group (one
+    # per GPU; a partial share of a contig is scored from a region of it), every rank scores, formats and compresses
+    # its own, rank 0 lays the pieces into the file (frag/_runs.py).
+    # rows a share can need: the reference's fetch window of an interval is [start - max_length, stop + max_length)
+    # (frag/_wps.py:156-157), and for a BAM the read1 ALIGNMENTS overlapping it decide
+    pad = max(int(window_size), int(max_length)) + 1
     if isinstance(output_file, str):
         if output_file.endswith(".bw"):
-            write_per_base_runs(output_file, "bw", header, contigs, starts, stops, score_run)
+            write_per_base_runs(output_file, "bw", header, contigs, starts, stops, score_run, src, pad)
         elif output_file.endswith(".bed.gz") or output_file.endswith("bedGraph.gz"):
-            write_per_base_runs(output_file, "bedgraph.gz", header, contigs, starts, stops, score_run)
+            write_per_base_runs(output_file, "bedgraph.gz", header, contigs, starts, stops, score_run, src, pad)
         else:
             raise ValueError("output_file can only have suffix .bw")
     elif output_file is not None:

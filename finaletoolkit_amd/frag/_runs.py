@@ -4,12 +4,15 @@ Per-base features over many intervals -> one output file, on one GPU or on one r
 ``multi_wps`` and ``multi_cleavage_profile`` (reference: ``frag/_multi_wps.py:196-198,300-341``,
 ``frag/_cleavage_profile.py:372-395,455-500``) fan their intervals out over ``Pool(workers)`` and the parent
 writes the file in interval order.  Here the intervals are grouped into RUNS (consecutive intervals on one
-contig = one kernel launch), the contigs are dealt to the ranks of the process group (LPT on their bases; no
-data-path exchange: a base's score depends only on its own contig's fragments), every rank scores, formats and
-compresses the runs of ITS contigs -- bigWig data sections or gzip members, so the host-side work is spread
-as well -- and rank 0 receives the compressed pieces (``sharding.gather_payloads``) and lays them into the
-file in run order.  A single process takes the same path with itself as the only rank, streaming run by run,
-which is what makes the multi-rank file byte-identical to the single-process one.
+contig), the runs cut into UNITS of at most ``UNIT_BASES`` bases (one kernel launch, one compressed payload each), and
+the units dealt to the ranks of the process group as equal-cost consecutive groups (the partition of
+``sharding.split_counts`` with bases for weights: whole contigs plus at most two partial ones per rank, a partial
+share scored from a REGION of the contig read through the index; no data-path exchange: a base's score depends only
+on its own contig's fragments).  Every rank scores, formats and compresses ITS units -- bigWig data sections or gzip
+members, so the host-side work is spread as well -- and rank 0 receives the compressed pieces
+(``sharding.gather_payloads``) and lays them into the file in unit order.  A single process takes the same path with
+itself as the only rank, streaming unit by unit; the units do not depend on the number of ranks, which is what makes
+the multi-rank file byte-identical to the single-process one.
 """
 from __future__ import annotations
 
@@ -34,18 +37,52 @@ def group_runs(contigs: Sequence[str]) -> List[Run]:
     return runs
 
 
+UNIT_BASES = 32 << 20  # per-base scores one unit holds at most (one launch, one compressed payload)
+
+
+def split_into_units(runs: Sequence[Run], starts, stops) -> List[Run]:
+    """Runs cut into UNITS of consecutive intervals of at most ``UNIT_BASES`` bases (an interval longer than that is a
+    unit of its own).  A function of the intervals alone - never of the number of ranks - so the compressed pieces of
+    the output file, and with them its bytes, are the same however many ranks produce them."""
+    units = []
+    for c, i, j in runs:
+        a, acc = i, 0
+        for k in range(i, j):
+            n = max(int(stops[k]) - int(starts[k]), 0)
+            if k > a and acc + n > UNIT_BASES:
+                units.append((c, a, k))
+                a, acc = k, 0
+            acc += n
+        units.append((c, a, j))
+    return units
+
+
+def deal_units(units: Sequence[Run], starts, stops, world: int) -> List[int]:
+    """Rank of every unit: the units laid end to end in file order and cut into ``world`` consecutive groups of equal
+    cost (bases + a fixed cost per unit), the partition of ``sharding.split_counts`` with bases for weights - a rank
+    scores whole contigs plus at most two partial ones."""
+    cost = [sum(max(int(stops[k]) - int(starts[k]), 0) for k in range(i, j)) + 4096 for _, i, j in units]
+    total = sum(cost)
+    owner, done = [], 0
+    for w in cost:
+        owner.append(min(world - 1, done * world // max(total, 1)))
+        done += w
+    return owner
+
+
 def write_per_base_runs(output_file: str, kind: str, header, contigs, starts, stops,
-                        compute: Callable[[str, list, list], tuple]) -> None:
+                        compute: Callable[[str, str, list, list], tuple], src=None, pad: int = 1) -> None:
     """``kind``: ``"bw"`` (fixedStep bigWig) or ``"bedgraph.gz"`` (``contig pos pos+1 value`` rows, gzip).
-    ``compute(contig, starts, stops) -> (values, offsets)`` scores one run on this rank's GPU."""
+    ``compute(key, contig, starts, stops) -> (values, offsets)`` scores one unit of intervals on this rank's GPU from
+    the fragment table ``key``: the contig's (``src.require``) when the rank scores all of the contig's units, else a
+    REGION of it spanning the rank's intervals ``pad`` bases either side (``src.require_region``)."""
     from .. import writers
     from ..bigwig import FixedStepBigWigWriter, RunOrder, fixed_step_payload, select_intervals
 
     runs = group_runs(contigs)
-    weights: dict = {}
-    for c, i, j in runs:
-        weights[c] = weights.get(c, 0.0) + float(sum(stops[i:j]) - sum(starts[i:j])) + 1.0
-    rank, world, owner = sharding.contig_owner(weights)
+    units = split_into_units(runs, starts, stops)
+    rank, world = sharding.rank_world()
+    owner = deal_units(units, starts, stops, world)
     writer = rank == 0
 
     # bigWig: which intervals pyBigWig would accept depends on their coordinates only -- decided up front, on
@@ -53,20 +90,41 @@ def write_per_base_runs(output_file: str, kind: str, header, contigs, starts, st
     keeps = None
     if kind == "bw":
         order = RunOrder(header, quiet=not writer)
-        keeps = [order.keep(c, starts[i:j], [b - a for a, b in zip(starts[i:j], stops[i:j])]) for c, i, j in runs]
+        keeps = [order.keep(c, starts[i:j], [b - a for a, b in zip(starts[i:j], stops[i:j])]) for c, i, j in units]
         chrom_id = order.chrom_id
 
-    def payload(k: int) -> bytes:
-        c, i, j = runs[k]
+    # the table a unit is scored from: the rank's share of a contig is one span of its units (they are consecutive)
+    share: dict = {}  # contig -> [n units of the contig, n of them mine, lowest start, highest stop of mine]
+    for k, (c, i, j) in enumerate(units):
+        e = share.setdefault(c, [0, 0, None, None])
+        e[0] += 1
+        if owner[k] == rank and j > i:
+            e[1] += 1
+            lo, hi = min(starts[i:j]), max(stops[i:j])
+            e[2] = lo if e[2] is None else min(e[2], lo)
+            e[3] = hi if e[3] is None else max(e[3], hi)
+    keys: dict = {}
+
+    def table(c):
+        if c not in keys:
+            n_all, n_mine, lo, hi = share[c]
+            if world == 1 or n_mine == n_all or lo is None or hi <= lo or not hasattr(src, "require_region"):
+                keys[c] = src.require(c)
+            else:
+                keys[c] = src.require_region(c, max(0, int(lo) - pad), int(hi) + pad)
+        return keys[c]
+
+    def payload(k: int):
+        c, i, j = units[k]
         if kind == "bw":
             if not keeps[k]:
                 return b""
             st = [starts[i + q] for q in keeps[k]]
             sp = [stops[i + q] for q in keeps[k]]
-            values, offsets = compute(c, st, sp)
-            blob, table, stats = fixed_step_payload(chrom_id[c], st, values, offsets)
-            return pickle.dumps((chrom_id[c], table, stats), protocol=4) + blob if world > 1 else (chrom_id[c], blob, table, stats)
-        values, offsets = compute(c, starts[i:j], stops[i:j])
+            values, offsets = compute(table(c), c, st, sp)
+            blob, table_, stats = fixed_step_payload(chrom_id[c], st, values, offsets)
+            return pickle.dumps((chrom_id[c], table_, stats), protocol=4) + blob if world > 1 else (chrom_id[c], blob, table_, stats)
+        values, offsets = compute(table(c), c, starts[i:j], stops[i:j])
         parts = []
         for rows in writers.bedgraph_batches(c, starts[i:j], values, offsets):
             with rows:
@@ -102,17 +160,21 @@ def write_per_base_runs(output_file: str, kind: str, header, contigs, starts, st
                 first = False
 
     if world == 1:
-        lay_down(payload(k) for k in range(len(runs)))  # streamed: one run in memory at a time
+        lay_down(payload(k) for k in range(len(units)))  # streamed: one unit in memory at a time
         return
     local, err = {}, None
     try:
-        for k, (c, _, _) in enumerate(runs):
-            if owner[c] == rank:
+        for k in range(len(units)):
+            if owner[k] == rank:
                 local[k] = payload(k)
     except Exception as e:  # noqa: BLE001 - handed to every rank below
         err = e
+    finally:
+        for key in keys.values():
+            if hasattr(src, "release_region"):
+                src.release_region(key)  # (a no-op for a whole contig's key)
     sharding.agree(err)
-    got = sharding.gather_payloads(local, [owner[c] for c, _, _ in runs])
+    got = sharding.gather_payloads(local, owner)
     err = None
     if writer:
         try:

@@ -280,6 +280,73 @@ def gather_unit_rows(local: Dict[tuple, np.ndarray], units, n_rows: Dict[tuple, 
     return {c: np.concatenate(parts, axis=0) if parts else np.zeros((0, k), np.int64) for c, parts in out.items()}
 
 
+class IntervalPlan:
+    """THE partition of every interval-driven command (``coverage``, ``frag_length_intervals``, the motif drivers; the
+    reference fans their intervals out over ``Pool(workers)``: frag/_coverage.py:212-248, frag/_frag_length.py:571-593,
+    frag/_motif_common.py:635-685): a contig's intervals in start order, all contigs laid end to end in order of first
+    appearance and cut into equal-cost consecutive runs (``split_counts`` - the partition ``frag.delfi`` and the bench
+    use), so a rank owns whole contigs plus at most two partial ones.  A partial share is answered from a REGION of the
+    contig (``unit_key``: the rows / records between its first interval's start and its last one's stop, read through
+    the index), a whole one from the contig.  Results travel as fixed-width integer rows in ONE all-gather
+    (``gather_unit_rows``) and come back in the input order of the intervals - on every rank."""
+
+    def __init__(self, contigs: Sequence[str], starts: Sequence[int], stops: Sequence[int], group=None):
+        self.rank, self.world = rank_world(group)
+        self.group = group
+        self.n = len(contigs)
+        starts = np.asarray(starts, dtype=np.int64)
+        stops = np.asarray(stops, dtype=np.int64)
+        by: Dict[str, list] = {}
+        for i, c in enumerate(contigs):
+            by.setdefault(c, []).append(i)
+        # a contig's intervals in start order (stable): consecutive shares are then compact regions of the contig
+        self.order = {c: np.asarray(idx, dtype=np.int64)[np.argsort(starts[idx], kind="stable")] for c, idx in by.items()}
+        self.starts, self.stops = starts, stops
+        self.units = split_counts({c: len(idx) for c, idx in self.order.items()}, self.world)
+        self.mine = [(c, i0, i1) for r, c, i0, i1 in self.units if r == self.rank]
+
+    def intervals(self, unit) -> np.ndarray:
+        """Input positions of the unit's intervals (start order)."""
+        c, i0, i1 = unit
+        return self.order[c][i0:i1]
+
+    def is_whole(self, unit) -> bool:
+        c, i0, i1 = unit
+        return i0 == 0 and i1 == len(self.order[c])
+
+    def extent(self, unit):
+        idx = self.intervals(unit)
+        return int(self.starts[idx].min()), int(self.stops[idx].max())
+
+    def unit_key(self, src, unit, pad: int = 1) -> str:
+        """Engine key of a table that answers every query of the unit: the contig (a whole share, one process, a file
+        that cannot be entered inside a contig) or the region its intervals span, ``pad`` bases either side."""
+        c = unit[0]
+        if self.world == 1 or self.is_whole(unit):
+            return src.require(c)
+        lo, hi = self.extent(unit)
+        if hi <= lo:
+            return src.require(c)
+        return src.require_region(c, max(0, lo - pad), hi + pad)
+
+    def release(self, src, key: str) -> None:
+        if hasattr(src, "release_region"):
+            src.release_region(key)  # (a no-op for a whole contig's key)
+
+    def gather(self, local: Dict[tuple, np.ndarray], k: int, dtype=np.int64) -> np.ndarray:
+        """``local[unit]``: ``[len(unit), k]`` rows of this rank's units (``dtype`` int64, or float64 - the bit
+        patterns travel).  Returns ``[n_intervals, k]`` in the intervals' input order, on every rank."""
+        as_float = np.dtype(dtype) == np.float64
+        send = {u: (np.ascontiguousarray(v, dtype=np.float64).view(np.int64) if as_float
+                    else np.ascontiguousarray(v, dtype=np.int64)).reshape(-1, k) for u, v in local.items()}
+        n_rows = {(c, i0, i1): i1 - i0 for _, c, i0, i1 in self.units}
+        got = gather_unit_rows(send, self.units, n_rows, k, group=self.group)
+        out = np.zeros((self.n, k), np.int64)
+        for c, rows in got.items():
+            out[self.order[c]] = rows
+        return out.view(np.float64) if as_float else out
+
+
 def allreduce_sum(value: int, group=None, device=None) -> int:
     """Sum of one int64 over ranks (the genome-wide total of ``coverage(normalize=True)``)."""
     import torch

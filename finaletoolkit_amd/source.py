@@ -40,6 +40,20 @@ def get_engine() -> Engine:
     return _ENGINE
 
 
+_SIDE_ENGINE: Optional[Engine] = None
+
+
+def get_side_engine() -> Engine:
+    """A SECOND context on the engine's device, for work that runs beside the main one from another thread (a ctx is
+    single-threaded; different ctxs may be driven from different threads - include/ftk.h).  ``frag.delfi`` counts the
+    bins' G + C on it while the fragment file is still being decoded.  Kept for the process (its reference blocks and
+    page-locked staging are recycled like the main engine's), dropped by ``close_all``."""
+    global _SIDE_ENGINE
+    if _SIDE_ENGINE is None:
+        _SIDE_ENGINE = Engine(get_engine().device)
+    return _SIDE_ENGINE
+
+
 def usable_cores() -> int:
     """Host cores this process may really use: scheduler affinity, capped by the cgroup CPU quota (a
     container can see 256 logical CPUs and own 16), divided by ``LOCAL_WORLD_SIZE`` when this process is one rank
@@ -541,6 +555,10 @@ def close_all():
         except Exception:
             pass
     _SOURCES.clear()
+    global _SIDE_ENGINE
+    if _SIDE_ENGINE is not None:
+        _SIDE_ENGINE.close()
+        _SIDE_ENGINE = None
     if _ENGINE is not None:
         _ENGINE.close()
         _ENGINE = None

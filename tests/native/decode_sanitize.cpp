@@ -16,14 +16,20 @@
 // The device row parser's kernels are not part of this host-only build; the harness opens host-mode
 // streams only, so the launcher is never reached.
 namespace ftk {
-void textparse_launch(hipStream_t, const uint8_t*, size_t, bool, uint32_t*, uint32_t*, size_t, int32_t*, int32_t*, uint8_t*,
-                      uint8_t*, TextSummary*) {
+size_t textparse_scratch_bytes(size_t n) { return n / 512 + 64; }
+void textparse_launch(hipStream_t, const uint8_t*, size_t, bool, void*, size_t, int32_t*, int32_t*, uint8_t*, uint8_t*,
+                      TextSummary*) {
     fprintf(stderr, "textparse_launch called in the sanitizer harness\n");
     abort();
 }
 void textparse_launch_inflated(hipStream_t, uint8_t*, uint32_t, uint32_t, const uint8_t*, const TextSummary*, uint32_t, bool, bool,
-                               uint32_t*, uint32_t*, size_t, int32_t*, int32_t*, uint8_t*, uint8_t*, TextSummary*) {
+                               void*, size_t, int32_t*, int32_t*, uint8_t*, uint8_t*, TextSummary*) {
     fprintf(stderr, "textparse_launch_inflated called in the sanitizer harness\n");
+    abort();
+}
+void append_rows_launch(hipStream_t, int32_t*, int32_t*, uint8_t*, uint8_t*, int32_t*, int32_t*, const int32_t*, const int32_t*,
+                        const uint8_t*, const uint8_t*, const int32_t*, const int32_t*, size_t) {
+    fprintf(stderr, "append_rows_launch called in the sanitizer harness\n");
     abort();
 }
 void inflate_launch(hipStream_t, const uint8_t*, const InflateBlock*, int, uint8_t*, InflateStatus*, uint32_t*) {

@@ -70,6 +70,7 @@ def test_config5_bam_at_real_size_streams_through_the_device_parser(big_bam):
     source.close_all()
     del source.REGION_READS[:]
     lazy = source.open_source(path)
+    eng = source.get_engine()                      # (close_all dropped the engine the stream used)
     assert lazy.lazy and not lazy.loaded
     regions = [("small_c", 2_000_000, 2_400_000), ("big", BIG * 24 // 25 // SC.WINDOW * SC.WINDOW, BIG * 24 // 25 // SC.WINDOW * SC.WINDOW + 400_000),
                ("small_a", 1_000_000, 1_300_000)]

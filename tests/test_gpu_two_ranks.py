@@ -289,3 +289,28 @@ def test_bench_two_ranks_share_the_gpu():
     assert [len(r["regions_read"]) for r in leg["per_rank"]] == [1, 1] and \
         leg["per_rank"][0]["regions_read"][0][0] == leg["per_rank"][1]["regions_read"][0][0]
     assert all(r["decoder_threads"] >= 1 and r["stages_s"]["total"] > 0 for r in leg["per_rank"])
+
+
+def test_bench_eight_ranks_share_the_gpu():
+    """The whole `bench.py --gpus 8` path - the world size the product is sized for - with eight ranks on GPU 0 (gloo
+    exchange): unit split of eight contigs (17-22, X, Y) into eight equal-cost runs, per-rank launches, the all-gather
+    of the DELFI vector, and the N-rank file leg (ONE indexed file, eight `frag.delfi` ranks, every cut contig read as
+    regions through the index by the ranks that share it).  What a first run on a real 8-GPU node must not discover."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(FTK_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--contigs",
+                        "17,18,19,20,21,22,X,Y", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=2400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["checks"] and all(line["checks"].values()), line["checks"]
+    assert "gloo" in line["exchange"] and "8 ranks" in line["exchange"]
+    leg = line["end_to_end"]["genome_frag_delfi_api_ranks"]
+    assert leg["ranks"] == 8 and leg["results_ok"] and leg["merged_rows"] > 50, line["end_to_end"]
+    per = leg["per_rank"]
+    assert len(per) == 8 and sorted(x["rank"] for x in per) == list(range(8))
+    # eight contigs, eight equal-cost runs: every rank reads at least one region (a cut falls into almost every
+    # contig), a contig is decoded whole by at most one rank, and every region read names one of the run's contigs
+    assert all(len(x["regions_read"]) >= 1 for x in per)
+    assert sum(x["contigs_decoded"] for x in per) + len({r[0] for x in per for r in x["regions_read"]}) == 8
+    assert all(x["decoder_threads"] >= 1 and x["stages_s"]["total"] > 0 for x in per)

@@ -98,10 +98,12 @@ def _fake_device(sizes):
     from oracle import oracle as O
     frs = {c: O.Frags(*synth.synth_contig(n, depth=3.0, seed=70 + i)) for i, (c, n) in enumerate(sizes.items())}
     asked = []
+    regions = []
 
     class Src:
         contigs = list(sizes)
         loaded = set(sizes)
+        region_reads = regions
         lengths = {c: None for c in sizes}
 
         def load_all(self):
@@ -116,6 +118,13 @@ def _fake_device(sizes):
 
         def require_interval(self, c, *a, **k):
             return self.require(c)
+
+        def require_region(self, c, a, b):  # (the whole contig's table answers every query of a region of it)
+            regions.append((c, int(a), int(b)))
+            return c
+
+        def release_region(self, key):
+            pass
 
     class Eng:
         def window_counts(self, name, starts, stops, q=30, lo=None, hi=None, policy="midpoint", out=None):
@@ -168,7 +177,7 @@ def _product_worker(rank, world, port, d, q):
     counted = sorted(set(asked))
     cov = Cv.coverage("x", f"{d}/iv.bed", f"{d}/cov_w{world}.bed", normalize=True, scale_factor=1e6)
     sharding.finalize()
-    q.put((rank, df.to_csv(), [tuple(c) for c in cov], counted))
+    q.put((rank, df.to_csv(), [tuple(c) for c in cov], counted, list(src.region_reads)))
 
 
 def test_sharded_delfi_and_coverage_equal_single_process(tmp_path):
@@ -183,7 +192,7 @@ def test_sharded_delfi_and_coverage_equal_single_process(tmp_path):
     (d / "bl.bed").write_text("".join(f"{c}\t{int(a)}\t{int(a) + 900}\n" for c, n in SIZES_P.items()
                                       for a in rng.integers(0, n - 1000, 20)))
     iv = [f"{c}\t{int(a)}\t{int(a) + int(rng.integers(1, 4000))}\t{c}{k}\n" for c, n in SIZES_P.items()
-          for k, a in enumerate(rng.integers(0, n - 4000, 30))]
+          for k, a in enumerate(rng.integers(0, n - 4000, 400 if c == "b" else 30))]  # (b is half of the cost: wherever the shuffle puts it, the cut of two equal-cost runs falls into it)
     rng.shuffle(iv)
     (d / "iv.bed").write_text("".join(iv))
     ctx = mp.get_context("spawn")
@@ -199,7 +208,7 @@ def test_sharded_delfi_and_coverage_equal_single_process(tmp_path):
             p.join(timeout=60)
             assert p.exitcode == 0
     one = res[1][0]
-    assert one[3] == sorted(SIZES_P) and len(one[2]) == 150 and one[1].count("\n") > 200
+    assert one[3] == sorted(SIZES_P) and len(one[2]) == 520 and one[1].count("\n") > 200
     for r in res[2]:
         assert r[1] == one[1] and r[2] == one[2]  # same frame, same coverage list on every rank
     a, b = set(res[2][0][3]), set(res[2][1][3])
@@ -208,6 +217,12 @@ def test_sharded_delfi_and_coverage_equal_single_process(tmp_path):
     assert a and b and len(a & b) == 1 and a | b == set(SIZES_P), (a, b)
     assert (d / "delfi_w2.tsv").read_text() == (d / "delfi_w1.tsv").read_text()
     assert (d / "cov_w2.bed").read_text() == (d / "cov_w1.bed").read_text()
+    # coverage's intervals take the same kind of partition (sharding.IntervalPlan): one process reads no region; with two
+    # ranks the contig the cut falls into is read as a region by both, each spanning only its own intervals
+    assert one[4] == []
+    r0, r1 = res[2][0][4], res[2][1][4]
+    assert len(r0) == 1 and len(r1) == 1 and r0[0][0] == r1[0][0] == "b" and r0[0][1:] != r1[0][1:]
+    assert r0[0][2] <= r1[0][1] + 4001 or r1[0][2] <= r0[0][1] + 4001  # (start-ordered shares: the two regions barely overlap)
 
 
 def test_launch_ranks_starts_n_ranks_and_propagates_failure(tmp_path):
@@ -285,20 +300,39 @@ def _helpers_worker(rank, world, port, d, q):
     contigs = ["a"] * 3 + ["b"] * 2 + ["c"] * 4 + ["a"]  # the last run comes back to `a`: skipped in the bigWig
     starts = [100, 5000, 20_000, 10, 9000, 0, 300, 7000, 29_000, 40_000]
     stops = [1100, 5000, 21_500, 4010, 9100, 200, 1300, 7001, 30_000, 41_000]
-    asked = []
+    asked, tables = [], []
 
-    def compute(c, st, sp):
-        asked.append(c)
+    class Src:  # what write_per_base_runs asks a FragSource for
+        def require(self, c):
+            tables.append((c, None, None))
+            return c
+
+        def require_region(self, c, lo, hi):
+            tables.append((c, int(lo), int(hi)))
+            return f"{c}@{lo}-{hi}"
+
+        def release_region(self, key):
+            pass
+
+    def compute(key, c, st, sp):
+        asked.append((c, tuple(st)))
+        assert key == c or key.startswith(c + "@")
+        if "@" in key:  # a region table: it must span every interval it is asked about
+            lo, hi = (int(x) for x in key.split("@")[1].split("-"))
+            assert all(lo <= a and b <= hi for a, b in zip(st, sp) if b > a), (key, st, sp)
         offs = np.concatenate([[0], np.cumsum([b - a for a, b in zip(st, sp)])]).astype(np.int64)
         vals = np.concatenate([np.arange(a, b, dtype=np.int64) * (ord(c) - 96) - 7 for a, b in zip(st, sp)] or
                               [np.zeros(0, np.int64)])
         return vals, offs
 
-    _runs.write_per_base_runs(f"{d}/w{world}.bw", "bw", header, contigs, starts, stops, compute)
+    _runs.UNIT_BASES = 1200  # (units of a few intervals: the ranks' shares are cut inside contigs)
+    assert len(_runs.split_into_units(_runs.group_runs(contigs), starts, stops)) == 7
+    _runs.write_per_base_runs(f"{d}/w{world}.bw", "bw", header, contigs, starts, stops, compute, Src(), 5)
     _runs.write_per_base_runs(f"{d}/w{world}.bed.gz", "bedgraph.gz", header, contigs, starts, stops,
-                              lambda c, st, sp: (compute(c, st, sp)[0].astype(np.float64) / 3.0, compute(c, st, sp)[1]))
+                              lambda k, c, st, sp: (compute(k, c, st, sp)[0].astype(np.float64) / 3.0, compute(k, c, st, sp)[1]),
+                              Src(), 5)
     sharding.finalize()
-    q.put((rank, raised, sorted(set(asked))))
+    q.put((rank, raised, sorted(set(asked)), sorted(set(tables), key=str)))
 
 
 def test_payload_gather_float_rows_agree_and_run_outputs(tmp_path):
@@ -320,7 +354,10 @@ def test_payload_gather_float_rows_agree_and_run_outputs(tmp_path):
     assert [r[1][:6] for r in res[2]] == ["other:", "own:bo"] and "rank 1 failed: ValueError: boom" in res[2][0][1]
     for world in (2, 3):
         owned = [set(r[2]) for r in res[world]]
-        assert set().union(*owned) == {"a", "b", "c"} and sum(map(len, owned)) == 3  # each contig scored by one rank
+        # every unit scored by exactly one rank (the bigWig skips the run that comes back to `a`, the bedGraph does not)
+        assert set().union(*owned) == set(res[1][0][2]) and sum(map(len, owned)) == len(res[1][0][2])
+        # a rank that scores only part of a contig's units asked for a REGION of it, the single process never did
+        assert any(t[1] is not None for r in res[world] for t in r[3]) and all(t[1] is None for t in res[1][0][3])
         assert (tmp_path / f"w{world}.bw").read_bytes() == (tmp_path / "w1.bw").read_bytes()
         assert (tmp_path / f"w{world}.bed.gz").read_bytes() == (tmp_path / "w1.bed.gz").read_bytes()
     from finaletoolkit_amd.bigwig import BigWigFile
@@ -347,3 +384,103 @@ def test_cli_refuses_gpus_for_unsharded_commands(tmp_path):
     r = subprocess.run([sys.executable, "-m", "finaletoolkit_amd.cli", "gap-bed", "hg19", str(out)], cwd=ROOT, env=env,
                        capture_output=True, text=True)
     assert r.returncode == 0 and out.exists()
+
+
+# ---- world 8 (the node the product is sized for), gloo on CPU ---------------------------------------------------
+def _rows_of(contig, i0, i1):
+    """Deterministic stand-in for a unit's counted rows: the LIVE items of [i0, i1) (every third one is not), four
+    int64 columns derived from the contig and the item - any rank can compute any unit's rows, so every rank can check
+    the whole gathered table."""
+    live = [i for i in range(i0, i1) if i % 3 != 1]
+    seed = sum(ord(ch) for ch in contig)
+    return np.array([[seed * 1_000_003 + i, i * i, -i, (seed << 40) + i] for i in live], np.int64).reshape(-1, 4)
+
+
+def _world8_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from finaletoolkit_amd import sharding, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    report = {}
+    try:
+        # (1) the product's partition on b37's 100 kb tiling, and (2) a tiny table that leaves ranks empty-handed
+        b37 = {c: -(-n // 100_000) for c, n in synth.B37_SIZES.items()}
+        tiny = {"p": 3, "q": 0, "r": 2}
+        for label, counts in (("b37", b37), ("tiny", tiny)):
+            units = sharding.split_counts(counts, world)
+            n_rows = {(c, i0, i1): len(_rows_of(c, i0, i1)) for _, c, i0, i1 in units}
+            local = {(c, i0, i1): _rows_of(c, i0, i1) for r, c, i0, i1 in units if r == rank}
+            got = sharding.gather_unit_rows(local, units, n_rows, 4)
+            want = {c: _rows_of(c, 0, n) for c, n in counts.items() if n > 0}
+            report[label] = (sorted(got) == sorted(want) and all(np.array_equal(got[c], want[c]) for c in want),
+                             len(local), int(sum(len(v) for v in local.values())))
+        # (3) byte payloads of numbered items to rank 0: unequal sizes, an empty one, ranks that own none
+        owner = [(7 * k + 3) % world if k % 5 else 2 for k in range(23)]  # rank 2 owns many, some ranks none
+        owner = [o if o not in (4, 6) else 1 for o in owner]              # ranks 4 and 6: empty-handed
+        mine = {k: (bytes([k]) * (0 if k == 11 else 1000 * k + 17)) for k in range(23) if owner[k] == rank}
+        out = sharding.gather_payloads(mine, owner)
+        if rank == 0:
+            report["payloads"] = out == [bytes([k]) * (0 if k == 11 else 1000 * k + 17) for k in range(23)]
+        else:
+            report["payloads"] = out is None
+        # (4) float rows with LPT owners, (5) the scalar all-reduce, (6) agreement on an error raised by ONE rank
+        names = list(synth.B37_SIZES)
+        lpt = sharding.lpt_assign({c: float(b37[c]) for c in names}, world)
+        n_f = {c: 1 + b37[c] % 7 for c in names}
+        fl = {c: np.full((n_f[c], 2), 0.1 * names.index(c)) + np.arange(2 * n_f[c]).reshape(-1, 2) / 3.0 for c in names}
+        gf = sharding.gather_float_rows({c: fl[c] for c in names if lpt[c] == rank}, names, n_f, lpt, 2)
+        report["floats"] = all(np.array_equal(gf[c], fl[c]) for c in names)
+        report["sum"] = sharding.allreduce_sum(rank + 1) == world * (world + 1) // 2
+        try:
+            sharding.agree(ValueError("rank five's share failed") if rank == 5 else None)
+            report["agree"] = False
+        except ValueError:
+            report["agree"] = rank == 5
+        except RuntimeError as e:
+            report["agree"] = rank != 5 and "rank 5 failed" in str(e)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+    q.put((rank, report))
+
+
+def test_world_8_partition_and_gathers():
+    """`split_counts` / `gather_unit_rows` / `gather_payloads` / `gather_float_rows` / `agree` at the world size the
+    product is sized for (one node of eight MI355X), over gloo: a rank owning pieces of three contigs, ranks without a
+    unit, unequal shard lengths - so that the first real 8-GPU run can only fail on hardware grounds."""
+    import torch.multiprocessing as mp
+    from finaletoolkit_amd import sharding, synth
+    world = 8
+    b37 = {c: -(-n // 100_000) for c, n in synth.B37_SIZES.items()}
+    units = sharding.split_counts(b37, world)
+    # the partition itself: every item once, in order; equal cost; a rank with three contigs' pieces; b37 balance
+    for c, n in b37.items():
+        cuts = [(i0, i1) for _, cc, i0, i1 in units if cc == c]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    per_rank = {r: [u for u in units if u[0] == r] for r in range(world)}
+    assert max(len({u[1] for u in us}) for us in per_rank.values()) >= 3
+    assert [u[0] for u in units] == sorted(u[0] for u in units)          # ranks take consecutive runs of the genome
+    loads = [sum(i1 - i0 for _, _, i0, i1 in us) for us in per_rank.values()]
+    assert (sum(loads) / world) / max(loads) >= 0.98
+    tiny_units = sharding.split_counts({"p": 3, "q": 0, "r": 2}, world)
+    assert len({u[0] for u in tiny_units}) < world                        # some ranks hold nothing
+    assert sorted((c, i) for _, c, i0, i1 in tiny_units for i in range(i0, i1)) == [("p", 0), ("p", 1), ("p", 2), ("r", 0), ("r", 1)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(res) == list(range(world))
+    for rank, rep in res.items():
+        assert rep["b37"][0] and rep["tiny"][0], (rank, rep)
+        assert rep["payloads"] and rep["floats"] and rep["sum"] and rep["agree"], (rank, rep)
+    assert sum(rep["b37"][1] for rep in res.values()) == len(units)
+    assert min(rep["tiny"][1] for rep in res.values()) == 0              # an empty-handed rank went through the gather
+    assert len({rep["b37"][2] for rep in res.values()}) > 1              # unequal shard lengths
