@@ -8,7 +8,29 @@ the C ABI of ``include/ftk.h`` (``libftk_hip.so``).  No CPU fallback.
 """
 import importlib as _importlib
 import importlib.util as _importlib_util
+import os as _os
 import sys as _sys
+
+
+def _hardware_queues():
+    """The ONE import side effect, and how to turn it off.  The streaming decoder keeps up to eight pieces of a file in
+    flight on HIP streams of their own; the HIP runtime multiplexes a process's streams onto ``GPU_MAX_HW_QUEUES``
+    hardware queues (ROCm's default: 4) and two streams on one queue run strictly one after the other: whole-genome
+    DELFI leg 0.176-0.183 s with 4 queues, 0.151-0.162 s with 16 (tools/e2e_genome_bench.py).  The runtime reads the
+    variable ONCE, at its first HIP call - which in most scripts is torch's, long before the engine is first used
+    (round 4 measured exactly that: set at library load instead, a script that touched ``torch.cuda`` first ran the leg
+    18 % slower) - so it is set here, when the package is imported.  It is process-wide (torch / RCCL in this process
+    and child processes see it).  A value the user has set wins; ``FTK_HW_QUEUES=<n>`` chooses another number and
+    ``FTK_HW_QUEUES=0`` leaves ROCm's default alone."""
+    want = _os.environ.get("FTK_HW_QUEUES", "16").strip()
+    if want in ("", "0", "off", "default") or "GPU_MAX_HW_QUEUES" in _os.environ:
+        return
+    if not want.isdigit():
+        raise ValueError(f"FTK_HW_QUEUES={want!r}: expected a number of hardware queues, or 0 to keep ROCm's default")
+    _os.environ["GPU_MAX_HW_QUEUES"] = want
+
+
+_hardware_queues()
 
 from .exceptions import (FinaleToolkitError, InvalidInputError, MissingIndexError,  # noqa: F401
                          UnsupportedFormatError)

@@ -157,20 +157,11 @@ def _check_single_hip_runtime():
 
 
 def _hardware_queues():
-    """The streaming decoder keeps up to eight pieces of a file in flight on HIP streams of their own (inflate kernels
-    of two or three pieces side by side, the row parser behind them on another stream); the HIP runtime multiplexes all
-    streams of a process onto ``GPU_MAX_HW_QUEUES`` hardware queues (ROCm's default: 4), and two streams on one queue
-    run strictly one after the other.  Whole-genome DELFI leg (tools/e2e_genome_bench.py): 4 queues 0.176-0.183 s,
-    8: 0.161-0.181 s, 16: 0.151-0.162 s.  The runtime reads the variable when it initialises, so it is set when the
-    library is LOADED (first use of the engine - not on ``import finaletoolkit_amd``), only if the user has not set it,
-    and ``FTK_HW_QUEUES`` chooses the number (``0`` = leave ROCm's default alone).  It is process-wide: torch / RCCL in
-    the same process and child processes see it too (environment table)."""
-    want = os.environ.get("FTK_HW_QUEUES", "16").strip()
-    if want in ("", "0", "off", "default") or "GPU_MAX_HW_QUEUES" in os.environ:
-        return
-    if not want.isdigit():
-        raise ValueError(f"FTK_HW_QUEUES={want!r}: expected a number of hardware queues, or 0 to keep ROCm's default")
-    os.environ["GPU_MAX_HW_QUEUES"] = want
+    """See ``finaletoolkit_amd/__init__.py``: the decoder's hardware-queue count is set when the package is imported
+    (before any HIP call of the process); repeated here for hosts that reach the library without the package import
+    having run first in this process' environment."""
+    from . import _hardware_queues as set_queues
+    set_queues()
 
 
 def load() -> C.CDLL:

@@ -53,6 +53,11 @@ constexpr int kGranShift = kRing >= 8192 ? 11 : 10, kGran = 1 << kGranShift;  //
 #ifndef FTK_INFLATE_DIST_ROOT
 #define FTK_INFLATE_DIST_ROOT 9
 #endif
+// A window's literal and match bytes resolved by the lanes side by side (see the symbol loop); 0 = the serial match loop
+// of round 3 for every window (tools/inflate_variants.sh compares the two builds)
+#ifndef FTK_INFLATE_VECMATCH
+#define FTK_INFLATE_VECMATCH 1
+#endif
 constexpr int kLitRoot = FTK_INFLATE_ROOT, kDistRoot = FTK_INFLATE_DIST_ROOT, kPreRoot = 7;
 constexpr int kFarDist = kRing - 258 - 64;    // matches further back than this read from HBM
 static_assert((kRing & (kRing - 1)) == 0 && kGran <= kRing / 2, "the write-behind granule must be at most half the ring");
@@ -531,6 +536,49 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         T = (uint32_t)__builtin_amdgcn_readlane(inc, 63);
                     }
                     if (T) {
+#if FTK_INFLATE_VECMATCH
+                        // ---- the window's bytes resolved side by side (round 4).  The serial match loop below costs one
+                        // LDS read -> write round trip per match, one after the other (a third of a window's cycles, DESIGN
+                        // 3.5).  When the window's output fits the wave (T <= 63 bytes) and every match reads the ring,
+                        // lane j becomes output byte j instead: the chain's lanes push their number to the lane of their
+                        // first output byte (ds_permute), a running maximum hands every byte its symbol, one gather brings
+                        // the symbol's distance or literal bytes, and then each byte knows where it comes from - a literal,
+                        // a ring byte written by an earlier window (one LDS read for all of them), or an EARLIER BYTE OF
+                        // THIS WINDOW (in fragment rows the END column's digits copy the START column's, a few bytes back).
+                        // The last kind is resolved by pointer jumping over the lanes (ds_bpermute: no memory), a round
+                        // per doubling of the dependency depth - two rounds for rows - and one store writes the window.
+                        if (T <= 63u && __ballot(mark == 3u) != 0ull && __ballot(mark == 3u && mdist > (unsigned)kFarDist) == 0ull) {
+                            int own = __builtin_amdgcn_ds_permute((mark ? (int)off : 63) << 2, mark ? lane + 1 : 0);
+                            own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x111, 0xf, 0xf, false));
+                            own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x112, 0xf, 0xf, false));
+                            own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x114, 0xf, 0xf, false));
+                            own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x118, 0xf, 0xf, false));
+                            own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x142, 0xa, 0xf, false));
+                            own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x143, 0xc, 0xf, false));
+                            // what a byte needs of its symbol: where the symbol starts, its kind, its distance or bytes
+                            const unsigned pk = (mark == 3u ? mdist : (((E >> 8) & 0xffu) | (((E >> 20) & 0xffu) << 8))) |
+                                                (off << 16) | (mark << 22);
+                            const unsigned oi = (unsigned)__builtin_amdgcn_ds_bpermute((own - 1) << 2, (int)pk);
+                            const unsigned o_pay = oi & 0xffffu, rel = (unsigned)lane - ((oi >> 16) & 63u);
+                            const bool is_m = (oi >> 22) == 3u;
+                            const int src = lane - (int)o_pay;  // (matches) the window byte this one copies; < 0: an older byte
+                            const unsigned old = L.ring[(A + (uint32_t)lane - o_pay) & kRingMask];
+                            // state: 0x100 | value once known, else the lane to take it from
+                            unsigned st = !is_m ? (0x100u | ((o_pay >> (8u * (rel & 1u))) & 0xffu))
+                                                : (src < 0 ? (0x100u | old) : (unsigned)src);
+                            if ((uint32_t)lane >= T) st = 0x100u;
+                            while (__ballot((st & 0x100u) == 0u)) {
+                                const unsigned g = (unsigned)__builtin_amdgcn_ds_bpermute((int)((st & 63u) << 2), (int)st);
+                                if ((st & 0x100u) == 0u) st = g;
+                            }
+                            if ((uint32_t)lane < T) L.ring[(A + (uint32_t)lane) & kRingMask] = (uint8_t)st;
+                            PROF(4, mark);
+                            advance(T);
+                            bp += (uint32_t)pos;
+                            PROF(5, mark);
+                            continue;
+                        }
+#endif
                         if (mark == 1u || mark == 2u) {
                             const uint32_t at = A + off;
                             L.ring[at & kRingMask] = (uint8_t)(E >> 8);

@@ -23,7 +23,7 @@ import pandas
 from ..genome.gaps import GenomeGaps
 from ..reference import ReferenceGenome
 from ..engine import Engine
-from ..source import get_engine, get_side_engine, region_contig, resident_contigs
+from ..source import EarlyContigs, get_engine, get_side_engine, region_contig, resident_contigs
 from .. import sharding
 from ..utils import chrom_sizes_to_list, overlaps
 from ._delfi_gc_correct import delfi_gc_correct
@@ -273,6 +273,25 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
     if verbose:
         t0 = time.time()
         stderr.write(f"delfi: {input_file} bins {bins_file}\n")
+    # One process: every contig of the file will be wanted (or skipped cheaply), so the decoder starts NOW and works
+    # towards chr1 while the side files below are read.  (Several ranks each want their own share: known after the plan.)
+    early = None
+    if sharding.rank_world()[1] == 1 and isinstance(get_engine(), Engine):
+        early = EarlyContigs(input_file, workers)
+    try:
+        return _delfi(early, t_begin, clock, input_file, chrom_sizes, bins_file, reference_file, blacklist_file, gap_file,
+                      output_file, no_gc_correct, gc_correct, remove_nocov, merge_bins, window_size, quality_threshold,
+                      workers, verbose)
+    except BaseException:
+        if early is not None:
+            early.close()
+        raise
+
+
+def _delfi(early, t_begin, clock, input_file, chrom_sizes, bins_file, reference_file, blacklist_file, gap_file, output_file,
+           no_gc_correct, gc_correct, remove_nocov, merge_bins, window_size, quality_threshold, workers, verbose):
+    if verbose:
+        t0 = time.time()
     contigs = chrom_sizes_to_list(chrom_sizes)
     if gc_correct is None:
         gc_correct = not no_gc_correct
@@ -347,8 +366,12 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
         err = None
         try:
             tw = time.perf_counter()
-            for src, contig in resident_contigs(input_file, whole, workers, stream_all=world == 1):
+            for src, contig in (early if early is not None else resident_contigs(input_file, whole, workers,
+                                                                                 stream_all=world == 1)):
                 clock["decode_wait"] += time.perf_counter() - tw
+                if contig not in plan:  # (the early stream hands out every contig of the file)
+                    tw = time.perf_counter()
+                    continue
                 starts, stops, arms, live, ok = plan[contig]
                 local[(contig, 0, len(starts))] = _contig_counts(src, eng, ref, contig, starts, stops, live, ok,
                                                                  contig_gaps.get(contig) if gaps is not None else None,

@@ -16,6 +16,7 @@ the multi-rank file byte-identical to the single-process one.
 """
 from __future__ import annotations
 
+import os
 import pickle
 from typing import Callable, List, Sequence, Tuple
 
@@ -37,7 +38,11 @@ def group_runs(contigs: Sequence[str]) -> List[Run]:
     return runs
 
 
-UNIT_BASES = 32 << 20  # per-base scores one unit holds at most (one launch, one compressed payload)
+# per-base scores one unit holds at most (one launch, one compressed payload): small enough that a few thousand sites
+# deal evenly over eight ranks, large enough that a launch (~20 us) and a payload's framing do not show.
+# ``FTK_UNIT_BASES`` overrides it (tests on contigs smaller than one unit) - for EVERY rank count alike, or the files of
+# different rank counts would differ in their compressed pieces.
+UNIT_BASES = int(os.environ.get("FTK_UNIT_BASES") or (1 << 20))
 
 
 def split_into_units(runs: Sequence[Run], starts, stops) -> List[Run]:
@@ -59,9 +64,15 @@ def split_into_units(runs: Sequence[Run], starts, stops) -> List[Run]:
 
 def deal_units(units: Sequence[Run], starts, stops, world: int) -> List[int]:
     """Rank of every unit: the units laid end to end in file order and cut into ``world`` consecutive groups of equal
-    cost (bases + a fixed cost per unit), the partition of ``sharding.split_counts`` with bases for weights - a rank
-    scores whole contigs plus at most two partial ones."""
-    cost = [sum(max(int(stops[k]) - int(starts[k]), 0) for k in range(i, j)) + 4096 for _, i, j in units]
+    cost - the partition of ``sharding.split_weighted``: a unit costs the bases its intervals span (gaps included: a
+    region read decodes every row in between) plus, for the first unit of a run, the fixed cost of entering a contig -
+    so a rank scores whole contigs plus at most two partial ones."""
+    enter = sharding.shard_overhead_bases()
+    cost = []
+    for k, (c, i, j) in enumerate(units):
+        span = (max(int(b) for b in stops[i:j]) - min(int(a) for a in starts[i:j])) if j > i else 0
+        first = k == 0 or units[k - 1][0] != c or units[k - 1][2] != i  # (a run's first unit: the contig is entered here)
+        cost.append(max(span, 1) + (enter if first else 0))
     total = sum(cost)
     owner, done = [], 0
     for w in cost:

@@ -173,6 +173,37 @@ def split_counts(counts: Dict[str, int], n_ranks: int, overhead: int = 50):
     return units
 
 
+def shard_overhead_bases() -> int:
+    """Fixed cost of entering a contig, in bases of decoded rows: what ``split_counts`` charges as 50 windows of
+    100 kb (an index seek, a first block, launch ramps - measured on simulated ranks, see there).
+    ``FTK_SHARD_OVERHEAD_BASES`` overrides it (tests with contigs far smaller than that set 0, so that the cut is
+    taken by the intervals' span alone)."""
+    v = os.environ.get("FTK_SHARD_OVERHEAD_BASES")
+    return max(0, int(v)) if v not in (None, "") else 5_000_000
+
+
+def split_weighted(weights: Dict[str, Sequence[float]], n_ranks: int, overhead: float):
+    """``split_counts`` with a cost per item: contigs in the given order, contig ``c``'s items costing
+    ``weights[c][i]`` each plus ``overhead`` per contig, cut into ``n_ranks`` consecutive runs of equal cost.  An item
+    belongs to the rank its cost interval STARTS in.  Returns ``[(rank, contig, i0, i1), ...]`` like ``split_counts``."""
+    items = {c: np.asarray(w, dtype=np.float64) for c, w in weights.items()}
+    if n_ranks <= 1:
+        return [(0, c, 0, len(w)) for c, w in items.items() if len(w) > 0]
+    total = float(sum(w.sum() for w in items.values()) + overhead * len(items))
+    units, done = [], 0.0
+    for c, w in items.items():
+        done += overhead
+        if len(w):
+            at = done + np.concatenate(([0.0], np.cumsum(w)[:-1]))  # where each item's cost starts
+            rank = np.minimum(n_ranks - 1, (at * n_ranks / max(total, 1e-300)).astype(np.int64))
+            cuts = np.flatnonzero(np.diff(rank)) + 1
+            bounds = np.concatenate(([0], cuts, [len(w)]))
+            for a, b in zip(bounds[:-1], bounds[1:]):
+                units.append((int(rank[a]), c, int(a), int(b)))
+        done += float(w.sum())
+    return units
+
+
 def split_units(sizes: Dict[str, int], n_ranks: int, window: int, unit_overhead_windows: int = 50):
     """``split_counts`` for a tiling of ``window`` bases (``bench.py``'s steps): ``[(rank, contig, start, stop), ...]``
     in genome order, ``start`` a multiple of ``window``.  A unit needs the contig's fragments starting in
@@ -284,8 +315,10 @@ class IntervalPlan:
     """THE partition of every interval-driven command (``coverage``, ``frag_length_intervals``, the motif drivers; the
     reference fans their intervals out over ``Pool(workers)``: frag/_coverage.py:212-248, frag/_frag_length.py:571-593,
     frag/_motif_common.py:635-685): a contig's intervals in start order, all contigs laid end to end in order of first
-    appearance and cut into equal-cost consecutive runs (``split_counts`` - the partition ``frag.delfi`` and the bench
-    use), so a rank owns whole contigs plus at most two partial ones.  A partial share is answered from a REGION of the
+    appearance and cut into equal-cost consecutive runs (``split_weighted``: the partition ``frag.delfi`` and the bench
+    use, ``split_counts``, with the BASES an interval adds to the span its share must decode as its cost - a region
+    read decodes every row between its first and last interval - plus the fixed cost of entering a contig), so a rank
+    owns whole contigs plus at most two partial ones.  A partial share is answered from a REGION of the
     contig (``unit_key``: the rows / records between its first interval's start and its last one's stop, read through
     the index), a whole one from the contig.  Results travel as fixed-width integer rows in ONE all-gather
     (``gather_unit_rows``) and come back in the input order of the intervals - on every rank."""
@@ -302,7 +335,12 @@ class IntervalPlan:
         # a contig's intervals in start order (stable): consecutive shares are then compact regions of the contig
         self.order = {c: np.asarray(idx, dtype=np.int64)[np.argsort(starts[idx], kind="stable")] for c, idx in by.items()}
         self.starts, self.stops = starts, stops
-        self.units = split_counts({c: len(idx) for c, idx in self.order.items()}, self.world)
+        cost = {}
+        for c, idx in self.order.items():  # an interval's cost: the bases up to the next one's start (the last: its own)
+            st = starts[idx]
+            nxt = np.concatenate((st[1:], [max(int(stops[idx].max()), int(st[-1]) + 1)]))
+            cost[c] = np.maximum(nxt - st, 1)
+        self.units = split_weighted(cost, self.world, shard_overhead_bases())
         self.mine = [(c, i0, i1) for r, c, i0, i1 in self.units if r == self.rank]
 
     def intervals(self, unit) -> np.ndarray:

@@ -49,33 +49,47 @@ sharding.finalize()
 WORKER2 = r"""
 import os, pickle, sys, warnings
 sys.path.insert(0, {root!r})
+os.environ["FTK_SHARD_OVERHEAD_BASES"] = "0"  # contigs under 1 Mb: the shares are cut by the intervals' span alone
+os.environ["FTK_UNIT_BASES"] = "20000"        # ... and the per-base commands' units hold a few intervals each
 from finaletoolkit_amd import frag, sharding, source
 rank, world = sharding.init_from_env()
 d = {tmp!r}
 o = d + f"/w{{world}}_"
+trail = {{}}  # command -> (contigs this rank decoded WHOLE for it, regions it read through the index)
+def ran(name, call):
+    source.close_all()            # every command starts with nothing resident
+    del source.REGION_READS[:]
+    out = call()
+    trail[name] = (sorted(k.split(":", 1)[1] for k in source.get_engine().contigs if "@" not in k),
+                   [tuple(r[1:]) for r in source.REGION_READS])
+    return out
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
-    frag.multi_wps(d + "/g.frag.gz", d + "/sites.bed", d + "/cs.genome", o + "wps.bw", interval_size=3000)
-    loaded = sorted(k.split(":", 1)[1] for k in source.get_engine().contigs)  # what THIS command made the rank decode
-    frag.multi_wps(d + "/g.frag.gz", d + "/sites.bed", d + "/cs.genome", o + "wps.bed.gz", interval_size=800,
-                   window_size=61, min_length=100, max_length=200)
-    frag.multi_cleavage_profile(d + "/g.frag.gz", d + "/clv.bed", d + "/cs.genome", left=20, right=30,
-                                output_file=o + "clv.bw")
-    frag.multi_cleavage_profile(d + "/g.frag.gz", d + "/clv_unsorted.bed", d + "/cs.genome", output_file=o + "clv2.bw")
-    frag.multi_cleavage_profile(d + "/g.frag.gz", d + "/clv.bed", d + "/cs.genome", min_length=100, max_length=250,
-                                output_file=o + "clv.bed.gz")
-    fli = frag.frag_length_intervals(d + "/g.frag.gz", d + "/iv.bed", o + "fli.bed", min_length=50, max_length=400)
-    flb = frag.frag_length_bins(d + "/g.frag.gz", output_file=o + "flb.tsv", bin_size=5, summary_stats=True,
-                                short_fraction=150)
-    flb1 = frag.frag_length_bins(d + "/g.frag.gz", contig="c3", start=1000, stop=300000, output_file=o + "flb1.tsv")
-    em = frag.end_motifs(d + "/g.frag.gz", d + "/ref.fa", k=3, output_file=o + "em.tsv")
-    iem = frag.interval_end_motifs(d + "/g.frag.gz", d + "/ref.fa", d + "/iv.bed", k=2, both_strands=False,
-                                   output_file=o + "iem.tsv")
-    ibm = frag.interval_breakpoint_motifs(d + "/g.frag.gz", d + "/ref.fa", d + "/iv.bed", k=4, output_file=o + "ibm.csv")
-    one = frag.wps(d + "/g.frag.gz", "c2", 5000, 9000, 700000, output_file=o + "one.wig")
+    ran("wps.bw", lambda: frag.multi_wps(d + "/g.frag.gz", d + "/sites.bed", d + "/cs.genome", o + "wps.bw", interval_size=3000))
+    ran("wps.bed.gz", lambda: frag.multi_wps(d + "/g.frag.gz", d + "/sites.bed", d + "/cs.genome", o + "wps.bed.gz",
+                                             interval_size=800, window_size=61, min_length=100, max_length=200))
+    ran("clv.bw", lambda: frag.multi_cleavage_profile(d + "/g.frag.gz", d + "/clv.bed", d + "/cs.genome", left=20, right=30,
+                                                      output_file=o + "clv.bw"))
+    ran("clv2.bw", lambda: frag.multi_cleavage_profile(d + "/g.frag.gz", d + "/clv_unsorted.bed", d + "/cs.genome",
+                                                       output_file=o + "clv2.bw"))
+    ran("clv.bed.gz", lambda: frag.multi_cleavage_profile(d + "/g.frag.gz", d + "/clv.bed", d + "/cs.genome", min_length=100,
+                                                          max_length=250, output_file=o + "clv.bed.gz"))
+    fli = ran("fli", lambda: frag.frag_length_intervals(d + "/g.frag.gz", d + "/iv.bed", o + "fli.bed", min_length=50,
+                                                        max_length=400))
+    flb = ran("flb", lambda: frag.frag_length_bins(d + "/g.frag.gz", output_file=o + "flb.tsv", bin_size=5,
+                                                   summary_stats=True, short_fraction=150))
+    flb1 = ran("flb1", lambda: frag.frag_length_bins(d + "/g.frag.gz", contig="c3", start=1000, stop=300000,
+                                                     output_file=o + "flb1.tsv"))
+    em = ran("em", lambda: frag.end_motifs(d + "/g.frag.gz", d + "/ref.fa", k=3, output_file=o + "em.tsv"))
+    iem = ran("iem", lambda: frag.interval_end_motifs(d + "/g.frag.gz", d + "/ref.fa", d + "/iv.bed", k=2, both_strands=False,
+                                                      output_file=o + "iem.tsv"))
+    ibm = ran("ibm", lambda: frag.interval_breakpoint_motifs(d + "/g.frag.gz", d + "/ref.fa", d + "/iv.bed", k=4,
+                                                             output_file=o + "ibm.csv"))
+    cov = ran("cov", lambda: frag.coverage(d + "/g.frag.gz", d + "/iv.bed", o + "cov.bed", intersect_policy="any"))
+    one = ran("one", lambda: frag.wps(d + "/g.frag.gz", "c2", 5000, 9000, 700000, output_file=o + "one.wig"))
 pickle.dump(dict(rank=rank, world=world, fli=[tuple(x) for x in fli], flb=(list(map(int, flb[0])), list(flb[1])),
                  flb1=(list(map(int, flb1[0])), list(flb1[1])), em=list(em), iem=[(iv, dict(f)) for iv, f in iem],
-                 ibm=[(iv, dict(f)) for iv, f in ibm], one=one.tolist(), loaded=loaded),
+                 ibm=[(iv, dict(f)) for iv, f in ibm], one=one.tolist(), cov=[tuple(c) for c in cov], trail=trail),
             open(d + f"/out2_w{{world}}_r{{rank}}.pkl", "wb"))
 sharding.finalize()
 """
@@ -187,10 +201,11 @@ def test_two_ranks_write_the_single_process_files_for_every_sharded_command(data
     one = _run_world(d, 1, "worker2.py", "out2")[0]
     two = _run_world(d, 2, "worker2.py", "out2")
     for r in two:
-        for key in ("fli", "flb", "flb1", "em", "iem", "ibm", "one"):
+        for key in ("fli", "flb", "flb1", "em", "iem", "ibm", "one", "cov"):
             assert r[key] == one[key], key
     assert len(one["fli"]) == 200 and sum(x[9] for x in one["fli"] if x[9] > 0) > 1000
-    for name in ("wps.bw", "clv.bw", "clv2.bw", "fli.bed", "flb.tsv", "flb1.tsv", "em.tsv", "iem.tsv", "ibm.csv", "one.wig"):
+    for name in ("wps.bw", "clv.bw", "clv2.bw", "fli.bed", "flb.tsv", "flb1.tsv", "em.tsv", "iem.tsv", "ibm.csv", "one.wig",
+                 "cov.bed"):
         a, b = open(d / f"w1_{name}", "rb").read(), open(d / f"w2_{name}", "rb").read()
         assert a == b and len(a) > 100, name
     for name in ("wps.bed.gz", "clv.bed.gz"):
@@ -202,9 +217,19 @@ def test_two_ranks_write_the_single_process_files_for_every_sharded_command(data
     with BigWigFile(d / "w2_clv2.bw") as bw:
         assert bw.intervals("c4", 0, 350_000) is not None and bw.intervals("c5", 0, 130_000) is not None
         assert bw.intervals("c2", 0, 700_000) is None  # c2 came back after c4: skipped, as pyBigWig's addEntries raises
-    # each contig's fragments were decoded by exactly one rank
-    a, b = set(two[0]["loaded"]), set(two[1]["loaded"])
-    assert a and b and not (a & b) and a | b == {"c1", "c2", "c3", "c4", "c5"}  # (recorded after the first command)
+    # ONE partition for every sharded command (sharding.IntervalPlan / frag/_runs.py: equal-cost consecutive shares):
+    # a contig is decoded whole by at most one rank, the contig the cut falls into is read by BOTH ranks as a region
+    # through the index - each its own part - and a single process never reads a region
+    everything = {"c1", "c2", "c3", "c4", "c5"}
+    for cmd in ("wps.bw", "wps.bed.gz", "clv.bw", "clv.bed.gz", "fli", "iem", "ibm", "cov"):  # (em: one 1 Mb window per contig here)
+        assert one["trail"][cmd][1] == [], cmd
+        (w0, r0), (w1, r1) = two[0]["trail"][cmd], two[1]["trail"][cmd]
+        assert not (set(w0) & set(w1)), (cmd, w0, w1)
+        assert len(r0) == 1 and len(r1) == 1 and r0[0][0] == r1[0][0] and r0[0][0] not in set(w0) | set(w1), (cmd, r0, r1)
+        assert r0[0][1:] != r1[0][1:] and set(w0) | set(w1) | {r0[0][0]} == everything, (cmd, w0, w1, r0, r1)
+    # whole-file commands (every fragment counts once) stay dealt by whole contigs: no region, nothing decoded twice
+    (w0, r0), (w1, r1) = two[0]["trail"]["flb"], two[1]["trail"]["flb"]
+    assert r0 == [] and r1 == [] and not (set(w0) & set(w1)) and set(w0) | set(w1) == everything
 
 
 def test_cli_refuses_gpus_on_commands_that_do_not_shard(tmp_path):

@@ -27,6 +27,7 @@ for src in sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")):
 names = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows), capture_output=True, text=True).stdout.splitlines()
 print("%-18s %-112s %5s %5s %4s %7s %7s" % ("file", "kernel", "VGPR", "SGPR", "occ", "LDS B", "scratch"))
 for r, n in zip(rows, names):
+    n = n.replace("(anonymous namespace)::", "")
     n = re.sub(r"\(.*", "", n).replace("ftk::", "")
     print("%-18s %-112s %5s %5s %4s %7s %7s" % (r["file"], n[:112], r.get("VGPRs", "?"), r.get("TotalSGPRs", "?"),
                                                  r.get("Occupancy [waves/SIMD]", "?"), r.get("LDS Size [bytes/block]", "?"),
