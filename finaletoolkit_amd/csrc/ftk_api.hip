@@ -1888,7 +1888,10 @@ int ftk_bgzf_inflate_device(ftk_ctx* ctx, const uint8_t* file_bytes, int64_t n, 
     HIPCHK(ctx, hipMemcpyAsync(d_comp, file_bytes, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(d_st, 0, sizeof(*d_st), ctx->stream));
-    ftk::inflate_launch(ctx->stream, d_comp, d_tab, (int)tab.size(), d_out, d_st, d_crc);
+    // (FTK_INFLATE_VECTOR_MATCHES=1: the launch shape BAM streams use - a window's matches resolved on the lanes side
+    // by side; read per call so that the tests can hold both shapes against zlib)
+    const char* vm = getenv("FTK_INFLATE_VECTOR_MATCHES");
+    ftk::inflate_launch(ctx->stream, d_comp, d_tab, (int)tab.size(), d_out, d_st, d_crc, vm && atoi(vm) != 0);
     HIPCHK(ctx, hipGetLastError());
     ftk::InflateStatus st{};
     std::vector<uint32_t> got_crc(tab.size());

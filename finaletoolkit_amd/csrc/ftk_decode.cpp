@@ -3451,7 +3451,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
                   (pc.blocks.empty() || hipMemcpyAsync(S.d_tab, S.h_tab, pc.blocks.size() * sizeof(ftk::InflateBlock),
                                                        hipMemcpyHostToDevice, pstream) == hipSuccess);
         if (ok) {
-            ftk::inflate_launch(pstream, S.d_comp, S.d_tab, (int)pc.blocks.size(), S.d_text, S.d_ist, S.d_crc);
+            ftk::inflate_launch(pstream, S.d_comp, S.d_tab, (int)pc.blocks.size(), S.d_text, S.d_ist, S.d_crc, /*vector_matches=*/true);
             ok = hipGetLastError() == hipSuccess &&
                  (pc.total == 0 || hipMemcpyAsync(S.h_text + kRoom, S.d_text + kRoom, pc.total, hipMemcpyDeviceToHost, pstream) == hipSuccess) &&
                  hipMemcpyAsync(S.h_ist, S.d_ist, sizeof(ftk::InflateStatus), hipMemcpyDeviceToHost, pstream) == hipSuccess &&
@@ -3907,7 +3907,7 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
                                                        hipMemcpyHostToDevice, st) == hipSuccess);
         if (direct) buf_in_flight = up_ev;  // (fill() parks the buffer behind it)
         if (ok) {
-            ftk::inflate_launch(st, S.d_comp, S.d_tab, (int)pc.blocks.size(), S.d_text, S.d_ist, S.d_crc);
+            ftk::inflate_launch(st, S.d_comp, S.d_tab, (int)pc.blocks.size(), S.d_text, S.d_ist, S.d_crc, /*vector_matches=*/true);
             ok = hipGetLastError() == hipSuccess && hipEventRecord(S.front, st) == hipSuccess;
         }
         if (!ok) {

@@ -53,11 +53,13 @@ constexpr int kGranShift = kRing >= 8192 ? 11 : 10, kGran = 1 << kGranShift;  //
 #ifndef FTK_INFLATE_DIST_ROOT
 #define FTK_INFLATE_DIST_ROOT 9
 #endif
-// A window's literal and match bytes resolved by the lanes side by side (see the symbol loop); 0 = the serial match loop
-// of round 3 for every window (tools/inflate_variants.sh compares the two builds)
-#ifndef FTK_INFLATE_VECMATCH
-#define FTK_INFLATE_VECMATCH 1
-#endif
+// A window's literal and match bytes resolved by the lanes side by side (see the symbol loop): a property of the LAUNCH
+// (template parameter VEC of the kernel; inflate_launch's vector_matches).  Measured on chip-filling launches
+// (tools/inflate_variants.sh, round 4): BAM records 10.17 -> 9.70 ms per 590 MB (-5 %: mostly literals, the few matches -
+// read names, flags - far apart), fragment rows 7.52 -> 7.62 ms per 650 MB and 3.39 -> 3.59 ms on a launch of fewer blocks
+// than the chip holds (+1 % / +6 %: three short matches per window whose serial copies cost no more than the
+// byte-to-symbol expansion) - so BAM streams ask for it and text streams do not.  FTK_INFLATE_VECMATCH=0/1 forces it
+// off / on for every launch (A/B builds).
 constexpr int kLitRoot = FTK_INFLATE_ROOT, kDistRoot = FTK_INFLATE_DIST_ROOT, kPreRoot = 7;
 constexpr int kFarDist = kRing - 258 - 64;    // matches further back than this read from HBM
 static_assert((kRing & (kRing - 1)) == 0 && kGran <= kRing / 2, "the write-behind granule must be at most half the ring");
@@ -307,6 +309,7 @@ __device__ unsigned long long g_block_ticks[2 * 65536];
 #else
 #define FTK_INFLATE_OCC
 #endif
+template <bool VEC>
 __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const uint8_t* __restrict__ comp,
                                                           const InflateBlock* __restrict__ tab, int n_blocks,
                                                           uint8_t* __restrict__ out, InflateStatus* __restrict__ status) {
@@ -536,8 +539,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         T = (uint32_t)__builtin_amdgcn_readlane(inc, 63);
                     }
                     if (T) {
-#if FTK_INFLATE_VECMATCH
-                        // ---- the window's bytes resolved side by side (round 4).  The serial match loop below costs one
+                        // ---- the window's bytes resolved side by side (round 4; launches that ask for it: VEC).  The serial match loop below costs one
                         // LDS read -> write round trip per match, one after the other (a third of a window's cycles, DESIGN
                         // 3.5).  When the window's output fits the wave (T <= 63 bytes) and every match reads the ring,
                         // lane j becomes output byte j instead: the chain's lanes push their number to the lane of their
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         // THIS WINDOW (in fragment rows the END column's digits copy the START column's, a few bytes back).
                         // The last kind is resolved by pointer jumping over the lanes (ds_bpermute: no memory), a round
                         // per doubling of the dependency depth - two rounds for rows - and one store writes the window.
-                        if (T <= 63u && __ballot(mark == 3u) != 0ull && __ballot(mark == 3u && mdist > (unsigned)kFarDist) == 0ull) {
+                        if (VEC && T <= 63u && __ballot(mark == 3u) != 0ull && __ballot(mark == 3u && mdist > (unsigned)kFarDist) == 0ull) {
                             int own = __builtin_amdgcn_ds_permute((mark ? (int)off : 63) << 2, mark ? lane + 1 : 0);
                             own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x111, 0xf, 0xf, false));
                             own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x112, 0xf, 0xf, false));
@@ -578,7 +580,6 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                             PROF(5, mark);
                             continue;
                         }
-#endif
                         if (mark == 1u || mark == 2u) {
                             const uint32_t at = A + off;
                             L.ring[at & kRingMask] = (uint8_t)(E >> 8);
@@ -1006,9 +1007,15 @@ extern "C" int ftk_debug_inflate_ticks(unsigned long long* out, int n_blocks) {
 #endif
 
 void inflate_launch(hipStream_t s, const uint8_t* d_comp, const InflateBlock* d_tab, int n_blocks, uint8_t* d_out,
-                    InflateStatus* d_status, uint32_t* d_crc) {
+                    InflateStatus* d_status, uint32_t* d_crc, bool vector_matches) {
     if (n_blocks <= 0) return;
-    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3(n_blocks), dim3(64), 0, s, d_comp, d_tab, n_blocks, d_out, d_status);
+#ifdef FTK_INFLATE_VECMATCH
+    vector_matches = FTK_INFLATE_VECMATCH != 0;
+#endif
+    if (vector_matches)
+        hipLaunchKernelGGL(bgzf_inflate_kernel<true>, dim3(n_blocks), dim3(64), 0, s, d_comp, d_tab, n_blocks, d_out, d_status);
+    else
+        hipLaunchKernelGGL(bgzf_inflate_kernel<false>, dim3(n_blocks), dim3(64), 0, s, d_comp, d_tab, n_blocks, d_out, d_status);
     if (d_crc) {
         // (workgroups of four waves, a block per wave)
         const int groups = std::min((n_blocks + kCrcWaves - 1) / kCrcWaves, 1 << 20);

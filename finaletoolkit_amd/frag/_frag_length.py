@@ -169,9 +169,14 @@ def frag_length_bins(input_file, contig: str | None = None, start: int | None = 
     _check_region(contig, start, stop)
     src = open_source(input_file)
     eng = get_engine()
-    names, whole = _region_contigs(src, contig)
-    # the whole file: contigs dealt to the ranks of the process group (one per GPU), the sparse length -> count
-    # maps meet in one all-gather of small objects; a single contig / region is counted by every rank alike
+    if contig is None and sharding.rank_world()[1] > 1:
+        # (several ranks: a rank decodes only the contigs it is dealt below - not the whole file, as ``load_all`` would)
+        names, whole = [c for c in src.contigs if src.has(c)], True
+    else:
+        names, whole = _region_contigs(src, contig)
+    # the whole file: every fragment counts once, so the contigs are dealt WHOLE to the ranks of the process group (LPT
+    # on their lengths; a region read hands a fragment to every rank whose region it overlaps); the sparse length ->
+    # count maps meet in one all-gather of small objects; a single contig / region is counted by every rank alike
     rank, world, owner = sharding.contig_owner({c: float(src.lengths.get(c) or 1) for c in names})
     shard = world > 1 and len(names) > 1
     dist: dict[int, int] = {}

@@ -25,7 +25,7 @@ def _member(data: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, extra=b"") -
     return head + payload + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data))
 
 
-def _inflate(engine, image: bytes):
+def _inflate_once(engine, image: bytes):
     lib = engine.lib
     n_out = C.c_int64()
     buf = np.zeros(1, np.uint8)
@@ -34,6 +34,26 @@ def _inflate(engine, image: bytes):
         buf = np.zeros(n_out.value, np.uint8)
         rc = lib.ftk_bgzf_inflate_device(engine.ctx, image, len(image), L.ptr(buf), len(buf), C.byref(n_out))
     return rc, buf[:n_out.value].tobytes()
+
+
+def _inflate(engine, image: bytes):
+    """Both launch shapes of the kernel on the same image - a window's matches copied one after the other (text streams)
+    and resolved on the lanes side by side (BAM streams; ``FTK_INFLATE_VECTOR_MATCHES=1``) - must agree; the callers
+    then hold the result against zlib."""
+    import os
+    keep = os.environ.get("FTK_INFLATE_VECTOR_MATCHES")
+    try:
+        os.environ["FTK_INFLATE_VECTOR_MATCHES"] = "0"
+        serial = _inflate_once(engine, image)
+        os.environ["FTK_INFLATE_VECTOR_MATCHES"] = "1"
+        vector = _inflate_once(engine, image)
+    finally:
+        if keep is None:
+            os.environ.pop("FTK_INFLATE_VECTOR_MATCHES", None)
+        else:
+            os.environ["FTK_INFLATE_VECTOR_MATCHES"] = keep
+    assert serial[0] == vector[0] and (serial[0] != L.FTK_OK or serial[1] == vector[1])
+    return vector
 
 
 def _rows(n, seed):
