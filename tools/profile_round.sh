@@ -14,7 +14,9 @@ for c in SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_I
   KBENCH=feat rocprofv3 --pmc $c --output-format csv -d $OUT/sq_$c -- python3 $GRAFT_REPO_ROOT/tools/kbench.py 243199373 3 > /dev/null 2> $OUT/sq_$c.err
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/e2e_stats -- python3 $GRAFT_REPO_ROOT/tools/e2e_legs.py 3 > $OUT/e2e_under_profiler.json 2> $OUT/e2e_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/genome_stats -- python3 $GRAFT_REPO_ROOT/tools/e2e_genome_bench.py all 30 12 delfi > $OUT/genome_leg_under_profiler.json 2> /dev/null
 cd $GRAFT_REPO_ROOT
+python tools/prof_summary.py stats $OUT/genome_stats > $OUT/genome_leg_kernel_stats.txt
 python tools/prof_summary.py stats $OUT/stats > $OUT/kernel_stats.txt
 python tools/prof_summary.py pmc $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_hbm.txt
 python tools/prof_summary.py pmc $OUT/sq_* > $OUT/pmc_sq_feature_kernels.txt
@@ -24,5 +26,5 @@ KBENCH=feat python tools/kbench.py > $OUT/kbench_feat_fast.txt 2>&1
 FTK_BENCH_MERGED=0 $B --no-cpu-baseline --no-end-to-end > $OUT/bench_two_launches.json 2> /dev/null
 FTK_FEAT_FAST=0 KBENCH=feat python tools/kbench.py > $OUT/kbench_feat_general.txt 2>&1
 FTK_BENCH_DETAIL=1 $B --no-cpu-baseline --no-end-to-end > $OUT/bench_detail.json 2> $OUT/bench_detail.err
-rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/sq_SQ_* $OUT/e2e_stats
+rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/sq_SQ_* $OUT/e2e_stats $OUT/genome_stats
 ls $OUT
