@@ -848,7 +848,7 @@ def end_to_end(torch, reps: int = 3, cpu=None):
             t_write = time.perf_counter() - t0
             n_win_total = sum(-(-synth.B37_SIZES[c] // WINDOW) for c in names)
             runs = []
-            for _ in range(3):
+            for _ in range(5):
                 source.close_all()
                 eng = source.get_engine()
                 t0 = time.perf_counter()
@@ -1010,7 +1010,7 @@ def frag_delfi_api_leg(torch, tmp, genome_file, threads, n_win_total, rows_total
     out_tsv = os.path.join(tmp, "delfi_5mb.tsv")
     runs, df = [], None
     import warnings
-    for _ in range(3):
+    for _ in range(5):
         source.close_all()
         ta = time.perf_counter()
         with warnings.catch_warnings():

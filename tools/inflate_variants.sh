@@ -7,6 +7,8 @@ for v in "$@"; do
   export FTK_LIB=$R/finaletoolkit_amd/libftk_$v.so
   for t in "inflate_bench 21" "inflate_bench 1" "bam_inflate_probe"; do
     set -- $t
+    # (the launch shape each kind of stream uses: BAM records with a window's matches resolved side by side)
+    if [ "$1" = "bam_inflate_probe" ]; then export FTK_INFLATE_VECTOR_MATCHES=1; else export FTK_INFLATE_VECTOR_MATCHES=0; fi
     rm -rf $R/gpurun_out/iv
     rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/iv -- python3 $R/tools/$1.py $2 > $R/gpurun_out/iv.log 2>&1
     python3 - "$R/gpurun_out/iv" "$v $t" <<'PY'
