@@ -1860,6 +1860,8 @@ std::string index_path_of(const std::string& path, bool bam) {
 struct ftk_fragstream {
     std::string path, only;
     bool has_only = false, bam = false, bed6 = false;
+    // compressed bytes per piece of THIS stream: kStreamPiece, doubled for a large BAM parsed on the device (run_guarded)
+    size_t piece_bytes = kStreamPiece;
     int n_threads = 1;
     size_t max_queued = 2;
     FILE* fp = nullptr;
@@ -1961,12 +1963,12 @@ struct ftk_fragstream {
     bool range_limited = false;    // the last read_piece() came back short because of read_end, not the file's end
     // One piece of the file -> dst; returns the bytes read (short at the end of the file / of the range).
     size_t read_piece(uint8_t* dst) {
-        size_t want = kStreamPiece;
+        size_t want = piece_bytes;
         range_limited = false;
         if (read_end >= 0) {
             const long long pos = ftell(fp);
-            want = pos >= read_end ? 0 : (size_t)std::min<long long>((long long)kStreamPiece, read_end - pos);
-            range_limited = want < kStreamPiece;
+            want = pos >= read_end ? 0 : (size_t)std::min<long long>((long long)piece_bytes, read_end - pos);
+            range_limited = want < piece_bytes;
         }
         size_t got = 0;
         bool done = false;
@@ -2008,7 +2010,7 @@ struct ftk_fragstream {
         if (got == want && want) {
             // ask the kernel for the piece after this one (a hint only; failure is ignored)
             const long long pos = ftell(fp);
-            if (pos >= 0) (void)posix_fadvise(fileno(fp), (off_t)pos, (off_t)kStreamPiece, POSIX_FADV_WILLNEED);
+            if (pos >= 0) (void)posix_fadvise(fileno(fp), (off_t)pos, (off_t)piece_bytes, POSIX_FADV_WILLNEED);
         }
         return got;
     }
@@ -2021,7 +2023,7 @@ struct ftk_fragstream {
     std::future<size_t> ahead_got;
     bool ahead_ok = true;  // false while the BAM header is probed before an index seek (the read would be thrown away)
     void start_ahead() {
-        if (!ahead_ok || !ahead.reserve(kHead + kStreamPiece)) return;
+        if (!ahead_ok || !ahead.reserve(kHead + piece_bytes)) return;
         ahead.head = 0;
         ahead_got = std::async(std::launch::async, [this] { return read_piece(ahead.p + kHead); });
     }
@@ -2080,7 +2082,7 @@ struct ftk_fragstream {
                 if (carry) memcpy(ahead.p + kHead - carry, buf.data() + carry_off, carry);
                 ahead.head = kHead - carry;
             } else {  // (not with BGZF blocks, which are at most 64 KB)
-                if (!ahead.reserve(carry + kStreamPiece)) return carry;
+                if (!ahead.reserve(carry + piece_bytes)) return carry;
                 memmove(ahead.p + carry, ahead.p + kHead, got);
                 memcpy(ahead.p, buf.data() + carry_off, carry);
                 ahead.head = 0;
@@ -2102,10 +2104,10 @@ struct ftk_fragstream {
             }
         } else {
             if (carry && carry_off) memmove(buf.data(), buf.data() + carry_off, carry);
-            if (!buf.reserve(buf.head + carry + kStreamPiece)) return carry;
+            if (!buf.reserve(buf.head + carry + piece_bytes)) return carry;
             got = read_piece(buf.data() + carry);
         }
-        if (got == kStreamPiece) start_ahead();
+        if (got == piece_bytes) start_ahead();
         return carry + got;
     }
     // seek to a contig's rows; false = index unusable (caller scans the whole file)
@@ -2178,7 +2180,18 @@ void ftk_fragstream::run_guarded() {
     {
         static const bool dev_bam = !(getenv("FTK_DEVICE_BAM_PARSE") && atoi(getenv("FTK_DEVICE_BAM_PARSE")) == 0) &&
                                     !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
-        if (bam && inflate_device >= 0 && dev_bam && have_hip_device()) buf.pinned = ahead.pinned = true;  // (see RawBuf)
+        if (bam && inflate_device >= 0 && dev_bam && have_hip_device()) {
+            buf.pinned = ahead.pinned = true;  // (see RawBuf)
+            // A launch of the inflate kernel lasts one block's chain (~4 ms for BAM records) whatever its size, until
+            // the chip's 5 120 wavefront slots are full; a 48 MB piece of BAM is ~1 900 blocks, and the stream keeps
+            // about two such launches side by side: a third of the slots idle.  Pieces of 96 MB: a chr1-sized 60x
+            // BAM 0.266 -> 0.233 s until resident (144 MB: no further gain; text streams, ~3 000 blocks per piece
+            // and three fronts side by side, LOSE 5-10 % with larger pieces - tools/piece_size_ab.sh).  Small files
+            // keep the short pieces (latency to the first contig); FTK_STREAM_PIECE set by hand wins.
+            struct stat sb;
+            if (!getenv("FTK_STREAM_PIECE") && fstat(fileno(fp), &sb) == 0 && (long long)sb.st_size >= (1ll << 30))
+                piece_bytes = 2 * kStreamPiece;
+        }
         // a text stream's GPU pieces go up straight from the read buffer too (FTK_TEXT_DIRECT_UP=0: staged in the buffer
         // sets' own page-locked memory by a copy of the producer's - 0.8 ms per 48 MB piece on 16 threads, and in the
         // way of the host threads' inflate jobs)
@@ -2323,7 +2336,7 @@ bool ftk_fragstream::run_text(RawBuf& buf, size_t n) {
     Contig cur;
     bool have_cur = false;
     std::set<std::string> seen;
-    bool eof = n < kStreamPiece;
+    bool eof = n < piece_bytes;
     for (;;) {
         size_t used = 0, total = 0;
         if (!whole_blocks(buf.data(), n, eof, &blocks, &used, &total)) return fail(FTK_ERR_FORMAT, "corrupt BGZF block");
@@ -2387,7 +2400,7 @@ bool ftk_fragstream::run_text(RawBuf& buf, size_t n) {
         clk.lap(5);
         n = fill(buf, raw_carry);
         clk.lap(0);
-        eof = n - raw_carry < kStreamPiece;
+        eof = n - raw_carry < piece_bytes;
         {
             std::lock_guard<std::mutex> lk(mu);
             if (stop) return false;
@@ -3044,7 +3057,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         }
         return true;
     };
-    bool eof = n < kStreamPiece;
+    bool eof = n < piece_bytes;
     // (region reads) this short read stopped at the linear index's hint, not at the end of the contig's rows: the piece
     // is parsed as one with more behind it, and the rows then say whether to read on
     auto at_soft_end = [&](size_t n_now) {
@@ -3224,7 +3237,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             n = fill(buf, raw_carry_d, buf_in_flight ? used : 0);
             clk.lap(0);
             mark(k, "next piece read");
-            eof = n - raw_carry_d < kStreamPiece;
+            eof = n - raw_carry_d < piece_bytes;
             soft = at_soft_end(n);
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -3302,7 +3315,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         clk.lap(5);
         n = fill(buf, raw_carry);
         clk.lap(0);
-        eof = n - raw_carry < kStreamPiece;
+        eof = n - raw_carry < piece_bytes;
         {
             std::lock_guard<std::mutex> lk(mu);
             if (stop) return false;
@@ -3490,7 +3503,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
     Piece curp;
     std::deque<Piece> ahead;  // pieces behind curp that are already on the device, in file order
     curp.n = n_first;
-    curp.eof = n_first < kStreamPiece;
+    curp.eof = n_first < piece_bytes;
     int n_submitted = 0;
     for (;;) {
         if (!list_blocks(curp)) return false;
@@ -3508,7 +3521,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
                 Piece np;
                 np.n = fill(buf, raw_carry);
                 clk.lap(0);
-                np.eof = np.n - raw_carry < kStreamPiece;
+                np.eof = np.n - raw_carry < piece_bytes;
                 if (!list_blocks(np) || !submit(np, n_submitted++)) return false;
                 ahead.push_back(std::move(np));
             }
@@ -3591,7 +3604,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
                     carry = 0;
                     curp = Piece{};
                     curp.n = fill(buf, 0);
-                    curp.eof = curp.n < kStreamPiece;
+                    curp.eof = curp.n < piece_bytes;
                     pending_skip = first_skip;
                     first_skip = 0;
                     continue;
@@ -3707,7 +3720,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
             Piece np;
             np.n = fill(buf, raw_carry);
             clk.lap(0);
-            np.eof = np.n - raw_carry < kStreamPiece;
+            np.eof = np.n - raw_carry < piece_bytes;
             curp = std::move(np);
         }
         {
@@ -3842,7 +3855,14 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         DevSet& S = sets[slot];
         hipStream_t st = streams[slot];
         if (S.pending) return fail(FTK_ERR_HIP, "buffer ring out of step");
-        if (pc.total + kRoom + 64 >= (size_t(1) << 32)) return fail(FTK_ERR_FORMAT, "BGZF piece too large");
+        if (pc.total + kRoom + 64 >= (size_t(1) << 32)) {
+            if (piece_bytes > kStreamPiece) {  // (a BAM that inflates > 40 x: once more with the standard pieces)
+                piece_bytes = kStreamPiece;
+                want_host_restart = true;
+                return false;
+            }
+            return fail(FTK_ERR_FORMAT, "BGZF piece too large");
+        }
         pc.on_host = host_share > 0 && index > 0 && (index % host_share) == host_share - 1;
         // a GPU piece goes up straight from the (page-locked) read buffer; the host threads work on their own copy of
         // theirs, which they read from the file (page cache) themselves when the piece's file offset is known
@@ -3972,7 +3992,7 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
     unsigned long long last_key = 0;    // the last record settled so far: (reference << 32) | position
     Piece curp;
     curp.n = n_first;
-    curp.eof = n_first < kStreamPiece;
+    curp.eof = n_first < piece_bytes;
     curp.file_off = 0;  // (run_guarded read the first piece from the start of the file)
     int n_submitted = 0;
     if (!list_blocks(curp)) return false;
@@ -3989,7 +4009,7 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
             Piece np;
             np.n = fill(buf, raw_carry, carry_at);
             clk.lap(0);
-            np.eof = np.n - raw_carry < kStreamPiece;
+            np.eof = np.n - raw_carry < piece_bytes;
             np.has_prev = true;
             np.prev_slot = last.slot;
             np.file_off = last.file_off >= 0 ? last.file_off + (long long)last.used : -1;
@@ -4084,7 +4104,7 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
                 const long long seek_pos = ftell(fp);
                 curp = Piece{};
                 curp.n = fill(buf, 0);
-                curp.eof = curp.n < kStreamPiece;
+                curp.eof = curp.n < piece_bytes;
                 curp.file_off = seek_pos;
                 curp.first_off = (uint32_t)first_skip;
                 first_skip = 0;
