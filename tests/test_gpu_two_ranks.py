@@ -339,3 +339,99 @@ def test_bench_eight_ranks_share_the_gpu():
     assert all(len(x["regions_read"]) >= 1 for x in per)
     assert sum(x["contigs_decoded"] for x in per) + len({r[0] for x in per for r in x["regions_read"]}) == 8
     assert all(x["decoder_threads"] >= 1 and x["stages_s"]["total"] > 0 for x in per)
+
+
+# ---- the same fan-outs on a BAM (BASELINE config 5's input; reference io/alignment.py:242-268) -------------------------------
+WORKER3 = r"""
+import os, pickle, sys, warnings
+sys.path.insert(0, {root!r})
+os.environ["FTK_SHARD_OVERHEAD_BASES"] = "0"
+os.environ["FTK_UNIT_BASES"] = "20000"
+from finaletoolkit_amd import frag, sharding, source
+rank, world = sharding.init_from_env()
+d = {tmp!r}
+o = d + f"/b{{world}}_"
+trail = {{}}
+def ran(name, call):
+    source.close_all()
+    del source.REGION_READS[:]
+    out = call()
+    trail[name] = (sorted(k.split(":", 1)[1] for k in source.get_engine().contigs if "@" not in k),
+                   [tuple(r[1:]) for r in source.REGION_READS])
+    return out
+bam = d + "/p.bam"
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    df = ran("delfi", lambda: frag.delfi(bam, d + "/cs.genome", d + "/bins.txt", d + "/ref.fa", blacklist_file=d + "/bl.bed",
+                                         gap_file=d + "/gaps.bed", no_gc_correct=True, remove_nocov=False, merge_bins=False,
+                                         output_file=o + "delfi.tsv"))
+    cov = ran("cov", lambda: frag.coverage(bam, d + "/iv.bed", o + "cov.bed", normalize=True, scale_factor=1e6))
+    ran("wps.bw", lambda: frag.multi_wps(bam, d + "/sites.bed", d + "/cs.genome", o + "wps.bw", interval_size=3000))
+    ran("clv.bed.gz", lambda: frag.multi_cleavage_profile(bam, d + "/clv.bed", d + "/cs.genome", left=20, right=30,
+                                                          output_file=o + "clv.bed.gz"))
+    fli = ran("fli", lambda: frag.frag_length_intervals(bam, d + "/iv.bed", o + "fli.bed", min_length=50, max_length=400))
+    iem = ran("iem", lambda: frag.interval_end_motifs(bam, d + "/ref.fa", d + "/iv.bed", k=2, output_file=o + "iem.tsv"))
+pickle.dump(dict(rank=rank, world=world, delfi=df, cov=[tuple(c) for c in cov], fli=[tuple(x) for x in fli],
+                 iem=[(iv, dict(f)) for iv, f in iem], trail=trail), open(d + f"/out3_w{{world}}_r{{rank}}.pkl", "wb"))
+sharding.finalize()
+"""
+
+
+@pytest.fixture(scope="module")
+def bam_dataset(tmp_path_factory):
+    from finaletoolkit_amd import synth
+    d = tmp_path_factory.mktemp("two_ranks_bam")
+    contigs = [("c1", 900_000), ("c2", 700_000), ("c3", 420_000), ("c4", 130_000)]
+    sizes = dict(contigs)
+    # 50 bp reads: a fragment's read1 lies up to 950 bp from its other end - the BAM window rule (read1 must overlap)
+    # and the region reads (every fragment whose read1 overlaps) are both exercised; 16 kb linear index per contig
+    synth.write_paired_bam_contigs(str(d / "p.bam"), contigs, 12.0, 321, read_len=50, step=1 << 18)
+    (d / "cs.genome").write_text("".join(f"{c}\t{n}\n" for c, n in contigs))
+    (d / "bins.txt").write_text("".join(f"{c}\t{a}\t{min(a + 9_999, n)}\n" for c, n in contigs for a in range(0, n, 10_000)))
+    rng = np.random.default_rng(14)
+    seqs = {c: np.frombuffer(b"ACGTNacgt", np.uint8)[rng.integers(0, 9, n)].tobytes().decode() for c, n in contigs}
+    H.write_fasta(d / "ref.fa", seqs)
+    (d / "gaps.bed").write_text("".join(
+        f"{c}\t0\t10000\ttelomere\n{c}\t{n // 2 // 10000 * 10000}\t{n // 2 // 10000 * 10000 + 30000}\tcentromere\n"
+        f"{c}\t{n - 10000}\t{n}\ttelomere\n" for c, n in contigs))
+    (d / "bl.bed").write_text("".join(f"{c}\t{int(a)}\t{int(a) + int(rng.integers(100, 2500))}\n"
+                                      for c, n in contigs for a in rng.integers(0, n - 3000, 20)))
+    iv = [f"{c}\t{int(a)}\t{int(a) + int(rng.integers(1, 5000))}\t{c}_{k}\n" for c, n in contigs
+          for k, a in enumerate(rng.integers(0, n - 5000, 40))]
+    rng.shuffle(iv)
+    (d / "iv.bed").write_text("".join(iv))
+    (d / "sites.bed").write_text("".join(f"{c}\t{int(a)}\t{int(a) + int(rng.integers(1, 1500))}\n" for c, n in contigs
+                                         for a in np.sort(rng.integers(0, n - 2000, 30))))
+    (d / "clv.bed").write_text("".join(f"{c}\t{int(a)}\t{int(a) + int(rng.integers(10, 2500))}\n" for c, n in contigs
+                                       for a in np.sort(rng.integers(0, n - 3000, 25))))
+    (d / "worker3.py").write_text(WORKER3.format(root=ROOT, tmp=str(d)))
+    return d, sizes
+
+
+def test_two_ranks_on_a_bam_equal_one_process(bam_dataset):
+    """BASELINE config 5's input under the rank fan-out: `frag.delfi`, `coverage(normalize=True)`, `multi_wps`,
+    `multi_cleavage_profile`, `frag_length_intervals` and `interval_end_motifs` on a coordinate-sorted paired-end BAM with
+    two ranks on GPU 0 return what one process returns and write byte-identical files; the contig a cut falls into is
+    read by both ranks as a region through the BAI's linear index (every fragment whose READ1 overlaps the region - the
+    reference's window rule for BAM input)."""
+    import gzip
+    d, sizes = bam_dataset
+    one = _run_world(d, 1, "worker3.py", "out3")[0]
+    two = _run_world(d, 2, "worker3.py", "out3")
+    for r in two:
+        assert r["delfi"].equals(one["delfi"])
+        for key in ("cov", "fli", "iem"):
+            assert r[key] == one[key], key
+    assert one["delfi"]["num_frags"].sum() > 10_000 and len(one["cov"]) == 160 and sum(x[9] for x in one["fli"] if x[9] > 0) > 500
+    for name in ("delfi.tsv", "cov.bed", "wps.bw", "fli.bed", "iem.tsv"):
+        a, b = open(d / f"b1_{name}", "rb").read(), open(d / f"b2_{name}", "rb").read()
+        assert a == b and len(a) > 100, name
+    assert open(d / "b1_clv.bed.gz", "rb").read() == open(d / "b2_clv.bed.gz", "rb").read()
+    assert gzip.open(d / "b1_clv.bed.gz").read().count(b"\n") > 10_000
+    everything = set(sizes)
+    for cmd in ("delfi", "wps.bw", "clv.bed.gz", "fli", "iem"):
+        assert one["trail"][cmd][1] == [], cmd
+        (w0, r0), (w1, r1) = two[0]["trail"][cmd], two[1]["trail"][cmd]
+        assert not (set(w0) & set(w1)), (cmd, w0, w1)
+        assert len(r0) == 1 and len(r1) == 1 and r0[0][0] == r1[0][0] and r0[0][0] not in set(w0) | set(w1), (cmd, r0, r1)
+        assert set(w0) | set(w1) | {r0[0][0]} == everything, (cmd, w0, w1, r0, r1)
