@@ -547,10 +547,10 @@ class EarlyContigs:
 
     def _run(self):
         try:
-            with warnings.catch_warnings(record=True) as caught:  # (warnings belong to the caller's thread)
-                warnings.simplefilter("always")
-                self._first = next(self._gen)
-            self._warned = caught
+            # (a BED6 warning of the first rows is raised from this thread: the warnings module's filters are
+            # process-wide, so it reaches the caller's `catch_warnings` / `pytest.warns` all the same - and touching
+            # them from here would race with the caller's own `catch_warnings` blocks)
+            self._first = next(self._gen)
         except StopIteration:
             self._end = True
         except BaseException as e:  # noqa: BLE001 - re-raised by the iterator
@@ -558,8 +558,6 @@ class EarlyContigs:
 
     def __iter__(self):
         self._thread.join()
-        for w in getattr(self, "_warned", []):
-            warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
         if self._err is not None:
             raise self._err
         if self._end:

@@ -192,7 +192,7 @@ def test_config5_bam_60x_stream_all_features(engine, tmp_path):
         assert np.array_equal(eng.wps(key, a, a + 5000, size, 120, 120, 180, 30),
                               O.c_wps(fr, a, a + 5000, size, 120, 120, 180, 30)), a
     a = 7_000_000
-    assert np.array_equal(eng.wps(key, a, a + 1_500_000, size), O.c_wps(fr, a, a + 1_500_000, size))
+    assert np.array_equal(eng.wps(key, a, a + 200_000, size), O.c_wps(fr, a, a + 200_000, size))  # (the oracle is quadratic in the interval: 1.5 Mb took 200 s of the suite)
     # ... and the whole contig (24 M bases in one launch; every read1 overlaps the contig-wide fetch window)
     # against the closed form: a passing fragment takes 1 from [fs-59, fs+60] and [fe-59, fe+60] and gives 1 to
     # the bases between
