@@ -31,11 +31,14 @@ __device__ __forceinline__ int wave_reduce_add(int v) {
 // ---------------------------------------------------------------------------
 // load-time kernels
 // ---------------------------------------------------------------------------
-// Validation summary of a freshly loaded contig (sortedness, length / coordinate extremes).  256 blocks of
-// 1024 threads, reduced in the wave and then in the block, ONE set of five atomics per block: device-scope
-// atomics on one cache line retire at ~9 ns each, and with a set per wave of 2048 x 256 threads (41 k sets)
-// the kernel took 380 us whatever the contig's size - half the GPU time of a small end-to-end run.
-constexpr int kStatsThreads = 1024;
+// Validation summary of a freshly loaded contig (sortedness, length / coordinate extremes).  Reduced in the wave and
+// then in the block, ONE set of five atomics per block: device-scope atomics on one cache line retire at ~9 ns each,
+// and with a set per wave of 2048 x 256 threads (41 k sets) the kernel took 380 us whatever the contig's size - half
+// the GPU time of a small end-to-end run.  Blocks of 256 threads (round 4; 1024 before): a contig is loaded while the
+// decoder's inflate waves hold five of a SIMD's wave slots and 410 of its 512 VGPRs on every CU - a 1 024-thread block
+// (four waves per SIMD at 68 VGPRs) could only start where inflate waves had retired and the kernel took 1.1-1.4 ms
+// beside them against 22 us alone (profiles/r4_a_genome_leg_kernel_stats.txt); one wave per SIMD fits at once.
+constexpr int kStatsThreads = 256;
 __global__ __launch_bounds__(kStatsThreads) void stats_kernel(const int32_t* start, const int32_t* end, int n, FragStats* st) {
     __shared__ int red[5][kStatsThreads / 64];
     int unsorted = 0, max_len = INT32_MIN, min_len = INT32_MAX, max_end = INT32_MIN, min_start = INT32_MAX;
@@ -1625,7 +1628,7 @@ void launch_add_i64(hipStream_t s, const int64_t* a, const int64_t* b, int64_t* 
 }
 
 void launch_stats(hipStream_t s, const int32_t* start, const int32_t* end, int n, FragStats* st) {
-    int blocks = min(256, max(1, (n + kStatsThreads - 1) / kStatsThreads));
+    int blocks = min(1024, max(1, (n + kStatsThreads - 1) / kStatsThreads));
     hipLaunchKernelGGL(stats_kernel, dim3(blocks), dim3(kStatsThreads), 0, s, start, end, n, st);
 }
 

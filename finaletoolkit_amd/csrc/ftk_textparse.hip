@@ -189,6 +189,12 @@ __device__ __forceinline__ uint32_t line_start_before(const Text& t, uint32_t fr
 // front of the halo is read from HBM instead.  The total goes to sum->n_lines (last block); a piece with more lines
 // than the outputs hold is reported (overflow) and its rows beyond them are not written.
 constexpr int kHalo = 256;
+// Line ends a block keeps in LDS.  A plain row is at least 10 bytes ("1\t1\t2\t0\t+\n"), so a 4 KB block of plain rows
+// holds at most 409; a block with more line ends than this holds rows the device does not parse anyway, and says so
+// (overflow: the host's field-rule parser takes the piece).  The cap is what keeps the kernel at 5.4 KB of LDS per
+// block: the inflate kernel's waves hold 150 of a CU's 160 KB while they are resident, and a block that needs 12.5 KB
+// (the first version: a slot for every byte of the block) waits for two of them to retire before it can start.
+constexpr int kMaxLinesPerBlock = 512;
 __global__ __launch_bounds__(kT) void lines_rows_kernel(const uint8_t* __restrict__ text_, size_t n_,
                                                          unsigned long long* __restrict__ state, unsigned n_max_blocks,
                                                          size_t max_lines, int bed6, int32_t* __restrict__ o_start,
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(kT) void lines_rows_kernel(const uint8_t* __restric
                                                          int indirect) {
     __shared__ unsigned s_bid, s_base, s_first, s_prev;
     __shared__ unsigned wave_tot[kT / 64];
-    __shared__ unsigned short nlpos[kTextBlockBytes];  // offsets of the block's line ends within the block
+    __shared__ unsigned short nlpos[kMaxLinesPerBlock];  // offsets of the block's line ends within the block
     __shared__ __align__(16) uint8_t s_text[kHalo + kTextBlockBytes];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_bid = atomicAdd(reinterpret_cast<unsigned*>(state + n_max_blocks), 1u);
@@ -234,7 +240,8 @@ __global__ __launch_bounds__(kT) void lines_rows_kernel(const uint8_t* __restric
         while (m) {
             const int j = __ffs(m) - 1;
             m &= m - 1;
-            nlpos[idx++] = (unsigned short)(tid * kB + j);
+            if (idx < (unsigned)kMaxLinesPerBlock) nlpos[idx] = (unsigned short)(tid * kB + j);
+            ++idx;
         }
     }
     if (wv == 0) {  // this block's place among all lines
@@ -269,6 +276,10 @@ __global__ __launch_bounds__(kT) void lines_rows_kernel(const uint8_t* __restric
     }
     __syncthreads();
     if (total == 0) return;
+    if (total > (unsigned)kMaxLinesPerBlock) {  // not a block of plain rows (see kMaxLinesPerBlock)
+        if (tid == 0) sum->overflow = 1;
+        return;
+    }
     // positions below are absolute (in the range); the LDS copy holds [lds_lo, blk_off + 4 KB)
     const uint32_t lds_lo = bid > 0 ? (uint32_t)blk_off - (uint32_t)kHalo : 0u;
     const LdsText LT{s_text, (uint32_t)blk_off - (uint32_t)kHalo};  // (block 0: positions start at kHalo of the copy)

@@ -38,7 +38,7 @@ def main():
         s, e, q, st = (t.cpu().numpy() for t in synth.gen_contig_device(torch, dev, size, n, synth.SEED_BASE + names.index(c)))
         truth[c] = dict(cov=int((q >= 30).sum()), keep=(s, e, q) if c in (contigs[0], contigs[-1]) else None)
         with writers.frag_rows(c, s, e, q, st) as text:
-            writers.bgzf_write(path, text, 1, append=k > 0, write_eof=k == len(contigs) - 1)
+            writers.bgzf_write(path, text, int(os.environ.get("FTK_E2E_LEVEL", "1")), append=k > 0, write_eof=k == len(contigs) - 1)
             text_bytes += text.n
         rows += n
     open(path + ".tbi", "wb").close()
