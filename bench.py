@@ -589,7 +589,7 @@ def leg_floor(leg, file_bytes, inflated_bytes, kind, h2d_gbs, rates):
     """The file legs' own roofline: no run of the leg can be shorter than the compressed bytes crossing PCIe at the
     measured rate, nor than the inflate kernel alone on all of its blocks (the slower of the two; they overlap)."""
     pcie_s = file_bytes / (h2d_gbs * 1e9) if h2d_gbs else None
-    rate = (rates or {}).get("bam_GBps" if kind == "bam" else "text_GBps")
+    rate = (rates or {}).get({"bam": "bam_GBps", "text": "text_GBps"}.get(kind, kind + "_GBps"))
     infl_s = inflated_bytes / (rate * 1e9) if rate else None
     terms = [t for t in (pcie_s, infl_s) if t]
     if not terms:
@@ -828,52 +828,59 @@ def end_to_end(torch, reps: int = 3, cpu=None):
         # BASELINE config 4 itself, file to feature vector: ONE whole-genome 30x frag.gz -> DELFI bins of every contig
         if os.environ.get("FTK_BENCH_GENOME_E2E", "1") != "0":
             from finaletoolkit_amd import writers
-            pg = os.path.join(tmp, "genome.frag.gz")
             names = list(synth.B37_SIZES)
-            t0 = time.perf_counter()
-            truth, truth_all, rows_total, text_bytes = {}, {}, 0, 0
-            for k, c in enumerate(names):
-                size = synth.B37_SIZES[c]
-                n = synth.n_fragments(size, 30.0)
-                s, e, q, st = (t.cpu().numpy() for t in gen_contig_device(torch, dev, size, n, synth.SEED_BASE + k))
-                ln = e - s
-                truth[c] = int(((q >= MAPQ) & (ln >= 100) & (ln <= 220)).sum())
-                truth_all[c] = dict(n=n, cov=int((q >= 30).sum()), delfi=truth[c])
-                with writers.frag_rows(c, s, e, q, st) as text:
-                    writers.bgzf_write(pg, text, 1, append=k > 0, write_eof=k == len(names) - 1)
-                    text_bytes += text.n
-                rows_total += n
-                del s, e, q, st, ln
-            open(pg + ".tbi", "wb").close()  # (the reader streams the whole file; the index only has to exist)
-            t_write = time.perf_counter() - t0
             n_win_total = sum(-(-synth.B37_SIZES[c] // WINDOW) for c in names)
-            runs = []
-            for _ in range(5):
-                source.close_all()
-                eng = source.get_engine()
+
+            def write_genome(path, level):
+                """ONE whole-genome 30x frag.gz at the given DEFLATE level (1: the files of rounds 1-3, fast to write;
+                6: what bgzip / htslib write by default)."""
                 t0 = time.perf_counter()
-                ok, seen, t_wait, tb, src = True, [], 0.0, t0, None
-                for src, c in source.stream_source(pg, threads):
-                    ta = time.perf_counter()
-                    t_wait += ta - tb
+                truth, truth_all, rows_total, text_bytes = {}, {}, 0, 0
+                for k, c in enumerate(names):
                     size = synth.B37_SIZES[c]
-                    ws, we = synth.tiling_windows(size, WINDOW)
-                    sh, lg, nf = eng.delfi_counts(src.key(c), ws, we, MAPQ, None, None, synth_gaps(size))
-                    ok = ok and bool(np.array_equal(sh + lg, nf)) and 0 < int(nf.sum()) <= truth[c]
-                    seen.append(c)
-                    tb = time.perf_counter()
-                total = tb - t0
-                cur = dict(total_s=round(total, 4), windows=n_win_total, windows_per_s=round(n_win_total / total, 1),
-                           fragments_per_s_M=round(rows_total / total / 1e6, 1), text_GB_per_s=round(text_bytes / total / 1e9, 2),
-                           waiting_for_resident_contigs_s=round(t_wait, 4),
-                           decoder_producer_stage_ms=src.decode_stage_ms if src is not None else None,
-                           results_ok=bool(ok and seen == names))
-                runs.append(cur)
-            leg = rep_summary(runs)
-            leg_floor(leg, os.path.getsize(pg), text_bytes, "text", h2d, rates)
-            res["genome_delfi_bins"] = dict(file_GB=round(os.path.getsize(pg) / 1e9, 2), text_GB=round(text_bytes / 1e9, 2),
-                                            fragments=rows_total, file_write_s=round(t_write, 1), decoder_threads=threads,
-                                            **leg)
+                    n = synth.n_fragments(size, 30.0)
+                    s, e, q, st = (t.cpu().numpy() for t in gen_contig_device(torch, dev, size, n, synth.SEED_BASE + k))
+                    ln = e - s
+                    truth[c] = int(((q >= MAPQ) & (ln >= 100) & (ln <= 220)).sum())
+                    truth_all[c] = dict(n=n, cov=int((q >= 30).sum()), delfi=truth[c])
+                    with writers.frag_rows(c, s, e, q, st) as text:
+                        writers.bgzf_write(path, text, level, append=k > 0, write_eof=k == len(names) - 1)
+                        text_bytes += text.n
+                    rows_total += n
+                    del s, e, q, st, ln
+                open(path + ".tbi", "wb").close()  # (the reader streams the whole file; the index only has to exist)
+                return truth, truth_all, rows_total, text_bytes, time.perf_counter() - t0
+
+            def genome_bins(path, truth, rows_total, text_bytes, t_write, rate_key):
+                runs = []
+                for _ in range(5):
+                    source.close_all()
+                    eng = source.get_engine()
+                    t0 = time.perf_counter()
+                    ok, seen, t_wait, tb, src = True, [], 0.0, t0, None
+                    for src, c in source.stream_source(path, threads):
+                        ta = time.perf_counter()
+                        t_wait += ta - tb
+                        size = synth.B37_SIZES[c]
+                        ws, we = synth.tiling_windows(size, WINDOW)
+                        sh, lg, nf = eng.delfi_counts(src.key(c), ws, we, MAPQ, None, None, synth_gaps(size))
+                        ok = ok and bool(np.array_equal(sh + lg, nf)) and 0 < int(nf.sum()) <= truth[c]
+                        seen.append(c)
+                        tb = time.perf_counter()
+                    total = tb - t0
+                    runs.append(dict(total_s=round(total, 4), windows=n_win_total, windows_per_s=round(n_win_total / total, 1),
+                                     fragments_per_s_M=round(rows_total / total / 1e6, 1),
+                                     text_GB_per_s=round(text_bytes / total / 1e9, 2), waiting_for_resident_contigs_s=round(t_wait, 4),
+                                     decoder_producer_stage_ms=src.decode_stage_ms if src is not None else None,
+                                     results_ok=bool(ok and seen == names)))
+                leg = rep_summary(runs)
+                leg_floor(leg, os.path.getsize(path), text_bytes, rate_key, h2d, rates)
+                return dict(file_GB=round(os.path.getsize(path) / 1e9, 2), text_GB=round(text_bytes / 1e9, 2), fragments=rows_total,
+                            file_write_s=round(t_write, 1), decoder_threads=threads, **leg)
+
+            pg = os.path.join(tmp, "genome.frag.gz")
+            truth, truth_all, rows_total, text_bytes, t_write = write_genome(pg, 1)
+            res["genome_delfi_bins"] = genome_bins(pg, truth, rows_total, text_bytes, t_write, "text")
             for c in names:
                 truth_all[c]["text_bytes"] = 0
             truth_all[names[0]]["text_bytes"] = text_bytes  # (the file's text, for the floor of the next leg)
@@ -890,6 +897,14 @@ def end_to_end(torch, reps: int = 3, cpu=None):
                                                              res["genome_delfi_bins"], cpu)
             os.remove(pg)
             os.remove(pg + ".tbi")
+            # the same genome written at DEFLATE level 6 - what bgzip / htslib write by default, i.e. what a user's
+            # frag.gz looks like (the level-1 file above is the one of rounds 1-3: 15 % larger, more and shorter matches)
+            if os.environ.get("FTK_BENCH_LEVEL6", "1") != "0":
+                pg6 = os.path.join(tmp, "genome_l6.frag.gz")
+                truth6, _all6, rows6, text6, t_write6 = write_genome(pg6, 6)
+                res["genome_delfi_bins_level6"] = dict(deflate_level=6, **genome_bins(pg6, truth6, rows6, text6, t_write6, "text_level6"))
+                os.remove(pg6)
+                os.remove(pg6 + ".tbi")
         res["note"] = ("every leg: first_s / median_s / best_s of its repetitions (total_s = best_s and the stage split are the "
                        "best repetition's; the first one of a process also pays thread-pool start, page-locked allocations and "
                        "the file's first read); floor = max(compressed bytes / measured H2D rate, the inflate kernel alone); PCIe "
