@@ -300,3 +300,56 @@ def test_linear_index_of_the_synthetic_files_is_tabix_s(tmp_path):
                 nxt = voff[ov[0]]
             assert lin[w] == nxt, (name, w)
         assert np.all(np.diff(lin.astype(np.int64)) >= 0)  # offsets never go back
+
+
+def test_interval_partition_properties():
+    """`sharding.split_weighted` / `IntervalPlan` (the ranks' partition of every interval-driven command): for random
+    interval lists and every world size 1..9 each interval lies in exactly one unit, a contig's units tile its
+    start-ordered intervals, ranks take consecutive runs, the cost of the heaviest rank stays within one contig entry +
+    one interval of the mean, and the single-process gather hands rows back in input order."""
+    from finaletoolkit_amd import sharding
+    rng = np.random.default_rng(11)
+    for trial in range(25):
+        n_contigs = int(rng.integers(1, 7))
+        contigs, starts, stops = [], [], []
+        for c in range(n_contigs):
+            n = int(rng.integers(0, 60))
+            s = rng.integers(0, 5_000_000, n)
+            contigs += [f"c{c}"] * n
+            starts += s.tolist()
+            stops += (s + rng.integers(0, 20_000, n)).tolist()
+        order = rng.permutation(len(contigs))
+        contigs = [contigs[i] for i in order]
+        starts = [starts[i] for i in order]
+        stops = [stops[i] for i in order]
+        plan = sharding.IntervalPlan(contigs, starts, stops)     # no process group: one rank
+        assert plan.world == 1 and all(plan.is_whole(u) for u in plan.mine)
+        seen = np.concatenate([plan.intervals(u) for u in plan.mine]) if plan.mine else np.zeros(0, np.int64)
+        assert sorted(seen.tolist()) == list(range(len(contigs)))
+        rows = {u: np.stack([plan.starts[plan.intervals(u)], plan.stops[plan.intervals(u)]], axis=1) for u in plan.mine}
+        back = plan.gather(rows, 2)
+        assert np.array_equal(back[:, 0], np.asarray(starts, np.int64).reshape(-1)[:len(back)]) if len(back) else True
+        assert np.array_equal(back[:, 1], np.asarray(stops, np.int64)) if len(back) else True
+        cost = {}
+        for c, idx in plan.order.items():
+            st = plan.starts[idx]
+            assert np.all(np.diff(st) >= 0)                      # a contig's intervals in start order
+            nxt = np.concatenate((st[1:], [max(int(plan.stops[idx].max()), int(st[-1]) + 1)]))
+            cost[c] = np.maximum(nxt - st, 1)
+        for world in range(1, 10):
+            for overhead in (0, 250_000):
+                units = sharding.split_weighted(cost, world, overhead)
+                ranks = [u[0] for u in units]
+                assert ranks == sorted(ranks) and all(0 <= r < world for r in ranks)
+                for c, w in cost.items():
+                    cuts = [(i0, i1) for _, cc, i0, i1 in units if cc == c]
+                    assert cuts[0][0] == 0 and cuts[-1][1] == len(w) and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+                if world > 1 and cost:
+                    total = sum(float(w.sum()) for w in cost.values()) + overhead * len(cost)
+                    load = [0.0] * world
+                    entered = set()
+                    for r, c, i0, i1 in units:
+                        load[r] += float(cost[c][i0:i1].sum()) + (overhead if c not in entered and i0 == 0 else 0)
+                        entered.add(c)
+                    biggest = max(float(w.max()) for w in cost.values())
+                    assert max(load) <= total / world + overhead + biggest + 1e-6, (trial, world, overhead)
