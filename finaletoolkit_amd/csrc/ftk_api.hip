@@ -11,6 +11,7 @@
 #include <type_traits>
 
 #include <dlfcn.h>
+#include <immintrin.h>
 #include <fcntl.h>
 #include <unistd.h>
 
@@ -349,6 +350,10 @@ void ftk_ctx_destroy(ftk_ctx* ctx) {
     for (int k = 0; k < 2; ++k) {
         if (ctx->ref_stage[k]) (void)hipHostFree(ctx->ref_stage[k]);
         if (ctx->ref_stage_done[k]) (void)hipEventDestroy(ctx->ref_stage_done[k]);
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->narrow_stage[k]) ftk_host_free(ctx->narrow_stage[k]);
+        if (ctx->narrow_done[k]) (void)hipEventDestroy(ctx->narrow_done[k]);
     }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
@@ -1094,6 +1099,117 @@ static int wps_params(ftk_ctx* ctx, const ContigData& c, int64_t chrom_size, int
     return FTK_OK;
 }
 
+// ---- per-base scores to the host on a narrow wire -------------------------------------------------------------------
+// The reference's WPS is int64 per base (frag/_wps.py:176-188): 2 GB for chr1, 24.8 GB for a genome - and a device -> host
+// copy of it runs at the link's 55 GB/s whatever the kernels do (0.45 s of the 0.54 s a genome's every-feature run takes).
+// The VALUES are small (a score is bounded by the fragments over a base: a few hundred at 60x), so they cross the link
+// as int16 - a quarter of the bytes - and the host threads widen them into the caller's int64 array while the next
+// chunk is on its way.  A score that does not fit (checked on the device, before anything is copied) sends the whole
+// result the plain way.  FTK_WPS_NARROW_WIRE=0 keeps the plain copy.
+namespace {
+constexpr int64_t kNarrowChunk = int64_t(1) << 24;     // scores per chunk (32 MB on the wire, 128 MB widened)
+constexpr int64_t kNarrowMin = int64_t(1) << 22;       // shorter results take the plain copy
+
+__global__ __launch_bounds__(256) void narrow_i16_kernel(const int64_t* __restrict__ in, int16_t* __restrict__ out, int64_t n,
+                                                         int* __restrict__ misfit) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+    bool bad = false;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+        if (i + 8 <= n) {
+            typedef long long ll2 __attribute__((ext_vector_type(2)));
+            const ll2* p = reinterpret_cast<const ll2*>(in + i);  // (in and out are 16-byte aligned, i % 8 == 0)
+            long long v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const ll2 t = __builtin_nontemporal_load(p + k);
+                v[2 * k] = t.x;
+                v[2 * k + 1] = t.y;
+            }
+            unsigned w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bad |= v[2 * k] != (long long)(short)v[2 * k] || v[2 * k + 1] != (long long)(short)v[2 * k + 1];
+                w[k] = ((unsigned)v[2 * k] & 0xffffu) | ((unsigned)v[2 * k + 1] << 16);
+            }
+            *reinterpret_cast<uint4*>(out + i) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (int64_t j = i; j < n; ++j) {
+                const long long v = in[j];
+                bad |= v != (long long)(short)v;
+                out[j] = (int16_t)v;
+            }
+        }
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(misfit, 1);
+}
+
+__attribute__((target("avx2"))) void widen_avx2(const int16_t* src, int64_t* dst, size_t a, size_t b) {
+    size_t i = a;
+    for (; i < b && ((uintptr_t)(dst + i) & 31u); ++i) dst[i] = src[i];
+    for (; i + 16 <= b; i += 16) {  // 16 scores: one 32-byte load, four sign extensions, four streaming stores
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i));
+        const __m128i lo = _mm256_castsi256_si128(v), hi = _mm256_extracti128_si256(v, 1);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i), _mm256_cvtepi16_epi64(lo));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 4), _mm256_cvtepi16_epi64(_mm_srli_si128(lo, 8)));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 8), _mm256_cvtepi16_epi64(hi));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 12), _mm256_cvtepi16_epi64(_mm_srli_si128(hi, 8)));
+    }
+    for (; i < b; ++i) dst[i] = src[i];
+    _mm_sfence();
+}
+
+void widen_i16(const int16_t* src, int64_t* dst, size_t n, int nt) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    nt = std::max(1, std::min(nt, (int)(n >> 18) + 1));
+    ftk_host::parallel_run_results(nt, [&](int t) {
+        const size_t a = n * (size_t)t / (size_t)nt, b = n * (size_t)(t + 1) / (size_t)nt;
+        if (avx2) widen_avx2(src, dst, a, b);
+        else
+            for (size_t i = a; i < b; ++i) dst[i] = src[i];
+    });
+}
+
+// d_scores[0, n) (device, int64, complete on ctx->stream) -> host_out[0, n); FTK_OK, or a HIP error.  *done = false:
+// nothing was copied (scores that do not fit 16 bits, no page-locked staging): the caller copies the plain way.
+int copy_scores_narrow(ftk_ctx* ctx, const int64_t* d_scores, int16_t* d_narrow, int* d_misfit, int64_t n, int64_t* host_out,
+                       bool* done) {
+    *done = false;
+    for (int k = 0; k < 2; ++k) {
+        // (page-locked blocks of the library's result cache: a ctx that is destroyed hands them back and the next one
+        // finds them there - pinning 64 MB anew for every engine cost the small file legs 4-5 ms)
+        if (!ctx->narrow_stage[k] && ftk_host_alloc(kNarrowChunk * 2, &ctx->narrow_stage[k]) != FTK_OK) {
+            ctx->narrow_stage[k] = nullptr;
+            return FTK_OK;
+        }
+        if (!ctx->narrow_done[k]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->narrow_done[k], hipEventDisableTiming));
+    }
+    HIPCHK(ctx, hipMemsetAsync(d_misfit, 0, sizeof(int), ctx->stream));
+    const int blocks = (int)std::min<int64_t>((n / 8 + 255) / 256 + 1, 8192);
+    hipLaunchKernelGGL(narrow_i16_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_scores, d_narrow, n, d_misfit);
+    HIPCHK(ctx, hipGetLastError());
+    int misfit = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&misfit, d_misfit, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (misfit) return FTK_OK;
+    const int nt = ftk_host::default_threads();
+    const int64_t n_chunks = (n + kNarrowChunk - 1) / kNarrowChunk;
+    for (int64_t c = 0; c <= n_chunks; ++c) {
+        if (c < n_chunks) {  // chunk c on its way (its staging buffer's previous chunk, c - 2, was widened in the last turn)
+            const int64_t a = c * kNarrowChunk, m = std::min(kNarrowChunk, n - a);
+            HIPCHK(ctx, hipMemcpyAsync(ctx->narrow_stage[c & 1], d_narrow + a, (size_t)m * 2, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipEventRecord(ctx->narrow_done[c & 1], ctx->stream));
+        }
+        if (c > 0) {  // ... while the host threads widen chunk c - 1
+            const int64_t a = (c - 1) * kNarrowChunk, m = std::min(kNarrowChunk, n - a);
+            HIPCHK(ctx, hipEventSynchronize(ctx->narrow_done[(c - 1) & 1]));
+            widen_i16(static_cast<const int16_t*>(ctx->narrow_stage[(c - 1) & 1]), host_out + a, (size_t)m, nt);
+        }
+    }
+    *done = true;
+    return FTK_OK;
+}
+}  // namespace
+
 int ftk_wps(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t chrom_size, int32_t window_size,
             int32_t min_len, int32_t max_len, int32_t mapq_min, int64_t* wps_out) {
     if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
@@ -1108,7 +1224,10 @@ int ftk_wps(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t ch
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int64_t n_pos = stop - start;
     const bool out_dev = is_device_ptr(wps_out);
-    if (!out_dev && (rc = reserve_scratch(ctx, align_up(n_pos * 8)))) return rc;
+    static const bool narrow_env = !(getenv("FTK_WPS_NARROW_WIRE") && atoi(getenv("FTK_WPS_NARROW_WIRE")) == 0);
+    const bool narrow = !out_dev && narrow_env && n_pos >= kNarrowMin;
+    const size_t wide_bytes = align_up((size_t)n_pos * 8);
+    if (!out_dev && (rc = reserve_scratch(ctx, wide_bytes + (narrow ? align_up((size_t)n_pos * 2) + 256 : 0)))) return rc;
     int64_t* d_out = out_dev ? wps_out : (int64_t*)ctx->scratch;
     p.start = start;
     p.stop = stop;
@@ -1116,8 +1235,16 @@ int ftk_wps(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t ch
     launch_wps(ctx->stream, c->v, p, n_tiles, nullptr, nullptr, nullptr, nullptr, nullptr, d_out);
     HIPCHK(ctx, hipGetLastError());
     if (!out_dev) {
-        HIPCHK(ctx, hipMemcpyAsync(wps_out, d_out, n_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        bool done = false;
+        if (narrow) {
+            char* tail = (char*)ctx->scratch + wide_bytes;
+            if ((rc = copy_scores_narrow(ctx, d_out, (int16_t*)tail, (int*)(tail + align_up((size_t)n_pos * 2)), n_pos, wps_out, &done)))
+                return rc;
+        }
+        if (!done) {
+            HIPCHK(ctx, hipMemcpyAsync(wps_out, d_out, n_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
     }
     return FTK_OK;
 }

@@ -590,6 +590,20 @@ namespace ftk_host {
 
 void parallel_run(int n, const std::function<void(int)>& fn) { ::parallel_run(n, fn); }
 
+void parallel_run_results(int n, const std::function<void(int)>& fn) {
+    static std::mutex init;
+    static WorkPool* pool = nullptr;
+    static std::once_flag fork_once;
+    WorkPool* p;
+    {
+        std::lock_guard<std::mutex> lk(init);
+        std::call_once(fork_once, [] { pthread_atfork(nullptr, nullptr, [] { pool = nullptr; }); });
+        if (!pool) pool = new WorkPool();  // never destroyed: its threads end with the process
+        p = pool;
+    }
+    p->run(n, fn);
+}
+
 void set_decode_error(const char* msg) { g_decode_err = msg ? msg : ""; }
 
 int default_threads() {

@@ -7,6 +7,9 @@ namespace ftk_host {
 
 // fn(0) runs on the caller, fn(1..n-1) on the library's persistent worker threads; returns when all are done.
 void parallel_run(int n, const std::function<void(int)>& fn);
+// The same on a SECOND pool of worker threads, for the consumer's side (results being widened or formatted while a
+// decoder stream's regions - which are serialised on the first pool, one at a time, some 10 ms long - are running).
+void parallel_run_results(int n, const std::function<void(int)>& fn);
 // Threads a host-side parallel region uses by default: the cores this process may use (affinity and cgroup
 // quota), at most 64.
 int default_threads();

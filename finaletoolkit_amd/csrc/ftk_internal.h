@@ -93,6 +93,10 @@ struct ftk_ctx {
     std::vector<std::pair<void*, size_t>> ref_pool;
     void* ref_stage[2] = {nullptr, nullptr};
     hipEvent_t ref_stage_done[2] = {nullptr, nullptr};
+    // per-base results on a narrow wire (ftk_wps with a host output): two page-locked chunks of 16-bit scores and the
+    // events behind their copies
+    void* narrow_stage[2] = {nullptr, nullptr};
+    hipEvent_t narrow_done[2] = {nullptr, nullptr};
     // batched launches: the per-item descriptors last uploaded (re-used while the caller repeats the batch)
     std::vector<unsigned char> batch_host[2];  // [0] window features, [1] WPS
     void* batch_dev[2] = {nullptr, nullptr};

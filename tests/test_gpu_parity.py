@@ -771,3 +771,33 @@ def test_features_and_wps_in_one_launch_equal_the_two_calls(engine, data, win_le
     engine.window_features_wps("synA", ws, we, host, 0, CONTIG_LEN, CONTIG_LEN, coverage=cov)
     assert np.array_equal(host, engine.wps("synA", 0, CONTIG_LEN, CONTIG_LEN))
     assert np.array_equal(cov, engine.window_counts("synA", ws, we, 30))
+
+
+def test_wps_host_results_cross_the_link_narrow_and_arrive_exact(engine):
+    """Results of 4 M positions or more go to the host as int16 and are widened there (`copy_scores_narrow`,
+    csrc/ftk_api.hip); a score beyond 16 bits - a pile of 40 000 identical fragments - must send the result the plain
+    way.  Both against the same launch left on the device (which never takes that path) and against the closed form at
+    the pile (reference frag/_wps.py:25-53: +1 per spanning fragment, -1 per fragment end inside the window)."""
+    import torch
+    size = 6_000_000
+    rng = np.random.default_rng(5)
+    s = np.sort(rng.integers(0, size - 400, 20_000)).astype(np.int32)
+    e = (s + rng.integers(120, 181, len(s))).astype(np.int32)
+    for name, pile in (("narrow_ok", 300), ("narrow_misfit", 40_000)):
+        ps = np.full(pile, 3_000_000, np.int32)
+        order = np.argsort(np.concatenate([s, ps]), kind="stable")
+        S = np.concatenate([s, ps])[order]
+        E = np.concatenate([e, ps + 150])[order]
+        q = np.full(len(S), 60, np.uint8)
+        engine.load_contig(name, S, E, q, np.ones(len(S), np.uint8))
+        host = engine.wps(name, 0, size, size)
+        dev = torch.empty(size, dtype=torch.int64, device="cuda:0")
+        engine.wps(name, 0, size, size, out=dev)
+        engine.sync()
+        assert host.dtype == np.int64 and np.array_equal(host, dev.cpu().numpy()), name
+        # bases 3 000 061 .. 3 000 090 are spanned by every fragment of the pile (and see none of its ends)
+        assert int(host[3_000_061:3_000_091].min()) >= pile - 40 and int(host.max()) <= pile + 40, name
+        assert (int(host.max()) > 32767) == (pile > 32767)
+        # a short interval takes the plain copy: same numbers
+        assert np.array_equal(engine.wps(name, 2_990_000, 3_010_000, size), host[2_990_000:3_010_000])
+        engine.release(name)
