@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the file -> result legs (end_to_end in the JSON)")
     args = ap.parse_args()
+    if os.environ.get("FTK_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after <seconds>
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["FTK_BENCH_WATCHDOG"]), exit=True)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: this process becomes the launcher of N fresh rank processes
@@ -77,6 +80,10 @@ def main():
     if share:
         local = 0
         os.environ.setdefault("FTK_BENCH_DIST_BACKEND", "gloo")
+        # (the product's own engine - frag.delfi in the N-rank file leg - picks its GPU from FTK_DEVICE, else LOCAL_RANK:
+        # under torch.distributed.run LOCAL_RANK is the rank, and rank 1 has no GPU 1 on a shared box - it failed there,
+        # alone, and the other ranks waited for it in the leg's first collective)
+        os.environ["FTK_DEVICE"] = "0"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # FTK_BENCH_FORCE_DIST=1 drives the collective code path with a 1-rank RCCL group (1-GPU boxes)
@@ -88,10 +95,13 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        import datetime
+        # (ten minutes instead of the backends' 10-30: a rank that failed alone must not hold the others for half an hour)
+        limit = datetime.timedelta(minutes=10)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
 
     sizes = dict(synth.B37_SIZES)
     if args.contigs:

@@ -276,7 +276,15 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
     # One process: every contig of the file will be wanted (or skipped cheaply), so the decoder starts NOW and works
     # towards chr1 while the side files below are read.  (Several ranks each want their own share: known after the plan.)
     early = None
-    if sharding.rank_world()[1] == 1 and isinstance(get_engine(), Engine):
+    if sharding.rank_world()[1] > 1:
+        # several ranks: a rank without a usable GPU must say so BEFORE the others enter the first collective
+        err = None
+        try:
+            get_engine()
+        except Exception as e:  # noqa: BLE001 - every rank learns of it
+            err = e
+        sharding.agree(err)
+    elif isinstance(get_engine(), Engine):
         early = EarlyContigs(input_file, workers)
     try:
         return _delfi(early, t_begin, clock, input_file, chrom_sizes, bins_file, reference_file, blacklist_file, gap_file,
