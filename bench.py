@@ -58,6 +58,9 @@ def main():
         raise SystemExit(launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
                                       share_gpu=os.environ.get("FTK_BENCH_SHARE_GPU") == "1"))
 
+    # (multi-process GPU work on this platform needs the dmabuf IPC mode - the host driver supports no other; exported
+    # on the build boxes already, kept here for a launcher that starts the ranks from a cleaner environment)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 

@@ -74,6 +74,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return 0, 1
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (RCCL between processes: the host driver only has dmabuf IPC)
     import torch
     import torch.distributed as dist
     if not dist.is_initialized():
