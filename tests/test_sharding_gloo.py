@@ -177,8 +177,18 @@ def _product_worker(rank, world, port, d, q):
                       no_gc_correct=True, remove_nocov=False, merge_bins=False, output_file=f"{d}/delfi_w{world}.tsv")
     counted = sorted(set(asked))
     cov = Cv.coverage("x", f"{d}/iv.bed", f"{d}/cov_w{world}.bed", normalize=True, scale_factor=1e6)
+    # an interval on a contig the input lacks fails on the rank that owns it - and must fail on EVERY rank (the owner
+    # with its own exception, the others with a RuntimeError naming it), not leave them in the gather
+    region_reads = list(src.region_reads)
+    try:
+        Cv.coverage("x", f"{d}/iv_bad.bed", None)
+        failed = "no error"
+    except RuntimeError as e:
+        failed = "other: " + str(e)
+    except Exception as e:  # noqa: BLE001
+        failed = "own: " + type(e).__name__
     sharding.finalize()
-    q.put((rank, df.to_csv(), [tuple(c) for c in cov], counted, list(src.region_reads)))
+    q.put((rank, df.to_csv(), [tuple(c) for c in cov], counted, region_reads, failed))
 
 
 def test_sharded_delfi_and_coverage_equal_single_process(tmp_path):
@@ -196,6 +206,7 @@ def test_sharded_delfi_and_coverage_equal_single_process(tmp_path):
           for k, a in enumerate(rng.integers(0, n - 4000, 400 if c == "b" else 30))]  # (b is half of the cost: wherever the shuffle puts it, the cut of two equal-cost runs falls into it)
     rng.shuffle(iv)
     (d / "iv.bed").write_text("".join(iv))
+    (d / "iv_bad.bed").write_text("".join(iv[:40]) + "nope\t10\t500\tmissing\n" + "".join(iv[40:80]))
     ctx = mp.get_context("spawn")
     res = {}
     for world in (1, 2):
@@ -220,7 +231,8 @@ def test_sharded_delfi_and_coverage_equal_single_process(tmp_path):
     assert (d / "cov_w2.bed").read_text() == (d / "cov_w1.bed").read_text()
     # coverage's intervals take the same kind of partition (sharding.IntervalPlan): one process reads no region; with two
     # ranks the contig the cut falls into is read as a region by both, each spanning only its own intervals
-    assert one[4] == []
+    assert one[4] == [] and one[5].startswith("own: ")
+    assert sorted(r[5].split(":")[0] for r in res[2]) == ["other", "own"] and any("rank" in r[5] and "failed" in r[5] for r in res[2])
     r0, r1 = res[2][0][4], res[2][1][4]
     assert len(r0) == 1 and len(r1) == 1 and r0[0][0] == r1[0][0] and r0[0][1:] != r1[0][1:]
     assert r0[0][2] <= r1[0][1] + 4001 or r1[0][2] <= r0[0][1] + 4001  # (start-ordered shares: the two regions barely overlap)
