@@ -125,26 +125,7 @@ def write_frag_gz(path, contig_rows, bed6: bool = False, with_tbi_stub: bool = T
     """
     contig_rows = list(contig_rows)
     if sum(len(r[1]) for r in contig_rows) > 50_000:
-        # large files: rows formatted and BGZF blocks deflated by the library's host threads, one contig after
-        # the other (a contig starts on a fresh block, so its virtual offset is just the block's file offset)
-        from . import writers
-        spans, linear = [], []
-        first = True
-        end_off = 0
-        for name, start, end, mapq, strand in contig_rows:
-            with writers.frag_rows(name, start, end, mapq, strand, bed6) as rows:
-                offs = writers.bgzf_write(path, rows, level, append=not first, write_eof=False)
-            spans.append((name, int(offs[0]), int(offs[-1])))
-            if with_index:
-                linear.append(linear_index(start, end, row_lengths(name, start, end, mapq, bed6), offs))
-            end_off = int(offs[-1])
-            first = False
-        with open(path, "ab") as fh:
-            fh.write(_EOF)
-        if with_index:
-            write_index(str(path) + ".tbi", False, [(n, a << 16, b << 16) for n, a, b in spans], linear)
-        elif with_tbi_stub:
-            open(str(path) + ".tbi", "ab").close()
+        write_frag_gz_contigs(path, contig_rows, bed6, level, with_index, with_tbi_stub)
         return
     parts = []
     marks = []  # (name, first byte, end byte) per run of a contig
@@ -167,3 +148,30 @@ def write_frag_gz(path, contig_rows, bed6: bool = False, with_tbi_stub: bool = T
                     [(n, virtual_offset(offsets, a), virtual_offset(offsets, b)) for n, a, b in marks], linear)
     elif with_tbi_stub:
         open(str(path) + ".tbi", "ab").close()
+
+
+def write_frag_gz_contigs(path, contig_rows, bed6: bool = False, level: int = 6, with_index: bool = True,
+                          with_tbi_stub: bool = True) -> dict:
+    """The large-file form of ``write_frag_gz``: ``contig_rows`` may be a GENERATOR - one contig's columns are alive at
+    a time, so a file larger than memory (or than 4 GiB) can be written.  Rows are formatted and BGZF blocks deflated
+    by the library's host threads, one contig after the other; a contig starts on a fresh block, so its virtual
+    offset is just the block's file offset.  Returns ``{name: dict(first_off, end_off, linear)}`` (file offsets of
+    the contig's first block and behind its last; its tabix linear index or None)."""
+    from . import writers
+    spans, linear, out = [], [], {}
+    first = True
+    for name, start, end, mapq, strand in contig_rows:
+        with writers.frag_rows(name, start, end, mapq, strand, bed6) as rows:
+            offs = writers.bgzf_write(path, rows, level, append=not first, write_eof=False)
+        spans.append((name, int(offs[0]), int(offs[-1])))
+        lin = linear_index(start, end, row_lengths(name, start, end, mapq, bed6), offs) if with_index else None
+        linear.append(lin)
+        out[name] = dict(first_off=int(offs[0]), end_off=int(offs[-1]), linear=lin)
+        first = False
+    with open(path, "ab" if not first else "wb") as fh:
+        fh.write(_EOF)
+    if with_index:
+        write_index(str(path) + ".tbi", False, [(n, a << 16, b << 16) for n, a, b in spans], linear)
+    elif with_tbi_stub:
+        open(str(path) + ".tbi", "ab").close()
+    return out

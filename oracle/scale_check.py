@@ -1,6 +1,7 @@
 """
 TEST INFRASTRUCTURE ONLY -- the checker of BASELINE config 5 at real size (a > 4 GiB, multi-contig 60x BAM streamed
-through the device parser).  Shared by ``tests/test_gpu_bam_scale.py`` and the untimed check of ``bench.py``'s
+through the device parser) and of its fragment-file twin (a > 4 GiB whole-genome frag.gz).  Shared by
+``tests/test_gpu_bam_scale.py``, ``tests/test_gpu_text_scale.py`` and the untimed check of ``bench.py``'s
 ``bam_60x_chr1_scale`` leg; never the thing measured, never imported by the product.
 
 Reference semantics being checked (``io/alignment.py:242-268`` behind ``utils/_frag_generator.py:58-141``): a BAM
@@ -31,7 +32,8 @@ def wps_ranges(size: int, length: int = 50_000):
 
 
 def frags_of(exp) -> O.Frags:
-    return O.Frags(exp["s"], exp["e"], exp["q"], exp["st"], exp["r1s"], exp["r1e"])
+    """(a fragment FILE's contig has no read1 span: tabix-overlap semantics, ``io/alignment.py:270-302``)"""
+    return O.Frags(exp["s"], exp["e"], exp["q"], exp["st"], exp.get("r1s"), exp.get("r1e"))
 
 
 def check_contig(eng, key, size, exp, features, n_sampled=24, wps_len=50_000):
