@@ -234,11 +234,11 @@ def gather_bin_vectors(local: Dict[str, np.ndarray], names: Sequence[str], n_bin
     """All-gather per-contig integer vectors (shape [n_bins[c], k]) so every rank
     holds all contigs.  ``local`` has this rank's contigs; ``n_bins`` the row
     count of EVERY contig (known from the bin file on all ranks)."""
+    if rank_world(group)[1] == 1:  # (decided without importing torch: seconds on every single-process call)
+        return dict(local)
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return dict(local)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if device is None:
@@ -276,13 +276,13 @@ def gather_unit_rows(local: Dict[tuple, np.ndarray], units, n_rows: Dict[tuple, 
     """All-gather the integer rows of ``split_counts`` units: ``local[(contig, i0, i1)]`` holds this rank's units
     (shape ``[n_rows[unit], k]``; every rank knows every unit's row count), the result maps each contig to its units'
     rows concatenated in unit order - on every rank.  One collective, like ``gather_bin_vectors``."""
-    import torch
-    import torch.distributed as dist
-
     keys = [(c, i0, i1) for _, c, i0, i1 in units]
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if rank_world(group)[1] == 1:  # (decided without importing torch)
         got = {key: np.asarray(local[key], dtype=np.int64).reshape(-1, k) for key in keys}
     else:
+        import torch
+        import torch.distributed as dist
+
         world = dist.get_world_size(group)
         rank = dist.get_rank(group)
         if device is None:
@@ -388,11 +388,11 @@ class IntervalPlan:
 
 def allreduce_sum(value: int, group=None, device=None) -> int:
     """Sum of one int64 over ranks (the genome-wide total of ``coverage(normalize=True)``)."""
+    if rank_world(group)[1] == 1:
+        return int(value)
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return int(value)
     if device is None:
         device = exchange_device(group)
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)

@@ -92,3 +92,27 @@ def test_cli_adjust_wps(tmp_path):
         s = int(A[f"w200_nosavgol_{i}_start"])
         st, en, v = bw.intervals(cs["run_contigs"][i], s, s + len(want))
         assert st[0] == s and np.array_equal(v.astype(np.float32), want)
+
+
+def test_one_gpu_commands_run_without_torch(tmp_path):
+    """A command on one GPU is a fresh process whose wall time is mostly start-up; ``import torch`` would add seconds
+    to it and nothing on the path needs it (torch is the launcher and the exchange of the MULTI-rank commands).  Every
+    sharded command's one-rank form is run here in one child process, which must end without torch loaded."""
+    frag_file = os.path.join(DATA, "12.3444.b37.frag.gz")
+    bed = os.path.join(DATA, "intervals.bed")
+    code = f"""
+import sys
+from finaletoolkit_amd import frag
+cov = frag.coverage({frag_file!r}, {bed!r}, {str(tmp_path / 'c.bed')!r}, normalize=True)
+assert len(cov) == 2 and cov[0].intersections > 0
+st = frag.frag_length_intervals({frag_file!r}, {bed!r}, None)
+assert len(st) == 2
+bins = frag.frag_length_bins({frag_file!r}, '12', 34443000, 34447000, bin_size=5)
+w = frag.wps({frag_file!r}, '12', 34443000, 34447000, output_file={str(tmp_path / 'w.wig')!r})
+assert len(w) == 4000
+frag.multi_wps({frag_file!r}, {bed!r}, {os.path.join(DATA, 'b37.chrom.sizes')!r}, {str(tmp_path / 'm.bed.gz')!r}, interval_size=400)
+assert 'torch' not in sys.modules, sorted(m for m in sys.modules if m.startswith('torch'))[:5]
+print('ok')
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]

@@ -353,3 +353,28 @@ def test_interval_partition_properties():
                         entered.add(c)
                     biggest = max(float(w.max()) for w in cost.values())
                     assert max(load) <= total / world + overhead + biggest + 1e-6, (trial, world, overhead)
+
+
+def test_single_process_calls_never_import_torch():
+    """``import torch`` costs seconds in a fresh process; a command on one GPU needs none of it (the exchanges of the
+    sharded commands return their local part).  A cold-start probe found ``frag.coverage`` paying 2.3 s for it in
+    ``IntervalPlan.gather`` - every helper a one-rank command passes through is held to that here."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "import finaletoolkit_amd, finaletoolkit_amd.frag, finaletoolkit_amd.cli\n"
+        "from finaletoolkit_amd import sharding as S\n"
+        "plan = S.IntervalPlan(['a', 'a', 'b'], [5, 1, 3], [9, 4, 8])\n"
+        "local = {u: np.arange(len(plan.intervals(u)), dtype=np.int64).reshape(-1, 1) for u in plan.mine}\n"
+        "assert plan.gather(local, 1).shape == (3, 1)\n"
+        "assert S.allreduce_sum(7) == 7 and S.rank_world() == (0, 1) and S.is_writer()\n"
+        "assert S.gather_bin_vectors({'a': np.zeros((2, 3), np.int64)}, ['a'], {'a': 2}, {'a': 1.0}, k=3)['a'].shape == (2, 3)\n"
+        "assert S.gather_float_rows({'a': np.ones((2, 1))}, ['a'], {'a': 2}, {'a': 0}, 1)['a'][1, 0] == 1.0\n"
+        "assert S.allgather_object(3) == [3] and S.gather_payloads({0: b'x'}, [0]) == [b'x']\n"
+        "assert S.contig_owner({'a': 1.0})[:2] == (0, 1)\n"
+        "S.agree(None); S.finalize()\n"
+        "assert 'torch' not in sys.modules, sorted(m for m in sys.modules if m.startswith('torch'))[:5]\n"
+        "print('ok')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
