@@ -104,11 +104,11 @@ def test_one_gpu_commands_run_without_torch(tmp_path):
 import sys
 from finaletoolkit_amd import frag
 cov = frag.coverage({frag_file!r}, {bed!r}, {str(tmp_path / 'c.bed')!r}, normalize=True)
-assert len(cov) == 2 and cov[0].intersections > 0
+assert len(cov) == 2 and cov[0].coverage > 0
 st = frag.frag_length_intervals({frag_file!r}, {bed!r}, None)
 assert len(st) == 2
 bins = frag.frag_length_bins({frag_file!r}, '12', 34443000, 34447000, bin_size=5)
-w = frag.wps({frag_file!r}, '12', 34443000, 34447000, output_file={str(tmp_path / 'w.wig')!r})
+w = frag.wps({frag_file!r}, '12', 34443000, 34447000, 133851895, output_file={str(tmp_path / 'w.wig')!r})
 assert len(w) == 4000
 frag.multi_wps({frag_file!r}, {bed!r}, {os.path.join(DATA, 'b37.chrom.sizes')!r}, {str(tmp_path / 'm.bed.gz')!r}, interval_size=400)
 assert 'torch' not in sys.modules, sorted(m for m in sys.modules if m.startswith('torch'))[:5]
