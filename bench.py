@@ -566,7 +566,8 @@ def rep_summary(runs):
     times = [r["total_s"] for r in runs]
     out = dict(min(runs, key=lambda r: r["total_s"]))
     out.update(first_s=round(times[0], 4), median_s=round(float(np.median(times)), 4), best_s=round(min(times), 4),
-               repetitions=len(times), results_ok=bool(all(r.get("results_ok", True) for r in runs)))
+               repetitions=len(times), all_s=[round(t, 4) for t in times],
+               results_ok=bool(all(r.get("results_ok", True) for r in runs)))
     return out
 
 

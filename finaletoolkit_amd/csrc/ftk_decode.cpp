@@ -2702,6 +2702,31 @@ StreamPool& stream_pool() {
     static StreamPool* p = new StreamPool();  // leaked: the driver frees at process exit
     return *p;
 }
+
+// The front streams of a decoder stream's ring, created when a piece first needs one.  With sixteen hardware queues
+// (GPU_MAX_HW_QUEUES, see _hardware_queues) a NEW stream costs 5.5 ms - its queue is set up with it - and a decoder
+// stream that opened its whole ring up front spent 72 of the 80 ms a small file takes in a fresh process on thirteen
+// hipStreamCreateWithFlags (profiles/r4_cold_start.txt); a file of one piece needs one.  Streams of earlier decoder
+// streams come back from the pool at no cost, so a warm process sees no difference.  If a stream cannot be created
+// the piece runs on `fallback` (the parse stream): ordering is by events, so that only serialises it.
+template <int N>
+struct FrontStreams {
+    int device = -1;
+    hipStream_t fallback = nullptr;
+    hipStream_t s[N] = {};
+    hipStream_t get(int k) {
+        if (!s[k] && (s[k] = stream_pool().take(device)) == nullptr) return fallback;
+        return s[k];
+    }
+    void settle_and_give() {  // (the caller has set the device)
+        for (auto& q : s)
+            if (q) {
+                (void)hipStreamSynchronize(q);
+                stream_pool().give(device, q);
+                q = nullptr;
+            }
+    }
+};
 }  // namespace
 
 bool ftk_fragstream::emit_device(Contig&& ct) {
@@ -2748,13 +2773,9 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     constexpr int kSets = 12, kHostLag = 8;
     DevSet sets[kSets];
     for (auto& S : sets) S = devset_pool().take(device);
-    hipStream_t fstream[kSets] = {};
-    for (auto& f : fstream)
-        if ((f = stream_pool().take(device)) == nullptr) {
-            for (auto& g : fstream) stream_pool().give(device, g);
-            for (auto& S : sets) devset_pool().give(device, S);
-            return fail(FTK_ERR_HIP, "cannot create the inflate streams");
-        }
+    FrontStreams<kSets> fstream;
+    fstream.device = device;
+    fstream.fallback = pstream;
     // FTK_DECODE_TIMING: the device time of every piece's front (copy up + inflate + CRC) and back (set-up + rows)
     hipEvent_t tev[kSets][5] = {};  // front start, front end, back start, back end, bytes up
     double front_ms = 0, front_max = 0, back_ms = 0, back_max = 0;
@@ -2776,13 +2797,10 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         DevSet* s;
         int device;
         hipStream_t stream;
-        hipStream_t* fs;
+        FrontStreams<kSets>* fs;
         hipEvent_t (*tev)[5];
         ~Cleanup() {
-            for (int k = 0; k < kSets; ++k) {
-                (void)hipStreamSynchronize(fs[k]);
-                stream_pool().give(device, fs[k]);
-            }
+            fs->settle_and_give();
             (void)hipStreamSynchronize(stream);  // nothing in flight touches the sets any more
             for (int k = 0; k < kSets; ++k) {
                 devset_pool().give(device, s[k]);
@@ -2790,7 +2808,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
                     if (ev) (void)hipEventDestroy(ev);
             }
         }
-    } cleanup{sets, device, pstream, fstream, tev};
+    } cleanup{sets, device, pstream, &fstream, tev};
     std::vector<Block> blocks;
     size_t carry = 0;
     const uint8_t* carry_src = nullptr;
@@ -3019,7 +3037,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         DevSet* P = M.has_prev ? &sets[(j - 1) % kSets] : nullptr;
         bool ok = true;
         if (M.on_host) {
-            hipStream_t front = fstream[sj];
+            hipStream_t front = fstream.get(sj);
             const auto t0 = std::chrono::steady_clock::now();
             const int jrc = host_job[sj].valid() ? host_job[sj].get() : (int)FTK_OK;
             t_jobwait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -3154,7 +3172,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             M.back_done = false;
             M.total = total;
             M.first_skip = (uint32_t)std::min<size_t>(first_skip, total);
-            hipStream_t front = fstream[k % kSets];
+            hipStream_t front = fstream.get(k % kSets);
             bool ok = true;
             if (M.on_host) {
                 // (the job owns its block list and works from its own copy of the bytes - the staging above - straight
@@ -3382,16 +3400,15 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
     static const bool want_dinf = !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
     const int device = inflate_device;  // (shadows the member: this path's GPU)
     bool dinf = want_dinf && device >= 0;
-    hipStream_t streams[kSlots] = {};  // streams[0] is the member pstream (destroyed with the stream object)
+    FrontStreams<kSlots> streams;  // (slot 0 runs on the member pstream, which is destroyed with the stream object)
     if (dinf) {
-        bool ok = hipSetDevice(device) == hipSuccess && (pstream || (pstream = stream_pool().take(device)) != nullptr);
-        streams[0] = pstream;
-        for (int k = 1; ok && k < kSlots; ++k) ok = (streams[k] = stream_pool().take(device)) != nullptr;
+        const bool ok = hipSetDevice(device) == hipSuccess && (pstream || (pstream = stream_pool().take(device)) != nullptr);
         if (!ok) {
             (void)hipGetLastError();
-            for (int k = 1; k < kSlots; ++k) stream_pool().give(device, streams[k]);
             dinf = false;
         }
+        streams.device = device;
+        streams.fallback = pstream;
     }
     DevSet sets[kSlots];
     if (dinf)
@@ -3399,17 +3416,16 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
     struct Cleanup {
         DevSet* s;
         int device;
-        hipStream_t* streams;
+        hipStream_t pst;
+        FrontStreams<kSlots>* streams;
         bool on;
         ~Cleanup() {
             if (!on) return;
-            for (int k = 0; k < kSlots; ++k) {
-                (void)hipStreamSynchronize(streams[k]);
-                if (k) stream_pool().give(device, streams[k]);
-                devset_pool().give(device, s[k]);
-            }
+            streams->settle_and_give();
+            (void)hipStreamSynchronize(pst);
+            for (int k = 0; k < kSlots; ++k) devset_pool().give(device, s[k]);
         }
-    } cleanup{sets, device, streams, dinf};
+    } cleanup{sets, device, pstream, &streams, dinf};
     // Every third piece of the look-ahead is inflated by the host threads instead (straight into its slot's
     // page-locked output, while the GPU works on the two in front of it): the chip turns a 64 KB block of BAM over
     // every 2.7 us = 24 GB/s of records, the 16 threads manage 11 GB/s, and between record walks they have nothing
@@ -3430,7 +3446,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
     auto submit = [&](Piece& pc, int index) -> bool {  // index: the piece's number among the submitted ones
         const int slot = index % kSlots;
         DevSet& S = sets[slot];
-        hipStream_t pstream = streams[slot];  // (shadows the member: this slot's stream)
+        hipStream_t pstream = slot ? streams.get(slot) : this->pstream;  // (shadows the member: this slot's stream)
         if (pc.total + kRoom + 64 >= (size_t(1) << 32)) return fail(FTK_ERR_FORMAT, "BGZF piece too large");
         slot_on_host[slot] = host_share > 0 && header_done && (index % host_share) == host_share - 1;
         if (slot_on_host[slot]) {
@@ -3790,12 +3806,9 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         (void)hipGetLastError();
         return fail(FTK_ERR_HIP, "cannot create the parse stream");
     }
-    hipStream_t streams[kSlots] = {};
-    for (auto& f : streams)
-        if ((f = stream_pool().take(device)) == nullptr) {
-            for (auto& g : streams) stream_pool().give(device, g);
-            return fail(FTK_ERR_HIP, "cannot create the inflate streams");
-        }
+    FrontStreams<kSlots> streams;
+    streams.device = device;
+    streams.fallback = pstream;
     DevSet sets[kSlots];
     for (auto& S : sets) S = devset_pool().take(device);
     uint8_t* d_wanted = nullptr;
@@ -3803,18 +3816,15 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         DevSet* s;
         int device;
         hipStream_t pst;
-        hipStream_t* streams;
+        FrontStreams<kSlots>* streams;
         uint8_t** wanted;
         ~Cleanup() {
-            for (int k = 0; k < kSlots; ++k) {
-                (void)hipStreamSynchronize(streams[k]);
-                stream_pool().give(device, streams[k]);
-            }
+            streams->settle_and_give();
             (void)hipStreamSynchronize(pst);
             for (int k = 0; k < kSlots; ++k) devset_pool().give(device, s[k]);
             if (*wanted) (void)hipFree(*wanted);
         }
-    } cleanup{sets, device, pstream, streams, &d_wanted};
+    } cleanup{sets, device, pstream, &streams, &d_wanted};
 
     struct Piece {
         size_t n = 0, used = 0, total = 0;
@@ -3867,7 +3877,7 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         struct Acc { double* d; std::chrono::steady_clock::time_point t0; ~Acc() { *d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } acc{&t_front, t_in};
         const int slot = index % kSlots;
         DevSet& S = sets[slot];
-        hipStream_t st = streams[slot];
+        hipStream_t st = streams.get(slot);
         if (S.pending) return fail(FTK_ERR_HIP, "buffer ring out of step");
         if (pc.total + kRoom + 64 >= (size_t(1) << 32)) {
             if (piece_bytes > kStreamPiece) {  // (a BAM that inflates > 40 x: once more with the standard pieces)
@@ -3957,7 +3967,7 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         DevSet& S = sets[pc.slot];
         DevSet* P = pc.has_prev ? &sets[pc.prev_slot] : nullptr;
         if (pc.on_host) {  // the host threads' text goes up on the slot's stream (behind the appends that read the set last)
-            hipStream_t st = streams[pc.slot];
+            hipStream_t st = streams.get(pc.slot);
             const auto t0 = tick();
             const int jrc = host_job[pc.slot].valid() ? host_job[pc.slot].get() : (int)FTK_OK;
             t_jobwait += since(t0);

@@ -18,8 +18,8 @@ from sys import stderr, stdout
 from typing import Union
 
 import numpy as np
-import pandas
 
+from .._lazy import LazyModule
 from ..genome.gaps import GenomeGaps
 from ..reference import ReferenceGenome
 from ..engine import Engine
@@ -28,6 +28,8 @@ from .. import sharding
 from ..utils import chrom_sizes_to_list, overlaps
 from ._delfi_gc_correct import delfi_gc_correct
 from ._delfi_merge_bins import delfi_merge_bins
+
+pandas = LazyModule("pandas")  # (imported by the first DELFI call, not by `import finaletoolkit_amd.frag`: 0.2-0.6 s)
 
 __all__ = ["delfi", "trim_coverage"]
 

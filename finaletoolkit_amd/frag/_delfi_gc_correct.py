@@ -10,7 +10,9 @@ installed, requesting GC correction raises ImportError (use
 from __future__ import annotations
 
 import numpy as np
-import pandas
+from .._lazy import LazyModule
+
+pandas = LazyModule("pandas")
 
 __all__ = ["delfi_gc_correct"]
 

@@ -11,7 +11,9 @@ per-window means.  Arms whose label holds neither ``p`` nor ``q`` are ignored.
 from __future__ import annotations
 
 import numpy as np
-import pandas as pd
+from .._lazy import LazyModule
+
+pd = LazyModule("pandas")
 
 __all__ = ["delfi_merge_bins"]
 

@@ -375,6 +375,8 @@ def test_single_process_calls_never_import_torch():
         "assert S.contig_owner({'a': 1.0})[:2] == (0, 1)\n"
         "S.agree(None); S.finalize()\n"
         "assert 'torch' not in sys.modules, sorted(m for m in sys.modules if m.startswith('torch'))[:5]\n"
+        "assert 'pandas' not in sys.modules  # (the DELFI frame's, imported by the first DELFI call)\n"
+        "assert finaletoolkit_amd.frag._delfi.pandas.DataFrame([], columns=['a']).shape == (0, 1) and 'pandas' in sys.modules\n"
         "print('ok')\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
