@@ -568,6 +568,8 @@ def rep_summary(runs):
     out.update(first_s=round(times[0], 4), median_s=round(float(np.median(times)), 4), best_s=round(min(times), 4),
                repetitions=len(times), all_s=[round(t, 4) for t in times],
                results_ok=bool(all(r.get("results_ok", True) for r in runs)))
+    if os.environ.get("FTK_BENCH_REP_STAGES") == "1":  # debugging aid: every repetition's stage split, not only the best one's
+        out["all_runs"] = [dict(r) for r in runs]
     return out
 
 

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -77,12 +78,17 @@ int reserve_scratch(ftk_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->scratch_bytes) return FTK_OK;
     // earlier work on the stream may still read the old scratch
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->scratch) HIPCHK(ctx, hipFree(ctx->scratch));
+    // The block comes from, and goes back to, the library's cache of idle device blocks: a context that is closed and
+    // opened again (one per file in a long-lived process, one per repetition in bench.py) then finds its scratch there.
+    // A fresh hipMalloc of 0.5 GB was seen to take 0.3-0.4 s now and then - when the process had just freed tens of GB
+    // (the allocation waits for the driver to finish with the memory it is handed) - in a call whose work is 3 ms.
+    if (ctx->scratch) ftk_host::device_block_give(ctx->scratch, ctx->scratch_bytes, ctx->device);
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
-    size_t want = align_up(bytes + bytes / 4, 1 << 20);
-    HIPCHK(ctx, hipMalloc(&ctx->scratch, want));
-    ctx->scratch_bytes = want;
+    size_t got = 0;
+    ctx->scratch = ftk_host::device_block_take(align_up(bytes + bytes / 4, 1 << 20), ctx->device, &got);
+    if (!ctx->scratch) return fail(ctx, FTK_ERR_OOM, "cannot allocate %zu bytes of device scratch", bytes);
+    ctx->scratch_bytes = got;
     return FTK_OK;
 }
 
@@ -355,7 +361,7 @@ void ftk_ctx_destroy(ftk_ctx* ctx) {
         if (ctx->narrow_stage[k]) ftk_host_free(ctx->narrow_stage[k]);
         if (ctx->narrow_done[k]) (void)hipEventDestroy(ctx->narrow_done[k]);
     }
-    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->scratch) ftk_host::device_block_give(ctx->scratch, ctx->scratch_bytes, ctx->device);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->copy_stream) {
         (void)hipStreamSynchronize(ctx->copy_stream);
@@ -1191,6 +1197,13 @@ int copy_scores_narrow(ftk_ctx* ctx, const int64_t* d_scores, int16_t* d_narrow,
     HIPCHK(ctx, hipMemcpyAsync(&misfit, d_misfit, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (misfit) return FTK_OK;
+    // FTK_WPS_TIMING=<ms>: a call that takes longer says where (stderr) - kernels, waits for chunks, widening
+    static const double slow_ms = getenv("FTK_WPS_TIMING") ? atof(getenv("FTK_WPS_TIMING")) : 0.0;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+    };
+    double t_wait = 0, t_widen = 0, widen_max = 0;
     const int nt = ftk_host::default_threads();
     const int64_t n_chunks = (n + kNarrowChunk - 1) / kNarrowChunk;
     for (int64_t c = 0; c <= n_chunks; ++c) {
@@ -1201,10 +1214,19 @@ int copy_scores_narrow(ftk_ctx* ctx, const int64_t* d_scores, int16_t* d_narrow,
         }
         if (c > 0) {  // ... while the host threads widen chunk c - 1
             const int64_t a = (c - 1) * kNarrowChunk, m = std::min(kNarrowChunk, n - a);
+            const auto t0 = std::chrono::steady_clock::now();
             HIPCHK(ctx, hipEventSynchronize(ctx->narrow_done[(c - 1) & 1]));
+            const auto t1 = std::chrono::steady_clock::now();
             widen_i16(static_cast<const int16_t*>(ctx->narrow_stage[(c - 1) & 1]), host_out + a, (size_t)m, nt);
+            const double w = ms_since(t1);
+            t_wait += std::chrono::duration<double, std::milli>(t1 - t0).count();
+            t_widen += w;
+            widen_max = std::max(widen_max, w);
         }
     }
+    if (slow_ms > 0 && ms_since(t_start) > slow_ms)
+        fprintf(stderr, "[ftk_wps] narrow copy of %lld scores: %.1f ms (waiting for chunks %.1f, widening %.1f - slowest of %lld chunks %.1f - on %d threads)\n",
+                (long long)n, ms_since(t_start), t_wait, t_widen, (long long)n_chunks, widen_max, nt);
     *done = true;
     return FTK_OK;
 }
@@ -1223,17 +1245,32 @@ int ftk_wps(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t ch
     if (!wps_out) return fail(ctx, FTK_ERR_INVALID, "wps_out is NULL");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int64_t n_pos = stop - start;
+    static const double slow_ms = getenv("FTK_WPS_TIMING") ? atof(getenv("FTK_WPS_TIMING")) : 0.0;
+    const auto t_call = std::chrono::steady_clock::now();
+    struct Slow {
+        double limit;
+        std::chrono::steady_clock::time_point t0;
+        long long n;
+        double reserve_ms = 0, kernel_ms = 0;
+        ~Slow() {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (limit > 0 && ms > limit)
+                fprintf(stderr, "[ftk_wps] %lld positions: %.1f ms (scratch %.1f, launch %.1f)\n", n, ms, reserve_ms, kernel_ms);
+        }
+    } slow{slow_ms, t_call, (long long)n_pos};
     const bool out_dev = is_device_ptr(wps_out);
     static const bool narrow_env = !(getenv("FTK_WPS_NARROW_WIRE") && atoi(getenv("FTK_WPS_NARROW_WIRE")) == 0);
     const bool narrow = !out_dev && narrow_env && n_pos >= kNarrowMin;
     const size_t wide_bytes = align_up((size_t)n_pos * 8);
     if (!out_dev && (rc = reserve_scratch(ctx, wide_bytes + (narrow ? align_up((size_t)n_pos * 2) + 256 : 0)))) return rc;
+    slow.reserve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
     int64_t* d_out = out_dev ? wps_out : (int64_t*)ctx->scratch;
     p.start = start;
     p.stop = stop;
     const int64_t n_tiles = (n_pos + kWpsTile - 1) / kWpsTile;
     launch_wps(ctx->stream, c->v, p, n_tiles, nullptr, nullptr, nullptr, nullptr, nullptr, d_out);
     HIPCHK(ctx, hipGetLastError());
+    slow.kernel_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count() - slow.reserve_ms;
     if (!out_dev) {
         bool done = false;
         if (narrow) {

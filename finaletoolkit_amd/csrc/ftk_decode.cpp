@@ -294,6 +294,12 @@ DeviceBlockCache& device_cache() {
     static DeviceBlockCache* c = new DeviceBlockCache();  // leaked: the driver frees at process exit
     return *c;
 }
+}  // namespace
+namespace ftk_host {
+void* device_block_take(size_t bytes, int device, size_t* cap_out) { return device_cache().take(bytes, device, cap_out, false); }
+void device_block_give(void* p, size_t cap, int device) { device_cache().give(p, cap, device); }
+}  // namespace ftk_host
+namespace {
 
 // A contig whose columns live in device memory (the streaming text decoder with the GPU row parser): ONE
 // block (start | end | mapq | strand at the block's row capacity), grown piece by piece with device-to-device
@@ -435,12 +441,33 @@ struct PinnedCache {
     const bool any_larger;   // reuse a block of any size >= the request
     const size_t max_bytes;  // held in the free list at most
     const size_t max_live;   // handed out at most (0: no limit); beyond it alloc() fails and the caller uses pageable memory
+    const bool pinned;       // false: ordinary (pageable) memory, recycled the same way - see plain_result_cache()
     size_t live_bytes = 0;
     std::mutex mu;
     std::vector<Blk> free_list;
     std::vector<Blk> live;  // capacity of the blocks handed out (needed when they come back)
     size_t cached = 0;
-    PinnedCache(bool any, size_t cap, size_t live_cap) : any_larger(any), max_bytes(cap), max_live(live_cap) {}
+    PinnedCache(bool any, size_t cap, size_t live_cap, bool pin = true)
+        : any_larger(any), max_bytes(cap), max_live(live_cap), pinned(pin) {}
+
+    void* fresh(size_t bytes) const {
+        void* p = nullptr;
+        if (pinned) {
+            if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            return p;
+        }
+        // 2 MB-aligned and advised huge: the first touch of a 2 GB result is then a thousand faults, not half a million
+        if (posix_memalign(&p, size_t(2) << 20, bytes) != 0) return nullptr;
+        (void)madvise(p, bytes, MADV_HUGEPAGE);
+        return p;
+    }
+    void drop(void* p) const {
+        if (pinned) (void)hipHostFree(p);
+        else free(p);
+    }
 
     void* alloc(size_t bytes) {
         {
@@ -465,11 +492,8 @@ struct PinnedCache {
                 return b.p;
             }
         }
-        void* p = nullptr;
-        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
+        void* p = fresh(bytes);
+        if (!p) return nullptr;
         std::lock_guard<std::mutex> lk(mu);
         live.push_back({p, bytes});
         live_bytes += bytes;
@@ -490,7 +514,7 @@ struct PinnedCache {
                 return true;
             }
         }
-        (void)hipHostFree(p);
+        drop(p);
         return true;
     }
     size_t trim() {  // unpin every idle block; returns the bytes released
@@ -502,7 +526,7 @@ struct PinnedCache {
         }
         size_t n = 0;
         for (auto& b : drop) {
-            (void)hipHostFree(b.p);
+            this->drop(b.p);
             n += b.cap;
         }
         return n;
@@ -521,6 +545,14 @@ PinnedCache& result_cache() {
         const long long mb = e ? atoll(e) : 8192;
         return new PinnedCache(true, size_t(6) << 30, (size_t)std::max<long long>(mb, 1) << 20);
     }();
+    return *c;
+}
+
+// Result arrays the DEVICE never writes (ftk_host_alloc_pageable: per-base scores that cross the link as int16 and are
+// widened into the array by the host threads): ordinary memory, kept between calls like the page-locked ones - a
+// block that went back to the C library would be unmapped and faulted in again by every call.
+PinnedCache& plain_result_cache() {
+    static PinnedCache* c = new PinnedCache(true, size_t(6) << 30, 0, /*pin=*/false);
     return *c;
 }
 
@@ -1436,8 +1468,15 @@ int ftk_host_alloc(int64_t bytes, void** out) {
     return FTK_OK;
 }
 
+int ftk_host_alloc_pageable(int64_t bytes, void** out) {
+    if (!out || bytes < 0) return dfail(FTK_ERR_INVALID, "ftk_host_alloc_pageable: bad argument");
+    *out = plain_result_cache().alloc((size_t)std::max<int64_t>(bytes, 1));
+    if (!*out) return dfail(FTK_ERR_OOM, "ftk_host_alloc_pageable: cannot allocate %lld bytes", (long long)bytes);
+    return FTK_OK;
+}
+
 void ftk_host_free(void* p) {
-    if (p) (void)result_cache().release(p);  // a pointer that is not one of ours is ignored
+    if (p && !result_cache().release(p)) (void)plain_result_cache().release(p);  // a pointer that is not one of ours is ignored
 }
 
 }  // extern "C"
@@ -4314,7 +4353,7 @@ extern "C" {
 // Give back what the library keeps for reuse between calls: idle page-locked blocks (decoded tables, result arrays),
 // idle device blocks of parsed contigs, the streams' idle buffer sets.  Nothing in use is touched.
 int64_t ftk_cache_trim(void) {
-    size_t n = table_cache().trim() + result_cache().trim();
+    size_t n = table_cache().trim() + result_cache().trim() + plain_result_cache().trim();
     if (have_hip_device()) {
         n += device_cache().trim() + devset_pool().trim();
         (void)stream_pool().trim();

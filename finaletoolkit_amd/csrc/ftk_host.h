@@ -13,6 +13,11 @@ void parallel_run_results(int n, const std::function<void(int)>& fn);
 // Threads a host-side parallel region uses by default: the cores this process may use (affinity and cgroup
 // quota), at most 64.
 int default_threads();
+// Device blocks that outlive their user (the decoders' contig blocks, a context's scratch): take() hands out the
+// smallest idle block of at least `bytes` on `device` or allocates one (nullptr: out of memory), give() keeps it for
+// the next taker (ftk_cache_trim releases the idle ones).  The giver has synchronised whatever used the block.
+void* device_block_take(size_t bytes, int device, size_t* cap_out);
+void device_block_give(void* p, size_t cap, int device);
 // Message behind ftk_fragtable_error() (thread-local), for host entry points that have no ctx.
 void set_decode_error(const char* msg);
 

@@ -52,12 +52,13 @@ def savgol_operators(window: int, deg: int):
 
 
 class _HostBlock:
-    """Owner of one page-locked host block (``ftk_host_alloc``); numpy arrays made from it keep it alive
-    through ``__array_interface__`` and the block goes back to the library's cache with the last of them."""
+    """Owner of one host block of the library's result caches (``ftk_host_alloc``: page-locked;
+    ``ftk_host_alloc_pageable``: ordinary memory); numpy arrays made from it keep it alive through
+    ``__array_interface__`` and the block goes back to the library's cache with the last of them."""
 
-    def __init__(self, lib, nbytes: int):
+    def __init__(self, lib, nbytes: int, pinned: bool = True):
         p = C.c_void_p()
-        rc = lib.ftk_host_alloc(int(nbytes), C.byref(p))
+        rc = (lib.ftk_host_alloc if pinned else lib.ftk_host_alloc_pageable)(int(nbytes), C.byref(p))
         if rc != 0:
             raise L.FtkError(rc, lib.ftk_fragtable_error().decode())
         self._lib, self._ptr = lib, p.value
@@ -76,6 +77,11 @@ class _HostBlock:
 # long leg of a per-base call); smaller ones are ordinary numpy arrays
 PINNED_RESULT_MIN = 8 << 20
 _PINNED_RESULTS = __import__("os").environ.get("FTK_PINNED_RESULTS", "1") != "0"
+# ftk_wps sends a host output of this many positions or more across the link as int16 and lets the host threads widen
+# it into the output (ftk_api.hip, kNarrowMin; FTK_WPS_NARROW_WIRE=0 keeps the plain copy): the device never writes
+# such an output, so page-locking it buys nothing and costs 0.2 ms per MB in a process's first call
+NARROW_WIRE_MIN = 1 << 22
+_NARROW_WIRE = __import__("os").environ.get("FTK_WPS_NARROW_WIRE", "1") != "0"
 
 
 class Engine:
@@ -115,16 +121,17 @@ class Engine:
     def __exit__(self, *exc):
         self.close()
 
-    def result_array(self, n: int, dtype) -> np.ndarray:
+    def result_array(self, n: int, dtype, pinned: bool = True) -> np.ndarray:
         """Uninitialised result array of ``n`` elements: page-locked (``ftk_host_alloc``) when large, so that
         the copy back from the device is one DMA; the memory returns to the library's cache when the array
-        (and every view of it) is gone."""
+        (and every view of it) is gone.  ``pinned=False``: a recycled block of ordinary memory
+        (``ftk_host_alloc_pageable``) for results the host threads fill."""
         dt = np.dtype(dtype)
         nbytes = int(n) * dt.itemsize
         if nbytes < PINNED_RESULT_MIN or not _PINNED_RESULTS:
             return np.empty(int(n), dt)
         try:
-            return np.asarray(_HostBlock(self.lib, nbytes)).view(dt)
+            return np.asarray(_HostBlock(self.lib, nbytes, pinned)).view(dt)
         except L.FtkError as e:
             if e.code != L.FTK_ERR_OOM:
                 raise
@@ -443,7 +450,10 @@ class Engine:
             max_length=180, quality_threshold=30, out=None):
         """a7: WPS per base of [start, stop) (frag/_wps.py:156-188)."""
         n_pos = max(int(stop) - int(start), 0)
-        res = self.result_array(n_pos, np.int64) if out is None else out  # every element is written by the call
+        if out is None:  # (every element is written by the call)
+            res = self.result_array(n_pos, np.int64, pinned=not (_NARROW_WIRE and n_pos >= NARROW_WIRE_MIN))
+        else:
+            res = out
         self._check(self.lib.ftk_wps(self.ctx, self.contig_id(name), int(start), int(stop), int(chrom_size),
                                      int(window_size), int(min_length), int(max_length), int(quality_threshold),
                                      L.ptr(res)))

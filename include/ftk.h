@@ -213,6 +213,12 @@ void ftk_fragtable_free(ftk_fragtable* t);
  * FTK_ERR_NO_DEVICE without a HIP device; FTK_ERR_OOM when the driver refuses or more than 8 GB
  * (FTK_PINNED_RESULT_LIMIT_MB) would be outstanding - the caller then uses ordinary memory. */
 int ftk_host_alloc(int64_t bytes, void** out);
+/* The same recycling for a result the DEVICE never writes: ordinary (pageable) memory, 2 MB-aligned.  ftk_wps with a
+ * host output of 4 M positions or more sends the scores across the link as int16 and the host threads widen them into
+ * the output (see ftk_wps) - page-locking such an output only costs its 0.2 ms per MB (0.4 s for a chr1 of scores, paid
+ * by the first call of a process = by every command-line call); the widening threads fault this one in in parallel.
+ * Works without a device.  Freed with ftk_host_free like the page-locked blocks. */
+int ftk_host_alloc_pageable(int64_t bytes, void** out);
 void ftk_host_free(void* p);
 /* Give back everything the library keeps for reuse between calls - idle page-locked blocks (decoded tables, result
  * arrays from ftk_host_alloc), idle device blocks of contigs parsed on the GPU, the streaming decoders' idle buffer

@@ -800,4 +800,15 @@ def test_wps_host_results_cross_the_link_narrow_and_arrive_exact(engine):
         assert (int(host.max()) > 32767) == (pile > 32767)
         # a short interval takes the plain copy: same numbers
         assert np.array_equal(engine.wps(name, 2_990_000, 3_010_000, size), host[2_990_000:3_010_000])
+        # the host threads fill such a result, so it lives in ordinary memory (ftk_host_alloc_pageable: nothing to
+        # page-lock in a process's first call) that the library recycles: the block of a dropped result serves the next
+        where, keep = host.ctypes.data, host.copy()
+        assert where % (2 << 20) == 0
+        del host
+        again = engine.wps(name, 0, size, size)
+        assert again.ctypes.data == where and np.array_equal(again, keep), name
+        # ... and into a page-locked array of the caller's (the round-4 default before) the numbers are the same
+        pinned = engine.result_array(size, np.int64)
+        assert pinned.ctypes.data != where and np.array_equal(engine.wps(name, 0, size, size, out=pinned), keep)
+        del again, pinned
         engine.release(name)
