@@ -733,6 +733,19 @@ def end_to_end(torch, reps: int = 3, cpu=None):
     res = {}
     try:
         threads = source.usable_cores()
+        # The resident workload of the timed steps (60+ GB) was handed back to the driver a moment ago, and the first
+        # large hipMalloc after such a release was seen to wait 0.3-0.6 s (FTK_WPS_TIMING: 0.57 s for the first leg's
+        # 0.5 GB of scratch; never in a process that had not freed anything).  That wait is this script's, not the
+        # path's, and it comes and goes (the driver cleans up behind the release): one second of rest and a 2 GB
+        # allocation take it here, before any leg's clock starts; device_settle_s says how long the allocation waited.
+        time.sleep(1.0)
+        t_settle = time.perf_counter()
+        pad = torch.empty(2 << 30, dtype=torch.uint8, device=dev)
+        pad.zero_()
+        torch.cuda.synchronize()
+        del pad
+        torch.cuda.empty_cache()
+        res["device_settle_s"] = round(time.perf_counter() - t_settle, 4)
         h2d = measure_h2d_gbs(torch, dev)
         rates = inflate_alone_rates()
 

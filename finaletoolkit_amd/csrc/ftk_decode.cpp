@@ -22,6 +22,7 @@
 #include <set>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include <dlfcn.h>
@@ -429,6 +430,77 @@ bool have_hip_device() {
     return yes;
 }
 
+// Page-locked host memory, large blocks.  hipHostMalloc allocates AND pins page by page on one thread - 0.2 ms per MB,
+// and concurrent calls serialise (8 x 96 MB: 174 ms one after the other, 171 ms from eight threads) - which was most of
+// what a process's first stream paid (a 5.9 GB BAM: 0.53 s first, 0.28 s warm; 163 ms of it the eight slots' staging).
+// The same memory from an anonymous mapping that asks for 2 MB pages, touched by a few threads, then REGISTERED
+// (hipHostRegister only pins what is there) takes 7.6 ms for the 768 MB, copies at the same 57 GB/s in both directions,
+// asynchronously like a hipHostMalloc block, and goes back in 11 ms instead of 45 (probe: docs/experiments.md,
+// "Page-locking").  FTK_PINNED_VIA=malloc keeps hipHostMalloc; a block that cannot be registered falls back to it.
+struct PinnedMaps {
+    std::mutex mu;
+    std::unordered_map<void*, size_t> mapped;  // registered mappings: base -> mapped bytes
+};
+PinnedMaps& pinned_maps() {
+    static PinnedMaps* m = new PinnedMaps();
+    return *m;
+}
+void* pinned_map(size_t bytes) {
+    static const bool via_malloc = [] {
+        const char* e = getenv("FTK_PINNED_VIA");
+        return e && strcmp(e, "malloc") == 0;
+    }();
+    void* p = nullptr;
+#if !defined(FTK_ASAN_BUILD)
+    if (!via_malloc && bytes >= (size_t(1) << 20)) {
+        const size_t m = huge_round(bytes);
+        uint8_t* q = huge_map(m);
+        if (q) {
+            // every 4 KB page present before the driver walks them (a 2 MB page: one fault for 512 of them)
+            const int nt = m >= (size_t(32) << 20) ? 8 : 1;
+            auto touch = [q, m, nt](int t) {
+                const size_t a = m / kHugePage * (size_t)t / (size_t)nt * kHugePage, b = m / kHugePage * (size_t)(t + 1) / (size_t)nt * kHugePage;
+                for (size_t o = a; o < b; o += 4096) q[o] = 0;
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t) th.emplace_back(touch, t);
+            touch(0);
+            for (auto& x : th) x.join();
+            if (hipHostRegister(q, m, hipHostRegisterDefault) == hipSuccess) {
+                std::lock_guard<std::mutex> lk(pinned_maps().mu);
+                pinned_maps().mapped[q] = m;
+                return q;
+            }
+            (void)hipGetLastError();
+            huge_unmap(q, m);
+        }
+    }
+#endif
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void pinned_unmap(void* p) {
+    if (!p) return;
+    size_t m = 0;
+    {
+        std::lock_guard<std::mutex> lk(pinned_maps().mu);
+        auto it = pinned_maps().mapped.find(p);
+        if (it != pinned_maps().mapped.end()) {
+            m = it->second;
+            pinned_maps().mapped.erase(it);
+        }
+    }
+    if (!m) {
+        (void)hipHostFree(p);
+        return;
+    }
+    (void)hipHostUnregister(p);
+    huge_unmap((uint8_t*)p, m);
+}
+
 // Page-locked blocks are recycled: hipHostMalloc has to pin every page (about 0.2 ms per MB), and a
 // streamed file asks for one block per contig and frees it a moment later.  A few freed blocks are kept
 // (at most 8, 2 GiB in total) and handed to the next request they fit without wasting more than half.
@@ -452,20 +524,14 @@ struct PinnedCache {
 
     void* fresh(size_t bytes) const {
         void* p = nullptr;
-        if (pinned) {
-            if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
-                (void)hipGetLastError();
-                return nullptr;
-            }
-            return p;
-        }
+        if (pinned) return pinned_map(bytes);
         // 2 MB-aligned and advised huge: the first touch of a 2 GB result is then a thousand faults, not half a million
         if (posix_memalign(&p, size_t(2) << 20, bytes) != 0) return nullptr;
         (void)madvise(p, bytes, MADV_HUGEPAGE);
         return p;
     }
     void drop(void* p) const {
-        if (pinned) (void)hipHostFree(p);
+        if (pinned) pinned_unmap(p);
         else free(p);
     }
 
@@ -2535,8 +2601,9 @@ struct DevSet {
     void release_inflate() {
         for (void* q : {(void*)d_comp, (void*)d_tab, (void*)d_crc, (void*)d_ist})
             if (q) (void)hipFree(q);
-        for (void* q : {(void*)h_tab, (void*)h_crc, (void*)h_ist, (void*)h_comp})
+        for (void* q : {(void*)h_tab, (void*)h_crc, (void*)h_ist})
             if (q) (void)hipHostFree(q);
+        pinned_unmap(h_comp);
         free(want_crc);
         d_comp = h_comp = nullptr; d_tab = h_tab = nullptr; d_crc = h_crc = want_crc = nullptr; d_ist = h_ist = nullptr;
         comp_cap = tab_cap = h_comp_cap = 0;
@@ -2544,7 +2611,7 @@ struct DevSet {
     void release() {
         release_inflate();
         release_bam();
-        if (h_text) (void)hipHostFree(h_text);
+        if (h_text) pinned_unmap(h_text);
         h_text_cap = 0;
         if (h_sum) (void)hipHostFree(h_sum);
         for (void* q : {(void*)d_text, (void*)d_blocks, (void*)d_s, (void*)d_e, (void*)d_q, (void*)d_t, (void*)d_sum})
@@ -2555,12 +2622,10 @@ struct DevSet {
     }
     bool ensure_host_comp(size_t comp_bytes) {
         if (comp_bytes <= h_comp_cap) return true;
-        if (h_comp) (void)hipHostFree(h_comp);
+        if (h_comp) pinned_unmap(h_comp);
         h_comp = nullptr;
         h_comp_cap = comp_bytes + comp_bytes / 4 + 4096;
-        if (hipHostMalloc((void**)&h_comp, h_comp_cap, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            h_comp = nullptr;
+        if ((h_comp = (uint8_t*)pinned_map(h_comp_cap)) == nullptr) {
             h_comp_cap = 0;
             return false;
         }
@@ -2604,12 +2669,10 @@ struct DevSet {
     // sets)
     bool ensure_host_text(size_t bytes) {
         if (bytes <= h_text_cap) return true;
-        if (h_text) (void)hipHostFree(h_text);
+        if (h_text) pinned_unmap(h_text);
         h_text = nullptr;
         h_text_cap = std::max(bytes + bytes / 4 + 4096, cap);
-        if (hipHostMalloc((void**)&h_text, h_text_cap, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            h_text = nullptr;
+        if ((h_text = (uint8_t*)pinned_map(h_text_cap)) == nullptr) {
             h_text_cap = 0;
             return false;
         }
