@@ -2067,6 +2067,13 @@ struct ftk_fragstream {
     bool emit_device_bam(Contig&& ct);
     std::set<int> emitted_refs;
     // single-contig requests with a usable index: read only the file range holding the contig
+    // pieces a whole-file read will come to (0 for an index-driven read of a contig or region: short, and its length is
+    // not the file's)
+    int pieces_expected() const {
+        struct stat sb;
+        if (read_end >= 0 || !fp || fstat(fileno(fp), &sb) != 0 || !S_ISREG(sb.st_mode) || piece_bytes == 0) return 0;
+        return (int)std::min<long long>((long long)sb.st_size / (long long)piece_bytes + 1, 1 << 20);
+    }
     long long read_end = -1;      // file offset to stop reading at (-1: none)
     bool partial_tail_ok = false;  // the range may end inside a block that belongs to the next contig
     size_t first_skip = 0;        // bytes of the first inflated block that precede the contig
@@ -2776,6 +2783,22 @@ struct StreamPool {
         }
         return s;
     }
+    void fill_to(int device, int n) {  // idle streams of `device` up to n (a helper thread's job: see FrontStreams::prefill)
+        for (;;) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                int have = 0;
+                for (auto& e : idle) have += e.first == device;
+                if (have >= n || idle.size() >= 16) return;
+            }
+            hipStream_t s = nullptr;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+                (void)hipGetLastError();
+                return;
+            }
+            give(device, s);
+        }
+    }
     void give(int device, hipStream_t s) {
         if (!s) return;
         {
@@ -2820,7 +2843,18 @@ struct FrontStreams {
         if (!s[k] && (s[k] = stream_pool().take(device)) == nullptr) return fallback;
         return s[k];
     }
+    // A file of many pieces will use the whole ring: a helper thread creates the streams the pool lacks while the
+    // producer reads and launches the first pieces (each get() then finds one idle instead of spending 5.5 ms).
+    std::thread filler;
+    void prefill(int n) {
+        if (n <= 0 || filler.joinable()) return;
+        const int dev = device;
+        filler = std::thread([dev, n] {
+            if (hipSetDevice(dev) == hipSuccess) stream_pool().fill_to(dev, std::min(n, N));
+        });
+    }
     void settle_and_give() {  // (the caller has set the device)
+        if (filler.joinable()) filler.join();
         for (auto& q : s)
             if (q) {
                 (void)hipStreamSynchronize(q);
@@ -2878,6 +2912,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     FrontStreams<kSets> fstream;
     fstream.device = device;
     fstream.fallback = pstream;
+    fstream.prefill(std::min(pieces_expected(), kSets) - 1);
     // FTK_DECODE_TIMING: the device time of every piece's front (copy up + inflate + CRC) and back (set-up + rows)
     hipEvent_t tev[kSets][5] = {};  // front start, front end, back start, back end, bytes up
     double front_ms = 0, front_max = 0, back_ms = 0, back_max = 0;
@@ -3511,6 +3546,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
         }
         streams.device = device;
         streams.fallback = pstream;
+        if (dinf) streams.prefill(std::min(pieces_expected(), kSlots) - 1);
     }
     DevSet sets[kSlots];
     if (dinf)
@@ -3911,6 +3947,7 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
     FrontStreams<kSlots> streams;
     streams.device = device;
     streams.fallback = pstream;
+    streams.prefill(std::min(pieces_expected(), kSlots) - 1);
     DevSet sets[kSlots];
     for (auto& S : sets) S = devset_pool().take(device);
     uint8_t* d_wanted = nullptr;
