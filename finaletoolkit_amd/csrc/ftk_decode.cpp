@@ -2088,13 +2088,31 @@ struct ftk_fragstream {
     long long hard_read_end = -1;  // where the contig's rows end (read_end of a whole-contig read)
     bool range_limited = false;    // the last read_piece() came back short because of read_end, not the file's end
     // One piece of the file -> dst; returns the bytes read (short at the end of the file / of the range).
-    size_t read_piece(uint8_t* dst) {
-        size_t want = piece_bytes;
+    // FTK_STREAM_RAMP=<bytes>: the first reads of a stream short - that many bytes, then twice as much each time up to
+    // piece_bytes.  The idea: a launch of the inflate kernel lasts one block's chain whatever its size, so the first
+    // rows would reach HBM after the time it takes to read and send up 4 MB instead of 48 (96 for a large BAM).
+    // Measured (tools/ramp_ab.sh, alternating runs on one box and file): the whole genome 0.123 -> 0.128 s, the 5.9 GB
+    // BAM 0.265 -> 0.272 s - the short launches fill the chip worse than the wait they save; OFF by default.  `base`
+    // is what a read asks for before any range limit; fewer bytes than that = the file, or the range, ended there
+    // (last_want, set by fill()).
+    size_t reads_issued = 0, last_want = 0, ahead_want = 0;
+    size_t next_want() {
+        static const size_t ramp0 = [] {
+            const char* e = getenv("FTK_STREAM_RAMP");
+            return e ? (size_t)std::max(0ll, atoll(e)) : (size_t)0;
+        }();
+        size_t w = piece_bytes;
+        if (ramp0 && reads_issued < 6) w = std::min(piece_bytes, ramp0 << reads_issued);
+        ++reads_issued;
+        return w;
+    }
+    size_t read_piece(uint8_t* dst, size_t base) {
+        size_t want = base;
         range_limited = false;
         if (read_end >= 0) {
             const long long pos = ftell(fp);
-            want = pos >= read_end ? 0 : (size_t)std::min<long long>((long long)piece_bytes, read_end - pos);
-            range_limited = want < piece_bytes;
+            want = pos >= read_end ? 0 : (size_t)std::min<long long>((long long)base, read_end - pos);
+            range_limited = want < base;
         }
         size_t got = 0;
         bool done = false;
@@ -2151,7 +2169,8 @@ struct ftk_fragstream {
     void start_ahead() {
         if (!ahead_ok || !ahead.reserve(kHead + piece_bytes)) return;
         ahead.head = 0;
-        ahead_got = std::async(std::launch::async, [this] { return read_piece(ahead.p + kHead); });
+        ahead_want = next_want();
+        ahead_got = std::async(std::launch::async, [this] { return read_piece(ahead.p + kHead, ahead_want); });
     }
     void drain_ahead() {  // before anything else moves the file position
         if (ahead_got.valid()) (void)ahead_got.get();
@@ -2204,6 +2223,7 @@ struct ftk_fragstream {
         }
         if (ahead_got.valid()) {
             got = ahead_got.get();
+            last_want = ahead_want;
             if (carry <= kHead) {
                 if (carry) memcpy(ahead.p + kHead - carry, buf.data() + carry_off, carry);
                 ahead.head = kHead - carry;
@@ -2231,9 +2251,10 @@ struct ftk_fragstream {
         } else {
             if (carry && carry_off) memmove(buf.data(), buf.data() + carry_off, carry);
             if (!buf.reserve(buf.head + carry + piece_bytes)) return carry;
-            got = read_piece(buf.data() + carry);
+            last_want = next_want();
+            got = read_piece(buf.data() + carry, last_want);
         }
-        if (got == piece_bytes) start_ahead();
+        if (got == last_want) start_ahead();
         return carry + got;
     }
     // seek to a contig's rows; false = index unusable (caller scans the whole file)
@@ -2462,7 +2483,7 @@ bool ftk_fragstream::run_text(RawBuf& buf, size_t n) {
     Contig cur;
     bool have_cur = false;
     std::set<std::string> seen;
-    bool eof = n < piece_bytes;
+    bool eof = n < last_want;
     for (;;) {
         size_t used = 0, total = 0;
         if (!whole_blocks(buf.data(), n, eof, &blocks, &used, &total)) return fail(FTK_ERR_FORMAT, "corrupt BGZF block");
@@ -2526,7 +2547,7 @@ bool ftk_fragstream::run_text(RawBuf& buf, size_t n) {
         clk.lap(5);
         n = fill(buf, raw_carry);
         clk.lap(0);
-        eof = n - raw_carry < piece_bytes;
+        eof = n - raw_carry < last_want;
         {
             std::lock_guard<std::mutex> lk(mu);
             if (stop) return false;
@@ -3226,7 +3247,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         }
         return true;
     };
-    bool eof = n < piece_bytes;
+    bool eof = n < last_want;
     // (region reads) this short read stopped at the linear index's hint, not at the end of the contig's rows: the piece
     // is parsed as one with more behind it, and the rows then say whether to read on
     auto at_soft_end = [&](size_t n_now) {
@@ -3406,7 +3427,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
             n = fill(buf, raw_carry_d, buf_in_flight ? used : 0);
             clk.lap(0);
             mark(k, "next piece read");
-            eof = n - raw_carry_d < piece_bytes;
+            eof = n - raw_carry_d < last_want;
             soft = at_soft_end(n);
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -3484,7 +3505,7 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         clk.lap(5);
         n = fill(buf, raw_carry);
         clk.lap(0);
-        eof = n - raw_carry < piece_bytes;
+        eof = n - raw_carry < last_want;
         {
             std::lock_guard<std::mutex> lk(mu);
             if (stop) return false;
@@ -3671,7 +3692,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
     Piece curp;
     std::deque<Piece> ahead;  // pieces behind curp that are already on the device, in file order
     curp.n = n_first;
-    curp.eof = n_first < piece_bytes;
+    curp.eof = n_first < last_want;
     int n_submitted = 0;
     for (;;) {
         if (!list_blocks(curp)) return false;
@@ -3689,7 +3710,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
                 Piece np;
                 np.n = fill(buf, raw_carry);
                 clk.lap(0);
-                np.eof = np.n - raw_carry < piece_bytes;
+                np.eof = np.n - raw_carry < last_want;
                 if (!list_blocks(np) || !submit(np, n_submitted++)) return false;
                 ahead.push_back(std::move(np));
             }
@@ -3772,7 +3793,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
                     carry = 0;
                     curp = Piece{};
                     curp.n = fill(buf, 0);
-                    curp.eof = curp.n < piece_bytes;
+                    curp.eof = curp.n < last_want;
                     pending_skip = first_skip;
                     first_skip = 0;
                     continue;
@@ -3888,7 +3909,7 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
             Piece np;
             np.n = fill(buf, raw_carry);
             clk.lap(0);
-            np.eof = np.n - raw_carry < piece_bytes;
+            np.eof = np.n - raw_carry < last_want;
             curp = std::move(np);
         }
         {
@@ -4155,7 +4176,7 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
     unsigned long long last_key = 0;    // the last record settled so far: (reference << 32) | position
     Piece curp;
     curp.n = n_first;
-    curp.eof = n_first < piece_bytes;
+    curp.eof = n_first < last_want;
     curp.file_off = 0;  // (run_guarded read the first piece from the start of the file)
     int n_submitted = 0;
     if (!list_blocks(curp)) return false;
@@ -4172,7 +4193,7 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
             Piece np;
             np.n = fill(buf, raw_carry, carry_at);
             clk.lap(0);
-            np.eof = np.n - raw_carry < piece_bytes;
+            np.eof = np.n - raw_carry < last_want;
             np.has_prev = true;
             np.prev_slot = last.slot;
             np.file_off = last.file_off >= 0 ? last.file_off + (long long)last.used : -1;
@@ -4267,7 +4288,7 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
                 const long long seek_pos = ftell(fp);
                 curp = Piece{};
                 curp.n = fill(buf, 0);
-                curp.eof = curp.n < piece_bytes;
+                curp.eof = curp.n < last_want;
                 curp.file_off = seek_pos;
                 curp.first_off = (uint32_t)first_skip;
                 first_skip = 0;

@@ -126,6 +126,8 @@ def test_device_contigs_growing_over_many_pieces(tmp_path):
     bgzf.write_frag_gz(p, rows, level=1)
     out = _child(p, threads=8, FTK_STREAM_PIECE=str(1 << 20))
     assert "['g0', 'g1', 'g2']" in out
+    # the first reads short, doubling up to the piece size (FTK_STREAM_RAMP, off by default): 64 KB -> 1 MB
+    assert "['g0', 'g1', 'g2']" in _child(p, threads=8, FTK_STREAM_PIECE=str(1 << 20), FTK_STREAM_RAMP="65536")
     # one piece per file: a contig's first block is sized by an arbitrary row count (not a multiple of 64)
     assert "['g0', 'g1', 'g2']" in _child(p, threads=8)
 

@@ -374,13 +374,15 @@ print("ok", order, "device_tables", n_device[0])
 """
 
 
-@pytest.mark.parametrize("piece,stretch", [(1 << 16, "64"), (1 << 16, "700"), (1 << 18, "4096"), (1 << 20, "16384"), (48 << 20, "16384")])
-def test_bam_records_parsed_on_the_device(tmp_path, piece, stretch):
+@pytest.mark.parametrize("piece,stretch,ramp", [(1 << 16, "64", None), (1 << 16, "700", None), (1 << 18, "4096", None),
+                                                (1 << 20, "16384", None), (48 << 20, "16384", None),
+                                                (1 << 20, "4096", "65536"), (1 << 19, "16384", "32768")])
+def test_bam_records_parsed_on_the_device(tmp_path, piece, stretch, ramp):
     """The same file with the RECORDS PARSED ON THE DEVICE (run_bam_device, ftk_bamparse.hip; the default): stretches
     from 64 bytes (several per record: most guesses are wrong and the fix passes settle the chain) to 16 KB, pieces from
     64 KB (records and the header's tail cut by piece ends, contig changes inside pieces) to one piece for the file; the
     tables hold device columns in stable fragment-start order and equal the whole-file host decoder's; one contig
-    through the BAI."""
+    through the BAI.  ``ramp``: the stream's first reads short, doubling up to the piece size (FTK_STREAM_RAMP)."""
     import os
     import subprocess
     import sys
@@ -397,8 +399,11 @@ def test_bam_records_parsed_on_the_device(tmp_path, piece, stretch):
         frags[name] = (s, s + rng.integers(210, 600, n), rng.integers(0, 61, n), rng.integers(0, 2, n).astype(bool))
     p = str(tmp_path / "multi.bam")
     write_synthetic_bam(p, contigs, frags)
+    env = dict(os.environ, FTK_STREAM_PIECE=str(piece), FTK_BAM_DEV_STRETCH=stretch, FTK_DECODE_TIMING="1")
+    if ramp:
+        env["FTK_STREAM_RAMP"] = ramp
     r = subprocess.run([sys.executable, "-c", _BAM_MULTI_CHILD.format(root=root), p], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, FTK_STREAM_PIECE=str(piece), FTK_BAM_DEV_STRETCH=stretch, FTK_DECODE_TIMING="1"))
+                       env=env)
     assert r.returncode == 0 and "ok ['chrA', 'chrB', 'chrC']" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
     assert "device_tables 7" in r.stdout, r.stdout[-500:]  # 3 + 3 + 1 tables, none through the host fall-back
     assert "parsed on the device" in r.stderr and "stretches of the record chain" not in r.stderr, r.stderr[-1500:]

@@ -91,7 +91,8 @@ print("ok", order)
 
 
 def _run_child(path, bam, contig, **extra):
-    env = dict(os.environ, FTK_STREAM_PIECE="65536", **extra)
+    env = dict(os.environ, FTK_STREAM_PIECE="65536")
+    env.update(extra)
     r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT), path, "1" if bam else "0", contig], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
@@ -108,6 +109,10 @@ def test_stream_small_pieces_text(tmp_path):
     bgzf.write_frag_gz(p, rows, level=1)
     out = _run_child(p, False, "c2")
     assert "['c0', 'c1', 'c2', 'c3']" in out
+    # a stream's first reads may be short and double up to the piece size (FTK_STREAM_RAMP, off by default; here
+    # 64 KB -> 1 MB): the end of the file is "fewer bytes than THAT read asked for", whichever size it had
+    assert "['c0', 'c1', 'c2', 'c3']" in _run_child(p, False, "c2", FTK_STREAM_PIECE=str(1 << 20), FTK_STREAM_RAMP="65536")
+    assert "['c0', 'c1', 'c2', 'c3']" in _run_child(p, False, "c2", FTK_STREAM_PIECE=str(1 << 20), FTK_STREAM_RAMP="0")
 
 
 def test_stream_small_pieces_bam(tmp_path):
@@ -124,6 +129,7 @@ def test_stream_small_pieces_bam(tmp_path):
     write_synthetic_bam(p, contigs, frags)
     out = _run_child(p, True, "chrB")
     assert "['chrA', 'chrB', 'chrC']" in out
+    assert "['chrA', 'chrB', 'chrC']" in _run_child(p, True, "chrB", FTK_STREAM_PIECE=str(1 << 19), FTK_STREAM_RAMP="65536")
     # the record chain walked as many speculative stretches per piece (4 KB: a dozen records each; 100 bytes:
     # shorter than a record, most stretches hold no record start)
     for stretch in ("4096", "100"):

@@ -16,12 +16,16 @@ from finaletoolkit_amd import bgzf, source, synth  # noqa: E402
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "bam"
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-tmp = tempfile.mkdtemp(prefix="ftk_first_")
+# FTK_PROBE_DIR=<dir>: the file is written there once and kept (several runs - A/B of an environment variable - on one file)
+keep = os.environ.get("FTK_PROBE_DIR")
+tmp = keep or tempfile.mkdtemp(prefix="ftk_first_")
+os.makedirs(tmp, exist_ok=True)
 W = 100_000
 if kind == "bam":
     contigs = [("small_a", 3_000_000), ("big", synth.B37_SIZES["1"]), ("small_c", 5_000_000)]
     path = os.path.join(tmp, "wg60x.bam")
-    synth.write_paired_bam_contigs(path, contigs, 60.0, 4242)
+    if not os.path.exists(path + ".bai"):
+        synth.write_paired_bam_contigs(path, contigs, 60.0, 4242)
     sizes = dict(contigs)
 else:
     names = list(synth.B37_SIZES)
@@ -31,7 +35,8 @@ else:
     def rows():
         for k, c in enumerate(names):
             yield (c,) + synth.synth_contig(sizes[c], 30.0, synth.SEED_BASE + k)
-    bgzf.write_frag_gz_contigs(path, rows(), level=1, with_index=False)
+    if not os.path.exists(path + ".tbi"):
+        bgzf.write_frag_gz_contigs(path, rows(), level=1, with_index=False)
 print(f"file {os.path.getsize(path) / 1e9:.2f} GB", file=sys.stderr)
 for rep in range(passes):
     source.close_all()
@@ -53,6 +58,7 @@ for rep in range(passes):
     print(f"pass {rep}: context {t_ctx:.3f} s, total {time.perf_counter() - t0:.3f} s, stages {src.decode_stage_ms}", file=sys.stderr)
     print("  (contig, resident at, scored at):", marks[:4], "...", marks[-2:], file=sys.stderr)
 source.close_all()
-for f in os.listdir(tmp):
-    os.remove(os.path.join(tmp, f))
-os.rmdir(tmp)
+if not keep:
+    for f in os.listdir(tmp):
+        os.remove(os.path.join(tmp, f))
+    os.rmdir(tmp)
