@@ -2091,7 +2091,7 @@ struct ftk_fragstream {
     // FTK_STREAM_RAMP=<bytes>: the first reads of a stream short - that many bytes, then twice as much each time up to
     // piece_bytes.  The idea: a launch of the inflate kernel lasts one block's chain whatever its size, so the first
     // rows would reach HBM after the time it takes to read and send up 4 MB instead of 48 (96 for a large BAM).
-    // Measured (tools/ramp_ab.sh, alternating runs on one box and file): the whole genome 0.123 -> 0.128 s, the 5.9 GB
+    // Measured (tools/env_ab.sh, alternating runs on one box and file): the whole genome 0.123 -> 0.128 s, the 5.9 GB
     // BAM 0.265 -> 0.272 s - the short launches fill the chip worse than the wait they save; OFF by default.  `base`
     // is what a read asks for before any range limit; fewer bytes than that = the file, or the range, ended there
     // (last_want, set by fill()).
