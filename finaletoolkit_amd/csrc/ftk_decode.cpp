@@ -2066,7 +2066,6 @@ struct ftk_fragstream {
     bool run_bam_device(RawBuf& first, size_t first_n);
     bool emit_device_bam(Contig&& ct);
     std::set<int> emitted_refs;
-    // single-contig requests with a usable index: read only the file range holding the contig
     // pieces a whole-file read will come to (0 for an index-driven read of a contig or region: short, and its length is
     // not the file's)
     int pieces_expected() const {
@@ -2074,6 +2073,7 @@ struct ftk_fragstream {
         if (read_end >= 0 || !fp || fstat(fileno(fp), &sb) != 0 || !S_ISREG(sb.st_mode) || piece_bytes == 0) return 0;
         return (int)std::min<long long>((long long)sb.st_size / (long long)piece_bytes + 1, 1 << 20);
     }
+    // single-contig requests with a usable index: read only the file range holding the contig
     long long read_end = -1;      // file offset to stop reading at (-1: none)
     bool partial_tail_ok = false;  // the range may end inside a block that belongs to the next contig
     size_t first_skip = 0;        // bytes of the first inflated block that precede the contig
