@@ -2627,10 +2627,9 @@ struct DevSet {
     }
 
     void release_inflate() {
-        for (void* q : {(void*)d_comp, (void*)d_tab, (void*)d_crc, (void*)d_ist})
+        for (void* q : {(void*)d_comp, (void*)d_tab})  // (d_crc / d_ist lie in d_tab's block, h_crc / h_ist in h_tab's)
             if (q) (void)hipFree(q);
-        for (void* q : {(void*)h_tab, (void*)h_crc, (void*)h_ist})
-            if (q) (void)hipHostFree(q);
+        if (h_tab) (void)hipHostFree(h_tab);
         pinned_unmap(h_comp);
         free(want_crc);
         d_comp = h_comp = nullptr; d_tab = h_tab = nullptr; d_crc = h_crc = want_crc = nullptr; d_ist = h_ist = nullptr;
@@ -2679,12 +2678,20 @@ struct DevSet {
             h_comp_cap = hc;
             tab_cap = n_blocks + n_blocks / 4 + 64;
             want_crc = (uint32_t*)malloc(tab_cap * 4);
-            ok = want_crc && hipMalloc((void**)&d_tab, tab_cap * sizeof(ftk::InflateBlock)) == hipSuccess &&
-                 hipHostMalloc((void**)&h_tab, tab_cap * sizeof(ftk::InflateBlock), hipHostMallocDefault) == hipSuccess &&
-                 hipMalloc((void**)&d_crc, tab_cap * 4) == hipSuccess &&
-                 hipHostMalloc((void**)&h_crc, tab_cap * 4, hipHostMallocDefault) == hipSuccess &&
-                 hipMalloc((void**)&d_ist, sizeof(ftk::InflateStatus)) == hipSuccess &&
-                 hipHostMalloc((void**)&h_ist, sizeof(ftk::InflateStatus), hipHostMallocDefault) == hipSuccess;
+            // block table | CRCs | status, ONE device block and ONE page-locked block (d_tab / h_tab are their bases): a
+            // small hipHostMalloc costs 1-8 ms in a process's first pass, a small hipMalloc ~1 ms, and a text stream's
+            // twelve sets made three of each
+            auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+            const size_t o_crc = up(tab_cap * sizeof(ftk::InflateBlock)), o_ist = o_crc + up(tab_cap * 4);
+            const size_t all = o_ist + up(sizeof(ftk::InflateStatus));
+            ok = want_crc && hipMalloc((void**)&d_tab, all) == hipSuccess &&
+                 hipHostMalloc((void**)&h_tab, all, hipHostMallocDefault) == hipSuccess;
+            if (ok) {
+                d_crc = (uint32_t*)((char*)d_tab + o_crc);
+                d_ist = (ftk::InflateStatus*)((char*)d_tab + o_ist);
+                h_crc = (uint32_t*)((char*)h_tab + o_crc);
+                h_ist = (ftk::InflateStatus*)((char*)h_tab + o_ist);
+            }
         }
         if (!ok) {
             (void)hipGetLastError();
