@@ -50,14 +50,13 @@ _FLAT_BY_MODULE = {
              "EndMotifsIntervals", "breakpoint_motifs", "region_breakpoint_motifs", "interval_breakpoint_motifs",
              "BreakpointMotifFreqs", "BreakpointMotifsIntervals", "CoverageResult", "FragLengthStats"),
     "utils": ("frag_generator", "frag_array", "frags_in_region", "agg_bw", "get_intervals", "overlaps", "gen_kmers",
-              "chrom_sizes_to_dict", "chrom_sizes_to_list"),
+              "chrom_sizes_to_dict", "chrom_sizes_to_list", "reverse_complement"),
     "genome": ("GenomeGaps", "ContigGaps", "ucsc_hg19_gap_bed", "b37_gap_bed", "ucsc_hg38_gap_bed"),
     "io": ("Fragment",),
 }
 _FLAT = {name: module for module, names in _FLAT_BY_MODULE.items() for name in names}
 _SINGULAR = {"end_motif": "end_motifs", "breakpoint_motif": "breakpoint_motifs"}
-_OUT_OF_SCOPE = ("filter_file", "frag_bam_to_bed", "low_quality_read_pairs", "reverse_complement", "ReferenceWrapper",
-                 "AlignmentWrapper")
+_OUT_OF_SCOPE = ("filter_file", "frag_bam_to_bed", "low_quality_read_pairs", "ReferenceWrapper", "AlignmentWrapper")
 
 
 def __getattr__(name):
@@ -103,8 +102,12 @@ def install_alias(name: str = "finaletoolkit", force: bool = False):
     for sub in _SUBMODULES + ("exceptions",):
         module = _importlib.import_module("." + sub, __name__)
         _sys.modules[f"{name}.{sub}"] = module
-    # the reference keeps its utilities in a package; ``finaletoolkit.utils.utils`` is the one deep path scripts use
+    # the reference keeps its utilities in a package; ``finaletoolkit.utils.utils`` and ``finaletoolkit.utils.validation``
+    # are the deep paths scripts (and the reference's own tests) use
     utils = _sys.modules[f"{name}.utils"]
     _sys.modules[f"{name}.utils.utils"] = utils
     utils.utils = utils
+    validation = _importlib.import_module(".validation", __name__)
+    _sys.modules[f"{name}.utils.validation"] = validation
+    utils.validation = validation
     return this

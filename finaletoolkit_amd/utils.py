@@ -17,7 +17,8 @@ from .exceptions import InvalidInputError
 from .source import get_engine, open_source
 
 __all__ = ["chrom_sizes_to_list", "chrom_sizes_to_dict", "get_intervals", "overlaps", "frags_in_region", "frag_generator",
-           "frag_array", "agg_bw", "gen_kmers"]
+           "frag_array", "agg_bw", "gen_kmers", "reverse_complement", "validate_compatible_contigs", "valid_interval",
+           "_none_eq", "_none_geq", "_none_leq"]
 
 FragTuple = Tuple[str, int, int, int, bool]
 
@@ -205,3 +206,28 @@ def agg_bw(input_file, interval_file, output_file, median_window_size: int = 1, 
     if verbose:
         stderr.write(f"Aggregating bigWig took {time.time() - t0} s to complete\n")
     return agg
+
+
+# ---- small pure helpers of the reference's utility layer (kept so that `finaletoolkit.utils.<name>` resolves) --------
+from .validation import valid_interval, validate_compatible_contigs  # noqa: E402
+
+_COMPLEMENT = str.maketrans("ACGTacgt", "TGCATGCA")
+
+
+def reverse_complement(kmer: str) -> str:
+    """utils/utils.py:413-437: the reverse complement of a DNA string - A/C/G/T in either case give the upper-case
+    complement, every other character (``N``) stays what it is."""
+    return kmer.translate(_COMPLEMENT)[::-1]
+
+
+def _none_leq(a, b) -> bool:
+    """utils/_comparison.py: ``a <= b`` where a missing operand means "unbounded" (true)."""
+    return a is None or b is None or a <= b
+
+
+def _none_geq(a, b) -> bool:
+    return a is None or b is None or a >= b
+
+
+def _none_eq(a, b) -> bool:
+    return a is None or b is None or a == b

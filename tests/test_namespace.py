@@ -21,10 +21,9 @@ ON_PATH = ["frag_length", "frag_length_bins", "frag_length_intervals", "coverage
            "end_motifs", "region_end_motifs", "interval_end_motifs", "EndMotifFreqs", "EndMotifsIntervals",
            "breakpoint_motifs", "region_breakpoint_motifs", "interval_breakpoint_motifs", "BreakpointMotifFreqs",
            "BreakpointMotifsIntervals", "frag_generator", "frag_array", "frags_in_region", "agg_bw", "get_intervals",
-           "overlaps", "gen_kmers", "chrom_sizes_to_dict", "chrom_sizes_to_list", "GenomeGaps", "ContigGaps",
+           "overlaps", "gen_kmers", "reverse_complement", "chrom_sizes_to_dict", "chrom_sizes_to_list", "GenomeGaps", "ContigGaps",
            "ucsc_hg19_gap_bed", "b37_gap_bed", "ucsc_hg38_gap_bed", "Fragment", "end_motif", "breakpoint_motif"]
-OFF_PATH = ["filter_file", "frag_bam_to_bed", "low_quality_read_pairs", "reverse_complement", "ReferenceWrapper",
-            "AlignmentWrapper"]
+OFF_PATH = ["filter_file", "frag_bam_to_bed", "low_quality_read_pairs", "ReferenceWrapper", "AlignmentWrapper"]
 
 
 @pytest.fixture()
@@ -151,3 +150,58 @@ def test_alias_in_a_fresh_process_cli_module(tmp_path):
             % (ROOT, os.path.join(DATA, "12.3444.b37.frag.gz")))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "2", out.stderr
+
+
+def test_validation_helpers_keep_the_references_contract(alias):
+    """``utils/validation.py`` of the reference, by the cases of its own ``tests/test_validation.py`` (29 of them:
+    return values, exception types, the words its tests match in the messages), imported the way it imports them."""
+    from finaletoolkit.utils.validation import valid_interval, validate_compatible_contigs
+    import finaletoolkit.utils as U
+    assert U.valid_interval is valid_interval and U.validate_compatible_contigs is validate_compatible_contigs
+    v = validate_compatible_contigs
+    assert v(["1", "2", "3"], ["1", "2", "3"]) and v(["1", "2", "3"], ["1", "2"])
+    with pytest.raises(ValueError, match="not found in reference"):
+        v(["1", "2"], ["1", "2", "4"])
+    assert not v(["1", "2"], ["1", "2", "4"], throw_on_error=False)
+    with pytest.raises(ValueError, match="not found in input"):
+        v(["1", "2", "3"], ["1", "2"], allow_subset=False)
+    assert not v(["1", "2", "3"], ["1", "2"], allow_subset=False, throw_on_error=False)
+    assert v(["1", "2"], ["1", "2"], allow_subset=False)
+    assert v({"1": 100, "2": 200}, {"1": 100, "2": 200}, validate_sizes=True)
+    with pytest.raises(RuntimeError, match="length mismatch"):
+        v({"1": 100, "2": 200}, {"1": 100, "2": 999}, validate_sizes=True)
+    assert not v({"1": 100, "2": 200}, {"1": 100, "2": 999}, validate_sizes=True, throw_on_error=False)
+    with pytest.raises(TypeError, match="requires both"):
+        v(["1", "2"], ["1", "2"], validate_sizes=True)
+    assert not v(["1", "2"], ["1", "2"], validate_sizes=True, throw_on_error=False)
+    assert v({"1": 100, "2": 999999}, {"1": 100}, validate_sizes=True)  # (only the input's contigs are measured)
+    i = valid_interval
+    assert not i(["1", "2"], "3")
+    with pytest.raises(ValueError, match="not found in reference"):
+        i(["1", "2"], "3", throw_on_error=True)
+    assert i({"1": 1000}, "1", start=0, stop=1000)
+    assert not i({"1": 1000}, "1", start=-1) and not i({"1": 1000}, "1", start=1000) and not i({"1": 1000}, "1", stop=-1)
+    with pytest.raises(IndexError, match="out of bounds"):
+        i({"1": 1000}, "1", start=-1, throw_on_error=True)
+    with pytest.raises(IndexError, match="out of bounds"):
+        i({"1": 1000}, "1", stop=1001, throw_on_error=True)
+    assert not i({"1": 1000}, "1", start=500, stop=500)
+    with pytest.raises(ValueError, match="must be less than stop"):
+        i({"1": 1000}, "1", start=500, stop=100, throw_on_error=True)
+    assert i({"1": 1000}, "1", start=999) and i({"1": 1000}, "1", stop=1000)
+    assert i(["1", "2"], "1", start=10 ** 9) and i(["1", "2"], "1") and not i(["1", "2"], "1", start=-1)
+    with pytest.raises(IndexError, match="cannot be negative"):
+        i(["1", "2"], "1", start=-1, throw_on_error=True)
+
+
+def test_small_pure_helpers():
+    """``reverse_complement`` (utils/utils.py:413-437: either case in, upper case out, anything else kept) and the
+    None-tolerant comparisons (utils/_comparison.py)."""
+    import finaletoolkit_amd as f
+    from finaletoolkit_amd.utils import _none_eq, _none_geq, _none_leq, reverse_complement
+    assert f.reverse_complement is reverse_complement
+    assert reverse_complement("ACGTN") == "NACGT" and reverse_complement("acgtn") == "nACGT" and reverse_complement("") == ""
+    assert reverse_complement("AAC-x") == "x-GTT"
+    assert _none_leq(None, 3) and _none_leq(3, None) and _none_leq(2, 3) and not _none_leq(4, 3)
+    assert _none_geq(None, 3) and _none_geq(3, None) and _none_geq(3, 3) and not _none_geq(2, 3)
+    assert _none_eq(None, 3) and _none_eq(3, None) and _none_eq(3, 3) and not _none_eq(2, 3)
