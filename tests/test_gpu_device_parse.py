@@ -130,6 +130,8 @@ def test_device_contigs_growing_over_many_pieces(tmp_path):
     assert "['g0', 'g1', 'g2']" in _child(p, threads=8, FTK_STREAM_PIECE=str(1 << 20), FTK_STREAM_RAMP="65536")
     # one piece per file: a contig's first block is sized by an arbitrary row count (not a multiple of 64)
     assert "['g0', 'g1', 'g2']" in _child(p, threads=8)
+    # page-locked blocks the old way (hipHostMalloc instead of a registered mapping: the fall-back of pinned_map)
+    assert "['g0', 'g1', 'g2']" in _child(p, threads=8, FTK_PINNED_VIA="malloc")
 
 
 @pytest.mark.parametrize("bed6", [False, True])
