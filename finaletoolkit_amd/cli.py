@@ -35,8 +35,30 @@ SHARDED_COMMANDS = ("coverage", "delfi", "wps", "cleavage-profile", "frag-length
                     "end-motifs", "interval-end-motifs", "breakpoint-motifs", "interval-breakpoint-motifs")
 
 
+class _Parser(argparse.ArgumentParser):
+    """argparse with the visible manners of the reference's Click group (its tests/test_cli.py:196-224): ``Usage:``
+    capitalised, an unknown subcommand answered with ``No such command``, exit status 2 for both."""
+
+    def format_usage(self):
+        return super().format_usage().replace("usage:", "Usage:", 1)
+
+    def format_help(self):
+        return super().format_help().replace("usage:", "Usage:", 1)
+
+    def error(self, message):
+        import re
+        m = re.match(r"argument command: invalid choice: '([^']*)'", message)
+        if m:
+            message = f"No such command '{m.group(1)}'."
+        self.print_usage(sys.stderr)
+        self.exit(2, f"Error: {message}\n")
+
+
 def build_parser() -> argparse.ArgumentParser:
-    ap = argparse.ArgumentParser(prog="finaletoolkit-amd", description="MI355X fragment-feature engine")
+    from . import __version__
+    ap = _Parser(prog="finaletoolkit-amd", description="MI355X fragment-feature engine")
+    ap.add_argument("--version", action="version",
+                    version=f"FinaleToolkit-AMD, version {__version__} (the MI355X hot path behind FinaleToolkit's interface)")
     ap.add_argument("--gpus", type=int, default=1, metavar="N",
                     help="run the command as N ranks, one per MI355X: contigs are dealt to the ranks, every rank "
                          "decodes and computes its own, the per-bin / per-interval vectors meet in one RCCL "

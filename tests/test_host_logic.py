@@ -165,6 +165,37 @@ def test_cli_flag_surface():
     assert p.parse_args(["frag-length-intervals", "in", "iv"]).short_reads == 150
 
 
+def test_cli_top_level_manners(capsys):
+    """What the reference's tests/test_cli.py:196-224 checks of its Click group, on this argparse one: --help and
+    --version exit 0 (the version line names FinaleToolkit), a bare call shows the usage (exit 0 or 2), an unknown
+    subcommand fails with "No such command", every subcommand answers --help with its usage."""
+    from finaletoolkit_amd.cli import build_parser
+    p = build_parser()
+
+    def run(argv):
+        try:
+            p.parse_args(argv)
+            code = 0
+        except SystemExit as e:
+            code = e.code
+        out = capsys.readouterr()
+        return code, out.out + out.err
+    code, text = run(["--help"])
+    assert code == 0 and "Usage" in text
+    code, text = run(["--version"])
+    assert code == 0 and "FinaleToolkit" in text
+    code, text = run([])
+    assert code in (0, 2) and "Usage" in text
+    code, text = run(["not-a-real-subcommand"])
+    assert code != 0 and "No such command" in text
+    commands = next(a for a in p._actions if a.dest == "command").choices
+    assert {"coverage", "frag-length-bins", "frag-length-intervals", "wps", "delfi", "cleavage-profile", "adjust-wps",
+            "end-motifs", "interval-end-motifs", "mds", "regional-mds", "agg-bw", "gap-bed"} <= set(commands)
+    for name in commands:
+        code, text = run([name, "--help"])
+        assert code == 0 and "Usage" in text, name
+
+
 def test_split_units_partition_and_balance():
     from finaletoolkit_amd import synth
     from finaletoolkit_amd.sharding import split_units, unit_halo
