@@ -196,6 +196,30 @@ def test_cli_top_level_manners(capsys):
         assert code == 0 and "Usage" in text, name
 
 
+def test_cli_flags_are_exactly_the_target_functions_arguments():
+    """The reference's tests/test_cli.py:41-78 on this command line: every flag of a command is an argument of the
+    function it calls, and every argument of that function is a flag (but the deprecated ``fraction_low`` /
+    ``fraction_high`` / ``gc_correct``); ``--strand`` stands for ``both_strands`` / ``negative_strand``."""
+    import inspect
+    from finaletoolkit_amd import frag, utils
+    from finaletoolkit_amd.cli import build_parser
+    commands = next(a for a in build_parser()._actions if a.dest == "command").choices
+    targets = {"coverage": frag.coverage, "frag-length-bins": frag.frag_length_bins,
+               "frag-length-intervals": frag.frag_length_intervals, "wps": frag.multi_wps, "adjust-wps": frag.adjust_wps,
+               "agg-bw": utils.agg_bw, "cleavage-profile": frag.multi_cleavage_profile, "end-motifs": frag.end_motifs,
+               "interval-end-motifs": frag.interval_end_motifs, "breakpoint-motifs": frag.breakpoint_motifs,
+               "interval-breakpoint-motifs": frag.interval_breakpoint_motifs, "delfi": frag.delfi}
+    assert set(commands) - set(targets) == {"mds", "regional-mds", "gap-bed"}  # (CLI-only shims in the reference too)
+    for name, fn in targets.items():
+        flags = [a.dest for a in commands[name]._actions if a.dest != "help"]
+        if "strand" in flags:
+            flags.remove("strand")
+            flags += ["both_strands", "negative_strand"]
+        args = set(inspect.signature(fn).parameters)
+        assert not [f for f in flags if f not in args], name
+        assert not [a for a in args if a not in flags and a not in ("fraction_low", "fraction_high", "gc_correct")], name
+
+
 def test_split_units_partition_and_balance():
     from finaletoolkit_amd import synth
     from finaletoolkit_amd.sharding import split_units, unit_halo
