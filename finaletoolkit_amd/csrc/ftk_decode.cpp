@@ -501,10 +501,9 @@ void pinned_unmap(void* p) {
     huge_unmap((uint8_t*)p, m);
 }
 
-// Page-locked blocks are recycled: hipHostMalloc has to pin every page (about 0.2 ms per MB), and a
-// streamed file asks for one block per contig and frees it a moment later.  A few freed blocks are kept
-// (at most 8, 2 GiB in total) and handed to the next request they fit without wasting more than half.
-// Page-locked blocks are recycled: pinning costs ~0.07-0.2 ms per MB, unpinning about as much.  Two
+// Page-locked blocks are recycled (a streamed file asks for one block per contig and frees it a moment later; a
+// fresh block is cheap since pinned_map - ~0.01 ms per MB - but not free, and hipHostMalloc, its fall-back, pins at
+// ~0.2 ms per MB and unpins about as slowly).  Two
 // caches: the decoder's contig tables (a block is reused for a request of at least half its size, so that
 // a small table does not sit on a huge block), and the callers' result arrays (ftk_host_alloc: any block
 // that is large enough - results shrink from contig to contig and one block then serves them all).

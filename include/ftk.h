@@ -209,13 +209,14 @@ void ftk_fragtable_free(ftk_fragtable* t);
 
 /* Page-locked host memory for large result arrays (the per-base scores of frag/_wps.py:181-188 are
  * 8 bytes a base): a device -> host copy into it is one DMA at PCIe speed, into pageable memory a staged
- * copy at a third to half of that.  Blocks are recycled by ftk_host_free (pinning costs ~0.2 ms per MB).
+ * copy at a third to half of that.  Blocks are recycled by ftk_host_free (a fresh one is a 2 MB-page mapping touched by
+ * a few threads and registered with the driver: ~0.01 ms per MB; hipHostMalloc, the fall-back, ~0.2 ms per MB).
  * FTK_ERR_NO_DEVICE without a HIP device; FTK_ERR_OOM when the driver refuses or more than 8 GB
  * (FTK_PINNED_RESULT_LIMIT_MB) would be outstanding - the caller then uses ordinary memory. */
 int ftk_host_alloc(int64_t bytes, void** out);
 /* The same recycling for a result the DEVICE never writes: ordinary (pageable) memory, 2 MB-aligned.  ftk_wps with a
  * host output of 4 M positions or more sends the scores across the link as int16 and the host threads widen them into
- * the output (see ftk_wps) - page-locking such an output only costs its 0.2 ms per MB (0.4 s for a chr1 of scores, paid
+ * the output (see ftk_wps) - page-locking such an output buys nothing and took 0.2 ms per MB when this entry point was added (0.4 s for a chr1 of scores, paid
  * by the first call of a process = by every command-line call); the widening threads fault this one in in parallel.
  * Works without a device.  Freed with ftk_host_free like the page-locked blocks. */
 int ftk_host_alloc_pageable(int64_t bytes, void** out);
@@ -224,7 +225,7 @@ void ftk_host_free(void* p);
  * arrays from ftk_host_alloc), idle device blocks of contigs parsed on the GPU, the streaming decoders' idle buffer
  * sets (up to four per process, ~1 GB of page-locked and ~2 GB of device memory after a large text stream).  Blocks
  * in use are not touched.  Returns the bytes released (a lower bound).  For long-lived processes between jobs; the
- * next call that needs a block allocates it again (page-locking costs ~0.1-0.2 ms per MB). */
+ * next call that needs a block allocates it again (~0.01 ms per MB for the page-locked ones). */
 int64_t ftk_cache_trim(void);
 /* Upload contig i of a decoded table (including the BAM read1 columns) as contig_id: the
  * decode -> pinned SoA -> hipMemcpyAsync leg of the pipeline, without a detour through the caller. */
