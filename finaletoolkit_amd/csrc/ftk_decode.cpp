@@ -3962,10 +3962,15 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
     const int device = inflate_device;
     constexpr size_t kRoom = size_t(32) << 20;
     constexpr int kAhead = 7, kSlots = kAhead + 1;  // (3 ahead: the 60x slice 0.050 s; 5: 0.038-0.044; 7: 0.036-0.042)
-    static const uint32_t stretch_bytes = [] {  // FTK_BAM_DEV_STRETCH: tests walk tiny stretches
+    // bytes of records per thread of the chain walk (FTK_BAM_DEV_STRETCH: tests walk tiny stretches).  A thread follows
+    // its stretch's records link by link - dependent loads - so shorter stretches are shorter chains on more threads,
+    // until the guesses at their starts and the fix passes cost more than they save: the 5.9 GB BAM, warm passes
+    // alternated on one box (tools/env_ab.sh), 32 KB 0.284-0.300 s, 16 KB (rounds 3-4) 0.253-0.287, 8 KB 0.248-0.269,
+    // 4 KB 0.250-0.270, 2 KB 0.254-0.268, 1 KB 0.283-0.314
+    static const uint32_t stretch_bytes = [] {
         const char* e = getenv("FTK_BAM_DEV_STRETCH");
         const long v = e ? atol(e) : 0;
-        return (uint32_t)(v >= 64 ? v : 16384);
+        return (uint32_t)(v >= 64 ? v : 8192);
     }();
     if (hipSetDevice(device) != hipSuccess || (!pstream && (pstream = stream_pool().take(device)) == nullptr)) {
         (void)hipGetLastError();
