@@ -53,7 +53,9 @@ EXPORTS = [
     "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals", "ftk_wps_adjust",
     "ftk_ref_upload", "ftk_ref_upload_file", "ftk_ref_release", "ftk_ref_gc_counts", "ftk_ref_set_layout", "ftk_motif_counts",
     "ftk_format_wig_i64", "ftk_format_bedgraph_i64", "ftk_format_bedgraph_f64", "ftk_buffer_free", "ftk_file_write", "ftk_gzip_members",
-    "ftk_bigwig_fixedstep_sections", "ftk_format_frag_rows", "ftk_bgzf_write", "ftk_fill_wps_records", "ftk_bgzf_inflate_device",
+    "ftk_bigwig_fixedstep_sections", "ftk_format_frag_rows", "ftk_bgzf_write", "ftk_synth_bam_contig", "ftk_fill_wps_records", "ftk_bgzf_inflate_device",
+    "ftk_comm_unique_id", "ftk_comm_create", "ftk_comm_size", "ftk_allgather_i64", "ftk_allreduce_sum_i64", "ftk_comm_send",
+    "ftk_comm_recv", "ftk_comm_join", "ftk_comm_destroy",
 ]
 
 
@@ -198,6 +200,8 @@ def load() -> C.CDLL:
     lib.ftk_bgzf_inflate_device.argtypes = [vp, vp, i64, vp, i64, pi64]
     lib.ftk_fill_wps_records.argtypes = [vp, i64, vp, i64, vp, C.c_int]
     lib.ftk_bgzf_write.argtypes = [C.c_char_p, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.ftk_synth_bam_contig.argtypes = [C.c_char_p, i32, i64, vp, vp, vp, vp, i64, i32, i32, C.c_uint64, C.c_int, C.c_int,
+                                         vp, i64, pi64, pi64, pi64]
     lib.ftk_file_write.argtypes = [C.c_char_p, vp, i64, C.c_int, C.c_int, C.c_int]
     lib.ftk_gzip_members.argtypes = [vp, i64, C.c_int, C.c_int, pp, pi64]
     lib.ftk_bigwig_fixedstep_sections.argtypes = [C.c_uint32, vp, vp, i64, vp, C.c_int, i32, C.c_int, C.c_int, pp, pi64,
@@ -289,6 +293,16 @@ def load() -> C.CDLL:
     lib.ftk_ref_gc_counts.argtypes = [vp, C.c_int, vp, vp, i64, vp]
     lib.ftk_ref_set_layout.argtypes = [vp, C.c_int, i64, i32, i32, vp, vp, i64]
     lib.ftk_motif_counts.argtypes = [vp, C.c_int, C.c_int, vp, vp, i64, C.POINTER(Motif), i32, i32, vp, vp, vp]
+    lib.ftk_comm_unique_id.argtypes = [C.c_char_p]
+    lib.ftk_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]
+    lib.ftk_comm_size.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.ftk_allgather_i64.argtypes = [vp, vp, i64, vp]
+    lib.ftk_allreduce_sum_i64.argtypes = [vp, vp, i64]
+    lib.ftk_comm_send.argtypes = [vp, C.c_int, vp, i64]
+    lib.ftk_comm_recv.argtypes = [vp, C.c_int, vp, i64]
+    lib.ftk_comm_join.argtypes = [vp]
+    lib.ftk_comm_destroy.argtypes = [vp]
+    lib.ftk_comm_destroy.restype = None
     _lib = lib
     return lib
 

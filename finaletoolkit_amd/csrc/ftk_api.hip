@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <type_traits>
 
@@ -554,9 +555,19 @@ int ftk_frags_set_read1(ftk_ctx* ctx, int contig_id, const int32_t* r1_start, co
         HIPCHK(ctx, hipMemcpyAsync(c->r1, r1_start, n * 4, k, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync((char*)c->r1 + b, r1_end, n * 4, k, ctx->stream));
     }
+    // do all fragments hold their read1 span?  (ContigView::r1_inside: the kernels then read these columns only for
+    // fragments that cross a window bound)
+    int bad = 0;
+    if (!ctx->d_stats) HIPCHK(ctx, hipMalloc(&ctx->d_stats, sizeof(FragStats)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(int), ctx->stream));
+    launch_r1_inside(ctx->stream, c->v.start, c->v.end, c->r1, (const int32_t*)((char*)c->r1 + b), (int)n, (int*)ctx->d_stats);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(&bad, ctx->d_stats, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     c->v.r1_start = c->r1;
     c->v.r1_end = (int32_t*)((char*)c->r1 + b);
+    static const bool r1_always = getenv("FTK_R1_ALWAYS") && atoi(getenv("FTK_R1_ALWAYS")) != 0;  // tests: both code paths
+    c->v.r1_inside = (bad == 0 && !r1_always) ? 1 : 0;
     return FTK_OK;
 }
 
@@ -1460,9 +1471,12 @@ int ftk_wps_window_features(ftk_ctx* ctx, int contig_id, int64_t start, int64_t 
     if ((rc = wps_params(ctx, *c, chrom_size, window_size, min_len, max_len, mapq_min, &p))) return rc;
     const bool ch = count_out || hist_out, df = short_out || long_out;
     if (!wps_out || (!ch && !df)) return fail(ctx, FTK_ERR_INVALID, "needs wps_out and at least one feature output");
-    if (c->v.r1_start) return fail(ctx, FTK_ERR_INVALID, "the fused pass takes tabix-style contigs (no read1 columns)");
-    if (ch && (!f || f->policy != FTK_POLICY_MIDPOINT || f->fetch_mode != FTK_FETCH_TABIX))
-        return fail(ctx, FTK_ERR_INVALID, "the fused pass needs a midpoint-policy, tabix-fetch filter");
+    if (ch && (!f || f->policy != FTK_POLICY_MIDPOINT))
+        return fail(ctx, FTK_ERR_INVALID, "the fused pass needs a midpoint-policy filter");
+    if (ch && (rc = check_filter(ctx, f, *c))) return rc;
+    // fetch semantics as everywhere else: read1 overlap (io/alignment.py:245) on a contig with read1 columns unless
+    // the filter asks for the tabix rule
+    const bool bam = c->v.r1_start != nullptr && (!ch || f->fetch_mode == FTK_FETCH_BAM_READ1);
     if (df && (!short_out || !long_out)) return fail(ctx, FTK_ERR_INVALID, "NULL DELFI output pointer");
     if (hist_out && (n_bins <= 0 || n_bins > 8192 || !overflow_out))
         return fail(ctx, FTK_ERR_INVALID, "histogram needs n_bins in [1, 8192] and overflow_out");
@@ -1480,6 +1494,7 @@ int ftk_wps_window_features(ftk_ctx* ctx, int contig_id, int64_t start, int64_t 
     F.win_start = win_start;
     F.win_len = win_len;
     F.n_win = n_win;
+    F.bam = bam;
     if (ch) {
         F.ch_q = std::min(std::max(f->mapq_min, 0), 256);
         F.ch_min = f->min_len < 0 ? 0 : std::min(f->min_len, 1 << 30);
@@ -2071,6 +2086,318 @@ int ftk_bgzf_inflate_device(ftk_ctx* ctx, const uint8_t* file_bytes, int64_t n, 
             return fail(ctx, FTK_ERR_FORMAT, "device inflate: CRC mismatch in BGZF block %zu (%08x, trailer says %08x)", k,
                         got_crc[k], want_crc[k]);
     return FTK_OK;
+}
+
+}  // extern "C"
+
+// ---- the exchange between the ranks of one node: RCCL behind the C ABI ---------------------------------------------
+// SURVEY section 8-b's export list ends with the two collectives that stand where the reference gathers its Pool's
+// results (frag/_delfi.py:289-300: imap over the bins -> one list; frag/_coverage.py:215-227: the interval counts and
+// the genome-wide total): one all-gather of fixed-size int64 rows and one int64 all-reduce.  One rank per GPU; the
+// library is NOT linked against RCCL: librccl is resolved when the first communicator is created (a process that holds
+// torch's copy already re-uses it: same soname), so one-GPU hosts never load it.
+// A communicator belongs to a ctx.  A collective is enqueued on the communicator's OWN stream behind whatever the ctx
+// stream holds at the call (an event), so kernels launched on the ctx stream afterwards run beside it; device results
+// are complete for the ctx stream after ftk_comm_join (another event, no host wait), host results when the call returns.
+#include <rccl/rccl.h>
+
+#include <sys/stat.h>
+
+struct ftk_comm {
+    ftk_ctx* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_done = nullptr;
+    void* stage = nullptr;  // device staging for host buffers
+    size_t stage_bytes = 0;
+    std::string id_path;    // rank 0: the rendezvous file it wrote (removed with the communicator)
+};
+
+namespace {
+
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi* rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a librccl already in the process (torch's) is re-used: same soname
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) return;
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+        api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+        api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+        api.Send = (decltype(api.Send))dlsym(api.lib, "ncclSend");
+        api.Recv = (decltype(api.Recv))dlsym(api.lib, "ncclRecv");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+        api.CommAbort = (decltype(api.CommAbort))dlsym(api.lib, "ncclCommAbort");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    });
+    const bool ok = api.lib && api.GetUniqueId && api.CommInitRank && api.AllGather && api.AllReduce && api.Send &&
+                    api.Recv && api.CommDestroy;
+    return ok ? &api : nullptr;
+}
+
+#define RCCLCHK(ctx, call)                                                                                        \
+    do {                                                                                                          \
+        ncclResult_t r_ = (call);                                                                                 \
+        if (r_ != ncclSuccess)                                                                                    \
+            return fail(ctx, FTK_ERR_HIP, "%s: %s", #call, rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "RCCL error"); \
+    } while (0)
+
+constexpr size_t kIdHex = 2 * NCCL_UNIQUE_ID_BYTES;
+
+void id_to_hex(const ncclUniqueId& id, char* hex) {
+    static const char d[] = "0123456789abcdef";
+    for (int i = 0; i < NCCL_UNIQUE_ID_BYTES; ++i) {
+        hex[2 * i] = d[((unsigned char)id.internal[i]) >> 4];
+        hex[2 * i + 1] = d[((unsigned char)id.internal[i]) & 15];
+    }
+    hex[kIdHex] = 0;
+}
+
+bool hex_to_id(const char* hex, ncclUniqueId* id) {
+    auto v = [](char c) { return c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1; };
+    for (int i = 0; i < NCCL_UNIQUE_ID_BYTES; ++i) {
+        const int a = v(hex[2 * i]), b = a < 0 ? -1 : v(hex[2 * i + 1]);
+        if (a < 0 || b < 0) return false;
+        id->internal[i] = (char)(a << 4 | b);
+    }
+    return true;
+}
+
+bool looks_like_hex_id(const char* s) {
+    if (strlen(s) != kIdHex) return false;
+    ncclUniqueId t;
+    return hex_to_id(s, &t);
+}
+
+// device staging of the communicator (host buffers of a collective), grown on demand
+int comm_stage(ftk_comm* c, size_t bytes) {
+    if (bytes <= c->stage_bytes) return FTK_OK;
+    ftk_ctx* ctx = c->ctx;
+    HIPCHK(ctx, hipStreamSynchronize(c->stream));
+    if (c->stage) (void)hipFree(c->stage);
+    c->stage = nullptr;
+    c->stage_bytes = 0;
+    HIPCHK(ctx, hipMalloc(&c->stage, align_up(bytes, 1 << 16)));
+    c->stage_bytes = align_up(bytes, 1 << 16);
+    return FTK_OK;
+}
+
+// the communicator's stream behind the ctx stream's work of this moment
+int comm_fork(ftk_comm* c) {
+    HIPCHK(c->ctx, hipSetDevice(c->ctx->device));
+    HIPCHK(c->ctx, hipEventRecord(c->ev_fork, c->ctx->stream));
+    HIPCHK(c->ctx, hipStreamWaitEvent(c->stream, c->ev_fork, 0));
+    return FTK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ftk_comm_unique_id(char* hex_out) {
+    if (!hex_out) return fail(nullptr, FTK_ERR_INVALID, "hex_out is NULL");
+    RcclApi* a = rccl();
+    if (!a) return fail(nullptr, FTK_ERR_NO_DEVICE, "librccl could not be loaded");
+    ncclUniqueId id;
+    RCCLCHK(nullptr, a->GetUniqueId(&id));
+    id_to_hex(id, hex_out);
+    return FTK_OK;
+}
+
+int ftk_comm_create(ftk_ctx* ctx, int rank, int world, const char* id_hex_or_path, ftk_comm** out) {
+    if (!ctx || !out) return fail(ctx, FTK_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail(ctx, FTK_ERR_INVALID, "bad rank %d / world %d", rank, world);
+    if (!id_hex_or_path && world > 1) return fail(ctx, FTK_ERR_INVALID, "ranks of a job need a common id (hex digits or a file path)");
+    RcclApi* a = rccl();
+    if (!a) return fail(ctx, FTK_ERR_NO_DEVICE, "librccl could not be loaded (dlopen librccl.so.1)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    std::string wrote;
+    if (!id_hex_or_path) {
+        RCCLCHK(ctx, a->GetUniqueId(&uid));
+    } else if (looks_like_hex_id(id_hex_or_path)) {
+        hex_to_id(id_hex_or_path, &uid);
+    } else if (rank == 0) {
+        // rendezvous through a file: rank 0 writes the id next to the final name and renames it into place, so that
+        // a reader never sees part of it
+        RCCLCHK(ctx, a->GetUniqueId(&uid));
+        char hex[kIdHex + 1];
+        id_to_hex(uid, hex);
+        const std::string tmp = std::string(id_hex_or_path) + ".tmp" + std::to_string((long long)getpid());
+        FILE* fh = fopen(tmp.c_str(), "w");
+        if (!fh || fwrite(hex, 1, kIdHex, fh) != kIdHex || fclose(fh) != 0 || rename(tmp.c_str(), id_hex_or_path) != 0) {
+            if (fh) (void)remove(tmp.c_str());
+            return fail(ctx, FTK_ERR_IO, "cannot write the rendezvous file %s: %s", id_hex_or_path, strerror(errno));
+        }
+        wrote = id_hex_or_path;
+    } else {
+        static const double limit_s = getenv("FTK_COMM_TIMEOUT_S") ? atof(getenv("FTK_COMM_TIMEOUT_S")) : 600.0;
+        const auto t0 = std::chrono::steady_clock::now();
+        char hex[kIdHex + 1] = {0};
+        for (;;) {
+            FILE* fh = fopen(id_hex_or_path, "r");
+            if (fh) {
+                const size_t got = fread(hex, 1, kIdHex, fh);
+                fclose(fh);
+                hex[got] = 0;
+                if (got == kIdHex && hex_to_id(hex, &uid)) break;
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
+                return fail(ctx, FTK_ERR_IO, "rank %d: no communicator id in %s after %.0f s (did rank 0 start?)", rank, id_hex_or_path, limit_s);
+            usleep(2000);
+        }
+    }
+    ftk_comm* c = new (std::nothrow) ftk_comm();
+    if (!c) return fail(ctx, FTK_ERR_OOM, "out of host memory");
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    c->id_path = wrote;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ftk_comm_destroy(c);
+        return fail(ctx, FTK_ERR_HIP, "communicator setup failed: %s", hipGetErrorString(e));
+    }
+    const ncclResult_t r = a->CommInitRank(&c->comm, world, uid, rank);
+    if (r != ncclSuccess) {
+        c->comm = nullptr;
+        ftk_comm_destroy(c);
+        return fail(ctx, FTK_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, a->GetErrorString ? a->GetErrorString(r) : "RCCL error");
+    }
+    *out = c;
+    return FTK_OK;
+}
+
+int ftk_comm_size(const ftk_comm* comm, int* rank_out, int* world_out) {
+    if (!comm) return fail(nullptr, FTK_ERR_INVALID, "comm is NULL");
+    if (rank_out) *rank_out = comm->rank;
+    if (world_out) *world_out = comm->world;
+    return FTK_OK;
+}
+
+int ftk_comm_join(ftk_comm* comm) {
+    if (!comm) return fail(nullptr, FTK_ERR_INVALID, "comm is NULL");
+    HIPCHK(comm->ctx, hipSetDevice(comm->ctx->device));
+    HIPCHK(comm->ctx, hipStreamWaitEvent(comm->ctx->stream, comm->ev_done, 0));
+    return FTK_OK;
+}
+
+int ftk_allgather_i64(ftk_comm* comm, const int64_t* send, int64_t n, int64_t* recv) {
+    if (!comm) return fail(nullptr, FTK_ERR_INVALID, "comm is NULL");
+    ftk_ctx* ctx = comm->ctx;
+    if (n < 0 || (n > 0 && (!send || !recv))) return fail(ctx, FTK_ERR_INVALID, "bad arguments");
+    if (n == 0) return FTK_OK;
+    int rc = comm_fork(comm);
+    if (rc) return rc;
+    const bool s_dev = is_device_ptr(send), r_dev = is_device_ptr(recv);
+    const size_t b = (size_t)n * 8, b_all = b * (size_t)comm->world;
+    const size_t s_off = 0, r_off = s_dev ? 0 : align_up(b);
+    if ((rc = comm_stage(comm, (s_dev ? 0 : align_up(b)) + (r_dev ? 0 : align_up(b_all))))) return rc;
+    const int64_t* d_send = send;
+    if (!s_dev) {
+        HIPCHK(ctx, hipMemcpyAsync((char*)comm->stage + s_off, send, b, hipMemcpyHostToDevice, comm->stream));
+        d_send = (const int64_t*)((char*)comm->stage + s_off);
+    }
+    int64_t* d_recv = r_dev ? recv : (int64_t*)((char*)comm->stage + r_off);
+    RCCLCHK(ctx, rccl()->AllGather(d_send, d_recv, (size_t)n, ncclInt64, comm->comm, comm->stream));
+    if (!r_dev) HIPCHK(ctx, hipMemcpyAsync(recv, d_recv, b_all, hipMemcpyDeviceToHost, comm->stream));
+    HIPCHK(ctx, hipEventRecord(comm->ev_done, comm->stream));
+    if (!r_dev || !s_dev) HIPCHK(ctx, hipStreamSynchronize(comm->stream));  // host buffers: done when the call returns
+    return FTK_OK;
+}
+
+int ftk_allreduce_sum_i64(ftk_comm* comm, int64_t* values, int64_t n) {
+    if (!comm) return fail(nullptr, FTK_ERR_INVALID, "comm is NULL");
+    ftk_ctx* ctx = comm->ctx;
+    if (n < 0 || (n > 0 && !values)) return fail(ctx, FTK_ERR_INVALID, "bad arguments");
+    if (n == 0) return FTK_OK;
+    int rc = comm_fork(comm);
+    if (rc) return rc;
+    const bool dev = is_device_ptr(values);
+    const size_t b = (size_t)n * 8;
+    int64_t* d = values;
+    if (!dev) {
+        if ((rc = comm_stage(comm, b))) return rc;
+        d = (int64_t*)comm->stage;
+        HIPCHK(ctx, hipMemcpyAsync(d, values, b, hipMemcpyHostToDevice, comm->stream));
+    }
+    RCCLCHK(ctx, rccl()->AllReduce(d, d, (size_t)n, ncclInt64, ncclSum, comm->comm, comm->stream));
+    if (!dev) HIPCHK(ctx, hipMemcpyAsync(values, d, b, hipMemcpyDeviceToHost, comm->stream));
+    HIPCHK(ctx, hipEventRecord(comm->ev_done, comm->stream));
+    if (!dev) HIPCHK(ctx, hipStreamSynchronize(comm->stream));
+    return FTK_OK;
+}
+
+// point to point, for the compressed output sections a rank hands to the writing rank (frag/_multi_wps.py:300-341 runs
+// its writer in the parent of the Pool): bytes in chunks of at most 1 GiB through the staging block
+static int comm_p2p(ftk_comm* comm, int peer, void* data, int64_t n_bytes, bool sending) {
+    if (!comm) return fail(nullptr, FTK_ERR_INVALID, "comm is NULL");
+    ftk_ctx* ctx = comm->ctx;
+    if (peer < 0 || peer >= comm->world || peer == comm->rank || n_bytes < 0 || (n_bytes > 0 && !data))
+        return fail(ctx, FTK_ERR_INVALID, "bad arguments (peer %d)", peer);
+    if (n_bytes == 0) return FTK_OK;
+    int rc = comm_fork(comm);
+    if (rc) return rc;
+    const bool dev = is_device_ptr(data);
+    constexpr size_t kChunk = size_t(1) << 28;
+    if (!dev && (rc = comm_stage(comm, std::min<size_t>((size_t)n_bytes, kChunk)))) return rc;
+    for (size_t off = 0; off < (size_t)n_bytes; off += kChunk) {
+        const size_t len = std::min(kChunk, (size_t)n_bytes - off);
+        char* h = (char*)data + off;
+        void* d = dev ? (void*)h : comm->stage;
+        if (sending) {
+            if (!dev) HIPCHK(ctx, hipMemcpyAsync(d, h, len, hipMemcpyHostToDevice, comm->stream));
+            RCCLCHK(ctx, rccl()->Send(d, len, ncclUint8, peer, comm->comm, comm->stream));
+        } else {
+            RCCLCHK(ctx, rccl()->Recv(d, len, ncclUint8, peer, comm->comm, comm->stream));
+            if (!dev) HIPCHK(ctx, hipMemcpyAsync(h, d, len, hipMemcpyDeviceToHost, comm->stream));
+        }
+        if (!dev) HIPCHK(ctx, hipStreamSynchronize(comm->stream));  // the staging block is reused by the next chunk
+    }
+    HIPCHK(ctx, hipEventRecord(comm->ev_done, comm->stream));
+    return FTK_OK;
+}
+
+int ftk_comm_send(ftk_comm* comm, int dst, const void* data, int64_t n_bytes) {
+    return comm_p2p(comm, dst, const_cast<void*>(data), n_bytes, true);
+}
+
+int ftk_comm_recv(ftk_comm* comm, int src, void* data, int64_t n_bytes) { return comm_p2p(comm, src, data, n_bytes, false); }
+
+void ftk_comm_destroy(ftk_comm* comm) {
+    if (!comm) return;
+    if (comm->ctx) (void)hipSetDevice(comm->ctx->device);
+    if (comm->stream) (void)hipStreamSynchronize(comm->stream);
+    if (comm->comm && rccl()) (void)rccl()->CommDestroy(comm->comm);
+    if (comm->stage) (void)hipFree(comm->stage);
+    if (comm->ev_fork) (void)hipEventDestroy(comm->ev_fork);
+    if (comm->ev_done) (void)hipEventDestroy(comm->ev_done);
+    if (comm->stream) (void)hipStreamDestroy(comm->stream);
+    if (!comm->id_path.empty()) (void)remove(comm->id_path.c_str());
+    delete comm;
 }
 
 }  // extern "C"

@@ -36,6 +36,11 @@ struct ContigView {
     int32_t n;                // fragments
     int32_t n_bins;
     int32_t max_len;          // longest fragment in the contig
+    // BAM: 1 when every fragment holds its read1 span (start <= r1_start < r1_end <= end; checked on the device by
+    // ftk_frags_set_read1).  A fragment that lies inside a window then has its read1 inside it too, so the read1
+    // fetch test (io/alignment.py:245) can only fail for fragments that cross a window bound and the kernels read
+    // the read1 columns for those alone.  0: the columns are read for every fragment.
+    int32_t r1_inside;
 };
 
 struct ContigData {

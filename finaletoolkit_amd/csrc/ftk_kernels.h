@@ -44,6 +44,9 @@ struct CleaveParams {
 
 void launch_stats(hipStream_t s, const int32_t* start, const int32_t* end, int n, FragStats* st);
 void launch_bin_index(hipStream_t s, const int32_t* start, int n, int n_bins, int32_t* idx);
+// *bad |= 1 when some fragment does not hold its read1 span (ContigView::r1_inside)
+void launch_r1_inside(hipStream_t s, const int32_t* start, const int32_t* end, const int32_t* r1s, const int32_t* r1e,
+                      int n, int* bad);
 void launch_plan(hipStream_t s, const ContigView& cv, const int32_t* ws, const int32_t* we, int n_win, int lmax,
                  int small_max, const WindowPlan& pl, int64_t* const zero[4]);
 
@@ -113,6 +116,7 @@ void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t
 // Window features computed inside the WPS pass (regular bin tiling, midpoint policy).
 struct FusedParams {
     int win_start, win_len, n_win;
+    int bam;  // read1 fetch semantics (the contig has read1 columns)
     int ch_q, ch_min, ch_max;
     int do_cov, do_hist, len_lo, n_bins;
     int do_delfi, df_q, cen0, cen1, tel0, tel1;

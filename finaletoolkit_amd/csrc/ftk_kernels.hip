@@ -93,6 +93,19 @@ __global__ void bin_index_kernel(const int32_t* start, int n, int n_bins, int32_
     idx[k] = lo;
 }
 
+// Does every fragment hold its read1 span (start <= r1_start < r1_end <= end)?  *bad is set when one does not
+// (ContigView::r1_inside; io/alignment.py:254-261 builds the fragment from read1's start or end and TLEN, so the
+// span can only stick out when TLEN is shorter than the read's own alignment).
+__global__ __launch_bounds__(256) void r1_inside_kernel(const int32_t* start, const int32_t* end, const int32_t* r1s,
+                                                        const int32_t* r1e, int n, int* bad) {
+    bool b = false;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int rs = r1s[i], re = r1e[i];
+        b |= !(start[i] <= rs && rs < re && re <= end[i]);
+    }
+    if (__ballot(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
+
 // ---------------------------------------------------------------------------
 // window planning: candidate range per window, chunk counts, chunk offsets
 // ---------------------------------------------------------------------------
@@ -757,14 +770,15 @@ struct FastAcc {
 
 struct FastWin {
     int ws2, we2, wsm1;  // 2 * max(ws, 0); 2 * (we - 1) + 1; -1 - max(ws, -1)
+    int ws, we;          // BAM: the clamped bounds themselves (ws >= -1, we <= 2^30)
+    int r1_all;          // BAM: -1 when the read1 columns must be read for every fragment, else 0
 };
 
+// One fragment whose window test x (sign set = rejected) is known.
 template <bool CHK, bool HIST, bool DF, bool BL, bool GAPS>
-__device__ __forceinline__ void fast_element(const FeatParams& P, int fs, int fe, int q, const FastWin& W, int o0,
-                                             int o1, uint32_t* h, FastAcc& a) {
+__device__ __forceinline__ void fast_element(const FeatParams& P, int fs, int fe, int x, int o0, int o1, uint32_t* h,
+                                             FastAcc& a) {
     const int len = fe - fs;
-    const int m2 = fs + fe;
-    const int x = (q - P.ch_q) | (m2 - W.ws2) | (W.we2 - m2) | (fe + W.wsm1);
     if (CHK) {
         const unsigned bad = (unsigned)x >> 31;
         a.cov += bad;
@@ -794,7 +808,42 @@ __device__ __forceinline__ void fast_element(const FeatParams& P, int fs, int fe
     }
 }
 
-template <int kFeatBS, bool CHK, bool HIST, bool DF, bool BL, bool GAPS>
+// Four fragments i .. i + 3 (one 16-byte load per column).  Tabix fetch: the fragment must overlap the window
+// (fe > ws; fs < we follows from the midpoint).  BAM fetch (io/alignment.py:245): its READ1 must.  A fragment
+// that lies inside the window holds its read1 there too when the contig's read1 spans lie inside their fragments
+// (ContigView::r1_inside), so only a fragment that crosses a window bound AND passes everything else can be
+// rejected by its read1: the group's two read1 loads are issued when it holds such a fragment (fragments are
+// sorted by start: those are the first and last few groups of a window's range), by every group when the
+// contig's spans are not known to lie inside (r1_all).
+template <bool CHK, bool HIST, bool DF, bool BL, bool GAPS, bool BAM>
+__device__ __forceinline__ void fast_group(const ContigView& cv, const FeatParams& P, int i, const int4& s,
+                                           const int4& e, const uchar4& q, const FastWin& W, int o0, int o1,
+                                           uint32_t* h, FastAcc& a) {
+    const int fs[4] = {s.x, s.y, s.z, s.w}, fe[4] = {e.x, e.y, e.z, e.w}, qq[4] = {q.x, q.y, q.z, q.w};
+    int x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m2 = fs[j] + fe[j];
+        x[j] = (qq[j] - P.ch_q) | (m2 - W.ws2) | (W.we2 - m2);
+        if (!BAM) x[j] |= fe[j] + W.wsm1;
+    }
+    if (BAM) {
+        int need = W.r1_all;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) need |= ((fs[j] - W.ws) | (W.we - fe[j])) & ~x[j];
+        if (need < 0) {
+            const int4 rs = *reinterpret_cast<const int4*>(cv.r1_start + i);
+            const int4 re = *reinterpret_cast<const int4*>(cv.r1_end + i);
+            const int r0[4] = {rs.x, rs.y, rs.z, rs.w}, r1[4] = {re.x, re.y, re.z, re.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] |= (W.we - 1 - r0[j]) | (r1[j] + W.wsm1);  // rs < we and re > ws
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fast_element<CHK, HIST, DF, BL, GAPS>(P, fs[j], fe[j], x[j], o0, o1, h, a);
+}
+
+template <int kFeatBS, bool CHK, bool HIST, bool DF, bool BL, bool GAPS, bool BAM>
 __device__ __forceinline__ void fast_stream(const ContigView& cv, const FeatParams& P, int lo, int hi, int tid,
                                             const FastWin& W, int o0, int o1, uint32_t* h, FastAcc& a) {
     int4 s4[4], e4[4];
@@ -822,16 +871,13 @@ __device__ __forceinline__ void fast_stream(const ContigView& cv, const FeatPara
                     e4[u] = *reinterpret_cast<const int4*>(cv.end + nxt);
                     q4[u] = *reinterpret_cast<const uchar4*>(cv.mapq + nxt);
                 }
-                fast_element<CHK, HIST, DF, BL, GAPS>(P, s.x, e.x, q.x, W, o0, o1, h, a);
-                fast_element<CHK, HIST, DF, BL, GAPS>(P, s.y, e.y, q.y, W, o0, o1, h, a);
-                fast_element<CHK, HIST, DF, BL, GAPS>(P, s.z, e.z, q.z, W, o0, o1, h, a);
-                fast_element<CHK, HIST, DF, BL, GAPS>(P, s.w, e.w, q.w, W, o0, o1, h, a);
+                fast_group<CHK, HIST, DF, BL, GAPS, BAM>(cv, P, i, s, e, q, W, o0, o1, h, a);
             }
         }
     }
 }
 
-template <int kFeatBS, bool CHK, bool HIST, bool DF>
+template <int kFeatBS, bool CHK, bool HIST, bool DF, bool BAM>
 __device__ __forceinline__ void feat_fast_body(const ContigView& cv, int ws_raw, int we_raw, int lmax,
                                                const FeatParams& P, int o0, int o1, size_t row, uint32_t* lds_hist,
                                                int (*red)[kFeatBS / 64]) {
@@ -850,6 +896,9 @@ __device__ __forceinline__ void feat_fast_body(const ContigView& cv, int ws_raw,
         W.ws2 = (int)(2u * (unsigned)max(ws, 0));
         W.we2 = 2 * we1 + 1;
         W.wsm1 = -1 - ws;
+        W.ws = ws;
+        W.we = we1 + 1;
+        W.r1_all = cv.r1_inside ? 0 : -1;
     }
     // a DELFI fragment of this window (midpoint inside, 100 <= len <= 220) lies within 110 bp of it: the gap
     // terms can only matter when the window, widened by a safe 256 bp, touches one of the two intervals
@@ -861,11 +910,11 @@ __device__ __forceinline__ void feat_fast_body(const ContigView& cv, int ws_raw,
     FastAcc a;
     const bool bl = DF && o1 > o0;
     if (bl) {
-        if (gaps) fast_stream<kFeatBS, CHK, HIST, DF, true, true>(cv, P, lo, hi, tid, W, o0, o1, lds_hist, a);
-        else fast_stream<kFeatBS, CHK, HIST, DF, true, false>(cv, P, lo, hi, tid, W, o0, o1, lds_hist, a);
+        if (gaps) fast_stream<kFeatBS, CHK, HIST, DF, true, true, BAM>(cv, P, lo, hi, tid, W, o0, o1, lds_hist, a);
+        else fast_stream<kFeatBS, CHK, HIST, DF, true, false, BAM>(cv, P, lo, hi, tid, W, o0, o1, lds_hist, a);
     } else {
-        if (gaps) fast_stream<kFeatBS, CHK, HIST, DF, false, true>(cv, P, lo, hi, tid, W, o0, o1, lds_hist, a);
-        else fast_stream<kFeatBS, CHK, HIST, DF, false, false>(cv, P, lo, hi, tid, W, o0, o1, lds_hist, a);
+        if (gaps) fast_stream<kFeatBS, CHK, HIST, DF, false, true, BAM>(cv, P, lo, hi, tid, W, o0, o1, lds_hist, a);
+        else fast_stream<kFeatBS, CHK, HIST, DF, false, false, BAM>(cv, P, lo, hi, tid, W, o0, o1, lds_hist, a);
     }
     if (HIST) {
         __syncthreads();
@@ -889,7 +938,7 @@ __device__ __forceinline__ void feat_fast_body(const ContigView& cv, int ws_raw,
     }
 }
 
-template <int kFeatBS, bool CHK, bool HIST, bool DF>
+template <int kFeatBS, bool CHK, bool HIST, bool DF, bool BAM>
 __global__ __launch_bounds__(kFeatBS) void feat_fast_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
                                                         int n_win, int lmax, FeatParams P) {
     extern __shared__ uint32_t lds_hist[];
@@ -897,10 +946,10 @@ __global__ __launch_bounds__(kFeatBS) void feat_fast_kernel(ContigView cv, const
     const int w = blockIdx.x;
     int o0 = 0, o1 = 0;
     if (DF && P.dp.bl_off) { o0 = P.dp.bl_off[w]; o1 = P.dp.bl_off[w + 1]; }
-    feat_fast_body<kFeatBS, CHK, HIST, DF>(cv, ws_[w], we_[w], lmax, P, o0, o1, (size_t)w, lds_hist, red);
+    feat_fast_body<kFeatBS, CHK, HIST, DF, BAM>(cv, ws_[w], we_[w], lmax, P, o0, o1, (size_t)w, lds_hist, red);
 }
 
-template <int kFeatBS, bool CHK, bool HIST, bool DF>
+template <int kFeatBS, bool CHK, bool HIST, bool DF, bool BAM>
 __global__ __launch_bounds__(kFeatBS) void feat_fast_batch_kernel(const FeatItem* __restrict__ items, int n_items,
                                                               FeatParams P) {
     extern __shared__ uint32_t lds_hist[];
@@ -924,7 +973,7 @@ __global__ __launch_bounds__(kFeatBS) void feat_fast_batch_kernel(const FeatItem
     int o0 = 0, o1 = 0;
     if (DF && I.bl_off) { o0 = I.bl_off[w]; o1 = I.bl_off[w + 1]; }
     const ContigView cv = I.cv;
-    feat_fast_body<kFeatBS, CHK, HIST, DF>(cv, I.ws[w], I.we[w], I.lmax, Q, o0, o1, (size_t)gw, lds_hist, red);
+    feat_fast_body<kFeatBS, CHK, HIST, DF, BAM>(cv, I.ws[w], I.we[w], I.lmax, Q, o0, o1, (size_t)gw, lds_hist, red);
 }
 
 // The same for the windows of SEVERAL contigs in one launch (ftk_window_features_batch): block b owns
@@ -1085,8 +1134,13 @@ __device__ __forceinline__ void wps_block(const unsigned block_id, const unsigne
         const int len = fe - fs;
         const long long mid = ((long long)fs + (long long)fe) >> 1;
         if (q < p.mapq_min || len < p.min_len || len > p.max_len || mid < ti.fmin || mid >= ti.fmax) return;
-        if (cv.r1_start) {  // BAM: the fetch returns read1 alignments overlapping [fmin, fmax)
-            if (!((long long)cv.r1_start[i] < ti.fmax && (long long)cv.r1_end[i] > ti.fmin)) return;
+        if (cv.r1_start) {
+            // BAM: the fetch returns read1 alignments overlapping [fmin, fmax).  A fragment inside the fetch window
+            // holds its read1 there (ContigView::r1_inside): the read1 columns are read for the fragments that
+            // cross its bounds - none at all in a whole-contig call.
+            if (!cv.r1_inside || (long long)fs < ti.fmin || (long long)fe > ti.fmax) {
+                if (!((long long)cv.r1_start[i] < ti.fmax && (long long)cv.r1_end[i] > ti.fmin)) return;
+            }
         } else if (!((long long)fs < ti.fmax && (long long)fe > ti.fmin)) {
             return;
         }
@@ -1113,7 +1167,12 @@ __device__ __forceinline__ void wps_block(const unsigned block_id, const unsigne
         const int w = f_w0 + (mid >= f_b1);
         if (w < 0 || w >= F.n_win) return;
         const int ws = F.win_start + w * F.win_len;  // mid is inside [ws, ws + win_len) by construction
-        const int t_lo = fe - 1 - ws;                 // fe > ws (fs < we follows from the midpoint)
+        int t_lo = fe - 1 - ws;                       // fe > ws (fs < we follows from the midpoint)
+        if (F.bam) {  // read1 fetch (io/alignment.py:245): read1 overlaps the bin; only a fragment that crosses a bound can fail
+            t_lo = 0;
+            const int we = ws + F.win_len;
+            if (!cv.r1_inside || fs < ws || fe > we) t_lo = (we - 1 - cv.r1_start[i]) | (cv.r1_end[i] - 1 - ws);
+        }
         const bool primary = w == f_w0;
         if (F.do_cov | F.do_hist) {
             const int x = (q - F.ch_q) | (len - F.ch_min) | (F.ch_max - len) | t_lo;
@@ -1330,7 +1389,7 @@ __global__ __launch_bounds__(256) void wps_stream_kernel(ContigView cv, WpsParam
 // retire (the feature pass's tail and the WPS ramp overlap instead of adding up), and WPS finds the contig's
 // columns in the Infinity Cache behind the feature blocks that just read them.  The two kinds of block share
 // nothing: results are those of the two separate launches.
-template <bool CHK, bool HIST, bool DF, bool NT>
+template <bool CHK, bool HIST, bool DF, bool BAM, bool NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void feat_then_wps_kernel(ContigView cv, const int32_t* ws_, const int32_t* we_,
                                                             int n_win, int lmax, FeatParams P, WpsParams p,
                                                             long long n_tiles, int64_t* __restrict__ out) {
@@ -1340,7 +1399,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         const int w = blockIdx.x;
         int o0 = 0, o1 = 0;
         if (DF && P.dp.bl_off) { o0 = P.dp.bl_off[w]; o1 = P.dp.bl_off[w + 1]; }
-        feat_fast_body<256, CHK, HIST, DF>(cv, ws_[w], we_[w], lmax, P, o0, o1, (size_t)w, lds_hist, red);
+        feat_fast_body<256, CHK, HIST, DF, BAM>(cv, ws_[w], we_[w], lmax, P, o0, o1, (size_t)w, lds_hist, red);
         return;
     }
     wps_block<false, false, false, NT>(blockIdx.x - (unsigned)n_win, gridDim.x - (unsigned)n_win, cv, p, nullptr, nullptr,
@@ -1383,7 +1442,8 @@ __device__ __forceinline__ void cleave_tile(const ContigView& cv, const CleavePa
         const int len = fe - fs;
         if (q < p.mapq_min || len < p.min_len || len > p.max_len) continue;
         if (!((long long)fe > iv_start && (long long)fs < iv_stop)) continue;  // "any" policy (= tabix overlap)
-        if (cv.r1_start && !((long long)cv.r1_start[i] < iv_stop && (long long)cv.r1_end[i] > iv_start)) continue;
+        if (cv.r1_start && (!cv.r1_inside || (long long)fs < iv_start || (long long)fe > iv_stop) &&
+            !((long long)cv.r1_start[i] < iv_stop && (long long)cv.r1_end[i] > iv_start)) continue;
         const long long a = (long long)fs - t0, b = (long long)fe - t0;
         if (b > 0 && a < len_t) {  // covers [max(a,0), min(b,len_t))
             if (a <= 0) atomicAdd(&pre_s, 1); else add(dd, (int)a, 1);
@@ -1637,6 +1697,12 @@ void launch_bin_index(hipStream_t s, const int32_t* start, int n, int n_bins, in
     hipLaunchKernelGGL(bin_index_kernel, dim3((threads + 255) / 256), dim3(256), 0, s, start, n, n_bins, idx);
 }
 
+void launch_r1_inside(hipStream_t s, const int32_t* start, const int32_t* end, const int32_t* r1s, const int32_t* r1e,
+                      int n, int* bad) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(r1_inside_kernel, dim3(min(2048, (n + 255) / 256)), dim3(256), 0, s, start, end, r1s, r1e, n, bad);
+}
+
 void launch_plan(hipStream_t s, const ContigView& cv, const int32_t* ws, const int32_t* we, int n_win, int lmax,
                  int small_max, const WindowPlan& pl, int64_t* const zero[4]) {
     ZeroList z;
@@ -1672,28 +1738,28 @@ static bool launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, c
                           int n_win, const WindowPlan& pl, const FeatParams& P, bool small_path, int block_lmax,
                           int block_threads, const WpsTail* tail) {
     const size_t lds1 = (CH && P.do_hist) ? (size_t)(P.n_bins + 1) * sizeof(uint32_t) : 0;  // + overflow bin
-    if (tail && tail->n_tiles > 0 && block_lmax >= 0 && CH != 2 && !BAM && feat_fast_ok(P, CH != 0, DF) &&
+    if (tail && tail->n_tiles > 0 && block_lmax >= 0 && CH != 2 && feat_fast_ok(P, CH != 0, DF) &&
         (long long)n_win + tail->n_tiles < (1LL << 31)) {
         // the merged launch: feature blocks first, the WPS tiles behind them (feat_then_wps_kernel)
         FeatParams Pf = P;
         if (!CH) Pf.ch_q = P.df_q;
         const dim3 grid((unsigned)((long long)n_win + tail->n_tiles));
 #define FTK_MERGED(HIST, NT)                                                                                         \
-    hipLaunchKernelGGL((feat_then_wps_kernel<CH != 0, HIST, DF, NT>), grid, dim3(256), lds1, s, cv, ws, we, n_win,   \
+    hipLaunchKernelGGL((feat_then_wps_kernel<CH != 0, HIST, DF, BAM, NT>), grid, dim3(256), lds1, s, cv, ws, we, n_win, \
                        block_lmax, Pf, tail->p, (long long)tail->n_tiles, tail->out)
         if (CH && P.do_hist) { if (tail->p.nt_store) FTK_MERGED(true, true); else FTK_MERGED(true, false); }
         else { if (tail->p.nt_store) FTK_MERGED(false, true); else FTK_MERGED(false, false); }
 #undef FTK_MERGED
         return true;
     }
-    if (block_lmax >= 0 && CH != 2 && !BAM && feat_fast_ok(P, CH != 0, DF)) {
+    if (block_lmax >= 0 && CH != 2 && feat_fast_ok(P, CH != 0, DF)) {
 #define FTK_FAST(BS)                                                                                                \
     do {                                                                                                            \
         if (CH && P.do_hist)                                                                                        \
-            hipLaunchKernelGGL((feat_fast_kernel<BS, CH != 0, true, DF>), dim3(n_win), dim3(BS), lds1, s, cv, ws, we,   \
+            hipLaunchKernelGGL((feat_fast_kernel<BS, CH != 0, true, DF, BAM>), dim3(n_win), dim3(BS), lds1, s, cv, ws, we,   \
                                n_win, block_lmax, Pf);                                                              \
         else                                                                                                        \
-            hipLaunchKernelGGL((feat_fast_kernel<BS, CH != 0, false, DF>), dim3(n_win), dim3(BS), lds1, s, cv, ws, we,  \
+            hipLaunchKernelGGL((feat_fast_kernel<BS, CH != 0, false, DF, BAM>), dim3(n_win), dim3(BS), lds1, s, cv, ws, we,  \
                                n_win, block_lmax, Pf);                                                              \
     } while (0)
         FeatParams Pf = P;
@@ -1815,12 +1881,16 @@ void launch_window_features_batch(hipStream_t s, const FeatItem* d_items, int n_
     P.short_out = r.short_out;
     P.long_out = r.long_out;
     const size_t lds1 = P.do_hist ? (size_t)(P.n_bins + 1) * sizeof(uint32_t) : 0;
-    if (!bam && feat_fast_ok(P, ch, df)) {
+    if (feat_fast_ok(P, ch, df)) {
         FeatParams Pf = P;
         if (!ch) Pf.ch_q = P.df_q;
 #define FTK_FASTB(CHK, HIST, DF)                                                                                   \
-    hipLaunchKernelGGL((feat_fast_batch_kernel<512, CHK, HIST, DF>), dim3(total_win), dim3(512), lds1, s, d_items, \
-                       n_items, Pf)
+    do {                                                                                                           \
+        if (bam) hipLaunchKernelGGL((feat_fast_batch_kernel<512, CHK, HIST, DF, true>), dim3(total_win), dim3(512), lds1, s, \
+                                    d_items, n_items, Pf);                                                         \
+        else hipLaunchKernelGGL((feat_fast_batch_kernel<512, CHK, HIST, DF, false>), dim3(total_win), dim3(512), lds1, s,    \
+                                d_items, n_items, Pf);                                                             \
+    } while (0)
         if (ch && df) { if (P.do_hist) FTK_FASTB(true, true, true); else FTK_FASTB(true, false, true); }
         else if (ch) { if (P.do_hist) FTK_FASTB(true, true, false); else FTK_FASTB(true, false, false); }
         else if (df) FTK_FASTB(false, false, true);

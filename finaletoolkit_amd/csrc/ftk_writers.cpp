@@ -18,6 +18,7 @@
 #include <limits>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <dlfcn.h>
@@ -468,6 +469,203 @@ int ftk_bgzf_write(const char* path, const char* data, int64_t n, int level, int
                                         0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (write_eof && write_all(fd, (const char*)eof, sizeof(eof))) rc = wfail(FTK_ERR_IO, "write to %s failed", path);
     }
+    if (close(fd) && rc == FTK_OK) rc = wfail(FTK_ERR_IO, "close of %s failed: %s", path, strerror(errno));
+    return rc;
+}
+
+// ---- a synthetic paired-end BAM, one contig per call (test / bench tooling like ftk_format_frag_rows) ---------------
+// BASELINE config 5 reads a whole-genome 60x BAM: 1.2 G records, ~145 GB of record bytes.  Assembled as numpy structured
+// arrays the records of a chr1-sized contig alone took 53 s (round 4); here the host threads build, sort and deflate
+// them window by window, so that writing the file is bound by libdeflate and the disk, not by Python.
+namespace {
+
+inline uint64_t splitmix64(uint64_t& x) {
+    uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// one BGZF block around `len` (<= 0xFF00) data bytes; returns its size, 0 on failure (dst holds >= bound bytes)
+size_t bgzf_block(void* comp, int level, const uint8_t* in, size_t len, uint8_t* tmp, uint8_t* dst, size_t bound) {
+    const size_t got = deflate_block(comp, true, level, in, len, tmp, bound);
+    if (got < 18 || got - 10 + 18 > 65536) return 0;
+    const size_t payload = got - 10 - 8;  // raw deflate bytes
+    const size_t total = 18 + payload + 8;
+    const uint8_t head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0,
+                              (uint8_t)((total - 1) & 255), (uint8_t)((total - 1) >> 8)};
+    memcpy(dst, head, 18);
+    memcpy(dst + 18, tmp + 10, payload + 8);
+    return total;
+}
+
+struct BamWindowJob {
+    std::vector<uint8_t> out;           // the window's BGZF blocks
+    std::vector<uint32_t> block_end;    // cumulative compressed size behind block k
+    std::vector<std::pair<int64_t, int64_t>> first;  // (16 kb window, byte offset of its first overlapping record in the window's stream)
+    int64_t n_records = 0;
+    bool bad = false;
+};
+
+}  // namespace
+
+int ftk_synth_bam_contig(const char* path, int32_t ref_id, int64_t contig_len, const int32_t* start, const int32_t* end,
+                         const uint8_t* mapq, const uint8_t* strand, int64_t n, int32_t read_len, int32_t name_len,
+                         uint64_t seed, int level, int n_threads, uint64_t* linear, int64_t n_linear,
+                         int64_t* first_off, int64_t* end_off, int64_t* n_records_out) {
+    if (!path || contig_len <= 0 || n < 0 || (n > 0 && (!start || !end || !mapq || !strand)) || read_len < 2 ||
+        read_len > 1000 || name_len < 2 || name_len > 32 || (linear && n_linear < ((contig_len + read_len) >> 14) + 1))
+        return wfail(FTK_ERR_INVALID, "bad arguments");
+    const int fd = open(path, O_WRONLY | O_APPEND);
+    if (fd < 0) return wfail(FTK_ERR_IO, "cannot open %s for appending: %s", path, strerror(errno));
+    int64_t file_pos = (int64_t)lseek(fd, 0, SEEK_END);
+    if (first_off) *first_off = -1;
+    if (end_off) *end_off = -1;
+    int64_t max_len = 0;
+    for (int64_t i = 0; i < n; ++i) max_len = std::max<int64_t>(max_len, (int64_t)end[i] - start[i]);
+    const size_t rec_bytes = 36 + (size_t)name_len + 4 + (size_t)(read_len + 1) / 2 + (size_t)read_len;
+    constexpr int64_t kStep = 1 << 19;  // bases per window: ~24 MB of records at 60x
+    constexpr size_t kBlock = 0xFF00;
+    const int64_t n_win = (contig_len + kStep - 1) / kStep;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads > 0 ? n_threads : ftk_host::default_threads(), n_win));
+    const size_t bound = compressBound(kBlock) + 64;
+    const Deflater& D = deflater();
+    std::vector<void*> comps(nt, nullptr);
+    if (D.ok)
+        for (auto& c : comps) c = D.alloc(std::min(std::max(level, 1), 12));
+    uint8_t qual_lut[256];  // 3 / 7 / 20 / 70 % of the qualities: 2, 11, 25, 37 (synth.write_paired_bam)
+    for (int k = 0; k < 256; ++k) qual_lut[k] = k < 8 ? 2 : k < 26 ? 11 : k < 77 ? 25 : 37;
+    const int64_t batch = (int64_t)nt * 2;
+    int rc = FTK_OK;
+    int64_t n_records = 0;
+    // two sets of window jobs: while one batch's blocks go to the file (a writer thread: the disk is the slowest stage
+    // wherever the file does not fit the page cache), the host threads build the next batch
+    std::vector<BamWindowJob> jobs_ab[2];
+    jobs_ab[0].resize((size_t)std::min(batch, n_win));
+    jobs_ab[1].resize((size_t)std::min(batch, n_win));
+    std::thread writer;
+    int write_rc = FTK_OK;
+    int side = 0;
+    for (int64_t w0 = 0; w0 < n_win && rc == FTK_OK; w0 += batch, side ^= 1) {
+        std::vector<BamWindowJob>& jobs = jobs_ab[side];
+        const int64_t nw = std::min(batch, n_win - w0);
+        std::atomic<int64_t> next{0};
+        ftk_host::parallel_run(nt, [&](int t) {
+            std::vector<uint64_t> keys;
+            std::vector<uint8_t> raw, tmp(bound);
+            for (;;) {
+                const int64_t k = next.fetch_add(1);
+                if (k >= nw) break;
+                BamWindowJob& J = jobs[(size_t)k];
+                J.out.clear(); J.block_end.clear(); J.first.clear(); J.n_records = 0; J.bad = false;
+                const int64_t a = (w0 + k) * kStep, b = std::min(a + kStep, contig_len);
+                const int64_t lo = std::lower_bound(start, start + n, (int32_t)std::max<int64_t>(a - max_len, INT32_MIN)) - start;
+                const int64_t hi = std::lower_bound(start, start + n, (int32_t)std::min<int64_t>(b, INT32_MAX)) - start;
+                // records of the window: key = (pos - a) << 40 | mate << 39 | fragment index (stable order of the numpy
+                // writer: by position, read1 records before read2 records, then by fragment)
+                keys.clear();
+                for (int64_t i = lo; i < hi; ++i) {
+                    const bool fwd = strand[i] != 0;
+                    const int64_t p1 = fwd ? start[i] : (int64_t)end[i] - read_len, p2 = fwd ? (int64_t)end[i] - read_len : start[i];
+                    if (p1 >= a && p1 < b) keys.push_back((uint64_t)(p1 - a) << 40 | (uint64_t)i);
+                    if (p2 >= a && p2 < b) keys.push_back((uint64_t)(p2 - a) << 40 | 1ull << 39 | (uint64_t)i);
+                }
+                std::sort(keys.begin(), keys.end());
+                J.n_records = (int64_t)keys.size();
+                raw.resize(keys.size() * rec_bytes);
+                uint8_t* p = raw.data();
+                int64_t seen_w = -1;  // highest 16 kb window a record of this job has touched (records come by position)
+                for (size_t r = 0; r < keys.size(); ++r, p += rec_bytes) {
+                    const uint64_t key = keys[r];
+                    const int64_t i = (int64_t)(key & ((1ull << 39) - 1));
+                    const bool mate2 = (key >> 39) & 1;
+                    const int64_t pos = a + (int64_t)(key >> 40);
+                    const bool fwd = strand[i] != 0;
+                    const int64_t len = (int64_t)end[i] - start[i];
+                    const int64_t p1 = fwd ? start[i] : (int64_t)end[i] - read_len, p2 = fwd ? (int64_t)end[i] - read_len : start[i];
+                    int32_t h[9];
+                    h[0] = (int32_t)rec_bytes - 4;
+                    h[1] = ref_id;
+                    h[2] = (int32_t)pos;
+                    h[3] = (int32_t)((uint32_t)name_len | (uint32_t)mapq[i] << 8);  // l_read_name, mapq, bin = 0
+                    const uint32_t flag = mate2 ? (fwd ? 147u : 163u) : (fwd ? 99u : 83u);
+                    h[4] = (int32_t)(1u | flag << 16);                               // n_cigar_op = 1, flag
+                    h[5] = read_len;
+                    h[6] = ref_id;
+                    h[7] = (int32_t)(mate2 ? p1 : p2);
+                    h[8] = (int32_t)((mate2 != fwd) ? len : -len);                   // read1 fwd: +len; read1 rev: -len; mates mirrored
+                    memcpy(p, h, 36);
+                    uint8_t* q = p + 36;
+                    int64_t v = i;
+                    for (int d = name_len - 2; d >= 0; --d) { q[d] = (uint8_t)('0' + v % 10); v /= 10; }
+                    q[name_len - 1] = 0;
+                    q += name_len;
+                    const uint32_t cig = (uint32_t)read_len << 4;
+                    memcpy(q, &cig, 4);
+                    q += 4;
+                    uint64_t st = seed ^ ((uint64_t)ref_id << 48) ^ ((uint64_t)i << 1) ^ (uint64_t)mate2;
+                    const size_t n_seq = (size_t)(read_len + 1) / 2;
+                    for (size_t j = 0; j < n_seq; j += 8) {
+                        const uint64_t x = splitmix64(st);
+                        memcpy(q + j, &x, std::min<size_t>(8, n_seq - j));
+                    }
+                    q += n_seq;
+                    for (size_t j = 0; j < (size_t)read_len; j += 8) {
+                        uint64_t x = splitmix64(st);
+                        for (size_t u = j; u < std::min<size_t>(j + 8, read_len); ++u, x >>= 8) q[u] = qual_lut[x & 255];
+                    }
+                    // linear index: the first record overlapping each 16 kb window (a read covers at most two)
+                    const int64_t wb = (pos + read_len - 1) >> 14;
+                    for (int64_t wq = std::max(pos >> 14, seen_w + 1); wq <= wb; ++wq) J.first.emplace_back(wq, (int64_t)(r * rec_bytes));
+                    seen_w = std::max(seen_w, wb);
+                }
+                const size_t n_blocks = (raw.size() + kBlock - 1) / kBlock;
+                J.out.resize(n_blocks * bound);
+                size_t w = 0;
+                for (size_t bk = 0; bk < n_blocks; ++bk) {
+                    const size_t off = bk * kBlock, len = std::min(kBlock, raw.size() - off);
+                    const size_t got = bgzf_block(comps[t], level, raw.data() + off, len, tmp.data(), J.out.data() + w, bound);
+                    if (!got) { J.bad = true; break; }
+                    w += got;
+                    J.block_end.push_back((uint32_t)w);
+                }
+                J.out.resize(w);
+            }
+        });
+        if (writer.joinable()) writer.join();  // the previous batch is on the disk
+        if (write_rc != FTK_OK) { rc = write_rc; break; }
+        for (int64_t k = 0; k < nw && rc == FTK_OK; ++k) {
+            BamWindowJob& J = jobs[(size_t)k];
+            if (J.bad) { rc = wfail(FTK_ERR_INVALID, "BGZF block did not fit (incompressible data)"); break; }
+            if (J.out.empty()) continue;
+            if (first_off && *first_off < 0) *first_off = file_pos;
+            if (linear)
+                for (const auto& f : J.first) {
+                    const size_t bk = (size_t)f.second / kBlock;
+                    const uint64_t voff = (uint64_t)(file_pos + (bk ? J.block_end[bk - 1] : 0)) << 16 | (uint64_t)((size_t)f.second % kBlock);
+                    if (f.first >= 0 && f.first < n_linear) linear[f.first] = std::min(linear[f.first], voff);
+                }
+            file_pos += (int64_t)J.out.size();
+            n_records += J.n_records;
+        }
+        if (rc != FTK_OK) break;
+        writer = std::thread([&jobs, nw, fd, &write_rc, path] {
+            for (int64_t k = 0; k < nw; ++k) {
+                const BamWindowJob& J = jobs[(size_t)k];
+                if (!J.out.empty() && write_all(fd, (const char*)J.out.data(), J.out.size())) {
+                    write_rc = wfail(FTK_ERR_IO, "write to %s failed: %s", path, strerror(errno));
+                    return;
+                }
+            }
+        });
+    }
+    if (writer.joinable()) writer.join();
+    if (rc == FTK_OK) rc = write_rc;
+    if (D.ok)
+        for (auto c : comps)
+            if (c) D.release(c);
+    if (end_off) *end_off = file_pos;
+    if (n_records_out) *n_records_out = n_records;
     if (close(fd) && rc == FTK_OK) rc = wfail(FTK_ERR_IO, "close of %s failed: %s", path, strerror(errno));
     return rc;
 }

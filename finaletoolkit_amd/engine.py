@@ -223,6 +223,12 @@ class Engine:
         self._bam[name] = False
         return cid
 
+    def set_read1(self, name: str, r1_start, r1_end, n: int):
+        """Read1 spans of a resident contig's fragments (host arrays, torch tensors or raw device addresses): the contig
+        then answers with the BAM fetch rule (io/alignment.py:245)."""
+        self._check(self.lib.ftk_frags_set_read1(self.ctx, self.contig_id(name), L.ptr(r1_start), L.ptr(r1_end), int(n)))
+        self._bam[name] = True
+
     def info(self, name: str):
         n, ml, me = C.c_int64(), C.c_int32(), C.c_int32()
         self._check(self.lib.ftk_frags_info(self.ctx, self.contig_id(name), C.byref(n), C.byref(ml), C.byref(me)))
@@ -381,7 +387,7 @@ class Engine:
         (allocated on the host when None)."""
         if wps_out is None:
             wps_out = np.zeros(int(chrom_size), np.int64)
-        f = L.make_filter(feat_quality, feat_min_length, feat_max_length, "midpoint")
+        f = self._filter(name, feat_quality, feat_min_length, feat_max_length, "midpoint")
         len_lo, n_bins = hist_bins if hist_bins is not None else (0, 0)
         bs = be = None
         n_bl = 0

@@ -3,9 +3,11 @@ Multi-GPU sharding of the hot path: one process per GPU, contigs assigned to
 ranks by longest-processing-time greedy (every window / bin / base depends only
 on the fragments of its own contig, so no data-path collective is needed), and
 one all-gather of the fixed-size per-bin vectors so every rank ends up with the
-whole-genome DELFI / coverage vector in contig order.  ``torch.distributed``
-(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests) is the
-transport; payloads are a few hundred KB, i.e. latency-bound.
+whole-genome DELFI / coverage vector in contig order.  The transport is
+``comm.py``: the library's own RCCL communicator (``ftk_comm_*``, include/ftk.h;
+no torch in the process) on the GPU box, ``torch.distributed``/gloo in CPU tests
+and when several ranks share one GPU; payloads are a few hundred KB, i.e.
+latency-bound.
 """
 from __future__ import annotations
 
@@ -65,39 +67,25 @@ def launch_ranks(cmd: Sequence[str], n: int, share_gpu: bool = False) -> int:
 
 
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int]:
-    """Join the job's process group when this process was started as one rank of several (``torchrun``, or
+    """Join the job's group when this process was started as one rank of several (``torchrun``, or
     ``python -m finaletoolkit_amd.cli --gpus N``: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* in the
-    environment): backend ``nccl`` (= RCCL over xGMI) bound to GPU ``LOCAL_RANK`` unless ``FTK_DIST_BACKEND``
-    / ``backend`` says ``gloo`` (CPU tests; several ranks sharing one GPU).  Returns ``(rank, world)``;
-    a plain single process returns ``(0, 1)`` and starts nothing.  This is the counterpart of the
-    reference's ``Pool(workers)`` (frag/_delfi.py:289, frag/_coverage.py:212): one rank per GPU."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
-        return 0, 1
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (RCCL between processes: the host driver only has dmabuf IPC)
-    import torch
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        backend = backend or os.environ.get("FTK_DIST_BACKEND", "nccl")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        rank = int(os.environ["RANK"])
-        if backend == "nccl":
-            from . import _lib
-            _lib._hardware_queues()  # torch starts the HIP runtime below; the decoder's queue count must be set before
-            local = int(os.environ.get("FTK_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-            if torch.cuda.device_count() <= local:
-                raise RuntimeError(f"rank {rank}: GPU {local} is not visible ({torch.cuda.device_count()} devices); "
-                                   f"one rank per GPU, no fallback")
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    return dist.get_rank(), dist.get_world_size()
+    environment): the library's RCCL communicator on GPU ``LOCAL_RANK`` (``comm.RcclGroup``, no torch) unless
+    ``FTK_DIST_BACKEND`` / ``backend`` says ``gloo`` (CPU tests; several ranks sharing one GPU) or ``nccl``
+    (``torch.distributed``).  Returns ``(rank, world)``; a plain single process returns ``(0, 1)`` and starts
+    nothing.  This is the counterpart of the reference's ``Pool(workers)`` (frag/_delfi.py:289,
+    frag/_coverage.py:212): one rank per GPU."""
+    from . import comm
+    g = comm.join(backend)
+    return g.rank, g.world
 
 
 def finalize():
-    """Leave the process group (end of a multi-rank command)."""
+    """Leave the group (end of a multi-rank command)."""
     import sys
+    from . import comm
+    if comm._GROUP is not None:
+        comm.leave()
+        return
     if "torch.distributed" not in sys.modules:
         return
     try:
@@ -110,28 +98,12 @@ def finalize():
 
 
 def rank_world(group=None) -> Tuple[int, int]:
-    """``(rank, world)`` of the initialised process group, ``(0, 1)`` without one.  A process that has not imported
-    ``torch.distributed`` cannot have one: torch is not imported just to find that out (seconds on a fresh box, and
+    """``(rank, world)`` of the group this process exchanges in, ``(0, 1)`` without one.  Never imports torch: a
+    process that has not imported ``torch.distributed`` cannot hold one of its groups (seconds on a fresh box, and
     every writer asks)."""
-    import sys
-    if "torch.distributed" not in sys.modules:
-        return 0, 1
-    try:
-        import torch.distributed as dist
-    except ImportError:  # pragma: no cover
-        return 0, 1
-    if not (dist.is_available() and dist.is_initialized()):
-        return 0, 1
-    return dist.get_rank(group), dist.get_world_size(group)
-
-
-def exchange_device(group=None):
-    """Where collective payloads live: the rank's GPU under RCCL, host memory under gloo."""
-    import torch
-    import torch.distributed as dist
-    if dist.get_backend(group) == "nccl":
-        return torch.device("cuda", torch.cuda.current_device())
-    return None
+    from . import comm
+    g = comm.current(group)
+    return g.rank, g.world
 
 
 def lpt_assign(weights: Dict[str, float], n_ranks: int) -> Dict[str, int]:
@@ -234,39 +206,30 @@ def gather_bin_vectors(local: Dict[str, np.ndarray], names: Sequence[str], n_bin
     """All-gather per-contig integer vectors (shape [n_bins[c], k]) so every rank
     holds all contigs.  ``local`` has this rank's contigs; ``n_bins`` the row
     count of EVERY contig (known from the bin file on all ranks)."""
-    if rank_world(group)[1] == 1:  # (decided without importing torch: seconds on every single-process call)
+    from . import comm
+    g = comm.current(group)
+    if g.world == 1:  # (decided without importing torch: seconds on every single-process call)
         return dict(local)
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    if device is None:
-        device = exchange_device(group)
+    world, rank = g.world, g.rank
     if owner is None:
         owner = lpt_assign({n: weights[n] for n in names}, world)
     if k is None:
         k = next((v.shape[1] for v in local.values()), None)
-        ks = [None] * world
-        dist.all_gather_object(ks, k, group=group)
-        k = next(x for x in ks if x is not None)
+        k = next(x for x in g.all_gather_object(k) if x is not None)
     rows = [sum(n_bins[n] for n in names if owner[n] == r) for r in range(world)]
     pad = max(max(rows), 1)  # RCCL does not take empty buffers
-    send = torch.zeros((pad, k), dtype=torch.int64)
+    send = np.zeros((pad, k), np.int64)
     off = 0
     for n in names:
         if owner[n] == rank:
-            send[off:off + n_bins[n]] = torch.from_numpy(np.ascontiguousarray(local[n], dtype=np.int64))
+            send[off:off + n_bins[n]] = np.ascontiguousarray(local[n], dtype=np.int64)
             off += n_bins[n]
-    if device is not None:
-        send = send.to(device)
-    recv = [torch.zeros_like(send) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
+    recv = g.all_gather_i64(send).reshape(world, pad, k)
     out = {}
     offs = [0] * world
     for n in names:
         r = owner[n]
-        out[n] = recv[r][offs[r]:offs[r] + n_bins[n]].cpu().numpy()
+        out[n] = recv[r, offs[r]:offs[r] + n_bins[n]].copy()
         offs[r] += n_bins[n]
     return out
 
@@ -276,35 +239,28 @@ def gather_unit_rows(local: Dict[tuple, np.ndarray], units, n_rows: Dict[tuple, 
     """All-gather the integer rows of ``split_counts`` units: ``local[(contig, i0, i1)]`` holds this rank's units
     (shape ``[n_rows[unit], k]``; every rank knows every unit's row count), the result maps each contig to its units'
     rows concatenated in unit order - on every rank.  One collective, like ``gather_bin_vectors``."""
+    from . import comm
+    g = comm.current(group)
     keys = [(c, i0, i1) for _, c, i0, i1 in units]
-    if rank_world(group)[1] == 1:  # (decided without importing torch)
+    if g.world == 1:  # (decided without importing torch)
         got = {key: np.asarray(local[key], dtype=np.int64).reshape(-1, k) for key in keys}
     else:
-        import torch
-        import torch.distributed as dist
-
-        world = dist.get_world_size(group)
-        rank = dist.get_rank(group)
-        if device is None:
-            device = exchange_device(group)
+        world, rank = g.world, g.rank
         rows = [sum(n_rows[(c, i0, i1)] for r, c, i0, i1 in units if r == q) for q in range(world)]
         pad = max(max(rows), 1)  # RCCL does not take empty buffers
-        send = torch.zeros((pad, k), dtype=torch.int64)
+        send = np.zeros((pad, k), np.int64)
         off = 0
         for r, c, i0, i1 in units:
             if r == rank:
                 n = n_rows[(c, i0, i1)]
-                send[off:off + n] = torch.from_numpy(np.ascontiguousarray(local[(c, i0, i1)], dtype=np.int64).reshape(n, k))
+                send[off:off + n] = np.ascontiguousarray(local[(c, i0, i1)], dtype=np.int64).reshape(n, k)
                 off += n
-        if device is not None:
-            send = send.to(device)
-        recv = [torch.zeros_like(send) for _ in range(world)]
-        dist.all_gather(recv, send, group=group)
+        recv = g.all_gather_i64(send).reshape(world, pad, k)
         offs = [0] * world
         got = {}
         for r, c, i0, i1 in units:
             n = n_rows[(c, i0, i1)]
-            got[(c, i0, i1)] = recv[r][offs[r]:offs[r] + n].cpu().numpy()
+            got[(c, i0, i1)] = recv[r, offs[r]:offs[r] + n].copy()
             offs[r] += n
     out: Dict[str, list] = {}
     for key in keys:
@@ -388,16 +344,11 @@ class IntervalPlan:
 
 def allreduce_sum(value: int, group=None, device=None) -> int:
     """Sum of one int64 over ranks (the genome-wide total of ``coverage(normalize=True)``)."""
-    if rank_world(group)[1] == 1:
+    from . import comm
+    g = comm.current(group)
+    if g.world == 1:
         return int(value)
-    import torch
-    import torch.distributed as dist
-
-    if device is None:
-        device = exchange_device(group)
-    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return int(t.item())
+    return int(g.all_reduce_sum_i64(np.array([int(value)], np.int64))[0])
 
 
 def contig_owner(weights: Dict[str, float], group=None) -> Tuple[int, int, Dict[str, int]]:
@@ -416,14 +367,13 @@ def agree(error: Optional[BaseException] = None, group=None) -> None:
     """Collective check-point of a sharded command: every rank passes the exception its share of the work
     raised (or None).  If any rank failed, ALL ranks raise -- the failing rank its own exception, the others a
     ``RuntimeError`` naming it -- instead of the healthy ranks waiting forever in the next collective."""
-    rank, world = rank_world(group)
-    if world == 1:
+    from . import comm
+    g = comm.current(group)
+    if g.world == 1:
         if error is not None:
             raise error
         return
-    import torch.distributed as dist
-    said = [None] * world
-    dist.all_gather_object(said, None if error is None else f"{type(error).__name__}: {error}", group=group)
+    said = g.all_gather_object(None if error is None else f"{type(error).__name__}: {error}")
     if error is not None:
         raise error
     for r, msg in enumerate(said):
@@ -432,55 +382,35 @@ def agree(error: Optional[BaseException] = None, group=None) -> None:
 
 
 def allgather_object(obj, group=None) -> list:
-    """Small Python objects of every rank, in rank order (``[obj]`` without a process group)."""
-    rank, world = rank_world(group)
-    if world == 1:
-        return [obj]
-    import torch.distributed as dist
-    out = [None] * world
-    dist.all_gather_object(out, obj, group=group)
-    return out
-
-
-_P2P_CHUNK = 1 << 30
+    """Small Python objects of every rank, in rank order (``[obj]`` without a group)."""
+    from . import comm
+    return comm.current(group).all_gather_object(obj)
 
 
 def gather_payloads(local: Dict[int, bytes], owner: Sequence[int], group=None, device=None) -> Optional[List[bytes]]:
     """Byte payloads of numbered work items to rank 0: item ``k`` was produced by rank ``owner[k]``
     (``local[k]`` there).  Rank 0 returns the list of all payloads in item order, the other ranks ``None``.
-    Transport: one size exchange, then one point-to-point message per sending rank (RCCL send / recv of a
-    uint8 tensor over xGMI; gloo in CPU tests) -- compressed output sections, a few hundred MB at most."""
-    rank, world = rank_world(group)
+    Transport: one size exchange, then one point-to-point message per sending rank (``ftk_comm_send`` / ``recv``:
+    RCCL over xGMI; gloo in CPU tests) -- compressed output sections, a few hundred MB at most."""
+    from . import comm
+    g = comm.current(group)
+    rank, world = g.rank, g.world
     n = len(owner)
     if world == 1:
         return [local[k] for k in range(n)]
-    import torch
-    import torch.distributed as dist
-    if device is None:
-        device = exchange_device(group)
     mine = [k for k in range(n) if owner[k] == rank]
-    sizes = [None] * world
-    dist.all_gather_object(sizes, [len(local[k]) for k in mine], group=group)
-
-    def chunks(total):
-        return [(o, min(o + _P2P_CHUNK, total)) for o in range(0, total, _P2P_CHUNK)]
-
+    sizes = g.all_gather_object([len(local[k]) for k in mine])
     if rank != 0:
         blob = np.frombuffer(b"".join(bytes(local[k]) for k in mine), dtype=np.uint8).copy()
-        for a, b in chunks(len(blob)):
-            t = torch.from_numpy(blob[a:b])
-            dist.send(t.to(device) if device is not None else t, dst=0, group=group)
+        if len(blob):
+            g.send_bytes(blob, 0)
         return None
     out: List[Optional[bytes]] = [None] * n
     for k in mine:
         out[k] = bytes(local[k])
     for r in range(1, world):
         total = int(sum(sizes[r]))
-        buf = np.empty(total, np.uint8)
-        for a, b in chunks(total):
-            t = torch.empty(b - a, dtype=torch.uint8, device=device if device is not None else "cpu")
-            dist.recv(t, src=r, group=group)
-            buf[a:b] = t.cpu().numpy()
+        buf = g.recv_bytes(total, r) if total else np.empty(0, np.uint8)
         off = 0
         items = [k for k in range(n) if owner[k] == r]
         for k, sz in zip(items, sizes[r]):

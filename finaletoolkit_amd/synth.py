@@ -232,6 +232,61 @@ def write_paired_bam_contigs(path, contigs, depth, seed, read_len=50, step=8_388
     return out
 
 
+def write_paired_bam_native(path, contigs, depth, seed, read_len=50, fragments=None, level=1, threads=0,
+                            keep=("s", "e", "q", "st", "r1s", "r1e")):
+    """The file ``write_paired_bam_contigs`` writes, at the rate of the host threads instead of numpy's: every contig's
+    records are built, sorted and deflated in C (``ftk_synth_bam_contig``: 512 kb position windows, libdeflate), so a
+    whole-genome 60x BAM (BASELINE config 5: 1.2 G records, ~145 GB of record bytes) is a matter of the disk.  Same record
+    layout and order; sequence / quality bytes come from a counter-based generator instead of numpy's.
+    ``fragments``: optional ``callable(k, name, size) -> (s, e, q, st)`` (e.g. columns generated on the GPU); default
+    ``synth_contig(size, depth, seed + k)``.  Ends are stretched to ``read_len``.  Returns the same dict per contig
+    (``keep`` names the columns worth holding on to: a whole genome's are 11 GB)."""
+    import ctypes as C
+    import struct
+    from . import _lib as L, bgzf, writers
+    lib = L.load()
+    name_len = 10
+    text = b"@HD\tVN:1.6\tSO:coordinate\n" + b"".join(b"@SQ\tSN:%s\tLN:%d\n" % (c.encode(), n) for c, n in contigs)
+    head = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(contigs))
+    for c, n in contigs:
+        head += struct.pack("<i", len(c) + 1) + c.encode() + b"\0" + struct.pack("<i", n)
+    writers.bgzf_write(path, head, level=1, write_eof=False)
+    out, spans, linear = {}, [], []
+    never = np.uint64(0xFFFFFFFFFFFFFFFF)
+    for k, (c, size) in enumerate(contigs):
+        s, e, q, st = fragments(k, c, size) if fragments else synth_contig(size, depth, seed + k)
+        s = np.ascontiguousarray(s, np.int32)
+        e = np.maximum(e, s + read_len).astype(np.int32)
+        q, st = np.ascontiguousarray(q, np.uint8), np.ascontiguousarray(st, np.uint8)
+        lin = np.full(((size + read_len) >> 14) + 1, never, np.uint64)
+        first, end, n_rec = C.c_int64(-1), C.c_int64(-1), C.c_int64(0)
+        rc = lib.ftk_synth_bam_contig(str(path).encode(), k, int(size), L.ptr(s), L.ptr(e), L.ptr(q), L.ptr(st), len(s),
+                                      int(read_len), name_len, int(seed) + k, int(level), int(threads), L.ptr(lin), len(lin),
+                                      C.byref(first), C.byref(end), C.byref(n_rec))
+        if rc != L.FTK_OK:
+            raise OSError(lib.ftk_fragtable_error().decode())
+        assert n_rec.value == 2 * len(s), (c, n_rec.value, len(s))
+        has = lin != never  # (htslib: a window without records points at the next one's; behind the last: 0)
+        idx = np.where(has, np.arange(len(lin)), len(lin))
+        nxt = np.minimum.accumulate(idx[::-1])[::-1]
+        lin = np.where(nxt < len(lin), lin[np.minimum(nxt, len(lin) - 1)], np.uint64(0))
+        first_off = first.value if first.value >= 0 else None
+        spans.append((c, (first_off or 0) << 16, (end.value if first_off is not None else 0) << 16))
+        linear.append(lin)
+        fwd = st == 1
+        d = dict(n=len(s), first_off=first_off, end_off=end.value if first_off is not None else None, linear=lin)
+        cols = dict(s=s, e=e, q=q, st=st)
+        if "r1s" in keep or "r1e" in keep:
+            r1 = np.where(fwd, s, e - read_len).astype(np.int32)
+            cols["r1s"], cols["r1e"] = r1, (r1 + read_len).astype(np.int32)
+        d.update({name: v for name, v in cols.items() if name in keep})
+        out[c] = d
+    with open(path, "ab") as fh:
+        fh.write(bgzf._EOF)
+    bgzf.write_index(str(path) + ".bai", True, spans, linear)
+    return out
+
+
 def write_random_2bit(path, sizes, seed=SEED_BASE, n_blocks=True):
     """A UCSC ``.2bit`` reference of random bases for ``sizes = {contig: length}`` (little endian, version 0): the
     packed DNA is written as random bytes (T=0 C=1 A=2 G=3, four bases per byte, first base in the high bits), each

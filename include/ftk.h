@@ -520,19 +520,57 @@ int ftk_format_frag_rows(const char* contig, const int32_t* start, const int32_t
                          const uint8_t* strand, int64_t n, int bed6, int n_threads, char** out, int64_t* out_len);
 int ftk_bgzf_write(const char* path, const char* data, int64_t n, int level, int n_threads, int append, int write_eof,
                    int64_t* block_offsets);
+/* Test / bench tooling (BASELINE config 5 reads a whole-genome 60x BAM: ~1.2 G records): appends to `path` -- which
+ * already holds the BAM header's BGZF blocks -- the coordinate-sorted paired-end records of ONE contig, two per
+ * fragment (read1: flag 99 / 83, at the fragment's start when strand != 0, else at its end; the mate mirrored;
+ * TLEN = +-(end - start); one `read_len`M CIGAR; name = the fragment's index in `name_len - 1` decimal digits), built,
+ * sorted (position, read1 before read2, fragment index) and deflated by the host threads in windows of 512 kb, so memory
+ * stays bounded and the rate is libdeflate's.  Fragments must be sorted by start with end >= start + read_len.
+ * linear (may be NULL): the contig's 16 kb BAI linear index, n_linear >= ((contig_len + read_len) >> 14) + 1 entries
+ * preset to all-ones; entry w receives the virtual offset of the first record overlapping window w.  first_off / end_off:
+ * file offsets of the contig's first block and behind its last one (-1 / unchanged file end when it has no records).
+ * What the reference reads these files with: pysam.AlignmentFile.fetch, io/alignment.py:242-268. */
+int ftk_synth_bam_contig(const char* path, int32_t ref_id, int64_t contig_len, const int32_t* start, const int32_t* end,
+                         const uint8_t* mapq, const uint8_t* strand, int64_t n, int32_t read_len, int32_t name_len,
+                         uint64_t seed, int level, int n_threads, uint64_t* linear, int64_t n_linear,
+                         int64_t* first_off, int64_t* end_off, int64_t* n_records_out);
 int ftk_bigwig_fixedstep_sections(uint32_t chrom_id, const int64_t* iv_start, const int64_t* offsets, int64_t n_iv,
                                   const void* values, int value_kind, int32_t items_per_section, int level,
                                   int n_threads, char** out, int64_t* out_len, int64_t* n_sections_out,
                                   int64_t** section_table_out, double** section_stats_out);
 
-/* ---- multi-GPU -----------------------------------------------------------
- * One process and one ftk_ctx per GPU.  Contigs / genome runs are dealt to the ranks by the host; no
- * entry point of this library exchanges data between GPUs.  The only exchanges of the path -- the
- * all-gather of the per-bin DELFI vector (frag/_delfi.py:289-300's pool.starmap result list) and the
- * all-reduce of the genome-wide total of coverage(normalize=True) (frag/_coverage.py:215-227) -- are
- * the host's: torch.distributed over RCCL (finaletoolkit_amd/sharding.py), on buffers this library
- * wrote through device pointers (outputs of ftk_window_features / ftk_delfi_counts may be device
- * memory, ordered on the ctx stream; ftk_ctx_set_stream puts the launches on the collective's stream). */
+/* ---- multi-GPU (SURVEY 8-e, 8-b's export list) -------------------------------------------------
+ * One process and one ftk_ctx per GPU.  Contigs / genome runs are dealt to the ranks by the host and every window,
+ * bin and base depends on its own contig's fragments only, so the data path has no collective.  What remains are the
+ * two exchanges that stand where the reference collects its Pool's results: the all-gather of the per-bin DELFI /
+ * per-interval rows (frag/_delfi.py:289-300: pool.starmap's result list; frag/_coverage.py:212-248) and the all-reduce
+ * of the genome-wide total of coverage(normalize=True) (frag/_coverage.py:215-227) -- RCCL over xGMI, here behind the
+ * C ABI so that a host in any language can shard (finaletoolkit_amd/comm.py is the ctypes host).  librccl is resolved
+ * when the first communicator is created (dlopen "librccl.so.1": a copy already in the process, e.g. torch's, is
+ * re-used); one-GPU hosts never load it.
+ *
+ * ftk_comm_create: rank `rank` of `world` joins the job's communicator on ctx's device.  `id_hex_or_path` is what the
+ * ranks have in common: the 256 hex digits of an RCCL unique id (ftk_comm_unique_id on one rank, handed to the others
+ * by the host's own means), or a FILE PATH all ranks can reach -- rank 0 creates the id and writes it there (atomic
+ * rename), the others wait for it (FTK_COMM_TIMEOUT_S, default 600), rank 0's ftk_comm_destroy removes it.  NULL is
+ * accepted for world == 1.  A collective runs on the communicator's own HIP stream behind the work the ctx stream
+ * holds at the call, so later launches on the ctx stream overlap it.  Buffers may be host or device memory: with a
+ * host buffer the call returns when the result is there; with device buffers it returns at once and ftk_comm_join
+ * makes the ctx stream wait for the result (no host wait).  Every rank must make the same calls in the same order. */
+typedef struct ftk_comm ftk_comm;
+int ftk_comm_unique_id(char* hex_out /* [257] */);
+int ftk_comm_create(ftk_ctx* ctx, int rank, int world, const char* id_hex_or_path, ftk_comm** out);
+int ftk_comm_size(const ftk_comm* comm, int* rank_out, int* world_out);
+/* recv[r * n + i] = rank r's send[i]; n equal on all ranks */
+int ftk_allgather_i64(ftk_comm* comm, const int64_t* send, int64_t n, int64_t* recv);
+/* values[i] = sum over ranks, in place */
+int ftk_allreduce_sum_i64(ftk_comm* comm, int64_t* values, int64_t n);
+/* point to point (the compressed output sections a rank hands to the writing rank, frag/_multi_wps.py:300-341's
+ * parent-side writer): matching send / recv pairs, any size */
+int ftk_comm_send(ftk_comm* comm, int dst, const void* data, int64_t n_bytes);
+int ftk_comm_recv(ftk_comm* comm, int src, void* data, int64_t n_bytes);
+int ftk_comm_join(ftk_comm* comm);
+void ftk_comm_destroy(ftk_comm* comm);
 
 #ifdef __cplusplus
 }

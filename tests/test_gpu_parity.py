@@ -21,7 +21,27 @@ def data(engine):
     s, e, q, st = synth.synth_contig(CONTIG_LEN, depth=30.0, seed=7)
     # sprinkle short (< 120) and very short fragments so every WPS branch is hit
     engine.load_contig("synA", s, e, q, st)
-    return dict(s=s, e=e, q=q, st=st, fr=O.Frags(s, e, q, st))
+    d = dict(s=s, e=e, q=q, st=st, fr=O.Frags(s, e, q, st))
+    # the same fragments as BAM contigs (read1 fetch rule, io/alignment.py:245).  synBAM: read1 spans inside their
+    # fragments (forward -> at the fragment start, reverse -> at its end), what TLEN reconstruction gives for
+    # ordinary pairs - the kernels then read the read1 columns only for fragments crossing a window bound.
+    # synBAMx: one read1 in six sticks out of its fragment (TLEN shorter than the read's alignment), so the
+    # columns are read for every fragment.
+    rl = np.minimum(e - s, 100)
+    r1s = np.where(st == 1, s, e - rl).astype(np.int32)
+    r1e = (r1s + rl).astype(np.int32)
+    engine.load_contig("synBAM", s, e, q, st, r1s, r1e)
+    rng = np.random.default_rng(99)
+    out = rng.random(len(s)) < 1 / 6
+    shift = rng.integers(1, 400, len(s))
+    x1s = np.where(out & (st == 0), np.maximum(r1s - shift, 0), r1s).astype(np.int32)
+    x1e = np.where(out & (st == 1), r1e + shift, r1e).astype(np.int32)
+    engine.load_contig("synBAMx", s, e, q, st, x1s, x1e)
+    d["frs"] = {"synA": d["fr"], "synBAM": O.Frags(s, e, q, st, r1s, r1e), "synBAMx": O.Frags(s, e, q, st, x1s, x1e)}
+    return d
+
+
+KINDS = ["synA", "synBAM", "synBAMx"]
 
 
 def _window_sets(rng):
@@ -238,28 +258,34 @@ def test_frag_select_and_lengths(engine, data, policy):
         assert np.array_equal(gl, we - ws)
 
 
-def test_bam_read1_fetch_mode(engine, data):
-    # synthesise read1 spans: forward -> read1 at the fragment start, reverse -> at its end
-    s, e, st = data["s"], data["e"], data["st"]
-    rl = np.minimum(e - s, 100)
-    r1s = np.where(st == 1, s, e - rl).astype(np.int32)
-    r1e = (r1s + rl).astype(np.int32)
-    engine.load_contig("synBAM", s, e, data["q"], st, r1s, r1e)
-    fr = O.Frags(s, e, data["q"], st, r1s, r1e)
+@pytest.mark.parametrize("kind", ["synBAM", "synBAMx"])
+def test_bam_read1_fetch_mode(engine, data, kind):
+    """Read1 fetch rule (io/alignment.py:245) on every launch shape: read1 spans inside their fragments (the
+    columns are read for boundary-crossing fragments only) and partly outside (read for all)."""
+    fr = data["frs"][kind]
     rng = np.random.default_rng(5)
     for name, (ws, we) in _window_sets(rng).items():
         for policy in ("midpoint", "any"):
             want = O.c_window_counts(fr, ws, we, mapq_min=30, policy=policy)
-            got = engine.window_counts("synBAM", ws, we, 30, None, None, policy)
+            got = engine.window_counts(kind, ws, we, 30, None, None, policy)
             assert np.array_equal(got, want), (name, policy)
-    want = O.c_wps(fr, 50_000, 58_000, CONTIG_LEN, 120, 120, 180, 30)
-    assert np.array_equal(engine.wps("synBAM", 50_000, 58_000, CONTIG_LEN, 120, 120, 180, 30), want)
+    # WPS: the interval's fetch window [start - max_len, stop + max_len) is where read1 must overlap
+    for a, b, W, mn, mx in ((50_000, 58_000, 120, 120, 180), (0, 9_000, 120, 30, 400), (2_990_000, CONTIG_LEN, 60, 30, 200),
+                            (1_234_567, 1_250_001, 121, 100, 300)):
+        want = O.c_wps(fr, a, b, CONTIG_LEN, W, mn, mx, 30)
+        assert np.array_equal(engine.wps(kind, a, b, CONTIG_LEN, W, mn, mx, 30), want), (a, b, W)
+    starts = np.arange(100_000, 2_900_000, 70_001, dtype=np.int64)
+    stops = starts + rng.integers(1, 9_000, len(starts))
+    got, offs = engine.wps_intervals(kind, starts, stops, CONTIG_LEN, 120, 120, 180, 30)
+    for i, (a, b) in enumerate(zip(starts, stops)):
+        assert np.array_equal(got[offs[i]:offs[i + 1]], O.c_wps(fr, int(a), int(b), CONTIG_LEN, 120, 120, 180, 30)), i
+    for a, b in ((300_000, 304_000), (0, 5_000), (2_995_000, CONTIG_LEN)):
+        assert np.array_equal(engine.cleavage(kind, a, b, None, None, 20), O.c_cleavage(fr, a, b, None, None, 20)[2])
     ws, we = synth.tiling_windows(CONTIG_LEN, 100_000)
     want = O.c_delfi_counts(fr, ws, we, 30, None, None, None)
-    got = engine.delfi_counts("synBAM", ws, we, 30)
+    got = engine.delfi_counts(kind, ws, we, 30)
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
-    engine.release("synBAM")
 
 
 def test_empty_and_errors(engine):
@@ -477,12 +503,16 @@ def test_block_kernels_forced_on_every_window_set(fast):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+@pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("seed", [0, 1, 2])
-def test_fast_block_kernels_against_the_oracle(engine, data, seed):
+def test_fast_block_kernels_against_the_oracle(engine, data, seed, kind):
     """The FAST block-per-window kernels (midpoint policy, no length bounds, one mapq cut: the request of the
     whole-genome pass) on tilings of several bin widths with extreme and inverted windows mixed in; coverage,
-    histogram and DELFI separately and fused, blacklist CSR and gap intervals near and far from the windows."""
+    histogram and DELFI separately and fused, blacklist CSR and gap intervals near and far from the windows.
+    On a tabix-style contig and on BAM contigs (read1 fetch rule) with read1 spans inside / partly outside
+    their fragments."""
     rng = np.random.default_rng(3000 + seed)
+    data = dict(data, fr=data["frs"][kind])
     for width in (100_000, 5_000, 1_237, 20_000):
         ws, we = synth.tiling_windows(CONTIG_LEN, width)
         ws, we = ws.copy(), we.copy()
@@ -504,8 +534,8 @@ def test_fast_block_kernels_against_the_oracle(engine, data, seed):
         tag = (seed, width, q, len_lo, n_bins)
         want_c = O.c_window_counts(data["fr"], ws, we, mapq_min=q)
         want_h, want_o = O.c_fraglen_hist(data["fr"], ws, we, len_lo, n_bins, mapq_min=q)
-        assert np.array_equal(engine.window_counts("synA", ws, we, q), want_c), tag
-        gh, go = engine.fraglen_hist("synA", ws, we, len_lo, n_bins, q)
+        assert np.array_equal(engine.window_counts(kind, ws, we, q), want_c), tag
+        gh, go = engine.fraglen_hist(kind, ws, we, len_lo, n_bins, q)
         assert np.array_equal(gh, want_h) and np.array_equal(go, want_o), tag
         bl_s = np.sort(rng.integers(0, CONTIG_LEN - 6000, 300)).astype(np.int32)
         bl_e = (bl_s + rng.integers(1, 5000, 300)).astype(np.int32)
@@ -516,17 +546,17 @@ def test_fast_block_kernels_against_the_oracle(engine, data, seed):
                      (700_000, 650_000, [(5, 2_000_000), (1_900_000, 2_100_000)])):
             for bl in ((None, None), (bl_s, bl_e)):
                 want = O.c_delfi_counts(data["fr"], ws, we, q, bl[0], bl[1], gaps)
-                got = engine.delfi_counts("synA", ws, we, q, bl[0], bl[1], gaps)
+                got = engine.delfi_counts(kind, ws, we, q, bl[0], bl[1], gaps)
                 for a, b in zip(got, want):
                     assert np.array_equal(a, b), (tag, gaps, bl[0] is None)
-            fused = engine.window_features("synA", ws, we, q, hist=(len_lo, n_bins),
+            fused = engine.window_features(kind, ws, we, q, hist=(len_lo, n_bins),
                                            delfi=dict(quality_threshold=q, bl_start=bl_s, bl_end=bl_e, gaps=gaps))
             want = O.c_delfi_counts(data["fr"], ws, we, q, bl_s, bl_e, gaps)
             assert np.array_equal(fused["coverage"], want_c) and np.array_equal(fused["hist"], want_h), (tag, gaps)
             assert np.array_equal(fused["overflow"], want_o), (tag, gaps)
             assert np.array_equal(fused["short"], want[0]) and np.array_equal(fused["long"], want[1]), (tag, gaps)
         # a different DELFI mapq cut takes the general kernels: same answers
-        fused = engine.window_features("synA", ws, we, q, hist=(len_lo, n_bins), delfi=dict(quality_threshold=17))
+        fused = engine.window_features(kind, ws, we, q, hist=(len_lo, n_bins), delfi=dict(quality_threshold=17))
         want = O.c_delfi_counts(data["fr"], ws, we, 17)
         assert np.array_equal(fused["coverage"], want_c) and np.array_equal(fused["short"], want[0]), tag
         assert np.array_equal(fused["long"], want[1]), tag
@@ -672,8 +702,9 @@ def test_one_call_file_loaders(engine, tmp_path):
     assert lib.ftk_frags_load_fraggz(engine.ctx, str(tmp_path / "absent.gz").encode(), None, 2, base, C.byref(n)) == L.FTK_ERR_IO
 
 
+@pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("win_len", [100_000, 5_200, 250_001])
-def test_fused_wps_and_window_features_equal_separate_calls(engine, data, win_len):
+def test_fused_wps_and_window_features_equal_separate_calls(engine, data, win_len, kind):
     """ftk_wps_window_features (one pass) == ftk_wps + ftk_window_features, for bin lengths from just above
     the minimum (tile + longest fragment) to odd sizes, with blacklist and gaps."""
     rng = np.random.default_rng(win_len)
@@ -683,13 +714,13 @@ def test_fused_wps_and_window_features_equal_separate_calls(engine, data, win_le
     bl_s = np.sort(rng.integers(0, CONTIG_LEN - 5000, 120)).astype(np.int32)
     bl_e = (bl_s + rng.integers(100, 4000, 120)).astype(np.int32)
     gaps = (1_200_000, 1_500_000, [(0, 10_000), (CONTIG_LEN - 10_000, CONTIG_LEN)])
-    want = engine.window_features("synA", ws, we, 25, 50, 700, hist=(20, 640),
+    want = engine.window_features(kind, ws, we, 25, 50, 700, hist=(20, 640),
                                   delfi=dict(quality_threshold=30, bl_start=bl_s, bl_end=bl_e, gaps=gaps))
-    want_wps = engine.wps("synA", 0, CONTIG_LEN, CONTIG_LEN)
+    want_wps = engine.wps(kind, 0, CONTIG_LEN, CONTIG_LEN)
     cov, over = np.zeros(n_win, np.int64), np.zeros(n_win, np.int64)
     hist = np.zeros((n_win, 640), np.uint32)
     sh, lg = np.zeros(n_win, np.int64), np.zeros(n_win, np.int64)
-    got_wps = engine.wps_window_features("synA", CONTIG_LEN, 0, win_len, n_win, feat_quality=25, feat_min_length=50,
+    got_wps = engine.wps_window_features(kind, CONTIG_LEN, 0, win_len, n_win, feat_quality=25, feat_min_length=50,
                                          feat_max_length=700, coverage=cov, hist=hist, hist_bins=(20, 640),
                                          overflow=over, delfi_q=30, bl_start=bl_s, bl_end=bl_e, gaps=gaps, short=sh,
                                          long=lg)
@@ -698,25 +729,26 @@ def test_fused_wps_and_window_features_equal_separate_calls(engine, data, win_le
         assert np.array_equal(got, want[key]), (key, win_len)
     # coverage only / DELFI only
     cov2 = np.zeros(n_win, np.int64)
-    engine.wps_window_features("synA", CONTIG_LEN, 0, win_len, n_win, feat_quality=25, feat_min_length=50,
+    engine.wps_window_features(kind, CONTIG_LEN, 0, win_len, n_win, feat_quality=25, feat_min_length=50,
                                feat_max_length=700, coverage=cov2)
     assert np.array_equal(cov2, cov)
     sh2, lg2 = np.zeros(n_win, np.int64), np.zeros(n_win, np.int64)
-    engine.wps_window_features("synA", CONTIG_LEN, 0, win_len, n_win, delfi_q=30, bl_start=bl_s, bl_end=bl_e,
+    engine.wps_window_features(kind, CONTIG_LEN, 0, win_len, n_win, delfi_q=30, bl_start=bl_s, bl_end=bl_e,
                                gaps=gaps, short=sh2, long=lg2)
     assert np.array_equal(sh2, sh) and np.array_equal(lg2, lg)
     # bins that start inside the contig and stop before its end: the rest of the contig is ignored
     sub = np.zeros(5, np.int64)
-    engine.wps_window_features("synA", CONTIG_LEN, win_len, win_len, 5, feat_quality=25, feat_min_length=50,
+    engine.wps_window_features(kind, CONTIG_LEN, win_len, win_len, 5, feat_quality=25, feat_min_length=50,
                                feat_max_length=700, coverage=sub)
     assert np.array_equal(sub, cov[1:6])
     from finaletoolkit_amd import _lib as L
     with pytest.raises(L.FtkError):  # bins shorter than tile + longest fragment
-        engine.wps_window_features("synA", CONTIG_LEN, 0, 4_000, 10, coverage=np.zeros(10, np.int64))
+        engine.wps_window_features(kind, CONTIG_LEN, 0, 4_000, 10, coverage=np.zeros(10, np.int64))
 
 
+@pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("win_len", [100_000, 37_777])
-def test_features_and_wps_in_one_launch_equal_the_two_calls(engine, data, win_len):
+def test_features_and_wps_in_one_launch_equal_the_two_calls(engine, data, win_len, kind):
     """ftk_window_features_wps: the merged launch (feature blocks first, WPS tiles behind them in the same grid)
     gives exactly the results of ftk_window_features followed by ftk_wps -- coverage + histogram + DELFI with
     blacklist and gaps, coverage alone, DELFI alone; a request the FAST block path does not serve (length bounds
@@ -742,12 +774,12 @@ def test_features_and_wps_in_one_launch_equal_the_two_calls(engine, data, win_le
                         (dict(quality_threshold=30), 123_457, 2_000_001, 121),
                         (dict(quality_threshold=25, min_length=50, max_length=700), 0, CONTIG_LEN, 120),  # general kernels
                         (dict(quality_threshold=30, intersect_policy="any"), 5_000, 900_000, 60)):
-        want = engine.window_features("synA", ws, we, hist=(20, 640),
+        want = engine.window_features(kind, ws, we, hist=(20, 640),
                                       delfi=dict(quality_threshold=30, bl_start=bl_s, bl_end=bl_e, gaps=gaps), **kw)
-        want_wps = engine.wps("synA", a, b, CONTIG_LEN, W, 100, 200, 20)
+        want_wps = engine.wps(kind, a, b, CONTIG_LEN, W, 100, 200, 20)
         o = outs()
         w = torch.full((b - a,), -99, dtype=torch.int64, device=dev)
-        engine.window_features_wps("synA", ws, we, w, a, b, CONTIG_LEN, coverage=o["coverage"], hist=o["hist"],
+        engine.window_features_wps(kind, ws, we, w, a, b, CONTIG_LEN, coverage=o["coverage"], hist=o["hist"],
                                    hist_bins=(20, 640), overflow=o["overflow"], delfi_q=30, bl_start=bl_s, bl_end=bl_e,
                                    gaps=gaps, short=o["short"], long=o["long"], window_size=W, wps_min_length=100,
                                    wps_max_length=200, wps_quality=20, **kw)
@@ -759,18 +791,18 @@ def test_features_and_wps_in_one_launch_equal_the_two_calls(engine, data, win_le
     # one feature at a time, and a host WPS array (two launches)
     o = outs()
     w = torch.empty(CONTIG_LEN, dtype=torch.int64, device=dev)
-    engine.window_features_wps("synA", ws, we, w, 0, CONTIG_LEN, CONTIG_LEN, coverage=o["coverage"])
-    assert np.array_equal(o["coverage"].cpu().numpy(), engine.window_counts("synA", ws, we, 30))
-    engine.window_features_wps("synA", ws, we, w, 0, CONTIG_LEN, CONTIG_LEN, delfi_q=30, bl_start=bl_s, bl_end=bl_e, gaps=gaps,
+    engine.window_features_wps(kind, ws, we, w, 0, CONTIG_LEN, CONTIG_LEN, coverage=o["coverage"])
+    assert np.array_equal(o["coverage"].cpu().numpy(), engine.window_counts(kind, ws, we, 30))
+    engine.window_features_wps(kind, ws, we, w, 0, CONTIG_LEN, CONTIG_LEN, delfi_q=30, bl_start=bl_s, bl_end=bl_e, gaps=gaps,
                                short=o["short"], long=o["long"])
-    sh, lg, _ = engine.delfi_counts("synA", ws, we, 30, bl_s, bl_e, gaps)
+    sh, lg, _ = engine.delfi_counts(kind, ws, we, 30, bl_s, bl_e, gaps)
     assert np.array_equal(o["short"].cpu().numpy(), sh) and np.array_equal(o["long"].cpu().numpy(), lg)
-    assert np.array_equal(w.cpu().numpy(), engine.wps("synA", 0, CONTIG_LEN, CONTIG_LEN))
+    assert np.array_equal(w.cpu().numpy(), engine.wps(kind, 0, CONTIG_LEN, CONTIG_LEN))
     host = np.zeros(CONTIG_LEN, np.int64)
     cov = np.zeros(n_win, np.int64)
-    engine.window_features_wps("synA", ws, we, host, 0, CONTIG_LEN, CONTIG_LEN, coverage=cov)
-    assert np.array_equal(host, engine.wps("synA", 0, CONTIG_LEN, CONTIG_LEN))
-    assert np.array_equal(cov, engine.window_counts("synA", ws, we, 30))
+    engine.window_features_wps(kind, ws, we, host, 0, CONTIG_LEN, CONTIG_LEN, coverage=cov)
+    assert np.array_equal(host, engine.wps(kind, 0, CONTIG_LEN, CONTIG_LEN))
+    assert np.array_equal(cov, engine.window_counts(kind, ws, we, 30))
 
 
 def test_wps_host_results_cross_the_link_narrow_and_arrive_exact(engine):

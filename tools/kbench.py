@@ -21,10 +21,22 @@ eng = Engine(0)
 _stream = torch.cuda.Stream()  # one explicit stream for torch ops and ftk launches (handle 0 = "own stream")
 torch.cuda.set_stream(_stream)
 eng.set_stream(_stream.cuda_stream)
-n = synth.n_fragments(size, 30.0)
+DEPTH = float(os.environ.get("KBENCH_DEPTH", "30"))
+BAM = os.environ.get("KBENCH_BAM", "0") != "0"   # read1 columns beside the fragments: the BAM fetch rule (io/alignment.py:245)
+n = synth.n_fragments(size, DEPTH)
 s, e, q, st = bench.gen_contig_device(torch, dev, size, n, 1)
 torch.cuda.synchronize()
 eng.load_contig_device("c", s, e, q, st, n)
+FRAG_BYTES = 10
+if BAM:
+    e = torch.maximum(e, s + 50)
+    eng.load_contig_device("c", s, e, q, st, n)
+    r1s = torch.where(st == 1, s, e - 50).to(torch.int32).contiguous()
+    r1e = (r1s + 50).contiguous()
+    torch.cuda.synchronize()
+    eng.set_read1("c", r1s, r1e, n)
+    FRAG_BYTES = 18  # +8 B per fragment for the read1 columns
+    print(f"BAM contig: {n} fragments at {DEPTH}x, read1 columns resident; is_bam={eng.is_bam('c')}", flush=True)
 ws, we = synth.tiling_windows(size, 100_000)
 d_ws, d_we = torch.from_numpy(ws).to(dev), torch.from_numpy(we).to(dev)
 out = torch.empty(size, dtype=torch.int64, device=dev)
@@ -73,7 +85,18 @@ if "cal" in which:
     timeit(lambda: out.copy_(src), "torch copy int64 (r+w)", 16 * size)
     del src
 if "wps" in which:
-    timeit(lambda: eng.wps("c", 0, size, size, 120, 120, 180, 30, out=out), "wps W=120 120-180", 10 * n + 8 * size)
+    timeit(lambda: eng.wps("c", 0, size, size, 120, 120, 180, 30, out=out), "wps W=120 120-180", FRAG_BYTES * n + 8 * size)
+if "merged" in which:
+    # the step's launch: feature blocks (coverage + 1001-bin histogram + DELFI with blacklist and gaps) first, WPS tiles behind
+    bl_s, bl_e = bench.synth_blacklist(size, 5, 160)
+    sh = torch.zeros(len(ws), dtype=torch.int64, device=dev)
+    lg = torch.zeros(len(ws), dtype=torch.int64, device=dev)
+    gp = bench.synth_gaps(size)
+    f = lambda: eng.window_features_wps("c", ws, we, out, 0, size, size, coverage=cov, hist=hist, hist_bins=(0, 1001),
+                                        overflow=over, delfi_q=30, bl_start=bl_s, bl_end=bl_e, gaps=gp, short=sh, long=lg)
+    nb = 2 * FRAG_BYTES * n + 8 * size + len(ws) * (1001 * 4 + 32)
+    timeit(f, "features + WPS, one launch", nb)
+    timeit(f, "features + WPS x10 chained", nb, cold="chain")
 if "rd" in which:
     big = torch.ones(60_000_000, dtype=torch.int32, device=dev)  # 240 MB
     timeit(lambda: big.sum(), "torch sum 240MB warm", 240e6)
@@ -97,7 +120,7 @@ if "hist" in which:
 if "feat" in which:
     import ctypes as C
     from finaletoolkit_amd import _lib as L
-    flt = L.make_filter(30, None, None, "midpoint")
+    flt = L.make_filter(30, None, None, "midpoint", L.FETCH_BAM_READ1 if BAM else L.FETCH_TABIX)
     sh = torch.zeros(len(ws), dtype=torch.int64, device=dev)
     lg = torch.zeros(len(ws), dtype=torch.int64, device=dev)
     bl_s, bl_e = bench.synth_blacklist(size, 5, 160)
@@ -110,9 +133,9 @@ if "feat" in which:
             len(bl_s), C.byref(g), L.ptr(sh) if delfi_on else None, L.ptr(lg) if delfi_on else None))
     for name, kw in [("cov", dict(hist_on=False, delfi_on=False)), ("cov+hist", dict(delfi_on=False)),
                      ("delfi", dict(cov_on=False, hist_on=False)), ("cov+hist+delfi", {})]:
-        timeit(lambda: fused(**kw), "fused " + name + " x10 chained", 10 * n, cold="chain")
-        timeit(lambda: fused(**kw), "fused " + name + " COLD(read)", 10 * n, cold="read")
-        timeit(lambda: fused(**kw), "fused " + name + " COLD(dirty)", 10 * n, cold=True)
+        timeit(lambda: fused(**kw), "fused " + name + " x10 chained", FRAG_BYTES * n, cold="chain")
+        timeit(lambda: fused(**kw), "fused " + name + " COLD(read)", FRAG_BYTES * n, cold="read")
+        timeit(lambda: fused(**kw), "fused " + name + " COLD(dirty)", FRAG_BYTES * n, cold=True)
 if "cleave" in which:
     # whole-contig cleavage profile into a device buffer (float64 per base, like WPS's int64)
     import ctypes as C
