@@ -62,7 +62,6 @@ def main():
     # on the build boxes already, kept here for a launcher that starts the ranks from a cleaner environment)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
-    import torch.distributed as dist
 
     from finaletoolkit_amd import _lib
     from finaletoolkit_amd.engine import Engine
@@ -89,22 +88,25 @@ def main():
         os.environ["FTK_DEVICE"] = "0"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # FTK_BENCH_FORCE_DIST=1 drives the collective code path with a 1-rank RCCL group (1-GPU boxes)
+    # FTK_BENCH_FORCE_DIST=1 drives the collective code path with a 1-rank RCCL communicator (1-GPU boxes)
     use_dist = world > 1 or bool(os.environ.get("FTK_BENCH_FORCE_DIST"))
-    # FTK_BENCH_DIST_BACKEND=gloo (test mode): collectives go through host copies, so several ranks can share
-    # one GPU (LOCAL_RANK=0 for all) and the multi-rank logic can be exercised on a 1-GPU box
-    backend = os.environ.get("FTK_BENCH_DIST_BACKEND", "nccl")
-    cdev = dev if backend == "nccl" else torch.device("cpu")
+    # The exchange goes through finaletoolkit_amd/comm.py: "rccl" = the library's own communicator (ftk_comm_* of
+    # include/ftk.h: RCCL over xGMI, device buffers, no torch.distributed); FTK_BENCH_DIST_BACKEND=gloo (test mode):
+    # torch.distributed over host copies, so several ranks can share one GPU (LOCAL_RANK=0 for all) and the
+    # multi-rank logic can be exercised on a 1-GPU box
+    backend = os.environ.get("FTK_BENCH_DIST_BACKEND", "rccl")
+    grp = None
     if use_dist:
+        from finaletoolkit_amd import comm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        import datetime
         # (ten minutes instead of the backends' 10-30: a rank that failed alone must not hold the others for half an hour)
-        limit = datetime.timedelta(minutes=10)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
+        os.environ.setdefault("FTK_DIST_TIMEOUT_S", "600")
+        os.environ["FTK_DEVICE"] = str(local)
+        if world > 1:
+            grp = comm.join(backend)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
+            grp = comm._GROUP = comm.RcclGroup(0, 1, local, None)
 
     sizes = dict(synth.B37_SIZES)
     if args.contigs:
@@ -195,23 +197,28 @@ def main():
     # The DELFI (short, long) vectors are written by the kernels straight into the all-gather send
     # buffer: row 0 = short, row 1 = long, this rank's contigs back to back (no packing kernels).
     gather_in = torch.zeros((2, max_bins_rank), dtype=torch.int64, device=dev)
-    gather_out = [torch.zeros_like(gather_in, device=cdev) for _ in range(world)] if use_dist else None
+    native = use_dist and grp.backend == "rccl"
+    # rank r's rows land in gather_out[r]: in HBM for the library's communicator, on the host in the gloo test mode
+    gather_out = torch.zeros((world, 2, max_bins_rank), dtype=torch.int64, device=dev if native else "cpu") if use_dist else None
+    if native:
+        grp.set_stream(stream.cuda_stream)  # the collectives fork from, and join into, the stream of the launches
     collect = [True]  # priming steps skip the collective: their count differs from rank to rank
 
     # The all-gather only needs the DELFI rows, which are complete once the step's LAST window-feature launch
-    # is on the stream: it is started there (RCCL's own stream, ordered after the feature pass) and runs
+    # is on the stream: it is started there (the communicator's own stream, ordered after the feature pass) and runs
     # concurrently with the WPS launches that follow; the step ends by making the compute stream wait for it.
     def exchange_start():
         if not (use_dist and collect[0]):
             return None
-        if backend != "nccl":  # test backend: host copies, synchronous
-            dist.all_gather(gather_out, gather_in.cpu())
+        if not native:  # test backend: host copies, synchronous
+            gather_out.copy_(torch.from_numpy(grp.all_gather_i64(gather_in.cpu().numpy())).reshape(gather_out.shape))
             return None
-        return dist.all_gather(gather_out, gather_in, async_op=True)
+        grp.all_gather_i64_device(gather_in, gather_in.numel(), gather_out)
+        return grp
 
     def exchange_finish(work):
         if work is not None:
-            work.wait()
+            work.join()
     r0 = 0
     for c in mine:
         per[c]["short"] = gather_in[0, r0:r0 + per[c]["nw"]]
@@ -351,7 +358,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
+            grp.barrier()
         torch.cuda.synchronize()
 
     # The host enqueues a step (about 100 asynchronous launches) much faster than the GPU runs it; keep at
@@ -402,10 +409,8 @@ def main():
     run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    if use_dist:  # the slowest rank's time
+        dt = max(grp.all_gather_object(dt))
     ms_per_step = dt * 1e3 / args.steps
     if trace is not None and rank == 0:
         for timed, host_s, e0, e1 in trace:
@@ -475,21 +480,19 @@ def main():
     checks["cov_sum_eq_hist_sum"] = tot_cov == tot_hist
 
     if use_dist:  # every rank must hold every contig's (short, long) rows, in LPT rank order
+        torch.cuda.synchronize()
         ok = True
         for c in mine:
             o = sum(per_rank_rows[rank][:per_rank_order[rank].index(c)])
-            ok = ok and torch.equal(gather_out[rank][0, o:o + per[c]["nw"]], per[c]["short"].to(cdev)) \
-                and torch.equal(gather_out[rank][1, o:o + per[c]["nw"]], per[c]["long"].to(cdev))
+            ok = ok and torch.equal(gather_out[rank, 0, o:o + per[c]["nw"]].cpu(), per[c]["short"].cpu()) \
+                and torch.equal(gather_out[rank, 1, o:o + per[c]["nw"]].cpu(), per[c]["long"].cpu())
         checks["allgather_roundtrip"] = bool(ok)
         # every rank now holds the whole-genome vector: total DELFI fragments must match on all ranks
-        tot = torch.stack([g.sum() for g in gather_out]).sum().reshape(1)
-        tots = [torch.zeros_like(tot) for _ in range(world)]
-        dist.all_gather(tots, tot)
-        checks["allgather_same_on_all_ranks"] = bool(all(int(t.item()) == int(tot.item()) for t in tots))
+        tot = int(gather_out.sum().item())
+        checks["allgather_same_on_all_ranks"] = bool(all(t == tot for t in grp.all_gather_object(tot)))
         # and it must be the whole genome's DELFI count: compare with the sum of what every rank computed itself
-        mine_tot = torch.stack([gather_in.sum()]).to(cdev)
-        dist.all_reduce(mine_tot)
-        checks["allgather_total_eq_sum_of_ranks"] = int(mine_tot.item()) == int(tot.item())
+        mine_tot = int(grp.all_reduce_sum_i64(np.array([int(gather_in.sum().item())], np.int64))[0])
+        checks["allgather_total_eq_sum_of_ranks"] = mine_tot == tot
     file_leg = None
     if use_dist and world > 1 and not sim and not args.no_end_to_end:
         # N ranks, ONE file: BASELINE config 4 end to end through the product function (every rank index-seeks and
@@ -503,7 +506,7 @@ def main():
         del all_wps, all_hist, all_cov, all_over
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
-        file_leg = multi_rank_file_leg(torch, dist, rank, world, {c: sizes[c] for c in names}, args.depth)
+        file_leg = multi_rank_file_leg(torch, grp, rank, world, {c: sizes[c] for c in names}, args.depth)
     e2e = None
     if rank == 0 and world == 1 and not sim and not args.no_end_to_end:
         # file -> result legs (SURVEY 8-d's second figure).  The resident workload is released first.
@@ -528,8 +531,9 @@ def main():
         out = {
             "metric": "genomic windows/sec (coverage+WPS+DELFI) at 30x WGS",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world,
-            "rccl_ranks": (dist.get_world_size() if use_dist and backend == "nccl" else None),
-            "exchange": (f"torch.distributed/{backend} all-gather, {dist.get_world_size()} ranks" if use_dist else "none (1 rank)"),
+            "rccl_ranks": (grp.world if native else None),  # the size ftk_comm_size reports for the library's communicator
+            "exchange": (f"{grp.backend} all-gather ({'libftk_hip.so ftk_comm_*: RCCL' if native else 'torch.distributed, test mode'}), "
+                         f"{grp.world} ranks" if use_dist else "none (1 rank)"),
             "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "int32/int64", "data": "synthetic",
@@ -546,8 +550,7 @@ def main():
                          + " per step") if batched else "per unit",
         }
     if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        comm.leave()
     if rank == 0:
         # RCCL prints its version banner through C stdio: flush that first so the JSON line is the last line
         try:
@@ -618,7 +621,7 @@ def leg_floor(leg, file_bytes, inflated_bytes, kind, h2d_gbs, rates):
                         frac_of_floor_best=round(floor / leg["best_s"], 3), frac_of_floor_median=round(floor / leg["median_s"], 3))
 
 
-def multi_rank_file_leg(torch, dist, rank, world, sizes, depth, reps: int = 2):
+def multi_rank_file_leg(torch, grp, rank, world, sizes, depth, reps: int = 2):
     """BASELINE config 4 with N ranks: rank 0 writes ONE indexed fragment file of the run's contigs (not timed), then
     every rank calls the product's ``frag.delfi`` on it under the bench's process group: contigs dealt by LPT, a rank
     reads its contigs' blocks through the tabix index and inflates / parses / counts them on ITS GPU with its share
@@ -655,7 +658,7 @@ def multi_rank_file_leg(torch, dist, rank, world, sizes, depth, reps: int = 2):
             synth.write_random_2bit(os.path.join(tmp, "genome.2bit"), sizes)
             t_write = time.perf_counter() - t0
             box[0] = (tmp, rows_total)
-        dist.broadcast_object_list(box, src=0)
+        box[0] = grp.broadcast_object(box[0], src=0)
         tmp, rows_total = box[0]
         pg = os.path.join(tmp, "genome.frag.gz")
         side = [os.path.join(tmp, f) for f in ("genome.chrom.sizes", "bins.bed", "blacklist.bed", "gaps.bed", "genome.2bit")]
@@ -666,7 +669,7 @@ def multi_rank_file_leg(torch, dist, rank, world, sizes, depth, reps: int = 2):
             source.close_all()
             del source.REGION_READS[:]
             torch.cuda.synchronize()
-            dist.barrier()
+            grp.barrier()
             t0 = time.perf_counter()
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
@@ -675,8 +678,7 @@ def multi_rank_file_leg(torch, dist, rank, world, sizes, depth, reps: int = 2):
                                 workers=threads)
             mine_s = time.perf_counter() - t0
             decoded = sorted(k.split(":", 1)[1] for k in source.get_engine().contigs)
-            said = [None] * world
-            dist.all_gather_object(said, dict(rank=rank, total_s=round(mine_s, 4), stages_s=dict(FD.LAST_STAGE_S),
+            said = grp.all_gather_object(dict(rank=rank, total_s=round(mine_s, 4), stages_s=dict(FD.LAST_STAGE_S),
                                               contigs_decoded=len(decoded), decoder_threads=threads,
                                               regions_read=[list(r[1:]) for r in source.REGION_READS],
                                               frame_sha=hashlib.sha256(df.to_csv(index=False).encode()).hexdigest(),
@@ -702,7 +704,7 @@ def multi_rank_file_leg(torch, dist, rank, world, sizes, depth, reps: int = 2):
                 file_and_side_files_write_s=round(t_write, 1), repetitions=reps, **best),
                 "note": "one indexed file read by all ranks through frag.delfi; wall time of the slowest rank; PCIe and "
                         "the all-gather included; never the headline value"}
-        dist.barrier()
+        grp.barrier()
         return out
     except Exception as exc:  # the headline line must still be printed
         return {"error": f"{type(exc).__name__}: {exc}"}

@@ -272,9 +272,11 @@ def join(backend: Optional[str] = None) -> Group:
             raise RuntimeError(f"rank {rank}: GPU {local} is not visible ({n.value} devices); one rank per GPU, no fallback")
         _GROUP = RcclGroup(rank, world, local, id_file())
         return _GROUP
+    import datetime
     import torch
     import torch.distributed as dist
     if not dist.is_initialized():
+        limit = datetime.timedelta(seconds=float(os.environ.get("FTK_DIST_TIMEOUT_S", "1800")))
         if backend == "nccl":
             from . import _lib
             _lib._hardware_queues()  # torch starts the HIP runtime below; the decoder's queue count must be set before
@@ -282,9 +284,9 @@ def join(backend: Optional[str] = None) -> Group:
                 raise RuntimeError(f"rank {rank}: GPU {local} is not visible ({torch.cuda.device_count()} devices); "
                                    f"one rank per GPU, no fallback")
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=limit)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
     _GROUP = TorchGroup()
     return _GROUP
 

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import time
 import warnings
+from contextlib import nullcontext
 from os import PathLike
 from pathlib import Path
 from sys import stderr, stdin
@@ -35,48 +36,39 @@ def _read_header(input_file, chrom_sizes, src) -> list[tuple[str, int]]:
     return chrom_sizes_to_list(chrom_sizes)
 
 
-def _read_sites(site_bed, interval_size, references, chrom_sizes_dict):
-    """Centred, non-overlapping windows from a site BED (frag/_multi_wps.py:240-297)."""
-    contigs, starts, stops = [], [], []
-    left_of_site = round(-interval_size / 2)
-    right_of_site = round(interval_size / 2)
-    assert right_of_site - left_of_site == interval_size
-    bed = stdin if site_bed == "-" else open(site_bed)
-    try:
-        prev_contig = None
-        prev_start = 0
-        prev_stop = 0
-        for line in bed:
-            contents = line.split()
-            contig = contents[0].strip()
-            if int(contents[1]) > int(contents[2]):
-                raise ValueError(
-                    f"[multi_wps] {contig}:{contents[1]}-{contents[2]} is invalid. Please be sure start coordinate "
-                    f"occurs before stop for all intervals in {site_bed}.")
-            if contig not in references:
-                warnings.warn(f"Skipping site {contig}:{int(contents[1])} from site_bed (chrom not in chrom_sizes)",
-                              UserWarning)
-                continue
-            midpoint = (int(contents[1]) + int(contents[2])) // 2
-            start = max(0, midpoint + int(left_of_site))
-            stop = min(midpoint + int(right_of_site), chrom_sizes_dict[contig])
-            if contig == prev_contig and start < prev_stop:
-                prev_stop = start
-            if prev_contig is not None and prev_stop > prev_start:
-                contigs.append(prev_contig)
-                starts.append(prev_start)
-                stops.append(prev_stop)
-            prev_contig = contig
-            prev_start = start
-            prev_stop = stop
-        if prev_stop > prev_start:
-            contigs.append(prev_contig)
-            starts.append(prev_start)
-            stops.append(prev_stop)
-    finally:
-        if site_bed != "-":
-            bed.close()
-    return contigs, starts, stops
+def _site_windows(site_bed, interval_size, lengths):
+    """The windows ``multi_wps`` scores, from a site BED (behaviour of the reference's frag/_multi_wps.py:240-297):
+    every site becomes ``interval_size`` bases around its midpoint, clipped to its contig (``lengths``: contig ->
+    length; a site on another contig is skipped with a warning); a window that runs into the NEXT line's window on the
+    same contig ends where that one starts; windows left empty are dropped.  Returns (contigs, starts, stops) in
+    file order, as an object array and two int64 arrays."""
+    reach = (round(-interval_size / 2), round(interval_size / 2))
+    if reach[1] - reach[0] != interval_size:  # (round() sends both halves of an odd size to the even neighbour)
+        raise AssertionError
+    with (nullcontext(stdin) if site_bed == "-" else open(site_bed)) as bed:
+        rows = [line.split() for line in bed]
+    names, mids = [], []
+    for fields in rows:  # line by line, so that warnings and the first error come in file order
+        name, a, b = fields[0].strip(), int(fields[1]), int(fields[2])
+        if a > b:
+            raise ValueError(f"[multi_wps] {name}:{fields[1]}-{fields[2]} is invalid. Please be sure start coordinate "
+                             f"occurs before stop for all intervals in {site_bed}.")
+        if name not in lengths:
+            warnings.warn(f"Skipping site {name}:{a} from site_bed (chrom not in chrom_sizes)", UserWarning)
+            continue
+        names.append(name)
+        mids.append((a + b) // 2)
+    names = np.array(names, dtype=object)
+    mids = np.array(mids, dtype=np.int64)
+    size = np.array([lengths[c] for c in names], dtype=np.int64)
+    starts = np.maximum(mids + reach[0], 0)
+    stops = np.minimum(mids + reach[1], size)
+    if len(names) > 1:  # the next line's window, when it is on the same contig and starts inside this one, cuts it
+        nxt = starts[1:]
+        cut = (names[1:] == names[:-1]) & (nxt < stops[:-1])
+        stops[:-1] = np.where(cut, nxt, stops[:-1])
+    keep = stops > starts
+    return names[keep], starts[keep], stops[keep]
 
 
 def multi_wps(input_file, site_bed, chrom_sizes=None, output_file: str | None = None, window_size: int = 120,
@@ -94,22 +86,15 @@ def multi_wps(input_file, site_bed, chrom_sizes=None, output_file: str | None = 
     src = open_source(input_file, workers)
     eng = get_engine()
     header = _read_header(input_file, chrom_sizes, src)
-    references = [chrom for (chrom, _) in header]
     chrom_sizes_dict = dict(header)
-    contigs, starts, stops = _read_sites(site_bed, interval_size, references, chrom_sizes_dict)
-
-    if header and contigs:  # header (contig) order, then start (:152-160)
-        chrom_order = {chrom: idx for idx, (chrom, _) in enumerate(header)}
-        order = sorted(range(len(contigs)), key=lambda i: (chrom_order.get(contigs[i], len(header)), starts[i]))
-        contigs = [contigs[i] for i in order]
-        starts = [starts[i] for i in order]
-        stops = [stops[i] for i in order]
-    try:
-        [chrom_sizes_dict[c] for c in contigs]
-    except KeyError as e:
-        raise ValueError(f"Chrom {e} from {site_bed} is not present in {input_file} or chrom.sizes file if "
-                         "applicable). Please ensure that all files use the same reference genome and chromosome "
-                         "naming conventions.")
+    names, lo, hi = _site_windows(site_bed, interval_size, chrom_sizes_dict)
+    # header order of the contigs, then start; equal keys keep their file order (the reference sorts the same way,
+    # frag/_multi_wps.py:152-160)
+    place = {chrom: k for k, (chrom, _) in enumerate(header)}
+    order = np.lexsort((lo, np.array([place[c] for c in names], dtype=np.int64))) if len(names) else []
+    contigs = [str(names[i]) for i in order]
+    starts = [int(lo[i]) for i in order]
+    stops = [int(hi[i]) for i in order]
 
     def score_run(key, c, run_starts, run_stops):
         """All intervals of one unit in ONE launch; interval k of the unit is values[offsets[k]:offsets[k+1]]."""

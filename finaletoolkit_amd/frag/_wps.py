@@ -23,22 +23,18 @@ _WPS_DTYPE = [("contig", "U16"), ("start", "i8"), ("wps", "i8")]
 
 
 def _resolve_aliases(min_length, max_length, fraction_low, fraction_high):
-    """frag/_wps.py:112-140 (supplying both spellings is an error)."""
-    if fraction_low is not None and min_length is None:
-        min_length = fraction_low
-        warnings.warn("fraction_low is deprecated. Use min_length instead.", category=DeprecationWarning, stacklevel=3)
-    elif fraction_low is not None and min_length is not None:
-        warnings.warn("fraction_low is deprecated. Use min_length instead.", category=DeprecationWarning, stacklevel=3)
-        raise ValueError("fraction_low and min_length cannot both be specified")
-    if fraction_high is not None and max_length is None:
-        max_length = fraction_high
-        warnings.warn("fraction_high is deprecated. Use max_length instead.", category=DeprecationWarning,
-                      stacklevel=3)
-    elif fraction_high is not None and max_length is not None:
-        warnings.warn("fraction_high is deprecated. Use max_length instead.", category=DeprecationWarning,
-                      stacklevel=3)
-        raise ValueError("fraction_high and max_length cannot both be specified")
-    return min_length, max_length
+    """The deprecated spellings of the length bounds (the reference's frag/_wps.py:112-140, frag/_multi_wps.py:105-133):
+    an old name warns and stands in for the new one; giving both is an error (after the warning)."""
+    bounds = []
+    for new, value, old, alias in (("min_length", min_length, "fraction_low", fraction_low),
+                                   ("max_length", max_length, "fraction_high", fraction_high)):
+        if alias is not None:
+            warnings.warn(f"{old} is deprecated. Use {new} instead.", category=DeprecationWarning, stacklevel=3)
+            if value is not None:
+                raise ValueError(f"{old} and {new} cannot both be specified")
+            value = alias
+        bounds.append(value)
+    return bounds[0], bounds[1]
 
 
 def _scores_array(chrom, start, values):

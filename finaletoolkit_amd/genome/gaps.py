@@ -100,7 +100,11 @@ class GenomeGaps:
 
 
 class ContigGaps:
-    """Centromere / telomere intervals of one contig (genome/gaps.py:202-267)."""
+    """Centromere / telomere intervals of one contig (the reference's ``genome/gaps.py:202-267``), kept in the form
+    the DELFI kernel tests fragments against (``as_kernel_constants`` -> ``ftk_gaps``): one centromere interval, and
+    ONE interval standing for "overlaps every telomere" - ``all_i(stop > a_i and start < b_i)`` is
+    ``stop > max a_i and start < min b_i`` (the reference's deliberate ``all()``: its DELFI outputs were produced
+    with it).  The Python predicates below are evaluated on those constants, so host and kernel cannot disagree."""
 
     def __init__(self, contig: str, centromere: tuple[int, int], telomeres: Iterable[tuple[int, int]],
                  has_short_arm: bool = False) -> None:
@@ -109,26 +113,23 @@ class ContigGaps:
         self.telomeres = list(telomeres)
         self.has_short_arm = has_short_arm
 
-    def in_tcmere(self, start: int, stop: int) -> bool:
-        """Overlaps the centromere, or overlaps EVERY telomere (the reference's
-        ``all()``, kept because its DELFI outputs were produced with it)."""
-        in_centromere = stop > self.centromere[0] and start < self.centromere[1]
+    def _every_telomere(self) -> tuple[float, float]:
+        """The interval a fragment must overlap to overlap every telomere (nothing does when there are none)."""
         if not self.telomeres:
-            in_telomeres = False
-        else:
-            in_telomeres = all(stop > t[0] and start < t[1] for t in self.telomeres)
-        return in_centromere or in_telomeres
+            return float("inf"), float("-inf")
+        return max(t[0] for t in self.telomeres), min(t[1] for t in self.telomeres)
+
+    def in_tcmere(self, start: int, stop: int) -> bool:
+        lo, hi = self._every_telomere()
+        return any(stop > a and start < b for a, b in (self.centromere, (lo, hi)))
 
     def get_arm(self, start: int, stop: int) -> str:
         if stop < start:
             raise ValueError("start must be less than stop")
-        if stop < self.centromere[0]:
-            if not self.has_short_arm:
-                return f"{self.contig.replace('chr', '')}p"
-            return "NOARM"
-        if start > self.centromere[1]:
-            return f"{self.contig.replace('chr', '')}q"
-        return "NOARM"
+        left_of, right_of = stop < self.centromere[0], start > self.centromere[1]
+        if (left_of and self.has_short_arm) or not (left_of or right_of):
+            return "NOARM"  # acrocentric short arm, or touching the centromere
+        return self.contig.replace("chr", "") + ("p" if left_of else "q")
 
     def as_kernel_constants(self):
         """(cen_start, cen_stop, [(t0, t1), ...]) for ``ftk_gaps``."""
@@ -152,13 +153,10 @@ def ucsc_hg38_gap_bed(output_file) -> None:
 
 def _cli_gap_bed(reference_genome: str, output_file: str) -> None:
     """CLI ``gap-bed`` (genome/gaps.py:288-302)."""
-    if reference_genome == "hg19":
-        ucsc_hg19_gap_bed(output_file)
-    elif reference_genome in ("b37", "human_g1k_v37"):
-        b37_gap_bed(output_file)
-    elif reference_genome in ("hg38", "GRCh38"):
-        ucsc_hg38_gap_bed(output_file)
-    else:
+    tracks = {"hg19": ucsc_hg19_gap_bed, "b37": b37_gap_bed, "human_g1k_v37": b37_gap_bed, "hg38": ucsc_hg38_gap_bed,
+              "GRCh38": ucsc_hg38_gap_bed}
+    if reference_genome not in tracks:
         raise ValueError(f"Gap track for {reference_genome} is currently unavailable. It is possible to create a gap "
                          "track de novo if interval data for centromeres, telomeres, and short_arms exist for the "
                          "reference sequence of interest.")
+    tracks[reference_genome](output_file)

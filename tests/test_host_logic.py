@@ -10,7 +10,7 @@ import pandas as pd
 import pytest
 
 from finaletoolkit_amd.frag._delfi_merge_bins import delfi_merge_bins
-from finaletoolkit_amd.frag._multi_wps import _read_sites
+from finaletoolkit_amd.frag._multi_wps import _site_windows
 from finaletoolkit_amd.genome.gaps import ContigGaps, GenomeGaps
 from finaletoolkit_amd.reference import ReferenceGenome
 from finaletoolkit_amd.utils import chrom_sizes_to_dict, chrom_sizes_to_list, get_intervals, overlaps
@@ -134,15 +134,59 @@ def test_reference_gc_reader_2bit_and_fasta(tmp_path):
 def test_multi_wps_site_windows(tmp_path):
     bed = tmp_path / "s.bed"
     bed.write_text("c1\t100\t300\nc1\t2000\t2100\nc1\t2600\t2700\nc1\t9990\t10000\nzz\t1\t2\nc2\t10\t20\n")
-    with pytest.warns(UserWarning):
-        contigs, starts, stops = _read_sites(str(bed), 1000, ["c1", "c2"], {"c1": 10000, "c2": 400})
+    with pytest.warns(UserWarning, match="Skipping site zz:1 from site_bed"):
+        contigs, starts, stops = _site_windows(str(bed), 1000, {"c1": 10000, "c2": 400})
     # centred windows, clipped to the contig; a window is truncated where the next one starts
-    assert contigs == ["c1", "c1", "c1", "c1", "c2"]
-    assert starts == [0, 1550, 2150, 9495, 0] and stops == [700, 2150, 3150, 10000, 400]
+    assert list(contigs) == ["c1", "c1", "c1", "c1", "c2"]
+    assert starts.tolist() == [0, 1550, 2150, 9495, 0] and stops.tolist() == [700, 2150, 3150, 10000, 400]
     bad = tmp_path / "b.bed"
     bad.write_text("c1\t300\t100\n")
-    with pytest.raises(ValueError):
-        _read_sites(str(bad), 1000, ["c1"], {"c1": 10000})
+    with pytest.raises(ValueError, match=r"\[multi_wps\] c1:300-100 is invalid"):
+        _site_windows(str(bad), 1000, {"c1": 10000})
+    # a window swallowed whole by the next line's window is dropped; the cut looks at the NEXT line only; a site on
+    # another contig in between resets nothing that matters; an odd interval size is refused like the reference does
+    bed.write_text("c1\t5000\t5000\nc1\t4400\t4400\nc2\t100\t100\nc1\t4500\t4500\n")
+    contigs, starts, stops = _site_windows(str(bed), 1000, {"c1": 10000, "c2": 400})
+    assert list(contigs) == ["c1", "c2", "c1"] and starts.tolist() == [3900, 0, 4000] and stops.tolist() == [4900, 400, 5000]
+    with pytest.raises(AssertionError):
+        _site_windows(str(bed), 1001, {"c1": 10000, "c2": 400})
+    empty = tmp_path / "e.bed"
+    empty.write_text("")
+    contigs, starts, stops = _site_windows(str(empty), 1000, {"c1": 10})
+    assert len(contigs) == len(starts) == len(stops) == 0
+
+
+def test_site_windows_and_gap_predicates_against_reference_goldens(tmp_path):
+    """The rewritten host glue against outputs recorded from the imported reference (oracle/gen_golden_sites.py):
+    ``_read_sites`` (frag/_multi_wps.py:240-297) windows, warnings and errors; ``ContigGaps.in_tcmere`` / ``get_arm``
+    (genome/gaps.py:217-267)."""
+    import json
+    import warnings
+    from finaletoolkit_amd.genome.gaps import ContigGaps
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "site_windows.json")))
+    bed = tmp_path / "s.bed"
+    assert any("error" in c for c in gold["sites"]) and any(c["warnings"] for c in gold["sites"])
+    for k, case in enumerate(gold["sites"]):
+        bed.write_text(case["bed"])
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            if "error" in case:
+                with pytest.raises(ValueError) as info:
+                    _site_windows(str(bed), case["interval_size"], gold["lengths"])
+                assert str(info.value) == case["error"].replace("{path}", str(bed)), k
+            else:
+                contigs, starts, stops = _site_windows(str(bed), case["interval_size"], gold["lengths"])
+                assert (list(contigs), starts.tolist(), stops.tolist()) == (case["contigs"], case["starts"], case["stops"]), k
+        assert [str(w.message) for w in seen] == case["warnings"], k
+    for case in gold["gaps"]:
+        g = ContigGaps(case["contig"], tuple(case["centromere"]), [tuple(t) for t in case["telomeres"]], case["has_short_arm"])
+        for s, e, inside, arm in case["queries"]:
+            assert g.in_tcmere(s, e) is inside, (case, s, e)
+            try:
+                got = g.get_arm(s, e)
+            except ValueError as exc:
+                got = "ValueError: " + str(exc)
+            assert got == arm, (case, s, e)
 
 
 def test_cli_flag_surface():
