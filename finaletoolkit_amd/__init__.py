@@ -40,7 +40,7 @@ __version__ = "0.1.0"
 # Flat namespace of the reference (``finaletoolkit.<name>``, src/finaletoolkit/__init__.py:49-128), resolved on first
 # use (PEP 562) so that importing the package for its names loads neither pandas nor the HIP library.  Listed per
 # submodule: every hot-path export that exists here.  Reference exports outside the path (``filter_file``,
-# ``frag_bam_to_bed``, ``low_quality_read_pairs``, ``reverse_complement``, the pysam wrappers) are named in
+# ``frag_bam_to_bed``, ``low_quality_read_pairs``, ``ReferenceWrapper``) are named in
 # ``_OUT_OF_SCOPE`` so that asking for one says why it is absent.
 _SUBMODULES = ("cli", "frag", "genome", "io", "utils")
 _FLAT_BY_MODULE = {
@@ -52,11 +52,11 @@ _FLAT_BY_MODULE = {
     "utils": ("frag_generator", "frag_array", "frags_in_region", "agg_bw", "get_intervals", "overlaps", "gen_kmers",
               "chrom_sizes_to_dict", "chrom_sizes_to_list", "reverse_complement"),
     "genome": ("GenomeGaps", "ContigGaps", "ucsc_hg19_gap_bed", "b37_gap_bed", "ucsc_hg38_gap_bed"),
-    "io": ("Fragment",),
+    "io": ("Fragment", "AlignmentWrapper"),
 }
 _FLAT = {name: module for module, names in _FLAT_BY_MODULE.items() for name in names}
 _SINGULAR = {"end_motif": "end_motifs", "breakpoint_motif": "breakpoint_motifs"}
-_OUT_OF_SCOPE = ("filter_file", "frag_bam_to_bed", "low_quality_read_pairs", "ReferenceWrapper", "AlignmentWrapper")
+_OUT_OF_SCOPE = ("filter_file", "frag_bam_to_bed", "low_quality_read_pairs", "ReferenceWrapper")
 
 
 def __getattr__(name):

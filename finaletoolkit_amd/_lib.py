@@ -31,6 +31,7 @@ OPEN_LO = -(2 ** 31)
 OPEN_HI = 2 ** 31 - 1
 LEN_OPEN = -1
 POLICY = {"midpoint": 0, "any": 1}
+POLICY_FETCH = 2  # no intersect test: the index query alone (AlignmentWrapper.fetch)
 FETCH_TABIX = 0
 FETCH_BAM_READ1 = 1
 MAX_TELOMERES = 8
@@ -322,7 +323,7 @@ def ptr(a):
 
 def make_filter(quality_threshold=30, min_length=None, max_length=None, intersect_policy="midpoint",
                 fetch_mode=FETCH_TABIX) -> Filter:
-    if intersect_policy not in POLICY:
+    if intersect_policy not in POLICY and intersect_policy != "fetch":  # ("fetch": internal, AlignmentWrapper.fetch)
         from .exceptions import InvalidInputError
         raise InvalidInputError(f"{intersect_policy} is not a valid policy")
     mn = LEN_OPEN if min_length is None else max(int(min_length), 0)
@@ -332,7 +333,7 @@ def make_filter(quality_threshold=30, min_length=None, max_length=None, intersec
         mn, mx = 1, 0
     else:
         mx = int(max_length)
-    return Filter(int(quality_threshold), mn, mx, POLICY[intersect_policy], fetch_mode)
+    return Filter(int(quality_threshold), mn, mx, POLICY.get(intersect_policy, POLICY_FETCH), fetch_mode)
 
 
 def make_gaps(gaps) -> Gaps:

@@ -21,6 +21,7 @@ _CHROM_TREE_MAGIC = 0x78CA8C91
 _RTREE_MAGIC = 0x2468ACE0
 _ITEMS_PER_SECTION = 16384  # <= 65535 (u16 item count)
 _BLOCK = 256                # children per index node
+_ZOOM_SLOTS = 10            # zoom headers a file has room for (libBigWig reserves ten)
 
 
 def _chrom_tree(header) -> bytes:
@@ -180,9 +181,12 @@ class FixedStepBigWigWriter:
         self.header = header
         tree, reloc = _chrom_tree(header)
         self.n_zoom = 1
-        self.chrom_tree_off = 64 + 24 * self.n_zoom
-        self.total_summary_off = self.chrom_tree_off + len(tree)
-        self.data_off = self.total_summary_off + 40
+        # the layout libBigWig (pyBigWig) writes: 64-byte header, room for ten zoom headers, the total summary, the
+        # chromosome tree, the data (tests/test_bigwig.py holds a file of this writer against tests/data/test.bw,
+        # which pyBigWig wrote, field by field)
+        self.total_summary_off = 64 + 24 * _ZOOM_SLOTS
+        self.chrom_tree_off = self.total_summary_off + 40
+        self.data_off = self.chrom_tree_off + len(tree)
         tree = bytearray(tree)
         for r in reloc:
             (v,) = struct.unpack_from("<Q", tree, r)
@@ -252,8 +256,9 @@ class FixedStepBigWigWriter:
         fh.write(struct.pack("<IHHQQQHHQQIQ", _BW_MAGIC, 4, self.n_zoom, self.chrom_tree_off, self.data_off, index_off,
                              0, 0, 0, self.total_summary_off, max(max_raw, 1), 0))
         fh.write(struct.pack("<IIQQ", _ITEMS_PER_SECTION, 0, zoom_data_off, zoom_index_off))
-        fh.write(bytes(self.tree))
+        fh.write(b"\0" * (24 * (_ZOOM_SLOTS - self.n_zoom)))
         fh.write(struct.pack("<Qdddd", self.n_valid, vmin, vmax, self.vsum, self.vsq))
+        fh.write(bytes(self.tree))
         fh.write(struct.pack("<Q", len(self.leaf_items)))
         fh.close()
         self.fh = None
@@ -450,10 +455,215 @@ class BigWigFile:
         return out
 
 
+_ZOOM_DT = np.dtype([("cid", "<u4"), ("s", "<u4"), ("e", "<u4"), ("n", "<u4"), ("mn", "<f4"), ("mx", "<f4"),
+                     ("sum", "<f4"), ("sq", "<f4")])
+_HEADER_FIELDS = ("magic", "version", "zoomLevels", "chromTreeOffset", "fullDataOffset", "fullIndexOffset", "fieldCount",
+                  "definedFieldCount", "autoSqlOffset", "totalSummaryOffset", "uncompressBufSize", "extensionOffset")
+_RTREE_FIELDS = ("magic", "blockSize", "itemCount", "startChromIx", "startBase", "endChromIx", "endBase", "endFileOffset",
+                 "itemsPerSlot", "reserved")
+
+
+def _rtree_leaves(b, off):
+    """Leaf items ``(chromIx, start, chromIx, end, offset, size)`` of the R-tree at ``off``, in tree order."""
+    head = dict(zip(_RTREE_FIELDS, struct.unpack_from("<IIQIIIIQII", b, off)))
+    leaves = []
+
+    def walk(at):
+        leaf, _, n = struct.unpack_from("<BBH", b, at)
+        at += 4
+        for _ in range(n):
+            if leaf:
+                leaves.append(struct.unpack_from("<IIIIQQ", b, at))
+                at += 32
+            else:
+                walk(struct.unpack_from("<Q", b, at + 16)[0])
+                at += 24
+
+    if head["itemCount"]:
+        walk(off + 48)
+    return head, leaves
+
+
+def describe(path) -> dict:
+    """Every field of a bigWig container a consumer (pyBigWig / libBigWig, IGV, bigWigToWig) reads, as plain data:
+    the 64-byte header, the zoom headers, the chromosome B+ tree (header, items), the total summary, the R-tree
+    header and leaves, every data section's 24-byte header and values (inflated), every zoom level's records and
+    index.  What tests compare between a file of this package's writer and one pyBigWig wrote."""
+    b = open(path, "rb").read()
+    hdr = dict(zip(_HEADER_FIELDS, struct.unpack_from("<IHHQQQHHQQIQ", b, 0)))
+    out = dict(header=hdr, file_bytes=len(b), trailer_magic=struct.unpack_from("<I", b, len(b) - 4)[0])
+    ct = hdr["chromTreeOffset"]
+    tree = dict(zip(("magic", "blockSize", "keySize", "valSize", "itemCount", "reserved"), struct.unpack_from("<IIIIQQ", b, ct)))
+    items = []
+
+    def walk_ct(at):
+        leaf, _, n = struct.unpack_from("<BBH", b, at)
+        at += 4
+        for _ in range(n):
+            if leaf:
+                items.append((b[at:at + tree["keySize"]], *struct.unpack_from("<II", b, at + tree["keySize"])))
+            else:
+                walk_ct(struct.unpack_from("<Q", b, at + tree["keySize"])[0])
+            at += tree["keySize"] + 8
+
+    if tree["itemCount"]:
+        walk_ct(ct + 32)
+    tree["items"] = items
+    out["chrom_tree"] = tree
+    out["total_summary"] = dict(zip(("validCount", "minVal", "maxVal", "sumData", "sumSquares"),
+                                    struct.unpack_from("<Qdddd", b, hdr["totalSummaryOffset"]))) if hdr["totalSummaryOffset"] else None
+    out["section_count"] = struct.unpack_from("<Q", b, hdr["fullDataOffset"])[0]
+    rhead, leaves = _rtree_leaves(b, hdr["fullIndexOffset"])
+    out["rtree"] = dict(rhead, leaves=leaves)
+    sections = []
+    for leaf in leaves:
+        raw = b[leaf[4]:leaf[4] + leaf[5]]
+        if hdr["uncompressBufSize"]:
+            raw = zlib.decompress(raw)
+        sh = dict(zip(("chromId", "chromStart", "chromEnd", "itemStep", "itemSpan", "type", "reserved", "itemCount"),
+                      struct.unpack_from("<IIIIIBBH", raw, 0)))
+        sh["raw_bytes"] = len(raw)
+        sh["payload"] = raw[24:]
+        sections.append(sh)
+    out["sections"] = sections
+    zooms = []
+    for k in range(hdr["zoomLevels"]):
+        red, rsv, zd, zi = struct.unpack_from("<IIQQ", b, 64 + 24 * k)
+        zhead, zleaves = _rtree_leaves(b, zi)
+        recs = []
+        for leaf in zleaves:
+            raw = b[leaf[4]:leaf[4] + leaf[5]]
+            if hdr["uncompressBufSize"]:
+                raw = zlib.decompress(raw)
+            recs.append(np.frombuffer(raw, _ZOOM_DT))
+        zooms.append(dict(reductionLevel=red, reserved=rsv, dataOffset=zd, indexOffset=zi,
+                          recordCount=struct.unpack_from("<I", b, zd)[0], rtree=dict(zhead, leaves=zleaves),
+                          records=np.concatenate(recs) if recs else np.zeros(0, _ZOOM_DT)))
+    out["zoom"] = zooms
+    return out
+
+
+def verify(path, strict: bool = True) -> list:
+    """Check a bigWig container against its own data - the parts ``BigWigFile`` does not need to answer queries but
+    other readers do: offsets in range, the trailer magic, section count = R-tree item count, every R-tree leaf's
+    bounds = its section's header, the R-tree header's bounds = the leaves' extremes, ``uncompressBufSize`` >= every
+    inflated section, the total summary (validCount / min / max / sum / sumSquares) recomputed from the sections, every
+    zoom record (bases covered, min, max, sum, sum of squares over the data inside its range) and the zoom index's
+    bounds.  Raises ``ValueError`` on the first violation.  ``strict=False`` tolerates the two things libBigWig itself
+    writes differently (a fixedStep section's chromEnd computed from the buffer length INCLUDING its 24-byte header,
+    i.e. 6 steps too far; zoom records whose sums are left zero) and returns them as notes."""
+    d = describe(path)
+    notes = []
+
+    def bad(msg):
+        raise ValueError(f"{path}: {msg}")
+
+    def quirk(msg):
+        if strict:
+            bad(msg)
+        notes.append(msg)
+
+    h = d["header"]
+    if h["magic"] != _BW_MAGIC or d["trailer_magic"] != _BW_MAGIC:
+        bad("magic numbers")
+    for k in ("chromTreeOffset", "fullDataOffset", "fullIndexOffset", "totalSummaryOffset"):
+        if not 64 <= h[k] < d["file_bytes"]:
+            bad(f"{k} {h[k]} outside the file")
+    if not 1 <= h["zoomLevels"] <= _ZOOM_SLOTS:
+        bad(f"{h['zoomLevels']} zoom levels")
+    if d["chrom_tree"]["magic"] != _CHROM_TREE_MAGIC or d["chrom_tree"]["valSize"] != 8 or \
+            d["chrom_tree"]["itemCount"] != len(d["chrom_tree"]["items"]):
+        bad("chromosome tree")
+    keys = [it[0] for it in d["chrom_tree"]["items"]]
+    if keys != sorted(keys) or any(len(k) != d["chrom_tree"]["keySize"] for k in keys):
+        bad("chromosome tree keys must be sorted and keySize wide")
+    sizes = {it[1]: it[2] for it in d["chrom_tree"]["items"]}
+    r = d["rtree"]
+    if r["magic"] != _RTREE_MAGIC or r["itemCount"] != len(r["leaves"]) or d["section_count"] != len(r["leaves"]):
+        bad("R-tree item count / section count")
+    covered = {}  # chromId -> list of (start, end, value) runs, as arrays
+    n_valid, vmin, vmax, vsum, vsq = 0, np.inf, -np.inf, 0.0, 0.0
+    for leaf, sec in zip(r["leaves"], d["sections"]):
+        if sec["raw_bytes"] > h["uncompressBufSize"]:
+            bad(f"section of {sec['raw_bytes']} bytes exceeds uncompressBufSize {h['uncompressBufSize']}")
+        n = sec["itemCount"]
+        if sec["type"] == 3:
+            v = np.frombuffer(sec["payload"], "<f4", n)
+            st = sec["chromStart"] + np.arange(n, dtype=np.int64) * sec["itemStep"]
+            en = st + sec["itemSpan"]
+        elif sec["type"] == 2:
+            rec = np.frombuffer(sec["payload"], _VARSTEP_DT, n)
+            st, v = rec["s"].astype(np.int64), rec["v"]
+            en = st + sec["itemSpan"]
+        else:
+            rec = np.frombuffer(sec["payload"], _BEDGRAPH_DT, n)
+            st, en, v = rec["s"].astype(np.int64), rec["e"].astype(np.int64), rec["v"]
+        true_end = int(en.max()) if n else sec["chromStart"]
+        if sec["chromId"] not in sizes or true_end > sizes[sec["chromId"]]:
+            bad("section outside its chromosome")
+        if sec["chromEnd"] != true_end:
+            quirk(f"section chromEnd {sec['chromEnd']} but its last item ends at {true_end}")
+        if (leaf[0], leaf[1], leaf[2], leaf[3]) != (sec["chromId"], sec["chromStart"], sec["chromId"], sec["chromEnd"]):
+            bad(f"R-tree leaf {leaf[:4]} does not match its section header")
+        covered.setdefault(sec["chromId"], []).append((st, en, v.astype(np.float64)))
+        w = (en - st).astype(np.float64)
+        n_valid += int(w.sum())
+        if n:
+            vmin, vmax = min(vmin, float(v.min())), max(vmax, float(v.max()))
+        vsum += float((v.astype(np.float64) * w).sum())
+        vsq += float((v.astype(np.float64) ** 2 * w).sum())
+    if r["leaves"]:
+        first, last = r["leaves"][0], r["leaves"][-1]
+        if (r["startChromIx"], r["startBase"], r["endChromIx"], r["endBase"]) != (first[0], first[1], last[2], last[3]):
+            bad("R-tree header bounds are not the leaves' extremes")
+        if r["endFileOffset"] != last[4] + last[5]:
+            quirk(f"R-tree endFileOffset {r['endFileOffset']} is not the end of the indexed data {last[4] + last[5]}")
+    ts = d["total_summary"]
+    if ts is None:
+        bad("no total summary")
+    want = (n_valid, vmin if n_valid else 0.0, vmax if n_valid else 0.0, vsum, vsq)
+    got = (ts["validCount"], ts["minVal"], ts["maxVal"], ts["sumData"], ts["sumSquares"])
+    if got[0] != want[0] or not np.allclose(got[1:], want[1:], rtol=1e-6, atol=1e-9):
+        bad(f"total summary {got} but the data give {want}")
+    for z in d["zoom"]:
+        recs = z["records"]
+        if z["recordCount"] != len(recs):
+            bad("zoom record count")
+        for rec in recs:
+            runs = covered.get(int(rec["cid"]), [])
+            n = 0
+            mn, mx, sm, sq = np.inf, -np.inf, 0.0, 0.0
+            for st, en, v in runs:
+                lo, hi = np.maximum(st, int(rec["s"])), np.minimum(en, int(rec["e"]))
+                w = np.maximum(hi - lo, 0).astype(np.float64)
+                if w.any():
+                    n += int(w.sum())
+                    mn, mx = min(mn, float(v[w > 0].min())), max(mx, float(v[w > 0].max()))
+                    sm += float((v * w).sum())
+                    sq += float((v * v * w).sum())
+            if int(rec["n"]) != n or (n and not np.allclose([rec["mn"], rec["mx"]], [mn, mx], rtol=1e-6, atol=1e-9)):
+                bad(f"zoom record {rec} does not describe the data in its range (valid {n}, min {mn}, max {mx})")
+            if n and not np.allclose([rec["sum"], rec["sq"]], [sm, sq], rtol=1e-5, atol=1e-6):
+                if float(rec["sum"]) == 0.0 and float(rec["sq"]) == 0.0:
+                    quirk(f"zoom record of {rec['cid']}:{rec['s']}-{rec['e']} carries zero sums (data: {sm}, {sq})")
+                else:
+                    bad(f"zoom record sums {rec['sum']}, {rec['sq']} but the data give {sm}, {sq}")
+        zl = z["rtree"]["leaves"]
+        if z["rtree"]["magic"] != _RTREE_MAGIC or z["rtree"]["itemCount"] != len(zl):
+            bad("zoom index")
+        if len(recs) and zl:
+            if (z["rtree"]["startChromIx"], z["rtree"]["startBase"]) != (int(recs[0]["cid"]), int(recs[0]["s"])) or \
+                    (z["rtree"]["endChromIx"], z["rtree"]["endBase"]) != (int(recs[-1]["cid"]), int(recs[-1]["e"])):
+                bad("zoom index bounds are not its records' extremes")
+    return notes
+
+
 def read_bigwig(path):
     """Return ``(chroms, intervals)``: ``chroms`` = {name: (id, size)};
     ``intervals`` = list of ``(chrom_name, start, end, value)`` decoded from
-    every data section, in file order."""
+    every data section, in file order.  The container is checked on the way (``verify``: summary, index bounds,
+    zoom records; libBigWig's own two deviations are tolerated)."""
+    verify(path, strict=False)
     bw = BigWigFile(path)
     out = []
     for name, st, en, v in bw.sections():

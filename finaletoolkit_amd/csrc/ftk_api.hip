@@ -108,9 +108,9 @@ void free_contig(ContigData& c) {
     c = ContigData{};
 }
 
-int check_filter(ftk_ctx* ctx, const ftk_filter* f, const ContigData& c) {
+int check_filter(ftk_ctx* ctx, const ftk_filter* f, const ContigData& c, bool allow_fetch = false) {
     if (!f) return fail(ctx, FTK_ERR_INVALID, "filter is NULL");
-    if (f->policy != FTK_POLICY_MIDPOINT && f->policy != FTK_POLICY_ANY)
+    if (f->policy != FTK_POLICY_MIDPOINT && f->policy != FTK_POLICY_ANY && !(allow_fetch && f->policy == FTK_POLICY_FETCH))
         return fail(ctx, FTK_ERR_INVALID, "unknown intersect policy %d", f->policy);
     if (f->fetch_mode != FTK_FETCH_TABIX && f->fetch_mode != FTK_FETCH_BAM_READ1)
         return fail(ctx, FTK_ERR_INVALID, "unknown fetch mode %d", f->fetch_mode);
@@ -1000,7 +1000,7 @@ static int select_common(ftk_ctx* ctx, int contig_id, int32_t w_start, int32_t w
     ContigData* c;
     int rc = get_contig(ctx, contig_id, &c);
     if (rc) return rc;
-    if ((rc = check_filter(ctx, f, *c))) return rc;
+    if ((rc = check_filter(ctx, f, *c, true))) return rc;
     if (!n_out || cap < 0) return fail(ctx, FTK_ERR_INVALID, "bad output arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // candidate range of the single window (planned on the device, read back)

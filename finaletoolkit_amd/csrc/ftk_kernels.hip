@@ -259,7 +259,7 @@ struct WinPred {
         }
         const int mid = (int)(((unsigned)fs + (unsigned)fe) >> 1);  // coordinates < 2^30
         const bool mid_in = (mid >= ws) & (mid < we);
-        ok &= (policy == FTK_POLICY_MIDPOINT) ? mid_in : overlap;
+        ok &= (policy == FTK_POLICY_MIDPOINT) ? mid_in : (policy == FTK_POLICY_ANY) ? overlap : true;  // FETCH: the query alone
         return ok;
     }
     __device__ __forceinline__ int operator()(const ContigView& cv, int i, int fs, int fe, int q, int ws, int we,

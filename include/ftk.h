@@ -54,6 +54,8 @@ extern "C" {
 
 #define FTK_POLICY_MIDPOINT 0 /* utils/_frag_generator.py:35-42 */
 #define FTK_POLICY_ANY 1      /* utils/_frag_generator.py:44-50 */
+#define FTK_POLICY_FETCH 2    /* no intersect test: whatever the index query returns (AlignmentWrapper.fetch,
+                               * io/alignment.py:216-240); taken by ftk_frag_select / ftk_frag_lengths only */
 
 #define FTK_FETCH_TABIX 0     /* io/alignment.py:270-302: rows overlapping the window */
 #define FTK_FETCH_BAM_READ1 1 /* io/alignment.py:242-268: read1 alignments overlapping the window */

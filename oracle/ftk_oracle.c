@@ -28,7 +28,7 @@ typedef struct {
     int32_t mapq_min;
     int32_t min_len; /* -1 = None */
     int32_t max_len; /* -1 = None */
-    int32_t policy;  /* 0 midpoint, 1 any */
+    int32_t policy;  /* 0 midpoint, 1 any, 2 none: whatever the index query returned (io/alignment.py:216-240) */
     int32_t fetch_mode; /* 0 tabix rows, 1 BAM read1 alignments */
 } orc_filter;
 
@@ -99,7 +99,7 @@ static int passes(const orc_frags* f, int64_t i, int32_t ws, int32_t we, const o
         int64_t mid = ((int64_t)fs + (int64_t)fe) / 2;            /* floor: operands >= 0 */
         if (ws != OPEN_LO && !(mid >= ws)) return 0;
         if (we != OPEN_HI && !(mid < we)) return 0;
-    } else {                                                      /* _frag_generator.py:44-50 */
+    } else if (flt->policy == 1) {                                /* _frag_generator.py:44-50 */
         if (ws != OPEN_LO && !(fe > ws)) return 0;
         if (we != OPEN_HI && !(fs < we)) return 0;
     }

@@ -88,7 +88,7 @@ class Frags:
 
 def _filter(mapq_min=30, min_len=None, max_len=None, policy="midpoint", bam=False):
     return _Filter(int(mapq_min), -1 if min_len is None else int(min_len), -1 if max_len is None else int(max_len),
-                   {"midpoint": 0, "any": 1}[policy], 1 if bam else 0)
+                   {"midpoint": 0, "any": 1, "fetch": 2}[policy], 1 if bam else 0)
 
 
 def _windows(ws, we):

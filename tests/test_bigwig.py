@@ -36,3 +36,134 @@ def test_roundtrip_many_contigs_multilevel_trees(tmp_path):
     chroms, iv = read_bigwig(p)
     assert len(chroms) == 700 and chroms["c699"] == (699, 10 ** 6)
     assert iv == [(c, s + i, s + i + 1, float(v)) for c, s, a in vals for i, v in enumerate(a)]
+
+
+def test_container_field_by_field_against_the_pybigwig_file(tmp_path):
+    """tests/data/test.bw was written by pyBigWig (libBigWig): five fixedStep entries chr1:1000-1005 = 0..4.  The same
+    entries through this package's writer must give a container whose every field a consumer reads either EQUALS
+    libBigWig's or differs for a stated reason.  Consumers: pyBigWig in frag/_adjust_wps.py:63-163 and
+    utils/_agg_bw.py:18-146 of the reference, IGV, bigWigToWig."""
+    from finaletoolkit_amd import bigwig
+    theirs = bigwig.describe(os.path.join(DATA, "test.bw"))
+    p = str(tmp_path / "ours.bw")
+    write_fixed_step_bigwig(p, [("chr1", 1_000_000)], [("chr1", 1000, np.arange(5, dtype=np.float64))])
+    ours = bigwig.describe(p)
+
+    # -- 64-byte header: everything but two size-dependent fields is the same number
+    for k in ("magic", "version", "zoomLevels", "chromTreeOffset", "fullDataOffset", "fieldCount", "definedFieldCount",
+              "autoSqlOffset", "totalSummaryOffset", "extensionOffset"):
+        assert ours["header"][k] == theirs["header"][k], k
+    assert ours["header"]["version"] == 4 and ours["header"]["zoomLevels"] == 1
+    # the order of the parts in the file (libBigWig's): header, zoom headers, total summary, chromosome tree, data, index, zoom
+    for d in (ours, theirs):
+        h, z = d["header"], d["zoom"][0]
+        assert 64 < h["totalSummaryOffset"] < h["chromTreeOffset"] < h["fullDataOffset"] < h["fullIndexOffset"] \
+            < z["dataOffset"] < z["indexOffset"] < d["file_bytes"]
+        assert h["totalSummaryOffset"] == 64 + 24 * 10 and h["chromTreeOffset"] == h["totalSummaryOffset"] + 40
+        assert d["trailer_magic"] == h["magic"]
+    # uncompressBufSize: libBigWig states its buffer size (32 768), this writer the largest inflated block; a reader
+    # needs it to be >= every block
+    for d in (ours, theirs):
+        assert d["header"]["uncompressBufSize"] >= max(s["raw_bytes"] for s in d["sections"])
+        assert d["header"]["uncompressBufSize"] >= max(len(z["records"].tobytes()) for z in d["zoom"])
+
+    # -- chromosome B+ tree: same key / value sizes, same item bytes (name padded to the key size, id, length)
+    for k in ("magic", "keySize", "valSize", "itemCount", "items"):
+        assert ours["chrom_tree"][k] == theirs["chrom_tree"][k], k
+    assert ours["chrom_tree"]["items"] == [(b"chr1", 0, 1_000_000)]
+    assert ours["chrom_tree"]["blockSize"] >= ours["chrom_tree"]["itemCount"]  # (block size is the writer's choice)
+
+    # -- total summary: identical
+    assert ours["total_summary"] == theirs["total_summary"] == dict(validCount=5, minVal=0.0, maxVal=4.0, sumData=10.0,
+                                                                   sumSquares=30.0)
+
+    # -- data: one section; its 24-byte header and its values
+    assert ours["section_count"] == theirs["section_count"] == 1
+    so, st = ours["sections"][0], theirs["sections"][0]
+    for k in ("chromId", "chromStart", "itemStep", "itemSpan", "type", "reserved", "itemCount", "raw_bytes", "payload"):
+        assert so[k] == st[k], k
+    assert (so["type"], so["itemStep"], so["itemSpan"], so["itemCount"]) == (3, 1, 1, 5)  # fixedStep, step 1, span 1
+    assert np.array_equal(np.frombuffer(so["payload"], "<f4"), np.arange(5, dtype=np.float32))
+    # chromEnd: the end of the last item.  libBigWig computes it from its buffer fill INCLUDING the 24 header bytes
+    # (start + (24 + 4 n) / 4 * step), six steps too far; a reader clips by the items either way
+    assert so["chromEnd"] == 1005 and st["chromEnd"] == 1005 + 6
+
+    # -- R-tree: header and the leaf
+    ro, rt = ours["rtree"], theirs["rtree"]
+    for k in ("magic", "itemCount", "startChromIx", "startBase", "endChromIx", "itemsPerSlot", "reserved"):
+        assert ro[k] == rt[k], k
+    assert (ro["endBase"], rt["endBase"]) == (so["chromEnd"], st["chromEnd"])  # each the extreme of its own leaves
+    lo, lt = ro["leaves"][0], rt["leaves"][0]
+    assert lo[:3] == lt[:3] == (0, 1000, 0) and (lo[3], lt[3]) == (1005, 1011)
+    assert lo[4] == ours["header"]["fullDataOffset"] + 8 and lt[4] == theirs["header"]["fullDataOffset"] + 8
+    # endFileOffset: the end of the indexed data (the format's definition); libBigWig leaves a small constant there
+    assert ro["endFileOffset"] == lo[4] + lo[5] == ours["header"]["fullIndexOffset"]
+    # same zlib stream for the same 44 bytes at the same level: the index sits at the same offset
+    assert lo[5] == lt[5] and ours["header"]["fullIndexOffset"] == theirs["header"]["fullIndexOffset"]
+
+    # -- zoom level: one record over the data; count / min / max as libBigWig's, and the sums libBigWig leaves zero
+    zo, zt = ours["zoom"][0], theirs["zoom"][0]
+    assert zo["recordCount"] == zt["recordCount"] == 1
+    a, b = zo["records"][0], zt["records"][0]
+    for k in ("cid", "s", "e", "n", "mn", "mx"):
+        assert a[k] == b[k], k
+    assert (float(a["sum"]), float(a["sq"])) == (10.0, 30.0) and (float(b["sum"]), float(b["sq"])) == (0.0, 0.0)
+    for z in (zo, zt):
+        zr = z["rtree"]
+        assert (zr["startChromIx"], zr["startBase"], zr["endChromIx"], zr["endBase"]) == (0, 1000, 0, 1005)
+
+    # -- and the self-check both ways: this writer's file is consistent to the letter, pyBigWig's with exactly the
+    #    deviations above
+    assert bigwig.verify(p, strict=True) == []
+    notes = bigwig.verify(os.path.join(DATA, "test.bw"), strict=False)
+    assert len(notes) == 3 and any("chromEnd 1011" in n for n in notes) and any("zero sums" in n for n in notes) \
+        and any("endFileOffset" in n for n in notes)
+    import pytest
+    with pytest.raises(ValueError):
+        bigwig.verify(os.path.join(DATA, "test.bw"), strict=True)
+
+
+def test_verify_catches_a_wrong_summary_index_bound_and_zoom_record(tmp_path):
+    """``verify`` is the check the round-trip tests lacked: a writer bug in the parts the package's own reader skips
+    (total summary, R-tree header bounds, zoom records) must not pass."""
+    import struct
+    import pytest
+    from finaletoolkit_amd import bigwig
+    p = str(tmp_path / "t.bw")
+    hdr = [("2", 50_000_000), ("10", 50_000_000)]
+    rng = np.random.default_rng(3)
+    write_fixed_step_bigwig(p, hdr, [("2", 7, rng.normal(size=40_000)), ("2", 90_000, rng.integers(-9, 9, 17)),
+                                     ("10", 0, rng.normal(size=3))])
+    assert bigwig.verify(p) == []
+    good = open(p, "rb").read()
+    d = bigwig.describe(p)
+
+    def broken(offset, fmt, value):
+        b = bytearray(good)
+        struct.pack_into(fmt, b, offset, value)
+        q = str(tmp_path / "b.bw")
+        open(q, "wb").write(bytes(b))
+        return q
+
+    ts = d["header"]["totalSummaryOffset"]
+    for off, fmt, val in ((ts, "<Q", d["total_summary"]["validCount"] + 1), (ts + 24, "<d", d["total_summary"]["sumData"] + 1.0),
+                          (d["header"]["fullIndexOffset"] + 28, "<I", 12345),           # R-tree endBase
+                          (d["header"]["fullDataOffset"], "<Q", 99),                     # section count
+                          (len(good) - 4, "<I", 0)):                                     # trailer magic
+        with pytest.raises(ValueError):
+            bigwig.verify(broken(off, fmt, val))
+    # a zoom record with a wrong sum: rewrite the (compressed) zoom block
+    import zlib
+    z = d["zoom"][0]
+    leaf = z["rtree"]["leaves"][0]
+    recs = z["records"][:512].copy()
+    recs["sum"][0] += 5
+    comp = zlib.compress(recs.tobytes(), 6)
+    assert len(comp) <= leaf[5] + 8
+    if len(comp) == leaf[5]:
+        b = bytearray(good)
+        b[leaf[4]:leaf[4] + leaf[5]] = comp
+        q = str(tmp_path / "z.bw")
+        open(q, "wb").write(bytes(b))
+        with pytest.raises(ValueError, match="zoom record"):
+            bigwig.verify(q)

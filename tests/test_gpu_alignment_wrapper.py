@@ -1,0 +1,109 @@
+"""
+GPU: the ``AlignmentWrapper`` / ``Fragment`` facade (finaletoolkit_amd/io.py) against fragments the IMPORTED reference's
+class yielded (io/alignment.py:74-302; tests/golden/fetch.json, oracle/gen_golden_fetch.py) on the reference's own
+fixtures and on the synthetic two-contig file; BAM input against the fixture's known fragments and the C oracle's
+restatement of the read1 region query (io/alignment.py:242-268).  Reads like the reference's tests/test_frag_io.py.
+"""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from finaletoolkit_amd import synth
+from finaletoolkit_amd.exceptions import MissingIndexError, UnsupportedFormatError
+from finaletoolkit_amd.io import AlignmentWrapper, Fragment
+from tests.helpers import DATA, GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+BAM = os.path.join(DATA, "12.3444.b37.bam")
+
+
+@pytest.mark.parametrize("tag", ["fixture", "fixture_bed6", "synth"])
+def test_fetch_yields_the_references_fragments(tag):
+    gold = json.load(open(os.path.join(GOLDEN, "fetch.json")))[tag]
+    path = os.path.join(ROOT, gold["path"])
+    by_q = {}
+    for case in gold["cases"]:
+        by_q.setdefault(case["quality_threshold"], []).append(case)
+    for q, cases in by_q.items():
+        from finaletoolkit_amd import source
+        source.close_all()  # every wrapper from a cold source: region reads through the index first
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            with AlignmentWrapper(path, quality_threshold=q) as aw:
+                assert aw.chroms == gold["chroms"] and aw.is_sam is False
+                assert aw.quality_threshold == q and aw.path == path and aw.read1_only is True
+                for case in cases:
+                    got = list(aw.fetch(case["contig"], case["start"], case["stop"]))
+                    assert all(isinstance(f, Fragment) for f in got)
+                    assert [[f.contig, f.start, f.stop, f.mapq, f.is_forward] for f in got] == case["fragments"], case
+                    assert all(f.length == f.stop - f.start for f in got)
+        assert sorted({str(w.message) for w in seen if issubclass(w.category, UserWarning)}) == gold["warnings"]
+    with pytest.raises(ValueError):
+        list(aw.fetch("12", 0, 10))  # closed
+
+
+def test_open_time_errors(tmp_path):
+    with pytest.raises(FileNotFoundError, match="Alignment file not found"):
+        AlignmentWrapper(str(tmp_path / "absent.frag.gz"))
+    p = tmp_path / "x.frag.gz"
+    p.write_bytes(open(os.path.join(DATA, "12.3444.b37.frag.gz"), "rb").read())
+    with pytest.raises(MissingIndexError, match="missing tabix index"):
+        AlignmentWrapper(str(p))
+    b = tmp_path / "x.bam"
+    b.write_bytes(open(BAM, "rb").read())
+    with pytest.raises(MissingIndexError, match="missing index"):
+        AlignmentWrapper(str(b))
+    t = tmp_path / "x.txt"
+    t.write_text("12\t1\t2\n")
+    with pytest.raises(UnsupportedFormatError, match="Unsupported file format"):
+        AlignmentWrapper(str(t))
+    with pytest.raises(UnsupportedFormatError):
+        AlignmentWrapper(object())
+    with pytest.raises(UnsupportedFormatError):
+        AlignmentWrapper(BAM, read1_only=False)
+
+
+def test_bam_fixture_fetch():
+    """The reference's BAM fixture: 17 read1 fragments on contig 12 equal to the fragment file's rows (one mapq
+    differs: 55 for 54), header lengths in ``chroms``, region queries by the read1 rule."""
+    gold = json.load(open(os.path.join(GOLDEN, "fetch.json")))["fixture"]
+    rows = next(c["fragments"] for c in gold["cases"] if c["quality_threshold"] == 0 and c["contig"] == "12" and c["start"] is None)
+    with AlignmentWrapper(BAM, quality_threshold=0) as aw:
+        assert aw.is_sam and aw.chroms["12"] == 133851895 and len(aw.chroms) == 84
+        got = list(aw.fetch("12"))
+        assert len(got) == 17
+        assert [(f.start, f.stop, f.is_forward) for f in got] == [(r[1], r[2], r[4]) for r in rows]
+        assert sum(f.mapq != r[3] for f, r in zip(got, rows)) == 1
+        assert [f.start for f in aw.fetch("12", 34444000, 34446000)] == [r[1] for r in rows if 34444000 <= r[1] < 34446000]
+        assert list(aw.fetch("12", 1, 2)) == []
+    with AlignmentWrapper(BAM, quality_threshold=60) as aw:
+        assert len(list(aw.fetch("12"))) == sum(r[3] == 60 for r in rows)
+
+
+def test_bam_region_fetch_is_the_read1_query(tmp_path):
+    """On a synthetic paired-end BAM with 50 bp reads: fetch(contig, a, b) = the fragments whose READ1 alignment
+    overlaps [a, b) with mapq >= cut, in file order (= by read1 position) - the C oracle's restatement of
+    io/alignment.py:242-268 - including fragments that overlap the region while their read1 does not (dropped) and
+    regions at 16 kb index boundaries."""
+    from oracle import oracle as O
+    size = 600_000
+    path = str(tmp_path / "p.bam")
+    exp = synth.write_paired_bam(path, "w", size, 60.0, 91, read_len=50)
+    fr = O.Frags(exp["s"], exp["e"], exp["q"], exp["st"], exp["r1s"], exp["r1e"])
+    with AlignmentWrapper(path, quality_threshold=20) as aw:
+        assert aw.chroms == {"w": size}
+        for a, b in [(100_000, 100_400), (16_384 * 7 - 30, 16_384 * 7 + 30), (0, 500), (size - 700, size), (300_000, 300_001),
+                     (250_000, 290_000)]:
+            ws, we, wq, wst = O.c_frag_select(fr, a, b, mapq_min=20, policy="fetch")
+            got = list(aw.fetch("w", a, b))
+            # the oracle's rows come in start order, the file's in read1 order: compare as multisets, then the order
+            assert sorted((f.start, f.stop, f.mapq, f.is_forward) for f in got) == sorted(zip(ws.tolist(), we.tolist(), wq.tolist(), (wst == 1).tolist())), (a, b)
+            r1 = [f.start if f.is_forward else f.stop - 50 for f in got]
+            assert r1 == sorted(r1), (a, b)
+            overlapping = int(((exp["s"] < b) & (exp["e"] > a) & (exp["q"] >= 20)).sum())
+            assert len(got) <= overlapping
+        whole = list(aw.fetch("w"))
+        assert len(whole) == int((exp["q"] >= 20).sum())

@@ -22,8 +22,8 @@ ON_PATH = ["frag_length", "frag_length_bins", "frag_length_intervals", "coverage
            "breakpoint_motifs", "region_breakpoint_motifs", "interval_breakpoint_motifs", "BreakpointMotifFreqs",
            "BreakpointMotifsIntervals", "frag_generator", "frag_array", "frags_in_region", "agg_bw", "get_intervals",
            "overlaps", "gen_kmers", "reverse_complement", "chrom_sizes_to_dict", "chrom_sizes_to_list", "GenomeGaps", "ContigGaps",
-           "ucsc_hg19_gap_bed", "b37_gap_bed", "ucsc_hg38_gap_bed", "Fragment", "end_motif", "breakpoint_motif"]
-OFF_PATH = ["filter_file", "frag_bam_to_bed", "low_quality_read_pairs", "ReferenceWrapper", "AlignmentWrapper"]
+           "ucsc_hg19_gap_bed", "b37_gap_bed", "ucsc_hg38_gap_bed", "Fragment", "AlignmentWrapper", "end_motif", "breakpoint_motif"]
+OFF_PATH = ["filter_file", "frag_bam_to_bed", "low_quality_read_pairs", "ReferenceWrapper"]
 
 
 @pytest.fixture()
