@@ -13,7 +13,9 @@
 #include <type_traits>
 
 #include <dlfcn.h>
+#if defined(__x86_64__)
 #include <immintrin.h>
+#endif
 #include <fcntl.h>
 #include <unistd.h>
 
@@ -1160,6 +1162,7 @@ __global__ __launch_bounds__(256) void narrow_i16_kernel(const int64_t* __restri
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(misfit, 1);
 }
 
+#if defined(__x86_64__)
 __attribute__((target("avx2"))) void widen_avx2(const int16_t* src, int64_t* dst, size_t a, size_t b) {
     size_t i = a;
     for (; i < b && ((uintptr_t)(dst + i) & 31u); ++i) dst[i] = src[i];
@@ -1175,14 +1178,19 @@ __attribute__((target("avx2"))) void widen_avx2(const int16_t* src, int64_t* dst
     _mm_sfence();
 }
 
+#endif
+
 void widen_i16(const int16_t* src, int64_t* dst, size_t n, int nt) {
+#if defined(__x86_64__)
     static const bool avx2 = __builtin_cpu_supports("avx2");
+#endif
     nt = std::max(1, std::min(nt, (int)(n >> 18) + 1));
     ftk_host::parallel_run_results(nt, [&](int t) {
         const size_t a = n * (size_t)t / (size_t)nt, b = n * (size_t)(t + 1) / (size_t)nt;
-        if (avx2) widen_avx2(src, dst, a, b);
-        else
-            for (size_t i = a; i < b; ++i) dst[i] = src[i];
+#if defined(__x86_64__)
+        if (avx2) { widen_avx2(src, dst, a, b); return; }
+#endif
+        for (size_t i = a; i < b; ++i) dst[i] = src[i];
     });
 }
 

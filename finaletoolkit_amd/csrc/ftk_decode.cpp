@@ -4050,8 +4050,15 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         DevSet& S = sets[slot];
         hipStream_t st = streams.get(slot);
         if (S.pending) return fail(FTK_ERR_HIP, "buffer ring out of step");
+        // The doubled pieces of a large BAM (run_guarded) assume records that deflate 3-5 x.  The first pieces of a
+        // stream are short (the read ramp): one that inflates 16 x or more says the file is of another kind (synthetic,
+        // all-N reads), and the stream goes on with the standard pieces before a 96 MB piece can outgrow the 4 GiB a
+        // piece's text may take.
+        if (index == 0 && piece_bytes > kStreamPiece && pc.used > 0 && pc.total / pc.used >= 16) piece_bytes = kStreamPiece;
         if (pc.total + kRoom + 64 >= (size_t(1) << 32)) {
-            if (piece_bytes > kStreamPiece) {  // (a BAM that inflates > 40 x: once more with the standard pieces)
+            if (piece_bytes > kStreamPiece) {
+                // (a file whose compression rises behind its first piece: the HOST decoder takes it from the start,
+                // skipping the contigs handed out - slower, correct, and not met on any file so far)
                 piece_bytes = kStreamPiece;
                 want_host_restart = true;
                 return false;

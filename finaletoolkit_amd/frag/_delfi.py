@@ -136,6 +136,7 @@ class _GCAhead:
         self.jobs = {key: (contig, starts, stops) for key, contig, starts, stops in jobs}
         self.done = {key: threading.Event() for key in self.jobs}
         self.out, self.err, self.thread = {}, None, None
+        self.stop = False  # set by close(abort=True): the worker gives up between two contigs
         if isinstance(eng, Engine) and jobs:
             self.thread = threading.Thread(target=self._run, args=([j[0] for j in jobs],), name="ftk-delfi-gc", daemon=True)
             self.thread.start()
@@ -144,6 +145,8 @@ class _GCAhead:
         try:
             side = get_side_engine()
             for key in order:
+                if self.stop:
+                    break
                 contig, starts, stops = self.jobs[key]
                 self.out[key] = self.ref.gc_counts(side, contig, starts, stops) if len(starts) else np.zeros(0, np.int64)
                 self.done[key].set()
@@ -162,7 +165,10 @@ class _GCAhead:
             raise self.err if self.err is not None else RuntimeError("the G + C worker stopped early")
         return self.out.pop(key)
 
-    def close(self):
+    def close(self, abort: bool = False):
+        """``abort`` (the caller failed): do not count the remaining contigs' references before the error is reported."""
+        if abort:
+            self.stop = True
         if self.thread is not None:
             self.thread.join()
 
@@ -287,7 +293,12 @@ def delfi(input_file: str, chrom_sizes: str, bins_file: str, reference_file: str
             err = e
         sharding.agree(err)
     elif isinstance(get_engine(), Engine):
-        early = EarlyContigs(input_file, workers)
+        try:  # chrom.sizes is a few hundred bytes: the names it lists are all this call can ask the file for
+            listed = list(dict.fromkeys(c for c, _ in chrom_sizes_to_list(chrom_sizes)))
+        except Exception:  # noqa: BLE001 - _delfi reads it again and raises the error where the reference does
+            listed = None
+        if listed is not None:
+            early = EarlyContigs(input_file, workers, names=listed)
     try:
         return _delfi(early, t_begin, clock, input_file, chrom_sizes, bins_file, reference_file, blacklist_file, gap_file,
                       output_file, no_gc_correct, gc_correct, remove_nocov, merge_bins, window_size, quality_threshold,
@@ -379,7 +390,7 @@ def _delfi(early, t_begin, clock, input_file, chrom_sizes, bins_file, reference_
             for src, contig in (early if early is not None else resident_contigs(input_file, whole, workers,
                                                                                  stream_all=world == 1)):
                 clock["decode_wait"] += time.perf_counter() - tw
-                if contig not in plan:  # (the early stream hands out every contig of the file)
+                if contig not in plan:  # (the early stream hands out every contig chrom.sizes lists)
                     tw = time.perf_counter()
                     continue
                 starts, stops, arms, live, ok = plan[contig]
@@ -417,7 +428,7 @@ def _delfi(early, t_begin, clock, input_file, chrom_sizes, bins_file, reference_
         except Exception as e:  # noqa: BLE001 - with several ranks every rank must learn of it (sharding.agree)
             err = e
         finally:
-            gc_ahead.close()  # (the worker reads the reference file: joined before it is closed)
+            gc_ahead.close(abort=err is not None)  # (the worker reads the reference file: joined before it is closed)
         if world > 1:
             sharding.agree(err)
         elif err is not None:

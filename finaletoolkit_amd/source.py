@@ -533,14 +533,16 @@ def resident_contigs(input_file, names, workers: int | None = None, stream_all: 
 
 
 class EarlyContigs:
-    """``resident_contigs(input_file, None, ...)`` started NOW, on a helper thread: the decoder opens the file and works
+    """``resident_contigs(input_file, names, ...)`` started NOW, on a helper thread: the decoder opens the file and works
     towards the first contig while the caller is still reading its side files (``frag.delfi``: bins, blacklist, gap
     annotation, reference header - 17 ms of a 0.16 s whole-genome call).  Iterating joins the helper and carries on
     from the first contig; an error of the early part is raised there.  ``close()`` abandons it."""
 
-    def __init__(self, input_file, workers=None, stream_all=True, warn_bed6=True):
+    def __init__(self, input_file, workers=None, stream_all=True, warn_bed6=True, names=None):
         import threading
-        self._gen = resident_contigs(input_file, None, workers, stream_all, warn_bed6)
+        # ``names``: the contigs the caller can want at all (its chrom.sizes) - a file with many more (decoys, alts) or
+        # a caller that wants a few of them is then read through the index instead of being streamed whole
+        self._gen = resident_contigs(input_file, names, workers, stream_all, warn_bed6)
         self._first, self._err, self._end = None, None, False
         self._thread = threading.Thread(target=self._run, name="ftk-early-decode", daemon=True)
         self._thread.start()
@@ -586,7 +588,9 @@ def _warn_bed6():
 
 
 def close_all():
-    """Drop every cached source and the engine (tests / long-running hosts)."""
+    """Drop every cached source and the engine (tests / long-running hosts).  The HBM of the contigs is released;
+    the engine's SCRATCH (up to 2.5 GB after a chr1 WPS) is parked in the library's cache of idle device blocks, where
+    the next engine finds it - ``release_caches()`` gives that back to the device as well."""
     global _ENGINE
     for src in list(_SOURCES.values()):
         try:

@@ -1,8 +1,9 @@
-#!/usr/bin/env python3
 """ONE streamed pass over a large file in a fresh process - what a command-line call pays - with the time of every
 contig's arrival, for runs under `rocprofv3 --hip-runtime-trace --stats` (which HIP calls the first pass spends its time
 in: page-locking, device allocations, stream creation, code-object loads).
-usage: tools/first_pass_probe.py bam|text [passes=1]"""
+usage: python3 tools/first_pass_probe.py bam|text [passes=1]
+under the profiler the interpreter itself stands behind `--` (an `env` / shebang hop would be an exec after the profiler's
+library has initialised the GPU): rocprofv3 --kernel-trace -d <dir> -- python3 tools/first_pass_probe.py text 4"""
 import os
 import sys
 import tempfile

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Occupancy of the GPU over ONE pass of a decoder stream, from a `rocprofv3 --kernel-trace --output-format csv`
-directory of `tools/first_pass_probe.py text|bam N` (the passes are told apart by the pauses between them; the last
+directory of `rocprofv3 --kernel-trace -d <dir> -- python3 tools/first_pass_probe.py text|bam N` (the passes are told apart by the pauses between them; the last
 one is analysed): how long any kernel is running, how many inflate launches run side by side and for how long, the
 start and duration of every inflate launch and every row-parser launch, kernel time by name.
 usage: tools/stream_timeline.py <trace dir>"""
