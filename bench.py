@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the file -> result legs (end_to_end in the JSON)")
+    ap.add_argument("--no-kernel-rows", action="store_true", help="skip the next-row / BAM-mode kernel rooflines (tools/kernel_rows.py)")
     args = ap.parse_args()
     if os.environ.get("FTK_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after <seconds>
         import faulthandler
@@ -429,12 +430,15 @@ def main():
             if one_launch:
                 wps_bytes += feat_unit_bytes(u)
     achieved = wps_bytes / (wps_ms * 1e-3) / 1e9 if wps_ms > 0 else 0.0
-    traffic = None  # HBM bytes per launch from the committed PMC passes (same workload only)
+    traffic = traffic_source = None  # HBM bytes per launch from the committed PMC passes (same workload only)
     tpath = os.path.join(ROOT, "profiles", "wps_traffic.json")
     if world == 1 and not sim and not args.contigs and args.depth == 30.0 and os.path.exists(tpath):
         tj = json.load(open(tpath))  # measured per step (the dominant kernel's launches of one step), reported per launch
         if tj.get("kernel", "wps_stream_kernel") == ("feat_then_wps_kernel" if one_launch else "wps_stream_kernel"):
             traffic = int(tj["hbm_bytes_per_step"] / max(len(wps_ev), 1))
+            # a committed measurement of this workload (two separate --pmc passes under rocprofv3: tools/profile_round.sh),
+            # not a counter read of THIS run: the line says which build's
+            traffic_source = f"{tj.get('source', 'profiles/wps_traffic.json')} ({tj.get('build', 'build not recorded')})"
     # second kernel of the step: the fused window-feature pass of a unit runs between the previous unit's WPS
     # stop event and this unit's WPS start event (per-unit launch shape only)
     feat = None
@@ -462,7 +466,7 @@ def main():
             prev = b
     roofline = dict(bound="hbm", kernel="feat_then_wps_kernel" if one_launch else "wps_stream_kernel",
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_bytes_per_launch=int(wps_bytes / max(len(wps_ev), 1)),
                     launches=len(wps_ev), avg_launch_ms=round(wps_ms / max(len(wps_ev), 1), 4))
     if feat:
@@ -493,6 +497,16 @@ def main():
         # and it must be the whole genome's DELFI count: compare with the sum of what every rank computed itself
         mine_tot = int(grp.all_reduce_sum_i64(np.array([int(gather_in.sum().item())], np.int64))[0])
         checks["allgather_total_eq_sum_of_ranks"] = mine_tot == tot
+    # ---- the kernels behind the headline launch: the section-8(f) rows and the BAM-mode kernels of config 5 ----------
+    next_rows = None
+    if rank == 0 and world == 1 and not sim and not args.no_kernel_rows:
+        try:
+            from tools import kernel_rows
+            kr = kernel_rows.measure(torch, eng, "all", reps=5)
+            next_rows = kr.get("next_rows")
+            roofline["bam_kernels"] = kr.get("bam_kernels")
+        except Exception as exc:  # noqa: BLE001 - the headline line must still be printed
+            next_rows = {"error": f"{type(exc).__name__}: {exc}"}
     file_leg = None
     if use_dist and world > 1 and not sim and not args.no_end_to_end:
         # N ranks, ONE file: BASELINE config 4 end to end through the product function (every rank index-seeks and
@@ -545,7 +559,7 @@ def main():
                        "sharding": (f"genome cut into {world} equal window-aligned runs ({len(units)} units, halo "
                                     f"{halo} bp); all-gather of DELFI bin vector") if world > 1
                        else ("single GPU" if not sim else f"simulated rank {sim} alone")},
-            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e if world == 1 else file_leg, "checks": checks, "load_s": round(t_load, 2),
+            "roofline": roofline, "next_rows": next_rows, "cpu_baseline": cpu, "end_to_end": e2e if world == 1 else file_leg, "checks": checks, "load_s": round(t_load, 2),
             "priming_steps": prime, "launches": "fused WPS + features, 1 launch per unit" if fused else "1 launch per unit: feature blocks, then WPS tiles" if one_launch else ("1 batched feature launch + " + ("1 batched WPS launch" if batch_wps else "1 WPS launch per unit")
                          + " per step") if batched else "per unit",
         }
@@ -784,10 +798,11 @@ def end_to_end(torch, reps: int = 3, cpu=None):
                     n_win += len(ws)
                     key = src.key(c)
                     if all_features:
-                        r = eng.window_features(key, ws, we, MAPQ, hist=(0, HIST_BINS), delfi=dict(quality_threshold=MAPQ))
-                        tf = time.perf_counter()
-                        w = eng.wps(key, 0, size, size, WPS_W, WPS_MIN, WPS_MAX, MAPQ)
-                        tw = time.perf_counter()
+                        # ONE launch per contig: feature blocks first, the WPS tiles behind them; everything to the host
+                        r, w = eng.all_features_wps(key, ws, we, size, MAPQ, hist_bins=(0, HIST_BINS), delfi_q=MAPQ,
+                                                    window_size=WPS_W, wps_min_length=WPS_MIN, wps_max_length=WPS_MAX,
+                                                    wps_quality=MAPQ)
+                        tf = tw = time.perf_counter()
                         ok = ok and int(r["coverage"].sum()) == truth[c]["cov"] and len(w) == size
                         ok = ok and int(r["short"].sum() + r["long"].sum()) == truth[c]["delfi"]
                         ok = ok and int(r["hist"].sum()) + int(r["overflow"].sum()) == truth[c]["cov"]
@@ -803,8 +818,9 @@ def end_to_end(torch, reps: int = 3, cpu=None):
                 total = tb - t0
                 cur = dict(total_s=round(total, 4), windows=n_win, windows_per_s=round(n_win / total, 1),
                            fragments_per_s_M=round(sum(t["n"] for t in truth.values()) / total / 1e6, 1),
-                           waiting_for_resident_contigs_s=round(t_res, 4), feature_kernels_s=round(t_feat, 4),
-                           wps_kernel_and_copy_back_s=round(t_wps, 4) if all_features else None,
+                           waiting_for_resident_contigs_s=round(t_res, 4),
+                           **({"features_wps_one_launch_and_copy_back_s": round(t_feat, 4)} if all_features
+                              else {"feature_kernels_s": round(t_feat, 4)}),
                            decoder_producer_stage_ms=src.decode_stage_ms if src is not None else None, results_ok=bool(ok))
                 runs.append(cur)
             leg = rep_summary(runs)
@@ -837,15 +853,14 @@ def end_to_end(torch, reps: int = 3, cpu=None):
             for src, c in source.stream_source(pb, threads):
                 t1 = time.perf_counter()
                 key = src.key(c)
-                r = eng.window_features(key, ws, we, MAPQ, hist=(0, HIST_BINS), delfi=dict(quality_threshold=MAPQ))
-                t2 = time.perf_counter()
-                w = eng.wps(key, 0, bsize, bsize, WPS_W, WPS_MIN, WPS_MAX, MAPQ)
-                t3 = time.perf_counter()
+                r, w = eng.all_features_wps(key, ws, we, bsize, MAPQ, hist_bins=(0, HIST_BINS), delfi_q=MAPQ, window_size=WPS_W,
+                                            wps_min_length=WPS_MIN, wps_max_length=WPS_MAX, wps_quality=MAPQ)  # ONE launch
+                t2 = t3 = time.perf_counter()
             ok = (eng.info(key)[0] == exp["n"] and len(w) == bsize and
                   int(r["hist"].sum()) + int(r["overflow"].sum()) == int(r["coverage"].sum()) and int(r["coverage"].sum()) > 0)
             cur = dict(total_s=round(t3 - t0, 4), windows=len(ws), windows_per_s=round(len(ws) / (t3 - t0), 1),
                        fragments_per_s_M=round(exp["n"] / (t3 - t0) / 1e6, 1), waiting_for_resident_contigs_s=round(t1 - t0, 4),
-                       feature_kernels_s=round(t2 - t1, 4), wps_kernel_and_copy_back_s=round(t3 - t2, 4),
+                       features_wps_one_launch_and_copy_back_s=round(t3 - t1, 4),
                        decoder_producer_stage_ms=src.decode_stage_ms, results_ok=bool(ok))
             del w, r
             runs.append(cur)
@@ -856,6 +871,10 @@ def end_to_end(torch, reps: int = 3, cpu=None):
         # BASELINE config 5 at real size: a > 4 GiB, three-contig 60x BAM (a chr1-sized contig between two small ones)
         if os.environ.get("FTK_BENCH_BIG_BAM", "1") != "0":
             res["bam_60x_chr1_scale"] = big_bam_leg(torch, tmp, threads, h2d, rates)
+        # BASELINE config 5 as stated: the WHOLE genome as one 60x BAM, all features + WPS, one pass
+        if os.environ.get("FTK_BENCH_GENOME_BAM", "1") != "0":
+            rate = (res.get("bam_60x_chr1_scale") or {}).get("writer_records_per_s_M")
+            res["bam_60x_genome"] = genome_bam_leg(torch, dev, threads, h2d, rates, rate * 1e6 if rate else None)
         # BASELINE config 4 itself, file to feature vector: ONE whole-genome 30x frag.gz -> DELFI bins of every contig
         if os.environ.get("FTK_BENCH_GENOME_E2E", "1") != "0":
             from finaletoolkit_amd import writers
@@ -964,7 +983,7 @@ def big_bam_leg(torch, tmp, threads, h2d, rates, reps: int = 3):
     path = os.path.join(tmp, "wg60x.bam")
     try:
         t0 = time.perf_counter()
-        exp = synth.write_paired_bam_contigs(path, contigs, 60.0, 4242)
+        exp = synth.write_paired_bam_native(path, contigs, 60.0, 4242)
         t_write = time.perf_counter() - t0
         file_bytes = os.path.getsize(path)
         n_frag = sum(v["n"] for v in exp.values())
@@ -980,10 +999,10 @@ def big_bam_leg(torch, tmp, threads, h2d, rates, reps: int = 3):
                 ta = time.perf_counter()
                 t_wait += ta - tb
                 ws, we = synth.tiling_windows(sizes[c], WINDOW)
-                r = eng.window_features(src.key(c), ws, we, MAPQ, hist=(0, HIST_BINS), delfi=dict(quality_threshold=MAPQ))
-                tf = time.perf_counter()
-                w = eng.wps(src.key(c), 0, sizes[c], sizes[c], WPS_W, WPS_MIN, WPS_MAX, MAPQ)
-                tw = time.perf_counter()
+                r, w = eng.all_features_wps(src.key(c), ws, we, sizes[c], MAPQ, hist_bins=(0, HIST_BINS), delfi_q=MAPQ,
+                                            window_size=WPS_W, wps_min_length=WPS_MIN, wps_max_length=WPS_MAX,
+                                            wps_quality=MAPQ)  # ONE launch: the read1 fetch rule on the fast kernels
+                tf = tw = time.perf_counter()
                 ok = ok and len(w) == sizes[c] and eng.info(src.key(c))[0] == exp[c]["n"]
                 if rep == 0:
                     feats[c], sums[c] = r, int(w.sum())
@@ -995,11 +1014,12 @@ def big_bam_leg(torch, tmp, threads, h2d, rates, reps: int = 3):
             total = tb - t0
             runs.append(dict(total_s=round(total, 4), windows=n_win, windows_per_s=round(n_win / total, 1),
                              fragments_per_s_M=round(n_frag / total / 1e6, 1), file_GB_per_s=round(file_bytes / total / 1e9, 2),
-                             waiting_for_resident_contigs_s=round(t_wait, 4), feature_kernels_s=round(t_feat, 4),
-                             wps_kernel_and_copy_back_s=round(t_wps, 4), decoder_producer_stage_ms=src.decode_stage_ms,
+                             waiting_for_resident_contigs_s=round(t_wait, 4),
+                             features_wps_one_launch_and_copy_back_s=round(t_feat + t_wps, 4),
+                             decoder_producer_stage_ms=src.decode_stage_ms,
                              results_ok=bool(ok and seen == [c for c, _ in contigs])))
         leg = rep_summary(runs)
-        leg_floor(leg, file_bytes, 2 * n_frag * 117, "bam", h2d, rates)  # (117-byte records: 50 bp reads, 10-byte names)
+        leg_floor(leg, file_bytes, 2 * n_frag * 125, "bam", h2d, rates)  # (125-byte records: 50 bp reads, 10-byte names)
         # ---- the checks (untimed; the contigs of the last repetition are still resident) ----
         detail, ok = {}, leg["results_ok"] and file_bytes > (1 << 32)
         try:
@@ -1028,8 +1048,8 @@ def big_bam_leg(torch, tmp, threads, h2d, rates, reps: int = 3):
             ok, detail["error"] = False, f"{type(exc).__name__}: {exc}"
         leg["results_ok"] = bool(ok)
         return dict(file_GB=round(file_bytes / 1e9, 3), larger_than_4GiB=file_bytes > (1 << 32), contigs=len(contigs),
-                    fragments=n_frag, records=2 * n_frag, file_write_s=round(t_write, 1), decoder_threads=threads, **leg,
-                    checked=detail)
+                    fragments=n_frag, records=2 * n_frag, file_write_s=round(t_write, 1),
+                    writer_records_per_s_M=round(2 * n_frag / t_write / 1e6, 1), decoder_threads=threads, **leg, checked=detail)
     except Exception as exc:  # noqa: BLE001 - the other legs must still be reported
         return {"error": f"{type(exc).__name__}: {exc}"}
     finally:
@@ -1037,6 +1057,112 @@ def big_bam_leg(torch, tmp, threads, h2d, rates, reps: int = 3):
         for q in (path, path + ".bai"):
             if os.path.exists(q):
                 os.remove(q)
+
+
+def genome_bam_leg(torch, dev, threads, h2d, rates, records_per_s, reps: int = 2):
+    """BASELINE config 5 as stated: ONE whole-genome 60x coordinate-sorted paired-end BAM - all 24 b37 contigs, 6.2 x 10^8
+    pairs / 1.24 x 10^9 records / ~71 GB at full scale; every contig shortened by the same factor when the box's scratch
+    space or its writer's rate (two minutes at the rate the three-contig leg measured) cannot take that, ``scale`` says
+    which - written once (not timed: ``synth.write_genome_bam``, records built, sorted and deflated by the host threads),
+    then streamed ``reps`` times through the device inflate + device record parser (``source.stream_source``): for every
+    contig every feature of every 100 kb window and the WPS of every base, ONE launch per contig (the read1 fetch rule of
+    reference io/alignment.py:242-268 on the fast kernels), all results in host memory.  Checked (untimed,
+    ``oracle/scale_check.py``): every contig's exact fragment count and the closed form of its WPS sum in every
+    repetition; after the last one 24 sampled windows (coverage, histogram, DELFI) and 3 x 50 kb of WPS per contig
+    against the C oracle in read1 mode on the still-resident contigs, and a region read through the BAI behind the offset
+    at which the LAST contig begins."""
+    import shutil
+    import tempfile
+    from finaletoolkit_amd import source
+    d = None
+    try:
+        base = synth.big_scratch_dir(synth.genome_bam_bytes())
+        d = tempfile.mkdtemp(prefix="ftk_wgbam_", dir=base)
+        scale = synth.genome_bam_scale(d, records_per_s=records_per_s, write_budget_s=120.0)
+        path = os.path.join(d, "genome60x.bam")
+        t0 = time.perf_counter()
+        contigs, info = synth.write_genome_bam(path, scale, 60.0, torch, dev)
+        t_write = time.perf_counter() - t0
+        sizes = dict(contigs)
+        names = [c for c, _ in contigs]
+        file_bytes = os.path.getsize(path)
+        n_frag = sum(v["n"] for v in info.values())
+        n_win = sum(-(-n // WINDOW) for n in sizes.values())
+        from oracle import scale_check as SC  # checker only
+        runs, sums, src = [], {}, None
+        for rep in range(reps):
+            source.close_all()
+            eng = source.get_engine()
+            t0 = time.perf_counter()
+            t_wait = t_launch = 0.0
+            tb, seen, ok = t0, [], True
+            for src, c in source.stream_source(path, threads):
+                ta = time.perf_counter()
+                t_wait += ta - tb
+                ws, we = synth.tiling_windows(sizes[c], WINDOW)
+                r, w = eng.all_features_wps(src.key(c), ws, we, sizes[c], MAPQ, hist_bins=(0, HIST_BINS), delfi_q=MAPQ,
+                                            window_size=WPS_W, wps_min_length=WPS_MIN, wps_max_length=WPS_MAX, wps_quality=MAPQ)
+                tl = time.perf_counter()
+                t_launch += tl - ta
+                ok = ok and len(w) == sizes[c] and eng.info(src.key(c))[0] == info[c]["n"]
+                ok = ok and int(r["hist"].sum()) + int(r["overflow"].sum()) == int(r["coverage"].sum()) > 0
+                if rep == reps - 1:
+                    sums[c] = (int(w.sum()), r)
+                seen.append(c)
+                del w
+                tb = time.perf_counter()  # (the sums above are the bench's own bookkeeping: outside the clock's stages, inside its total)
+            total = tb - t0
+            runs.append(dict(total_s=round(total, 4), windows=n_win, windows_per_s=round(n_win / total, 1),
+                             fragments_per_s_M=round(n_frag / total / 1e6, 1), file_GB_per_s=round(file_bytes / total / 1e9, 2),
+                             waiting_for_resident_contigs_s=round(t_wait, 4),
+                             features_wps_one_launch_and_copy_back_s=round(t_launch, 4),
+                             decoder_producer_stage_ms=src.decode_stage_ms, results_ok=bool(ok and seen == names)))
+        leg = rep_summary(runs)
+        leg_floor(leg, file_bytes, 2 * n_frag * 125, "bam", h2d, rates)
+        detail, ok = {}, leg["results_ok"]
+        try:
+            eng = source.get_engine()
+            n_checked = wps_checked = 0
+            for k, (c, size) in enumerate(contigs):
+                exp = synth.genome_bam_expected(k, size, 60.0, torch, dev)
+                good, dd = SC.check_contig(eng, src.key(c), size, exp, sums[c][1], n_sampled=24)
+                good = good and sums[c][0] == SC.wps_closed_form_sum(exp, size)
+                n_checked += dd["windows_checked"]
+                wps_checked += dd["wps_bases_checked"]
+                if not good:
+                    detail[c] = dd
+                ok = ok and good
+                if c == names[-1]:
+                    last_exp = exp
+            detail["contigs_checked"] = len(contigs)
+            detail["windows_checked"] = n_checked
+            detail["wps_bases_checked"] = wps_checked
+            detail["every_contig_wps_sum_equals_closed_form"] = bool(ok)
+            source.close_all()
+            lazy = source.open_source(path)
+            eng = source.get_engine()
+            c, size = contigs[-1]
+            a = size // 2 // WINDOW * WINDOW
+            off = SC.region_file_offset(dict(linear=info[c]["linear"]), a)
+            key = lazy.require_region(c, a, a + 4 * WINDOW)
+            good, dd = SC.check_region(eng, key, size, last_exp, a, a + 4 * WINDOW)
+            dd["file_offset"] = off
+            dd["behind_the_last_contigs_offset"] = bool(off >= info[c]["first_off"])
+            dd["behind_4GiB"] = bool(off > (1 << 32))
+            detail[f"region {c}:{a}-{a + 4 * WINDOW}"] = dd
+            ok = ok and good and dd["behind_the_last_contigs_offset"] and c not in lazy.loaded
+        except Exception as exc:  # noqa: BLE001
+            ok, detail["error"] = False, f"{type(exc).__name__}: {exc}"
+        leg["results_ok"] = bool(ok)
+        return dict(scale=scale, full_genome=bool(scale >= 1.0), contigs=len(contigs), file_GB=round(file_bytes / 1e9, 2),
+                    scratch=base, fragments=n_frag, records=2 * n_frag, file_write_s=round(t_write, 1),
+                    writer_GB_per_s=round(file_bytes / t_write / 1e9, 2), decoder_threads=threads, **leg, checked=detail)
+    except Exception as exc:  # noqa: BLE001 - the other legs must still be reported
+        return {"error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        source.close_all()
+        if d:
+            shutil.rmtree(d, ignore_errors=True)
 
 
 def frag_delfi_api_leg(torch, tmp, genome_file, threads, n_win_total, rows_total, raw_leg, cpu):

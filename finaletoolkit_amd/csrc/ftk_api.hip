@@ -732,8 +732,11 @@ struct FeatCall {
     const MotifParams* motif = nullptr;  // hist_out = k-mer histogram, overflow_out = error counts
 };
 
+// tail: a whole-interval WPS to run in the same launch (see launch_window_features).  scratch_prefix > 0: the caller keeps
+// that many bytes at the start of the ctx scratch for itself - the tail's scores when they are bound for host memory -
+// and tail->out is taken to be the scratch base.
 int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
-                    const FeatCall& fc, const WpsTail* tail = nullptr, bool* tail_merged = nullptr) {
+                    const FeatCall& fc, const WpsTail* tail = nullptr, bool* tail_merged = nullptr, size_t scratch_prefix = 0) {
     if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
     ContigData* c;
     int rc = get_contig(ctx, contig_id, &c);
@@ -767,8 +770,15 @@ int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const i
                l_dev = is_device_ptr(fc.long_out), n_dev = is_device_ptr(fc.nfrag_out);
     const size_t hist_elems = fc.hist_out ? (size_t)n_win * (size_t)fc.n_bins : 0;
     size_t need = window_scratch_bytes(n_win) + 5 * align_up(n_win * 8) + (h_dev ? 0 : align_up(hist_elems * 4));
-    if ((rc = reserve_scratch(ctx, need))) return rc;
+    if ((rc = reserve_scratch(ctx, scratch_prefix + need))) return rc;
     Arena a(ctx);
+    a.off = scratch_prefix;
+    WpsTail tail_here;
+    if (tail && scratch_prefix) {
+        tail_here = *tail;
+        tail_here.out = (int64_t*)ctx->scratch;
+        tail = &tail_here;
+    }
     FeatureRequest r;
     r.filter = fc.f;
     r.cov_out = fc.count_out ? (c_dev ? fc.count_out : a.take<int64_t>(n_win)) : nullptr;
@@ -1319,8 +1329,15 @@ int ftk_window_features_wps(ftk_ctx* ctx, int contig_id, const int32_t* w_start,
     if (rc) return rc;
     WpsTail tail{};
     if ((rc = wps_params(ctx, *c, chrom_size, window_size, min_len, max_len, mapq_min, &tail.p))) return rc;
-    const bool wps_ok = stop > start && start >= -(1LL << 30) && stop <= (1LL << 31) && wps_out && is_device_ptr(wps_out) &&
-                        n_win > 0;
+    const bool wps_ok = stop > start && start >= -(1LL << 30) && stop <= (1LL << 31) && wps_out && n_win > 0;
+    // scores bound for host memory: the merged launch writes them to the head of the ctx scratch and they cross the link
+    // like ftk_wps' (16 bits per score when they fit)
+    const bool host_wps = wps_ok && !is_device_ptr(wps_out);
+    const int64_t n_pos = stop - start;
+    static const bool narrow_env = !(getenv("FTK_WPS_NARROW_WIRE") && atoi(getenv("FTK_WPS_NARROW_WIRE")) == 0);
+    const bool narrow = host_wps && narrow_env && n_pos >= kNarrowMin;
+    const size_t wide_bytes = host_wps ? align_up((size_t)n_pos * 8) : 0;
+    const size_t prefix = host_wps ? wide_bytes + (narrow ? align_up((size_t)n_pos * 2) + 256 : 0) : 0;
     FeatCall fc;
     fc.f = f;
     fc.count_out = count_out;
@@ -1341,11 +1358,24 @@ int ftk_window_features_wps(ftk_ctx* ctx, int contig_id, const int32_t* w_start,
         tail.p.start = start;
         tail.p.stop = stop;
         tail.n_tiles = (stop - start + kWpsTile - 1) / kWpsTile;
-        tail.out = wps_out;
+        tail.out = wps_out;  // (host_wps: replaced by the scratch base inside features_common)
     }
-    if ((rc = features_common(ctx, contig_id, w_start, w_end, n_win, fc, wps_ok ? &tail : nullptr, &merged))) return rc;
-    if (merged) return FTK_OK;
-    return ftk_wps(ctx, contig_id, start, stop, chrom_size, window_size, min_len, max_len, mapq_min, wps_out);
+    if ((rc = features_common(ctx, contig_id, w_start, w_end, n_win, fc, wps_ok ? &tail : nullptr, &merged, prefix))) return rc;
+    if (!merged) return ftk_wps(ctx, contig_id, start, stop, chrom_size, window_size, min_len, max_len, mapq_min, wps_out);
+    if (host_wps) {
+        int64_t* d_out = (int64_t*)ctx->scratch;
+        bool done = false;
+        if (narrow) {
+            char* nw = (char*)ctx->scratch + wide_bytes;
+            if ((rc = copy_scores_narrow(ctx, d_out, (int16_t*)nw, (int*)(nw + align_up((size_t)n_pos * 2)), n_pos, wps_out, &done)))
+                return rc;
+        }
+        if (!done) {
+            HIPCHK(ctx, hipMemcpyAsync(wps_out, d_out, (size_t)n_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    return FTK_OK;
 }
 
 int ftk_wps_async(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t chrom_size, int32_t window_size,

@@ -340,6 +340,25 @@ class Engine:
             L.ptr(long), int(wps_start), int(wps_stop), int(chrom_size), int(window_size), int(wps_min_length),
             int(wps_max_length), int(wps_quality), L.ptr(wps_out)))
 
+    def all_features_wps(self, name: str, starts, stops, chrom_size: int, quality_threshold=30, hist_bins=(0, 1001),
+                         delfi_q=30, bl_start=None, bl_end=None, gaps=None, window_size=120, wps_min_length=120,
+                         wps_max_length=180, wps_quality=30):
+        """Every feature of the windows AND the WPS of every base of the contig, in host memory, from ONE launch
+        (``window_features_wps``: coverage, length histogram + overflow, DELFI short / long; scores of
+        ``[0, chrom_size)``) - BASELINE config 5's "all features fused single pass" as this engine serves it.
+        Returns ``(features dict, scores int64)``."""
+        ws, we = _win(starts, L.OPEN_LO), _win(stops, L.OPEN_HI)
+        n = len(ws)
+        f = dict(coverage=np.zeros(n, np.int64), hist=np.zeros((n, int(hist_bins[1])), np.uint32), overflow=np.zeros(n, np.int64),
+                 short=np.zeros(n, np.int64), long=np.zeros(n, np.int64))
+        size = int(chrom_size)
+        w = self.result_array(size, np.int64, pinned=not (_NARROW_WIRE and size >= NARROW_WIRE_MIN))
+        self.window_features_wps(name, ws, we, w, 0, size, size, quality_threshold, coverage=f["coverage"], hist=f["hist"],
+                                 hist_bins=hist_bins, overflow=f["overflow"], delfi_q=delfi_q, bl_start=bl_start, bl_end=bl_end,
+                                 gaps=gaps, short=f["short"], long=f["long"], window_size=window_size,
+                                 wps_min_length=wps_min_length, wps_max_length=wps_max_length, wps_quality=wps_quality)
+        return f, w
+
     def feature_batch(self, items, quality_threshold=30, min_length=None, max_length=None,
                       intersect_policy="midpoint"):
         """Prepare a multi-contig window-feature batch (``ftk_window_features_batch``): ``items`` is a list of

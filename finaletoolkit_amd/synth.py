@@ -287,6 +287,95 @@ def write_paired_bam_native(path, contigs, depth, seed, read_len=50, fragments=N
     return out
 
 
+# ---- BASELINE config 5: a whole-genome 60x BAM -------------------------------------------------------------------------
+GENOME_BAM_SEED = 5150
+GENOME_BAM_READ = 50
+
+
+def genome_bam_contigs(scale: float = 1.0):
+    """The 24 b37 contigs, each at ``scale`` of its length (1.0: the real genome - 6.2 x 10^8 pairs at 60x, ~70 GB of
+    BAM; a smaller scale keeps every contig and shortens them all, for boxes that cannot hold the file)."""
+    return [(c, max(int(n * scale), 200_000)) for c, n in B37_SIZES.items()]
+
+
+def genome_bam_fragments(k: int, size: int, depth: float = 60.0, torch=None, dev=None):
+    """Contig ``k``'s fragments of the whole-genome BAM (start-sorted host columns, ends stretched to the read length) -
+    from the seeded generator on the device when torch is given (0.1 s for chr1), else numpy's.  The writer and the
+    checks call this with the same arguments, so nothing of a 6 x 10^8-pair genome has to be kept in between."""
+    n = n_fragments(size, depth)
+    if torch is not None:
+        s, e, q, st = (t.cpu().numpy() for t in gen_contig_device(torch, dev, size, n, GENOME_BAM_SEED + k))
+    else:
+        s, e, q, st = synth_contig(size, depth, GENOME_BAM_SEED + k)
+    e = np.maximum(e, s + GENOME_BAM_READ).astype(np.int32)
+    return s, e, q, st
+
+
+def genome_bam_expected(k: int, size: int, depth: float = 60.0, torch=None, dev=None):
+    """What the decoder must hand out for contig ``k``: the fragments with their read1 span (``oracle.scale_check``)."""
+    s, e, q, st = genome_bam_fragments(k, size, depth, torch, dev)
+    r1 = np.where(st == 1, s, e - GENOME_BAM_READ).astype(np.int32)
+    return dict(s=s, e=e, q=q, st=st, r1s=r1, r1e=(r1 + GENOME_BAM_READ).astype(np.int32), n=len(s))
+
+
+def write_genome_bam(path, scale: float = 1.0, depth: float = 60.0, torch=None, dev=None, threads: int = 0):
+    """BASELINE config 5's input: ONE coordinate-sorted paired-end BAM of all 24 contigs (``genome_bam_contigs``) at
+    ``depth``, with its ``.bai`` (spans + 16 kb linear index), written by ``write_paired_bam_native``.  Returns
+    ``(contigs, info)``: ``info[name]`` = ``dict(n, first_off, end_off, linear)``."""
+    contigs = genome_bam_contigs(scale)
+    info = write_paired_bam_native(path, contigs, depth, GENOME_BAM_SEED, read_len=GENOME_BAM_READ,
+                                   fragments=lambda k, c, size: genome_bam_fragments(k, size, depth, torch, dev),
+                                   threads=threads, keep=())
+    return contigs, info
+
+
+_BAM_BYTES_PER_RECORD = 57.6  # measured: 2.302 GB for 2 x 20 M records of 125 bytes deflated at level 1
+
+
+def genome_bam_bytes(scale: float = 1.0, depth: float = 60.0) -> int:
+    """Expected size of the whole-genome BAM at ``scale`` (71 GB at 1.0 / 60x)."""
+    return int(2 * sum(n_fragments(n, depth) for _, n in genome_bam_contigs(scale)) * _BAM_BYTES_PER_RECORD)
+
+
+def big_scratch_dir(bytes_needed: int) -> str:
+    """A directory that can hold ``bytes_needed`` with room to spare: ``FTK_BIG_TMP``, the temp directory, or - when that
+    is too small and the machine has the memory - ``/dev/shm``; else whichever has the most free space."""
+    import os
+    import shutil
+    import tempfile
+    cands = [d for d in (os.environ.get("FTK_BIG_TMP"), tempfile.gettempdir(), "/dev/shm") if d and os.path.isdir(d)]
+
+    def free(d):
+        f = shutil.disk_usage(d).free
+        if d == "/dev/shm":  # (memory: leave 48 GB for everything else)
+            try:
+                avail = next(int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable"))
+                f = min(f, max(avail - (48 << 30), 0))
+            except (OSError, StopIteration, ValueError):
+                pass
+        return f
+    for d in cands:
+        if free(d) >= 1.5 * bytes_needed:
+            return d
+    return max(cands, key=free)
+
+
+def genome_bam_scale(directory, records_per_s: float | None = None, write_budget_s: float = 120.0, depth: float = 60.0):
+    """The largest ``scale`` (<= 1) of the whole-genome BAM that ``directory`` holds with room to spare and that the
+    writer finishes within ``write_budget_s`` at ``records_per_s`` (measured by the caller on a small file).
+    ``FTK_WG_BAM_SCALE`` overrides."""
+    import os
+    import shutil
+    env = os.environ.get("FTK_WG_BAM_SCALE")
+    if env:
+        return float(env)
+    free = shutil.disk_usage(directory).free
+    scale = min(1.0, 0.6 * free / genome_bam_bytes(1.0, depth))
+    if records_per_s:
+        scale = min(scale, write_budget_s * records_per_s / (2 * sum(n_fragments(n, depth) for n in B37_SIZES.values())))
+    return max(0.02, round(scale, 3))
+
+
 def write_random_2bit(path, sizes, seed=SEED_BASE, n_blocks=True):
     """A UCSC ``.2bit`` reference of random bases for ``sizes = {contig: length}`` (little endian, version 0): the
     packed DNA is written as random bytes (T=0 C=1 A=2 G=3, four bases per byte, first base in the high bits), each

@@ -347,11 +347,13 @@ int ftk_wps_async(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int6
 int ftk_result_wait(ftk_ctx* ctx, int token);
 
 /* ftk_window_features (all arguments as there) FOLLOWED BY ftk_wps (all arguments as there) on the same contig, as
- * ONE launch when the feature request takes the FAST block path (tabix fetch, midpoint policy, no length bounds on
- * the coverage filter, one mapq cut, a bin tiling) and wps_out is a device pointer: the grid holds the feature
- * blocks first and the WPS tiles behind them, so the feature pass's tail and the WPS ramp overlap and WPS finds the
- * contig's columns in the Infinity Cache.  Any other request runs as the two launches.  Results are those of the
- * two calls (reference: frag/_coverage.py:117-130, _frag_length.py:147-153, _delfi.py:443-472, _wps.py:156-188). */
+ * ONE launch when the feature request takes the FAST block path (midpoint policy, no length bounds on the coverage
+ * filter, one mapq cut, a bin tiling; tabix fetch or - on a contig with read1 columns - the BAM read1 fetch rule):
+ * the grid holds the feature blocks first and the WPS tiles behind them, so the feature pass's tail and the WPS ramp
+ * overlap and WPS finds the contig's columns in the Infinity Cache.  wps_out may be device memory or a host array
+ * (the scores then cross the link like ftk_wps': 16 bits each when they fit).  Any other request runs as the two
+ * launches.  Results are those of the two calls (reference: frag/_coverage.py:117-130, _frag_length.py:147-153,
+ * _delfi.py:443-472, _wps.py:156-188; BAM fetch rule: io/alignment.py:242-268). */
 int ftk_window_features_wps(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
                             const ftk_filter* f, int64_t* count_out, int32_t len_lo, int32_t n_bins, uint32_t* hist_out,
                             int64_t* overflow_out, int32_t delfi_mapq_min, const int32_t* bl_start, const int32_t* bl_end,

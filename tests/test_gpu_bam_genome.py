@@ -1,0 +1,133 @@
+"""
+GPU: BASELINE config 5 as BASELINE states it -- "whole-genome 60x BAM stream, all features (coverage+WPS+frag-len+DELFI)
+fused single pass": ONE coordinate-sorted paired-end BAM of all 24 b37 contigs (6.2 x 10^8 pairs, 1.24 x 10^9 records,
+~71 GB at full scale), streamed ONCE through the device inflate + device record parser (``source.stream_source``); for
+every contig every feature of every 100 kb window and the WPS of every base from ONE launch (``Engine.all_features_wps``:
+the read1 fetch rule of reference ``io/alignment.py:242-268`` on the fast kernels), against the C oracle in read1 mode
+on >= 24 sampled windows and 150 kb of WPS per contig (``oracle/scale_check.py``), exact fragment counts, the closed
+form of every contig's WPS sum; then region reads through the BAI - one BEHIND THE LAST CONTIG'S OFFSET (on Y, the
+file's last contig; behind the 4 GiB mark whenever the file is larger), one in the middle of the file - equal to the
+oracle and to the streamed answer.  What the three-contig file of tests/test_gpu_bam_scale.py cannot show: 24 contig
+hand-overs, a BAI of 24 references with ~190 000 linear-index windows, the slot ring over ~700 pieces.
+
+Size: the file is written at the largest scale (all 24 contigs, each at ``scale`` of its length) the box's scratch
+space holds and its host threads write within two minutes (``synth.genome_bam_scale``; ``FTK_WG_BAM_SCALE`` overrides;
+a box with the space - /dev/shm counts - and >= 64 cores writes the real genome, scale 1.0, in about a minute).
+"""
+import os
+import shutil
+import tempfile
+import time
+
+import numpy as np
+import pytest
+
+from finaletoolkit_amd import synth
+from oracle import scale_check as SC
+
+pytestmark = pytest.mark.gpu
+GIB4 = 1 << 32
+
+
+@pytest.fixture(scope="module")
+def genome_bam():
+    import torch
+    dev = torch.device("cuda", 0)
+    base = synth.big_scratch_dir(synth.genome_bam_bytes())
+    d = tempfile.mkdtemp(prefix="ftk_wgbam_", dir=base)
+    try:
+        # how fast this box writes records (a 30 Mb contig), then the scale that fits its space and two minutes
+        t0 = time.perf_counter()
+        probe = os.path.join(d, "probe.bam")
+        info = synth.write_paired_bam_native(probe, [("p", 30_000_000)], 60.0, 1, keep=())
+        rate = 2 * info["p"]["n"] / (time.perf_counter() - t0)
+        os.remove(probe)
+        os.remove(probe + ".bai")
+        scale = synth.genome_bam_scale(d, records_per_s=rate, write_budget_s=120.0)
+        path = os.path.join(d, "genome60x.bam")
+        t0 = time.perf_counter()
+        contigs, info = synth.write_genome_bam(path, scale, 60.0, torch, dev)
+        yield dict(path=path, contigs=contigs, info=info, scale=scale, write_s=time.perf_counter() - t0, torch=torch, dev=dev)
+    finally:
+        from finaletoolkit_amd import source
+        source.close_all()
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def test_config5_whole_genome_bam_all_features_in_one_pass(genome_bam):
+    from finaletoolkit_amd import source
+    g = genome_bam
+    path, contigs, info, torch, dev = g["path"], g["contigs"], g["info"], g["torch"], g["dev"]
+    names = [c for c, _ in contigs]
+    sizes = dict(contigs)
+    assert len(contigs) == 24 and names == list(synth.B37_SIZES)
+    file_bytes = os.path.getsize(path)
+    pairs = sum(v["n"] for v in info.values())
+    if g["scale"] >= 1.0:
+        assert pairs == 619_135_482 and file_bytes > 60e9
+    print(f"\n[config 5] scale {g['scale']}: {pairs} pairs, {file_bytes / 1e9:.2f} GB written in {g['write_s']:.1f} s "
+          f"({file_bytes / 1e9 / g['write_s']:.2f} GB/s of file)")
+    source.close_all()
+    eng = source.get_engine()
+    seen, kept = [], {}
+    t0 = time.perf_counter()
+    t_check = 0.0
+    for src, name in source.stream_source(path):
+        tc = time.perf_counter()
+        size = sizes[name]
+        key = src.key(name)
+        assert eng.is_bam(key)
+        ws, we = synth.tiling_windows(size, SC.WINDOW)
+        f, w = eng.all_features_wps(key, ws, we, size)          # ONE launch: feature blocks, then the WPS tiles
+        exp = synth.genome_bam_expected(names.index(name), size, 60.0, torch, dev)
+        assert exp["n"] == info[name]["n"]
+        ok, detail = SC.check_contig(eng, key, size, exp, f, n_sampled=24)
+        assert ok, (name, detail)
+        assert detail["windows_checked"] >= min(24, len(ws)) and detail["wps_bases_checked"] >= min(150_000, 3 * size)
+        # every base: the one-launch scores against the closed form of their sum and against a separate ftk_wps launch
+        # on three ranges (check_contig's: first, middle, last bases)
+        assert len(w) == size and int(w.sum()) == SC.wps_closed_form_sum(exp, size), name
+        for a, b in SC.wps_ranges(size):
+            assert np.array_equal(w[a:b], eng.wps(key, a, b, size, 120, 120, 180, 30)), (name, a, b)
+        # tiling + midpoint policy: a passing pair counts in at most one window - and in none when its read1 lies
+        # outside the window holding its midpoint (the read1 fetch rule: io/alignment.py:245)
+        passing = int((exp["q"] >= 30).sum())
+        assert 0.99 * passing < int(f["coverage"].sum()) <= passing
+        if name in ("Y", "9"):
+            kept[name] = (f, exp)
+        seen.append(name)
+        del w, exp
+        t_check += time.perf_counter() - tc
+    total = time.perf_counter() - t0
+    assert seen == names
+    print(f"[config 5] streamed + scored + checked in {total:.1f} s ({t_check:.1f} s of it the checks)")
+    # ---- region reads through the BAI's linear index ------------------------------------------------------------------
+    source.close_all()
+    del source.REGION_READS[:]
+    lazy = source.open_source(path)
+    eng = source.get_engine()
+    assert lazy.lazy and not lazy.loaded
+    last_off = info["Y"]["first_off"]
+    for name, frac in (("Y", 0.5), ("9", 0.5)):
+        size = sizes[name]
+        a = int(size * frac) // SC.WINDOW * SC.WINDOW
+        b = a + 4 * SC.WINDOW
+        f, exp = kept[name]
+        off = SC.region_file_offset(dict(linear=info[name]["linear"]), a)
+        if name == "Y":
+            assert off >= last_off  # behind the offset at which the file's LAST contig begins
+            if file_bytes > 2 * GIB4:
+                assert off > GIB4
+        key = lazy.require_region(name, a, b)
+        assert key in lazy.regions and name not in lazy.loaded
+        ok, detail = SC.check_region(eng, key, size, exp, a, b)
+        assert ok, (name, a, b, detail)
+        assert detail["region_rows"] < max(detail["contig_rows"] // 5, 1)
+        ws = np.arange(a, b, SC.WINDOW, dtype=np.int32)
+        got = eng.window_features(key, ws, (ws + SC.WINDOW).astype(np.int32), 30, hist=(0, 1001), delfi=dict(quality_threshold=30))
+        i0 = a // SC.WINDOW
+        for k in ("coverage", "hist", "overflow", "short", "long"):
+            assert np.array_equal(got[k], f[k][i0:i0 + len(ws)]), (name, k)
+        lazy.release_region(key)
+    assert [r[1] for r in source.REGION_READS] == ["Y", "9"]
+    source.close_all()

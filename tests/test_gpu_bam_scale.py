@@ -28,7 +28,7 @@ GIB4 = 1 << 32
 def big_bam(tmp_path_factory):
     d = tmp_path_factory.mktemp("bigbam")
     path = str(d / "wg60x.bam")
-    exp = synth.write_paired_bam_contigs(path, CONTIGS, 60.0, 4242)
+    exp = synth.write_paired_bam_native(path, CONTIGS, 60.0, 4242)  # (same records as write_paired_bam_contigs, written in C)
     yield path, exp
     from finaletoolkit_amd import source
     source.close_all()

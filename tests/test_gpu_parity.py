@@ -779,6 +779,7 @@ def test_features_and_wps_in_one_launch_equal_the_two_calls(engine, data, win_le
         want_wps = engine.wps(kind, a, b, CONTIG_LEN, W, 100, 200, 20)
         o = outs()
         w = torch.full((b - a,), -99, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()  # (torch fills the outputs on ITS stream, the engine launches on its own)
         engine.window_features_wps(kind, ws, we, w, a, b, CONTIG_LEN, coverage=o["coverage"], hist=o["hist"],
                                    hist_bins=(20, 640), overflow=o["overflow"], delfi_q=30, bl_start=bl_s, bl_end=bl_e,
                                    gaps=gaps, short=o["short"], long=o["long"], window_size=W, wps_min_length=100,
@@ -788,13 +789,16 @@ def test_features_and_wps_in_one_launch_equal_the_two_calls(engine, data, win_le
         for key in ("coverage", "overflow", "short", "long"):
             assert np.array_equal(o[key].cpu().numpy(), want[key]), (key, kw)
         assert np.array_equal(o["hist"].cpu().numpy().astype(np.uint32), want["hist"]), kw
-    # one feature at a time, and a host WPS array (two launches)
+    # one feature at a time, and a host WPS array (the merged launch, its scores copied back by the library)
     o = outs()
     w = torch.empty(CONTIG_LEN, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()  # (torch fills the outputs on ITS stream, the engine launches on its own)
     engine.window_features_wps(kind, ws, we, w, 0, CONTIG_LEN, CONTIG_LEN, coverage=o["coverage"])
+    engine.sync()
     assert np.array_equal(o["coverage"].cpu().numpy(), engine.window_counts(kind, ws, we, 30))
     engine.window_features_wps(kind, ws, we, w, 0, CONTIG_LEN, CONTIG_LEN, delfi_q=30, bl_start=bl_s, bl_end=bl_e, gaps=gaps,
                                short=o["short"], long=o["long"])
+    engine.sync()
     sh, lg, _ = engine.delfi_counts(kind, ws, we, 30, bl_s, bl_e, gaps)
     assert np.array_equal(o["short"].cpu().numpy(), sh) and np.array_equal(o["long"].cpu().numpy(), lg)
     assert np.array_equal(w.cpu().numpy(), engine.wps(kind, 0, CONTIG_LEN, CONTIG_LEN))
@@ -832,6 +836,11 @@ def test_wps_host_results_cross_the_link_narrow_and_arrive_exact(engine):
         assert (int(host.max()) > 32767) == (pile > 32767)
         # a short interval takes the plain copy: same numbers
         assert np.array_equal(engine.wps(name, 2_990_000, 3_010_000, size), host[2_990_000:3_010_000])
+        # the merged launch (feature blocks + WPS tiles) with a HOST score array takes the same wire
+        ws, we = synth.tiling_windows(size, 10_000)
+        cov, merged_host = np.zeros(len(ws), np.int64), np.full(size, -1, np.int64)
+        engine.window_features_wps(name, ws, we, merged_host, 0, size, size, coverage=cov)
+        assert np.array_equal(merged_host, host) and np.array_equal(cov, engine.window_counts(name, ws, we, 30)), name
         # the host threads fill such a result, so it lives in ordinary memory (ftk_host_alloc_pageable: nothing to
         # page-lock in a process's first call) that the library recycles: the block of a dropped result serves the next
         where, keep = host.ctypes.data, host.copy()

@@ -1,0 +1,177 @@
+"""Rooflines of the kernels BEHIND the headline launch, measured live with HIP events on the stream they are launched on:
+
+  next_rows    the §8(f) kernels on a chr2-sized 30x contig - ``cleavage_kernel`` (whole contig, float64 per base), the
+               end-motif mode of the window-feature kernels (k = 4, 2bit reference, 1 Mb windows), ``adjust_median_kernel``
+               (10 000 x 5 kb score runs, W = 1000), ``gc_count_kernel`` (100 kb bins of a 2bit image);
+  bam_kernels  the window-feature blocks, the WPS tiles and the merged launch on a chr1-sized 60x contig WITH read1 columns
+               (the BAM fetch rule, io/alignment.py:242-268): the kernels of BASELINE config 5.
+
+``bench.py`` calls ``measure()`` for its ``next_rows`` / ``roofline.bam_kernels`` entries; run as a script (under
+``rocprofv3 --kernel-trace --stats`` or ``--pmc`` for the summaries in profiles/) it prints the same dict as JSON.
+usage: python3 tools/kernel_rows.py [next|bam|all] [reps=5]
+
+Algorithmic bytes (SURVEY section 8-d's convention: what the result needs, once): fragment columns 10 B per fragment
+(+8 B with read1 columns), 8 B per per-base score, outputs once; stated per row in ``algorithmic``.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _row(kernel, ms, nbytes, algorithmic, launches=1, note=None):
+    ms = np.asarray(ms, dtype=np.float64)
+    med = float(np.median(ms))
+    out = dict(kernel=kernel, achieved=round(nbytes / (med * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+               frac=round(nbytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), algorithmic_bytes=int(nbytes),
+               algorithmic=algorithmic, avg_launch_ms=round(med / launches, 4), best_launch_ms=round(float(ms.min()) / launches, 4),
+               launches_timed=int(len(ms) * launches))
+    if note:
+        out["note"] = note
+    return out
+
+
+def _time(eng, fn, reps, flush=None):
+    fn()
+    eng.sync()
+    ts = []
+    for _ in range(reps):
+        if flush is not None:
+            flush()
+        eng.event_record(10)
+        fn()
+        eng.event_record(11)
+        ts.append(eng.event_elapsed_ms(10, 11))
+    return ts
+
+
+def measure(torch, eng, which="all", reps=5, seed=1):
+    """``eng``: an Engine whose stream is torch's current stream.  Returns ``{"next_rows": {...}, "bam_kernels": {...}}``."""
+    import ctypes as C
+    from finaletoolkit_amd import _lib as L, synth
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = {}
+    flush_buf = torch.empty(160_000_000, dtype=torch.int32, device=dev)  # 640 MB > the 256 MB Infinity Cache
+
+    def flush():
+        flush_buf.sum()  # evicts with clean lines: the kernel reads its columns from HBM
+
+    if which in ("all", "next"):
+        size = synth.B37_SIZES["2"]
+        n = synth.n_fragments(size, 30.0)
+        s, e, q, st = synth.gen_contig_device(torch, dev, size, n, seed)
+        torch.cuda.synchronize()
+        eng.load_contig_device("kr_next", s, e, q, st, n)
+        rows = {}
+        # cleavage profile of the whole contig into device memory
+        cl = torch.empty(size, dtype=torch.float64, device=dev)
+        s0, s1, so = np.array([0], np.int64), np.array([size], np.int64), np.array([0], np.int64)
+        f = lambda: eng._check(eng.lib.ftk_cleavage_intervals(eng.ctx, eng.contig_id("kr_next"), L.ptr(s0), L.ptr(s1), 1,
+                                                              L.ptr(so), L.LEN_OPEN, L.LEN_OPEN, 20, L.ptr(cl)))
+        rows["cleavage_kernel"] = _row("cleavage_kernel", _time(eng, f, reps, flush), 10 * n + 8 * size,
+                                       "10 B x fragments + 8 B x bases (float64 per base)")
+        del cl
+        # end motifs, k = 4, 2bit reference, 1 Mb windows (end_motifs' tiling)
+        rng = np.random.default_rng(5)
+        packed = rng.integers(0, 256, (size + 3) // 4, dtype=np.uint8)
+        rid = eng.ref_upload(("kr", "2bit"), packed, 1)
+        eng.ref_set_layout(rid, size, 0, 0, [10_000], [20_000])
+        mws, mwe = synth.tiling_windows(size, 1_000_000)
+        k = 4
+        f = lambda: eng.motif_counts("kr_next", rid, mws, mwe, k, 0, -k, True, False, 0, False, 30)
+        rows["motif_pass"] = _row("feat_*_kernel<CH=2> (end motifs k=4, 2bit)", _time(eng, f, reps, flush),
+                                  10 * n + 2 * n + len(mws) * (4 ** k) * 4,
+                                  "10 B x fragments + 2 x 1 B of packed reference per fragment + 4^k x 4 B per window",
+                                  note="host round trip of the 243 x 256 counts included in the events")
+        # G + C of 100 kb bins from the 2bit image
+        glo, ghi = synth.tiling_windows(size, 100_000)
+        d_lo = torch.from_numpy(glo.astype(np.int64)).to(dev)
+        d_hi = torch.from_numpy(ghi.astype(np.int64)).to(dev)
+        d_gc = torch.zeros(len(glo), dtype=torch.int64, device=dev)
+        f = lambda: eng._check(eng.lib.ftk_ref_gc_counts(eng.ctx, rid, L.ptr(d_lo), L.ptr(d_hi), len(glo), L.ptr(d_gc)))
+        rows["gc_count_kernel"] = _row("gc_count_kernel", _time(eng, f, reps, flush), size // 4 + 8 * len(glo),
+                                       "1/4 B per base (2bit image) + 8 B per bin")
+        eng.release("kr_next")
+        del s, e, q, st, d_lo, d_hi, d_gc
+        # adjust_wps: running median W = 1000 over 10 000 x 5 kb score runs (device resident)
+        n_iv, ilen, W = 10_000, 5_000, 1000
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        x = torch.randint(-60, 60, (n_iv * ilen,), device=dev, generator=g).to(torch.float64)
+        offs = np.arange(n_iv + 1, dtype=np.int64) * ilen
+        y = torch.empty(n_iv * (ilen - W), dtype=torch.float64, device=dev)
+        f = lambda: eng.wps_adjust(x.data_ptr(), offs, W, out=y.data_ptr(), savgol=False)
+        rows["adjust_median_kernel"] = _row("adjust_median_kernel", _time(eng, f, reps), 8 * n_iv * ilen + 8 * n_iv * (ilen - W),
+                                            "8 B per input score + 8 B per output",
+                                            note="an exact sliding median: bound by its LDS sort and slot walk (DESIGN 3.4), not by HBM")
+        del x, y
+        out["next_rows"] = rows
+    if which in ("all", "bam"):
+        size = synth.B37_SIZES["1"]
+        n = synth.n_fragments(size, 60.0)
+        s, e, q, st = synth.gen_contig_device(torch, dev, size, n, seed)
+        e = torch.maximum(e, s + 50)
+        r1s = torch.where(st == 1, s, e - 50).to(torch.int32).contiguous()
+        r1e = (r1s + 50).contiguous()
+        torch.cuda.synchronize()
+        eng.load_contig_device("kr_bam", s, e, q, st, n)
+        eng.set_read1("kr_bam", r1s, r1e, n)
+        ws, we = synth.tiling_windows(size, 100_000)
+        nw = len(ws)
+        cov = torch.zeros(nw, dtype=torch.int64, device=dev)
+        hist = torch.zeros((nw, 1001), dtype=torch.int32, device=dev)
+        over = torch.zeros(nw, dtype=torch.int64, device=dev)
+        sh = torch.zeros(nw, dtype=torch.int64, device=dev)
+        lg = torch.zeros(nw, dtype=torch.int64, device=dev)
+        w = torch.empty(size, dtype=torch.int64, device=dev)
+        bl_s, bl_e = synth.synth_blacklist(size, 5, 160)
+        gaps = synth.synth_gaps(size)
+        flt = L.make_filter(30, None, None, "midpoint", L.FETCH_BAM_READ1)
+        gp = L.make_gaps(gaps)
+        feat_out = nw * (1001 * 4 + 32)
+        f_feat = lambda: eng._check(eng.lib.ftk_window_features(
+            eng.ctx, eng.contig_id("kr_bam"), L.ptr(ws), L.ptr(we), nw, C.byref(flt), L.ptr(cov), 0, 1001, L.ptr(hist),
+            L.ptr(over), 30, L.ptr(bl_s), L.ptr(bl_e), len(bl_s), C.byref(gp), L.ptr(sh), L.ptr(lg)))
+        f_wps = lambda: eng.wps("kr_bam", 0, size, size, 120, 120, 180, 30, out=w)
+        f_one = lambda: eng.window_features_wps("kr_bam", ws, we, w, 0, size, size, coverage=cov, hist=hist, hist_bins=(0, 1001),
+                                                overflow=over, delfi_q=30, bl_start=bl_s, bl_end=bl_e, gaps=gaps, short=sh, long=lg)
+        note = ("algorithmic = 18 B per fragment (SURVEY 8-d: 10 B + 8 B of read1 columns); the kernels read the read1 columns "
+                "only for fragments that cross a window / fetch bound (ContigView::r1_inside), so HBM traffic is ~10 B per "
+                "fragment: achieved_at_10B is the same launch priced at the bytes it really needs")
+        rows = {}
+        for key, kern, fn, b18, b10 in (
+                ("window_features", "feat_fast_kernel<512,1,1,1,BAM>", f_feat, 18 * n + 8 * nw + feat_out, 10 * n + 8 * nw + feat_out),
+                ("wps", "wps_stream_kernel", f_wps, 18 * n + 8 * size, 10 * n + 8 * size),
+                ("features_then_wps_one_launch", "feat_then_wps_kernel<1,1,1,BAM,NT>", f_one,
+                 2 * 18 * n + 8 * size + 8 * nw + feat_out, 2 * 10 * n + 8 * size + 8 * nw + feat_out)):
+            ts = _time(eng, fn, reps, flush)
+            r = _row(kern, ts, b18, "18 B x fragments (x2 in the merged launch: feature blocks, then WPS tiles) + 8 B x bases + outputs",
+                     note=note)
+            r["achieved_at_10B"] = round(b10 / (float(np.median(ts)) * 1e-3) / 1e9, 1)
+            r["frac_at_10B"] = round(r["achieved_at_10B"] / HBM_PEAK_GBS, 4)
+            rows[key] = r
+        rows["workload"] = f"chr1-sized contig, 60x, {n} fragments with read1 columns, {nw} x 100 kb windows, {size} bases"
+        eng.release("kr_bam")
+        out["bam_kernels"] = rows
+    del flush_buf
+    torch.cuda.empty_cache()
+    return out
+
+
+if __name__ == "__main__":
+    import torch
+    from finaletoolkit_amd.engine import Engine
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    eng = Engine(0)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    eng.set_stream(stream.cuda_stream)
+    print(json.dumps(measure(torch, eng, which, reps)))

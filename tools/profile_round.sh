@@ -27,4 +27,22 @@ FTK_BENCH_MERGED=0 $B --no-cpu-baseline --no-end-to-end > $OUT/bench_two_launche
 FTK_FEAT_FAST=0 KBENCH=feat python tools/kbench.py > $OUT/kbench_feat_general.txt 2>&1
 FTK_BENCH_DETAIL=1 $B --no-cpu-baseline --no-end-to-end > $OUT/bench_detail.json 2> $OUT/bench_detail.err
 rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/sq_SQ_* $OUT/e2e_stats $OUT/genome_stats
+# ---- round 5: the kernels behind the headline launch (tools/kernel_rows.py) under the profiler ------------------
+# BAM-mode kernels of config 5 (chr1-sized 60x contig with read1 columns): kernel stats + the two HBM counter passes
+cd /tmp
+K="python3 $GRAFT_REPO_ROOT/tools/kernel_rows.py"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bam_stats -- $K bam 5 > $OUT/bam_kernels_under_profiler.json 2> $OUT/bam_stats.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/bam_fetch -- $K bam 2 > /dev/null 2> $OUT/bam_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/bam_write -- $K bam 2 > /dev/null 2> $OUT/bam_write.err
+# next-row kernels (cleavage, motif pass, adjust median, G + C count)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/next_stats -- $K next 5 > $OUT/next_rows_under_profiler.json 2> $OUT/next_stats.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/next_fetch -- $K next 2 > /dev/null 2> $OUT/next_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/next_write -- $K next 2 > /dev/null 2> $OUT/next_write.err
+cd $GRAFT_REPO_ROOT
+python tools/prof_summary.py stats $OUT/bam_stats > $OUT/bam_kernel_stats.txt
+python tools/prof_summary.py pmc $OUT/bam_fetch $OUT/bam_write > $OUT/bam_pmc_hbm.txt
+python tools/prof_summary.py stats $OUT/next_stats > $OUT/nextrow_kernel_stats.txt
+python tools/prof_summary.py pmc $OUT/next_fetch $OUT/next_write > $OUT/nextrow_pmc_hbm.txt
+$K all 5 > $OUT/kernel_rows.json 2> $OUT/kernel_rows.err
+rm -rf $OUT/bam_stats $OUT/bam_fetch $OUT/bam_write $OUT/next_stats $OUT/next_fetch $OUT/next_write
 ls $OUT

@@ -9,6 +9,7 @@ import sys
 path = sys.argv[1]
 kernel = sys.argv[2] if len(sys.argv) > 2 else "feat_then_wps_kernel"
 per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 24  # launches of the kernel in one step (one per contig)
+build = sys.argv[4] if len(sys.argv) > 4 else "build not recorded"  # e.g. "r5_c, git 1a2b3c4"
 vals, calls = {}, {}
 for line in open(path):
     f = line.split()
@@ -18,7 +19,7 @@ for line in open(path):
 fetch, write = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
 per_launch = int((2 * fetch + write) * 1024)
 print(json.dumps({
-    "kernel": kernel, "source": path, "workload": "whole-genome b37 30x, %d launches per step" % per_step,
+    "kernel": kernel, "source": path, "build": build, "workload": "whole-genome b37 30x, %d launches per step" % per_step,
     "dispatches_profiled": calls["FETCH_SIZE"],
     "fetch_size_kib_per_launch": round(fetch, 3), "write_size_kib_per_launch": round(write, 3),
     "hbm_bytes_per_launch": per_launch, "hbm_bytes_per_step": per_launch * per_step,
