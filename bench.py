@@ -1125,7 +1125,7 @@ def genome_bam_leg(torch, dev, threads, h2d, rates, records_per_s, reps: int = 2
             n_checked = wps_checked = 0
             for k, (c, size) in enumerate(contigs):
                 exp = synth.genome_bam_expected(k, size, 60.0, torch, dev)
-                good, dd = SC.check_contig(eng, src.key(c), size, exp, sums[c][1], n_sampled=24)
+                good, dd = SC.check_contig(eng, src.key(c), size, exp, sums[c][1], n_sampled=28)
                 good = good and sums[c][0] == SC.wps_closed_form_sum(exp, size)
                 n_checked += dd["windows_checked"]
                 wps_checked += dd["wps_bases_checked"]

@@ -1399,8 +1399,7 @@ int ftk_wps_async(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int6
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->a_copy_done[k], hipEventDisableTiming));
         }
     }
-    const int k = ctx->a_next;
-    ctx->a_next ^= 1;
+    const int k = ctx->a_issued & 1;  // tokens count up; a token's buffer is its lowest bit
     if (ctx->a_pending[k]) {  // the buffer's previous result is still on its way to the host
         HIPCHK(ctx, hipEventSynchronize(ctx->a_copy_done[k]));
         ctx->a_pending[k] = false;
@@ -1424,18 +1423,24 @@ int ftk_wps_async(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int6
     HIPCHK(ctx, hipMemcpyAsync(wps_out_host, ctx->abuf[k], (size_t)n_pos * 8, hipMemcpyDeviceToHost, ctx->copy_stream));
     HIPCHK(ctx, hipEventRecord(ctx->a_copy_done[k], ctx->copy_stream));
     ctx->a_pending[k] = true;
-    *token_out = k;
+    ctx->a_token[k] = ctx->a_issued;
+    *token_out = ctx->a_issued;
+    ctx->a_issued = ctx->a_issued == INT32_MAX ? (ctx->a_issued & 1) ^ 1 : ctx->a_issued + 1;  // (wraps with the parity kept)
     return FTK_OK;
 }
 
 int ftk_result_wait(ftk_ctx* ctx, int token) {
     if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
     if (token < 0) return FTK_OK;  // an empty result
-    if (token > 1) return fail(ctx, FTK_ERR_INVALID, "bad result token %d", token);
-    if (ctx->a_pending[token]) {
+    const int k = token & 1;
+    if (ctx->a_token[k] < 0 || (ctx->a_token[k] != token && ctx->a_token[1 - k] != token && token >= ctx->a_issued))
+        return fail(ctx, FTK_ERR_INVALID, "result token %d was never handed out", token);
+    // a token older than the one in its buffer names a result that is complete: the call that reused the buffer waited
+    // for its copy first
+    if (ctx->a_token[k] == token && ctx->a_pending[k]) {
         HIPCHK(ctx, hipSetDevice(ctx->device));
-        HIPCHK(ctx, hipEventSynchronize(ctx->a_copy_done[token]));
-        ctx->a_pending[token] = false;
+        HIPCHK(ctx, hipEventSynchronize(ctx->a_copy_done[k]));
+        ctx->a_pending[k] = false;
     }
     return FTK_OK;
 }

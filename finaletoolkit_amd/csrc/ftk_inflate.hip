@@ -503,21 +503,26 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                 // serves both ends of the loop, and the store of its kind - 0 - marks nothing)
                 unsigned NB = kind ? (is_match ? lb + xb + dbits + dxb : lb) : 64u;
                 PROF(1, NB);  // the lanes' bits, the two gathers and the decode
+                // (round 5: the lanes on the chain are collected in a SCALAR bit mask - s_bitset1_b64, one scalar
+                // instruction a hop - and every lane picks its kind from it once, behind the loop; until then each hop
+                // marked its lane on the vector unit, v_cmp + v_cndmask = eight of a SIMD's cycles per symbol, and the
+                // vector unit is what this kernel is short of.  Five instructions a hop, one of them the vector unit's.)
                 unsigned mark, t;
                 int pos;
+                uint64_t chain;
                 asm volatile(
                     "s_mov_b32 %[pos], 0\n\t"
-                    "v_mov_b32 %[mark], 0\n"
+                    "s_mov_b64 %[chain], 0\n"
                     "1:\n\t"
                     "v_readlane_b32 %[t], %[NB], %[pos]\n\t"
-                    "v_cmp_eq_u32 vcc, %[pos], %[lane]\n\t"
-                    "v_cndmask_b32 %[mark], %[mark], %[kind], vcc\n\t"
+                    "s_bitset1_b64 %[chain], %[pos]\n\t"
                     "s_add_i32 %[pos], %[pos], %[t]\n\t"
                     "s_cmp_lt_u32 %[pos], 64\n\t"
                     "s_cbranch_scc1 1b\n\t"
-                    : [pos] "=&s"(pos), [mark] "=&v"(mark), [t] "=&s"(t)
-                    : [NB] "v"(NB), [lane] "v"(lane), [kind] "v"(kind)
-                    : "vcc", "scc");
+                    "v_cndmask_b32 %[mark], 0, %[kind], %[chain]\n\t"
+                    : [pos] "=&s"(pos), [mark] "=&v"(mark), [t] "=&s"(t), [chain] "=&s"(chain)
+                    : [NB] "v"(NB), [kind] "v"(kind)
+                    : "scc");
                 PROF(2, mark);  // the chain
                 pos = UNI(pos);
                 if ((unsigned)UNI(t) == 64u) pos -= 64;  // stopped in front of a lane, not beyond the window

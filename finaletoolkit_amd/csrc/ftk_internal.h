@@ -118,4 +118,6 @@ struct ftk_ctx {
     hipEvent_t a_kernel_done[2] = {nullptr, nullptr}, a_copy_done[2] = {nullptr, nullptr};
     bool a_pending[2] = {false, false};
     int a_next = 0;
+    int a_token[2] = {-1, -1};  // the token whose result sits in each buffer; tokens count up, token & 1 is its buffer
+    int a_issued = 0;           // tokens handed out so far
 };

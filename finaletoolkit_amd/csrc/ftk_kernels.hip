@@ -1422,36 +1422,47 @@ template <bool NARROW, int TT>
 __device__ __forceinline__ void cleave_tile(const ContigView& cv, const CleaveParams& p, long long iv_start, long long iv_stop,
                                             long long t0, int len_t, int lo, int hi, double* __restrict__ dst, int* dd,
                                             int* en, int& pre_s, int (*wtot)[4]) {
-    constexpr int NP = TT / 1024, NW = NARROW ? TT / 2 : TT;  // 32-bit words per array
+    // (the caller has cleared dd / en / pre_s and passed a barrier)
+    constexpr int NP = TT / 1024;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 2) pre_s = 0;
-    {
-        const int4 z = make_int4(0, 0, 0, 0);
-        int4* a4 = reinterpret_cast<int4*>(dd);
-        int4* b4 = reinterpret_cast<int4*>(en);
-#pragma unroll
-        for (int j = 0; j < NW / 4 / 256; ++j) { a4[j * 256 + tid] = z; b4[j * 256 + tid] = z; }
-    }
-    __syncthreads();
     auto add = [&](int* arr, int idx, int v) {
         if (NARROW) atomicAdd(&arr[idx >> 1], (idx & 1) ? v * 65536 : v);
         else atomicAdd(&arr[idx], v);
     };
-    for (int i = lo + tid; i < hi; i += 256) {
-        const int fs = cv.start[i], fe = cv.end[i], q = cv.mapq[i];
+    auto apply = [&](int i, int fs, int fe, int q, int fwd) {
         const int len = fe - fs;
-        if (q < p.mapq_min || len < p.min_len || len > p.max_len) continue;
-        if (!((long long)fe > iv_start && (long long)fs < iv_stop)) continue;  // "any" policy (= tabix overlap)
+        if (q < p.mapq_min || len < p.min_len || len > p.max_len) return;
+        if (!((long long)fe > iv_start && (long long)fs < iv_stop)) return;  // "any" policy (= tabix overlap)
         if (cv.r1_start && (!cv.r1_inside || (long long)fs < iv_start || (long long)fe > iv_stop) &&
-            !((long long)cv.r1_start[i] < iv_stop && (long long)cv.r1_end[i] > iv_start)) continue;
+            !((long long)cv.r1_start[i] < iv_stop && (long long)cv.r1_end[i] > iv_start)) return;
         const long long a = (long long)fs - t0, b = (long long)fe - t0;
         if (b > 0 && a < len_t) {  // covers [max(a,0), min(b,len_t))
             if (a <= 0) atomicAdd(&pre_s, 1); else add(dd, (int)a, 1);
             if (b < len_t) add(dd, (int)b, -1);
         }
-        const long long e = cv.strand[i] ? a : b;
+        const long long e = fwd ? a : b;
         if (e >= 0 && e < len_t) add(en, (int)e, 1);
+    };
+    // the tile's candidates, four columns each, requested in ONE batch (round 5: until then a thread loaded a fragment's
+    // start / end / mapq, filtered, and only then asked for its strand - two dependent trips to HBM per fragment and
+    // loop turn, and the block's life is a chain of such trips: 0.53 -> see DESIGN 3.4)
+    constexpr int PF = 4;
+    int ps[PF], pe[PF], pq[PF], pw[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        const int i = lo + tid + 256 * k;
+        const bool ok = i < hi;
+        ps[k] = ok ? cv.start[i] : 0;
+        pe[k] = ok ? cv.end[i] : 0;
+        pq[k] = ok ? (int)cv.mapq[i] : -1;
+        pw[k] = ok ? (int)cv.strand[i] : 0;
     }
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        const int i = lo + tid + 256 * k;
+        if (i < hi) apply(i, ps[k], pe[k], pq[k], pw[k]);
+    }
+    for (int i = lo + PF * 256 + tid; i < hi; i += 256) apply(i, cv.start[i], cv.end[i], cv.mapq[i], cv.strand[i]);
     __syncthreads();
     // element pair (2i, 2i + 1) of an array, whichever way it is stored
     auto pair_at = [&](const int* arr, int i) -> int2 {
@@ -1497,8 +1508,12 @@ __device__ __forceinline__ void cleave_tile(const ContigView& cv, const CleavePa
             const int g0 = carry + (h ? exb[j] : exa[j]) + v.x, g1 = g0 + v.y;
             const int i0 = j * 1024 + wv * 256 + h * 128 + 2 * lane;
             // numpy: ends / depth * 100 in float64, 0 where depth == 0 (frag/_cleavage_profile.py:208-210)
+#ifdef FTK_CLEAVE_NODIV  // (experiment: what the kernel would take without its divisions - wrong numbers)
+            const double o0 = (double)(ends.x * g0), o1 = (double)(ends.y * g1);
+#else
             const double o0 = g0 ? (double)ends.x / (double)g0 * 100.0 : 0.0;
             const double o1 = g1 ? (double)ends.y / (double)g1 * 100.0 : 0.0;
+#endif
             if (i0 + 1 < len_t) {
                 if (vec_ok) {
                     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -1543,7 +1558,17 @@ __global__ __launch_bounds__(256) void cleavage_kernel(ContigView cv, CleavePara
     }
     const long long t0 = iv_start + k * T;
     const int len_t = (int)(min(t0 + (long long)T, iv_stop) - t0);
+    auto clear = [&]() {  // both arrays (16 KB whichever layout) and the carry word
+        const int4 z = make_int4(0, 0, 0, 0);
+        int4* a4 = reinterpret_cast<int4*>(dd);
+        int4* b4 = reinterpret_cast<int4*>(en);
+#pragma unroll
+        for (int j = 0; j < H / 4 / 256; ++j) { a4[j * 256 + tid] = z; b4[j * 256 + tid] = z; }
+        if (tid == 2) pre_s = 0;
+    };
+    // the candidates' bounds (two index reads) and the clearing of the arrays share ONE barrier
     if (tid < 2) rng_s[tid] = cleave_bound(cv, tid == 0 ? t0 - (long long)p.lmax : t0 + len_t, tid);
+    clear();
     __syncthreads();
     const int lo = rng_s[0], hi = rng_s[1];
     double* dst = out + out_off + k * T;
@@ -1557,6 +1582,7 @@ __global__ __launch_bounds__(256) void cleavage_kernel(ContigView cv, CleavePara
         if (len_h <= 0) break;
         __syncthreads();  // (the arrays and rng_s of the first half are done with)
         if (tid < 2) rng_s[tid] = cleave_bound(cv, tid == 0 ? th - (long long)p.lmax : th + len_h, tid);
+        clear();
         __syncthreads();
         cleave_tile<false, H>(cv, p, iv_start, iv_stop, th, len_h, rng_s[0], rng_s[1], dst + (long long)half * H, dd, en, pre_s,
                               wtot);

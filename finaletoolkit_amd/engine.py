@@ -496,9 +496,11 @@ class Engine:
                                            int(window_size), int(min_length), int(max_length), int(quality_threshold),
                                            L.ptr(res), C.byref(tok)))
         if tok.value >= 0:
-            # a token is the copy slot (0 / 1) and is reused every second call; the library waited for the
-            # slot's previous copy before reusing it, so the array registered under it before is complete
+            # tokens count up; two results can be in flight (token & 1 is the library's buffer): an array registered
+            # under an older token is complete - the library waited for that buffer's copy before reusing it
             self._pending[int(tok.value)] = res
+            for old in [t for t in self._pending if t < tok.value - 1]:
+                del self._pending[old]
         return res, int(tok.value)
 
     def result_wait(self, token: int):

@@ -339,9 +339,10 @@ int ftk_wps_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start, cons
  * the scores into wps_out_host (the ctx's copy stream, behind the kernel) are enqueued; the next calls on the ctx
  * - loading and scoring the next contig - overlap the copy.  *token_out identifies the result: the array is
  * valid after ftk_result_wait(ctx, token) (or ftk_ctx_sync).  Two results can be in flight; a third call
- * waits for the older one's copy.  A token is the index of the copy slot (0 or 1) and is REUSED every second
- * call: wait for a result before issuing the call after next, or its token names the newer result in that slot.  wps_out_host should come from ftk_host_alloc (a pageable array is copied
- * through a staging buffer and gains nothing).  A degenerate interval gives token -1 (nothing to wait for). */
+ * waits for the older one's copy.  Tokens count up and are never reused: waiting for an old token whose buffer has
+ * been taken over by a later call returns at once (that call waited for the old copy before it reused the buffer); a
+ * token that was never handed out is FTK_ERR_INVALID.  wps_out_host should come from ftk_host_alloc (a pageable array
+ * is copied through a staging buffer and gains nothing).  A degenerate interval gives token -1 (nothing to wait for). */
 int ftk_wps_async(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int64_t chrom_size, int32_t window_size,
                   int32_t min_len, int32_t max_len, int32_t mapq_min, int64_t* wps_out_host, int* token_out);
 int ftk_result_wait(ftk_ctx* ctx, int token);

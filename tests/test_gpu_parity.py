@@ -205,9 +205,10 @@ def test_wps_async_results_equal_the_synchronous_call(engine, data):
     spans = [(0, 1_200_000), (900_000, 2_950_000), (5, 77), (1_000_000, 2_300_000), (2_990_000, 3_000_000)]
     want = [engine.wps("synA", a, b, CONTIG_LEN, 120, 120, 180, 30) for a, b in spans]
     got = [engine.wps_async("synA", a, b, CONTIG_LEN, 120, 120, 180, 30) for a, b in spans]  # never more than 2 pending
+    toks = [t for _, t in got]
+    assert toks == list(range(toks[0], toks[0] + len(spans)))  # tokens count up: none names two results
     for (arr, tok), w in zip(got, want):
-        assert tok in (0, 1)
-        engine.result_wait(tok)
+        engine.result_wait(tok)  # (an old token whose buffer a later call took over: complete, returns at once)
         assert np.array_equal(arr, w)
     arr, tok = engine.wps_async("synA", 500, 500, CONTIG_LEN)
     assert tok == -1 and len(arr) == 0
@@ -219,7 +220,7 @@ def test_wps_async_results_equal_the_synchronous_call(engine, data):
     whole = engine.wps("synA", 0, 3_000_000, CONTIG_LEN, 120, 120, 180, 30)
     assert np.array_equal(np.concatenate([a1, a2]), whole) and int(cov[0]) > 0
     with pytest.raises(Exception):
-        engine.result_wait(7)
+        engine.result_wait(toks[-1] + 1000)  # never handed out
 
 
 def test_page_locked_result_limit_falls_back_to_ordinary_memory():

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """BASELINE config 5 at full contig size on one GPU: a chr1-sized 60x coordinate-sorted paired-end BAM (49.9 M pairs,
 99.7 M records, > 4 GiB on disk) written in position windows (bounded memory), streamed through the product's path
 (source.stream_source: BGZF inflate and record parse on the device, sort by start on the device) and scored:
@@ -27,72 +26,24 @@ path = os.path.join(tmp, "big.bam")
 contig = "big"
 
 t0 = time.time()
-s, e, q, st = synth.synth_contig(size, depth, 4242)
-e = np.maximum(e, s + READ).astype(np.int32)
-n = len(s)
-fwd = st == 1
-ln = (e - s).astype(np.int64)
-r1_pos = np.where(fwd, s, e - READ).astype(np.int64)
-r2_pos = np.where(fwd, e - READ, s).astype(np.int64)
-rec = np.dtype([("block_size", "<i4"), ("ref", "<i4"), ("pos", "<i4"), ("l_name", "u1"), ("mapq", "u1"), ("bin", "<u2"),
-                ("n_cigar", "<u2"), ("flag", "<u2"), ("l_seq", "<i4"), ("next_ref", "<i4"), ("next_pos", "<i4"),
-                ("tlen", "<i4"), ("name", "S9"), ("cigar", "<u4"), ("seq", "u1", (READ // 2,)), ("qual", "u1", (READ,))])
-text = b"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:%s\tLN:%d\n" % (contig.encode(), size)
-head = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 1)
-head += struct.pack("<i", len(contig) + 1) + contig.encode() + b"\0" + struct.pack("<i", size)
-offs = writers.bgzf_write(path, head, level=1, write_eof=False)
-first_off = None
-lut = np.repeat(np.array([2, 11, 25, 37], np.uint8), [8, 18, 51, 179])
-STEP = 8_000_000
-rng = np.random.default_rng(99)
-n_records = 0
-last = None
-for a in range(0, size, STEP):
-    b = min(a + STEP, size)
-    lo, hi = int(np.searchsorted(s, a - 1000)), int(np.searchsorted(s, b))
-    idx = np.arange(lo, hi)
-    m = len(idx)
-    blk = np.zeros(2 * m, rec)
-    blk["block_size"] = rec.itemsize - 4
-    blk["l_name"], blk["n_cigar"], blk["l_seq"], blk["cigar"] = 9, 1, READ, READ << 4
-    blk["pos"][:m], blk["pos"][m:] = r1_pos[idx], r2_pos[idx]
-    blk["next_pos"][:m], blk["next_pos"][m:] = r2_pos[idx], r1_pos[idx]
-    blk["mapq"][:m] = blk["mapq"][m:] = q[idx]
-    blk["tlen"][:m], blk["tlen"][m:] = np.where(fwd[idx], ln[idx], -ln[idx]), np.where(fwd[idx], -ln[idx], ln[idx])
-    blk["flag"][:m], blk["flag"][m:] = np.where(fwd[idx], 99, 83), np.where(fwd[idx], 147, 163)
-    digits = np.zeros((m, 9), np.uint8)
-    digits[:, :8] = idx[:, None] // 10 ** np.arange(7, -1, -1, dtype=np.int64)[None, :] % 10 + 48
-    blk["name"][:m] = blk["name"][m:] = digits.view("S9")[:, 0]
-    keep = (blk["pos"] >= a) & (blk["pos"] < b)
-    blk = blk[keep]
-    blk["seq"] = rng.integers(0, 256, (len(blk), READ // 2), dtype=np.uint8)
-    blk["qual"] = lut[rng.integers(0, 256, (len(blk), READ), dtype=np.uint8)]
-    blk = blk[np.argsort(blk["pos"], kind="stable")]
-    n_records += len(blk)
-    o2 = writers.bgzf_write(path, blk.tobytes(), level=1, append=True, write_eof=b >= size)
-    if first_off is None:
-        first_off = int(o2[0])
-    last = int(o2[-1])
-    del blk, digits, keep
-bgzf.write_index(path + ".bai", True, [(contig, first_off << 16, last << 16)])
+exp = synth.write_paired_bam_native(path, [(contig, size)], depth, 4242, read_len=READ)[contig]
+s, e, q, st, r1_pos, n = exp["s"], exp["e"], exp["q"], exp["st"], exp["r1s"].astype(np.int64), exp["n"]
+n_records = 2 * n
 res = {"contig_bp": size, "depth": depth, "pairs": n, "records": n_records, "file_GB": round(os.path.getsize(path) / 1e9, 3),
        "larger_than_4GiB": os.path.getsize(path) > (1 << 32), "write_s": round(time.time() - t0, 1),
-       "threads": source.usable_cores(), "reps": []}
-assert n_records == 2 * n
+       "threads": source.usable_cores(), "host_share": os.environ.get("FTK_BAM_HOST_SHARE", "default"), "reps": []}
 
 from oracle import oracle as O  # noqa: E402  (checker only)
 ws, we = synth.tiling_windows(size, 100_000)
-for rep in range(2):
+for rep in range(int(os.environ.get('FTK_BIG_REPS', '3'))):
     source.close_all()
     eng = source.get_engine()
     t0 = time.perf_counter()
     for src, c in source.stream_source(path):
         t1 = time.perf_counter()
         key = src.key(c)
-        r = eng.window_features(key, ws, we, 30, hist=(0, 1001), delfi=dict(quality_threshold=30))
-        t2 = time.perf_counter()
-        w = eng.wps(key, 0, size, size)
-        t3 = time.perf_counter()
+        r, w = eng.all_features_wps(key, ws, we, size)  # ONE launch
+        t2 = t3 = time.perf_counter()
     total = t3 - t0
     st_ms = src.decode_stage_ms
     res["reps"].append({"total_s": round(total, 4), "decode_until_resident_s": round(t1 - t0, 4), "features_s": round(t2 - t1, 4),
