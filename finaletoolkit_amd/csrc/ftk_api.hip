@@ -1723,9 +1723,34 @@ int ftk_cleavage_intervals(ftk_ctx* ctx, int contig_id, const int64_t* iv_start,
 
 int ftk_cleavage(ftk_ctx* ctx, int contig_id, int64_t start, int64_t stop, int32_t min_len, int32_t max_len,
                  int32_t mapq_min, double* prop_out) {
-    if (ctx && stop <= start) return FTK_OK;
-    const int64_t off = 0;
-    return ftk_cleavage_intervals(ctx, contig_id, &start, &stop, 1, &off, min_len, max_len, mapq_min, prop_out);
+    if (!ctx) return fail(nullptr, FTK_ERR_INVALID, "ctx is NULL");
+    if (stop <= start) return FTK_OK;
+    ContigData* c;
+    int rc = get_contig(ctx, contig_id, &c);
+    if (rc) return rc;
+    if (start < 0 || stop > (1LL << 31)) return fail(ctx, FTK_ERR_INVALID, "interval out of range");
+    if (!prop_out) return fail(ctx, FTK_ERR_INVALID, "NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // ONE interval: its tiles are numbered by the grid (no descriptor arrays to build and upload - for a whole contig
+    // 60 000 tiles, half a megabyte of pageable staging and a stream synchronisation per call)
+    CleaveParams p{};
+    p.start = start;
+    p.stop = stop;
+    p.min_len = min_len < 0 ? INT32_MIN : min_len;
+    p.max_len = max_len < 0 ? INT32_MAX : max_len;
+    p.mapq_min = mapq_min;
+    p.lmax = std::max(0, max_len < 0 ? c->max_len : std::min(max_len, c->max_len));
+    const int64_t n_pos = stop - start, n_tiles = (n_pos + kWpsTile - 1) / kWpsTile;
+    const bool out_dev = is_device_ptr(prop_out);
+    if (!out_dev && (rc = reserve_scratch(ctx, align_up((size_t)n_pos * 8)))) return rc;
+    double* d_out = out_dev ? prop_out : (double*)ctx->scratch;
+    launch_cleavage(ctx->stream, c->v, p, n_tiles, nullptr, nullptr, nullptr, nullptr, nullptr, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    if (!out_dev) {
+        HIPCHK(ctx, hipMemcpyAsync(prop_out, d_out, (size_t)n_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FTK_OK;
 }
 
 int ftk_wps_adjust(ftk_ctx* ctx, const double* scores, const int64_t* offsets, int64_t n_iv, int32_t median_window,

@@ -1223,7 +1223,16 @@ __device__ __forceinline__ void wps_block(const unsigned block_id, const unsigne
             for (int b = tid; b <= F.n_bins; b += 256) fhist[b] = 0;
         if (tid < 4) fcnt[tid] = 0;
     }
+    // The first tile's candidate bounds come from two threads (vector loads) through LDS, behind the barrier the clearing
+    // needs anyway.  Tried in round 5 (-DFTK_WPS_BOUNDS_SCALAR): every thread reading the two index entries itself at
+    // block-uniform addresses - scalar loads, no hand-over - 4.57-4.60 -> 4.73-4.81 ms per whole-genome step (0.846 ->
+    // 0.813 of peak): four waves' scalar loads per tile through the scalar cache, and their s_waitcnt also waits for the
+    // LDS writes of the clearing.
+#ifdef FTK_WPS_BOUNDS_SCALAR
+    int lo = cand_bound(cur, 0), hi = cand_bound(cur, 1);
+#else
     if (tid < 2) rng_s[tid] = cand_bound(cur, tid);
+#endif
     if (tid == 2) { pre_s[0] = 0; pre_s[1] = 0; }
     {
         const int4 z = make_int4(0, 0, 0, 0);
@@ -1232,7 +1241,9 @@ __device__ __forceinline__ void wps_block(const unsigned block_id, const unsigne
         for (int j = 0; j < T / 4 / 256; ++j) d4[j * 256 + tid] = z;
     }
     __syncthreads();
+#ifndef FTK_WPS_BOUNDS_SCALAR
     int lo = rng_s[0], hi = rng_s[1];
+#endif
     int pfs[PF], pfe[PF], pfq[PF];
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
@@ -1460,7 +1471,11 @@ __device__ __forceinline__ void cleave_tile(const ContigView& cv, const CleavePa
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
         const int i = lo + tid + 256 * k;
+#ifdef FTK_CLEAVE_NOFRAG  // (experiment: the loads stay, the LDS atomics go - wrong numbers)
+        if (i < hi && ps[k] == -7) apply(i, ps[k], pe[k], pq[k], pw[k]);
+#else
         if (i < hi) apply(i, ps[k], pe[k], pq[k], pw[k]);
+#endif
     }
     for (int i = lo + PF * 256 + tid; i < hi; i += 256) apply(i, cv.start[i], cv.end[i], cv.mapq[i], cv.strand[i]);
     __syncthreads();
@@ -1514,6 +1529,9 @@ __device__ __forceinline__ void cleave_tile(const ContigView& cv, const CleavePa
             const double o0 = g0 ? (double)ends.x / (double)g0 * 100.0 : 0.0;
             const double o1 = g1 ? (double)ends.y / (double)g1 * 100.0 : 0.0;
 #endif
+#ifdef FTK_CLEAVE_NOSTORE  // (experiment: everything but the stores - a result that cannot occur keeps the arithmetic alive)
+            if (o0 != -1.0) continue;
+#endif
             if (i0 + 1 < len_t) {
                 if (vec_ok) {
                     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -1546,7 +1564,6 @@ __global__ __launch_bounds__(256) void cleavage_kernel(ContigView cv, CleavePara
     __shared__ __attribute__((aligned(16))) int dd[H];
     __shared__ __attribute__((aligned(16))) int en[H];
     __shared__ int pre_s;
-    __shared__ int rng_s[2];
     __shared__ int wtot[T / 1024][4];
     const int tid = threadIdx.x;
     long long iv_start, iv_stop, out_off, k;
@@ -1566,11 +1583,11 @@ __global__ __launch_bounds__(256) void cleavage_kernel(ContigView cv, CleavePara
         for (int j = 0; j < H / 4 / 256; ++j) { a4[j * 256 + tid] = z; b4[j * 256 + tid] = z; }
         if (tid == 2) pre_s = 0;
     };
-    // the candidates' bounds (two index reads) and the clearing of the arrays share ONE barrier
-    if (tid < 2) rng_s[tid] = cleave_bound(cv, tid == 0 ? t0 - (long long)p.lmax : t0 + len_t, tid);
+    // The candidates' bounds: two reads of the position index at block-uniform addresses, taken by every thread (scalar
+    // loads, under way while the arrays are cleared; no hand-over through LDS, one barrier instead of two).
+    const int lo = cleave_bound(cv, t0 - (long long)p.lmax, 0), hi = cleave_bound(cv, t0 + len_t, 1);
     clear();
     __syncthreads();
-    const int lo = rng_s[0], hi = rng_s[1];
     double* dst = out + out_off + k * T;
     if (hi - lo < 32768) {
         cleave_tile<true, T>(cv, p, iv_start, iv_stop, t0, len_t, lo, hi, dst, dd, en, pre_s, wtot);
@@ -1580,12 +1597,11 @@ __global__ __launch_bounds__(256) void cleavage_kernel(ContigView cv, CleavePara
         const long long th = t0 + (long long)half * H;
         const int len_h = min(len_t - half * H, H);
         if (len_h <= 0) break;
-        __syncthreads();  // (the arrays and rng_s of the first half are done with)
-        if (tid < 2) rng_s[tid] = cleave_bound(cv, tid == 0 ? th - (long long)p.lmax : th + len_h, tid);
+        __syncthreads();  // (the arrays of the first half are done with)
+        const int lo_h = cleave_bound(cv, th - (long long)p.lmax, 0), hi_h = cleave_bound(cv, th + len_h, 1);
         clear();
         __syncthreads();
-        cleave_tile<false, H>(cv, p, iv_start, iv_stop, th, len_h, rng_s[0], rng_s[1], dst + (long long)half * H, dd, en, pre_s,
-                              wtot);
+        cleave_tile<false, H>(cv, p, iv_start, iv_stop, th, len_h, lo_h, hi_h, dst + (long long)half * H, dd, en, pre_s, wtot);
     }
 }
 

@@ -539,8 +539,17 @@ class Engine:
                 L.LEN_OPEN if max_length is None else int(max_length), int(quality_threshold), L.ptr(out)))
         return out, offs
 
-    def cleavage(self, name: str, start: int, stop: int, min_length=None, max_length=None, quality_threshold=30):
-        return self.cleavage_intervals(name, [start], [stop], min_length, max_length, quality_threshold)[0]
+    def cleavage(self, name: str, start: int, stop: int, min_length=None, max_length=None, quality_threshold=30, out=None):
+        """Cleavage proportion (percent) per base of ONE interval (``ftk_cleavage``: the tiles are numbered by the grid, no
+        descriptor arrays); ``out``: a float64 host array or device tensor / address of ``stop - start`` elements."""
+        n = max(int(stop) - int(start), 0)
+        res = self.result_array(n, np.float64) if out is None else out
+        if n:
+            self._check(self.lib.ftk_cleavage(self.ctx, self.contig_id(name), int(start), int(stop),
+                                              L.LEN_OPEN if min_length is None else max(int(min_length), 0),
+                                              L.LEN_OPEN if max_length is None else int(max_length), int(quality_threshold),
+                                              L.ptr(res)))
+        return res
 
     # -- WPS post-processing --------------------------------------------------------
     def wps_adjust(self, scores, offsets, median_window_size=1000, mean=False, edge_sub=None, savgol_window_size=21,

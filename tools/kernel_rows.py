@@ -72,9 +72,7 @@ def measure(torch, eng, which="all", reps=5, seed=1):
         rows = {}
         # cleavage profile of the whole contig into device memory
         cl = torch.empty(size, dtype=torch.float64, device=dev)
-        s0, s1, so = np.array([0], np.int64), np.array([size], np.int64), np.array([0], np.int64)
-        f = lambda: eng._check(eng.lib.ftk_cleavage_intervals(eng.ctx, eng.contig_id("kr_next"), L.ptr(s0), L.ptr(s1), 1,
-                                                              L.ptr(so), L.LEN_OPEN, L.LEN_OPEN, 20, L.ptr(cl)))
+        f = lambda: eng.cleavage("kr_next", 0, size, None, None, 20, out=cl)
         rows["cleavage_kernel"] = _row("cleavage_kernel", _time(eng, f, reps, flush), 10 * n + 8 * size,
                                        "10 B x fragments + 8 B x bases (float64 per base)")
         del cl
