@@ -24,6 +24,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "ftk_inflate.h"
 
@@ -309,14 +312,56 @@ __device__ unsigned long long g_block_ticks[2 * 65536];
 #else
 #define FTK_INFLATE_OCC
 #endif
-template <bool VEC>
+// ---- lane-parallel symbol decoding (round 5; template flag LANES, inflate_launch's lane_scratch) --------------------
+// The windows above spend their vector work on 64 bit offsets of which ~9 start a symbol, and the chain through those
+// starts is serial.  Here the lanes take DIFFERENT stretches of the input instead: a super-window is 64 stretches of
+// kLaneBits bits; lane l decodes the symbols of its stretch one after the other, all lanes in lock step - 64 symbols per
+// trip through the loop.  Only lane 0 knows where its first symbol starts; the others start at their stretch's first bit,
+// which is most likely the middle of a symbol, and rely on what prefix codes do: a decoder that starts anywhere falls
+// into step with the true symbol sequence after a few symbols.  So: (A) every lane decodes its stretch from its first
+// bit, noting which bit positions it took for symbol starts and writing its symbols as 32-bit tokens (literals or
+// length + distance) to a scratch region; (B) lane l's TRUE first symbol starts where lane l - 1's last one ends, so the
+// lanes pass their end positions to the right and every lane decodes again from its true start until it lands on a
+// position it has visited - from there on its tokens of (A) are the right ones - repeated while any end position
+// still moves (a lane that never falls into step inside its stretch moves its end and so its right neighbour's start);
+// (C) the valid tokens are laid end to end; (D) 64 tokens at a time, a prefix sum gives every token its place in the
+// output, literal tokens store their bytes, matches copy in stream order - what the windows do behind their chain.
+// A lane stops at anything the tables do not resolve in one look-up (end of block, a code longer than a table's root, a
+// bit pattern that is no code): the super-window ends in front of it and ONE window of the older kind takes it.
+constexpr int kLaneBits = 128;                    // bits of input per lane and super-window
+constexpr int kLaneTok = 64;                      // tokens a lane may write in (A); more ends its stretch early
+constexpr int kLaneCatch = 32;                    // ... and on its way into step in (B)
+constexpr int kLaneRounds = 6;                    // passes of (B) before the super-window is cut at the first unsettled lane
+constexpr int kLaneSlots = 8192;                  // scratch slots: as many as the chip can hold waves (256 CUs x 32)
+constexpr size_t kLaneSlotWords = 64 * kLaneTok + 64 * kLaneCatch + 64 * (kLaneTok + kLaneCatch);  // spec, catch-up, stream
+struct LaneScratch {
+    unsigned busy[kLaneSlots];
+    uint32_t words[1];  // kLaneSlots x kLaneSlotWords
+};
+
+template <bool VEC, bool LANES>
 __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const uint8_t* __restrict__ comp,
                                                           const InflateBlock* __restrict__ tab, int n_blocks,
-                                                          uint8_t* __restrict__ out, InflateStatus* __restrict__ status) {
+                                                          uint8_t* __restrict__ out, InflateStatus* __restrict__ status,
+                                                          LaneScratch* __restrict__ lane_scratch) {
     __shared__ WaveLds L;
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
     if (blk >= n_blocks) return;
+    uint32_t* lane_tok = nullptr;  // this wave's scratch slot (LANES)
+    int lane_slot = -1;
+    if (LANES) {
+        // a slot nobody holds: there are as many as the chip can hold waves, so one is free; probing starts at a place
+        // of the block's own
+        unsigned s0 = ((unsigned)blk * 2654435761u) >> 19;  // 13 bits
+        if (lane == 0) {
+            for (;; s0 = (s0 + 1u) & (unsigned)(kLaneSlots - 1))
+                if (atomicCAS(&lane_scratch->busy[s0], 0u, 1u) == 0u) break;
+        }
+        lane_slot = UNI(s0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        lane_tok = lane_scratch->words + (size_t)lane_slot * kLaneSlotWords;
+    }
 #ifdef FTK_INFLATE_TIMING
     if (lane == 0 && blk < 65536) g_block_ticks[2 * blk] = wall_clock64();
 #endif
@@ -456,9 +501,243 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
 #if FTK_INFLATE_WINDOWED
         uint32_t bp = b.bitpos();  // the windows work from the absolute bit position; `b` follows when the serial path needs it
         bool b_moved = false;
+        bool lanes_rest = false;   // LANES: the symbol at bp stopped a super-window - one window of the older kind takes it
 #endif
         for (;;) {
             PROF(7, lane_dep);  // (whatever ran since the last mark: the serial path, the loop's bookkeeping)
+#if FTK_INFLATE_WINDOWED
+            if (LANES && !lanes_rest) {
+                if (b_moved) {
+                    bp = b.bitpos();
+                    b_moved = false;
+                }
+                // ---- (A) every lane decodes its own stretch of kLaneBits bits from the stretch's first bit ----
+                const uint32_t in_bits = b.end_word * 32u;
+                // one symbol at bit position `at` of this lane: bits it takes (0: the tables do not resolve it), its token
+                auto decode_at = [&](uint32_t at, unsigned& nb, unsigned& tok) {
+                    const uint32_t wi = at >> 5;
+                    const unsigned c_lo = wi < b.end_word ? b.w[wi] : 0u;
+                    const unsigned c_mid = wi + 1u < b.end_word ? b.w[wi + 1u] : 0u;
+                    const unsigned c_hi = wi + 2u < b.end_word ? b.w[wi + 2u] : 0u;
+                    const unsigned sh = at & 31u;
+                    const unsigned w0 = __builtin_amdgcn_alignbit(c_mid, c_lo, sh), w1 = __builtin_amdgcn_alignbit(c_hi, c_mid, sh);
+                    const unsigned E = L.pair[w0 & ((1u << kLitRoot) - 1u)];
+                    const unsigned k1 = (E >> 5) & 3u, lb = E & 31u, lbase = (E >> 8) & 511u, xb = (E >> 20) & 7u;
+                    const unsigned wl = __builtin_amdgcn_alignbit(w1, w0, lb);
+                    const unsigned mlen = lbase + (wl & ((1u << xb) - 1u));
+                    const unsigned wd = wl >> xb;
+                    const unsigned D = L.dist[wd & ((1u << kDistRoot) - 1u)];
+                    const unsigned dbits = D & 15u, dxb = (D >> 4) & 15u, dbase = D >> 8;
+                    const unsigned mdist = dbase + ((wd >> dbits) & ((1u << dxb) - 1u));
+                    const bool is_match = k1 == 0u && lbase != 0u && lbase != 511u && D != 0u && dbase != 0x7fffffu;
+                    nb = is_match ? lb + xb + dbits + dxb : (k1 ? lb : 0u);
+                    // token: kind (1 / 2 literals, 3 match) | literal bytes at bits 8 and 16, or length << 2 | distance << 11
+                    tok = is_match ? (3u | (mlen << 2) | (mdist << 11)) : (k1 | (((E >> 8) & 0xffu) << 8) | (((E >> 20) & 0xffu) << 16));
+                };
+                const uint32_t p0 = bp + (uint32_t)lane * (uint32_t)kLaneBits, sub_end = p0 + (uint32_t)kLaneBits;
+                uint32_t* spec = lane_tok + (size_t)lane * kLaneTok;
+                uint32_t* catchup = lane_tok + 64 * kLaneTok + (size_t)lane * kLaneCatch;
+                uint32_t* stream = lane_tok + 64 * kLaneTok + 64 * kLaneCatch;
+                unsigned vis[kLaneBits / 32];
+#pragma unroll
+                for (int k = 0; k < kLaneBits / 32; ++k) vis[k] = 0u;
+                auto vis_set = [&](unsigned rel) {
+#pragma unroll
+                    for (int k = 0; k < kLaneBits / 32; ++k)
+                        if ((int)(rel >> 5) == k) vis[k] |= 1u << (rel & 31u);
+                };
+                auto vis_get = [&](unsigned rel) -> bool {
+                    unsigned w = 0u;
+#pragma unroll
+                    for (int k = 0; k < kLaneBits / 32; ++k)
+                        if ((int)(rel >> 5) == k) w = vis[k];
+                    return (w >> (rel & 31u)) & 1u;
+                };
+                auto vis_below = [&](unsigned rel) -> int {  // visited positions in front of `rel`
+                    int n = 0;
+#pragma unroll
+                    for (int k = 0; k < kLaneBits / 32; ++k) {
+                        const unsigned m = (int)(rel >> 5) > k ? 0xffffffffu : ((int)(rel >> 5) == k ? ((1u << (rel & 31u)) - 1u) : 0u);
+                        n += __popc(vis[k] & m);
+                    }
+                    return n;
+                };
+                uint32_t pos = p0;
+                int ntok = 0;
+                bool stopped = false;               // the chain ended at something a window of the older kind must take
+                bool active = p0 < in_bits;
+                if (!active) stopped = true;        // (a lane behind the payload: nothing of it counts)
+                while (__ballot(active)) {
+                    if (active) {
+                        unsigned nb, tok;
+                        decode_at(pos, nb, tok);
+                        if (nb == 0u || ntok == kLaneTok) {
+                            stopped = true;
+                            active = false;
+                        } else {
+                            vis_set(pos - p0);
+                            spec[ntok++] = tok;
+                            pos += nb;
+                            active = pos < sub_end;
+                        }
+                    }
+                }
+                // ---- (B) true starts: lane l's first symbol starts where lane l - 1's chain ends ----
+                const uint32_t spec_end = pos;
+                const bool spec_stop = stopped;
+                uint32_t my_end = spec_end, cur_start = p0;
+                bool my_stop = spec_stop;
+                int first_valid = 0, ncatch = 0;    // valid tokens: catchup[0, ncatch) then spec[first_valid, ntok)
+                uint64_t unsettled = 0;
+                for (int round = 0; round < kLaneRounds; ++round) {
+                    const uint32_t prev_end = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)my_end, 0x138, 0xf, 0xf, false);  // wave_shr:1
+                    const uint32_t c = lane == 0 ? bp : prev_end;
+                    const uint64_t stops = __ballot(my_stop);
+                    const bool behind_stop = (stops & ((1ull << lane) - 1ull)) != 0ull;  // a lane in front has stopped: nothing behind it counts
+                    bool need = lane > 0 && !behind_stop && c != cur_start;
+                    unsettled = __ballot(need);
+                    if (!unsettled) break;
+                    uint32_t q = c;
+                    int nc = 0;
+                    bool joined = false, cstop = false, go = need;
+                    while (__ballot(go)) {
+                        if (go) {
+                            const uint32_t rel = q - p0;  // (c >= p0: the lane in front ran to the end of its stretch or beyond)
+                            if (rel < (uint32_t)kLaneBits && vis_get(rel)) {
+                                joined = true;
+                                go = false;
+                            } else if (q >= sub_end) {
+                                go = false;
+                            } else {
+                                unsigned nb, tok;
+                                decode_at(q, nb, tok);
+                                if (nb == 0u || nc == kLaneCatch) {
+                                    cstop = true;
+                                    go = false;
+                                } else {
+                                    catchup[nc++] = tok;
+                                    q += nb;
+                                }
+                            }
+                        }
+                    }
+                    if (need) {
+                        cur_start = c;
+                        ncatch = nc;
+                        if (joined) {
+                            first_valid = vis_below(q - p0);
+                            my_end = spec_end;
+                            my_stop = spec_stop;
+                        } else {
+                            first_valid = ntok;
+                            my_end = q;
+                            my_stop = cstop;
+                        }
+                    }
+                }
+                // lanes that count: in front of (and including) the first one that stopped, in front of the first one whose
+                // start was still moving when the rounds ran out
+                {
+                    const uint32_t prev_end = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)my_end, 0x138, 0xf, 0xf, false);
+                    const uint32_t c = lane == 0 ? bp : prev_end;
+                    unsettled = __ballot(lane > 0 && c != cur_start);
+                }
+                const uint64_t stops = __ballot(my_stop);
+                int n_lanes = 64;
+                if (stops) n_lanes = min(n_lanes, __ffsll((unsigned long long)stops));          // the stopped lane itself counts
+                if (unsettled) n_lanes = min(n_lanes, __ffsll((unsigned long long)unsettled) - 1);
+                if (n_lanes >= 1) {
+                    // ---- (C) the valid tokens end to end ----
+                    const int nvalid = lane < n_lanes ? ncatch + (ntok - first_valid) : 0;
+                    const int incl = wave_incl_scan(nvalid);
+                    const int n_tokens = __builtin_amdgcn_readlane(incl, 63);
+                    int at = incl - nvalid;
+                    if (lane < n_lanes) {
+                        for (int k = 0; k < ncatch; ++k) stream[at++] = catchup[k];
+                        for (int k = first_valid; k < ntok; ++k) stream[at++] = spec[k];
+                    }
+                    const uint32_t new_bp = (uint32_t)__builtin_amdgcn_readlane((int)my_end, n_lanes - 1);
+                    const bool end_stop = ((stops >> (n_lanes - 1)) & 1ull) != 0ull;
+                    // (the stream is written by some lanes and read by others: the stores out to L2, the loads from there)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    // ---- (D) 64 tokens at a time: places from a prefix sum, literals stored, matches copied in order ----
+                    bool fail_d = false;
+                    for (int base = 0; base < n_tokens && !fail_d;) {
+                        const unsigned tok = base + lane < n_tokens
+                                                 ? __hip_atomic_load(&stream[base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                 : 0u;
+                        unsigned mark = tok & 3u;
+                        const unsigned mlen = (tok >> 2) & 511u, mdist = tok >> 11;
+                        const int olen = mark == 3u ? (int)mlen : (int)mark;
+                        const int inc = wave_incl_scan(olen);
+                        const uint32_t off = (uint32_t)(inc - olen);
+                        const uint32_t room = min((uint32_t)kWinCap, A_end - A);
+                        const uint64_t bad = __ballot(mark != 0u && ((uint32_t)inc > room || (mark == 3u && mdist > (A - out_off) + off)));
+                        uint32_t T;
+                        int took = min(64, n_tokens - base);
+                        if (bad) {
+                            const int cut = __ffsll((unsigned long long)bad) - 1;
+                            if (cut == 0) {
+                                // the first token does not fit: it reaches beyond the block's data or in front of it
+                                const bool far = __builtin_amdgcn_readlane((int)(mark == 3u && mdist > (A - out_off) + off), 0) != 0;
+                                err = far ? kInflateBadDistance : kInflateOverrun;
+                                fail_d = true;
+                                break;
+                            }
+                            if (lane >= cut) mark = 0u;
+                            took = cut;
+                            T = (uint32_t)__builtin_amdgcn_readlane((int)off, cut);
+                        } else {
+                            T = (uint32_t)__builtin_amdgcn_readlane(inc, 63);
+                        }
+                        if (mark == 1u || mark == 2u) {
+                            const uint32_t at2 = A + off;
+                            L.ring[at2 & kRingMask] = (uint8_t)(tok >> 8);
+                            if (mark == 2u) L.ring[(at2 + 1u) & kRingMask] = (uint8_t)(tok >> 16);
+                        }
+                        const uint32_t M0v = A + off;
+                        uint64_t mm = __ballot(mark == 3u);
+                        while (mm) {  // the matches in stream order (each may read what the one before it wrote)
+                            const int l = __ffsll((unsigned long long)mm) - 1;
+                            mm &= mm - 1;
+                            const int len = __builtin_amdgcn_readlane((int)mlen, l), d = __builtin_amdgcn_readlane((int)mdist, l);
+                            const uint32_t M0 = (uint32_t)__builtin_amdgcn_readlane((int)M0v, l);
+                            if (d >= len && len <= 64 && d <= kFarDist) {
+                                if (lane < len) {
+                                    const uint32_t a = M0 + (uint32_t)lane;
+                                    L.ring[a & kRingMask] = L.ring[(a - (uint32_t)d) & kRingMask];
+                                }
+                            } else if (d <= kFarDist) {
+                                int done = 0, DD = d;
+                                while (done < len) {
+                                    const int n = min(min(len - done, DD), 64);
+                                    if (lane < n) {
+                                        const uint32_t a = M0 + (uint32_t)(done + lane);
+                                        L.ring[a & kRingMask] = L.ring[(a - (uint32_t)DD) & kRingMask];
+                                    }
+                                    done += n;
+                                    if (2 * DD <= done + d) DD *= 2;
+                                }
+                            } else {
+                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                                for (int o = lane; o < len; o += 64) {
+                                    const uint32_t a = M0 + (uint32_t)o;
+                                    L.ring[a & kRingMask] = out[a - (uint32_t)d];
+                                }
+                            }
+                        }
+                        advance(T);
+                        base += took;
+                    }
+                    if (fail_d) break;
+                    bp = new_bp;
+                    lanes_rest = end_stop;
+                    continue;
+                }
+                lanes_rest = true;  // not even lane 0's stretch went through: a window of the older kind
+            }
+            lanes_rest = false;
+#endif
 #if FTK_INFLATE_WINDOWED
             // ---- a window of symbols at once.  Every lane decodes, COMPLETELY and on the vector unit, the symbol that
             // would start at its bit offset: one or two literals, or a match with its extra bits and its distance (a
@@ -862,6 +1141,10 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
             status->reason = err;
         }
     }
+    if (LANES) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) atomicExch(&lane_scratch->busy[lane_slot], 0u);
+    }
 }
 
 // ---- CRC-32 of every block's data (the gzip trailer carries the expected value; the host compares) ----------
@@ -1011,16 +1294,41 @@ extern "C" int ftk_debug_inflate_ticks(unsigned long long* out, int n_blocks) {
 }
 #endif
 
+// Scratch of the lane-parallel symbol loop: kLaneSlots token regions and their busy words, one allocation per device,
+// made (and cleared) the first time a launch asks for it and kept for the process.
+static LaneScratch* lane_scratch_of_device() {
+    static std::mutex mu;
+    static std::map<int, LaneScratch*> have;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = have.find(dev);
+    if (it != have.end()) return it->second;
+    LaneScratch* p = nullptr;
+    const size_t bytes = sizeof(unsigned) * kLaneSlots + sizeof(uint32_t) * kLaneSlots * kLaneSlotWords + 256;
+    if (hipMalloc((void**)&p, bytes) != hipSuccess || hipMemset(p, 0, sizeof(unsigned) * kLaneSlots) != hipSuccess) {
+        (void)hipGetLastError();
+        p = nullptr;
+    }
+    have[dev] = p;
+    return p;
+}
+
 void inflate_launch(hipStream_t s, const uint8_t* d_comp, const InflateBlock* d_tab, int n_blocks, uint8_t* d_out,
                     InflateStatus* d_status, uint32_t* d_crc, bool vector_matches) {
     if (n_blocks <= 0) return;
 #ifdef FTK_INFLATE_VECMATCH
     vector_matches = FTK_INFLATE_VECMATCH != 0;
 #endif
-    if (vector_matches)
-        hipLaunchKernelGGL(bgzf_inflate_kernel<true>, dim3(n_blocks), dim3(64), 0, s, d_comp, d_tab, n_blocks, d_out, d_status);
+    // FTK_INFLATE_LANES=1: the lane-parallel symbol loop (read per launch: the tests hold both loops against zlib)
+    const char* le = getenv("FTK_INFLATE_LANES");
+    LaneScratch* ls = (le && atoi(le) != 0) ? lane_scratch_of_device() : nullptr;
+    if (ls)
+        hipLaunchKernelGGL((bgzf_inflate_kernel<false, true>), dim3(n_blocks), dim3(64), 0, s, d_comp, d_tab, n_blocks, d_out, d_status, ls);
+    else if (vector_matches)
+        hipLaunchKernelGGL((bgzf_inflate_kernel<true, false>), dim3(n_blocks), dim3(64), 0, s, d_comp, d_tab, n_blocks, d_out, d_status, ls);
     else
-        hipLaunchKernelGGL(bgzf_inflate_kernel<false>, dim3(n_blocks), dim3(64), 0, s, d_comp, d_tab, n_blocks, d_out, d_status);
+        hipLaunchKernelGGL((bgzf_inflate_kernel<false, false>), dim3(n_blocks), dim3(64), 0, s, d_comp, d_tab, n_blocks, d_out, d_status, ls);
     if (d_crc) {
         // (workgroups of four waves, a block per wave)
         const int groups = std::min((n_blocks + kCrcWaves - 1) / kCrcWaves, 1 << 20);

@@ -6,7 +6,7 @@ set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py"
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-kernel-rows"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > $OUT/bench_under_profiler.json 2> $OUT/stats.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end > /dev/null 2> $OUT/pmc_write.err

@@ -11,11 +11,13 @@ kernel = sys.argv[2] if len(sys.argv) > 2 else "feat_then_wps_kernel"
 per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 24  # launches of the kernel in one step (one per contig)
 build = sys.argv[4] if len(sys.argv) > 4 else "build not recorded"  # e.g. "r5_c, git 1a2b3c4"
 vals, calls = {}, {}
-for line in open(path):
-    f = line.split()
-    if len(f) >= 5 and f[0].startswith(kernel) and f[-4] in ("FETCH_SIZE", "WRITE_SIZE"):
-        vals[f[-4]] = float(f[-2])
-        calls[f[-4]] = int(f[-3])
+for line in open(path):  # (fixed-width rows of tools/prof_summary.py: 70 characters of kernel name, then four fields)
+    name, f = line[:70].rstrip(), line[70:].split()
+    # the step's launch is the tabix-fetch variant <CHK, HIST, DF, BAM = false, NT>; the BAM-mode variant in the same
+    # file comes from tools/kernel_rows.py
+    if len(f) == 4 and name.startswith(kernel) and "false, true>" in name.replace("false,true", "false, true") and f[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+        vals[f[0]] = float(f[2])
+        calls[f[0]] = int(f[1])
 fetch, write = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
 per_launch = int((2 * fetch + write) * 1024)
 print(json.dumps({
