@@ -328,16 +328,28 @@ __device__ unsigned long long g_block_ticks[2 * 65536];
 // output, literal tokens store their bytes, matches copy in stream order - what the windows do behind their chain.
 // A lane stops at anything the tables do not resolve in one look-up (end of block, a code longer than a table's root, a
 // bit pattern that is no code): the super-window ends in front of it and ONE window of the older kind takes it.
-constexpr int kLaneBits = 128;                    // bits of input per lane and super-window
-constexpr int kLaneTok = 64;                      // tokens a lane may write in (A); more ends its stretch early
-constexpr int kLaneCatch = 32;                    // ... and on its way into step in (B)
+constexpr int kLaneBits = 512;                    // bits of input per lane and super-window
+constexpr int kLaneTok = 176;                     // tokens a lane may write in (A); more ends its stretch early
+constexpr int kLaneCatch = 80;                    // ... and on its way into step in (B)
 constexpr int kLaneRounds = 6;                    // passes of (B) before the super-window is cut at the first unsettled lane
-constexpr int kLaneSlots = 8192;                  // scratch slots: as many as the chip can hold waves (256 CUs x 32)
-constexpr size_t kLaneSlotWords = 64 * kLaneTok + 64 * kLaneCatch + 64 * (kLaneTok + kLaneCatch);  // spec, catch-up, stream
+constexpr int kLaneSlots = 4096;                  // scratch slots: more than the chip holds of these waves (256 CUs x <= 13)
+constexpr size_t kLaneSlotWords = 64 * kLaneTok + 64 * kLaneCatch;  // a lane's tokens of (A), and of its way into step
 struct LaneScratch {
     unsigned busy[kLaneSlots];
     uint32_t words[1];  // kLaneSlots x kLaneSlotWords
 };
+
+#ifdef FTK_LANES_STATS
+// tools/lanes_stats.py (library built with -DFTK_LANES_STATS): what the super-windows of a launch looked like
+__device__ unsigned long long g_lanes_stats[16];
+#define LSTAT(i, v) do { if (lane == 0) atomicAdd(&g_lanes_stats[i], (unsigned long long)(v)); } while (0)
+#define LTIME_DECL unsigned long long lt_last = clock64()
+#define LTIME(i) do { const unsigned long long t_ = clock64(); LSTAT(i, t_ - lt_last); lt_last = t_; } while (0)
+#else
+#define LSTAT(i, v)
+#define LTIME_DECL
+#define LTIME(i)
+#endif
 
 template <bool VEC, bool LANES>
 __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const uint8_t* __restrict__ comp,
@@ -345,6 +357,11 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                                                           uint8_t* __restrict__ out, InflateStatus* __restrict__ status,
                                                           LaneScratch* __restrict__ lane_scratch) {
     __shared__ WaveLds L;
+    __shared__ uint32_t lanes_vis[LANES ? 64 * (kLaneBits / 32) : 1];
+#ifndef FTK_LANES_LDS_INPUT
+#define FTK_LANES_LDS_INPUT 1
+#endif
+    __shared__ uint32_t lanes_in[LANES && FTK_LANES_LDS_INPUT ? 64 * (kLaneBits / 32) + 64 : 1];  // the super-window's input words (+ the overhang of the last symbol)
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
     if (blk >= n_blocks) return;
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
     if (LANES) {
         // a slot nobody holds: there are as many as the chip can hold waves, so one is free; probing starts at a place
         // of the block's own
-        unsigned s0 = ((unsigned)blk * 2654435761u) >> 19;  // 13 bits
+        unsigned s0 = ((unsigned)blk * 2654435761u) >> 20;  // 12 bits
         if (lane == 0) {
             for (;; s0 = (s0 + 1u) & (unsigned)(kLaneSlots - 1))
                 if (atomicCAS(&lane_scratch->busy[s0], 0u, 1u) == 0u) break;
@@ -514,51 +531,101 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                 // ---- (A) every lane decodes its own stretch of kLaneBits bits from the stretch's first bit ----
                 const uint32_t in_bits = b.end_word * 32u;
                 // one symbol at bit position `at` of this lane: bits it takes (0: the tables do not resolve it), its token
+                // a code longer than a table's root, bit by bit, by the lane itself (decode_long's walk): symbol or -1
+                auto long_code = [&](unsigned v, int which, int& len_out) -> int {
+                    int code = 0, first = 0, index = 0;
+                    for (int len = 1; len <= 15; ++len) {
+                        code |= (int)(v & 1u);
+                        v >>= 1;
+                        const int count = L.cnt[which][len];
+                        if (code - count < first) {
+                            len_out = len;
+                            return L.sorted[which * 288 + index + (code - first)];
+                        }
+                        index += count;
+                        first = (first + count) << 1;
+                        code <<= 1;
+                    }
+                    return -1;
+                };
+                // the super-window's input words into LDS (coalesced; words behind the payload read as zeros): a lane's
+                // 64-bit view at any bit position of the super-window is then three LDS reads, not three trips to L2
+                LTIME_DECL;
+                const uint32_t in_w0 = bp >> 5;
+#if FTK_LANES_LDS_INPUT
+#pragma unroll
+                for (int k = 0; k <= kLaneBits / 32; ++k) {
+                    const uint32_t wi = in_w0 + (uint32_t)(k * 64 + lane);
+                    lanes_in[k * 64 + lane] = wi < b.end_word ? b.w[wi] : 0u;
+                }
+#endif
                 auto decode_at = [&](uint32_t at, unsigned& nb, unsigned& tok) {
+#if FTK_LANES_LDS_INPUT
+                    const uint32_t wr = (at >> 5) - in_w0;  // (at most 64 * kLaneBits / 32 + 2: the overhang is staged too)
+                    const unsigned c_lo = lanes_in[wr], c_mid = lanes_in[wr + 1u], c_hi = lanes_in[wr + 2u];
+#else
                     const uint32_t wi = at >> 5;
                     const unsigned c_lo = wi < b.end_word ? b.w[wi] : 0u;
                     const unsigned c_mid = wi + 1u < b.end_word ? b.w[wi + 1u] : 0u;
                     const unsigned c_hi = wi + 2u < b.end_word ? b.w[wi + 2u] : 0u;
+#endif
                     const unsigned sh = at & 31u;
                     const unsigned w0 = __builtin_amdgcn_alignbit(c_mid, c_lo, sh), w1 = __builtin_amdgcn_alignbit(c_hi, c_mid, sh);
                     const unsigned E = L.pair[w0 & ((1u << kLitRoot) - 1u)];
-                    const unsigned k1 = (E >> 5) & 3u, lb = E & 31u, lbase = (E >> 8) & 511u, xb = (E >> 20) & 7u;
+                    unsigned k1 = (E >> 5) & 3u, lb = E & 31u, lbase = (E >> 8) & 511u, xb = (E >> 20) & 7u;
+                    unsigned lit = (((E >> 8) & 0xffu) << 8) | (((E >> 20) & 0xffu) << 16);
+                    if (E == 0u) {  // (rare: a literal / length code longer than the root)
+                        int len = 0;
+                        const int sym = long_code(w0, 0, len);
+                        lb = (unsigned)len;
+                        k1 = 0u;
+                        lbase = 0u;  // (stays 0 for end of block and for no code at all: the lane stops)
+                        xb = 0u;
+                        if (sym >= 0 && sym < 256) {
+                            k1 = 1u;
+                            lit = (unsigned)sym << 8;
+                        } else if (sym > 256) {
+                            const unsigned ls = (unsigned)sym - 257u;
+                            if (ls < 8u) lbase = ls + 3u;
+                            else if (ls == 28u) lbase = 258u;
+                            else if (ls < 28u) { xb = (ls >> 2) - 1u; lbase = ((4u + (ls & 3u)) << xb) + 3u; }
+                            else lbase = 511u;
+                        }
+                    }
                     const unsigned wl = __builtin_amdgcn_alignbit(w1, w0, lb);
                     const unsigned mlen = lbase + (wl & ((1u << xb) - 1u));
                     const unsigned wd = wl >> xb;
-                    const unsigned D = L.dist[wd & ((1u << kDistRoot) - 1u)];
+                    unsigned D = L.dist[wd & ((1u << kDistRoot) - 1u)];
+                    if (D == 0u && k1 == 0u && lbase != 0u && lbase != 511u) {  // (rarer still: a long distance code)
+                        int len = 0;
+                        const int ds = long_code(wd, 1, len);
+                        if (ds >= 0) D = dist_entry((unsigned)len, (unsigned)ds);
+                    }
                     const unsigned dbits = D & 15u, dxb = (D >> 4) & 15u, dbase = D >> 8;
                     const unsigned mdist = dbase + ((wd >> dbits) & ((1u << dxb) - 1u));
                     const bool is_match = k1 == 0u && lbase != 0u && lbase != 511u && D != 0u && dbase != 0x7fffffu;
                     nb = is_match ? lb + xb + dbits + dxb : (k1 ? lb : 0u);
                     // token: kind (1 / 2 literals, 3 match) | literal bytes at bits 8 and 16, or length << 2 | distance << 11
-                    tok = is_match ? (3u | (mlen << 2) | (mdist << 11)) : (k1 | (((E >> 8) & 0xffu) << 8) | (((E >> 20) & 0xffu) << 16));
+                    tok = is_match ? (3u | (mlen << 2) | (mdist << 11)) : (k1 | lit);
                 };
                 const uint32_t p0 = bp + (uint32_t)lane * (uint32_t)kLaneBits, sub_end = p0 + (uint32_t)kLaneBits;
                 uint32_t* spec = lane_tok + (size_t)lane * kLaneTok;
                 uint32_t* catchup = lane_tok + 64 * kLaneTok + (size_t)lane * kLaneCatch;
-                uint32_t* stream = lane_tok + 64 * kLaneTok + 64 * kLaneCatch;
-                unsigned vis[kLaneBits / 32];
+                // the bit positions a lane has taken for symbol starts: a mask of its stretch, in LDS (word k of lane l at
+                // [k][l]: a wave's accesses fall into different banks)
+                constexpr int kVisWords = kLaneBits / 32;
 #pragma unroll
-                for (int k = 0; k < kLaneBits / 32; ++k) vis[k] = 0u;
-                auto vis_set = [&](unsigned rel) {
-#pragma unroll
-                    for (int k = 0; k < kLaneBits / 32; ++k)
-                        if ((int)(rel >> 5) == k) vis[k] |= 1u << (rel & 31u);
+                for (int k = 0; k < kVisWords; ++k) lanes_vis[k * 64 + lane] = 0u;
+                auto vis_set = [&](unsigned rel) {  // (ds_or_b32: one LDS instruction, nothing to wait for)
+                    __hip_atomic_fetch_or(&lanes_vis[(rel >> 5) * 64u + (unsigned)lane], 1u << (rel & 31u), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_WAVEFRONT);
                 };
-                auto vis_get = [&](unsigned rel) -> bool {
-                    unsigned w = 0u;
-#pragma unroll
-                    for (int k = 0; k < kLaneBits / 32; ++k)
-                        if ((int)(rel >> 5) == k) w = vis[k];
-                    return (w >> (rel & 31u)) & 1u;
-                };
+                auto vis_get = [&](unsigned rel) -> bool { return (lanes_vis[(rel >> 5) * 64u + (unsigned)lane] >> (rel & 31u)) & 1u; };
                 auto vis_below = [&](unsigned rel) -> int {  // visited positions in front of `rel`
                     int n = 0;
-#pragma unroll
-                    for (int k = 0; k < kLaneBits / 32; ++k) {
-                        const unsigned m = (int)(rel >> 5) > k ? 0xffffffffu : ((int)(rel >> 5) == k ? ((1u << (rel & 31u)) - 1u) : 0u);
-                        n += __popc(vis[k] & m);
+                    for (unsigned k = 0; k <= (rel >> 5) && k < (unsigned)kVisWords; ++k) {
+                        const unsigned w = lanes_vis[k * 64u + (unsigned)lane];
+                        n += __popc(k < (rel >> 5) ? w : (w & ((1u << (rel & 31u)) - 1u)));
                     }
                     return n;
                 };
@@ -567,7 +634,9 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                 bool stopped = false;               // the chain ended at something a window of the older kind must take
                 bool active = p0 < in_bits;
                 if (!active) stopped = true;        // (a lane behind the payload: nothing of it counts)
+                LSTAT(0, 1);
                 while (__ballot(active)) {
+                    LSTAT(5, 1);
                     if (active) {
                         unsigned nb, tok;
                         decode_at(pos, nb, tok);
@@ -582,6 +651,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         }
                     }
                 }
+                LTIME(10);  // staging + pass A
                 // ---- (B) true starts: lane l's first symbol starts where lane l - 1's chain ends ----
                 const uint32_t spec_end = pos;
                 const bool spec_stop = stopped;
@@ -600,7 +670,9 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     uint32_t q = c;
                     int nc = 0;
                     bool joined = false, cstop = false, go = need;
+                    LSTAT(3, 1);
                     while (__ballot(go)) {
+                        LSTAT(6, 1);
                         if (go) {
                             const uint32_t rel = q - p0;  // (c >= p0: the lane in front ran to the end of its stretch or beyond)
                             if (rel < (uint32_t)kLaneBits && vis_get(rel)) {
@@ -646,26 +718,45 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                 int n_lanes = 64;
                 if (stops) n_lanes = min(n_lanes, __ffsll((unsigned long long)stops));          // the stopped lane itself counts
                 if (unsettled) n_lanes = min(n_lanes, __ffsll((unsigned long long)unsettled) - 1);
+                LTIME(11);  // the rounds
+                LSTAT(1, n_lanes);
+                LSTAT(7, stops ? 1 : 0);
+                LSTAT(8, (unsettled && (!stops || __ffsll((unsigned long long)unsettled) - 1 < __ffsll((unsigned long long)stops))) ? 1 : 0);
                 if (n_lanes >= 1) {
-                    // ---- (C) the valid tokens end to end ----
+                    // ---- (C) where the valid tokens are: every lane's count, first valid token and catch-up count go to
+                    // LDS (the visited masks are done with), so that any lane can find the owner of the t-th token of the
+                    // super-window and fetch it from that lane's region - no copy into one stream
                     const int nvalid = lane < n_lanes ? ncatch + (ntok - first_valid) : 0;
                     const int incl = wave_incl_scan(nvalid);
                     const int n_tokens = __builtin_amdgcn_readlane(incl, 63);
-                    int at = incl - nvalid;
-                    if (lane < n_lanes) {
-                        for (int k = 0; k < ncatch; ++k) stream[at++] = catchup[k];
-                        for (int k = first_valid; k < ntok; ++k) stream[at++] = spec[k];
-                    }
+                    LSTAT(2, n_tokens);
+                    lanes_vis[lane] = (uint32_t)(incl - nvalid);        // tokens in front of this lane's
+                    lanes_vis[64 + lane] = (uint32_t)ncatch;
+                    lanes_vis[128 + lane] = (uint32_t)first_valid;
                     const uint32_t new_bp = (uint32_t)__builtin_amdgcn_readlane((int)my_end, n_lanes - 1);
                     const bool end_stop = ((stops >> (n_lanes - 1)) & 1ull) != 0ull;
-                    // (the stream is written by some lanes and read by others: the stores out to L2, the loads from there)
+                    // (tokens are written by one lane and read by another: the stores out to L2, the loads from there)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    LTIME(12);
+                    auto fetch = [&](int base) -> unsigned {
+                        const int t = base + lane;
+                        if (t >= n_tokens) return 0u;
+                        int lo = 0, hi = n_lanes - 1;  // the last lane whose tokens start at or in front of t
+#pragma unroll
+                        for (int step = 0; step < 6; ++step) {
+                            const int mid = (lo + hi + 1) >> 1;
+                            if ((int)lanes_vis[mid] <= t) lo = mid; else hi = mid - 1;
+                        }
+                        const int loc = t - (int)lanes_vis[lo], nc = (int)lanes_vis[64 + lo];
+                        const uint32_t* src = loc < nc ? lane_tok + 64 * kLaneTok + (size_t)lo * kLaneCatch + loc
+                                                       : lane_tok + (size_t)lo * kLaneTok + (int)lanes_vis[128 + lo] + (loc - nc);
+                        return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    };
                     // ---- (D) 64 tokens at a time: places from a prefix sum, literals stored, matches copied in order ----
                     bool fail_d = false;
+                    unsigned tok_next = fetch(0);
                     for (int base = 0; base < n_tokens && !fail_d;) {
-                        const unsigned tok = base + lane < n_tokens
-                                                 ? __hip_atomic_load(&stream[base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                 : 0u;
+                        const unsigned tok = tok_next;
                         unsigned mark = tok & 3u;
                         const unsigned mlen = (tok >> 2) & 511u, mdist = tok >> 11;
                         const int olen = mark == 3u ? (int)mlen : (int)mark;
@@ -690,39 +781,75 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         } else {
                             T = (uint32_t)__builtin_amdgcn_readlane(inc, 63);
                         }
+                        tok_next = fetch(base + took);  // (on its way while this group's bytes are stored and copied)
                         if (mark == 1u || mark == 2u) {
                             const uint32_t at2 = A + off;
                             L.ring[at2 & kRingMask] = (uint8_t)(tok >> 8);
                             if (mark == 2u) L.ring[(at2 + 1u) & kRingMask] = (uint8_t)(tok >> 16);
                         }
+                        // the matches, in stream order - the loops of the windows (see there)
+                        const unsigned ccase = (mdist >= mlen && mlen <= 64u && mdist <= (unsigned)kFarDist) ? 0u
+                                               : mdist <= (unsigned)kFarDist                                ? 1u
+                                                                                                            : 2u;
+                        const unsigned lenc = mlen | (ccase << 16);
                         const uint32_t M0v = A + off;
                         uint64_t mm = __ballot(mark == 3u);
-                        while (mm) {  // the matches in stream order (each may read what the one before it wrote)
-                            const int l = __ffsll((unsigned long long)mm) - 1;
-                            mm &= mm - 1;
-                            const int len = __builtin_amdgcn_readlane((int)mlen, l), d = __builtin_amdgcn_readlane((int)mdist, l);
-                            const uint32_t M0 = (uint32_t)__builtin_amdgcn_readlane((int)M0v, l);
-                            if (d >= len && len <= 64 && d <= kFarDist) {
-                                if (lane < len) {
-                                    const uint32_t a = M0 + (uint32_t)lane;
-                                    L.ring[a & kRingMask] = L.ring[(a - (uint32_t)d) & kRingMask];
-                                }
-                            } else if (d <= kFarDist) {
-                                int done = 0, DD = d;
-                                while (done < len) {
-                                    const int n = min(min(len - done, DD), 64);
-                                    if (lane < n) {
-                                        const uint32_t a = M0 + (uint32_t)(done + lane);
-                                        L.ring[a & kRingMask] = L.ring[(a - (uint32_t)DD) & kRingMask];
+                        if (mm && __ballot(mark == 3u && ccase != 0u) == 0ull) {
+                            unsigned lc, md, m0, va, vs, vx;
+                            int l;
+                            const unsigned spare = (unsigned)offsetof(WaveLds, lens);
+                            asm volatile(
+                                "1:\n\t"
+                                "s_ff1_i32_b64 %[l], %[mm]\n\t"
+                                "s_bitset0_b64 %[mm], %[l]\n\t"
+                                "v_readlane_b32 %[lc], %[lenc], %[l]\n\t"
+                                "v_readlane_b32 %[md], %[mdist], %[l]\n\t"
+                                "v_readlane_b32 %[m0], %[M0v], %[l]\n\t"
+                                "v_cmp_gt_u32 vcc, %[lc], %[lane]\n\t"
+                                "v_add_u32 %[va], %[m0], %[lane]\n\t"
+                                "v_subrev_u32 %[vs], %[md], %[va]\n\t"
+                                "v_and_b32 %[vs], %[mask], %[vs]\n\t"
+                                "v_and_b32 %[va], %[mask], %[va]\n\t"
+                                "v_cndmask_b32 %[vs], %[spare], %[vs], vcc\n\t"
+                                "v_cndmask_b32 %[va], %[spare], %[va], vcc\n\t"
+                                "ds_read_u8 %[vx], %[vs]\n\t"
+                                "s_waitcnt lgkmcnt(0)\n\t"
+                                "ds_write_b8 %[va], %[vx]\n\t"
+                                "s_cmp_lg_u64 %[mm], 0\n\t"
+                                "s_cbranch_scc1 1b\n\t"
+                                : [mm] "+s"(mm), [lc] "=&s"(lc), [md] "=&s"(md), [m0] "=&s"(m0), [l] "=&s"(l), [va] "=&v"(va),
+                                  [vs] "=&v"(vs), [vx] "=&v"(vx)
+                                : [lenc] "v"(lenc), [mdist] "v"(mdist), [M0v] "v"(M0v), [lane] "v"(lane), [mask] "i"(kRingMask),
+                                  [spare] "v"(spare)
+                                : "vcc", "scc", "memory");
+                        } else {
+                            while (mm) {
+                                const int l = __ffsll((unsigned long long)mm) - 1;
+                                mm &= mm - 1;
+                                const int len = __builtin_amdgcn_readlane((int)mlen, l), d = __builtin_amdgcn_readlane((int)mdist, l);
+                                const uint32_t M0 = (uint32_t)__builtin_amdgcn_readlane((int)M0v, l);
+                                if (d >= len && len <= 64 && d <= kFarDist) {
+                                    if (lane < len) {
+                                        const uint32_t a = M0 + (uint32_t)lane;
+                                        L.ring[a & kRingMask] = L.ring[(a - (uint32_t)d) & kRingMask];
                                     }
-                                    done += n;
-                                    if (2 * DD <= done + d) DD *= 2;
-                                }
-                            } else {
-                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                                for (int o = lane; o < len; o += 64) {
-                                    const uint32_t a = M0 + (uint32_t)o;
-                                    L.ring[a & kRingMask] = out[a - (uint32_t)d];
+                                } else if (d <= kFarDist) {
+                                    int done = 0, DD = d;
+                                    while (done < len) {
+                                        const int n = min(min(len - done, DD), 64);
+                                        if (lane < n) {
+                                            const uint32_t a = M0 + (uint32_t)(done + lane);
+                                            L.ring[a & kRingMask] = L.ring[(a - (uint32_t)DD) & kRingMask];
+                                        }
+                                        done += n;
+                                        if (2 * DD <= done + d) DD *= 2;
+                                    }
+                                } else {
+                                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                                    for (int o = lane; o < len; o += 64) {
+                                        const uint32_t a = M0 + (uint32_t)o;
+                                        L.ring[a & kRingMask] = out[a - (uint32_t)d];
+                                    }
                                 }
                             }
                         }
@@ -730,6 +857,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         base += took;
                     }
                     if (fail_d) break;
+                    LTIME(13);  // phase D
                     bp = new_bp;
                     lanes_rest = end_stop;
                     continue;
@@ -737,6 +865,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                 lanes_rest = true;  // not even lane 0's stretch went through: a window of the older kind
             }
             lanes_rest = false;
+            if (LANES) LSTAT(4, 1);
 #endif
 #if FTK_INFLATE_WINDOWED
             // ---- a window of symbols at once.  Every lane decodes, COMPLETELY and on the vector unit, the symbol that
@@ -1284,6 +1413,16 @@ extern "C" int ftk_debug_inflate_profile(unsigned long long* out, int reset) {  
     if (reset) {
         unsigned long long z[32] = {};
         rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z);
+    }
+    return rc;
+}
+#endif
+#ifdef FTK_LANES_STATS
+extern "C" int ftk_debug_lanes_stats(unsigned long long* out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lanes_stats), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {};
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lanes_stats), z, sizeof z);
     }
     return rc;
 }
