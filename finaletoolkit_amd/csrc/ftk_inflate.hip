@@ -332,6 +332,7 @@ constexpr int kLaneBits = 512;                    // bits of input per lane and 
 constexpr int kLaneTok = 176;                     // tokens a lane may write in (A); more ends its stretch early
 constexpr int kLaneCatch = 80;                    // ... and on its way into step in (B)
 constexpr int kLaneRounds = 6;                    // passes of (B) before the super-window is cut at the first unsettled lane
+constexpr int kLaneAutoBlocks = 2048;  // launches up to this many blocks take the lane-parallel loop (measured: tools/lanes_sweep.sh)
 constexpr int kLaneSlots = 4096;                  // scratch slots: more than the chip holds of these waves (256 CUs x <= 13)
 constexpr size_t kLaneSlotWords = 64 * kLaneTok + 64 * kLaneCatch;  // a lane's tokens of (A), and of its way into step
 struct LaneScratch {
@@ -1459,9 +1460,14 @@ void inflate_launch(hipStream_t s, const uint8_t* d_comp, const InflateBlock* d_
 #ifdef FTK_INFLATE_VECMATCH
     vector_matches = FTK_INFLATE_VECMATCH != 0;
 #endif
-    // FTK_INFLATE_LANES=1: the lane-parallel symbol loop (read per launch: the tests hold both loops against zlib)
+    // Which symbol loop: the lane-parallel one finishes a BLOCK sooner but spends more instructions on it, so it wins
+    // while the launch leaves the chip's wave slots unfilled (region reads, small contigs) and loses once the blocks
+    // queue for them.  FTK_INFLATE_LANES=0 / 1 forces one or the other (read per launch: the tests hold both
+    // against zlib), FTK_INFLATE_LANES_MAX moves the block count up to which the lane-parallel loop is chosen.
     const char* le = getenv("FTK_INFLATE_LANES");
-    LaneScratch* ls = (le && atoi(le) != 0) ? lane_scratch_of_device() : nullptr;
+    const char* lm = getenv("FTK_INFLATE_LANES_MAX");
+    const bool lanes = le && *le ? atoi(le) != 0 : n_blocks <= (lm && *lm ? atoi(lm) : kLaneAutoBlocks);
+    LaneScratch* ls = lanes ? lane_scratch_of_device() : nullptr;
     if (ls)
         hipLaunchKernelGGL((bgzf_inflate_kernel<false, true>), dim3(n_blocks), dim3(64), 0, s, d_comp, d_tab, n_blocks, d_out, d_status, ls);
     else if (vector_matches)

@@ -37,22 +37,28 @@ def _inflate_once(engine, image: bytes):
 
 
 def _inflate(engine, image: bytes):
-    """Both launch shapes of the kernel on the same image - a window's matches copied one after the other (text streams)
-    and resolved on the lanes side by side (BAM streams; ``FTK_INFLATE_VECTOR_MATCHES=1``) - must agree; the callers
-    then hold the result against zlib."""
+    """Every symbol loop of the kernel on the same image - the windowed loop with a window's matches copied one after
+    the other (text streams) or resolved on the lanes side by side (BAM streams; ``FTK_INFLATE_VECTOR_MATCHES=1``), and
+    the lane-parallel loop small launches take (``FTK_INFLATE_LANES``; unset, the block count decides) - must agree;
+    the callers then hold the result against zlib."""
     import os
-    keep = os.environ.get("FTK_INFLATE_VECTOR_MATCHES")
+    names = ("FTK_INFLATE_VECTOR_MATCHES", "FTK_INFLATE_LANES")
+    keep = {k: os.environ.get(k) for k in names}
     try:
-        os.environ["FTK_INFLATE_VECTOR_MATCHES"] = "0"
-        serial = _inflate_once(engine, image)
-        os.environ["FTK_INFLATE_VECTOR_MATCHES"] = "1"
-        vector = _inflate_once(engine, image)
+        got = []
+        for vec, lanes in (("0", "0"), ("1", "0"), ("0", "1")):
+            os.environ.update(FTK_INFLATE_VECTOR_MATCHES=vec, FTK_INFLATE_LANES=lanes)
+            got.append(_inflate_once(engine, image))
     finally:
-        if keep is None:
-            os.environ.pop("FTK_INFLATE_VECTOR_MATCHES", None)
-        else:
-            os.environ["FTK_INFLATE_VECTOR_MATCHES"] = keep
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    serial, vector, lanes = got
     assert serial[0] == vector[0] and (serial[0] != L.FTK_OK or serial[1] == vector[1])
+    # (a damaged payload may trip a different check first in the lane-parallel loop: both must refuse it)
+    assert (serial[0] == L.FTK_OK) == (lanes[0] == L.FTK_OK) and (serial[0] != L.FTK_OK or serial[1] == lanes[1])
     return vector
 
 
