@@ -236,7 +236,7 @@ __device__ __forceinline__ void build_pairs(WaveLds& L, int lane) {
                 v = l1 | (1u << 5) | (s1 << 8);
                 const unsigned t2 = one[e >> l1];  // the bits behind the first code, zero-extended: valid for a code
                 const unsigned l2 = t2 & 15u, s2 = t2 >> 4;  // that fits into what is left of the root bits
-                if (l2 && l1 + l2 <= (unsigned)kLitRoot && s2 < 256u) v = (l1 + l2) | (2u << 5) | (s1 << 8) | (s2 << 20);
+                if (l2 && l1 + l2 <= (unsigned)kLitRoot && s2 < 256u) v = (l1 + l2) | (2u << 5) | (s1 << 8) | (s2 << 20) | (l1 << 28);  // (bits 28..31: the first code's own length, for decoders that step one literal at a time)
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -328,11 +328,31 @@ __device__ unsigned long long g_block_ticks[2 * 65536];
 // output, literal tokens store their bytes, matches copy in stream order - what the windows do behind their chain.
 // A lane stops at anything the tables do not resolve in one look-up (end of block, a code longer than a table's root, a
 // bit pattern that is no code): the super-window ends in front of it and ONE window of the older kind takes it.
-constexpr int kLaneBits = 512;                    // bits of input per lane and super-window
-constexpr int kLaneTok = 176;                     // tokens a lane may write in (A); more ends its stretch early
-constexpr int kLaneCatch = 80;                    // ... and on its way into step in (B)
+#ifndef FTK_LANES_VEC_D
+#define FTK_LANES_VEC_D 1   // (D) resolves a group's bytes side by side; 0: its matches one after the other (A/B builds)
+#endif
+#ifndef FTK_LANE_BITS
+#define FTK_LANE_BITS 512
+#define FTK_LANE_TOK 176
+#define FTK_LANE_CATCH 80
+#endif
+// Bytes a group of (D) may produce.  With the group's bytes resolved side by side nothing is stored before every source has
+// been read, so a window's kWinCap does not bind; what does: a far match's sources must have been written behind (byte j of
+// the group reads A + j - d < A + j - kFarDist, and everything in front of A - (kGran - 1) is in HBM: j < kFarDist - kGran
+// + 2), and the write-behind takes one granule per group (T <= kGran).
+#if FTK_LANES_VEC_D
+#ifndef FTK_LANE_CAP
+#define FTK_LANE_CAP 384
+#endif
+constexpr int kLaneCap = FTK_LANE_CAP;
+static_assert(kLaneCap % 64 == 0 && kLaneCap <= kFarDist - kGran + 2 && kLaneCap <= kGran, "see above");
+#else
+constexpr int kLaneCap = kWinCap;
+#endif
+constexpr int kLaneBits = FTK_LANE_BITS;          // bits of input per lane and super-window
+constexpr int kLaneTok = FTK_LANE_TOK;            // tokens a lane may write in (A); more ends its stretch early
+constexpr int kLaneCatch = FTK_LANE_CATCH;        // ... and on its way into step in (B)
 constexpr int kLaneRounds = 6;                    // passes of (B) before the super-window is cut at the first unsettled lane
-constexpr int kLaneAutoBlocks = 2048;  // launches up to this many blocks take the lane-parallel loop (measured: tools/lanes_sweep.sh)
 constexpr int kLaneSlots = 4096;                  // scratch slots: more than the chip holds of these waves (256 CUs x <= 13)
 constexpr size_t kLaneSlotWords = 64 * kLaneTok + 64 * kLaneCatch;  // a lane's tokens of (A), and of its way into step
 struct LaneScratch {
@@ -342,13 +362,42 @@ struct LaneScratch {
 
 #ifdef FTK_LANES_STATS
 // tools/lanes_stats.py (library built with -DFTK_LANES_STATS): what the super-windows of a launch looked like
-__device__ unsigned long long g_lanes_stats[16];
+__device__ unsigned long long g_lanes_stats[32];
 #define LSTAT(i, v) do { if (lane == 0) atomicAdd(&g_lanes_stats[i], (unsigned long long)(v)); } while (0)
-#define LTIME_DECL unsigned long long lt_last = clock64()
-#define LTIME(i) do { const unsigned long long t_ = clock64(); LSTAT(i, t_ - lt_last); lt_last = t_; } while (0)
+// (times are kept in registers and added once a super-window: an atomic per mark costs more than what it marks)
+#if FTK_LANES_STATS > 1
+#define LT_N 14
 #else
+#define LT_N 4
+#endif
+#define LTIME_DECL unsigned lt_last = (unsigned)wall_clock64(), lt_acc[LT_N] = {}; unsigned l_trips_a = 0, l_trips_b = 0, l_rounds = 0, l_need2 = 0, l_nojoin1 = 0, l_trips_b1 = 0
+#define LTIME(i) do { const unsigned t_ = (unsigned)wall_clock64(); lt_acc[(i) - 10] += t_ - lt_last; lt_last = t_; } while (0)
+#define BT_DECL unsigned bt_last = (unsigned)wall_clock64(), bt_acc[3] = {0, 0, 0}
+#define BTIME(i) do { const unsigned t_ = (unsigned)wall_clock64(); bt_acc[i] += t_ - bt_last; bt_last = t_; } while (0)
+#define BT_FLUSH do { LSTAT(30, bt_acc[0]); LSTAT(31, bt_acc[1]); LSTAT(14, bt_acc[2]); LSTAT(15, 1); } while (0)
+#define LACC_DECL unsigned d_matches = 0, d_groups = 0, d_rounds = 0
+#define LACC(x, v) x += (unsigned)(v)
+#if FTK_LANES_STATS > 1
+#define LTIME_FLUSH_D do { LSTAT(16, lt_acc[6]); LSTAT(17, lt_acc[7]); LSTAT(18, lt_acc[8]); LSTAT(19, lt_acc[9]); LSTAT(20, lt_acc[10]); LSTAT(27, lt_acc[11]); LSTAT(28, lt_acc[12]); LSTAT(29, lt_acc[13]); } while (0)
+#else
+#define LTIME_FLUSH_D
+#endif
+#define LTIME_FLUSH do { LSTAT(10, lt_acc[0]); LSTAT(11, lt_acc[1]); LSTAT(12, lt_acc[2]); LSTAT(13, lt_acc[3]); LSTAT(5, l_trips_a); LSTAT(6, l_trips_b); LSTAT(3, l_rounds); LSTAT(22, l_need2); LSTAT(23, l_nojoin1); LSTAT(24, l_trips_b1); LTIME_FLUSH_D; } while (0)
+#if FTK_LANES_STATS > 1   // (markers inside (D): they cost more than what they time, so only on request)
+#define LTIME_D(i) LTIME(i)
+#else
+#define LTIME_D(i)
+#endif
+#else
+#define LTIME_D(i)
 #define LSTAT(i, v)
 #define LTIME_DECL
+#define LTIME_FLUSH
+#define LACC_DECL
+#define LACC(x, v)
+#define BT_DECL
+#define BTIME(i)
+#define BT_FLUSH
 #define LTIME(i)
 #endif
 
@@ -400,6 +449,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
     unsigned err = kInflateOk;
     bool final_seen = false;
     PROF_DECL;
+    BT_DECL;
 #ifdef FTK_INFLATE_PROFILE
     int lane_dep = lane;
     PROF(7, lane_dep);
@@ -422,6 +472,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
     };
 
     while (!final_seen && err == kInflateOk) {
+        BTIME(2);
         b.refill(lane);
         final_seen = b.take(1) != 0;
         const unsigned type = b.take(2);
@@ -504,6 +555,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
         }
         build_pairs(L, lane);
         build_dist(L, lane);
+        BTIME(0);  // the block's header and tables
         // ---- the symbols of this DEFLATE block --------------------------------------------------------
         // Literals: lane k looks up the symbol that would start k bits ahead (one LDS gather); the wave then hops from
         // symbol to symbol through that register - one v_readlane and a handful of scalar operations per hop, the
@@ -523,6 +575,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
 #endif
         for (;;) {
             PROF(7, lane_dep);  // (whatever ran since the last mark: the serial path, the loop's bookkeeping)
+            BTIME(2);  // (windows of the older kind, the serial path)
 #if FTK_INFLATE_WINDOWED
             if (LANES && !lanes_rest) {
                 if (b_moved) {
@@ -560,7 +613,11 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     lanes_in[k * 64 + lane] = wi < b.end_word ? b.w[wi] : 0u;
                 }
 #endif
-                auto decode_at = [&](uint32_t at, unsigned& nb, unsigned& tok) {
+                // (`single`: a pair of literals is taken one at a time - the chain then visits EVERY symbol start.  The
+                // lanes on their way into step (B) do: a chain that pairs its literals the other way round than the chain
+                // it is to meet - literal-heavy input, BAM records - is in step with it symbol by symbol and would still
+                // never land on one of its starts)
+                auto decode_at = [&](uint32_t at, unsigned& nb, unsigned& tok, bool single) {
 #if FTK_LANES_LDS_INPUT
                     const uint32_t wr = (at >> 5) - in_w0;  // (at most 64 * kLaneBits / 32 + 2: the overhang is staged too)
                     const unsigned c_lo = lanes_in[wr], c_mid = lanes_in[wr + 1u], c_hi = lanes_in[wr + 2u];
@@ -575,6 +632,11 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     const unsigned E = L.pair[w0 & ((1u << kLitRoot) - 1u)];
                     unsigned k1 = (E >> 5) & 3u, lb = E & 31u, lbase = (E >> 8) & 511u, xb = (E >> 20) & 7u;
                     unsigned lit = (((E >> 8) & 0xffu) << 8) | (((E >> 20) & 0xffu) << 16);
+                    if (single && k1 == 2u) {
+                        k1 = 1u;
+                        lb = E >> 28;
+                        lit &= 0xff00u;
+                    }
                     if (E == 0u) {  // (rare: a literal / length code longer than the root)
                         int len = 0;
                         const int sym = long_code(w0, 0, len);
@@ -637,10 +699,10 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                 if (!active) stopped = true;        // (a lane behind the payload: nothing of it counts)
                 LSTAT(0, 1);
                 while (__ballot(active)) {
-                    LSTAT(5, 1);
+                    LACC(l_trips_a, 1);
                     if (active) {
                         unsigned nb, tok;
-                        decode_at(pos, nb, tok);
+                        decode_at(pos, nb, tok, false);
                         if (nb == 0u || ntok == kLaneTok) {
                             stopped = true;
                             active = false;
@@ -671,9 +733,11 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     uint32_t q = c;
                     int nc = 0;
                     bool joined = false, cstop = false, go = need;
-                    LSTAT(3, 1);
+                    LACC(l_rounds, 1);
+                    if (round == 1) LACC(l_need2, __popcll(unsettled));
                     while (__ballot(go)) {
-                        LSTAT(6, 1);
+                        LACC(l_trips_b, 1);
+                        if (round == 0) LACC(l_trips_b1, 1);
                         if (go) {
                             const uint32_t rel = q - p0;  // (c >= p0: the lane in front ran to the end of its stretch or beyond)
                             if (rel < (uint32_t)kLaneBits && vis_get(rel)) {
@@ -683,7 +747,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                                 go = false;
                             } else {
                                 unsigned nb, tok;
-                                decode_at(q, nb, tok);
+                                decode_at(q, nb, tok, true);
                                 if (nb == 0u || nc == kLaneCatch) {
                                     cstop = true;
                                     go = false;
@@ -694,6 +758,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                             }
                         }
                     }
+                    if (round == 0) LACC(l_nojoin1, __popcll(__ballot(need && !joined)));
                     if (need) {
                         cur_start = c;
                         ncatch = nc;
@@ -755,15 +820,24 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     };
                     // ---- (D) 64 tokens at a time: places from a prefix sum, literals stored, matches copied in order ----
                     bool fail_d = false;
+                    LACC_DECL;
+#if FTK_LANES_VEC_D
+#pragma unroll
+                    for (int i = 0; i < kLaneCap / 64; ++i) lanes_vis[192 + 64 * i + lane] = 0u;  // the rows the symbols drop their keys in
+#endif
                     unsigned tok_next = fetch(0);
                     for (int base = 0; base < n_tokens && !fail_d;) {
                         const unsigned tok = tok_next;
+#if defined(FTK_LANES_STATS) && FTK_LANES_STATS > 1
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        LTIME(16);  // waiting for the group's tokens
+#endif
                         unsigned mark = tok & 3u;
                         const unsigned mlen = (tok >> 2) & 511u, mdist = tok >> 11;
                         const int olen = mark == 3u ? (int)mlen : (int)mark;
                         const int inc = wave_incl_scan(olen);
                         const uint32_t off = (uint32_t)(inc - olen);
-                        const uint32_t room = min((uint32_t)kWinCap, A_end - A);
+                        const uint32_t room = min((uint32_t)kLaneCap, A_end - A);
                         const uint64_t bad = __ballot(mark != 0u && ((uint32_t)inc > room || (mark == 3u && mdist > (A - out_off) + off)));
                         uint32_t T;
                         int took = min(64, n_tokens - base);
@@ -782,7 +856,133 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         } else {
                             T = (uint32_t)__builtin_amdgcn_readlane(inc, 63);
                         }
+                        LTIME_D(17);  // places
                         tok_next = fetch(base + took);  // (on its way while this group's bytes are stored and copied)
+                        LTIME_D(18);  // the next group's owners found
+#if FTK_LANES_VEC_D
+                        const uint64_t mm_any = __ballot(mark == 3u);
+                        LACC(d_matches, __popcll(mm_any));
+                        LACC(d_groups, 1);
+#ifndef FTK_LANES_SKIP
+#define FTK_LANES_SKIP 0   // (timing experiments only - results are wrong: 1 no byte resolution at all, 2 no doubling rounds, 4 no far loads)
+#endif
+                        if (mm_any && !(FTK_LANES_SKIP & 1)) {
+                            // ---- the group's BYTES side by side (T <= kWinCap = 320: five rows of 64).  Copying the matches in
+                            // stream order costs an LDS read -> write round trip per match, ~30 of them per group of fragment
+                            // rows, one after the other - four fifths of this loop's time when the chip is full.  Instead every
+                            // symbol drops a key (its place << 17 | match << 16 | distance - 1 or its literal bytes) at its first
+                            // output byte in a zeroed row of LDS; a running maximum over the rows hands every byte the key of
+                            // its symbol (the place is the key's top, so the latest symbol at or in front of a byte wins); and
+                            // then each byte knows where it comes from: a literal, a byte of the ring older than the group (one
+                            // LDS read), a byte further back than the ring holds (one load from HBM - written behind long ago,
+                            // see kFarDist), or an EARLIER BYTE OF THIS GROUP.  The last kind is a pointer; pointers are followed
+                            // by doubling (state array in LDS: the value once known, else a pointer to a byte of the same value),
+                            // ~log2 of the deepest chain of copies-of-copies rounds, and one pass stores the group.
+                            // (keys and states share the rows: all keys are read before any state is written, the rounds
+                            // start when all rows hold states, and the rows are zeroed again behind the group.  Every step
+                            // is written row by row in loops of its own - all reads of a step, then all its writes - so that
+                            // the rows' LDS round trips overlap instead of following each other.)
+                            uint32_t* const S = lanes_vis + 192;      // (words 0..191 hold (C)'s arrays, which fetch() reads)
+                            constexpr unsigned kRes = 0x80000000u;
+                            constexpr int kRows = kLaneCap / 64;
+                            static_assert(192 + kRows * 64 <= 64 * (kLaneBits / 32), "the byte states of a group must fit behind (C)'s arrays");
+                            const int R = (int)((T + 63u) >> 6);
+                            if (mark) S[off] = (off << 17) | (mark == 3u ? (0x10000u | (mdist - 1u)) : ((tok >> 8) & 0xffffu));
+                            const bool any_far = __ballot(mark == 3u && mdist > (unsigned)kFarDist) != 0ull;
+                            unsigned stv[kRows];
+#pragma unroll
+                            for (int i = 0; i < kRows; ++i) stv[i] = i < R ? S[lane + 64 * i] : 0u;
+#pragma unroll
+                            for (int i = 0; i < kRows; ++i) {
+                                if (i < R) {
+                                    unsigned k = stv[i];
+                                    k = max(k, (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x111, 0xf, 0xf, false));
+                                    k = max(k, (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x112, 0xf, 0xf, false));
+                                    k = max(k, (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x114, 0xf, 0xf, false));
+                                    k = max(k, (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x118, 0xf, 0xf, false));
+                                    k = max(k, (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x142, 0xa, 0xf, false));
+                                    k = max(k, (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x143, 0xc, 0xf, false));
+                                    stv[i] = k;
+                                }
+                            }
+                            unsigned carry = 0u;
+#pragma unroll
+                            for (int i = 0; i < kRows; ++i) {
+                                if (i < R) {
+                                    stv[i] = max(stv[i], carry);
+                                    carry = (unsigned)__builtin_amdgcn_readlane((int)stv[i], 63);
+                                }
+                            }
+                            LTIME_D(21);  // keys dropped, read, running maximum
+                            // where each byte comes from; the ring bytes of all rows are read together (a row that needs none
+                            // reads its own slot)
+                            unsigned old[kRows];
+#pragma unroll
+                            for (int i = 0; i < kRows; ++i) {
+                                const uint32_t j = (uint32_t)(lane + 64 * i);
+                                const unsigned k = stv[i];
+                                const uint32_t d = (k & 0x7fffu) + 1u;
+                                const bool from_ring = i < R && j < T && (k & 0x10000u) != 0u && j < d && d <= (uint32_t)kFarDist;
+                                old[i] = i < R ? L.ring[(from_ring ? A + j - d : A + j) & kRingMask] : 0u;
+                            }
+                            if (any_far && !(FTK_LANES_SKIP & 4)) {
+                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#pragma unroll
+                                for (int i = 0; i < kRows; ++i) {
+                                    const uint32_t j = (uint32_t)(lane + 64 * i);
+                                    const unsigned k = stv[i];
+                                    const uint32_t d = (k & 0x7fffu) + 1u;
+                                    if (i < R && j < T && (k & 0x10000u) != 0u && j < d && d > (uint32_t)kFarDist) old[i] = out[A + j - d];
+                                }
+                            }
+#pragma unroll
+                            for (int i = 0; i < kRows; ++i) {
+                                if (i < R) {
+                                    const uint32_t j = (uint32_t)(lane + 64 * i);
+                                    const unsigned k = stv[i];
+                                    const uint32_t rel = j - (k >> 17);
+                                    const uint32_t d = (k & 0x7fffu) + 1u;
+                                    unsigned st;
+                                    if (j >= T) st = kRes;
+                                    else if ((k & 0x10000u) == 0u) st = kRes | (((k & 0xffffu) >> (8u * (rel & 1u))) & 0xffu);
+                                    else st = j >= d ? j - d : (kRes | old[i]);
+                                    stv[i] = st;
+                                    S[j] = st;
+                                }
+                            }
+                            LTIME_D(22);  // sources and states
+                            for (;;) {
+                                bool open = false;
+#pragma unroll
+                                for (int i = 0; i < kRows; ++i) open |= i < R && (stv[i] & kRes) == 0u;
+                                if (!__ballot(open) || (FTK_LANES_SKIP & 2)) break;
+                                LACC(d_rounds, 1);
+                                unsigned g[kRows];
+#pragma unroll
+                                for (int i = 0; i < kRows; ++i) g[i] = i < R ? S[(stv[i] & kRes) ? (unsigned)(lane + 64 * i) : stv[i]] : 0u;
+#pragma unroll
+                                for (int i = 0; i < kRows; ++i) {
+                                    if (i < R && (stv[i] & kRes) == 0u) {
+                                        stv[i] = g[i];
+                                        S[lane + 64 * i] = g[i];
+                                    }
+                                }
+                            }
+                            LTIME_D(23);  // rounds of pointer doubling
+#pragma unroll
+                            for (int i = 0; i < kRows; ++i) {
+                                const uint32_t j = (uint32_t)(lane + 64 * i);
+                                if (i < R) {
+                                    S[j] = 0u;
+                                    if (j < T) L.ring[(A + j) & kRingMask] = (uint8_t)stv[i];
+                                }
+                            }
+                        } else if (mark == 1u || mark == 2u) {
+                            const uint32_t at2 = A + off;
+                            L.ring[at2 & kRingMask] = (uint8_t)(tok >> 8);
+                            if (mark == 2u) L.ring[(at2 + 1u) & kRingMask] = (uint8_t)(tok >> 16);
+                        }
+#else
                         if (mark == 1u || mark == 2u) {
                             const uint32_t at2 = A + off;
                             L.ring[at2 & kRingMask] = (uint8_t)(tok >> 8);
@@ -854,13 +1054,21 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                                 }
                             }
                         }
+#endif
+                        LTIME_D(19);  // literals and matches
                         advance(T);
+                        LTIME_D(20);  // write-behind
                         base += took;
                     }
                     if (fail_d) break;
                     LTIME(13);  // phase D
+                    LSTAT(21, d_matches);
+                    LSTAT(25, d_groups);
+                    LSTAT(26, d_rounds);
+                    LTIME_FLUSH;
                     bp = new_bp;
                     lanes_rest = end_stop;
+                    BTIME(1);  // a super-window
                     continue;
                 }
                 lanes_rest = true;  // not even lane 0's stretch went through: a window of the older kind
@@ -1262,6 +1470,8 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
     if (err == kInflateOk && A != A_end) err = kInflateShort;
     // the unfinished granule
     if ((A & (kGran - 1)) != 0 || A == out_off) flush(A >> kGranShift);
+    BTIME(2);
+    BT_FLUSH;
 #ifdef FTK_INFLATE_TIMING
     if (lane == 0 && blk < 65536) g_block_ticks[2 * blk + 1] = wall_clock64();
 #endif
@@ -1420,9 +1630,9 @@ extern "C" int ftk_debug_inflate_profile(unsigned long long* out, int reset) {  
 #endif
 #ifdef FTK_LANES_STATS
 extern "C" int ftk_debug_lanes_stats(unsigned long long* out, int reset) {
-    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lanes_stats), sizeof(unsigned long long) * 16);
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lanes_stats), sizeof(unsigned long long) * 32);
     if (reset) {
-        unsigned long long z[16] = {};
+        unsigned long long z[32] = {};
         rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lanes_stats), z, sizeof z);
     }
     return rc;
@@ -1460,13 +1670,11 @@ void inflate_launch(hipStream_t s, const uint8_t* d_comp, const InflateBlock* d_
 #ifdef FTK_INFLATE_VECMATCH
     vector_matches = FTK_INFLATE_VECMATCH != 0;
 #endif
-    // Which symbol loop: the lane-parallel one finishes a BLOCK sooner but spends more instructions on it, so it wins
-    // while the launch leaves the chip's wave slots unfilled (region reads, small contigs) and loses once the blocks
-    // queue for them.  FTK_INFLATE_LANES=0 / 1 forces one or the other (read per launch: the tests hold both
-    // against zlib), FTK_INFLATE_LANES_MAX moves the block count up to which the lane-parallel loop is chosen.
+    // Which symbol loop: the lane-parallel one unless FTK_INFLATE_LANES=0 asks for the windowed loop (read per launch: the
+    // tests hold both against zlib).  Since (D) resolves a group's bytes side by side it is ahead at every launch size
+    // (a 1 882-block launch 1.3 vs 2.9 ms, chip-filling text 6.3 vs 7.5 ms, BAM records 9.4 vs 9.5 ms).
     const char* le = getenv("FTK_INFLATE_LANES");
-    const char* lm = getenv("FTK_INFLATE_LANES_MAX");
-    const bool lanes = le && *le ? atoi(le) != 0 : n_blocks <= (lm && *lm ? atoi(lm) : kLaneAutoBlocks);
+    const bool lanes = !(le && *le) || atoi(le) != 0;
     LaneScratch* ls = lanes ? lane_scratch_of_device() : nullptr;
     if (ls)
         hipLaunchKernelGGL((bgzf_inflate_kernel<false, true>), dim3(n_blocks), dim3(64), 0, s, d_comp, d_tab, n_blocks, d_out, d_status, ls);

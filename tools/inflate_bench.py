@@ -17,6 +17,7 @@ from finaletoolkit_amd import _lib as L, bgzf, synth, writers  # noqa: E402
 from finaletoolkit_amd.engine import Engine  # noqa: E402
 
 contig = sys.argv[1] if len(sys.argv) > 1 else "21"
+NOCHECK = os.environ.get("INFLATE_BENCH_NOCHECK") == "1"  # (timing builds that skip work: FTK_LANES_SKIP)
 size = synth.B37_SIZES[contig]
 s, e, q, st = synth.synth_contig(size, 30.0, 5)
 eng = Engine(0)
@@ -33,10 +34,10 @@ for level in (1, 6):
         t0 = time.perf_counter()
         rc = eng.lib.ftk_bgzf_inflate_device(eng.ctx, image, len(image), L.ptr(out), len(out), C.byref(n))
         dt = time.perf_counter() - t0
-        assert rc == 0, eng.lib.ftk_last_error(eng.ctx)
+        assert rc == 0 or NOCHECK, eng.lib.ftk_last_error(eng.ctx)
         print(f"libdeflate level {level}: {len(image) / 1e6:.1f} MB -> {n.value / 1e6:.1f} MB, {len(image) // 1 and -(-len(text) // 0xFF00)} blocks, "
               f"call {dt * 1e3:.1f} ms ({n.value / dt / 1e9:.1f} GB/s of text incl. copies)", flush=True)
-    assert out.tobytes() == text
+    assert NOCHECK or out.tobytes() == text
 # bgzip-like: zlib level 6 blocks (Python zlib, first 40 MB)
 part = text[:40_000_000]
 p = os.path.join(tmp, "z6.gz")
@@ -48,6 +49,6 @@ for rep in range(3):
     t0 = time.perf_counter()
     rc = eng.lib.ftk_bgzf_inflate_device(eng.ctx, image, len(image), L.ptr(out), len(out), C.byref(n))
     dt = time.perf_counter() - t0
-    assert rc == 0, eng.lib.ftk_last_error(eng.ctx)
+    assert rc == 0 or NOCHECK, eng.lib.ftk_last_error(eng.ctx)
     print(f"zlib level 6: {len(image) / 1e6:.1f} MB -> {n.value / 1e6:.1f} MB, call {dt * 1e3:.1f} ms", flush=True)
-assert out.tobytes() == part
+assert NOCHECK or out.tobytes() == part
