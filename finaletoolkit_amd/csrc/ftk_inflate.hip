@@ -672,8 +672,10 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     tok = is_match ? (3u | (mlen << 2) | (mdist << 11)) : (k1 | lit);
                 };
                 const uint32_t p0 = bp + (uint32_t)lane * (uint32_t)kLaneBits, sub_end = p0 + (uint32_t)kLaneBits;
-                uint32_t* spec = lane_tok + (size_t)lane * kLaneTok;
-                uint32_t* catchup = lane_tok + 64 * kLaneTok + (size_t)lane * kLaneCatch;
+                // token k of lane l at [k][l]: the lanes run in lock step, so a trip's 64 tokens are one 256-byte store (lane
+                // by lane - [l][k] - every trip wrote to 64 cache lines, and the address unit was busy with little else)
+                uint32_t* spec = lane_tok + lane;
+                uint32_t* catchup = lane_tok + 64 * kLaneTok + lane;
                 // the bit positions a lane has taken for symbol starts: a mask of its stretch, in LDS (word k of lane l at
                 // [k][l]: a wave's accesses fall into different banks)
                 constexpr int kVisWords = kLaneBits / 32;
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                             active = false;
                         } else {
                             vis_set(pos - p0);
-                            spec[ntok++] = tok;
+                            spec[64 * ntok++] = tok;
                             pos += nb;
                             active = pos < sub_end;
                         }
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                                     cstop = true;
                                     go = false;
                                 } else {
-                                    catchup[nc++] = tok;
+                                    catchup[64 * nc++] = tok;
                                     q += nb;
                                 }
                             }
@@ -814,8 +816,8 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                             if ((int)lanes_vis[mid] <= t) lo = mid; else hi = mid - 1;
                         }
                         const int loc = t - (int)lanes_vis[lo], nc = (int)lanes_vis[64 + lo];
-                        const uint32_t* src = loc < nc ? lane_tok + 64 * kLaneTok + (size_t)lo * kLaneCatch + loc
-                                                       : lane_tok + (size_t)lo * kLaneTok + (int)lanes_vis[128 + lo] + (loc - nc);
+                        const uint32_t* src = loc < nc ? lane_tok + 64 * kLaneTok + 64 * loc + lo
+                                                       : lane_tok + 64 * ((int)lanes_vis[128 + lo] + (loc - nc)) + lo;
                         return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     };
                     // ---- (D) 64 tokens at a time: places from a prefix sum, literals stored, matches copied in order ----
