@@ -53,8 +53,11 @@ constexpr int kGranShift = kRing >= 8192 ? 11 : 10, kGran = 1 << kGranShift;  //
 #ifndef FTK_INFLATE_WINDOWED
 #define FTK_INFLATE_WINDOWED 1
 #endif
+// Root of the distance look-up: 8 bits (1 KB; 9 until round 5).  Distance codes longer than the root are walked bit by bit
+// (long_code / decode_long) - rare - and the smaller table is worth 10 % on chip-filling launches of the lane-parallel
+// loop (fragment rows 5.84 -> 5.25 ms; 7 bits the same again).
 #ifndef FTK_INFLATE_DIST_ROOT
-#define FTK_INFLATE_DIST_ROOT 9
+#define FTK_INFLATE_DIST_ROOT 8
 #endif
 // A window's literal and match bytes resolved by the lanes side by side (see the symbol loop): a property of the LAUNCH
 // (template parameter VEC of the kernel; inflate_launch's vector_matches).  Measured on chip-filling launches
@@ -409,9 +412,11 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
     __shared__ WaveLds L;
     __shared__ uint32_t lanes_vis[LANES ? 64 * (kLaneBits / 32) : 1];
 #ifndef FTK_LANES_LDS_INPUT
-#define FTK_LANES_LDS_INPUT 1
+#define FTK_LANES_LDS_INPUT 0
 #endif
-    __shared__ uint32_t lanes_in[LANES && FTK_LANES_LDS_INPUT ? 64 * (kLaneBits / 32) + 64 : 1];  // the super-window's input words (+ the overhang of the last symbol)
+#if FTK_LANES_LDS_INPUT
+    __shared__ uint32_t lanes_in[LANES ? 64 * (kLaneBits / 32) + 64 : 1];  // the super-window's input words (+ the overhang of the last symbol)
+#endif
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
     if (blk >= n_blocks) return;
@@ -602,30 +607,63 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     }
                     return -1;
                 };
-                // the super-window's input words into LDS (coalesced; words behind the payload read as zeros): a lane's
-                // 64-bit view at any bit position of the super-window is then three LDS reads, not three trips to L2
                 LTIME_DECL;
-                const uint32_t in_w0 = bp >> 5;
 #if FTK_LANES_LDS_INPUT
+                const uint32_t in_w0 = bp >> 5;
+                // (A/B builds) the super-window's input words into LDS (coalesced; words behind the payload read as zeros):
+                // a lane's 64-bit view at any bit position of the super-window is then three LDS reads
 #pragma unroll
                 for (int k = 0; k <= kLaneBits / 32; ++k) {
                     const uint32_t wi = in_w0 + (uint32_t)(k * 64 + lane);
                     lanes_in[k * 64 + lane] = wi < b.end_word ? b.w[wi] : 0u;
                 }
 #endif
+                // A lane reads its stretch front to back, so its input is a WINDOW IN REGISTERS: the word its position is in
+                // and the four behind it (r0..r3, nx), moved up as the position crosses words (a symbol takes at most 48
+                // bits: one or two words a trip) and refilled by the lane's own loads - which have a trip or more to arrive,
+                // since a symbol is decoded from r0..r2 alone.  Until round 5's last third the super-window's words were
+                // staged in LDS (4.3 KB a wave, the largest single item of the 16 KB that kept a CU at ten waves) and every
+                // symbol began with an LDS round trip for its three words.  Words behind the payload read as zeros.
+                struct InWin {
+                    uint32_t wi;
+                    unsigned r0, r1, r2, r3, nx;
+                };
+                auto ldw = [&](uint32_t wi) -> unsigned { return wi < b.end_word ? b.w[wi] : 0u; };
+                auto win_open = [&](InWin& W, uint32_t at) {
+                    W.wi = at >> 5;
+                    W.r0 = ldw(W.wi);
+                    W.r1 = ldw(W.wi + 1u);
+                    W.r2 = ldw(W.wi + 2u);
+                    W.r3 = ldw(W.wi + 3u);
+                    W.nx = ldw(W.wi + 4u);
+                };
+                auto win_seek = [&](InWin& W, uint32_t at) {  // (at most two words further than the window's first)
+                    const uint32_t adv = (at >> 5) - W.wi;
+                    if (adv != 0u) {
+                        const bool one = adv == 1u;
+                        W.r0 = one ? W.r1 : W.r2;
+                        W.r1 = one ? W.r2 : W.r3;
+                        W.r2 = one ? W.r3 : W.nx;
+                        if (one) {
+                            W.r3 = W.nx;
+                            W.nx = ldw(W.wi + 5u);
+                        } else {
+                            W.r3 = ldw(W.wi + 5u);
+                            W.nx = ldw(W.wi + 6u);
+                        }
+                        W.wi += adv;
+                    }
+                };
                 // (`single`: a pair of literals is taken one at a time - the chain then visits EVERY symbol start.  The
                 // lanes on their way into step (B) do: a chain that pairs its literals the other way round than the chain
                 // it is to meet - literal-heavy input, BAM records - is in step with it symbol by symbol and would still
                 // never land on one of its starts)
-                auto decode_at = [&](uint32_t at, unsigned& nb, unsigned& tok, bool single) {
+                auto decode_at = [&](const InWin& W, uint32_t at, unsigned& nb, unsigned& tok, bool single) {
 #if FTK_LANES_LDS_INPUT
                     const uint32_t wr = (at >> 5) - in_w0;  // (at most 64 * kLaneBits / 32 + 2: the overhang is staged too)
                     const unsigned c_lo = lanes_in[wr], c_mid = lanes_in[wr + 1u], c_hi = lanes_in[wr + 2u];
 #else
-                    const uint32_t wi = at >> 5;
-                    const unsigned c_lo = wi < b.end_word ? b.w[wi] : 0u;
-                    const unsigned c_mid = wi + 1u < b.end_word ? b.w[wi + 1u] : 0u;
-                    const unsigned c_hi = wi + 2u < b.end_word ? b.w[wi + 2u] : 0u;
+                    const unsigned c_lo = W.r0, c_mid = W.r1, c_hi = W.r2;  // (W.wi == at >> 5: the caller has moved the window)
 #endif
                     const unsigned sh = at & 31u;
                     const unsigned w0 = __builtin_amdgcn_alignbit(c_mid, c_lo, sh), w1 = __builtin_amdgcn_alignbit(c_hi, c_mid, sh);
@@ -700,19 +738,24 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                 bool active = p0 < in_bits;
                 if (!active) stopped = true;        // (a lane behind the payload: nothing of it counts)
                 LSTAT(0, 1);
+                InWin W;
+                win_open(W, p0);
                 while (__ballot(active)) {
                     LACC(l_trips_a, 1);
                     if (active) {
                         unsigned nb, tok;
-                        decode_at(pos, nb, tok, false);
+                        decode_at(W, pos, nb, tok, false);
                         if (nb == 0u || ntok == kLaneTok) {
                             stopped = true;
                             active = false;
                         } else {
                             vis_set(pos - p0);
-                            spec[64 * ntok++] = tok;
                             pos += nb;
                             active = pos < sub_end;
+                            // (the window's loads BEFORE the token's store: memory operations are counted off in order, so a
+                            // load behind the store would not be seen to arrive before the store is acknowledged)
+                            if (!FTK_LANES_LDS_INPUT && active) win_seek(W, pos);
+                            spec[64 * ntok++] = tok;
                         }
                     }
                 }
@@ -735,6 +778,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     uint32_t q = c;
                     int nc = 0;
                     bool joined = false, cstop = false, go = need;
+                    if (!FTK_LANES_LDS_INPUT && need) win_open(W, c);
                     LACC(l_rounds, 1);
                     if (round == 1) LACC(l_need2, __popcll(unsettled));
                     while (__ballot(go)) {
@@ -749,13 +793,14 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                                 go = false;
                             } else {
                                 unsigned nb, tok;
-                                decode_at(q, nb, tok, true);
+                                decode_at(W, q, nb, tok, true);
                                 if (nb == 0u || nc == kLaneCatch) {
                                     cstop = true;
                                     go = false;
                                 } else {
-                                    catchup[64 * nc++] = tok;
                                     q += nb;
+                                    if (!FTK_LANES_LDS_INPUT) win_seek(W, q);
+                                    catchup[64 * nc++] = tok;
                                 }
                             }
                         }
