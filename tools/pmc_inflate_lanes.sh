@@ -6,7 +6,7 @@ C=${2:-1}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export FTK_INFLATE_VECTOR_MATCHES=0
-for lanes in 0 1; do
+for lanes in ${LANES_LIST:-0 1}; do
   export FTK_INFLATE_LANES=$lanes
   for c in SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA; do
     rocprofv3 --pmc $c --output-format csv -d $OUT/sq_$c -- python3 $GRAFT_REPO_ROOT/tools/inflate_bench.py $C > /dev/null 2> $OUT/sq_$c.err
