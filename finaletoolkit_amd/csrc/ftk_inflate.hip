@@ -22,6 +22,7 @@
 // workgroup fence); and an LDS-to-LDS match (d <= kFarDist) never has its sources overwritten by its own stores,
 // which reach at most 258 + 64 bytes past A0: kFarDist + 258 + 64 <= kRing.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <algorithm>
 #include <cstdlib>
@@ -933,15 +934,18 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                             constexpr unsigned kRes = 0x80000000u;
                             constexpr int kRows = kLaneCap / 64;
                             static_assert(192 + kRows * 64 <= 64 * (kLaneBits / 32), "the byte states of a group must fit behind (C)'s arrays");
-                            const int R = (int)((T + 63u) >> 6);
                             if (mark) S[off] = (off << 17) | (mark == 3u ? (0x10000u | (mdist - 1u)) : ((tok >> 8) & 0xffffu));
                             const bool any_far = __ballot(mark == 3u && mdist > (unsigned)kFarDist) != 0ull;
-                            unsigned stv[kRows];
+                            // (the rows are worked on without asking row by row whether the group reaches them - a row behind
+                            // its end holds zeros and resolves to nothing: the tests cost more than the rows, and kept the
+                            // rows' instructions from being interleaved - in two sizes: half the rows for short groups)
+                            auto rows = [&](auto nr_tag) {
+                                constexpr int NR = decltype(nr_tag)::value;
+                                unsigned stv[NR];
 #pragma unroll
-                            for (int i = 0; i < kRows; ++i) stv[i] = i < R ? S[lane + 64 * i] : 0u;
+                                for (int i = 0; i < NR; ++i) stv[i] = S[lane + 64 * i];
 #pragma unroll
-                            for (int i = 0; i < kRows; ++i) {
-                                if (i < R) {
+                                for (int i = 0; i < NR; ++i) {
                                     unsigned k = stv[i];
                                     k = max(k, (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x111, 0xf, 0xf, false));
                                     k = max(k, (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x112, 0xf, 0xf, false));
@@ -951,40 +955,36 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                                     k = max(k, (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, 0x143, 0xc, 0xf, false));
                                     stv[i] = k;
                                 }
-                            }
-                            unsigned carry = 0u;
+                                unsigned carry = 0u;
 #pragma unroll
-                            for (int i = 0; i < kRows; ++i) {
-                                if (i < R) {
+                                for (int i = 0; i < NR; ++i) {
                                     stv[i] = max(stv[i], carry);
                                     carry = (unsigned)__builtin_amdgcn_readlane((int)stv[i], 63);
                                 }
-                            }
-                            LTIME_D(21);  // keys dropped, read, running maximum
-                            // where each byte comes from; the ring bytes of all rows are read together (a row that needs none
-                            // reads its own slot)
-                            unsigned old[kRows];
+                                LTIME_D(21);  // keys dropped, read, running maximum
+                                // where each byte comes from; the ring bytes of all rows are read together (a row that needs
+                                // none reads its own slot)
+                                unsigned old[NR];
 #pragma unroll
-                            for (int i = 0; i < kRows; ++i) {
-                                const uint32_t j = (uint32_t)(lane + 64 * i);
-                                const unsigned k = stv[i];
-                                const uint32_t d = (k & 0x7fffu) + 1u;
-                                const bool from_ring = i < R && j < T && (k & 0x10000u) != 0u && j < d && d <= (uint32_t)kFarDist;
-                                old[i] = i < R ? L.ring[(from_ring ? A + j - d : A + j) & kRingMask] : 0u;
-                            }
-                            if (any_far && !(FTK_LANES_SKIP & 4)) {
-                                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-#pragma unroll
-                                for (int i = 0; i < kRows; ++i) {
+                                for (int i = 0; i < NR; ++i) {
                                     const uint32_t j = (uint32_t)(lane + 64 * i);
                                     const unsigned k = stv[i];
                                     const uint32_t d = (k & 0x7fffu) + 1u;
-                                    if (i < R && j < T && (k & 0x10000u) != 0u && j < d && d > (uint32_t)kFarDist) old[i] = out[A + j - d];
+                                    const bool from_ring = j < T && (k & 0x10000u) != 0u && j < d && d <= (uint32_t)kFarDist;
+                                    old[i] = L.ring[(from_ring ? A + j - d : A + j) & kRingMask];
                                 }
-                            }
+                                if (any_far && !(FTK_LANES_SKIP & 4)) {
+                                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #pragma unroll
-                            for (int i = 0; i < kRows; ++i) {
-                                if (i < R) {
+                                    for (int i = 0; i < NR; ++i) {
+                                        const uint32_t j = (uint32_t)(lane + 64 * i);
+                                        const unsigned k = stv[i];
+                                        const uint32_t d = (k & 0x7fffu) + 1u;
+                                        if (j < T && (k & 0x10000u) != 0u && j < d && d > (uint32_t)kFarDist) old[i] = out[A + j - d];
+                                    }
+                                }
+#pragma unroll
+                                for (int i = 0; i < NR; ++i) {
                                     const uint32_t j = (uint32_t)(lane + 64 * i);
                                     const unsigned k = stv[i];
                                     const uint32_t rel = j - (k >> 17);
@@ -996,34 +996,34 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                                     stv[i] = st;
                                     S[j] = st;
                                 }
-                            }
-                            LTIME_D(22);  // sources and states
-                            for (;;) {
-                                bool open = false;
+                                LTIME_D(22);  // sources and states
+                                for (;;) {
+                                    bool open = false;
 #pragma unroll
-                                for (int i = 0; i < kRows; ++i) open |= i < R && (stv[i] & kRes) == 0u;
-                                if (!__ballot(open) || (FTK_LANES_SKIP & 2)) break;
-                                LACC(d_rounds, 1);
-                                unsigned g[kRows];
+                                    for (int i = 0; i < NR; ++i) open |= (stv[i] & kRes) == 0u;
+                                    if (!__ballot(open) || (FTK_LANES_SKIP & 2)) break;
+                                    LACC(d_rounds, 1);
+                                    unsigned g[NR];
 #pragma unroll
-                                for (int i = 0; i < kRows; ++i) g[i] = i < R ? S[(stv[i] & kRes) ? (unsigned)(lane + 64 * i) : stv[i]] : 0u;
+                                    for (int i = 0; i < NR; ++i) g[i] = S[(stv[i] & kRes) ? (unsigned)(lane + 64 * i) : stv[i]];
 #pragma unroll
-                                for (int i = 0; i < kRows; ++i) {
-                                    if (i < R && (stv[i] & kRes) == 0u) {
-                                        stv[i] = g[i];
-                                        S[lane + 64 * i] = g[i];
+                                    for (int i = 0; i < NR; ++i) {
+                                        if ((stv[i] & kRes) == 0u) {
+                                            stv[i] = g[i];
+                                            S[lane + 64 * i] = g[i];
+                                        }
                                     }
                                 }
-                            }
-                            LTIME_D(23);  // rounds of pointer doubling
+                                LTIME_D(23);  // rounds of pointer doubling
 #pragma unroll
-                            for (int i = 0; i < kRows; ++i) {
-                                const uint32_t j = (uint32_t)(lane + 64 * i);
-                                if (i < R) {
+                                for (int i = 0; i < NR; ++i) {
+                                    const uint32_t j = (uint32_t)(lane + 64 * i);
                                     S[j] = 0u;
                                     if (j < T) L.ring[(A + j) & kRingMask] = (uint8_t)stv[i];
                                 }
-                            }
+                            };
+                            if (T <= 64u * (uint32_t)(kRows / 2)) rows(std::integral_constant<int, kRows / 2>{});
+                            else rows(std::integral_constant<int, kRows>{});
                         } else if (mark == 1u || mark == 2u) {
                             const uint32_t at2 = A + off;
                             L.ring[at2 & kRingMask] = (uint8_t)(tok >> 8);
