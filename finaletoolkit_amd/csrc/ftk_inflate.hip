@@ -849,8 +849,11 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     lanes_vis[128 + lane] = (uint32_t)first_valid;
                     const uint32_t new_bp = (uint32_t)__builtin_amdgcn_readlane((int)my_end, n_lanes - 1);
                     const bool end_stop = ((stops >> (n_lanes - 1)) & 1ull) != 0ull;
-                    // (tokens are written by one lane and read by another: the stores out to L2, the loads from there)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    // (tokens are written by one lane and read by another lane OF THE SAME WAVE: a workgroup-scope release /
+                    // acquire pair.  The agent-scope pair of the first version made every super-window write back its
+                    // XCD's L2 - buffer_wbl2 - and its token loads bypass the cache)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     LTIME(12);
                     auto fetch = [&](int base) -> unsigned {
                         const int t = base + lane;
@@ -864,7 +867,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         const int loc = t - (int)lanes_vis[lo], nc = (int)lanes_vis[64 + lo];
                         const uint32_t* src = loc < nc ? lane_tok + 64 * kLaneTok + 64 * loc + lo
                                                        : lane_tok + 64 * ((int)lanes_vis[128 + lo] + (loc - nc)) + lo;
-                        return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     };
                     // ---- (D) 64 tokens at a time: places from a prefix sum, literals stored, matches copied in order ----
                     bool fail_d = false;
@@ -1103,6 +1106,9 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         }
 #endif
                         LTIME_D(19);  // literals and matches
+                        // (the next group's tokens are waited for HERE, in front of the write-behind: memory operations are
+                        // counted off in order, so behind it the wait would also be for the granule's stores to be acknowledged)
+                        asm volatile("" : "+v"(tok_next));
                         advance(T);
                         LTIME_D(20);  // write-behind
                         base += took;
