@@ -837,16 +837,15 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                 LSTAT(7, stops ? 1 : 0);
                 LSTAT(8, (unsettled && (!stops || __ffsll((unsigned long long)unsettled) - 1 < __ffsll((unsigned long long)stops))) ? 1 : 0);
                 if (n_lanes >= 1) {
-                    // ---- (C) where the valid tokens are: every lane's count, first valid token and catch-up count go to
-                    // LDS (the visited masks are done with), so that any lane can find the owner of the t-th token of the
-                    // super-window and fetch it from that lane's region - no copy into one stream
+                    // ---- (C) where the valid tokens are: every lane keeps its count, its first valid token and its catch-up
+                    // count in registers; fetch() finds the owner of the t-th token of the super-window and loads the token
+                    // from the owner's column - no copy into one stream
                     const int nvalid = lane < n_lanes ? ncatch + (ntok - first_valid) : 0;
                     const int incl = wave_incl_scan(nvalid);
                     const int n_tokens = __builtin_amdgcn_readlane(incl, 63);
+                    const int my_first = incl - nvalid;                  // tokens in front of this lane's
                     LSTAT(2, n_tokens);
-                    lanes_vis[lane] = (uint32_t)(incl - nvalid);        // tokens in front of this lane's
-                    lanes_vis[64 + lane] = (uint32_t)ncatch;
-                    lanes_vis[128 + lane] = (uint32_t)first_valid;
+                    lanes_vis[lane] = 0u;                                // (the slots fetch() drops owners in)
                     const uint32_t new_bp = (uint32_t)__builtin_amdgcn_readlane((int)my_end, n_lanes - 1);
                     const bool end_stop = ((stops >> (n_lanes - 1)) & 1ull) != 0ull;
                     // (tokens are written by one lane and read by another lane OF THE SAME WAVE: a workgroup-scope release /
@@ -855,18 +854,32 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     LTIME(12);
+                    // The owners of tokens base .. base + 63.  The owner of `base` is the last lane with tokens that starts at
+                    // or in front of it - one ballot; every lane whose tokens start further inside drops its number at the
+                    // slot of its first token, and a running maximum hands it to the slots behind (the lanes' starts rise
+                    // with their numbers); the owner's numbers come over ds_bpermute.  One LDS round trip where the
+                    // bisection of the first version took six, one after the other.
                     auto fetch = [&](int base) -> unsigned {
                         const int t = base + lane;
+                        const uint64_t le = __ballot(nvalid > 0 && my_first <= base);
+                        const int o0 = le ? 63 - __clzll((long long)le) : 0;
+                        const int rel = my_first - base;
+                        if (nvalid > 0 && rel > 0 && rel < 64) lanes_vis[rel] = (uint32_t)lane;
+                        unsigned own = lanes_vis[lane];
+                        lanes_vis[lane] = 0u;
+                        own = max(own, (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0x111, 0xf, 0xf, false));
+                        own = max(own, (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0x112, 0xf, 0xf, false));
+                        own = max(own, (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0x114, 0xf, 0xf, false));
+                        own = max(own, (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0x118, 0xf, 0xf, false));
+                        own = max(own, (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0x142, 0xa, 0xf, false));
+                        own = max(own, (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0x143, 0xc, 0xf, false));
+                        const int lo = max((int)own, o0);
+                        const int o_first = __builtin_amdgcn_ds_bpermute(lo << 2, my_first);
+                        const int nc = __builtin_amdgcn_ds_bpermute(lo << 2, ncatch);
+                        const int fv = __builtin_amdgcn_ds_bpermute(lo << 2, first_valid);
                         if (t >= n_tokens) return 0u;
-                        int lo = 0, hi = n_lanes - 1;  // the last lane whose tokens start at or in front of t
-#pragma unroll
-                        for (int step = 0; step < 6; ++step) {
-                            const int mid = (lo + hi + 1) >> 1;
-                            if ((int)lanes_vis[mid] <= t) lo = mid; else hi = mid - 1;
-                        }
-                        const int loc = t - (int)lanes_vis[lo], nc = (int)lanes_vis[64 + lo];
-                        const uint32_t* src = loc < nc ? lane_tok + 64 * kLaneTok + 64 * loc + lo
-                                                       : lane_tok + 64 * ((int)lanes_vis[128 + lo] + (loc - nc)) + lo;
+                        const int loc = t - o_first;
+                        const uint32_t* src = loc < nc ? lane_tok + 64 * kLaneTok + 64 * loc + lo : lane_tok + 64 * (fv + (loc - nc)) + lo;
                         return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     };
                     // ---- (D) 64 tokens at a time: places from a prefix sum, literals stored, matches copied in order ----
