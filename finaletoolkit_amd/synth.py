@@ -312,7 +312,7 @@ def genome_bam_fragments(k: int, size: int, depth: float = 60.0, torch=None, dev
 
 
 def genome_bam_expected(k: int, size: int, depth: float = 60.0, torch=None, dev=None):
-    """What the decoder must hand out for contig ``k``: the fragments with their read1 span (``oracle.scale_check``)."""
+    """What the decoder must hand out for contig ``k``: the fragments with their read1 span (what the tests' checker compares with)."""
     s, e, q, st = genome_bam_fragments(k, size, depth, torch, dev)
     r1 = np.where(st == 1, s, e - GENOME_BAM_READ).astype(np.int32)
     return dict(s=s, e=e, q=q, st=st, r1s=r1, r1e=(r1 + GENOME_BAM_READ).astype(np.int32), n=len(s))
