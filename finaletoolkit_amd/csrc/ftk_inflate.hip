@@ -724,7 +724,6 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     __hip_atomic_fetch_or(&lanes_vis[(rel >> 5) * 64u + (unsigned)lane], 1u << (rel & 31u), __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
                 };
-                auto vis_get = [&](unsigned rel) -> bool { return (lanes_vis[(rel >> 5) * 64u + (unsigned)lane] >> (rel & 31u)) & 1u; };
                 auto vis_below = [&](unsigned rel) -> int {  // visited positions in front of `rel`
                     int n = 0;
                     for (unsigned k = 0; k <= (rel >> 5) && k < (unsigned)kVisWords; ++k) {
@@ -787,14 +786,18 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         if (round == 0) LACC(l_trips_b1, 1);
                         if (go) {
                             const uint32_t rel = q - p0;  // (c >= p0: the lane in front ran to the end of its stretch or beyond)
-                            if (rel < (uint32_t)kLaneBits && vis_get(rel)) {
+                            // (the symbol at q is decoded whether or not q turns out to be a visited position: the mask word
+                            // and the table entries then come in ONE LDS round trip, not one behind the other)
+                            const bool inside = rel < (uint32_t)kLaneBits;
+                            const unsigned visw = lanes_vis[((inside ? rel : 0u) >> 5) * 64u + (unsigned)lane];
+                            unsigned nb, tok;
+                            decode_at(W, q, nb, tok, true);
+                            if (inside && ((visw >> (rel & 31u)) & 1u)) {
                                 joined = true;
                                 go = false;
                             } else if (q >= sub_end) {
                                 go = false;
                             } else {
-                                unsigned nb, tok;
-                                decode_at(W, q, nb, tok, true);
                                 if (nb == 0u || nc == kLaneCatch) {
                                     cstop = true;
                                     go = false;
