@@ -2355,6 +2355,12 @@ int ftk_comm_create(ftk_ctx* ctx, int rank, int world, const char* id_hex_or_pat
         ftk_comm_destroy(c);
         return fail(ctx, FTK_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, a->GetErrorString ? a->GetErrorString(r) : "RCCL error");
     }
+    // (every rank has read the id by now - the initialisation is collective - so the rendezvous file goes at once: a job
+    // that dies later leaves nothing for the next one to trip over)
+    if (!c->id_path.empty()) {
+        (void)remove(c->id_path.c_str());
+        c->id_path.clear();
+    }
     *out = c;
     return FTK_OK;
 }
