@@ -2279,10 +2279,34 @@ int comm_fork(ftk_comm* c) {
 
 }  // namespace
 
+// RCCL announces itself on STDOUT when a communicator comes up ("RCCL version : ...", five lines) - in the way of a host
+// whose stdout is its result (bench.py's one JSON line).  While the library is inside RCCL's set-up calls, file descriptor
+// 1 points where 2 points; FTK_COMM_BANNER=1 leaves it alone.
+struct QuietStdout {
+    int saved = -1;
+    QuietStdout() {
+        static const bool keep = getenv("FTK_COMM_BANNER") && atoi(getenv("FTK_COMM_BANNER")) != 0;
+        if (keep) return;
+        fflush(stdout);
+        saved = dup(1);
+        if (saved >= 0 && dup2(2, 1) < 0) {
+            close(saved);
+            saved = -1;
+        }
+    }
+    ~QuietStdout() {
+        if (saved < 0) return;
+        fflush(stdout);
+        (void)dup2(saved, 1);
+        close(saved);
+    }
+};
+
 extern "C" {
 
 int ftk_comm_unique_id(char* hex_out) {
     if (!hex_out) return fail(nullptr, FTK_ERR_INVALID, "hex_out is NULL");
+    QuietStdout quiet;
     RcclApi* a = rccl();
     if (!a) return fail(nullptr, FTK_ERR_NO_DEVICE, "librccl could not be loaded");
     ncclUniqueId id;
@@ -2296,6 +2320,7 @@ int ftk_comm_create(ftk_ctx* ctx, int rank, int world, const char* id_hex_or_pat
     *out = nullptr;
     if (world < 1 || rank < 0 || rank >= world) return fail(ctx, FTK_ERR_INVALID, "bad rank %d / world %d", rank, world);
     if (!id_hex_or_path && world > 1) return fail(ctx, FTK_ERR_INVALID, "ranks of a job need a common id (hex digits or a file path)");
+    QuietStdout quiet;
     RcclApi* a = rccl();
     if (!a) return fail(ctx, FTK_ERR_NO_DEVICE, "librccl could not be loaded (dlopen librccl.so.1)");
     HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -332,6 +332,9 @@ __device__ unsigned long long g_block_ticks[2 * 65536];
 // output, literal tokens store their bytes, matches copy in stream order - what the windows do behind their chain.
 // A lane stops at anything the tables do not resolve in one look-up (end of block, a code longer than a table's root, a
 // bit pattern that is no code): the super-window ends in front of it and ONE window of the older kind takes it.
+#ifndef FTK_LANES_SINGLE
+#define FTK_LANES_SINGLE 1  // the lanes on their way into step take a pair of literals one at a time (0: A/B builds)
+#endif
 #ifndef FTK_LANES_VEC_D
 #define FTK_LANES_VEC_D 1   // (D) resolves a group's bytes side by side; 0: its matches one after the other (A/B builds)
 #endif
@@ -791,7 +794,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                             const bool inside = rel < (uint32_t)kLaneBits;
                             const unsigned visw = lanes_vis[((inside ? rel : 0u) >> 5) * 64u + (unsigned)lane];
                             unsigned nb, tok;
-                            decode_at(W, q, nb, tok, true);
+                            decode_at(W, q, nb, tok, FTK_LANES_SINGLE != 0);
                             if (inside && ((visw >> (rel & 31u)) & 1u)) {
                                 joined = true;
                                 go = false;

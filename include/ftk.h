@@ -557,8 +557,9 @@ int ftk_bigwig_fixedstep_sections(uint32_t chrom_id, const int64_t* iv_start, co
  * ftk_comm_create: rank `rank` of `world` joins the job's communicator on ctx's device.  `id_hex_or_path` is what the
  * ranks have in common: the 256 hex digits of an RCCL unique id (ftk_comm_unique_id on one rank, handed to the others
  * by the host's own means), or a FILE PATH all ranks can reach -- rank 0 creates the id and writes it there (atomic
- * rename), the others wait for it (FTK_COMM_TIMEOUT_S, default 600), rank 0's ftk_comm_destroy removes it.  NULL is
- * accepted for world == 1.  A collective runs on the communicator's own HIP stream behind the work the ctx stream
+ * rename), the others wait for it (FTK_COMM_TIMEOUT_S, default 600), rank 0 removes it as soon as the communicator is
+ * up (every rank has read it by then).  RCCL's start-up banner is kept off stdout (FTK_COMM_BANNER=1 lets it through).
+ * NULL is accepted for world == 1.  A collective runs on the communicator's own HIP stream behind the work the ctx stream
  * holds at the call, so later launches on the ctx stream overlap it.  Buffers may be host or device memory: with a
  * host buffer the call returns when the result is there; with device buffers it returns at once and ftk_comm_join
  * makes the ctx stream wait for the result (no host wait).  Every rank must make the same calls in the same order. */

@@ -114,7 +114,9 @@ def test_rccl_communicator_through_the_c_abi_one_rank(tmp_path):
             r, w = C.c_int(-1), C.c_int(-1)
             assert lib.ftk_comm_size(h, C.byref(r), C.byref(w)) == L.FTK_OK and (r.value, w.value) == (0, 1)
             if ident is not None and len(ident) != 256:
-                assert len(open(ident.decode()).read()) == 256  # rank 0 wrote the id for the others
+                # rank 0 wrote the id for the others and took the file away again once the communicator was up (every
+                # rank has read it by then): nothing is left for a later job to trip over
+                assert not os.path.exists(ident.decode()) and not os.listdir(os.path.dirname(ident.decode()))
             send = np.arange(1000, dtype=np.int64) * 3
             recv = np.zeros(1000, np.int64)
             assert lib.ftk_allgather_i64(h, L.ptr(send), 1000, L.ptr(recv)) == L.FTK_OK
