@@ -333,7 +333,7 @@ __device__ unsigned long long g_block_ticks[2 * 65536];
 // A lane stops at anything the tables do not resolve in one look-up (end of block, a code longer than a table's root, a
 // bit pattern that is no code): the super-window ends in front of it and ONE window of the older kind takes it.
 #ifndef FTK_LANES_SINGLE
-#define FTK_LANES_SINGLE 1  // the lanes on their way into step take a pair of literals one at a time (0: A/B builds)
+#define FTK_LANES_SINGLE 0  // 1: the lanes on their way into step take a pair of literals one at a time (measured: 2 % slower)
 #endif
 #ifndef FTK_LANES_VEC_D
 #define FTK_LANES_VEC_D 1   // (D) resolves a group's bytes side by side; 0: its matches one after the other (A/B builds)
@@ -658,10 +658,10 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         W.wi += adv;
                     }
                 };
-                // (`single`: a pair of literals is taken one at a time - the chain then visits EVERY symbol start.  The
-                // lanes on their way into step (B) do: a chain that pairs its literals the other way round than the chain
-                // it is to meet - literal-heavy input, BAM records - is in step with it symbol by symbol and would still
-                // never land on one of its starts)
+                // (`single`: a pair of literals is taken one at a time - the chain then visits EVERY symbol start.  Tried for
+                // the lanes on their way into step (B), on the idea that a chain which pairs its literals the other way
+                // round than the chain it is to meet would be in step with it symbol by symbol and still never land on one
+                // of its starts; the trips of (B) did not change and the launches were 2 % slower: FTK_LANES_SINGLE=0)
                 auto decode_at = [&](const InWin& W, uint32_t at, unsigned& nb, unsigned& tok, bool single) {
 #if FTK_LANES_LDS_INPUT
                     const uint32_t wr = (at >> 5) - in_w0;  // (at most 64 * kLaneBits / 32 + 2: the overhang is staged too)
