@@ -429,14 +429,26 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
     if (LANES) {
         // a slot nobody holds: there are as many as the chip can hold waves, so one is free; probing starts at a place
         // of the block's own
+        // (a wave that finds none in two rounds over all of them - which the slot count rules out - does not spin on:
+        // it decodes its block with windows of the older kind alone)
         unsigned s0 = ((unsigned)blk * 2654435761u) >> 20;  // 12 bits
+        int got = 0;
         if (lane == 0) {
-            for (;; s0 = (s0 + 1u) & (unsigned)(kLaneSlots - 1))
-                if (atomicCAS(&lane_scratch->busy[s0], 0u, 1u) == 0u) break;
+            for (int tries = 0; tries < 2 * kLaneSlots; ++tries, s0 = (s0 + 1u) & (unsigned)(kLaneSlots - 1))
+                if (atomicCAS(&lane_scratch->busy[s0], 0u, 1u) == 0u) {
+                    got = 1;
+                    break;
+                }
         }
-        lane_slot = UNI(s0);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        lane_tok = lane_scratch->words + (size_t)lane_slot * kLaneSlotWords;
+#ifdef FTK_LANES_NO_SLOT  // (test builds: every wave takes the path of a wave that found no slot)
+        if (got && lane == 0) atomicExch(&lane_scratch->busy[s0], 0u);
+        got = 0;
+#endif
+        if (UNI(got)) {
+            lane_slot = UNI(s0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            lane_tok = lane_scratch->words + (size_t)lane_slot * kLaneSlotWords;
+        }
     }
 #ifdef FTK_INFLATE_TIMING
     if (lane == 0 && blk < 65536) g_block_ticks[2 * blk] = wall_clock64();
@@ -586,7 +598,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
             PROF(7, lane_dep);  // (whatever ran since the last mark: the serial path, the loop's bookkeeping)
             BTIME(2);  // (windows of the older kind, the serial path)
 #if FTK_INFLATE_WINDOWED
-            if (LANES && !lanes_rest) {
+            if (LANES && lane_tok != nullptr && !lanes_rest) {
                 if (b_moved) {
                     bp = b.bitpos();
                     b_moved = false;
@@ -1553,7 +1565,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
             status->reason = err;
         }
     }
-    if (LANES) {
+    if (LANES && lane_slot >= 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (lane == 0) atomicExch(&lane_scratch->busy[lane_slot], 0u);
     }
