@@ -339,9 +339,9 @@ __device__ unsigned long long g_block_ticks[2 * 65536];
 #define FTK_LANES_VEC_D 1   // (D) resolves a group's bytes side by side; 0: its matches one after the other (A/B builds)
 #endif
 #ifndef FTK_LANE_BITS
-#define FTK_LANE_BITS 512
-#define FTK_LANE_TOK 176
-#define FTK_LANE_CATCH 80
+#define FTK_LANE_BITS 768   // (512 / 640 / 768 / 896 / 1024 measured with checkpoints: fragment rows the same to 1 % up to 768 and
+#define FTK_LANE_TOK 256    // 4-5 % slower beyond, BAM records 5.27 / 5.06 / 5.03 / 5.15 / 5.19 ms per chip-filling launch)
+#define FTK_LANE_CATCH 96
 #endif
 // Bytes a group of (D) may produce.  With the group's bytes resolved side by side nothing is stored before every source has
 // been read, so a window's kWinCap does not bind; what does: a far match's sources must have been written behind (byte j of
@@ -356,12 +356,20 @@ static_assert(kLaneCap % 64 == 0 && kLaneCap <= kFarDist - kGran + 2 && kLaneCap
 #else
 constexpr int kLaneCap = kWinCap;
 #endif
+#ifndef FTK_LANES_CP
+#define FTK_LANES_CP 1  // what a lane remembers of the symbol starts of (A): 1 a checkpoint per 32-bit word, 0 a mask of every bit
+#endif
 constexpr int kLaneBits = FTK_LANE_BITS;          // bits of input per lane and super-window
 constexpr int kLaneTok = FTK_LANE_TOK;            // tokens a lane may write in (A); more ends its stretch early
 constexpr int kLaneCatch = FTK_LANE_CATCH;        // ... and on its way into step in (B)
 constexpr int kLaneRounds = 6;                    // passes of (B) before the super-window is cut at the first unsettled lane
 constexpr int kLaneSlots = 4096;                  // scratch slots: more than the chip holds of these waves (256 CUs x <= 13)
 constexpr size_t kLaneSlotWords = 64 * kLaneTok + 64 * kLaneCatch;  // a lane's tokens of (A), and of its way into step
+// LDS of the loop beside the tables: the symbol starts of (A) - a mask of the stretch's bits per lane, or a 16-bit checkpoint
+// per 32-bit word of it - and, in (C) / (D), the owner slots (words 0..63) and a group's rows of byte states (from word 192)
+constexpr int kLaneStartWords = FTK_LANES_CP ? 64 * (kLaneBits / 32) / 2 : 64 * (kLaneBits / 32);
+constexpr int kLaneLdsWords = kLaneStartWords > 192 + (kLaneCap / 64) * 64 ? kLaneStartWords : 192 + (kLaneCap / 64) * 64;
+static_assert(kLaneTok < 1024, "a checkpoint holds a token number in ten bits");
 struct LaneScratch {
     unsigned busy[kLaneSlots];
     uint32_t words[1];  // kLaneSlots x kLaneSlotWords
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                                                           uint8_t* __restrict__ out, InflateStatus* __restrict__ status,
                                                           LaneScratch* __restrict__ lane_scratch) {
     __shared__ WaveLds L;
-    __shared__ uint32_t lanes_vis[LANES ? 64 * (kLaneBits / 32) : 1];
+    __shared__ uint32_t lanes_vis[LANES ? kLaneLdsWords : 1];
 #ifndef FTK_LANES_LDS_INPUT
 #define FTK_LANES_LDS_INPUT 0
 #endif
@@ -730,23 +738,29 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                 // by lane - [l][k] - every trip wrote to 64 cache lines, and the address unit was busy with little else)
                 uint32_t* spec = lane_tok + lane;
                 uint32_t* catchup = lane_tok + 64 * kLaneTok + lane;
-                // the bit positions a lane has taken for symbol starts: a mask of its stretch, in LDS (word k of lane l at
-                // [k][l]: a wave's accesses fall into different banks)
-                constexpr int kVisWords = kLaneBits / 32;
+                // What a lane remembers of the positions it took for symbol starts, in LDS.  FTK_LANES_CP: a CHECKPOINT per
+                // 32-bit word of the stretch - the first start inside the word (5 bits, + 1 so that 0 says none) and the
+                // number of the token that starts there, 16 bits at [word][lane].  A chain that has met the chain of (A)
+                // walks its starts from there on, so it is recognised at the first start of the NEXT word at the latest,
+                // and the tokens it wrote in between are the same tokens: nothing is lost but a few trips.  Half the LDS
+                // of a mask of every bit (which also had to be counted through to number a token), so that a stretch can
+                // be 1 024 bits: the rounds of (B) cost what they cost per STRETCH, not per bit.
+                uint16_t* const cp16 = reinterpret_cast<uint16_t*>(lanes_vis);
 #pragma unroll
-                for (int k = 0; k < kVisWords; ++k) lanes_vis[k * 64 + lane] = 0u;
-                auto vis_set = [&](unsigned rel) {  // (ds_or_b32: one LDS instruction, nothing to wait for)
+                for (int k = 0; k < kLaneStartWords / 64; ++k) lanes_vis[k * 64 + lane] = 0u;
+                auto vis_set = [&](unsigned rel) {  // (FTK_LANES_CP=0: ds_or_b32, one LDS instruction, nothing to wait for)
                     __hip_atomic_fetch_or(&lanes_vis[(rel >> 5) * 64u + (unsigned)lane], 1u << (rel & 31u), __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
                 };
                 auto vis_below = [&](unsigned rel) -> int {  // visited positions in front of `rel`
                     int n = 0;
-                    for (unsigned k = 0; k <= (rel >> 5) && k < (unsigned)kVisWords; ++k) {
+                    for (unsigned k = 0; k <= (rel >> 5) && k < (unsigned)(kLaneBits / 32); ++k) {
                         const unsigned w = lanes_vis[k * 64u + (unsigned)lane];
                         n += __popc(k < (rel >> 5) ? w : (w & ((1u << (rel & 31u)) - 1u)));
                     }
                     return n;
                 };
+                unsigned last_word = ~0u;  // (FTK_LANES_CP) the word of the stretch the last checkpoint was written for
                 uint32_t pos = p0;
                 int ntok = 0;
                 bool stopped = false;               // the chain ended at something a window of the older kind must take
@@ -764,7 +778,13 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                             stopped = true;
                             active = false;
                         } else {
-                            vis_set(pos - p0);
+                            if (FTK_LANES_CP) {
+                                const unsigned rel = pos - p0, word = rel >> 5;
+                                if (word != last_word) cp16[word * 64u + (unsigned)lane] = (uint16_t)(((unsigned)ntok << 6) | ((rel & 31u) + 1u));
+                                last_word = word;
+                            } else {
+                                vis_set(pos - p0);
+                            }
                             pos += nb;
                             active = pos < sub_end;
                             // (the window's loads BEFORE the token's store: memory operations are counted off in order, so a
@@ -793,6 +813,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     uint32_t q = c;
                     int nc = 0;
                     bool joined = false, cstop = false, go = need;
+                    int join_tok = 0;  // (FTK_LANES_CP) the number of the token of (A) the lane landed on
                     if (!FTK_LANES_LDS_INPUT && need) win_open(W, c);
                     LACC(l_rounds, 1);
                     if (round == 1) LACC(l_need2, __popcll(unsettled));
@@ -804,11 +825,13 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                             // (the symbol at q is decoded whether or not q turns out to be a visited position: the mask word
                             // and the table entries then come in ONE LDS round trip, not one behind the other)
                             const bool inside = rel < (uint32_t)kLaneBits;
-                            const unsigned visw = lanes_vis[((inside ? rel : 0u) >> 5) * 64u + (unsigned)lane];
+                            const unsigned word = (inside ? rel : 0u) >> 5;
+                            const unsigned visw = FTK_LANES_CP ? (unsigned)cp16[word * 64u + (unsigned)lane] : lanes_vis[word * 64u + (unsigned)lane];
                             unsigned nb, tok;
                             decode_at(W, q, nb, tok, FTK_LANES_SINGLE != 0);
-                            if (inside && ((visw >> (rel & 31u)) & 1u)) {
+                            if (inside && (FTK_LANES_CP ? (visw & 63u) == (rel & 31u) + 1u : ((visw >> (rel & 31u)) & 1u) != 0u)) {
                                 joined = true;
+                                join_tok = (int)(visw >> 6);
                                 go = false;
                             } else if (q >= sub_end) {
                                 go = false;
@@ -829,7 +852,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         cur_start = c;
                         ncatch = nc;
                         if (joined) {
-                            first_valid = vis_below(q - p0);
+                            first_valid = FTK_LANES_CP ? join_tok : vis_below(q - p0);
                             my_end = spec_end;
                             my_stop = spec_stop;
                         } else {
@@ -967,7 +990,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                             uint32_t* const S = lanes_vis + 192;      // (words 0..191 hold (C)'s arrays, which fetch() reads)
                             constexpr unsigned kRes = 0x80000000u;
                             constexpr int kRows = kLaneCap / 64;
-                            static_assert(192 + kRows * 64 <= 64 * (kLaneBits / 32), "the byte states of a group must fit behind (C)'s arrays");
+                            static_assert(192 + kRows * 64 <= kLaneLdsWords, "the byte states of a group must fit behind the owner slots");
                             if (mark) S[off] = (off << 17) | (mark == 3u ? (0x10000u | (mdist - 1u)) : ((tok >> 8) & 0xffffu));
                             const bool any_far = __ballot(mark == 3u && mdist > (unsigned)kFarDist) != 0ull;
                             // (the rows are worked on without asking row by row whether the group reaches them - a row behind
