@@ -2986,17 +2986,17 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
     // page-locked memory.  FTK_DEVICE_INFLATE=0 keeps the inflate on the host threads (libdeflate / zlib).
     static const bool dev_inflate_env = !(getenv("FTK_DEVICE_INFLATE") && atoi(getenv("FTK_DEVICE_INFLATE")) == 0);
     const bool dev_inflate = dev_inflate_env && !host_inflate_only;
-    // The host threads inflate pieces beside the GPU: the chip turns fragment rows over at ~30 GB/s of text (one
-    // dependent Huffman chain per block), 14 threads manage ~19 GB/s and have nothing else to do while
-    // the rows are parsed on the device; a host piece's text goes up in one DMA before its parse.  They take the next
-    // piece whenever their previous one is done (one job at a time), so the split follows the two rates.
-    // FTK_TEXT_HOST_SHARE=<n>: every n-th piece instead (0: none, 1: as the threads are free = the default).  Only
-    // with enough threads to keep up (a rank of eight on a 16-core quota has two).
+    // The host threads CAN inflate pieces beside the GPU (a host piece's text goes up in one DMA before its parse; they
+    // take the next piece whenever their previous one is done, so the split follows the two rates).  That was worth 18 %
+    // when the chip turned fragment rows over at ~30 GB/s (round 3) and 3-5 % at 87 GB/s (round 4); with round 5's
+    // symbol loop (185 GB/s) the pieces they take arrive LATER than the GPU would have had them:
+    // whole-genome pass 0.089-0.109 s with, 0.078-0.089 s without (tools/env_ab.sh text).  Off by default since.
+    // FTK_TEXT_HOST_SHARE=<n>: 0 none (the default), 1 as the threads are free, n > 1 every n-th piece.
     static const int host_share_env = [] {
         const char* e = getenv("FTK_TEXT_HOST_SHARE");
         return e ? atoi(e) : -1;
     }();
-    const int host_share = !dev_inflate ? 0 : host_share_env >= 0 ? host_share_env : (n_threads >= 8 ? 1 : 0);
+    const int host_share = !dev_inflate ? 0 : host_share_env >= 0 ? host_share_env : 0;
     const int kLag = host_share > 0 ? kHostLag + 1 : 2;
     struct PieceMeta {
         bool on_host = false, eof = false, has_prev = false, back_done = true;
@@ -4018,7 +4018,10 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         const char* e = getenv("FTK_BAM_HOST_SHARE");
         return e ? atoi(e) : -1;
     }();
-    const int host_share = host_share_env >= 0 ? host_share_env : (n_threads >= 8 ? 6 : 0);
+    // (round 5, with the lane-parallel inflate loop - tools/env_ab.sh bam, five runs each on one box, warm passes of the
+    // 5.9 GB file: none 0.238-0.251 s, every 32nd 0.221-0.241, every 16th 0.214-0.225, 12th 0.253-0.258, 8th 0.251-0.281,
+    // 6th - the default of round 4 - 0.234-0.249, 4th 0.31-0.33)
+    const int host_share = host_share_env >= 0 ? host_share_env : (n_threads >= 8 ? 16 : 0);
     std::future<int> host_job[kSlots];
     struct JobGuard {  // no job outlives the buffers it works on
         std::future<int>* j;
