@@ -240,7 +240,7 @@ __device__ __forceinline__ void build_pairs(WaveLds& L, int lane) {
                 v = l1 | (1u << 5) | (s1 << 8);
                 const unsigned t2 = one[e >> l1];  // the bits behind the first code, zero-extended: valid for a code
                 const unsigned l2 = t2 & 15u, s2 = t2 >> 4;  // that fits into what is left of the root bits
-                if (l2 && l1 + l2 <= (unsigned)kLitRoot && s2 < 256u) v = (l1 + l2) | (2u << 5) | (s1 << 8) | (s2 << 20) | (l1 << 28);  // (bits 28..31: the first code's own length, for decoders that step one literal at a time)
+                if (l2 && l1 + l2 <= (unsigned)kLitRoot && s2 < 256u) v = (l1 + l2) | (2u << 5) | (s1 << 8) | (s2 << 20);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -316,58 +316,46 @@ __device__ unsigned long long g_block_ticks[2 * 65536];
 #else
 #define FTK_INFLATE_OCC
 #endif
-// ---- lane-parallel symbol decoding (round 5; template flag LANES, inflate_launch's lane_scratch) --------------------
+// ---- lane-parallel symbol decoding (round 5; template flag LANES, inflate_launch's lane_scratch) ----------
 // The windows above spend their vector work on 64 bit offsets of which ~9 start a symbol, and the chain through those
 // starts is serial.  Here the lanes take DIFFERENT stretches of the input instead: a super-window is 64 stretches of
 // kLaneBits bits; lane l decodes the symbols of its stretch one after the other, all lanes in lock step - 64 symbols per
 // trip through the loop.  Only lane 0 knows where its first symbol starts; the others start at their stretch's first bit,
 // which is most likely the middle of a symbol, and rely on what prefix codes do: a decoder that starts anywhere falls
 // into step with the true symbol sequence after a few symbols.  So: (A) every lane decodes its stretch from its first
-// bit, noting which bit positions it took for symbol starts and writing its symbols as 32-bit tokens (literals or
-// length + distance) to a scratch region; (B) lane l's TRUE first symbol starts where lane l - 1's last one ends, so the
-// lanes pass their end positions to the right and every lane decodes again from its true start until it lands on a
-// position it has visited - from there on its tokens of (A) are the right ones - repeated while any end position
-// still moves (a lane that never falls into step inside its stretch moves its end and so its right neighbour's start);
-// (C) the valid tokens are laid end to end; (D) 64 tokens at a time, a prefix sum gives every token its place in the
-// output, literal tokens store their bytes, matches copy in stream order - what the windows do behind their chain.
-// A lane stops at anything the tables do not resolve in one look-up (end of block, a code longer than a table's root, a
-// bit pattern that is no code): the super-window ends in front of it and ONE window of the older kind takes it.
-#ifndef FTK_LANES_SINGLE
-#define FTK_LANES_SINGLE 0  // 1: the lanes on their way into step take a pair of literals one at a time (measured: 2 % slower)
-#endif
-#ifndef FTK_LANES_VEC_D
-#define FTK_LANES_VEC_D 1   // (D) resolves a group's bytes side by side; 0: its matches one after the other (A/B builds)
-#endif
+// bit, noting the positions it took for symbol starts (a checkpoint per 32-bit word, LDS) and writing its symbols as
+// 32-bit tokens (literals or length + distance) to a scratch region; (B) lane l's TRUE first symbol starts where lane
+// l - 1's last one ends, so the lanes pass their end positions to the right and every lane decodes again from its true
+// start until it lands on a position it has visited - from there on its tokens of (A) are the right ones - repeated
+// while any end position still moves (a lane that never falls into step inside its stretch moves its end and so its right
+// neighbour's start); (C) every lane keeps where its valid tokens are, fetch() finds the owner of the t-th token; (D) 64
+// tokens at a time, a prefix sum gives every token its place in the output and the group's BYTES are resolved side by
+// side (keys at symbol starts, running maximum, pointer doubling - see there).
+// A lane stops at anything the tables do not resolve in one look-up (end of block, a bit pattern that is no code): the
+// super-window ends in front of it and ONE window of the older kind takes it.
 #ifndef FTK_LANE_BITS
-#define FTK_LANE_BITS 768   // (512 / 640 / 768 / 896 / 1024 measured with checkpoints: fragment rows the same to 1 % up to 768 and
-#define FTK_LANE_TOK 256    // 4-5 % slower beyond, BAM records 5.27 / 5.06 / 5.03 / 5.15 / 5.19 ms per chip-filling launch)
+#define FTK_LANE_BITS 768   // (512 / 640 / 768 / 896 / 1024 measured: fragment rows the same to 1 % up to 768 and 4-5 % slower
+#define FTK_LANE_TOK 256    // beyond, BAM records 5.27 / 5.06 / 5.03 / 5.15 / 5.19 ms per chip-filling launch)
 #define FTK_LANE_CATCH 96
 #endif
 // Bytes a group of (D) may produce.  With the group's bytes resolved side by side nothing is stored before every source has
 // been read, so a window's kWinCap does not bind; what does: a far match's sources must have been written behind (byte j of
 // the group reads A + j - d < A + j - kFarDist, and everything in front of A - (kGran - 1) is in HBM: j < kFarDist - kGran
-// + 2), and the write-behind takes one granule per group (T <= kGran).
-#if FTK_LANES_VEC_D
+// + 2), and the write-behind takes one granule per group (T <= kGran).  256 .. 640 measured: 384 is the flat minimum.
 #ifndef FTK_LANE_CAP
 #define FTK_LANE_CAP 384
 #endif
 constexpr int kLaneCap = FTK_LANE_CAP;
 static_assert(kLaneCap % 64 == 0 && kLaneCap <= kFarDist - kGran + 2 && kLaneCap <= kGran, "see above");
-#else
-constexpr int kLaneCap = kWinCap;
-#endif
-#ifndef FTK_LANES_CP
-#define FTK_LANES_CP 1  // what a lane remembers of the symbol starts of (A): 1 a checkpoint per 32-bit word, 0 a mask of every bit
-#endif
 constexpr int kLaneBits = FTK_LANE_BITS;          // bits of input per lane and super-window
 constexpr int kLaneTok = FTK_LANE_TOK;            // tokens a lane may write in (A); more ends its stretch early
 constexpr int kLaneCatch = FTK_LANE_CATCH;        // ... and on its way into step in (B)
 constexpr int kLaneRounds = 6;                    // passes of (B) before the super-window is cut at the first unsettled lane
-constexpr int kLaneSlots = 4096;                  // scratch slots: more than the chip holds of these waves (256 CUs x <= 13)
+constexpr int kLaneSlots = 4096;                  // scratch slots: as many as the chip holds of these waves (256 CUs x <= 16)
 constexpr size_t kLaneSlotWords = 64 * kLaneTok + 64 * kLaneCatch;  // a lane's tokens of (A), and of its way into step
-// LDS of the loop beside the tables: the symbol starts of (A) - a mask of the stretch's bits per lane, or a 16-bit checkpoint
-// per 32-bit word of it - and, in (C) / (D), the owner slots (words 0..63) and a group's rows of byte states (from word 192)
-constexpr int kLaneStartWords = FTK_LANES_CP ? 64 * (kLaneBits / 32) / 2 : 64 * (kLaneBits / 32);
+// LDS of the loop beside the tables: the symbol starts of (A) - a 16-bit checkpoint per 32-bit word of a lane's stretch -
+// and, in (C) / (D), the owner slots (words 0..63) and a group's rows of byte states (from word 192)
+constexpr int kLaneStartWords = 64 * (kLaneBits / 32) / 2;
 constexpr int kLaneLdsWords = kLaneStartWords > 192 + (kLaneCap / 64) * 64 ? kLaneStartWords : 192 + (kLaneCap / 64) * 64;
 static_assert(kLaneTok < 1024, "a checkpoint holds a token number in ten bits");
 struct LaneScratch {
@@ -423,12 +411,6 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                                                           LaneScratch* __restrict__ lane_scratch) {
     __shared__ WaveLds L;
     __shared__ uint32_t lanes_vis[LANES ? kLaneLdsWords : 1];
-#ifndef FTK_LANES_LDS_INPUT
-#define FTK_LANES_LDS_INPUT 0
-#endif
-#if FTK_LANES_LDS_INPUT
-    __shared__ uint32_t lanes_in[LANES ? 64 * (kLaneBits / 32) + 64 : 1];  // the super-window's input words (+ the overhang of the last symbol)
-#endif
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
     if (blk >= n_blocks) return;
@@ -632,22 +614,12 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     return -1;
                 };
                 LTIME_DECL;
-#if FTK_LANES_LDS_INPUT
-                const uint32_t in_w0 = bp >> 5;
-                // (A/B builds) the super-window's input words into LDS (coalesced; words behind the payload read as zeros):
-                // a lane's 64-bit view at any bit position of the super-window is then three LDS reads
-#pragma unroll
-                for (int k = 0; k <= kLaneBits / 32; ++k) {
-                    const uint32_t wi = in_w0 + (uint32_t)(k * 64 + lane);
-                    lanes_in[k * 64 + lane] = wi < b.end_word ? b.w[wi] : 0u;
-                }
-#endif
                 // A lane reads its stretch front to back, so its input is a WINDOW IN REGISTERS: the word its position is in
                 // and the four behind it (r0..r3, nx), moved up as the position crosses words (a symbol takes at most 48
                 // bits: one or two words a trip) and refilled by the lane's own loads - which have a trip or more to arrive,
-                // since a symbol is decoded from r0..r2 alone.  Until round 5's last third the super-window's words were
-                // staged in LDS (4.3 KB a wave, the largest single item of the 16 KB that kept a CU at ten waves) and every
-                // symbol began with an LDS round trip for its three words.  Words behind the payload read as zeros.
+                // since a symbol is decoded from r0..r2 alone.  The first version staged the super-window's words
+                // in LDS (4.3 KB a wave, the largest single item of the 16 KB that kept a CU at ten waves) and every symbol
+                // began with an LDS round trip for its three words.  Words behind the payload read as zeros.
                 struct InWin {
                     uint32_t wi;
                     unsigned r0, r1, r2, r3, nx;
@@ -678,27 +650,13 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         W.wi += adv;
                     }
                 };
-                // (`single`: a pair of literals is taken one at a time - the chain then visits EVERY symbol start.  Tried for
-                // the lanes on their way into step (B), on the idea that a chain which pairs its literals the other way
-                // round than the chain it is to meet would be in step with it symbol by symbol and still never land on one
-                // of its starts; the trips of (B) did not change and the launches were 2 % slower: FTK_LANES_SINGLE=0)
-                auto decode_at = [&](const InWin& W, uint32_t at, unsigned& nb, unsigned& tok, bool single) {
-#if FTK_LANES_LDS_INPUT
-                    const uint32_t wr = (at >> 5) - in_w0;  // (at most 64 * kLaneBits / 32 + 2: the overhang is staged too)
-                    const unsigned c_lo = lanes_in[wr], c_mid = lanes_in[wr + 1u], c_hi = lanes_in[wr + 2u];
-#else
+                auto decode_at = [&](const InWin& W, uint32_t at, unsigned& nb, unsigned& tok) {
                     const unsigned c_lo = W.r0, c_mid = W.r1, c_hi = W.r2;  // (W.wi == at >> 5: the caller has moved the window)
-#endif
                     const unsigned sh = at & 31u;
                     const unsigned w0 = __builtin_amdgcn_alignbit(c_mid, c_lo, sh), w1 = __builtin_amdgcn_alignbit(c_hi, c_mid, sh);
                     const unsigned E = L.pair[w0 & ((1u << kLitRoot) - 1u)];
                     unsigned k1 = (E >> 5) & 3u, lb = E & 31u, lbase = (E >> 8) & 511u, xb = (E >> 20) & 7u;
                     unsigned lit = (((E >> 8) & 0xffu) << 8) | (((E >> 20) & 0xffu) << 16);
-                    if (single && k1 == 2u) {
-                        k1 = 1u;
-                        lb = E >> 28;
-                        lit &= 0xff00u;
-                    }
                     if (E == 0u) {  // (rare: a literal / length code longer than the root)
                         int len = 0;
                         const int sym = long_code(w0, 0, len);
@@ -738,29 +696,16 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                 // by lane - [l][k] - every trip wrote to 64 cache lines, and the address unit was busy with little else)
                 uint32_t* spec = lane_tok + lane;
                 uint32_t* catchup = lane_tok + 64 * kLaneTok + lane;
-                // What a lane remembers of the positions it took for symbol starts, in LDS.  FTK_LANES_CP: a CHECKPOINT per
-                // 32-bit word of the stretch - the first start inside the word (5 bits, + 1 so that 0 says none) and the
-                // number of the token that starts there, 16 bits at [word][lane].  A chain that has met the chain of (A)
-                // walks its starts from there on, so it is recognised at the first start of the NEXT word at the latest,
-                // and the tokens it wrote in between are the same tokens: nothing is lost but a few trips.  Half the LDS
-                // of a mask of every bit (which also had to be counted through to number a token), so that a stretch can
-                // be 1 024 bits: the rounds of (B) cost what they cost per STRETCH, not per bit.
+                // What a lane remembers of the positions it took for symbol starts, in LDS: a CHECKPOINT per 32-bit word of the
+                // stretch - the first start inside the word (5 bits, + 1 so that 0 says none) and the number of the token that
+                // starts there, 16 bits at [word][lane].  A chain that has met the chain of (A) walks its starts from there
+                // on, so it is recognised at the first start of the NEXT word at the latest, and the tokens it wrote in
+                // between are the same tokens: nothing is lost but a few trips.  (The first version kept a mask of every
+                // bit: twice the LDS, and the mask had to be counted through to number the token a lane had landed on.)
                 uint16_t* const cp16 = reinterpret_cast<uint16_t*>(lanes_vis);
 #pragma unroll
                 for (int k = 0; k < kLaneStartWords / 64; ++k) lanes_vis[k * 64 + lane] = 0u;
-                auto vis_set = [&](unsigned rel) {  // (FTK_LANES_CP=0: ds_or_b32, one LDS instruction, nothing to wait for)
-                    __hip_atomic_fetch_or(&lanes_vis[(rel >> 5) * 64u + (unsigned)lane], 1u << (rel & 31u), __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_WAVEFRONT);
-                };
-                auto vis_below = [&](unsigned rel) -> int {  // visited positions in front of `rel`
-                    int n = 0;
-                    for (unsigned k = 0; k <= (rel >> 5) && k < (unsigned)(kLaneBits / 32); ++k) {
-                        const unsigned w = lanes_vis[k * 64u + (unsigned)lane];
-                        n += __popc(k < (rel >> 5) ? w : (w & ((1u << (rel & 31u)) - 1u)));
-                    }
-                    return n;
-                };
-                unsigned last_word = ~0u;  // (FTK_LANES_CP) the word of the stretch the last checkpoint was written for
+                unsigned last_word = ~0u;  // the word of the stretch the last checkpoint was written for
                 uint32_t pos = p0;
                 int ntok = 0;
                 bool stopped = false;               // the chain ended at something a window of the older kind must take
@@ -773,23 +718,19 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     LACC(l_trips_a, 1);
                     if (active) {
                         unsigned nb, tok;
-                        decode_at(W, pos, nb, tok, false);
+                        decode_at(W, pos, nb, tok);
                         if (nb == 0u || ntok == kLaneTok) {
                             stopped = true;
                             active = false;
                         } else {
-                            if (FTK_LANES_CP) {
-                                const unsigned rel = pos - p0, word = rel >> 5;
-                                if (word != last_word) cp16[word * 64u + (unsigned)lane] = (uint16_t)(((unsigned)ntok << 6) | ((rel & 31u) + 1u));
-                                last_word = word;
-                            } else {
-                                vis_set(pos - p0);
-                            }
+                            const unsigned rel = pos - p0, word = rel >> 5;
+                            if (word != last_word) cp16[word * 64u + (unsigned)lane] = (uint16_t)(((unsigned)ntok << 6) | ((rel & 31u) + 1u));
+                            last_word = word;
                             pos += nb;
                             active = pos < sub_end;
                             // (the window's loads BEFORE the token's store: memory operations are counted off in order, so a
                             // load behind the store would not be seen to arrive before the store is acknowledged)
-                            if (!FTK_LANES_LDS_INPUT && active) win_seek(W, pos);
+                            if (active) win_seek(W, pos);
                             spec[64 * ntok++] = tok;
                         }
                     }
@@ -813,8 +754,8 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     uint32_t q = c;
                     int nc = 0;
                     bool joined = false, cstop = false, go = need;
-                    int join_tok = 0;  // (FTK_LANES_CP) the number of the token of (A) the lane landed on
-                    if (!FTK_LANES_LDS_INPUT && need) win_open(W, c);
+                    int join_tok = 0;  // the number of the token of (A) the lane landed on
+                    if (need) win_open(W, c);
                     LACC(l_rounds, 1);
                     if (round == 1) LACC(l_need2, __popcll(unsettled));
                     while (__ballot(go)) {
@@ -822,14 +763,14 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         if (round == 0) LACC(l_trips_b1, 1);
                         if (go) {
                             const uint32_t rel = q - p0;  // (c >= p0: the lane in front ran to the end of its stretch or beyond)
-                            // (the symbol at q is decoded whether or not q turns out to be a visited position: the mask word
+                            // (the symbol at q is decoded whether or not q turns out to be a visited position: the checkpoint
                             // and the table entries then come in ONE LDS round trip, not one behind the other)
                             const bool inside = rel < (uint32_t)kLaneBits;
                             const unsigned word = (inside ? rel : 0u) >> 5;
-                            const unsigned visw = FTK_LANES_CP ? (unsigned)cp16[word * 64u + (unsigned)lane] : lanes_vis[word * 64u + (unsigned)lane];
+                            const unsigned visw = cp16[word * 64u + (unsigned)lane];
                             unsigned nb, tok;
-                            decode_at(W, q, nb, tok, FTK_LANES_SINGLE != 0);
-                            if (inside && (FTK_LANES_CP ? (visw & 63u) == (rel & 31u) + 1u : ((visw >> (rel & 31u)) & 1u) != 0u)) {
+                            decode_at(W, q, nb, tok);
+                            if (inside && (visw & 63u) == (rel & 31u) + 1u) {
                                 joined = true;
                                 join_tok = (int)(visw >> 6);
                                 go = false;
@@ -841,7 +782,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                                     go = false;
                                 } else {
                                     q += nb;
-                                    if (!FTK_LANES_LDS_INPUT) win_seek(W, q);
+                                    win_seek(W, q);
                                     catchup[64 * nc++] = tok;
                                 }
                             }
@@ -852,7 +793,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         cur_start = c;
                         ncatch = nc;
                         if (joined) {
-                            first_valid = FTK_LANES_CP ? join_tok : vis_below(q - p0);
+                            first_valid = join_tok;
                             my_end = spec_end;
                             my_stop = spec_stop;
                         } else {
@@ -926,10 +867,8 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                     // ---- (D) 64 tokens at a time: places from a prefix sum, literals stored, matches copied in order ----
                     bool fail_d = false;
                     LACC_DECL;
-#if FTK_LANES_VEC_D
 #pragma unroll
                     for (int i = 0; i < kLaneCap / 64; ++i) lanes_vis[192 + 64 * i + lane] = 0u;  // the rows the symbols drop their keys in
-#endif
                     unsigned tok_next = fetch(0);
                     for (int base = 0; base < n_tokens && !fail_d;) {
                         const unsigned tok = tok_next;
@@ -964,7 +903,6 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                         LTIME_D(17);  // places
                         tok_next = fetch(base + took);  // (on its way while this group's bytes are stored and copied)
                         LTIME_D(18);  // the next group's owners found
-#if FTK_LANES_VEC_D
                         const uint64_t mm_any = __ballot(mark == 3u);
                         LACC(d_matches, __popcll(mm_any));
                         LACC(d_groups, 1);
@@ -1086,79 +1024,6 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                             L.ring[at2 & kRingMask] = (uint8_t)(tok >> 8);
                             if (mark == 2u) L.ring[(at2 + 1u) & kRingMask] = (uint8_t)(tok >> 16);
                         }
-#else
-                        if (mark == 1u || mark == 2u) {
-                            const uint32_t at2 = A + off;
-                            L.ring[at2 & kRingMask] = (uint8_t)(tok >> 8);
-                            if (mark == 2u) L.ring[(at2 + 1u) & kRingMask] = (uint8_t)(tok >> 16);
-                        }
-                        // the matches, in stream order - the loops of the windows (see there)
-                        const unsigned ccase = (mdist >= mlen && mlen <= 64u && mdist <= (unsigned)kFarDist) ? 0u
-                                               : mdist <= (unsigned)kFarDist                                ? 1u
-                                                                                                            : 2u;
-                        const unsigned lenc = mlen | (ccase << 16);
-                        const uint32_t M0v = A + off;
-                        uint64_t mm = __ballot(mark == 3u);
-                        if (mm && __ballot(mark == 3u && ccase != 0u) == 0ull) {
-                            unsigned lc, md, m0, va, vs, vx;
-                            int l;
-                            const unsigned spare = (unsigned)offsetof(WaveLds, lens);
-                            asm volatile(
-                                "1:\n\t"
-                                "s_ff1_i32_b64 %[l], %[mm]\n\t"
-                                "s_bitset0_b64 %[mm], %[l]\n\t"
-                                "v_readlane_b32 %[lc], %[lenc], %[l]\n\t"
-                                "v_readlane_b32 %[md], %[mdist], %[l]\n\t"
-                                "v_readlane_b32 %[m0], %[M0v], %[l]\n\t"
-                                "v_cmp_gt_u32 vcc, %[lc], %[lane]\n\t"
-                                "v_add_u32 %[va], %[m0], %[lane]\n\t"
-                                "v_subrev_u32 %[vs], %[md], %[va]\n\t"
-                                "v_and_b32 %[vs], %[mask], %[vs]\n\t"
-                                "v_and_b32 %[va], %[mask], %[va]\n\t"
-                                "v_cndmask_b32 %[vs], %[spare], %[vs], vcc\n\t"
-                                "v_cndmask_b32 %[va], %[spare], %[va], vcc\n\t"
-                                "ds_read_u8 %[vx], %[vs]\n\t"
-                                "s_waitcnt lgkmcnt(0)\n\t"
-                                "ds_write_b8 %[va], %[vx]\n\t"
-                                "s_cmp_lg_u64 %[mm], 0\n\t"
-                                "s_cbranch_scc1 1b\n\t"
-                                : [mm] "+s"(mm), [lc] "=&s"(lc), [md] "=&s"(md), [m0] "=&s"(m0), [l] "=&s"(l), [va] "=&v"(va),
-                                  [vs] "=&v"(vs), [vx] "=&v"(vx)
-                                : [lenc] "v"(lenc), [mdist] "v"(mdist), [M0v] "v"(M0v), [lane] "v"(lane), [mask] "i"(kRingMask),
-                                  [spare] "v"(spare)
-                                : "vcc", "scc", "memory");
-                        } else {
-                            while (mm) {
-                                const int l = __ffsll((unsigned long long)mm) - 1;
-                                mm &= mm - 1;
-                                const int len = __builtin_amdgcn_readlane((int)mlen, l), d = __builtin_amdgcn_readlane((int)mdist, l);
-                                const uint32_t M0 = (uint32_t)__builtin_amdgcn_readlane((int)M0v, l);
-                                if (d >= len && len <= 64 && d <= kFarDist) {
-                                    if (lane < len) {
-                                        const uint32_t a = M0 + (uint32_t)lane;
-                                        L.ring[a & kRingMask] = L.ring[(a - (uint32_t)d) & kRingMask];
-                                    }
-                                } else if (d <= kFarDist) {
-                                    int done = 0, DD = d;
-                                    while (done < len) {
-                                        const int n = min(min(len - done, DD), 64);
-                                        if (lane < n) {
-                                            const uint32_t a = M0 + (uint32_t)(done + lane);
-                                            L.ring[a & kRingMask] = L.ring[(a - (uint32_t)DD) & kRingMask];
-                                        }
-                                        done += n;
-                                        if (2 * DD <= done + d) DD *= 2;
-                                    }
-                                } else {
-                                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                                    for (int o = lane; o < len; o += 64) {
-                                        const uint32_t a = M0 + (uint32_t)o;
-                                        L.ring[a & kRingMask] = out[a - (uint32_t)d];
-                                    }
-                                }
-                            }
-                        }
-#endif
                         LTIME_D(19);  // literals and matches
                         // (the next group's tokens are waited for HERE, in front of the write-behind: memory operations are
                         // counted off in order, so behind it the wait would also be for the granule's stores to be acknowledged)
