@@ -2997,7 +2997,13 @@ bool ftk_fragstream::run_text_device(RawBuf& buf, size_t n) {
         return e ? atoi(e) : -1;
     }();
     const int host_share = !dev_inflate ? 0 : host_share_env >= 0 ? host_share_env : 0;
-    const int kLag = host_share > 0 ? kHostLag + 1 : 2;
+    static const int lag_env = [] {
+        const char* e = getenv("FTK_TEXT_LAG");
+        return e ? atoi(e) : -1;
+    }();
+    // (pieces the producer lets the GPU fall behind before it waits: FTK_TEXT_LAG; without host pieces 2 until round 5 -
+    // 0.078-0.089 s per genome pass - now 4: 0.074-0.085 s; 6 and 9 the same)
+    const int kLag = lag_env >= 1 ? std::min(lag_env, kHostLag + 1) : host_share > 0 ? kHostLag + 1 : 4;
     struct PieceMeta {
         bool on_host = false, eof = false, has_prev = false, back_done = true;
         size_t total = 0;
