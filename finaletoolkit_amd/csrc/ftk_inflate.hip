@@ -910,7 +910,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
 #define FTK_LANES_SKIP 0   // (timing experiments only - results are wrong: 1 no byte resolution at all, 2 no doubling rounds, 4 no far loads)
 #endif
                         if (mm_any && !(FTK_LANES_SKIP & 1)) {
-                            // ---- the group's BYTES side by side (T <= kWinCap = 320: five rows of 64).  Copying the matches in
+                            // ---- the group's BYTES side by side (T <= kLaneCap = 384: six rows of 64).  Copying the matches in
                             // stream order costs an LDS read -> write round trip per match, ~30 of them per group of fragment
                             // rows, one after the other - four fifths of this loop's time when the chip is full.  Instead every
                             // symbol drops a key (its place << 17 | match << 16 | distance - 1 or its literal bytes) at its first
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(64) FTK_INFLATE_OCC void bgzf_inflate_kernel(const 
                             // start when all rows hold states, and the rows are zeroed again behind the group.  Every step
                             // is written row by row in loops of its own - all reads of a step, then all its writes - so that
                             // the rows' LDS round trips overlap instead of following each other.)
-                            uint32_t* const S = lanes_vis + 192;      // (words 0..191 hold (C)'s arrays, which fetch() reads)
+                            uint32_t* const S = lanes_vis + 192;      // (words 0..63 are the slots fetch() drops owners in)
                             constexpr unsigned kRes = 0x80000000u;
                             constexpr int kRows = kLaneCap / 64;
                             static_assert(192 + kRows * 64 <= kLaneLdsWords, "the byte states of a group must fit behind the owner slots");
