@@ -2132,23 +2132,51 @@ int ftk_bgzf_inflate_device(ftk_ctx* ctx, const uint8_t* file_bytes, int64_t n, 
     uint32_t* d_crc = a.take<uint32_t>(tab.size());
     uint8_t* d_out = a.take<uint8_t>((size_t)total + 4096 + 16);
     d_out = (uint8_t*)(((uintptr_t)d_out + 4095) & ~(uintptr_t)4095);
+    // The kernel addresses its input by 32-BIT BIT POSITIONS from the pointer it is given: a launch takes blocks whose
+    // compressed bytes lie within 2^28 bytes of its first one (the streams' pieces are 48-96 MB; an image of more than
+    // that goes in several launches, each from a base of its own - block offsets are rebased here, before the table goes up).
+    struct Run {
+        size_t first, count, base;
+    };
+    std::vector<Run> runs;
+    for (size_t i = 0; i < tab.size();) {
+        const size_t base = (size_t)tab[i].in_off & ~(size_t)3;
+        size_t j = i;
+        while (j < tab.size() && (size_t)tab[j].in_off + tab[j].in_len - base < (size_t(1) << 28)) ++j;
+        if (j == i) return fail(ctx, FTK_ERR_FORMAT, "BGZF block too large");  // (cannot happen: a block is at most 64 KB)
+        runs.push_back({i, j - i, base});
+        for (size_t k = i; k < j; ++k) tab[k].in_off -= (uint32_t)base;
+        i = j;
+    }
     HIPCHK(ctx, hipMemcpyAsync(d_comp, file_bytes, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(tab[0]), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(d_st, 0, sizeof(*d_st), ctx->stream));
     // (FTK_INFLATE_VECTOR_MATCHES=1: the launch shape BAM streams use - a window's matches resolved on the lanes side
     // by side; read per call so that the tests can hold both shapes against zlib)
     const char* vm = getenv("FTK_INFLATE_VECTOR_MATCHES");
-    ftk::inflate_launch(ctx->stream, d_comp, d_tab, (int)tab.size(), d_out, d_st, d_crc, vm && atoi(vm) != 0);
-    HIPCHK(ctx, hipGetLastError());
     ftk::InflateStatus st{};
+    for (size_t r = 0; r < runs.size(); ++r) {
+        HIPCHK(ctx, hipMemsetAsync(d_st, 0, sizeof(*d_st), ctx->stream));
+        ftk::inflate_launch(ctx->stream, d_comp + runs[r].base, d_tab + runs[r].first, (int)runs[r].count, d_out, d_st,
+                            d_crc + runs[r].first, vm && atoi(vm) != 0);
+        HIPCHK(ctx, hipGetLastError());
+        if (r + 1 < runs.size()) {  // (the status words are the launch's own: read before the next one clears them)
+            ftk::InflateStatus sr{};
+            HIPCHK(ctx, hipMemcpyAsync(&sr, d_st, sizeof(sr), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (sr.n_bad)
+                return fail(ctx, FTK_ERR_FORMAT, "device inflate: %u of %zu BGZF blocks did not decode (block %zu: reason %u)", sr.n_bad,
+                            tab.size(), runs[r].first + sr.first_bad, sr.reason);
+        }
+    }
+    const size_t last_first = runs.back().first;
     std::vector<uint32_t> got_crc(tab.size());
     HIPCHK(ctx, hipMemcpyAsync(&st, d_st, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(got_crc.data(), d_crc, tab.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(out, d_out, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (st.n_bad)
-        return fail(ctx, FTK_ERR_FORMAT, "device inflate: %u of %zu BGZF blocks did not decode (block %u: reason %u)", st.n_bad,
-                    tab.size(), st.first_bad, st.reason);
+        return fail(ctx, FTK_ERR_FORMAT, "device inflate: %u of %zu BGZF blocks did not decode (block %zu: reason %u)", st.n_bad,
+                    tab.size(), last_first + st.first_bad, st.reason);
     for (size_t k = 0; k < tab.size(); ++k)  // the gzip trailer's CRC-32 against the one computed on the device
         if (got_crc[k] != want_crc[k])
             return fail(ctx, FTK_ERR_FORMAT, "device inflate: CRC mismatch in BGZF block %zu (%08x, trailer says %08x)", k,

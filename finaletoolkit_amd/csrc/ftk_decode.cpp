@@ -1561,7 +1561,8 @@ namespace {
 const size_t kStreamPiece = [] {
     const char* e = getenv("FTK_STREAM_PIECE");
     const long long v = e ? atoll(e) : 0;
-    return v >= (1 << 16) ? (size_t)v : (size_t)(48u << 20);
+    // (at most 120 MB: a large BAM doubles it, and the device inflate addresses a piece by 32-bit bit positions - 2^28 bytes a launch)
+    return v >= (1 << 16) ? (size_t)std::min<long long>(v, 120ll << 20) : (size_t)(48u << 20);
 }();
 
 // bytes of inflated BAM per speculative stretch of the record chain (FTK_BAM_STRETCH: the tests make the

@@ -476,7 +476,9 @@ int ftk_motif_counts(ftk_ctx* ctx, int contig_id, int ref_id, const int32_t* w_s
  * This entry point inflates a whole BGZF image (every block a BGZF member, as bgzip / htslib write them) held
  * in host memory and returns the data in host memory: *n_out = sum of the blocks' ISIZE fields; FTK_ERR_INVALID
  * when cap is too small (with *n_out set), FTK_ERR_FORMAT for anything that is not BGZF or does not decode to
- * its ISIZE.  (The fragment stream uses the same kernel on device-resident pieces: FTK_DEVICE_INFLATE.) */
+ * its ISIZE.  An image of up to 4 GB of data (compressed and inflated) per call; compressed bytes beyond 2^28 go in
+ * further launches of the kernel, which addresses its input by 32-bit bit positions.  (The fragment stream uses the
+ * same kernel on device-resident pieces: FTK_DEVICE_INFLATE.) */
 int ftk_bgzf_inflate_device(ftk_ctx* ctx, const uint8_t* file_bytes, int64_t n, uint8_t* out, int64_t cap, int64_t* n_out);
 
 /* ---- output writers (host only; no ctx / GPU needed) ---------------------------------------------

@@ -227,6 +227,33 @@ def test_many_blocks_from_the_library_writer(engine, tmp_path):
         assert got == rows, level
 
 
+def test_image_beyond_one_launch_of_the_kernel(engine, tmp_path):
+    """The kernel addresses its input by 32-bit bit positions: ``ftk_bgzf_inflate_device`` cuts an image whose compressed
+    bytes span more than 2^28 into launches from rebased pointers (until round 5 the blocks behind 2^29 bytes did not
+    decode: 'reason 5').  ~340 MB of BAM records -> 750 MB, both symbol loops, against zlib."""
+    import gzip
+    import os
+    p = str(tmp_path / "big.bam")
+    synth.write_paired_bam_native(p, [("x", 14_000_000)], 60.0, 31, keep=())
+    image = open(p, "rb").read()
+    assert len(image) > (1 << 28) + (1 << 24)
+    text = gzip.open(p, "rb").read()
+    keep = os.environ.get("FTK_INFLATE_LANES")
+    try:
+        for lanes in ("1", "0"):
+            os.environ["FTK_INFLATE_LANES"] = lanes
+            out = np.zeros(len(text), np.uint8)
+            n = C.c_int64()
+            rc = engine.lib.ftk_bgzf_inflate_device(engine.ctx, image, len(image), L.ptr(out), len(out), C.byref(n))
+            assert rc == L.FTK_OK, engine.lib.ftk_last_error(engine.ctx)
+            assert n.value == len(text) and out.tobytes() == text
+    finally:
+        if keep is None:
+            os.environ.pop("FTK_INFLATE_LANES", None)
+        else:
+            os.environ["FTK_INFLATE_LANES"] = keep
+
+
 def test_damaged_payloads_are_errors(engine):
     text = _rows(2000, 9)
     good = _member(text, 6)
