@@ -1644,7 +1644,7 @@ void inflate_launch(hipStream_t s, const uint8_t* d_comp, const InflateBlock* d_
 #endif
     // Which symbol loop: the lane-parallel one unless FTK_INFLATE_LANES=0 asks for the windowed loop (read per launch: the
     // tests hold both against zlib).  Since (D) resolves a group's bytes side by side it is ahead at every launch size
-    // (a 1 882-block launch 1.3 vs 2.9 ms, chip-filling text 6.3 vs 7.5 ms, BAM records 9.4 vs 9.5 ms).
+    // (a 1 883-block launch 1.2 vs 3.4 ms, chip-filling text 3.4 vs 7.5 ms, BAM records 5.0 vs 9.6 ms).
     const char* le = getenv("FTK_INFLATE_LANES");
     const bool lanes = !(le && *le) || atoi(le) != 0;
     LaneScratch* ls = lanes ? lane_scratch_of_device() : nullptr;
