@@ -42,7 +42,6 @@ def _scores_array(chrom, start, values):
     ones are filled by the library's host threads (``ftk_fill_wps_records``), small ones by numpy."""
     n = len(values)
     if n >= 1 << 20:
-        import ctypes as C
         from .. import _lib as L
         scores = np.empty(n, dtype=_WPS_DTYPE)
         name = np.zeros(1, dtype="U16")
