@@ -44,7 +44,7 @@ EXPORTS = [
     "ftk_frags_from_host", "ftk_frags_from_device", "ftk_frags_set_read1", "ftk_frags_set_order", "ftk_frags_load_fraggz", "ftk_frags_load_bam", "ftk_frags_name",
     "ftk_frags_info", "ftk_frags_release",
     "ftk_fragfile_decode", "ftk_bam_decode", "ftk_host_alloc", "ftk_host_alloc_pageable", "ftk_host_free", "ftk_cache_trim", "ftk_wps_async", "ftk_result_wait", "ftk_fragfile_index_contigs", "ftk_fragstream_open", "ftk_fragstream_open_device", "ftk_fragstream_open_region", "ftk_fragtable_is_device", "ftk_fragtable_ready_event", "ftk_fragtable_columns_to_host", "ftk_fragtable_read1_to_host", "ftk_fragstream_next", "ftk_fragstream_n_refs",
-    "ftk_fragstream_ref_name", "ftk_fragstream_ref_length", "ftk_fragstream_close", "ftk_fragstream_stage_ms", "ftk_fragtable_error", "ftk_fragtable_is_bed6",
+    "ftk_fragstream_ref_name", "ftk_fragstream_ref_length", "ftk_fragstream_close", "ftk_fragstream_stage_ms", "ftk_fragstream_skipped", "ftk_fragtable_skipped", "ftk_fragtable_error", "ftk_fragtable_is_bed6",
     "ftk_fragtable_n_contigs", "ftk_fragtable_contig_name", "ftk_fragtable_contig_length",
     "ftk_fragtable_contig_rows", "ftk_fragtable_columns", "ftk_fragtable_order", "ftk_fragtable_is_pinned", "ftk_fragtable_free",
     "ftk_frags_from_table",
@@ -253,6 +253,8 @@ def load() -> C.CDLL:
     lib.ftk_fragstream_ref_length.restype = i64
     lib.ftk_fragstream_close.argtypes = [vp]
     lib.ftk_fragstream_stage_ms.argtypes = [vp, C.POINTER(C.c_double * 6)]
+    lib.ftk_fragstream_skipped.argtypes = [vp, C.POINTER(i64 * 2)]
+    lib.ftk_fragtable_skipped.argtypes = [vp, C.POINTER(i64 * 2)]
     lib.ftk_fragstream_close.restype = None
     lib.ftk_fragtable_is_bed6.argtypes = [vp]
     lib.ftk_fragtable_n_contigs.argtypes = [vp]

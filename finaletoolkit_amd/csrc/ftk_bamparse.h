@@ -24,6 +24,8 @@ struct BamSummary {
     uint32_t carry_overflow;  // the previous piece's unfinished record does not fit in front of the data
     uint32_t n_rows;          // fragments written
     uint32_t n_records;       // records on the chain, any reference
+    uint32_t n_unrepresentable;  // records the reference makes a fragment of that the columns cannot hold (ftk_bamrule.h)
+    uint32_t n_nocigar_reverse;  // CIGAR-less read1 records with TLEN < 0: the reference raises TypeError on them
     uint32_t n_runs;          // contig runs among the fragments (> kBamMaxRuns: too many to list)
     uint32_t n_stretch;       // stretches the range was cut into
     uint32_t n_repairs;       // stretches the last kernel had to walk again serially

@@ -18,6 +18,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "ftk_bamparse.h"
+#include "ftk_bamrule.h"
 
 namespace ftk {
 namespace {
@@ -75,43 +76,9 @@ __device__ uint32_t guess_record_start(const uint8_t* p, uint32_t from, uint32_t
     return fallback;
 }
 
-struct Frag {
-    int32_t fs, fe, r1s, r1e;
-    uint8_t q, st;
+struct RdDev {
+    __device__ __forceinline__ uint32_t operator()(const uint8_t* p) const { return rd_u32(p); }
 };
-
-// ftk_decode.cpp: bam_record (io/alignment.py:60-71,242-268) - false: not a fragment
-__device__ bool bam_fragment(const uint8_t* r, uint32_t bs, Frag& f) {
-    const int32_t pos = rd_i32(r + 4);
-    const uint32_t l_read_name = r[8];
-    const uint32_t n_cigar = rd_u16(r + 12);
-    const uint32_t flag = rd_u16(r + 14);
-    const int32_t tlen = rd_i32(r + 28);
-    if ((flag & 0x4) || (flag & 0x100) || !(flag & 0x1) || (flag & 0x8) || (flag & 0x400) || (flag & 0x200) || (flag & 0x800) ||
-        !(flag & 0x2))
-        return false;
-    if (flag & 0x80) return false;  // read1 only
-    if (tlen == 0 || n_cigar == 0) return false;
-    if (32 + (uint64_t)l_read_name + 4ull * n_cigar > bs) return false;
-    const uint8_t* cg = r + 32 + l_read_name;
-    long long ref_len = 0;
-    for (uint32_t k = 0; k < n_cigar; ++k) {
-        const uint32_t v = rd_u32(cg + 4 * k);
-        const uint32_t op = v & 15u;
-        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += v >> 4;
-    }
-    const long long ref_end = (long long)pos + ref_len;
-    long long fs, fe;
-    if (tlen > 0) { fs = pos; fe = (long long)pos + tlen; } else { fs = ref_end + tlen; fe = ref_end; }
-    if (fs < 0 || fe < 0 || fs > INT32_MAX || fe > INT32_MAX) return false;
-    f.fs = (int32_t)fs;
-    f.fe = (int32_t)fe;
-    f.q = r[9];
-    f.st = (flag & 0x10) ? 0 : 1;
-    f.r1s = pos;
-    f.r1e = (int32_t)ref_end;
-    return true;
-}
 
 struct Out {
     int32_t *start, *end, *r1s, *r1e, *ref;
@@ -123,7 +90,7 @@ struct Out {
 template <bool EMIT>
 __device__ uint32_t walk(const uint8_t* p, uint32_t m, uint32_t from, uint32_t until, const uint8_t* wanted, int n_ref,
                          uint32_t& n_frag, uint32_t& n_rec, bool& bad, const Out& out, uint32_t row0, size_t max_rows,
-                         unsigned long long* last_key = nullptr) {
+                         unsigned long long* last_key = nullptr, uint32_t* skipped = nullptr) {
     uint64_t o = from;
     n_frag = 0;
     n_rec = 0;
@@ -137,21 +104,24 @@ __device__ uint32_t walk(const uint8_t* p, uint32_t m, uint32_t from, uint32_t u
         ++n_rec;
         if (EMIT && last_key) *last_key = ((unsigned long long)(uint32_t)ref_id << 32) | (uint32_t)max(rd_i32(r + 4), 0);
         if (ref_id >= 0 && ref_id < n_ref && wanted[ref_id]) {
-            Frag f;
-            if (bam_fragment(r, bs, f)) {
+            BamRow f;
+            const int rule = bam_rule(r, bs, RdDev{}, f);  // io/alignment.py:60-71,242-268 (ftk_bamrule.h)
+            if (rule == kBamFragment) {
                 if (EMIT) {
                     const size_t i = (size_t)row0 + n_frag;
                     if (i < max_rows) {
                         out.start[i] = f.fs;
                         out.end[i] = f.fe;
-                        out.mapq[i] = f.q;
-                        out.strand[i] = f.st;
+                        out.mapq[i] = f.mapq;
+                        out.strand[i] = f.fwd;
                         out.r1s[i] = f.r1s;
                         out.r1e[i] = f.r1e;
                         out.ref[i] = ref_id;
                     }
                 }
                 ++n_frag;
+            } else if (EMIT && rule != kBamNotFragment && skipped) {
+                ++skipped[rule == kBamNoCigarReverse];
             }
         }
         o += 4 + (uint64_t)bs;
@@ -320,17 +290,20 @@ __global__ __launch_bounds__(64) void bam_emit_kernel(const uint8_t* __restrict_
     const uint32_t* st_start = st;
     const uint32_t* st_off = st + 3 * (size_t)n_stretch;
     uint32_t recs = 0;
+    uint32_t skipped[2] = {0, 0};  // fragments the columns cannot hold; CIGAR-less read1 with TLEN < 0 (ftk_bamrule.h)
     for (uint32_t k = blockIdx.x * 64u + threadIdx.x; k < n_stretch; k += gridDim.x * 64u) {
         const uint64_t b1 = ((uint64_t)k + 1) * stretch_bytes;
         const uint32_t until = b1 < m ? (uint32_t)b1 : m;
         uint32_t n_frag, n_rec;
         bool bad;
         unsigned long long key = 0;
-        (void)walk<true>(p, m, st_start[k], until, wanted, n_ref, n_frag, n_rec, bad, out, st_off[k], max_rows, &key);
+        (void)walk<true>(p, m, st_start[k], until, wanted, n_ref, n_frag, n_rec, bad, out, st_off[k], max_rows, &key, skipped);
         recs += n_rec;
         if (n_rec) atomicMax(&sum->last_key, key);  // (records are sorted by reference and position: the last one's)
     }
     if (recs) atomicAdd(&sum->n_records, recs);
+    if (skipped[0]) atomicAdd(&sum->n_unrepresentable, skipped[0]);
+    if (skipped[1]) atomicAdd(&sum->n_nocigar_reverse, skipped[1]);
 }
 
 // contig runs of the rows: row i starts a run when its reference differs from row i - 1's

@@ -38,6 +38,7 @@
 #include "ftk_host.h"
 #include "ftk_inflate.h"
 #include "ftk_bamparse.h"
+#include "ftk_bamrule.h"
 #include "ftk_textparse.h"
 
 namespace {
@@ -213,7 +214,12 @@ struct Columns {
     std::vector<int32_t> start, end, r1s, r1e;
     std::vector<int32_t> ord;  // BAM: rank of the read1 record in the file (set by sort_by_start)
     std::vector<uint8_t> mapq, strand;
+    // BAM: records the reference handles differently from a row (ftk_bamrule.h): [0] fragments the columns cannot
+    // hold, [1] CIGAR-less read1 records with TLEN < 0
+    uint32_t skipped[2] = {0, 0};
     void append(const Columns& o) {
+        skipped[0] += o.skipped[0];
+        skipped[1] += o.skipped[1];
         start.insert(start.end(), o.start.begin(), o.start.end());
         end.insert(end.end(), o.end.begin(), o.end.end());
         mapq.insert(mapq.end(), o.mapq.begin(), o.mapq.end());
@@ -733,6 +739,7 @@ struct ftk_fragtable {
     std::vector<Contig> contigs;
     bool bed6 = false;
     bool bam = false;
+    int64_t skipped[2] = {0, 0};  // ftk_fragtable_skipped (whole-file BAM decoder)
     void* block = nullptr;  // one allocation holding every contig's columns (text decoder)
     bool block_pinned = false;
     ~ftk_fragtable() {
@@ -1220,6 +1227,25 @@ inline int32_t rd_i32(const uint8_t* p) { return (int32_t)((uint32_t)p[0] | ((ui
 inline uint32_t rd_u32(const uint8_t* p) { return (uint32_t)rd_i32(p); }
 inline uint16_t rd_u16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
+// One BAM alignment record -> fragment columns (io/alignment.py:60-71,242-268: the rule lives in ftk_bamrule.h,
+// shared with the device parser); false = no row.  Records the reference treats differently from "no fragment"
+// are counted in c.skipped.
+inline bool bam_record(const uint8_t* r, uint32_t bs, Columns& c) {
+    ftk::BamRow f;
+    const int rule = ftk::bam_rule(r, bs, [](const uint8_t* p) { return rd_u32(p); }, f);
+    if (rule != ftk::kBamFragment) {
+        if (rule != ftk::kBamNotFragment) ++c.skipped[rule == ftk::kBamNoCigarReverse];
+        return false;
+    }
+    c.start.push_back(f.fs);
+    c.end.push_back(f.fe);
+    c.mapq.push_back(f.mapq);
+    c.strand.push_back(f.fwd);
+    c.r1s.push_back(f.r1s);
+    c.r1e.push_back(f.r1e);
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1365,39 +1391,11 @@ static int ftk_bam_decode_impl(const char* path, const char* contig, int n_threa
         off += bs;
         int32_t ref_id = rd_i32(r);
         if (ref_id < 0 || (uint32_t)ref_id >= n_ref || ref_to_contig[ref_id] < 0) continue;
-        int32_t pos = rd_i32(r + 4);
-        uint8_t l_read_name = r[8];
-        uint8_t mapq = r[9];
-        uint16_t n_cigar = rd_u16(r + 12);
-        uint16_t flag = rd_u16(r + 14);
-        int32_t tlen = rd_i32(r + 28);
-        // _read_is_low_quality (io/alignment.py:60-71), mapq cut left to the kernels
-        if ((flag & 0x4) || (flag & 0x100) || !(flag & 0x1) || (flag & 0x8) || (flag & 0x400) || (flag & 0x200) ||
-            (flag & 0x800) || !(flag & 0x2))
-            continue;
-        if (flag & 0x80) continue;  // read1_only: skip read2
-        if (tlen == 0) continue;
-        if (32 + (size_t)l_read_name + 4 * (size_t)n_cigar > bs) return dfail(FTK_ERR_FORMAT, "corrupt BAM record");
-        const uint8_t* cg = r + 32 + l_read_name;
-        int64_t ref_len = 0;
-        for (uint16_t k = 0; k < n_cigar; ++k) {
-            uint32_t v = rd_u32(cg + 4 * k);
-            uint32_t op = v & 15;
-            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += v >> 4;
-        }
-        if (n_cigar == 0) continue;  // reference_end is None in pysam: cannot form the fragment
-        int64_t ref_end = (int64_t)pos + ref_len;
-        int64_t fs, fe;
-        if (tlen > 0) { fs = pos; fe = (int64_t)pos + tlen; } else { fs = ref_end + tlen; fe = ref_end; }
-        if (fs < 0 || fe < 0 || fs > INT32_MAX || fe > INT32_MAX) continue;
+        if (32 + (size_t)r[8] + 4 * (size_t)rd_u16(r + 12) > bs) return dfail(FTK_ERR_FORMAT, "corrupt BAM record");
         Columns& c = t->contigs[ref_to_contig[ref_id]].c;
-        c.start.push_back((int32_t)fs);
-        c.end.push_back((int32_t)fe);
-        c.mapq.push_back(mapq);
-        c.strand.push_back((flag & 0x10) ? 0 : 1);
-        c.r1s.push_back(pos);
-        c.r1e.push_back((int32_t)ref_end);
+        bam_record(r, bs, c);  // io/alignment.py:60-71,242-268 (ftk_bamrule.h)
     }
+    for (auto& ct : t->contigs) { t->skipped[0] += ct.c.skipped[0]; t->skipped[1] += ct.c.skipped[1]; }
     sw.lap("records");
     // the kernels need start-sorted fragments; read1 order is by read position (kept in `ord`)
     for (auto& ct : t->contigs) sort_by_start(ct.c, n_threads);
@@ -1796,40 +1794,6 @@ inline size_t guess_record_start(const uint8_t* p, size_t from, size_t m, int n_
     return fallback;
 }
 
-// One BAM alignment record -> fragment columns (io/alignment.py:60-71,242-268); false = not a fragment.
-inline bool bam_record(const uint8_t* r, uint32_t bs, Columns& c) {
-    const int32_t pos = rd_i32(r + 4);
-    const uint8_t l_read_name = r[8];
-    const uint8_t mapq = r[9];
-    const uint16_t n_cigar = rd_u16(r + 12);
-    const uint16_t flag = rd_u16(r + 14);
-    const int32_t tlen = rd_i32(r + 28);
-    if ((flag & 0x4) || (flag & 0x100) || !(flag & 0x1) || (flag & 0x8) || (flag & 0x400) || (flag & 0x200) ||
-        (flag & 0x800) || !(flag & 0x2))
-        return false;
-    if (flag & 0x80) return false;  // read1 only
-    if (tlen == 0 || n_cigar == 0) return false;
-    if (32 + (size_t)l_read_name + 4 * (size_t)n_cigar > bs) return false;
-    const uint8_t* cg = r + 32 + l_read_name;
-    int64_t ref_len = 0;
-    for (uint16_t k = 0; k < n_cigar; ++k) {
-        const uint32_t v = rd_u32(cg + 4 * k);
-        const uint32_t op = v & 15;
-        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += v >> 4;
-    }
-    const int64_t ref_end = (int64_t)pos + ref_len;
-    int64_t fs, fe;
-    if (tlen > 0) { fs = pos; fe = (int64_t)pos + tlen; } else { fs = ref_end + tlen; fe = ref_end; }
-    if (fs < 0 || fe < 0 || fs > INT32_MAX || fe > INT32_MAX) return false;
-    c.start.push_back((int32_t)fs);
-    c.end.push_back((int32_t)fe);
-    c.mapq.push_back(mapq);
-    c.strand.push_back((flag & 0x10) ? 0 : 1);
-    c.r1s.push_back(pos);
-    c.r1e.push_back((int32_t)ref_end);
-    return true;
-}
-
 }  // namespace
 
 // ---- tabix (.tbi) / BAM (.bai) index: where a contig's rows start and end in the file --------
@@ -1997,6 +1961,9 @@ struct ftk_fragstream {
     std::vector<int64_t> ref_lens;
     bool header_ready = false;
     double stage_ms[6] = {0, 0, 0, 0, 0, 0};  // read, inflate, parse, merge, emit, other: set when the producer is done
+    // BAM records the reference handles differently from "no fragment" (ftk_bamrule.h), met so far: [0] fragments the
+    // columns cannot hold (negative start / beyond int32), [1] CIGAR-less read1 with TLEN < 0 (ftk_fragstream_skipped)
+    std::atomic<int64_t> skipped[2] = {{0}, {0}};
 
     // Text files on a stream opened with ftk_fragstream_open_on: the rows are parsed on this GPU
     // (run_text_device) and the tables handed out hold device columns.
@@ -2363,6 +2330,8 @@ void ftk_fragstream::run_guarded() {
             fail(rc, g_decode_err.c_str());
         } else {
             bed6 = whole->bed6;
+            skipped[0] += whole->skipped[0];
+            skipped[1] += whole->skipped[1];
             if (bam) {
                 std::lock_guard<std::mutex> lk(mu);
                 for (auto& ct : whole->contigs) { ref_names.push_back(ct.name); ref_lens.push_back(ct.length); }
@@ -3903,6 +3872,8 @@ bool ftk_fragstream::run_bam(RawBuf& buf, size_t n_first) {
                         cur.length = ref_lens[r.ref];
                     }
                     cur_rows += r.c.start.size();
+                    skipped[0] += r.c.skipped[0];
+                    skipped[1] += r.c.skipped[1];
                     if (!r.c.start.empty()) cur.parts.push_back(std::move(r.c));  // sorted / gathered by the packer
                 }
             clk.lap(3);
@@ -4428,6 +4399,8 @@ bool ftk_fragstream::run_bam_device(RawBuf& buf, size_t n_first) {
         ++n_pieces;
         n_rows_total += B.n_rows;
         n_records += B.n_records;
+        skipped[0] += B.n_unrepresentable;
+        skipped[1] += B.n_nocigar_reverse;
         last_key = std::max(last_key, (unsigned long long)B.last_key);
         S.freed_valid = hipEventRecord(S.freed, pstream) == hipSuccess;
         if (!S.freed_valid) {
@@ -4643,6 +4616,20 @@ const char* ftk_fragstream_ref_name(ftk_fragstream* s, int i) {
 int64_t ftk_fragstream_ref_length(ftk_fragstream* s, int i) {
     if (!s || i < 0 || i >= ftk_fragstream_n_refs(s)) return -1;
     return s->ref_lens[i];
+}
+
+int ftk_fragstream_skipped(ftk_fragstream* s, int64_t out[2]) {
+    if (!s || !out) return FTK_ERR_INVALID;
+    out[0] = s->skipped[0].load();
+    out[1] = s->skipped[1].load();
+    return FTK_OK;
+}
+
+int ftk_fragtable_skipped(const ftk_fragtable* t, int64_t out[2]) {
+    if (!t || !out) return FTK_ERR_INVALID;
+    out[0] = t->skipped[0];
+    out[1] = t->skipped[1];
+    return FTK_OK;
 }
 
 int ftk_fragstream_stage_ms(ftk_fragstream* s, double out[6]) {

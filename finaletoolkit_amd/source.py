@@ -91,6 +91,25 @@ def decode_threads(workers: int | None = None) -> int:
     return max(1, min(64, usable_cores()))
 
 
+
+def _check_skipped(lib, stream, path: str, seen: list) -> None:
+    """After an ``ftk_fragstream_next`` on a BAM stream: act on the records the decoder met that the reference does
+    not simply skip (``include/ftk.h``: ``ftk_fragstream_skipped``).  A CIGAR-less read1 with TLEN < 0 makes the
+    reference raise ``TypeError`` (``None + tlen``, io/alignment.py:257) - so does this; a fragment with a negative
+    start is yielded by the reference and cannot be held by the int32 columns here - dropped, with a warning."""
+    out = (C.c_int64 * 2)()
+    if lib.ftk_fragstream_skipped(stream, C.byref(out)) != L.FTK_OK:
+        return
+    if out[1] > 0:
+        raise TypeError("unsupported operand type(s) for +: 'NoneType' and 'int' "
+                        f"({path}: {out[1]} read1 record(s) without a CIGAR and with TLEN < 0 - pysam's reference_end "
+                        "is None for them, and the reference fails the same way at io/alignment.py:257)")
+    if out[0] > seen[0]:
+        warnings.warn(f"{path}: {out[0] - seen[0]} read1 record(s) whose fragment starts before position 0 "
+                      "(reference_end + TLEN < 0) or lies beyond 2^31 were dropped; the reference keeps such "
+                      "fragments", UserWarning, stacklevel=3)
+        seen[0] = out[0]
+
 class FragSource:
     """One input file; contig ``c`` lives on the engine as ``key(c)`` once it has been decoded.
 
@@ -148,6 +167,13 @@ class FragSource:
             rc = lib.ftk_fragstream_next(stream, C.byref(table))
             if rc != L.FTK_OK:
                 raise UnsupportedFormatError(lib.ftk_fragtable_error().decode())
+            if self.is_bam:
+                try:
+                    _check_skipped(lib, stream, self.path, [0])
+                except TypeError:
+                    if table.value:
+                        lib.ftk_fragtable_free(table)
+                    raise
             if table.value:
                 try:
                     eng.load_contig_from_table(self.key(contig), table, 0, self.is_bam)
@@ -192,6 +218,13 @@ class FragSource:
             rc = lib.ftk_fragstream_next(stream, C.byref(table))
             if rc != L.FTK_OK:
                 raise UnsupportedFormatError(lib.ftk_fragtable_error().decode())
+            if self.is_bam:
+                try:
+                    _check_skipped(lib, stream, self.path, [0])
+                except TypeError:
+                    if table.value:
+                        lib.ftk_fragtable_free(table)
+                    raise
             if table.value:
                 try:
                     eng.load_contig_from_table(key, table, 0, self.is_bam)
@@ -261,12 +294,20 @@ class FragSource:
                                             decode_threads(self.workers), 2, C.byref(stream))
         if rc != L.FTK_OK:
             raise UnsupportedFormatError(lib.ftk_fragtable_error().decode())
+        seen = [0]
         try:
             while True:
                 table = C.c_void_p()
                 rc = lib.ftk_fragstream_next(stream, C.byref(table))
                 if rc != L.FTK_OK:
                     raise UnsupportedFormatError(lib.ftk_fragtable_error().decode())
+                if self.is_bam:
+                    try:
+                        _check_skipped(lib, stream, self.path, seen)
+                    except TypeError:
+                        if table.value:
+                            lib.ftk_fragtable_free(table)
+                        raise
                 if not table.value:
                     break
                 try:
@@ -373,12 +414,20 @@ def stream_source(input_file, workers: int | None = None, queued: int = 2):
                 name = lib.ftk_fragstream_ref_name(stream, i).decode()
                 src.contigs.append(name)
                 src.lengths[name] = lib.ftk_fragstream_ref_length(stream, i)
+        seen = [0]
         while True:
             table = C.c_void_p()
             rc = lib.ftk_fragstream_next(stream, C.byref(table))
             if rc != L.FTK_OK:
                 msg = lib.ftk_fragtable_error().decode()
                 raise FileNotFoundError(msg) if rc == L.FTK_ERR_IO else UnsupportedFormatError(msg)
+            if is_bam:
+                try:
+                    _check_skipped(lib, stream, path, seen)
+                except TypeError:
+                    if table.value:
+                        lib.ftk_fragtable_free(table)
+                    raise
             if not table.value:
                 break
             try:

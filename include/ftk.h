@@ -134,7 +134,9 @@ int ftk_frags_release(ftk_ctx* ctx, int contig_id);
  * col 5.  Rows that do not parse are skipped (io/alignment.py:301-302).  No
  * mapq filtering here: mapq is a column, the cut is applied by the kernels.
  * io/alignment.py:242-268 (_fetch_sam): BAM records -> fragments (flag filter,
- * read1 only, TLEN reconstruction); rows sorted by fragment start. */
+ * read1 only, TLEN reconstruction: TLEN > 0 -> [pos, pos + TLEN), CIGAR or not; TLEN < 0 ->
+ * [end + TLEN, end) with end = htslib's bam_endpos = pos + max(reference length of the CIGAR, 1));
+ * the read1 span kept for region queries is [pos, bam_endpos); rows sorted by fragment start. */
 int ftk_fragfile_decode(const char* path, const char* contig /* NULL = all */, int n_threads, ftk_fragtable** out);
 int ftk_bam_decode(const char* path, const char* contig /* NULL = all */, int n_threads, ftk_fragtable** out);
 /* The same decoders as a stream: a producer thread decodes the file piece by piece (BGZF blocks in
@@ -192,6 +194,17 @@ int64_t ftk_fragstream_ref_length(ftk_fragstream* s, int i);
  * collect, hand-over (pack + waiting for queue space), everything else.  The stages of one piece run one after
  * the other on the producer; their work is spread over n_threads (and the GPU for the device row parser). */
 int ftk_fragstream_stage_ms(ftk_fragstream* s, double out[6]);
+/* BAM records met so far (cumulative; read it after every ftk_fragstream_next, the final one included) that the
+ * reference does NOT simply skip and this library cannot turn into a row (csrc/ftk_bamrule.h):
+ *   out[0]  read1 records whose fragment the int32 columns cannot hold - a NEGATIVE start (reference_end + TLEN < 0,
+ *           io/alignment.py:257) or a coordinate beyond 2^31 - 1.  The reference yields such a fragment; here it is
+ *           dropped and counted (the Python surface issues a UserWarning).
+ *   out[1]  read1 records WITHOUT a CIGAR and TLEN < 0.  pysam's reference_end is None for them and the reference
+ *           raises TypeError at io/alignment.py:257; here they are dropped and counted (the Python surface raises
+ *           TypeError).  A CIGAR-less read1 with TLEN > 0 is a fragment, as in the reference (:253-255).
+ * ftk_fragtable_skipped: the same two numbers for a table of the whole-file decoder ftk_bam_decode. */
+int ftk_fragstream_skipped(ftk_fragstream* s, int64_t out[2]);
+int ftk_fragtable_skipped(const ftk_fragtable* t, int64_t out[2]);
 void ftk_fragstream_close(ftk_fragstream* s);
 const char* ftk_fragtable_error(void); /* message for a failed decode call (thread-local) */
 int ftk_fragtable_is_bed6(const ftk_fragtable* t);

@@ -48,8 +48,12 @@ typedef struct {
     const int32_t* r1s; /* BAM: read1 alignment span, else NULL */
     const int32_t* r1e;
     int64_t n;
-    int32_t max_len; /* longest row, for the bisection bound */
+    int32_t max_len; /* bisection bound: how far behind its start a row's tested interval (the row; BAM: read1) ends */
+    int32_t hi_slack; /* BAM: how far in FRONT of its fragment's start a read1 alignment begins (0 for tabix rows) */
 } orc_frags;
+
+/* Python's `//` by 2 (floor), also for the negative sums a BAM fragment with a negative start gives. */
+static int64_t floor_half(int64_t v) { return (v - (v < 0 ? 1 : 0)) / 2; }
 
 static int64_t lower_bound_i32(const int32_t* a, int64_t n, int64_t v) {
     int64_t lo = 0, hi = n;
@@ -63,19 +67,23 @@ static int64_t lower_bound_i32(const int32_t* a, int64_t n, int64_t v) {
 void orc_frags_init(orc_frags* f, const int32_t* start, const int32_t* end, const uint8_t* mapq,
                     const uint8_t* strand, const int32_t* r1s, const int32_t* r1e, int64_t n) {
     f->start = start; f->end = end; f->mapq = mapq; f->strand = strand; f->r1s = r1s; f->r1e = r1e; f->n = n;
-    int32_t m = 0;
+    int64_t m = 0, h = 0;
     for (int64_t i = 0; i < n; ++i) {
-        int32_t len = end[i] - start[i];
+        int64_t len = (int64_t)end[i] - start[i];
         if (len > m) m = len;
-        if (r1s && r1e[i] - r1s[i] > m) m = r1e[i] - r1s[i];
+        if (r1s) { /* read1 need not lie inside its fragment (TLEN is whatever the aligner wrote) */
+            if ((int64_t)r1e[i] - start[i] > m) m = (int64_t)r1e[i] - start[i];
+            if ((int64_t)start[i] - r1s[i] > h) h = (int64_t)start[i] - r1s[i];
+        }
     }
-    f->max_len = m;
+    f->max_len = (int32_t)(m > INT32_MAX ? INT32_MAX : m);
+    f->hi_slack = (int32_t)(h > INT32_MAX ? INT32_MAX : h);
 }
 
 /* Row range that can contain anything an index query for [ws, we) returns. */
 static void fetch_range(const orc_frags* f, int32_t ws, int32_t we, int64_t* lo, int64_t* hi) {
     *lo = (ws == OPEN_LO) ? 0 : lower_bound_i32(f->start, f->n, (int64_t)ws - f->max_len);
-    *hi = (we == OPEN_HI) ? f->n : lower_bound_i32(f->start, f->n, (int64_t)we);
+    *hi = (we == OPEN_HI) ? f->n : lower_bound_i32(f->start, f->n, (int64_t)we + f->hi_slack);
     if (*hi < *lo) *hi = *lo;
 }
 
@@ -96,7 +104,7 @@ static int passes(const orc_frags* f, int64_t i, int32_t ws, int32_t we, const o
     if (flt->min_len != -1 && !(len >= flt->min_len)) return 0;   /* _comparison.py:20-24 */
     if (flt->max_len != -1 && !(len <= flt->max_len)) return 0;   /* _comparison.py:13-17 */
     if (flt->policy == 0) {                                       /* _frag_generator.py:35-42 */
-        int64_t mid = ((int64_t)fs + (int64_t)fe) / 2;            /* floor: operands >= 0 */
+        int64_t mid = floor_half((int64_t)fs + (int64_t)fe);
         if (ws != OPEN_LO && !(mid >= ws)) return 0;
         if (we != OPEN_HI && !(mid < we)) return 0;
     } else if (flt->policy == 1) {                                /* _frag_generator.py:44-50 */
@@ -198,7 +206,7 @@ void orc_delfi_counts(const orc_frags* f, const int32_t* ws, const int32_t* we, 
             int32_t frag_start = f->start[i], frag_stop = f->end[i];
             int32_t frag_length = frag_stop - frag_start;
             if (frag_length < 100 || frag_length > 220) continue;            /* :448 */
-            int64_t midpoint = ((int64_t)frag_start + frag_stop) / 2;         /* :451 */
+            int64_t midpoint = floor_half((int64_t)frag_start + frag_stop);   /* :451 */
             if (midpoint < window_start || midpoint >= window_stop) continue; /* :452 */
             int blacklisted = 0;                                              /* :455-462 */
             for (int64_t r = 0; r < n_reg; ++r) {
@@ -230,7 +238,7 @@ int orc_wps(const orc_frags* f, int64_t start, int64_t stop, int64_t chrom_size,
     int64_t maximum = stop + max_len; if (maximum > chrom_size) maximum = chrom_size; /* :157 */
     /* frag_array(start=minimum, stop=maximum, midpoint) */
     int64_t lo = lower_bound_i32(f->start, f->n, minimum - f->max_len);
-    int64_t hi = lower_bound_i32(f->start, f->n, maximum);
+    int64_t hi = lower_bound_i32(f->start, f->n, maximum + f->hi_slack);
     if (hi < lo) hi = lo;
     int64_t cap = hi - lo, m = 0;
     double* fs = (double*)malloc(sizeof(double) * (size_t)(cap > 0 ? cap : 1));
@@ -246,7 +254,7 @@ int orc_wps(const orc_frags* f, int64_t start, int64_t stop, int64_t chrom_size,
         if ((int32_t)f->mapq[i] < mapq_min) continue;
         int32_t len = e - s;
         if (!(len >= min_len) || !(len <= max_len)) continue;
-        int64_t mid = ((int64_t)s + e) / 2;
+        int64_t mid = floor_half((int64_t)s + e);
         if (!(mid >= minimum && mid < maximum)) continue;
         fs[m] = (double)s; fe[m] = (double)e; ++m;
     }

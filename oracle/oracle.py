@@ -42,7 +42,8 @@ class _Gaps(C.Structure):
 
 class _Frags(C.Structure):
     _fields_ = [("start", C.c_void_p), ("end", C.c_void_p), ("mapq", C.c_void_p), ("strand", C.c_void_p),
-                ("r1s", C.c_void_p), ("r1e", C.c_void_p), ("n", C.c_int64), ("max_len", C.c_int32)]
+                ("r1s", C.c_void_p), ("r1e", C.c_void_p), ("n", C.c_int64), ("max_len", C.c_int32),
+                ("hi_slack", C.c_int32)]
 
 
 def build():
@@ -197,6 +198,65 @@ def c_cleavage(fr: Frags, adj_start, adj_stop, min_len=None, max_len=None, mapq_
 
 
 # ---------------------------------------------------------------------------
+# BAM records -> rows (restates io/alignment.py:60-71,242-268 over records read with gzip + struct; pinned to the
+# reference's own code by tests/golden/bam.json.gz, oracle/gen_golden_bam.py)
+# ---------------------------------------------------------------------------
+def bam_rows(path, read1_only=True):
+    """``(names, lengths, {contig: rows})``: per contig the rows ``(fs, fe, mapq, fwd, r1s, r1e)`` the reference's
+    ``_fetch_sam`` yields for a whole-contig fetch at ``quality_threshold=0``, in FILE order; ``[r1s, r1e)`` is the
+    alignment htslib's region iterator tests (``bam_endpos``: a reference length of 0 counts as 1).  Raises TypeError
+    where the reference does (a CIGAR-less read1 with TLEN < 0: ``None + tlen``, :257)."""
+    import gzip
+    import struct
+    with gzip.open(path, "rb") as fh:
+        data = fh.read()
+    assert data[:4] == b"BAM\1"
+    (l_text,) = struct.unpack_from("<i", data, 4)
+    o = 8 + l_text
+    (n_ref,) = struct.unpack_from("<i", data, o)
+    o += 4
+    names, lengths = [], []
+    for _ in range(n_ref):
+        (l_name,) = struct.unpack_from("<i", data, o)
+        names.append(data[o + 4:o + 4 + l_name - 1].decode())
+        lengths.append(struct.unpack_from("<i", data, o + 4 + l_name)[0])
+        o += 8 + l_name
+    out = {n: [] for n in names}
+    while o + 4 <= len(data):
+        (bs,) = struct.unpack_from("<i", data, o)
+        ref_id, pos, l_name, mapq, _bin, n_cigar, flag, _l_seq, _nref, _npos, tlen = struct.unpack_from("<iiBBHHHiiii", data, o + 4)
+        cigar = struct.unpack_from(f"<{n_cigar}I", data, o + 4 + 32 + l_name)
+        o += 4 + bs
+        if ref_id < 0:
+            continue
+        # _read_is_low_quality (:60-71) at quality_threshold 0
+        if (flag & 0x4) or (flag & 0x100) or not (flag & 0x1) or (flag & 0x8) or (flag & 0x400) or (flag & 0x200) \
+                or (flag & 0x800) or not (flag & 0x2):
+            continue
+        if read1_only and (flag & 0x80):  # :248
+            continue
+        rlen = sum(v >> 4 for v in cigar if (v & 15) in (0, 2, 3, 7, 8))
+        end_pos = pos + (rlen or 1)                       # htslib bam_endpos
+        reference_end = end_pos if n_cigar else None      # pysam: None without a CIGAR
+        if tlen > 0:                                      # :253-255
+            fs, fe = pos, pos + tlen
+        elif tlen < 0:                                    # :256-258
+            fs, fe = reference_end + tlen, reference_end
+        else:
+            continue
+        out[names[ref_id]].append((fs, fe, mapq, 0 if flag & 0x10 else 1, pos, end_pos))
+    return names, lengths, out
+
+
+def frags_from_bam_rows(rows):
+    """``Frags`` (start-sorted, stable: equal starts keep file order) of one contig's ``bam_rows`` + the file rank
+    of every sorted row."""
+    order = sorted(range(len(rows)), key=lambda j: rows[j][0])
+    a = np.array([rows[j] for j in order], dtype=np.int64).reshape(-1, 6)
+    return Frags(a[:, 0], a[:, 1], a[:, 2], a[:, 3], a[:, 4], a[:, 5]), np.array(order, np.int64)
+
+
+# ---------------------------------------------------------------------------
 # Pure-Python, reference-shaped restatement (small cases / timed baseline)
 # ---------------------------------------------------------------------------
 def _none_geq(a, b):  # utils/_comparison.py:20-24
@@ -209,11 +269,15 @@ def _none_leq(a, b):  # utils/_comparison.py:13-17
 
 def py_fetch(rows, start, stop, quality_threshold):
     """io/alignment.py:270-302 over in-memory rows ``(fs, fe, mapq, fwd)``
-    of one contig: tabix overlap query, then the mapq cut."""
-    for fs, fe, mapq, fwd in rows:
-        if stop is not None and not fs < stop:
+    of one contig: tabix overlap query, then the mapq cut.  Rows of a BAM
+    (``bam_rows``) carry two more fields, read1's alignment ``[r1s, r1e)``:
+    that is what the index query tests there (io/alignment.py:245)."""
+    for row in rows:
+        fs, fe, mapq, fwd = row[:4]
+        a, b = (row[4], row[5]) if len(row) > 4 else (fs, fe)
+        if stop is not None and not a < stop:
             continue
-        if start is not None and not fe > start:
+        if start is not None and not b > start:
             continue
         if mapq < quality_threshold:
             continue

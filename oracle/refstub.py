@@ -139,8 +139,12 @@ def install():
     if "pysam" not in sys.modules:
         pysam = types.ModuleType("pysam")
         pysam.TabixFile = _TabixFile
-        pysam.AlignmentFile = type("AlignmentFile", (_Dummy,), {})
-        pysam.AlignedSegment = type("AlignedSegment", (_Dummy,), {})
+        try:
+            from . import bamstub
+        except ImportError:
+            import bamstub
+        pysam.AlignmentFile = bamstub.AlignmentFile
+        pysam.AlignedSegment = bamstub.AlignedSegment
         pysam.FastaFile = _FastaFile
         pysam.asTuple = lambda *a, **k: None
         pysam.faidx = lambda *a, **k: None

@@ -224,3 +224,54 @@ def write_bins20(path, contigs):
         for c in sorted(contigs, reverse=True):
             for a in range(0, contigs[c], 20):
                 fh.write(f"{c}\t{a}\t{min(a + 19, contigs[c])}\n")
+
+
+def bam_reg2bin(beg, end):
+    """The SAM specification's ``reg2bin`` (the ``bin`` field of a BAM record)."""
+    end -= 1
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return base + (beg >> shift)
+    return 0
+
+
+_CIGAR_OPS = "MIDNSHP=XB"
+
+
+def bam_record(ref_id, pos, mapq, flag, cigar, tlen, name, l_seq=None, mate_ref=None, mate_pos=0, aux=b""):
+    """One BAM alignment record (block_size included).  ``cigar``: text (``"5S40M3I2D"``, ``"*"`` / ``""`` = none) or
+    ``[(op, length)]`` with numeric ops; ``l_seq`` defaults to the query length the CIGAR implies."""
+    import re
+    import struct
+    if isinstance(cigar, str):
+        cigar = [] if cigar in ("", "*") else [(_CIGAR_OPS.index(o), int(n)) for n, o in re.findall(r"(\d+)([MIDNSHP=XB])", cigar)]
+    if l_seq is None:
+        l_seq = sum(n for op, n in cigar if op in (0, 1, 4, 7, 8))
+    rlen = 0 if flag & 0x4 else sum(n for op, n in cigar if op in (0, 2, 3, 7, 8))
+    nm = name.encode() + b"\0"
+    body = struct.pack("<iiBBHHHiiii", ref_id, pos, len(nm), mapq, bam_reg2bin(max(pos, 0), max(pos, 0) + (rlen or 1)),
+                       len(cigar), flag, l_seq, ref_id if mate_ref is None else mate_ref, mate_pos, tlen)
+    body += nm + b"".join(struct.pack("<I", (n << 4) | op) for op, n in cigar)
+    body += b"\x12" * ((l_seq + 1) // 2) + b"\x1e" * l_seq + aux
+    return struct.pack("<i", len(body)) + body
+
+
+def write_bam(path, contigs, records, level=6):
+    """Write ``records`` -- ``[(ref_id, pos, bytes from bam_record)]``, already in file order -- as a BAM with the
+    header of ``contigs = [(name, length)]`` and a minimal BAI (every reference's span), using only ``zlib``."""
+    import struct
+    from finaletoolkit_amd import bgzf
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{c}\tLN:{n}\n" for c, n in contigs)
+    head = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(contigs))
+    for c, n in contigs:
+        head += struct.pack("<i", len(c) + 1) + c.encode() + b"\0" + struct.pack("<i", n)
+    spans = {}
+    o = len(head)
+    for ref_id, _, b in records:
+        a, _ = spans.get(ref_id, (o, o))
+        spans[ref_id] = (a, o + len(b))
+        o += len(b)
+    offsets = bgzf.write_bgzf(path, head + b"".join(r[2] for r in records), level=level)
+    bgzf.write_index(str(path) + ".bai", True,
+                     [(c, bgzf.virtual_offset(offsets, spans.get(k, (0, 0))[0]), bgzf.virtual_offset(offsets, spans.get(k, (0, 0))[1]))
+                      for k, (c, _) in enumerate(contigs)])

@@ -175,3 +175,69 @@ def test_bam_wps_interval_calls_through_the_index_equal_the_whole_contig(tmp_pat
         differ_from_slice += int(r.any())
     assert differ_from_slice == len(cases)
     source.close_all()
+
+
+def _golden_rows(contig):
+    """Whole-contig rows of tests/golden/edge.bam as the imported reference's AlignmentWrapper yielded them
+    (oracle/gen_golden_bam.py), file order; fragments with a negative start removed (the int32 columns cannot
+    hold them: counted by ftk_*_skipped instead)."""
+    from tests.test_oracle_golden_bam import bam_golden
+    G = bam_golden()
+    for sec in ("edge", "negative_start"):
+        for case in G[sec]["fetch"]:
+            if case["contig"] == contig and case["start"] is None and case["stop"] is None and case["quality_threshold"] == 0:
+                return [r for r in case["fragments"] if r[1] >= 0], sum(r[1] < 0 for r in case["fragments"])
+    raise KeyError(contig)
+
+
+def test_host_decoders_hold_the_reference_generated_rows():
+    """ftk_bam_decode and the host stream on the edge BAM (multi-op CIGARs, CIGAR-less records, alignments that
+    consume no reference, every rejected flag): the rows the REFERENCE yields, in its order, the read1 spans
+    htslib's iterator would test; what it cannot hold is counted, not silently dropped."""
+    import ctypes as C
+    import os
+    from finaletoolkit_amd import _lib as L
+    from oracle import oracle as O
+    from tests.helpers import GOLDEN
+    from tests.test_stream_decoder import _stream
+    path = os.path.join(GOLDEN, "edge.bam")
+    _, _, rows = O.bam_rows(path)  # (held to the same goldens by tests/test_oracle_golden_bam.py)
+    whole = _decode(path, bam=True, threads=3)
+    streamed, order, refs = _stream(path, bam=True, threads=2)
+    assert [r[0] for r in refs] == ["chrA", "chrB", "chrN", "chrZ"] and order == ["chrA", "chrB", "chrN"]
+    n_neg = 0
+    for c in ("chrA", "chrB", "chrN"):
+        want, neg = _golden_rows(c)
+        n_neg += neg
+        r1 = {}
+        for r in rows[c]:
+            r1.setdefault(r[:4], []).append(r[4:6])
+        for got in (whole[c], streamed[c]):
+            n, cols, _ = got
+            assert n == len(want), c
+            rank = _order(path, c)
+            by_file = np.argsort(rank, kind="stable")
+            s, e, q, st, a, b = [np.asarray(x)[by_file].tolist() for x in cols]
+            assert [[c, s[i], e[i], q[i], bool(st[i])] for i in range(n)] == want, c
+            for i in range(n):  # the read1 span of every row: [pos, bam_endpos)
+                assert (a[i], b[i]) in r1[(s[i], e[i], q[i], st[i])], (c, i)
+            assert np.all(np.diff(np.asarray(cols[0], np.int64)) >= 0)
+    assert whole["chrZ"][0] == 0 and n_neg == 4
+    lib = L.load()
+    out = (C.c_int64 * 2)()
+    t = C.c_void_p()
+    assert lib.ftk_bam_decode(path.encode(), None, 2, C.byref(t)) == 0
+    assert lib.ftk_fragtable_skipped(t, C.byref(out)) == 0 and list(out) == [4, 0]
+    lib.ftk_fragtable_free(t)
+    t = C.c_void_p()
+    assert lib.ftk_bam_decode(os.path.join(GOLDEN, "edge_nocigar.bam").encode(), None, 1, C.byref(t)) == 0
+    assert lib.ftk_fragtable_skipped(t, C.byref(out)) == 0 and list(out) == [0, 1]   # the reference raises TypeError there
+    assert lib.ftk_fragtable_contig_rows(t, 0) == 1
+    lib.ftk_fragtable_free(t)
+    s = C.c_void_p()
+    assert lib.ftk_fragstream_open(path.encode(), b"chrN", 1, 2, 1, C.byref(s)) == 0
+    t = C.c_void_p()
+    assert lib.ftk_fragstream_next(s, C.byref(t)) == 0 and t.value
+    assert lib.ftk_fragstream_skipped(s, C.byref(out)) == 0 and list(out) == [4, 0]
+    lib.ftk_fragtable_free(t)
+    lib.ftk_fragstream_close(s)
