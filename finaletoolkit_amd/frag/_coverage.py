@@ -76,6 +76,7 @@ def single_coverage(input_file: Union[str, Path], contig: str | None = None, sta
     _check_policy(intersect_policy)
     _check_region(contig, start, stop)
     src = open_source(input_file)
+    src.check_fetch(contig, start, stop)
     cov = _total(src, contig, start, stop, min_length, max_length, intersect_policy, quality_threshold)
     if verbose:
         sys.stderr.write(f"single_coverage took {time.time() - t0} s to complete\n")

@@ -129,6 +129,7 @@ def frag_length(input_file: Union[str, Path], contig: str | None = None, start: 
     _check_policy(intersect_policy)
     _check_region(contig, start, stop)
     src = open_source(input_file)
+    src.check_fetch(contig, start, stop)
     eng = get_engine()
     names, whole = _region_contigs(src, contig)
     parts = [eng.frag_lengths(src.require(c) if whole else src.require_interval(c, start, stop, 1), None if whole else start, None if whole else stop, quality_threshold,
@@ -168,6 +169,7 @@ def frag_length_bins(input_file, contig: str | None = None, start: int | None = 
     _check_policy(intersect_policy)
     _check_region(contig, start, stop)
     src = open_source(input_file)
+    src.check_fetch(contig, start, stop)
     eng = get_engine()
     if contig is None and sharding.rank_world()[1] > 1:
         # (several ranks: a rank decodes only the contigs it is dealt below - not the whole file, as ``load_all`` would)

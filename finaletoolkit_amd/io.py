@@ -74,6 +74,7 @@ class AlignmentWrapper:
             raise ValueError("I/O operation on closed file")
         from .source import get_engine
         src, eng = self._src, get_engine()
+        src.check_fetch(contig, start, stop)
         if contig is None:
             src.load_all()
             todo = [(c, src.require(c), None, None) for c in src.contigs if c in src.loaded]

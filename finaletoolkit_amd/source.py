@@ -144,6 +144,22 @@ class FragSource:
     def has(self, contig: str) -> bool:
         return contig in self.loaded or (self.lazy and contig in self.contigs)
 
+    def check_fetch(self, contig, start, stop) -> None:
+        """pysam's argument checks for ``AlignmentFile.fetch(contig, start, stop)`` (libcalignmentfile.pyx
+        ``parse_region``), which the reference's BAM path inherits (io/alignment.py:245): a negative start and
+        ``start > stop`` are ``ValueError``s.  (Unknown contigs: ``require``.)  Tabix input is not checked here - the
+        reference's tabix path is pinned with bounds it accepts only."""
+        if not self.is_bam or contig is None:
+            return
+        a = 0 if start is None else int(start)
+        b = (1 << 31) - 1 if stop is None else int(stop)
+        if a > b:
+            raise ValueError(f"invalid coordinates: start ({a}) > stop ({b})")
+        if not 0 <= a < (1 << 31) - 1:
+            raise ValueError(f"start out of range ({a})")
+        if not 0 <= b <= (1 << 31) - 1:
+            raise ValueError(f"stop out of range ({b})")
+
     def require(self, contig: str) -> str:
         """Engine key of ``contig`` (decoding it now if the source is lazy); ValueError if the file has no
         such contig (pysam raises ValueError for an unknown region, which the reference lets propagate)."""

@@ -120,6 +120,7 @@ def frag_generator(input_file, contig, quality_threshold: int = 30, start=None, 
     _check_policy(intersect_policy)
     _check_region(contig, start, stop)
     src = open_source(input_file)
+    src.check_fetch(contig, start, stop)
     eng = get_engine()
     names, whole = _region_contigs(src, contig)
     for c in names:
@@ -137,6 +138,7 @@ def frag_array(input_file, contig: str, quality_threshold: int = 30, start=None,
     _check_policy(intersect_policy)
     _check_region(contig, start, stop)
     src = open_source(input_file)
+    src.check_fetch(contig, start, stop)
     eng = get_engine()
     names, whole = _region_contigs(src, contig)
     parts = []
