@@ -618,21 +618,69 @@ def inflate_alone_rates():
         return None
 
 
-def leg_floor(leg, file_bytes, inflated_bytes, kind, h2d_gbs, rates):
-    """The file legs' own roofline: no run of the leg can be shorter than the compressed bytes crossing PCIe at the
-    measured rate, nor than the inflate kernel alone on all of its blocks (the slower of the two; they overlap)."""
+def measure_d2h_gbs(torch, dev, mb: int = 256) -> float:
+    """Device -> host rate of this box for one large page-locked copy (GB/s, best of four): the score term of the floor
+    of the legs that return per-base results."""
+    dst = torch.empty(mb << 20, dtype=torch.uint8).pin_memory()
+    src = torch.empty(mb << 20, dtype=torch.uint8, device=dev)
+    best = 1e9
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    del src, dst
+    return (mb << 20) / best / 1e9
+
+
+def measure_host_write_gbs(threads: int, mb_per_thread: int = 192) -> float:
+    """What this box's cores can WRITE to memory together (GB/s): `threads` threads each filling their own array, best of
+    three.  An upper bound on any widening of narrow per-base scores into the caller's int64 array, whose result bytes
+    must at least be written once - the host term of the floor of the legs that return per-base results."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = max(1, min(threads, 64))
+    bufs = [np.empty(mb_per_thread << 20, np.uint8) for _ in range(n)]
+    for b in bufs:
+        b.fill(1)  # (pages faulted in before the clock starts)
+    best = 1e9
+    with ThreadPoolExecutor(n) as ex:
+        for _ in range(3):
+            t0 = time.perf_counter()
+            list(ex.map(lambda b: b.fill(0), bufs))
+            best = min(best, time.perf_counter() - t0)
+    return n * (mb_per_thread << 20) / best / 1e9
+
+
+LINK = {}  # measured once per run by end_to_end: d2h_GBps, host_write_GBps
+
+
+def leg_floor(leg, file_bytes, inflated_bytes, kind, h2d_gbs, rates, score_bases: int = 0):
+    """The file legs' own roofline.  No run of the leg can be shorter than (the stages overlap, so the floor is the
+    LONGEST of them): the compressed bytes crossing PCIe at the measured H2D rate; the inflate kernel alone on all of its
+    blocks; and, for a leg that hands `score_bases` per-base int64 scores to the host, those scores crossing the link the
+    other way on the narrow wire (2 B per base at the measured D2H rate) and their 8 B per base being written into the
+    caller's array by the host cores (at what the cores can write together, measured)."""
     pcie_s = file_bytes / (h2d_gbs * 1e9) if h2d_gbs else None
     rate = (rates or {}).get({"bam": "bam_GBps", "text": "text_GBps"}.get(kind, kind + "_GBps"))
     infl_s = inflated_bytes / (rate * 1e9) if rate else None
-    terms = [t for t in (pcie_s, infl_s) if t]
+    d2h_s = widen_s = None
+    if score_bases and LINK.get("d2h_GBps"):
+        d2h_s = 2 * score_bases / (LINK["d2h_GBps"] * 1e9)
+    if score_bases and LINK.get("host_write_GBps"):
+        widen_s = 8 * score_bases / (LINK["host_write_GBps"] * 1e9)
+    terms = [t for t in (pcie_s, infl_s, d2h_s, widen_s) if t]
     if not terms:
         return
     floor = max(terms)
-    leg["floor"] = dict(floor_s=round(floor, 4), pcie_s=None if pcie_s is None else round(pcie_s, 4),
-                        inflate_alone_s=None if infl_s is None else round(infl_s, 4),
+    r4 = lambda v: None if v is None else round(v, 4)  # noqa: E731
+    leg["floor"] = dict(floor_s=round(floor, 4), pcie_s=r4(pcie_s), inflate_alone_s=r4(infl_s),
                         h2d_GBps_measured=None if not h2d_gbs else round(h2d_gbs, 1), inflate_GBps=rate,
                         inflate_rate_source=(rates or {}).get("source"),
                         frac_of_floor_best=round(floor / leg["best_s"], 3), frac_of_floor_median=round(floor / leg["median_s"], 3))
+    if score_bases:
+        leg["floor"].update(d2h_s=r4(d2h_s), host_widen_s=r4(widen_s), score_bases=int(score_bases),
+                            d2h_GBps_measured=LINK.get("d2h_GBps"), host_write_GBps_measured=LINK.get("host_write_GBps"))
 
 
 def multi_rank_file_leg(torch, grp, rank, world, sizes, depth, reps: int = 2):
@@ -763,6 +811,8 @@ def end_to_end(torch, reps: int = 3, cpu=None):
         torch.cuda.empty_cache()
         res["device_settle_s"] = round(time.perf_counter() - t_settle, 4)
         h2d = measure_h2d_gbs(torch, dev)
+        LINK["d2h_GBps"] = round(measure_d2h_gbs(torch, dev), 1)
+        LINK["host_write_GBps"] = round(measure_host_write_gbs(threads), 1)
         rates = inflate_alone_rates()
 
         def make_file(path, names):
@@ -824,7 +874,8 @@ def end_to_end(torch, reps: int = 3, cpu=None):
                            decoder_producer_stage_ms=src.decode_stage_ms if src is not None else None, results_ok=bool(ok))
                 runs.append(cur)
             leg = rep_summary(runs)
-            leg_floor(leg, os.path.getsize(path), sum(t.get("text_bytes", 0) for t in truth.values()), "text", h2d, rates)
+            leg_floor(leg, os.path.getsize(path), sum(t.get("text_bytes", 0) for t in truth.values()), "text", h2d, rates,
+                      score_bases=sum(synth.B37_SIZES[c] for c in names) if all_features else 0)
             return leg
 
         p22 = os.path.join(tmp, "chr22.frag.gz")
@@ -865,7 +916,7 @@ def end_to_end(torch, reps: int = 3, cpu=None):
             del w, r
             runs.append(cur)
         leg = rep_summary(runs)
-        leg_floor(leg, exp["file_bytes"], 2 * exp["n"] * 115, "bam", h2d, rates)  # (115-byte records: 50 bp reads)
+        leg_floor(leg, exp["file_bytes"], 2 * exp["n"] * 115, "bam", h2d, rates, score_bases=bsize)  # (115-byte records: 50 bp reads)
         res["bam_60x_slice"] = dict(file_MB=round(exp["file_bytes"] / 1e6, 1), fragments=exp["n"], records=2 * exp["n"],
                                     file_write_s=round(t_write, 2), decoder_threads=threads, **leg)
         # BASELINE config 5 at real size: a > 4 GiB, three-contig 60x BAM (a chr1-sized contig between two small ones)
@@ -957,9 +1008,12 @@ def end_to_end(torch, reps: int = 3, cpu=None):
                 os.remove(pg6 + ".tbi")
         res["note"] = ("every leg: first_s / median_s / best_s of its repetitions (total_s = best_s and the stage split are the "
                        "best repetition's; the first one of a process also pays thread-pool start, page-locked allocations and "
-                       "the file's first read); floor = max(compressed bytes / measured H2D rate, the inflate kernel alone); PCIe "
-                       "transfers included; never the headline value")
+                       "the file's first read); floor = max(compressed bytes / measured H2D rate, the inflate kernel alone, and - legs that "
+                       "return per-base scores - 2 B per base / measured D2H rate, 8 B per base / what the host cores write together); "
+                       "PCIe transfers included; never the headline value")
         res["h2d_GBps_measured"] = round(h2d, 1)
+        res["d2h_GBps_measured"] = LINK.get("d2h_GBps")
+        res["host_write_GBps_measured"] = LINK.get("host_write_GBps")
         source.close_all()
     except Exception as exc:  # the headline line must still be printed
         res["error"] = f"{type(exc).__name__}: {exc}"
@@ -1019,7 +1073,7 @@ def big_bam_leg(torch, tmp, threads, h2d, rates, reps: int = 3):
                              decoder_producer_stage_ms=src.decode_stage_ms,
                              results_ok=bool(ok and seen == [c for c, _ in contigs])))
         leg = rep_summary(runs)
-        leg_floor(leg, file_bytes, 2 * n_frag * 125, "bam", h2d, rates)  # (125-byte records: 50 bp reads, 10-byte names)
+        leg_floor(leg, file_bytes, 2 * n_frag * 125, "bam", h2d, rates, score_bases=sum(sizes.values()))  # (125-byte records: 50 bp reads, 10-byte names)
         # ---- the checks (untimed; the contigs of the last repetition are still resident) ----
         detail, ok = {}, leg["results_ok"] and file_bytes > (1 << 32)
         try:
@@ -1059,7 +1113,7 @@ def big_bam_leg(torch, tmp, threads, h2d, rates, reps: int = 3):
                 os.remove(q)
 
 
-def genome_bam_leg(torch, dev, threads, h2d, rates, records_per_s, reps: int = 2):
+def genome_bam_leg(torch, dev, threads, h2d, rates, records_per_s, reps: int = 3):
     """BASELINE config 5 as stated: ONE whole-genome 60x coordinate-sorted paired-end BAM - all 24 b37 contigs, 6.2 x 10^8
     pairs / 1.24 x 10^9 records / ~71 GB at full scale; every contig shortened by the same factor when the box's scratch
     space or its writer's rate (two minutes at the rate the three-contig leg measured) cannot take that, ``scale`` says
@@ -1118,7 +1172,7 @@ def genome_bam_leg(torch, dev, threads, h2d, rates, records_per_s, reps: int = 2
                              features_wps_one_launch_and_copy_back_s=round(t_launch, 4),
                              decoder_producer_stage_ms=src.decode_stage_ms, results_ok=bool(ok and seen == names)))
         leg = rep_summary(runs)
-        leg_floor(leg, file_bytes, 2 * n_frag * 125, "bam", h2d, rates)
+        leg_floor(leg, file_bytes, 2 * n_frag * 125, "bam", h2d, rates, score_bases=sum(sizes.values()))
         detail, ok = {}, leg["results_ok"]
         try:
             eng = source.get_engine()

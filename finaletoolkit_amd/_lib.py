@@ -48,7 +48,7 @@ EXPORTS = [
     "ftk_fragtable_n_contigs", "ftk_fragtable_contig_name", "ftk_fragtable_contig_length",
     "ftk_fragtable_contig_rows", "ftk_fragtable_columns", "ftk_fragtable_order", "ftk_fragtable_is_pinned", "ftk_fragtable_free",
     "ftk_frags_from_table",
-    "ftk_window_counts", "ftk_delfi_counts", "ftk_fraglen_hist", "ftk_window_features",
+    "ftk_window_counts", "ftk_delfi_counts", "ftk_fraglen_hist", "ftk_fraglen_stats", "ftk_window_features",
     "ftk_window_features_batch", "ftk_wps_batch", "ftk_wps_window_features", "ftk_window_features_wps", "ftk_frag_lengths",
     "ftk_frag_select",
     "ftk_wps", "ftk_wps_intervals", "ftk_cleavage", "ftk_cleavage_intervals", "ftk_wps_adjust",
@@ -272,6 +272,7 @@ def load() -> C.CDLL:
     lib.ftk_window_counts.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), vp]
     lib.ftk_delfi_counts.argtypes = [vp, C.c_int, vp, vp, i64, i32, vp, vp, i64, C.POINTER(Gaps), vp, vp, vp]
     lib.ftk_fraglen_hist.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), i32, i32, vp, vp]
+    lib.ftk_fraglen_stats.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), i32, i32, i32, vp]
     lib.ftk_window_features.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), vp, i32, i32, vp, vp, i32, vp, vp,
                                         i64, C.POINTER(Gaps), vp, vp]
     lib.ftk_window_features_wps.argtypes = [vp, C.c_int, vp, vp, i64, C.POINTER(Filter), vp, i32, i32, vp, vp, i32, vp, vp,

@@ -730,6 +730,11 @@ struct FeatCall {
     const ftk_gaps* gaps = nullptr;
     int64_t *short_out = nullptr, *long_out = nullptr, *nfrag_out = nullptr;
     const MotifParams* motif = nullptr;  // hist_out = k-mer histogram, overflow_out = error counts
+    // per-window length statistics computed on the device from the histogram rows (which then need not leave it):
+    // stats_out[w][7] = mean median stdev min max total n_short (launch_window_stats)
+    double* stats_out = nullptr;
+    int32_t short_cut = 0;
+    bool want_hist() const { return hist_out || stats_out; }
 };
 
 // tail: a whole-interval WPS to run in the same launch (see launch_window_features).  scratch_prefix > 0: the caller keeps
@@ -741,10 +746,10 @@ int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const i
     ContigData* c;
     int rc = get_contig(ctx, contig_id, &c);
     if (rc) return rc;
-    const bool ch = fc.count_out || fc.hist_out;
+    const bool ch = fc.count_out || fc.want_hist();
     if (ch && (rc = check_filter(ctx, fc.f, *c))) return rc;
     if (n_win < 0 || n_win > (1 << 30)) return fail(ctx, FTK_ERR_INVALID, "n_win out of range");
-    if (fc.hist_out && (fc.n_bins <= 0 || fc.n_bins > kHistMaxBins))
+    if (fc.want_hist() && (fc.n_bins <= 0 || fc.n_bins > kHistMaxBins))
         return fail(ctx, FTK_ERR_INVALID, "n_bins must be in [1, %d]; split the length range", kHistMaxBins);
     if (n_win == 0) return FTK_OK;
     if (!w_start || !w_end) return fail(ctx, FTK_ERR_INVALID, "NULL window pointer");
@@ -768,8 +773,10 @@ int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const i
     const bool c_dev = is_device_ptr(fc.count_out), h_dev = is_device_ptr(fc.hist_out),
                o_dev = is_device_ptr(fc.overflow_out), s_dev = is_device_ptr(fc.short_out),
                l_dev = is_device_ptr(fc.long_out), n_dev = is_device_ptr(fc.nfrag_out);
-    const size_t hist_elems = fc.hist_out ? (size_t)n_win * (size_t)fc.n_bins : 0;
-    size_t need = window_scratch_bytes(n_win) + 5 * align_up(n_win * 8) + (h_dev ? 0 : align_up(hist_elems * 4));
+    const bool st_dev = is_device_ptr(fc.stats_out);
+    const size_t hist_elems = fc.want_hist() ? (size_t)n_win * (size_t)fc.n_bins : 0;
+    size_t need = window_scratch_bytes(n_win) + 5 * align_up(n_win * 8) + (h_dev ? 0 : align_up(hist_elems * 4)) +
+                  (fc.stats_out && !st_dev ? align_up((size_t)n_win * 7 * 8) : 0);
     if ((rc = reserve_scratch(ctx, scratch_prefix + need))) return rc;
     Arena a(ctx);
     a.off = scratch_prefix;
@@ -782,8 +789,9 @@ int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const i
     FeatureRequest r;
     r.filter = fc.f;
     r.cov_out = fc.count_out ? (c_dev ? fc.count_out : a.take<int64_t>(n_win)) : nullptr;
-    r.hist_out = fc.hist_out ? (h_dev ? fc.hist_out : a.take<uint32_t>(hist_elems)) : nullptr;
-    r.over_out = fc.hist_out ? (o_dev ? fc.overflow_out : a.take<int64_t>(n_win)) : nullptr;
+    r.hist_out = fc.want_hist() ? (h_dev ? fc.hist_out : a.take<uint32_t>(hist_elems)) : nullptr;
+    r.over_out = fc.want_hist() ? (o_dev && fc.hist_out ? fc.overflow_out : a.take<int64_t>(n_win)) : nullptr;
+    double* d_stats = fc.stats_out ? (st_dev ? fc.stats_out : a.take<double>((size_t)n_win * 7)) : nullptr;
     r.len_lo = fc.len_lo;
     r.n_bins = fc.n_bins;
     r.motif = fc.motif;
@@ -800,7 +808,7 @@ int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const i
     int lmax = 0;
     if (ch) lmax = std::max(lmax, eff_lmax(fc.f, *c));
     if (fc.delfi) lmax = std::max(lmax, std::max(0, std::min(220, c->max_len)));
-    const bool small_path = !(fc.hist_out && fc.n_bins > kHistSmallMaxBins);
+    const bool small_path = !(fc.want_hist() && fc.n_bins > kHistSmallMaxBins);
     const bool block_path = !is_device_ptr(w_start) && !is_device_ptr(w_end) &&
                             windows_suit_block_path(ctx, *c, lmax, w_start, w_end, n_win);
     WindowCall wc;
@@ -826,6 +834,7 @@ int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const i
                                                r, small_path, block_path ? lmax : -1, tail);
     if (tail_merged) *tail_merged = merged;
     if (d_nfrag) launch_add_i64(ctx->stream, r.short_out, r.long_out, d_nfrag, (int)n_win);
+    if (d_stats) launch_window_stats(ctx->stream, r.hist_out, (int)n_win, fc.n_bins, fc.len_lo, fc.short_cut, d_stats);
     HIPCHK(ctx, hipGetLastError());
     bool host_out = false;
     auto back = [&](void* dst, const void* src, size_t bytes, bool dev) -> hipError_t {
@@ -839,6 +848,7 @@ int features_common(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const i
     HIPCHK(ctx, back(fc.short_out, r.short_out, n_win * 8, s_dev));
     HIPCHK(ctx, back(fc.long_out, r.long_out, n_win * 8, l_dev));
     HIPCHK(ctx, back(fc.nfrag_out, d_nfrag, n_win * 8, n_dev));
+    HIPCHK(ctx, back(fc.stats_out, d_stats, (size_t)n_win * 7 * 8, st_dev));
     if (host_out) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return FTK_OK;
 }
@@ -980,6 +990,18 @@ int ftk_fraglen_hist(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const 
     fc.overflow_out = overflow_out;
     fc.len_lo = len_lo;
     fc.n_bins = n_bins;
+    return features_common(ctx, contig_id, w_start, w_end, n_win, fc);
+}
+
+int ftk_fraglen_stats(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                      const ftk_filter* f, int32_t len_lo, int32_t n_bins, int32_t short_cut, double* stats_out) {
+    if (ctx && n_win > 0 && !stats_out) return fail(ctx, FTK_ERR_INVALID, "stats_out is NULL");
+    FeatCall fc;
+    fc.f = f;
+    fc.len_lo = len_lo;
+    fc.n_bins = n_bins;
+    fc.stats_out = stats_out;
+    fc.short_cut = short_cut;
     return features_common(ctx, contig_id, w_start, w_end, n_win, fc);
 }
 

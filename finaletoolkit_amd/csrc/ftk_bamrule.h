@@ -1,7 +1,7 @@
 // One BAM alignment record -> one fragment row: the ONE statement of the reference's BAM rule in this library
 // (io/alignment.py:60-71 `_read_is_low_quality`, :242-268 `_fetch_sam`), shared by the device record parser
 // (ftk_bamparse.hip) and the two host decoders (ftk_decode.cpp).  Pinned to the reference's own code by
-// tests/golden/bam.json.gz (oracle/gen_golden_bam.py: the imported reference over a BAM stand-in for pysam).
+// tests/golden/bam.json.gz (vectors the imported reference produced over a BAM stand-in for pysam).
 //
 // What pysam / htslib contribute to the reference's result and is restated here:
 //   * reference_end (pysam libcalignedsegment.pyx): None when the read has no CIGAR, else htslib's bam_endpos;

@@ -110,6 +110,8 @@ bool launch_window_features(hipStream_t s, int grid_large, const ContigView& cv,
                             int n_win, const WindowPlan& pl, const FeatureRequest& r, bool small_path,
                             int block_lmax = -1, const WpsTail* tail = nullptr);
 void launch_add_i64(hipStream_t s, const int64_t* a, const int64_t* b, int64_t* out, int n);
+// per-window length statistics from dense histogram rows: out[w][7] = mean median stdev min max total n_short
+void launch_window_stats(hipStream_t s, const uint32_t* hist, int n_win, int n_bins, int len_lo, int short_cut, double* out);
 void launch_wps(hipStream_t s, const ContigView& cv, const WpsParams& p, int64_t n_tiles, const int64_t* iv_start,
                 const int64_t* iv_stop, const int64_t* out_off, const int32_t* tile_iv, const int32_t* tile_k,
                 int64_t* out);

@@ -1723,10 +1723,103 @@ __global__ void add_i64_kernel(const int64_t* a, const int64_t* b, int64_t* out,
 }
 
 // ---------------------------------------------------------------------------
+// Length statistics of every window from its dense histogram row (a9: frag/_frag_length.py:156-172 `_find_median`,
+// :202-224 `_frag_length_stats`): one wavefront per window, the row read three times out of L2 (sums; squared
+// deviations around the mean; the cumulative search of the median).  out[w] = mean, median, stdev, min, max, total,
+// n_short as float64 (integers below 2^53: exact); a window without fragments gets zeros (total 0 says so).
+//   mean   = sum(v c) / n            both exact integers, one IEEE division - Python's int / int
+//   median = the reference's search: odd n looks for cdf >= n // 2 (not n // 2 + 1), even n averages the values at
+//            cdf >= n // 2 and cdf >= n // 2 + 1; n // 2 == 0 (a single fragment) takes the first value
+//   stdev  = sqrt(sum(c (v - mean)^2) / n), population; summed lane-wise and then across the wave (the reference sums
+//            in dict insertion order: equal to ~1e-16 relative, the tests allow 1e-9)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void window_stats_kernel(const uint32_t* __restrict__ hist, int n_win, int n_bins,
+                                                           int len_lo, int short_cut, double* __restrict__ out) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_win) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t* h = hist + (size_t)w * (size_t)n_bins;
+    long long tot = 0, sum = 0, n_short = 0;
+    int first = INT32_MAX, last = -1;
+    for (int b = lane; b < n_bins; b += 64) {
+        const long long c = h[b];
+        if (c) {
+            const int v = len_lo + b;
+            tot += c;
+            sum += c * v;
+            if (v <= short_cut) n_short += c;
+            first = min(first, b);
+            last = b;
+        }
+    }
+    tot = wave_sum_ll(tot);
+    sum = wave_sum_ll(sum);
+    n_short = wave_sum_ll(n_short);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        first = min(first, __shfl_xor(first, d, 64));
+        last = max(last, __shfl_xor(last, d, 64));
+    }
+    double* o = out + (size_t)w * 7;
+    if (tot == 0) {
+        if (lane < 7) o[lane] = 0.0;
+        return;
+    }
+    const double mean = (double)sum / (double)tot;
+    double var = 0.0;
+    for (int b = lane; b < n_bins; b += 64) {
+        const uint32_t c = h[b];
+        if (c) {
+            const double d = (double)(len_lo + b) - mean;
+            var += (double)c * (d * d);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) var += __shfl_xor(var, d, 64);
+    // the two cumulative searches, 64 bins a step
+    const long long k1 = tot / 2;
+    int i1 = k1 == 0 ? first : -1, i2 = -1;
+    long long base = 0;
+    for (int b0 = first & ~63; b0 < n_bins && (i1 < 0 || i2 < 0); b0 += 64) {
+        long long s = b0 + lane < n_bins ? (long long)h[b0 + lane] : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long t = __shfl_up(s, d, 64);
+            if (lane >= d) s += t;
+        }
+        const long long cdf = base + s;
+        const unsigned long long m1 = __ballot(cdf >= k1), m2 = __ballot(cdf >= k1 + 1);
+        if (i1 < 0 && m1) i1 = b0 + __builtin_ctzll(m1);
+        if (i2 < 0 && m2) i2 = b0 + __builtin_ctzll(m2);
+        base += __shfl(s, 63, 64);
+    }
+    if (lane == 0) {
+        o[0] = mean;
+        o[1] = (tot & 1) ? (double)(len_lo + i1) : ((double)(len_lo + i1) + (double)(len_lo + i2)) / 2.0;
+        o[2] = sqrt(var / (double)tot);
+        o[3] = (double)(len_lo + first);
+        o[4] = (double)(len_lo + last);
+        o[5] = (double)tot;
+        o[6] = (double)n_short;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------
 void launch_add_i64(hipStream_t s, const int64_t* a, const int64_t* b, int64_t* out, int n) {
     hipLaunchKernelGGL(add_i64_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);
+}
+
+void launch_window_stats(hipStream_t s, const uint32_t* hist, int n_win, int n_bins, int len_lo, int short_cut, double* out) {
+    if (n_win <= 0) return;
+    hipLaunchKernelGGL(window_stats_kernel, dim3((n_win + 3) / 4), dim3(256), 0, s, hist, n_win, n_bins, len_lo, short_cut, out);
 }
 
 void launch_stats(hipStream_t s, const int32_t* start, const int32_t* end, int n, FragStats* st) {

@@ -279,6 +279,17 @@ class Engine:
                                               C.byref(f), int(len_lo), int(n_bins), L.ptr(hist), L.ptr(over)))
         return hist, over
 
+    def fraglen_stats(self, name: str, starts, stops, len_lo: int, n_bins: int, short_cut: int, quality_threshold=30,
+                      min_length=None, max_length=None, intersect_policy="midpoint"):
+        """a9: per-window length statistics computed on the device from the histogram rows (frag/_frag_length.py:156-172,
+        202-224): float64 ``[n_win, 7]`` = mean median stdev min max count n_short; count 0 = no passing fragment."""
+        ws, we = _win(starts, L.OPEN_LO), _win(stops, L.OPEN_HI)
+        f = self._filter(name, quality_threshold, min_length, max_length, intersect_policy)
+        out = np.zeros((len(ws), 7), np.float64)
+        self._check(self.lib.ftk_fraglen_stats(self.ctx, self.contig_id(name), L.ptr(ws), L.ptr(we), len(ws), C.byref(f),
+                                               int(len_lo), int(n_bins), int(short_cut), L.ptr(out)))
+        return out
+
     def window_features(self, name: str, starts, stops, quality_threshold=30, min_length=None, max_length=None,
                         intersect_policy="midpoint", coverage=True, hist=None, delfi=None):
         """Coverage / length histogram / DELFI counts of the same windows in ONE pass

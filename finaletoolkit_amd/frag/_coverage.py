@@ -8,7 +8,6 @@ launch per contig over every interval of the BED file at once.
 """
 from __future__ import annotations
 
-import gzip
 import sys
 import time
 from pathlib import Path
@@ -16,11 +15,15 @@ from typing import NamedTuple, Union
 
 import numpy as np
 
-from .. import sharding
-from ..source import get_engine, open_source
+from .. import sharding, writers
+from .._stages import Stages
+from ..source import ContigFeed, get_engine, open_source
 from ..utils import _check_policy, _check_region, _region_contigs, get_intervals
 
 __all__ = ["coverage", "single_coverage", "CoverageResult"]
+
+
+LAST_STAGE_S: dict = {}  # the last coverage() call's wall time by stage (seconds)
 
 
 class CoverageResult(NamedTuple):
@@ -115,6 +118,48 @@ def _interval_counts(src, intervals, min_length, max_length, intersect_policy, q
     return plan.gather(local, 1).reshape(-1)
 
 
+def _coverage_one_process(clock, input_file, interval_file, min_length, max_length, normalize, intersect_policy,
+                          quality_threshold, workers):
+    """One process (no rank group): the decode starts at once on a helper thread (``source.ContigFeed``), the interval
+    file is read beside it, and every contig is counted - its intervals in one launch, its total for ``normalize`` in
+    another - as soon as it is resident, while the decoder is in the next one.  Returns ``(counts, total, intervals)``
+    with ``counts`` in interval order (the ``imap`` of the reference, frag/_coverage.py:244-248)."""
+    eng = get_engine()
+    # ``normalize`` counts the whole file, so every contig is wanted and the decode can start before the intervals are
+    # known; otherwise only the intervals' contigs are (a lazily indexed file is then read through its index for them)
+    feed = ContigFeed(input_file, workers) if normalize else None
+    intervals = get_intervals(interval_file)
+    by_contig, _ = _by_contig(intervals)
+    clock.lap("read_intervals")
+    if feed is None:
+        feed = ContigFeed(input_file, workers, names=list(by_contig))
+    starts = np.array([iv[1] for iv in intervals], dtype=np.int64)
+    stops = np.array([iv[2] for iv in intervals], dtype=np.int64)
+    counts = np.zeros(len(intervals), np.int64)
+    total, left = 0, dict(by_contig)
+    try:
+        for src, c in feed:
+            clock.lap("decode_wait")
+            key = src.key(c)
+            if normalize:  # single_coverage(input_file, None, 0, None): every fragment of the file once (:215-227)
+                total += int(eng.window_counts(key, [None], [None], quality_threshold, min_length, max_length,
+                                               intersect_policy)[0])
+            idx = left.pop(c, None)
+            if idx is not None:
+                idx = np.asarray(idx, dtype=np.int64)
+                order = idx[np.argsort(starts[idx], kind="stable")]  # (sorted windows take the block-per-window launch)
+                counts[order] = eng.window_counts(key, starts[order].astype(np.int32), stops[order].astype(np.int32),
+                                                  quality_threshold, min_length, max_length, intersect_policy)
+            clock.lap("count_kernels")
+        src = feed.finish()
+    except BaseException:
+        feed.close()
+        raise
+    for c in left:  # contigs the file does not hold: the error the reference's fetch raises (ValueError)
+        src.require(c)
+    return counts, total, intervals
+
+
 def coverage(input_file: Union[str, Path], interval_file: str, output_file: str, scale_factor: float = 1.0,
              min_length: int | None = None, max_length: int | None = None, normalize: bool = False,
              intersect_policy: str = "midpoint", quality_threshold: int = 30, workers: int = 1,
@@ -125,56 +170,41 @@ def coverage(input_file: Union[str, Path], interval_file: str, output_file: str,
         t0 = time.time()
         sys.stderr.write(f"coverage: {input_file} over {interval_file}\n")
     _check_policy(intersect_policy)
-    src = open_source(input_file, workers)
-    intervals = get_intervals(interval_file)
-    if normalize:
-        # single_coverage(input_file, None, 0, None, "."): the whole file (:215-227).  Every fragment counts once, so
-        # this part is dealt by whole contigs (LPT on their lengths; a region read returns a fragment to every rank
-        # whose region it overlaps), one int64 all-reduce.
-        by_contig, extent = _by_contig(intervals)
-        names = list(dict.fromkeys(list(src.contigs) + list(by_contig)))
-        rank, world, owner, _weights = _owners(src, names, extent)
-        total = _total(src, None, 0, None, min_length, max_length, intersect_policy, quality_threshold,
-                       shard=(rank, world, owner))
-    counts = _interval_counts(src, intervals, min_length, max_length, intersect_policy, quality_threshold)
+    clock = Stages()
+    if sharding.rank_world()[1] == 1:
+        counts, total, intervals = _coverage_one_process(clock, input_file, interval_file, min_length, max_length, normalize,
+                                                         intersect_policy, quality_threshold, workers)
+    else:
+        src = open_source(input_file, workers)
+        clock.lap("open")
+        intervals = get_intervals(interval_file)
+        clock.lap("read_intervals")
+        if normalize:
+            # single_coverage(input_file, None, 0, None, "."): the whole file (:215-227).  Every fragment counts once, so
+            # this part is dealt by whole contigs (LPT on their lengths; a region read returns a fragment to every rank
+            # whose region it overlaps), one int64 all-reduce.
+            by_contig, extent = _by_contig(intervals)
+            names = list(dict.fromkeys(list(src.contigs) + list(by_contig)))
+            rank, world, owner, _weights = _owners(src, names, extent)
+            total = _total(src, None, 0, None, min_length, max_length, intersect_policy, quality_threshold,
+                           shard=(rank, world, owner))
+            clock.lap("decode_and_total")
+        counts = _interval_counts(src, intervals, min_length, max_length, intersect_policy, quality_threshold)
+        clock.lap("interval_counts")
     if normalize:
         if verbose:
             sys.stderr.write(f"Total coverage is {total}\n")
         scale_factor /= total
 
-    if output_file is not None and sharding.rank_world()[0] != 0:
-        # every rank returns the same list; rank 0 alone writes the file / stdout
-        if not (output_file.endswith((".bed", ".bedgraph", ".bed.gz")) or output_file == "-"):
-            raise ValueError("output_file should have .bed or .bed.gz as suffix")
-        output_file = None
-    return_val: list[CoverageResult] = []
-    output_is_file = False
+    values = (counts * scale_factor).tolist()  # int64 -> float64 times a Python float: `cov * scale_factor` of :250
+    return_val = list(map(CoverageResult._make, zip(*zip(*intervals), values))) if intervals else []
     if output_file is not None:
-        try:
-            if output_file.endswith(".bed") or output_file.endswith(".bedgraph"):
-                output_is_file = True
-                output = open(output_file, "w")
-            elif output_file.endswith(".bed.gz"):
-                output = gzip.open(output_file, "wt")
-                output_is_file = True
-            elif output_file == "-":
-                output = sys.stdout
-            else:
-                raise ValueError("output_file should have .bed or .bed.gz as suffix")
-            bedgraph = output_file.endswith(".bedgraph")
-            for (contig, start, stop, name), cov in zip(intervals, counts.tolist()):
-                value = cov * scale_factor
-                if bedgraph:
-                    output.write(f"{contig}\t{start}\t{stop}\t{value}\n")
-                else:
-                    output.write(f"{contig}\t{start}\t{stop}\t{name}\t{value}\n")
-                return_val.append(CoverageResult(contig, start, stop, name, value))
-        finally:
-            if output_is_file:
-                output.close()
-    else:
-        return_val = [CoverageResult(contig, start, stop, name, cov * scale_factor)
-                      for (contig, start, stop, name), cov in zip(intervals, counts.tolist())]
+        if sharding.rank_world()[0] == 0:
+            writers.write_coverage_rows(output_file, intervals, values)
+        else:  # every rank returns the same list; rank 0 alone writes the file / stdout
+            writers.check_suffix(output_file, (".bed", ".bedgraph", ".bed.gz"), "output_file should have .bed or .bed.gz as suffix")
+    clock.lap("rows_and_write")
+    clock.publish(LAST_STAGE_S)
     if verbose:
         sys.stderr.write(f"coverage took {time.time() - t0} s to complete\n")
     return return_val

@@ -20,14 +20,19 @@ from typing import NamedTuple, Union
 
 import numpy as np
 
-from .. import sharding
-from ..source import get_engine, open_source
+from .. import sharding, writers
+from .._stages import Stages
+from ..source import ContigFeed, get_engine, open_source
 from ..utils import _check_policy, _check_region, _region_contigs, get_intervals
 
 __all__ = ["frag_length", "frag_length_bins", "frag_length_intervals", "FragLengthStats"]
 
 _MAX_BINS = 32768               # kHistMaxBins of the kernel
+_DEVICE_STATS = __import__("os").environ.get("FTK_DEVICE_STATS", "1") != "0"  # 0: the numpy statistics (tests hold the two together)
 _HIST_BYTES_PER_CALL = 1 << 29  # window batches are cut to keep one histogram block <= 512 MiB
+
+
+LAST_STAGE_S: dict = {}  # the last frag_length_bins / frag_length_intervals call's wall time by stage (seconds)
 
 
 class FragLengthStats(NamedTuple):
@@ -168,9 +173,11 @@ def frag_length_bins(input_file, contig: str | None = None, start: int | None = 
         stderr.write("Generating fragment dictionary. \n")
     _check_policy(intersect_policy)
     _check_region(contig, start, stop)
+    clock = Stages()
     src = open_source(input_file)
     src.check_fetch(contig, start, stop)
     eng = get_engine()
+    clock.lap("open")
     if contig is None and sharding.rank_world()[1] > 1:
         # (several ranks: a rank decodes only the contigs it is dealt below - not the whole file, as ``load_all`` would)
         names, whole = [c for c in src.contigs if src.has(c)], True
@@ -179,6 +186,7 @@ def frag_length_bins(input_file, contig: str | None = None, start: int | None = 
     # the whole file: every fragment counts once, so the contigs are dealt WHOLE to the ranks of the process group (LPT
     # on their lengths; a region read hands a fragment to every rank whose region it overlaps); the sparse length ->
     # count maps meet in one all-gather of small objects; a single contig / region is counted by every rank alike
+    clock.lap("decode_wait")
     rank, world, owner = sharding.contig_owner({c: float(src.lengths.get(c) or 1) for c in names})
     shard = world > 1 and len(names) > 1
     dist: dict[int, int] = {}
@@ -188,9 +196,11 @@ def frag_length_bins(input_file, contig: str | None = None, start: int | None = 
             if shard and owner[c] != rank:
                 continue
             key = src.require(c)
+            clock.lap("decode_wait")
             lo, hi = _length_range(eng, key, min_length, max_length)
             h = _window_hists(eng, key, [None if whole else start], [None if whole else stop], lo, hi,
                               quality_threshold, min_length, max_length, intersect_policy)
+            clock.lap("histograms")
             if h.shape[1]:
                 for b in np.nonzero(h[0])[0]:
                     dist[lo + int(b)] = dist.get(lo + int(b), 0) + int(h[0, b])
@@ -228,25 +238,9 @@ def frag_length_bins(input_file, contig: str | None = None, start: int | None = 
     counts = counts_arr.tolist()
 
     if output_file is not None and sharding.is_writer():
-        out_is_file = False
-        try:
-            if output_file == "-":
-                out = stdout
-            elif output_file.endswith(".gz"):
-                out_is_file = True
-                out = gzip.open(output_file, "wt")
-            else:
-                out_is_file = True
-                out = open(output_file, "w")
-            out.write("min\tmax\tcount\n")
-            for bin_val, count in zip(bins, counts):
-                out.write(f"{bin_val}\t{bin_val + bin_size - 1}\t{count}\n")
-            if summary_stats:
-                for name, value in stats:
-                    out.write(f"#{name}: {value}\n")
-        finally:
-            if out_is_file:
-                out.close()
+        writers.write_length_bins(output_file, bins, counts, bin_size, stats if summary_stats else None)
+    clock.lap("statistics_and_write")
+    clock.publish(LAST_STAGE_S)
     if histogram_path is not None:
         raise NotImplementedError("histogram plotting (matplotlib) is outside the MI355X hot path")
     if verbose:
@@ -264,22 +258,35 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
         t0 = time.time()
         stderr.write("Reading intervals.\n")
     _check_policy(intersect_policy)
-    src = open_source(input_file, workers)
+    clock = Stages()
+    one_process = sharding.rank_world()[1] == 1
     eng = get_engine()
+    if not one_process:
+        src = open_source(input_file, workers)
+        clock.lap("open")
     intervals = get_intervals(interval_file)
+    clock.lap("read_intervals")
     results: list = [None] * len(intervals)
     # Pool(workers) of the reference (:571-593) = one rank per GPU: the intervals are cut into equal-cost runs over the
     # ranks (sharding.IntervalPlan: whole contigs, a region of the contig a cut falls into), a rank decodes and counts
     # only its share, and one all-gather of the seven statistics per interval (float64 bit patterns) gives every rank
     # the whole list; rank 0 writes.
-    plan = sharding.IntervalPlan([iv[0] for iv in intervals], [iv[1] for iv in intervals], [iv[2] for iv in intervals])
+    iv_starts = np.array([iv[1] for iv in intervals], dtype=np.int64)
+    iv_stops = np.array([iv[2] for iv in intervals], dtype=np.int64)
 
     def unit_stats(key, idx):
         """float64 [len(idx), 7]: mean median stdev min max total n_short; total 0 = no fragment"""
         out = np.zeros((len(idx), 7), np.float64)
         lo, hi = _length_range(eng, key, min_length, max_length)
-        ws = plan.starts[idx].astype(np.int32)
-        we = plan.stops[idx].astype(np.int32)
+        ws = iv_starts[idx].astype(np.int32)
+        we = iv_stops[idx].astype(np.int32)
+        if lo <= hi and hi - lo + 1 <= _MAX_BINS and _DEVICE_STATS:
+            # the statistics on the device, from histogram rows that never leave it (ftk_fraglen_stats)
+            step = max(1, _HIST_BYTES_PER_CALL // (4 * (hi - lo + 1)))
+            for w0 in range(0, len(idx), step):
+                out[w0:w0 + step] = eng.fraglen_stats(key, ws[w0:w0 + step], we[w0:w0 + step], lo, hi - lo + 1, short_reads,
+                                                      quality_threshold, min_length, max_length, intersect_policy)
+            return out
         n_total = max(hi - lo + 1, 1)
         step = max(1, _HIST_BYTES_PER_CALL // (8 * n_total))
         for w0 in range(0, len(idx), step):
@@ -298,49 +305,63 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
                 dst[cols[5] == 0] = 0.0
         return out
 
-    local, err = {}, None
-    try:
-        for unit in plan.mine:
-            key = plan.unit_key(src, unit, 1)
-            try:
-                local[unit] = unit_stats(key, plan.intervals(unit))
-            finally:
-                plan.release(src, key)
-    except Exception as e:  # noqa: BLE001 - every rank learns of it below
-        err = e
-    sharding.agree(err)
-    stats = plan.gather(local, 7, np.float64)
-    mean, median, stdev, vmin, vmax, total, n_short = (stats[:, k].tolist() for k in range(7))
-    for i, (contig, start, stop, name) in enumerate(intervals):
-        if total[i] == 0:
-            results[i] = FragLengthStats(contig, start, stop, name, -1, -1, -1, -1, -1, -1, -1)
-        else:
-            results[i] = FragLengthStats(contig, start, stop, name, mean[i], median[i], stdev[i], int(vmin[i]),
-                                         int(vmax[i]), int(total[i]), int(n_short[i]) / int(total[i]))
-
-    if output_file is not None and not sharding.is_writer():
-        if not (output_file.endswith((".bed", ".bedgraph", ".bed.gz")) or output_file == "-"):
-            raise ValueError("The output file should have .bed or .bed.gz as as suffix.")
-        output_file = None
-    output_is_file = False
-    if output_file is not None:
+    if one_process:
+        # One process: the decode runs ahead on a helper thread (source.ContigFeed: only the intervals' contigs are
+        # wanted) and a contig's intervals are counted and summarised as soon as it is resident.
+        by_contig: dict = {}
+        for i, iv in enumerate(intervals):
+            by_contig.setdefault(iv[0], []).append(i)
+        stats = np.zeros((len(intervals), 7), np.float64)
+        feed = ContigFeed(input_file, workers, names=list(by_contig))
         try:
-            if output_file.endswith(".bed") or output_file.endswith(".bedgraph"):
-                output_is_file = True
-                output = open(output_file, "w")
-            elif output_file.endswith(".bed.gz"):
-                output = gzip.open(output_file, "wt")
-                output_is_file = True
-            elif output_file == "-":
-                output = stdout
-            else:
-                raise ValueError("The output file should have .bed or .bed.gz as as suffix.")
-            output.write(f"contig\tstart\tstop\tname\tmean\tmedian\tstdev\tmin\tmax\tcount\ts{short_reads}\n")
-            output.write("\n".join("\t".join(str(element) for element in item) for item in results))
-            output.write("\n")
-        finally:
-            if output_is_file:
-                output.close()
+            for src, c in feed:
+                clock.lap("decode_wait")
+                idx = by_contig.pop(c, None)
+                if idx is not None:
+                    idx = np.asarray(idx, dtype=np.int64)
+                    order = idx[np.argsort(iv_starts[idx], kind="stable")]
+                    stats[order] = unit_stats(src.key(c), order)
+                clock.lap("histograms_and_statistics")
+            src = feed.finish()
+        except BaseException:
+            feed.close()
+            raise
+        for c in by_contig:  # contigs the file does not hold: the error the reference's fetch raises (ValueError)
+            src.require(c)
+    else:
+        plan = sharding.IntervalPlan([iv[0] for iv in intervals], iv_starts.tolist(), iv_stops.tolist())
+        local, err = {}, None
+        try:
+            for unit in plan.mine:
+                key = plan.unit_key(src, unit, 1)
+                clock.lap("decode_wait")
+                try:
+                    local[unit] = unit_stats(key, plan.intervals(unit))
+                finally:
+                    plan.release(src, key)
+                clock.lap("histograms_and_statistics")
+        except Exception as e:  # noqa: BLE001 - every rank learns of it below
+            err = e
+        sharding.agree(err)
+        stats = plan.gather(local, 7, np.float64)
+        clock.lap("gather")
+    total = stats[:, 5].astype(np.int64)
+    some = total > 0
+    frac = np.divide(stats[:, 6].astype(np.int64), total, out=np.zeros(len(total), np.float64), where=some)  # int / int
+    cols = (stats[:, 0].tolist(), stats[:, 1].tolist(), stats[:, 2].tolist(), stats[:, 3].astype(np.int64).tolist(),
+            stats[:, 4].astype(np.int64).tolist(), total.tolist(), frac.tolist())
+    results = list(map(FragLengthStats._make, zip(*zip(*intervals), *cols))) if intervals else []
+    for i in np.flatnonzero(~some).tolist():  # (an interval without a fragment: every statistic is the integer -1)
+        results[i] = FragLengthStats(*intervals[i], -1, -1, -1, -1, -1, -1, -1)
+
+    clock.lap("result_rows")
+    if output_file is not None:
+        if sharding.is_writer():
+            writers.write_length_stats(output_file, results, short_reads)
+        else:
+            writers.check_suffix(output_file, (".bed", ".bedgraph", ".bed.gz"), "The output file should have .bed or .bed.gz as as suffix.")
+    clock.lap("write")
+    clock.publish(LAST_STAGE_S)
     if verbose:
         stderr.write(f"Calculating fragment length statistics for intervals took {time.time() - t0} s\n")
     return results

@@ -19,7 +19,8 @@ from typing import Union
 
 import numpy as np
 
-from ..source import get_engine, open_source
+from .. import sharding
+from ..source import ContigFeed, get_engine, open_source
 from ..utils import chrom_sizes_to_list
 from ._runs import write_per_base_runs
 from ._wps import _resolve_aliases
@@ -83,11 +84,19 @@ def multi_wps(input_file, site_bed, chrom_sizes=None, output_file: str | None = 
     if input_file == "-" and site_bed == "-":
         raise ValueError("input_file and site_bed cannot both read from stdin")
     min_length, max_length = _resolve_aliases(min_length, max_length, fraction_low, fraction_high)
-    src = open_source(input_file, workers)
+    is_bam = isinstance(input_file, (str, PathLike)) and str(input_file).endswith((".sam", ".bam", ".cram"))
+    one_process = sharding.rank_world()[1] == 1
+    # several ranks, or a BAM (whose header is the contig list): the source is opened now; one process on a fragment
+    # file: the decode starts below, once the sites say which contigs are wanted, and runs ahead of the scoring
+    src = open_source(input_file, workers) if (is_bam or not one_process) else None
     eng = get_engine()
     header = _read_header(input_file, chrom_sizes, src)
     chrom_sizes_dict = dict(header)
     names, lo, hi = _site_windows(site_bed, interval_size, chrom_sizes_dict)
+    if one_process:
+        # (source.ContigFeed: a helper thread decodes towards the next contig while this one's windows are scored,
+        # compressed and written; a lazily indexed file is read through its index for the sites' contigs alone)
+        src = ContigFeed(input_file, workers, names=list(dict.fromkeys(str(c) for c in names)))
     # header order of the contigs, then start; equal keys keep their file order (the reference sorts the same way,
     # frag/_multi_wps.py:152-160)
     place = {chrom: k for k, (chrom, _) in enumerate(header)}
@@ -109,16 +118,23 @@ def multi_wps(input_file, site_bed, chrom_sizes=None, output_file: str | None = 
     # rows a share can need: the reference's fetch window of an interval is [start - max_length, stop + max_length)
     # (frag/_wps.py:156-157), and for a BAM the read1 ALIGNMENTS overlapping it decide
     pad = max(int(window_size), int(max_length)) + 1
-    if isinstance(output_file, str):
-        if output_file.endswith(".bw"):
-            write_per_base_runs(output_file, "bw", header, contigs, starts, stops, score_run, src, pad)
-        elif output_file.endswith(".bed.gz") or output_file.endswith("bedGraph.gz"):
-            write_per_base_runs(output_file, "bedgraph.gz", header, contigs, starts, stops, score_run, src, pad)
-        else:
-            raise ValueError("output_file can only have suffix .bw")
-    elif output_file is not None:
-        raise TypeError(f'output_file is unsupported type "{type(input_file)}". output_file should be a string '
-                        "specifying the path of the file to output scores to.")
+    try:
+        if isinstance(output_file, str):
+            if output_file.endswith(".bw"):
+                write_per_base_runs(output_file, "bw", header, contigs, starts, stops, score_run, src, pad)
+            elif output_file.endswith(".bed.gz") or output_file.endswith("bedGraph.gz"):
+                write_per_base_runs(output_file, "bedgraph.gz", header, contigs, starts, stops, score_run, src, pad)
+            else:
+                raise ValueError("output_file can only have suffix .bw")
+        elif output_file is not None:
+            raise TypeError(f'output_file is unsupported type "{type(input_file)}". output_file should be a string '
+                            "specifying the path of the file to output scores to.")
+        if isinstance(src, ContigFeed):
+            src.finish()  # (a streamed file is decoded to its end, so that the cached source is whole)
+    except BaseException:
+        if isinstance(src, ContigFeed):
+            src.close()
+        raise
     if verbose:
         stderr.write(f"multi_wps took {time.time() - t0} s to complete\n")
     return output_file

@@ -23,6 +23,9 @@ from typing import Callable, List, Sequence, Tuple
 import numpy as np
 
 from .. import sharding
+from .._stages import Stages
+
+LAST_STAGE_S: dict = {}  # the last write_per_base_runs call's wall time by stage (seconds)
 
 Run = Tuple[str, int, int]  # contig, first interval, one past the last interval
 
@@ -90,6 +93,7 @@ def write_per_base_runs(output_file: str, kind: str, header, contigs, starts, st
     from .. import writers
     from ..bigwig import FixedStepBigWigWriter, RunOrder, fixed_step_payload, select_intervals
 
+    clock = Stages()
     runs = group_runs(contigs)
     units = split_into_units(runs, starts, stops)
     rank, world = sharding.rank_world()
@@ -119,28 +123,38 @@ def write_per_base_runs(output_file: str, kind: str, header, contigs, starts, st
     def table(c):
         if c not in keys:
             n_all, n_mine, lo, hi = share[c]
+            clock.lap("other")
             if world == 1 or n_mine == n_all or lo is None or hi <= lo or not hasattr(src, "require_region"):
                 keys[c] = src.require(c)
             else:
                 keys[c] = src.require_region(c, max(0, int(lo) - pad), int(hi) + pad)
+            clock.lap("decode_wait")
         return keys[c]
 
     def payload(k: int):
+        clock.lap("file_write" if k else "plan")  # (between two payloads the consumer lays the previous one into the file)
         c, i, j = units[k]
         if kind == "bw":
             if not keeps[k]:
                 return b""
             st = [starts[i + q] for q in keeps[k]]
             sp = [stops[i + q] for q in keeps[k]]
-            values, offsets = compute(table(c), c, st, sp)
+            key = table(c)
+            values, offsets = compute(key, c, st, sp)
+            clock.lap("score_and_copy_back")
             blob, table_, stats = fixed_step_payload(chrom_id[c], st, values, offsets)
+            clock.lap("sections_compress")
             return pickle.dumps((chrom_id[c], table_, stats), protocol=4) + blob if world > 1 else (chrom_id[c], blob, table_, stats)
-        values, offsets = compute(table(c), c, starts[i:j], stops[i:j])
+        key = table(c)
+        values, offsets = compute(key, c, starts[i:j], stops[i:j])
+        clock.lap("score_and_copy_back")
         parts = []
         for rows in writers.bedgraph_batches(c, starts[i:j], values, offsets):
             with rows:
+                clock.lap("format_rows")
                 if rows.n:
                     parts.append(rows.gzip_bytes(writers.GZIP_LEVEL))
+                clock.lap("gzip")
         return b"".join(parts)
 
     def unpack_bw(p):
@@ -172,6 +186,8 @@ def write_per_base_runs(output_file: str, kind: str, header, contigs, starts, st
 
     if world == 1:
         lay_down(payload(k) for k in range(len(units)))  # streamed: one unit in memory at a time
+        clock.lap("file_write")
+        clock.publish(LAST_STAGE_S)
         return
     local, err = {}, None
     try:

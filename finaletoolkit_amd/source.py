@@ -637,6 +637,51 @@ class EarlyContigs:
         self._gen.close()
 
 
+
+class ContigFeed:
+    """One process, one file, every contig it needs: the decode runs ahead on a helper thread (``EarlyContigs``) from
+    the moment the command starts, and the command's per-contig work (a kernel launch, a handful of result rows) is done
+    as each contig becomes resident - while the decoder is already in the next one - instead of after ``open_source``
+    has decoded the whole file.  Iterate for ``(src, contig)`` in the order the contigs become resident; ``finish()``
+    drains what is left and returns the source.  ``names``: the contigs the caller can want (``None``: all) - a lazily
+    indexed file is then read through its index for those alone."""
+
+    def __init__(self, input_file, workers=None, names=None, warn_bed6: bool = True):
+        self._early = EarlyContigs(input_file, workers, True, warn_bed6, names=names)
+        self._it = None
+        self.src: Optional[FragSource] = None
+        self.seen: list = []
+        self._input, self._workers, self._warn = input_file, workers, warn_bed6
+
+    def __iter__(self):
+        if self._it is None:
+            self._it = iter(self._early)
+        for src, c in self._it:
+            self.src = src
+            self.seen.append(c)
+            yield src, c
+
+    def require(self, contig: str) -> str:
+        """Engine key of ``contig``, waiting for the decoder to reach it (contigs that become resident on the way
+        stay resident) - the ``FragSource.require`` face of a feed, for consumers that ask contig by contig."""
+        if contig not in self.seen:
+            for _, c in self:
+                if c == contig:
+                    break
+        if contig in self.seen:
+            return self.src.key(contig)
+        return self.finish().require(contig)  # not in the file: ValueError, as from a source
+
+    def finish(self) -> FragSource:
+        for _ in self:
+            pass
+        if self.src is None:  # a file without a single wanted contig: still a valid, open source
+            self.src = open_source(self._input, self._workers, self._warn)
+        return self.src
+
+    def close(self):
+        self._early.close()
+
 def region_contig(input_file, contig: str, start: int, stop: int, workers: int | None = None, warn_bed6: bool = True):
     """``(src, key)``: the source of ``input_file`` and the engine key of a table with every fragment of ``contig``
     that overlaps ``[start, stop)`` (``FragSource.require_region``) - the way in for a rank that owns PART of a

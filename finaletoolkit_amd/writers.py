@@ -185,3 +185,61 @@ def bgzf_write(path: str, data, level: int = 6, append: bool = False, write_eof:
     if rc != L.FTK_OK:
         raise OSError(lib.ftk_fragtable_error().decode())
     return offs
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Row files of the interval commands.  What the formats ARE is the reference's contract (suffix rules, column order,
+# header lines, `str()` / `repr()` of every value: frag/_coverage.py:262-296, frag/_frag_length.py:466-490,607-632);
+# how they are produced is ours: the rows of a call are one string, written once (`.gz`: as gzip members, compressed
+# by the library's threads - the decompressed stream is what `gzip.open(..., "wt")` would have held).
+# ---------------------------------------------------------------------------------------------------------------
+def _emit(output_file: str, text: str, plain: tuple, gz: tuple, bad_suffix: str) -> None:
+    """``text`` to ``output_file``: ``"-"`` = stdout, a name ending in one of ``gz`` = gzip, in one of ``plain`` = as
+    is (``plain=None``: any other name), else ``ValueError(bad_suffix)``."""
+    import sys
+    if output_file == "-":
+        sys.stdout.write(text)
+    elif gz and output_file.endswith(gz):
+        write_text(output_file, text.encode(), GZIP_LEVEL)
+    elif plain is None or output_file.endswith(plain):
+        with open(output_file, "w") as fh:
+            fh.write(text)
+    else:
+        raise ValueError(bad_suffix)
+
+
+def check_suffix(output_file: str, suffixes: tuple, message: str) -> None:
+    if not (output_file == "-" or output_file.endswith(suffixes)):
+        raise ValueError(message)
+
+
+def write_coverage_rows(output_file: str, intervals, values) -> None:
+    """``contig start stop name value`` per interval (``.bedgraph``: no name column); ``.bed`` / ``.bedgraph`` /
+    ``.bed.gz`` / ``-``."""
+    message = "output_file should have .bed or .bed.gz as suffix"
+    check_suffix(output_file, (".bed", ".bedgraph", ".bed.gz"), message)
+    if output_file.endswith(".bedgraph"):
+        text = "".join([f"{c}\t{a}\t{b}\t{v}\n" for (c, a, b, _), v in zip(intervals, values)])
+    else:
+        text = "".join([f"{c}\t{a}\t{b}\t{n}\t{v}\n" for (c, a, b, n), v in zip(intervals, values)])
+    _emit(output_file, text, (".bed", ".bedgraph"), (".bed.gz",), message)
+
+
+def write_length_bins(output_file: str, bins, counts, bin_size: int, stats=None) -> None:
+    """The ``min max count`` table of ``frag_length_bins`` (+ ``#name: value`` lines when ``stats`` is given); any
+    file name, ``.gz`` = gzip, ``-`` = stdout."""
+    rows = ["min\tmax\tcount\n"]
+    rows += [f"{lo}\t{lo + bin_size - 1}\t{n}\n" for lo, n in zip(bins, counts)]
+    if stats:
+        rows += [f"#{name}: {value}\n" for name, value in stats]
+    _emit(output_file, "".join(rows), None, (".gz",), "")
+
+
+def write_length_stats(output_file: str, results, short_reads: int) -> None:
+    """The per-interval statistics table of ``frag_length_intervals``: a header line, then the eleven fields of every
+    result, tab-separated, ``str()`` of each; ``.bed`` / ``.bedgraph`` / ``.bed.gz`` / ``-``."""
+    message = "The output file should have .bed or .bed.gz as as suffix."
+    check_suffix(output_file, (".bed", ".bedgraph", ".bed.gz"), message)
+    head = f"contig\tstart\tstop\tname\tmean\tmedian\tstdev\tmin\tmax\tcount\ts{short_reads}\n"
+    body = "\n".join([f"{r[0]}\t{r[1]}\t{r[2]}\t{r[3]}\t{r[4]}\t{r[5]}\t{r[6]}\t{r[7]}\t{r[8]}\t{r[9]}\t{r[10]}" for r in results])
+    _emit(output_file, head + body + "\n", (".bed", ".bedgraph"), (".bed.gz",), message)

@@ -289,6 +289,15 @@ int ftk_delfi_counts(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const 
  * arithmetic on these histograms. */
 int ftk_fraglen_hist(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
                      const ftk_filter* f, int32_t len_lo, int32_t n_bins, uint32_t* hist_out, int64_t* overflow_out);
+/* a9, the statistics themselves (frag/_frag_length.py:156-172 `_find_median`, :202-224 `_frag_length_stats`): the same
+ * pass as ftk_fraglen_hist over lengths [len_lo, len_lo + n_bins), then per window - on the device, from the histogram
+ * rows, which never leave it - stats_out[w][7] = mean, median, stdev (population), min, max, count, #(len <= short_cut)
+ * as float64 (the integers are exact).  count 0: the window holds no passing fragment (the other six are 0; the
+ * reference reports -1 for all).  The length range must hold every length the filter passes (the caller takes
+ * [max(min_len, 0), min(max_len, longest fragment of the contig)]); n_bins as in ftk_fraglen_hist.  stats_out may be
+ * host or device memory. */
+int ftk_fraglen_stats(ftk_ctx* ctx, int contig_id, const int32_t* w_start, const int32_t* w_end, int64_t n_win,
+                      const ftk_filter* f, int32_t len_lo, int32_t n_bins, int32_t short_cut, double* stats_out);
 
 /* ---- fused pass: any combination of the three window features in ONE sweep over
  * the contig's fragments (one plan, one launch pair instead of three): coverage
