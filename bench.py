@@ -996,6 +996,17 @@ def end_to_end(torch, reps: int = 3, cpu=None):
             # merge and the TSV written -- everything reference frag/_delfi.py:129-401 does around its per-bin loop.
             res["genome_frag_delfi_api"] = frag_delfi_api_leg(torch, tmp, pg, threads, n_win_total, rows_total,
                                                              res["genome_delfi_bins"], cpu)
+            # The reference's OTHER commands through their product functions on the same file (tools/cmd_legs.py):
+            # coverage(normalize=True) over the 30 970-row BED, multi_wps over 20 000 sites to .bw and to .bed.gz,
+            # frag_length_intervals over the BED, genome-wide frag_length_bins - each with its stage split, a check
+            # of one whole contig against the oracle (untimed) and the reference-shaped Python rate beside it.
+            if os.environ.get("FTK_BENCH_CMD_LEGS", "1") != "0":
+                try:
+                    from tools import cmd_legs
+                    res["commands"] = cmd_legs.measure(torch, tmp, pg, dict(synth.B37_SIZES), threads,
+                                                       raw_floor=res["genome_delfi_bins"].get("floor"))
+                except Exception as exc:  # noqa: BLE001 - the other legs must still be reported
+                    res["commands"] = {"error": f"{type(exc).__name__}: {exc}"}
             os.remove(pg)
             os.remove(pg + ".tbi")
             # the same genome written at DEFLATE level 6 - what bgzip / htslib write by default, i.e. what a user's

@@ -11,7 +11,16 @@
 // All lanes of a wave read the same slots in step 2 (LDS broadcast reads), and a
 // wave stops as soon as all of its outputs are resolved: about n_in / 2 slots
 // per output instead of W reads per bit of a radix descent.
+//
+// Round 6: raw WPS scores are small INTEGERS (a bigWig of `multi_wps` holds counts), and the median of integers in a
+// narrow range needs no sort: `adjust_median_hist_kernel` gives every lane a run of consecutive outputs and a
+// histogram of its own (256 bins of 16 bits, lane-interleaved in LDS); the window slides by one - one bin down, one up -
+// and the two middle order statistics follow by O(1) steps from where they were.  A tile whose values are not integers
+// within a range of 256 marks its interval, and the sort kernel above redoes the marked intervals: same result, bit for
+// bit (the medians are the same input values).
 #include "ftk_kernels.h"
+
+#include <cmath>
 
 namespace ftk {
 
@@ -32,10 +41,12 @@ __device__ __forceinline__ double key_f64(unsigned long long k) {
 __global__ __launch_bounds__(kAdjThreads) void adjust_median_kernel(const double* __restrict__ scores,
                                                                      const AdjustTile* __restrict__ tiles,
                                                                      const double* __restrict__ edge_sub, int W,
-                                                                     int n_sort, double* __restrict__ out) {
+                                                                     int n_sort, double* __restrict__ out,
+                                                                     const int* __restrict__ todo) {
     extern __shared__ unsigned long long lds_keys[];       // [n_sort] sorted keys
     unsigned int* pos = (unsigned int*)(lds_keys + n_sort);  // [n_sort] input position of each sorted slot
     const AdjustTile t = tiles[blockIdx.x];
+    if (todo && !todo[t.interval]) return;  // the histogram kernel has answered this interval
     const double sub = edge_sub ? edge_sub[t.interval] : 0.0;
     const double* in = scores + t.in_base;
     const int n_in = t.n_out + W - 1;
@@ -95,6 +106,85 @@ __global__ __launch_bounds__(kAdjThreads) void adjust_median_kernel(const double
         }
         const double med = (key_f64(lds_keys[s1]) + key_f64(lds_keys[s])) * 0.5;
         out[t.out_base + o] = (in[o + W / 2] - sub) - med;
+    }
+}
+
+// ---- the median of small integers: one lane, one run of outputs, one sliding histogram ---------------------------
+constexpr int kFastBins = 256;      // value range a tile may span
+constexpr int kFastThreads = 64;    // one wavefront per tile
+
+__global__ __launch_bounds__(kFastThreads) void adjust_median_hist_kernel(const double* __restrict__ scores,
+                                                                           const AdjustTile* __restrict__ tiles,
+                                                                           const double* __restrict__ edge_sub, int W,
+                                                                           double* __restrict__ out, int* __restrict__ todo) {
+    extern __shared__ unsigned int lds_fast[];
+    unsigned int* hh = lds_fast;                                           // [kFastBins / 2][64]: bins 2k, 2k + 1 of lane l
+    unsigned char* sv = (unsigned char*)(lds_fast + kFastBins / 2 * 64);   // [n_in]: value - base
+    const AdjustTile t = tiles[blockIdx.x];
+    const int lane = threadIdx.x;
+    const double* in = scores + t.in_base;
+    const int n_in = t.n_out + W - 1;
+    // integers (no -0.0) within a range of kFastBins?
+    double lo = INFINITY, hi = -INFINITY;
+    bool ok = true;
+    for (int i = lane; i < n_in; i += kFastThreads) {
+        const double v = in[i];
+        ok = ok && v == rint(v) && fabs(v) < 1e9 && !(v == 0.0 && signbit(v));
+        lo = fmin(lo, v);
+        hi = fmax(hi, v);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, d, 64));
+        hi = fmax(hi, __shfl_xor(hi, d, 64));
+    }
+    if (!__all(ok) || !(hi - lo < (double)kFastBins)) {
+        if (lane == 0) todo[t.interval] = 1;  // (benign race: every writer writes 1)
+        return;
+    }
+    const int base = (int)lo;
+    for (int i = lane; i < n_in; i += kFastThreads) sv[i] = (unsigned char)((int)in[i] - base);
+    for (int k = lane; k < kFastBins / 2 * 64; k += kFastThreads) hh[k] = 0;
+    __syncthreads();
+    const int L = (t.n_out + kFastThreads - 1) / kFastThreads;
+    const int o_begin = lane * L, o_end = min(o_begin + L, t.n_out);
+    if (o_begin >= t.n_out) return;
+    const double sub = edge_sub ? edge_sub[t.interval] : 0.0;
+    unsigned int* mine = hh + lane;
+    auto add = [&](int b) { atomicAdd(&mine[(b >> 1) * 64], 1u << ((b & 1) * 16)); };   // (no carry: a bin holds <= W <= 2048)
+    auto take = [&](int b) { atomicSub(&mine[(b >> 1) * 64], 1u << ((b & 1) * 16)); };  // (no borrow: the bin held the value)
+    auto cnt = [&](int b) { return (int)((mine[(b >> 1) * 64] >> ((b & 1) * 16)) & 0xffffu); };
+    for (int j = 0; j < W; ++j) add(sv[o_begin + j]);
+    const int tgt = W / 2;  // the lower middle is the tgt-th smallest, the upper one the next
+    int m = 0, below = 0;   // below = values in bins < m; below < tgt <= below + cnt(m)
+    for (;;) {
+        const int c = cnt(m);
+        if (below + c >= tgt) break;
+        below += c;
+        ++m;
+    }
+    for (int o = o_begin;;) {
+        int m2 = m;
+        if (below + cnt(m) < tgt + 1) {
+            m2 = m + 1;
+            while (cnt(m2) == 0) ++m2;
+        }
+        // the sort kernel's arithmetic on the same values: ((x1 - sub) + (x2 - sub)) * 0.5, x - sub - median
+        const double med = (((double)(base + m) - sub) + ((double)(base + m2) - sub)) * 0.5;
+        out[t.out_base + o] = ((double)(base + (int)sv[o + W / 2]) - sub) - med;
+        if (++o >= o_end) break;
+        const int b_old = sv[o - 1], b_new = sv[o + W - 1];
+        if (b_old == b_new) continue;
+        take(b_old);
+        add(b_new);
+        below += (b_new < m) - (b_old < m);
+        while (below >= tgt) { --m; below -= cnt(m); }
+        for (;;) {
+            const int c = cnt(m);
+            if (below + c >= tgt) break;
+            below += c;
+            ++m;
+        }
     }
 }
 
@@ -161,16 +251,23 @@ int adjust_sort_size(int W, int* tile_out) {
 }
 
 void launch_adjust_filter(hipStream_t s, const double* scores, const AdjustTile* tiles, int n_tiles,
-                          const double* edge_sub, int W, int use_mean, double* out) {
+                          const double* edge_sub, int W, int use_mean, double* out, const AdjustTile* fast_tiles,
+                          int n_fast_tiles, int* todo, int n_iv) {
     int tile;
     const int n_sort = adjust_sort_size(W, &tile);
     if (use_mean) {
         const size_t lds = (size_t)(tile + W - 1) * 8;
         adjust_mean_kernel<<<n_tiles, kAdjThreads, lds, s>>>(scores, tiles, edge_sub, W, out);
-    } else {
-        const size_t lds = (size_t)n_sort * (8 + 4);
-        adjust_median_kernel<<<n_tiles, kAdjThreads, lds, s>>>(scores, tiles, edge_sub, W, n_sort, out);
+        return;
     }
+    if (fast_tiles && todo) {  // integers in a narrow range: sliding histograms; what they cannot take is marked ...
+        (void)hipMemsetAsync(todo, 0, (size_t)n_iv * sizeof(int), s);
+        const size_t lds_fast = (size_t)kFastBins / 2 * 64 * 4 + (size_t)(kAdjustFastTile + W - 1 + 3) / 4 * 4;
+        adjust_median_hist_kernel<<<n_fast_tiles, kFastThreads, lds_fast, s>>>(scores, fast_tiles, edge_sub, W, out, todo);
+    }
+    // ... and sorted (every interval when there is no histogram pass)
+    const size_t lds = (size_t)n_sort * (8 + 4);
+    adjust_median_kernel<<<n_tiles, kAdjThreads, lds, s>>>(scores, tiles, edge_sub, W, n_sort, out, fast_tiles && todo ? todo : nullptr);
 }
 
 void launch_savgol(hipStream_t s, const double* adj, const AdjustTile* tiles, int n_tiles, const double* coef,

@@ -1793,7 +1793,10 @@ int ftk_wps_adjust(ftk_ctx* ctx, const double* scores, const int64_t* offsets, i
         return fail(ctx, FTK_ERR_INVALID, "savgol_window must be odd and come with coef/edge arrays");
     int tile;
     adjust_sort_size(W, &tile);
-    std::vector<AdjustTile> tiles;
+    // FTK_ADJUST_HIST=0: every interval through the sort kernel (the tests hold the two medians together)
+    static const bool use_hist = !(getenv("FTK_ADJUST_HIST") && atoi(getenv("FTK_ADJUST_HIST")) == 0);
+    const bool fast = use_hist && !use_mean;
+    std::vector<AdjustTile> tiles, fast_tiles;
     for (int64_t i = 0; i < n_iv; ++i) {
         const int64_t len = offsets[i + 1] - offsets[i];
         if (offsets[i] < 0 || len < W)
@@ -1815,6 +1818,16 @@ int ftk_wps_adjust(ftk_ctx* ctx, const double* scores, const int64_t* offsets, i
             t.interval = (int32_t)i;
             tiles.push_back(t);
         }
+        for (int64_t o0 = 0; fast && o0 < m; o0 += kAdjustFastTile) {
+            AdjustTile t;
+            t.in_base = offsets[i] + o0;
+            t.out_base = out_i + o0;
+            t.n_out = (int32_t)std::min<int64_t>(kAdjustFastTile, m - o0);
+            t.o0 = (int32_t)o0;
+            t.m = (int32_t)m;
+            t.interval = (int32_t)i;
+            fast_tiles.push_back(t);
+        }
     }
     const int64_t total_in = offsets[n_iv], total_out = total_in - n_iv * (int64_t)W;
     if (tiles.empty()) return FTK_OK;
@@ -1822,13 +1835,16 @@ int ftk_wps_adjust(ftk_ctx* ctx, const double* scores, const int64_t* offsets, i
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const bool in_dev = is_device_ptr(scores), out_dev = is_device_ptr(out);
     const int half = sw / 2;
-    size_t need = align_up(tiles.size() * sizeof(AdjustTile)) + align_up(n_iv * 8) + align_up((size_t)sw * 8) +
+    size_t need = align_up(tiles.size() * sizeof(AdjustTile)) + align_up(fast_tiles.size() * sizeof(AdjustTile)) + align_up(n_iv * 4) +
+                  align_up(n_iv * 8) + align_up((size_t)sw * 8) +
                   align_up((size_t)2 * half * sw * 8) + (in_dev ? 0 : align_up(total_in * 8)) +
                   (out_dev ? 0 : align_up(total_out * 8)) + (sw ? align_up(total_out * 8) : 0);
     int rc = reserve_scratch(ctx, need);
     if (rc) return rc;
     Arena a(ctx);
     AdjustTile* d_tiles = a.take<AdjustTile>(tiles.size());
+    AdjustTile* d_fast = fast_tiles.empty() ? nullptr : a.take<AdjustTile>(fast_tiles.size());
+    int* d_todo = fast_tiles.empty() ? nullptr : a.take<int>(n_iv);
     double* d_sub = edge_sub ? a.take<double>(n_iv) : nullptr;
     double* d_coef = sw ? a.take<double>(sw) : nullptr;
     double* d_edge = sw ? a.take<double>((size_t)2 * half * sw) : nullptr;
@@ -1842,6 +1858,8 @@ int ftk_wps_adjust(ftk_ctx* ctx, const double* scores, const int64_t* offsets, i
     double* d_adj = sw ? a.take<double>(total_out) : d_out;
     HIPCHK(ctx, hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(AdjustTile), hipMemcpyHostToDevice,
                                ctx->stream));
+    if (d_fast)
+        HIPCHK(ctx, hipMemcpyAsync(d_fast, fast_tiles.data(), fast_tiles.size() * sizeof(AdjustTile), hipMemcpyHostToDevice, ctx->stream));
     if (d_sub) HIPCHK(ctx, hipMemcpyAsync(d_sub, edge_sub, n_iv * 8, hipMemcpyHostToDevice, ctx->stream));
     if (sw) {
         HIPCHK(ctx, hipMemcpyAsync(d_coef, savgol_coef, (size_t)sw * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1849,7 +1867,8 @@ int ftk_wps_adjust(ftk_ctx* ctx, const double* scores, const int64_t* offsets, i
             HIPCHK(ctx, hipMemcpyAsync(d_edge, savgol_edge, (size_t)2 * half * sw * 8, hipMemcpyHostToDevice,
                                        ctx->stream));
     }
-    launch_adjust_filter(ctx->stream, d_in, d_tiles, (int)tiles.size(), d_sub, W, use_mean, d_adj);
+    launch_adjust_filter(ctx->stream, d_in, d_tiles, (int)tiles.size(), d_sub, W, use_mean, d_adj, d_fast, (int)fast_tiles.size(), d_todo,
+                         (int)n_iv);
     if (sw) launch_savgol(ctx->stream, d_adj, d_tiles, (int)tiles.size(), d_coef, d_edge, sw, d_out);
     HIPCHK(ctx, hipGetLastError());
     if (!out_dev) HIPCHK(ctx, hipMemcpyAsync(out, d_out, total_out * 8, hipMemcpyDeviceToHost, ctx->stream));

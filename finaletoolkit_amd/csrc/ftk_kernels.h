@@ -158,9 +158,13 @@ struct AdjustTile {
     int32_t interval;
 };
 constexpr int kAdjustMaxWindow = 2048;
+constexpr int kAdjustFastTile = 4096;  // outputs per tile of the histogram median (64 lanes x 64 consecutive outputs)
 int adjust_sort_size(int W, int* tile_out);
+// fast_tiles / todo (may be NULL): the tiles of the histogram median (at most kAdjustFastTile outputs each) and one int
+// per interval in which it marks the intervals it leaves to the sort kernel
 void launch_adjust_filter(hipStream_t s, const double* scores, const AdjustTile* tiles, int n_tiles,
-                          const double* edge_sub, int W, int use_mean, double* out);
+                          const double* edge_sub, int W, int use_mean, double* out, const AdjustTile* fast_tiles = nullptr,
+                          int n_fast_tiles = 0, int* todo = nullptr, int n_iv = 0);
 void launch_savgol(hipStream_t s, const double* adj, const AdjustTile* tiles, int n_tiles, const double* coef,
                    const double* edge, int sw, double* out);
 void launch_gc_count(hipStream_t s, const uint8_t* img, int64_t img_bytes, int kind, const int64_t* lo,

@@ -1652,8 +1652,7 @@ __global__ __launch_bounds__(256) void gc_count_kernel(const uint8_t* __restrict
             // interior bytes are whole: every base of a 2-bit byte is inside [lo, hi) unless it is the very
             // first or last byte of the range, which can only sit in the interior if it is complete
             const int64_t first_full = kind ? ((lo + 3) >> 2) : b0, last_full = kind ? (hi >> 2) : b1;
-            for (int64_t b = a0 + 16 * lane; b < a1; b += 16 * 64) {
-                const uint4 v = *reinterpret_cast<const uint4*>(img + b);
+            auto chunk = [&](int64_t b, const uint4& v) {
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
                 if (!kind) {
                     acc += gc_in_text_word(w[0]) + gc_in_text_word(w[1]) + gc_in_text_word(w[2]) + gc_in_text_word(w[3]);
@@ -1663,7 +1662,18 @@ __global__ __launch_bounds__(256) void gc_count_kernel(const uint8_t* __restrict
                 } else {
                     for (int k = 0; k < 16; ++k) acc += byte_gc(b + k);
                 }
+            };
+            // four 1 KB rows of the wave in flight per trip (a 100 kb bin of a 2bit image is 25 of them: the loop
+            // is as long as its loads' latency, so the loads are issued together), then row by row
+            int64_t b = a0 + 16 * lane;
+            for (; b + 3 * 16 * 64 < a1; b += 4 * 16 * 64) {
+                uint4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(img + b + u * 16 * 64);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) chunk(b + u * 16 * 64, v[u]);
             }
+            for (; b < a1; b += 16 * 64) chunk(b, *reinterpret_cast<const uint4*>(img + b));
         }
     }
 #pragma unroll

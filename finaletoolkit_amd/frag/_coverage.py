@@ -197,7 +197,14 @@ def coverage(input_file: Union[str, Path], interval_file: str, output_file: str,
         scale_factor /= total
 
     values = (counts * scale_factor).tolist()  # int64 -> float64 times a Python float: `cov * scale_factor` of :250
-    return_val = list(map(CoverageResult._make, zip(*zip(*intervals), values))) if intervals else []
+    import gc
+    was = gc.isenabled()
+    gc.disable()  # (tens of thousands of small tuples: the collector would walk them again and again)
+    try:
+        return_val = [CoverageResult(c, a, b, n, v) for (c, a, b, n), v in zip(intervals, values)]
+    finally:
+        if was:
+            gc.enable()
     if output_file is not None:
         if sharding.rank_world()[0] == 0:
             writers.write_coverage_rows(output_file, intervals, values)

@@ -248,6 +248,27 @@ def frag_length_bins(input_file, contig: str | None = None, start: int | None = 
     return bins, counts
 
 
+def _result_rows(results: list, intervals, index, stats: np.ndarray) -> None:
+    """``results[i] = FragLengthStats(...)`` for the intervals ``index`` from their statistics rows ``stats[k]`` =
+    mean median stdev min max count n_short; an interval without a fragment: every statistic is the integer -1
+    (frag/_frag_length.py:202-238)."""
+    import gc
+    total = stats[:, 5].astype(np.int64)
+    frac = np.divide(stats[:, 6].astype(np.int64), total, out=np.zeros(len(total), np.float64), where=total > 0)  # int / int
+    cols = zip(np.asarray(index).tolist(), stats[:, 0].tolist(), stats[:, 1].tolist(), stats[:, 2].tolist(),
+               stats[:, 3].astype(np.int64).tolist(), stats[:, 4].astype(np.int64).tolist(), total.tolist(), frac.tolist())
+    was = gc.isenabled()
+    gc.disable()  # (tens of thousands of small tuples: the collector would walk them again and again)
+    try:
+        for i, mean, median, stdev, vmin, vmax, n, short in cols:
+            c, a, b, name = intervals[i]
+            results[i] = (FragLengthStats(c, a, b, name, mean, median, stdev, vmin, vmax, n, short) if n else
+                          FragLengthStats(c, a, b, name, -1, -1, -1, -1, -1, -1, -1))
+    finally:
+        if was:
+            gc.enable()
+
+
 def frag_length_intervals(input_file, interval_file: str, output_file: str | None = None,
                           min_length: int | None = 0, max_length: int | None = None, quality_threshold: int = 30,
                           intersect_policy: str = "midpoint", short_reads: int = 150, workers: int = 1,
@@ -311,7 +332,7 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
         by_contig: dict = {}
         for i, iv in enumerate(intervals):
             by_contig.setdefault(iv[0], []).append(i)
-        stats = np.zeros((len(intervals), 7), np.float64)
+        stats = None
         feed = ContigFeed(input_file, workers, names=list(by_contig))
         try:
             for src, c in feed:
@@ -320,8 +341,10 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
                 if idx is not None:
                     idx = np.asarray(idx, dtype=np.int64)
                     order = idx[np.argsort(iv_starts[idx], kind="stable")]
-                    stats[order] = unit_stats(src.key(c), order)
-                clock.lap("histograms_and_statistics")
+                    block = unit_stats(src.key(c), order)
+                    clock.lap("histograms_and_statistics")
+                    _result_rows(results, intervals, order, block)  # (while the decoder is in the next contig)
+                    clock.lap("result_rows")
             src = feed.finish()
         except BaseException:
             feed.close()
@@ -345,14 +368,8 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
         sharding.agree(err)
         stats = plan.gather(local, 7, np.float64)
         clock.lap("gather")
-    total = stats[:, 5].astype(np.int64)
-    some = total > 0
-    frac = np.divide(stats[:, 6].astype(np.int64), total, out=np.zeros(len(total), np.float64), where=some)  # int / int
-    cols = (stats[:, 0].tolist(), stats[:, 1].tolist(), stats[:, 2].tolist(), stats[:, 3].astype(np.int64).tolist(),
-            stats[:, 4].astype(np.int64).tolist(), total.tolist(), frac.tolist())
-    results = list(map(FragLengthStats._make, zip(*zip(*intervals), *cols))) if intervals else []
-    for i in np.flatnonzero(~some).tolist():  # (an interval without a fragment: every statistic is the integer -1)
-        results[i] = FragLengthStats(*intervals[i], -1, -1, -1, -1, -1, -1, -1)
+    if stats is not None:
+        _result_rows(results, intervals, np.arange(len(intervals)), stats)
 
     clock.lap("result_rows")
     if output_file is not None:

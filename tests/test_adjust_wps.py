@@ -144,6 +144,34 @@ def test_gpu_ragged_runs_vs_oracle(engine, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("W", [2, 120, 1000, 2048])
+def test_gpu_histogram_median_takes_what_it_can_and_leaves_the_rest(engine, W):
+    """Integer scores in a narrow range go through the sliding-histogram median (`adjust_median_hist_kernel`), anything
+    else - a range beyond 256, a non-integer, a -0.0 - is left to the sort kernel, interval by interval; both give the
+    numpy median of the oracle bit for bit, with and without the edge term."""
+    rng = np.random.default_rng(100 + W)
+    lens = [W + 1, W + 63, W + 64, W + 4096, W + 4097, W + 9000, W + 5000, W + 3000, W + 700, W + 2000]
+    runs = [rng.integers(-40, 25, n).astype(np.float64) for n in lens]
+    runs[3] = np.round(rng.normal(0, 3, lens[3]))                      # many ties, few bins
+    runs[5] = np.repeat(rng.integers(-100, 100, lens[5] // 50 + 1), 50)[:lens[5]].astype(np.float64)   # plateaus: pointers jump
+    runs[6][2500] = 400.0                                              # range beyond 256 in ONE tile of the interval
+    runs[7][10] = 0.5                                                  # a non-integer
+    runs[8][5] = -0.0                                                  # negative zero
+    runs[9] = rng.integers(-(1 << 20), 1 << 20, lens[9]).astype(np.float64)   # wide integers
+    offs = np.zeros(len(runs) + 1, np.int64)
+    np.cumsum(lens, out=offs[1:])
+    flat = np.concatenate(runs)
+    got = engine.wps_adjust(flat, offs, W, savgol=False)
+    want = np.concatenate([O.py_adjust_run(r, W, savgol=False) for r in runs])
+    assert np.array_equal(got, want)
+    e = max(1, min(500, W // 2))
+    sub = [np.mean([np.mean(r[:e]), np.mean(r[-e:])]) for r in runs]
+    got = engine.wps_adjust(flat, offs, W, False, sub, savgol=False)
+    want = np.concatenate([O.py_adjust_run(r, W, edge_size=e, savgol=False) for r in runs])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
 def test_gpu_adjust_errors(engine):
     x = np.zeros(1500)
     offs = np.array([0, 1500], np.int64)

@@ -113,8 +113,9 @@ def measure(torch, tmp, genome_file, sizes, threads, raw_floor=None, depth=30.0,
     def floor(leg, extra_s=0.0, note=None):
         if raw_floor:
             f = dict(raw_floor)
-            f["floor_s"] = round(f["floor_s"] + extra_s, 4)
-            if extra_s:
+            if extra_s:  # (the output is compressed beside the decode: the floor is the longer of the two)
+                f["decode_floor_s"] = f["floor_s"]
+                f["floor_s"] = round(max(f["floor_s"], extra_s), 4)
                 f["output_term_s"] = round(extra_s, 4)
                 f["output_term"] = note
             f["frac_of_floor_best"] = round(f["floor_s"] / leg["best_s"], 3)
@@ -166,6 +167,28 @@ def measure(torch, tmp, genome_file, sizes, threads, raw_floor=None, depth=30.0,
         if len(m) > 1:
             b[:-1] = np.minimum(b[:-1], a[1:])
         bases += int(np.maximum(b - a, 0).sum())
+    # what the output side of these two legs cannot go below: their bytes through the container's compressor (zlib
+    # streams of float32 sections; gzip members of text rows - both at level 6, libdeflate when the box has it) at the
+    # rate ONE thread reaches on a 4 Mb sample of this very track, times the threads the writers use
+    from finaletoolkit_amd import writers
+    eng = source.get_engine()
+    probe_key = source.open_source(genome_file).require(CHECK)
+    a0 = sizes[CHECK] // 2
+    n_probe = min(4 << 20, sizes[CHECK] - a0)
+    sample = eng.wps(probe_key, a0, a0 + n_probe, sizes[CHECK])
+    t0 = time.perf_counter()
+    writers.bigwig_sections(0, [a0], sample, None, 16384, 6, 1)
+    bw_1t = 4 * n_probe / (time.perf_counter() - t0)          # float32 bytes per second, one thread
+    with writers.bedgraph_rows(CHECK, [a0], sample[:1 << 20], None, 1) as rows:
+        text_per_base = rows.n / float(1 << 20)
+        t0 = time.perf_counter()
+        rows.gzip_bytes(writers.GZIP_LEVEL, 1)
+        gz_1t = rows.n / (time.perf_counter() - t0)           # text bytes per second, one thread
+    source.close_all()
+    out_floor = {".bw": (4 * bases / (bw_1t * threads), f"{4 * bases / 1e6:.0f} MB of float32 sections through zlib level 6 at "
+                         f"{bw_1t / 1e6:.0f} MB/s per thread (measured on a 4 Mb sample) x {threads} threads"),
+                 ".bed.gz": (text_per_base * bases / (gz_1t * threads), f"{text_per_base * bases / 1e6:.0f} MB of rows through gzip level "
+                             f"{writers.GZIP_LEVEL} at {gz_1t / 1e6:.0f} MB/s per thread (measured on 1 Mi rows) x {threads} threads")}
     for suffix, key in ((".bw", "multi_wps_bw"), (".bed.gz", "multi_wps_bedgz")):
         out = os.path.join(tmp, "legs_wps" + suffix)
         leg, _ = timed(lambda: frag.multi_wps(genome_file, sites, cs, out, interval_size=5000, workers=threads),
@@ -204,6 +227,7 @@ def measure(torch, tmp, genome_file, sizes, threads, raw_floor=None, depth=30.0,
                    checked=f"contig {CHECK}: {n_chk} site window(s) read back from the file == C oracle WPS" + ("" if suffix == ".bw" else f"; {bases} rows"),
                    reference_shaped_python_sites_per_s=round(rate, 3), python_sample=f"{n} sites of contig {CHECK}",
                    x_vs_reference_shaped_python=round(n_site_rows / leg["best_s"] / rate, 1))
+        floor(leg, *out_floor[suffix])
         res[key] = leg
         os.remove(out)
 
@@ -268,13 +292,19 @@ def main():
         path = os.path.join(tmp, "genome.frag.gz")
         t0 = time.perf_counter()
         names = list(sizes)
+        text_bytes = 0
         for k, c in enumerate(names):
             s, e, q, st = (t.cpu().numpy() for t in gen_contig_device(torch, dev, sizes[c], synth.n_fragments(sizes[c], 30.0), synth.SEED_BASE + k))
             with writers.frag_rows(c, s, e, q, st) as text:
                 writers.bgzf_write(path, text, 1, append=k > 0, write_eof=k == len(names) - 1)
+                text_bytes += text.n
         open(path + ".tbi", "wb").close()
         sys.stderr.write(f"genome file {os.path.getsize(path) / 1e9:.2f} GB written in {time.perf_counter() - t0:.1f} s\n")
-        res = measure(torch, tmp, path, sizes, source.usable_cores(), reps=args.reps, n_sites=args.sites)
+        import bench  # the decode floor of bench.py's file legs: compressed bytes over PCIe, the inflate kernel alone
+        h2d, rates = bench.measure_h2d_gbs(torch, dev), bench.inflate_alone_rates()
+        probe = dict(best_s=1.0, median_s=1.0)
+        bench.leg_floor(probe, os.path.getsize(path), text_bytes, "text", h2d, rates)
+        res = measure(torch, tmp, path, sizes, source.usable_cores(), raw_floor=probe.get("floor"), reps=args.reps, n_sites=args.sites)
         text = json.dumps(res, indent=1)
         print(text)
         if args.out:

@@ -83,11 +83,19 @@ def measure(torch, eng, which="all", reps=5, seed=1):
         eng.ref_set_layout(rid, size, 0, 0, [10_000], [20_000])
         mws, mwe = synth.tiling_windows(size, 1_000_000)
         k = 4
-        f = lambda: eng.motif_counts("kr_next", rid, mws, mwe, k, 0, -k, True, False, 0, False, 30)
+        d_counts = torch.zeros((len(mws), 4 ** k), dtype=torch.int32, device=dev)  # (the counts stay on the device: no host round trip inside the events)
+        d_nfrag = torch.zeros(len(mws), dtype=torch.int64, device=dev)
+        d_err = torch.zeros(len(mws), dtype=torch.int64, device=dev)
+        mot = L.Motif(k, 0, -k, 1, 0, 0, 0)
+        f = lambda: eng._check(eng.lib.ftk_motif_counts(eng.ctx, eng.contig_id("kr_next"), rid, L.ptr(mws), L.ptr(mwe), len(mws),
+                                                        C.byref(mot), 30, L.FETCH_TABIX, L.ptr(d_counts), L.ptr(d_nfrag), L.ptr(d_err)))
         rows["motif_pass"] = _row("feat_*_kernel<CH=2> (end motifs k=4, 2bit)", _time(eng, f, reps, flush),
                                   10 * n + 2 * n + len(mws) * (4 ** k) * 4,
                                   "10 B x fragments + 2 x 1 B of packed reference per fragment + 4^k x 4 B per window",
-                                  note="host round trip of the 243 x 256 counts included in the events")
+                                  note="the planner, the window kernels and the count rows written to HBM; nothing crosses to the host inside the events")
+        got_host = eng.motif_counts("kr_next", rid, mws, mwe, k, 0, -k, True, False, 0, False, 30)[0]
+        rows["motif_pass"]["device_counts_equal_host_call"] = bool(np.array_equal(d_counts.cpu().numpy().view(np.uint32), got_host))
+        del d_counts, d_nfrag, d_err
         # G + C of 100 kb bins from the 2bit image
         glo, ghi = synth.tiling_windows(size, 100_000)
         d_lo = torch.from_numpy(glo.astype(np.int64)).to(dev)
@@ -108,7 +116,14 @@ def measure(torch, eng, which="all", reps=5, seed=1):
         f = lambda: eng.wps_adjust(x.data_ptr(), offs, W, out=y.data_ptr(), savgol=False)
         rows["adjust_median_kernel"] = _row("adjust_median_kernel", _time(eng, f, reps), 8 * n_iv * ilen + 8 * n_iv * (ilen - W),
                                             "8 B per input score + 8 B per output",
-                                            note="an exact sliding median: bound by its LDS sort and slot walk (DESIGN 3.4), not by HBM")
+                                            note="integer scores (raw WPS): adjust_median_hist_kernel, one sliding histogram per lane; the sort kernel "
+                                                 "behind it finds every interval answered and exits")
+        xf = x + 0.25  # the same runs as non-integers: every interval goes through the sort kernel (the path of round 5)
+        f = lambda: eng.wps_adjust(xf.data_ptr(), offs, W, out=y.data_ptr(), savgol=False)
+        rows["adjust_median_kernel_sort_path"] = _row("adjust_median_kernel (non-integer scores)", _time(eng, f, reps), 8 * n_iv * ilen + 8 * n_iv * (ilen - W),
+                                                      "8 B per input score + 8 B per output",
+                                                      note="an exact sliding median of arbitrary doubles: bound by its LDS sort and slot walk, not by HBM")
+        del xf
         del x, y
         out["next_rows"] = rows
     if which in ("all", "bam"):
