@@ -14,12 +14,13 @@
 //
 // Round 6: raw WPS scores are small INTEGERS (a bigWig of `multi_wps` holds counts), and the median of integers in a
 // narrow range needs no sort: `adjust_median_hist_kernel` gives every lane a run of consecutive outputs and a
-// histogram of its own (256 bins of 16 bits, lane-interleaved in LDS); the window slides by one - one bin down, one up -
-// and the two middle order statistics follow by O(1) steps from where they were.  A tile whose values are not integers
-// within a range of 256 marks its interval, and the sort kernel above redoes the marked intervals: same result, bit for
-// bit (the medians are the same input values).
+// histogram of its own (128 or 256 bins of 16 bits in LDS, two lanes to a word); the window slides by one - one bin
+// down, one up - and the two middle order statistics follow by O(1) steps from where they were.  A tile whose values
+// are not integers within a range of 256 marks its interval, and the sort kernel redoes the marked intervals: same
+// result, bit for bit (the medians are the same input values).  10 000 x 5 kb runs at W = 1000: 7.2 ms -> 0.52 ms.
 #include "ftk_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace ftk {
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(kAdjThreads) void adjust_median_kernel(const double
     extern __shared__ unsigned long long lds_keys[];       // [n_sort] sorted keys
     unsigned int* pos = (unsigned int*)(lds_keys + n_sort);  // [n_sort] input position of each sorted slot
     const AdjustTile t = tiles[blockIdx.x];
-    if (todo && !todo[t.interval]) return;  // the histogram kernel has answered this interval
+    if (todo && todo[t.interval] != 2) return;  // a histogram kernel has answered this interval
     const double sub = edge_sub ? edge_sub[t.interval] : 0.0;
     const double* in = scores + t.in_base;
     const int n_in = t.n_out + W - 1;
@@ -110,28 +111,54 @@ __global__ __launch_bounds__(kAdjThreads) void adjust_median_kernel(const double
 }
 
 // ---- the median of small integers: one lane, one run of outputs, one sliding histogram ---------------------------
-constexpr int kFastBins = 256;      // value range a tile may span
+// Two sizes: 128 bins (16 KB of histograms per wavefront: seven tiles per CU - the ALU and LDS latencies of one lane's
+// chain are hidden by the other waves of its SIMD; raw WPS at 30x spans 60-80 values over 5 kb) and 256 bins (32 KB,
+// four per CU) for the tiles the first leaves (todo == kTodoWide), which in turn leaves the rest to the sort kernel
+// (todo == kTodoSort).  An interval is redone as a whole by the next kernel of the chain when one of its tiles asks.
 constexpr int kFastThreads = 64;    // one wavefront per tile
+constexpr int kTodoWide = 1, kTodoSort = 2;
 
+template <int kFastBins>
 __global__ __launch_bounds__(kFastThreads) void adjust_median_hist_kernel(const double* __restrict__ scores,
                                                                            const AdjustTile* __restrict__ tiles,
                                                                            const double* __restrict__ edge_sub, int W,
                                                                            double* __restrict__ out, int* __restrict__ todo) {
+    // (the inputs are parked as int16 offsets where the histograms go: 128 bins x 64 lanes x 2 B hold the largest tile)
+    constexpr int kHistWords = kFastBins / 2 * 64;
+    static_assert((kAdjustFastTile + kAdjustMaxWindow) * 2 <= kHistWords * 4, "the parked inputs must fit where the histograms go");
     extern __shared__ unsigned int lds_fast[];
-    unsigned int* hh = lds_fast;                                           // [kFastBins / 2][64]: bins 2k, 2k + 1 of lane l
-    unsigned char* sv = (unsigned char*)(lds_fast + kFastBins / 2 * 64);   // [n_in]: value - base
+    unsigned int* hh = lds_fast;                                   // [kFastBins][32]: bin b of lanes 2p (low half), 2p + 1 (high half)
+    unsigned char* sv = (unsigned char*)(lds_fast + kHistWords);   // [n_in]: value - base
     const AdjustTile t = tiles[blockIdx.x];
+    if (kFastBins > 128 && todo[t.interval] != kTodoWide) return;  // (answered by the 128-bin pass)
     const int lane = threadIdx.x;
     const double* in = scores + t.in_base;
     const int n_in = t.n_out + W - 1;
-    // integers (no -0.0) within a range of kFastBins?
+    // integers (no -0.0) within a range of kFastBins?  The tile's inputs are read ONCE, eight 512-byte rows of the wave
+    // in flight per trip (one wave per block: a loop of single loads would wait out a memory latency per row), and
+    // parked as int32 where the histograms will be; then shifted to bytes, then the histograms cleared.
+    short* parked = (short*)hh;  // value - the tile's first value (a tile the histograms can take spans < 256)
+    const double v0 = in[0];
     double lo = INFINITY, hi = -INFINITY;
     bool ok = true;
-    for (int i = lane; i < n_in; i += kFastThreads) {
-        const double v = in[i];
-        ok = ok && v == rint(v) && fabs(v) < 1e9 && !(v == 0.0 && signbit(v));
-        lo = fmin(lo, v);
-        hi = fmax(hi, v);
+    for (int i0 = 0; i0 < n_in; i0 += 8 * kFastThreads) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * kFastThreads + lane;
+            v[u] = i < n_in ? in[i] : v0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * kFastThreads + lane;
+            if (i < n_in) {
+                const double d = v[u] - v0;
+                ok = ok && v[u] == rint(v[u]) && fabs(v[u]) < 1e9 && fabs(d) < 30000.0 && !(v[u] == 0.0 && signbit(v[u]));
+                lo = fmin(lo, v[u]);
+                hi = fmax(hi, v[u]);
+                parked[i] = (short)(int)d;
+            }
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -139,33 +166,53 @@ __global__ __launch_bounds__(kFastThreads) void adjust_median_hist_kernel(const 
         hi = fmax(hi, __shfl_xor(hi, d, 64));
     }
     if (!__all(ok) || !(hi - lo < (double)kFastBins)) {
-        if (lane == 0) todo[t.interval] = 1;  // (benign race: every writer writes 1)
+        // (racing writers of one interval: the larger request must win)
+        if (lane == 0) atomicMax(&todo[t.interval], (__all(ok) && kFastBins <= 128 && hi - lo < 256.0) ? kTodoWide : kTodoSort);
         return;
     }
-    const int base = (int)lo;
-    for (int i = lane; i < n_in; i += kFastThreads) sv[i] = (unsigned char)((int)in[i] - base);
+    const int base = (int)lo, rel = (int)(lo - v0);
+    __syncthreads();
+    for (int i = lane; i < n_in; i += kFastThreads) sv[i] = (unsigned char)((int)parked[i] - rel);
+    __syncthreads();
     for (int k = lane; k < kFastBins / 2 * 64; k += kFastThreads) hh[k] = 0;
     __syncthreads();
-    const int L = (t.n_out + kFastThreads - 1) / kFastThreads;
+    // A lane's run of outputs starts on a multiple of 4 bytes of `sv` (it reads its values four at a time), and the
+    // runs' length in dwords is ODD: lane l then starts in bank (l x odd) mod 32 - all 32 banks, two lanes each, the
+    // least a wavefront can have.  (With the obvious 64 outputs per lane every lane read the same two banks: 0.93 ms
+    // per 10 000 x 5 kb intervals instead of what follows.)
+    int L = ((t.n_out + kFastThreads - 1) / kFastThreads + 3) & ~3;
+    if (!((L >> 2) & 1)) L += 4;
     const int o_begin = lane * L, o_end = min(o_begin + L, t.n_out);
     if (o_begin >= t.n_out) return;
     const double sub = edge_sub ? edge_sub[t.interval] : 0.0;
-    unsigned int* mine = hh + lane;
-    auto add = [&](int b) { atomicAdd(&mine[(b >> 1) * 64], 1u << ((b & 1) * 16)); };   // (no carry: a bin holds <= W <= 2048)
-    auto take = [&](int b) { atomicSub(&mine[(b >> 1) * 64], 1u << ((b & 1) * 16)); };  // (no borrow: the bin held the value)
-    auto cnt = [&](int b) { return (int)((mine[(b >> 1) * 64] >> ((b & 1) * 16)) & 0xffffu); };
-    for (int j = 0; j < W; ++j) add(sv[o_begin + j]);
+    // bin b of lanes 2p and 2p + 1 share the word hh[b * 32 + p] (low / high half): a value's bin is its word's row, the
+    // half and the increment are the lane's own constants - two instructions of address arithmetic per value
+    unsigned int* mine = hh + (lane >> 1);
+    const int half = (lane & 1) * 16;
+    const unsigned int one = 1u << half;
+    auto add = [&](int b) { atomicAdd(&mine[b * 32], one); };   // (no carry: a bin holds <= W <= 2048)
+    auto take = [&](int b) { atomicSub(&mine[b * 32], one); };  // (no borrow: the bin held the value)
+    auto cnt = [&](int b) { return (int)((mine[b * 32] >> half) & 0xffffu); };
+    {
+        int j = 0;
+        for (; j + 4 <= W; j += 4) {  // (the adds return nothing: they queue up behind one 4-byte read)
+            const unsigned int pk = *reinterpret_cast<const unsigned int*>(sv + o_begin + j);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add((pk >> (8 * u)) & 0xffu);
+        }
+        for (; j < W; ++j) add(sv[o_begin + j]);
+    }
     const int tgt = W / 2;  // the lower middle is the tgt-th smallest, the upper one the next
-    int m = 0, below = 0;   // below = values in bins < m; below < tgt <= below + cnt(m)
-    for (;;) {
-        const int c = cnt(m);
-        if (below + c >= tgt) break;
-        below += c;
+    // m: the bin of the lower middle; below: values in bins < m; cm: values in bin m.  below < tgt <= below + cm.
+    int m = 0, below = 0, cm = cnt(0);
+    while (below + cm < tgt) {
+        below += cm;
         ++m;
+        cm = cnt(m);
     }
     for (int o = o_begin;;) {
         int m2 = m;
-        if (below + cnt(m) < tgt + 1) {
+        if (below + cm < tgt + 1) {  // (rare with hundreds of values in a few dozen bins)
             m2 = m + 1;
             while (cnt(m2) == 0) ++m2;
         }
@@ -178,12 +225,17 @@ __global__ __launch_bounds__(kFastThreads) void adjust_median_hist_kernel(const 
         take(b_old);
         add(b_new);
         below += (b_new < m) - (b_old < m);
-        while (below >= tgt) { --m; below -= cnt(m); }
-        for (;;) {
-            const int c = cnt(m);
-            if (below + c >= tgt) break;
-            below += c;
+        cm += (b_new == m) - (b_old == m);
+        // the middle moves by a bin or two at most: the counts of the bins it crosses are the only reads of a step
+        while (below >= tgt) {
+            --m;
+            cm = cnt(m);
+            below -= cm;
+        }
+        while (below + cm < tgt) {
+            below += cm;
             ++m;
+            cm = cnt(m);
         }
     }
 }
@@ -262,8 +314,9 @@ void launch_adjust_filter(hipStream_t s, const double* scores, const AdjustTile*
     }
     if (fast_tiles && todo) {  // integers in a narrow range: sliding histograms; what they cannot take is marked ...
         (void)hipMemsetAsync(todo, 0, (size_t)n_iv * sizeof(int), s);
-        const size_t lds_fast = (size_t)kFastBins / 2 * 64 * 4 + (size_t)(kAdjustFastTile + W - 1 + 3) / 4 * 4;
-        adjust_median_hist_kernel<<<n_fast_tiles, kFastThreads, lds_fast, s>>>(scores, fast_tiles, edge_sub, W, out, todo);
+        const size_t bytes_sv = (size_t)(kAdjustFastTile + W - 1 + 3) / 4 * 4;
+        adjust_median_hist_kernel<128><<<n_fast_tiles, kFastThreads, (size_t)128 / 2 * 64 * 4 + bytes_sv, s>>>(scores, fast_tiles, edge_sub, W, out, todo);
+        adjust_median_hist_kernel<256><<<n_fast_tiles, kFastThreads, (size_t)256 / 2 * 64 * 4 + bytes_sv, s>>>(scores, fast_tiles, edge_sub, W, out, todo);
     }
     // ... and sorted (every interval when there is no histogram pass)
     const size_t lds = (size_t)n_sort * (8 + 4);
