@@ -80,6 +80,8 @@ class RcclGroup(Group):
         self.device = device
         h = C.c_void_p()
         ident = None if id_hex_or_path is None else str(id_hex_or_path).encode()
+        if job_nonce():  # (the library reads the launch's nonce from the environment: ftk_comm_create)
+            os.environ["FTK_COMM_NONCE"] = job_nonce()
         rc = self.lib.ftk_comm_create(self.eng.ctx, int(rank), int(world), ident, C.byref(h))
         if rc != L.FTK_OK:
             msg = self.lib.ftk_last_error(self.eng.ctx).decode()
@@ -220,13 +222,30 @@ class TorchGroup(Group):
             self.dist.destroy_process_group()
 
 
+def job_nonce() -> str:
+    """What tells this launch's rendezvous file from any other's: ``FTK_COMM_NONCE`` (``sharding.launch_ranks`` makes
+    one per launch), else the launcher's run id (``TORCHELASTIC_RUN_ID`` when it is not torchrun's default ``none``),
+    else nothing - the library then relies on the file's age alone (``ftk_comm_create``)."""
+    n = os.environ.get("FTK_COMM_NONCE")
+    if n:
+        return n
+    run = os.environ.get("TORCHELASTIC_RUN_ID", "")
+    return run if run and run != "none" else ""
+
+
 def id_file() -> str:
-    """Where the ranks of this job meet: ``FTK_COMM_ID_FILE``, else a name all ranks of one launch derive alike - the
-    launcher's pid (the ranks' common parent) and MASTER_PORT."""
+    """Where the ranks of this job meet: ``FTK_COMM_ID_FILE`` (``sharding.launch_ranks`` exports one inside a fresh
+    directory of its own), else a name all ranks of one launch derive alike from what the LAUNCHER gave them - its run
+    id when it set one, MASTER_ADDR / MASTER_PORT - and, only without a run id, the ranks' common parent pid (a launcher
+    that puts a wrapper process around every rank must therefore set ``FTK_COMM_ID_FILE`` or a run id)."""
     p = os.environ.get("FTK_COMM_ID_FILE")
     if p:
         return p
-    return os.path.join(tempfile.gettempdir(), f"ftk_comm_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}.id")
+    run = job_nonce()
+    tag = run if run else str(os.getppid())
+    tag = "".join(ch if ch.isalnum() else "_" for ch in tag)[:64]
+    port = os.environ.get("MASTER_PORT", "0")
+    return os.path.join(tempfile.gettempdir(), f"ftk_comm_{os.getuid()}_{tag}_{port}.id")
 
 
 def current(group=None) -> Group:

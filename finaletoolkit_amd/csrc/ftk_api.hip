@@ -8,8 +8,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <future>
+#include <memory>
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <type_traits>
 
 #include <dlfcn.h>
@@ -2384,48 +2389,80 @@ int ftk_comm_unique_id(char* hex_out) {
     return FTK_OK;
 }
 
+// The rendezvous file.  Content: the 256 hex digits of the id, then - when the launcher gave the job a nonce
+// (FTK_COMM_NONCE: sharding.launch_ranks makes one per launch; comm.py passes TORCHELASTIC_RUN_ID on) - a newline and
+// the nonce.  A reader takes a file only if (i) its nonce is the reader's own, when the reader has one, and (ii) it was
+// written after this library was loaded into the reader (minus a slack for ranks that start a moment apart): the file
+// a killed job left behind - rank 0 removes it only once its communicator is up - is older than that and is ignored
+// instead of being joined, which would hang in ncclCommInitRank for ever.
+static const time_t g_loaded_at = time(nullptr);
+
+static const char* comm_nonce() {
+    const char* e = getenv("FTK_COMM_NONCE");
+    return e ? e : "";
+}
+
 int ftk_comm_create(ftk_ctx* ctx, int rank, int world, const char* id_hex_or_path, ftk_comm** out) {
     if (!ctx || !out) return fail(ctx, FTK_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (world < 1 || rank < 0 || rank >= world) return fail(ctx, FTK_ERR_INVALID, "bad rank %d / world %d", rank, world);
     if (!id_hex_or_path && world > 1) return fail(ctx, FTK_ERR_INVALID, "ranks of a job need a common id (hex digits or a file path)");
-    QuietStdout quiet;
     RcclApi* a = rccl();
     if (!a) return fail(ctx, FTK_ERR_NO_DEVICE, "librccl could not be loaded (dlopen librccl.so.1)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    static const double limit_s = getenv("FTK_COMM_TIMEOUT_S") ? atof(getenv("FTK_COMM_TIMEOUT_S")) : 600.0;
     ncclUniqueId uid;
     std::string wrote;
+    auto fresh_id = [&]() -> ncclResult_t {
+        QuietStdout quiet;  // (only around the RCCL calls that print the banner: other threads' stdout stays theirs)
+        return a->GetUniqueId(&uid);
+    };
     if (!id_hex_or_path) {
-        RCCLCHK(ctx, a->GetUniqueId(&uid));
+        RCCLCHK(ctx, fresh_id());
     } else if (looks_like_hex_id(id_hex_or_path)) {
         hex_to_id(id_hex_or_path, &uid);
     } else if (rank == 0) {
-        // rendezvous through a file: rank 0 writes the id next to the final name and renames it into place, so that
-        // a reader never sees part of it
-        RCCLCHK(ctx, a->GetUniqueId(&uid));
+        // rendezvous through a file: rank 0 writes the id next to the final name - a new file of its own (O_EXCL), never
+        // through a link somebody planted (O_NOFOLLOW), readable by its user alone - and renames it into place, so that
+        // a reader never sees part of it.  A file already at the final name is a dead job's: it goes first.
+        (void)unlink(id_hex_or_path);
+        RCCLCHK(ctx, fresh_id());
         char hex[kIdHex + 1];
         id_to_hex(uid, hex);
+        const std::string body = std::string(hex) + "\n" + std::string(comm_nonce());
         const std::string tmp = std::string(id_hex_or_path) + ".tmp" + std::to_string((long long)getpid());
-        FILE* fh = fopen(tmp.c_str(), "w");
-        if (!fh || fwrite(hex, 1, kIdHex, fh) != kIdHex || fclose(fh) != 0 || rename(tmp.c_str(), id_hex_or_path) != 0) {
-            if (fh) (void)remove(tmp.c_str());
-            return fail(ctx, FTK_ERR_IO, "cannot write the rendezvous file %s: %s", id_hex_or_path, strerror(errno));
+        (void)unlink(tmp.c_str());
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+        bool ok = fd >= 0 && write(fd, body.data(), body.size()) == (ssize_t)body.size();
+        if (fd >= 0) ok = (close(fd) == 0) && ok;
+        if (!ok || rename(tmp.c_str(), id_hex_or_path) != 0) {
+            const int err = errno;
+            if (fd >= 0) (void)unlink(tmp.c_str());
+            return fail(ctx, FTK_ERR_IO, "cannot write the rendezvous file %s: %s", id_hex_or_path, strerror(err));
         }
         wrote = id_hex_or_path;
     } else {
-        static const double limit_s = getenv("FTK_COMM_TIMEOUT_S") ? atof(getenv("FTK_COMM_TIMEOUT_S")) : 600.0;
         const auto t0 = std::chrono::steady_clock::now();
-        char hex[kIdHex + 1] = {0};
+        const std::string want_nonce(comm_nonce());
         for (;;) {
-            FILE* fh = fopen(id_hex_or_path, "r");
-            if (fh) {
-                const size_t got = fread(hex, 1, kIdHex, fh);
-                fclose(fh);
-                hex[got] = 0;
-                if (got == kIdHex && hex_to_id(hex, &uid)) break;
+            const int fd = open(id_hex_or_path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+            if (fd >= 0) {
+                char buf[kIdHex + 258] = {0};
+                struct stat st;
+                const bool have = fstat(fd, &st) == 0;
+                const ssize_t got = read(fd, buf, sizeof(buf) - 1);
+                close(fd);
+                if (have && got >= (ssize_t)kIdHex + 1 && buf[kIdHex] == '\n') {
+                    buf[got] = 0;
+                    buf[kIdHex] = 0;
+                    const bool nonce_ok = want_nonce.empty() || want_nonce == (buf + kIdHex + 1);
+                    const bool recent = st.st_mtime + 10 >= g_loaded_at;  // (written by THIS launch, not left by an earlier one)
+                    if (nonce_ok && recent && hex_to_id(buf, &uid)) break;
+                }
             }
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
-                return fail(ctx, FTK_ERR_IO, "rank %d: no communicator id in %s after %.0f s (did rank 0 start?)", rank, id_hex_or_path, limit_s);
+                return fail(ctx, FTK_ERR_IO, "rank %d: no communicator id of this launch in %s after %.0f s (did rank 0 start? do all ranks "
+                            "share FTK_COMM_ID_FILE / FTK_COMM_NONCE? a file older than this process is ignored)", rank, id_hex_or_path, limit_s);
             usleep(2000);
         }
     }
@@ -2443,7 +2480,26 @@ int ftk_comm_create(ftk_ctx* ctx, int rank, int world, const char* id_hex_or_pat
         ftk_comm_destroy(c);
         return fail(ctx, FTK_ERR_HIP, "communicator setup failed: %s", hipGetErrorString(e));
     }
-    const ncclResult_t r = a->CommInitRank(&c->comm, world, uid, rank);
+    // ncclCommInitRank has no timeout of its own and waits for ever for a rank that never comes (one that died, or read
+    // another launch's id): it runs on a helper thread, and a launch whose ranks do not meet within the limit fails here
+    // with a message instead of hanging (the helper is abandoned; the process is expected to exit on this error)
+    auto init = std::make_shared<std::promise<ncclResult_t>>();
+    std::future<ncclResult_t> done = init->get_future();
+    {
+        ncclComm_t* dst = &c->comm;
+        const int dev = ctx->device;
+        std::thread([a, dst, world, uid, rank, dev, init] {
+            (void)hipSetDevice(dev);
+            QuietStdout quiet;
+            init->set_value(a->CommInitRank(dst, world, uid, rank));
+        }).detach();
+    }
+    if (done.wait_for(std::chrono::duration<double>(limit_s)) != std::future_status::ready) {
+        // (c is leaked on purpose: the helper may still write c->comm)
+        return fail(ctx, FTK_ERR_IO, "rank %d of %d: the ranks did not meet in ncclCommInitRank within %.0f s (FTK_COMM_TIMEOUT_S); rendezvous %s",
+                    rank, world, limit_s, id_hex_or_path ? (looks_like_hex_id(id_hex_or_path) ? "by id" : id_hex_or_path) : "none");
+    }
+    const ncclResult_t r = done.get();
     if (r != ncclSuccess) {
         c->comm = nullptr;
         ftk_comm_destroy(c);

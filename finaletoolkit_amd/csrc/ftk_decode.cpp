@@ -4479,6 +4479,7 @@ int64_t ftk_cache_trim(void) {
     if (have_hip_device()) {
         n += device_cache().trim() + devset_pool().trim();
         (void)stream_pool().trim();
+        n += ftk::inflate_release_scratch();
     }
     return (int64_t)n;
 }

@@ -42,6 +42,8 @@ enum : unsigned {
 // zeroed beforehand (stream-ordered).  d_crc (may be NULL): CRC-32 of every block's data.  vector_matches: resolve a
 // window's matches on the lanes side by side instead of one after the other - pays for BAM records (few, far-apart
 // matches among literals: -5 %), not for fragment rows (+1..6 %): ftk_inflate.hip.
+// the lane-parallel loop's scratch (per device, ~370 MB) back to the device; bytes freed.  Only with no inflate launch in flight.
+size_t inflate_release_scratch();
 void inflate_launch(hipStream_t s, const uint8_t* d_comp, const InflateBlock* d_tab, int n_blocks, uint8_t* d_out,
                     InflateStatus* d_status, uint32_t* d_crc, bool vector_matches = false);
 

@@ -1616,24 +1616,53 @@ extern "C" int ftk_debug_inflate_ticks(unsigned long long* out, int n_blocks) {
 }
 #endif
 
-// Scratch of the lane-parallel symbol loop: kLaneSlots token regions and their busy words, one allocation per device,
-// made (and cleared) the first time a launch asks for it and kept for the process.
+// Scratch of the lane-parallel symbol loop: kLaneSlots token regions and their busy words (~370 MB), one allocation per
+// device, made (and cleared) the first time a launch asks for it.  A failed allocation is NOT remembered - that launch
+// takes the windowed loop and the next one asks again -, and inflate_release_scratch (ftk_cache_trim) gives the memory
+// back: several ranks that share a GPU, or a host that keeps the library loaded between jobs, need not hold it.
+namespace {
+std::mutex g_lane_mu;
+std::map<int, LaneScratch*> g_lane_have;
+}  // namespace
+
 static LaneScratch* lane_scratch_of_device() {
-    static std::mutex mu;
-    static std::map<int, LaneScratch*> have;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = have.find(dev);
-    if (it != have.end()) return it->second;
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    auto it = g_lane_have.find(dev);
+    if (it != g_lane_have.end()) return it->second;
     LaneScratch* p = nullptr;
     const size_t bytes = sizeof(unsigned) * kLaneSlots + sizeof(uint32_t) * kLaneSlots * kLaneSlotWords + 256;
-    if (hipMalloc((void**)&p, bytes) != hipSuccess || hipMemset(p, 0, sizeof(unsigned) * kLaneSlots) != hipSuccess) {
+    if (hipMalloc((void**)&p, bytes) != hipSuccess) {
         (void)hipGetLastError();
-        p = nullptr;
+        return nullptr;
     }
-    have[dev] = p;
+    if (hipMemset(p, 0, sizeof(unsigned) * kLaneSlots) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(p);
+        return nullptr;
+    }
+    g_lane_have[dev] = p;
     return p;
+}
+
+size_t inflate_release_scratch() {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    size_t freed = 0;
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (auto& kv : g_lane_have) {
+        if (!kv.second) continue;
+        if (hipSetDevice(kv.first) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {  // (no launch may still use it)
+            (void)hipGetLastError();
+            continue;
+        }
+        if (hipFree(kv.second) == hipSuccess) freed += sizeof(unsigned) * kLaneSlots + sizeof(uint32_t) * kLaneSlots * kLaneSlotWords + 256;
+        kv.second = nullptr;
+    }
+    for (auto it = g_lane_have.begin(); it != g_lane_have.end();) it = it->second ? std::next(it) : g_lane_have.erase(it);
+    if (have_cur) (void)hipSetDevice(cur);
+    return freed;
 }
 
 void inflate_launch(hipStream_t s, const uint8_t* d_comp, const InflateBlock* d_tab, int n_blocks, uint8_t* d_out,

@@ -46,23 +46,38 @@ def launch_ranks(cmd: Sequence[str], n: int, share_gpu: bool = False) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if share_gpu:
         env.setdefault("FTK_DIST_BACKEND", "gloo")
+    # The ranks of THIS launch meet in a file of their own: a fresh directory only this user can enter, and a nonce the
+    # file must carry - nothing a killed earlier launch left behind, and nothing another user put there, can be taken
+    # for it (ftk_comm_create; comm.id_file).
+    import secrets
+    import shutil
+    import tempfile
+    meet = None
+    if "FTK_COMM_ID_FILE" not in env:
+        meet = tempfile.mkdtemp(prefix="ftk_comm_")  # (mode 0700)
+        env["FTK_COMM_ID_FILE"] = os.path.join(meet, "id")
+    env.setdefault("FTK_COMM_NONCE", secrets.token_hex(16))
     procs = []
-    for r in range(n):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(0 if share_gpu else r))
-        procs.append(subprocess.Popen(list(cmd), env=e, stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
-    live = list(procs)
-    while live:
-        time.sleep(0.05)
-        for p in list(live):
-            if p.poll() is not None:
-                live.remove(p)
-                rc = rc or p.returncode
-        if rc:
-            for p in live:
-                p.kill()
-                p.wait()
-            break
+    try:
+        for r in range(n):
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(0 if share_gpu else r))
+            procs.append(subprocess.Popen(list(cmd), env=e, stdout=None if r == 0 else subprocess.DEVNULL))
+        live = list(procs)
+        while live:
+            time.sleep(0.05)
+            for p in list(live):
+                if p.poll() is not None:
+                    live.remove(p)
+                    rc = rc or p.returncode
+            if rc:
+                for p in live:
+                    p.kill()
+                    p.wait()
+                break
+    finally:
+        if meet:
+            shutil.rmtree(meet, ignore_errors=True)
     return rc
 
 

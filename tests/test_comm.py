@@ -40,12 +40,38 @@ print("ok")
 
 def test_rendezvous_file_name(monkeypatch, tmp_path):
     from finaletoolkit_amd import comm
-    monkeypatch.delenv("FTK_COMM_ID_FILE", raising=False)
+    for k in ("FTK_COMM_ID_FILE", "FTK_COMM_NONCE", "TORCHELASTIC_RUN_ID"):
+        monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("MASTER_PORT", "4711")
-    a = comm.id_file()
-    assert a.endswith(f"ftk_comm_{os.getppid()}_4711.id")
+    assert comm.id_file().endswith(f"ftk_comm_{os.getuid()}_{os.getppid()}_4711.id") and comm.job_nonce() == ""
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")  # torchrun's default says nothing about the launch
+    assert comm.id_file().endswith(f"ftk_comm_{os.getuid()}_{os.getppid()}_4711.id")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job 17/a")  # a launcher-given run id names the file, not the parent pid
+    assert comm.id_file().endswith(f"ftk_comm_{os.getuid()}_job_17_a_4711.id") and comm.job_nonce() == "job 17/a"
+    monkeypatch.setenv("FTK_COMM_NONCE", "abc")
+    assert comm.job_nonce() == "abc"
     monkeypatch.setenv("FTK_COMM_ID_FILE", str(tmp_path / "x.id"))
     assert comm.id_file() == str(tmp_path / "x.id")
+
+
+def test_launch_ranks_gives_every_launch_its_own_meeting_place(tmp_path):
+    """sharding.launch_ranks: a fresh directory only this user can enter, the file name and a nonce in the ranks'
+    environment; the directory is gone when the launch is over."""
+    from finaletoolkit_amd import sharding
+    out = tmp_path / "env"
+    code = ("import os, stat; p = os.environ['FTK_COMM_ID_FILE']; d = os.path.dirname(p); "
+            f"open(r'{out}' + os.environ['RANK'], 'w').write('|'.join([p, os.environ['FTK_COMM_NONCE'], oct(stat.S_IMODE(os.stat(d).st_mode))]))")
+    env = {k: os.environ.pop(k) for k in ("FTK_COMM_ID_FILE", "FTK_COMM_NONCE") if k in os.environ}
+    try:
+        assert sharding.launch_ranks([sys.executable, "-c", code], 2, share_gpu=True) == 0
+        a = open(str(out) + "0").read().split("|")
+        b = open(str(out) + "1").read().split("|")
+        assert sharding.launch_ranks([sys.executable, "-c", code], 2, share_gpu=True) == 0
+        c = open(str(out) + "0").read().split("|")
+    finally:
+        os.environ.update(env)
+    assert a == b and a[2] == "0o700" and len(a[1]) == 32 and not os.path.exists(os.path.dirname(a[0]))
+    assert c[0] != a[0] and c[1] != a[1]
 
 
 _WORKER = """
@@ -136,6 +162,74 @@ def test_rccl_communicator_through_the_c_abi_one_rank(tmp_path):
                 assert not os.path.exists(ident.decode())  # rank 0 takes the rendezvous file with it
         h = C.c_void_p()
         assert lib.ftk_comm_create(eng.ctx, 2, 2, hexid.value, C.byref(h)) == L.FTK_ERR_INVALID
+
+
+@pytest.mark.gpu
+def test_a_dead_jobs_rendezvous_file_is_not_joined(tmp_path, monkeypatch):
+    """A rank that is not rank 0 ignores a rendezvous file another launch left behind - one that is older than this
+    process, one that carries another launch's nonce, one that is a symbolic link - and says so after its time limit
+    instead of joining a communicator nobody else is in (ncclCommInitRank would wait for ever)."""
+    import subprocess
+    code = r'''
+import ctypes as C, os, sys, time
+sys.path.insert(0, os.environ["FTK_ROOT"])
+from finaletoolkit_amd import _lib as L
+from finaletoolkit_amd.engine import Engine
+lib = L.load()
+path, kind = sys.argv[1], sys.argv[2]
+hexid = C.create_string_buffer(257)
+assert lib.ftk_comm_unique_id(hexid) == L.FTK_OK
+body = hexid.value.decode() + "\n" + ("other-launch" if kind == "nonce" else os.environ.get("FTK_COMM_NONCE", ""))
+if kind == "link":
+    open(path + ".real", "w").write(body)
+    os.symlink(path + ".real", path)
+else:
+    open(path, "w").write(body)
+if kind == "old":
+    os.utime(path, (time.time() - 3600, time.time() - 3600))
+with Engine(0) as eng:
+    h = C.c_void_p()
+    t0 = time.time()
+    rc = lib.ftk_comm_create(eng.ctx, 1, 2, path.encode(), C.byref(h))
+    print(rc, round(time.time() - t0, 1), lib.ftk_last_error(eng.ctx).decode())
+'''
+    for kind in ("old", "nonce", "link"):
+        env = dict(os.environ, FTK_ROOT=ROOT, FTK_COMM_TIMEOUT_S="1.5", FTK_COMM_NONCE="this-launch")
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path / f"{kind}.id"), kind], env=env, capture_output=True, text=True, timeout=300)
+        rc, took, msg = r.stdout.strip().split(" ", 2)
+        assert r.returncode == 0 and int(rc) == -5 and 1.0 <= float(took) < 20 and "no communicator id of this launch" in msg, (kind, r.stdout, r.stderr[-500:])
+
+
+@pytest.mark.gpu
+def test_two_ranks_over_rccl_on_two_gpus(tmp_path):
+    """World 2 over RCCL proper (boxes with two GPUs; skipped on one): the rendezvous through launch_ranks' file, the
+    int64 collectives, send / recv and the payload gather of the sharded commands."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU: RCCL across ranks needs two")
+    from finaletoolkit_amd import sharding
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.environ["FTK_ROOT"])
+from finaletoolkit_amd import comm, sharding
+g = comm.join("rccl")
+r, w = g.rank, g.world
+rows = g.all_gather_i64(np.arange(6, dtype=np.int64) + 100 * r)
+assert rows.shape == (w, 6) and all(np.array_equal(rows[k], np.arange(6) + 100 * k) for k in range(w))
+assert int(g.all_reduce_sum_i64(np.array([r + 1]))[0]) == 3
+objs = g.all_gather_object({"rank": r, "blob": "x" * (1000 * (r + 1))})
+assert [o["rank"] for o in objs] == [0, 1]
+got = sharding.gather_payloads({k: bytes([k]) * (k + 1) for k in range(4) if k % 2 == r}, [0, 1, 0, 1])
+assert r != 0 or [bytes(x) for x in got] == [bytes([k]) * (k + 1) for k in range(4)]
+comm.leave()
+open(os.environ["FTK_OK_FILE"] + str(r), "w").write("ok")
+'''
+    os.environ["FTK_ROOT"], os.environ["FTK_OK_FILE"] = ROOT, str(tmp_path / "ok")
+    try:
+        assert sharding.launch_ranks([sys.executable, "-c", code], 2) == 0
+    finally:
+        os.environ.pop("FTK_OK_FILE", None)
+    assert all(os.path.exists(str(tmp_path / "ok") + str(r)) for r in (0, 1))
 
 
 @pytest.mark.gpu

@@ -39,8 +39,8 @@ def _inflate_once(engine, image: bytes):
 def _inflate(engine, image: bytes):
     """Every symbol loop of the kernel on the same image - the windowed loop with a window's matches copied one after
     the other (text streams) or resolved on the lanes side by side (BAM streams; ``FTK_INFLATE_VECTOR_MATCHES=1``), and
-    the lane-parallel loop small launches take (``FTK_INFLATE_LANES``; unset, the block count decides) - must agree;
-    the callers then hold the result against zlib."""
+    the lane-parallel loop, the default at every launch size (``FTK_INFLATE_LANES`` unset or non-zero; ``=0`` selects the
+    windowed loop) - must agree; the callers then hold the result against zlib."""
     import os
     names = ("FTK_INFLATE_VECTOR_MATCHES", "FTK_INFLATE_LANES")
     keep = {k: os.environ.get(k) for k in names}
