@@ -1224,15 +1224,11 @@ __device__ __forceinline__ void wps_block(const unsigned block_id, const unsigne
         if (tid < 4) fcnt[tid] = 0;
     }
     // The first tile's candidate bounds come from two threads (vector loads) through LDS, behind the barrier the clearing
-    // needs anyway.  Tried in round 5 (-DFTK_WPS_BOUNDS_SCALAR): every thread reading the two index entries itself at
-    // block-uniform addresses - scalar loads, no hand-over - 4.57-4.60 -> 4.73-4.81 ms per whole-genome step (0.846 ->
-    // 0.813 of peak): four waves' scalar loads per tile through the scalar cache, and their s_waitcnt also waits for the
-    // LDS writes of the clearing.
-#ifdef FTK_WPS_BOUNDS_SCALAR
-    int lo = cand_bound(cur, 0), hi = cand_bound(cur, 1);
-#else
+    // needs anyway.  Tried in round 5 (tools/experiments/wps_bounds_scalar.patch): every thread reading the two index
+    // entries itself at block-uniform addresses - scalar loads, no hand-over - 4.57-4.60 -> 4.73-4.81 ms per
+    // whole-genome step (0.846 -> 0.813 of peak): four waves' scalar loads per tile through the scalar cache, and their
+    // s_waitcnt also waits for the LDS writes of the clearing.
     if (tid < 2) rng_s[tid] = cand_bound(cur, tid);
-#endif
     if (tid == 2) { pre_s[0] = 0; pre_s[1] = 0; }
     {
         const int4 z = make_int4(0, 0, 0, 0);
@@ -1241,9 +1237,7 @@ __device__ __forceinline__ void wps_block(const unsigned block_id, const unsigne
         for (int j = 0; j < T / 4 / 256; ++j) d4[j * 256 + tid] = z;
     }
     __syncthreads();
-#ifndef FTK_WPS_BOUNDS_SCALAR
     int lo = rng_s[0], hi = rng_s[1];
-#endif
     int pfs[PF], pfe[PF], pfq[PF];
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
@@ -1471,11 +1465,7 @@ __device__ __forceinline__ void cleave_tile(const ContigView& cv, const CleavePa
 #pragma unroll
     for (int k = 0; k < PF; ++k) {
         const int i = lo + tid + 256 * k;
-#ifdef FTK_CLEAVE_NOFRAG  // (experiment: the loads stay, the LDS atomics go - wrong numbers)
-        if (i < hi && ps[k] == -7) apply(i, ps[k], pe[k], pq[k], pw[k]);
-#else
         if (i < hi) apply(i, ps[k], pe[k], pq[k], pw[k]);
-#endif
     }
     for (int i = lo + PF * 256 + tid; i < hi; i += 256) apply(i, cv.start[i], cv.end[i], cv.mapq[i], cv.strand[i]);
     __syncthreads();
@@ -1523,15 +1513,8 @@ __device__ __forceinline__ void cleave_tile(const ContigView& cv, const CleavePa
             const int g0 = carry + (h ? exb[j] : exa[j]) + v.x, g1 = g0 + v.y;
             const int i0 = j * 1024 + wv * 256 + h * 128 + 2 * lane;
             // numpy: ends / depth * 100 in float64, 0 where depth == 0 (frag/_cleavage_profile.py:208-210)
-#ifdef FTK_CLEAVE_NODIV  // (experiment: what the kernel would take without its divisions - wrong numbers)
-            const double o0 = (double)(ends.x * g0), o1 = (double)(ends.y * g1);
-#else
             const double o0 = g0 ? (double)ends.x / (double)g0 * 100.0 : 0.0;
             const double o1 = g1 ? (double)ends.y / (double)g1 * 100.0 : 0.0;
-#endif
-#ifdef FTK_CLEAVE_NOSTORE  // (experiment: everything but the stores - a result that cannot occur keeps the arithmetic alive)
-            if (o0 != -1.0) continue;
-#endif
             if (i0 + 1 < len_t) {
                 if (vec_ok) {
                     typedef double d2 __attribute__((ext_vector_type(2)));

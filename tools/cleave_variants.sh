@@ -1,6 +1,6 @@
 #!/bin/bash
 # cleavage_kernel in alternative builds of the library (finaletoolkit_amd/libftk_cv_*.so: ftk_kernels.hip compiled with
-# the FTK_CLEAVE_* switches of DESIGN 3.4) beside the shipped one: tools/kernel_rows.py's cleavage row (HIP events,
+# the FTK_CLEAVE_* switches of tools/experiments/kernel_experiment_switches.patch, built by tools/experiments/build_variant.sh) beside the shipped one: tools/kernel_rows.py's cleavage row (HIP events,
 # chr2-sized 30x contig).  usage (repo root on the GPU box): bash tools/cleave_variants.sh [variant names...]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 for v in hip "$@"; do
