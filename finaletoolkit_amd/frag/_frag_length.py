@@ -248,10 +248,12 @@ def frag_length_bins(input_file, contig: str | None = None, start: int | None = 
     return bins, counts
 
 
-def _result_rows(results: list, intervals, index, stats: np.ndarray) -> None:
+def _result_rows(results: list, intervals, index, stats: np.ndarray, lines: list | None = None) -> None:
     """``results[i] = FragLengthStats(...)`` for the intervals ``index`` from their statistics rows ``stats[k]`` =
     mean median stdev min max count n_short; an interval without a fragment: every statistic is the integer -1
-    (frag/_frag_length.py:202-238)."""
+    (frag/_frag_length.py:202-238).  ``lines[i]``, when asked for, is the interval's row of the output file (the
+    eleven fields, tab-separated, ``str()`` of each) - made here, contig by contig while the decoder works on the next
+    one, instead of in one go behind the last contig."""
     import gc
     total = stats[:, 5].astype(np.int64)
     frac = np.divide(stats[:, 6].astype(np.int64), total, out=np.zeros(len(total), np.float64), where=total > 0)  # int / int
@@ -262,8 +264,14 @@ def _result_rows(results: list, intervals, index, stats: np.ndarray) -> None:
     try:
         for i, mean, median, stdev, vmin, vmax, n, short in cols:
             c, a, b, name = intervals[i]
-            results[i] = (FragLengthStats(c, a, b, name, mean, median, stdev, vmin, vmax, n, short) if n else
-                          FragLengthStats(c, a, b, name, -1, -1, -1, -1, -1, -1, -1))
+            if n:
+                results[i] = FragLengthStats(c, a, b, name, mean, median, stdev, vmin, vmax, n, short)
+                if lines is not None:
+                    lines[i] = f"{c}\t{a}\t{b}\t{name}\t{mean}\t{median}\t{stdev}\t{vmin}\t{vmax}\t{n}\t{short}"
+            else:
+                results[i] = FragLengthStats(c, a, b, name, -1, -1, -1, -1, -1, -1, -1)
+                if lines is not None:
+                    lines[i] = f"{c}\t{a}\t{b}\t{name}\t-1\t-1\t-1\t-1\t-1\t-1\t-1"
     finally:
         if was:
             gc.enable()
@@ -288,6 +296,7 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
     intervals = get_intervals(interval_file)
     clock.lap("read_intervals")
     results: list = [None] * len(intervals)
+    lines = [None] * len(intervals) if output_file is not None and sharding.is_writer() else None
     # Pool(workers) of the reference (:571-593) = one rank per GPU: the intervals are cut into equal-cost runs over the
     # ranks (sharding.IntervalPlan: whole contigs, a region of the contig a cut falls into), a rank decodes and counts
     # only its share, and one all-gather of the seven statistics per interval (float64 bit patterns) gives every rank
@@ -343,7 +352,7 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
                     order = idx[np.argsort(iv_starts[idx], kind="stable")]
                     block = unit_stats(src.key(c), order)
                     clock.lap("histograms_and_statistics")
-                    _result_rows(results, intervals, order, block)  # (while the decoder is in the next contig)
+                    _result_rows(results, intervals, order, block, lines)  # (while the decoder is in the next contig)
                     clock.lap("result_rows")
             src = feed.finish()
         except BaseException:
@@ -369,12 +378,12 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
         stats = plan.gather(local, 7, np.float64)
         clock.lap("gather")
     if stats is not None:
-        _result_rows(results, intervals, np.arange(len(intervals)), stats)
+        _result_rows(results, intervals, np.arange(len(intervals)), stats, lines)
 
     clock.lap("result_rows")
     if output_file is not None:
         if sharding.is_writer():
-            writers.write_length_stats(output_file, results, short_reads)
+            writers.write_length_stats(output_file, results, short_reads, lines)
         else:
             writers.check_suffix(output_file, (".bed", ".bedgraph", ".bed.gz"), "The output file should have .bed or .bed.gz as as suffix.")
     clock.lap("write")

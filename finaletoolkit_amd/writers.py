@@ -235,11 +235,14 @@ def write_length_bins(output_file: str, bins, counts, bin_size: int, stats=None)
     _emit(output_file, "".join(rows), None, (".gz",), "")
 
 
-def write_length_stats(output_file: str, results, short_reads: int) -> None:
+def write_length_stats(output_file: str, results, short_reads: int, lines=None) -> None:
     """The per-interval statistics table of ``frag_length_intervals``: a header line, then the eleven fields of every
-    result, tab-separated, ``str()`` of each; ``.bed`` / ``.bedgraph`` / ``.bed.gz`` / ``-``."""
+    result, tab-separated, ``str()`` of each (``lines``: the rows already formatted, one per result); ``.bed`` /
+    ``.bedgraph`` / ``.bed.gz`` / ``-``."""
     message = "The output file should have .bed or .bed.gz as as suffix."
     check_suffix(output_file, (".bed", ".bedgraph", ".bed.gz"), message)
     head = f"contig\tstart\tstop\tname\tmean\tmedian\tstdev\tmin\tmax\tcount\ts{short_reads}\n"
-    body = "\n".join([f"{r[0]}\t{r[1]}\t{r[2]}\t{r[3]}\t{r[4]}\t{r[5]}\t{r[6]}\t{r[7]}\t{r[8]}\t{r[9]}\t{r[10]}" for r in results])
+    if lines is None or any(ln is None for ln in lines):
+        lines = [f"{r[0]}\t{r[1]}\t{r[2]}\t{r[3]}\t{r[4]}\t{r[5]}\t{r[6]}\t{r[7]}\t{r[8]}\t{r[9]}\t{r[10]}" for r in results]
+    body = "\n".join(lines)
     _emit(output_file, head + body + "\n", (".bed", ".bedgraph"), (".bed.gz",), message)

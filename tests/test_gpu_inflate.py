@@ -591,6 +591,45 @@ def test_bam_device_parser_hands_over_to_the_host_decoder(tmp_path):
     assert "'alt149', 'big1']" in r.stdout
 
 
+def test_bam_whose_compression_rises_behind_its_first_piece_stays_on_the_device(tmp_path):
+    """A large BAM is read in doubled pieces, sized for records that deflate 3-5 x.  A file whose later records deflate
+    far better can outgrow the text a piece may hold (4 GiB; FTK_TEST_PIECE_LIMIT shrinks that limit and applies the
+    doubling to a small file): the stream then starts over ON THE DEVICE with standard pieces - not on the host decoder -,
+    skips the contig it had handed out, and every contig arrives once with the whole-file decoder's rows."""
+    import gzip
+    import os
+    from tests.helpers import write_synthetic_bam
+    rng = np.random.default_rng(47)
+    contigs = [("first", 900_000), ("second", 3_000_000)]
+    frags = {}
+    for name, size in contigs:
+        n = size // 30
+        s = np.sort(rng.integers(0, size - 2_000, n))
+        frags[name] = (s, s + rng.integers(420, 900, n), rng.integers(0, 61, n), rng.integers(0, 2, n).astype(bool))
+    # two files with one header, spliced: short reads (names dominate: ~5 x) in front, long constant reads (~40 x) behind
+    a, b = str(tmp_path / "a.bam"), str(tmp_path / "b.bam")
+    write_synthetic_bam(a, contigs, {"first": frags["first"]}, read_len=30, junk=False)
+    write_synthetic_bam(b, contigs, {"second": frags["second"]}, read_len=400, junk=False)
+    ra, rb = gzip.open(a, "rb").read(), gzip.open(b, "rb").read()
+    head = 12 + int.from_bytes(ra[4:8], "little")
+    head += 4 + sum(8 + len(c) + 1 for c, _ in contigs)
+    assert ra[:head] == rb[:head]
+    from finaletoolkit_amd import bgzf
+    p = str(tmp_path / "rising.bam")
+    offs = bgzf.write_bgzf(p, ra + rb[head:], level=6)
+    bgzf.write_index(p + ".bai", True, [("first", bgzf.virtual_offset(offs, head), bgzf.virtual_offset(offs, len(ra))),
+                                        ("second", bgzf.virtual_offset(offs, len(ra)), bgzf.virtual_offset(offs, len(ra) + len(rb) - head))])
+    ratio_first = len(ra) / os.path.getsize(a)
+    ratio_second = (len(rb) - head) / max(os.path.getsize(p) - os.path.getsize(a), 1)
+    assert ratio_first < 14 and ratio_second > 1.6 * ratio_first, (ratio_first, ratio_second)
+    piece = 1 << 16
+    limit = int(1.5 * piece * ratio_second)  # a standard piece of the second contig fits, a doubled one does not
+    assert 2 * piece * ratio_first < limit
+    r = _multi_child(tmp_path, p, ("first", "second"), dict(FTK_STREAM_PIECE=str(piece), FTK_TEST_PIECE_LIMIT=str(limit)))
+    assert "the device path starts over with standard pieces" in r.stderr and "the host decoder takes over" not in r.stderr, r.stderr[-2000:]
+    assert "['first', 'second']" in r.stdout, r.stdout[-600:]
+
+
 def test_bam_device_parser_with_records_longer_than_a_stretch(tmp_path):
     """Long reads: records of 6-8 KB (read length 4 000) against stretches of 1 KB and 16 KB - most stretches hold no
     record start at all, the guesses land inside sequence bytes, and the chain still settles on the device."""
