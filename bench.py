@@ -1050,6 +1050,7 @@ def big_bam_leg(torch, tmp, threads, h2d, rates, reps: int = 3):
         t0 = time.perf_counter()
         exp = synth.write_paired_bam_native(path, contigs, 60.0, 4242)
         t_write = time.perf_counter() - t0
+        os.sync()  # (untimed: see genome_bam_leg)
         file_bytes = os.path.getsize(path)
         n_frag = sum(v["n"] for v in exp.values())
         n_win = sum(-(-n // WINDOW) for n in sizes.values())
@@ -1148,6 +1149,12 @@ def genome_bam_leg(torch, dev, threads, h2d, rates, records_per_s, reps: int = 3
         t0 = time.perf_counter()
         contigs, info = synth.write_genome_bam(path, scale, 60.0, torch, dev)
         t_write = time.perf_counter() - t0
+        # (untimed) the file's dirty pages go to the disk NOW: the first pass must not share the memory bus and the page
+        # cache's locks with the write-back of the tens of GB it is about to read - first_s is a reader's first call,
+        # not a writer's aftermath
+        t0 = time.perf_counter()
+        os.sync()
+        t_sync = time.perf_counter() - t0
         sizes = dict(contigs)
         names = [c for c, _ in contigs]
         file_bytes = os.path.getsize(path)
@@ -1220,7 +1227,7 @@ def genome_bam_leg(torch, dev, threads, h2d, rates, records_per_s, reps: int = 3
             ok, detail["error"] = False, f"{type(exc).__name__}: {exc}"
         leg["results_ok"] = bool(ok)
         return dict(scale=scale, full_genome=bool(scale >= 1.0), contigs=len(contigs), file_GB=round(file_bytes / 1e9, 2),
-                    scratch=base, fragments=n_frag, records=2 * n_frag, file_write_s=round(t_write, 1),
+                    scratch=base, fragments=n_frag, records=2 * n_frag, file_write_s=round(t_write, 1), file_sync_s=round(t_sync, 1),
                     writer_GB_per_s=round(file_bytes / t_write / 1e9, 2), decoder_threads=threads, **leg, checked=detail)
     except Exception as exc:  # noqa: BLE001 - the other legs must still be reported
         return {"error": f"{type(exc).__name__}: {exc}"}

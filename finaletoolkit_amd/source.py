@@ -548,7 +548,8 @@ def open_source(input_file, workers: int | None = None, warn_bed6: bool = True) 
     return src
 
 
-def resident_contigs(input_file, names, workers: int | None = None, stream_all: bool = True, warn_bed6: bool = True):
+def resident_contigs(input_file, names, workers: int | None = None, stream_all: bool = True, warn_bed6: bool = True,
+                     queued: int = 2):
     """Generator of ``(src, contig)`` over the contigs of ``names`` the file holds, each yielded as soon as it is
     resident in HBM -- the way in for whole-genome drivers (``frag.delfi``): the caller's kernels for contig k run
     while the decoder is already in contig k+1.  A file without a usable index is decoded in ONE streaming pass
@@ -589,7 +590,7 @@ def resident_contigs(input_file, names, workers: int | None = None, stream_all: 
                 yield src, c
         return
     warned = False
-    for src, c in stream_source(input_file, workers):
+    for src, c in stream_source(input_file, workers, queued):
         if src.bed6 and warn_bed6 and not warned:
             _warn_bed6()
             warned = True
@@ -603,11 +604,11 @@ class EarlyContigs:
     annotation, reference header - 17 ms of a 0.16 s whole-genome call).  Iterating joins the helper and carries on
     from the first contig; an error of the early part is raised there.  ``close()`` abandons it."""
 
-    def __init__(self, input_file, workers=None, stream_all=True, warn_bed6=True, names=None):
+    def __init__(self, input_file, workers=None, stream_all=True, warn_bed6=True, names=None, queued: int = 2):
         import threading
         # ``names``: the contigs the caller can want at all (its chrom.sizes) - a file with many more (decoys, alts) or
         # a caller that wants a few of them is then read through the index instead of being streamed whole
-        self._gen = resident_contigs(input_file, names, workers, stream_all, warn_bed6)
+        self._gen = resident_contigs(input_file, names, workers, stream_all, warn_bed6, queued)
         self._first, self._err, self._end = None, None, False
         self._thread = threading.Thread(target=self._run, name="ftk-early-decode", daemon=True)
         self._thread.start()
@@ -647,7 +648,9 @@ class ContigFeed:
     indexed file is then read through its index for those alone."""
 
     def __init__(self, input_file, workers=None, names=None, warn_bed6: bool = True):
-        self._early = EarlyContigs(input_file, workers, True, warn_bed6, names=names)
+        # (the decoder may run a whole genome's contigs ahead of a consumer that is busy with one contig's rows: the
+        #  finished tables wait in HBM, 10 B per fragment)
+        self._early = EarlyContigs(input_file, workers, True, warn_bed6, names=names, queued=32)
         self._it = None
         self.src: Optional[FragSource] = None
         self.seen: list = []

@@ -437,6 +437,50 @@ def test_two_ranks_on_a_bam_equal_one_process(bam_dataset):
         assert set(w0) | set(w1) | {r0[0][0]} == everything, (cmd, w0, w1, r0, r1)
 
 
+WORKER_EDGE = """
+import os, pickle, sys, warnings
+sys.path.insert(0, {root!r})
+warnings.simplefilter("ignore")
+from finaletoolkit_amd import frag, sharding
+rank, world = sharding.init_from_env()
+G = {gold!r}
+bam, iv = os.path.join(G, "edge.bam"), os.path.join(G, "edge_intervals.bed")
+out = dict(world=world)
+out["cov"] = [list(r) for r in frag.coverage(bam, iv, {tmp!r} + f"/e{{world}}_cov.bed")]
+out["cov_any"] = [list(r) for r in frag.coverage(bam, iv, None, intersect_policy="any", quality_threshold=0)]
+out["fli"] = [tuple(r) for r in frag.frag_length_intervals(bam, iv)]
+frag.multi_wps(bam, os.path.join(G, "edge_sites.bed"), None, {tmp!r} + f"/e{{world}}_wps.bed.gz", interval_size=2000)
+pickle.dump(out, open({tmp!r} + f"/edge_w{{world}}_r{{rank}}.pkl", "wb"))
+sharding.finalize()
+"""
+
+
+def test_two_ranks_on_the_multi_op_cigar_bam_give_the_reference_rows(tmp_path):
+    """The edge BAM of tests/golden (soft clips, I / D / N ops, CIGAR-less records, read1 poking out of its fragment ...)
+    under the rank fan-out: two ranks on GPU 0 return - and write - what the REFERENCE returned for it in BAM mode
+    (tests/golden/bam.json.gz, produced by the imported reference over oracle/bamstub.py), not merely what one process
+    of this package returns."""
+    import gzip
+    from tests.helpers import GOLDEN
+    from tests.test_oracle_golden_bam import bam_golden
+    G = bam_golden()["edge"]
+    A = np.load(os.path.join(GOLDEN, "bam.npz"))
+    d = tmp_path
+    (d / "worker_edge.py").write_text(WORKER_EDGE.format(root=ROOT, gold=GOLDEN, tmp=str(d)))
+    one = _run_world(d, 1, "worker_edge.py", "edge")[0]
+    two = _run_world(d, 2, "worker_edge.py", "edge")
+    for r in [one] + two:
+        assert r["cov"] == G["coverage_default"] and r["cov_any"] == G["coverage_any_q0"]
+        for got, want in zip(r["fli"], G["frag_length_intervals"], strict=True):
+            assert list(got[:4]) == list(want[:4]) and got[9] == want[9] and list(got[7:9]) == list(want[7:9])
+            assert got[4] == pytest.approx(want[4], rel=1e-12) and got[5] == want[5] and got[6] == pytest.approx(want[6], rel=1e-9)
+    assert open(d / "e1_cov.bed").read() == open(d / "e2_cov.bed").read()
+    for w in (1, 2):
+        rows = [ln.split("\t") for ln in gzip.open(d / f"e{w}_wps.bed.gz", "rt").read().splitlines()]
+        assert np.array_equal(np.array([int(x[1]) for x in rows]), A["edge_multi_wps_pos"])
+        assert np.array_equal(np.array([int(x[3]) for x in rows]), A["edge_multi_wps_val"])
+
+
 def test_bench_under_torch_distributed_run():
     """The driver's own launch form for N > 1 - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
     --gpus N` - with two ranks on GPU 0.  (Round 4 found it hanging on a shared box: LOCAL_RANK is the rank under that
