@@ -320,6 +320,23 @@ __device__ __forceinline__ int kmer_code(const MotifParams& M, int lo, bool revc
             if (M.nblk_end[m] <= lo) a = m + 1; else b = m;
         }
         if (a < M.n_nblk && M.nblk_start[a] < lo + M.k) return -1;
+        if (M.k <= 13) {
+            // bases lo .. lo + k - 1 lie in at most four consecutive bytes: ONE (unaligned) 4-byte load instead of a
+            // byte load per base (the image's block is at least 32 bytes longer than the image), the sixteen 2-bit
+            // groups translated at once, the k-mer cut out with a shift and a mask
+            typedef uint32_t __attribute__((aligned(1))) u32u;
+            const uint32_t be = __builtin_bswap32(*reinterpret_cast<const u32u*>(M.img + (lo >> 2)));  // first base on top
+            const uint32_t v1 = (be >> 1) & 0x55555555u, v0 = be & 0x55555555u;    // T=00 C=01 A=10 G=11
+            const uint32_t acgt = ((~(v1 ^ v0) & 0x55555555u) << 1) | (~v1 & 0x55555555u);  // -> A=00 C=01 G=10 T=11
+            const uint32_t mask = (1u << (2 * M.k)) - 1u;
+            uint32_t x = (acgt >> (32 - 2 * ((lo & 3) + M.k))) & mask;  // base 0 most significant
+            if (revcomp) {  // base j complemented at bits 2j: the 2-bit groups in reverse order, each XOR 3
+                uint32_t y = __brev(x) >> (32 - 2 * M.k);
+                y = ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u);
+                x = y ^ mask;
+            }
+            return (int)x;
+        }
         for (int j = 0; j < M.k; ++j) {
             const int p = lo + j;
             const int v = (M.img[p >> 2] >> (6 - 2 * (p & 3))) & 3;   // T=0 C=1 A=2 G=3
