@@ -600,7 +600,7 @@ def test_bam_whose_compression_rises_behind_its_first_piece_stays_on_the_device(
     import os
     from tests.helpers import write_synthetic_bam
     rng = np.random.default_rng(47)
-    contigs = [("first", 900_000), ("second", 3_000_000)]
+    contigs = [("first", 3_600_000), ("second", 4_000_000)]
     frags = {}
     for name, size in contigs:
         n = size // 30
@@ -622,9 +622,10 @@ def test_bam_whose_compression_rises_behind_its_first_piece_stays_on_the_device(
     ratio_first = len(ra) / os.path.getsize(a)
     ratio_second = (len(rb) - head) / max(os.path.getsize(p) - os.path.getsize(a), 1)
     assert ratio_first < 14 and ratio_second > 1.6 * ratio_first, (ratio_first, ratio_second)
-    piece = 1 << 16
-    limit = int(1.5 * piece * ratio_second)  # a standard piece of the second contig fits, a doubled one does not
-    assert 2 * piece * ratio_first < limit
+    piece = 1 << 20
+    room = 32 << 20  # (kRoom of the stream: a piece's text is held behind room for the carried record)
+    limit = room + int(1.5 * piece * ratio_second)  # a standard piece of the second contig fits, a doubled one does not
+    assert room + 2 * piece * ratio_first < limit and os.path.getsize(a) > 2.5 * piece and os.path.getsize(p) - os.path.getsize(a) > 3 * piece
     r = _multi_child(tmp_path, p, ("first", "second"), dict(FTK_STREAM_PIECE=str(piece), FTK_TEST_PIECE_LIMIT=str(limit)))
     assert "the device path starts over with standard pieces" in r.stderr and "the host decoder takes over" not in r.stderr, r.stderr[-2000:]
     assert "['first', 'second']" in r.stdout, r.stdout[-600:]

@@ -79,6 +79,46 @@ def test_window_counts_total_property(engine, data):
     assert got.sum() == int((data["q"] >= 30).sum())
 
 
+@pytest.mark.parametrize("kw", [dict(quality_threshold=30), dict(quality_threshold=0, min_length=120, max_length=180, intersect_policy="any"),
+                                dict(quality_threshold=60, max_length=150)])
+def test_fraglen_stats_on_the_device_equal_the_reference_formulas(engine, data, kw):
+    """ftk_fraglen_stats (window_stats_kernel: mean / median / stdev / min / max / count / short count from the
+    histogram rows on the device) against the oracle's statement of frag/_frag_length.py:156-172,202-238 on the C
+    oracle's histograms: tilings, tiny windows with one, two, three fragments (the odd-count median search), overlapping
+    and empty windows; on the tabix contig and on the BAM contigs (read1 fetch rule)."""
+    rng = np.random.default_rng(21)
+    flt = dict(mapq_min=kw.get("quality_threshold", 30), min_len=kw.get("min_length"), max_len=kw.get("max_length"),
+               policy=kw.get("intersect_policy", "midpoint"))
+    lo = max(kw.get("min_length") or 0, 0)
+    hi = min(kw.get("max_length") or 1000, 1000)
+    sets = _window_sets(rng)
+    a = np.arange(1_000_000, 1_024_000, 8, dtype=np.int32)
+    sets["tile8"] = (a, a + 8)  # under one fragment a window: single values, pairs, triples
+    for kind in KINDS:
+        for name, (ws, we) in sets.items():
+            if name == "tile400":
+                ws, we = ws[:1500], we[:1500]
+            hist, over = O.c_fraglen_hist(data["frs"][kind], ws, we, lo, hi - lo + 1, **flt)
+            assert not over.any()
+            got = engine.fraglen_stats(kind, ws, we, lo, hi - lo + 1, 150, **kw)
+            assert got.shape == (len(ws), 7)
+            n_small = 0
+            for k in range(len(ws)):
+                h = hist[k]
+                nz = np.nonzero(h)[0]
+                if len(nz) == 0:
+                    assert got[k, 5] == 0, (kind, name, k)
+                    continue
+                want = O.py_frag_length_stats({int(b) + lo: int(h[b]) for b in nz}, 150)
+                n_small += want[5] <= 3
+                assert got[k, 0] == want[0] and got[k, 1] == want[1], (kind, name, k, got[k], want)  # mean: one IEEE division of exact sums
+                assert got[k, 2] == pytest.approx(want[2], rel=1e-12, abs=1e-12)                       # stdev: summation order
+                assert (got[k, 3], got[k, 4], got[k, 5]) == (want[3], want[4], want[5])
+                assert got[k, 6] == round(want[6] * want[5])
+            if name == "tile8" and kw.get("intersect_policy", "midpoint") == "midpoint":
+                assert n_small > 20  # windows with one to three fragments: the single-value and odd-count medians
+
+
 @pytest.mark.parametrize("n_bins,len_lo", [(1001, 0), (64, 150), (3000, 0)])
 def test_fraglen_hist(engine, data, n_bins, len_lo):
     rng = np.random.default_rng(12)
