@@ -32,9 +32,11 @@ _BATCH_SCORES = 1 << 25
 def _read_intervals(interval_file, interval_size, median_window_size):
     """Centred intervals, merged where the median filter's trimmed ends would still overlap
     (frag/_adjust_wps.py:226-262)."""
-    left_of_site = round(-interval_size / 2)
-    right_of_site = round(interval_size / 2)
-    assert right_of_site - left_of_site == interval_size
+    # reach of an interval either side of its site's midpoint; Python's round() sends both halves of an odd size to the
+    # even neighbour, so an odd interval_size cannot be met - the reference asserts that (frag/_adjust_wps.py:219-221)
+    reach = (round(-interval_size / 2), round(interval_size / 2))
+    if reach[1] - reach[0] != interval_size:
+        raise AssertionError
     if not (interval_file.endswith(".bed") or interval_file.endswith(".bed.gz")):
         raise ValueError("Invalid filetype for interval_file.")
     end_decrease = median_window_size // 2
@@ -45,8 +47,8 @@ def _read_intervals(interval_file, interval_size, median_window_size):
             f = line.split("\t")
             contig = f[0].strip()
             mid = (int(f[1]) + int(f[2])) // 2
-            start = max(0, mid + int(left_of_site))
-            stop = mid + int(right_of_site)
+            start = max(0, mid + reach[0])
+            stop = mid + reach[1]
             if out and out[-1][0] == contig and out[-1][2] - end_decrease > start + end_decrease:
                 start = out[-1][1]
                 out.pop()
