@@ -113,7 +113,12 @@ def _fake_device(sizes):
             return c in self.contigs
 
         def require(self, c):
+            if c not in self.contigs:
+                raise ValueError(f"could not create iterator for region '{c}'")
             asked.append(c)
+            return c
+
+        def key(self, c):
             return c
 
         def require_interval(self, c, *a, **k):
@@ -166,6 +171,23 @@ def _product_worker(rank, world, port, d, q):
         assert sharding.init_from_env() == (rank, world)
     src, eng, Ref, asked = _fake_device(SIZES_P)
     Cv.open_source = lambda *a, **k: src
+
+    class Feed:  # source.ContigFeed over the stand-in: the one-process path of frag.coverage
+        def __init__(self, *a, names=None, **k):
+            self.names = list(src.contigs) if names is None else [c for c in names if src.has(c)]
+
+        def __iter__(self):
+            for c in self.names:
+                asked.append(c)
+                yield src, c
+
+        def finish(self):
+            return src
+
+        def close(self):
+            pass
+
+    Cv.ContigFeed = Feed
     Df.resident_contigs = lambda path, names, *a, **k: ((src, c) for c in names if src.has(c))
     Df.region_contig = lambda path, c, lo, hi, *a, **k: (src, src.require(c))  # (the whole contig: a superset of the region)
     for mod in (Cv, Df):
