@@ -585,6 +585,8 @@ def rep_summary(runs):
     out.update(first_s=round(times[0], 4), median_s=round(float(np.median(times)), 4), best_s=round(min(times), 4),
                repetitions=len(times), all_s=[round(t, 4) for t in times],
                results_ok=bool(all(r.get("results_ok", True) for r in runs)))
+    if runs[0].get("decoder_producer_stage_ms"):  # what the FIRST repetition's producer spent where (a file's first read ...)
+        out["first_repetition_producer_stage_ms"] = runs[0]["decoder_producer_stage_ms"]
     if os.environ.get("FTK_BENCH_REP_STAGES") == "1":  # debugging aid: every repetition's stage split, not only the best one's
         out["all_runs"] = [dict(r) for r in runs]
     return out
@@ -1144,6 +1146,17 @@ def genome_bam_leg(torch, dev, threads, h2d, rates, records_per_s, reps: int = 3
     try:
         base = synth.big_scratch_dir(synth.genome_bam_bytes())
         d = tempfile.mkdtemp(prefix="ftk_wgbam_", dir=base)
+        # How much of the genome the box can take: its scratch space, and two minutes of THIS writer on THIS box - measured
+        # on a 2 % genome first (a second of writing; the three-contig leg's rate comes from another writer path and
+        # undersold this one threefold, which kept the file at 0.66 of the genome on boxes that hold all of it).
+        if not os.environ.get("FTK_WG_BAM_SCALE"):
+            probe = os.path.join(d, "probe.bam")
+            t0 = time.perf_counter()
+            _, pinfo = synth.write_genome_bam(probe, 0.02, 60.0, torch, dev)
+            records_per_s = 2 * sum(v["n"] for v in pinfo.values()) / (time.perf_counter() - t0)
+            for q in (probe, probe + ".bai"):
+                if os.path.exists(q):
+                    os.remove(q)
         scale = synth.genome_bam_scale(d, records_per_s=records_per_s, write_budget_s=120.0)
         path = os.path.join(d, "genome60x.bam")
         t0 = time.perf_counter()
