@@ -307,6 +307,10 @@ struct DelfiPred {
     }
 };
 
+// CH of the window-feature kernels: 0 no coverage filter, 1 coverage / histogram, 2 motif pass (any image, any k),
+// kMotifWord the motif pass on a 2bit image with k <= 13.
+constexpr int kMotifWord = 3;
+
 // k-mer starting at base `lo` of the reference image as a base-4 number in ACGT order
 // (gen_kmers order, utils/utils.py:388-410), or -1 when it holds anything but A/C/G/T
 // (upper- or lower-case: io/reference.py:171 upper-cases).  revcomp: the reverse complement's code.
@@ -362,6 +366,74 @@ __device__ __forceinline__ int kmer_code(const MotifParams& M, int lo, bool revc
     return code;
 }
 
+// ---- the motif pass with its reference loads batched ---------------------------------------------------------
+// A fragment of the motif pass costs two gathers from the reference image.  Done one element at a time (test, N-block
+// search, load, atomic) every element is a chain of dependent loads and the pass is bound by their latency (162 us for
+// the 24 M fragments of a chr2-sized contig, 16 elements per thread in a row).  Here the N elements a thread holds are
+// tested first, ALL their 2 N words requested (an element that contributes nothing loads word 0), and only then turned
+// into codes and LDS atomics.  The N-block search is cut down per window: [o0, o1) are the blocks within reach of the
+// window's fragments (motif_window), none at all for most windows.
+
+// Positions a fetched fragment's k-mers can start at: (g_lo, g_hi).  fs < we, fe > ws, fe - fs <= max_len.
+__device__ __forceinline__ void motif_reach(const MotifParams& M, const ContigView& cv, int ws, int we, int& g_lo, int& g_hi) {
+    const long long r = (long long)cv.max_len + abs(M.f_off) + abs(M.r_off) + 1;
+    const long long lo = (long long)ws - r, hi = (long long)we + r + M.k;
+    g_lo = (int)max(lo, (long long)INT32_MIN / 2);
+    g_hi = (int)min(hi, (long long)INT32_MAX / 2);
+}
+
+// N blocks [o0, o1) that a k-mer starting inside the window's reach can touch.  The blocks are sorted and disjoint:
+// o0 = blocks ending at or before g_lo, o1 = blocks starting before g_hi, counted 64 at a time by the wave.
+__device__ __forceinline__ void motif_window(const MotifParams& M, const ContigView& cv, int ws, int we, int& o0, int& o1) {
+    o0 = o1 = 0;
+    if (M.kind != FTK_REF_2BIT || M.n_nblk == 0) return;
+    int g_lo, g_hi;
+    motif_reach(M, cv, ws, we, g_lo, g_hi);
+    const int lane = threadIdx.x & 63;
+    for (int b = 0; b < M.n_nblk; b += 64) {
+        const bool in = b + lane < M.n_nblk;
+        const int e = in ? M.nblk_end[b + lane] : INT32_MAX, st = in ? M.nblk_start[b + lane] : INT32_MAX;
+        o0 += __popcll(__ballot(e <= g_lo));
+        o1 += __popcll(__ballot(st < g_hi));
+    }
+}
+
+// does the k-mer at p touch an N block?  (p outside the window's reach -- a BAM read1 poking out of its fragment is
+// the one way there -- searches every block)
+__device__ __attribute__((noinline)) bool motif_n_search(const int32_t* nblk_start, const int32_t* nblk_end, int n_nblk,
+                                                         int k, int p, int a, int b) {
+    while (a < b) {  // first block ending after p
+        const int m = (a + b) >> 1;
+        if (nblk_end[m] <= p) a = m + 1; else b = m;
+    }
+    return a < n_nblk && nblk_start[a] < p + k;
+}
+__device__ __forceinline__ bool motif_has_n(const MotifParams& M, int p, int o0, int o1, int g_lo, int g_hi) {
+    int a = o0, b = o1;
+    if (p <= g_lo || p + M.k >= g_hi) { a = 0; b = M.n_nblk; }
+    if (a >= b) return false;  // nearly always
+    return motif_n_search(M.nblk_start, M.nblk_end, M.n_nblk, M.k, p, a, b);
+}
+
+// The k-mer (k <= 13) at base p cut out of the four bytes that hold it, as a base-4 number in the 2bit format's OWN
+// digit order (T C A G); revcomp: the reverse complement's (T<->A, C<->G is XOR 10b per digit; a bit reversal turns the
+// digits around and swaps the two bits of each, put back by the pair swap).  The histogram in LDS is kept in this
+// order and its bins are renamed to A C G T order (gen_kmers, utils/utils.py:388-410) when it is written out
+// (motif_bin): 4^k translations per window and block instead of one per fragment end.
+__device__ __forceinline__ int kmer_from_word(uint32_t w, int p, int k, bool revcomp) {
+    const uint32_t be = __builtin_bswap32(w);  // first base on top
+    if (!revcomp) return (int)__builtin_amdgcn_ubfe(be, 32 - 2 * ((p & 3) + k), 2 * k);
+    // the field of the bit-reversed word: digits in reverse order, the two bits of each swapped
+    uint32_t y = __builtin_amdgcn_ubfe(__brev(be), 2 * (p & 3), 2 * k);
+    y = ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u);
+    return (int)(y ^ (0xAAAAAAAAu & ((1u << (2 * k)) - 1u)));
+}
+// bin b of a T C A G ordered histogram -> its place in A C G T order (digit by digit: T=00 C=01 A=10 G=11 -> 11 01 00 10)
+__device__ __forceinline__ int motif_bin(int b, int n_bins) {
+    const uint32_t v1 = ((uint32_t)b >> 1) & 0x55555555u, v0 = (uint32_t)b & 0x55555555u;
+    return (int)((((~(v1 ^ v0) & 0x55555555u) << 1) | (~v1 & 0x55555555u)) & (uint32_t)(n_bins - 1));
+}
+
 // What one window-feature launch computes (any combination, ONE pass over the fragments):
 //   coverage count + length histogram under `wp`  (frag/_coverage.py:117-130, _frag_length.py:147-153)
 //   DELFI short / long under `dp`                   (frag/_delfi.py:443-472)
@@ -383,7 +455,7 @@ struct FeatParams {
 };
 
 // cov / sh / lg count REJECTED elements for CH == 1 / DF (passing = processed - rejected) and passing ones
-// for CH == 2; over: motif errors (CH == 2; the length histogram keeps its overflow in an extra LDS bin).
+// for CH >= 2; over: motif errors (CH == 2; the length histogram keeps its overflow in an extra LDS bin).
 struct FeatAcc {
     int n = 0, cov = 0, over = 0, sh = 0, lg = 0;
 };
@@ -438,7 +510,7 @@ __device__ __forceinline__ void feat_element(const ContigView& cv, const FeatPar
         }
         a.n += 1;
     }
-    if (CH == 2) {
+    if (CH >= 2) {
         // frag/_end_motifs.py:118-176, frag/_breakpoint_motifs.py:124-185: every fetched fragment
         // (index overlap + mapq only) contributes the k-mer at its start and / or the reverse
         // complement of the k-mer at its stop.  ws / we1 are the raw window bounds here.
@@ -472,6 +544,128 @@ __device__ __forceinline__ void feat_element(const ContigView& cv, const FeatPar
     }
 }
 
+// Every condition below is a difference whose SIGN says "fails", OR-ed together like feat_element's: sixteen elements'
+// worth of bool flags live as 64-bit lane masks in SGPRs, spill to VGPR lanes, and the pass turns issue-bound on the
+// readlane / mask traffic (134 VALU + 79 SALU instructions per fragment in the first form of this function).
+// ws / we1 are the CLAMPED bounds (window_bounds<1>); the filter is the motif pass' own (policy ANY, no length
+// bounds: ftk_motif_counts), so the window test is overlap + mapq (+ read1 overlap for a BAM fetch).
+template <bool BAM, int N>
+__device__ __forceinline__ void motif_prep(const ContigView& cv, const FeatParams& P, const int (&idx)[N],
+                                           const int (&fs)[N], const int (&fe)[N], const int (&q)[N], int hi, int ws,
+                                           int we1, int (&pf)[N], int (&pr)[N], uint32_t (&cf)[N], uint32_t (&cr)[N],
+                                           uint32_t (&wf)[N], uint32_t (&wr)[N], FeatAcc& a, int& n_ok) {
+    const MotifParams& M = P.mp;
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+    const int u_rev = (M.both || M.neg) ? 0 : -1;   // the stop's k-mer is wanted at all
+    const int last = M.chrom_len - M.k;              // last base a k-mer may start at
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        int x = (q[j] - P.ch_q) | (fe[j] - 1 - ws) | (we1 - fs[j]) | (hi - 1 - idx[j]);
+        if (BAM) x |= (we1 - cv.r1_start[min(idx[j], hi - 1)]) | (cv.r1_end[min(idx[j], hi - 1)] - 1 - ws);
+        n_ok += __popcll(__ballot(x >= 0));  // (scalar unit) fetched fragments of the wave
+        if (M.guard > 0) x |= (fs[j] - M.guard) | (M.chrom_len - 1 - M.guard - fs[j]);
+        int u_fwd = M.both ? 0 : -1;
+        if (!M.both && !M.neg) u_fwd = cv.strand[min(idx[j], hi - 1)] != 0 ? 0 : -1;
+        pf[j] = fs[j] + M.f_off;  // where the two k-mers start
+        pr[j] = fe[j] + M.r_off;
+        const int f_out = pf[j] | (last - pf[j]), r_out = pr[j] | (last - pr[j]);
+        const int no_f = x | u_fwd | f_out;
+        x |= ~u_fwd & f_out;  // the reference's `continue` on a start outside the contig also drops the other end
+        const int no_r = x | u_rev | r_out;
+        if (M.rev_err) a.over += (unsigned)(~(x | u_rev) & r_out) >> 31;
+        cf[j] = (uint32_t)~no_f >> 31;  // what the end adds to its bin: 1, or 0 when it contributes nothing
+        cr[j] = (uint32_t)~no_r >> 31;
+        wf[j] = *reinterpret_cast<const u32u*>(M.img + (min((unsigned)pf[j], (unsigned)max(last, 0)) >> 2));
+        wr[j] = *reinterpret_cast<const u32u*>(M.img + (min((unsigned)pr[j], (unsigned)max(last, 0)) >> 2));
+    }
+}
+
+template <bool BAM, int N>
+__device__ __forceinline__ void motif_commit(const ContigView& cv, const FeatParams& P, int ws, int we1, int o0, int o1,
+                                             const int (&pf)[N], const int (&pr)[N], const uint32_t (&cf)[N],
+                                             const uint32_t (&cr)[N], const uint32_t (&wf)[N], const uint32_t (&wr)[N],
+                                             uint32_t* h) {
+    const MotifParams& M = P.mp;
+    int g_lo = 0, g_hi = 0;
+    const bool n_near = o1 > o0;  // (uniform) N blocks within the window's reach
+    if (M.n_nblk && (BAM || n_near)) motif_reach(M, cv, ws, we1 + 1, g_lo, g_hi);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        // tabix fetch: every k-mer lies within reach, so a window without N blocks nearby never searches;
+        // an end that contributes nothing adds 0 to whatever bin its word names -- no branch
+        uint32_t f = cf[j], r = cr[j];
+        if (M.n_nblk && (BAM || n_near)) {
+            if (f && motif_has_n(M, pf[j], o0, o1, g_lo, g_hi)) f = 0;
+            if (r && motif_has_n(M, pr[j], o0, o1, g_lo, g_hi)) r = 0;
+        }
+        atomicAdd(&h[kmer_from_word(wf[j], pf[j], M.k, false)], f);
+        atomicAdd(&h[kmer_from_word(wr[j], pr[j], M.k, true)], r);
+    }
+}
+
+template <bool BAM, int N>
+__device__ __forceinline__ void motif_elements(const ContigView& cv, const FeatParams& P, const int (&idx)[N],
+                                               const int (&fs)[N], const int (&fe)[N], const int (&q)[N], int hi,
+                                               int ws, int we1, int o0, int o1, uint32_t* h, FeatAcc& a) {
+    int pf[N], pr[N], n_ok = 0;
+    uint32_t cf[N], cr[N], wf[N], wr[N];
+    motif_prep<BAM, N>(cv, P, idx, fs, fe, q, hi, ws, we1, pf, pr, cf, cr, wf, wr, a, n_ok);
+    motif_commit<BAM, N>(cv, P, ws, we1, o0, o1, pf, pr, cf, cr, wf, wr, h);
+    if ((threadIdx.x & 63) == 0) a.cov += n_ok;
+}
+
+// The fragments [lo, hi) of one window as a software pipeline, kBS threads: kMotifAhead slabs (4 fragments per thread
+// each) of columns are in flight; a slab that has arrived is tested and its reference words requested, its column
+// registers are re-filled with the slab kMotifAhead further on, and only then is the PREVIOUS slab's histogram work
+// done -- so a wave always has column loads and gathers outstanding while it computes.
+constexpr int kMotifAhead = 4;
+template <int kBS, bool BAM>
+__device__ __forceinline__ void motif_stream(const ContigView& cv, const FeatParams& P, int lo, int hi, int tid, int ws,
+                                             int we1, int o0, int o1, uint32_t* h, FeatAcc& a) {
+    constexpr int D = kMotifAhead, kSlab = 4 * kBS;
+    if (lo >= hi) return;  // (uniform)
+    int4 s4[D], e4[D];
+    uchar4 q4[D];
+    const int i0 = lo + 4 * tid;
+    // Loads are never conditional: a group past the end reads the range's last group again (its elements fail the
+    // idx < hi test).  A load under `if (i < hi)` makes the compiler merge old and new registers right behind it --
+    // with an s_waitcnt on the load it has just issued, which is the end of any prefetch.
+    const int last_group = (hi - 1) & ~3;  // lo is a multiple of 4 and hi > lo
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        const int i = min(i0 + u * kSlab, last_group);
+        s4[u] = *reinterpret_cast<const int4*>(cv.start + i);
+        e4[u] = *reinterpret_cast<const int4*>(cv.end + i);
+        q4[u] = *reinterpret_cast<const uchar4*>(cv.mapq + i);
+    }
+    int pf0[4] = {0, 0, 0, 0}, pr0[4] = {0, 0, 0, 0}, n_ok = 0;  // the slab whose words are on their way
+    uint32_t cf0[4] = {0, 0, 0, 0}, cr0[4] = {0, 0, 0, 0}, wf0[4] = {0, 0, 0, 0}, wr0[4] = {0, 0, 0, 0};
+    for (int slab = lo; slab < hi; slab += D * kSlab) {  // (uniform)
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            if (slab + u * kSlab >= hi) break;           // (uniform)
+            const int i = slab + 4 * tid + u * kSlab;
+            const int ii[4] = {i, i + 1, i + 2, i + 3};
+            const int ss[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w}, ee[4] = {e4[u].x, e4[u].y, e4[u].z, e4[u].w};
+            const int qq[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
+            int pf[4], pr[4];
+            uint32_t cf[4], cr[4], wf[4], wr[4];
+            motif_prep<BAM, 4>(cv, P, ii, ss, ee, qq, hi, ws, we1, pf, pr, cf, cr, wf, wr, a, n_ok);
+            const int nxt = min(i + D * kSlab, last_group);
+            s4[u] = *reinterpret_cast<const int4*>(cv.start + nxt);
+            e4[u] = *reinterpret_cast<const int4*>(cv.end + nxt);
+            q4[u] = *reinterpret_cast<const uchar4*>(cv.mapq + nxt);
+            motif_commit<BAM, 4>(cv, P, ws, we1, o0, o1, pf0, pr0, cf0, cr0, wf0, wr0, h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pf0[j] = pf[j]; pr0[j] = pr[j]; cf0[j] = cf[j]; cr0[j] = cr[j]; wf0[j] = wf[j]; wr0[j] = wr[j];
+            }
+        }
+    }
+    motif_commit<BAM, 4>(cv, P, ws, we1, o0, o1, pf0, pr0, cf0, cr0, wf0, wr0, h);
+    if ((tid & 63) == 0) a.cov += n_ok;
+}
+
 // Window bounds as the element tests want them.
 template <int CH>
 __device__ __forceinline__ void window_bounds(int ws_raw, int we_raw, int& ws, int& we1) {
@@ -488,6 +682,11 @@ __device__ __forceinline__ void feat_group(const ContigView& cv, const FeatParam
                                            const int4& e, const uchar4& q, int ws, int we1, int o0, int o1,
                                            uint32_t* h, FeatAcc& a) {
     const int ss[4] = {s.x, s.y, s.z, s.w}, ee[4] = {e.x, e.y, e.z, e.w}, qq[4] = {q.x, q.y, q.z, q.w};
+    if (CH == kMotifWord) {  // o0 / o1: the window's N blocks
+        const int ii[4] = {i, i + 1, i + 2, i + 3};
+        motif_elements<BAM, 4>(cv, P, ii, ss, ee, qq, hi, ws, we1, o0, o1, h, a);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         feat_element<CH, DF, BAM, BL>(cv, P, i + j, ss[j], ee[j], qq[j], ws, we1, o0, o1, h, a, i + j < hi);
@@ -526,6 +725,7 @@ __global__ __launch_bounds__(256) void feat_small_kernel(ContigView cv, const in
     }
     int o0 = 0, o1 = 0;
     if (DF && P.dp.bl_off) { o0 = P.dp.bl_off[w]; o1 = P.dp.bl_off[w + 1]; }
+    if (CH == kMotifWord) motif_window(P.mp, cv, ws, we1 + 1, o0, o1);
     FeatAcc a;
     for (int i = lo + 4 * lane; i < hi; i += 256) {  // lo is a multiple of 4 (planner)
         const int4 s = *reinterpret_cast<const int4*>(cv.start + i);
@@ -539,7 +739,7 @@ __global__ __launch_bounds__(256) void feat_small_kernel(ContigView cv, const in
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint32_t* dst = P.hist_out + (size_t)w * P.n_bins;
-        for (int b = lane; b < P.n_bins; b += 64) dst[b] = h[b];  // full row: no pre-fill needed
+        for (int b = lane; b < P.n_bins; b += 64) dst[CH == kMotifWord ? motif_bin(b, P.n_bins) : b] = h[b];  // full row: no pre-fill needed
         if (CH == 1) over = (int)h[P.n_bins];
     } else if (hist) {
         uint32_t* dst = P.hist_out + (size_t)w * P.n_bins;
@@ -547,7 +747,7 @@ __global__ __launch_bounds__(256) void feat_small_kernel(ContigView cv, const in
     }
     a.n = wave_reduce_add(a.n);
     a.cov = wave_reduce_add(a.cov);
-    if (CH == 2) over = wave_reduce_add(a.over);
+    if (CH >= 2) over = wave_reduce_add(a.over);
     a.sh = wave_reduce_add(a.sh);
     a.lg = wave_reduce_add(a.lg);
     if (lane == 0) {
@@ -603,10 +803,16 @@ __global__ __launch_bounds__(256) void feat_large_kernel(ContigView cv, const in
     }
     int w;
     {
-        int lo = 0, hi = n_win;  // largest w with chunk_off[w] <= c0
+        // largest w with chunk_off[w] <= c0, 64 probes per step (each wave for itself): two or three dependent loads
+        // where a bisection needs log2(n_win) -- a block that walks one or two chunks spent longer finding its window
+        // than on its fragments
+        int lo = 0, hi = n_win;  // chunk_off[lo] <= c0 < chunk_off[hi]
         while (hi - lo > 1) {
-            const int m = (lo + hi) >> 1;
-            if (chunk_off[m] <= c0) lo = m; else hi = m;
+            const int step = (hi - lo + 63) >> 6;
+            const int at = lo + (lane + 1) * step;
+            const bool le = at < hi && chunk_off[at] <= c0;  // true for a prefix of the lanes (chunk_off ascends)
+            lo += __popcll(__ballot(le)) * step;
+            hi = min(hi, lo + step);
         }
         w = lo;
     }
@@ -620,7 +826,14 @@ __global__ __launch_bounds__(256) void feat_large_kernel(ContigView cv, const in
         const int wlo = cand_lo[w], whi = cand_hi[w];
         int o0 = 0, o1 = 0;
         if (DF && P.dp.bl_off) { o0 = P.dp.bl_off[w]; o1 = P.dp.bl_off[w + 1]; }
+        if (CH == kMotifWord) motif_window(P.mp, cv, ws, we1 + 1, o0, o1);
         const uint32_t c_end = min(c1, w_next);
+        if (CH == kMotifWord) {  // this block's chunks of the window as one stream
+            const int lo = wlo + (int)(c - w_first) * kChunk;  // multiple of 4 (planner)
+            const int hi = (int)min((long long)wlo + (long long)(c_end - w_first) * kChunk, (long long)whi);
+            motif_stream<256, BAM>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
+            c = c_end;
+        } else
         for (; c < c_end; ++c) {
             const int lo = wlo + (int)(c - w_first) * kChunk;  // multiple of 4 (planner)
             const int hi = min(lo + kChunk, whi);
@@ -633,7 +846,7 @@ __global__ __launch_bounds__(256) void feat_large_kernel(ContigView cv, const in
             uint32_t* dst = P.hist_out + (size_t)w * P.n_bins;
             for (int b = tid; b < P.n_bins; b += 256) {
                 const uint32_t v = lds_hist[b];
-                if (v) { atomicAdd(&dst[b], v); lds_hist[b] = 0; }
+                if (v) { atomicAdd(&dst[CH == kMotifWord ? motif_bin(b, P.n_bins) : b], v); lds_hist[b] = 0; }
             }
         }
         a.n = wave_reduce_add(a.n);
@@ -721,12 +934,14 @@ __device__ __forceinline__ void feat_block_body(const ContigView& cv, int ws_raw
     int ws, we1;
     window_bounds<CH>(ws_raw, we_raw, ws, we1);
     FeatAcc a;
-    if (DF && o1 > o0) feat_stream<kFeatBS, CH, DF, BAM, true>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
+    if (CH == kMotifWord) motif_window(P.mp, cv, ws, we1 + 1, o0, o1);
+    if (CH == kMotifWord) motif_stream<kFeatBS, BAM>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
+    else if (DF && o1 > o0) feat_stream<kFeatBS, CH, DF, BAM, true>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
     else feat_stream<kFeatBS, CH, DF, BAM, false>(cv, P, lo, hi, tid, ws, we1, o0, o1, lds_hist, a);
     if (hist) {
         __syncthreads();
         uint32_t* dst = P.hist_out + row * P.n_bins;
-        for (int b = tid; b < P.n_bins; b += kFeatBS) dst[b] = lds_hist[b];
+        for (int b = tid; b < P.n_bins; b += kFeatBS) dst[CH == kMotifWord ? motif_bin(b, P.n_bins) : b] = lds_hist[b];
     }
     a.n = wave_reduce_add(a.n);
     a.cov = wave_reduce_add(a.cov);
@@ -1883,7 +2098,7 @@ static bool launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, c
                           int n_win, const WindowPlan& pl, const FeatParams& P, bool small_path, int block_lmax,
                           int block_threads, const WpsTail* tail) {
     const size_t lds1 = (CH && P.do_hist) ? (size_t)(P.n_bins + 1) * sizeof(uint32_t) : 0;  // + overflow bin
-    if (tail && tail->n_tiles > 0 && block_lmax >= 0 && CH != 2 && feat_fast_ok(P, CH != 0, DF) &&
+    if (tail && tail->n_tiles > 0 && block_lmax >= 0 && CH < 2 && feat_fast_ok(P, CH != 0, DF) &&
         (long long)n_win + tail->n_tiles < (1LL << 31)) {
         // the merged launch: feature blocks first, the WPS tiles behind them (feat_then_wps_kernel)
         FeatParams Pf = P;
@@ -1897,7 +2112,7 @@ static bool launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, c
 #undef FTK_MERGED
         return true;
     }
-    if (block_lmax >= 0 && CH != 2 && feat_fast_ok(P, CH != 0, DF)) {
+    if (block_lmax >= 0 && CH < 2 && feat_fast_ok(P, CH != 0, DF)) {
 #define FTK_FAST(BS)                                                                                                \
     do {                                                                                                            \
         if (CH && P.do_hist)                                                                                        \
@@ -1926,7 +2141,10 @@ static bool launch_feat_t(hipStream_t s, int grid_large, const ContigView& cv, c
     if (small_path)
         hipLaunchKernelGGL((feat_small_kernel<CH, DF, BAM>), dim3((n_win + 3) / 4), dim3(256), 4 * lds1, s, cv, ws, we,
                            n_win, pl.cand_lo, pl.cand_hi, pl.nchunks, P);
-    hipLaunchKernelGGL((feat_large_kernel<CH, DF, BAM>), dim3(grid_large), dim3(256), lds1, s, cv, ws, we, n_win,
+    // the motif stream keeps four waves per SIMD busy with a quarter of the blocks: fewer window searches and
+    // histogram flushes per fragment (110 -> 101 us for a chr2-sized contig in 1 Mb windows; 16 / 6 per CU: 103 / 112)
+    const int grid = CH == kMotifWord ? std::max(grid_large / 4, 1) : grid_large;
+    hipLaunchKernelGGL((feat_large_kernel<CH, DF, BAM>), dim3(grid), dim3(256), lds1, s, cv, ws, we, n_win,
                        pl.cand_lo, pl.cand_hi, pl.chunk_off, P);
     return false;
 }
@@ -1976,7 +2194,10 @@ bool launch_window_features(hipStream_t s, int grid_large, const ContigView& cv,
     if (r.motif) {
         P.mp = *r.motif;
         P.do_hist = 1;
-        FTK_FEAT(2, false);
+        // a 2bit image and k <= 13: the k-mer is cut out of one 4-byte load (its own instantiation: the general form's
+        // loops, unrolled with the window kernels, do not fit the instruction cache beside it)
+        if (P.mp.kind == FTK_REF_2BIT && P.mp.k <= 13 && P.is_any && P.ch_min <= 0 && P.ch_max >= (1 << 30)) FTK_FEAT(kMotifWord, false);
+        else FTK_FEAT(2, false);
     } else if (ch && df) FTK_FEAT(1, true);
     else if (ch) FTK_FEAT(1, false);
     else if (df) FTK_FEAT(0, true);

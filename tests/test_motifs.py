@@ -268,6 +268,48 @@ def test_gpu_large_random_vs_oracle(engine, k, kind, tmp_path):
     engine.release("motif_big")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["end", "breakpoint"])
+def test_gpu_many_equal_windows_take_the_block_kernels(engine, kind, tmp_path):
+    """400 tiles of 5 kb (one block per window, no planner): the streamed word form of the motif pass and the general
+    form (FASTA text) against the oracle, window by window; N blocks by the hundred, both strand rules."""
+    k = 4
+    rng = np.random.default_rng(77)
+    L = 2_000_000
+    seq = np.frombuffer(b"ACGTN", np.uint8)[rng.choice(5, L, p=[0.26, 0.24, 0.24, 0.255, 0.005])].copy()
+    seq[1_200_000:1_230_000] = ord("N")
+    s = seq.tobytes().decode()
+    H.write_fasta(tmp_path / "r.fa", {"c": s})
+    H.write_2bit(tmp_path / "r.2bit", {"c": s})
+    n = 60_000
+    fs = np.sort(rng.integers(0, L - 400, n)).astype(np.int32)
+    fe = (fs + rng.integers(1, 400, n)).astype(np.int32)
+    mq = rng.integers(0, 61, n).astype(np.uint8)
+    st = rng.integers(0, 2, n).astype(np.uint8)
+    engine.load_contig("motif_tiles", fs, fe, mq, st)
+    from finaletoolkit_amd.reference import ReferenceGenome
+    ws = np.arange(0, L, 5000, dtype=np.int32)
+    we = (ws + 5000).astype(np.int32)
+    h = k // 2
+    spec = (dict(fwd_offset=0, rev_offset=-k, guard=0, rev_oob_is_error=False) if kind == "end" else
+            dict(fwd_offset=-h, rev_offset=-h, guard=h, rev_oob_is_error=False))
+    for both, neg in ((False, False), (False, True)):
+        want = []
+        for a, b in zip(ws.tolist(), we.tolist()):
+            lo, hi = np.searchsorted(fs, a - 400), np.searchsorted(fs, b)
+            rws = list(zip(fs[lo:hi].tolist(), fe[lo:hi].tolist(), mq[lo:hi].tolist(), st[lo:hi].tolist()))
+            want.append(O.py_region_motifs(rws, s, a, b, k, kind, both, neg, 25))
+        want = np.stack(want)
+        for path in ("r.fa", "r.2bit"):
+            with ReferenceGenome(str(tmp_path / path)) as ref:
+                rid = ref.device_image(engine, "c")
+                got, nfrag, err = engine.motif_counts("motif_tiles", rid, ws, we, k, both_strands=both,
+                                                      negative_strand=neg, quality_threshold=25, **spec)
+            assert np.array_equal(got.astype(np.int64), want), (both, neg, path)
+            assert err.sum() == 0
+    engine.release("motif_tiles")
+
+
 def _end_both_no_raise(rws, s, a, b, k, q):
     """both-strands end motifs where no 3' k-mer leaves the contig (fe >= k holds for all rows here
     except possibly tiny fragments at the contig start: those raise in the reference, so they are
