@@ -1879,7 +1879,9 @@ __global__ __launch_bounds__(256) void gc_count_kernel(const uint8_t* __restrict
                 }
             };
             // four 1 KB rows of the wave in flight per trip (a 100 kb bin of a 2bit image is 25 of them: the loop
-            // is as long as its loads' latency, so the loads are issued together), then row by row
+            // is as long as its loads' latency, so the loads are issued together), then row by row.  Sixteen rows per
+            // trip (two trips per bin) were measured: 16.7 us against 13.3 -- 2 432 waves with 16 KB each in flight are 39 MB
+            // of requests at once, and HBM serves that many concurrent streams worse than fewer, longer ones
             int64_t b = a0 + 16 * lane;
             for (; b + 3 * 16 * 64 < a1; b += 4 * 16 * 64) {
                 uint4 v[4];
