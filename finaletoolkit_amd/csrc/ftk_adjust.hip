@@ -134,22 +134,25 @@ __global__ __launch_bounds__(kFastThreads) void adjust_median_hist_kernel(const 
     const int lane = threadIdx.x;
     const double* in = scores + t.in_base;
     const int n_in = t.n_out + W - 1;
-    // integers (no -0.0) within a range of kFastBins?  The tile's inputs are read ONCE, eight 512-byte rows of the wave
-    // in flight per trip (one wave per block: a loop of single loads would wait out a memory latency per row), and
-    // parked as int32 where the histograms will be; then shifted to bytes, then the histograms cleared.
+    // integers (no -0.0) within a range of kFastBins?  The tile's inputs are read ONCE and parked as int16 where the
+    // histograms will be; then shifted to bytes, then the histograms cleared.
     short* parked = (short*)hh;  // value - the tile's first value (a tile the histograms can take spans < 256)
     const double v0 = in[0];
     double lo = INFINITY, hi = -INFINITY;
     bool ok = true;
-    for (int i0 = 0; i0 < n_in; i0 += 8 * kFastThreads) {
-        double v[8];
+    // kParkRows rows of the wave in flight per trip.  The histograms leave room for seven of these one-wave blocks per
+    // CU, so what a CU has in flight is what its seven waves ask for at once: with 8 rows (28 KB per CU) this loop
+    // alone was 240 of the kernel's 524 us -- 400 MB read at 1.7 TB/s.
+    constexpr int kParkRows = 32;
+    for (int i0 = 0; i0 < n_in; i0 += kParkRows * kFastThreads) {
+        double v[kParkRows];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kParkRows; ++u) {
             const int i = i0 + u * kFastThreads + lane;
-            v[u] = i < n_in ? in[i] : v0;
+            v[u] = in[min(i, n_in - 1)];  // (no load under a branch)
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kParkRows; ++u) {
             const int i = i0 + u * kFastThreads + lane;
             if (i < n_in) {
                 const double d = v[u] - v0;
@@ -210,32 +213,69 @@ __global__ __launch_bounds__(kFastThreads) void adjust_median_hist_kernel(const 
         ++m;
         cm = cnt(m);
     }
-    for (int o = o_begin;;) {
-        int m2 = m;
-        if (below + cm < tgt + 1) {  // (rare with hundreds of values in a few dozen bins)
-            m2 = m + 1;
-            while (cnt(m2) == 0) ++m2;
-        }
-        // the sort kernel's arithmetic on the same values: ((x1 - sub) + (x2 - sub)) * 0.5, x - sub - median
-        const double med = (((double)(base + m) - sub) + ((double)(base + m2) - sub)) * 0.5;
-        out[t.out_base + o] = ((double)(base + (int)sv[o + W / 2]) - sub) - med;
-        if (++o >= o_end) break;
-        const int b_old = sv[o - 1], b_new = sv[o + W - 1];
-        if (b_old == b_new) continue;
-        take(b_old);
-        add(b_new);
-        below += (b_new < m) - (b_old < m);
-        cm += (b_new == m) - (b_old == m);
-        // the middle moves by a bin or two at most: the counts of the bins it crosses are the only reads of a step
-        while (below >= tgt) {
-            --m;
-            cm = cnt(m);
-            below -= cm;
-        }
-        while (below + cm < tgt) {
-            below += cm;
-            ++m;
-            cm = cnt(m);
+    // The run, four outputs per trip: the three byte streams a step reads -- the value leaving the window, the one
+    // entering it, the one at its centre -- are consecutive in `sv`, so one trip's twelve bytes are three (five, when
+    // W / 2 or W is not a multiple of 4) dword reads issued together and waited for once.  (One byte read at a time
+    // every step began with an LDS round trip behind the queue of atomics: 247 of the kernel's 502 us.)
+    const int n_steps = o_end - o_begin;
+    const unsigned char* p_old = sv + o_begin;             // 4-byte aligned
+    const unsigned char* p_new = sv + o_begin + W;         // W & 3 into a dword (uniform)
+    const unsigned char* p_cen = sv + o_begin + W / 2;
+    const int sh_new = W & 3, sh_cen = (W / 2) & 3;
+    auto four = [](const unsigned char* p, int sh) -> unsigned int {
+        const unsigned int* q = reinterpret_cast<const unsigned int*>(p - sh);
+        const unsigned int lo = q[0];
+        if (sh == 0) return lo;
+        return __builtin_amdgcn_alignbyte(q[1], lo, (unsigned)sh);
+    };
+    for (int s0 = 0; s0 < n_steps; s0 += 4) {
+        const unsigned int old4 = *reinterpret_cast<const unsigned int*>(p_old + s0);
+        const unsigned int new4 = four(p_new + s0, sh_new);
+        const unsigned int cen4 = four(p_cen + s0, sh_cen);
+        double r[4];  // the trip's outputs: written as 2 x 16 bytes (a lane's run is its own stretch of `out`: one 8-byte
+                      // store per step made every store instruction 64 partial sectors -- 2.1 x the output in HBM writes)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int st = s0 + u;
+            if (st >= n_steps) break;
+            int m2 = m;
+            if (below + cm < tgt + 1) {  // (rare with hundreds of values in a few dozen bins)
+                m2 = m + 1;
+                while (cnt(m2) == 0) ++m2;
+            }
+            // the sort kernel's arithmetic on the same values: ((x1 - sub) + (x2 - sub)) * 0.5, x - sub - median
+            const double med = (((double)(base + m) - sub) + ((double)(base + m2) - sub)) * 0.5;
+            r[u] = ((double)(base + (int)((cen4 >> (8 * u)) & 0xffu)) - sub) - med;
+            if (u == 3 || st + 1 >= n_steps) {  // the trip's (or the run's) last output: hand the trip over
+                double* dst = out + t.out_base + o_begin + s0;
+                if (u == 3) {
+                    typedef double __attribute__((ext_vector_type(2), aligned(8))) d2u;
+                    *reinterpret_cast<d2u*>(dst) = d2u{r[0], r[1]};
+                    *reinterpret_cast<d2u*>(dst + 2) = d2u{r[2], r[3]};
+                } else {
+                    dst[0] = r[0];
+                    if (u >= 1) dst[1] = r[1];
+                    if (u >= 2) dst[2] = r[2];
+                }
+            }
+            if (st + 1 >= n_steps) break;
+            const int b_old = (int)((old4 >> (8 * u)) & 0xffu), b_new = (int)((new4 >> (8 * u)) & 0xffu);
+            if (b_old == b_new) continue;
+            take(b_old);
+            add(b_new);
+            below += (b_new < m) - (b_old < m);
+            cm += (b_new == m) - (b_old == m);
+            // the middle moves by a bin or two at most: the counts of the bins it crosses are the only reads of a step
+            while (below >= tgt) {
+                --m;
+                cm = cnt(m);
+                below -= cm;
+            }
+            while (below + cm < tgt) {
+                below += cm;
+                ++m;
+                cm = cnt(m);
+            }
         }
     }
 }
@@ -314,7 +354,7 @@ void launch_adjust_filter(hipStream_t s, const double* scores, const AdjustTile*
     }
     if (fast_tiles && todo) {  // integers in a narrow range: sliding histograms; what they cannot take is marked ...
         (void)hipMemsetAsync(todo, 0, (size_t)n_iv * sizeof(int), s);
-        const size_t bytes_sv = (size_t)(kAdjustFastTile + W - 1 + 3) / 4 * 4;
+        const size_t bytes_sv = (size_t)(kAdjustFastTile + W - 1 + 3) / 4 * 4 + 8;  // (+8: a run's last trip reads whole dwords)
         adjust_median_hist_kernel<128><<<n_fast_tiles, kFastThreads, (size_t)128 / 2 * 64 * 4 + bytes_sv, s>>>(scores, fast_tiles, edge_sub, W, out, todo);
         adjust_median_hist_kernel<256><<<n_fast_tiles, kFastThreads, (size_t)256 / 2 * 64 * 4 + bytes_sv, s>>>(scores, fast_tiles, edge_sub, W, out, todo);
     }
