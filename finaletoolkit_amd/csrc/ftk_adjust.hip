@@ -334,12 +334,86 @@ __global__ __launch_bounds__(kAdjThreads) void savgol_kernel(const double* __res
 
 }  // namespace
 
+// ---- the tile lists, built where they are used --------------------------------------------------------------------
+// (one 32-byte descriptor per tile: 40 000 + 10 000 of them for 10 000 runs of 5 kb were 1.6 MB of pageable uploads
+// and ~70 us of the stream before the first kernel of a 0.5 ms call; the run offsets are 80 KB)
+// pre[k][i]: tiles of kind k (0: sort kernel, 1: histogram median) before run i; one block, runs 1024 at a time.
+__global__ __launch_bounds__(1024) void adjust_tile_counts_kernel(const int64_t* __restrict__ offs, int n_iv, int W,
+                                                                   int tile0, int tile1, int* __restrict__ pre0,
+                                                                   int* __restrict__ pre1) {
+    __shared__ int wave_tot[2][16];
+    __shared__ int carry[2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 2) carry[tid] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n_iv; i0 += 1024) {
+        const int i = i0 + tid;
+        int c[2] = {0, 0};
+        if (i < n_iv) {
+            const int64_t m = offs[i + 1] - offs[i] - W;
+            c[0] = (int)((m + tile0 - 1) / tile0);
+            c[1] = tile1 ? (int)((m + tile1 - 1) / tile1) : 0;
+        }
+        int x[2] = {c[0], c[1]};
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y0 = __shfl_up(x[0], d, 64), y1 = __shfl_up(x[1], d, 64);
+            if (lane >= d) { x[0] += y0; x[1] += y1; }
+        }
+        if (lane == 63) { wave_tot[0][wv] = x[0]; wave_tot[1][wv] = x[1]; }
+        __syncthreads();
+        int p[2] = {carry[0], carry[1]};
+        for (int j = 0; j < wv; ++j) { p[0] += wave_tot[0][j]; p[1] += wave_tot[1][j]; }
+        if (i < n_iv) { pre0[i] = p[0] + x[0] - c[0]; pre1[i] = p[1] + x[1] - c[1]; }
+        __syncthreads();
+        if (tid == 1023) { carry[0] = p[0] + x[0]; carry[1] = p[1] + x[1]; }
+        __syncthreads();
+    }
+    if (tid == 0) { pre0[n_iv] = carry[0]; pre1[n_iv] = carry[1]; }
+}
+
+// tile j of kind k: its run by bisection of pre[k], then the descriptor (ftk_wps_adjust's own arithmetic)
+__global__ __launch_bounds__(256) void adjust_tile_fill_kernel(const int64_t* __restrict__ offs, int n_iv, int W, int tile0,
+                                                                int tile1, const int* __restrict__ pre0,
+                                                                const int* __restrict__ pre1, AdjustTile* __restrict__ t0,
+                                                                AdjustTile* __restrict__ t1) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int* pre = k ? pre1 : pre0;
+        const int tile = k ? tile1 : tile0;
+        AdjustTile* dst = k ? t1 : t0;
+        if (!tile || !dst || j >= pre[n_iv]) continue;
+        int lo = 0, hi = n_iv;  // largest i with pre[i] <= j
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= j) lo = mid; else hi = mid;
+        }
+        const int64_t o0 = (int64_t)(j - pre[lo]) * tile, m = offs[lo + 1] - offs[lo] - W;
+        AdjustTile t;
+        t.in_base = offs[lo] + o0;
+        t.out_base = offs[lo] - (int64_t)lo * W + o0;
+        t.n_out = (int32_t)min((int64_t)tile, m - o0);
+        t.o0 = (int32_t)o0;
+        t.m = (int32_t)m;
+        t.interval = lo;
+        dst[j] = t;
+    }
+}
+
 int adjust_sort_size(int W, int* tile_out) {
     int n = 1;
     while (n < 2 * W) n <<= 1;
     n = n < 256 ? 256 : n;
     if (tile_out) *tile_out = n - W + 1;
     return n;
+}
+
+void launch_adjust_tiles(hipStream_t s, const int64_t* offs, int n_iv, int W, int tile0, int tile1, int* pre0, int* pre1,
+                         AdjustTile* t0, int n0, AdjustTile* t1, int n1) {
+    adjust_tile_counts_kernel<<<1, 1024, 0, s>>>(offs, n_iv, W, tile0, tile1, pre0, pre1);
+    const int n = n0 > n1 ? n0 : n1;
+    if (n > 0) adjust_tile_fill_kernel<<<(n + 255) / 256, 256, 0, s>>>(offs, n_iv, W, tile0, t1 ? tile1 : 0, pre0, pre1, t0, t1);
 }
 
 void launch_adjust_filter(hipStream_t s, const double* scores, const AdjustTile* tiles, int n_tiles,

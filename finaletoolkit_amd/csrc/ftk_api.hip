@@ -384,6 +384,7 @@ void ftk_ctx_destroy(ftk_ctx* ctx) {
         if (ctx->narrow_stage[k]) ftk_host_free(ctx->narrow_stage[k]);
         if (ctx->narrow_done[k]) (void)hipEventDestroy(ctx->narrow_done[k]);
     }
+    if (ctx->param_stage) (void)hipHostFree(ctx->param_stage);
     if (ctx->scratch) ftk_host::device_block_give(ctx->scratch, ctx->scratch_bytes, ctx->device);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->copy_stream) {

@@ -106,6 +106,10 @@ struct ftk_ctx {
     std::vector<unsigned char> batch_host[2];  // [0] window features, [1] WPS
     void* batch_dev[2] = {nullptr, nullptr};
     size_t batch_cap[2] = {0, 0};
+    // small host arrays on their way to the device by DMA (a pageable copy above 16 KB takes the runtime's slow route:
+    // ~28 us for 80 KB); page-locked, grow-only, used by calls that synchronise before they return
+    void* param_stage = nullptr;
+    size_t param_stage_bytes = 0;
     // grow-only device scratch, reused by every call (stream-ordered)
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
