@@ -39,14 +39,11 @@ __device__ __forceinline__ double key_f64(unsigned long long k) {
 }
 
 // median_window W (even), n_sort = power of two >= n_out + W - 1
-__global__ __launch_bounds__(kAdjThreads) void adjust_median_kernel(const double* __restrict__ scores,
-                                                                     const AdjustTile* __restrict__ tiles,
-                                                                     const double* __restrict__ edge_sub, int W,
-                                                                     int n_sort, double* __restrict__ out,
-                                                                     const int* __restrict__ todo) {
-    extern __shared__ unsigned long long lds_keys[];       // [n_sort] sorted keys
+__device__ __forceinline__ void adjust_median_tile(const double* __restrict__ scores, const AdjustTile& t,
+                                                   const double* __restrict__ edge_sub, int W, int n_sort,
+                                                   double* __restrict__ out, const int* __restrict__ todo,
+                                                   unsigned long long* lds_keys) {
     unsigned int* pos = (unsigned int*)(lds_keys + n_sort);  // [n_sort] input position of each sorted slot
-    const AdjustTile t = tiles[blockIdx.x];
     if (todo && todo[t.interval] != 2) return;  // a histogram kernel has answered this interval
     const double sub = edge_sub ? edge_sub[t.interval] : 0.0;
     const double* in = scores + t.in_base;
@@ -110,6 +107,23 @@ __global__ __launch_bounds__(kAdjThreads) void adjust_median_kernel(const double
     }
 }
 
+// With histogram kernels in front (left != NULL) a block leaves at once when they marked nothing at all (left[1] == 0):
+// 40 000 blocks that each load their tile and look up its interval's mark were 18 us of an 0.5 ms call.  (A small grid
+// striding over the tiles was tried for the same reason: 21 % slower when the tiles do need sorting.)
+__global__ __launch_bounds__(kAdjThreads) void adjust_median_kernel(const double* __restrict__ scores,
+                                                                     const AdjustTile* __restrict__ tiles, int n_tiles,
+                                                                     const double* __restrict__ edge_sub, int W,
+                                                                     int n_sort, double* __restrict__ out,
+                                                                     const int* __restrict__ todo,
+                                                                     const int* __restrict__ left) {
+    extern __shared__ unsigned long long lds_keys[];       // [n_sort] sorted keys, [n_sort] positions
+    if (left && left[1] == 0) return;
+    for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+        adjust_median_tile(scores, tiles[ti], edge_sub, W, n_sort, out, todo, lds_keys);
+        __syncthreads();
+    }
+}
+
 // ---- the median of small integers: one lane, one run of outputs, one sliding histogram ---------------------------
 // Two sizes: 128 bins (16 KB of histograms per wavefront: seven tiles per CU - the ALU and LDS latencies of one lane's
 // chain are hidden by the other waves of its SIMD; raw WPS at 30x spans 60-80 values over 5 kb) and 256 bins (32 KB,
@@ -119,17 +133,15 @@ constexpr int kFastThreads = 64;    // one wavefront per tile
 constexpr int kTodoWide = 1, kTodoSort = 2;
 
 template <int kFastBins>
-__global__ __launch_bounds__(kFastThreads) void adjust_median_hist_kernel(const double* __restrict__ scores,
-                                                                           const AdjustTile* __restrict__ tiles,
-                                                                           const double* __restrict__ edge_sub, int W,
-                                                                           double* __restrict__ out, int* __restrict__ todo) {
+__device__ __forceinline__ void adjust_median_hist_tile(const double* __restrict__ scores, const AdjustTile& t,
+                                                        const double* __restrict__ edge_sub, int W,
+                                                        double* __restrict__ out, int* __restrict__ todo,
+                                                        int* __restrict__ left, unsigned int* lds_fast) {
     // (the inputs are parked as int16 offsets where the histograms go: 128 bins x 64 lanes x 2 B hold the largest tile)
     constexpr int kHistWords = kFastBins / 2 * 64;
     static_assert((kAdjustFastTile + kAdjustMaxWindow) * 2 <= kHistWords * 4, "the parked inputs must fit where the histograms go");
-    extern __shared__ unsigned int lds_fast[];
     unsigned int* hh = lds_fast;                                   // [kFastBins][32]: bin b of lanes 2p (low half), 2p + 1 (high half)
     unsigned char* sv = (unsigned char*)(lds_fast + kHistWords);   // [n_in]: value - base
-    const AdjustTile t = tiles[blockIdx.x];
     if (kFastBins > 128 && todo[t.interval] != kTodoWide) return;  // (answered by the 128-bin pass)
     const int lane = threadIdx.x;
     const double* in = scores + t.in_base;
@@ -168,9 +180,14 @@ __global__ __launch_bounds__(kFastThreads) void adjust_median_hist_kernel(const 
         lo = fmin(lo, __shfl_xor(lo, d, 64));
         hi = fmax(hi, __shfl_xor(hi, d, 64));
     }
-    if (!__all(ok) || !(hi - lo < (double)kFastBins)) {
+    const bool all_ok = __all(ok);
+    if (!all_ok || !(hi - lo < (double)kFastBins)) {
         // (racing writers of one interval: the larger request must win)
-        if (lane == 0) atomicMax(&todo[t.interval], (__all(ok) && kFastBins <= 128 && hi - lo < 256.0) ? kTodoWide : kTodoSort);
+        if (lane == 0) {
+            const int want = (all_ok && kFastBins <= 128 && hi - lo < 256.0) ? kTodoWide : kTodoSort;
+            atomicMax(&todo[t.interval], want);
+            left[want == kTodoWide ? 0 : 1] = 1;  // (racing writers all write 1) something is left for the next kernels
+        }
         return;
     }
     const int base = (int)lo, rel = (int)(lo - v0);
@@ -280,6 +297,22 @@ __global__ __launch_bounds__(kFastThreads) void adjust_median_hist_kernel(const 
     }
 }
 
+// The 128-bin pass has a block per tile; the 256-bin pass behind it strides over the tiles with a small grid and leaves
+// at once when the first marked nothing for it (left[0] == 0).
+template <int kFastBins>
+__global__ __launch_bounds__(kFastThreads) void adjust_median_hist_kernel(const double* __restrict__ scores,
+                                                                           const AdjustTile* __restrict__ tiles, int n_tiles,
+                                                                           const double* __restrict__ edge_sub, int W,
+                                                                           double* __restrict__ out, int* __restrict__ todo,
+                                                                           int* __restrict__ left) {
+    extern __shared__ unsigned int lds_fast[];
+    if (kFastBins > 128 && left[0] == 0) return;
+    for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+        adjust_median_hist_tile<kFastBins>(scores, tiles[ti], edge_sub, W, out, todo, left, lds_fast);
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(kAdjThreads) void adjust_mean_kernel(const double* __restrict__ scores,
                                                                    const AdjustTile* __restrict__ tiles,
                                                                    const double* __restrict__ edge_sub, int W,
@@ -340,21 +373,42 @@ __global__ __launch_bounds__(kAdjThreads) void savgol_kernel(const double* __res
 // pre[k][i]: tiles of kind k (0: sort kernel, 1: histogram median) before run i; one block, runs 1024 at a time.
 __global__ __launch_bounds__(1024) void adjust_tile_counts_kernel(const int64_t* __restrict__ offs, int n_iv, int W,
                                                                    int tile0, int tile1, int* __restrict__ pre0,
-                                                                   int* __restrict__ pre1) {
+                                                                   int* __restrict__ pre1, int* __restrict__ todo) {
+    // a thread takes kR consecutive runs of a trip (their offsets: kR + 1 loads in flight at once -- a trip per 1024
+    // runs was a memory latency per trip, 23 us for 10 000 runs); also clears the marks of the histogram kernels
+    constexpr int kR = 16;
+    // ceil(m / t) for m < 2^31 without an integer division (32 of them per thread were half of this one-block kernel):
+    // the double product is within 1e-7 of the quotient, so its floor is right or one short; the remainder settles it
+    const double rcp0 = 1.0 / (double)tile0, rcp1 = tile1 ? 1.0 / (double)tile1 : 0.0;
+    auto ceil_div = [](unsigned int m, unsigned int t, double rcp) -> unsigned int {
+        const unsigned int x = m + t - 1u;
+        unsigned int q = (unsigned int)((double)x * rcp);
+        if (x - q * t >= t) ++q;
+        return q;
+    };
     __shared__ int wave_tot[2][16];
     __shared__ int carry[2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < 2) carry[tid] = 0;
+    if (todo)
+        for (int i = tid; i < n_iv + 2; i += 1024) todo[i] = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < n_iv; i0 += 1024) {
-        const int i = i0 + tid;
-        int c[2] = {0, 0};
-        if (i < n_iv) {
-            const int64_t m = offs[i + 1] - offs[i] - W;
-            c[0] = (int)((m + tile0 - 1) / tile0);
-            c[1] = tile1 ? (int)((m + tile1 - 1) / tile1) : 0;
+    for (int i0 = 0; i0 < n_iv; i0 += 1024 * kR) {
+        const int first = i0 + tid * kR;
+        int64_t o[kR + 1];
+#pragma unroll
+        for (int r = 0; r <= kR; ++r) o[r] = offs[min(first + r, n_iv)];
+        int c0[kR], c1[kR], x[2] = {0, 0};
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const unsigned int m = (unsigned int)(o[r + 1] - o[r] - W);  // (0 .. INT32_MAX, checked by the caller)
+            const bool in = first + r < n_iv;
+            c0[r] = in ? (int)ceil_div(m, (unsigned)tile0, rcp0) : 0;
+            c1[r] = in && tile1 ? (int)ceil_div(m, (unsigned)tile1, rcp1) : 0;
+            x[0] += c0[r];
+            x[1] += c1[r];
         }
-        int x[2] = {c[0], c[1]};
+        const int mine[2] = {x[0], x[1]};
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int y0 = __shfl_up(x[0], d, 64), y1 = __shfl_up(x[1], d, 64);
@@ -364,7 +418,13 @@ __global__ __launch_bounds__(1024) void adjust_tile_counts_kernel(const int64_t*
         __syncthreads();
         int p[2] = {carry[0], carry[1]};
         for (int j = 0; j < wv; ++j) { p[0] += wave_tot[0][j]; p[1] += wave_tot[1][j]; }
-        if (i < n_iv) { pre0[i] = p[0] + x[0] - c[0]; pre1[i] = p[1] + x[1] - c[1]; }
+        int q0 = p[0] + x[0] - mine[0], q1 = p[1] + x[1] - mine[1];
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            if (first + r < n_iv) { pre0[first + r] = q0; pre1[first + r] = q1; }
+            q0 += c0[r];
+            q1 += c1[r];
+        }
         __syncthreads();
         if (tid == 1023) { carry[0] = p[0] + x[0]; carry[1] = p[1] + x[1]; }
         __syncthreads();
@@ -410,8 +470,8 @@ int adjust_sort_size(int W, int* tile_out) {
 }
 
 void launch_adjust_tiles(hipStream_t s, const int64_t* offs, int n_iv, int W, int tile0, int tile1, int* pre0, int* pre1,
-                         AdjustTile* t0, int n0, AdjustTile* t1, int n1) {
-    adjust_tile_counts_kernel<<<1, 1024, 0, s>>>(offs, n_iv, W, tile0, tile1, pre0, pre1);
+                         AdjustTile* t0, int n0, AdjustTile* t1, int n1, int* todo) {
+    adjust_tile_counts_kernel<<<1, 1024, 0, s>>>(offs, n_iv, W, tile0, tile1, pre0, pre1, todo);
     const int n = n0 > n1 ? n0 : n1;
     if (n > 0) adjust_tile_fill_kernel<<<(n + 255) / 256, 256, 0, s>>>(offs, n_iv, W, tile0, t1 ? tile1 : 0, pre0, pre1, t0, t1);
 }
@@ -426,15 +486,16 @@ void launch_adjust_filter(hipStream_t s, const double* scores, const AdjustTile*
         adjust_mean_kernel<<<n_tiles, kAdjThreads, lds, s>>>(scores, tiles, edge_sub, W, out);
         return;
     }
-    if (fast_tiles && todo) {  // integers in a narrow range: sliding histograms; what they cannot take is marked ...
-        (void)hipMemsetAsync(todo, 0, (size_t)n_iv * sizeof(int), s);
+    const bool hist = fast_tiles && todo;
+    int* left = hist ? todo + n_iv : nullptr;  // [2]: something marked kTodoWide / kTodoSort (cleared with todo by launch_adjust_tiles)
+    if (hist) {  // integers in a narrow range: sliding histograms; what they cannot take is marked ...
         const size_t bytes_sv = (size_t)(kAdjustFastTile + W - 1 + 3) / 4 * 4 + 8;  // (+8: a run's last trip reads whole dwords)
-        adjust_median_hist_kernel<128><<<n_fast_tiles, kFastThreads, (size_t)128 / 2 * 64 * 4 + bytes_sv, s>>>(scores, fast_tiles, edge_sub, W, out, todo);
-        adjust_median_hist_kernel<256><<<n_fast_tiles, kFastThreads, (size_t)256 / 2 * 64 * 4 + bytes_sv, s>>>(scores, fast_tiles, edge_sub, W, out, todo);
+        adjust_median_hist_kernel<128><<<n_fast_tiles, kFastThreads, (size_t)128 / 2 * 64 * 4 + bytes_sv, s>>>(scores, fast_tiles, n_fast_tiles, edge_sub, W, out, todo, left);
+        adjust_median_hist_kernel<256><<<std::min(n_fast_tiles, 1024), kFastThreads, (size_t)256 / 2 * 64 * 4 + bytes_sv, s>>>(scores, fast_tiles, n_fast_tiles, edge_sub, W, out, todo, left);
     }
     // ... and sorted (every interval when there is no histogram pass)
     const size_t lds = (size_t)n_sort * (8 + 4);
-    adjust_median_kernel<<<n_tiles, kAdjThreads, lds, s>>>(scores, tiles, edge_sub, W, n_sort, out, fast_tiles && todo ? todo : nullptr);
+    adjust_median_kernel<<<n_tiles, kAdjThreads, lds, s>>>(scores, tiles, n_tiles, edge_sub, W, n_sort, out, hist ? todo : nullptr, left);
 }
 
 void launch_savgol(hipStream_t s, const double* adj, const AdjustTile* tiles, int n_tiles, const double* coef,

@@ -104,6 +104,12 @@ def measure(torch, eng, which="all", reps=5, seed=1):
         f = lambda: eng._check(eng.lib.ftk_ref_gc_counts(eng.ctx, rid, L.ptr(d_lo), L.ptr(d_hi), len(glo), L.ptr(d_gc)))
         rows["gc_count_kernel"] = _row("gc_count_kernel", _time(eng, f, reps, flush), size // 4 + 8 * len(glo),
                                        "1/4 B per base (2bit image) + 8 B per bin")
+        # raw WPS of the contig's first 50 Mb (the scores adjust_wps is made for): kept for the adjust row below
+        n_iv, ilen, W = 10_000, 5_000, 1000
+        wps_i64 = torch.empty(n_iv * ilen, dtype=torch.int64, device=dev)
+        eng.wps("kr_next", 0, n_iv * ilen, size, out=wps_i64)
+        x_wps = wps_i64.to(torch.float64)
+        del wps_i64
         eng.release("kr_next")
         del s, e, q, st, d_lo, d_hi, d_gc
         # adjust_wps: running median W = 1000 over 10 000 x 5 kb score runs (device resident)
@@ -118,6 +124,13 @@ def measure(torch, eng, which="all", reps=5, seed=1):
                                             "8 B per input score + 8 B per output",
                                             note="integer scores (raw WPS): adjust_median_hist_kernel, one sliding histogram per lane; the sort kernel "
                                                  "behind it finds every interval answered and exits")
+        f = lambda: eng.wps_adjust(x_wps.data_ptr(), offs, W, out=y.data_ptr(), savgol=False)
+        rows["adjust_median_kernel_on_wps"] = _row("adjust_median_kernel (the contig's own WPS)", _time(eng, f, reps), 8 * n_iv * ilen + 8 * n_iv * (ilen - W),
+                                                   "8 B per input score + 8 B per output",
+                                                   note="the scores the filter is made for: WPS (window 120, fragments 120-180) of the first 50 Mb of the 30x contig, "
+                                                        "as 10 000 runs of 5 kb; value range %d..%d.  The row above is the same shape on uniformly random integers in "
+                                                        "[-60, 60): every step replaces a value and moves the middle" % (int(x_wps.min().item()), int(x_wps.max().item())))
+        del x_wps
         xf = x + 0.25  # the same runs as non-integers: every interval goes through the sort kernel (the path of round 5)
         f = lambda: eng.wps_adjust(xf.data_ptr(), offs, W, out=y.data_ptr(), savgol=False)
         rows["adjust_median_kernel_sort_path"] = _row("adjust_median_kernel (non-integer scores)", _time(eng, f, reps), 8 * n_iv * ilen + 8 * n_iv * (ilen - W),
