@@ -16,7 +16,7 @@ from typing import NamedTuple, Union
 import numpy as np
 
 from .. import sharding, writers
-from .._stages import Stages
+from .._stages import Stages, without_collector
 from ..source import ContigFeed, get_engine, open_source
 from ..utils import _check_policy, _check_region, _region_contigs, get_intervals
 
@@ -160,6 +160,7 @@ def _coverage_one_process(clock, input_file, interval_file, min_length, max_leng
     return counts, total, intervals
 
 
+@without_collector
 def coverage(input_file: Union[str, Path], interval_file: str, output_file: str, scale_factor: float = 1.0,
              min_length: int | None = None, max_length: int | None = None, normalize: bool = False,
              intersect_policy: str = "midpoint", quality_threshold: int = 30, workers: int = 1,

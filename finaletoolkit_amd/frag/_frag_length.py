@@ -12,6 +12,8 @@ the odd-count median search for ``total // 2``.
 from __future__ import annotations
 
 import gzip
+import queue
+import threading
 import time
 import warnings
 from pathlib import Path
@@ -21,7 +23,7 @@ from typing import NamedTuple, Union
 import numpy as np
 
 from .. import sharding, writers
-from .._stages import Stages
+from .._stages import Stages, without_collector
 from ..source import ContigFeed, get_engine, open_source
 from ..utils import _check_policy, _check_region, _region_contigs, get_intervals
 
@@ -160,6 +162,7 @@ def frag_length(input_file: Union[str, Path], contig: str | None = None, start: 
     return lengths
 
 
+@without_collector
 def frag_length_bins(input_file, contig: str | None = None, start: int | None = None, stop: int | None = None,
                      min_length: int | None = 0, max_length: int | None = None, bin_size: int = 1,
                      output_file: str | None = None, intersect_policy: str = "midpoint", quality_threshold: int = 30,
@@ -277,6 +280,7 @@ def _result_rows(results: list, intervals, index, stats: np.ndarray, lines: list
             gc.enable()
 
 
+@without_collector
 def frag_length_intervals(input_file, interval_file: str, output_file: str | None = None,
                           min_length: int | None = 0, max_length: int | None = None, quality_threshold: int = 30,
                           intersect_policy: str = "midpoint", short_reads: int = 150, workers: int = 1,
@@ -343,6 +347,27 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
             by_contig.setdefault(iv[0], []).append(i)
         stats = None
         feed = ContigFeed(input_file, workers, names=list(by_contig))
+        # (starting the decode before the intervals are parsed - the contigs named by a quick pass over the BED file - was
+        # measured: the parse and the decoder's start slow each other down by what the head start gains)
+        # A contig's rows (named tuples, output lines: 1.5 us of interpreter time per interval) are made on a second
+        # thread while this one waits - without the interpreter lock - for the next contig or for its kernels: made
+        # here, between two contigs, they were longer than the decoder needs for a contig and set the command's pace.
+        todo: queue.SimpleQueue = queue.SimpleQueue()
+        failed: list = []
+
+        def make_rows():
+            while True:
+                item = todo.get()
+                if item is None:
+                    return
+                try:
+                    _result_rows(results, intervals, item[0], item[1], lines)
+                except BaseException as e:  # noqa: BLE001 - re-raised by the command's own thread below
+                    failed.append(e)
+                    return
+
+        rows_thread = threading.Thread(target=make_rows, name="ftk-length-rows", daemon=True)
+        rows_thread.start()
         try:
             for src, c in feed:
                 clock.lap("decode_wait")
@@ -352,12 +377,17 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
                     order = idx[np.argsort(iv_starts[idx], kind="stable")]
                     block = unit_stats(src.key(c), order)
                     clock.lap("histograms_and_statistics")
-                    _result_rows(results, intervals, order, block, lines)  # (while the decoder is in the next contig)
-                    clock.lap("result_rows")
+                    todo.put((order, block))
             src = feed.finish()
         except BaseException:
             feed.close()
             raise
+        finally:
+            todo.put(None)
+            rows_thread.join()
+        if failed:
+            raise failed[0]
+        clock.lap("result_rows_tail")
         for c in by_contig:  # contigs the file does not hold: the error the reference's fetch raises (ValueError)
             src.require(c)
     else:

@@ -19,6 +19,7 @@ from typing import Union
 
 import numpy as np
 
+from .._stages import without_collector
 from .. import sharding
 from ..source import ContigFeed, get_engine, open_source
 from ..utils import chrom_sizes_to_list
@@ -72,6 +73,7 @@ def _site_windows(site_bed, interval_size, lengths):
     return names[keep], starts[keep], stops[keep]
 
 
+@without_collector
 def multi_wps(input_file, site_bed, chrom_sizes=None, output_file: str | None = None, window_size: int = 120,
               interval_size: int = 5000, min_length: int = 120, max_length: int = 180, quality_threshold: int = 30,
               workers: int = 1, verbose: Union[bool, int] = 0, fraction_low: int | None = None,
