@@ -192,9 +192,22 @@ __device__ __forceinline__ void adjust_median_hist_tile(const double* __restrict
     }
     const int base = (int)lo, rel = (int)(lo - v0);
     __syncthreads();
-    for (int i = lane; i < n_in; i += kFastThreads) sv[i] = (unsigned char)((int)parked[i] - rel);
+    {   // four values a step: two dwords of int16 in, one dword of bytes out (the parked array and `sv` are 4-byte
+        // aligned; the last step may convert up to three slots past n_in, which both arrays have)
+        const uint2* p4 = reinterpret_cast<const uint2*>(parked);
+        unsigned int* s4 = reinterpret_cast<unsigned int*>(sv);
+        for (int i = lane; i < (n_in + 3) / 4; i += kFastThreads) {
+            const uint2 v = p4[i];
+            const int a = (short)(v.x & 0xffffu) - rel, b = (short)(v.x >> 16) - rel, c = (short)(v.y & 0xffffu) - rel,
+                      d = (short)(v.y >> 16) - rel;
+            s4[i] = (unsigned)(a & 0xff) | ((unsigned)(b & 0xff) << 8) | ((unsigned)(c & 0xff) << 16) | ((unsigned)(d & 0xff) << 24);
+        }
+    }
     __syncthreads();
-    for (int k = lane; k < kFastBins / 2 * 64; k += kFastThreads) hh[k] = 0;
+    {
+        uint4* h4 = reinterpret_cast<uint4*>(hh);
+        for (int k = lane; k < kFastBins / 2 * 64 / 4; k += kFastThreads) h4[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
     __syncthreads();
     // A lane's run of outputs starts on a multiple of 4 bytes of `sv` (it reads its values four at a time), and the
     // runs' length in dwords is ODD: lane l then starts in bank (l x odd) mod 32 - all 32 banks, two lanes each, the
@@ -215,7 +228,16 @@ __device__ __forceinline__ void adjust_median_hist_tile(const double* __restrict
     auto cnt = [&](int b) { return (int)((mine[b * 32] >> half) & 0xffffu); };
     {
         int j = 0;
-        for (; j + 4 <= W; j += 4) {  // (the adds return nothing: they queue up behind one 4-byte read)
+        for (; j + 16 <= W; j += 16) {  // (the adds return nothing: sixteen of them queue up behind four 4-byte reads)
+            unsigned int pk[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pk[r] = *reinterpret_cast<const unsigned int*>(sv + o_begin + j + 4 * r);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) add((pk[r] >> (8 * u)) & 0xffu);
+        }
+        for (; j + 4 <= W; j += 4) {
             const unsigned int pk = *reinterpret_cast<const unsigned int*>(sv + o_begin + j);
 #pragma unroll
             for (int u = 0; u < 4; ++u) add((pk >> (8 * u)) & 0xffu);
