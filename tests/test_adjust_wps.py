@@ -172,6 +172,32 @@ def test_gpu_histogram_median_takes_what_it_can_and_leaves_the_rest(engine, W):
 
 
 @pytest.mark.gpu
+def test_gpu_many_short_runs_build_their_tiles_on_the_device(engine):
+    """40 000 runs (more than one trip of the tile-count kernel's 16 384) of W .. W + 150 scores - runs with NO output
+    (length == W) among them, integer and non-integer runs interleaved so that every kernel of the chain has tiles:
+    every 97th run against the oracle, the rest through the negation property."""
+    rng = np.random.default_rng(4242)
+    n_iv, W = 40_000, 64
+    lens = W + rng.integers(0, 151, n_iv)
+    lens[::11] = W                                     # nothing to write for these
+    offs = np.zeros(n_iv + 1, np.int64)
+    np.cumsum(lens, out=offs[1:])
+    x = rng.integers(-30, 30, int(offs[-1])).astype(np.float64)
+    for i in range(5, n_iv, 13):                       # non-integers: left to the sort kernel
+        x[offs[i]] += 0.5
+    for i in range(7, n_iv, 17):                       # a range beyond 128 but within 256: the second histogram pass
+        if lens[i] > W + 2:
+            x[offs[i] + 1] = 150.0
+    got = engine.wps_adjust(x, offs, W, savgol=False)
+    out_offs = offs - np.arange(n_iv + 1) * W
+    assert len(got) == out_offs[-1]
+    for i in range(0, n_iv, 97):
+        want = O.py_adjust_run(x[offs[i]:offs[i + 1]], W, savgol=False) if lens[i] > W else np.zeros(0)
+        assert np.array_equal(got[out_offs[i]:out_offs[i + 1]], want), i
+    assert np.array_equal(engine.wps_adjust(-x, offs, W, savgol=False), -got)
+
+
+@pytest.mark.gpu
 def test_gpu_adjust_errors(engine):
     x = np.zeros(1500)
     offs = np.array([0, 1500], np.int64)
