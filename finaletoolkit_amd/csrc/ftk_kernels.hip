@@ -549,7 +549,9 @@ __device__ __forceinline__ void feat_element(const ContigView& cv, const FeatPar
 // readlane / mask traffic (134 VALU + 79 SALU instructions per fragment in the first form of this function).
 // ws / we1 are the CLAMPED bounds (window_bounds<1>); the filter is the motif pass' own (policy ANY, no length
 // bounds: ftk_motif_counts), so the window test is overlap + mapq (+ read1 overlap for a BAM fetch).
-template <bool BAM, int N>
+// EDGE = false: the window's reach (motif_reach) lies inside the contig, so no k-mer of a FETCHED fragment can start
+// outside it and the two range tests are left out (chosen per window; never for a BAM fetch, whose read1 may poke out).
+template <bool BAM, int N, bool EDGE = true>
 __device__ __forceinline__ void motif_prep(const ContigView& cv, const FeatParams& P, const int (&idx)[N],
                                            const int (&fs)[N], const int (&fe)[N], const int (&q)[N], int hi, int ws,
                                            int we1, int (&pf)[N], int (&pr)[N], uint32_t (&cf)[N], uint32_t (&cr)[N],
@@ -568,11 +570,16 @@ __device__ __forceinline__ void motif_prep(const ContigView& cv, const FeatParam
         if (!M.both && !M.neg) u_fwd = cv.strand[min(idx[j], hi - 1)] != 0 ? 0 : -1;
         pf[j] = fs[j] + M.f_off;  // where the two k-mers start
         pr[j] = fe[j] + M.r_off;
-        const int f_out = pf[j] | (last - pf[j]), r_out = pr[j] | (last - pr[j]);
-        const int no_f = x | u_fwd | f_out;
-        x |= ~u_fwd & f_out;  // the reference's `continue` on a start outside the contig also drops the other end
-        const int no_r = x | u_rev | r_out;
-        if (M.rev_err) a.over += (unsigned)(~(x | u_rev) & r_out) >> 31;
+        int no_f = x | u_fwd, no_r;
+        if (EDGE) {
+            const int f_out = pf[j] | (last - pf[j]), r_out = pr[j] | (last - pr[j]);
+            no_f |= f_out;
+            x |= ~u_fwd & f_out;  // the reference's `continue` on a start outside the contig also drops the other end
+            no_r = x | u_rev | r_out;
+            if (M.rev_err) a.over += (unsigned)(~(x | u_rev) & r_out) >> 31;
+        } else {
+            no_r = x | u_rev;
+        }
         cf[j] = (uint32_t)~no_f >> 31;  // what the end adds to its bin: 1, or 0 when it contributes nothing
         cr[j] = (uint32_t)~no_r >> 31;
         wf[j] = *reinterpret_cast<const u32u*>(M.img + (min((unsigned)pf[j], (unsigned)max(last, 0)) >> 2));
@@ -619,9 +626,9 @@ __device__ __forceinline__ void motif_elements(const ContigView& cv, const FeatP
 // registers are re-filled with the slab kMotifAhead further on, and only then is the PREVIOUS slab's histogram work
 // done -- so a wave always has column loads and gathers outstanding while it computes.
 constexpr int kMotifAhead = 4;
-template <int kBS, bool BAM>
-__device__ __forceinline__ void motif_stream(const ContigView& cv, const FeatParams& P, int lo, int hi, int tid, int ws,
-                                             int we1, int o0, int o1, uint32_t* h, FeatAcc& a) {
+template <int kBS, bool BAM, bool EDGE>
+__device__ __forceinline__ void motif_stream_t(const ContigView& cv, const FeatParams& P, int lo, int hi, int tid, int ws,
+                                               int we1, int o0, int o1, uint32_t* h, FeatAcc& a) {
     constexpr int D = kMotifAhead, kSlab = 4 * kBS;
     if (lo >= hi) return;  // (uniform)
     int4 s4[D], e4[D];
@@ -650,7 +657,7 @@ __device__ __forceinline__ void motif_stream(const ContigView& cv, const FeatPar
             const int qq[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
             int pf[4], pr[4];
             uint32_t cf[4], cr[4], wf[4], wr[4];
-            motif_prep<BAM, 4>(cv, P, ii, ss, ee, qq, hi, ws, we1, pf, pr, cf, cr, wf, wr, a, n_ok);
+            motif_prep<BAM, 4, EDGE>(cv, P, ii, ss, ee, qq, hi, ws, we1, pf, pr, cf, cr, wf, wr, a, n_ok);
             const int nxt = min(i + D * kSlab, last_group);
             s4[u] = *reinterpret_cast<const int4*>(cv.start + nxt);
             e4[u] = *reinterpret_cast<const int4*>(cv.end + nxt);
@@ -664,6 +671,17 @@ __device__ __forceinline__ void motif_stream(const ContigView& cv, const FeatPar
     }
     motif_commit<BAM, 4>(cv, P, ws, we1, o0, o1, pf0, pr0, cf0, cr0, wf0, wr0, h);
     if ((tid & 63) == 0) a.cov += n_ok;
+}
+
+template <int kBS, bool BAM>
+__device__ __forceinline__ void motif_stream(const ContigView& cv, const FeatParams& P, int lo, int hi, int tid, int ws,
+                                             int we1, int o0, int o1, uint32_t* h, FeatAcc& a) {
+    int g_lo, g_hi;
+    motif_reach(P.mp, cv, ws, we1 + 1, g_lo, g_hi);
+    if (!BAM && g_lo >= -1 && g_hi - 1 <= P.mp.chrom_len && P.mp.guard <= 0)  // (uniform) every k-mer inside the contig
+        motif_stream_t<kBS, BAM, false>(cv, P, lo, hi, tid, ws, we1, o0, o1, h, a);
+    else
+        motif_stream_t<kBS, BAM, true>(cv, P, lo, hi, tid, ws, we1, o0, o1, h, a);
 }
 
 // Window bounds as the element tests want them.
