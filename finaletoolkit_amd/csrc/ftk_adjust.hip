@@ -108,8 +108,9 @@ __device__ __forceinline__ void adjust_median_tile(const double* __restrict__ sc
 }
 
 // With histogram kernels in front (left != NULL) a block leaves at once when they marked nothing at all (left[1] == 0):
-// 40 000 blocks that each load their tile and look up its interval's mark were 18 us of an 0.5 ms call.  (A small grid
-// striding over the tiles was tried for the same reason: 21 % slower when the tiles do need sorting.)
+// 40 000 blocks that each load their tile and look up its interval's mark were 18 us of an 0.5 ms call.  The grid then
+// strides over the tiles in equal shares (launch_adjust_filter; one resident block per slot, 1 536 blocks, was tried
+// first: 21 % slower when the tiles do need sorting - no block left to balance the tail).
 __global__ __launch_bounds__(kAdjThreads) void adjust_median_kernel(const double* __restrict__ scores,
                                                                      const AdjustTile* __restrict__ tiles, int n_tiles,
                                                                      const double* __restrict__ edge_sub, int W,
@@ -393,14 +394,19 @@ __global__ __launch_bounds__(kAdjThreads) void savgol_kernel(const double* __res
 // (one 32-byte descriptor per tile: 40 000 + 10 000 of them for 10 000 runs of 5 kb were 1.6 MB of pageable uploads
 // and ~70 us of the stream before the first kernel of a 0.5 ms call; the run offsets are 80 KB)
 // pre[k][i]: tiles of kind k (0: sort kernel, 1: histogram median) before run i; one block, runs 1024 at a time.
-__global__ __launch_bounds__(1024) void adjust_tile_counts_kernel(const int64_t* __restrict__ offs, int n_iv, int W,
-                                                                   int tile0, int tile1, int* __restrict__ pre0,
+// offs: the run offsets where the caller put them - page-locked HOST memory the device reads across the link (80 KB for
+// 10 000 runs: a copy of its own in front of this kernel was 7 us of DMA, 9 us of gap and a dozen of engine-to-engine
+// synchronisation); offs_dev: the device copy the other kernels read, written here.
+__global__ __launch_bounds__(1024) void adjust_tile_counts_kernel(const int64_t* __restrict__ offs, int64_t* __restrict__ offs_dev,
+                                                                   int n_iv, int W, int tile0, int tile1, int* __restrict__ pre0,
                                                                    int* __restrict__ pre1, int* __restrict__ todo) {
-    // a thread takes kR consecutive runs of a trip (their offsets: kR + 1 loads in flight at once -- a trip per 1024
-    // runs was a memory latency per trip, 23 us for 10 000 runs); also clears the marks of the histogram kernels
+    // kR trips of 1024 runs are LOADED together (coalesced: thread t takes run r * 1024 + t of every trip) and then
+    // scanned one after the other: a trip per load was a memory latency per 1024 runs (23 us for 10 000), a thread's
+    // kR consecutive runs were 64 cache lines per load instruction on the one CU this block has (20 us).  Also clears
+    // the marks of the histogram kernels.
     constexpr int kR = 16;
-    // ceil(m / t) for m < 2^31 without an integer division (32 of them per thread were half of this one-block kernel):
-    // the double product is within 1e-7 of the quotient, so its floor is right or one short; the remainder settles it
+    // ceil(m / t) for m < 2^31 without an integer division: the double product is within 1e-7 of the quotient, so its
+    // floor is right or one short; the remainder settles it
     const double rcp0 = 1.0 / (double)tile0, rcp1 = tile1 ? 1.0 / (double)tile1 : 0.0;
     auto ceil_div = [](unsigned int m, unsigned int t, double rcp) -> unsigned int {
         const unsigned int x = m + t - 1u;
@@ -416,40 +422,46 @@ __global__ __launch_bounds__(1024) void adjust_tile_counts_kernel(const int64_t*
         for (int i = tid; i < n_iv + 2; i += 1024) todo[i] = 0;
     __syncthreads();
     for (int i0 = 0; i0 < n_iv; i0 += 1024 * kR) {
-        const int first = i0 + tid * kR;
-        int64_t o[kR + 1];
-#pragma unroll
-        for (int r = 0; r <= kR; ++r) o[r] = offs[min(first + r, n_iv)];
-        int c0[kR], c1[kR], x[2] = {0, 0};
+        int64_t o[kR], o1[kR];
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
-            const unsigned int m = (unsigned int)(o[r + 1] - o[r] - W);  // (0 .. INT32_MAX, checked by the caller)
-            const bool in = first + r < n_iv;
-            c0[r] = in ? (int)ceil_div(m, (unsigned)tile0, rcp0) : 0;
-            c1[r] = in && tile1 ? (int)ceil_div(m, (unsigned)tile1, rcp1) : 0;
-            x[0] += c0[r];
-            x[1] += c1[r];
+            const int i = min(i0 + r * 1024 + tid, n_iv - 1);
+            o[r] = offs[i];
+            o1[r] = offs[i + 1];
         }
-        const int mine[2] = {x[0], x[1]};
+        if (offs_dev) {
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int y0 = __shfl_up(x[0], d, 64), y1 = __shfl_up(x[1], d, 64);
-            if (lane >= d) { x[0] += y0; x[1] += y1; }
+            for (int r = 0; r < kR; ++r) {
+                const int i = i0 + r * 1024 + tid;
+                if (i < n_iv) offs_dev[i] = o[r];
+                if (i == n_iv - 1) offs_dev[n_iv] = o1[r];
+            }
         }
-        if (lane == 63) { wave_tot[0][wv] = x[0]; wave_tot[1][wv] = x[1]; }
-        __syncthreads();
-        int p[2] = {carry[0], carry[1]};
-        for (int j = 0; j < wv; ++j) { p[0] += wave_tot[0][j]; p[1] += wave_tot[1][j]; }
-        int q0 = p[0] + x[0] - mine[0], q1 = p[1] + x[1] - mine[1];
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
-            if (first + r < n_iv) { pre0[first + r] = q0; pre1[first + r] = q1; }
-            q0 += c0[r];
-            q1 += c1[r];
+            if (i0 + r * 1024 >= n_iv) break;  // (uniform)
+            const int i = i0 + r * 1024 + tid;
+            int c0 = 0, c1 = 0;
+            if (i < n_iv) {
+                const unsigned int m = (unsigned int)(o1[r] - o[r] - W);  // (0 .. INT32_MAX, checked by the caller)
+                c0 = (int)ceil_div(m, (unsigned)tile0, rcp0);
+                c1 = tile1 ? (int)ceil_div(m, (unsigned)tile1, rcp1) : 0;
+            }
+            int x0 = c0, x1 = c1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y0 = __shfl_up(x0, d, 64), y1 = __shfl_up(x1, d, 64);
+                if (lane >= d) { x0 += y0; x1 += y1; }
+            }
+            if (lane == 63) { wave_tot[0][wv] = x0; wave_tot[1][wv] = x1; }
+            __syncthreads();
+            int p0 = carry[0], p1 = carry[1];
+            for (int j = 0; j < wv; ++j) { p0 += wave_tot[0][j]; p1 += wave_tot[1][j]; }
+            if (i < n_iv) { pre0[i] = p0 + x0 - c0; pre1[i] = p1 + x1 - c1; }
+            __syncthreads();
+            if (tid == 1023) { carry[0] = p0 + x0; carry[1] = p1 + x1; }
+            __syncthreads();
         }
-        __syncthreads();
-        if (tid == 1023) { carry[0] = p[0] + x[0]; carry[1] = p[1] + x[1]; }
-        __syncthreads();
     }
     if (tid == 0) { pre0[n_iv] = carry[0]; pre1[n_iv] = carry[1]; }
 }
@@ -491,9 +503,9 @@ int adjust_sort_size(int W, int* tile_out) {
     return n;
 }
 
-void launch_adjust_tiles(hipStream_t s, const int64_t* offs, int n_iv, int W, int tile0, int tile1, int* pre0, int* pre1,
-                         AdjustTile* t0, int n0, AdjustTile* t1, int n1, int* todo) {
-    adjust_tile_counts_kernel<<<1, 1024, 0, s>>>(offs, n_iv, W, tile0, tile1, pre0, pre1, todo);
+void launch_adjust_tiles(hipStream_t s, const int64_t* offs_src, int64_t* offs, int n_iv, int W, int tile0, int tile1,
+                         int* pre0, int* pre1, AdjustTile* t0, int n0, AdjustTile* t1, int n1, int* todo) {
+    adjust_tile_counts_kernel<<<1, 1024, 0, s>>>(offs_src, offs, n_iv, W, tile0, tile1, pre0, pre1, todo);
     const int n = n0 > n1 ? n0 : n1;
     if (n > 0) adjust_tile_fill_kernel<<<(n + 255) / 256, 256, 0, s>>>(offs, n_iv, W, tile0, t1 ? tile1 : 0, pre0, pre1, t0, t1);
 }
@@ -517,7 +529,14 @@ void launch_adjust_filter(hipStream_t s, const double* scores, const AdjustTile*
     }
     // ... and sorted (every interval when there is no histogram pass)
     const size_t lds = (size_t)n_sort * (8 + 4);
-    adjust_median_kernel<<<n_tiles, kAdjThreads, lds, s>>>(scores, tiles, n_tiles, edge_sub, W, n_sort, out, hist ? todo : nullptr, left);
+    // behind histogram kernels: at most ~8192 blocks, every block the same number of tiles (40 000 blocks that only look
+    // at left[1] and leave are 9 us; the tiles of one call cost the same, so equal shares lose nothing when they do sort)
+    int grid = n_tiles;
+    if (hist && n_tiles > 8192) {
+        const int per = (n_tiles + 8191) / 8192;
+        grid = (n_tiles + per - 1) / per;
+    }
+    adjust_median_kernel<<<grid, kAdjThreads, lds, s>>>(scores, tiles, n_tiles, edge_sub, W, n_sort, out, hist ? todo : nullptr, left);
 }
 
 void launch_savgol(hipStream_t s, const double* adj, const AdjustTile* tiles, int n_tiles, const double* coef,

@@ -165,8 +165,10 @@ int adjust_sort_size(int W, int* tile_out);
 // the tile lists of both kinds from the run offsets, on the device: t0 the sort kernel's (tile0 outputs each), t1 the
 // histogram median's (tile1; NULL / 0: none); pre0 / pre1: n_iv + 1 ints of scratch each
 // todo (may be NULL): the histogram kernels' marks, n_iv + 2 ints, cleared here
-void launch_adjust_tiles(hipStream_t s, const int64_t* offs, int n_iv, int W, int tile0, int tile1, int* pre0, int* pre1,
-                         AdjustTile* t0, int n0, AdjustTile* t1, int n1, int* todo);
+// offs_src: the offsets in device-readable memory (page-locked host memory will do); offs: n_iv + 1 slots in HBM that
+// receive them (what the other kernels read)
+void launch_adjust_tiles(hipStream_t s, const int64_t* offs_src, int64_t* offs, int n_iv, int W, int tile0, int tile1,
+                         int* pre0, int* pre1, AdjustTile* t0, int n0, AdjustTile* t1, int n1, int* todo);
 void launch_adjust_filter(hipStream_t s, const double* scores, const AdjustTile* tiles, int n_tiles,
                           const double* edge_sub, int W, int use_mean, double* out, const AdjustTile* fast_tiles = nullptr,
                           int n_fast_tiles = 0, int* todo = nullptr, int n_iv = 0);
