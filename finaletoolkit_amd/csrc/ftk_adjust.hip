@@ -108,9 +108,9 @@ __device__ __forceinline__ void adjust_median_tile(const double* __restrict__ sc
 }
 
 // With histogram kernels in front (left != NULL) a block leaves at once when they marked nothing at all (left[1] == 0):
-// 40 000 blocks that each load their tile and look up its interval's mark were 18 us of an 0.5 ms call.  The grid then
-// strides over the tiles in equal shares (launch_adjust_filter; one resident block per slot, 1 536 blocks, was tried
-// first: 21 % slower when the tiles do need sorting - no block left to balance the tail).
+// 40 000 blocks that each load their tile and look up its interval's mark were 18 us of an 0.5 ms call; leaving on
+// left[1] alone they are 9.  (Smaller grids striding over the tiles were measured for the rest: 1 536 blocks - one per
+// resident slot - cost the sorting case 21 %, 8 000 blocks of five tiles each 8 %, for 5 us of the other.)
 __global__ __launch_bounds__(kAdjThreads) void adjust_median_kernel(const double* __restrict__ scores,
                                                                      const AdjustTile* __restrict__ tiles, int n_tiles,
                                                                      const double* __restrict__ edge_sub, int W,
@@ -529,14 +529,7 @@ void launch_adjust_filter(hipStream_t s, const double* scores, const AdjustTile*
     }
     // ... and sorted (every interval when there is no histogram pass)
     const size_t lds = (size_t)n_sort * (8 + 4);
-    // behind histogram kernels: at most ~8192 blocks, every block the same number of tiles (40 000 blocks that only look
-    // at left[1] and leave are 9 us; the tiles of one call cost the same, so equal shares lose nothing when they do sort)
-    int grid = n_tiles;
-    if (hist && n_tiles > 8192) {
-        const int per = (n_tiles + 8191) / 8192;
-        grid = (n_tiles + per - 1) / per;
-    }
-    adjust_median_kernel<<<grid, kAdjThreads, lds, s>>>(scores, tiles, n_tiles, edge_sub, W, n_sort, out, hist ? todo : nullptr, left);
+    adjust_median_kernel<<<n_tiles, kAdjThreads, lds, s>>>(scores, tiles, n_tiles, edge_sub, W, n_sort, out, hist ? todo : nullptr, left);
 }
 
 void launch_savgol(hipStream_t s, const double* adj, const AdjustTile* tiles, int n_tiles, const double* coef,
