@@ -390,6 +390,16 @@ __global__ __launch_bounds__(kAdjThreads) void savgol_kernel(const double* __res
 
 }  // namespace
 
+__device__ __forceinline__ int wave_incl_scan_dpp(int x) {  // inclusive prefix sum over the 64 lanes (row shifts + row broadcasts)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+
 // ---- the tile lists, built where they are used --------------------------------------------------------------------
 // (one 32-byte descriptor per tile: 40 000 + 10 000 of them for 10 000 runs of 5 kb were 1.6 MB of pageable uploads
 // and ~70 us of the stream before the first kernel of a 0.5 ms call; the run offsets are 80 KB)
@@ -414,7 +424,11 @@ __global__ __launch_bounds__(1024) void adjust_tile_counts_kernel(const int64_t*
         if (x - q * t >= t) ++q;
         return q;
     };
-    __shared__ int wave_tot[2][16];
+    // One pass of kR trips: every wave scans its 64 runs of each trip, the kR x 16 wave totals are scanned ONCE by the
+    // first four waves, and every thread adds its wave's base - four barriers per 16 384 runs (a barrier trio and a
+    // serial walk over the wave totals per trip were 19 of this kernel's 25 us for 10 000 runs).
+    __shared__ int wave_tot[2][kR * 16];  // [kind][trip * 16 + wave]: the wave's total, then its exclusive base
+    __shared__ int quad_tot[2][4];
     __shared__ int carry[2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < 2) carry[tid] = 0;
@@ -437,31 +451,51 @@ __global__ __launch_bounds__(1024) void adjust_tile_counts_kernel(const int64_t*
                 if (i == n_iv - 1) offs_dev[n_iv] = o1[r];
             }
         }
+        int c0[kR], c1[kR], x0[kR], x1[kR];
 #pragma unroll
         for (int r = 0; r < kR; ++r) {
-            if (i0 + r * 1024 >= n_iv) break;  // (uniform)
             const int i = i0 + r * 1024 + tid;
-            int c0 = 0, c1 = 0;
+            c0[r] = c1[r] = 0;
             if (i < n_iv) {
                 const unsigned int m = (unsigned int)(o1[r] - o[r] - W);  // (0 .. INT32_MAX, checked by the caller)
-                c0 = (int)ceil_div(m, (unsigned)tile0, rcp0);
-                c1 = tile1 ? (int)ceil_div(m, (unsigned)tile1, rcp1) : 0;
+                c0[r] = (int)ceil_div(m, (unsigned)tile0, rcp0);
+                c1[r] = tile1 ? (int)ceil_div(m, (unsigned)tile1, rcp1) : 0;
             }
-            int x0 = c0, x1 = c1;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int y0 = __shfl_up(x0, d, 64), y1 = __shfl_up(x1, d, 64);
-                if (lane >= d) { x0 += y0; x1 += y1; }
-            }
-            if (lane == 63) { wave_tot[0][wv] = x0; wave_tot[1][wv] = x1; }
-            __syncthreads();
-            int p0 = carry[0], p1 = carry[1];
-            for (int j = 0; j < wv; ++j) { p0 += wave_tot[0][j]; p1 += wave_tot[1][j]; }
-            if (i < n_iv) { pre0[i] = p0 + x0 - c0; pre1[i] = p1 + x1 - c1; }
-            __syncthreads();
-            if (tid == 1023) { carry[0] = p0 + x0; carry[1] = p1 + x1; }
-            __syncthreads();
+            x0[r] = wave_incl_scan_dpp(c0[r]);  // (`__shfl_up` is an LDS permute: twelve dependent ones per trip were most of this kernel)
+            x1[r] = wave_incl_scan_dpp(c1[r]);
+            if (lane == 63) { wave_tot[0][r * 16 + wv] = x0[r]; wave_tot[1][r * 16 + wv] = x1[r]; }
         }
+        __syncthreads();
+        if (tid < kR * 16) {  // the 256 wave totals, in run order: exclusive scan by four waves
+            const int t0 = wave_tot[0][tid], t1 = wave_tot[1][tid];
+            const int s0 = wave_incl_scan_dpp(t0), s1 = wave_incl_scan_dpp(t1);
+            if (lane == 63) { quad_tot[0][wv] = s0; quad_tot[1][wv] = s1; }
+            wave_tot[0][tid] = s0 - t0;  // (exclusive within the quarter; the quarters in front are added below)
+            wave_tot[1][tid] = s1 - t1;
+        }
+        __syncthreads();
+        if (tid < kR * 16) {
+            int b0 = 0, b1 = 0;
+            for (int j = 0; j < wv; ++j) { b0 += quad_tot[0][j]; b1 += quad_tot[1][j]; }
+            wave_tot[0][tid] += b0;
+            wave_tot[1][tid] += b1;
+        }
+        __syncthreads();
+        const int base0 = carry[0], base1 = carry[1];
+#pragma unroll
+        for (int r = 0; r < kR; ++r) {
+            const int i = i0 + r * 1024 + tid;
+            if (i < n_iv) {
+                pre0[i] = base0 + wave_tot[0][r * 16 + wv] + x0[r] - c0[r];
+                pre1[i] = base1 + wave_tot[1][r * 16 + wv] + x1[r] - c1[r];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            carry[0] = base0 + quad_tot[0][0] + quad_tot[0][1] + quad_tot[0][2] + quad_tot[0][3];
+            carry[1] = base1 + quad_tot[1][0] + quad_tot[1][1] + quad_tot[1][2] + quad_tot[1][3];
+        }
+        __syncthreads();
     }
     if (tid == 0) { pre0[n_iv] = carry[0]; pre1[n_iv] = carry[1]; }
 }
