@@ -537,9 +537,13 @@ int adjust_sort_size(int W, int* tile_out) {
     return n;
 }
 
-void launch_adjust_tiles(hipStream_t s, const int64_t* offs_src, int64_t* offs, int n_iv, int W, int tile0, int tile1,
-                         int* pre0, int* pre1, AdjustTile* t0, int n0, AdjustTile* t1, int n1, int* todo) {
+void launch_adjust_tile_counts(hipStream_t s, const int64_t* offs_src, int64_t* offs, int n_iv, int W, int tile0, int tile1,
+                               int* pre0, int* pre1, int* todo) {
     adjust_tile_counts_kernel<<<1, 1024, 0, s>>>(offs_src, offs, n_iv, W, tile0, tile1, pre0, pre1, todo);
+}
+
+void launch_adjust_tile_fill(hipStream_t s, const int64_t* offs, int n_iv, int W, int tile0, int tile1, const int* pre0,
+                             const int* pre1, AdjustTile* t0, int n0, AdjustTile* t1, int n1) {
     const int n = n0 > n1 ? n0 : n1;
     if (n > 0) adjust_tile_fill_kernel<<<(n + 255) / 256, 256, 0, s>>>(offs, n_iv, W, tile0, t1 ? tile1 : 0, pre0, pre1, t0, t1);
 }

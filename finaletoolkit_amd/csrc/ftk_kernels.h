@@ -162,13 +162,16 @@ constexpr int kAdjustFastTile = 4096;  // outputs per tile of the histogram medi
 int adjust_sort_size(int W, int* tile_out);
 // fast_tiles / todo (may be NULL): the tiles of the histogram median (at most kAdjustFastTile outputs each) and n_iv + 2
 // ints (cleared by launch_adjust_tiles) in which it marks the intervals it leaves to the sort kernel
-// the tile lists of both kinds from the run offsets, on the device: t0 the sort kernel's (tile0 outputs each), t1 the
-// histogram median's (tile1; NULL / 0: none); pre0 / pre1: n_iv + 1 ints of scratch each
-// todo (may be NULL): the histogram kernels' marks, n_iv + 2 ints, cleared here
-// offs_src: the offsets in device-readable memory (page-locked host memory will do); offs: n_iv + 1 slots in HBM that
-// receive them (what the other kernels read)
-void launch_adjust_tiles(hipStream_t s, const int64_t* offs_src, int64_t* offs, int n_iv, int W, int tile0, int tile1,
-                         int* pre0, int* pre1, AdjustTile* t0, int n0, AdjustTile* t1, int n1, int* todo);
+// The tile lists of both kinds from the run offsets, on the device, in two launches.  Counts: pre0 / pre1 (n_iv + 1 ints
+// each) = tiles of the sort kernel (tile0 outputs each) / of the histogram median (tile1; 0: none) in front of every run;
+// offs_src: the offsets in device-readable memory (page-locked host memory will do), copied to offs (n_iv + 1 slots in
+// HBM, what the other kernels read); todo (may be NULL): the histogram kernels' marks, n_iv + 2 ints, cleared.  The
+// launch touches nothing but these arrays whatever the offsets hold - it may go out before they are validated.
+void launch_adjust_tile_counts(hipStream_t s, const int64_t* offs_src, int64_t* offs, int n_iv, int W, int tile0, int tile1,
+                               int* pre0, int* pre1, int* todo);
+// Fill: t0[n0] / t1[n1] (t1 NULL: none) from the counts.
+void launch_adjust_tile_fill(hipStream_t s, const int64_t* offs, int n_iv, int W, int tile0, int tile1, const int* pre0,
+                             const int* pre1, AdjustTile* t0, int n0, AdjustTile* t1, int n1);
 void launch_adjust_filter(hipStream_t s, const double* scores, const AdjustTile* tiles, int n_tiles,
                           const double* edge_sub, int W, int use_mean, double* out, const AdjustTile* fast_tiles = nullptr,
                           int n_fast_tiles = 0, int* todo = nullptr, int n_iv = 0);
