@@ -111,7 +111,9 @@ def measure(torch, eng, which="all", reps=5, seed=1):
         d_gc = torch.zeros(len(glo), dtype=torch.int64, device=dev)
         f = lambda: eng._check(eng.lib.ftk_ref_gc_counts(eng.ctx, rid, L.ptr(d_lo), L.ptr(d_hi), len(glo), L.ptr(d_gc)))
         rows["gc_count_kernel"] = _row("gc_count_kernel", _time(eng, f, reps, flush), size // 4 + 8 * len(glo),
-                                       "1/4 B per base (2bit image) + 8 B per bin")
+                                       "1/4 B per base (2bit image) + 8 B per bin",
+                                       note="61 MB per launch: a plain sum-everything read of the same bytes takes 13.3-15.0 us by events on this device in "
+                                            "every shape tried, an empty launch 6.2 us (tools/native/read_probe.hip, profiles/r6_read_probe.txt)")
         # raw WPS of the contig's first 50 Mb (the scores adjust_wps is made for): kept for the adjust row below
         n_iv, ilen, W = 10_000, 5_000, 1000
         wps_i64 = torch.empty(n_iv * ilen, dtype=torch.int64, device=dev)
