@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import gzip
 import queue
+import sys
 import threading
 import time
 import warnings
@@ -367,6 +368,10 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
                     return
 
         rows_thread = threading.Thread(target=make_rows, name="ftk-length-rows", daemon=True)
+        # (the row thread is pure interpreter work: with the default 5 ms switch interval this thread would wait that
+        # long for the lock every time a contig arrives or a kernel returns)
+        switch = sys.getswitchinterval()
+        sys.setswitchinterval(min(switch, 2e-4))
         rows_thread.start()
         try:
             for src, c in feed:
@@ -385,6 +390,7 @@ def frag_length_intervals(input_file, interval_file: str, output_file: str | Non
         finally:
             todo.put(None)
             rows_thread.join()
+            sys.setswitchinterval(switch)
         if failed:
             raise failed[0]
         clock.lap("result_rows_tail")

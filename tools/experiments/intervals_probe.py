@@ -18,6 +18,8 @@ from finaletoolkit_amd.synth import gen_contig_device  # noqa: E402
 import cmd_legs  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+if os.environ.get('NO_SWITCH'):  # A/B: leave the interpreter's switch interval alone
+    sys.setswitchinterval = lambda x: None
 _lib.load()
 dev = torch.device("cuda", 0)
 sizes = dict(synth.B37_SIZES)
